@@ -1,0 +1,195 @@
+"""oracle/oracle.py — TEST INFRASTRUCTURE: ctypes loader for oracle/liboracle.so and a runner for
+oracle/_ref/ref_driver (the real reference, built from its own sources by oracle/Makefile).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module, and only
+as the checker. The product (colibri-core_amd/) never does.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle.so")
+REF_DRIVER = os.path.join(HERE, "_ref", "ref_driver")
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("mintokens", C.c_int32),
+        ("maxlength", C.c_int32),
+        ("mintokens_skipgrams", C.c_int32),
+        ("minskiptypes", C.c_int32),
+        ("maxskips", C.c_int32),
+        ("doskipgrams", C.c_int32),
+        ("doskipgrams_exhaustive", C.c_int32),
+        ("indexed", C.c_int32),
+    ]
+
+
+def build():
+    """(Re)build liboracle.so with gcc; cheap (one C file)."""
+    subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.co_spooky64.restype = C.c_uint64
+        L.co_spooky64.argtypes = [C.c_void_p, C.c_uint64]
+        L.co_skip_configurations.restype = C.c_int
+        L.co_skip_configurations.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.co_v1_to_v2.restype = C.c_int
+        L.co_v1_to_v2.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
+        L.co_train.restype = C.c_void_p
+        L.co_train.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Options), C.c_uint32]
+        L.co_free.argtypes = [C.c_void_p]
+        for name in ("co_npatterns", "co_totaltokens", "co_totaltypes", "co_keybytes", "co_nrefs", "co_windows"):
+            getattr(L, name).restype = C.c_uint64
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.co_maxn.restype = C.c_int
+        L.co_maxn.argtypes = [C.c_void_p]
+        L.co_order_stat.restype = C.c_int64
+        L.co_order_stat.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.co_export.argtypes = [C.c_void_p] * 7
+        _lib = L
+    return _lib
+
+
+def spooky64(data: bytes) -> int:
+    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data or b"\0")
+    return int(lib().co_spooky64(buf, len(data)))
+
+
+def skip_configurations(n: int, maxskips: int = 3):
+    out = np.zeros(1 << 14, dtype=np.uint32)
+    k = lib().co_skip_configurations(n, maxskips, out.ctypes.data, out.size)
+    return [int(x) for x in out[:k]]
+
+
+def v1_to_v2(data: bytes) -> bytes:
+    src = np.frombuffer(data, dtype=np.uint8)
+    nout = C.c_uint64(0)
+    assert lib().co_v1_to_v2(src.ctypes.data, src.size, None, C.byref(nout)) == 0
+    out = np.zeros(max(1, nout.value), dtype=np.uint8)
+    assert lib().co_v1_to_v2(src.ctypes.data, src.size, out.ctypes.data, C.byref(nout)) == 0
+    return out[: nout.value].tobytes()
+
+
+class Model:
+    """Result of a training run in canonical form: dict key-bytes -> count (and -> [(sentence, token)])."""
+
+    def __init__(self, tokens, types, counts, refs=None, stats=None, maxn=0, windows=0):
+        self.tokens, self.types, self.counts, self.refs = tokens, types, counts, refs
+        self.stats, self.maxn, self.windows = stats or {}, maxn, windows
+
+    def __len__(self):
+        return len(self.counts)
+
+
+def train(payload: bytes, mintokens=2, maxlength=100, *, indexed=False, doskipgrams=False, doskipgrams_exhaustive=False,
+          minskiptypes=2, maxskips=3, mintokens_skipgrams=-1, firstsentence=1) -> Model:
+    """PatternModel::train on a v2 payload (header stripped) with the C restatement."""
+    L = lib()
+    src = np.frombuffer(payload, dtype=np.uint8) if len(payload) else np.zeros(0, dtype=np.uint8)
+    opt = Options(mintokens, maxlength, mintokens_skipgrams, minskiptypes, maxskips, int(doskipgrams), int(doskipgrams_exhaustive),
+                  int(indexed))
+    ptr = src.ctypes.data if src.size else None
+    m = L.co_train(ptr, src.size, C.byref(opt), firstsentence)
+    if not m:
+        raise ValueError("options outside the restated subset")
+    try:
+        npat = L.co_npatterns(m)
+        key_off = np.zeros(npat + 1, dtype=np.uint64)
+        key_bytes = np.zeros(max(1, L.co_keybytes(m)), dtype=np.uint8)
+        counts = np.zeros(max(1, npat), dtype=np.uint32)
+        nrefs = L.co_nrefs(m)
+        ref_off = np.zeros(npat + 1, dtype=np.uint64)
+        ref_s = np.zeros(max(1, nrefs), dtype=np.uint32)
+        ref_t = np.zeros(max(1, nrefs), dtype=np.uint16)
+        L.co_export(m, key_off.ctypes.data, key_bytes.ctypes.data, counts.ctypes.data, ref_off.ctypes.data if indexed else None,
+                    ref_s.ctypes.data, ref_t.ctypes.data)
+        kb = key_bytes.tobytes()
+        cd, rd = {}, ({} if indexed else None)
+        for j in range(npat):
+            k = kb[int(key_off[j]): int(key_off[j + 1])]
+            cd[k] = int(counts[j])
+            if indexed:
+                a, b = int(ref_off[j]), int(ref_off[j + 1])
+                rd[k] = list(zip(ref_s[a:b].tolist(), ref_t[a:b].tolist()))
+        stats = {n: tuple(int(L.co_order_stat(m, n, w)) for w in range(3)) for n in range(1, min(maxlength, 127) + 1)}
+        return Model(int(L.co_totaltokens(m)), int(L.co_totaltypes(m)), cd, rd, stats, int(L.co_maxn(m)), int(L.co_windows(m)))
+    finally:
+        L.co_free(m)
+
+
+def train_timed(payload: bytes, mintokens=2, maxlength=5):
+    """Time co_train only (no export); returns (seconds, windows, npatterns)."""
+    import time
+    L = lib()
+    src = np.frombuffer(payload, dtype=np.uint8)
+    opt = Options(mintokens, maxlength, -1, 2, 3, 0, 0, 0)
+    t0 = time.perf_counter()
+    m = L.co_train(src.ctypes.data, src.size, C.byref(opt), 1)
+    dt = time.perf_counter() - t0
+    w, n = int(L.co_windows(m)), int(L.co_npatterns(m))
+    L.co_free(m)
+    return dt, w, n
+
+
+# ---------------------------------------------------------------------------------------------
+# the real reference (only where oracle/_ref/ref_driver exists: the build container, and the GPU box
+# because the prebuilt binary travels with the snapshot)
+# ---------------------------------------------------------------------------------------------
+def have_ref() -> bool:
+    return os.path.exists(REF_DRIVER) and os.access(REF_DRIVER, os.X_OK)
+
+
+def parse_dump(text: str, indexed=False) -> Model:
+    lines = text.splitlines()
+    tokens = int(lines[0].split()[1])
+    types = int(lines[1].split()[1])
+    npat = int(lines[2].split()[1])
+    cd, rd = {}, ({} if indexed else None)
+    for ln in lines[3:]:
+        parts = ln.split("\t")
+        k = bytes.fromhex(parts[0])
+        cd[k] = int(parts[1])
+        if indexed:
+            refs = []
+            if len(parts) > 2 and parts[2]:
+                for r in parts[2].split(" "):
+                    s, t = r.split(":")
+                    refs.append((int(s), int(t)))
+            rd[k] = refs
+    assert len(cd) == npat, (len(cd), npat)
+    return Model(tokens, types, cd, rd)
+
+
+def ref_train(corpus_path: str, mode: str, maxlength: int, mintokens: int, *, minskiptypes=None, mintokens_skipgrams=None, dump_path=None,
+              model_path=None):
+    """Run the real reference through ref_driver. Returns (Model or None, info dict with train_s)."""
+    cmd = [REF_DRIVER, "train", corpus_path, mode, str(maxlength), str(mintokens), "-q"]
+    if minskiptypes is not None:
+        cmd += ["-T", str(minskiptypes)]
+    if mintokens_skipgrams is not None:
+        cmd += ["-y", str(mintokens_skipgrams)]
+    if dump_path:
+        cmd += ["-d", dump_path]
+    if model_path:
+        cmd += ["-o", model_path]
+    out = subprocess.run(cmd, check=True, capture_output=True, text=True)
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    model = None
+    if dump_path:
+        with open(dump_path) as f:
+            model = parse_dump(f.read(), indexed=mode in ("i", "is"))
+    return model, info

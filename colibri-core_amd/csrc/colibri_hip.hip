@@ -1,0 +1,562 @@
+// colibri_hip.hip — host orchestration + the C ABI of libcolibri_hip.so (include/colibri_hip.h).
+//
+// The order loop of PatternModel::train (reference include/patternmodel.h:981-1270) is enqueued on one HIP
+// stream with every per-order quantity (table capacity, candidate/survivor counts, result offsets, the
+// "None found" termination) kept in a DevState record in HBM: kernels of order n+1 read what order n left
+// there, so the host does not synchronise between orders. There is no CPU implementation behind this
+// file: every entry point either runs the kernels in kernels.hpp or fails with a status.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "colibri_hip.h"
+#include "kernels.hpp"
+
+using namespace colibri;
+
+namespace {
+
+template <class T>
+struct DevBuf {
+    T*     p = nullptr;
+    size_t n = 0;  // elements
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    int        cls;
+};
+
+}  // namespace
+
+struct colibri_ctx {
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // corpus
+    bool              have_corpus = false;
+    uint64_t          nbytes      = 0;
+    uint32_t          first_sentence = 1;
+    uint32_t          npos = 0, ndelim = 0, nsent = 0, maxclass = 0, flags = 0;
+    uint64_t          ntokens = 0;
+    DevBuf<uint8_t>   bytes;
+    DevBuf<uint32_t>  tokstart;
+    DevBuf<uint32_t>  delimpos;
+    std::vector<uint64_t> lenhist;  // sentence-length histogram (host copy)
+
+    // training state
+    bool              trained = false;
+    colibri_options   opt{};
+    DevBuf<uint32_t>  ids[2];
+    DevBuf<Slot>      table;
+    DevBuf<uint32_t>  res_rep, res_cnt;
+    DevBuf<DevState>  state;
+    DevState          hstate{};
+    colibri_stats     stats{};
+    // export scratch
+    DevBuf<uint32_t>           keylen;
+    DevBuf<unsigned long long> keyoff;
+    uint64_t                   keybytes = 0;
+
+    // profiling
+    bool                   profile = false;
+    std::vector<EventPair> events;
+    double                 k_ms[COLIBRI_K_NCLASSES]{};
+    uint64_t               k_launches[COLIBRI_K_NCLASSES]{};
+};
+
+namespace {
+
+int fail(colibri_ctx* c, int code, const char* fmt, ...) {
+    char    buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                                              \
+    do {                                                                                                                \
+        hipError_t e_ = (call);                                                                                         \
+        if (e_ != hipSuccess) return fail((ctx), COLIBRI_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <class T>
+int dev_alloc(colibri_ctx* c, DevBuf<T>& b, size_t n) {
+    if (b.p && b.n >= n) return COLIBRI_OK;
+    if (b.p) {
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.n = 0;
+    }
+    if (n == 0) n = 1;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&b.p), n * sizeof(T)));
+    b.n = n;
+    return COLIBRI_OK;
+}
+template <class T>
+void dev_free(DevBuf<T>& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.n = 0;
+}
+
+inline uint32_t blocks_for(uint64_t n, uint32_t per) { return (uint32_t)((n + per - 1) / per); }
+// grid for grid-stride streaming kernels: enough waves to fill 256 CUs x 8 blocks, no more
+inline uint32_t stream_grid(uint64_t n) { return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, 256ull * 16)); }
+
+struct Prof {
+    colibri_ctx* c;
+    int          cls;
+    size_t       idx = (size_t)-1;
+    Prof(colibri_ctx* c_, int cls_) : c(c_), cls(cls_) {
+        if (!c->profile) return;
+        EventPair ev{};
+        ev.cls = cls;
+        if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return;
+        (void)hipEventRecord(ev.a, c->stream);
+        c->events.push_back(ev);
+        idx = c->events.size() - 1;
+    }
+    ~Prof() {
+        if (idx != (size_t)-1) (void)hipEventRecord(c->events[idx].b, c->stream);
+    }
+};
+
+void collect_events(colibri_ctx* c) {
+    for (auto& ev : c->events) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+            c->k_ms[ev.cls] += ms;
+            c->k_launches[ev.cls] += 1;
+        }
+        (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
+    }
+    c->events.clear();
+}
+
+// ---- corpus ingestion -----------------------------------------------------------------------------
+int tokenise(colibri_ctx* c) {
+    const uint64_t B = c->nbytes;
+    // upper bound of positions = bytes; sized exactly after the count pass
+    const uint32_t   nblk = std::max<uint32_t>(1, blocks_for(B, kTokBytesPerBlock));
+    DevBuf<uint32_t> blockcnt, total;
+    DevBuf<CorpusInfo> info;
+    DevBuf<unsigned long long> hist;
+    int rc;
+    if ((rc = dev_alloc(c, blockcnt, nblk + 1))) return rc;
+    if ((rc = dev_alloc(c, total, 1))) return rc;
+    if ((rc = dev_alloc(c, info, 1))) return rc;
+    if ((rc = dev_alloc(c, hist, kLenHistBins))) return rc;
+    auto cleanup = [&]() {
+        dev_free(blockcnt);
+        dev_free(total);
+        dev_free(info);
+        dev_free(hist);
+    };
+    {
+        Prof p(c, COLIBRI_K_TOKENISE);
+        hipLaunchKernelGGL(tokenise_count_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, c->bytes.p, B, blockcnt.p);
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, blockcnt.p, nblk, total.p);
+    }
+    uint32_t npos = 0;
+    HIP_TRY(c, hipMemcpyAsync(&npos, total.p, sizeof npos, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->npos = npos;
+    if ((rc = dev_alloc(c, c->tokstart, (size_t)npos + 2))) {
+        cleanup();
+        return rc;
+    }
+    HIP_TRY(c, hipMemsetAsync(c->tokstart.p, 0, sizeof(uint32_t), c->stream));  // tokstart[0] = 0
+    HIP_TRY(c, hipMemsetAsync(info.p, 0, sizeof(CorpusInfo), c->stream));
+    HIP_TRY(c, hipMemsetAsync(hist.p, 0, sizeof(unsigned long long) * kLenHistBins, c->stream));
+    const uint32_t   pblk = std::max<uint32_t>(1, blocks_for(npos, kBlock));
+    DevBuf<uint32_t> dcnt;
+    if ((rc = dev_alloc(c, dcnt, pblk + 1))) {
+        cleanup();
+        return rc;
+    }
+    {
+        Prof p(c, COLIBRI_K_TOKENISE);
+        hipLaunchKernelGGL(tokenise_write_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, c->bytes.p, B, blockcnt.p, c->tokstart.p);
+        hipLaunchKernelGGL(position_info_kernel, dim3(pblk), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, npos, info.p, dcnt.p);
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, dcnt.p, pblk, total.p);
+    }
+    uint32_t   ndelim = 0;
+    CorpusInfo hinfo{};
+    HIP_TRY(c, hipMemcpyAsync(&ndelim, total.p, sizeof ndelim, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&hinfo, info.p, sizeof hinfo, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->ndelim   = ndelim;
+    c->maxclass = hinfo.maxclass;
+    c->flags    = hinfo.flags;
+    c->ntokens  = (uint64_t)npos - ndelim;
+    if ((rc = dev_alloc(c, c->delimpos, (size_t)ndelim + 1))) {
+        dev_free(dcnt);
+        cleanup();
+        return rc;
+    }
+    uint32_t last_delim = 0;
+    {
+        Prof p(c, COLIBRI_K_TOKENISE);
+        hipLaunchKernelGGL(delimiter_write_kernel, dim3(pblk), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, npos, dcnt.p, c->delimpos.p);
+        hipLaunchKernelGGL(sentence_length_kernel, dim3(stream_grid((uint64_t)ndelim + 1)), dim3(kBlock), 0, c->stream, c->delimpos.p, ndelim, npos, hist.p);
+    }
+    c->lenhist.assign(kLenHistBins, 0);
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64");
+    HIP_TRY(c, hipMemcpyAsync(c->lenhist.data(), hist.p, sizeof(uint64_t) * kLenHistBins, hipMemcpyDeviceToHost, c->stream));
+    if (ndelim) HIP_TRY(c, hipMemcpyAsync(&last_delim, c->delimpos.p + (ndelim - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    const uint32_t trailing = ndelim ? npos - (last_delim + 1) : npos;
+    c->nsent                = ndelim + (trailing ? 1u : 0u);
+    dev_free(dcnt);
+    cleanup();
+    if (c->flags & kFlagTokenTooLong) return fail(c, COLIBRI_ERR_CORPUS, "corpus has a token longer than 8 bytes; not a valid class encoding for the accelerated path");
+    if (c->flags & kFlagFlexClass)
+        return fail(c, COLIBRI_ERR_CORPUS, "corpus contains the literal flexgram class {**} (04); the reference collapses these while counting, not accelerated");
+    return COLIBRI_OK;
+}
+
+int ingest(colibri_ctx* c, const void* src, uint64_t nbytes, uint32_t first_sentence, hipMemcpyKind kind) {
+    if (!c) return COLIBRI_ERR_ARG;
+    if (!src && nbytes) return fail(c, COLIBRI_ERR_ARG, "payload is NULL");
+    if (nbytes >= 0xFFFFFF00ull) return fail(c, COLIBRI_ERR_CORPUS, "corpus shard of %llu bytes exceeds the 4 GiB per-device limit (32-bit byte offsets); shard it", (unsigned long long)nbytes);
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->have_corpus    = false;
+    c->trained        = false;
+    c->nbytes         = nbytes;
+    c->first_sentence = first_sentence;
+    const size_t padded = ((size_t)nbytes + 15) / 16 * 16 + 64;  // 16-byte tokenise loads + 15-byte hash tail over-read
+    int          rc;
+    if ((rc = dev_alloc(c, c->bytes, padded))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->bytes.p + nbytes, 0, padded - nbytes, c->stream));
+    if (nbytes) HIP_TRY(c, hipMemcpyAsync(c->bytes.p, src, nbytes, kind, c->stream));
+    if ((rc = tokenise(c))) return rc;
+    c->have_corpus = true;
+    return COLIBRI_OK;
+}
+
+int check_options(colibri_ctx* c, colibri_options& o) {
+    if (o.mintokens == -1) o.mintokens = 2;  // patternmodel.h:883-886
+    if (o.mintokens == 0) o.mintokens = 1;
+    if (o.mintokens_skipgrams < o.mintokens) o.mintokens_skipgrams = o.mintokens;  // :887-888
+    if (o.maxlength < 1) return fail(c, COLIBRI_ERR_ARG, "MAXLENGTH must be >= 1");
+    if (o.mintokens < 2) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINTOKENS=1 (single-pass, no look-back) is not on the accelerated path");
+    if (o.minlength > 1) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINLENGTH>1 is not on the accelerated path");
+    if (o.maxbackofflength < o.maxlength) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MAXBACKOFFLENGTH < MAXLENGTH is not on the accelerated path");
+    if (o.mintokens_unigrams > o.mintokens) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINTOKENS_UNIGRAMS > MINTOKENS is not on the accelerated path");
+    if (o.dopatternperline || o.prunenonsubsumed || o.prunesubsumed)
+        return fail(c, COLIBRI_ERR_UNSUPPORTED, "DOPATTERNPERLINE / PRUNE(NON)SUBSUMED are not on the accelerated path");
+    if (o.doskipgrams && o.doskipgrams_exhaustive)
+        return fail(c, COLIBRI_ERR_ARG, "Both DOSKIPGRAMS as well as DOSKIPGRAMS_EXHAUSTIVE are set, this shouldn't happen, choose one.");  // :958-963
+    if (o.doskipgrams || o.doskipgrams_exhaustive || o.indexed)
+        return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgram / indexed training is not built into this library version");
+    return COLIBRI_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+int colibri_abi_version(void) { return COLIBRI_ABI_VERSION; }
+
+int colibri_create(colibri_ctx** out, int device) {
+    if (!out) return COLIBRI_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return COLIBRI_ERR_NODEVICE;
+    if (device < 0 || device >= ndev) return COLIBRI_ERR_ARG;
+    colibri_ctx* c = new (std::nothrow) colibri_ctx();
+    if (!c) return COLIBRI_ERR_ARG;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return COLIBRI_ERR_HIP;
+    }
+    *out = c;
+    return COLIBRI_OK;
+}
+
+void colibri_destroy(colibri_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    collect_events(c);
+    dev_free(c->bytes);
+    dev_free(c->tokstart);
+    dev_free(c->delimpos);
+    dev_free(c->ids[0]);
+    dev_free(c->ids[1]);
+    dev_free(c->table);
+    dev_free(c->res_rep);
+    dev_free(c->res_cnt);
+    dev_free(c->state);
+    dev_free(c->keylen);
+    dev_free(c->keyoff);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* colibri_last_error(const colibri_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int colibri_upload_corpus(colibri_ctx* c, const uint8_t* payload, uint64_t nbytes, uint32_t first_sentence) {
+    return ingest(c, payload, nbytes, first_sentence, hipMemcpyHostToDevice);
+}
+int colibri_upload_corpus_device(colibri_ctx* c, const void* device_payload, uint64_t nbytes, uint32_t first_sentence) {
+    return ingest(c, device_payload, nbytes, first_sentence, hipMemcpyDeviceToDevice);
+}
+
+int colibri_corpus_info(const colibri_ctx* c, uint64_t* ntokens, uint64_t* nsentences, uint64_t* maxclass) {
+    if (!c) return COLIBRI_ERR_ARG;
+    if (!c->have_corpus) return COLIBRI_ERR_STATE;
+    if (ntokens) *ntokens = c->ntokens;
+    if (nsentences) *nsentences = c->nsent;
+    if (maxclass) *maxclass = c->maxclass;
+    return COLIBRI_OK;
+}
+
+int colibri_positions(const colibri_ctx* c, uint64_t* npositions) {
+    if (!c || !npositions) return COLIBRI_ERR_ARG;
+    if (!c->have_corpus) return COLIBRI_ERR_STATE;
+    *npositions = c->npos;
+    return COLIBRI_OK;
+}
+
+int colibri_train(colibri_ctx* c, const colibri_options* opt_in, colibri_stats* stats_out) {
+    if (!c || !opt_in) return COLIBRI_ERR_ARG;
+    if (!c->have_corpus) return fail(c, COLIBRI_ERR_STATE, "no corpus uploaded");
+    colibri_options o = *opt_in;
+    int             rc;
+    if ((rc = check_options(c, o))) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->opt     = o;
+    c->trained = false;
+    c->profile = o.profile != 0;
+    collect_events(c);
+    std::fill(std::begin(c->k_ms), std::end(c->k_ms), 0.0);
+    std::fill(std::begin(c->k_launches), std::end(c->k_launches), 0);
+
+    const uint32_t npos = c->npos;
+    // ---- HBM layout (sized once; nothing is allocated inside the order loop) -------------------------
+    // table: an order admits at most `npos` windows -> 1.5x slots; results: every survivor has >= 2 occurrences
+    const uint64_t table_slots64 = (uint64_t)npos + (npos >> 1) + 2048;
+    if (table_slots64 >= 0x7FFFFFFFull) return fail(c, COLIBRI_ERR_CORPUS, "corpus shard too large for one device table");
+    const uint32_t table_slots = (uint32_t)table_slots64;
+    const uint32_t res_cap     = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)npos * 2 + 1024);
+    if ((rc = dev_alloc(c, c->ids[0], (size_t)npos + 1))) return rc;
+    if ((rc = dev_alloc(c, c->ids[1], (size_t)npos + 1))) return rc;
+    if ((rc = dev_alloc(c, c->table, table_slots))) return rc;
+    if ((rc = dev_alloc(c, c->res_rep, res_cap))) return rc;
+    if ((rc = dev_alloc(c, c->res_cnt, res_cap))) return rc;
+    if ((rc = dev_alloc(c, c->state, 1))) return rc;
+
+    // order 1: distinct unigrams <= distinct class ids when the encoding is canonical
+    DevState init{};
+    uint64_t cap1 = (uint64_t)c->ntokens + (c->ntokens >> 1) + 1024;
+    if (!(c->flags & kFlagNonCanonical)) cap1 = std::min<uint64_t>(cap1, 2ull * ((uint64_t)c->maxclass + 1) + 1024);
+    init.cap = (uint32_t)std::min<uint64_t>(cap1, table_slots);
+    if (c->ntokens == 0) init.done = 1;  // empty corpus: "None found" at n = 1
+    HIP_TRY(c, hipMemcpyAsync(c->state.p, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+
+    const auto     t0        = std::chrono::steady_clock::now();
+    const uint32_t thr       = (uint32_t)o.mintokens;
+    const uint32_t cnt_grid  = std::max<uint32_t>(1, std::min<uint32_t>(blocks_for(npos, kCountTile), 256u * 6u));  // persistent: 6 blocks/CU by LDS
+    const uint32_t tab_grid  = stream_grid(table_slots);
+    const uint32_t pos_grid  = stream_grid(npos);
+    int            cur       = 0;  // ids[cur] = survivor ids of order n-1; ids[cur^1] receives order n
+    const int      maxlength = std::min<int>(o.maxlength, COLIBRI_MAX_ORDER - 1);
+    for (int n = 1; n <= maxlength; ++n) {
+        uint32_t* id_prev = c->ids[cur].p;
+        uint32_t* id_cur  = c->ids[cur ^ 1].p;
+        {
+            Prof p(c, COLIBRI_K_CLEAR);
+            hipLaunchKernelGGL(clear_table_kernel, dim3(tab_grid), dim3(kBlock), 0, c->stream, c->table.p, c->state.p);
+        }
+        {
+            Prof p(c, COLIBRI_K_COUNT);
+            if (n == 1)
+                hipLaunchKernelGGL(count_kernel<true>, dim3(cnt_grid), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, id_prev, id_cur, c->table.p, c->state.p, npos, n);
+            else
+                hipLaunchKernelGGL(count_kernel<false>, dim3(cnt_grid), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, id_prev, id_cur, c->table.p, c->state.p, npos,
+                                   n);
+        }
+        {
+            Prof p(c, COLIBRI_K_PRUNE);
+            hipLaunchKernelGGL(prune_kernel, dim3(tab_grid), dim3(kBlock), 0, c->stream, c->table.p, c->state.p, thr, c->res_rep.p, c->res_cnt.p, res_cap);
+        }
+        {
+            Prof p(c, COLIBRI_K_RESOLVE);
+            hipLaunchKernelGGL(resolve_kernel, dim3(pos_grid), dim3(kBlock), 0, c->stream, id_cur, c->table.p, c->state.p, npos);
+        }
+        hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, n, table_slots);
+        cur ^= 1;
+        // no host round trip per order: peek at the termination flag only every 8 orders (MAXLENGTH defaults to 100)
+        if ((n % 8) == 0 && n < maxlength) {
+            uint32_t done = 0;
+            HIP_TRY(c, hipMemcpyAsync(&done, &c->state.p->done, sizeof done, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (done) break;
+        }
+    }
+    HIP_TRY(c, hipMemcpyAsync(&c->hstate, c->state.p, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    collect_events(c);
+    if (c->hstate.overflow) return fail(c, COLIBRI_ERR_OVERFLOW, "device result buffer or table exhausted");
+
+    colibri_stats& s = c->stats;
+    std::memset(&s, 0, sizeof s);
+    s.totaltokens = c->ntokens;
+    s.nsentences  = c->nsent;
+    s.npatterns   = c->hstate.res_total;
+    s.maxn        = (int32_t)c->hstate.maxn;
+    s.minn        = s.npatterns ? 1 : 0;
+    s.train_ms    = ms;
+    for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) {
+        s.found[n]    = c->hstate.s_found[n];
+        s.kept[n]     = c->hstate.s_kept[n];
+        s.pruned[n]   = s.found[n] - s.kept[n];
+        s.admitted[n] = c->hstate.s_admitted[n];
+        uint64_t w    = 0;
+        for (size_t len = (size_t)n; len < c->lenhist.size(); ++len) w += c->lenhist[len] * (uint64_t)(len - n + 1);
+        s.windows[n] = (n <= o.maxlength) ? w : 0;
+    }
+    s.totaltypes = s.found[1];  // distinct unigrams before pruning (patternmodel.h:1199-1201)
+    c->trained   = true;
+    c->keybytes  = 0;
+
+    // key byte lengths + offsets (device), so that result_sizes can answer and export is a gather
+    const uint32_t R = c->hstate.res_total;
+    if ((rc = dev_alloc(c, c->keylen, (size_t)R + 1))) return rc;
+    if ((rc = dev_alloc(c, c->keyoff, (size_t)R + 1))) return rc;
+    if (R) {
+        Prof p(c, COLIBRI_K_EXPORT);
+        for (int n = 1; n <= (int)c->hstate.maxn; ++n) {
+            const uint32_t first = c->hstate.res_off[n], cnt = c->hstate.res_off[n + 1] - first;
+            if (cnt) hipLaunchKernelGGL(export_len_kernel, dim3(blocks_for(cnt, kBlock)), dim3(kBlock), 0, c->stream, c->tokstart.p, c->res_rep.p, first, cnt, n, c->keylen.p);
+        }
+        const uint32_t             nb = blocks_for(R, kBlock * 4);
+        DevBuf<unsigned long long> bsum;
+        if ((rc = dev_alloc(c, bsum, (size_t)nb + 1))) return rc;
+        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->keylen.p, R, bsum.p);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1), 0, c->stream, bsum.p, nb, bsum.p + nb);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->keylen.p, R, bsum.p, c->keyoff.p);
+        unsigned long long total = 0;
+        HIP_TRY(c, hipMemcpyAsync(&total, bsum.p + nb, sizeof total, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+        dev_free(bsum);
+        c->keybytes = total;
+    }
+    collect_events(c);
+    s.keybytes = c->keybytes;
+    if (stats_out) *stats_out = s;
+    return COLIBRI_OK;
+}
+
+int colibri_result_sizes(const colibri_ctx* c, uint64_t* npatterns, uint64_t* keybytes, uint64_t* nrefs) {
+    if (!c) return COLIBRI_ERR_ARG;
+    if (!c->trained) return COLIBRI_ERR_STATE;
+    if (npatterns) *npatterns = c->hstate.res_total;
+    if (keybytes) *keybytes = c->keybytes;
+    if (nrefs) *nrefs = 0;
+    return COLIBRI_OK;
+}
+
+int colibri_export_unindexed(colibri_ctx* c, uint64_t* key_off, uint8_t* key_bytes, uint32_t* counts) {
+    if (!c || !key_off || !counts || (!key_bytes && c->keybytes)) return COLIBRI_ERR_ARG;
+    if (!c->trained) return fail(c, COLIBRI_ERR_STATE, "export before train");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t R = c->hstate.res_total;
+    key_off[R]       = c->keybytes;
+    if (!R) return COLIBRI_OK;
+    DevBuf<uint8_t> out;
+    int             rc;
+    if ((rc = dev_alloc(c, out, (size_t)c->keybytes + 1))) return rc;
+    {
+        Prof p(c, COLIBRI_K_EXPORT);
+        hipLaunchKernelGGL(export_bytes_kernel, dim3(blocks_for(R, kBlock)), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, c->res_rep.p, c->keylen.p, c->keyoff.p, R,
+                           out.p);
+    }
+    HIP_TRY(c, hipMemcpyAsync(key_bytes, out.p, c->keybytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(key_off, c->keyoff.p, sizeof(uint64_t) * R, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(counts, c->res_cnt.p, sizeof(uint32_t) * R, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    dev_free(out);
+    collect_events(c);
+    return COLIBRI_OK;
+}
+
+int colibri_export_indexed(colibri_ctx* c, uint64_t*, uint8_t*, uint32_t*, uint64_t*, uint32_t*, uint16_t*) {
+    return fail(c, COLIBRI_ERR_UNSUPPORTED, "indexed export is not built into this library version");
+}
+
+int colibri_hash_windows(colibri_ctx* c, int n, uint64_t* out_host) {
+    if (!c || !out_host || n < 1) return COLIBRI_ERR_ARG;
+    if (!c->have_corpus) return fail(c, COLIBRI_ERR_STATE, "no corpus uploaded");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->npos) return COLIBRI_OK;
+    DevBuf<uint64_t> out;
+    int              rc;
+    if ((rc = dev_alloc(c, out, c->npos))) return rc;
+    hipLaunchKernelGGL(hash_windows_kernel, dim3(blocks_for(c->npos, kBlock)), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, c->npos, n, out.p);
+    HIP_TRY(c, hipMemcpyAsync(out_host, out.p, sizeof(uint64_t) * c->npos, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    dev_free(out);
+    return COLIBRI_OK;
+}
+
+int colibri_hash_keys(colibri_ctx* c, const uint8_t* bytes, const uint64_t* off, uint64_t nkeys, uint64_t* out_host) {
+    if (!c || !off || !out_host || (!bytes && nkeys && off[nkeys])) return COLIBRI_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!nkeys) return COLIBRI_OK;
+    for (uint64_t j = 0; j < nkeys; ++j)
+        if (off[j + 1] - off[j] >= 192) return fail(c, COLIBRI_ERR_UNSUPPORTED, "keys of 192 bytes or more take SpookyHash's long path, which no pattern on this path reaches");
+    DevBuf<uint8_t>            dbytes;
+    DevBuf<unsigned long long> doff;
+    DevBuf<uint64_t>           dout;
+    int                        rc;
+    const uint64_t             total = off[nkeys];
+    if ((rc = dev_alloc(c, dbytes, (size_t)total + 64))) return rc;
+    if ((rc = dev_alloc(c, doff, (size_t)nkeys + 1))) return rc;
+    if ((rc = dev_alloc(c, dout, (size_t)nkeys))) return rc;
+    HIP_TRY(c, hipMemsetAsync(dbytes.p, 0, total + 64, c->stream));
+    if (total) HIP_TRY(c, hipMemcpyAsync(dbytes.p, bytes, total, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(doff.p, off, sizeof(uint64_t) * (nkeys + 1), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(hash_keys_kernel, dim3(blocks_for(nkeys, kBlock)), dim3(kBlock), 0, c->stream, dbytes.p, doff.p, nkeys, dout.p);
+    HIP_TRY(c, hipMemcpyAsync(out_host, dout.p, sizeof(uint64_t) * nkeys, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    dev_free(dbytes);
+    dev_free(doff);
+    dev_free(dout);
+    return COLIBRI_OK;
+}
+
+int colibri_kernel_time(const colibri_ctx* c, int cls, double* total_ms, uint64_t* launches) {
+    if (!c || cls < 0 || cls >= COLIBRI_K_NCLASSES) return COLIBRI_ERR_ARG;
+    if (total_ms) *total_ms = c->k_ms[cls];
+    if (launches) *launches = c->k_launches[cls];
+    return COLIBRI_OK;
+}
+
+}  // extern "C"

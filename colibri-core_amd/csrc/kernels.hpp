@@ -1,0 +1,570 @@
+// kernels.hpp — the HIP kernels of the hot path (gfx950, wave64). See DESIGN.md §3 for the data layout
+// and §4 for the roofline of each kernel. Host orchestration and the C ABI are in colibri_hip.hip.
+#pragma once
+#include "device_common.hpp"
+#include "spooky_device.hpp"
+
+namespace colibri {
+
+// =================================================================================================
+// block-level helpers (256-thread blocks = 4 waves)
+// =================================================================================================
+constexpr int kBlock = 256;
+
+// exclusive scan of one u32 per thread over a 256-thread block; returns the exclusive prefix, *total = block sum
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
+    __shared__ uint32_t wave_sum[kBlock / kWave];
+    const uint32_t      lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t            incl = v;
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, kWave);
+        if ((int)lane >= off) incl += t;
+    }
+    if (lane == kWave - 1) wave_sum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) {
+        const uint32_t s = wave_sum[w];
+        if (w < (int)wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+// =================================================================================================
+// 1. tokenise: class-encoded byte stream -> token-start vector
+//    replaces the byte-at-a-time line reader (reference src/pattern.cpp:483-587) and the sentence index
+//    scan of IndexedCorpus::load (:1942-1958). A byte < 128 ends a position (token or delimiter); every
+//    lane classifies 16 bytes with bit tricks, wave/block prefix sums give each terminator its position
+//    index, and the start offset of position k+1 is written at tokstart[k+1]. Two passes over the bytes
+//    (count, write) with a small scan of per-block counts in between: 2*B read + 4*(T+S) written.
+// =================================================================================================
+constexpr int kTokBytesPerThread = 16;
+constexpr int kTokBytesPerBlock  = kBlock * kTokBytesPerThread;
+
+// bit j set <=> byte g0+j is < 128 (a terminator) and lies inside the corpus
+__device__ __forceinline__ uint32_t terminator_mask16(const uint8_t* bytes, uint64_t g0, uint64_t nbytes) {
+    if (g0 >= nbytes) return 0;
+    const uint4    v = *reinterpret_cast<const uint4*>(bytes + g0);  // buffer is padded to a multiple of 16
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t       mask = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t m = ((~w[k]) & 0x80808080u) >> 7;  // bits 0,8,16,24
+        mask |= ((m | (m >> 7) | (m >> 14) | (m >> 21)) & 0xFu) << (4 * k);
+    }
+    const uint64_t left = nbytes - g0;
+    if (left < 16) mask &= (1u << left) - 1u;
+    return mask;
+}
+
+__global__ __launch_bounds__(kBlock) void tokenise_count_kernel(const uint8_t* __restrict__ bytes, uint64_t nbytes, uint32_t* __restrict__ blockcnt) {
+    const uint64_t g0 = (uint64_t)blockIdx.x * kTokBytesPerBlock + (uint64_t)threadIdx.x * kTokBytesPerThread;
+    uint32_t       total;
+    block_exclusive_scan((uint32_t)__popc(terminator_mask16(bytes, g0, nbytes)), &total);
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kBlock) void tokenise_write_kernel(const uint8_t* __restrict__ bytes, uint64_t nbytes, const uint32_t* __restrict__ blockoff,
+                                                                 uint32_t* __restrict__ tokstart) {
+    const uint64_t g0   = (uint64_t)blockIdx.x * kTokBytesPerBlock + (uint64_t)threadIdx.x * kTokBytesPerThread;
+    uint32_t       mask = terminator_mask16(bytes, g0, nbytes);
+    uint32_t       total;
+    uint32_t       k = blockoff[blockIdx.x] + block_exclusive_scan((uint32_t)__popc(mask), &total);
+    while (mask) {
+        const int j = __builtin_ctz(mask);
+        mask &= mask - 1;
+        tokstart[++k] = (uint32_t)(g0 + j + 1);  // position k ends at byte g0+j, so position k+1 starts after it
+    }
+}
+
+// in-place exclusive scan of n u32 values by ONE block (n = number of tokenise blocks: small)
+__global__ __launch_bounds__(kBlock) void scan_small_kernel(uint32_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ total_out) {
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += kBlock * 4) {
+        uint32_t v[4], s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = base + threadIdx.x * 4 + k;
+            v[k]             = i < n ? data[i] : 0;
+            s += v[k];
+        }
+        uint32_t tot;
+        uint32_t ex = carry + block_exclusive_scan(s, &tot);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = base + threadIdx.x * 4 + k;
+            if (i < n) data[i] = ex;
+            ex += v[k];
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+// corpus facts gathered once per upload
+struct CorpusInfo {
+    uint32_t npos;      // positions = tokens + delimiters
+    uint32_t ndelim;    // delimiter positions
+    uint32_t maxclass;  // highest class id (tokens of <= 5 bytes)
+    uint32_t flags;     // kFlag*
+};
+constexpr uint32_t kFlagTokenTooLong = 1u;  // a token longer than 8 bytes (cannot be a 64-bit order-1 key)
+constexpr uint32_t kFlagFlexClass    = 2u;  // literal class 4 {**}: the reference collapses runs of them (pattern.cpp:1043-1065)
+constexpr uint32_t kFlagSkipClass    = 4u;  // literal class 3 {*}: changes skipgram validity (patternmodel.h:1440-1486)
+constexpr uint32_t kFlagNonCanonical = 8u;  // a multi-byte token whose last byte is 0 (class id not canonical)
+
+__device__ __forceinline__ bool is_delimiter(const uint8_t* bytes, const uint32_t* tokstart, uint32_t i) {
+    const uint32_t a = tokstart[i];
+    return (tokstart[i + 1] - a == 1u) && bytes[a] == 0;
+}
+
+// pass over positions: validation flags, max class, delimiter count per block
+__global__ __launch_bounds__(kBlock) void position_info_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ tokstart, uint32_t npos,
+                                                                CorpusInfo* __restrict__ info, uint32_t* __restrict__ blockcnt) {
+    const uint32_t i     = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t       flags = 0, cls = 0, delim = 0;
+    if (i < npos) {
+        const uint32_t a = tokstart[i], len = tokstart[i + 1] - a;
+        const uint64_t raw = keep_bytes(ld64u(bytes + a), len);
+        if (len > 8) flags |= kFlagTokenTooLong;
+        if (len == 1) {
+            const uint32_t b = (uint32_t)raw;
+            delim            = b == 0;
+            if (b == 4) flags |= kFlagFlexClass;
+            if (b == 3) flags |= kFlagSkipClass;
+        } else if (len <= 8 && ((raw >> (8 * (len - 1))) & 0xFF) == 0) {
+            flags |= kFlagNonCanonical;
+        }
+        if (len <= 5) {  // little-endian base-128 (reference src/classdecoder.cpp:20-43), integer shifts instead of pow()
+            uint64_t c = 0;
+            for (uint32_t k = 0; k < len; ++k) c |= ((raw >> (8 * k)) & 0x7F) << (7 * k);
+            cls = c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c;
+        } else {
+            cls = 0xFFFFFFFFu;
+        }
+    }
+    uint32_t total;
+    block_exclusive_scan(delim, &total);
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
+    // wave reductions, then one atomic per wave
+    uint32_t f = flags, c = cls;
+    for (int off = 32; off > 0; off >>= 1) {
+        f |= __shfl_down(f, off, kWave);
+        c = max(c, __shfl_down(c, off, kWave));
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        if (f) atomicOr(&info->flags, f);
+        if (c) atomicMax(&info->maxclass, c);
+    }
+}
+
+// ordered compaction of delimiter positions: delimpos[s] = position index of the delimiter closing sentence s
+__global__ __launch_bounds__(kBlock) void delimiter_write_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ tokstart, uint32_t npos,
+                                                                  const uint32_t* __restrict__ blockoff, uint32_t* __restrict__ delimpos) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t d = (i < npos) && is_delimiter(bytes, tokstart, i);
+    uint32_t       total;
+    const uint32_t k = blockoff[blockIdx.x] + block_exclusive_scan(d, &total);
+    if (d) delimpos[k] = i;
+}
+
+// histogram of sentence lengths (in tokens): W_n = sum_len hist[len]*max(0,len-n+1) is finished on the host
+constexpr int kLenHistBins = 65537;  // a sentence has at most 65535 tokens in the reference (IndexReference.token is u16)
+constexpr int kLenHistLds  = 2048;
+__global__ __launch_bounds__(kBlock) void sentence_length_kernel(const uint32_t* __restrict__ delimpos, uint32_t ndelim, uint32_t npos,
+                                                                  unsigned long long* __restrict__ hist) {
+    __shared__ uint32_t lh[kLenHistLds];
+    for (int k = threadIdx.x; k < kLenHistLds; k += kBlock) lh[k] = 0;
+    __syncthreads();
+    const uint32_t nsent = ndelim + ((ndelim == 0 ? npos : npos - (delimpos[ndelim - 1] + 1)) > 0 ? 1u : 0u);
+    for (uint32_t s = blockIdx.x * kBlock + threadIdx.x; s < nsent; s += gridDim.x * kBlock) {
+        const uint32_t begin = s == 0 ? 0 : delimpos[s - 1] + 1;
+        const uint32_t end   = s < ndelim ? delimpos[s] : npos;
+        uint32_t       len   = end - begin;
+        if (len < (uint32_t)kLenHistLds) {
+            atomicAdd(&lh[len], 1u);
+        } else {
+            if (len > 65536u) len = 65536u;
+            atomicAdd(&hist[len], 1ull);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kLenHistLds; k += kBlock)
+        if (lh[k]) atomicAdd(&hist[k], (unsigned long long)lh[k]);
+}
+
+// =================================================================================================
+// 2. the order-n pass: scan + SpookyHash + hash-table build (THE dominant kernel)
+//
+//    replaces the window loop of PatternModel::train (reference include/patternmodel.h:1078-1178):
+//    line.ngrams() (:1063), the look-back has() of both (n-1)-grams (:1139-1152) and add() (:1155-1161 ->
+//    :2059-2073 -> PatternMap::operator[] -> valuehandler.add).
+//
+//    One lane per token position i (delimiters are positions). Window i of order n is admissible iff
+//    windows i and i+1 of order n-1 survived the threshold: two coalesced reads of the survivor-id vector
+//    replace both hash probes of the reference. Its exact 64-bit identity is the pair
+//    of those two survivor ids (order 1: the token bytes), so distinct patterns can never merge; the slot
+//    is chosen by the 64-bit SpookyHash of the window's bytes — the same value std::hash<Pattern> feeds the
+//    reference's unordered_map (include/pattern.h:563-597) — read straight from the corpus bytes.
+//
+//    Heavy hitters: a block first reduces its 1024 windows in LDS (one representative lane per distinct key
+//    collects the block's occurrences with LDS atomics), so the Zipf head costs one device-scope atomic per
+//    block instead of one per occurrence (same-address device atomics serialise at ~11 ns each).
+//    Representatives then find-or-insert: plain 16-byte probe load; CAS only on an empty slot; one
+//    no-return atomicAdd of the block-local count. slot_of[i] records the slot for the resolve pass.
+// =================================================================================================
+constexpr int kCountPer   = 4;                    // positions per lane
+constexpr int kCountTile  = kBlock * kCountPer;   // 1024 positions per block
+constexpr int kCountLSlot = 2048;                 // LDS election slots
+
+__device__ __forceinline__ uint32_t table_find_or_insert(Slot* __restrict__ table, uint32_t cap, uint64_t key, uint64_t h, uint32_t pos, uint32_t add,
+                                                         uint32_t* inserted, DevState* __restrict__ st) {
+    uint32_t idx   = slot_of_hash(h, cap);
+    uint32_t probe = 0;
+    bool     won   = false;
+    for (; probe < cap; ++probe) {
+        const uint64_t cur = table[idx].key;
+        if (cur == key) break;
+        if (cur == kEmptyKey) {
+            const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[idx].key), (unsigned long long)kEmptyKey, (unsigned long long)key);
+            if (old == kEmptyKey) {
+                won = true;
+                break;
+            }
+            if (old == key) break;
+        }
+        idx = (idx + 1 == cap) ? 0 : idx + 1;
+    }
+    if (probe == cap) {  // table exhausted: cannot happen while cap >= admitted windows; reported, never silent
+        st->overflow = 1;
+        return kInvalid;
+    }
+    // {count, rep} is one aligned 64-bit word: the CAS winner adds its position into the (zeroed) rep half in the same
+    // no-return atomic that adds its count; everybody else adds to the count half only (counts stay < 2^32).
+    unsigned long long inc = add;
+    if (won) {
+        inc |= (unsigned long long)pos << 32;
+        *inserted = 1;
+    }
+    atomicAdd(reinterpret_cast<unsigned long long*>(&table[idx].count), inc);
+    return idx;
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(kBlock) void count_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ tokstart,
+                                                        const uint32_t* __restrict__ id_prev, uint32_t* __restrict__ slot_of, Slot* __restrict__ table,
+                                                        DevState* __restrict__ st, uint32_t npos, int n) {
+    if (st->done) return;
+    __shared__ uint64_t keyL[kCountTile];
+    __shared__ uint32_t winL[kCountLSlot];
+    __shared__ uint32_t cntL[kCountTile];
+    __shared__ uint32_t slotL[kCountTile];
+    __shared__ uint32_t redL[2][kBlock / kWave];
+
+    const uint32_t cap    = st->cap;
+    const uint32_t ntiles = (npos + kCountTile - 1) / kCountTile;
+    uint32_t       nadm = 0, nins = 0;
+
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t base = tile * kCountTile;
+        uint64_t       key[kCountPer], hash[kCountPer];
+        bool           adm[kCountPer];
+#pragma unroll
+        for (int k = 0; k < kCountPer; ++k) {
+            const uint32_t e = k * kBlock + threadIdx.x, i = base + e;
+            adm[k]  = false;
+            key[k]  = 0;
+            hash[k] = 0;
+            if (i < npos) {
+                if (FIRST) {
+                    const uint32_t a = tokstart[i], len = tokstart[i + 1] - a;
+                    const uint64_t raw = keep_bytes(ld64u(bytes + a), len);
+                    adm[k]             = !(len == 1 && raw == 0);  // not a delimiter
+                    if (adm[k]) {
+                        key[k]  = raw;
+                        hash[k] = spooky64_short(bytes + a, len);
+                    }
+                } else if (i + 1 < npos) {
+                    const uint32_t l = id_prev[i], r = id_prev[i + 1];
+                    adm[k]           = (l != kInvalid) && (r != kInvalid);
+                    if (adm[k]) {
+                        key[k]           = ((uint64_t)l << 32) | r;
+                        const uint32_t a = tokstart[i];
+                        hash[k]          = spooky64_short(bytes + a, tokstart[i + n] - a);
+                    }
+                }
+            }
+            cntL[e] = 0;
+            if (adm[k]) {
+                keyL[e]                                     = key[k];
+                winL[(uint32_t)hash[k] & (kCountLSlot - 1)] = e;  // racing plain stores: any one writer wins the election
+            }
+        }
+        __syncthreads();
+        uint32_t rep[kCountPer];
+#pragma unroll
+        for (int k = 0; k < kCountPer; ++k) {
+            const uint32_t e = k * kBlock + threadIdx.x;
+            rep[k]           = e;
+            if (adm[k]) {
+                const uint32_t w = winL[(uint32_t)hash[k] & (kCountLSlot - 1)];
+                if (w != e && keyL[w] == key[k]) {
+                    rep[k] = w;
+                    atomicAdd(&cntL[w], 1u);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kCountPer; ++k) {
+            const uint32_t e = k * kBlock + threadIdx.x;
+            if (adm[k]) {
+                ++nadm;
+                if (rep[k] == e) {
+                    uint32_t ins = 0;
+                    slotL[e]     = table_find_or_insert(table, cap, key[k], hash[k], base + e, 1u + cntL[e], &ins, st);
+                    nins += ins;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kCountPer; ++k) {
+            const uint32_t e = k * kBlock + threadIdx.x, i = base + e;
+            if (i < npos) slot_of[i] = adm[k] ? slotL[rep[k]] : kInvalid;
+        }
+        // no barrier needed here: the next tile does not touch slotL before its second barrier
+    }
+    // one pair of counter atomics per BLOCK (a single address takes ~88 M device-scope atomics/s)
+    for (int off = 32; off > 0; off >>= 1) {
+        nadm += __shfl_down(nadm, off, kWave);
+        nins += __shfl_down(nins, off, kWave);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        redL[0][threadIdx.x / kWave] = nadm;
+        redL[1][threadIdx.x / kWave] = nins;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0, f = 0;
+        for (int w = 0; w < kBlock / kWave; ++w) {
+            a += redL[0][w];
+            f += redL[1][w];
+        }
+        if (a) atomicAdd(&st->admitted, a);
+        if (f) atomicAdd(&st->found, f);
+    }
+}
+
+// table reset for the capacity the current order uses
+__global__ __launch_bounds__(kBlock) void clear_table_kernel(Slot* __restrict__ table, const DevState* __restrict__ st) {
+    if (st->done) return;
+    const uint32_t cap = st->cap;
+    const uint4    e   = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < cap; i += gridDim.x * kBlock) reinterpret_cast<uint4*>(table)[i] = e;
+}
+
+// =================================================================================================
+// 3. prune + survivor compaction — replaces PatternModel::prune(threshold, n) (patternmodel.h:2107-2128)
+//    One streaming pass over the table: survivors (count >= threshold) are appended to the result arrays
+//    (wave-aggregated reservation) and their slot is tagged with the result index, which is the survivor id
+//    the next order's keys are built from.
+// =================================================================================================
+constexpr int kPrunePer  = 16;
+constexpr int kPruneTile = kBlock * kPrunePer;  // 4096 slots per block iteration
+__global__ __launch_bounds__(kBlock) void prune_kernel(Slot* __restrict__ table, DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ res_rep,
+                                                        uint32_t* __restrict__ res_cnt, uint32_t res_cap) {
+    if (st->done) return;
+    __shared__ uint32_t baseL;
+    const uint32_t      cap = st->cap, res_base = st->res_total;
+    const uint32_t      ntiles = (cap + kPruneTile - 1) / kPruneTile;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t t0 = tile * kPruneTile;
+        uint32_t       cnt[kPrunePer], rep[kPrunePer];
+        uint32_t       keepmask = 0, usedmask = 0;
+#pragma unroll
+        for (int k = 0; k < kPrunePer; ++k) {
+            const uint32_t i = t0 + k * kBlock + threadIdx.x;
+            cnt[k] = rep[k] = 0;
+            if (i < cap) {
+                const Slot s = table[i];
+                if (s.key != kEmptyKey) {
+                    usedmask |= 1u << k;
+                    cnt[k] = s.count;
+                    rep[k] = s.rep;
+                    if (s.count >= threshold) keepmask |= 1u << k;
+                }
+            }
+        }
+        uint32_t       total;
+        const uint32_t excl = block_exclusive_scan((uint32_t)__popc(keepmask), &total);
+        if (threadIdx.x == 0) baseL = total ? atomicAdd(&st->kept, total) : 0;  // one reservation per 4096 slots
+        __syncthreads();
+        uint32_t r = res_base + baseL + excl;
+#pragma unroll
+        for (int k = 0; k < kPrunePer; ++k) {
+            if (usedmask & (1u << k)) {
+                const uint32_t i   = t0 + k * kBlock + threadIdx.x;
+                uint32_t       tag = 0;
+                if (keepmask & (1u << k)) {
+                    if (r < res_cap) {
+                        res_rep[r] = rep[k];
+                        res_cnt[r] = cnt[k];
+                        tag        = kKeptFlag | r;
+                    } else {
+                        st->overflow = 1;
+                    }
+                    ++r;
+                }
+                table[i].count = tag;
+            }
+        }
+        __syncthreads();  // baseL is rewritten by the next tile
+    }
+}
+
+// =================================================================================================
+// 4. resolve: slot index per position -> survivor id per position (in place)
+// =================================================================================================
+__global__ __launch_bounds__(kBlock) void resolve_kernel(uint32_t* __restrict__ ids, const Slot* __restrict__ table, DevState* __restrict__ st, uint32_t npos) {
+    if (st->done) return;
+    uint32_t nvalid = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npos; i += gridDim.x * kBlock) {
+        const uint32_t s  = ids[i];
+        uint32_t       id = kInvalid;
+        if (s != kInvalid) {
+            const uint32_t tag = table[s].count;
+            if (tag & kKeptFlag) {
+                id = tag & ~kKeptFlag;
+                ++nvalid;
+            }
+        }
+        ids[i] = id;
+    }
+    __shared__ uint32_t redL[kBlock / kWave];
+    for (int off = 32; off > 0; off >>= 1) nvalid += __shfl_down(nvalid, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nvalid;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t v = redL[0] + redL[1] + redL[2] + redL[3];
+        if (v) atomicAdd(&st->valid, v);
+    }
+}
+
+// single-lane bookkeeping between orders: statistics, result offsets, next capacity, termination
+__global__ void advance_kernel(DevState* __restrict__ st, int n, uint32_t table_slots) {
+    if (st->done) return;
+    if (n < COLIBRI_MAX_ORDER) {
+        st->s_found[n]    = st->found;
+        st->s_kept[n]     = st->kept;
+        st->s_admitted[n] = st->admitted;
+    }
+    if (st->found == 0) {  // reference: "None found" -> break (patternmodel.h:1189-1194)
+        st->done = 1;
+    } else {
+        st->maxn = (uint32_t)n;
+    }
+    st->res_total += st->kept;
+    if (n + 1 <= COLIBRI_MAX_ORDER) st->res_off[n + 1] = st->res_total;
+    // next order: at most `valid` windows can be admitted, so 1.5x that many slots keeps the load factor <= 2/3
+    uint64_t want = (uint64_t)st->valid + (st->valid >> 1) + 1024u;
+    if (want > table_slots) want = table_slots;
+    st->cap = (uint32_t)want;
+    if (st->valid == 0) st->done = 1;  // nothing can be admitted at n+1: the next order would find nothing
+    st->found = st->kept = st->admitted = st->valid = 0;
+}
+
+// =================================================================================================
+// 5. export: survivors (representative position, order, count) -> key bytes
+//    replaces Pattern::write / BaseValueHandler::write over the map (pattern.cpp:268-277, datatypes.h:219-221)
+// =================================================================================================
+__global__ __launch_bounds__(kBlock) void export_len_kernel(const uint32_t* __restrict__ tokstart, const uint32_t* __restrict__ res_rep, uint32_t first, uint32_t count,
+                                                             int n, uint32_t* __restrict__ keylen) {
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    if (j < count) {
+        const uint32_t p  = res_rep[first + j];
+        keylen[first + j] = tokstart[p + n] - tokstart[p];
+    }
+}
+
+// two-level exclusive scan u32 -> u64 (block sums, then scan_sums_kernel, then apply)
+__global__ __launch_bounds__(kBlock) void scan_reduce_kernel(const uint32_t* __restrict__ in, uint32_t n, unsigned long long* __restrict__ blocksum) {
+    unsigned long long s = 0;
+    const uint32_t     base = blockIdx.x * kBlock * 4;
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = base + k * kBlock + threadIdx.x;
+        if (i < n) s += in[i];
+    }
+    __shared__ unsigned long long ws[kBlock / kWave];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) ws[threadIdx.x / kWave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ void scan_sums_kernel(unsigned long long* __restrict__ blocksum, uint32_t nblocks, unsigned long long* __restrict__ total) {
+    // serial over block sums (one per 1024 inputs): nblocks is at most a few hundred thousand
+    unsigned long long run = 0;
+    for (uint32_t b = 0; b < nblocks; ++b) {
+        const unsigned long long v = blocksum[b];
+        blocksum[b]                = run;
+        run += v;
+    }
+    *total = run;
+}
+__global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t* __restrict__ in, uint32_t n, const unsigned long long* __restrict__ blocksum,
+                                                             unsigned long long* __restrict__ out) {
+    // each block re-scans its 1024 inputs: thread t owns 4 consecutive inputs
+    const uint32_t base = blockIdx.x * kBlock * 4 + threadIdx.x * 4;
+    uint32_t       v[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        s += v[k];
+    }
+    uint32_t           tot;
+    unsigned long long ex = blocksum[blockIdx.x] + block_exclusive_scan(s, &tot);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n) out[base + k] = ex;
+        ex += v[k];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void export_bytes_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ tokstart, const uint32_t* __restrict__ res_rep,
+                                                               const uint32_t* __restrict__ keylen, const unsigned long long* __restrict__ keyoff, uint32_t count,
+                                                               uint8_t* __restrict__ out) {
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    if (j < count) {
+        const uint8_t* src = bytes + tokstart[res_rep[j]];
+        uint8_t*       dst = out + keyoff[j];
+        const uint32_t len = keylen[j];
+        for (uint32_t b = 0; b < len; ++b) dst[b] = src[b];
+    }
+}
+
+// =================================================================================================
+// parity hooks
+// =================================================================================================
+__global__ __launch_bounds__(kBlock) void hash_windows_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ tokstart, uint32_t npos, int n,
+                                                               uint64_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npos) return;
+    uint64_t h  = 0;
+    bool     ok = (uint64_t)i + n <= npos;
+    for (int k = 0; ok && k < n; ++k) ok = !is_delimiter(bytes, tokstart, i + k);
+    if (ok) h = spooky64_short(bytes + tokstart[i], tokstart[i + n] - tokstart[i]);
+    out[i] = h;
+}
+__global__ __launch_bounds__(kBlock) void hash_keys_kernel(const uint8_t* __restrict__ bytes, const unsigned long long* __restrict__ off, uint64_t nkeys,
+                                                            uint64_t* __restrict__ out) {
+    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j < nkeys) {
+        const uint32_t len = (uint32_t)(off[j + 1] - off[j]);
+        out[j]             = len == 0 ? 0 : spooky64_short(bytes + off[j], len);  // Pattern::hash: empty -> 0 (pattern.cpp:235-236)
+    }
+}
+
+}  // namespace colibri

@@ -1,0 +1,204 @@
+"""ctypes binding of libcolibri_hip.so (include/colibri_hip.h). No torch types cross this boundary.
+
+The library is the product; this module only marshals numpy buffers into the C ABI. It fails loudly if
+the shared library is missing (there is no Python or CPU fallback for the hot path).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(os.path.dirname(HERE))  # colibri-core_amd/
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libcolibri_hip.so")
+
+MAX_ORDER = 128
+K_TOKENISE, K_CLEAR, K_COUNT, K_PRUNE, K_RESOLVE, K_SKIPGRAM, K_INDEX, K_EXPORT = range(8)
+KERNEL_CLASSES = ["tokenise", "clear", "count", "prune", "resolve", "skipgram", "index", "export"]
+
+EXPORTED = [
+    "colibri_abi_version", "colibri_create", "colibri_destroy", "colibri_last_error", "colibri_upload_corpus",
+    "colibri_upload_corpus_device", "colibri_corpus_info", "colibri_train", "colibri_result_sizes", "colibri_export_unindexed",
+    "colibri_export_indexed", "colibri_hash_windows", "colibri_positions", "colibri_hash_keys", "colibri_kernel_time",
+]
+
+
+class Options(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "mintokens", "maxlength", "minlength", "maxbackofflength", "mintokens_unigrams", "mintokens_skipgrams", "minskiptypes",
+        "maxskips", "doskipgrams", "doskipgrams_exhaustive", "dopatternperline", "prunenonsubsumed", "prunesubsumed", "indexed",
+        "profile", "reserved")]
+
+    @classmethod
+    def defaults(cls, **kw):
+        """PatternModelOptions() defaults (reference include/patternmodel.h:153-180)."""
+        o = cls(mintokens=-1, maxlength=100, minlength=1, maxbackofflength=100, mintokens_unigrams=1, mintokens_skipgrams=-1,
+                minskiptypes=2, maxskips=3)
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise AttributeError(k)
+            setattr(o, k, int(v))
+        return o
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("totaltokens", C.c_uint64), ("totaltypes", C.c_uint64), ("npatterns", C.c_uint64), ("keybytes", C.c_uint64),
+        ("nrefs", C.c_uint64), ("nsentences", C.c_uint64), ("maxn", C.c_int32), ("minn", C.c_int32),
+        ("windows", C.c_uint64 * MAX_ORDER), ("admitted", C.c_uint64 * MAX_ORDER), ("found", C.c_uint64 * MAX_ORDER),
+        ("pruned", C.c_uint64 * MAX_ORDER), ("kept", C.c_uint64 * MAX_ORDER), ("train_ms", C.c_double),
+    ]
+
+
+class ColibriError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"colibri_hip status {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). There is no fallback path.")
+        L = C.CDLL(LIB_PATH)
+        L.colibri_abi_version.restype = C.c_int
+        L.colibri_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.colibri_destroy.argtypes = [C.c_void_p]
+        L.colibri_destroy.restype = None
+        L.colibri_last_error.argtypes = [C.c_void_p]
+        L.colibri_last_error.restype = C.c_char_p
+        L.colibri_upload_corpus.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+        L.colibri_upload_corpus_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+        L.colibri_corpus_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 3
+        L.colibri_train.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Stats)]
+        L.colibri_result_sizes.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 3
+        L.colibri_export_unindexed.argtypes = [C.c_void_p] * 4
+        L.colibri_export_indexed.argtypes = [C.c_void_p] * 7
+        L.colibri_hash_windows.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.colibri_positions.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.colibri_hash_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.colibri_kernel_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        _lib = L
+    return _lib
+
+
+class Context:
+    """One device context = one corpus shard resident in HBM + its training state."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.colibri_create(C.byref(h), device)
+        if rc != 0:
+            raise ColibriError(rc, "colibri_create failed (no usable HIP device?)")
+        self.h = h
+        self.stats = None
+        self.indexed = False
+
+    def close(self):
+        if self.h:
+            self.L.colibri_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ColibriError(rc, self.L.colibri_last_error(self.h).decode())
+
+    # -- corpus ----------------------------------------------------------------------------------
+    def upload(self, payload, first_sentence=1):
+        """payload: bytes / numpy uint8 of the v2 corpus WITHOUT its A2 02 header."""
+        buf = np.frombuffer(payload, dtype=np.uint8) if not isinstance(payload, np.ndarray) else payload
+        self._keep = buf
+        self._check(self.L.colibri_upload_corpus(self.h, buf.ctypes.data if buf.size else None, buf.size, first_sentence))
+
+    def upload_device(self, dptr, nbytes, first_sentence=1):
+        self._check(self.L.colibri_upload_corpus_device(self.h, C.c_void_p(dptr), nbytes, first_sentence))
+
+    def corpus_info(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.L.colibri_corpus_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"tokens": a.value, "sentences": b.value, "maxclass": c.value}
+
+    def positions(self):
+        n = C.c_uint64()
+        self._check(self.L.colibri_positions(self.h, C.byref(n)))
+        return n.value
+
+    # -- training --------------------------------------------------------------------------------
+    def train(self, options=None, **kw):
+        opt = options if options is not None else Options.defaults(**kw)
+        st = Stats()
+        self._check(self.L.colibri_train(self.h, C.byref(opt), C.byref(st)))
+        self.stats = st
+        self.indexed = bool(opt.indexed)
+        return st
+
+    def result_sizes(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.L.colibri_result_sizes(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def export_arrays(self):
+        npat, kb, nrefs = self.result_sizes()
+        key_off = np.zeros(npat + 1, dtype=np.uint64)
+        key_bytes = np.zeros(max(1, kb), dtype=np.uint8)
+        counts = np.zeros(max(1, npat), dtype=np.uint32)
+        if not self.indexed:
+            self._check(self.L.colibri_export_unindexed(self.h, key_off.ctypes.data, key_bytes.ctypes.data, counts.ctypes.data))
+            return key_off, key_bytes[:kb], counts[:npat], None
+        ref_off = np.zeros(npat + 1, dtype=np.uint64)
+        ref_s = np.zeros(max(1, nrefs), dtype=np.uint32)
+        ref_t = np.zeros(max(1, nrefs), dtype=np.uint16)
+        self._check(self.L.colibri_export_indexed(self.h, key_off.ctypes.data, key_bytes.ctypes.data, counts.ctypes.data, ref_off.ctypes.data,
+                                                  ref_s.ctypes.data, ref_t.ctypes.data))
+        return key_off, key_bytes[:kb], counts[:npat], (ref_off, ref_s[:nrefs], ref_t[:nrefs])
+
+    def export_dict(self):
+        """Canonical form for parity checks: {key bytes: count} and, for indexed models, {key bytes: [(sentence, token)]}."""
+        key_off, key_bytes, counts, refs = self.export_arrays()
+        kb = key_bytes.tobytes()
+        off = key_off.tolist()
+        cd = {kb[off[j]: off[j + 1]]: int(c) for j, c in enumerate(counts.tolist())}
+        rd = None
+        if refs is not None:
+            ref_off, rs, rt = refs
+            ro = ref_off.tolist()
+            rs, rt = rs.tolist(), rt.tolist()
+            rd = {kb[off[j]: off[j + 1]]: list(zip(rs[ro[j]: ro[j + 1]], rt[ro[j]: ro[j + 1]])) for j in range(len(counts))}
+        return cd, rd
+
+    # -- parity / measurement hooks --------------------------------------------------------------
+    def hash_windows(self, n):
+        out = np.zeros(max(1, self.positions()), dtype=np.uint64)
+        self._check(self.L.colibri_hash_windows(self.h, n, out.ctypes.data))
+        return out[: self.positions()]
+
+    def hash_keys(self, keys):
+        off = np.zeros(len(keys) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(k) for k in keys])
+        blob = np.frombuffer(b"".join(keys) or b"\0", dtype=np.uint8)
+        out = np.zeros(max(1, len(keys)), dtype=np.uint64)
+        self._check(self.L.colibri_hash_keys(self.h, blob.ctypes.data, off.ctypes.data, len(keys), out.ctypes.data))
+        return out[: len(keys)]
+
+    def kernel_time(self, cls):
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self.L.colibri_kernel_time(self.h, cls, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,140 @@
+/* include/colibri_hip.h — the C ABI of libcolibri_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary of the hot path: the reference has no FFI layer of its
+ * own, its path sits behind C++ template methods; these entry points are what a binding for that path
+ * would call. The C++ face in colibri-core_amd/host/ (PatternModelOptions / PatternModel<uint32_t> /
+ * IndexedPatternModel<> / IndexedCorpus with the reference's names and signatures) is implemented on
+ * top of exactly these functions. Plain pointers and sizes only; no exceptions, no STL, no torch types.
+ *
+ * Every function returns COLIBRI_OK (0) or a negative status; colibri_last_error() gives the message the
+ * C++ face prints before throwing InternalError (reference include/common.h:41-44). There is no CPU
+ * fallback anywhere behind this interface: without a usable HIP device colibri_create fails.
+ *
+ * One context per host thread (the reference is not thread-safe either, include/classencoder.h:193-207).
+ */
+#ifndef COLIBRI_HIP_H
+#define COLIBRI_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COLIBRI_ABI_VERSION 1
+#define COLIBRI_MAX_ORDER 128 /* per-order statistics are kept for n < 128; MAXLENGTH defaults to 100 in the reference */
+
+enum {
+    COLIBRI_OK              = 0,
+    COLIBRI_ERR_ARG         = -1,  /* NULL / out-of-range argument                                         */
+    COLIBRI_ERR_HIP         = -2,  /* a HIP runtime call failed (message has the call and hipGetErrorString) */
+    COLIBRI_ERR_NODEVICE    = -3,  /* no gfx950-class device visible                                       */
+    COLIBRI_ERR_UNSUPPORTED = -4,  /* options outside the accelerated subset            */
+    COLIBRI_ERR_CORPUS      = -5,  /* corpus not usable: > 4 GiB per device, token > 8 bytes, flexgram class  */
+    COLIBRI_ERR_STATE       = -6,  /* call order: no corpus uploaded / not trained yet                     */
+    COLIBRI_ERR_OVERFLOW    = -7   /* a device table or result buffer was exhausted                        */
+};
+
+typedef struct colibri_ctx colibri_ctx;
+
+/* POD mirror of the PatternModelOptions fields PatternModel::train reads on this path
+ * (reference include/patternmodel.h:103-213; defaults :153-180). */
+typedef struct colibri_options {
+    int32_t mintokens;              /* MINTOKENS: -1 -> 2, 0 -> 1 (patternmodel.h:883-886); accelerated for >= 2 */
+    int32_t maxlength;              /* MAXLENGTH (default 100)                                                    */
+    int32_t minlength;              /* MINLENGTH (default 1; only 1 is accelerated)                               */
+    int32_t maxbackofflength;       /* MAXBACKOFFLENGTH (must be >= maxlength)                                    */
+    int32_t mintokens_unigrams;     /* MINTOKENS_UNIGRAMS (must be <= mintokens)                                  */
+    int32_t mintokens_skipgrams;    /* MINTOKENS_SKIPGRAMS (raised to mintokens when lower, :887-888)             */
+    int32_t minskiptypes;           /* MINSKIPTYPES (default 2)                                                   */
+    int32_t maxskips;               /* MAXSKIPS (default 3)                                                       */
+    int32_t doskipgrams;            /* DOSKIPGRAMS (indexed models)                                               */
+    int32_t doskipgrams_exhaustive; /* DOSKIPGRAMS_EXHAUSTIVE                                                     */
+    int32_t dopatternperline;       /* DOPATTERNPERLINE (must be 0)                                               */
+    int32_t prunenonsubsumed;       /* PRUNENONSUBSUMED (must be 0)                                               */
+    int32_t prunesubsumed;          /* PRUNESUBSUMED (must be 0)                                                  */
+    int32_t indexed;                /* 0: PatternModel<uint32_t> (model type 10), 1: IndexedPatternModel<> (20)   */
+    int32_t profile;                /* 1: bracket every kernel class with HIP events (colibri_kernel_time)        */
+    int32_t reserved;
+} colibri_options;
+
+/* What train() reports: the numbers the reference keeps in the model (totaltokens/totaltypes/maxn/minn,
+ * patternmodel.h:550-556) and prints per order on stderr (:1195-1245). */
+typedef struct colibri_stats {
+    uint64_t totaltokens;                  /* sum of sentence lengths (patternmodel.h:1047-1048)            */
+    uint64_t totaltypes;                   /* distinct unigrams BEFORE pruning (:1199-1201)                  */
+    uint64_t npatterns;                    /* size of the final model                                        */
+    uint64_t keybytes;                     /* sum of key byte lengths over the final model                   */
+    uint64_t nrefs;                        /* indexed: total index entries                                   */
+    uint64_t nsentences;                   /* sentences incl. empty ones                                     */
+    int32_t  maxn, minn;                   /* as PatternModel::maxlength()/minlength()                       */
+    uint64_t windows[COLIBRI_MAX_ORDER];   /* W_n: n-token windows inside sentences (line.ngrams(), :1063)    */
+    uint64_t admitted[COLIBRI_MAX_ORDER];  /* P_n: windows that passed the look-back and were counted        */
+    uint64_t found[COLIBRI_MAX_ORDER];     /* distinct new patterns of order n before pruning                */
+    uint64_t pruned[COLIBRI_MAX_ORDER];    /* erased by prune()/pruneskipgrams() at order n                  */
+    uint64_t kept[COLIBRI_MAX_ORDER];      /* found - pruned                                                 */
+    double   train_ms;                     /* wall time of the device work of train(), host clock            */
+} colibri_stats;
+
+/* kernel classes for colibri_kernel_time */
+enum {
+    COLIBRI_K_TOKENISE = 0, /* byte stream -> token-start vector (upload time, not train)        */
+    COLIBRI_K_CLEAR    = 1, /* table reset                                                       */
+    COLIBRI_K_COUNT    = 2, /* scan + SpookyHash + hash-table build: the dominant kernel         */
+    COLIBRI_K_PRUNE    = 3, /* threshold prune + survivor compaction                             */
+    COLIBRI_K_RESOLVE  = 4, /* per-position survivor ids for the next order                      */
+    COLIBRI_K_SKIPGRAM = 5, /* skipgram counting                                                 */
+    COLIBRI_K_INDEX    = 6, /* forward-index build                                               */
+    COLIBRI_K_EXPORT   = 7,
+    COLIBRI_K_NCLASSES = 8
+};
+
+/* ---- lifecycle ------------------------------------------------------------------------------- */
+int         colibri_abi_version(void);
+int         colibri_create(colibri_ctx** out, int device); /* device = HIP ordinal                  */
+void        colibri_destroy(colibri_ctx* ctx);
+const char* colibri_last_error(const colibri_ctx* ctx);   /* never NULL                            */
+
+/* ---- corpus: replaces IndexedCorpus::load (reference src/pattern.cpp:1916-1967) ------------------
+ * payload = the .colibri.dat v2 file minus its 2-byte header (A2 02). first_sentence = the index given
+ * to the first sentence (train()'s `firstsentence`, patternmodel.h:880-881,896; 1 by default) — this is
+ * also how a sentence-sharded rank keeps global sentence numbers. The bytes are copied to HBM and
+ * tokenised there (token-start vector + sentence table). */
+int colibri_upload_corpus(colibri_ctx* ctx, const uint8_t* payload, uint64_t nbytes, uint32_t first_sentence);
+/* same, for bytes that already live in this device's HBM (no PCIe copy; a device-to-device copy is made) */
+int colibri_upload_corpus_device(colibri_ctx* ctx, const void* device_payload, uint64_t nbytes, uint32_t first_sentence);
+/* tokens (delimiters excluded), sentences (empty ones included), highest class id */
+int colibri_corpus_info(const colibri_ctx* ctx, uint64_t* ntokens, uint64_t* nsentences, uint64_t* maxclass);
+
+/* ---- training: replaces PatternModel::train (reference include/patternmodel.h:880-1345) and, for
+ * indexed models, IndexedPatternModel::train/trainskipgrams (:2828-2844, :2969-3010). All orders run on
+ * the device without a host round trip per order. */
+int colibri_train(colibri_ctx* ctx, const colibri_options* opt, colibri_stats* stats);
+
+/* ---- results: replaces iteration over PatternMap + valuehandler.write (patternstore.h:534-542,
+ * datatypes.h:219-221,263-270). Caller allocates from colibri_result_sizes():
+ *   key_off[npatterns+1], key_bytes[keybytes], counts[npatterns]
+ *   indexed: ref_off[npatterns+1], ref_sentence[nrefs], ref_token[nrefs]; refs sorted by (sentence, token).
+ * Keys are the pattern's bytes without the trailing 00 (a skipgram's gaps are the byte 03). Order: by
+ * pattern length n, unspecified inside an order (the reference's order is unordered_map order). */
+int colibri_result_sizes(const colibri_ctx* ctx, uint64_t* npatterns, uint64_t* keybytes, uint64_t* nrefs);
+int colibri_export_unindexed(colibri_ctx* ctx, uint64_t* key_off, uint8_t* key_bytes, uint32_t* counts);
+int colibri_export_indexed(colibri_ctx* ctx, uint64_t* key_off, uint8_t* key_bytes, uint32_t* counts, uint64_t* ref_off,
+                           uint32_t* ref_sentence, uint16_t* ref_token);
+
+/* ---- parity / measurement hooks ------------------------------------------------------------------ */
+/* SpookyHash::Hash64 (reference include/SpookyV2.h:59-66) of every n-token window, computed by the same
+ * device routine the count kernel uses: out[i] for token position i (delimiters are positions too);
+ * 0 where no n-token window starts. out has colibri_positions() entries. */
+int colibri_hash_windows(colibri_ctx* ctx, int n, uint64_t* out_host);
+int colibri_positions(const colibri_ctx* ctx, uint64_t* npositions);
+/* SpookyHash::Hash64 of nkeys independent byte strings (off[nkeys+1] into bytes) on the device */
+int colibri_hash_keys(colibri_ctx* ctx, const uint8_t* bytes, const uint64_t* off, uint64_t nkeys, uint64_t* out_host);
+/* accumulated HIP-event time and launch count of one kernel class since the last colibri_train() began
+ * (only when options.profile = 1; events are recorded on the library's own stream) */
+int colibri_kernel_time(const colibri_ctx* ctx, int kernel_class, double* total_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,66 @@
+"""pytest configuration: the `gpu` marker, import paths and shared corpora.
+
+`-m "not gpu"` runs here (no GPU): oracle vs golden fixtures, host logic, C-ABI symbol checks.
+`-m gpu` runs on an MI355X: parity of the HIP path (through the C ABI) against the oracle.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "colibri-core_amd", "pyhost"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun)")
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def hamlet_payload():
+    """exp/hamlet.v1.colibri.dat of the reference (a data fixture, copied to tests/golden/) converted v1 -> v2."""
+    import oracle
+    with open(os.path.join(GOLDEN, "hamlet.v1.colibri.dat"), "rb") as f:
+        return oracle.v1_to_v2(f.read())
+
+
+def small_corpora():
+    """Named v2 payloads (no header) covering the edge cases the reference's tests and SURVEY §8c list."""
+    from colibri_amd import synth
+    rng = np.random.default_rng(20240917)
+    out = {}
+    for i in range(4):
+        out[f"rand{i}"] = synth.random_corpus(rng, nsent=150 + 50 * i, maxlen=10 + 2 * i, vocab=8 + 4 * i)
+    out["rand_noempty"] = synth.random_corpus(rng, nsent=300, maxlen=9, vocab=10, empty_rate=0.0, big_classes=False)
+    out["empty"] = b""
+    out["only_delims"] = b"\x00\x00\x00"
+    out["one_token"] = b"\x06\x00"
+    out["no_trailing_delim"] = b"\x06\x07\x06\x07\x00\x06\x07\x06\x07"
+    out["short_sentences"] = b"\x06\x00\x06\x07\x00\x06\x07\x08\x00\x06\x00\x06\x07\x00\x06\x07\x08\x00"
+    out["repeat"] = (b"\x06\x07\x08\x09\x0a\x0b\x0c\x00") * 5
+    out["one_long_sentence"] = bytes([6, 7, 8, 9] * 300) + b"\x00"
+    out["multibyte"] = synth.encode_v2(np.array([200, 300, 20000, 200, 300, 20000, 0, 3000000, 200, 300, 0, 300000000, 300000000, 0], dtype=np.uint32)).tobytes()
+    out["zipf20k"] = synth.zipf_corpus(20000, 500, 5, header=False)
+    out["zipf200k_phrases"] = synth.zipf_corpus(200000, 5000, 7, phrases=True, header=False)
+    return out

@@ -1,0 +1,139 @@
+"""GPU parity tests: the HIP path, called through the C ABI (include/colibri_hip.h), against the oracle.
+
+Bit-exact bar: identical pattern set, identical counts, identical totaltokens / totaltypes and identical
+per-order found / pruned / kept (the numbers the reference prints, patternmodel.h:1195-1245).
+"""
+import numpy as np
+import pytest
+
+from conftest import small_corpora
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from colibri_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def test_library_is_native():
+    """The product path is the HIP shared library; it must be the thing that is loaded."""
+    from colibri_amd import capi
+    L = capi.load()
+    assert L.colibri_abi_version() == 1
+
+
+def test_spooky_known_answers(ctx):
+    # values printed by the reference's SpookyHash::Hash64 (oracle/_ref/ref_driver hash ...)
+    kat = {bytes([6]): 0x5D3553AC0AA134FA, bytes([6, 7, 8]): 0x6EE4E90E1C0B57C9, bytes.fromhex("8601904e07"): 0x626A44955A1C64F0}
+    got = ctx.hash_keys(list(kat))
+    assert [int(x) for x in got] == list(kat.values())
+
+
+def test_spooky_random_keys_all_lengths(ctx):
+    import oracle
+    rng = np.random.default_rng(3)
+    keys = [bytes(rng.integers(0, 256, size=n, dtype=np.uint8)) for n in range(0, 192) for _ in range(3)]
+    got = ctx.hash_keys(keys)
+    want = [0 if not k else oracle.spooky64(k) for k in keys]
+    assert [int(x) for x in got] == want
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 9])
+def test_window_hashes_match_reference_hash(ctx, n):
+    """The device routine the count kernel uses, on real windows (reference: std::hash<Pattern>, pattern.h:563-597)."""
+    import oracle
+    payload = small_corpora()["rand2"]
+    ctx.upload(payload)
+    got = ctx.hash_windows(n)
+    # host re-derivation of windows
+    pos, i, start = [], 0, 0
+    for j, b in enumerate(payload):
+        if b < 128:
+            pos.append((start, j + 1))
+            start = j + 1
+    delim = [e - s == 1 and payload[s] == 0 for s, e in pos]
+    for i in range(len(pos)):
+        ok = i + n <= len(pos) and not any(delim[i:i + n])
+        want = oracle.spooky64(payload[pos[i][0]: pos[i + n - 1][1]]) if ok else 0
+        assert int(got[i]) == want, (i, n)
+
+
+def _compare(ctx, payload, maxlength, mintokens=2):
+    import oracle
+    want = oracle.train(payload, mintokens, maxlength)
+    ctx.upload(payload)
+    st = ctx.train(mintokens=mintokens, maxlength=maxlength)
+    got, _ = ctx.export_dict()
+    assert st.totaltokens == want.tokens
+    assert st.totaltypes == want.types
+    assert st.npatterns == len(want)
+    assert got == want.counts
+    assert st.maxn == want.maxn
+    for n in range(1, min(maxlength, 127) + 1):
+        assert (st.found[n], st.pruned[n], st.kept[n]) == want.stats[n], n
+    # the oracle (like the reference) stops visiting orders after the first one that finds nothing
+    last = min(maxlength, 127, want.maxn + 1)
+    assert sum(st.windows[1:last + 1]) == want.windows
+    return st
+
+
+@pytest.mark.parametrize("name", sorted(small_corpora()))
+@pytest.mark.parametrize("maxlength", [1, 3, 5, 100])
+def test_train_matches_oracle(ctx, name, maxlength):
+    _compare(ctx, small_corpora()[name], maxlength)
+
+
+@pytest.mark.parametrize("mintokens", [2, 3, 5, -1, 10])
+def test_thresholds(ctx, mintokens):
+    _compare(ctx, small_corpora()["zipf20k"], 5, mintokens)
+
+
+def test_hamlet_fixture_known_answers(ctx, hamlet_payload):
+    """reference src/test.cpp:1214-1221: 111 patterns / 186 types / 354 tokens with default options;
+    config 1 of BASELINE.json: n <= 3 -> 81 patterns (45/22/14)."""
+    st = _compare(ctx, hamlet_payload, 100)
+    assert (st.npatterns, st.totaltypes, st.totaltokens) == (111, 186, 354)
+    st = _compare(ctx, hamlet_payload, 3)
+    assert st.npatterns == 81 and [st.kept[n] for n in (1, 2, 3)] == [45, 22, 14]
+    got, _ = ctx.export_dict()
+    assert got[bytes([6])] == 27
+
+
+def test_repeated_runs_are_identical(ctx):
+    payload = small_corpora()["zipf200k_phrases"]
+    ctx.upload(payload)
+    ctx.train(maxlength=5)
+    a, _ = ctx.export_dict()
+    ctx.train(maxlength=5)
+    b, _ = ctx.export_dict()
+    assert a == b
+
+
+def test_unsupported_options_fail_loudly(ctx):
+    from colibri_amd import capi
+    ctx.upload(small_corpora()["rand0"])
+    with pytest.raises(capi.ColibriError):
+        ctx.train(mintokens=1)
+    with pytest.raises(capi.ColibriError):
+        ctx.train(minlength=2)
+    with pytest.raises(capi.ColibriError):
+        ctx.train(doskipgrams=1, doskipgrams_exhaustive=1)
+
+
+def test_flexgram_class_in_corpus_is_rejected(ctx):
+    from colibri_amd import capi
+    with pytest.raises(capi.ColibriError):
+        ctx.upload(b"\x06\x04\x04\x07\x00")
+
+
+def test_medium_zipf_properties(ctx):
+    """1M-token Zipf corpus: full parity against the oracle (about a second of CPU)."""
+    from colibri_amd import synth
+    payload = synth.zipf_corpus(10**6, 10**5, 42, scalar_draws=True, header=False)
+    st = _compare(ctx, payload, 5)
+    # the survey's reference run on this exact corpus kept 56240/61036/15024/1369/44
+    assert [st.kept[n] for n in range(1, 6)] == [56240, 61036, 15024, 1369, 44]

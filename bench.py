@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""bench.py — the driver's benchmark contract for the hot path (PatternModel::train, n <= 5, thr = 2).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one complete train() (all five orders: scan + SpookyHash + hash build + prune + resolve) over one
+synthetic class-encoded corpus that is already resident in HBM when the timed region starts.
+  N = 1 : BASELINE.json configs[1] — 100M-token Zipf(1.0, V = 1e6) corpus, unindexed, n <= 5, threshold 2.
+  N > 1 : the corpus is sharded by sentence, 100M tokens PER RANK (weak scaling), with the per-order exchange of
+          candidate counts over RCCL (colibri_amd.dist).
+Metric (BASELINE.json): M patterns counted / s, patterns counted = sum_{n<=5} W_n = the n-token windows inside
+sentences that the reference enumerates in line.ngrams() (include/patternmodel.h:1063) — a property of the input.
+Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (count) against HBM peak with the algorithmic
+bytes of SURVEY.md §8(d) (stated in DESIGN.md §4); `cpu_baseline` times the real reference (oracle/_ref/ref_driver,
+built from the reference's own sources) on a bounded sample of the same distribution on this box's host cores.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "colibri-core_amd", "pyhost"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+MAXLENGTH, MINTOKENS = 5, 2
+
+
+def algorithmic_bytes(nbytes, npos, stats, maxlength):
+    """SURVEY.md §8(d), per order n, for the count kernel (scan + hash + table build):
+         B + 4*(T+S)            corpus bytes + token-start vector, read once
+       + [n>1] * W_n * 2/8      two survivor bits per window (look-back)
+       + P_n * (8 + 4 + 4)      per admitted window: key read, count read, count write
+       + D_n * (8 + 4)          per distinct candidate: key + count written once
+       (the T/8 survivor-bitmap write of the formula belongs to the resolve kernel and is left out)."""
+    total = 0.0
+    per_order = []
+    for n in range(1, maxlength + 1):
+        b = nbytes + 4.0 * npos
+        if n > 1:
+            b += stats.windows[n] * 2.0 / 8.0
+        b += stats.admitted[n] * 16.0 + stats.found[n] * 12.0
+        per_order.append(b)
+        total += b
+    return total, per_order
+
+
+def cpu_baseline(sample_tokens, vocab):
+    """Time the reference's PatternModel<uint32_t>::train on a preloaded IndexedCorpus (src/benchmarks.cpp test 5
+    style), 1 thread (the reference is single-threaded), on a bounded sample of the bench distribution."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    from colibri_amd import synth
+    data = synth.zipf_corpus(sample_tokens, vocab, 45)
+    arr = np.frombuffer(data, dtype=np.uint8)[2:]
+    term = arr < 128
+    prev_low = np.concatenate([[True], term[:-1]])
+    delim = (arr == 0) & prev_low
+    dpos = np.flatnonzero(delim[term])  # delimiter positions in position space
+    lens = np.diff(np.concatenate([[-1], dpos])) - 1
+    windows = int(sum(np.maximum(0, lens - n + 1).sum() for n in range(1, MAXLENGTH + 1)))
+    sample = f"{sample_tokens}-token Zipf(1.0,V={vocab}) corpus, seed 45, same generator as the GPU workload; train() only, corpus preloaded"
+    if oracle.have_ref():
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "sample.colibri.dat")
+            with open(path, "wb") as f:
+                f.write(data)
+            _, info = oracle.ref_train(path, "U", MAXLENGTH, MINTOKENS)
+        return {"value": round(windows / info["train_s"] / 1e6, 4), "unit": "M patterns counted/s", "cores": 1, "kind": "reference",
+                "sample": sample, "seconds": round(info["train_s"], 3), "host_cores": os.cpu_count()}
+    dt, w, _ = oracle.train_timed(data[2:], MINTOKENS, MAXLENGTH)
+    return {"value": round(w / dt / 1e6, 4), "unit": "M patterns counted/s", "cores": 1, "kind": "port", "sample": sample,
+            "seconds": round(dt, 3), "host_cores": os.cpu_count()}
+
+
+def measured_traffic(workload_tokens):
+    """HBM bytes per count-kernel launch from the committed rocprofv3 PMC passes (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_count_kernel.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if int(d.get("tokens", 0)) == int(workload_tokens):
+            return d.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--tokens", type=int, default=100_000_000, help="tokens per GPU (default: the 100M-token config)")
+    ap.add_argument("--vocab", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="tokens of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    from colibri_amd import capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU path to measure")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- synthetic input, resident in HBM before the timed region ---------------------------------
+    seed = 44 + rank
+    t0 = time.time()
+    payload = np.frombuffer(synth.zipf_corpus(args.tokens, args.vocab, seed, header=False), dtype=np.uint8)
+    gen_s = time.time() - t0
+    ctx = capi.Context(local_rank)
+    dev_payload = torch.from_numpy(payload.copy()).cuda()  # H2D outside the timed region
+    torch.cuda.synchronize()
+    t0 = time.time()
+    ctx.upload_device(dev_payload.data_ptr(), payload.size, 1)  # tokenise on device
+    tokenise_ms = (time.time() - t0) * 1e3
+    opt = capi.Options.defaults(mintokens=MINTOKENS, maxlength=MAXLENGTH, profile=1)
+
+    if world > 1:
+        from colibri_amd import dist as cdist
+        trainer = cdist.ShardedTrainer(ctx, dist, torch)
+        step = lambda: trainer.train(opt)
+    else:
+        step = lambda: ctx.train(opt)
+
+    for _ in range(args.warmup):
+        st = step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    count_ms, count_launches = 0.0, 0
+    for _ in range(args.steps):
+        st = step()
+        ms, n = ctx.kernel_time(capi.K_COUNT)  # HIP events on the library's own stream, this step
+        count_ms += ms
+        count_launches += n
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    windows = sum(st.windows[1:MAXLENGTH + 1])
+    if dist is not None:
+        t = torch.tensor([elapsed, float(windows)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, windows = float(tmax[0]), float(t[1])
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    value = windows * args.steps / elapsed / 1e6
+    abytes, _ = algorithmic_bytes(payload.size, ctx.positions(), st, MAXLENGTH)
+    launches_per_step = count_launches / max(1, args.steps)
+    avg_launch_ms = count_ms / max(1, count_launches)
+    achieved = (abytes / max(1.0, launches_per_step)) / (avg_launch_ms * 1e-3) / 1e9 if count_launches else 0.0
+    out = {
+        "metric": "M patterns counted/sec at n<=5 thr=2; identical pattern set vs reference",
+        "value": round(value, 3),
+        "unit": "M patterns counted/s",
+        "n_gpus": args.gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.tokens}-token-per-GPU synthetic Zipf(1.0, V={args.vocab}) class-encoded corpus (.colibri.dat v2), sentences 5..35 tokens, "
+                        f"unindexed PatternModel<uint32_t>, MAXLENGTH={MAXLENGTH}, MINTOKENS={MINTOKENS}",
+            "tokens_per_gpu": args.tokens,
+            "patterns_counted_per_step": int(windows),
+            "patterns_in_model": int(st.npatterns),
+            "kept_per_order": [int(st.kept[n]) for n in range(1, MAXLENGTH + 1)],
+            "parallelism": "single device" if args.gpus == 1 else f"sentence-sharded x{args.gpus}, per-order candidate exchange over RCCL",
+            "tokenise_ms_untimed": round(tokenise_ms, 3),
+            "corpus_generation_s_untimed": round(gen_s, 2),
+        },
+        "roofline": {
+            "kernel": "colibri::count_kernel (scan + SpookyHash + hash-table build), one launch per order",
+            "bound": "hbm",
+            "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": measured_traffic(args.tokens) if args.gpus == 1 else None,
+            "algorithmic_bytes_per_launch": round(abytes / max(1.0, launches_per_step)),
+            "avg_launch_ms": round(avg_launch_ms, 4),
+            "launches_per_step": launches_per_step,
+            "kernel_ms_per_step": {capi.KERNEL_CLASSES[k]: round(ctx.kernel_time(k)[0], 4) for k in (capi.K_CLEAR, capi.K_COUNT, capi.K_PRUNE, capi.K_RESOLVE)},
+        },
+    }
+    if args.gpus == 1 and args.cpu_sample > 0:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.vocab)
+    print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -376,7 +376,9 @@ int colibri_train(colibri_ctx* c, const colibri_options* opt_in, colibri_stats* 
 
     const auto     t0        = std::chrono::steady_clock::now();
     const uint32_t thr       = (uint32_t)o.mintokens;
-    const uint32_t cnt_grid  = std::max<uint32_t>(1, std::min<uint32_t>(blocks_for(npos, kCountTile), 256u * 6u));  // persistent: 6 blocks/CU by LDS
+    constexpr uint32_t kCountLdsBytes = kCountTile * 16u + kCountLSlot * 4u + 64u;  // keyL + cntL + slotL + winL
+    constexpr uint32_t kCountBlocksPerCU = (160u * 1024u / kCountLdsBytes) < 8u ? (160u * 1024u / kCountLdsBytes) : 8u;
+    const uint32_t cnt_grid  = std::max<uint32_t>(1, std::min<uint32_t>(blocks_for(npos, kCountTile), 256u * kCountBlocksPerCU));  // persistent blocks: all resident
     const uint32_t tab_grid  = stream_grid(table_slots);
     const uint32_t pos_grid  = stream_grid(npos);
     int            cur       = 0;  // ids[cur] = survivor ids of order n-1; ids[cur^1] receives order n

@@ -216,9 +216,12 @@ __global__ __launch_bounds__(kBlock) void sentence_length_kernel(const uint32_t*
 //    Representatives then find-or-insert: plain 16-byte probe load; CAS only on an empty slot; one
 //    no-return atomicAdd of the block-local count. slot_of[i] records the slot for the resolve pass.
 // =================================================================================================
-constexpr int kCountPer   = 4;                    // positions per lane
+#ifndef COLIBRI_COUNT_PER
+#define COLIBRI_COUNT_PER 8
+#endif
+constexpr int kCountPer   = COLIBRI_COUNT_PER;    // positions per lane
 constexpr int kCountTile  = kBlock * kCountPer;   // 1024 positions per block
-constexpr int kCountLSlot = 2048;                 // LDS election slots
+constexpr int kCountLSlot = 2 * kCountTile;       // LDS election slots
 
 __device__ __forceinline__ uint32_t table_find_or_insert(Slot* __restrict__ table, uint32_t cap, uint64_t key, uint64_t h, uint32_t pos, uint32_t add,
                                                          uint32_t* inserted, DevState* __restrict__ st) {
@@ -311,7 +314,11 @@ __global__ __launch_bounds__(kBlock) void count_kernel(const uint8_t* __restrict
             rep[k]           = e;
             if (adm[k]) {
                 const uint32_t w = winL[(uint32_t)hash[k] & (kCountLSlot - 1)];
+#ifdef COLIBRI_EXP_NOELECT
+                if (false) {
+#else
                 if (w != e && keyL[w] == key[k]) {
+#endif
                     rep[k] = w;
                     atomicAdd(&cntL[w], 1u);
                 }
@@ -325,7 +332,11 @@ __global__ __launch_bounds__(kBlock) void count_kernel(const uint8_t* __restrict
                 ++nadm;
                 if (rep[k] == e) {
                     uint32_t ins = 0;
+#ifdef COLIBRI_EXP_NOATOMIC
+                    slotL[e] = slot_of_hash(hash[k], cap);
+#else
                     slotL[e]     = table_find_or_insert(table, cap, key[k], hash[k], base + e, 1u + cntL[e], &ins, st);
+#endif
                     nins += ins;
                 }
             }

@@ -10,7 +10,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(os.path.dirname(HERE))  # colibri-core_amd/
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libcolibri_hip.so")
+LIB_PATH = os.environ.get("COLIBRI_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libcolibri_hip.so")  # env override: kernel experiments only
 
 MAX_ORDER = 128
 K_TOKENISE, K_CLEAR, K_COUNT, K_PRUNE, K_RESOLVE, K_SKIPGRAM, K_INDEX, K_EXPORT = range(8)

@@ -1,0 +1,120 @@
+"""Generates the golden fixtures in this directory by running the REAL reference (oracle/_ref/ref_driver, built
+from /root/reference by oracle/Makefile) — run in the build container only:  python tests/golden/make_golden.py
+
+Inputs (data, committed): hamlet.v1.colibri.dat (the reference's own fixture exp/hamlet.v1.colibri.dat),
+edge.colibri.dat / zipf20k.colibri.dat / phrases15k.colibri.dat (written by this script from seeded generators).
+Outputs: <corpus>.<mode>.l<maxlength>.txt — canonical dumps (sorted hex key, count[, refs]) of the reference's
+models; spooky_kat.json — SpookyHash::Hash64 values; masks.json — compute_skip_configurations outputs.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "colibri-core_amd", "pyhost"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle  # noqa: E402
+from colibri_amd import synth  # noqa: E402
+
+DRIVER = oracle.REF_DRIVER
+
+
+def corpora():
+    rng = np.random.default_rng(11)
+    edge = (b"\x06\x07\x08\x00" b"\x00" b"\x06\x07\x08\x09\x0a\x00" b"\x06\x00" b"\x00\x00" b"\x06\x07\x00"
+            + synth.encode_v2(np.array([200, 300, 20000, 200, 300, 20000, 3000000, 0, 200, 300, 20000, 3000000, 0], dtype=np.uint32)).tobytes()
+            + synth.random_corpus(rng, nsent=60, maxlen=9, vocab=7, big_classes=False))
+    return {
+        "edge": synth.HEADER + edge,
+        "zipf20k": synth.zipf_corpus(20000, 500, 5),
+        "phrases15k": synth.zipf_corpus(15000, 800, 9, phrases=True),
+    }
+
+
+def tokens_of(key):
+    out, start = [], 0
+    for j, b in enumerate(key):
+        if b < 128:
+            out.append(key[start:j + 1])
+            start = j + 1
+    return out
+
+
+def reference_is_dump_is_stable(path, minskiptypes, maxlength):
+    """IndexedPatternModel::trainskipgrams inserts into the unordered_map it is iterating (reference
+    include/patternmodel.h:2986-2991); when that rehashes mid-loop the reference revisits / skips n-grams. A dump is
+    kept as a golden only if it is self-consistent: every skipgram's index equals the union of the indices of the
+    n-grams (present in the same dump) that it abstracts, no duplicates, and it has >= MINSKIPTYPES sources."""
+    m = oracle.parse_dump(open(path).read(), indexed=True)
+    ngrams = {k: r for k, r in m.refs.items() if b"\x03" not in tokens_of(k)}
+    skip = {k: r for k, r in m.refs.items() if b"\x03" in tokens_of(k)}
+    exp, nsrc = {}, {}
+    for k, refs in ngrams.items():
+        toks = tokens_of(k)
+        n = len(toks)
+        if n < 3 or n > maxlength:
+            continue
+        for mask in oracle.skip_configurations(n, 3):
+            sk = b"".join(b"\x03" if (mask >> i) & 1 else t for i, t in enumerate(toks))
+            exp.setdefault(sk, []).extend(refs)
+            nsrc[sk] = nsrc.get(sk, 0) + 1
+    exp = {k: sorted(v) for k, v in exp.items() if nsrc[k] >= minskiptypes}
+    return exp == skip
+
+
+def main():
+    unstable = []
+    for name, data in corpora().items():
+        with open(os.path.join(HERE, f"{name}.colibri.dat"), "wb") as f:
+            f.write(data)
+    jobs = []
+    for name in ["hamlet.v1", "edge", "zipf20k", "phrases15k"]:
+        path = os.path.join(HERE, f"{name}.colibri.dat")
+        modes = [("u", 3, []), ("u", 5, []), ("u", 100, [])] if name == "hamlet.v1" else [("u", 5, [])]
+        if name != "hamlet.v1":  # v1 input cannot be preloaded into an IndexedCorpus (reference pattern.cpp:1936-1940)
+            modes += [("us", 5, []), ("us", 5, ["-y", "3"]), ("i", 5, []), ("is", 5, []), ("is", 5, ["-T", "1"])]
+        for mode, l, extra in modes:
+            tag = mode + "".join(extra).replace("-", "")
+            out = os.path.join(HERE, f"{name}.{tag}.l{l}.txt")
+            jobs.append(out)
+            subprocess.check_call([DRIVER, "train", path, mode, str(l), "2", "-q", "-d", out] + extra, stdout=subprocess.DEVNULL)
+            if mode == "is" and not reference_is_dump_is_stable(out, 1 if extra else 2, l):
+                unstable.append(os.path.basename(out))
+                os.remove(out)
+    # hamlet as v2 (converted by the oracle's v1->v2, which is itself checked against the reference reading v1 directly)
+    v1 = open(os.path.join(HERE, "hamlet.v1.colibri.dat"), "rb").read()
+    with open(os.path.join(HERE, "hamlet.v2.colibri.dat"), "wb") as f:
+        f.write(synth.HEADER + oracle.v1_to_v2(v1))
+    for mode, l, extra in [("u", 5, []), ("us", 5, []), ("i", 5, []), ("is", 5, []), ("is", 5, ["-T", "1"]), ("us", 100, []), ("is", 100, [])]:
+        tag = mode + "".join(extra).replace("-", "")
+        out = os.path.join(HERE, f"hamlet.v2.{tag}.l{l}.txt")
+        subprocess.check_call([DRIVER, "train", os.path.join(HERE, "hamlet.v2.colibri.dat"), mode, str(l), "2", "-q", "-d", out] + extra, stdout=subprocess.DEVNULL)
+        if mode == "is" and not reference_is_dump_is_stable(out, 1 if extra else 2, l):
+            unstable.append(os.path.basename(out))
+            os.remove(out)
+    with open(os.path.join(HERE, "unstable_reference_outputs.json"), "w") as f:
+        json.dump({"note": "indexed+skipgram dumps of the reference that were NOT kept because the reference's insert-while-iterating "
+                           "hazard (patternmodel.h:2986-2991) corrupted them (self-consistency check in make_golden.py)", "dropped": unstable}, f, indent=1)
+    # SpookyHash known answers from the reference's own implementation
+    rng = np.random.default_rng(5)
+    keys = [bytes([6]), bytes([6, 7, 8]), bytes.fromhex("8601904e07")] + [bytes(rng.integers(0, 256, size=n, dtype=np.uint8)) for n in range(1, 192, 3)]
+    out = subprocess.run([DRIVER, "hash"] + [k.hex() for k in keys], check=True, capture_output=True, text=True).stdout
+    kat = {ln.split("\t")[0]: ln.split("\t")[1] for ln in out.strip().splitlines()}
+    with open(os.path.join(HERE, "spooky_kat.json"), "w") as f:
+        json.dump(kat, f, indent=0)
+    masks = {}
+    for n in range(3, 10):
+        for ms in (1, 2, 3):
+            o = subprocess.run([DRIVER, "masks", str(n), str(ms)], check=True, capture_output=True, text=True).stdout.split()
+            masks[f"{n},{ms}"] = [int(x) for x in o]
+    with open(os.path.join(HERE, "masks.json"), "w") as f:
+        json.dump(masks, f)
+    print("golden fixtures written:", len(os.listdir(HERE)), "files")
+
+
+if __name__ == "__main__":
+    main()

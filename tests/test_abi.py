@@ -1,0 +1,73 @@
+"""CPU tests of the drop-in boundary: libcolibri_hip.so loads without a GPU, exports every symbol that
+include/colibri_hip.h declares, the ctypes mirrors match the C layouts, and the product fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT, has_gpu
+
+from colibri_amd import capi
+
+HEADER = os.path.join(ROOT, "include", "colibri_hip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(colibri_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.load()
+    names = declared_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/colibri_hip.h but not exported"
+    assert sorted(capi.EXPORTED) == names
+    assert L.colibri_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "colibri_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(colibri_options), sizeof(colibri_stats),'
+                   ' offsetof(colibri_stats, windows), offsetof(colibri_stats, kept), offsetof(colibri_stats, train_ms));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    so, ss, ow, ok, ot = (int(x) for x in subprocess.check_output([str(exe)]).split())
+    assert C.sizeof(capi.Options) == so
+    assert C.sizeof(capi.Stats) == ss
+    assert capi.Stats.windows.offset == ow and capi.Stats.kept.offset == ok and capi.Stats.train_ms.offset == ot
+
+
+def test_header_is_plain_c():
+    """The boundary is a C ABI: the header must compile as C11 with warnings as errors."""
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", HEADER])
+
+
+def test_options_defaults_mirror_patternmodeloptions():
+    o = capi.Options.defaults()
+    # reference include/patternmodel.h:153-180
+    assert (o.mintokens, o.mintokens_skipgrams, o.mintokens_unigrams, o.minlength, o.maxlength, o.maxbackofflength) == (-1, -1, 1, 1, 100, 100)
+    assert (o.minskiptypes, o.maxskips, o.doskipgrams, o.doskipgrams_exhaustive) == (2, 3, 0, 0)
+
+
+@pytest.mark.skipif(has_gpu(), reason="only meaningful on the GPU-less build container")
+def test_no_device_fails_loudly_not_silently():
+    with pytest.raises(capi.ColibriError) as e:
+        capi.Context(0)
+    assert e.value.code == -3  # COLIBRI_ERR_NODEVICE: there is no CPU fallback behind the ABI
+
+
+def test_product_does_not_touch_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/ (task contract ③)."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "colibri-core_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".c", "Makefile")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"\boracle\b", text) and "colibri_oracle" in text or re.search(r"import oracle|liboracle|ref_driver", text):
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad

@@ -11,21 +11,26 @@
 // bytes in HBM/L2 (adjacent lanes hash adjacent, overlapping windows, so a wave touches a few hundred
 // contiguous bytes); the corpus buffer is padded so that the 16-byte tail fetch never leaves the allocation.
 #pragma once
-#include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+#define COLIBRI_HD __host__ __device__ __forceinline__
+#else  // the C++ face (g++) uses the very same routine for Pattern::hash on the host
+#define COLIBRI_HD inline
+#endif
 
 namespace colibri {
 
-__device__ __forceinline__ uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+COLIBRI_HD uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
 
 // unaligned little-endian 8-byte fetch (gfx950 global loads accept unaligned addresses)
-__device__ __forceinline__ uint64_t ld64u(const uint8_t* p) {
+COLIBRI_HD uint64_t ld64u(const uint8_t* p) {
     uint64_t v;
     __builtin_memcpy(&v, p, 8);
     return v;
 }
 // keep the low `nbytes` (0..8) bytes of v
-__device__ __forceinline__ uint64_t keep_bytes(uint64_t v, uint32_t nbytes) {
+COLIBRI_HD uint64_t keep_bytes(uint64_t v, uint32_t nbytes) {
     return nbytes >= 8 ? v : (v & ((1ull << (8 * nbytes)) - 1ull));
 }
 
@@ -34,7 +39,7 @@ struct Spooky4 {
 };
 
 // the 12-step mix applied after every 16-byte group that is followed by more data
-__device__ __forceinline__ void spooky_mix(Spooky4& s) {
+COLIBRI_HD void spooky_mix(Spooky4& s) {
 #define COLIBRI_MIX(r, ad, x, k) \
     s.r = rotl64(s.r, k);        \
     s.r += s.ad;                 \
@@ -46,7 +51,7 @@ __device__ __forceinline__ void spooky_mix(Spooky4& s) {
 }
 
 // the 11-step finaliser
-__device__ __forceinline__ void spooky_end(Spooky4& s) {
+COLIBRI_HD void spooky_end(Spooky4& s) {
 #define COLIBRI_END(t, u, k) \
     s.t ^= s.u;              \
     s.u = rotl64(s.u, k);    \
@@ -60,7 +65,7 @@ __device__ __forceinline__ void spooky_end(Spooky4& s) {
 constexpr uint64_t kSpookyConst = 0xdeadbeefdeadbeefULL;
 
 // Hash64 of p[0..len), len < 192. Reads at most 15 bytes beyond p+len (never used in the result).
-__device__ __forceinline__ uint64_t spooky64_short(const uint8_t* p, uint32_t len) {
+COLIBRI_HD uint64_t spooky64_short(const uint8_t* p, uint32_t len) {
     Spooky4  s{0ull, 0ull, kSpookyConst, kSpookyConst};
     uint32_t left = len;
     if (len > 15) {

@@ -1,0 +1,417 @@
+// colibri_host.cpp — non-template parts of the C++ face: key-type helpers, corpus / model file formats, and the glue
+// that drives libcolibri_hip.so through its C ABI (include/colibri_hip.h). No counting happens here.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <iterator>
+#include <map>
+#include <sstream>
+
+#include "patternmodel.h"
+#include "spooky_device.hpp"  // the same SpookyHash routine the kernels use, compiled for the host
+
+// ---------------------------------------------------------------------------------------------------
+// key helpers
+// ---------------------------------------------------------------------------------------------------
+namespace colibri_host {
+
+uint64_t spooky_hash64(const unsigned char* data, size_t len) {
+    if (len >= 192) {
+        std::cerr << "ERROR: pattern of " << len << " bytes: SpookyHash's long form is not part of this build" << std::endl;
+        throw InternalError();
+    }
+    unsigned char buf[192 + 16] = {0};  // the device routine may read 15 bytes past the key
+    std::memcpy(buf, data, len);
+    return colibri::spooky64_short(buf, (uint32_t)len);
+}
+
+size_t token_count(const unsigned char* data, size_t bytes) {
+    size_t n = 0;
+    for (size_t i = 0; i < bytes; ++i) n += data[i] < 128;
+    return n;
+}
+
+size_t key_bytesize(const unsigned char* data) {
+    size_t i        = 0;
+    bool   prevhigh = false;
+    while (prevhigh || data[i] != 0) {
+        prevhigh = data[i] >= 128;
+        ++i;
+    }
+    return i;
+}
+
+PatternCategory category_of(const unsigned char* data, size_t bytes) {
+    bool prevhigh = false;
+    for (size_t i = 0; i < bytes; ++i) {
+        if (!prevhigh && data[i] == colibri_classes::flexclass) return FLEXGRAM;
+        if (!prevhigh && data[i] == colibri_classes::skipclass) return SKIPGRAM;
+        prevhigh = data[i] >= 128;
+    }
+    return NGRAM;
+}
+
+std::string decode_key(const unsigned char* data, size_t bytes, const ClassDecoder& decoder) {
+    std::string out;
+    size_t      i = 0;
+    while (i < bytes) {
+        unsigned int len = 0;
+        const unsigned int cls = bytestoint(data + i, &len);
+        if (!out.empty()) out += ' ';
+        if (decoder.hasclass(cls)) {
+            out += decoder[cls];
+        } else {
+            out += "{?}";
+        }
+        i += len;
+    }
+    return out;
+}
+
+}  // namespace colibri_host
+
+Pattern::Pattern(const PatternPointer& pp) {
+    if (pp.data == NULL || pp.bytes == 0) {
+        data = NULL;
+        return;
+    }
+    if (pp.mask == 0) {
+        assign(pp.data, pp.bytes);
+        return;
+    }
+    // skipgram / flexgram: every gapped token becomes one marker byte; adjacent flex gaps collapse (reference src/pattern.cpp:886-908, :1043-1065)
+    const bool                 flex = pp.isflexgram();
+    std::vector<unsigned char> buf;
+    buf.reserve(pp.bytes);
+    int  tok     = 0;
+    bool prevgap = false;
+    size_t start = 0;
+    for (size_t i = 0; i < pp.bytes; ++i) {
+        if (pp.data[i] < 128) {
+            if (pp.isgap(tok)) {
+                if (!(flex && prevgap)) buf.push_back(flex ? colibri_classes::flexclass : colibri_classes::skipclass);
+                prevgap = true;
+            } else {
+                buf.insert(buf.end(), pp.data + start, pp.data + i + 1);
+                prevgap = false;
+            }
+            ++tok;
+            start = i + 1;
+        }
+    }
+    assign(buf.data(), buf.size());
+}
+
+Pattern::Pattern(std::istream& in, bool ignoreeol, const unsigned char version) {
+    (void)ignoreeol;
+    data            = NULL;
+    const Pattern p = colibri_host::read_model_pattern(in, version);
+    assign(p.data, p.data ? p.bytesize() : 0);
+}
+
+void Pattern::write(std::ostream& out, const unsigned char*) const {
+    const size_t s = bytesize();
+    if (s > 0) {
+        out.write((const char*)data, (std::streamsize)s + 1);
+    } else {
+        const char null = 0;
+        out.write(&null, 1);
+    }
+}
+
+std::string Pattern::tostring(const ClassDecoder& decoder) const { return data ? colibri_host::decode_key(data, bytesize(), decoder) : std::string(); }
+
+std::string Pattern::tohex() const {
+    static const char* d = "0123456789abcdef";
+    std::string        s;
+    const size_t       b = bytesize();
+    for (size_t i = 0; i < b; ++i) {
+        s.push_back(d[data[i] >> 4]);
+        s.push_back(d[data[i] & 15]);
+    }
+    return s;
+}
+
+int PatternPointer::ngrams(std::vector<std::pair<PatternPointer, int>>& container, const int n) const {
+    std::vector<size_t> starts{0};
+    for (size_t i = 0; i < bytes; ++i)
+        if (data[i] < 128) starts.push_back(i + 1);
+    const int ntok = (int)starts.size() - 1;
+    if (n > ntok) return 0;
+    for (int i = 0; i + n <= ntok; ++i) container.push_back(std::make_pair(PatternPointer(data + starts[i], starts[i + n] - starts[i]), i));
+    return ntok - n + 1;
+}
+int PatternPointer::ngrams(std::vector<PatternPointer>& container, const int n) const {
+    std::vector<std::pair<PatternPointer, int>> tmp;
+    const int                                   r = ngrams(tmp, n);
+    for (const auto& p : tmp) container.push_back(p.first);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// class decoding
+// ---------------------------------------------------------------------------------------------------
+unsigned int bytestoint(const unsigned char* a, unsigned int* length) {
+    unsigned int result = 0, i = 0;
+    for (;; ++i) {
+        const unsigned char b = a[i];
+        if (i < 5) result |= (unsigned int)(b & 127) << (7 * i);
+        if (b < 128) break;
+    }
+    if (length) *length = i + 1;
+    return result;
+}
+
+unsigned char getdataversion(std::istream& in) {
+    if (!in.good()) {
+        std::cerr << "ERROR: Supplied data file can not be opened. Check whether it exists and whether you have proper permissions..." << std::endl;
+        throw InternalError();
+    }
+    in.clear();
+    in.seekg(0);
+    unsigned char b = 0, version = 1;
+    in.read((char*)&b, 1);
+    if (b == 0xa2) {
+        in.read((char*)&version, 1);
+    } else {
+        if (b > 5 && in.gcount() == 1) {
+            std::cerr << "ERROR: Supplied data file is not a valid Colibri Data file, did you pass plain-text instead perhaps?..." << std::endl;
+            throw InternalError();
+        }
+        in.clear();
+        in.seekg(0);
+    }
+    return version;
+}
+
+ClassDecoder::ClassDecoder() : highestclass(0) {
+    classes[unknownclass] = "{?}";
+    classes[skipclass]    = "{*}";
+    classes[flexclass]    = "{**}";
+    classes[boundaryclass] = "{|}";
+}
+ClassDecoder::ClassDecoder(const std::string& filename) : ClassDecoder() { load(filename); }
+void ClassDecoder::load(const std::string& filename) {
+    std::ifstream in(filename);
+    if (!in.good()) {
+        std::cerr << "ERROR: Unable to load class file " << filename << std::endl;
+        throw InternalError();
+    }
+    std::string line;
+    while (std::getline(in, line)) {
+        const size_t tab = line.find('\t');
+        if (tab == std::string::npos) continue;
+        const unsigned int cls = (unsigned int)std::strtoul(line.substr(0, tab).c_str(), NULL, 10);
+        classes[cls]           = line.substr(tab + 1);
+        if (cls > highestclass) highestclass = cls;
+    }
+}
+const std::string& ClassDecoder::operator[](unsigned int cls) const {
+    static const std::string unknown = "{?}";
+    auto                     it      = classes.find(cls);
+    return it == classes.end() ? unknown : it->second;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// corpus files
+// ---------------------------------------------------------------------------------------------------
+namespace colibri_host {
+
+// v1: token = length byte (1..127) + little-endian base-256 digits; 00 ends a sentence; 128/129 = skip/flex markers
+static std::vector<unsigned char> v1_to_v2(const std::vector<unsigned char>& in) {
+    std::vector<unsigned char> out;
+    out.reserve(in.size());
+    size_t i = 0;
+    while (i < in.size()) {
+        const unsigned char c = in[i];
+        if (c == 0) {
+            out.push_back(0);
+            ++i;
+        } else if (c < 128) {
+            if (i + 1 + c > in.size()) {
+                std::cerr << "ERROR: Invalid pattern data, unexpected end of file" << std::endl;
+                throw InternalError();
+            }
+            uint32_t cls = 0;
+            for (unsigned k = 0; k < c && k < 4; ++k) cls |= (uint32_t)in[i + 1 + k] << (8 * k);
+            do {
+                unsigned char b = cls & 127;
+                cls >>= 7;
+                if (cls) b |= 128;
+                out.push_back(b);
+            } while (cls);
+            i += (size_t)c + 1;
+        } else {
+            if (c == 128) out.push_back(colibri_classes::skipclass);
+            if (c == 129) out.push_back(colibri_classes::flexclass);
+            ++i;
+        }
+    }
+    return out;
+}
+
+std::vector<unsigned char> read_corpus_payload(std::istream& in) {
+    const unsigned char version = getdataversion(in);  // leaves the stream after the 2-byte header for v2, at 0 for v1
+    std::vector<unsigned char> raw((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    if (version >= 2) return raw;
+    return v1_to_v2(raw);
+}
+
+Pattern read_model_pattern(std::istream& in, unsigned char classencodingversion) {
+    std::vector<unsigned char> buf;
+    unsigned char              c = 0;
+    if (classencodingversion == 1) {
+        while (in.read((char*)&c, 1)) {
+            buf.push_back(c);
+            if (c == 0) break;
+            if (c < 128) {
+                for (unsigned k = 0; k < c; ++k) {
+                    unsigned char d = 0;
+                    in.read((char*)&d, 1);
+                    buf.push_back(d);
+                }
+            }
+        }
+        std::vector<unsigned char> v2 = v1_to_v2(buf);
+        if (!v2.empty() && v2.back() == 0) v2.pop_back();
+        return Pattern(v2.data(), v2.size());
+    }
+    bool prevhigh = false;
+    while (in.read((char*)&c, 1)) {
+        if (!prevhigh && c == 0) break;
+        buf.push_back(c);
+        prevhigh = c >= 128;
+    }
+    return Pattern(buf.data(), buf.size());
+}
+
+// ---------------------------------------------------------------------------------------------------
+// driving the device library
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct CtxGuard {
+    colibri_ctx* c = nullptr;
+    ~CtxGuard() { colibri_destroy(c); }
+};
+[[noreturn]] void raise(colibri_ctx* c, int rc, const char* what) {
+    std::cerr << "ERROR: " << what << " failed (status " << rc << "): " << (c ? colibri_last_error(c) : "no MI355X / HIP device available; there is no CPU fallback") << std::endl;
+    throw InternalError();
+}
+}  // namespace
+
+void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out) {
+    CtxGuard    g;
+    const char* dev = std::getenv("COLIBRI_DEVICE");
+    int         rc  = colibri_create(&g.c, dev ? std::atoi(dev) : 0);
+    if (rc != COLIBRI_OK) raise(nullptr, rc, "colibri_create");
+    if ((rc = colibri_upload_corpus(g.c, payload, nbytes, firstsentence)) != COLIBRI_OK) raise(g.c, rc, "colibri_upload_corpus");
+    if ((rc = colibri_train(g.c, &opt, &out.stats)) != COLIBRI_OK) raise(g.c, rc, "colibri_train");
+    uint64_t np = 0, kb = 0, nr = 0;
+    if ((rc = colibri_result_sizes(g.c, &np, &kb, &nr)) != COLIBRI_OK) raise(g.c, rc, "colibri_result_sizes");
+    out.key_off.assign(np + 1, 0);
+    out.key_bytes.assign(kb + 1, 0);
+    out.counts.assign(np, 0);
+    if (opt.indexed) {
+        out.ref_off.assign(np + 1, 0);
+        out.ref_sentence.assign(nr + 1, 0);
+        out.ref_token.assign(nr + 1, 0);
+        rc = colibri_export_indexed(g.c, out.key_off.data(), out.key_bytes.data(), out.counts.data(), out.ref_off.data(), out.ref_sentence.data(), out.ref_token.data());
+        if (rc != COLIBRI_OK) raise(g.c, rc, "colibri_export_indexed");
+    } else {
+        uint32_t dummy = 0;
+        rc = colibri_export_unindexed(g.c, out.key_off.data(), out.key_bytes.data(), np ? out.counts.data() : &dummy);
+        if (rc != COLIBRI_OK) raise(g.c, rc, "colibri_export_unindexed");
+    }
+}
+
+void print_training_log(const colibri_stats& s, const colibri_options& o, std::ostream& err) {
+    for (int n = 1; n <= o.maxlength && n < COLIBRI_MAX_ORDER; ++n) {
+        err << "Counting " << n << "-grams" << std::endl;
+        if (s.found[n] == 0) {
+            err << "None found" << std::endl;
+            break;
+        }
+        err << " Found " << s.found[n] << " ngrams...";
+        err << "pruned " << s.pruned[n] << "...total kept: " << s.kept[n] << std::endl;
+    }
+}
+
+}  // namespace colibri_host
+
+int getmodeltype(const std::string& filename) {
+    std::ifstream in(filename, std::ios::in | std::ios::binary);
+    unsigned char null = 1, type = 0;
+    in.read((char*)&null, 1);
+    in.read((char*)&type, 1);
+    return (in.good() && null == 0) ? (int)type : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// IndexedCorpus
+// ---------------------------------------------------------------------------------------------------
+void IndexedCorpus::load(std::istream& in, bool) {
+    std::vector<unsigned char> payload = colibri_host::read_corpus_payload(in);
+    delete[] corpus;
+    corpussize = payload.size();
+    corpus     = new unsigned char[corpussize + 16];
+    std::memset(corpus, 0, corpussize + 16);
+    if (corpussize) std::memcpy(corpus, payload.data(), corpussize);
+    sentencestart.clear();
+    delimiters         = 0;
+    bool prevdelimiter = true, prevhigh = false;
+    for (size_t i = 0; i < corpussize; ++i) {  // every delimiter opens a new sentence, empty ones included (reference src/pattern.cpp:1947-1958)
+        if (prevdelimiter) {
+            sentencestart.push_back(i);
+            prevdelimiter = false;
+        }
+        if (!prevhigh && corpus[i] == 0) {
+            prevdelimiter = true;
+            ++delimiters;
+        }
+        prevhigh = corpus[i] >= 128;
+    }
+}
+void IndexedCorpus::load(const std::string& filename, bool debug) {
+    std::ifstream in(filename, std::ios::in | std::ios::binary);
+    if (!in.good()) {
+        std::cerr << "ERROR: Unable to load file " << filename << std::endl;
+        throw InternalError();
+    }
+    load(in, debug);
+}
+PatternPointer IndexedCorpus::getsentence(int sentence) const {
+    if (sentence < 1 || (size_t)sentence > sentencestart.size()) throw KeyError();
+    const size_t b = sentencestart[sentence - 1];
+    size_t       e = b;
+    bool         prevhigh = false;
+    while (e < corpussize && (prevhigh || corpus[e] != 0)) {
+        prevhigh = corpus[e] >= 128;
+        ++e;
+    }
+    return PatternPointer(corpus + b, e - b);
+}
+PatternPointer IndexedCorpus::getpattern(const IndexReference& begin, int length) const {
+    const PatternPointer s = getsentence((int)begin.sentence);
+    size_t               tok = 0, i = 0, startb = 0;
+    bool                 found = begin.token == 0;
+    for (; i < s.bytes && !found; ++i) {
+        if (s.data[i] < 128) {
+            ++tok;
+            if (tok == begin.token) {
+                startb = i + 1;
+                found  = true;
+            }
+        }
+    }
+    if (!found) throw KeyError();
+    size_t e = startb;
+    int    got = 0;
+    while (e < s.bytes && got < length) {
+        if (s.data[e] < 128) ++got;
+        ++e;
+    }
+    if (got < length) throw KeyError();
+    return PatternPointer(s.data + startb, e - startb);
+}

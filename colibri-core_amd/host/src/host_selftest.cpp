@@ -1,0 +1,97 @@
+// host_selftest — exercises the C++ face the way the reference's callers use it (src/test.cpp:1211-1232, src/benchmarks.cpp:228-237):
+//   host_selftest cpu  <hamlet.v2.colibri.dat> <hamlet.v1.colibri.patternmodel>   host-only checks (formats, key types; no GPU)
+//   host_selftest gpu  <corpus.colibri.dat> <out.model> <u|i> <maxlength> <mintokens>   train on the GPU, write the model, print a summary
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "patternmodel.h"
+
+static int fails = 0;
+#define CHECK(cond)                                                               \
+    do {                                                                          \
+        if (!(cond)) {                                                            \
+            std::cerr << "FAILED: " #cond " (" << __FILE__ << ":" << __LINE__ << ")" << std::endl; \
+            ++fails;                                                              \
+        }                                                                         \
+    } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    const std::string mode = argv[1];
+    if (mode == "cpu") {
+        // SpookyHash known answers of the reference
+        const unsigned char k1[] = {6}, k3[] = {6, 7, 8}, k5[] = {0x86, 0x01, 0x90, 0x4e, 0x07};
+        CHECK(Pattern(k1, 1).hash() == 0x5d3553ac0aa134faULL);
+        CHECK(Pattern(k3, 3).hash() == 0x6ee4e90e1c0b57c9ULL);
+        CHECK(Pattern(k5, 5).hash() == 0x626a44955a1c64f0ULL);
+        CHECK(Pattern().hash() == 0);
+        CHECK(Pattern(k5, 5).n() == 3 && Pattern(k5, 5).bytesize() == 5);
+        CHECK(Pattern(k3, 3) == Pattern(k3, 3) && Pattern(k3, 3) != Pattern(k1, 1));
+        // skipgram materialisation: gapped tokens -> 03, multi-byte token dropped whole
+        unsigned char  w[] = {0x86, 0x01, 0x90, 0x4e, 0x07};
+        PatternPointer pp(w, 5, 0b010);
+        const unsigned char want[] = {0x86, 0x01, 0x03, 0x07};
+        CHECK(Pattern(pp) == Pattern(want, 4));
+        CHECK(Pattern(pp).category() == SKIPGRAM && Pattern(k3, 3).category() == NGRAM);
+        std::vector<std::pair<PatternPointer, int>> grams;
+        CHECK(PatternPointer(w, 5).ngrams(grams, 2) == 2 && grams[1].second == 1 && grams[1].first.bytes == 3);
+        if (argc >= 3) {
+            IndexedCorpus corpus{std::string(argv[2])};
+            CHECK(corpus.sentences() == 40);  // reference src/test.cpp:1549
+            CHECK(corpus.size() == 354);
+            CHECK(corpus.getsentence(1).n() > 0);
+            CHECK(corpus.getpattern(IndexReference(1, 0), 1).n() == 1);
+        }
+        if (argc >= 4) {  // the reference's own golden model (model version 1, v1 class encoding)
+            PatternModelOptions options;
+            options.QUIET = true;
+            PatternModel<uint32_t> model(std::string(argv[3]), options);
+            CHECK(model.size() == 111 && model.tokens() == 354 && model.types() == 186);
+            CHECK(model.maxlength() == 7 && model.minlength() == 1);
+            CHECK(model.occurrencecount(Pattern(k1, 1)) == 27);
+            std::stringstream ss;
+            model.write(ss);  // rewritten as version 2
+            PatternModel<uint32_t> again(&ss, options);
+            CHECK(again.size() == 111 && again.tokens() == 354 && again.types() == 186);
+            CHECK(again.occurrencecount(Pattern(k1, 1)) == 27);
+        }
+        std::cout << (fails ? "FAILED" : "OK") << std::endl;
+        return fails ? 1 : 0;
+    }
+    if (mode == "gpu" && argc >= 7) {
+        PatternModelOptions options;
+        options.MAXLENGTH = std::atoi(argv[5]);
+        options.MINTOKENS = std::atoi(argv[6]);
+        options.QUIET     = false;
+        const std::string kind = argv[4];
+        try {
+            if (kind == "u") {
+                PatternModel<uint32_t> model;
+                model.train(std::string(argv[2]), options);
+                model.write(std::string(argv[3]));
+                std::cout << model.size() << " " << model.tokens() << " " << model.types() << " " << model.maxlength() << std::endl;
+            } else if (kind == "U") {  // preloaded corpus, as src/benchmarks.cpp test 5
+                IndexedCorpus          corpus{std::string(argv[2])};
+                PatternModel<uint32_t> model(&corpus);
+                model.train(std::string(argv[2]), options);
+                model.write(std::string(argv[3]));
+                const unsigned char k1[] = {6};
+                std::cout << model.size() << " " << model.tokens() << " " << model.types() << " " << model.maxlength() << " " << model.occurrencecount(Pattern(k1, 1)) << std::endl;
+            } else {
+                IndexedCorpus         corpus{std::string(argv[2])};
+                IndexedPatternModel<> model(&corpus);
+                if (kind == "is") options.DOSKIPGRAMS = true;
+                model.train(std::string(argv[2]), options);
+                model.write(std::string(argv[3]));
+                std::cout << model.size() << " " << model.tokens() << " " << model.types() << " " << model.maxlength() << std::endl;
+            }
+        } catch (const std::exception& e) {
+            std::cout << "EXCEPTION " << e.what() << std::endl;
+            return 1;
+        }
+        return 0;
+    }
+    return 2;
+}

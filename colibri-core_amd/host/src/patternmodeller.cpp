@@ -1,0 +1,135 @@
+// colibri-patternmodeller (MI355X build) — a drop-in for the reference's command-line driver on the accelerated path.
+// Same flags and flag meanings as reference src/patternmodeller.cpp:404-858 for: -f -c -o -i -u -t -l -m -b -W -s -y -T -P -R -r -H -e -D -h
+// (build a model from a .colibri.dat, save it, load a model, print / report / histogram). Flags that select paths outside the
+// accelerated subset (-j -I -2 -E -F -L -M -p -Q -q -g ...) are reported and rejected instead of being silently ignored.
+// All counting happens in libcolibri_hip.so; this file only parses options and calls the C++ face.
+#include <getopt.h>
+
+#include <cstdlib>
+#include <iostream>
+#include <string>
+
+#include "patternmodel.h"
+
+namespace {
+
+void usage() {
+    std::cerr << "colibri-patternmodeller (MI355X-native build of the Colibri Core pattern-model builder)\n"
+                 "Syntax: colibri-patternmodeller [options]\n"
+                 " Input/output:\n"
+                 "\t-f|--datafile <file>        class-encoded corpus (.colibri.dat, v2 or v1)\n"
+                 "\t-c|--classfile <file>       class file (.colibri.cls), needed to print patterns as text\n"
+                 "\t-i|--inputmodel <file>      load a model (.colibri.patternmodel)\n"
+                 "\t-o|--outputmodel <file>     write the model\n"
+                 " Building (runs on the GPU):\n"
+                 "\t-t|--threshold <n>          occurrence threshold (default 2)\n"
+                 "\t-u|--unindexed              unindexed model (default is indexed)\n"
+                 "\t-l|--maxlength <n>          maximum pattern length (default 100)\n"
+                 "\t-m|--minlength <n>          minimum pattern length (default 1)\n"
+                 "\t-b|--backofflength <n>      maximum back-off length (default 100)\n"
+                 "\t-W|--wordthreshold <n>      secondary word occurrence threshold\n"
+                 "\t-s|--skipgrams              compute skipgrams\n"
+                 "\t-y|--skipthreshold <n>      occurrence threshold for skipgrams\n"
+                 "\t-T|--skiptypes <n>          skip type threshold (default 2)\n"
+                 "\t-e|--expand <n>             sentence offset given to the first sentence\n"
+                 " Viewing:\n"
+                 "\t-P|--print   -R|--report   -r|--simplereport   -H|--histogram\n"
+                 "\t-D|--debug   -h|--help\n";
+}
+
+template <class ModelType>
+int run(ModelType& model, const std::string& corpusfile, const std::string& inputmodel, const std::string& outputmodel, const PatternModelOptions& options, uint32_t firstsentence,
+        bool doprint, bool doreport, bool dohistogram, const ClassDecoder* decoder) {
+    if (!inputmodel.empty()) {
+        model.load(inputmodel, options);
+    } else {
+        model.train(corpusfile, options, NULL, NULL, false, firstsentence);
+    }
+    if (!outputmodel.empty()) {
+        std::cerr << "Writing model to " << outputmodel << std::endl;
+        model.write(outputmodel);
+    }
+    if (doprint) model.print(&std::cout, decoder);
+    if (doreport) model.report(&std::cout);
+    if (dohistogram) model.histogram(&std::cout);
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    std::string         corpusfile, classfile, inputmodel, outputmodel;
+    PatternModelOptions options;
+    bool                unindexed = false, doprint = false, doreport = false, dohistogram = false;
+    uint32_t            firstsentence = 1;
+    static struct option longopts[] = {{"datafile", required_argument, 0, 'f'},    {"classfile", required_argument, 0, 'c'},      {"inputmodel", required_argument, 0, 'i'},
+                                       {"outputmodel", required_argument, 0, 'o'}, {"threshold", required_argument, 0, 't'},      {"unindexed", no_argument, 0, 'u'},
+                                       {"maxlength", required_argument, 0, 'l'},   {"minlength", required_argument, 0, 'm'},      {"backofflength", required_argument, 0, 'b'},
+                                       {"wordthreshold", required_argument, 0, 'W'}, {"skipgrams", no_argument, 0, 's'},          {"skipthreshold", required_argument, 0, 'y'},
+                                       {"skiptypes", required_argument, 0, 'T'},   {"expand", required_argument, 0, 'e'},         {"print", no_argument, 0, 'P'},
+                                       {"report", no_argument, 0, 'R'},            {"simplereport", no_argument, 0, 'r'},         {"histogram", no_argument, 0, 'H'},
+                                       {"debug", no_argument, 0, 'D'},             {"help", no_argument, 0, 'h'},                 {0, 0, 0, 0}};
+    int c;
+    while ((c = getopt_long(argc, argv, "f:c:i:o:t:ul:m:b:W:sy:T:e:PRrHDhj:I2EF:LMp:Qq:gZV", longopts, NULL)) != -1) {
+        switch (c) {
+            case 'f': corpusfile = optarg; break;
+            case 'c': classfile = optarg; break;
+            case 'i': inputmodel = optarg; break;
+            case 'o': outputmodel = optarg; break;
+            case 't': options.MINTOKENS = std::atoi(optarg); break;
+            case 'u': unindexed = true; break;
+            case 'l': options.MAXLENGTH = std::atoi(optarg); break;
+            case 'm': options.MINLENGTH = std::atoi(optarg); break;
+            case 'b': options.MAXBACKOFFLENGTH = std::atoi(optarg); break;
+            case 'W': options.MINTOKENS_UNIGRAMS = std::atoi(optarg); break;
+            case 's': options.DOSKIPGRAMS = true; break;
+            case 'y': options.MINTOKENS_SKIPGRAMS = std::atoi(optarg); break;
+            case 'T': options.MINSKIPTYPES = std::atoi(optarg); break;
+            case 'e': firstsentence = (uint32_t)std::atoi(optarg); break;
+            case 'P': doprint = true; break;
+            case 'R':
+            case 'r': doreport = true; break;
+            case 'H': dohistogram = true; break;
+            case 'D': options.DEBUG = true; break;
+            case 'h': usage(); return 0;
+            default:
+                std::cerr << "ERROR: option -" << (char)(c == '?' ? optopt : c) << " selects a path that is not part of the MI355X-accelerated build (see DESIGN.md, out of scope)" << std::endl;
+                return 2;
+        }
+    }
+    if (corpusfile.empty() && inputmodel.empty()) {
+        usage();
+        return 2;
+    }
+    try {
+        ClassDecoder* decoder = NULL;
+        ClassDecoder  loaded;
+        if (!classfile.empty()) {
+            loaded.load(classfile);
+            decoder = &loaded;
+        }
+        if (unindexed) {
+            if (options.DOSKIPGRAMS) {  // unindexed models can only do this exhaustively, on a loaded corpus (reference src/patternmodeller.cpp:723-737)
+                options.DOSKIPGRAMS            = false;
+                options.DOSKIPGRAMS_EXHAUSTIVE = true;
+            }
+            if (inputmodel.empty() && options.DOSKIPGRAMS_EXHAUSTIVE) {
+                IndexedCorpus          corpus(corpusfile);
+                PatternModel<uint32_t> model(&corpus);
+                return run(model, corpusfile, inputmodel, outputmodel, options, firstsentence, doprint, doreport, dohistogram, decoder);
+            }
+            PatternModel<uint32_t> model;
+            return run(model, corpusfile, inputmodel, outputmodel, options, firstsentence, doprint, doreport, dohistogram, decoder);
+        }
+        if (inputmodel.empty()) {
+            IndexedCorpus         corpus(corpusfile);  // indexed models are built on a loaded corpus (reference :735-737)
+            IndexedPatternModel<> model(&corpus);
+            return run(model, corpusfile, inputmodel, outputmodel, options, firstsentence, doprint, doreport, dohistogram, decoder);
+        }
+        IndexedPatternModel<> model;
+        return run(model, corpusfile, inputmodel, outputmodel, options, firstsentence, doprint, doreport, dohistogram, decoder);
+    } catch (const std::exception& e) {
+        std::cerr << "colibri-patternmodeller: " << e.what() << std::endl;
+        return 1;
+    }
+}

@@ -91,6 +91,7 @@ int usage() {
                  "      U  = unindexed, corpus preloaded in an IndexedCorpus (benchmarks.cpp test 5)\n"
                  "      us = unindexed + exhaustive skipgrams (preloaded corpus)\n"
                  "      i  = indexed (preloaded corpus);  is = indexed + skipgrams\n"
+                 "  ref_driver load <model.colibri.patternmodel> <u|i> <dump.txt>\n"
                  "  ref_driver hash <hex> [<hex> ...]\n"
                  "  ref_driver encode <text file> <out prefix>\n"
                  "  ref_driver masks <n> <maxskips>\n";
@@ -135,6 +136,30 @@ int main(int argc, char** argv) {
         enc.build(files, true, 0, "");
         enc.save(prefix + ".colibri.cls");
         enc.encodefile(text, prefix + ".colibri.dat", false, false, false, false);
+        return 0;
+    }
+
+    if (cmd == "load") {  // the REFERENCE reads a .colibri.patternmodel (e.g. one written by the MI355X build) and dumps it canonically
+        if (argc < 5) return usage();
+        const std::string modelfile = argv[2], kind = argv[3], dumpout = argv[4];
+        PatternModelOptions options;
+        options.QUIET     = true;
+        options.MINTOKENS = 1;
+        std::vector<Row> rows;
+        uint64_t tokens = 0, types = 0;
+        if (kind == "u") {
+            PatternModel<uint32_t> model(modelfile, options);
+            tokens = model.tokens();
+            types  = model.types();
+            collect_unindexed(model, rows);
+        } else {
+            IndexedPatternModel<> model(modelfile, options);
+            tokens = model.tokens();
+            types  = model.types();
+            collect_indexed(model, rows);
+        }
+        std::ofstream out(dumpout);
+        dump(out, tokens, types, rows);
         return 0;
     }
 

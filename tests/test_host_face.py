@@ -1,0 +1,104 @@
+"""The C++ face (colibri-core_amd/host: PatternModelOptions / PatternModel<uint32_t> / IndexedPatternModel<> / IndexedCorpus)
+and the colibri-patternmodeller-compatible CLI.
+CPU part: key types, SpookyHash on the host, reading the reference's own golden model (v1), v2 write/read round trip.
+GPU part: the CLI builds models through the C ABI; the written .colibri.patternmodel is parsed here AND loaded by the real
+reference (oracle/_ref/ref_driver load) — the on-disk format is what makes the build a drop-in."""
+import os
+import struct
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+BIN = os.path.join(ROOT, "colibri-core_amd", "bin")
+SELFTEST = os.path.join(BIN, "host_selftest")
+CLI = os.path.join(BIN, "colibri-patternmodeller")
+
+
+def parse_model(path):
+    raw = open(path, "rb").read()
+    assert raw[0] == 0 and raw[2] == 2
+    mtype = raw[1]
+    tokens, types, npat = struct.unpack_from("<QQQ", raw, 3)
+    pos, counts, refs = 27, {}, {}
+    for _ in range(npat):
+        start, prevhigh = pos, False
+        while prevhigh or raw[pos] != 0:
+            prevhigh = raw[pos] >= 128
+            pos += 1
+        key = raw[start:pos]
+        pos += 1
+        (c,) = struct.unpack_from("<I", raw, pos)
+        pos += 4
+        counts[key] = c
+        if mtype == 20:
+            r = []
+            for _ in range(c):
+                s, t = struct.unpack_from("<IH", raw, pos)
+                pos += 6
+                r.append((s, t))
+            refs[key] = r
+    assert pos == len(raw)
+    return mtype, tokens, types, counts, refs
+
+
+def test_binaries_are_built():
+    assert os.access(SELFTEST, os.X_OK) and os.access(CLI, os.X_OK), "run __graft_entry__.build()"
+
+
+def test_host_selftest_cpu():
+    out = subprocess.run([SELFTEST, "cpu", os.path.join(GOLDEN, "hamlet.v2.colibri.dat"), os.path.join(GOLDEN, "hamlet.v1.colibri.patternmodel")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "OK", out.stdout + out.stderr
+
+
+def test_cli_rejects_out_of_scope_flags():
+    out = subprocess.run([CLI, "-f", os.path.join(GOLDEN, "hamlet.v2.colibri.dat"), "-j", "x"], capture_output=True, text=True)
+    assert out.returncode == 2 and "not part of the MI355X-accelerated build" in out.stderr
+
+
+def test_cli_prints_the_references_golden_model(tmp_path):
+    """-i <reference's own v1 model> -P: loads and prints 111 patterns (hex keys without a class file)."""
+    out = subprocess.run([CLI, "-i", os.path.join(GOLDEN, "hamlet.v1.colibri.patternmodel"), "-u", "-P"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 111
+    assert "06\t27" in lines
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("corpus,maxlength", [("hamlet.v1", 3), ("hamlet.v1", 100), ("hamlet.v2", 5), ("edge", 5), ("zipf20k", 5), ("phrases15k", 5)])
+def test_cli_builds_unindexed_model_reference_can_load(tmp_path, corpus, maxlength):
+    import oracle
+    model = str(tmp_path / "m.colibri.patternmodel")
+    data = os.path.join(GOLDEN, corpus + ".colibri.dat")
+    out = subprocess.run([CLI, "-f", data, "-u", "-t", "2", "-l", str(maxlength), "-o", model], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    golden = os.path.join(GOLDEN, f"{corpus}.u.l{maxlength}.txt")
+    want = oracle.parse_dump(open(golden).read())
+    mtype, tokens, types, counts, _ = parse_model(model)
+    assert (mtype, tokens, types) == (10, want.tokens, want.types)
+    assert counts == want.counts
+    # the progress lines mirror the reference's (found / pruned / kept per order)
+    assert "Counting 1-grams" in out.stderr and "total kept" in out.stderr
+    if oracle.have_ref():  # the real reference reads the file this build wrote
+        dump = str(tmp_path / "d.txt")
+        subprocess.check_call([oracle.REF_DRIVER, "load", model, "u", dump])
+        got = oracle.parse_dump(open(dump).read())
+        assert (got.tokens, got.types, got.counts) == (want.tokens, want.types, want.counts)
+
+
+@pytest.mark.gpu
+def test_cxx_api_preloaded_corpus(tmp_path):
+    """PatternModel<uint32_t> model(&corpus); model.train(file, options) — src/benchmarks.cpp test 5 / src/test.cpp:1211-1221."""
+    model = str(tmp_path / "m.colibri.patternmodel")
+    out = subprocess.run([SELFTEST, "gpu", os.path.join(GOLDEN, "hamlet.v2.colibri.dat"), model, "U", "100", "-1"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.split() == ["111", "354", "186", "7", "27"]
+
+
+@pytest.mark.gpu
+def test_cxx_api_errors_are_internalerror(tmp_path):
+    out = subprocess.run([SELFTEST, "gpu", os.path.join(GOLDEN, "hamlet.v2.colibri.dat"), str(tmp_path / "m"), "u", "5", "1"], capture_output=True, text=True)
+    assert out.returncode == 1 and "EXCEPTION" in out.stdout  # MINTOKENS=1 is outside the accelerated subset: loud failure, no fallback

@@ -55,15 +55,23 @@ struct colibri_ctx {
     // training state
     bool              trained = false;
     colibri_options   opt{};
-    DevBuf<uint32_t>  ids[2];
+    std::vector<DevBuf<uint32_t>> ids;  // plain mode: 2 ping-pong buffers; skipgram / indexed modes: one per order
+    DevBuf<uint32_t>  scratch[2];       // per-position slot arrays of the skipgram passes
+    DevBuf<uint32_t>  nsrc;             // per-slot distinct-source counter (indexed skipgrams)
     DevBuf<Slot>      table;
+    struct Segment {
+        uint32_t first, count;
+        int      n;
+        uint32_t mask;
+    };
+    std::vector<Segment> segments;      // result ranges: one per order (n-grams) and one per (order, gap mask) pass
     DevBuf<uint32_t>  res_rep, res_cnt;
     DevBuf<DevState>  state;
     DevState          hstate{};
     colibri_stats     stats{};
     // export scratch
     DevBuf<uint32_t>           keylen;
-    DevBuf<unsigned long long> keyoff;
+    DevBuf<unsigned long long> keyoff, bsum;
     uint64_t                   keybytes = 0;
 
     // profiling
@@ -261,8 +269,12 @@ int check_options(colibri_ctx* c, colibri_options& o) {
         return fail(c, COLIBRI_ERR_UNSUPPORTED, "DOPATTERNPERLINE / PRUNE(NON)SUBSUMED are not on the accelerated path");
     if (o.doskipgrams && o.doskipgrams_exhaustive)
         return fail(c, COLIBRI_ERR_ARG, "Both DOSKIPGRAMS as well as DOSKIPGRAMS_EXHAUSTIVE are set, this shouldn't happen, choose one.");  // :958-963
-    if (o.doskipgrams || o.doskipgrams_exhaustive || o.indexed)
-        return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgram / indexed training is not built into this library version");
+    if (o.doskipgrams && !o.indexed)
+        return fail(c, COLIBRI_ERR_UNSUPPORTED, "Can not compute skipgrams on unindexed model (except exhaustively during train() )");  // reference patternmodel.h:1558
+    if (o.doskipgrams_exhaustive && o.indexed) return fail(c, COLIBRI_ERR_UNSUPPORTED, "exhaustive skipgrams on an indexed model are not on the accelerated path");
+    if ((o.doskipgrams || o.doskipgrams_exhaustive) && (c->flags & kFlagSkipClass))
+        return fail(c, COLIBRI_ERR_UNSUPPORTED, "corpus contains the literal skip class {*} (03): skipgram validity then follows the reference's extra checks, not accelerated");
+    if (o.maxskips < 1) return fail(c, COLIBRI_ERR_ARG, "MAXSKIPS must be >= 1");
     return COLIBRI_OK;
 }
 
@@ -300,14 +312,17 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->bytes);
     dev_free(c->tokstart);
     dev_free(c->delimpos);
-    dev_free(c->ids[0]);
-    dev_free(c->ids[1]);
+    for (auto& b : c->ids) dev_free(b);
+    dev_free(c->scratch[0]);
+    dev_free(c->scratch[1]);
+    dev_free(c->nsrc);
     dev_free(c->table);
     dev_free(c->res_rep);
     dev_free(c->res_cnt);
     dev_free(c->state);
     dev_free(c->keylen);
     dev_free(c->keyoff);
+    dev_free(c->bsum);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -337,7 +352,121 @@ int colibri_positions(const colibri_ctx* c, uint64_t* npositions) {
     return COLIBRI_OK;
 }
 
-int colibri_train(colibri_ctx* c, const colibri_options* opt_in, colibri_stats* stats_out) {
+}  // extern "C" (reopened after colibri_train's helpers)
+
+// ---- helpers of colibri_train ---------------------------------------------------------------------------------
+namespace {
+
+struct TrainPlan {
+    uint32_t npos, table_slots, res_cap, thr;
+    uint32_t cnt_grid, tab_grid, pos_grid;
+};
+
+// gap masks of an n-token pattern: bit i = token i is a gap; never at either end; at most `maxskips` separate gaps when
+// n - 2 >= maxskips (reference src/algorithms.cpp:79-94)
+std::vector<uint32_t> gap_masks(int n, int maxskips) {
+    std::vector<uint32_t> out;
+    if (n < 3) return out;
+    for (uint32_t i = 1; i < (1u << (n - 2)); ++i) {
+        const uint32_t mask = i << 1;
+        int            runs = 0, in = 0;
+        for (int k = 0; k < n; ++k) {
+            const int g = (mask >> k) & 1;
+            runs += (g && !in);
+            in = g;
+        }
+        if (n - 2 >= maxskips && runs > maxskips) continue;
+        out.push_back(mask);
+    }
+    return out;
+}
+// contiguous runs of non-gap tokens: (first token, length)
+std::vector<std::pair<int, int>> mask_parts(uint32_t mask, int n) {
+    std::vector<std::pair<int, int>> parts;
+    int                              k = 0;
+    while (k < n) {
+        if ((mask >> k) & 1) {
+            ++k;
+            continue;
+        }
+        int e = k;
+        while (e < n && !((mask >> e) & 1)) ++e;
+        parts.push_back({k, e - k});
+        k = e;
+    }
+    return parts;
+}
+
+int read_state(colibri_ctx* c) {
+    HIP_TRY(c, hipMemcpyAsync(&c->hstate, c->state.p, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    if (c->hstate.overflow) return fail(c, COLIBRI_ERR_OVERFLOW, "device result buffer or table exhausted");
+    return COLIBRI_OK;
+}
+int write_state(colibri_ctx* c) {
+    HIP_TRY(c, hipMemcpyAsync(c->state.p, &c->hstate, sizeof(DevState), hipMemcpyHostToDevice, c->stream));
+    return COLIBRI_OK;
+}
+
+template <class KeyFn>
+void launch_count(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t* slot_of, int track, int cls) {
+    Prof p(c, cls);
+    hipLaunchKernelGGL((count_kernel<KeyFn>), dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, fn, slot_of, c->table.p, c->state.p, pl.npos, track);
+}
+void launch_clear(colibri_ctx* c, const TrainPlan& pl) {
+    Prof p(c, COLIBRI_K_CLEAR);
+    hipLaunchKernelGGL(clear_table_kernel, dim3(pl.tab_grid), dim3(kBlock), 0, c->stream, c->table.p, c->state.p);
+}
+void launch_prune(colibri_ctx* c, const TrainPlan& pl, uint32_t thr, const uint32_t* nsrc, uint32_t minsrc) {
+    Prof p(c, COLIBRI_K_PRUNE);
+    hipLaunchKernelGGL(prune_kernel, dim3(pl.tab_grid), dim3(kBlock), 0, c->stream, c->table.p, c->state.p, thr, c->res_rep.p, c->res_cnt.p, nsrc, minsrc, pl.res_cap);
+}
+void launch_resolve(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids) {
+    Prof p(c, COLIBRI_K_RESOLVE);
+    hipLaunchKernelGGL(resolve_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, ids, c->table.p, c->state.p, pl.npos);
+}
+
+// One (order, gap mask) skipgram pass. Exact identity of a skipgram = the survivor ids of its contiguous parts, paired
+// left to right: level 1 interns (part1, part2) into slot numbers, level j pairs those with part j+1; the last level counts.
+// gate/gate2 select the windows that take part (exhaustive: both (n-1)-grams survived; indexed: the n-gram survived).
+int skipgram_pass(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, const uint32_t* gate, const uint32_t* gate2, uint32_t participants, uint32_t thr, bool count_sources,
+                  uint32_t minsrc, uint32_t* found_out, uint32_t* kept_out) {
+    const std::vector<std::pair<int, int>> parts = mask_parts(mask, n);
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(pl.table_slots, (uint64_t)participants + (participants >> 1) + 1024u);
+    const uint32_t* left = c->ids[parts[0].second].p;
+    uint32_t        offl = (uint32_t)parts[0].first;
+    uint32_t*       out  = nullptr;
+    int             rc;
+    for (size_t j = 1; j < parts.size(); ++j) {
+        const bool last = j + 1 == parts.size();
+        c->hstate.cap   = cap;
+        c->hstate.found = c->hstate.kept = 0;
+        if ((rc = write_state(c))) return rc;
+        launch_clear(c, pl);
+        out = c->scratch[j & 1].p;
+        KeyPair fn{gate, gate2, left, offl, c->ids[parts[j].second].p, (uint32_t)parts[j].first};
+        launch_count(c, pl, fn, out, last ? 2 : 0, COLIBRI_K_SKIPGRAM);
+        left = out;
+        offl = 0;
+    }
+    const uint32_t* nsrc = nullptr;
+    if (count_sources) {
+        HIP_TRY(c, hipMemsetAsync(c->nsrc.p, 0, sizeof(uint32_t) * cap, c->stream));
+        Prof p(c, COLIBRI_K_SKIPGRAM);
+        hipLaunchKernelGGL(skip_sources_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, gate, c->res_rep.p, out, c->nsrc.p, c->state.p, pl.npos);
+        nsrc = c->nsrc.p;
+    }
+    launch_prune(c, pl, thr, nsrc, minsrc);
+    if ((rc = read_state(c))) return rc;
+    *found_out = c->hstate.found;
+    *kept_out  = c->hstate.kept;
+    return COLIBRI_OK;
+}
+
+}  // namespace
+
+extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, colibri_stats* stats_out) {
     if (!c || !opt_in) return COLIBRI_ERR_ARG;
     if (!c->have_corpus) return fail(c, COLIBRI_ERR_STATE, "no corpus uploaded");
     colibri_options o = *opt_in;
@@ -350,93 +479,159 @@ int colibri_train(colibri_ctx* c, const colibri_options* opt_in, colibri_stats* 
     collect_events(c);
     std::fill(std::begin(c->k_ms), std::end(c->k_ms), 0.0);
     std::fill(std::begin(c->k_launches), std::end(c->k_launches), 0);
+    c->segments.clear();
 
-    const uint32_t npos = c->npos;
-    // ---- HBM layout (sized once; nothing is allocated inside the order loop) -------------------------
+    const uint32_t npos   = c->npos;
+    const bool     synced = o.indexed || o.doskipgrams || o.doskipgrams_exhaustive;  // these modes keep every order's ids and talk to the host per order
+    // ---- HBM layout (sized once; nothing is allocated inside the unsynced order loop) ----------------
     // table: an order admits at most `npos` windows -> 1.5x slots; results: every survivor has >= 2 occurrences
     const uint64_t table_slots64 = (uint64_t)npos + (npos >> 1) + 2048;
     if (table_slots64 >= 0x7FFFFFFFull) return fail(c, COLIBRI_ERR_CORPUS, "corpus shard too large for one device table");
-    const uint32_t table_slots = (uint32_t)table_slots64;
-    const uint32_t res_cap     = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)npos * 2 + 1024);
+    TrainPlan pl{};
+    pl.npos        = npos;
+    pl.table_slots = (uint32_t)table_slots64;
+    pl.res_cap     = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)npos * (synced ? 4 : 2) + 1024);
+    pl.thr         = (uint32_t)o.mintokens;
+    constexpr uint32_t kCountLdsBytes    = kCountTile * 16u + kCountLSlot * 4u + 64u;  // keyL + cntL + slotL + winL
+    constexpr uint32_t kCountBlocksPerCU = (160u * 1024u / kCountLdsBytes) < 8u ? (160u * 1024u / kCountLdsBytes) : 8u;
+    pl.cnt_grid = std::max<uint32_t>(1, std::min<uint32_t>(blocks_for(npos, kCountTile), 256u * kCountBlocksPerCU));  // persistent blocks: all resident
+    pl.tab_grid = stream_grid(pl.table_slots);
+    pl.pos_grid = stream_grid(npos);
+    const int maxlength = std::min<int>(o.maxlength, COLIBRI_MAX_ORDER - 1);
+
+    if (c->ids.size() < 2) c->ids.resize(2);
     if ((rc = dev_alloc(c, c->ids[0], (size_t)npos + 1))) return rc;
     if ((rc = dev_alloc(c, c->ids[1], (size_t)npos + 1))) return rc;
-    if ((rc = dev_alloc(c, c->table, table_slots))) return rc;
-    if ((rc = dev_alloc(c, c->res_rep, res_cap))) return rc;
-    if ((rc = dev_alloc(c, c->res_cnt, res_cap))) return rc;
+    if ((rc = dev_alloc(c, c->table, pl.table_slots))) return rc;
+    if ((rc = dev_alloc(c, c->res_rep, pl.res_cap))) return rc;
+    if ((rc = dev_alloc(c, c->res_cnt, pl.res_cap))) return rc;
     if ((rc = dev_alloc(c, c->state, 1))) return rc;
+    if (o.doskipgrams || o.doskipgrams_exhaustive) {
+        if ((rc = dev_alloc(c, c->scratch[0], (size_t)npos + 1))) return rc;
+        if ((rc = dev_alloc(c, c->scratch[1], (size_t)npos + 1))) return rc;
+    }
+    if (o.doskipgrams && (rc = dev_alloc(c, c->nsrc, pl.table_slots))) return rc;
 
     // order 1: distinct unigrams <= distinct class ids when the encoding is canonical
     DevState init{};
     uint64_t cap1 = (uint64_t)c->ntokens + (c->ntokens >> 1) + 1024;
     if (!(c->flags & kFlagNonCanonical)) cap1 = std::min<uint64_t>(cap1, 2ull * ((uint64_t)c->maxclass + 1) + 1024);
-    init.cap = (uint32_t)std::min<uint64_t>(cap1, table_slots);
+    init.cap = (uint32_t)std::min<uint64_t>(cap1, pl.table_slots);
     if (c->ntokens == 0) init.done = 1;  // empty corpus: "None found" at n = 1
-    HIP_TRY(c, hipMemcpyAsync(c->state.p, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    c->hstate = init;
+    if ((rc = write_state(c))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-
-    const auto     t0        = std::chrono::steady_clock::now();
-    const uint32_t thr       = (uint32_t)o.mintokens;
-    constexpr uint32_t kCountLdsBytes = kCountTile * 16u + kCountLSlot * 4u + 64u;  // keyL + cntL + slotL + winL
-    constexpr uint32_t kCountBlocksPerCU = (160u * 1024u / kCountLdsBytes) < 8u ? (160u * 1024u / kCountLdsBytes) : 8u;
-    const uint32_t cnt_grid  = std::max<uint32_t>(1, std::min<uint32_t>(blocks_for(npos, kCountTile), 256u * kCountBlocksPerCU));  // persistent blocks: all resident
-    const uint32_t tab_grid  = stream_grid(table_slots);
-    const uint32_t pos_grid  = stream_grid(npos);
-    int            cur       = 0;  // ids[cur] = survivor ids of order n-1; ids[cur^1] receives order n
-    const int      maxlength = std::min<int>(o.maxlength, COLIBRI_MAX_ORDER - 1);
-    for (int n = 1; n <= maxlength; ++n) {
-        uint32_t* id_prev = c->ids[cur].p;
-        uint32_t* id_cur  = c->ids[cur ^ 1].p;
-        {
-            Prof p(c, COLIBRI_K_CLEAR);
-            hipLaunchKernelGGL(clear_table_kernel, dim3(tab_grid), dim3(kBlock), 0, c->stream, c->table.p, c->state.p);
-        }
-        {
-            Prof p(c, COLIBRI_K_COUNT);
-            if (n == 1)
-                hipLaunchKernelGGL(count_kernel<true>, dim3(cnt_grid), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, id_prev, id_cur, c->table.p, c->state.p, npos, n);
-            else
-                hipLaunchKernelGGL(count_kernel<false>, dim3(cnt_grid), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, id_prev, id_cur, c->table.p, c->state.p, npos,
-                                   n);
-        }
-        {
-            Prof p(c, COLIBRI_K_PRUNE);
-            hipLaunchKernelGGL(prune_kernel, dim3(tab_grid), dim3(kBlock), 0, c->stream, c->table.p, c->state.p, thr, c->res_rep.p, c->res_cnt.p, res_cap);
-        }
-        {
-            Prof p(c, COLIBRI_K_RESOLVE);
-            hipLaunchKernelGGL(resolve_kernel, dim3(pos_grid), dim3(kBlock), 0, c->stream, id_cur, c->table.p, c->state.p, npos);
-        }
-        hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, n, table_slots);
-        cur ^= 1;
-        // no host round trip per order: peek at the termination flag only every 8 orders (MAXLENGTH defaults to 100)
-        if ((n % 8) == 0 && n < maxlength) {
-            uint32_t done = 0;
-            HIP_TRY(c, hipMemcpyAsync(&done, &c->state.p->done, sizeof done, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            if (done) break;
-        }
-    }
-    HIP_TRY(c, hipMemcpyAsync(&c->hstate, c->state.p, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipGetLastError());
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    collect_events(c);
-    if (c->hstate.overflow) return fail(c, COLIBRI_ERR_OVERFLOW, "device result buffer or table exhausted");
 
     colibri_stats& s = c->stats;
     std::memset(&s, 0, sizeof s);
+    const auto t0 = std::chrono::steady_clock::now();
+
+    if (!synced) {
+        // ---------- the headline path: all orders enqueued back to back, no host round trip per order ----------
+        int cur = 0;  // ids[cur] = survivor ids of order n-1; ids[cur^1] receives order n
+        for (int n = 1; n <= maxlength; ++n) {
+            uint32_t* id_prev = c->ids[cur].p;
+            uint32_t* id_cur  = c->ids[cur ^ 1].p;
+            launch_clear(c, pl);
+            if (n == 1)
+                launch_count(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, id_cur, 3, COLIBRI_K_COUNT);
+            else
+                launch_count(c, pl, KeyNgram{c->bytes.p, c->tokstart.p, id_prev, n}, id_cur, 3, COLIBRI_K_COUNT);
+            launch_prune(c, pl, pl.thr, nullptr, 0);
+            launch_resolve(c, pl, id_cur);
+            hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, n, pl.table_slots);
+            cur ^= 1;
+            // peek at the termination flag only every 8 orders (MAXLENGTH defaults to 100)
+            if ((n % 8) == 0 && n < maxlength) {
+                uint32_t done = 0;
+                HIP_TRY(c, hipMemcpyAsync(&done, &c->state.p->done, sizeof done, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if (done) break;
+            }
+        }
+        if ((rc = read_state(c))) return rc;
+        s.maxn = (int32_t)c->hstate.maxn;
+        for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) {
+            s.found[n]    = c->hstate.s_found[n];
+            s.kept[n]     = c->hstate.s_kept[n];
+            s.admitted[n] = c->hstate.s_admitted[n];
+            if (n <= s.maxn && s.kept[n]) c->segments.push_back({c->hstate.res_off[n], c->hstate.res_off[n + 1] - c->hstate.res_off[n], n, 0u});
+        }
+    } else {
+        // ---------- skipgram / indexed modes: one host round trip per pass (sizes, lazily grown per-order id arrays) ----------
+        if ((int)c->ids.size() < maxlength + 2) c->ids.resize(maxlength + 2);
+        std::vector<uint32_t> valid_n(maxlength + 2, 0), adm_n(maxlength + 2, 0);
+        uint32_t              res_total = 0;
+        const uint32_t        thr_skip  = o.minskiptypes > 1 ? (uint32_t)o.mintokens_skipgrams : pl.thr;  // base pruneskipgrams is a no-op when MINSKIPTYPES <= 1 (patternmodel.h:2167-2186)
+        for (int n = 1; n <= maxlength && !c->hstate.done; ++n) {
+            if ((rc = dev_alloc(c, c->ids[n], (size_t)npos + 1))) return rc;
+            launch_clear(c, pl);
+            if (n == 1)
+                launch_count(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, c->ids[n].p, 3, COLIBRI_K_COUNT);
+            else
+                launch_count(c, pl, KeyNgram{c->bytes.p, c->tokstart.p, c->ids[n - 1].p, n}, c->ids[n].p, 3, COLIBRI_K_COUNT);
+            launch_prune(c, pl, pl.thr, nullptr, 0);
+            launch_resolve(c, pl, c->ids[n].p);
+            if ((rc = read_state(c))) return rc;
+            const uint32_t found = c->hstate.found, kept = c->hstate.kept;
+            adm_n[n]   = c->hstate.admitted;
+            valid_n[n] = c->hstate.valid;
+            s.admitted[n] = adm_n[n];
+            if (found == 0) break;  // "None found" (patternmodel.h:1189-1194)
+            s.maxn     = n;
+            s.found[n] = found;
+            s.kept[n]  = kept;
+            if (kept) c->segments.push_back({res_total, kept, n, 0u});
+            res_total += kept;
+            c->hstate.res_total = res_total;
+            if (o.doskipgrams_exhaustive && n >= 3) {  // patternmodel.h:1163-1171 -> computeskipgrams :1370-1527, for every admissible window
+                if (n > 13) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 13 tokens are not on the accelerated path (set MAXLENGTH)");
+                for (uint32_t mask : gap_masks(n, o.maxskips)) {
+                    uint32_t f = 0, k = 0;
+                    if ((rc = skipgram_pass(c, pl, n, mask, c->ids[n - 1].p, c->ids[n - 1].p, adm_n[n], thr_skip, false, 0, &f, &k))) return rc;
+                    s.found[n] += f;
+                    s.kept[n] += k;
+                    if (k) c->segments.push_back({res_total, k, n, mask});
+                    res_total += k;
+                    c->hstate.res_total = res_total;
+                }
+            }
+            // next order
+            c->hstate.cap   = (uint32_t)std::min<uint64_t>(pl.table_slots, (uint64_t)valid_n[n] + (valid_n[n] >> 1) + 1024u);
+            c->hstate.found = c->hstate.kept = c->hstate.admitted = c->hstate.valid = 0;
+            if ((rc = write_state(c))) return rc;
+            if (valid_n[n] == 0) break;  // nothing can be admitted at n + 1
+        }
+        if (o.doskipgrams) {  // IndexedPatternModel::trainskipgrams (patternmodel.h:2969-3010): from the SURVIVING n-grams, n = 3..
+            for (int n = 3; n <= std::min<int>(maxlength, s.maxn); ++n) {
+                if (n > 13) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 13 tokens are not on the accelerated path (set MAXLENGTH)");
+                uint32_t found_n = 0;
+                for (uint32_t mask : gap_masks(n, o.maxskips)) {
+                    uint32_t f = 0, k = 0;
+                    if ((rc = skipgram_pass(c, pl, n, mask, c->ids[n].p, nullptr, valid_n[n], pl.thr, true, o.minskiptypes > 1 ? (uint32_t)o.minskiptypes : 0u, &f, &k))) return rc;
+                    found_n += f;
+                    s.found[n] += f;
+                    s.kept[n] += k;
+                    if (k) c->segments.push_back({res_total, k, n, mask});
+                    res_total += k;
+                    c->hstate.res_total = res_total;
+                }
+                if (!found_n) break;  // " None found" (:2992-2994)
+            }
+        }
+        c->hstate.res_total = res_total;
+    }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    collect_events(c);
+
     s.totaltokens = c->ntokens;
     s.nsentences  = c->nsent;
     s.npatterns   = c->hstate.res_total;
-    s.maxn        = (int32_t)c->hstate.maxn;
     s.minn        = s.npatterns ? 1 : 0;
     s.train_ms    = ms;
     for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) {
-        s.found[n]    = c->hstate.s_found[n];
-        s.kept[n]     = c->hstate.s_kept[n];
-        s.pruned[n]   = s.found[n] - s.kept[n];
-        s.admitted[n] = c->hstate.s_admitted[n];
-        uint64_t w    = 0;
+        s.pruned[n] = s.found[n] - s.kept[n];
+        uint64_t w  = 0;
         for (size_t len = (size_t)n; len < c->lenhist.size(); ++len) w += c->lenhist[len] * (uint64_t)(len - n + 1);
         s.windows[n] = (n <= o.maxlength) ? w : 0;
     }
@@ -450,21 +645,17 @@ int colibri_train(colibri_ctx* c, const colibri_options* opt_in, colibri_stats* 
     if ((rc = dev_alloc(c, c->keyoff, (size_t)R + 1))) return rc;
     if (R) {
         Prof p(c, COLIBRI_K_EXPORT);
-        for (int n = 1; n <= (int)c->hstate.maxn; ++n) {
-            const uint32_t first = c->hstate.res_off[n], cnt = c->hstate.res_off[n + 1] - first;
-            if (cnt) hipLaunchKernelGGL(export_len_kernel, dim3(blocks_for(cnt, kBlock)), dim3(kBlock), 0, c->stream, c->tokstart.p, c->res_rep.p, first, cnt, n, c->keylen.p);
-        }
-        const uint32_t             nb = blocks_for(R, kBlock * 4);
-        DevBuf<unsigned long long> bsum;
-        if ((rc = dev_alloc(c, bsum, (size_t)nb + 1))) return rc;
-        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->keylen.p, R, bsum.p);
-        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1), 0, c->stream, bsum.p, nb, bsum.p + nb);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->keylen.p, R, bsum.p, c->keyoff.p);
+        for (const auto& sg : c->segments)
+            hipLaunchKernelGGL(export_len_kernel, dim3(blocks_for(sg.count, kBlock)), dim3(kBlock), 0, c->stream, c->tokstart.p, c->res_rep.p, sg.first, sg.count, sg.n, sg.mask, c->keylen.p);
+        const uint32_t nb = blocks_for(R, kBlock * 4);
+        if ((rc = dev_alloc(c, c->bsum, (size_t)nb + 1))) return rc;
+        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->keylen.p, R, c->bsum.p);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->bsum.p, nb, c->bsum.p + nb);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->keylen.p, R, c->bsum.p, c->keyoff.p);
         unsigned long long total = 0;
-        HIP_TRY(c, hipMemcpyAsync(&total, bsum.p + nb, sizeof total, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&total, c->bsum.p + nb, sizeof total, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipGetLastError());
-        dev_free(bsum);
         c->keybytes = total;
     }
     collect_events(c);
@@ -472,6 +663,8 @@ int colibri_train(colibri_ctx* c, const colibri_options* opt_in, colibri_stats* 
     if (stats_out) *stats_out = s;
     return COLIBRI_OK;
 }
+
+extern "C" {
 
 int colibri_result_sizes(const colibri_ctx* c, uint64_t* npatterns, uint64_t* keybytes, uint64_t* nrefs) {
     if (!c) return COLIBRI_ERR_ARG;
@@ -494,8 +687,9 @@ int colibri_export_unindexed(colibri_ctx* c, uint64_t* key_off, uint8_t* key_byt
     if ((rc = dev_alloc(c, out, (size_t)c->keybytes + 1))) return rc;
     {
         Prof p(c, COLIBRI_K_EXPORT);
-        hipLaunchKernelGGL(export_bytes_kernel, dim3(blocks_for(R, kBlock)), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, c->res_rep.p, c->keylen.p, c->keyoff.p, R,
-                           out.p);
+        for (const auto& sg : c->segments)
+            hipLaunchKernelGGL(export_bytes_kernel, dim3(blocks_for(sg.count, kBlock)), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, c->res_rep.p, c->keylen.p, c->keyoff.p,
+                               sg.first, sg.count, sg.n, sg.mask, out.p);
     }
     HIP_TRY(c, hipMemcpyAsync(key_bytes, out.p, c->keybytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(key_off, c->keyoff.p, sizeof(uint64_t) * R, hipMemcpyDeviceToHost, c->stream));

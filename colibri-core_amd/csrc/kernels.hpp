@@ -256,10 +256,69 @@ __device__ __forceinline__ uint32_t table_find_or_insert(Slot* __restrict__ tabl
     return idx;
 }
 
-template <bool FIRST>
-__global__ __launch_bounds__(kBlock) void count_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ tokstart,
-                                                        const uint32_t* __restrict__ id_prev, uint32_t* __restrict__ slot_of, Slot* __restrict__ table,
-                                                        DevState* __restrict__ st, uint32_t npos, int n) {
+// ---- key functors: what a position contributes at a given pass --------------------------------------------------
+// order 1: the token's own bytes (<= 8, validated at upload) are the exact key
+struct KeyUnigram {
+    const uint8_t*  bytes;
+    const uint32_t* tokstart;
+    __device__ __forceinline__ bool operator()(uint32_t i, uint32_t npos, uint64_t& key, uint64_t& hash) const {
+        (void)npos;
+        const uint32_t a = tokstart[i], len = tokstart[i + 1] - a;
+        const uint64_t raw = keep_bytes(ld64u(bytes + a), len);
+        if (len == 1 && raw == 0) return false;  // delimiter
+        key  = raw;
+        hash = spooky64_short(bytes + a, len);
+        return true;
+    }
+};
+// order n >= 2: admissible iff both (n-1)-grams survived; exact key = their two survivor ids; slot by SpookyHash of the bytes
+struct KeyNgram {
+    const uint8_t*  bytes;
+    const uint32_t* tokstart;
+    const uint32_t* id_prev;
+    int             n;
+    __device__ __forceinline__ bool operator()(uint32_t i, uint32_t npos, uint64_t& key, uint64_t& hash) const {
+        if (i + 1 >= npos) return false;
+        const uint32_t l = id_prev[i], r = id_prev[i + 1];
+        if (l == kInvalid || r == kInvalid) return false;
+        key              = ((uint64_t)l << 32) | r;
+        const uint32_t a = tokstart[i];
+        hash             = spooky64_short(bytes + a, tokstart[i + n] - a);
+        return true;
+    }
+};
+// skipgram passes: the key is a pair of ids taken at two offsets from the window start. `gate`/`gate2` say which windows take
+// part (exhaustive: both (n-1)-grams survived = gate[i], gate2[i+1]; indexed: the n-gram itself survived = gate[i]).
+// Level >= 2 of a multi-part skipgram pairs the previous level's slot index (left, offset 0) with the next part's id.
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+struct KeyPair {
+    const uint32_t* gate;
+    const uint32_t* gate2;  // may be NULL
+    const uint32_t* left;
+    uint32_t        offl;
+    const uint32_t* right;
+    uint32_t        offr;
+    __device__ __forceinline__ bool operator()(uint32_t i, uint32_t npos, uint64_t& key, uint64_t& hash) const {
+        if (gate[i] == kInvalid) return false;
+        if (gate2 != nullptr && (i + 1 >= npos || gate2[i + 1] == kInvalid)) return false;
+        const uint32_t l = left[i + offl], r = right[i + offr];
+        if (l == kInvalid || r == kInvalid) return false;  // cannot happen for an admissible window; kept as a guard
+        key  = ((uint64_t)l << 32) | r;
+        hash = mix64(key);  // the reference's hash of a materialised skipgram is never observable; slots need any good 64-bit mix
+        return true;
+    }
+};
+
+template <class KeyFn>
+__global__ __launch_bounds__(kBlock) void count_kernel(KeyFn keyfn, uint32_t* __restrict__ slot_of, Slot* __restrict__ table, DevState* __restrict__ st, uint32_t npos,
+                                                        int track) {  // track: bit 0 = add to st->admitted, bit 1 = add CAS wins to st->found
     if (st->done) return;
     __shared__ uint64_t keyL[kCountTile];
     __shared__ uint32_t winL[kCountLSlot];
@@ -278,28 +337,9 @@ __global__ __launch_bounds__(kBlock) void count_kernel(const uint8_t* __restrict
 #pragma unroll
         for (int k = 0; k < kCountPer; ++k) {
             const uint32_t e = k * kBlock + threadIdx.x, i = base + e;
-            adm[k]  = false;
             key[k]  = 0;
             hash[k] = 0;
-            if (i < npos) {
-                if (FIRST) {
-                    const uint32_t a = tokstart[i], len = tokstart[i + 1] - a;
-                    const uint64_t raw = keep_bytes(ld64u(bytes + a), len);
-                    adm[k]             = !(len == 1 && raw == 0);  // not a delimiter
-                    if (adm[k]) {
-                        key[k]  = raw;
-                        hash[k] = spooky64_short(bytes + a, len);
-                    }
-                } else if (i + 1 < npos) {
-                    const uint32_t l = id_prev[i], r = id_prev[i + 1];
-                    adm[k]           = (l != kInvalid) && (r != kInvalid);
-                    if (adm[k]) {
-                        key[k]           = ((uint64_t)l << 32) | r;
-                        const uint32_t a = tokstart[i];
-                        hash[k]          = spooky64_short(bytes + a, tokstart[i + n] - a);
-                    }
-                }
-            }
+            adm[k]  = (i < npos) && keyfn(i, npos, key[k], hash[k]);
             cntL[e] = 0;
             if (adm[k]) {
                 keyL[e]                                     = key[k];
@@ -365,8 +405,19 @@ __global__ __launch_bounds__(kBlock) void count_kernel(const uint8_t* __restrict
             a += redL[0][w];
             f += redL[1][w];
         }
-        if (a) atomicAdd(&st->admitted, a);
-        if (f) atomicAdd(&st->found, f);
+        if (a && (track & 1)) atomicAdd(&st->admitted, a);
+        if (f && (track & 2)) atomicAdd(&st->found, f);
+    }
+}
+
+// indexed skipgrams: number of distinct surviving source n-grams per skipgram (= distinct skip contents, reference
+// patternmodel.h:3029-3059): every surviving n-gram has exactly one representative position; that position bumps the count.
+__global__ __launch_bounds__(kBlock) void skip_sources_kernel(const uint32_t* __restrict__ ids_n, const uint32_t* __restrict__ res_rep, const uint32_t* __restrict__ slot_of,
+                                                               uint32_t* __restrict__ nsrc, const DevState* __restrict__ st, uint32_t npos) {
+    if (st->done) return;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npos; i += gridDim.x * kBlock) {
+        const uint32_t r = ids_n[i], s = slot_of[i];
+        if (r != kInvalid && s != kInvalid && res_rep[r] == i) atomicAdd(&nsrc[s], 1u);
     }
 }
 
@@ -387,7 +438,7 @@ __global__ __launch_bounds__(kBlock) void clear_table_kernel(Slot* __restrict__ 
 constexpr int kPrunePer  = 16;
 constexpr int kPruneTile = kBlock * kPrunePer;  // 4096 slots per block iteration
 __global__ __launch_bounds__(kBlock) void prune_kernel(Slot* __restrict__ table, DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ res_rep,
-                                                        uint32_t* __restrict__ res_cnt, uint32_t res_cap) {
+                                                        uint32_t* __restrict__ res_cnt, const uint32_t* __restrict__ nsrc, uint32_t minsrc, uint32_t res_cap) {
     if (st->done) return;
     __shared__ uint32_t baseL;
     const uint32_t      cap = st->cap, res_base = st->res_total;
@@ -406,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void prune_kernel(Slot* __restrict__ table,
                     usedmask |= 1u << k;
                     cnt[k] = s.count;
                     rep[k] = s.rep;
-                    if (s.count >= threshold) keepmask |= 1u << k;
+                    if (s.count >= threshold && (nsrc == nullptr || nsrc[i] >= minsrc)) keepmask |= 1u << k;
                 }
             }
         }
@@ -465,6 +516,17 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(uint32_t* __restrict__ 
     }
 }
 
+// skipgram passes (the host has synchronised and knows how many windows take part): set capacity, reset per-pass counters
+__global__ void begin_pass_kernel(DevState* __restrict__ st, uint32_t cap) {
+    st->cap  = cap;
+    st->kept = 0;
+}
+// fold the survivors of a finished skipgram pass into the result total
+__global__ void end_pass_kernel(DevState* __restrict__ st) {
+    st->res_total += st->kept;
+    st->kept = 0;
+}
+
 // single-lane bookkeeping between orders: statistics, result offsets, next capacity, termination
 __global__ void advance_kernel(DevState* __restrict__ st, int n, uint32_t table_slots) {
     if (st->done) return;
@@ -493,11 +555,17 @@ __global__ void advance_kernel(DevState* __restrict__ st, int n, uint32_t table_
 //    replaces Pattern::write / BaseValueHandler::write over the map (pattern.cpp:268-277, datatypes.h:219-221)
 // =================================================================================================
 __global__ __launch_bounds__(kBlock) void export_len_kernel(const uint32_t* __restrict__ tokstart, const uint32_t* __restrict__ res_rep, uint32_t first, uint32_t count,
-                                                             int n, uint32_t* __restrict__ keylen) {
+                                                             int n, uint32_t mask, uint32_t* __restrict__ keylen) {
     const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
     if (j < count) {
-        const uint32_t p  = res_rep[first + j];
-        keylen[first + j] = tokstart[p + n] - tokstart[p];
+        const uint32_t p = res_rep[first + j];
+        uint32_t       len = 0;
+        if (mask == 0) {
+            len = tokstart[p + n] - tokstart[p];
+        } else {  // a gapped token is the single byte 03 (reference src/pattern.cpp:886-908)
+            for (int k = 0; k < n; ++k) len += ((mask >> k) & 1u) ? 1u : (tokstart[p + k + 1] - tokstart[p + k]);
+        }
+        keylen[first + j] = len;
     }
 }
 
@@ -515,15 +583,34 @@ __global__ __launch_bounds__(kBlock) void scan_reduce_kernel(const uint32_t* __r
     __syncthreads();
     if (threadIdx.x == 0) blocksum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
-__global__ void scan_sums_kernel(unsigned long long* __restrict__ blocksum, uint32_t nblocks, unsigned long long* __restrict__ total) {
-    // serial over block sums (one per 1024 inputs): nblocks is at most a few hundred thousand
-    unsigned long long run = 0;
-    for (uint32_t b = 0; b < nblocks; ++b) {
-        const unsigned long long v = blocksum[b];
-        blocksum[b]                = run;
-        run += v;
+__global__ __launch_bounds__(kBlock) void scan_sums_kernel(unsigned long long* __restrict__ blocksum, uint32_t nblocks, unsigned long long* __restrict__ total) {
+    // ONE block scans the block sums (one per 1024 inputs) in chunks of 256 with a running carry
+    __shared__ unsigned long long ws[kBlock / kWave];
+    __shared__ unsigned long long carryL;
+    if (threadIdx.x == 0) carryL = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += kBlock) {
+        const uint32_t     b = base + threadIdx.x;
+        unsigned long long v = b < nblocks ? blocksum[b] : 0ull, incl = v;
+        const uint32_t     lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+        for (int off = 1; off < kWave; off <<= 1) {
+            const unsigned long long t = __shfl_up(incl, off, kWave);
+            if ((int)lane >= off) incl += t;
+        }
+        if (lane == kWave - 1) ws[wave] = incl;
+        __syncthreads();
+        unsigned long long wbase = 0, tot = 0;
+        for (int w = 0; w < kBlock / kWave; ++w) {
+            if (w < (int)wave) wbase += ws[w];
+            tot += ws[w];
+        }
+        const unsigned long long carry = carryL;
+        if (b < nblocks) blocksum[b] = carry + wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carryL = carry + tot;
+        __syncthreads();
     }
-    *total = run;
+    if (threadIdx.x == 0) *total = carryL;
 }
 __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t* __restrict__ in, uint32_t n, const unsigned long long* __restrict__ blocksum,
                                                              unsigned long long* __restrict__ out) {
@@ -545,14 +632,26 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t* __re
 }
 
 __global__ __launch_bounds__(kBlock) void export_bytes_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ tokstart, const uint32_t* __restrict__ res_rep,
-                                                               const uint32_t* __restrict__ keylen, const unsigned long long* __restrict__ keyoff, uint32_t count,
-                                                               uint8_t* __restrict__ out) {
+                                                               const uint32_t* __restrict__ keylen, const unsigned long long* __restrict__ keyoff, uint32_t first,
+                                                               uint32_t count, int n, uint32_t mask, uint8_t* __restrict__ out) {
     const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
     if (j < count) {
-        const uint8_t* src = bytes + tokstart[res_rep[j]];
-        uint8_t*       dst = out + keyoff[j];
-        const uint32_t len = keylen[j];
-        for (uint32_t b = 0; b < len; ++b) dst[b] = src[b];
+        const uint32_t p = res_rep[first + j];
+        uint8_t*       dst = out + keyoff[first + j];
+        if (mask == 0) {
+            const uint8_t* src = bytes + tokstart[p];
+            const uint32_t len = keylen[first + j];
+            for (uint32_t b = 0; b < len; ++b) dst[b] = src[b];
+        } else {
+            uint32_t o = 0;
+            for (int k = 0; k < n; ++k) {
+                if ((mask >> k) & 1u) {
+                    dst[o++] = 3;
+                } else {
+                    for (uint32_t b = tokstart[p + k]; b < tokstart[p + k + 1]; ++b) dst[o++] = bytes[b];
+                }
+            }
+        }
     }
 }
 

@@ -62,12 +62,14 @@ def test_window_hashes_match_reference_hash(ctx, n):
         assert int(got[i]) == want, (i, n)
 
 
-def _compare(ctx, payload, maxlength, mintokens=2):
+def _compare(ctx, payload, maxlength, mintokens=2, **mode):
     import oracle
-    want = oracle.train(payload, mintokens, maxlength)
+    want = oracle.train(payload, mintokens, maxlength, **mode)
     ctx.upload(payload)
-    st = ctx.train(mintokens=mintokens, maxlength=maxlength)
-    got, _ = ctx.export_dict()
+    st = ctx.train(mintokens=mintokens, maxlength=maxlength, **mode)
+    got, gotrefs = ctx.export_dict()
+    if mode.get("indexed"):
+        assert gotrefs == want.refs
     assert st.totaltokens == want.tokens
     assert st.totaltypes == want.types
     assert st.npatterns == len(want)
@@ -137,3 +139,27 @@ def test_medium_zipf_properties(ctx):
     st = _compare(ctx, payload, 5)
     # the survey's reference run on this exact corpus kept 56240/61036/15024/1369/44
     assert [st.kept[n] for n in range(1, 6)] == [56240, 61036, 15024, 1369, 44]
+
+
+SKIP_CORPORA = ["rand0", "rand1", "rand2", "rand3", "rand_noempty", "repeat", "one_long_sentence", "multibyte", "short_sentences", "zipf20k", "zipf200k_phrases", "empty"]
+
+
+@pytest.mark.parametrize("name", SKIP_CORPORA)
+@pytest.mark.parametrize("extra", [{}, {"minskiptypes": 1}, {"mintokens_skipgrams": 3}, {"maxskips": 1}], ids=["default", "T1", "y3", "maxskips1"])
+def test_exhaustive_skipgrams_match_oracle(ctx, name, extra):
+    """config 4 (unindexed): PatternModel::train with DOSKIPGRAMS_EXHAUSTIVE (patternmodel.h:1163-1171, :1370-1527, :2167-2186)."""
+    _compare(ctx, small_corpora()[name], 5, doskipgrams_exhaustive=1, **extra)
+
+
+def test_exhaustive_skipgrams_longer_patterns(ctx, hamlet_payload):
+    st = _compare(ctx, hamlet_payload, 100, mintokens=-1, doskipgrams_exhaustive=1)
+    assert st.npatterns == 385  # reference src/test.cpp:1268-1283, test.py:236
+    _compare(ctx, small_corpora()["repeat"], 8, doskipgrams_exhaustive=1)
+
+
+def test_skipgrams_rejected_when_corpus_has_literal_skip_tokens(ctx):
+    from colibri_amd import capi
+    ctx.upload(b"\x06\x03\x07\x00\x06\x03\x07\x00")
+    ctx.train(maxlength=3)  # plain n-grams are fine: the bytes are the key either way
+    with pytest.raises(capi.ColibriError):
+        ctx.train(maxlength=3, doskipgrams_exhaustive=1)

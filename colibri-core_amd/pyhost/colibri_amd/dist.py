@@ -1,0 +1,108 @@
+"""Sentence-sharded training across the GPUs of one node: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" in the CPU tests) for the one real exchange step the path has.
+
+The reference is single-threaded and has no counterpart. What is distributed here is PatternModel::train's order loop
+(reference include/patternmodel.h:981-1270): windows never cross sentences, so each rank counts its own contiguous range of
+sentences; the only cross-shard dependency is the GLOBAL count of each candidate pattern, needed before the threshold prune of
+every order. Per order n:
+    1. every rank counts its shard (HIP count kernel) and partitions its distinct candidates by owner = hash(key) % world;
+    2. all-to-all of (key, local count) records [sizes first];
+    3. each owner sums the exact global counts, applies the threshold and — after an all-gather of the survivor counts — hands
+       out GLOBAL survivor ids and names the exporting rank of each survivor;
+    4. all-to-all of the replies back; every rank tags its local table and writes survivor ids per position for order n+1.
+Keys are exact 64-bit identities (order 1: the token bytes; order n: the two global survivor ids of the (n-1)-grams), so counts
+from different ranks are summed exactly — no approximate filter, no merged collisions. Volume per order and rank: 12 B per local
+distinct candidate out, 8 B back; xGMI is point-to-point (7 links per GPU), and an all-to-all uses all of them at once.
+"""
+import numpy as np
+
+MAX_ORDER = 128
+
+
+class ShardedTrainer:
+    def __init__(self, engine, dist, torch, device=None):
+        """engine: capi.HipShardEngine (GPU) or any object with the same methods (the CPU tests use a numpy stand-in);
+        dist: an initialised torch.distributed; device: where exchange tensors live (None = CPU for gloo)."""
+        self.engine, self.dist, self.torch = engine, dist, torch
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = device
+        # gloo moves host memory only: device tensors are staged through the host (CPU tests, and 2 ranks sharing one GPU)
+        self.stage_host = dist.get_backend() == "gloo"
+        if self.stage_host:
+            self.device = None
+
+    # ---- collectives ------------------------------------------------------------------------------
+    def _exchange_sizes(self, sizes):
+        t = self.torch
+        s = t.tensor(sizes, dtype=t.int64, device=self.device)
+        r = t.empty(self.world, dtype=t.int64, device=self.device)
+        self.dist.all_to_all_single(r, s)
+        return [int(x) for x in r.tolist()]
+
+    def _all_to_all_v(self, tensor, send_sizes, recv_sizes):
+        home = tensor.device
+        src = tensor.contiguous().cpu() if (self.stage_host and tensor.is_cuda) else tensor.contiguous()
+        out = self.torch.empty(sum(recv_sizes), dtype=src.dtype, device=src.device)
+        self.dist.all_to_all_single(out, src, recv_sizes, send_sizes)
+        return out.to(home) if out.device != home else out
+
+    def _all_gather_ints(self, values):
+        t = self.torch
+        mine = t.tensor(values, dtype=t.int64, device=self.device)
+        out = [t.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return [[int(x) for x in o.tolist()] for o in out]
+
+    # ---- one training run -------------------------------------------------------------------------
+    def train(self, opt):
+        eng = self.engine
+        eng.begin(opt, self.world)
+        maxlength = min(int(opt.maxlength), MAX_ORDER - 1)
+        found_g, kept_g = [0] * MAX_ORDER, [0] * MAX_ORDER
+        gid_total, maxn = 0, 0
+        tokens_g = sum(v[0] for v in self._all_gather_ints([eng.local_tokens()]))
+        for n in range(1, maxlength + 1):
+            ncand, per_owner = eng.count(n)
+            recv_sizes = self._exchange_sizes(per_owner)
+            keys, cnts = eng.send_buffers()
+            rkeys = self._all_to_all_v(keys, per_owner, recv_sizes)
+            rcnts = self._all_to_all_v(cnts, per_owner, recv_sizes)
+            found, kept = eng.merge(rkeys, rcnts, recv_sizes)
+            everyone = self._all_gather_ints([found, kept])
+            found_all, kept_all = sum(v[0] for v in everyone), sum(v[1] for v in everyone)
+            if found_all == 0:  # "None found" on every rank at once (reference patternmodel.h:1189-1194)
+                break
+            maxn = n
+            found_g[n], kept_g[n] = found_all, kept_all
+            base = gid_total + sum(everyone[r][1] for r in range(self.rank))
+            if gid_total + kept_all >= (1 << 31):
+                raise OverflowError("more than 2^31 surviving patterns")
+            rgid, rtot = eng.reply(base)
+            gid = self._all_to_all_v(rgid, recv_sizes, per_owner)
+            tot = self._all_to_all_v(rtot, recv_sizes, per_owner)
+            eng.apply(n, gid, tot)
+            gid_total += kept_all
+            if kept_all == 0:  # nothing can be admitted at n + 1
+                break
+        return eng.finish(found_g, kept_g, tokens_g, maxn)
+
+
+def shard_payload(payload, world):
+    """Split a v2 payload (header stripped) into `world` contiguous sentence ranges of about equal bytes.
+    Returns [(bytes, first_sentence)], first_sentence being the 1-based global index of the shard's first sentence."""
+    arr = np.frombuffer(payload, dtype=np.uint8)
+    term = arr < 128
+    prev_low = np.concatenate([[True], term[:-1]]) if arr.size else np.zeros(0, dtype=bool)
+    delim_idx = np.flatnonzero((arr == 0) & prev_low)  # byte index of every sentence delimiter
+    cuts = [0]
+    for r in range(1, world):
+        target = arr.size * r // world
+        j = int(np.searchsorted(delim_idx, target))
+        cut = int(delim_idx[j]) + 1 if j < delim_idx.size else arr.size
+        cuts.append(max(cut, cuts[-1]))
+    cuts.append(arr.size)
+    out = []
+    for r in range(world):
+        first = 1 + int(np.searchsorted(delim_idx, cuts[r]))  # sentences before the cut + 1
+        out.append((arr[cuts[r]: cuts[r + 1]].tobytes(), first))
+    return out

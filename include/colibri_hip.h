@@ -122,6 +122,29 @@ int colibri_export_unindexed(colibri_ctx* ctx, uint64_t* key_off, uint8_t* key_b
 int colibri_export_indexed(colibri_ctx* ctx, uint64_t* key_off, uint8_t* key_bytes, uint32_t* counts, uint64_t* ref_off,
                            uint32_t* ref_sentence, uint16_t* ref_token);
 
+/* ---- sentence-sharded multi-GPU training (one context per rank; the collectives themselves are the caller's: RCCL through
+ * torch.distributed in colibri_amd.dist, or any all-to-all). The reference has no counterpart — it is single-threaded; these
+ * entry points split PatternModel::train's order loop (patternmodel.h:981-1270) at its only cross-shard dependency: the global
+ * count of a candidate pattern. Survivor ids are global (handed out by the owner rank of a key), so the 64-bit keys of all ranks
+ * are comparable and counts are summed exactly. Unindexed n-gram models only. All *_dev arguments are DEVICE pointers.
+ *   per order n:  shard_count -> [all-to-all sizes] -> shard_send -> [all-to-all keys,counts] -> shard_merge -> [all-gather
+ *                 found,kept] -> shard_reply -> [all-to-all replies back] -> shard_apply ;  after the last order: shard_finish.
+ * Each rank then exports (colibri_export_unindexed) the patterns it was named exporter of; the union over ranks is the model. */
+int colibri_shard_begin(colibri_ctx* ctx, const colibri_options* opt, int world);
+/* local count pass of order n, then this rank's distinct candidates partitioned by owner = hash(key) % world */
+int colibri_shard_count(colibri_ctx* ctx, int n, uint64_t* ncandidates, uint64_t* per_owner /* [world] */);
+/* copy the partitioned candidates (keys: u64[ncandidates], counts: u32[ncandidates]) into the caller's send buffers */
+int colibri_shard_send(colibri_ctx* ctx, void* keys_dev, void* counts_dev);
+/* owner side: merge the records received from every rank (concatenated in rank order; per_src[r] records from rank r) */
+int colibri_shard_merge(colibri_ctx* ctx, const void* keys_dev, const void* counts_dev, const uint64_t* per_src /* [world] */, uint64_t* found, uint64_t* kept);
+/* owner side: assign global survivor ids gid_base.. to the kept keys and fill one reply per received record
+ * (reply_gid: u32 global id | bit 31 = "you export it", 0xFFFFFFFF = pruned; reply_cnt: u32 global count) */
+int colibri_shard_reply(colibri_ctx* ctx, uint32_t gid_base, void* reply_gid_dev, void* reply_cnt_dev);
+/* contributor side: apply the replies (same order as the records sent), write survivor ids per position for order n+1 */
+int colibri_shard_apply(colibri_ctx* ctx, int n, const void* reply_gid_dev, const void* reply_cnt_dev, uint64_t* exported, uint64_t* admitted);
+/* close the run: global per-order found / kept (caller-reduced), global token count; fills stats like colibri_train */
+int colibri_shard_finish(colibri_ctx* ctx, const uint64_t* found_global, const uint64_t* kept_global, uint64_t totaltokens_global, int maxn, colibri_stats* stats);
+
 /* ---- parity / measurement hooks ------------------------------------------------------------------ */
 /* SpookyHash::Hash64 (reference include/SpookyV2.h:59-66) of every n-token window, computed by the same
  * device routine the count kernel uses: out[i] for token position i (delimiters are positions too);

@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--tokens", type=int, default=100_000_000, help="tokens per GPU (default: the 100M-token config)")
     ap.add_argument("--vocab", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="tokens of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for debugging)")
+    ap.add_argument("--share-gpu", action="store_true", help="debugging: all ranks use cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -113,12 +115,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU path to measure")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     # ---- synthetic input, resident in HBM before the timed region ---------------------------------
     seed = 44 + rank
@@ -128,14 +136,21 @@ def main():
     ctx = capi.Context(local_rank)
     dev_payload = torch.from_numpy(payload.copy()).cuda()  # H2D outside the timed region
     torch.cuda.synchronize()
+    first_sentence = 1
+    if dist is not None:  # global sentence numbers: this rank's shard starts after the sentences of the lower ranks
+        prev_low = np.concatenate([[True], payload[:-1] < 128])
+        nsent = int(((payload == 0) & prev_low).sum())
+        counts = [None] * world
+        dist.all_gather_object(counts, nsent)
+        first_sentence = 1 + sum(counts[:rank])
     t0 = time.time()
-    ctx.upload_device(dev_payload.data_ptr(), payload.size, 1)  # tokenise on device
+    ctx.upload_device(dev_payload.data_ptr(), payload.size, first_sentence)  # tokenise on device
     tokenise_ms = (time.time() - t0) * 1e3
     opt = capi.Options.defaults(mintokens=MINTOKENS, maxlength=MAXLENGTH, profile=1)
 
     if world > 1:
         from colibri_amd import dist as cdist
-        trainer = cdist.ShardedTrainer(ctx, dist, torch)
+        trainer = cdist.ShardedTrainer(capi.HipShardEngine(ctx, torch, device), dist, torch, device)
         step = lambda: trainer.train(opt)
     else:
         step = lambda: ctx.train(opt)
@@ -157,12 +172,14 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     windows = sum(st.windows[1:MAXLENGTH + 1])
+    npatterns = int(st.npatterns)
     if dist is not None:
-        t = torch.tensor([elapsed, float(windows)], dtype=torch.float64, device="cuda")
+        where = device if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed, float(windows), float(npatterns), count_ms], dtype=torch.float64, device=where)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed, windows = float(tmax[0]), float(t[1])
+        elapsed, windows, npatterns = float(tmax[0]), float(t[1]), int(t[2])
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -191,7 +208,7 @@ def main():
                         f"unindexed PatternModel<uint32_t>, MAXLENGTH={MAXLENGTH}, MINTOKENS={MINTOKENS}",
             "tokens_per_gpu": args.tokens,
             "patterns_counted_per_step": int(windows),
-            "patterns_in_model": int(st.npatterns),
+            "patterns_in_model": npatterns,
             "kept_per_order": [int(st.kept[n]) for n in range(1, MAXLENGTH + 1)],
             "parallelism": "single device" if args.gpus == 1 else f"sentence-sharded x{args.gpus}, per-order candidate exchange over RCCL",
             "tokenise_ms_untimed": round(tokenise_ms, 3),

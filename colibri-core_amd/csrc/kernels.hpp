@@ -833,13 +833,38 @@ __global__ __launch_bounds__(kBlock) void shard_extract_kernel(const Slot* __res
 __global__ __launch_bounds__(kBlock) void shard_partition_kernel(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ slots,
                                                                   uint32_t n, uint32_t world, const uint32_t* __restrict__ owner_off, uint32_t* __restrict__ cursor,
                                                                   unsigned long long* __restrict__ okeys, uint32_t* __restrict__ ocounts, uint32_t* __restrict__ oslots) {
-    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
-        const unsigned long long k = keys[j];
-        const uint32_t           o = (uint32_t)(mix64(k) % world);
-        const uint32_t           d = owner_off[o] + atomicAdd(&cursor[o], 1u);
-        okeys[d]   = k;
-        ocounts[d] = counts[j];
-        oslots[d]  = slots[j];
+    // a block ranks its 1024 records per owner in LDS and reserves ONE range per owner (a single cursor word takes ~88 M atomics/s)
+    __shared__ uint32_t histL[64], baseL[64];
+    const uint32_t      ntiles = (n + kEmitTile - 1) / kEmitTile;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (threadIdx.x < 64) histL[threadIdx.x] = 0;
+        __syncthreads();
+        unsigned long long k[kEmitPer];
+        uint32_t           own[kEmitPer], rank[kEmitPer];
+#pragma unroll
+        for (int q = 0; q < kEmitPer; ++q) {
+            const uint32_t j = tile * kEmitTile + q * kBlock + threadIdx.x;
+            own[q]           = kInvalid;
+            if (j < n) {
+                k[q]    = keys[j];
+                own[q]  = (uint32_t)(mix64(k[q]) % world);
+                rank[q] = atomicAdd(&histL[own[q]], 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < world) baseL[threadIdx.x] = histL[threadIdx.x] ? owner_off[threadIdx.x] + atomicAdd(&cursor[threadIdx.x], histL[threadIdx.x]) : 0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kEmitPer; ++q) {
+            const uint32_t j = tile * kEmitTile + q * kBlock + threadIdx.x;
+            if (own[q] != kInvalid) {
+                const uint32_t d = baseL[own[q]] + rank[q];
+                okeys[d]         = k[q];
+                ocounts[d]       = counts[j];
+                oslots[d]        = slots[j];
+            }
+        }
+        __syncthreads();
     }
 }
 // owner: sum the received records per key; remember the lowest contributing rank (it will export the pattern)
@@ -858,8 +883,14 @@ __global__ __launch_bounds__(kBlock) void shard_merge_kernel(const unsigned long
         slot_out[j] = s;
         if (s != kInvalid) atomicMin(&minrank[s], src);
     }
+    __shared__ uint32_t redL[kBlock / kWave];
     for (int off = 32; off > 0; off >>= 1) ins += __shfl_down(ins, off, kWave);
-    if ((threadIdx.x & (kWave - 1)) == 0 && ins) atomicAdd(&st->found, ins);
+    if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = ins;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t f = redL[0] + redL[1] + redL[2] + redL[3];
+        if (f) atomicAdd(&st->found, f);
+    }
 }
 // owner: how many keys reach the threshold
 __global__ __launch_bounds__(kBlock) void shard_owner_count_kernel(const Slot* __restrict__ table, DevState* __restrict__ st, uint32_t threshold) {

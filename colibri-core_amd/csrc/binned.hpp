@@ -1,0 +1,355 @@
+// binned.hpp — radix-partition + LDS count: the order-n pass WITHOUT per-window global atomics.
+//
+// Device-scope atomics run memory-side on MI355X at ~18 G/s (one address: ~83 M/s), and every 16-byte slot update moves a
+// 64-byte sector each way, so the open-addressed global table (kernels.hpp §2) tops out near 4 % of the HBM roofline. This
+// path produces the same result with streaming traffic only:
+//   emit     per 2048-window tile the block-local reduce (same LDS election as count_kernel) turns windows into records
+//            {exact 64-bit key, representative position, tile count, 16 SpookyHash bits}; rep_of[i] remembers each window's
+//            representative; a histogram over the top 8 hash bits is accumulated
+//   scatter  two tile-local counting sorts (256 bins each, LDS-staged so that a bin's records leave as one contiguous run):
+//            by hash bits 8..15 (level A), then by bits 0..7 inside each A bin (level B) -> 65 536 final bins
+//   count    one block per final bin builds that bin's table entirely in LDS (64-bit CAS + add on LDS), applies the threshold,
+//            reserves a result range with ONE global atomic, and writes the survivor id at each representative position
+//   resolve  ids[i] = ids_at[rep_of[i]]   (a gather that stays inside the tile)
+// Exactness is unchanged: keys are the exact (id_left, id_right) pairs; hash bits only choose bins. If a final bin ever
+// holds more distinct keys than its LDS table (adversarial hash skew), `st->overflow_bin` is raised and the host re-runs
+// the training with the global-table kernels.
+#pragma once
+#include "kernels.hpp"
+
+namespace colibri {
+
+struct __attribute__((aligned(16))) Rec {
+    uint64_t key;
+    uint32_t pos;   // representative position (token position index)
+    uint32_t meta;  // [31:16] 16 SpookyHash bits (A bin = [31:24], B bin = [23:16]); [15:0] occurrences inside the tile
+};
+
+constexpr int      kBins       = 256;                // per level
+constexpr int      kFinalBins  = kBins * kBins;      // 65 536
+constexpr int      kScatTile   = 4096;               // records per scatter tile (64 KB of LDS staging)
+constexpr int      kScatPer    = kScatTile / kBlock; // 16 per lane
+constexpr int      kBinSlots   = 2048;               // LDS table of one final bin
+constexpr uint32_t kBinMaxLoad = 1900;               // distinct keys a final bin may hold
+
+// small device-side bookkeeping of one binned pass
+struct BinState {
+    uint32_t nrec;               // records emitted
+    uint32_t overflow_bin;       // a final bin exceeded its LDS table -> host falls back to the global-table path
+    uint32_t pad[2];
+    uint32_t histA[kBins];       // records per A bin
+    uint32_t offA[kBins + 1];    // exclusive scan
+    uint32_t tprefA[kBins + 1];  // tiles per A bin, exclusive scan (for the level-B kernels)
+    uint32_t curA[kBins];        // scatter cursors
+    uint32_t hist2[kFinalBins];  // records per final bin, then (after the scan) their offsets
+    uint32_t total2;             // sum (written by the scan)
+    uint32_t cur2[kFinalBins];
+};
+
+// -------------------------------------------------------------------------------------------------------------------
+// emit: scan + SpookyHash + block-local reduce -> records
+// -------------------------------------------------------------------------------------------------------------------
+template <class KeyFn>
+__global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __restrict__ recs, uint32_t* __restrict__ rep_of, DevState* __restrict__ st, BinState* __restrict__ bs,
+                                                           uint32_t npos) {
+    if (st->done) return;
+    __shared__ uint64_t keyL[kCountTile];
+    __shared__ uint32_t winL[kCountLSlot];
+    __shared__ uint32_t cntL[kCountTile];
+    __shared__ uint32_t histL[kBins];
+    __shared__ uint32_t redL[kBlock / kWave];
+    __shared__ uint32_t baseL;
+    histL[threadIdx.x] = 0;
+    const uint32_t ntiles = (npos + kCountTile - 1) / kCountTile;
+    uint32_t       nadm   = 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t base = tile * kCountTile;
+        uint64_t       key[kCountPer], hash[kCountPer];
+        bool           adm[kCountPer];
+#pragma unroll
+        for (int k = 0; k < kCountPer; ++k) {
+            const uint32_t e = k * kBlock + threadIdx.x, i = base + e;
+            key[k]  = 0;
+            hash[k] = 0;
+            adm[k]  = (i < npos) && keyfn(i, npos, key[k], hash[k]);
+            cntL[e] = 0;
+            if (adm[k]) {
+                keyL[e]                                     = key[k];
+                winL[(uint32_t)hash[k] & (kCountLSlot - 1)] = e;
+            }
+        }
+        __syncthreads();
+        uint32_t rep[kCountPer], nrep = 0;
+#pragma unroll
+        for (int k = 0; k < kCountPer; ++k) {
+            const uint32_t e = k * kBlock + threadIdx.x;
+            rep[k]           = e;
+            if (adm[k]) {
+                ++nadm;
+                const uint32_t w = winL[(uint32_t)hash[k] & (kCountLSlot - 1)];
+                if (w != e && keyL[w] == key[k]) {
+                    rep[k] = w;
+                    atomicAdd(&cntL[w], 1u);
+                } else {
+                    ++nrep;
+                }
+            }
+        }
+        uint32_t       total;
+        const uint32_t excl = block_exclusive_scan(nrep, &total);  // (contains the barrier that completes cntL)
+        if (threadIdx.x == 0) baseL = total ? atomicAdd(&bs->nrec, total) : 0;
+        __syncthreads();
+        uint32_t o = baseL + excl;
+#pragma unroll
+        for (int k = 0; k < kCountPer; ++k) {
+            const uint32_t e = k * kBlock + threadIdx.x, i = base + e;
+            if (i < npos) rep_of[i] = adm[k] ? base + rep[k] : kInvalid;
+            if (adm[k] && rep[k] == e) {
+                const uint32_t hb = (uint32_t)(hash[k] >> 48);
+                Rec            r;
+                r.key  = key[k];
+                r.pos  = i;
+                r.meta = (hb << 16) | (1u + cntL[e]);
+                recs[o++] = r;
+                atomicAdd(&histL[hb >> 8], 1u);
+            }
+        }
+        __syncthreads();
+    }
+    if (histL[threadIdx.x]) atomicAdd(&bs->histA[threadIdx.x], histL[threadIdx.x]);
+    for (int off = 32; off > 0; off >>= 1) nadm += __shfl_down(nadm, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nadm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t a = redL[0] + redL[1] + redL[2] + redL[3];
+        if (a) atomicAdd(&st->admitted, a);
+    }
+}
+
+// one block: A-bin offsets and the tile prefix used by the level-B kernels
+__global__ __launch_bounds__(kBlock) void bin_offsets_kernel(BinState* __restrict__ bs) {
+    uint32_t       tot;
+    const uint32_t h = bs->histA[threadIdx.x];
+    const uint32_t o = block_exclusive_scan(h, &tot);
+    bs->offA[threadIdx.x] = o;
+    const uint32_t t  = (h + kScatTile - 1) / kScatTile;
+    uint32_t       tt;
+    const uint32_t tp = block_exclusive_scan(t, &tt);
+    bs->tprefA[threadIdx.x] = tp;
+    if (threadIdx.x == 0) {
+        bs->offA[kBins]   = tot;
+        bs->tprefA[kBins] = tt;
+    }
+}
+
+// which A bin / which tile of it does block `t` own? (LEVEL_B only)
+__device__ __forceinline__ bool locate_tile(const BinState* bs, uint32_t t, uint32_t& a, uint32_t& begin, uint32_t& end) {
+    if (t >= bs->tprefA[kBins]) return false;
+    uint32_t lo = 0, hi = kBins;  // last a with tprefA[a] <= t
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (bs->tprefA[mid] <= t)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    a     = lo;
+    begin = bs->offA[a] + (t - bs->tprefA[a]) * kScatTile;
+    end   = min(bs->offA[a + 1], begin + (uint32_t)kScatTile);
+    return true;
+}
+
+// level-B histogram: records per final bin
+__global__ __launch_bounds__(kBlock) void bin_hist2_kernel(const Rec* __restrict__ recs, const DevState* __restrict__ st, BinState* __restrict__ bs) {
+    if (st->done) return;
+    __shared__ uint32_t histL[kBins];
+    uint32_t            a, begin, end;
+    if (!locate_tile(bs, blockIdx.x, a, begin, end)) return;
+    histL[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t j = begin + threadIdx.x; j < end; j += kBlock) atomicAdd(&histL[(recs[j].meta >> 16) & 255u], 1u);
+    __syncthreads();
+    if (histL[threadIdx.x]) atomicAdd(&bs->hist2[a * kBins + threadIdx.x], histL[threadIdx.x]);
+}
+
+// tile-local counting sort + one reserved output run per (tile, bin)
+template <bool LEVEL_B>
+__global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restrict__ in, Rec* __restrict__ out, const DevState* __restrict__ st, BinState* __restrict__ bs) {
+    if (st->done) return;
+    __shared__ Rec      recL[kScatTile];
+    __shared__ uint32_t histL[kBins], offL[kBins], gbaseL[kBins];
+    uint32_t            a = 0, begin, end;
+    if (LEVEL_B) {
+        if (!locate_tile(bs, blockIdx.x, a, begin, end)) return;
+    } else {
+        const uint32_t nrec = bs->nrec;
+        begin               = blockIdx.x * kScatTile;
+        if (begin >= nrec) return;
+        end = min(nrec, begin + (uint32_t)kScatTile);
+    }
+    histL[threadIdx.x] = 0;
+    __syncthreads();
+    Rec      r[kScatPer];
+    uint32_t rank[kScatPer];
+#pragma unroll
+    for (int q = 0; q < kScatPer; ++q) {
+        const uint32_t j = begin + q * kBlock + threadIdx.x;
+        if (j < end) {
+            r[q]             = in[j];
+            const uint32_t b = LEVEL_B ? ((r[q].meta >> 16) & 255u) : (r[q].meta >> 24);
+            rank[q]          = atomicAdd(&histL[b], 1u);
+        }
+    }
+    __syncthreads();
+    {
+        uint32_t       tot;
+        const uint32_t h   = histL[threadIdx.x];
+        offL[threadIdx.x]  = block_exclusive_scan(h, &tot);
+        uint32_t g         = 0;
+        if (h) {
+            if (LEVEL_B)
+                g = bs->hist2[a * kBins + threadIdx.x] + atomicAdd(&bs->cur2[a * kBins + threadIdx.x], h);  // hist2 holds offsets after the scan
+            else
+                g = bs->offA[threadIdx.x] + atomicAdd(&bs->curA[threadIdx.x], h);
+        }
+        gbaseL[threadIdx.x] = g;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kScatPer; ++q) {
+        const uint32_t j = begin + q * kBlock + threadIdx.x;
+        if (j < end) {
+            const uint32_t b       = LEVEL_B ? ((r[q].meta >> 16) & 255u) : (r[q].meta >> 24);
+            recL[offL[b] + rank[q]] = r[q];
+        }
+    }
+    __syncthreads();
+    const uint32_t n = end - begin;
+    for (uint32_t j = threadIdx.x; j < n; j += kBlock) {
+        const Rec      x = recL[j];
+        const uint32_t b = LEVEL_B ? ((x.meta >> 16) & 255u) : (x.meta >> 24);
+        out[gbaseL[b] + (j - offL[b])] = x;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// count: one block per final bin, table in LDS
+// -------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
+                                                            uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap, uint32_t* __restrict__ ids_at) {
+    if (st->done) return;
+    const uint32_t f     = blockIdx.x;
+    const uint32_t begin = bs->hist2[f];
+    const uint32_t end   = (f + 1 < (uint32_t)kFinalBins) ? bs->hist2[f + 1] : bs->total2;
+    if (begin >= end) return;
+    __shared__ unsigned long long keyT[kBinSlots];
+    __shared__ uint32_t           cntT[kBinSlots], repT[kBinSlots], idT[kBinSlots];
+    __shared__ uint32_t           baseL, redL[kBlock / kWave], failL;
+    for (int s = threadIdx.x; s < kBinSlots; s += kBlock) {
+        keyT[s] = kEmptyKey;
+        cntT[s] = 0;
+        repT[s] = 0xFFFFFFFFu;
+    }
+    if (threadIdx.x == 0) failL = 0;
+    __syncthreads();
+    uint32_t nnew = 0;
+    for (uint32_t j = begin + threadIdx.x; j < end; j += kBlock) {
+        const Rec x = recs[j];
+        uint32_t  s = (uint32_t)mix64(x.key) & (kBinSlots - 1);
+        bool      ok = false;
+        for (int probe = 0; probe < kBinSlots; ++probe) {
+            const unsigned long long old = atomicCAS(&keyT[s], (unsigned long long)kEmptyKey, (unsigned long long)x.key);
+            if (old == kEmptyKey) {
+                ++nnew;
+                ok = true;
+                break;
+            }
+            if (old == x.key) {
+                ok = true;
+                break;
+            }
+            s = (s + 1) & (kBinSlots - 1);
+        }
+        if (ok) {
+            atomicAdd(&cntT[s], x.meta & 0xFFFFu);
+            atomicMin(&repT[s], x.pos);  // smallest representative position: deterministic
+        } else {
+            failL = 1;
+        }
+    }
+    // distinct keys of this bin
+    for (int off = 32; off > 0; off >>= 1) nnew += __shfl_down(nnew, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nnew;
+    __syncthreads();
+    const uint32_t distinct = redL[0] + redL[1] + redL[2] + redL[3];
+    if (failL || distinct > kBinMaxLoad) {
+        if (threadIdx.x == 0) {
+            bs->overflow_bin = 1;
+            st->pad[0]       = 1;  // sticky across orders: BinState is zeroed per order
+        }
+        return;
+    }
+    // survivors -> one reserved result range per bin
+    uint32_t keep = 0;
+#pragma unroll
+    for (int q = 0; q < kBinSlots / kBlock; ++q) {
+        const int s = threadIdx.x * (kBinSlots / kBlock) + q;
+        keep += (keyT[s] != kEmptyKey && cntT[s] >= threshold);
+    }
+    uint32_t       total;
+    const uint32_t excl = block_exclusive_scan(keep, &total);
+    if (threadIdx.x == 0) {
+        baseL = total ? atomicAdd(&st->kept, total) : 0;
+        atomicAdd(&st->found, distinct);
+    }
+    __syncthreads();
+    uint32_t r = st->res_total + baseL + excl;
+#pragma unroll
+    for (int q = 0; q < kBinSlots / kBlock; ++q) {
+        const int s  = threadIdx.x * (kBinSlots / kBlock) + q;
+        uint32_t  id = kInvalid;
+        if (keyT[s] != kEmptyKey && cntT[s] >= threshold) {
+            if (r < res_cap) {
+                res_rep[r] = repT[s];
+                res_cnt[r] = cntT[s];
+                id         = r;
+            } else {
+                st->overflow = 1;
+            }
+            ++r;
+        }
+        idT[s] = id;
+    }
+    __syncthreads();
+    // survivor id at every representative position of a surviving key (ids_at was pre-filled with kInvalid)
+    for (uint32_t j = begin + threadIdx.x; j < end; j += kBlock) {
+        const Rec x = recs[j];
+        uint32_t  s = (uint32_t)mix64(x.key) & (kBinSlots - 1);
+        while (keyT[s] != x.key) s = (s + 1) & (kBinSlots - 1);
+        const uint32_t id = idT[s];
+        if (id != kInvalid) ids_at[x.pos] = id;
+    }
+}
+
+// ids[i] = survivor id found at the window's representative position
+__global__ __launch_bounds__(kBlock) void bin_resolve_kernel(const uint32_t* __restrict__ rep_of, const uint32_t* __restrict__ ids_at, uint32_t* __restrict__ ids,
+                                                              DevState* __restrict__ st, uint32_t npos) {
+    if (st->done) return;
+    uint32_t nvalid = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npos; i += gridDim.x * kBlock) {
+        const uint32_t r  = rep_of[i];
+        const uint32_t id = (r != kInvalid) ? ids_at[r] : kInvalid;
+        nvalid += id != kInvalid;
+        ids[i] = id;
+    }
+    __shared__ uint32_t redL[kBlock / kWave];
+    for (int off = 32; off > 0; off >>= 1) nvalid += __shfl_down(nvalid, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nvalid;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t v = redL[0] + redL[1] + redL[2] + redL[3];
+        if (v) atomicAdd(&st->valid, v);
+    }
+}
+
+}  // namespace colibri

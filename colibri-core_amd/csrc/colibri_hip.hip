@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "colibri_hip.h"
+#include "binned.hpp"
 #include "kernels.hpp"
 
 using namespace colibri;
@@ -63,6 +64,10 @@ struct colibri_ctx {
     DevBuf<uint32_t>  ref_sentence;
     DevBuf<uint16_t>  ref_token;
     DevBuf<Slot>      table;
+    DevBuf<Rec>       recs[2];          // binned path: record ping-pong
+    DevBuf<uint32_t>  rep_of, ids_at;   // binned path: representative position per window; survivor id at representative positions
+    DevBuf<BinState>  binstate;
+    int               last_mode = 0;    // 1 = global table, 2 = binned (what the last train() actually ran)
     struct Segment {
         uint32_t first, count;
         int      n;
@@ -335,6 +340,11 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->scratch[0]);
     dev_free(c->scratch[1]);
     dev_free(c->nsrc);
+    dev_free(c->recs[0]);
+    dev_free(c->recs[1]);
+    dev_free(c->rep_of);
+    dev_free(c->ids_at);
+    dev_free(c->binstate);
     for (int k = 0; k < 2; ++k) {
         dev_free(c->pair_id[k]);
         dev_free(c->pair_pos[k]);
@@ -461,6 +471,36 @@ void launch_prune(colibri_ctx* c, const TrainPlan& pl, uint32_t thr, const uint3
 void launch_resolve(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids) {
     Prof p(c, COLIBRI_K_RESOLVE);
     hipLaunchKernelGGL(resolve_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, ids, c->table.p, c->state.p, pl.npos);
+}
+
+// ---- binned path: one order = emit -> scatter A -> hist2 -> scan -> scatter B -> per-bin LDS count -> resolve --------------
+template <class KeyFn>
+int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t* ids_out) {
+    const uint32_t tiles = blocks_for(pl.npos, kScatTile) + 1;
+    HIP_TRY(c, hipMemsetAsync(c->binstate.p, 0, sizeof(BinState), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->ids_at.p, 0xFF, sizeof(uint32_t) * (size_t)pl.npos, c->stream));
+    {
+        Prof p(c, COLIBRI_K_EMIT);
+        hipLaunchKernelGGL((bin_emit_kernel<KeyFn>), dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, fn, c->recs[0].p, c->rep_of.p, c->state.p, c->binstate.p, pl.npos);
+    }
+    {
+        Prof p(c, COLIBRI_K_SCATTER);
+        hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->binstate.p);
+        hipLaunchKernelGGL((bin_scatter_kernel<false>), dim3(tiles), dim3(kBlock), 0, c->stream, c->recs[0].p, c->recs[1].p, c->state.p, c->binstate.p);
+        hipLaunchKernelGGL(bin_hist2_kernel, dim3(tiles + kBins), dim3(kBlock), 0, c->stream, c->recs[1].p, c->state.p, c->binstate.p);
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, &c->binstate.p->hist2[0], (uint32_t)kFinalBins, &c->binstate.p->total2);
+        hipLaunchKernelGGL((bin_scatter_kernel<true>), dim3(tiles + kBins), dim3(kBlock), 0, c->stream, c->recs[1].p, c->recs[0].p, c->state.p, c->binstate.p);
+    }
+    {
+        Prof p(c, COLIBRI_K_BINCOUNT);
+        hipLaunchKernelGGL(bin_count_kernel, dim3(kFinalBins), dim3(kBlock), 0, c->stream, c->recs[0].p, c->state.p, c->binstate.p, pl.thr, c->res_rep.p, c->res_cnt.p, pl.res_cap,
+                           c->ids_at.p);
+    }
+    {
+        Prof p(c, COLIBRI_K_RESOLVE);
+        hipLaunchKernelGGL(bin_resolve_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->rep_of.p, c->ids_at.p, ids_out, c->state.p, pl.npos);
+    }
+    return COLIBRI_OK;
 }
 
 // One (order, gap mask) skipgram pass. Exact identity of a skipgram = the survivor ids of its contiguous parts, paired
@@ -630,6 +670,9 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
 
     const uint32_t npos   = c->npos;
     const bool     synced = o.indexed || o.doskipgrams || o.doskipgrams_exhaustive;  // these modes keep every order's ids and talk to the host per order
+    // radix-partition + LDS count (binned.hpp) for the plain n-gram path when every final bin fits its LDS table: 65 536 bins
+    // x <= ~1000 distinct keys expected; beyond ~128 M tokens per device (or on request) the global open-addressed table is used
+    bool binned = !synced && (o.table_mode == 2 || (o.table_mode == 0 && c->ntokens <= 128ull * 1000 * 1000));
     // ---- HBM layout (sized once; nothing is allocated inside the unsynced order loop) ----------------
     // table: an order admits at most `npos` windows -> 1.5x slots; results: every survivor has >= 2 occurrences
     const uint64_t table_slots64 = (uint64_t)npos + (npos >> 1) + 2048;
@@ -649,7 +692,12 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     if (c->ids.size() < 2) c->ids.resize(2);
     if ((rc = dev_alloc(c, c->ids[0], (size_t)npos + 1))) return rc;
     if ((rc = dev_alloc(c, c->ids[1], (size_t)npos + 1))) return rc;
-    if ((rc = dev_alloc(c, c->table, pl.table_slots))) return rc;
+    if (binned) {
+        if ((rc = dev_alloc(c, c->recs[0], (size_t)npos + 1)) || (rc = dev_alloc(c, c->recs[1], (size_t)npos + 1))) return rc;
+        if ((rc = dev_alloc(c, c->rep_of, (size_t)npos + 1)) || (rc = dev_alloc(c, c->ids_at, (size_t)npos + 1)) || (rc = dev_alloc(c, c->binstate, 1))) return rc;
+    } else if ((rc = dev_alloc(c, c->table, pl.table_slots))) {
+        return rc;
+    }
     if ((rc = dev_alloc(c, c->res_rep, pl.res_cap))) return rc;
     if ((rc = dev_alloc(c, c->res_cnt, pl.res_cap))) return rc;
     if ((rc = dev_alloc(c, c->state, 1))) return rc;
@@ -679,13 +727,21 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
         for (int n = 1; n <= maxlength; ++n) {
             uint32_t* id_prev = c->ids[cur].p;
             uint32_t* id_cur  = c->ids[cur ^ 1].p;
-            launch_clear(c, pl);
-            if (n == 1)
-                launch_count(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, id_cur, 3, COLIBRI_K_COUNT);
-            else
-                launch_count(c, pl, KeyNgram{c->bytes.p, c->tokstart.p, id_prev, n}, id_cur, 3, COLIBRI_K_COUNT);
-            launch_prune(c, pl, pl.thr, nullptr, 0);
-            launch_resolve(c, pl, id_cur);
+            if (binned) {
+                if (n == 1)
+                    rc = binned_order(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, id_cur);
+                else
+                    rc = binned_order(c, pl, KeyNgram{c->bytes.p, c->tokstart.p, id_prev, n}, id_cur);
+                if (rc) return rc;
+            } else {
+                launch_clear(c, pl);
+                if (n == 1)
+                    launch_count(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, id_cur, 3, COLIBRI_K_COUNT);
+                else
+                    launch_count(c, pl, KeyNgram{c->bytes.p, c->tokstart.p, id_prev, n}, id_cur, 3, COLIBRI_K_COUNT);
+                launch_prune(c, pl, pl.thr, nullptr, 0);
+                launch_resolve(c, pl, id_cur);
+            }
             hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, n, pl.table_slots);
             cur ^= 1;
             // peek at the termination flag only every 8 orders (MAXLENGTH defaults to 100)
@@ -697,6 +753,13 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             }
         }
         if ((rc = read_state(c))) return rc;
+        if (binned && c->hstate.pad[0]) {  // a final bin outgrew its LDS table (hash skew): run again on the global table — loud, exact, rare
+            if (o.table_mode == 2) return fail(c, COLIBRI_ERR_OVERFLOW, "a radix bin outgrew its LDS table (table_mode = 2 forbids the global-table rerun)");
+            colibri_options again = o;
+            again.table_mode      = 1;
+            return colibri_train(c, &again, stats_out);
+        }
+        c->last_mode = binned ? 2 : 1;
         s.maxn = (int32_t)c->hstate.maxn;
         for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) {
             s.found[n]    = c->hstate.s_found[n];

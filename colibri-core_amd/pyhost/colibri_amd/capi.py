@@ -13,8 +13,8 @@ PKG_ROOT = os.path.dirname(os.path.dirname(HERE))  # colibri-core_amd/
 LIB_PATH = os.environ.get("COLIBRI_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libcolibri_hip.so")  # env override: kernel experiments only
 
 MAX_ORDER = 128
-K_TOKENISE, K_CLEAR, K_COUNT, K_PRUNE, K_RESOLVE, K_SKIPGRAM, K_INDEX, K_EXPORT = range(8)
-KERNEL_CLASSES = ["tokenise", "clear", "count", "prune", "resolve", "skipgram", "index", "export"]
+K_TOKENISE, K_CLEAR, K_COUNT, K_PRUNE, K_RESOLVE, K_SKIPGRAM, K_INDEX, K_EXPORT, K_EMIT, K_SCATTER, K_BINCOUNT = range(11)
+KERNEL_CLASSES = ["tokenise", "clear", "count", "prune", "resolve", "skipgram", "index", "export", "emit", "scatter", "bincount"]
 
 EXPORTED = [
     "colibri_abi_version", "colibri_create", "colibri_destroy", "colibri_last_error", "colibri_upload_corpus",
@@ -29,7 +29,7 @@ class Options(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "mintokens", "maxlength", "minlength", "maxbackofflength", "mintokens_unigrams", "mintokens_skipgrams", "minskiptypes",
         "maxskips", "doskipgrams", "doskipgrams_exhaustive", "dopatternperline", "prunenonsubsumed", "prunesubsumed", "indexed",
-        "profile", "reserved")]
+        "profile", "table_mode")]
 
     @classmethod
     def defaults(cls, **kw):

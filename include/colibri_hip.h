@@ -55,7 +55,7 @@ typedef struct colibri_options {
     int32_t prunesubsumed;          /* PRUNESUBSUMED (must be 0)                                                  */
     int32_t indexed;                /* 0: PatternModel<uint32_t> (model type 10), 1: IndexedPatternModel<> (20)   */
     int32_t profile;                /* 1: bracket every kernel class with HIP events (colibri_kernel_time)        */
-    int32_t reserved;
+    int32_t table_mode;             /* 0: automatic; 1: force the global open-addressed table; 2: force radix-partition + LDS count */
 } colibri_options;
 
 /* What train() reports: the numbers the reference keeps in the model (totaltokens/totaltypes/maxn/minn,
@@ -86,7 +86,10 @@ enum {
     COLIBRI_K_SKIPGRAM = 5, /* skipgram counting                                                 */
     COLIBRI_K_INDEX    = 6, /* forward-index build                                               */
     COLIBRI_K_EXPORT   = 7,
-    COLIBRI_K_NCLASSES = 8
+    COLIBRI_K_EMIT     = 8,  /* binned path: scan + SpookyHash + block-local reduce -> (key, position, count) records */
+    COLIBRI_K_SCATTER  = 9,  /* binned path: two-level radix partition of the records by hash bits            */
+    COLIBRI_K_BINCOUNT = 10, /* binned path: per-bin LDS hash build + threshold + survivor ids                */
+    COLIBRI_K_NCLASSES = 11
 };
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */

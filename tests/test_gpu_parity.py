@@ -64,7 +64,7 @@ def test_window_hashes_match_reference_hash(ctx, n):
 
 def _compare(ctx, payload, maxlength, mintokens=2, firstsentence=1, **mode):
     import oracle
-    want = oracle.train(payload, mintokens, maxlength, firstsentence=firstsentence, **mode)
+    want = oracle.train(payload, mintokens, maxlength, firstsentence=firstsentence, **{k: v for k, v in mode.items() if k != "table_mode"})
     ctx.upload(payload, first_sentence=firstsentence)
     st = ctx.train(mintokens=mintokens, maxlength=maxlength, **mode)
     got, gotrefs = ctx.export_dict()
@@ -85,8 +85,10 @@ def _compare(ctx, payload, maxlength, mintokens=2, firstsentence=1, **mode):
 
 @pytest.mark.parametrize("name", sorted(small_corpora()))
 @pytest.mark.parametrize("maxlength", [1, 3, 5, 100])
-def test_train_matches_oracle(ctx, name, maxlength):
-    _compare(ctx, small_corpora()[name], maxlength)
+@pytest.mark.parametrize("table_mode", [1, 2], ids=["global_table", "radix_bins"])
+def test_train_matches_oracle(ctx, name, maxlength, table_mode):
+    """both implementations of the order-n pass: the open-addressed global table (device atomics) and radix partition + LDS count"""
+    _compare(ctx, small_corpora()[name], maxlength, table_mode=table_mode)
 
 
 @pytest.mark.parametrize("mintokens", [2, 3, 5, -1, 10])
@@ -132,11 +134,12 @@ def test_flexgram_class_in_corpus_is_rejected(ctx):
         ctx.upload(b"\x06\x04\x04\x07\x00")
 
 
-def test_medium_zipf_properties(ctx):
+@pytest.mark.parametrize("table_mode", [1, 2], ids=["global_table", "radix_bins"])
+def test_medium_zipf_properties(ctx, table_mode):
     """1M-token Zipf corpus: full parity against the oracle (about a second of CPU)."""
     from colibri_amd import synth
     payload = synth.zipf_corpus(10**6, 10**5, 42, scalar_draws=True, header=False)
-    st = _compare(ctx, payload, 5)
+    st = _compare(ctx, payload, 5, table_mode=table_mode)
     # the survey's reference run on this exact corpus kept 56240/61036/15024/1369/44 (SURVEY.md §8d)
     assert [st.kept[n] for n in range(1, 6)] == [56240, 61036, 15024, 1369, 44]
 

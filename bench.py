@@ -33,22 +33,18 @@ MAXLENGTH, MINTOKENS = 5, 2
 
 
 def algorithmic_bytes(nbytes, npos, stats, maxlength):
-    """SURVEY.md §8(d), per order n, for the count kernel (scan + hash + table build):
-         B + 4*(T+S)            corpus bytes + token-start vector, read once
-       + [n>1] * W_n * 2/8      two survivor bits per window (look-back)
-       + P_n * (8 + 4 + 4)      per admitted window: key read, count read, count write
-       + D_n * (8 + 4)          per distinct candidate: key + count written once
-       (the T/8 survivor-bitmap write of the formula belongs to the resolve kernel and is left out)."""
-    total = 0.0
-    per_order = []
+    """SURVEY.md §8(d), per order n, for the counting stage (scan + hash + table build):
+         scan share   B + 4*(T+S)            corpus bytes + token-start vector, read once
+                    + [n>1] * W_n * 2/8      two survivor bits per window (look-back)
+         build share  P_n * (8 + 4 + 4)      per admitted window: key read, count read, count write
+                    + D_n * (8 + 4)          per distinct candidate: key + count written once
+       (the T/8 survivor-bitmap write of the formula belongs to the resolve kernel and is left out).
+       Returns (scan bytes, build bytes) summed over the orders."""
+    scan = build = 0.0
     for n in range(1, maxlength + 1):
-        b = nbytes + 4.0 * npos
-        if n > 1:
-            b += stats.windows[n] * 2.0 / 8.0
-        b += stats.admitted[n] * 16.0 + stats.found[n] * 12.0
-        per_order.append(b)
-        total += b
-    return total, per_order
+        scan += nbytes + 4.0 * npos + (stats.windows[n] * 2.0 / 8.0 if n > 1 else 0.0)
+        build += stats.admitted[n] * 16.0 + stats.found[n] * 12.0
+    return scan, build
 
 
 def cpu_baseline(sample_tokens, vocab):
@@ -79,13 +75,13 @@ def cpu_baseline(sample_tokens, vocab):
             "seconds": round(dt, 3), "host_cores": os.cpu_count()}
 
 
-def measured_traffic(workload_tokens):
-    """HBM bytes per count-kernel launch from the committed rocprofv3 PMC passes (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "pmc_count_kernel.json")
+def measured_traffic(workload_tokens, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        if int(d.get("tokens", 0)) == int(workload_tokens):
+        if int(d.get("tokens", 0)) == int(workload_tokens) and d.get("kernel") == kernel:
             return d.get("hbm_bytes_per_launch")
     except Exception:
         pass
@@ -161,12 +157,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    count_ms, count_launches = 0.0, 0
+    kclasses = (capi.K_CLEAR, capi.K_COUNT, capi.K_PRUNE, capi.K_RESOLVE, capi.K_EMIT, capi.K_SCATTER, capi.K_BINCOUNT)
+    kms = {k: 0.0 for k in kclasses}
+    kn = {k: 0 for k in kclasses}
     for _ in range(args.steps):
         st = step()
-        ms, n = ctx.kernel_time(capi.K_COUNT)  # HIP events on the library's own stream, this step
-        count_ms += ms
-        count_launches += n
+        for k in kclasses:  # HIP events on the library's own stream, this step
+            ms, n = ctx.kernel_time(k)
+            kms[k] += ms
+            kn[k] += n
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -175,7 +174,7 @@ def main():
     npatterns = int(st.npatterns)
     if dist is not None:
         where = device if args.backend == "nccl" else "cpu"
-        t = torch.tensor([elapsed, float(windows), float(npatterns), count_ms], dtype=torch.float64, device=where)
+        t = torch.tensor([elapsed, float(windows), float(npatterns)], dtype=torch.float64, device=where)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -186,10 +185,18 @@ def main():
         return
 
     value = windows * args.steps / elapsed / 1e6
-    abytes, _ = algorithmic_bytes(payload.size, ctx.positions(), st, MAXLENGTH)
-    launches_per_step = count_launches / max(1, args.steps)
-    avg_launch_ms = count_ms / max(1, count_launches)
-    achieved = (abytes / max(1.0, launches_per_step)) / (avg_launch_ms * 1e-3) / 1e9 if count_launches else 0.0
+    scan_b, build_b = algorithmic_bytes(payload.size, ctx.positions(), st, MAXLENGTH)
+    binned = kn[capi.K_BINCOUNT] > 0
+    # the dominant kernel: radix path -> bin_count_kernel (per-bin LDS hash build; the build share of the formula);
+    #                      global-table path -> count_kernel (scan + hash + build in one launch per order)
+    dom = capi.K_BINCOUNT if binned else capi.K_COUNT
+    dom_bytes = build_b if binned else scan_b + build_b
+    launches_per_step = kn[dom] / max(1, args.steps)
+    avg_launch_ms = kms[dom] / max(1, kn[dom])
+    achieved = (dom_bytes / max(1.0, launches_per_step)) / (avg_launch_ms * 1e-3) / 1e9 if kn[dom] else 0.0
+    stage = (capi.K_EMIT, capi.K_SCATTER, capi.K_BINCOUNT) if binned else (capi.K_COUNT,)
+    stage_ms = sum(kms[k] for k in stage) / max(1, args.steps)
+    stage_gbs = (scan_b + build_b) / (stage_ms * 1e-3) / 1e9 if stage_ms else 0.0
     out = {
         "metric": "M patterns counted/sec at n<=5 thr=2; identical pattern set vs reference",
         "value": round(value, 3),
@@ -215,17 +222,21 @@ def main():
             "corpus_generation_s_untimed": round(gen_s, 2),
         },
         "roofline": {
-            "kernel": "colibri::count_kernel (scan + SpookyHash + hash-table build), one launch per order",
+            "kernel": ("colibri::bin_count_kernel (per-bin LDS hash build + threshold + survivor ids; one launch per order)" if binned else
+                       "colibri::count_kernel (scan + SpookyHash + global hash-table build; one launch per order)"),
             "bound": "hbm",
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": measured_traffic(args.tokens) if args.gpus == 1 else None,
-            "algorithmic_bytes_per_launch": round(abytes / max(1.0, launches_per_step)),
+            "traffic": measured_traffic(args.tokens, "bin_count_kernel" if binned else "count_kernel") if args.gpus == 1 else None,
+            "algorithmic_bytes_per_launch": round(dom_bytes / max(1.0, launches_per_step)),
             "avg_launch_ms": round(avg_launch_ms, 4),
             "launches_per_step": launches_per_step,
-            "kernel_ms_per_step": {capi.KERNEL_CLASSES[k]: round(ctx.kernel_time(k)[0], 4) for k in (capi.K_CLEAR, capi.K_COUNT, capi.K_PRUNE, capi.K_RESOLVE)},
+            "counting_stage": {"kernels": [capi.KERNEL_CLASSES[k] for k in stage], "ms_per_step": round(stage_ms, 4),
+                               "algorithmic_bytes_per_step": round(scan_b + build_b), "achieved_GBps": round(stage_gbs, 2),
+                               "frac": round(stage_gbs / HBM_PEAK_GBS, 5)},
+            "kernel_ms_per_step": {capi.KERNEL_CLASSES[k]: round(kms[k] / max(1, args.steps), 4) for k in kclasses if kn[k]},
         },
     }
     if args.gpus == 1 and args.cpu_sample > 0:

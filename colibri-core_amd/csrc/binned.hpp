@@ -27,7 +27,10 @@ struct __attribute__((aligned(16))) Rec {
 
 constexpr int      kBins       = 256;                // per level
 constexpr int      kFinalBins  = kBins * kBins;      // 65 536
-constexpr int      kScatTile   = 4096;               // records per scatter tile (64 KB of LDS staging)
+#ifndef COLIBRI_SCAT_TILE
+#define COLIBRI_SCAT_TILE 4096
+#endif
+constexpr int      kScatTile   = COLIBRI_SCAT_TILE;  // records per scatter tile (16 B each of LDS staging)
 constexpr int      kScatPer    = kScatTile / kBlock; // 16 per lane
 constexpr int      kBinSlots   = 2048;               // LDS table of one final bin
 constexpr uint32_t kBinMaxLoad = 1900;               // distinct keys a final bin may hold
@@ -44,6 +47,7 @@ struct BinState {
     uint32_t hist2[kFinalBins];  // records per final bin, then (after the scan) their offsets
     uint32_t total2;             // sum (written by the scan)
     uint32_t cur2[kFinalBins];
+    uint32_t found_part[kBins];  // distinct keys, accumulated per A bin (a single counter would serialise 65 536 atomics)
 };
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -235,8 +239,11 @@ __global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restri
 // -------------------------------------------------------------------------------------------------------------------
 // count: one block per final bin, table in LDS
 // -------------------------------------------------------------------------------------------------------------------
+// Survivors are written WITHOUT any global atomic: bin f owns the index range [hist2[f], hist2[f+1]) of the per-order sparse
+// arrays (it has at least as many records as survivors); the survivor id handed to the next order is id_base + that sparse
+// index — ids only have to be unique. compact_results_kernel turns the sparse arrays into the dense result list.
 __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
-                                                            uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap, uint32_t* __restrict__ ids_at) {
+                                                            uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt, uint32_t* __restrict__ ids_at) {
     if (st->done) return;
     const uint32_t f     = blockIdx.x;
     const uint32_t begin = bs->hist2[f];
@@ -244,8 +251,13 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict
     if (begin >= end) return;
     __shared__ unsigned long long keyT[kBinSlots];
     __shared__ uint32_t           cntT[kBinSlots], repT[kBinSlots], idT[kBinSlots];
-    __shared__ uint32_t           baseL, redL[kBlock / kWave], failL;
-    for (int s = threadIdx.x; s < kBinSlots; s += kBlock) {
+    __shared__ uint32_t           redL[kBlock / kWave], failL;
+    // table size follows the bin: >= 2x its records (so never more than half full), a power of two in [256, 2048] — small
+    // orders touch 65 536 mostly tiny bins and must not pay 40 KB of LDS initialisation each
+    uint32_t nslots = kBlock;
+    while (nslots < (uint32_t)kBinSlots && nslots < 2u * (end - begin)) nslots <<= 1;
+    const uint32_t smask = nslots - 1;
+    for (uint32_t s = threadIdx.x; s < nslots; s += kBlock) {
         keyT[s] = kEmptyKey;
         cntT[s] = 0;
         repT[s] = 0xFFFFFFFFu;
@@ -255,9 +267,9 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict
     uint32_t nnew = 0;
     for (uint32_t j = begin + threadIdx.x; j < end; j += kBlock) {
         const Rec x = recs[j];
-        uint32_t  s = (uint32_t)mix64(x.key) & (kBinSlots - 1);
+        uint32_t  s = (uint32_t)mix64(x.key) & smask;
         bool      ok = false;
-        for (int probe = 0; probe < kBinSlots; ++probe) {
+        for (uint32_t probe = 0; probe < nslots; ++probe) {
             const unsigned long long old = atomicCAS(&keyT[s], (unsigned long long)kEmptyKey, (unsigned long long)x.key);
             if (old == kEmptyKey) {
                 ++nnew;
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict
                 ok = true;
                 break;
             }
-            s = (s + 1) & (kBinSlots - 1);
+            s = (s + 1) & smask;
         }
         if (ok) {
             atomicAdd(&cntT[s], x.meta & 0xFFFFu);
@@ -290,45 +302,86 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict
         return;
     }
     // survivors -> one reserved result range per bin
-    uint32_t keep = 0;
-#pragma unroll
-    for (int q = 0; q < kBinSlots / kBlock; ++q) {
-        const int s = threadIdx.x * (kBinSlots / kBlock) + q;
+    const uint32_t per = nslots / kBlock;  // 1..8 consecutive slots per lane
+    uint32_t       keep = 0;
+    for (uint32_t q = 0; q < per; ++q) {
+        const uint32_t s = threadIdx.x * per + q;
         keep += (keyT[s] != kEmptyKey && cntT[s] >= threshold);
     }
     uint32_t       total;
     const uint32_t excl = block_exclusive_scan(keep, &total);
-    if (threadIdx.x == 0) {
-        baseL = total ? atomicAdd(&st->kept, total) : 0;
-        atomicAdd(&st->found, distinct);
-    }
-    __syncthreads();
-    uint32_t r = st->res_total + baseL + excl;
-#pragma unroll
-    for (int q = 0; q < kBinSlots / kBlock; ++q) {
-        const int s  = threadIdx.x * (kBinSlots / kBlock) + q;
-        uint32_t  id = kInvalid;
+    if (threadIdx.x == 0) atomicAdd(&bs->found_part[f >> 8], distinct);
+    const uint32_t id_base = st->pad[1];  // survivor ids of this order start here
+    uint32_t       r       = begin + excl;
+    for (uint32_t q = 0; q < per; ++q) {
+        const uint32_t s  = threadIdx.x * per + q;
+        uint32_t       id = kInvalid;
         if (keyT[s] != kEmptyKey && cntT[s] >= threshold) {
-            if (r < res_cap) {
-                res_rep[r] = repT[s];
-                res_cnt[r] = cntT[s];
-                id         = r;
-            } else {
-                st->overflow = 1;
-            }
+            sp_rep[r] = repT[s];
+            sp_cnt[r] = cntT[s];
+            id        = id_base + r;
             ++r;
         }
         idT[s] = id;
     }
+    for (uint32_t j = begin + total + threadIdx.x; j < end; j += kBlock) sp_cnt[j] = 0;  // the unused tail of this bin's range
     __syncthreads();
+    if (total == 0) return;  // nothing in this bin survives: ids_at keeps its kInvalid fill
     // survivor id at every representative position of a surviving key (ids_at was pre-filled with kInvalid)
     for (uint32_t j = begin + threadIdx.x; j < end; j += kBlock) {
         const Rec x = recs[j];
-        uint32_t  s = (uint32_t)mix64(x.key) & (kBinSlots - 1);
-        while (keyT[s] != x.key) s = (s + 1) & (kBinSlots - 1);
+        uint32_t  s = (uint32_t)mix64(x.key) & smask;
+        while (keyT[s] != x.key) s = (s + 1) & smask;
         const uint32_t id = idT[s];
         if (id != kInvalid) ids_at[x.pos] = id;
     }
+}
+
+// sparse per-order survivors -> dense result list (block-tiled reservation: one atomic per 4096 entries)
+__global__ __launch_bounds__(kBlock) void compact_results_kernel(const uint32_t* __restrict__ sp_rep, const uint32_t* __restrict__ sp_cnt, DevState* __restrict__ st,
+                                                                  const BinState* __restrict__ bs, uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap) {
+    if (st->done) return;
+    __shared__ uint32_t baseL;
+    const uint32_t      n = bs->nrec, res_base = st->res_total;
+    const uint32_t      ntiles = (n + kPruneTile - 1) / kPruneTile;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t j0 = tile * kPruneTile + threadIdx.x * kPrunePer;
+        uint32_t       c[kPrunePer], k = 0;
+#pragma unroll
+        for (int q = 0; q < kPrunePer; ++q) {
+            c[q] = (j0 + q < n) ? sp_cnt[j0 + q] : 0u;
+            k += c[q] != 0;
+        }
+        uint32_t       total;
+        const uint32_t excl = block_exclusive_scan(k, &total);
+        if (threadIdx.x == 0) baseL = total ? atomicAdd(&st->kept, total) : 0;
+        __syncthreads();
+        uint32_t r = res_base + baseL + excl;
+#pragma unroll
+        for (int q = 0; q < kPrunePer; ++q) {
+            if (c[q]) {
+                if (r < res_cap) {
+                    res_rep[r] = sp_rep[j0 + q];
+                    res_cnt[r] = c[q];
+                } else {
+                    st->overflow = 1;
+                }
+                ++r;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// bookkeeping between orders on the binned path: found = sum of the partial counters; survivor-id base moves on by nrec
+__global__ void bin_advance_prepare_kernel(DevState* __restrict__ st, const BinState* __restrict__ bs) {
+    if (st->done) return;
+    uint32_t f = 0;
+    for (int a = 0; a < kBins; ++a) f += bs->found_part[a];
+    st->found = f;
+    const uint64_t next = (uint64_t)st->pad[1] + bs->nrec;
+    if (next >= 0xFFFFFFF0ull) st->pad[0] = 1;  // survivor ids would wrap: the host re-runs on the global table
+    st->pad[1] = (uint32_t)next;
 }
 
 // ids[i] = survivor id found at the window's representative position

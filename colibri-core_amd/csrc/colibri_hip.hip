@@ -101,6 +101,7 @@ struct colibri_ctx {
     // profiling
     bool                   profile = false;
     std::vector<EventPair> events;
+    std::vector<hipEvent_t> event_pool;  // events are recycled: creating/destroying ~60 of them per train() costs milliseconds
     double                 k_ms[COLIBRI_K_NCLASSES]{};
     uint64_t               k_launches[COLIBRI_K_NCLASSES]{};
 };
@@ -155,7 +156,15 @@ struct Prof {
         if (!c->profile) return;
         EventPair ev{};
         ev.cls = cls;
-        if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return;
+        auto take = [&](hipEvent_t& e) {
+            if (!c->event_pool.empty()) {
+                e = c->event_pool.back();
+                c->event_pool.pop_back();
+                return true;
+            }
+            return hipEventCreate(&e) == hipSuccess;
+        };
+        if (!take(ev.a) || !take(ev.b)) return;
         (void)hipEventRecord(ev.a, c->stream);
         c->events.push_back(ev);
         idx = c->events.size() - 1;
@@ -172,8 +181,8 @@ void collect_events(colibri_ctx* c) {
             c->k_ms[ev.cls] += ms;
             c->k_launches[ev.cls] += 1;
         }
-        (void)hipEventDestroy(ev.a);
-        (void)hipEventDestroy(ev.b);
+        c->event_pool.push_back(ev.a);
+        c->event_pool.push_back(ev.b);
     }
     c->events.clear();
 }
@@ -333,6 +342,8 @@ void colibri_destroy(colibri_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     collect_events(c);
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    c->event_pool.clear();
     dev_free(c->bytes);
     dev_free(c->tokstart);
     dev_free(c->delimpos);
@@ -493,8 +504,17 @@ int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t*
     }
     {
         Prof p(c, COLIBRI_K_BINCOUNT);
-        hipLaunchKernelGGL(bin_count_kernel, dim3(kFinalBins), dim3(kBlock), 0, c->stream, c->recs[0].p, c->state.p, c->binstate.p, pl.thr, c->res_rep.p, c->res_cnt.p, pl.res_cap,
-                           c->ids_at.p);
+        // sparse survivor arrays of this order live in recs[1] (free again after scatter B): two u32 planes of npos entries
+        uint32_t* sp_rep = reinterpret_cast<uint32_t*>(c->recs[1].p);
+        uint32_t* sp_cnt = sp_rep + pl.npos;
+        hipLaunchKernelGGL(bin_count_kernel, dim3(kFinalBins), dim3(kBlock), 0, c->stream, c->recs[0].p, c->state.p, c->binstate.p, pl.thr, sp_rep, sp_cnt, c->ids_at.p);
+    }
+    {
+        Prof p(c, COLIBRI_K_PRUNE);
+        uint32_t* sp_rep = reinterpret_cast<uint32_t*>(c->recs[1].p);
+        uint32_t* sp_cnt = sp_rep + pl.npos;
+        hipLaunchKernelGGL(compact_results_kernel, dim3(pl.tab_grid), dim3(kBlock), 0, c->stream, sp_rep, sp_cnt, c->state.p, c->binstate.p, c->res_rep.p, c->res_cnt.p, pl.res_cap);
+        hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
     }
     {
         Prof p(c, COLIBRI_K_RESOLVE);

@@ -14,7 +14,7 @@ for T in sizes:
         st = c.train(maxlength=5, mintokens=2, profile=1)
         W = sum(st.windows[1:6])
         print('train ms', round(st.train_ms, 3), 'windows', W, 'Mpat/s', round(W/st.train_ms/1e3, 1), 'kept', [st.kept[n] for n in range(1, 6)], 'found', [st.found[n] for n in range(1, 6)], 'adm', [st.admitted[n] for n in range(1, 6)], flush=True)
-        print('  kernels', {capi.KERNEL_CLASSES[k]: tuple(round(x, 3) for x in c.kernel_time(k)) for k in range(8)}, flush=True)
+        print('  kernels', {capi.KERNEL_CLASSES[k]: tuple(round(x, 3) for x in c.kernel_time(k)) for k in range(len(capi.KERNEL_CLASSES))}, flush=True)
     st = c.train(maxlength=5, mintokens=2, profile=0)
     print('train ms (no events)', round(st.train_ms, 3), flush=True)
     t = time.time(); a = c.export_arrays(); print('export s', round(time.time()-t, 4), len(a[2]), flush=True)

@@ -1,7 +1,7 @@
 """Turn a gpurun_out/prof_<tag>/ directory (tools/profile_bench.sh) into the committed summaries under profiles/:
    profiles/<tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats summary (verbatim)
    profiles/<tag>_pmc_by_kernel.csv     FETCH_SIZE / WRITE_SIZE per kernel (separate --pmc passes), KiB as reported
-   profiles/pmc_count_kernel.json       HBM bytes per count-kernel launch, corrected as MI355X_MICROARCH.md §HBM prescribes
+   profiles/pmc_dominant_kernel.json    HBM bytes per launch of the dominant kernel, corrected as MI355X_MICROARCH.md §HBM prescribes
 Usage: python tools/summarise_profile.py gpurun_out/prof_r01a r01 <tokens> <nbytes> <npos>
 """
 import collections
@@ -35,25 +35,43 @@ with open(os.path.join(out, f"{tag}_pmc_by_kernel.csv"), "w", newline="") as f:
         n = max(len(fs), len(ws), 1)
         w.writerow([k, n, round(sum(fs), 1), round(sum(fs) / n, 1), round(sum(ws), 1), round(sum(ws) / n, 1)])
 
-fetch = sum(sum(d.get("FETCH_SIZE", [])) for k, d in agg.items() if "count_kernel" in k)
-write = sum(sum(d.get("WRITE_SIZE", [])) for k, d in agg.items() if "count_kernel" in k)
-launches = sum(len(d.get("FETCH_SIZE", [])) for k, d in agg.items() if "count_kernel" in k)
-# calibration on known byte counts in this very run (MI355X_MICROARCH.md §HBM: FETCH_SIZE reports 1/2 of a wide coalesced
-# streaming read on gfx950; other widths must be calibrated): clear_table writes exactly 16 B x cap; prune reads the same.
-clear_w = sum(sum(d.get("WRITE_SIZE", [])) for k, d in agg.items() if "clear_table" in k)
-prune_f = sum(sum(d.get("FETCH_SIZE", [])) for k, d in agg.items() if "prune_kernel" in k)
-# streamed (coalesced) reads of one count launch: corpus bytes + token starts (+ two survivor-id reads for n > 1)
-streamed_per_launch = nbytes + 4 * npos * (1 + 2 * 4 / 5)
-corrected = (fetch + write) * 1024 / max(1, launches) + streamed_per_launch / 2
+def tot(pattern, counter):
+    return sum(sum(d.get(counter, [])) for k, d in agg.items() if pattern in k)
+
+
+def launches(pattern):
+    return max(sum(len(d.get("FETCH_SIZE", [])) for k, d in agg.items() if pattern in k), 1)
+
+
+binned = any("bin_count_kernel" in k for k in agg)
+dom = "bin_count_kernel" if binned else "count_kernel"
+fetch, write, nl = tot(dom, "FETCH_SIZE"), tot(dom, "WRITE_SIZE"), launches(dom)
+# MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming read; other access
+# widths must be calibrated on a known byte count in the same run. Calibration kernels of this run:
+#   bin_resolve / resolve : streams 4 B x npos in (rep_of or slot ids) and 4 B x npos out -> known write bytes
+cal = {}
+for name in ("bin_resolve_kernel", "resolve_kernel", "clear_table_kernel", "prune_kernel", "compact_results_kernel"):
+    if any(name in k for k in agg):
+        cal[name] = {"FETCH_SIZE_KiB_per_launch": round(tot(name, "FETCH_SIZE") / launches(name), 1), "WRITE_SIZE_KiB_per_launch": round(tot(name, "WRITE_SIZE") / launches(name), 1)}
+if binned:
+    # bin_count reads its records with coalesced 16 B/lane loads (twice: build sweep + id sweep, the second mostly from L2):
+    # the streamed-read share is under-counted by 1/2 of ONE sweep = 8 B per record; records per launch ~ admitted windows
+    streamed = None  # filled by the caller-provided record count if given
+    corrected = (2 * fetch + write) * 1024 / nl
+    note = ("bin_count_kernel reads 16 B/lane coalesced records, the access width for which gfx950's FETCH_SIZE is documented to report "
+            "half the bytes: hbm = (2 x FETCH_SIZE + WRITE_SIZE) x 1024")
+else:
+    streamed_per_launch = nbytes + 4 * npos * (1 + 2 * 4 / 5)
+    corrected = (fetch + write) * 1024 / nl + streamed_per_launch / 2
+    note = ("count_kernel: raw (FETCH_SIZE + WRITE_SIZE) x 1024 + 1/2 of the launch's coalesced streamed reads (corpus bytes, token starts, "
+            "survivor ids); its random 16-B slot accesses are counted at face value")
 json.dump({
-    "tokens": tokens, "launches_profiled": launches,
-    "fetch_size_kib_per_launch": round(fetch / max(1, launches), 1), "write_size_kib_per_launch": round(write / max(1, launches), 1),
-    "hbm_bytes_per_launch_raw": round((fetch + write) * 1024 / max(1, launches)),
+    "tokens": tokens, "kernel": dom, "launches_profiled": nl,
+    "fetch_size_kib_per_launch": round(fetch / nl, 1), "write_size_kib_per_launch": round(write / nl, 1),
+    "hbm_bytes_per_launch_raw": round((fetch + write) * 1024 / nl),
     "hbm_bytes_per_launch": round(corrected),
-    "correction": "raw = (FETCH_SIZE + WRITE_SIZE) x 1024, separate --pmc passes; + 1/2 of the launch's coalesced 16 B/lane streamed reads "
-                  "(gfx950 FETCH_SIZE counts wide streaming reads at half, MI355X_MICROARCH.md §HBM). In-run calibration: clear_table "
-                  f"WRITE_SIZE total {clear_w:.3e} KiB for a known 16 B x cap; prune FETCH_SIZE total {prune_f:.3e} KiB reading the same bytes "
-                  f"(ratio {prune_f / max(1.0, clear_w):.2f} ~ 0.5 confirms the half-counting of streamed reads).",
+    "correction": note + "; FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc passes (no tracing domains combined).",
+    "calibration_kernels_same_run": cal,
     "source": f"profiles/{tag}_pmc_by_kernel.csv",
-}, open(os.path.join(out, "pmc_count_kernel.json"), "w"), indent=1)
-print(open(os.path.join(out, "pmc_count_kernel.json")).read())
+}, open(os.path.join(out, "pmc_dominant_kernel.json"), "w"), indent=1)
+print(open(os.path.join(out, "pmc_dominant_kernel.json")).read())

@@ -53,29 +53,37 @@ struct BinState {
 // -------------------------------------------------------------------------------------------------------------------
 // emit: scan + SpookyHash + block-local reduce -> records
 // -------------------------------------------------------------------------------------------------------------------
-template <class KeyFn>
+// LIST = false: one lane per corpus position (orders 1 and 2). LIST = true: one lane per entry of the active list = the positions
+// that still carry a survivor id of order n-1 (orders >= 3, where only a few percent of the positions can start a window);
+// rep_of is then indexed by list entry.
+template <class KeyFn, bool LIST>
 __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __restrict__ recs, uint32_t* __restrict__ rep_of, DevState* __restrict__ st, BinState* __restrict__ bs,
-                                                           uint32_t npos) {
+                                                           uint32_t npos, const uint32_t* __restrict__ list, const uint32_t* __restrict__ nlist) {
     if (st->done) return;
+    const uint32_t nitems = LIST ? *nlist : npos;
     __shared__ uint64_t keyL[kCountTile];
     __shared__ uint32_t winL[kCountLSlot];
     __shared__ uint32_t cntL[kCountTile];
     __shared__ uint32_t histL[kBins];
     __shared__ uint32_t redL[kBlock / kWave];
     __shared__ uint32_t baseL;
+    __shared__ uint32_t posL[LIST ? kCountTile : 1];
     histL[threadIdx.x] = 0;
-    const uint32_t ntiles = (npos + kCountTile - 1) / kCountTile;
+    const uint32_t ntiles = (nitems + kCountTile - 1) / kCountTile;
     uint32_t       nadm   = 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t base = tile * kCountTile;
         uint64_t       key[kCountPer], hash[kCountPer];
+        uint32_t       posn[kCountPer];
         bool           adm[kCountPer];
 #pragma unroll
         for (int k = 0; k < kCountPer; ++k) {
-            const uint32_t e = k * kBlock + threadIdx.x, i = base + e;
+            const uint32_t e = k * kBlock + threadIdx.x, j = base + e;
             key[k]  = 0;
             hash[k] = 0;
-            adm[k]  = (i < npos) && keyfn(i, npos, key[k], hash[k]);
+            posn[k] = LIST ? (j < nitems ? list[j] : 0u) : j;
+            if (LIST) posL[e] = posn[k];
+            adm[k]  = (j < nitems) && keyfn(posn[k], npos, key[k], hash[k]);
             cntL[e] = 0;
             if (adm[k]) {
                 keyL[e]                                     = key[k];
@@ -106,13 +114,13 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
         uint32_t o = baseL + excl;
 #pragma unroll
         for (int k = 0; k < kCountPer; ++k) {
-            const uint32_t e = k * kBlock + threadIdx.x, i = base + e;
-            if (i < npos) rep_of[i] = adm[k] ? base + rep[k] : kInvalid;
+            const uint32_t e = k * kBlock + threadIdx.x, j = base + e;
+            if (j < nitems) rep_of[j] = adm[k] ? (LIST ? posL[rep[k]] : base + rep[k]) : kInvalid;  // always a corpus POSITION
             if (adm[k] && rep[k] == e) {
                 const uint32_t hb = (uint32_t)(hash[k] >> 48);
                 Rec            r;
                 r.key  = key[k];
-                r.pos  = i;
+                r.pos  = posn[k];
                 r.meta = (hb << 16) | (1u + cntL[e]);
                 recs[o++] = r;
                 atomicAdd(&histL[hb >> 8], 1u);
@@ -384,18 +392,52 @@ __global__ void bin_advance_prepare_kernel(DevState* __restrict__ st, const BinS
     st->pad[1] = (uint32_t)next;
 }
 
-// ids[i] = survivor id found at the window's representative position
+// ids[i] = survivor id found at the window's representative position; also builds the active list for the next order
+// (positions whose window survived), tile by tile with one reservation per 8192 items.
+constexpr int kResPer  = 32;
+constexpr int kResTile = kBlock * kResPer;
+template <bool LIST>
 __global__ __launch_bounds__(kBlock) void bin_resolve_kernel(const uint32_t* __restrict__ rep_of, const uint32_t* __restrict__ ids_at, uint32_t* __restrict__ ids,
-                                                              DevState* __restrict__ st, uint32_t npos) {
+                                                              DevState* __restrict__ st, uint32_t npos, const uint32_t* __restrict__ list_in,
+                                                              const uint32_t* __restrict__ nlist_in, uint32_t* __restrict__ list_out, uint32_t* __restrict__ nlist_out) {
     if (st->done) return;
-    uint32_t nvalid = 0;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npos; i += gridDim.x * kBlock) {
-        const uint32_t r  = rep_of[i];
-        const uint32_t id = (r != kInvalid) ? ids_at[r] : kInvalid;
-        nvalid += id != kInvalid;
-        ids[i] = id;
-    }
+    __shared__ uint32_t baseL;
     __shared__ uint32_t redL[kBlock / kWave];
+    const uint32_t      nitems = LIST ? *nlist_in : npos;
+    const uint32_t      ntiles = (nitems + kResTile - 1) / kResTile;
+    uint32_t            nvalid = 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t id[kResPer], pos[kResPer], c = 0;
+#pragma unroll
+        for (int q = 0; q < kResPer; ++q) {
+            const uint32_t j = tile * kResTile + q * kBlock + threadIdx.x;
+            id[q]            = kInvalid;
+            pos[q]           = 0;
+            if (j < nitems) {
+                const uint32_t r = rep_of[j];
+                pos[q]           = LIST ? list_in[j] : j;
+                if (r != kInvalid) id[q] = ids_at[r];
+                if (LIST) {
+                    if (id[q] != kInvalid) ids[pos[q]] = id[q];  // ids was pre-filled with kInvalid
+                } else {
+                    ids[j] = id[q];
+                }
+                c += id[q] != kInvalid;
+            }
+        }
+        nvalid += c;
+        if (list_out != nullptr) {
+            uint32_t       total;
+            const uint32_t excl = block_exclusive_scan(c, &total);
+            if (threadIdx.x == 0) baseL = total ? atomicAdd(nlist_out, total) : 0;
+            __syncthreads();
+            uint32_t o = baseL + excl;
+#pragma unroll
+            for (int q = 0; q < kResPer; ++q)
+                if (id[q] != kInvalid) list_out[o++] = pos[q];
+            __syncthreads();
+        }
+    }
     for (int off = 32; off > 0; off >>= 1) nvalid += __shfl_down(nvalid, off, kWave);
     if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nvalid;
     __syncthreads();

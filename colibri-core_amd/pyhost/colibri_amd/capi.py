@@ -21,7 +21,7 @@ EXPORTED = [
     "colibri_upload_corpus_device", "colibri_corpus_info", "colibri_train", "colibri_result_sizes", "colibri_export_unindexed",
     "colibri_export_indexed", "colibri_hash_windows", "colibri_positions", "colibri_hash_keys", "colibri_kernel_time",
     "colibri_shard_begin", "colibri_shard_count", "colibri_shard_send", "colibri_shard_merge", "colibri_shard_reply", "colibri_shard_apply",
-    "colibri_shard_finish",
+    "colibri_shard_finish", "colibri_shard_export_gids", "colibri_shard_index_sizes", "colibri_shard_export_index",
 ]
 
 
@@ -86,12 +86,15 @@ def load():
         L.colibri_hash_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.colibri_kernel_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.colibri_shard_begin.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int]
-        L.colibri_shard_count.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_void_p]
-        L.colibri_shard_send.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        L.colibri_shard_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.colibri_shard_count.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.c_void_p]
+        L.colibri_shard_send.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.colibri_shard_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.colibri_shard_reply.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
-        L.colibri_shard_apply.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.colibri_shard_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.colibri_shard_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Stats)]
+        L.colibri_shard_export_gids.argtypes = [C.c_void_p, C.c_void_p]
+        L.colibri_shard_index_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.colibri_shard_export_index.argtypes = [C.c_void_p] * 5
         _lib = L
     return _lib
 
@@ -228,12 +231,13 @@ class HipShardEngine:
     def begin(self, opt, world):
         self.world = world
         self.ctx._check(self.L.colibri_shard_begin(self.ctx.h, C.byref(opt), world))
-        self.ctx.indexed = False
+        self.ctx.indexed = False  # exports of a sharded run go through export_local()
+        self.indexed = bool(opt.indexed)
 
-    def count(self, n):
+    def count(self, n, mask=0, level=1):
         nc = C.c_uint64()
         per = np.zeros(self.world, dtype=np.uint64)
-        self.ctx._check(self.L.colibri_shard_count(self.ctx.h, n, C.byref(nc), per.ctypes.data))
+        self.ctx._check(self.L.colibri_shard_count(self.ctx.h, n, mask, level, C.byref(nc), per.ctypes.data))
         self.ncand = int(nc.value)
         return self.ncand, [int(x) for x in per]
 
@@ -241,14 +245,16 @@ class HipShardEngine:
         t = self.torch
         keys = t.empty(max(1, self.ncand), dtype=t.int64, device=self.device)
         cnts = t.empty(max(1, self.ncand), dtype=t.int32, device=self.device)
-        self.ctx._check(self.L.colibri_shard_send(self.ctx.h, C.c_void_p(keys.data_ptr()), C.c_void_p(cnts.data_ptr())))
-        return keys[: self.ncand], cnts[: self.ncand]
+        aux = t.empty(max(1, self.ncand), dtype=t.int32, device=self.device)
+        self.ctx._check(self.L.colibri_shard_send(self.ctx.h, C.c_void_p(keys.data_ptr()), C.c_void_p(cnts.data_ptr()), C.c_void_p(aux.data_ptr())))
+        return keys[: self.ncand], cnts[: self.ncand], aux[: self.ncand]
 
-    def merge(self, keys, cnts, per_src):
+    def merge(self, keys, cnts, aux, per_src):
         per = np.asarray(per_src, dtype=np.uint64)
         f, k = C.c_uint64(), C.c_uint64()
         self.nrecv = int(per.sum())
-        self.ctx._check(self.L.colibri_shard_merge(self.ctx.h, C.c_void_p(keys.data_ptr()), C.c_void_p(cnts.data_ptr()), per.ctypes.data, C.byref(f), C.byref(k)))
+        self.ctx._check(self.L.colibri_shard_merge(self.ctx.h, C.c_void_p(keys.data_ptr()), C.c_void_p(cnts.data_ptr()), C.c_void_p(aux.data_ptr()), per.ctypes.data,
+                                                   C.byref(f), C.byref(k)))
         return int(f.value), int(k.value)
 
     def reply(self, gid_base):
@@ -258,9 +264,9 @@ class HipShardEngine:
         self.ctx._check(self.L.colibri_shard_reply(self.ctx.h, gid_base, C.c_void_p(gid.data_ptr()), C.c_void_p(cnt.data_ptr())))
         return gid[: self.nrecv], cnt[: self.nrecv]
 
-    def apply(self, n, gid, cnt):
+    def apply(self, gid, cnt):
         e, a = C.c_uint64(), C.c_uint64()
-        self.ctx._check(self.L.colibri_shard_apply(self.ctx.h, n, C.c_void_p(gid.data_ptr()), C.c_void_p(cnt.data_ptr()), C.byref(e), C.byref(a)))
+        self.ctx._check(self.L.colibri_shard_apply(self.ctx.h, C.c_void_p(gid.data_ptr()), C.c_void_p(cnt.data_ptr()), C.byref(e), C.byref(a)))
         return int(e.value), int(a.value)
 
     def finish(self, found_g, kept_g, tokens_g, maxn):
@@ -272,3 +278,23 @@ class HipShardEngine:
         self.ctx._check(self.L.colibri_shard_finish(self.ctx.h, f.ctypes.data, k.ctypes.data, tokens_g, maxn, C.byref(st)))
         self.ctx.stats = st
         return st
+
+    def export_local(self):
+        """This rank's share of the model: {"patterns": {gid: (key bytes, global count)}, "index": {gid: [(sentence, token)]} or None}."""
+        key_off, key_bytes, counts, _ = self.ctx.export_arrays()
+        gids = np.zeros(max(1, counts.size), dtype=np.uint32)
+        self.ctx._check(self.L.colibri_shard_export_gids(self.ctx.h, gids.ctypes.data))
+        kb, off = key_bytes.tobytes(), key_off.tolist()
+        patterns = {int(g): (kb[off[j]: off[j + 1]], int(c)) for j, (g, c) in enumerate(zip(gids[: counts.size].tolist(), counts.tolist()))}
+        index = None
+        if self.indexed:
+            ng, nr = C.c_uint64(), C.c_uint64()
+            self.ctx._check(self.L.colibri_shard_index_sizes(self.ctx.h, C.byref(ng), C.byref(nr)))
+            ug = np.zeros(max(1, ng.value), dtype=np.uint32)
+            ro = np.zeros(ng.value + 1, dtype=np.uint64)
+            rs = np.zeros(max(1, nr.value), dtype=np.uint32)
+            rt = np.zeros(max(1, nr.value), dtype=np.uint16)
+            self.ctx._check(self.L.colibri_shard_export_index(self.ctx.h, ug.ctypes.data, ro.ctypes.data, rs.ctypes.data, rt.ctypes.data))
+            ro, rs, rt = ro.tolist(), rs.tolist(), rt.tolist()
+            index = {int(g): list(zip(rs[ro[j]: ro[j + 1]], rt[ro[j]: ro[j + 1]])) for j, g in enumerate(ug[: ng.value].tolist())}
+        return {"patterns": patterns, "index": index}

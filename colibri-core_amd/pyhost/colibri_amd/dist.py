@@ -53,38 +53,125 @@ class ShardedTrainer:
         self.dist.all_gather(out, mine)
         return [[int(x) for x in o.tolist()] for o in out]
 
+    # ---- one pass: local count -> exchange -> owner merge -> global ids back ---------------------------------
+    def _pass(self, n, mask, level, state):
+        eng = self.engine
+        ncand, per_owner = eng.count(n, mask, level)
+        recv_sizes = self._exchange_sizes(per_owner)
+        keys, cnts, aux = eng.send_buffers()
+        rkeys = self._all_to_all_v(keys, per_owner, recv_sizes)
+        rcnts = self._all_to_all_v(cnts, per_owner, recv_sizes)
+        raux = self._all_to_all_v(aux, per_owner, recv_sizes)
+        found, kept = eng.merge(rkeys, rcnts, raux, recv_sizes)
+        everyone = self._all_gather_ints([found, kept])
+        found_all, kept_all = sum(v[0] for v in everyone), sum(v[1] for v in everyone)
+        if found_all == 0:  # nothing anywhere: every rank sees it at once (reference "None found", patternmodel.h:1189-1194)
+            return 0, 0
+        base = state["gid_total"] + sum(everyone[r][1] for r in range(self.rank))
+        if state["gid_total"] + kept_all >= (1 << 31):
+            raise OverflowError("more than 2^31 surviving patterns")
+        rgid, rtot = eng.reply(base)
+        gid = self._all_to_all_v(rgid, recv_sizes, per_owner)
+        tot = self._all_to_all_v(rtot, recv_sizes, per_owner)
+        eng.apply(gid, tot)
+        state["gid_total"] += kept_all
+        return found_all, kept_all
+
+    def _skipgram_order(self, n, opt, state):
+        """all gap masks of order n, each built level by level; returns (distinct skipgrams found, kept)"""
+        found_n = kept_n = 0
+        for mask in gap_masks(n, int(opt.maxskips)):
+            levels = len(mask_parts(mask, n)) - 1
+            f = k = 0
+            for level in range(1, levels + 1):
+                f, k = self._pass(n, mask, level, state)
+                if f == 0:
+                    break
+            else:
+                found_n += f
+                kept_n += k
+        return found_n, kept_n
+
     # ---- one training run -------------------------------------------------------------------------
     def train(self, opt):
         eng = self.engine
         eng.begin(opt, self.world)
         maxlength = min(int(opt.maxlength), MAX_ORDER - 1)
         found_g, kept_g = [0] * MAX_ORDER, [0] * MAX_ORDER
-        gid_total, maxn = 0, 0
+        state, maxn = {"gid_total": 0}, 0
         tokens_g = sum(v[0] for v in self._all_gather_ints([eng.local_tokens()]))
         for n in range(1, maxlength + 1):
-            ncand, per_owner = eng.count(n)
-            recv_sizes = self._exchange_sizes(per_owner)
-            keys, cnts = eng.send_buffers()
-            rkeys = self._all_to_all_v(keys, per_owner, recv_sizes)
-            rcnts = self._all_to_all_v(cnts, per_owner, recv_sizes)
-            found, kept = eng.merge(rkeys, rcnts, recv_sizes)
-            everyone = self._all_gather_ints([found, kept])
-            found_all, kept_all = sum(v[0] for v in everyone), sum(v[1] for v in everyone)
-            if found_all == 0:  # "None found" on every rank at once (reference patternmodel.h:1189-1194)
+            found_all, kept_all = self._pass(n, 0, 1, state)
+            if found_all == 0:
                 break
             maxn = n
             found_g[n], kept_g[n] = found_all, kept_all
-            base = gid_total + sum(everyone[r][1] for r in range(self.rank))
-            if gid_total + kept_all >= (1 << 31):
-                raise OverflowError("more than 2^31 surviving patterns")
-            rgid, rtot = eng.reply(base)
-            gid = self._all_to_all_v(rgid, recv_sizes, per_owner)
-            tot = self._all_to_all_v(rtot, recv_sizes, per_owner)
-            eng.apply(n, gid, tot)
-            gid_total += kept_all
+            if opt.doskipgrams_exhaustive and n >= 3:  # every admissible window also counts its masked forms (patternmodel.h:1163-1171)
+                f, k = self._skipgram_order(n, opt, state)
+                found_g[n] += f
+                kept_g[n] += k
             if kept_all == 0:  # nothing can be admitted at n + 1
                 break
+        if opt.doskipgrams and opt.indexed:  # IndexedPatternModel::trainskipgrams: from the surviving n-grams, n = 3.. (patternmodel.h:2969-3010)
+            for n in range(3, min(maxlength, maxn) + 1):
+                f, k = self._skipgram_order(n, opt, state)
+                found_g[n] += f
+                kept_g[n] += k
+                if f == 0:
+                    break
         return eng.finish(found_g, kept_g, tokens_g, maxn)
+
+
+def gap_masks(n, maxskips):
+    """bit i = token i is a gap; never at either end; at most `maxskips` separate gaps when n - 2 >= maxskips
+    (reference src/algorithms.cpp:79-94)"""
+    out = []
+    if n < 3:
+        return out
+    for i in range(1, 1 << (n - 2)):
+        mask = i << 1
+        runs = sum(1 for k in range(n) if (mask >> k) & 1 and not (k and (mask >> (k - 1)) & 1))
+        if n - 2 >= maxskips and runs > maxskips:
+            continue
+        out.append(mask)
+    return out
+
+
+def mask_parts(mask, n):
+    """contiguous runs of non-gap tokens: [(first token, length)]"""
+    parts, k = [], 0
+    while k < n:
+        if (mask >> k) & 1:
+            k += 1
+            continue
+        e = k
+        while e < n and not (mask >> e) & 1:
+            e += 1
+        parts.append((k, e - k))
+        k = e
+    return parts
+
+
+def merge_exports(per_rank):
+    """Union of the ranks' exports (in rank order): {key bytes: count} and, for indexed models, {key bytes: [(sentence, token)]}.
+    Every pattern is exported by exactly one rank; a pattern's index is the concatenation of the ranks' local runs — rank order is
+    sentence order, so the result is sorted."""
+    patterns, dup = {}, 0
+    for ex in per_rank:
+        for g, kc in ex["patterns"].items():
+            dup += g in patterns
+            patterns[g] = kc
+    if dup:
+        raise ValueError(f"{dup} patterns were exported by more than one rank")
+    counts = {k: c for k, c in patterns.values()}
+    refs = None
+    if per_rank and per_rank[0]["index"] is not None:
+        refs = {k: [] for k, _ in patterns.values()}
+        for ex in per_rank:
+            for g, r in ex["index"].items():
+                if g in patterns:  # ids of interned (intermediate) pairs never reach the index; kept for safety
+                    refs[patterns[g][0]].extend(r)
+    return counts, refs
 
 
 def shard_payload(payload, world):

@@ -127,26 +127,38 @@ int colibri_export_indexed(colibri_ctx* ctx, uint64_t* key_off, uint8_t* key_byt
 
 /* ---- sentence-sharded multi-GPU training (one context per rank; the collectives themselves are the caller's: RCCL through
  * torch.distributed in colibri_amd.dist, or any all-to-all). The reference has no counterpart — it is single-threaded; these
- * entry points split PatternModel::train's order loop (patternmodel.h:981-1270) at its only cross-shard dependency: the global
- * count of a candidate pattern. Survivor ids are global (handed out by the owner rank of a key), so the 64-bit keys of all ranks
- * are comparable and counts are summed exactly. Unindexed n-gram models only. All *_dev arguments are DEVICE pointers.
- *   per order n:  shard_count -> [all-to-all sizes] -> shard_send -> [all-to-all keys,counts] -> shard_merge -> [all-gather
- *                 found,kept] -> shard_reply -> [all-to-all replies back] -> shard_apply ;  after the last order: shard_finish.
- * Each rank then exports (colibri_export_unindexed) the patterns it was named exporter of; the union over ranks is the model. */
+ * entry points split PatternModel::train's order loop (patternmodel.h:981-1270) and the skipgram passes (:1163-1171, :2969-3010)
+ * at their only cross-shard dependency: the global count of a candidate pattern. Survivor ids are GLOBAL (handed out by the owner
+ * rank of a key), so the 64-bit keys of all ranks are comparable and counts are summed exactly. All *_dev arguments are DEVICE
+ * pointers. A "pass" is identified by (n, mask, level): mask 0 = the n-gram pass of order n; mask != 0 = level 1..parts-1 of the
+ * skipgram (n, mask), whose identity is built by pairing the global ids of its contiguous parts left to right.
+ *   per pass:  shard_count -> [all-to-all sizes] -> shard_send -> [all-to-all keys, counts (, aux)] -> shard_merge ->
+ *              [all-gather found, kept] -> shard_reply -> [all-to-all replies back] -> shard_apply ;  at the end: shard_finish.
+ * Each rank then exports (colibri_export_unindexed + colibri_shard_export_gids) the patterns it was named exporter of — the
+ * union over ranks is the model — and, for indexed models, its LOCAL forward index keyed by global id
+ * (colibri_shard_export_index); a pattern's index is the concatenation of the ranks' runs in rank order (sentence ranges of
+ * the ranks are disjoint and ascending, so that concatenation is already sorted). */
 int colibri_shard_begin(colibri_ctx* ctx, const colibri_options* opt, int world);
-/* local count pass of order n, then this rank's distinct candidates partitioned by owner = hash(key) % world */
-int colibri_shard_count(colibri_ctx* ctx, int n, uint64_t* ncandidates, uint64_t* per_owner /* [world] */);
-/* copy the partitioned candidates (keys: u64[ncandidates], counts: u32[ncandidates]) into the caller's send buffers */
-int colibri_shard_send(colibri_ctx* ctx, void* keys_dev, void* counts_dev);
+/* local count of pass (n, mask, level), then this rank's distinct candidates partitioned by owner = hash(key) % world */
+int colibri_shard_count(colibri_ctx* ctx, int n, uint32_t mask, int level, uint64_t* ncandidates, uint64_t* per_owner /* [world] */);
+/* copy the partitioned candidates into the caller's send buffers: keys u64[ncandidates], counts u32[ncandidates],
+ * aux u32[ncandidates] (distinct-source counts of indexed skipgrams; zeros otherwise; may be NULL when not wanted) */
+int colibri_shard_send(colibri_ctx* ctx, void* keys_dev, void* counts_dev, void* aux_dev);
 /* owner side: merge the records received from every rank (concatenated in rank order; per_src[r] records from rank r) */
-int colibri_shard_merge(colibri_ctx* ctx, const void* keys_dev, const void* counts_dev, const uint64_t* per_src /* [world] */, uint64_t* found, uint64_t* kept);
+int colibri_shard_merge(colibri_ctx* ctx, const void* keys_dev, const void* counts_dev, const void* aux_dev, const uint64_t* per_src /* [world] */,
+                        uint64_t* found, uint64_t* kept);
 /* owner side: assign global survivor ids gid_base.. to the kept keys and fill one reply per received record
  * (reply_gid: u32 global id | bit 31 = "you export it", 0xFFFFFFFF = pruned; reply_cnt: u32 global count) */
 int colibri_shard_reply(colibri_ctx* ctx, uint32_t gid_base, void* reply_gid_dev, void* reply_cnt_dev);
-/* contributor side: apply the replies (same order as the records sent), write survivor ids per position for order n+1 */
-int colibri_shard_apply(colibri_ctx* ctx, int n, const void* reply_gid_dev, const void* reply_cnt_dev, uint64_t* exported, uint64_t* admitted);
+/* contributor side: apply the replies (same order as the records sent) and write global survivor ids per position */
+int colibri_shard_apply(colibri_ctx* ctx, const void* reply_gid_dev, const void* reply_cnt_dev, uint64_t* exported, uint64_t* admitted);
 /* close the run: global per-order found / kept (caller-reduced), global token count; fills stats like colibri_train */
 int colibri_shard_finish(colibri_ctx* ctx, const uint64_t* found_global, const uint64_t* kept_global, uint64_t totaltokens_global, int maxn, colibri_stats* stats);
+/* global id of every pattern this rank exports, in the order of colibri_export_unindexed (gids[npatterns]) */
+int colibri_shard_export_gids(colibri_ctx* ctx, uint32_t* gids);
+/* indexed models: this rank's forward index — gids[ngids] ascending, ref_off[ngids+1], sentence/token[nrefs] */
+int colibri_shard_index_sizes(const colibri_ctx* ctx, uint64_t* ngids, uint64_t* nrefs);
+int colibri_shard_export_index(colibri_ctx* ctx, uint32_t* gids, uint64_t* ref_off, uint32_t* ref_sentence, uint16_t* ref_token);
 
 /* ---- parity / measurement hooks ------------------------------------------------------------------ */
 /* SpookyHash::Hash64 (reference include/SpookyV2.h:59-66) of every n-token window, computed by the same

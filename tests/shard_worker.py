@@ -52,7 +52,8 @@ class NumpyShardEngine:
         self.world, self.thr = world, (2 if opt.mintokens == -1 else max(1, opt.mintokens))
         self.ids_prev, self.results, self.admitted = None, [], {}
 
-    def count(self, n):
+    def count(self, n, mask=0, level=1):
+        assert mask == 0, "the numpy stand-in covers the n-gram passes"
         self.n, self.keyof, table = n, [None] * len(self.pos), {}
         for i in range(len(self.pos)):
             if n == 1:
@@ -78,9 +79,9 @@ class NumpyShardEngine:
     def send_buffers(self):
         keys = np.array([k for k, _ in self.send], dtype=np.uint64).view(np.int64)
         cnts = np.array([c for _, c in self.send], dtype=np.uint32).view(np.int32)
-        return torch.from_numpy(keys.copy()), torch.from_numpy(cnts.copy())
+        return torch.from_numpy(keys.copy()), torch.from_numpy(cnts.copy()), torch.zeros(len(self.send), dtype=torch.int32)
 
-    def merge(self, keys, cnts, per_src):
+    def merge(self, keys, cnts, aux, per_src):
         self.rkeys = keys.numpy().view(np.uint64).tolist()
         rc = cnts.numpy().view(np.uint32).tolist()
         self.rsrc = [r for r, m in enumerate(per_src) for _ in range(m)]
@@ -100,7 +101,8 @@ class NumpyShardEngine:
         t = [self.owner[k][0] for k in self.rkeys]
         return torch.from_numpy(np.array(g, dtype=np.uint32).view(np.int32).copy()), torch.from_numpy(np.array(t, dtype=np.uint32).view(np.int32).copy())
 
-    def apply(self, n, gid, tot):
+    def apply(self, gid, tot):
+        n = self.n
         g = gid.numpy().view(np.uint32).tolist()
         t = tot.numpy().view(np.uint32).tolist()
         gmap, exported = {}, 0
@@ -124,8 +126,13 @@ class NumpyShardEngine:
         return {self.payload[self.pos[p][0]: self.pos[p + n - 1][1]]: c for p, n, c in self.results}
 
 
+MODES = {"u": {}, "us": dict(doskipgrams_exhaustive=1), "i": dict(indexed=1), "is": dict(indexed=1, doskipgrams=1), "isT1": dict(indexed=1, doskipgrams=1, minskiptypes=1),
+         "usy3": dict(doskipgrams_exhaustive=1, mintokens_skipgrams=3)}
+
+
 def main():
     engine_kind, corpus_kind, maxlength, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    mode = sys.argv[5] if len(sys.argv) > 5 else "u"
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     if corpus_kind == "zipf":
@@ -135,30 +142,37 @@ def main():
     else:
         payload = synth.random_corpus(np.random.default_rng(int(corpus_kind)), nsent=300, maxlen=12, vocab=12)
     shard, first = shard_payload(payload, world)[rank]
-    opt = capi.Options.defaults(mintokens=2, maxlength=maxlength)
+    opt = capi.Options.defaults(mintokens=2, maxlength=maxlength, **MODES[mode])
     if engine_kind == "numpy":
         eng = NumpyShardEngine(shard)
         trainer = ShardedTrainer(eng, dist, torch)
         st = trainer.train(opt)
-        mine = eng.export_dict()
+        mine = {"patterns": {i: kv for i, kv in enumerate(eng.export_dict().items())}, "index": None}
+        mine["patterns"] = {(rank << 40) | i: kv for i, kv in mine["patterns"].items()}
     else:
         ctx = capi.Context(0)
         ctx.upload(shard, first_sentence=first)
         eng = capi.HipShardEngine(ctx, torch, torch.device("cuda", 0))
         trainer = ShardedTrainer(eng, dist, torch)
         st = trainer.train(opt)
-        mine, _ = ctx.export_dict()
+        mine = eng.export_local()
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
     if rank == 0:
-        union, dup = {}, 0
-        for d in gathered:
-            for k, v in d.items():
-                dup += k in union
-                union[k] = v
+        from colibri_amd.dist import merge_exports
+        dup = 0
+        try:
+            counts, refs = merge_exports(gathered)
+            seen = {}
+            for ex in gathered:  # the same key bytes must not come from two ranks either
+                for g, (k, c) in ex["patterns"].items():
+                    dup += k in seen
+                    seen[k] = c
+        except ValueError:
+            counts, refs, dup = {}, None, 1
         with open(out, "wb") as f:
-            pickle.dump({"union": union, "dup": dup, "tokens": int(st.totaltokens), "types": int(st.totaltypes), "maxn": int(st.maxn),
-                         "found": [int(x) for x in list(st.found)[:16]], "kept": [int(x) for x in list(st.kept)[:16]], "payload": payload}, f)
+            pickle.dump({"union": counts, "refs": refs, "dup": dup, "tokens": int(st.totaltokens), "types": int(st.totaltypes), "maxn": int(st.maxn),
+                         "found": [int(x) for x in list(st.found)[:16]], "kept": [int(x) for x in list(st.kept)[:16]], "payload": payload, "mode": mode}, f)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -15,19 +15,25 @@ WORKER = os.path.join(ROOT, "tests", "shard_worker.py")
 _port = [29700]
 
 
-def run_workers(tmp_path, world, engine, corpus, maxlength):
+ORACLE_MODES = {"u": {}, "us": dict(doskipgrams_exhaustive=True), "i": dict(indexed=True), "is": dict(indexed=True, doskipgrams=True),
+                "isT1": dict(indexed=True, doskipgrams=True, minskiptypes=1), "usy3": dict(doskipgrams_exhaustive=True, mintokens_skipgrams=3)}
+
+
+def run_workers(tmp_path, world, engine, corpus, maxlength, mode="u"):
     import oracle
-    out = str(tmp_path / f"res_{engine}_{corpus}_{world}.pkl")
+    out = str(tmp_path / f"res_{engine}_{corpus}_{world}_{mode}.pkl")
     _port[0] += 1
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(_port[0]),
-           WORKER, engine, corpus, str(maxlength), out]
+           WORKER, engine, corpus, str(maxlength), out, mode]
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     res = pickle.load(open(out, "rb"))
-    want = oracle.train(res["payload"], 2, maxlength)
+    want = oracle.train(res["payload"], 2, maxlength, **ORACLE_MODES[mode])
     assert res["dup"] == 0, "a pattern was exported by two ranks"
     assert res["union"] == want.counts
+    if want.refs is not None:
+        assert res["refs"] == want.refs
     assert (res["tokens"], res["types"], res["maxn"]) == (want.tokens, want.types, want.maxn)
     for n in range(1, min(maxlength, 15) + 1):
         assert (res["found"][n], res["kept"][n]) == (want.stats[n][0], want.stats[n][2]), n
@@ -55,3 +61,27 @@ def test_shard_payload_keeps_global_sentence_numbers():
 @pytest.mark.parametrize("world,corpus,maxlength", [(1, "zipf", 5), (2, "zipf", 5), (2, "3", 8), (3, "tiny", 4), (4, "zipf", 5)])
 def test_hip_shard_engine_gloo_staged(tmp_path, world, corpus, maxlength):
     run_workers(tmp_path, world, "hip", corpus, maxlength)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["us", "usy3", "i", "is", "isT1"])
+@pytest.mark.parametrize("world,corpus", [(1, "zipf"), (2, "zipf"), (3, "2"), (2, "tiny")])
+def test_hip_shard_engine_skipgram_and_indexed_modes(tmp_path, world, corpus, mode):
+    """configs 4 and 5 of BASELINE.json are multi-GPU: exhaustive skipgrams, the forward index and indexed skipgrams, sharded —
+    the union over ranks equals the oracle's single-process model (counts and, for indexed models, every reference list)."""
+    run_workers(tmp_path, world, "hip", corpus, 5, mode)
+
+
+def test_merge_exports_concatenates_in_rank_order():
+    from colibri_amd.dist import merge_exports, gap_masks, mask_parts
+    a = {"patterns": {7: (b"\x06", 5)}, "index": {7: [(1, 0), (2, 3)], 9: [(2, 1)]}}
+    b = {"patterns": {9: (b"\x07", 2)}, "index": {7: [(5, 0)], 9: [(6, 2)]}}
+    counts, refs = merge_exports([a, b])
+    assert counts == {b"\x06": 5, b"\x07": 2}
+    assert refs == {b"\x06": [(1, 0), (2, 3), (5, 0)], b"\x07": [(2, 1), (6, 2)]}
+    with pytest.raises(ValueError):
+        merge_exports([a, a])
+    import oracle
+    for n in range(3, 9):
+        assert gap_masks(n, 3) == oracle.skip_configurations(n, 3)
+    assert mask_parts(0b01010, 5) == [(0, 1), (2, 1), (4, 1)]

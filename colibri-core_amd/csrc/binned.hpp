@@ -273,10 +273,39 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict
     if (threadIdx.x == 0) failL = 0;
     __syncthreads();
     uint32_t nnew = 0;
-    for (uint32_t j = begin + threadIdx.x; j < end; j += kBlock) {
-        const Rec x = recs[j];
-        uint32_t  s = (uint32_t)mix64(x.key) & smask;
-        bool      ok = false;
+    for (uint32_t j0 = begin; j0 < end; j0 += kBlock) {  // block-uniform trip count: the wave-level merge below uses ballots
+        const uint32_t j     = j0 + threadIdx.x;
+        const bool     valid = j < end;
+        Rec            x{};
+        if (valid) x = recs[j];
+        // Heavy hitters arrive as many records with the same key (one per 2048-window tile). Lanes that hold the same key as the
+        // wave's first active lane fold into that lane before touching LDS: a hot bin then costs one LDS update per wave
+        // instead of 64 serialised ones on the same address.
+        uint32_t       cnt   = x.meta & 0xFFFFu;
+        uint32_t       pos   = x.pos;
+        bool           alive = valid;
+        const uint64_t act   = __ballot(valid);
+        if (act) {
+            const int                leader = __builtin_ctzll(act);
+            const unsigned long long k0     = __shfl((unsigned long long)x.key, leader, kWave);
+            const bool               same   = valid && x.key == k0;
+            const uint64_t           sm     = __ballot(same);
+            if (__popcll(sm) > 1) {
+                uint32_t c = same ? cnt : 0u, pmin = same ? pos : 0xFFFFFFFFu;
+                for (int off = 32; off > 0; off >>= 1) {
+                    c += __shfl_xor(c, off, kWave);
+                    pmin = min(pmin, __shfl_xor(pmin, off, kWave));
+                }
+                if (same) {
+                    alive = (int)(threadIdx.x & (kWave - 1)) == leader;
+                    cnt   = c;
+                    pos   = pmin;
+                }
+            }
+        }
+        if (!alive) continue;
+        uint32_t s  = (uint32_t)mix64(x.key) & smask;
+        bool     ok = false;
         for (uint32_t probe = 0; probe < nslots; ++probe) {
             const unsigned long long old = atomicCAS(&keyT[s], (unsigned long long)kEmptyKey, (unsigned long long)x.key);
             if (old == kEmptyKey) {
@@ -291,8 +320,8 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict
             s = (s + 1) & smask;
         }
         if (ok) {
-            atomicAdd(&cntT[s], x.meta & 0xFFFFu);
-            atomicMin(&repT[s], x.pos);  // smallest representative position: deterministic
+            atomicAdd(&cntT[s], cnt);
+            atomicMin(&repT[s], pos);  // smallest representative position: deterministic
         } else {
             failL = 1;
         }

@@ -51,6 +51,8 @@ struct colibri_ctx {
     DevBuf<uint8_t>   bytes;
     DevBuf<uint32_t>  tokstart;
     DevBuf<uint32_t>  delimpos;
+    DevBuf<uint32_t>  cls;              // class id per position (0 = delimiter)
+    DevBuf<uint32_t>  cnt1, rep1;       // order-1 fast path: count / representative position per class
     std::vector<uint64_t> lenhist;  // sentence-length histogram (host copy)
 
     // training state
@@ -224,7 +226,7 @@ int tokenise(colibri_ctx* c) {
     HIP_TRY(c, hipMemcpyAsync(&npos, total.p, sizeof npos, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->npos = npos;
-    if ((rc = dev_alloc(c, c->tokstart, (size_t)npos + 2))) {
+    if ((rc = dev_alloc(c, c->tokstart, (size_t)npos + 2)) || (rc = dev_alloc(c, c->cls, (size_t)npos + 1))) {
         cleanup();
         return rc;
     }
@@ -240,7 +242,7 @@ int tokenise(colibri_ctx* c) {
     {
         Prof p(c, COLIBRI_K_TOKENISE);
         hipLaunchKernelGGL(tokenise_write_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, c->bytes.p, B, blockcnt.p, c->tokstart.p);
-        hipLaunchKernelGGL(position_info_kernel, dim3(pblk), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, npos, info.p, dcnt.p);
+        hipLaunchKernelGGL(position_info_kernel, dim3(pblk), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, npos, info.p, dcnt.p, c->cls.p);
         hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, dcnt.p, pblk, total.p);
     }
     uint32_t   ndelim = 0;
@@ -356,6 +358,9 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->bytes);
     dev_free(c->tokstart);
     dev_free(c->delimpos);
+    dev_free(c->cls);
+    dev_free(c->cnt1);
+    dev_free(c->rep1);
     for (auto& b : c->ids) dev_free(b);
     dev_free(c->scratch[0]);
     dev_free(c->scratch[1]);
@@ -734,6 +739,10 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     // radix-partition + LDS count (binned.hpp) for the plain n-gram path when every final bin fits its LDS table: 65 536 bins
     // x <= ~1000 distinct keys expected; beyond ~128 M tokens per device (or on request) the global open-addressed table is used
     bool binned = !synced && (o.table_mode == 2 || (o.table_mode == 0 && c->ntokens <= 128ull * 1000 * 1000));
+    // order 1 counted per class id when the encoding is canonical (class id <-> token bytes is then a bijection) and the class
+    // space is small enough for a dense array; table_mode 1 / 2 force the generic table / radix implementations (tests)
+    const bool uni_direct = !synced && o.table_mode == 0 && !(c->flags & kFlagNonCanonical) && c->maxclass < (1u << 28);
+    if (uni_direct && ((rc = dev_alloc(c, c->cnt1, (size_t)c->maxclass + 2)) || (rc = dev_alloc(c, c->rep1, (size_t)c->maxclass + 2)))) return rc;
     // ---- HBM layout (sized once; nothing is allocated inside the unsynced order loop) ----------------
     // table: an order admits at most `npos` windows -> 1.5x slots; results: every survivor has >= 2 occurrences
     const uint64_t table_slots64 = (uint64_t)npos + (npos >> 1) + 2048;
@@ -789,7 +798,24 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
         for (int n = 1; n <= maxlength; ++n) {
             uint32_t* id_prev = c->ids[cur].p;
             uint32_t* id_cur  = c->ids[cur ^ 1].p;
-            if (binned) {
+            if (n == 1 && uni_direct) {
+                // order 1 on the class-indexed count array (kernels.hpp §2b): no hashing, no table, LDS histogram for the Zipf head
+                const uint32_t nclasses = c->maxclass + 1;
+                HIP_TRY(c, hipMemsetAsync(c->cnt1.p, 0, sizeof(uint32_t) * nclasses, c->stream));
+                {
+                    Prof p(c, COLIBRI_K_COUNT);
+                    hipLaunchKernelGGL(uni_count_kernel, dim3(512), dim3(kBlock), 0, c->stream, c->cls.p, npos, c->cnt1.p, c->rep1.p, c->state.p);
+                }
+                {
+                    Prof p(c, COLIBRI_K_PRUNE);
+                    hipLaunchKernelGGL(uni_finish_kernel, dim3(stream_grid(nclasses)), dim3(kBlock), 0, c->stream, c->cnt1.p, c->rep1.p, nclasses, pl.thr, c->state.p, c->res_rep.p,
+                                       c->res_cnt.p, pl.res_cap);
+                }
+                {
+                    Prof p(c, COLIBRI_K_RESOLVE);
+                    hipLaunchKernelGGL(uni_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->cnt1.p, pl.thr, id_cur, c->state.p, npos);
+                }
+            } else if (binned) {
                 // orders 1-2 scan every position (almost all are admissible); from order 3 on only the positions that still
                 // carry a survivor id are visited (the active list the previous order's resolve left behind)
                 if (n == 1)

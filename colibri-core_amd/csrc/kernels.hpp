@@ -123,7 +123,7 @@ __device__ __forceinline__ bool is_delimiter(const uint8_t* bytes, const uint32_
 
 // pass over positions: validation flags, max class, delimiter count per block
 __global__ __launch_bounds__(kBlock) void position_info_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ tokstart, uint32_t npos,
-                                                                CorpusInfo* __restrict__ info, uint32_t* __restrict__ blockcnt) {
+                                                                CorpusInfo* __restrict__ info, uint32_t* __restrict__ blockcnt, uint32_t* __restrict__ cls_out) {
     const uint32_t i     = blockIdx.x * kBlock + threadIdx.x;
     uint32_t       flags = 0, cls = 0, delim = 0;
     if (i < npos) {
@@ -146,6 +146,7 @@ __global__ __launch_bounds__(kBlock) void position_info_kernel(const uint8_t* __
             cls = 0xFFFFFFFFu;
         }
     }
+    if (i < npos) cls_out[i] = delim ? 0u : cls;  // class id per position (0 = sentence delimiter); used by the order-1 fast path
     uint32_t total;
     block_exclusive_scan(delim, &total);
     if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
@@ -430,13 +431,132 @@ __global__ __launch_bounds__(kBlock) void clear_table_kernel(Slot* __restrict__ 
 }
 
 // =================================================================================================
+// 2b. order 1, class-indexed: for a canonical class encoding the class id IS an exact 32-bit identity of a unigram, so order 1
+//     needs neither hashing nor a table: a dense count array indexed by class (RCCL-all-reducible across shards), with the Zipf
+//     head absorbed by a per-block LDS histogram — class ids are frequency-ranked by construction of the class encoding
+//     (reference src/classencoder.cpp:220-224: most frequent word = lowest id), so "class < 8192" is the heavy-hitter set.
+//     The survivor id of a unigram is its class id.
+// =================================================================================================
+constexpr int kPrunePer  = 16;
+constexpr int kPruneTile = kBlock * kPrunePer;  // 4096 slots / classes per block iteration (prune, uni_finish, shard kernels)
+constexpr int kUniHead = 8192;  // classes counted in LDS
+constexpr int kUniPer  = 8;
+__global__ __launch_bounds__(kBlock) void uni_count_kernel(const uint32_t* __restrict__ cls, uint32_t npos, uint32_t* __restrict__ cnt1, uint32_t* __restrict__ rep1,
+                                                            DevState* __restrict__ st) {
+    if (st->done) return;
+    __shared__ uint32_t histL[kUniHead], fposL[kUniHead];
+    __shared__ uint32_t redL[kBlock / kWave];
+    for (int k = threadIdx.x; k < kUniHead; k += kBlock) {
+        histL[k] = 0;
+        fposL[k] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    // contiguous chunk per block (so that a head class gets ONE flush per block)
+    const uint32_t per   = (npos + gridDim.x - 1) / gridDim.x;
+    const uint32_t begin = blockIdx.x * per, end = min(npos, begin + per);
+    uint32_t       nadm  = 0;
+    for (uint32_t i0 = begin; i0 < end; i0 += kBlock * kUniPer) {
+#pragma unroll
+        for (int q = 0; q < kUniPer; ++q) {
+            const uint32_t i = i0 + q * kBlock + threadIdx.x;
+            if (i < end) {
+                const uint32_t c = cls[i];
+                if (c != 0) {
+                    ++nadm;
+                    if (c < (uint32_t)kUniHead) {
+                        atomicAdd(&histL[c], 1u);
+                        atomicMin(&fposL[c], i);
+                    } else if (atomicAdd(&cnt1[c], 1u) == 0u) {
+                        rep1[c] = i;  // exactly one increment sees 0: it names the representative position
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kUniHead; k += kBlock) {
+        const uint32_t h = histL[k];
+        if (h && atomicAdd(&cnt1[k], h) == 0u) rep1[k] = fposL[k];
+    }
+    for (int off = 32; off > 0; off >>= 1) nadm += __shfl_down(nadm, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nadm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t a = redL[0] + redL[1] + redL[2] + redL[3];
+        if (a) atomicAdd(&st->admitted, a);
+    }
+}
+// classes -> result list (threshold), found / kept
+__global__ __launch_bounds__(kBlock) void uni_finish_kernel(const uint32_t* __restrict__ cnt1, const uint32_t* __restrict__ rep1, uint32_t nclasses, uint32_t threshold,
+                                                             DevState* __restrict__ st, uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap) {
+    if (st->done) return;
+    __shared__ uint32_t baseL, redL[kBlock / kWave];
+    const uint32_t      res_base = st->res_total;
+    const uint32_t      ntiles   = (nclasses + kPruneTile - 1) / kPruneTile;
+    uint32_t            nfound   = 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t c0 = tile * kPruneTile + threadIdx.x * kPrunePer;
+        uint32_t       v[kPrunePer], k = 0;
+#pragma unroll
+        for (int q = 0; q < kPrunePer; ++q) {
+            v[q] = (c0 + q < nclasses) ? cnt1[c0 + q] : 0u;
+            nfound += v[q] != 0;
+            k += v[q] >= threshold;
+        }
+        uint32_t       total;
+        const uint32_t excl = block_exclusive_scan(k, &total);
+        if (threadIdx.x == 0) baseL = total ? atomicAdd(&st->kept, total) : 0;
+        __syncthreads();
+        uint32_t r = res_base + baseL + excl;
+#pragma unroll
+        for (int q = 0; q < kPrunePer; ++q) {
+            if (v[q] >= threshold) {
+                if (r < res_cap) {
+                    res_rep[r] = rep1[c0 + q];
+                    res_cnt[r] = v[q];
+                } else {
+                    st->overflow = 1;
+                }
+                ++r;
+            }
+        }
+        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) nfound += __shfl_down(nfound, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nfound;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t f = redL[0] + redL[1] + redL[2] + redL[3];
+        if (f) atomicAdd(&st->found, f);
+    }
+}
+// survivor id per position = the class id of a surviving unigram
+__global__ __launch_bounds__(kBlock) void uni_ids_kernel(const uint32_t* __restrict__ cls, const uint32_t* __restrict__ cnt1, uint32_t threshold, uint32_t* __restrict__ ids,
+                                                          DevState* __restrict__ st, uint32_t npos) {
+    if (st->done) return;
+    uint32_t nvalid = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npos; i += gridDim.x * kBlock) {
+        const uint32_t c  = cls[i];
+        const uint32_t id = (c != 0 && cnt1[c] >= threshold) ? c : kInvalid;
+        nvalid += id != kInvalid;
+        ids[i] = id;
+    }
+    __shared__ uint32_t redL[kBlock / kWave];
+    for (int off = 32; off > 0; off >>= 1) nvalid += __shfl_down(nvalid, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nvalid;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t v = redL[0] + redL[1] + redL[2] + redL[3];
+        if (v) atomicAdd(&st->valid, v);
+    }
+}
+
+// =================================================================================================
 // 3. prune + survivor compaction — replaces PatternModel::prune(threshold, n) (patternmodel.h:2107-2128)
 //    One streaming pass over the table: survivors (count >= threshold) are appended to the result arrays
 //    (wave-aggregated reservation) and their slot is tagged with the result index, which is the survivor id
 //    the next order's keys are built from.
 // =================================================================================================
-constexpr int kPrunePer  = 16;
-constexpr int kPruneTile = kBlock * kPrunePer;  // 4096 slots per block iteration
 __global__ __launch_bounds__(kBlock) void prune_kernel(Slot* __restrict__ table, DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ res_rep,
                                                         uint32_t* __restrict__ res_cnt, const uint32_t* __restrict__ nsrc, uint32_t minsrc, uint32_t res_cap) {
     if (st->done) return;

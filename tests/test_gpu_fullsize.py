@@ -46,7 +46,7 @@ def models():
     out = {}
     with capi.Context(0) as ctx:
         ctx.upload(payload)
-        for mode in (1, 2, 2):
+        for mode in (1, 2, 2, 0):
             st = ctx.train(mintokens=2, maxlength=5, table_mode=mode)
             key_off, key_bytes, counts, _ = ctx.export_arrays()
             out.setdefault(mode, []).append((st, key_off.copy(), key_bytes.copy(), counts.copy()))
@@ -64,6 +64,15 @@ def test_two_implementations_agree_at_full_size(models):
     assert sa.totaltokens == TOKENS and sum(sa.windows[1:6]) == 450005710
     ha = row_hashes(oa, ba, ca)
     hb = row_hashes(ob, bb, cb)
+    for x, y in zip(ha, hb):
+        assert np.array_equal(np.sort(x), np.sort(y))
+
+
+def test_default_mode_agrees_at_full_size(models):
+    """table_mode 0 (what bench.py runs): class-indexed order 1 + radix path for the higher orders"""
+    (sa, oa, ba, ca), (sb, ob, bb, cb) = models[1][0], models[0][0]
+    assert summary(sa) == summary(sb)
+    ha, hb = row_hashes(oa, ba, ca), row_hashes(ob, bb, cb)
     for x, y in zip(ha, hb):
         assert np.array_equal(np.sort(x), np.sort(y))
 

@@ -85,7 +85,7 @@ def _compare(ctx, payload, maxlength, mintokens=2, firstsentence=1, **mode):
 
 @pytest.mark.parametrize("name", sorted(small_corpora()))
 @pytest.mark.parametrize("maxlength", [1, 3, 5, 100])
-@pytest.mark.parametrize("table_mode", [1, 2], ids=["global_table", "radix_bins"])
+@pytest.mark.parametrize("table_mode", [0, 1, 2], ids=["auto", "global_table", "radix_bins"])
 def test_train_matches_oracle(ctx, name, maxlength, table_mode):
     """both implementations of the order-n pass: the open-addressed global table (device atomics) and radix partition + LDS count"""
     _compare(ctx, small_corpora()[name], maxlength, table_mode=table_mode)
@@ -134,7 +134,7 @@ def test_flexgram_class_in_corpus_is_rejected(ctx):
         ctx.upload(b"\x06\x04\x04\x07\x00")
 
 
-@pytest.mark.parametrize("table_mode", [1, 2], ids=["global_table", "radix_bins"])
+@pytest.mark.parametrize("table_mode", [0, 1, 2], ids=["auto", "global_table", "radix_bins"])
 def test_medium_zipf_properties(ctx, table_mode):
     """1M-token Zipf corpus: full parity against the oracle (about a second of CPU)."""
     from colibri_amd import synth

@@ -56,19 +56,24 @@ struct BinState {
 // LIST = false: one lane per corpus position (orders 1 and 2). LIST = true: one lane per entry of the active list = the positions
 // that still carry a survivor id of order n-1 (orders >= 3, where only a few percent of the positions can start a window);
 // rep_of is then indexed by list entry.
+// The level-A partition is fused in: the tile's records are counting-sorted by A bin inside LDS (the election arrays are dead by
+// then and are reused as the staging buffer) and leave as one contiguous run per (tile, bin) into that bin's fixed-capacity
+// region [a * region, (a+1) * region) of `recs`. A region that would overflow raises st->pad[0] (global-table rerun).
 template <class KeyFn, bool LIST>
-__global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __restrict__ recs, uint32_t* __restrict__ rep_of, DevState* __restrict__ st, BinState* __restrict__ bs,
-                                                           uint32_t npos, const uint32_t* __restrict__ list, const uint32_t* __restrict__ nlist) {
+__global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __restrict__ recs, uint32_t region, uint32_t* __restrict__ rep_of, DevState* __restrict__ st,
+                                                           BinState* __restrict__ bs, uint32_t npos, const uint32_t* __restrict__ list, const uint32_t* __restrict__ nlist) {
     if (st->done) return;
     const uint32_t nitems = LIST ? *nlist : npos;
-    __shared__ uint64_t keyL[kCountTile];
-    __shared__ uint32_t winL[kCountLSlot];
+    // phase E (election): keyL u64[2048] | winL u32[4096]   -- 32 KB, later reused as recL Rec[2048]
+    __shared__ __attribute__((aligned(16))) unsigned char rawL[kCountTile * sizeof(Rec)];
+    static_assert(kCountTile * sizeof(Rec) >= kCountTile * sizeof(uint64_t) + kCountLSlot * sizeof(uint32_t), "staging buffer must cover the election arrays");
+    uint64_t* const keyL = reinterpret_cast<uint64_t*>(rawL);
+    uint32_t* const winL = reinterpret_cast<uint32_t*>(rawL + kCountTile * sizeof(uint64_t));
+    Rec* const      recL = reinterpret_cast<Rec*>(rawL);
     __shared__ uint32_t cntL[kCountTile];
-    __shared__ uint32_t histL[kBins];
+    __shared__ uint32_t histL[kBins], offL[kBins], gbaseL[kBins];
     __shared__ uint32_t redL[kBlock / kWave];
-    __shared__ uint32_t baseL;
     __shared__ uint32_t posL[LIST ? kCountTile : 1];
-    histL[threadIdx.x] = 0;
     const uint32_t ntiles = (nitems + kCountTile - 1) / kCountTile;
     uint32_t       nadm   = 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -76,6 +81,7 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
         uint64_t       key[kCountPer], hash[kCountPer];
         uint32_t       posn[kCountPer];
         bool           adm[kCountPer];
+        histL[threadIdx.x] = 0;
 #pragma unroll
         for (int k = 0; k < kCountPer; ++k) {
             const uint32_t e = k * kBlock + threadIdx.x, j = base + e;
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
             }
         }
         __syncthreads();
-        uint32_t rep[kCountPer], nrep = 0;
+        uint32_t rep[kCountPer];
 #pragma unroll
         for (int k = 0; k < kCountPer; ++k) {
             const uint32_t e = k * kBlock + threadIdx.x;
@@ -102,33 +108,54 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
                 if (w != e && keyL[w] == key[k]) {
                     rep[k] = w;
                     atomicAdd(&cntL[w], 1u);
-                } else {
-                    ++nrep;
                 }
             }
         }
-        uint32_t       total;
-        const uint32_t excl = block_exclusive_scan(nrep, &total);  // (contains the barrier that completes cntL)
-        if (threadIdx.x == 0) baseL = total ? atomicAdd(&bs->nrec, total) : 0;
-        __syncthreads();
-        uint32_t o = baseL + excl;
+        __syncthreads();  // election done: keyL / winL are dead from here, cntL is complete
+        uint32_t rank[kCountPer];
 #pragma unroll
         for (int k = 0; k < kCountPer; ++k) {
             const uint32_t e = k * kBlock + threadIdx.x, j = base + e;
             if (j < nitems) rep_of[j] = adm[k] ? (LIST ? posL[rep[k]] : base + rep[k]) : kInvalid;  // always a corpus POSITION
-            if (adm[k] && rep[k] == e) {
+            rank[k] = kInvalid;
+            if (adm[k] && rep[k] == e) rank[k] = atomicAdd(&histL[(uint32_t)(hash[k] >> 56)], 1u);
+        }
+        __syncthreads();
+        {
+            uint32_t       tot;
+            const uint32_t h  = histL[threadIdx.x];
+            offL[threadIdx.x] = block_exclusive_scan(h, &tot);
+            uint32_t g        = 0;
+            if (h) {
+                const uint32_t at = atomicAdd(&bs->curA[threadIdx.x], h);  // one reservation per (tile, bin)
+                if (at + h > region) st->pad[0] = 1;                        // region full: the host re-runs on the global table
+                g = threadIdx.x * region + min(at, region - min(region, h));
+            }
+            gbaseL[threadIdx.x] = g;
+        }
+        __syncthreads();
+        uint32_t nrec_tile = 0;
+#pragma unroll
+        for (int k = 0; k < kCountPer; ++k) {
+            if (rank[k] != kInvalid) {
+                const uint32_t e  = k * kBlock + threadIdx.x;
                 const uint32_t hb = (uint32_t)(hash[k] >> 48);
                 Rec            r;
                 r.key  = key[k];
                 r.pos  = posn[k];
                 r.meta = (hb << 16) | (1u + cntL[e]);
-                recs[o++] = r;
-                atomicAdd(&histL[hb >> 8], 1u);
+                recL[offL[hb >> 8] + rank[k]] = r;
             }
         }
         __syncthreads();
+        nrec_tile = offL[kBins - 1] + histL[kBins - 1];
+        for (uint32_t j = threadIdx.x; j < nrec_tile; j += kBlock) {
+            const Rec      x = recL[j];
+            const uint32_t a = x.meta >> 24;
+            recs[gbaseL[a] + (j - offL[a])] = x;
+        }
+        __syncthreads();  // recL (= keyL / winL) is rewritten by the next tile
     }
-    if (histL[threadIdx.x]) atomicAdd(&bs->histA[threadIdx.x], histL[threadIdx.x]);
     for (int off = 32; off > 0; off >>= 1) nadm += __shfl_down(nadm, off, kWave);
     if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nadm;
     __syncthreads();
@@ -138,18 +165,20 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
     }
 }
 
-// one block: A-bin offsets and the tile prefix used by the level-B kernels
-__global__ __launch_bounds__(kBlock) void bin_offsets_kernel(BinState* __restrict__ bs) {
+// one block: A-bin record counts (left in curA by the fused emit), region bases, and the tile prefix of the level-B kernels
+__global__ __launch_bounds__(kBlock) void bin_offsets_kernel(BinState* __restrict__ bs, uint32_t region) {
     uint32_t       tot;
-    const uint32_t h = bs->histA[threadIdx.x];
-    const uint32_t o = block_exclusive_scan(h, &tot);
-    bs->offA[threadIdx.x] = o;
+    const uint32_t h = min(bs->curA[threadIdx.x], region);
+    block_exclusive_scan(h, &tot);
+    bs->histA[threadIdx.x] = h;
+    bs->offA[threadIdx.x]  = threadIdx.x * region;
     const uint32_t t  = (h + kScatTile - 1) / kScatTile;
     uint32_t       tt;
     const uint32_t tp = block_exclusive_scan(t, &tt);
     bs->tprefA[threadIdx.x] = tp;
     if (threadIdx.x == 0) {
-        bs->offA[kBins]   = tot;
+        bs->nrec          = tot;
+        bs->offA[kBins]   = kBins * region;
         bs->tprefA[kBins] = tt;
     }
 }
@@ -167,7 +196,7 @@ __device__ __forceinline__ bool locate_tile(const BinState* bs, uint32_t t, uint
     }
     a     = lo;
     begin = bs->offA[a] + (t - bs->tprefA[a]) * kScatTile;
-    end   = min(bs->offA[a + 1], begin + (uint32_t)kScatTile);
+    end   = min(bs->offA[a] + bs->histA[a], begin + (uint32_t)kScatTile);
     return true;
 }
 

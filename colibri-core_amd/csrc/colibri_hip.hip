@@ -523,29 +523,30 @@ int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t*
     HIP_TRY(c, hipMemsetAsync(c->ids_at.p, 0xFF, sizeof(uint32_t) * (size_t)pl.npos, c->stream));
     HIP_TRY(c, hipMemsetAsync(nlist_out, 0, sizeof(uint32_t), c->stream));
     if (use_list) HIP_TRY(c, hipMemsetAsync(ids_out, 0xFF, sizeof(uint32_t) * (size_t)pl.npos, c->stream));
+    // records leave the emit kernel already partitioned by A bin into fixed-capacity regions of recs[0]; level B moves them to recs[1]
+    const uint32_t region = (uint32_t)(c->recs[0].n / kBins);
     {
         Prof p(c, COLIBRI_K_EMIT);
         if (use_list)
-            hipLaunchKernelGGL((bin_emit_kernel<KeyFn, true>), dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, fn, c->recs[0].p, c->rep_of.p, c->state.p, c->binstate.p, pl.npos, list_in,
-                               nlist_in);
+            hipLaunchKernelGGL((bin_emit_kernel<KeyFn, true>), dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, fn, c->recs[0].p, region, c->rep_of.p, c->state.p, c->binstate.p, pl.npos,
+                               list_in, nlist_in);
         else
-            hipLaunchKernelGGL((bin_emit_kernel<KeyFn, false>), dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, fn, c->recs[0].p, c->rep_of.p, c->state.p, c->binstate.p, pl.npos,
+            hipLaunchKernelGGL((bin_emit_kernel<KeyFn, false>), dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, fn, c->recs[0].p, region, c->rep_of.p, c->state.p, c->binstate.p, pl.npos,
                                (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     }
     {
         Prof p(c, COLIBRI_K_SCATTER);
-        hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->binstate.p);
-        hipLaunchKernelGGL((bin_scatter_kernel<false>), dim3(tiles), dim3(kBlock), 0, c->stream, c->recs[0].p, c->recs[1].p, c->state.p, c->binstate.p);
-        hipLaunchKernelGGL(bin_hist2_kernel, dim3(tiles + kBins), dim3(kBlock), 0, c->stream, c->recs[1].p, c->state.p, c->binstate.p);
+        hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->binstate.p, region);
+        hipLaunchKernelGGL(bin_hist2_kernel, dim3(tiles + kBins), dim3(kBlock), 0, c->stream, c->recs[0].p, c->state.p, c->binstate.p);
         hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, &c->binstate.p->hist2[0], (uint32_t)kFinalBins, &c->binstate.p->total2);
-        hipLaunchKernelGGL((bin_scatter_kernel<true>), dim3(tiles + kBins), dim3(kBlock), 0, c->stream, c->recs[1].p, c->recs[0].p, c->state.p, c->binstate.p);
+        hipLaunchKernelGGL((bin_scatter_kernel<true>), dim3(tiles + kBins), dim3(kBlock), 0, c->stream, c->recs[0].p, c->recs[1].p, c->state.p, c->binstate.p);
     }
-    // sparse survivor arrays of this order live in recs[1] (free again after scatter B): two u32 planes of npos entries
-    uint32_t* sp_rep = reinterpret_cast<uint32_t*>(c->recs[1].p);
+    // sparse survivor arrays of this order live in recs[0] (free again after scatter B): two u32 planes of npos entries
+    uint32_t* sp_rep = reinterpret_cast<uint32_t*>(c->recs[0].p);
     uint32_t* sp_cnt = sp_rep + pl.npos;
     {
         Prof p(c, COLIBRI_K_BINCOUNT);
-        hipLaunchKernelGGL(bin_count_kernel, dim3(kFinalBins), dim3(kBlock), 0, c->stream, c->recs[0].p, c->state.p, c->binstate.p, pl.thr, sp_rep, sp_cnt, c->ids_at.p);
+        hipLaunchKernelGGL(bin_count_kernel, dim3(kFinalBins), dim3(kBlock), 0, c->stream, c->recs[1].p, c->state.p, c->binstate.p, pl.thr, sp_rep, sp_cnt, c->ids_at.p);
     }
     {
         Prof p(c, COLIBRI_K_PRUNE);
@@ -763,7 +764,8 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     if ((rc = dev_alloc(c, c->ids[0], (size_t)npos + 1))) return rc;
     if ((rc = dev_alloc(c, c->ids[1], (size_t)npos + 1))) return rc;
     if (binned) {
-        if ((rc = dev_alloc(c, c->recs[0], (size_t)npos + 1)) || (rc = dev_alloc(c, c->recs[1], (size_t)npos + 1))) return rc;
+        // recs[0]: 256 fixed-capacity A-bin regions (25 % slack over a uniform split + one scatter tile each); recs[1]: exact
+        if ((rc = dev_alloc(c, c->recs[0], ((size_t)npos + (npos >> 2)) / kBins * kBins + (size_t)kBins * kScatTile)) || (rc = dev_alloc(c, c->recs[1], (size_t)npos + 1))) return rc;
         if ((rc = dev_alloc(c, c->rep_of, (size_t)npos + 1)) || (rc = dev_alloc(c, c->ids_at, (size_t)npos + 1)) || (rc = dev_alloc(c, c->binstate, 1))) return rc;
         if ((rc = dev_alloc(c, c->alist[0], (size_t)npos + 1)) || (rc = dev_alloc(c, c->alist[1], (size_t)npos + 1)) || (rc = dev_alloc(c, c->alist_n, 2))) return rc;
     } else if ((rc = dev_alloc(c, c->table, pl.table_slots))) {

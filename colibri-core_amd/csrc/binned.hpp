@@ -213,6 +213,17 @@ __global__ __launch_bounds__(kBlock) void bin_hist2_kernel(const Rec* __restrict
     if (histL[threadIdx.x]) atomicAdd(&bs->hist2[a * kBins + threadIdx.x], histL[threadIdx.x]);
 }
 
+// final-bin offsets: hist2 -> exclusive offsets in (A, B) order, one block per A bin (the A totals are already known)
+__global__ __launch_bounds__(kBlock) void bin_scan2_kernel(BinState* __restrict__ bs) {
+    const uint32_t a = blockIdx.x;
+    uint32_t       before, tot;
+    block_exclusive_scan(threadIdx.x < a ? bs->histA[threadIdx.x] : 0u, &before);  // records in the A bins before this one
+    const uint32_t h = bs->hist2[a * kBins + threadIdx.x];
+    const uint32_t o = block_exclusive_scan(h, &tot);
+    bs->hist2[a * kBins + threadIdx.x] = before + o;
+    if (a == kBins - 1 && threadIdx.x == 0) bs->total2 = before + tot;
+}
+
 // tile-local counting sort + one reserved output run per (tile, bin)
 template <bool LEVEL_B>
 __global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restrict__ in, Rec* __restrict__ out, const DevState* __restrict__ st, BinState* __restrict__ bs) {
@@ -279,16 +290,10 @@ __global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restri
 // Survivors are written WITHOUT any global atomic: bin f owns the index range [hist2[f], hist2[f+1]) of the per-order sparse
 // arrays (it has at least as many records as survivors); the survivor id handed to the next order is id_base + that sparse
 // index — ids only have to be unique. compact_results_kernel turns the sparse arrays into the dense result list.
-__global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
-                                                            uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt, uint32_t* __restrict__ ids_at) {
-    if (st->done) return;
-    const uint32_t f     = blockIdx.x;
-    const uint32_t begin = bs->hist2[f];
-    const uint32_t end   = (f + 1 < (uint32_t)kFinalBins) ? bs->hist2[f + 1] : bs->total2;
-    if (begin >= end) return;
-    __shared__ unsigned long long keyT[kBinSlots];
-    __shared__ uint32_t           cntT[kBinSlots], repT[kBinSlots], idT[kBinSlots];
-    __shared__ uint32_t           redL[kBlock / kWave], failL;
+__device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t begin, const uint32_t end, const Rec* __restrict__ recs, DevState* __restrict__ st,
+                                              BinState* __restrict__ bs, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
+                                              uint32_t* __restrict__ ids_at, unsigned long long* keyT, uint32_t* cntT, uint32_t* repT, uint32_t* idT, uint32_t* redL,
+                                              uint32_t* failL) {
     // table size follows the bin: >= 2x its records (so never more than half full), a power of two in [256, 2048] — small
     // orders touch 65 536 mostly tiny bins and must not pay 40 KB of LDS initialisation each
     uint32_t nslots = kBlock;
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict
         cntT[s] = 0;
         repT[s] = 0xFFFFFFFFu;
     }
-    if (threadIdx.x == 0) failL = 0;
+    if (threadIdx.x == 0) *failL = 0;
     __syncthreads();
     uint32_t nnew = 0;
     for (uint32_t j0 = begin; j0 < end; j0 += kBlock) {  // block-uniform trip count: the wave-level merge below uses ballots
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict
             atomicAdd(&cntT[s], cnt);
             atomicMin(&repT[s], pos);  // smallest representative position: deterministic
         } else {
-            failL = 1;
+            *failL = 1;
         }
     }
     // distinct keys of this bin
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict
     if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nnew;
     __syncthreads();
     const uint32_t distinct = redL[0] + redL[1] + redL[2] + redL[3];
-    if (failL || distinct > kBinMaxLoad) {
+    if (*failL || distinct > kBinMaxLoad) {
         if (threadIdx.x == 0) {
             bs->overflow_bin = 1;
             st->pad[0]       = 1;  // sticky across orders: BinState is zeroed per order
@@ -400,6 +405,23 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict
         while (keyT[s] != x.key) s = (s + 1) & smask;
         const uint32_t id = idT[s];
         if (id != kInvalid) ids_at[x.pos] = id;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
+                                                            uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt, uint32_t* __restrict__ ids_at) {
+    if (st->done) return;
+    __shared__ unsigned long long keyT[kBinSlots];
+    __shared__ uint32_t           cntT[kBinSlots], repT[kBinSlots], idT[kBinSlots];
+    __shared__ uint32_t           redL[kBlock / kWave], failL;
+    // persistent blocks walk the final bins: small orders leave most of the 65 536 bins empty, and an empty bin must cost a
+    // loop iteration, not a block launch
+    for (uint32_t f = blockIdx.x; f < (uint32_t)kFinalBins; f += gridDim.x) {
+        const uint32_t begin = bs->hist2[f];
+        const uint32_t end   = (f + 1 < (uint32_t)kFinalBins) ? bs->hist2[f + 1] : bs->total2;
+        if (begin >= end) continue;
+        bin_count_one(f, begin, end, recs, st, bs, threshold, sp_rep, sp_cnt, ids_at, keyT, cntT, repT, idT, redL, &failL);
+        __syncthreads();
     }
 }
 

@@ -538,7 +538,7 @@ int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t*
         Prof p(c, COLIBRI_K_SCATTER);
         hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->binstate.p, region);
         hipLaunchKernelGGL(bin_hist2_kernel, dim3(tiles + kBins), dim3(kBlock), 0, c->stream, c->recs[0].p, c->state.p, c->binstate.p);
-        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, &c->binstate.p->hist2[0], (uint32_t)kFinalBins, &c->binstate.p->total2);
+        hipLaunchKernelGGL(bin_scan2_kernel, dim3(kBins), dim3(kBlock), 0, c->stream, c->binstate.p);
         hipLaunchKernelGGL((bin_scatter_kernel<true>), dim3(tiles + kBins), dim3(kBlock), 0, c->stream, c->recs[0].p, c->recs[1].p, c->state.p, c->binstate.p);
     }
     // sparse survivor arrays of this order live in recs[0] (free again after scatter B): two u32 planes of npos entries
@@ -546,7 +546,7 @@ int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t*
     uint32_t* sp_cnt = sp_rep + pl.npos;
     {
         Prof p(c, COLIBRI_K_BINCOUNT);
-        hipLaunchKernelGGL(bin_count_kernel, dim3(kFinalBins), dim3(kBlock), 0, c->stream, c->recs[1].p, c->state.p, c->binstate.p, pl.thr, sp_rep, sp_cnt, c->ids_at.p);
+        hipLaunchKernelGGL(bin_count_kernel, dim3(256 * 12), dim3(kBlock), 0, c->stream, c->recs[1].p, c->state.p, c->binstate.p, pl.thr, sp_rep, sp_cnt, c->ids_at.p);
     }
     {
         Prof p(c, COLIBRI_K_PRUNE);

@@ -290,12 +290,75 @@ __global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restri
 // Survivors are written WITHOUT any global atomic: bin f owns the index range [hist2[f], hist2[f+1]) of the per-order sparse
 // arrays (it has at least as many records as survivors); the survivor id handed to the next order is id_base + that sparse
 // index — ids only have to be unique. compact_results_kernel turns the sparse arrays into the dense result list.
+// insert one record per lane into the bin's LDS table; returns the slot (kInvalid for lanes that are idle or were folded into
+// their wave's leader). Must be called by all lanes of the block together (wave ballots inside).
+__device__ __forceinline__ uint32_t bin_insert(const bool valid, const Rec& x, unsigned long long* keyT, uint32_t* cntT, uint32_t* repT, const uint32_t smask,
+                                               const uint32_t nslots, uint32_t& nnew, uint32_t* failL) {
+    // Heavy hitters arrive as many records with the same key (one per 2048-window tile). Lanes that hold the same key as the
+    // wave's first active lane fold into that lane before touching LDS: a hot bin then costs one LDS update per wave
+    // instead of 64 serialised ones on the same address.
+    uint32_t       cnt   = x.meta & 0xFFFFu;
+    uint32_t       pos   = x.pos;
+    bool           alive = valid;
+    const uint64_t act   = __ballot(valid);
+    if (act) {
+        const int                leader = __builtin_ctzll(act);
+        const unsigned long long k0     = __shfl((unsigned long long)x.key, leader, kWave);
+        const bool               same   = valid && x.key == k0;
+        const uint64_t           sm     = __ballot(same);
+        if (__popcll(sm) > 1) {
+            uint32_t c = same ? cnt : 0u, pmin = same ? pos : 0xFFFFFFFFu;
+            for (int off = 32; off > 0; off >>= 1) {
+                c += __shfl_xor(c, off, kWave);
+                pmin = min(pmin, __shfl_xor(pmin, off, kWave));
+            }
+            if (same) {
+                alive = (int)(threadIdx.x & (kWave - 1)) == leader;
+                cnt   = c;
+                pos   = pmin;
+            }
+        }
+    }
+    if (!alive) return kInvalid;
+    uint32_t s  = (uint32_t)mix64(x.key) & smask;
+    bool     ok = false;
+    for (uint32_t probe = 0; probe < nslots; ++probe) {
+        const unsigned long long old = atomicCAS(&keyT[s], (unsigned long long)kEmptyKey, (unsigned long long)x.key);
+        if (old == kEmptyKey) {
+            ++nnew;
+            ok = true;
+            break;
+        }
+        if (old == x.key) {
+            ok = true;
+            break;
+        }
+        s = (s + 1) & smask;
+    }
+    if (!ok) {
+        *failL = 1;
+        return kInvalid;
+    }
+    atomicAdd(&cntT[s], cnt);
+    atomicMin(&repT[s], pos);  // smallest representative position: deterministic
+    return s;
+}
+
+constexpr int kBinRegPer = 8;  // records per lane held in registers: bins of up to 2048 records are read from HBM exactly once
+
 __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t begin, const uint32_t end, const Rec* __restrict__ recs, DevState* __restrict__ st,
                                               BinState* __restrict__ bs, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
                                               uint32_t* __restrict__ ids_at, unsigned long long* keyT, uint32_t* cntT, uint32_t* repT, uint32_t* idT, uint32_t* redL,
                                               uint32_t* failL) {
+    // all loads of the (first 2048) records are issued before anything else: a bin is latency-bound, not bandwidth-bound
+    Rec xr[kBinRegPer];
+#pragma unroll
+    for (int q = 0; q < kBinRegPer; ++q) {
+        const uint32_t j = begin + q * kBlock + threadIdx.x;
+        if (j < end) xr[q] = recs[j];
+    }
     // table size follows the bin: >= 2x its records (so never more than half full), a power of two in [256, 2048] — small
-    // orders touch 65 536 mostly tiny bins and must not pay 40 KB of LDS initialisation each
+    // orders touch mostly tiny bins and must not pay 40 KB of LDS initialisation each
     uint32_t nslots = kBlock;
     while (nslots < (uint32_t)kBinSlots && nslots < 2u * (end - begin)) nslots <<= 1;
     const uint32_t smask = nslots - 1;
@@ -307,58 +370,19 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
     if (threadIdx.x == 0) *failL = 0;
     __syncthreads();
     uint32_t nnew = 0;
-    for (uint32_t j0 = begin; j0 < end; j0 += kBlock) {  // block-uniform trip count: the wave-level merge below uses ballots
-        const uint32_t j     = j0 + threadIdx.x;
-        const bool     valid = j < end;
+    uint32_t sl[kBinRegPer];
+#pragma unroll
+    for (int q = 0; q < kBinRegPer; ++q) {
+        const uint32_t j = begin + q * kBlock + threadIdx.x;
+        sl[q]            = kInvalid;
+        if (begin + q * kBlock < end) sl[q] = bin_insert(j < end, xr[q], keyT, cntT, repT, smask, nslots, nnew, failL);  // block-uniform guard
+    }
+    const uint32_t rest = begin + kBinRegPer * kBlock;  // bins larger than the register window (hot bins) stream the remainder
+    for (uint32_t j0 = rest; j0 < end; j0 += kBlock) {
+        const uint32_t j = j0 + threadIdx.x;
         Rec            x{};
-        if (valid) x = recs[j];
-        // Heavy hitters arrive as many records with the same key (one per 2048-window tile). Lanes that hold the same key as the
-        // wave's first active lane fold into that lane before touching LDS: a hot bin then costs one LDS update per wave
-        // instead of 64 serialised ones on the same address.
-        uint32_t       cnt   = x.meta & 0xFFFFu;
-        uint32_t       pos   = x.pos;
-        bool           alive = valid;
-        const uint64_t act   = __ballot(valid);
-        if (act) {
-            const int                leader = __builtin_ctzll(act);
-            const unsigned long long k0     = __shfl((unsigned long long)x.key, leader, kWave);
-            const bool               same   = valid && x.key == k0;
-            const uint64_t           sm     = __ballot(same);
-            if (__popcll(sm) > 1) {
-                uint32_t c = same ? cnt : 0u, pmin = same ? pos : 0xFFFFFFFFu;
-                for (int off = 32; off > 0; off >>= 1) {
-                    c += __shfl_xor(c, off, kWave);
-                    pmin = min(pmin, __shfl_xor(pmin, off, kWave));
-                }
-                if (same) {
-                    alive = (int)(threadIdx.x & (kWave - 1)) == leader;
-                    cnt   = c;
-                    pos   = pmin;
-                }
-            }
-        }
-        if (!alive) continue;
-        uint32_t s  = (uint32_t)mix64(x.key) & smask;
-        bool     ok = false;
-        for (uint32_t probe = 0; probe < nslots; ++probe) {
-            const unsigned long long old = atomicCAS(&keyT[s], (unsigned long long)kEmptyKey, (unsigned long long)x.key);
-            if (old == kEmptyKey) {
-                ++nnew;
-                ok = true;
-                break;
-            }
-            if (old == x.key) {
-                ok = true;
-                break;
-            }
-            s = (s + 1) & smask;
-        }
-        if (ok) {
-            atomicAdd(&cntT[s], cnt);
-            atomicMin(&repT[s], pos);  // smallest representative position: deterministic
-        } else {
-            *failL = 1;
-        }
+        if (j < end) x = recs[j];
+        bin_insert(j < end, x, keyT, cntT, repT, smask, nslots, nnew, failL);
     }
     // distinct keys of this bin
     for (int off = 32; off > 0; off >>= 1) nnew += __shfl_down(nnew, off, kWave);
@@ -372,7 +396,7 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
         }
         return;
     }
-    // survivors -> one reserved result range per bin
+    // survivors -> this bin's own range of the sparse result arrays (no global atomic)
     const uint32_t per = nslots / kBlock;  // 1..8 consecutive slots per lane
     uint32_t       keep = 0;
     for (uint32_t q = 0; q < per; ++q) {
@@ -399,7 +423,20 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
     __syncthreads();
     if (total == 0) return;  // nothing in this bin survives: ids_at keeps its kInvalid fill
     // survivor id at every representative position of a surviving key (ids_at was pre-filled with kInvalid)
-    for (uint32_t j = begin + threadIdx.x; j < end; j += kBlock) {
+#pragma unroll
+    for (int q = 0; q < kBinRegPer; ++q) {
+        const uint32_t j = begin + q * kBlock + threadIdx.x;
+        if (j < end) {
+            uint32_t s = sl[q];
+            if (s == kInvalid) {  // folded into a wave leader: look the key up
+                s = (uint32_t)mix64(xr[q].key) & smask;
+                while (keyT[s] != xr[q].key) s = (s + 1) & smask;
+            }
+            const uint32_t id = idT[s];
+            if (id != kInvalid) ids_at[xr[q].pos] = id;
+        }
+    }
+    for (uint32_t j = rest + threadIdx.x; j < end; j += kBlock) {
         const Rec x = recs[j];
         uint32_t  s = (uint32_t)mix64(x.key) & smask;
         while (keyT[s] != x.key) s = (s + 1) & smask;

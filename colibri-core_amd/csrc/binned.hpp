@@ -39,7 +39,8 @@ constexpr uint32_t kBinMaxLoad = 1900;               // distinct keys a final bi
 struct BinState {
     uint32_t nrec;               // records emitted
     uint32_t overflow_bin;       // a final bin exceeded its LDS table -> host falls back to the global-table path
-    uint32_t pad[2];
+    uint32_t bshift;             // level B uses 256 >> bshift sub-bins: small orders get fewer, fuller final bins
+    uint32_t pad;
     uint32_t histA[kBins];       // records per A bin
     uint32_t offA[kBins + 1];    // exclusive scan
     uint32_t tprefA[kBins + 1];  // tiles per A bin, exclusive scan (for the level-B kernels)
@@ -180,6 +181,12 @@ __global__ __launch_bounds__(kBlock) void bin_offsets_kernel(BinState* __restric
         bs->nrec          = tot;
         bs->offA[kBins]   = kBins * region;
         bs->tprefA[kBins] = tt;
+        // aim at <= ~1024 records per final bin: nB = smallest power of two >= nrec / (256 * 1024), at most 256
+        uint32_t nb = 1;
+        while (nb < (uint32_t)kBins && (uint64_t)nb * kBins * 1024u < tot) nb <<= 1;
+        uint32_t sh = 0;
+        while ((uint32_t)kBins >> sh > nb) ++sh;
+        bs->bshift = sh;
     }
 }
 
@@ -208,7 +215,8 @@ __global__ __launch_bounds__(kBlock) void bin_hist2_kernel(const Rec* __restrict
     if (!locate_tile(bs, blockIdx.x, a, begin, end)) return;
     histL[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t j = begin + threadIdx.x; j < end; j += kBlock) atomicAdd(&histL[(recs[j].meta >> 16) & 255u], 1u);
+    const uint32_t bsh = bs->bshift;
+    for (uint32_t j = begin + threadIdx.x; j < end; j += kBlock) atomicAdd(&histL[((recs[j].meta >> 16) & 255u) >> bsh], 1u);
     __syncthreads();
     if (histL[threadIdx.x]) atomicAdd(&bs->hist2[a * kBins + threadIdx.x], histL[threadIdx.x]);
 }
@@ -239,6 +247,7 @@ __global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restri
         if (begin >= nrec) return;
         end = min(nrec, begin + (uint32_t)kScatTile);
     }
+    const uint32_t bsh = LEVEL_B ? bs->bshift : 0u;
     histL[threadIdx.x] = 0;
     __syncthreads();
     Rec      r[kScatPer];
@@ -248,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restri
         const uint32_t j = begin + q * kBlock + threadIdx.x;
         if (j < end) {
             r[q]             = in[j];
-            const uint32_t b = LEVEL_B ? ((r[q].meta >> 16) & 255u) : (r[q].meta >> 24);
+            const uint32_t b = LEVEL_B ? (((r[q].meta >> 16) & 255u) >> bsh) : (r[q].meta >> 24);
             rank[q]          = atomicAdd(&histL[b], 1u);
         }
     }
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restri
     for (int q = 0; q < kScatPer; ++q) {
         const uint32_t j = begin + q * kBlock + threadIdx.x;
         if (j < end) {
-            const uint32_t b       = LEVEL_B ? ((r[q].meta >> 16) & 255u) : (r[q].meta >> 24);
+            const uint32_t b       = LEVEL_B ? (((r[q].meta >> 16) & 255u) >> bsh) : (r[q].meta >> 24);
             recL[offL[b] + rank[q]] = r[q];
         }
     }
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restri
     const uint32_t n = end - begin;
     for (uint32_t j = threadIdx.x; j < n; j += kBlock) {
         const Rec      x = recL[j];
-        const uint32_t b = LEVEL_B ? ((x.meta >> 16) & 255u) : (x.meta >> 24);
+        const uint32_t b = LEVEL_B ? (((x.meta >> 16) & 255u) >> bsh) : (x.meta >> 24);
         out[gbaseL[b] + (j - offL[b])] = x;
     }
 }

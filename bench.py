@@ -39,11 +39,11 @@ def algorithmic_bytes(nbytes, npos, stats, maxlength):
          build share  P_n * (8 + 4 + 4)      per admitted window: key read, count read, count write
                     + D_n * (8 + 4)          per distinct candidate: key + count written once
        (the T/8 survivor-bitmap write of the formula belongs to the resolve kernel and is left out).
-       Returns (scan bytes, build bytes) summed over the orders."""
-    scan = build = 0.0
+       Returns per-order lists (scan bytes, build bytes), index 0 = order 1."""
+    scan, build = [], []
     for n in range(1, maxlength + 1):
-        scan += nbytes + 4.0 * npos + (stats.windows[n] * 2.0 / 8.0 if n > 1 else 0.0)
-        build += stats.admitted[n] * 16.0 + stats.found[n] * 12.0
+        scan.append(nbytes + 4.0 * npos + (stats.windows[n] * 2.0 / 8.0 if n > 1 else 0.0))
+        build.append(stats.admitted[n] * 16.0 + stats.found[n] * 12.0)
     return scan, build
 
 
@@ -185,16 +185,19 @@ def main():
         return
 
     value = windows * args.steps / elapsed / 1e6
-    scan_b, build_b = algorithmic_bytes(payload.size, ctx.positions(), st, MAXLENGTH)
+    scan_n, build_n = algorithmic_bytes(payload.size, ctx.positions(), st, MAXLENGTH)
+    scan_b, build_b = sum(scan_n), sum(build_n)
     binned = kn[capi.K_BINCOUNT] > 0
-    # the dominant kernel: radix path -> bin_count_kernel (per-bin LDS hash build; the build share of the formula);
-    #                      global-table path -> count_kernel (scan + hash + build in one launch per order)
+    # Which kernels ran: global-table path -> count_kernel does scan + hash + build for every order. Radix path -> order 1 is the
+    # class-indexed uni_count_kernel (class K_COUNT, one launch), orders >= 2 are emit / scatter / bin_count; the dominant kernel
+    # (largest total time in the rocprofv3 stats) is bin_count_kernel, whose algorithmic bytes are the build share of ITS orders.
+    uni = binned and kn[capi.K_COUNT] > 0
     dom = capi.K_BINCOUNT if binned else capi.K_COUNT
-    dom_bytes = build_b if binned else scan_b + build_b
+    dom_bytes = (sum(build_n[1:]) if uni else build_b) if binned else scan_b + build_b
     launches_per_step = kn[dom] / max(1, args.steps)
     avg_launch_ms = kms[dom] / max(1, kn[dom])
     achieved = (dom_bytes / max(1.0, launches_per_step)) / (avg_launch_ms * 1e-3) / 1e9 if kn[dom] else 0.0
-    stage = (capi.K_EMIT, capi.K_SCATTER, capi.K_BINCOUNT) if binned else (capi.K_COUNT,)
+    stage = (capi.K_COUNT, capi.K_EMIT, capi.K_SCATTER, capi.K_BINCOUNT) if binned else (capi.K_COUNT,)
     stage_ms = sum(kms[k] for k in stage) / max(1, args.steps)
     stage_gbs = (scan_b + build_b) / (stage_ms * 1e-3) / 1e9 if stage_ms else 0.0
     out = {
@@ -222,7 +225,7 @@ def main():
             "corpus_generation_s_untimed": round(gen_s, 2),
         },
         "roofline": {
-            "kernel": ("colibri::bin_count_kernel (per-bin LDS hash build + threshold + survivor ids; one launch per order)" if binned else
+            "kernel": ("colibri::bin_count_kernel (per-bin LDS hash build + threshold + survivor ids; one launch per order >= 2)" if binned else
                        "colibri::count_kernel (scan + SpookyHash + global hash-table build; one launch per order)"),
             "bound": "hbm",
             "achieved": round(achieved, 2),

@@ -54,6 +54,7 @@ struct colibri_ctx {
     DevBuf<uint32_t>  cls;              // class id per position (0 = delimiter)
     DevBuf<uint32_t>  cnt1, rep1;       // order-1 fast path: count / representative position per class
     std::vector<uint64_t> lenhist;  // sentence-length histogram (host copy)
+    uint64_t              windows_n[COLIBRI_MAX_ORDER] = {0};  // W_n = n-token windows inside sentences, from the histogram (once per upload)
 
     // training state
     bool              trained = false;
@@ -271,6 +272,15 @@ int tokenise(colibri_ctx* c) {
     if (ndelim) HIP_TRY(c, hipMemcpyAsync(&last_delim, c->delimpos.p + (ndelim - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
+    {  // W_n = sum_len hist[len] * (len - n + 1) for len >= n, via suffix sums: S0(n) = #sentences with len >= n, S1(n) = sum of their lengths
+        uint64_t s0 = 0, s1 = 0;
+        std::fill(std::begin(c->windows_n), std::end(c->windows_n), 0);
+        for (size_t len = c->lenhist.size(); len-- > 1;) {
+            s0 += c->lenhist[len];
+            s1 += c->lenhist[len] * (uint64_t)len;
+            if (len < COLIBRI_MAX_ORDER) c->windows_n[len] = s1 - s0 * (uint64_t)(len - 1);
+        }
+    }
     const uint32_t trailing = ndelim ? npos - (last_delim + 1) : npos;
     c->nsent                = ndelim + (trailing ? 1u : 0u);
     dev_free(dcnt);
@@ -940,9 +950,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     s.train_ms    = ms;
     for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) {
         s.pruned[n] = s.found[n] - s.kept[n];
-        uint64_t w  = 0;
-        for (size_t len = (size_t)n; len < c->lenhist.size(); ++len) w += c->lenhist[len] * (uint64_t)(len - n + 1);
-        s.windows[n] = (n <= o.maxlength) ? w : 0;
+        s.windows[n] = (n <= o.maxlength) ? c->windows_n[n] : 0;
     }
     s.totaltypes = s.found[1];  // distinct unigrams before pruning (patternmodel.h:1199-1201)
     c->trained   = true;
@@ -1390,9 +1398,7 @@ int colibri_shard_finish(colibri_ctx* c, const uint64_t* found_global, const uin
         s.kept[n]     = kept_global[n];
         s.pruned[n]   = s.found[n] - s.kept[n];
         s.admitted[n] = sh.admitted_n[n];
-        uint64_t w    = 0;
-        for (size_t len = (size_t)n; len < c->lenhist.size(); ++len) w += c->lenhist[len] * (uint64_t)(len - n + 1);
-        s.windows[n] = (n <= c->opt.maxlength) ? w : 0;
+        s.windows[n] = (n <= c->opt.maxlength) ? c->windows_n[n] : 0;
     }
     s.totaltypes        = s.found[1];
     c->hstate.res_total = sh.res_total;

@@ -156,9 +156,11 @@ __global__ __launch_bounds__(kBlock) void position_info_kernel(const uint8_t* __
         f |= __shfl_down(f, off, kWave);
         c = max(c, __shfl_down(c, off, kWave));
     }
+    // one atomic per wave only when it would change something: a hot word takes ~83 M atomics/s, and 1.6 M wave-level atomicMax
+    // calls on one address used to make this kernel 18 ms for 100 M tokens
     if ((threadIdx.x & (kWave - 1)) == 0) {
-        if (f) atomicOr(&info->flags, f);
-        if (c) atomicMax(&info->maxclass, c);
+        if (f && (__hip_atomic_load(&info->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & f) != f) atomicOr(&info->flags, f);
+        if (c > __hip_atomic_load(&info->maxclass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&info->maxclass, c);
     }
 }
 

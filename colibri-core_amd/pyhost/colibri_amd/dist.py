@@ -39,12 +39,20 @@ class ShardedTrainer:
         self.dist.all_to_all_single(r, s)
         return [int(x) for x in r.tolist()]
 
+    def _sync(self, tensor):
+        """RCCL collectives are enqueued on torch's stream; the library works on its own HIP stream and must only see finished
+        buffers (and vice versa: every colibri_shard_* call returns with its stream drained)."""
+        if tensor.is_cuda:
+            self.torch.cuda.current_stream(tensor.device).synchronize()
+
     def _all_to_all_v(self, tensor, send_sizes, recv_sizes):
         home = tensor.device
         src = tensor.contiguous().cpu() if (self.stage_host and tensor.is_cuda) else tensor.contiguous()
         out = self.torch.empty(sum(recv_sizes), dtype=src.dtype, device=src.device)
         self.dist.all_to_all_single(out, src, recv_sizes, send_sizes)
-        return out.to(home) if out.device != home else out
+        out = out.to(home) if out.device != home else out
+        self._sync(out)
+        return out
 
     def _all_gather_ints(self, values):
         t = self.torch

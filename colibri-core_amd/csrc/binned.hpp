@@ -357,8 +357,8 @@ constexpr int kBinRegPer = 8;  // records per lane held in registers: bins of up
 
 __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t begin, const uint32_t end, const Rec* __restrict__ recs, DevState* __restrict__ st,
                                               BinState* __restrict__ bs, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
-                                              uint32_t* __restrict__ ids_at, unsigned long long* keyT, uint32_t* cntT, uint32_t* repT, uint32_t* idT, uint32_t* redL,
-                                              uint32_t* failL) {
+                                              unsigned long long* __restrict__ sp_key, uint32_t* __restrict__ ids_at, unsigned long long* keyT, uint32_t* cntT,
+                                              uint32_t* repT, uint32_t* idT, uint32_t* redL, uint32_t* failL) {
     // all loads of the (first 2048) records are issued before anything else: a bin is latency-bound, not bandwidth-bound
     Rec xr[kBinRegPer];
 #pragma unroll
@@ -423,7 +423,8 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
         if (keyT[s] != kEmptyKey && cntT[s] >= threshold) {
             sp_rep[r] = repT[s];
             sp_cnt[r] = cntT[s];
-            id        = id_base + r;
+            if (sp_key != nullptr) sp_key[r] = keyT[s];  // sharded runs: the sparse arrays ARE the local candidate list
+            id = id_base + r;
             ++r;
         }
         idT[s] = id;
@@ -455,7 +456,8 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
 }
 
 __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
-                                                            uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt, uint32_t* __restrict__ ids_at) {
+                                                            uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt, unsigned long long* __restrict__ sp_key,
+                                                            uint32_t* __restrict__ ids_at) {
     if (st->done) return;
     __shared__ unsigned long long keyT[kBinSlots];
     __shared__ uint32_t           cntT[kBinSlots], repT[kBinSlots], idT[kBinSlots];
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict
         const uint32_t begin = bs->hist2[f];
         const uint32_t end   = (f + 1 < (uint32_t)kFinalBins) ? bs->hist2[f + 1] : bs->total2;
         if (begin >= end) continue;
-        bin_count_one(f, begin, end, recs, st, bs, threshold, sp_rep, sp_cnt, ids_at, keyT, cntT, repT, idT, redL, &failL);
+        bin_count_one(f, begin, end, recs, st, bs, threshold, sp_rep, sp_cnt, sp_key, ids_at, keyT, cntT, repT, idT, redL, &failL);
         __syncthreads();
     }
 }
@@ -525,7 +527,8 @@ constexpr int kResTile = kBlock * kResPer;
 template <bool LIST>
 __global__ __launch_bounds__(kBlock) void bin_resolve_kernel(const uint32_t* __restrict__ rep_of, const uint32_t* __restrict__ ids_at, uint32_t* __restrict__ ids,
                                                               DevState* __restrict__ st, uint32_t npos, const uint32_t* __restrict__ list_in,
-                                                              const uint32_t* __restrict__ nlist_in, uint32_t* __restrict__ list_out, uint32_t* __restrict__ nlist_out) {
+                                                              const uint32_t* __restrict__ nlist_in, uint32_t* __restrict__ list_out, uint32_t* __restrict__ nlist_out,
+                                                              const uint32_t* __restrict__ remap, uint32_t remap_base) {
     if (st->done) return;
     __shared__ uint32_t baseL;
     __shared__ uint32_t redL[kBlock / kWave];
@@ -543,6 +546,7 @@ __global__ __launch_bounds__(kBlock) void bin_resolve_kernel(const uint32_t* __r
                 const uint32_t r = rep_of[j];
                 pos[q]           = LIST ? list_in[j] : j;
                 if (r != kInvalid) id[q] = ids_at[r];
+                if (remap != nullptr && id[q] != kInvalid) id[q] = remap[id[q] - remap_base];  // sharded: local sparse id -> global survivor id
                 if (LIST) {
                     if (id[q] != kInvalid) ids[pos[q]] = id[q];  // ids was pre-filled with kInvalid
                 } else {

@@ -101,6 +101,9 @@ struct colibri_ctx {
         DevBuf<uint32_t> sorted_gid, ugid;    // forward index: sorted global ids of the pairs; distinct ids
         DevBuf<unsigned long long> uoff;      // first reference of each distinct id
         uint64_t         index_gids = 0;
+        bool             radix = false, pass_radix = false, list_valid = false, pass_list = false;  // local counting of n-gram passes on the radix path (<= 128 M tokens per rank)
+        uint32_t         nsparse = 0;                         // sparse candidate range of the current radix pass
+        DevBuf<uint32_t> gid_of_sparse;
         DevBuf<unsigned long long> tkeys, pkeys;      // candidates: extracted, then partitioned by owner
         DevBuf<uint32_t>           tcounts, tslots, pcounts, pslots;
         DevBuf<uint32_t>           small;             // [0]=ncand, [1..64]=owner hist, [65..129]=owner offsets, [130..193]=cursors, [200..265]=src offsets
@@ -408,6 +411,7 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->sh.sorted_gid);
     dev_free(c->sh.ugid);
     dev_free(c->sh.uoff);
+    dev_free(c->sh.gid_of_sparse);
     dev_free(c->table);
     dev_free(c->res_rep);
     dev_free(c->res_cnt);
@@ -522,17 +526,27 @@ void launch_resolve(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids) {
 // ---- binned path: one order = emit -> scatter A -> hist2 -> scan -> scatter B -> per-bin LDS count -> resolve --------------
 // `use_list`: iterate the active list built by the previous order's resolve instead of all positions (orders >= 3);
 // `build_list`: make resolve build the list for the next order. Lists ping-pong: order n reads alist[n & 1], writes alist[(n+1) & 1].
+struct BinnedIO {
+    uint32_t*           sp_rep;
+    uint32_t*           sp_cnt;
+    unsigned long long* sp_key;  // only filled for sharded runs (the sparse arrays are then the local candidate list)
+};
+BinnedIO binned_planes(colibri_ctx* c, const TrainPlan& pl, bool with_keys) {
+    // the sparse survivor arrays of an order live in recs[0] (free again after scatter B): u32 planes of npos entries, then u64 keys
+    BinnedIO io{};
+    io.sp_rep = reinterpret_cast<uint32_t*>(c->recs[0].p);
+    io.sp_cnt = io.sp_rep + pl.npos;
+    io.sp_key = with_keys ? reinterpret_cast<unsigned long long*>(io.sp_rep + 2 * (size_t)pl.npos) : nullptr;
+    return io;
+}
+
 template <class KeyFn>
-int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t* ids_out, int n, bool use_list, bool build_list) {
+int binned_count_stage(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, int n, bool use_list, uint32_t thr, bool with_keys) {
     const uint32_t  tiles    = blocks_for(pl.npos, kScatTile) + 1;
     const uint32_t* list_in  = c->alist[n & 1].p;
     const uint32_t* nlist_in = c->alist_n.p + (n & 1);
-    uint32_t*       list_out  = build_list ? c->alist[(n + 1) & 1].p : nullptr;
-    uint32_t*       nlist_out = c->alist_n.p + ((n + 1) & 1);
     HIP_TRY(c, hipMemsetAsync(c->binstate.p, 0, sizeof(BinState), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->ids_at.p, 0xFF, sizeof(uint32_t) * (size_t)pl.npos, c->stream));
-    HIP_TRY(c, hipMemsetAsync(nlist_out, 0, sizeof(uint32_t), c->stream));
-    if (use_list) HIP_TRY(c, hipMemsetAsync(ids_out, 0xFF, sizeof(uint32_t) * (size_t)pl.npos, c->stream));
     // records leave the emit kernel already partitioned by A bin into fixed-capacity regions of recs[0]; level B moves them to recs[1]
     const uint32_t region = (uint32_t)(c->recs[0].n / kBins);
     {
@@ -551,28 +565,42 @@ int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t*
         hipLaunchKernelGGL(bin_scan2_kernel, dim3(kBins), dim3(kBlock), 0, c->stream, c->binstate.p);
         hipLaunchKernelGGL((bin_scatter_kernel<true>), dim3(tiles + kBins), dim3(kBlock), 0, c->stream, c->recs[0].p, c->recs[1].p, c->state.p, c->binstate.p);
     }
-    // sparse survivor arrays of this order live in recs[0] (free again after scatter B): two u32 planes of npos entries
-    uint32_t* sp_rep = reinterpret_cast<uint32_t*>(c->recs[0].p);
-    uint32_t* sp_cnt = sp_rep + pl.npos;
+    const BinnedIO io = binned_planes(c, pl, with_keys);
     {
         Prof p(c, COLIBRI_K_BINCOUNT);
-        hipLaunchKernelGGL(bin_count_kernel, dim3(256 * 12), dim3(kBlock), 0, c->stream, c->recs[1].p, c->state.p, c->binstate.p, pl.thr, sp_rep, sp_cnt, c->ids_at.p);
-    }
-    {
-        Prof p(c, COLIBRI_K_PRUNE);
-        hipLaunchKernelGGL(compact_results_kernel, dim3(pl.tab_grid), dim3(kBlock), 0, c->stream, sp_rep, sp_cnt, c->state.p, c->binstate.p, c->res_rep.p, c->res_cnt.p, pl.res_cap);
-        hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
-    }
-    {
-        Prof p(c, COLIBRI_K_RESOLVE);
-        if (use_list)
-            hipLaunchKernelGGL((bin_resolve_kernel<true>), dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->rep_of.p, c->ids_at.p, ids_out, c->state.p, pl.npos, list_in, nlist_in, list_out,
-                               nlist_out);
-        else
-            hipLaunchKernelGGL((bin_resolve_kernel<false>), dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->rep_of.p, c->ids_at.p, ids_out, c->state.p, pl.npos,
-                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, list_out, nlist_out);
+        hipLaunchKernelGGL(bin_count_kernel, dim3(256 * 12), dim3(kBlock), 0, c->stream, c->recs[1].p, c->state.p, c->binstate.p, thr, io.sp_rep, io.sp_cnt, io.sp_key, c->ids_at.p);
     }
     return COLIBRI_OK;
+}
+
+int binned_resolve_stage(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids_out, int n, bool use_list, bool build_list, const uint32_t* remap, uint32_t remap_base) {
+    const uint32_t* list_in   = c->alist[n & 1].p;
+    const uint32_t* nlist_in  = c->alist_n.p + (n & 1);
+    uint32_t*       list_out  = build_list ? c->alist[(n + 1) & 1].p : nullptr;
+    uint32_t*       nlist_out = c->alist_n.p + ((n + 1) & 1);
+    HIP_TRY(c, hipMemsetAsync(nlist_out, 0, sizeof(uint32_t), c->stream));
+    if (use_list) HIP_TRY(c, hipMemsetAsync(ids_out, 0xFF, sizeof(uint32_t) * (size_t)pl.npos, c->stream));
+    Prof p(c, COLIBRI_K_RESOLVE);
+    if (use_list)
+        hipLaunchKernelGGL((bin_resolve_kernel<true>), dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->rep_of.p, c->ids_at.p, ids_out, c->state.p, pl.npos, list_in, nlist_in, list_out,
+                           nlist_out, remap, remap_base);
+    else
+        hipLaunchKernelGGL((bin_resolve_kernel<false>), dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->rep_of.p, c->ids_at.p, ids_out, c->state.p, pl.npos, (const uint32_t*)nullptr,
+                           (const uint32_t*)nullptr, list_out, nlist_out, remap, remap_base);
+    return COLIBRI_OK;
+}
+
+template <class KeyFn>
+int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t* ids_out, int n, bool use_list, bool build_list) {
+    int rc;
+    if ((rc = binned_count_stage(c, pl, fn, n, use_list, pl.thr, false))) return rc;
+    const BinnedIO io = binned_planes(c, pl, false);
+    {
+        Prof p(c, COLIBRI_K_PRUNE);
+        hipLaunchKernelGGL(compact_results_kernel, dim3(pl.tab_grid), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, c->binstate.p, c->res_rep.p, c->res_cnt.p, pl.res_cap);
+        hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
+    }
+    return binned_resolve_stage(c, pl, ids_out, n, use_list, build_list, nullptr, 0u);
 }
 
 // One (order, gap mask) skipgram pass. Exact identity of a skipgram = the survivor ids of its contiguous parts, paired
@@ -1133,6 +1161,14 @@ int colibri_shard_begin(colibri_ctx* c, const colibri_options* opt_in, int world
         HIP_TRY(c, hipMemsetAsync(c->sh.mark.p, 0, sizeof(uint32_t) * ((size_t)npos + 1), c->stream));
     }
     auto& sh      = c->sh;
+    sh.radix      = o.table_mode != 1 && c->ntokens <= 128ull * 1000 * 1000;
+    if (sh.radix) {
+        if ((rc = dev_alloc(c, c->recs[0], ((size_t)npos + (npos >> 2)) / kBins * kBins + (size_t)kBins * kScatTile)) || (rc = dev_alloc(c, c->recs[1], (size_t)npos + 1))) return rc;
+        if ((rc = dev_alloc(c, c->rep_of, (size_t)npos + 1)) || (rc = dev_alloc(c, c->ids_at, (size_t)npos + 1)) || (rc = dev_alloc(c, c->binstate, 1))) return rc;
+        if ((rc = dev_alloc(c, c->alist[0], (size_t)npos + 1)) || (rc = dev_alloc(c, c->alist[1], (size_t)npos + 1)) || (rc = dev_alloc(c, c->alist_n, 2))) return rc;
+        if ((rc = dev_alloc(c, sh.gid_of_sparse, (size_t)npos + 1))) return rc;
+    }
+    sh.list_valid = false;
     sh.active     = true;
     sh.world      = world;
     sh.n          = 0;
@@ -1198,6 +1234,38 @@ int colibri_shard_count(colibri_ctx* c, int n, uint32_t mask, int level, uint64_
     hs.found = hs.kept = hs.admitted = hs.valid = 0;
     hs.res_total = sh.res_total;
     if ((rc = write_state(c))) return rc;
+    // n-gram passes of order >= 2 count locally on the radix path (threshold 1: every distinct local key is a candidate); order 1
+    // and the skipgram passes use the global table
+    sh.pass_radix = sh.radix && mask == 0 && n >= 2;
+    uint32_t hist[64] = {0};
+    uint32_t D        = 0;
+    if (sh.pass_radix) {
+        hs.pad[0] = 0;
+        hs.pad[1] = 0;  // sparse ids restart at 0 every pass: they are remapped to global ids when the replies arrive
+        if ((rc = write_state(c))) return rc;
+        const bool use_list = n >= 3 && sh.list_valid;
+        if ((rc = binned_count_stage(c, pl, KeyNgram{c->bytes.p, c->tokstart.p, c->ids[n - 1].p, n}, n, use_list, 1u, true))) return rc;
+        hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
+        sh.pass_list = use_list;
+        if ((rc = read_state(c))) return rc;
+        if (hs.pad[0]) return fail(c, COLIBRI_ERR_OVERFLOW, "a radix bin outgrew its LDS table in a sharded pass; rerun with table_mode = 1");
+        HIP_TRY(c, hipMemcpy(&sh.nsparse, &c->binstate.p->nrec, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        sh.admitted_n[n] = hs.admitted;
+        D                = hs.found;
+        sh.ncand         = D;
+        if ((rc = dev_alloc(c, sh.tkeys, (size_t)D + 1)) || (rc = dev_alloc(c, sh.tcounts, (size_t)D + 1)) || (rc = dev_alloc(c, sh.tslots, (size_t)D + 1)) ||
+            (rc = dev_alloc(c, sh.pkeys, (size_t)D + 1)) || (rc = dev_alloc(c, sh.pcounts, (size_t)D + 1)) || (rc = dev_alloc(c, sh.pslots, (size_t)D + 1)) ||
+            (rc = dev_alloc(c, sh.taux, (size_t)D + 1)) || (rc = dev_alloc(c, sh.paux, (size_t)D + 1)))
+            return rc;
+        HIP_TRY(c, hipMemsetAsync(sh.small.p, 0, sizeof(uint32_t) * kShSmall, c->stream));
+        HIP_TRY(c, hipMemsetAsync(sh.gid_of_sparse.p, 0xFF, sizeof(uint32_t) * ((size_t)sh.nsparse + 1), c->stream));
+        if (D) {
+            const BinnedIO io = binned_planes(c, pl, true);
+            Prof           p(c, COLIBRI_K_PRUNE);
+            hipLaunchKernelGGL(shard_extract_sparse_kernel, dim3(stream_grid(sh.nsparse)), dim3(kBlock), 0, c->stream, io.sp_key, io.sp_cnt, sh.nsparse, (uint32_t)sh.world, sh.tkeys.p,
+                               sh.tcounts.p, sh.tslots.p, sh.small.p, sh.small.p + kShHist);
+        }
+    } else {
     launch_clear(c, pl);
     if (mask == 0) {
         if (n == 1)
@@ -1221,19 +1289,20 @@ int colibri_shard_count(colibri_ctx* c, int n, uint32_t mask, int level, uint64_
     sh.out = out;
     if ((rc = read_state(c))) return rc;
     if (mask == 0) sh.admitted_n[n] = hs.admitted;
-    const uint32_t D = hs.found;  // distinct local candidates
-    sh.ncand         = D;
+    D        = hs.found;  // distinct local candidates
+    sh.ncand = D;
     if ((rc = dev_alloc(c, sh.tkeys, (size_t)D + 1)) || (rc = dev_alloc(c, sh.tcounts, (size_t)D + 1)) || (rc = dev_alloc(c, sh.tslots, (size_t)D + 1)) ||
         (rc = dev_alloc(c, sh.pkeys, (size_t)D + 1)) || (rc = dev_alloc(c, sh.pcounts, (size_t)D + 1)) || (rc = dev_alloc(c, sh.pslots, (size_t)D + 1)) ||
         (rc = dev_alloc(c, sh.taux, (size_t)D + 1)) || (rc = dev_alloc(c, sh.paux, (size_t)D + 1)))
         return rc;
     HIP_TRY(c, hipMemsetAsync(sh.small.p, 0, sizeof(uint32_t) * kShSmall, c->stream));
-    uint32_t hist[64] = {0};
     if (D) {
         Prof p(c, COLIBRI_K_PRUNE);
         hipLaunchKernelGGL(shard_extract_kernel, dim3(stream_grid(hs.cap)), dim3(kBlock), 0, c->stream, c->table.p, hs.cap, (uint32_t)sh.world, sh.tkeys.p, sh.tcounts.p, sh.tslots.p,
                            sh.small.p, sh.small.p + kShHist, sh.use_aux ? c->nsrc.p : (const uint32_t*)nullptr, sh.use_aux ? sh.taux.p : (uint32_t*)nullptr);
     }
+    }
+    sh.out = out;
     HIP_TRY(c, hipMemcpyAsync(hist, sh.small.p + kShHist, sizeof(uint32_t) * 64, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     uint32_t off[65] = {0};
@@ -1359,15 +1428,29 @@ int colibri_shard_apply(colibri_ctx* c, const void* reply_gid_dev, const void* r
     // only final passes export; replies of intermediate skipgram levels carry ids only. The exporter of an n-gram also marks its
     // representative position (distinct-source counting of indexed skipgrams).
     uint32_t* mark = (sh.mask == 0 && c->opt.doskipgrams && n < 32) ? sh.mark.p : nullptr;
-    if (sh.ncand) {
-        Prof p(c, COLIBRI_K_PRUNE);
-        if (sh.final_level)
-            hipLaunchKernelGGL(shard_apply_kernel, dim3(stream_grid(sh.ncand)), dim3(kBlock), 0, c->stream, sh.pslots.p, (const uint32_t*)reply_gid_dev, (const uint32_t*)reply_cnt_dev,
-                               sh.ncand, c->table.p, c->state.p, c->res_rep.p, c->res_cnt.p, sh.res_gid.p, pl.res_cap, mark, 1u << (n & 31));
-        else
-            hipLaunchKernelGGL(shard_tag_kernel, dim3(stream_grid(sh.ncand)), dim3(kBlock), 0, c->stream, sh.pslots.p, (const uint32_t*)reply_gid_dev, sh.ncand, c->table.p);
+    if (sh.pass_radix) {
+        if (sh.ncand) {
+            const BinnedIO io = binned_planes(c, pl, true);
+            Prof           p(c, COLIBRI_K_PRUNE);
+            hipLaunchKernelGGL(shard_apply_sparse_kernel, dim3(stream_grid(sh.ncand)), dim3(kBlock), 0, c->stream, sh.pslots.p, (const uint32_t*)reply_gid_dev,
+                               (const uint32_t*)reply_cnt_dev, sh.ncand, io.sp_rep, sh.gid_of_sparse.p, c->state.p, c->res_rep.p, c->res_cnt.p, sh.res_gid.p, pl.res_cap, mark,
+                               1u << (n & 31));
+        }
+        // ids[n][i] = global id of the survivor at the window's representative (sparse id -> gid), and the active list for order n+1
+        if ((rc = binned_resolve_stage(c, pl, sh.out, n, sh.pass_list, true, sh.gid_of_sparse.p, 0u))) return rc;
+        sh.list_valid = true;
+    } else {
+        if (sh.ncand) {
+            Prof p(c, COLIBRI_K_PRUNE);
+            if (sh.final_level)
+                hipLaunchKernelGGL(shard_apply_kernel, dim3(stream_grid(sh.ncand)), dim3(kBlock), 0, c->stream, sh.pslots.p, (const uint32_t*)reply_gid_dev, (const uint32_t*)reply_cnt_dev,
+                                   sh.ncand, c->table.p, c->state.p, c->res_rep.p, c->res_cnt.p, sh.res_gid.p, pl.res_cap, mark, 1u << (n & 31));
+            else
+                hipLaunchKernelGGL(shard_tag_kernel, dim3(stream_grid(sh.ncand)), dim3(kBlock), 0, c->stream, sh.pslots.p, (const uint32_t*)reply_gid_dev, sh.ncand, c->table.p);
+        }
+        launch_resolve(c, pl, sh.out);
+        if (sh.mask == 0) sh.list_valid = false;  // the global-table pass leaves no active list behind
     }
-    launch_resolve(c, pl, sh.out);
     if ((rc = read_state(c))) return rc;
     const uint32_t k = sh.final_level ? c->hstate.kept : 0;
     if (k) c->segments.push_back({sh.res_total, k, n, sh.mask});
@@ -1431,6 +1514,79 @@ int colibri_shard_finish(colibri_ctx* c, const uint64_t* found_global, const uin
     s.keybytes = c->keybytes;
     s.nrefs    = c->opt.indexed ? c->npairs : 0;
     if (stats_out) *stats_out = s;
+    return COLIBRI_OK;
+}
+
+// ---- order 1 on the class-indexed arrays (canonical encodings): local counts -> [all-reduce SUM / MIN by the caller] -> apply
+int colibri_shard_uni_info(const colibri_ctx* c, int* eligible, uint64_t* maxclass) {
+    if (!c || !eligible || !maxclass) return COLIBRI_ERR_ARG;
+    if (!c->have_corpus) return COLIBRI_ERR_STATE;
+    *eligible = (!(c->flags & kFlagNonCanonical) && c->maxclass < (1u << 28) && c->opt.table_mode != 1) ? 1 : 0;
+    *maxclass = c->maxclass;
+    return COLIBRI_OK;
+}
+
+int colibri_shard_uni_count(colibri_ctx* c, void* cnt_dev, void* minrank_dev, uint32_t nclasses, int rank) {
+    if (!c || !cnt_dev || !minrank_dev || nclasses <= c->maxclass) return COLIBRI_ERR_ARG;
+    if (!c->sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto&           sh = c->sh;
+    const TrainPlan pl = shard_plan(c);
+    int             rc;
+    if ((int)c->ids.size() < 3) c->ids.resize(3);
+    if ((rc = dev_alloc(c, c->ids[1], (size_t)c->npos + 1)) || (rc = dev_alloc(c, c->rep1, (size_t)nclasses + 1))) return rc;
+    sh.n = 1;
+    sh.mask = 0;
+    sh.level = 1;
+    sh.final_level = true;
+    sh.pass_radix = false;
+    DevState& hs = c->hstate;
+    hs.done      = 0;
+    hs.found = hs.kept = hs.admitted = hs.valid = 0;
+    hs.res_total = sh.res_total;
+    if ((rc = write_state(c))) return rc;
+    HIP_TRY(c, hipMemsetAsync(cnt_dev, 0, sizeof(uint32_t) * nclasses, c->stream));
+    {
+        Prof p(c, COLIBRI_K_COUNT);
+        hipLaunchKernelGGL(uni_count_kernel, dim3(512), dim3(kBlock), 0, c->stream, c->cls.p, pl.npos, (uint32_t*)cnt_dev, c->rep1.p, c->state.p);
+        hipLaunchKernelGGL(shard_uni_minrank_kernel, dim3(stream_grid(nclasses)), dim3(kBlock), 0, c->stream, (const uint32_t*)cnt_dev, nclasses, (uint32_t)rank, (uint32_t*)minrank_dev);
+    }
+    if ((rc = read_state(c))) return rc;
+    sh.admitted_n[1] = hs.admitted;
+    return COLIBRI_OK;
+}
+
+int colibri_shard_uni_apply(colibri_ctx* c, const void* cnt_global_dev, const void* minrank_global_dev, uint32_t nclasses, int rank, uint64_t* found, uint64_t* kept,
+                            uint64_t* exported) {
+    if (!c || !cnt_global_dev || !minrank_global_dev || !found || !kept) return COLIBRI_ERR_ARG;
+    if (!c->sh.active || c->sh.n != 1) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_uni_apply out of order");
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto&           sh = c->sh;
+    const TrainPlan pl = shard_plan(c);
+    int             rc;
+    c->hstate.found = c->hstate.kept = c->hstate.admitted = c->hstate.valid = 0;
+    if ((rc = write_state(c))) return rc;
+    {
+        Prof p(c, COLIBRI_K_PRUNE);
+        hipLaunchKernelGGL(shard_uni_finish_kernel, dim3(stream_grid(nclasses)), dim3(kBlock), 0, c->stream, (const uint32_t*)cnt_global_dev, (const uint32_t*)minrank_global_dev,
+                           c->rep1.p, nclasses, (uint32_t)rank, pl.thr, c->state.p, c->res_rep.p, c->res_cnt.p, sh.res_gid.p, pl.res_cap, c->opt.doskipgrams ? sh.mark.p : (uint32_t*)nullptr);
+    }
+    {
+        Prof p(c, COLIBRI_K_RESOLVE);
+        hipLaunchKernelGGL(uni_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, (const uint32_t*)cnt_global_dev, pl.thr, c->ids[1].p, c->state.p, pl.npos);
+    }
+    if ((rc = read_state(c))) return rc;
+    const uint32_t k = c->hstate.kept;  // exported by THIS rank
+    if (k) c->segments.push_back({sh.res_total, k, 1, 0u});
+    sh.res_total += k;
+    sh.valid_n[1]    = c->hstate.valid;
+    sh.exported_n[1] = k;
+    sh.list_valid    = false;
+    sh.out           = c->ids[1].p;
+    if (c->opt.indexed && c->hstate.valid && (rc = emit_pairs(c, pl, sh.out))) return rc;
+    *found = c->hstate.found;     // global: every rank sees the same reduced array
+    *kept  = c->hstate.admitted;  // (the finish kernel parks the global kept count here)
+    if (exported) *exported = k;
     return COLIBRI_OK;
 }
 

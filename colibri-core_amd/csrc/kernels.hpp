@@ -1130,6 +1130,149 @@ __global__ __launch_bounds__(kBlock) void shard_apply_kernel(const uint32_t* __r
         __syncthreads();
     }
 }
+// sharded radix path: the local candidates are the non-empty entries of the sparse per-bin arrays (bin_count with threshold 1);
+// the handle that travels with a candidate is its sparse index
+__global__ __launch_bounds__(kBlock) void shard_extract_sparse_kernel(const unsigned long long* __restrict__ sp_key, const uint32_t* __restrict__ sp_cnt, uint32_t n, uint32_t world,
+                                                                       unsigned long long* __restrict__ keys, uint32_t* __restrict__ counts, uint32_t* __restrict__ handles,
+                                                                       uint32_t* __restrict__ ncand, uint32_t* __restrict__ owner_hist) {
+    __shared__ uint32_t histL[64];
+    __shared__ uint32_t baseL;
+    if (threadIdx.x < 64) histL[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t ntiles = (n + kPruneTile - 1) / kPruneTile;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t j0 = tile * kPruneTile + threadIdx.x * kPrunePer;
+        uint32_t       c[kPrunePer], used = 0;
+#pragma unroll
+        for (int q = 0; q < kPrunePer; ++q) {
+            c[q] = (j0 + q < n) ? sp_cnt[j0 + q] : 0u;
+            used += c[q] != 0;
+        }
+        uint32_t       total;
+        const uint32_t excl = block_exclusive_scan(used, &total);
+        if (threadIdx.x == 0) baseL = total ? atomicAdd(ncand, total) : 0;
+        __syncthreads();
+        uint32_t o = baseL + excl;
+#pragma unroll
+        for (int q = 0; q < kPrunePer; ++q) {
+            if (c[q]) {
+                const unsigned long long k = sp_key[j0 + q];
+                keys[o]    = k;
+                counts[o]  = c[q];
+                handles[o] = j0 + q;
+                atomicAdd(&histL[(uint32_t)(mix64(k) % world)], 1u);
+                ++o;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < world && histL[threadIdx.x]) atomicAdd(&owner_hist[threadIdx.x], histL[threadIdx.x]);
+}
+// sharded radix path: replies -> global id per sparse index (+ exports on the exporting rank)
+__global__ __launch_bounds__(kBlock) void shard_apply_sparse_kernel(const uint32_t* __restrict__ handles, const uint32_t* __restrict__ reply_gid,
+                                                                     const uint32_t* __restrict__ reply_cnt, uint32_t n, const uint32_t* __restrict__ sp_rep,
+                                                                     uint32_t* __restrict__ gid_of_sparse, DevState* __restrict__ st, uint32_t* __restrict__ res_rep,
+                                                                     uint32_t* __restrict__ res_cnt, uint32_t* __restrict__ res_gid, uint32_t res_cap, uint32_t* __restrict__ mark,
+                                                                     uint32_t markbit) {
+    __shared__ uint32_t baseL;
+    const uint32_t      res_base = st->res_total;
+    const uint32_t      ntiles   = (n + kEmitTile - 1) / kEmitTile;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t j0 = tile * kEmitTile + threadIdx.x * kEmitPer;
+        uint32_t       g[kEmitPer], nexp = 0;
+#pragma unroll
+        for (int k = 0; k < kEmitPer; ++k) {
+            g[k] = (j0 + k < n) ? reply_gid[j0 + k] : kInvalid;
+            nexp += (g[k] != kInvalid) && (g[k] & kExportBit);
+        }
+        uint32_t       total;
+        const uint32_t excl = block_exclusive_scan(nexp, &total);
+        if (threadIdx.x == 0) baseL = total ? atomicAdd(&st->kept, total) : 0;
+        __syncthreads();
+        uint32_t r = res_base + baseL + excl;
+#pragma unroll
+        for (int k = 0; k < kEmitPer; ++k) {
+            if (j0 + k < n) {
+                const uint32_t h = handles[j0 + k];
+                if (g[k] != kInvalid && (g[k] & kExportBit)) {
+                    if (r < res_cap) {
+                        const uint32_t rp = sp_rep[h];
+                        res_rep[r]        = rp;
+                        res_cnt[r]        = reply_cnt[j0 + k];
+                        res_gid[r]        = g[k] & ~kExportBit;
+                        if (mark != nullptr) atomicOr(&mark[rp], markbit);
+                    } else {
+                        st->overflow = 1;
+                    }
+                    ++r;
+                }
+                gid_of_sparse[h] = (g[k] == kInvalid) ? kInvalid : (g[k] & ~kExportBit);
+            }
+        }
+        __syncthreads();
+    }
+}
+// sharded order 1 on the class-indexed arrays: after the all-reduce, every rank knows the global count of every class and the
+// lowest rank that saw it (that rank exports the unigram; its representative position also counts as the distinct source)
+__global__ __launch_bounds__(kBlock) void shard_uni_minrank_kernel(const uint32_t* __restrict__ cnt_local, uint32_t nclasses, uint32_t rank, uint32_t* __restrict__ minrank) {
+    for (uint32_t c = blockIdx.x * kBlock + threadIdx.x; c < nclasses; c += gridDim.x * kBlock) minrank[c] = cnt_local[c] ? rank : 0x7FFFFFFFu;
+}
+__global__ __launch_bounds__(kBlock) void shard_uni_finish_kernel(const uint32_t* __restrict__ cnt_global, const uint32_t* __restrict__ minrank, const uint32_t* __restrict__ rep1,
+                                                                   uint32_t nclasses, uint32_t rank, uint32_t threshold, DevState* __restrict__ st,
+                                                                   uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t* __restrict__ res_gid, uint32_t res_cap,
+                                                                   uint32_t* __restrict__ mark) {
+    __shared__ uint32_t baseL, redL[2][kBlock / kWave];
+    const uint32_t      res_base = st->res_total;
+    const uint32_t      ntiles   = (nclasses + kPruneTile - 1) / kPruneTile;
+    uint32_t            nfound = 0, nkept = 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t c0 = tile * kPruneTile + threadIdx.x * kPrunePer;
+        uint32_t       v[kPrunePer], k = 0;
+        bool           mine[kPrunePer];
+#pragma unroll
+        for (int q = 0; q < kPrunePer; ++q) {
+            v[q]    = (c0 + q < nclasses) ? cnt_global[c0 + q] : 0u;
+            mine[q] = v[q] >= threshold && minrank[c0 + q] == rank;
+            nfound += v[q] != 0;
+            nkept += v[q] >= threshold;
+            k += mine[q];
+        }
+        uint32_t       total;
+        const uint32_t excl = block_exclusive_scan(k, &total);
+        if (threadIdx.x == 0) baseL = total ? atomicAdd(&st->kept, total) : 0;
+        __syncthreads();
+        uint32_t r = res_base + baseL + excl;
+#pragma unroll
+        for (int q = 0; q < kPrunePer; ++q) {
+            if (mine[q]) {
+                if (r < res_cap) {
+                    res_rep[r] = rep1[c0 + q];
+                    res_cnt[r] = v[q];
+                    res_gid[r] = c0 + q;  // the global id of a unigram is its class id
+                    if (mark != nullptr) atomicOr(&mark[rep1[c0 + q]], 2u);  // bit 1 = order 1
+                } else {
+                    st->overflow = 1;
+                }
+                ++r;
+            }
+        }
+        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        nfound += __shfl_down(nfound, off, kWave);
+        nkept += __shfl_down(nkept, off, kWave);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        redL[0][threadIdx.x / kWave] = nfound;
+        redL[1][threadIdx.x / kWave] = nkept;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t f = redL[0][0] + redL[0][1] + redL[0][2] + redL[0][3], kk = redL[1][0] + redL[1][1] + redL[1][2] + redL[1][3];
+        if (f) atomicAdd(&st->found, f);
+        if (kk) atomicAdd(&st->admitted, kk);  // (admitted doubles as the GLOBAL kept count of this pass)
+    }
+}
 // intermediate skipgram level: the replies only carry the global id of the interned pair
 __global__ __launch_bounds__(kBlock) void shard_tag_kernel(const uint32_t* __restrict__ slots, const uint32_t* __restrict__ reply_gid, uint32_t n, Slot* __restrict__ table) {
     for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {

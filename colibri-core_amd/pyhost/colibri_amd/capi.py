@@ -22,6 +22,7 @@ EXPORTED = [
     "colibri_export_indexed", "colibri_hash_windows", "colibri_positions", "colibri_hash_keys", "colibri_kernel_time",
     "colibri_shard_begin", "colibri_shard_count", "colibri_shard_send", "colibri_shard_merge", "colibri_shard_reply", "colibri_shard_apply",
     "colibri_shard_finish", "colibri_shard_export_gids", "colibri_shard_index_sizes", "colibri_shard_export_index",
+    "colibri_shard_uni_info", "colibri_shard_uni_count", "colibri_shard_uni_apply",
 ]
 
 
@@ -92,6 +93,9 @@ def load():
         L.colibri_shard_reply.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.colibri_shard_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.colibri_shard_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Stats)]
+        L.colibri_shard_uni_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+        L.colibri_shard_uni_count.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+        L.colibri_shard_uni_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.colibri_shard_export_gids.argtypes = [C.c_void_p, C.c_void_p]
         L.colibri_shard_index_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.colibri_shard_export_index.argtypes = [C.c_void_p] * 5
@@ -233,6 +237,24 @@ class HipShardEngine:
         self.ctx._check(self.L.colibri_shard_begin(self.ctx.h, C.byref(opt), world))
         self.ctx.indexed = False  # exports of a sharded run go through export_local()
         self.indexed = bool(opt.indexed)
+
+    # -- order 1 on class-indexed arrays (dense all-reduce instead of a key exchange) -----------------
+    def uni_info(self):
+        ok, mc = C.c_int(), C.c_uint64()
+        self.ctx._check(self.L.colibri_shard_uni_info(self.ctx.h, C.byref(ok), C.byref(mc)))
+        return bool(ok.value), int(mc.value)
+
+    def uni_count(self, nclasses, rank):
+        t = self.torch
+        cnt = t.empty(nclasses, dtype=t.int32, device=self.device)
+        mr = t.empty(nclasses, dtype=t.int32, device=self.device)
+        self.ctx._check(self.L.colibri_shard_uni_count(self.ctx.h, C.c_void_p(cnt.data_ptr()), C.c_void_p(mr.data_ptr()), nclasses, rank))
+        return cnt, mr
+
+    def uni_apply(self, cnt, mr, nclasses, rank):
+        f, k, e = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.ctx._check(self.L.colibri_shard_uni_apply(self.ctx.h, C.c_void_p(cnt.data_ptr()), C.c_void_p(mr.data_ptr()), nclasses, rank, C.byref(f), C.byref(k), C.byref(e)))
+        return int(f.value), int(k.value), int(e.value)
 
     def count(self, n, mask=0, level=1):
         nc = C.c_uint64()

@@ -54,6 +54,35 @@ class ShardedTrainer:
         self._sync(out)
         return out
 
+    def _all_reduce(self, tensor, op):
+        """in-place all-reduce of a dense device array (RCCL ring over xGMI; staged through the host under gloo)"""
+        if self.stage_host and tensor.is_cuda:
+            h = tensor.cpu()
+            self.dist.all_reduce(h, op=op)
+            tensor.copy_(h)
+        else:
+            self.dist.all_reduce(tensor, op=op)
+        self._sync(tensor)
+
+    def _unigram_pass_dense(self, state):
+        """Order 1 without any key exchange: when every rank's class encoding is canonical the class id is the unigram's identity, so
+        the ranks all-reduce their dense per-class count arrays (SUM) and first-seen ranks (MIN) — the north star's "RCCL all-reduce of
+        the per-bucket count tables before the prune" — and apply the reduced arrays locally. Returns None if not applicable."""
+        eng = self.engine
+        if not hasattr(eng, "uni_info"):
+            return None
+        ok, maxclass = eng.uni_info()
+        everyone = self._all_gather_ints([int(ok), maxclass])
+        if not all(v[0] for v in everyone):
+            return None
+        nclasses = max(v[1] for v in everyone) + 1
+        cnt, mr = eng.uni_count(nclasses, self.rank)
+        self._all_reduce(cnt, self.dist.ReduceOp.SUM)
+        self._all_reduce(mr, self.dist.ReduceOp.MIN)
+        found, kept, _ = eng.uni_apply(cnt, mr, nclasses, self.rank)
+        state["gid_total"] = max(state["gid_total"], nclasses)  # unigram ids are class ids: later passes number from nclasses on
+        return found, kept
+
     def _all_gather_ints(self, values):
         t = self.torch
         mine = t.tensor(values, dtype=t.int64, device=self.device)
@@ -109,7 +138,8 @@ class ShardedTrainer:
         state, maxn = {"gid_total": 0}, 0
         tokens_g = sum(v[0] for v in self._all_gather_ints([eng.local_tokens()]))
         for n in range(1, maxlength + 1):
-            found_all, kept_all = self._pass(n, 0, 1, state)
+            dense = self._unigram_pass_dense(state) if n == 1 else None
+            found_all, kept_all = dense if dense is not None else self._pass(n, 0, 1, state)
             if found_all == 0:
                 break
             maxn = n

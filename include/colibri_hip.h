@@ -152,6 +152,14 @@ int colibri_shard_merge(colibri_ctx* ctx, const void* keys_dev, const void* coun
 int colibri_shard_reply(colibri_ctx* ctx, uint32_t gid_base, void* reply_gid_dev, void* reply_cnt_dev);
 /* contributor side: apply the replies (same order as the records sent) and write global survivor ids per position */
 int colibri_shard_apply(colibri_ctx* ctx, const void* reply_gid_dev, const void* reply_cnt_dev, uint64_t* exported, uint64_t* admitted);
+/* order 1 on class-indexed arrays (the north star's "all-reduce of the per-bucket count tables before the prune"): when every rank's
+ * encoding is canonical (eligible) the unigram pass needs no key exchange — each rank fills cnt[nclasses] (u32 per class id) and
+ * minrank[nclasses] (its rank where it saw the class, else 0x7FFFFFFF), the caller all-reduces them (SUM / MIN), and every rank
+ * applies the reduced arrays. The global id of a unigram is its class id; later passes must start their ids at nclasses. */
+int colibri_shard_uni_info(const colibri_ctx* ctx, int* eligible, uint64_t* maxclass);
+int colibri_shard_uni_count(colibri_ctx* ctx, void* cnt_dev, void* minrank_dev, uint32_t nclasses, int rank);
+int colibri_shard_uni_apply(colibri_ctx* ctx, const void* cnt_global_dev, const void* minrank_global_dev, uint32_t nclasses, int rank, uint64_t* found, uint64_t* kept,
+                            uint64_t* exported);
 /* close the run: global per-order found / kept (caller-reduced), global token count; fills stats like colibri_train */
 int colibri_shard_finish(colibri_ctx* ctx, const uint64_t* found_global, const uint64_t* kept_global, uint64_t totaltokens_global, int maxn, colibri_stats* stats);
 /* global id of every pattern this rank exports, in the order of colibri_export_unindexed (gids[npatterns]) */

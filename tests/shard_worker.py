@@ -126,7 +126,7 @@ class NumpyShardEngine:
         return {self.payload[self.pos[p][0]: self.pos[p + n - 1][1]]: c for p, n, c in self.results}
 
 
-MODES = {"u": {}, "us": dict(doskipgrams_exhaustive=1), "i": dict(indexed=1), "is": dict(indexed=1, doskipgrams=1), "isT1": dict(indexed=1, doskipgrams=1, minskiptypes=1),
+MODES = {"u": {}, "ug": dict(table_mode=1), "us": dict(doskipgrams_exhaustive=1), "i": dict(indexed=1), "is": dict(indexed=1, doskipgrams=1), "isT1": dict(indexed=1, doskipgrams=1, minskiptypes=1),
          "usy3": dict(doskipgrams_exhaustive=1, mintokens_skipgrams=3)}
 
 

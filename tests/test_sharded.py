@@ -15,7 +15,7 @@ WORKER = os.path.join(ROOT, "tests", "shard_worker.py")
 _port = [29700]
 
 
-ORACLE_MODES = {"u": {}, "us": dict(doskipgrams_exhaustive=True), "i": dict(indexed=True), "is": dict(indexed=True, doskipgrams=True),
+ORACLE_MODES = {"u": {}, "ug": {}, "us": dict(doskipgrams_exhaustive=True), "i": dict(indexed=True), "is": dict(indexed=True, doskipgrams=True),
                 "isT1": dict(indexed=True, doskipgrams=True, minskiptypes=1), "usy3": dict(doskipgrams_exhaustive=True, mintokens_skipgrams=3)}
 
 
@@ -61,6 +61,12 @@ def test_shard_payload_keeps_global_sentence_numbers():
 @pytest.mark.parametrize("world,corpus,maxlength", [(1, "zipf", 5), (2, "zipf", 5), (2, "3", 8), (3, "tiny", 4), (4, "zipf", 5)])
 def test_hip_shard_engine_gloo_staged(tmp_path, world, corpus, maxlength):
     run_workers(tmp_path, world, "hip", corpus, maxlength)
+
+
+@pytest.mark.gpu
+def test_hip_shard_engine_global_table_local_count(tmp_path):
+    """table_mode = 1: local counting on the open-addressed table and a key exchange for order 1 too (the path used above 128 M tokens per rank)"""
+    run_workers(tmp_path, 2, "hip", "zipf", 5, "ug")
 
 
 @pytest.mark.gpu

@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="tokens of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for debugging)")
     ap.add_argument("--share-gpu", action="store_true", help="debugging: all ranks use cuda:0 (needs --backend gloo)")
+    ap.add_argument("--force-shard", action="store_true", help="debugging: run the sharded trainer even with one rank (prices the exchange machinery)")
     args = ap.parse_args()
 
     import torch
@@ -116,8 +117,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_shard:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -144,7 +148,7 @@ def main():
     tokenise_ms = (time.time() - t0) * 1e3
     opt = capi.Options.defaults(mintokens=MINTOKENS, maxlength=MAXLENGTH, profile=1)
 
-    if world > 1:
+    if dist is not None:
         from colibri_amd import dist as cdist
         trainer = cdist.ShardedTrainer(capi.HipShardEngine(ctx, torch, device), dist, torch, device)
         step = lambda: trainer.train(opt)

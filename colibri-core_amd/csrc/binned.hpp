@@ -5,9 +5,10 @@
 // path produces the same result with streaming traffic only:
 //   emit     per 2048-window tile the block-local reduce (same LDS election as count_kernel) turns windows into records
 //            {exact 64-bit key, representative position, tile count, 16 SpookyHash bits}; rep_of[i] remembers each window's
-//            representative; a histogram over the top 8 hash bits is accumulated
-//   scatter  two tile-local counting sorts (256 bins each, LDS-staged so that a bin's records leave as one contiguous run):
-//            by hash bits 8..15 (level A), then by bits 0..7 inside each A bin (level B) -> 65 536 final bins
+//            representative. Level A of the partition is fused in: the tile's records are counting-sorted by the top 8 hash
+//            bits inside LDS and leave as one contiguous run per bin into that bin's fixed-capacity region
+//   scatter  level B: the same tile-local counting sort on the next (up to) 8 hash bits inside each A region -> up to 65 536
+//            final bins (fewer, fuller bins when an order has few records)
 //   count    one block per final bin builds that bin's table entirely in LDS (64-bit CAS + add on LDS), applies the threshold,
 //            reserves a result range with ONE global atomic, and writes the survivor id at each representative position
 //   resolve  ids[i] = ids_at[rep_of[i]]   (a gather that stays inside the tile)
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void bin_offsets_kernel(BinState* __restric
     }
 }
 
-// which A bin / which tile of it does block `t` own? (LEVEL_B only)
+// which A bin / which tile of it does block `t` own?
 __device__ __forceinline__ bool locate_tile(const BinState* bs, uint32_t t, uint32_t& a, uint32_t& begin, uint32_t& end) {
     if (t >= bs->tprefA[kBins]) return false;
     uint32_t lo = 0, hi = kBins;  // last a with tprefA[a] <= t
@@ -232,22 +233,14 @@ __global__ __launch_bounds__(kBlock) void bin_scan2_kernel(BinState* __restrict_
     if (a == kBins - 1 && threadIdx.x == 0) bs->total2 = before + tot;
 }
 
-// tile-local counting sort + one reserved output run per (tile, bin)
-template <bool LEVEL_B>
+// level B: tile-local counting sort + one reserved output run per (tile, sub-bin), inside each A region
 __global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restrict__ in, Rec* __restrict__ out, const DevState* __restrict__ st, BinState* __restrict__ bs) {
     if (st->done) return;
     __shared__ Rec      recL[kScatTile];
     __shared__ uint32_t histL[kBins], offL[kBins], gbaseL[kBins];
     uint32_t            a = 0, begin, end;
-    if (LEVEL_B) {
-        if (!locate_tile(bs, blockIdx.x, a, begin, end)) return;
-    } else {
-        const uint32_t nrec = bs->nrec;
-        begin               = blockIdx.x * kScatTile;
-        if (begin >= nrec) return;
-        end = min(nrec, begin + (uint32_t)kScatTile);
-    }
-    const uint32_t bsh = LEVEL_B ? bs->bshift : 0u;
+    if (!locate_tile(bs, blockIdx.x, a, begin, end)) return;
+    const uint32_t bsh = bs->bshift;
     histL[threadIdx.x] = 0;
     __syncthreads();
     Rec      r[kScatPer];
@@ -257,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restri
         const uint32_t j = begin + q * kBlock + threadIdx.x;
         if (j < end) {
             r[q]             = in[j];
-            const uint32_t b = LEVEL_B ? (((r[q].meta >> 16) & 255u) >> bsh) : (r[q].meta >> 24);
+            const uint32_t b = ((r[q].meta >> 16) & 255u) >> bsh;
             rank[q]          = atomicAdd(&histL[b], 1u);
         }
     }
@@ -267,12 +260,7 @@ __global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restri
         const uint32_t h   = histL[threadIdx.x];
         offL[threadIdx.x]  = block_exclusive_scan(h, &tot);
         uint32_t g         = 0;
-        if (h) {
-            if (LEVEL_B)
-                g = bs->hist2[a * kBins + threadIdx.x] + atomicAdd(&bs->cur2[a * kBins + threadIdx.x], h);  // hist2 holds offsets after the scan
-            else
-                g = bs->offA[threadIdx.x] + atomicAdd(&bs->curA[threadIdx.x], h);
-        }
+        if (h) g = bs->hist2[a * kBins + threadIdx.x] + atomicAdd(&bs->cur2[a * kBins + threadIdx.x], h);  // hist2 holds offsets after the scan
         gbaseL[threadIdx.x] = g;
     }
     __syncthreads();
@@ -280,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restri
     for (int q = 0; q < kScatPer; ++q) {
         const uint32_t j = begin + q * kBlock + threadIdx.x;
         if (j < end) {
-            const uint32_t b       = LEVEL_B ? (((r[q].meta >> 16) & 255u) >> bsh) : (r[q].meta >> 24);
+            const uint32_t b       = ((r[q].meta >> 16) & 255u) >> bsh;
             recL[offL[b] + rank[q]] = r[q];
         }
     }
@@ -288,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restri
     const uint32_t n = end - begin;
     for (uint32_t j = threadIdx.x; j < n; j += kBlock) {
         const Rec      x = recL[j];
-        const uint32_t b = LEVEL_B ? (((x.meta >> 16) & 255u) >> bsh) : (x.meta >> 24);
+        const uint32_t b = ((x.meta >> 16) & 255u) >> bsh;
         out[gbaseL[b] + (j - offL[b])] = x;
     }
 }

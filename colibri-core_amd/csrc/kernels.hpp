@@ -357,11 +357,7 @@ __global__ __launch_bounds__(kBlock) void count_kernel(KeyFn keyfn, uint32_t* __
             rep[k]           = e;
             if (adm[k]) {
                 const uint32_t w = winL[(uint32_t)hash[k] & (kCountLSlot - 1)];
-#ifdef COLIBRI_EXP_NOELECT
-                if (false) {
-#else
                 if (w != e && keyL[w] == key[k]) {
-#endif
                     rep[k] = w;
                     atomicAdd(&cntL[w], 1u);
                 }
@@ -375,11 +371,7 @@ __global__ __launch_bounds__(kBlock) void count_kernel(KeyFn keyfn, uint32_t* __
                 ++nadm;
                 if (rep[k] == e) {
                     uint32_t ins = 0;
-#ifdef COLIBRI_EXP_NOATOMIC
-                    slotL[e] = slot_of_hash(hash[k], cap);
-#else
                     slotL[e]     = table_find_or_insert(table, cap, key[k], hash[k], base + e, 1u + cntL[e], &ins, st);
-#endif
                     nins += ins;
                 }
             }

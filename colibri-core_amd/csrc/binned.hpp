@@ -60,7 +60,7 @@ struct BinState {
 // rep_of is then indexed by list entry.
 // The level-A partition is fused in: the tile's records are counting-sorted by A bin inside LDS (the election arrays are dead by
 // then and are reused as the staging buffer) and leave as one contiguous run per (tile, bin) into that bin's fixed-capacity
-// region [a * region, (a+1) * region) of `recs`. A region that would overflow raises st->pad[0] (global-table rerun).
+// region [a * region, (a+1) * region) of `recs`. A region that would overflow raises st->radix_overflow (global-table rerun).
 template <class KeyFn, bool LIST>
 __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __restrict__ recs, uint32_t region, uint32_t* __restrict__ rep_of, DevState* __restrict__ st,
                                                            BinState* __restrict__ bs, uint32_t npos, const uint32_t* __restrict__ list, const uint32_t* __restrict__ nlist) {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
             uint32_t g        = 0;
             if (h) {
                 const uint32_t at = atomicAdd(&bs->curA[threadIdx.x], h);  // one reservation per (tile, bin)
-                if (at + h > region) st->pad[0] = 1;                        // region full: the host re-runs on the global table
+                if (at + h > region) st->radix_overflow = 1;                        // region full: the host re-runs on the global table
                 g = threadIdx.x * region + min(at, region - min(region, h));
             }
             gbaseL[threadIdx.x] = g;
@@ -389,7 +389,7 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
     if (*failL || distinct > kBinMaxLoad) {
         if (threadIdx.x == 0) {
             bs->overflow_bin = 1;
-            st->pad[0]       = 1;  // sticky across orders: BinState is zeroed per order
+            st->radix_overflow       = 1;  // sticky across orders: BinState is zeroed per order
         }
         return;
     }
@@ -403,7 +403,7 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
     uint32_t       total;
     const uint32_t excl = block_exclusive_scan(keep, &total);
     if (threadIdx.x == 0) atomicAdd(&bs->found_part[f >> 8], distinct);
-    const uint32_t id_base = st->pad[1];  // survivor ids of this order start here
+    const uint32_t id_base = st->id_base;  // survivor ids of this order start here
     uint32_t       r       = begin + excl;
     for (uint32_t q = 0; q < per; ++q) {
         const uint32_t s  = threadIdx.x * per + q;
@@ -503,9 +503,9 @@ __global__ void bin_advance_prepare_kernel(DevState* __restrict__ st, const BinS
     uint32_t f = 0;
     for (int a = 0; a < kBins; ++a) f += bs->found_part[a];
     st->found = f;
-    const uint64_t next = (uint64_t)st->pad[1] + bs->nrec;
-    if (next >= 0xFFFFFFF0ull) st->pad[0] = 1;  // survivor ids would wrap: the host re-runs on the global table
-    st->pad[1] = (uint32_t)next;
+    const uint64_t next = (uint64_t)st->id_base + bs->nrec;
+    if (next >= 0xFFFFFFF0ull) st->radix_overflow = 1;  // survivor ids would wrap: the host re-runs on the global table
+    st->id_base = (uint32_t)next;
 }
 
 // ids[i] = survivor id found at the window's representative position; also builds the active list for the next order

@@ -883,7 +883,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             }
         }
         if ((rc = read_state(c))) return rc;
-        if (binned && c->hstate.pad[0]) {  // a final bin outgrew its LDS table (hash skew): run again on the global table — loud, exact, rare
+        if (binned && c->hstate.radix_overflow) {  // a final bin outgrew its LDS table (hash skew): run again on the global table — loud, exact, rare
             if (o.table_mode == 2) return fail(c, COLIBRI_ERR_OVERFLOW, "a radix bin outgrew its LDS table (table_mode = 2 forbids the global-table rerun)");
             colibri_options again = o;
             again.table_mode      = 1;
@@ -1240,15 +1240,15 @@ int colibri_shard_count(colibri_ctx* c, int n, uint32_t mask, int level, uint64_
     uint32_t hist[64] = {0};
     uint32_t D        = 0;
     if (sh.pass_radix) {
-        hs.pad[0] = 0;
-        hs.pad[1] = 0;  // sparse ids restart at 0 every pass: they are remapped to global ids when the replies arrive
+        hs.radix_overflow = 0;
+        hs.id_base = 0;  // sparse ids restart at 0 every pass: they are remapped to global ids when the replies arrive
         if ((rc = write_state(c))) return rc;
         const bool use_list = n >= 3 && sh.list_valid;
         if ((rc = binned_count_stage(c, pl, KeyNgram{c->bytes.p, c->tokstart.p, c->ids[n - 1].p, n}, n, use_list, 1u, true))) return rc;
         hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
         sh.pass_list = use_list;
         if ((rc = read_state(c))) return rc;
-        if (hs.pad[0]) return fail(c, COLIBRI_ERR_OVERFLOW, "a radix bin outgrew its LDS table in a sharded pass; rerun with table_mode = 1");
+        if (hs.radix_overflow) return fail(c, COLIBRI_ERR_OVERFLOW, "a radix bin outgrew its LDS table in a sharded pass; rerun with table_mode = 1");
         HIP_TRY(c, hipMemcpy(&sh.nsparse, &c->binstate.p->nrec, sizeof(uint32_t), hipMemcpyDeviceToHost));
         sh.admitted_n[n] = hs.admitted;
         D                = hs.found;

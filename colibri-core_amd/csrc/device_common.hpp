@@ -34,7 +34,9 @@ struct DevState {
     uint32_t res_total;  // survivors of all finished orders
     uint32_t overflow;   // set when a result buffer or the table was exhausted
     uint32_t maxn;       // last order that found anything
-    uint32_t pad[7];
+    uint32_t radix_overflow;  // radix path: an A region or a final bin overflowed -> the host re-runs on the global table (sticky)
+    uint32_t id_base;         // radix path: survivor ids of the current order start here (ids only need to be unique)
+    uint32_t pad[5];
     uint32_t s_found[COLIBRI_MAX_ORDER];
     uint32_t s_kept[COLIBRI_MAX_ORDER];
     uint32_t s_admitted[COLIBRI_MAX_ORDER];

@@ -9,12 +9,16 @@
 #ifndef COLIBRI_AMD_PATTERNMODEL_H
 #define COLIBRI_AMD_PATTERNMODEL_H
 #include <cstdint>
+#include <algorithm>
 #include <fstream>
+#include <iomanip>
 #include <iostream>
 #include <limits>
 #include <map>
 #include <memory>
+#include <set>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "colibri_hip.h"
@@ -89,6 +93,11 @@ std::vector<unsigned char> read_corpus_payload(std::istream& in);
 void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out);
 /** the per-order progress lines the reference prints while training (patternmodel.h:1005-1019, :1195-1245) */
 void print_training_log(const colibri_stats& s, const colibri_options& o, std::ostream& err);
+/** the tokens of a key as byte strings, gaps included (what the reference's pattern.ngrams(…, 1) yields, src/pattern.cpp:1284-1296) */
+void token_slices(const unsigned char* data, size_t bytes, std::vector<std::string>& out);
+/** the column legends the reference writes to stderr after print() (:2306-2320, :2918-2927) and report() (:2591-2600) */
+void print_legend(std::ostream& err, bool indexed);
+void report_legend(std::ostream& err, bool indexed);
 /** reads one pattern of a model file in the given class-encoding version (1 or 2) and returns it v2-encoded */
 Pattern read_model_pattern(std::istream& in, unsigned char classencodingversion);
 
@@ -182,7 +191,10 @@ class PatternModel : public MapType, public PatternModelInterface {
     bool         has(const PatternPointer& p) const override { return MapType::has(p); }
     int          maxlength() const override { return maxn; }
     int          minlength() const override { return minn; }
-    unsigned int types() override { return (unsigned int)totaltypes; }
+    unsigned int types() override {  // a loaded model without a type count falls back to the word types its patterns hold (reference :1700-1704)
+        if (totaltypes == 0 && this->size() != 0) totaltypes = this->totalwordtypesingroup(0, 0);
+        return (unsigned int)totaltypes;
+    }
     unsigned int tokens() const override { return (unsigned int)totaltokens; }
     unsigned char type() const { return model_type; }
     unsigned char version() const { return model_version; }
@@ -198,9 +210,8 @@ class PatternModel : public MapType, public PatternModelInterface {
         ValueType* v = getdata(pattern, false);
         return v ? valuehandler.count(*v) : 0;
     }
-    double frequency(const Pattern& pattern) override {  // occurrences over total tokens (coverage-free variant of reference :1697-1718)
-        return totaltokens ? (double)occurrencecount(pattern) / (double)totaltokens : 0.0;
-    }
+    /** the pattern's share of the occurrences of its own (category, size) group (reference :2047-2050) */
+    double frequency(const Pattern& pattern) override { return this->occurrencecount(pattern) / (double)totaloccurrencesingroup((int)pattern.category(), (int)pattern.n()); }
     /** host-side add of one occurrence (reference :2059-2073); training itself never calls this, it is here for callers that extend a model */
     virtual void add(const Pattern& pattern, const IndexReference& ref) { valuehandler.add(getdata(pattern, true), ref); }
     /** erase patterns under a threshold, optionally only of size _n (reference :2107-2128) */
@@ -400,36 +411,230 @@ class PatternModel : public MapType, public PatternModelInterface {
         this->write(out);
     }
 
-    /** one line per pattern: decoded text (or hex when no decoder), TAB, count — the core columns of reference print() (:2294-2340) */
-    void print(std::ostream* out, const ClassDecoder* decoder = NULL) {
+    // ---- views: print / report / histogram, text-identical to the reference's (goldens: tests/golden/views/) --------------------------------
+
+    /** statistics per (category, size) group, 0 = all (reference computestats :1903-1935): occurrences and distinct patterns */
+    void computestats() {
+        cache_categories.clear();
+        cache_n.clear();
+        cache_grouptotal.clear();
+        cache_grouptotalpatterns.clear();
+        cache_categories.insert(0);
+        cache_n.insert(0);
         for (typename MapType::iterator it = this->begin(); it != this->end(); ++it) {
-            *out << (decoder ? it->first.tostring(*decoder) : it->first.tohex()) << "\t" << valuehandler.count(it->second);
+            const int          c   = (int)it->first.category();
+            const int          n   = (int)it->first.n();
+            const unsigned int occ = valuehandler.count(it->second);
+            cache_categories.insert(c);
+            cache_n.insert(n);
+            const int cs[2] = {c, 0}, ns[2] = {n, 0};
+            for (int ci = 0; ci < 2; ++ci)
+                for (int ni = 0; ni < 2; ++ni) {
+                    if (ni == 0 && c == FLEXGRAM) continue;  // flexgrams have no per-size rows (:1918)
+                    cache_grouptotal[cs[ci]][ns[ni]] += occ;
+                    cache_grouptotalpatterns[cs[ci]][ns[ni]] += 1;
+                }
+        }
+    }
+    virtual void resetstats() {
+        cache_grouptotalwordtypes.clear();
+        cache_grouptotaltokens.clear();
+        cache_coverage_done = false;
+    }
+    /**
+     * word types and covered tokens per group (reference computecoveragestats :1946-1995). The reference walks the whole model once per group;
+     * here every pattern is visited once and dropped into the (at most four) groups it belongs to. A group's word types are the distinct
+     * tokens of its patterns — a skipgram's gap counts as one type, as it does there (pattern.ngrams(…,1) yields the gap token).
+     * Unindexed models: the "covered tokens" of every group is the occurrence total of the whole model (the reference adds each pattern's count
+     * outside its group filter, :1974), capped to tokens() by report().
+     */
+    virtual void computecoveragestats(int category = 0, int n = 0) {
+        (void)category;
+        (void)n;
+        if (cache_coverage_done || this->size() == 0) return;
+        if (cache_grouptotal.empty()) computestats();
+        std::map<int, std::map<int, std::unordered_set<std::string>>> typesets;
+        uint64_t alloccurrences = 0;
+        for (typename MapType::iterator it = this->begin(); it != this->end(); ++it) {
+            const int c = (int)it->first.category(), pn = (int)it->first.n();
+            alloccurrences += valuehandler.count(it->second);
+            std::vector<std::string> toks;
+            colibri_host::token_slices(it->first.data, it->first.bytesize(), toks);
+            const int cs[2] = {c, 0}, ns[2] = {pn, 0};
+            for (int ci = 0; ci < 2; ++ci)
+                for (int ni = 0; ni < 2; ++ni)
+                    for (const std::string& t : toks) typesets[cs[ci]][ns[ni]].insert(t);
+            this->coverage_visit(it, c, pn);
+        }
+        for (const int c : cache_categories)
+            for (const int gn : cache_n) {
+                cache_grouptotalwordtypes[c][gn] = (unsigned int)typesets[c][gn].size();
+                cache_grouptotaltokens[c][gn]    = this->coverage_tokens(c, gn, alloccurrences);
+            }
+        this->coverage_finish();
+        cache_coverage_done = true;
+    }
+    unsigned int totaloccurrencesingroup(int category, int n) {
+        if (cache_grouptotal.empty() && this->size() != 0) computestats();
+        return (unsigned int)cache_grouptotal[category][n];
+    }
+    unsigned int totalpatternsingroup(int category, int n) {
+        if (cache_grouptotalpatterns.empty() && this->size() != 0) computestats();
+        return (unsigned int)cache_grouptotalpatterns[category][n];
+    }
+    unsigned int totalwordtypesingroup(int category, int n) {
+        if (cache_grouptotalwordtypes.empty() && this->size() != 0) computecoveragestats(category, n);
+        return cache_grouptotalwordtypes[category][n];
+    }
+    unsigned int totaltokensingroup(int category, int n) {
+        if (cache_grouptotaltokens.empty() && this->size() != 0) computecoveragestats(category, n);
+        return (unsigned int)cache_grouptotaltokens[category][n];
+    }
+    /** occurrences × size: a maximal projection, also for indexed models (reference :1725-1727) */
+    size_t coveragecount(const Pattern& key) { return (size_t)this->occurrencecount(key) * key.size(); }
+    double coverage(const Pattern& key) { return coveragecount(key) / (double)this->tokens(); }
+
+    /** the whole model, one pattern per line, under the reference's header (reference :2294-2321; the legend goes to stderr there and here) */
+    virtual void print(std::ostream& out, const ClassDecoder& decoder, bool instantiate = false) {
+        (void)instantiate;
+        bool haveoutput = false;
+        for (typename MapType::iterator it = this->begin(); it != this->end(); ++it) {
+            if (!haveoutput) {
+                out << "PATTERN\tCOUNT\tTOKENS\tCOVERAGE\tCATEGORY\tSIZE\tFREQUENCY" << (colibri_host::is_indexed_value<ValueType>::value ? "\tREFERENCES" : "") << std::endl;
+                haveoutput = true;
+            }
+            this->print(out, decoder, it->first, instantiate, true);
+        }
+        if (haveoutput) colibri_host::print_legend(std::cerr, colibri_host::is_indexed_value<ValueType>::value);
+    }
+    /** one pattern: text, count, count×size, that over tokens(), category, size, frequency within its (category, size) group (reference :2354-2373, :2930-2959) */
+    void print(std::ostream& out, const ClassDecoder& decoder, const Pattern& pattern, bool instantiate = false, bool endline = true) {
+        (void)instantiate;
+        const unsigned int count    = this->occurrencecount(pattern);
+        const size_t       covcount = this->coveragecount(pattern);
+        const int          cat      = (int)pattern.category();
+        out << pattern.tostring(decoder) << "\t" << count << "\t" << covcount << "\t" << covcount / (double)this->tokens() << "\t"
+            << (cat == NGRAM ? "ngram" : cat == SKIPGRAM ? "skipgram" : cat == FLEXGRAM ? "flexgram" : "") << "\t" << pattern.size() << "\t" << this->frequency(pattern);
+        typename MapType::iterator it = this->find(pattern);
+        if (it != this->end()) print_value_extra(out, it->second);
+        if (endline) out << std::endl;
+    }
+    void printpattern(std::ostream& out, const ClassDecoder& decoder, const Pattern& pattern, bool instantiate = false, bool endline = true) {
+        this->print(out, decoder, pattern, instantiate, endline);
+    }
+    /** pointer-style call kept for callers of the earlier form of this face: the same table; hex keys when there is no decoder */
+    void print(std::ostream* out, const ClassDecoder* decoder = NULL) {
+        if (decoder != NULL) {
+            this->print(*out, *decoder, false);
+            return;
+        }
+        for (typename MapType::iterator it = this->begin(); it != this->end(); ++it) {
+            *out << it->first.tohex() << "\t" << valuehandler.count(it->second);
             print_value_extra(*out, it->second);
             *out << std::endl;
         }
     }
-    /** pattern and occurrence totals per order (a compact form of reference report(), :2500-2601) */
-    void report(std::ostream* out) {
-        std::vector<uint64_t> types_n(maxn + 2, 0), occ_n(maxn + 2, 0);
+
+    /** occurrence count -> number of patterns (reference :2391-2410). cap keeps the top counts until `cap` patterns are covered. */
+    void histogram(std::map<unsigned int, unsigned int>& hist, unsigned int threshold = 0, unsigned int cap = 0, int category = 0, unsigned int size = 0) {
         for (typename MapType::iterator it = this->begin(); it != this->end(); ++it) {
-            const size_t n = it->first.n();
-            if (n < types_n.size()) {
-                types_n[n] += 1;
-                occ_n[n] += valuehandler.count(it->second);
+            if ((category != 0 && (int)it->first.category() != category) || (size != 0 && size != it->first.size())) continue;
+            const unsigned int c = valuehandler.count(it->second);
+            if (c >= threshold) hist[c]++;
+        }
+        if (cap > 0) {
+            unsigned int sum = 0;
+            std::map<unsigned int, unsigned int>::iterator cut = hist.end();
+            while (sum < cap && cut != hist.begin()) {
+                --cut;
+                sum += cut->second;
+            }
+            hist.erase(hist.begin(), cut);
+        }
+    }
+    void histogram(std::ostream& OUT, unsigned int threshold = 0, unsigned int cap = 0, int category = 0, unsigned int size = 0) {  // reference :2432-2441
+        std::map<unsigned int, unsigned int> hist;
+        histogram(hist, threshold, cap, category, size);
+        OUT << "HISTOGRAM" << std::endl << "------------------------------" << std::endl << "OCCURRENCES\tPATTERNS" << std::endl;
+        for (const auto& kv : hist) OUT << kv.first << "\t" << kv.second << std::endl;
+    }
+    void histogram(std::ostream* out) { histogram(*out); }
+    /** smallest occurrence count among the top `amount` patterns (reference :2412-2422) */
+    unsigned int topthreshold(int amount, int category = 0, int size = 0) {
+        std::map<unsigned int, unsigned int> hist;
+        histogram(hist, 0, (unsigned int)amount, category, (unsigned int)size);
+        return hist.empty() ? 0 : hist.begin()->first;
+    }
+
+    /** the REPORT table (reference :2499-2601): totals, coverage, then one row per (category, size) group; leaves OUT in fixed/4 like the reference */
+    void report(std::ostream& OUT, bool nocoverage = false) {
+        const bool indexed = this->getmodeltype() != UNINDEXEDPATTERNMODEL;
+        if (this->size() != 0) {
+            if (nocoverage) {
+                std::cerr << "Computing statistics without coverage information..." << std::endl;
+                computestats();
+            } else {
+                std::cerr << "Computing statistics with coverage information (may take a while)..." << std::endl;
+                computecoveragestats();
             }
         }
-        *out << "REPORT" << std::endl << "   Total word tokens in corpus: " << totaltokens << std::endl << "   Total word types in corpus:  " << totaltypes << std::endl;
-        *out << "   Patterns in model: " << this->size() << std::endl << "   n\tpatterns\toccurrences" << std::endl;
-        for (size_t n = 1; n < types_n.size(); ++n)
-            if (types_n[n]) *out << "   " << n << "\t" << types_n[n] << "\t" << occ_n[n] << std::endl;
+        const int W = 15;
+        OUT << std::setiosflags(std::ios::fixed) << std::setprecision(4) << std::endl;
+        OUT << "REPORT" << std::endl;
+        if (!indexed && !nocoverage) {
+            OUT << "   Warning: Model is unindexed, token coverage counts are mere maximal projections" << std::endl;
+            OUT << "            assuming no overlap at all!!! Use an indexed model for accurate coverage counts" << std::endl;
+        }
+        OUT << "----------------------------------" << std::endl;
+        OUT << "                          " << std::setw(W) << "PATTERNS" << std::setw(W) << "TOKENS" << std::setw(W) << "COVERAGE" << std::setw(W) << "TYPES" << std::setw(W) << std::endl;
+        OUT << "Total:                    " << std::setw(W) << "-" << std::setw(W) << this->tokens() << std::setw(W) << "-" << std::setw(W) << this->types() << std::endl;
+        if (!nocoverage) {
+            const size_t coveredtypes  = totalwordtypesingroup(0, 0);
+            size_t       coveredtokens = totaltokensingroup(0, 0);
+            if (coveredtokens > this->tokens()) coveredtokens = this->tokens();
+            const size_t uncoveredtokens = this->tokens() - coveredtokens;
+            OUT << "Uncovered:                " << std::setw(W) << "-" << std::setw(W) << uncoveredtokens << std::setw(W) << uncoveredtokens / (double)this->tokens() << std::setw(W)
+                << this->types() - coveredtypes << std::endl;
+            OUT << "Covered:                  " << std::setw(W) << this->size() << std::setw(W) << coveredtokens << std::setw(W) << coveredtokens / (double)this->tokens() << std::setw(W)
+                << coveredtypes << std::endl
+                << std::endl;
+        } else {
+            OUT << std::endl;
+        }
+        bool haveoutput = false;
+        for (const int c : cache_categories) {
+            if (!cache_grouptotalpatterns.count(c)) continue;
+            for (const int n : cache_n) {
+                if (!cache_grouptotalpatterns[c].count(n)) continue;
+                if (!haveoutput) {
+                    OUT << std::setw(W) << "CATEGORY" << std::setw(W) << "N (SIZE) " << std::setw(W) << "PATTERNS";
+                    if (indexed && !nocoverage) OUT << std::setw(W) << "TOKENS" << std::setw(W) << "COVERAGE";
+                    if (!nocoverage) OUT << std::setw(W) << "TYPES";
+                    OUT << std::setw(W) << "OCCURRENCES" << std::endl;
+                    haveoutput = true;
+                }
+                OUT << std::setw(W) << (c == 0 ? "all" : c == NGRAM ? "n-gram" : c == SKIPGRAM ? "skipgram" : "flexgram");
+                if (n == 0) OUT << std::setw(W) << "all";
+                else OUT << std::setw(W) << n;
+                OUT << std::setw(W) << cache_grouptotalpatterns[c][n];
+                if (indexed && !nocoverage) OUT << std::setw(W) << cache_grouptotaltokens[c][n] << std::setw(W) << cache_grouptotaltokens[c][n] / (double)this->tokens();
+                if (!nocoverage) OUT << std::setw(W) << cache_grouptotalwordtypes[c][n];
+                OUT << std::setw(W) << cache_grouptotal[c][n] << std::endl;
+            }
+        }
+        if (haveoutput) colibri_host::report_legend(std::cerr, indexed);
     }
-    /** occurrence-count histogram (reference histogram(), :2603-2640) */
-    void histogram(std::ostream* out) {
-        std::map<unsigned int, uint64_t> hist;
-        for (typename MapType::iterator it = this->begin(); it != this->end(); ++it) hist[valuehandler.count(it->second)] += 1;
-        *out << "HISTOGRAM" << std::endl << "occurrences\tpatterns" << std::endl;
-        for (const auto& kv : hist) *out << kv.first << "\t" << kv.second << std::endl;
-    }
+    void report(std::ostream* out, bool nocoverage = false) { report(*out, nocoverage); }
+
+  protected:
+    std::set<int>                                  cache_categories, cache_n;
+    std::map<int, std::map<int, uint64_t>>         cache_grouptotal, cache_grouptotalpatterns, cache_grouptotaltokens;
+    std::map<int, std::map<int, unsigned int>>     cache_grouptotalwordtypes;
+    bool                                           cache_coverage_done = false;
+    // hooks the indexed model fills in to count really covered positions (reference :3390-3450)
+    virtual void     coverage_visit(typename MapType::iterator, int, int) {}
+    virtual uint64_t coverage_tokens(int, int, uint64_t alloccurrences) { return alloccurrences; }
+    virtual void     coverage_finish() {}
 
   private:
     static void assign_loaded(uint32_t& dst, const IndexedData&, unsigned int count) { dst = count; }
@@ -455,6 +660,29 @@ class IndexedPatternModel : public PatternModel<IndexedData, IndexedDataHandler,
         : PatternModel<IndexedData, IndexedDataHandler, MapType>(filename, options, constrainmodel, corpus) {}
     int getmodeltype() const override { return INDEXEDPATTERNMODEL; }
 
+  protected:
+    // Really covered positions (reference :3390-3450): every occurrence covers size() consecutive positions, gaps included. The reference
+    // fills this only for the "all sizes" rows — its per-size test compares the *argument* n (0 from report()) with the group's size
+    // (:3425) — so per-size rows report 0 tokens there, and here.
+    std::map<int, std::vector<uint64_t>> covered_;
+    void coverage_visit(typename PatternMap<IndexedData>::iterator it, int c, int pn) override {
+        std::vector<uint64_t>&bycat = covered_[c], &all = covered_[0];
+        for (const IndexReference& r : it->second.data)
+            for (int i = 0; i < pn; ++i) {
+                const uint64_t pos = ((uint64_t)r.sentence << 16) | (uint16_t)(r.token + i);
+                bycat.push_back(pos);
+                all.push_back(pos);
+            }
+    }
+    uint64_t coverage_tokens(int c, int gn, uint64_t) override {
+        if (gn != 0) return 0;
+        std::vector<uint64_t>& v = covered_[c];
+        std::sort(v.begin(), v.end());
+        return (uint64_t)(std::unique(v.begin(), v.end()) - v.begin());
+    }
+    void coverage_finish() override { covered_.clear(); }
+
+  public:
     void train(std::istream* in, const PatternModelOptions& options, PatternModelInterface* constrainbymodel = NULL, PatternSet<>* filter = NULL, bool continued = false,
                uint32_t firstsentence = 1, bool ignoreerrors = false) override {
         if (options.DOSKIPGRAMS && this->reverseindex == NULL) {  // reference :2828-2833

@@ -134,6 +134,43 @@ std::string Pattern::tohex() const {
     return s;
 }
 
+namespace colibri_host {
+void token_slices(const unsigned char* data, size_t bytes, std::vector<std::string>& out) {
+    size_t begin = 0;
+    for (size_t i = 0; i < bytes; ++i)
+        if (data[i] < 128) {  // a byte under 128 closes a token
+            out.emplace_back((const char*)data + begin, i + 1 - begin);
+            begin = i + 1;
+        }
+}
+void print_legend(std::ostream& err, bool indexed) {
+    err << std::endl << "Legend:" << std::endl;
+    err << " - PATTERN    : The pattern, Gaps in skipgrams are represented as {*}. Variable-width gaps in flexgrams are shown using {**}." << std::endl;
+    err << " - COUNT      : The occurrence count - the amount of times the pattern occurs in the data" << std::endl;
+    if (indexed) {
+        err << " - TOKENS     : The number of tokens in the corpus that this pattern covers" << std::endl;
+        err << " - COVERAGE   : The number of tokens covered, as a fraction of the total in the corpus" << std::endl;
+    } else {
+        err << " - TOKENS     : The maximum number of tokens in the corpus that this pattern covers (a projection: count x size, the model is not indexed)" << std::endl;
+        err << " - COVERAGE   : The maximum number of tokens covered, as a fraction of the total in the corpus (projection)" << std::endl;
+    }
+    err << " - CATEGORY   : The pattern type category (ngram,skipgram,flexgram)" << std::endl;
+    err << " - SIZE       : The size of the pattern (in tokens)" << std::endl;
+    err << " - FREQUENCY  : The frequency of the pattern within its pattern type category and size-class." << std::endl;
+    err << " - REFERENCES : A space-delimited list of sentence:token position where the pattern occurs in the data. Sentences start at 1, tokens at 0" << std::endl;
+}
+void report_legend(std::ostream& err, bool indexed) {
+    err << std::endl << "Legend:" << std::endl;
+    err << " - PATTERNS    : The number of distinct patterns within the group" << std::endl;
+    if (indexed) {
+        err << " - TOKENS      : The number of tokens that is covered by the patterns in the group." << std::endl;
+        err << " - COVERAGE    : The number of tokens covered, as a fraction of the total in the corpus" << std::endl;
+    }
+    err << " - TYPES       : The number of unique *word/unigram* types in this group" << std::endl;
+    err << " - OCCURRENCES : The total number of occurrences of the patterns in this group" << std::endl;
+}
+}  // namespace colibri_host
+
 int PatternPointer::ngrams(std::vector<std::pair<PatternPointer, int>>& container, const int n) const {
     std::vector<size_t> starts{0};
     for (size_t i = 0; i < bytes; ++i)

@@ -39,7 +39,7 @@ void usage() {
 
 template <class ModelType>
 int run(ModelType& model, const std::string& corpusfile, const std::string& inputmodel, const std::string& outputmodel, const PatternModelOptions& options, uint32_t firstsentence,
-        bool doprint, bool doreport, bool dohistogram, const ClassDecoder* decoder) {
+        bool doprint, bool doreport, bool nocoverage, bool dohistogram, const ClassDecoder* decoder) {
     if (!inputmodel.empty()) {
         model.load(inputmodel, options);
     } else {
@@ -49,9 +49,14 @@ int run(ModelType& model, const std::string& corpusfile, const std::string& inpu
         std::cerr << "Writing model to " << outputmodel << std::endl;
         model.write(outputmodel);
     }
-    if (doprint) model.print(&std::cout, decoder);
-    if (doreport) model.report(&std::cout);
-    if (dohistogram) model.histogram(&std::cout);
+    // the views, in the reference's order and on the same stream (viewmodel, reference src/patternmodeller.cpp:242-289)
+    std::cerr << "Generating desired views..." << std::endl;
+    if (doprint) {
+        if (decoder == NULL) std::cerr << "ERROR: Unable to print model, no class file specified (--classfile)" << std::endl;
+        else model.print(std::cout, *decoder);
+    }
+    if (doreport) model.report(std::cout, nocoverage);
+    if (dohistogram) model.histogram(std::cout);
     return 0;
 }
 
@@ -60,7 +65,7 @@ int run(ModelType& model, const std::string& corpusfile, const std::string& inpu
 int main(int argc, char** argv) {
     std::string         corpusfile, classfile, inputmodel, outputmodel;
     PatternModelOptions options;
-    bool                unindexed = false, doprint = false, doreport = false, dohistogram = false;
+    bool                unindexed = false, doprint = false, doreport = false, nocoverage = false, dohistogram = false;
     uint32_t            firstsentence = 1;
     static struct option longopts[] = {{"datafile", required_argument, 0, 'f'},    {"classfile", required_argument, 0, 'c'},      {"inputmodel", required_argument, 0, 'i'},
                                        {"outputmodel", required_argument, 0, 'o'}, {"threshold", required_argument, 0, 't'},      {"unindexed", no_argument, 0, 'u'},
@@ -87,8 +92,11 @@ int main(int argc, char** argv) {
             case 'T': options.MINSKIPTYPES = std::atoi(optarg); break;
             case 'e': firstsentence = (uint32_t)std::atoi(optarg); break;
             case 'P': doprint = true; break;
-            case 'R':
-            case 'r': doreport = true; break;
+            case 'R': doreport = true; break;
+            case 'r':  // report without the coverage columns (reference :603-606)
+                doreport   = true;
+                nocoverage = true;
+                break;
             case 'H': dohistogram = true; break;
             case 'D': options.DEBUG = true; break;
             case 'h': usage(); return 0;
@@ -116,18 +124,18 @@ int main(int argc, char** argv) {
             if (inputmodel.empty() && options.DOSKIPGRAMS_EXHAUSTIVE) {
                 IndexedCorpus          corpus(corpusfile);
                 PatternModel<uint32_t> model(&corpus);
-                return run(model, corpusfile, inputmodel, outputmodel, options, firstsentence, doprint, doreport, dohistogram, decoder);
+                return run(model, corpusfile, inputmodel, outputmodel, options, firstsentence, doprint, doreport, nocoverage, dohistogram, decoder);
             }
             PatternModel<uint32_t> model;
-            return run(model, corpusfile, inputmodel, outputmodel, options, firstsentence, doprint, doreport, dohistogram, decoder);
+            return run(model, corpusfile, inputmodel, outputmodel, options, firstsentence, doprint, doreport, nocoverage, dohistogram, decoder);
         }
         if (inputmodel.empty()) {
             IndexedCorpus         corpus(corpusfile);  // indexed models are built on a loaded corpus (reference :735-737)
             IndexedPatternModel<> model(&corpus);
-            return run(model, corpusfile, inputmodel, outputmodel, options, firstsentence, doprint, doreport, dohistogram, decoder);
+            return run(model, corpusfile, inputmodel, outputmodel, options, firstsentence, doprint, doreport, nocoverage, dohistogram, decoder);
         }
         IndexedPatternModel<> model;
-        return run(model, corpusfile, inputmodel, outputmodel, options, firstsentence, doprint, doreport, dohistogram, decoder);
+        return run(model, corpusfile, inputmodel, outputmodel, options, firstsentence, doprint, doreport, nocoverage, dohistogram, decoder);
     } catch (const std::exception& e) {
         std::cerr << "colibri-patternmodeller: " << e.what() << std::endl;
         return 1;

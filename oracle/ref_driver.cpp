@@ -92,6 +92,7 @@ int usage() {
                  "      us = unindexed + exhaustive skipgrams (preloaded corpus)\n"
                  "      i  = indexed (preloaded corpus);  is = indexed + skipgrams\n"
                  "  ref_driver load <model.colibri.patternmodel> <u|i> <dump.txt>\n"
+                 "  ref_driver view <model> <u|i> <print|report|simplereport|histogram|info> <classfile>\n"
                  "  ref_driver hash <hex> [<hex> ...]\n"
                  "  ref_driver encode <text file> <out prefix>\n"
                  "  ref_driver masks <n> <maxskips>\n";
@@ -160,6 +161,30 @@ int main(int argc, char** argv) {
         }
         std::ofstream out(dumpout);
         dump(out, tokens, types, rows);
+        return 0;
+    }
+
+    if (cmd == "view") {  // the REFERENCE's own print / report / histogram of a model file (golden text for the C++ face and the CLI)
+        if (argc < 6) return usage();
+        const std::string modelfile = argv[2], kind = argv[3], what = argv[4], classfile = argv[5];
+        PatternModelOptions options;
+        options.QUIET     = true;
+        options.MINTOKENS = 1;
+        ClassDecoder decoder(classfile);
+        auto run = [&](auto& model) {
+            if (what == "print") model.print(std::cout, decoder);
+            else if (what == "report") model.report(std::cout, false);
+            else if (what == "simplereport") model.report(std::cout, true);
+            else if (what == "histogram") model.histogram(std::cout);
+            else if (what == "info") model.info(std::cout);
+        };
+        if (kind == "u") {
+            PatternModel<uint32_t> model(modelfile, options);
+            run(model);
+        } else {
+            IndexedPatternModel<> model(modelfile, options);
+            run(model);
+        }
         return 0;
     }
 

@@ -59,12 +59,18 @@ def test_cli_rejects_out_of_scope_flags():
 
 
 def test_cli_prints_the_references_golden_model(tmp_path):
-    """-i <reference's own v1 model> -P: loads and prints 111 patterns (hex keys without a class file)."""
-    out = subprocess.run([CLI, "-i", os.path.join(GOLDEN, "hamlet.v1.colibri.patternmodel"), "-u", "-P"], capture_output=True, text=True)
+    """-i <reference's own v1 model> -c <its class file> -P: loads and prints 111 patterns under the reference's header;
+    without a class file the reference refuses to print (src/patternmodeller.cpp:247-249) and so does this CLI."""
+    model = os.path.join(GOLDEN, "hamlet.v1.colibri.patternmodel")
+    out = subprocess.run([CLI, "-i", model, "-u", "-P", "-c", os.path.join(GOLDEN, "hamlet.colibri.cls")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 111
-    assert "06\t27" in lines
+    assert lines[0] == "PATTERN\tCOUNT\tTOKENS\tCOVERAGE\tCATEGORY\tSIZE\tFREQUENCY"
+    assert len(lines) == 112
+    assert ",\t27\t27\t0.0762712\tngram\t1\t0.126761" in lines
+    out = subprocess.run([CLI, "-i", model, "-u", "-P"], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout == ""
+    assert "ERROR: Unable to print model, no class file specified (--classfile)" in out.stderr
 
 
 @pytest.mark.gpu

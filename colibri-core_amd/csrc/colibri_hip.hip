@@ -861,14 +861,14 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                 if (n == 1)
                     rc = binned_order(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, id_cur, n, false, false);
                 else
-                    rc = binned_order(c, pl, KeyNgram{c->bytes.p, c->tokstart.p, id_prev, n}, id_cur, n, n >= 3, n < maxlength);
+                    rc = binned_order(c, pl, KeyNgram{id_prev, n}, id_cur, n, n >= 3, n < maxlength);
                 if (rc) return rc;
             } else {
                 launch_clear(c, pl);
                 if (n == 1)
                     launch_count(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, id_cur, 3, COLIBRI_K_COUNT);
                 else
-                    launch_count(c, pl, KeyNgram{c->bytes.p, c->tokstart.p, id_prev, n}, id_cur, 3, COLIBRI_K_COUNT);
+                    launch_count(c, pl, KeyNgram{id_prev, n}, id_cur, 3, COLIBRI_K_COUNT);
                 launch_prune(c, pl, pl.thr, nullptr, 0);
                 launch_resolve(c, pl, id_cur);
             }
@@ -909,7 +909,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             if (n == 1)
                 launch_count(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, c->ids[n].p, 3, COLIBRI_K_COUNT);
             else
-                launch_count(c, pl, KeyNgram{c->bytes.p, c->tokstart.p, c->ids[n - 1].p, n}, c->ids[n].p, 3, COLIBRI_K_COUNT);
+                launch_count(c, pl, KeyNgram{c->ids[n - 1].p, n}, c->ids[n].p, 3, COLIBRI_K_COUNT);
             launch_prune(c, pl, pl.thr, nullptr, 0);
             launch_resolve(c, pl, c->ids[n].p);
             if ((rc = read_state(c))) return rc;
@@ -1244,7 +1244,7 @@ int colibri_shard_count(colibri_ctx* c, int n, uint32_t mask, int level, uint64_
         hs.id_base = 0;  // sparse ids restart at 0 every pass: they are remapped to global ids when the replies arrive
         if ((rc = write_state(c))) return rc;
         const bool use_list = n >= 3 && sh.list_valid;
-        if ((rc = binned_count_stage(c, pl, KeyNgram{c->bytes.p, c->tokstart.p, c->ids[n - 1].p, n}, n, use_list, 1u, true))) return rc;
+        if ((rc = binned_count_stage(c, pl, KeyNgram{c->ids[n - 1].p, n}, n, use_list, 1u, true))) return rc;
         hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
         sh.pass_list = use_list;
         if ((rc = read_state(c))) return rc;
@@ -1271,7 +1271,7 @@ int colibri_shard_count(colibri_ctx* c, int n, uint32_t mask, int level, uint64_
         if (n == 1)
             launch_count(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, out, 3, COLIBRI_K_COUNT);
         else
-            launch_count(c, pl, KeyNgram{c->bytes.p, c->tokstart.p, c->ids[n - 1].p, n}, out, 3, COLIBRI_K_COUNT);
+            launch_count(c, pl, KeyNgram{c->ids[n - 1].p, n}, out, 3, COLIBRI_K_COUNT);
     } else {
         const auto      parts = mask_parts(mask, n);
         const uint32_t* gate  = o.doskipgrams ? c->ids[n].p : c->ids[n - 1].p;

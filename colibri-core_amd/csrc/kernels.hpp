@@ -274,25 +274,7 @@ struct KeyUnigram {
         return true;
     }
 };
-// order n >= 2: admissible iff both (n-1)-grams survived; exact key = their two survivor ids; slot by SpookyHash of the bytes
-struct KeyNgram {
-    const uint8_t*  bytes;
-    const uint32_t* tokstart;
-    const uint32_t* id_prev;
-    int             n;
-    __device__ __forceinline__ bool operator()(uint32_t i, uint32_t npos, uint64_t& key, uint64_t& hash) const {
-        if (i + 1 >= npos) return false;
-        const uint32_t l = id_prev[i], r = id_prev[i + 1];
-        if (l == kInvalid || r == kInvalid) return false;
-        key              = ((uint64_t)l << 32) | r;
-        const uint32_t a = tokstart[i];
-        hash             = spooky64_short(bytes + a, tokstart[i + n] - a);
-        return true;
-    }
-};
-// skipgram passes: the key is a pair of ids taken at two offsets from the window start. `gate`/`gate2` say which windows take
-// part (exhaustive: both (n-1)-grams survived = gate[i], gate2[i+1]; indexed: the n-gram itself survived = gate[i]).
-// Level >= 2 of a multi-part skipgram pairs the previous level's slot index (left, offset 0) with the next part's id.
+// 64-bit finaliser used wherever a table slot / radix bin has to be chosen from an exact 64-bit key
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     x ^= x >> 33;
     x *= 0xff51afd7ed558ccdULL;
@@ -301,6 +283,26 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     x ^= x >> 33;
     return x;
 }
+// order n >= 2: admissible iff both (n-1)-grams survived; exact key = their two survivor ids. The bin / slot comes from a mix of
+// the exact key: the reference's SpookyHash of the window bytes only places a node in its unordered_map and is not observable
+// in any output, while computing it per window costs two more index loads, unaligned byte loads and ~100 integer
+// ops — 0.7 ms of a 12.8 ms Z100M step when it was measured (gpurun_out/mixhash.log). The bit-exact device SpookyHash stays in
+// the order-1 key functor and behind colibri_hash_windows / colibri_hash_keys (known-answer tested).
+struct KeyNgram {
+    const uint32_t* id_prev;
+    int             n;
+    __device__ __forceinline__ bool operator()(uint32_t i, uint32_t npos, uint64_t& key, uint64_t& hash) const {
+        if (i + 1 >= npos) return false;
+        const uint32_t l = id_prev[i], r = id_prev[i + 1];
+        if (l == kInvalid || r == kInvalid) return false;
+        key  = ((uint64_t)l << 32) | r;
+        hash = mix64(key);
+        return true;
+    }
+};
+// skipgram passes: the key is a pair of ids taken at two offsets from the window start. `gate`/`gate2` say which windows take
+// part (exhaustive: both (n-1)-grams survived = gate[i], gate2[i+1]; indexed: the n-gram itself survived = gate[i]).
+// Level >= 2 of a multi-part skipgram pairs the previous level's slot index (left, offset 0) with the next part's id.
 struct KeyPair {
     const uint32_t* gate;
     const uint32_t* gate2;  // may be NULL

@@ -41,15 +41,16 @@ struct BinState {
     uint32_t nrec;               // records emitted
     uint32_t overflow_bin;       // a final bin exceeded its LDS table -> host falls back to the global-table path
     uint32_t bshift;             // level B uses 256 >> bshift sub-bins: small orders get fewer, fuller final bins
-    uint32_t pad;
+    uint32_t kept_total;         // survivors of this order (written by bin_kept_scan_kernel)
     uint32_t histA[kBins];       // records per A bin
     uint32_t offA[kBins + 1];    // exclusive scan
     uint32_t tprefA[kBins + 1];  // tiles per A bin, exclusive scan (for the level-B kernels)
     uint32_t curA[kBins];        // scatter cursors
     uint32_t hist2[kFinalBins];  // records per final bin, then (after the scan) their offsets
     uint32_t total2;             // sum (written by the scan)
-    uint32_t cur2[kFinalBins];
+    uint32_t cur2[kFinalBins];   // level-B scatter cursors; afterwards bin_count leaves each bin's survivor count here, and the scan turns them into dense offsets
     uint32_t found_part[kBins];  // distinct keys, accumulated per A bin (a single counter would serialise 65 536 atomics)
+    uint32_t kept_part[kBins];   // survivors, accumulated per A bin
 };
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -61,9 +62,11 @@ struct BinState {
 // The level-A partition is fused in: the tile's records are counting-sorted by A bin inside LDS (the election arrays are dead by
 // then and are reused as the staging buffer) and leave as one contiguous run per (tile, bin) into that bin's fixed-capacity
 // region [a * region, (a+1) * region) of `recs`. A region that would overflow raises st->radix_overflow (global-table rerun).
+// ids_at (optional) is reset at every record position, which spares a fill of the whole array per order.
 template <class KeyFn, bool LIST>
 __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __restrict__ recs, uint32_t region, uint32_t* __restrict__ rep_of, DevState* __restrict__ st,
-                                                           BinState* __restrict__ bs, uint32_t npos, const uint32_t* __restrict__ list, const uint32_t* __restrict__ nlist) {
+                                                           BinState* __restrict__ bs, uint32_t npos, const uint32_t* __restrict__ list, const uint32_t* __restrict__ nlist,
+                                                           uint32_t* __restrict__ ids_at) {
     if (st->done) return;
     const uint32_t nitems = LIST ? *nlist : npos;
     // phase E (election): keyL u64[2048] | winL u32[4096]   -- 32 KB, later reused as recL Rec[2048]
@@ -147,6 +150,7 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
                 r.pos  = posn[k];
                 r.meta = (hb << 16) | (1u + cntL[e]);
                 recL[offL[hb >> 8] + rank[k]] = r;
+                if (ids_at != nullptr) ids_at[posn[k]] = kInvalid;  // "no survivor here" until bin_count says otherwise: only record positions are ever read back
             }
         }
         __syncthreads();
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restri
 // -------------------------------------------------------------------------------------------------------------------
 // Survivors are written WITHOUT any global atomic: bin f owns the index range [hist2[f], hist2[f+1]) of the per-order sparse
 // arrays (it has at least as many records as survivors); the survivor id handed to the next order is id_base + that sparse
-// index — ids only have to be unique. compact_results_kernel turns the sparse arrays into the dense result list.
+// index — ids only have to be unique. bin_kept_scan_kernel + compact_bins_kernel turn the sparse arrays into the dense result list.
 // insert one record per lane into the bin's LDS table; returns the slot (kInvalid for lanes that are idle or were folded into
 // their wave's leader). Must be called by all lanes of the block together (wave ballots inside).
 __device__ __forceinline__ uint32_t bin_insert(const bool valid, const Rec& x, unsigned long long* keyT, uint32_t* cntT, uint32_t* repT, const uint32_t smask,
@@ -402,7 +406,11 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
     }
     uint32_t       total;
     const uint32_t excl = block_exclusive_scan(keep, &total);
-    if (threadIdx.x == 0) atomicAdd(&bs->found_part[f >> 8], distinct);
+    if (threadIdx.x == 0) {
+        atomicAdd(&bs->found_part[f >> 8], distinct);
+        bs->cur2[f] = total;  // this bin's survivors (cur2 is free after the level-B scatter; empty bins hold 0 there already)
+        if (total) atomicAdd(&bs->kept_part[f >> 8], total);
+    }
     const uint32_t id_base = st->id_base;  // survivor ids of this order start here
     uint32_t       r       = begin + excl;
     for (uint32_t q = 0; q < per; ++q) {
@@ -417,9 +425,10 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
         }
         idT[s] = id;
     }
-    for (uint32_t j = begin + total + threadIdx.x; j < end; j += kBlock) sp_cnt[j] = 0;  // the unused tail of this bin's range
+    if (sp_key != nullptr)  // sharded runs scan the whole sparse range for candidates: mark the unused tail of this bin's range
+        for (uint32_t j = begin + total + threadIdx.x; j < end; j += kBlock) sp_cnt[j] = 0;
     __syncthreads();
-    if (total == 0) return;  // nothing in this bin survives: ids_at keeps its kInvalid fill
+    if (total == 0 || ids_at == nullptr) return;  // nothing in this bin survives (ids_at keeps the kInvalid the emit kernel wrote), or nobody needs the ids
     // survivor id at every representative position of a surviving key (ids_at was pre-filled with kInvalid)
 #pragma unroll
     for (int q = 0; q < kBinRegPer; ++q) {
@@ -461,39 +470,40 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict
     }
 }
 
-// sparse per-order survivors -> dense result list (block-tiled reservation: one atomic per 4096 entries)
-__global__ __launch_bounds__(kBlock) void compact_results_kernel(const uint32_t* __restrict__ sp_rep, const uint32_t* __restrict__ sp_cnt, DevState* __restrict__ st,
-                                                                  const BinState* __restrict__ bs, uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap) {
+// per-bin survivor counts (left in cur2 by bin_count) -> dense result offsets, bin by bin; kept = their total. Block a scans A bin a.
+__global__ __launch_bounds__(kBlock) void bin_kept_scan_kernel(DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t res_cap) {
     if (st->done) return;
-    __shared__ uint32_t baseL;
-    const uint32_t      n = bs->nrec, res_base = st->res_total;
-    const uint32_t      ntiles = (n + kPruneTile - 1) / kPruneTile;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t j0 = tile * kPruneTile + threadIdx.x * kPrunePer;
-        uint32_t       c[kPrunePer], k = 0;
-#pragma unroll
-        for (int q = 0; q < kPrunePer; ++q) {
-            c[q] = (j0 + q < n) ? sp_cnt[j0 + q] : 0u;
-            k += c[q] != 0;
-        }
-        uint32_t       total;
-        const uint32_t excl = block_exclusive_scan(k, &total);
-        if (threadIdx.x == 0) baseL = total ? atomicAdd(&st->kept, total) : 0;
-        __syncthreads();
-        uint32_t r = res_base + baseL + excl;
-#pragma unroll
-        for (int q = 0; q < kPrunePer; ++q) {
-            if (c[q]) {
-                if (r < res_cap) {
-                    res_rep[r] = sp_rep[j0 + q];
-                    res_cnt[r] = c[q];
-                } else {
-                    st->overflow = 1;
-                }
-                ++r;
+    const uint32_t a = blockIdx.x;
+    uint32_t       before, tot;
+    block_exclusive_scan(threadIdx.x < a ? bs->kept_part[threadIdx.x] : 0u, &before);
+    const uint32_t h = bs->cur2[a * kBins + threadIdx.x];
+    const uint32_t o = block_exclusive_scan(h, &tot);
+    bs->cur2[a * kBins + threadIdx.x] = before + o;
+    if (a == kBins - 1 && threadIdx.x == 0) {
+        const uint32_t kept = before + tot;
+        bs->kept_total      = kept;
+        st->kept            = kept;
+        if ((uint64_t)st->res_total + kept > res_cap) st->overflow = 1;
+    }
+}
+// sparse per-bin survivors -> dense result list: one wave copies one bin's run (no atomics, no scan over dead entries)
+__global__ __launch_bounds__(kBlock) void compact_bins_kernel(const uint32_t* __restrict__ sp_rep, const uint32_t* __restrict__ sp_cnt, const DevState* __restrict__ st,
+                                                               const BinState* __restrict__ bs, uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap) {
+    if (st->done) return;
+    const uint32_t res_base = st->res_total, lane = threadIdx.x & (kWave - 1);
+    const uint32_t nwaves = gridDim.x * (kBlock / kWave);
+    for (uint32_t f = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; f < (uint32_t)kFinalBins; f += nwaves) {
+        const uint32_t off = bs->cur2[f];
+        const uint32_t n   = ((f + 1 < (uint32_t)kFinalBins) ? bs->cur2[f + 1] : bs->kept_total) - off;
+        if (n == 0) continue;
+        const uint32_t src = bs->hist2[f];
+        for (uint32_t j = lane; j < n; j += kWave) {
+            const uint32_t r = res_base + off + j;
+            if (r < res_cap) {
+                res_rep[r] = sp_rep[src + j];
+                res_cnt[r] = sp_cnt[src + j];
             }
         }
-        __syncthreads();
     }
 }
 
@@ -535,11 +545,10 @@ __global__ __launch_bounds__(kBlock) void bin_resolve_kernel(const uint32_t* __r
                 pos[q]           = LIST ? list_in[j] : j;
                 if (r != kInvalid) id[q] = ids_at[r];
                 if (remap != nullptr && id[q] != kInvalid) id[q] = remap[id[q] - remap_base];  // sharded: local sparse id -> global survivor id
-                if (LIST) {
-                    if (id[q] != kInvalid) ids[pos[q]] = id[q];  // ids was pre-filled with kInvalid
-                } else {
-                    ids[j] = id[q];
-                }
+                // LIST: every listed position is written, valid or not. The next order reads ids at i and i+1 only for i on the NEW
+                // list, and a surviving n-gram at i means the (n-1)-gram at i+1 survived, i.e. i+1 is on THIS list: no fill needed
+                // for that reader (callers that read ids at arbitrary positions pre-fill it with kInvalid).
+                ids[LIST ? pos[q] : j] = id[q];
                 c += id[q] != kInvalid;
             }
         }

@@ -541,22 +541,22 @@ BinnedIO binned_planes(colibri_ctx* c, const TrainPlan& pl, bool with_keys) {
 }
 
 template <class KeyFn>
-int binned_count_stage(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, int n, bool use_list, uint32_t thr, bool with_keys) {
+int binned_count_stage(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, int n, bool use_list, uint32_t thr, bool with_keys, bool need_ids = true) {
     const uint32_t  tiles    = blocks_for(pl.npos, kScatTile) + 1;
     const uint32_t* list_in  = c->alist[n & 1].p;
     const uint32_t* nlist_in = c->alist_n.p + (n & 1);
     HIP_TRY(c, hipMemsetAsync(c->binstate.p, 0, sizeof(BinState), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->ids_at.p, 0xFF, sizeof(uint32_t) * (size_t)pl.npos, c->stream));
+    uint32_t* const ids_at = need_ids ? c->ids_at.p : nullptr;  // reset by the emit kernel at every record position; not needed when nobody resolves ids
     // records leave the emit kernel already partitioned by A bin into fixed-capacity regions of recs[0]; level B moves them to recs[1]
     const uint32_t region = (uint32_t)(c->recs[0].n / kBins);
     {
         Prof p(c, COLIBRI_K_EMIT);
         if (use_list)
             hipLaunchKernelGGL((bin_emit_kernel<KeyFn, true>), dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, fn, c->recs[0].p, region, c->rep_of.p, c->state.p, c->binstate.p, pl.npos,
-                               list_in, nlist_in);
+                               list_in, nlist_in, ids_at);
         else
             hipLaunchKernelGGL((bin_emit_kernel<KeyFn, false>), dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, fn, c->recs[0].p, region, c->rep_of.p, c->state.p, c->binstate.p, pl.npos,
-                               (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, ids_at);
     }
     {
         Prof p(c, COLIBRI_K_SCATTER);
@@ -568,18 +568,19 @@ int binned_count_stage(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, int
     const BinnedIO io = binned_planes(c, pl, with_keys);
     {
         Prof p(c, COLIBRI_K_BINCOUNT);
-        hipLaunchKernelGGL(bin_count_kernel, dim3(256 * 12), dim3(kBlock), 0, c->stream, c->recs[1].p, c->state.p, c->binstate.p, thr, io.sp_rep, io.sp_cnt, io.sp_key, c->ids_at.p);
+        hipLaunchKernelGGL(bin_count_kernel, dim3(256 * 12), dim3(kBlock), 0, c->stream, c->recs[1].p, c->state.p, c->binstate.p, thr, io.sp_rep, io.sp_cnt, io.sp_key, ids_at);
     }
     return COLIBRI_OK;
 }
 
-int binned_resolve_stage(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids_out, int n, bool use_list, bool build_list, const uint32_t* remap, uint32_t remap_base) {
+int binned_resolve_stage(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids_out, int n, bool use_list, bool build_list, const uint32_t* remap, uint32_t remap_base,
+                         bool prefill_ids = true) {
     const uint32_t* list_in   = c->alist[n & 1].p;
     const uint32_t* nlist_in  = c->alist_n.p + (n & 1);
     uint32_t*       list_out  = build_list ? c->alist[(n + 1) & 1].p : nullptr;
     uint32_t*       nlist_out = c->alist_n.p + ((n + 1) & 1);
     HIP_TRY(c, hipMemsetAsync(nlist_out, 0, sizeof(uint32_t), c->stream));
-    if (use_list) HIP_TRY(c, hipMemsetAsync(ids_out, 0xFF, sizeof(uint32_t) * (size_t)pl.npos, c->stream));
+    if (use_list && prefill_ids) HIP_TRY(c, hipMemsetAsync(ids_out, 0xFF, sizeof(uint32_t) * (size_t)pl.npos, c->stream));
     Prof p(c, COLIBRI_K_RESOLVE);
     if (use_list)
         hipLaunchKernelGGL((bin_resolve_kernel<true>), dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->rep_of.p, c->ids_at.p, ids_out, c->state.p, pl.npos, list_in, nlist_in, list_out,
@@ -590,17 +591,22 @@ int binned_resolve_stage(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids_out,
     return COLIBRI_OK;
 }
 
+// one order of the plain (unsynced) run. need_ids = false at the last order: nothing reads its survivor ids, so the id scatter and
+// the resolve pass are skipped.
 template <class KeyFn>
-int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t* ids_out, int n, bool use_list, bool build_list) {
+int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t* ids_out, int n, bool use_list, bool need_ids) {
     int rc;
-    if ((rc = binned_count_stage(c, pl, fn, n, use_list, pl.thr, false))) return rc;
+    if ((rc = binned_count_stage(c, pl, fn, n, use_list, pl.thr, false, need_ids))) return rc;
     const BinnedIO io = binned_planes(c, pl, false);
     {
         Prof p(c, COLIBRI_K_PRUNE);
-        hipLaunchKernelGGL(compact_results_kernel, dim3(pl.tab_grid), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, c->binstate.p, c->res_rep.p, c->res_cnt.p, pl.res_cap);
+        hipLaunchKernelGGL(bin_kept_scan_kernel, dim3(kBins), dim3(kBlock), 0, c->stream, c->state.p, c->binstate.p, pl.res_cap);
+        hipLaunchKernelGGL(compact_bins_kernel, dim3(1024), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, c->binstate.p, c->res_rep.p, c->res_cnt.p, pl.res_cap);
         hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
     }
-    return binned_resolve_stage(c, pl, ids_out, n, use_list, build_list, nullptr, 0u);
+    if (!need_ids) return COLIBRI_OK;
+    // the only later reader is the next order's emit kernel (ids at i and i+1 for i on the new active list): no fill of ids_out
+    return binned_resolve_stage(c, pl, ids_out, n, use_list, /*build_list=*/n >= 2, nullptr, 0u, false);
 }
 
 // One (order, gap mask) skipgram pass. Exact identity of a skipgram = the survivor ids of its contiguous parts, paired
@@ -859,7 +865,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                 // orders 1-2 scan every position (almost all are admissible); from order 3 on only the positions that still
                 // carry a survivor id are visited (the active list the previous order's resolve left behind)
                 if (n == 1)
-                    rc = binned_order(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, id_cur, n, false, false);
+                    rc = binned_order(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, id_cur, n, false, n < maxlength);
                 else
                     rc = binned_order(c, pl, KeyNgram{id_prev, n}, id_cur, n, n >= 3, n < maxlength);
                 if (rc) return rc;

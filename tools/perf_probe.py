@@ -5,17 +5,18 @@ sys.path.insert(0, os.path.join(ROOT, 'colibri-core_amd', 'pyhost'))
 import numpy as np
 from colibri_amd import capi, synth
 sizes = [int(x) for x in sys.argv[1:]] or [10**7, 10**8]
+MAXLEN = int(os.environ.get('PROBE_MAXLENGTH', '5'))
 for T in sizes:
     V, seed = 10**6, 43 if T == 10**7 else 44
     t = time.time(); payload = synth.zipf_corpus(T, V, seed, header=False); print('gen', T, round(time.time()-t, 2), len(payload), flush=True)
     c = capi.Context(0)
     t = time.time(); c.upload(payload); print('upload+tokenise s', round(time.time()-t, 4), c.corpus_info(), flush=True)
     for rep in range(3):
-        st = c.train(maxlength=5, mintokens=2, profile=1)
+        st = c.train(maxlength=MAXLEN, mintokens=2, profile=1)
         W = sum(st.windows[1:6])
         print('train ms', round(st.train_ms, 3), 'windows', W, 'Mpat/s', round(W/st.train_ms/1e3, 1), 'kept', [st.kept[n] for n in range(1, 6)], 'found', [st.found[n] for n in range(1, 6)], 'adm', [st.admitted[n] for n in range(1, 6)], flush=True)
         print('  kernels', {capi.KERNEL_CLASSES[k]: tuple(round(x, 3) for x in c.kernel_time(k)) for k in range(len(capi.KERNEL_CLASSES))}, flush=True)
-    st = c.train(maxlength=5, mintokens=2, profile=0)
+    st = c.train(maxlength=MAXLEN, mintokens=2, profile=0)
     print('train ms (no events)', round(st.train_ms, 3), flush=True)
     t = time.time(); a = c.export_arrays(); print('export s', round(time.time()-t, 4), len(a[2]), flush=True)
     c.close()

@@ -57,8 +57,10 @@ struct BinState {
 // emit: scan + SpookyHash + block-local reduce -> records
 // -------------------------------------------------------------------------------------------------------------------
 // LIST = false: one lane per corpus position (orders 1 and 2). LIST = true: one lane per entry of the active list = the positions
-// that still carry a survivor id of order n-1 (orders >= 3, where only a few percent of the positions can start a window);
-// rep_of is then indexed by list entry.
+// that still carry a survivor id of order n-1 (orders >= 3, where only a few percent of the positions can start a window).
+// Everything downstream of the key (Rec::pos, rep_of, ids_at, sp_rep) then lives in LIST-ENTRY space: the id scatter of bin_count
+// and the gather of bin_resolve touch an array as small as the list (cache-resident at orders >= 4) and the resolve reads it densely;
+// compact_bins / the shard kernels translate representatives back to corpus positions through the list.
 // The level-A partition is fused in: the tile's records are counting-sorted by A bin inside LDS (the election arrays are dead by
 // then and are reused as the staging buffer) and leave as one contiguous run per (tile, bin) into that bin's fixed-capacity
 // region [a * region, (a+1) * region) of `recs`. A region that would overflow raises st->radix_overflow (global-table rerun).
@@ -78,7 +80,6 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
     __shared__ uint32_t cntL[kCountTile];
     __shared__ uint32_t histL[kBins], offL[kBins], gbaseL[kBins];
     __shared__ uint32_t redL[kBlock / kWave];
-    __shared__ uint32_t posL[LIST ? kCountTile : 1];
     const uint32_t ntiles = (nitems + kCountTile - 1) / kCountTile;
     uint32_t       nadm   = 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -93,7 +94,6 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
             key[k]  = 0;
             hash[k] = 0;
             posn[k] = LIST ? (j < nitems ? list[j] : 0u) : j;
-            if (LIST) posL[e] = posn[k];
             adm[k]  = (j < nitems) && keyfn(posn[k], npos, key[k], hash[k]);
             cntL[e] = 0;
             if (adm[k]) {
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
 #pragma unroll
         for (int k = 0; k < kCountPer; ++k) {
             const uint32_t e = k * kBlock + threadIdx.x, j = base + e;
-            if (j < nitems) rep_of[j] = adm[k] ? (LIST ? posL[rep[k]] : base + rep[k]) : kInvalid;  // always a corpus POSITION
+            if (j < nitems) rep_of[j] = adm[k] ? base + rep[k] : kInvalid;  // an ITEM index: the corpus position, or the list entry (LIST)
             rank[k] = kInvalid;
             if (adm[k] && rep[k] == e) rank[k] = atomicAdd(&histL[(uint32_t)(hash[k] >> 56)], 1u);
         }
@@ -147,10 +147,10 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
                 const uint32_t hb = (uint32_t)(hash[k] >> 48);
                 Rec            r;
                 r.key  = key[k];
-                r.pos  = posn[k];
+                r.pos  = base + e;  // item index (corpus position, or list entry when LIST): what ids_at / rep_of / sp_rep are indexed by
                 r.meta = (hb << 16) | (1u + cntL[e]);
                 recL[offL[hb >> 8] + rank[k]] = r;
-                if (ids_at != nullptr) ids_at[posn[k]] = kInvalid;  // "no survivor here" until bin_count says otherwise: only record positions are ever read back
+                if (ids_at != nullptr) ids_at[base + e] = kInvalid;  // "no survivor here" until bin_count says otherwise: only record positions are ever read back
             }
         }
         __syncthreads();
@@ -459,9 +459,12 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict
     __shared__ unsigned long long keyT[kBinSlots];
     __shared__ uint32_t           cntT[kBinSlots], repT[kBinSlots], idT[kBinSlots];
     __shared__ uint32_t           redL[kBlock / kWave], failL;
-    // persistent blocks walk the final bins: small orders leave most of the 65 536 bins empty, and an empty bin must cost a
-    // loop iteration, not a block launch
-    for (uint32_t f = blockIdx.x; f < (uint32_t)kFinalBins; f += gridDim.x) {
+    // persistent blocks walk the final bins. Small orders use only the first (256 >> bshift) sub-bins of every A bin, i.e. the
+    // non-empty bins are f = a * 256 + b with b small: walked in f order, they would all land on the few blocks with
+    // blockIdx = a * 256 mod gridDim (12 of 3072), 21 bins in a row each — 0.2 ms of serial latency per order. Walking the
+    // transposed index (a fastest) hands consecutive non-empty bins to consecutive blocks.
+    for (uint32_t g = blockIdx.x; g < (uint32_t)kFinalBins; g += gridDim.x) {
+        const uint32_t f     = ((g & (uint32_t)(kBins - 1)) << 8) | (g >> 8);
         const uint32_t begin = bs->hist2[f];
         const uint32_t end   = (f + 1 < (uint32_t)kFinalBins) ? bs->hist2[f + 1] : bs->total2;
         if (begin >= end) continue;
@@ -488,11 +491,13 @@ __global__ __launch_bounds__(kBlock) void bin_kept_scan_kernel(DevState* __restr
 }
 // sparse per-bin survivors -> dense result list: one wave copies one bin's run (no atomics, no scan over dead entries)
 __global__ __launch_bounds__(kBlock) void compact_bins_kernel(const uint32_t* __restrict__ sp_rep, const uint32_t* __restrict__ sp_cnt, const DevState* __restrict__ st,
-                                                               const BinState* __restrict__ bs, uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap) {
+                                                               const BinState* __restrict__ bs, uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap,
+                                                               const uint32_t* __restrict__ list /* item index -> corpus position, or NULL */) {
     if (st->done) return;
     const uint32_t res_base = st->res_total, lane = threadIdx.x & (kWave - 1);
     const uint32_t nwaves = gridDim.x * (kBlock / kWave);
-    for (uint32_t f = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; f < (uint32_t)kFinalBins; f += nwaves) {
+    for (uint32_t g = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; g < (uint32_t)kFinalBins; g += nwaves) {
+        const uint32_t f   = ((g & (uint32_t)(kBins - 1)) << 8) | (g >> 8);  // transposed walk, as in bin_count_kernel
         const uint32_t off = bs->cur2[f];
         const uint32_t n   = ((f + 1 < (uint32_t)kFinalBins) ? bs->cur2[f + 1] : bs->kept_total) - off;
         if (n == 0) continue;
@@ -500,7 +505,8 @@ __global__ __launch_bounds__(kBlock) void compact_bins_kernel(const uint32_t* __
         for (uint32_t j = lane; j < n; j += kWave) {
             const uint32_t r = res_base + off + j;
             if (r < res_cap) {
-                res_rep[r] = sp_rep[src + j];
+                const uint32_t rp = sp_rep[src + j];
+                res_rep[r]        = list != nullptr ? list[rp] : rp;
                 res_cnt[r] = sp_cnt[src + j];
             }
         }

@@ -53,6 +53,8 @@ struct colibri_ctx {
     DevBuf<uint32_t>  delimpos;
     DevBuf<uint32_t>  cls;              // class id per position (0 = delimiter)
     DevBuf<uint32_t>  cnt1, rep1;       // order-1 fast path: count / representative position per class
+    DevBuf<UniState>  unistate;         // ... its atomic-free variant: tail-bin sizes / offsets / cursors
+    DevBuf<uint16_t>  uni_tail;         // ... and the tail tokens as 2-byte offsets inside their class-range bin
     std::vector<uint64_t> lenhist;  // sentence-length histogram (host copy)
     uint64_t              windows_n[COLIBRI_MAX_ORDER] = {0};  // W_n = n-token windows inside sentences, from the histogram (once per upload)
 
@@ -374,6 +376,8 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->cls);
     dev_free(c->cnt1);
     dev_free(c->rep1);
+    dev_free(c->unistate);
+    dev_free(c->uni_tail);
     for (auto& b : c->ids) dev_free(b);
     dev_free(c->scratch[0]);
     dev_free(c->scratch[1]);
@@ -601,7 +605,8 @@ int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t*
     {
         Prof p(c, COLIBRI_K_PRUNE);
         hipLaunchKernelGGL(bin_kept_scan_kernel, dim3(kBins), dim3(kBlock), 0, c->stream, c->state.p, c->binstate.p, pl.res_cap);
-        hipLaunchKernelGGL(compact_bins_kernel, dim3(1024), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, c->binstate.p, c->res_rep.p, c->res_cnt.p, pl.res_cap);
+        hipLaunchKernelGGL(compact_bins_kernel, dim3(1024), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, c->binstate.p, c->res_rep.p, c->res_cnt.p, pl.res_cap,
+                           use_list ? (const uint32_t*)c->alist[n & 1].p : (const uint32_t*)nullptr);
         hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
     }
     if (!need_ids) return COLIBRI_OK;
@@ -788,6 +793,14 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     // space is small enough for a dense array; table_mode 1 / 2 force the generic table / radix implementations (tests)
     const bool uni_direct = !synced && o.table_mode == 0 && !(c->flags & kFlagNonCanonical) && c->maxclass < (1u << 28);
     if (uni_direct && ((rc = dev_alloc(c, c->cnt1, (size_t)c->maxclass + 2)) || (rc = dev_alloc(c, c->rep1, (size_t)c->maxclass + 2)))) return rc;
+    // class-range width of the atomic-free order 1: 256 bins must cover every class and a bin's counters must fit in LDS (<= 2^14)
+    uint32_t uni_shift = 0;
+    if (uni_direct && !synced) {
+        uni_shift = 12;
+        while (uni_shift <= 14 && ((uint64_t)c->maxclass >> uni_shift) >= (uint64_t)kUniBins) ++uni_shift;
+        if (uni_shift > 14) uni_shift = 0;  // more than 4 M classes: keep the atomics kernel
+    }
+    if (uni_shift && ((rc = dev_alloc(c, c->unistate, 1)) || (rc = dev_alloc(c, c->uni_tail, (size_t)c->npos + 1)))) return rc;
     // ---- HBM layout (sized once; nothing is allocated inside the unsynced order loop) ----------------
     // table: an order admits at most `npos` windows -> 1.5x slots; results: every survivor has >= 2 occurrences
     const uint64_t table_slots64 = (uint64_t)npos + (npos >> 1) + 2048;
@@ -848,14 +861,23 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                 // order 1 on the class-indexed count array (kernels.hpp §2b): no hashing, no table, LDS histogram for the Zipf head
                 const uint32_t nclasses = c->maxclass + 1;
                 HIP_TRY(c, hipMemsetAsync(c->cnt1.p, 0, sizeof(uint32_t) * nclasses, c->stream));
-                {
+                if (uni_shift) {
+                    // no per-token global atomics: head histogram in LDS, tail partitioned into 256 class ranges and counted per range in LDS
+                    HIP_TRY(c, hipMemsetAsync(c->unistate.p, 0, sizeof(UniState), c->stream));
+                    Prof p(c, COLIBRI_K_COUNT);
+                    hipLaunchKernelGGL(uni_head_kernel, dim3(512), dim3(kBlock), 0, c->stream, c->cls.p, npos, uni_shift, c->cnt1.p, c->unistate.p, c->state.p);
+                    hipLaunchKernelGGL(uni_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->unistate.p);
+                    hipLaunchKernelGGL(uni_partition_kernel, dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, c->cls.p, npos, uni_shift, c->unistate.p, c->uni_tail.p, c->state.p);
+                    hipLaunchKernelGGL(uni_tail_count_kernel, dim3(kUniBins * kUniSlices), dim3(kBlock), sizeof(uint32_t) << uni_shift, c->stream, c->uni_tail.p, c->unistate.p,
+                                       uni_shift, c->cnt1.p, nclasses, c->state.p);
+                } else {
                     Prof p(c, COLIBRI_K_COUNT);
                     hipLaunchKernelGGL(uni_count_kernel, dim3(512), dim3(kBlock), 0, c->stream, c->cls.p, npos, c->cnt1.p, c->rep1.p, c->state.p);
                 }
                 {
                     Prof p(c, COLIBRI_K_PRUNE);
-                    hipLaunchKernelGGL(uni_finish_kernel, dim3(stream_grid(nclasses)), dim3(kBlock), 0, c->stream, c->cnt1.p, c->rep1.p, nclasses, pl.thr, c->state.p, c->res_rep.p,
-                                       c->res_cnt.p, pl.res_cap);
+                    hipLaunchKernelGGL(uni_finish_kernel, dim3(stream_grid(nclasses)), dim3(kBlock), 0, c->stream, c->cnt1.p, uni_shift ? (const uint32_t*)nullptr : c->rep1.p, nclasses,
+                                       pl.thr, c->state.p, c->res_rep.p, c->res_cnt.p, pl.res_cap);
                 }
                 {
                     Prof p(c, COLIBRI_K_RESOLVE);
@@ -901,7 +923,8 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             s.found[n]    = c->hstate.s_found[n];
             s.kept[n]     = c->hstate.s_kept[n];
             s.admitted[n] = c->hstate.s_admitted[n];
-            if (n <= s.maxn && s.kept[n]) c->segments.push_back({c->hstate.res_off[n], c->hstate.res_off[n + 1] - c->hstate.res_off[n], n, 0u});
+            if (n <= s.maxn && s.kept[n])
+                c->segments.push_back({c->hstate.res_off[n], c->hstate.res_off[n + 1] - c->hstate.res_off[n], n, (n == 1 && uni_shift) ? kMaskFromClass : 0u});
         }
     } else {
         // ---------- skipgram / indexed modes: one host round trip per pass (sizes, lazily grown per-order id arrays) ----------
@@ -1440,7 +1463,7 @@ int colibri_shard_apply(colibri_ctx* c, const void* reply_gid_dev, const void* r
             Prof           p(c, COLIBRI_K_PRUNE);
             hipLaunchKernelGGL(shard_apply_sparse_kernel, dim3(stream_grid(sh.ncand)), dim3(kBlock), 0, c->stream, sh.pslots.p, (const uint32_t*)reply_gid_dev,
                                (const uint32_t*)reply_cnt_dev, sh.ncand, io.sp_rep, sh.gid_of_sparse.p, c->state.p, c->res_rep.p, c->res_cnt.p, sh.res_gid.p, pl.res_cap, mark,
-                               1u << (n & 31));
+                               1u << (n & 31), sh.pass_list ? (const uint32_t*)c->alist[n & 1].p : (const uint32_t*)nullptr);
         }
         // ids[n][i] = global id of the survivor at the window's representative (sparse id -> gid), and the active list for order n+1
         if ((rc = binned_resolve_stage(c, pl, sh.out, n, sh.pass_list, true, sh.gid_of_sparse.p, 0u))) return rc;

@@ -482,6 +482,149 @@ __global__ __launch_bounds__(kBlock) void uni_count_kernel(const uint32_t* __res
         if (a) atomicAdd(&st->admitted, a);
     }
 }
+// ---- order 1 without per-token global atomics (plain single-device runs) -------------------------------------------------------------
+// Global atomics execute memory-side at a fixed ~27 G/s on MI355X whatever their locality (tools/atomics_scope_bench.hip), so the
+// third of a Zipf corpus that lies outside the LDS head costs uni_count_kernel 1.2 ms per 100 M tokens. Here the tail is instead
+// partitioned by class range (256 bins of 2^shift consecutive classes, shift <= 14 so that a bin's counters fit in LDS) as 2-byte
+// in-bin offsets, and every bin is then counted privately in LDS:
+//   uni_head_kernel       head histogram (classes < kUniHead) in LDS + tokens per tail bin           reads cls
+//   uni_offsets_kernel    exclusive scan of the bin sizes
+//   uni_partition_kernel  tile-local counting sort of the tail tokens -> one run per (tile, bin)      reads cls, writes 2 B per tail token
+//   uni_tail_count_kernel one LDS histogram per (bin, slice)                                         reads 2 B per tail token
+// No representative positions are recorded: the key bytes of a unigram of a canonical encoding are the varint of its class
+// (export_*_kernel with kMaskFromClass).
+constexpr int kUniBins     = 256;
+constexpr int kUniTile     = 16384;  // tokens per partition tile
+constexpr int kUniTilePer  = kUniTile / kBlock;
+constexpr int kUniSlices   = 8;      // blocks per tail bin (a bin is streamed by up to 8 blocks)
+constexpr uint32_t kUniSliceMin = 65536;  // ... but a slice is never smaller than this
+struct UniState {
+    uint32_t hist[kUniBins];     // tail tokens per bin
+    uint32_t off[kUniBins + 1];  // exclusive scan
+    uint32_t cur[kUniBins];      // partition cursors
+};
+__global__ __launch_bounds__(kBlock) void uni_head_kernel(const uint32_t* __restrict__ cls, uint32_t npos, uint32_t shift, uint32_t* __restrict__ cnt1, UniState* __restrict__ us,
+                                                           DevState* __restrict__ st) {
+    if (st->done) return;
+    __shared__ uint32_t histL[kUniHead], binL[kUniBins];
+    __shared__ uint32_t redL[kBlock / kWave];
+    for (int k = threadIdx.x; k < kUniHead; k += kBlock) histL[k] = 0;
+    binL[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t per   = (npos + gridDim.x - 1) / gridDim.x;
+    const uint32_t begin = blockIdx.x * per, end = min(npos, begin + per);
+    uint32_t       nadm  = 0;
+    for (uint32_t i0 = begin; i0 < end; i0 += kBlock * kUniPer) {
+#pragma unroll
+        for (int q = 0; q < kUniPer; ++q) {
+            const uint32_t i = i0 + q * kBlock + threadIdx.x;
+            if (i < end) {
+                const uint32_t c = cls[i];
+                if (c != 0) {
+                    ++nadm;
+                    if (c < (uint32_t)kUniHead)
+                        atomicAdd(&histL[c], 1u);
+                    else
+                        atomicAdd(&binL[c >> shift], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kUniHead; k += kBlock) {
+        const uint32_t h = histL[k];
+        if (h) atomicAdd(&cnt1[k], h);
+    }
+    if (binL[threadIdx.x]) atomicAdd(&us->hist[threadIdx.x], binL[threadIdx.x]);
+    for (int off = 32; off > 0; off >>= 1) nadm += __shfl_down(nadm, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nadm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t a = redL[0] + redL[1] + redL[2] + redL[3];
+        if (a) atomicAdd(&st->admitted, a);
+    }
+}
+__global__ __launch_bounds__(kBlock) void uni_offsets_kernel(UniState* __restrict__ us) {
+    uint32_t       tot;
+    const uint32_t o     = block_exclusive_scan(us->hist[threadIdx.x], &tot);
+    us->off[threadIdx.x] = o;
+    us->cur[threadIdx.x] = 0;
+    if (threadIdx.x == 0) us->off[kUniBins] = tot;
+}
+__global__ __launch_bounds__(kBlock) void uni_partition_kernel(const uint32_t* __restrict__ cls, uint32_t npos, uint32_t shift, UniState* __restrict__ us,
+                                                                uint16_t* __restrict__ tail, const DevState* __restrict__ st) {
+    if (st->done) return;
+    __shared__ uint16_t stageL[kUniTile];
+    __shared__ uint32_t cntL[kUniBins], offL[kUniBins + 1], curL[kUniBins], gbaseL[kUniBins];
+    const uint32_t lowmask = (1u << shift) - 1u;
+    const uint32_t ntiles  = (npos + kUniTile - 1) / kUniTile;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t base = tile * kUniTile;
+        uint32_t       c[kUniTilePer];
+        cntL[threadIdx.x] = 0;
+        curL[threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kUniTilePer; ++q) {
+            const uint32_t i = base + q * kBlock + threadIdx.x;
+            c[q]             = (i < npos) ? cls[i] : 0u;
+            if (c[q] >= (uint32_t)kUniHead) atomicAdd(&cntL[c[q] >> shift], 1u);
+        }
+        __syncthreads();
+        {
+            uint32_t       tot;
+            const uint32_t h  = cntL[threadIdx.x];
+            offL[threadIdx.x] = block_exclusive_scan(h, &tot);
+            if (threadIdx.x == 0) offL[kUniBins] = tot;
+            gbaseL[threadIdx.x] = h ? us->off[threadIdx.x] + atomicAdd(&us->cur[threadIdx.x], h) : 0u;  // one reservation per (tile, bin)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kUniTilePer; ++q) {
+            if (c[q] >= (uint32_t)kUniHead) {
+                const uint32_t b                               = c[q] >> shift;
+                stageL[offL[b] + atomicAdd(&curL[b], 1u)] = (uint16_t)(c[q] & lowmask);
+            }
+        }
+        __syncthreads();
+        const uint32_t total = offL[kUniBins];
+        for (uint32_t j = threadIdx.x; j < total; j += kBlock) {
+            uint32_t lo = 0, hi = kUniBins;  // last bin with offL[bin] <= j
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (offL[mid] <= j)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            tail[gbaseL[lo] + (j - offL[lo])] = stageL[j];
+        }
+        __syncthreads();
+    }
+}
+// block (bin, slice): LDS histogram of 2^shift classes (dynamic LDS: 4 << shift bytes)
+__global__ __launch_bounds__(kBlock) void uni_tail_count_kernel(const uint16_t* __restrict__ tail, const UniState* __restrict__ us, uint32_t shift, uint32_t* __restrict__ cnt1,
+                                                                 uint32_t nclasses, const DevState* __restrict__ st) {
+    if (st->done) return;
+    extern __shared__ uint32_t uniHistL[];
+    const uint32_t bin = blockIdx.x / kUniSlices, slice = blockIdx.x % kUniSlices;
+    const uint32_t b0 = us->off[bin], n = us->off[bin + 1] - b0;
+    if (n == 0) return;
+    uint32_t nsl = (n + kUniSliceMin - 1) / kUniSliceMin;
+    if (nsl > (uint32_t)kUniSlices) nsl = kUniSlices;
+    if (slice >= nsl) return;
+    const uint32_t per = (n + nsl - 1) / nsl, begin = b0 + slice * per, end = min(b0 + n, begin + per);
+    const uint32_t width = 1u << shift;
+    for (uint32_t k = threadIdx.x; k < width; k += kBlock) uniHistL[k] = 0;
+    __syncthreads();
+    for (uint32_t j = begin + threadIdx.x; j < end; j += kBlock) atomicAdd(&uniHistL[tail[j]], 1u);
+    __syncthreads();
+    const uint32_t cbase = bin << shift;
+    for (uint32_t k = threadIdx.x; k < width; k += kBlock) {
+        const uint32_t h = uniHistL[k];
+        if (h && cbase + k < nclasses) atomicAdd(&cnt1[cbase + k], h);
+    }
+}
 // classes -> result list (threshold), found / kept
 __global__ __launch_bounds__(kBlock) void uni_finish_kernel(const uint32_t* __restrict__ cnt1, const uint32_t* __restrict__ rep1, uint32_t nclasses, uint32_t threshold,
                                                              DevState* __restrict__ st, uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap) {
@@ -508,7 +651,7 @@ __global__ __launch_bounds__(kBlock) void uni_finish_kernel(const uint32_t* __re
         for (int q = 0; q < kPrunePer; ++q) {
             if (v[q] >= threshold) {
                 if (r < res_cap) {
-                    res_rep[r] = rep1[c0 + q];
+                    res_rep[r] = rep1 != nullptr ? rep1[c0 + q] : c0 + q;  // no representative recorded: the class itself (kMaskFromClass export)
                     res_cnt[r] = v[q];
                 } else {
                     st->overflow = 1;
@@ -670,13 +813,17 @@ __global__ void advance_kernel(DevState* __restrict__ st, int n, uint32_t table_
 // 5. export: survivors (representative position, order, count) -> key bytes
 //    replaces Pattern::write / BaseValueHandler::write over the map (pattern.cpp:268-277, datatypes.h:219-221)
 // =================================================================================================
+constexpr uint32_t kMaskFromClass = 0xFFFFFFFFu;  // segment of unigrams whose res_rep holds the CLASS: key bytes = its canonical varint (reference classencoder.cpp:22-42)
+__device__ __forceinline__ uint32_t varint_len(uint32_t c) { return c < (1u << 7) ? 1u : c < (1u << 14) ? 2u : c < (1u << 21) ? 3u : c < (1u << 28) ? 4u : 5u; }
 __global__ __launch_bounds__(kBlock) void export_len_kernel(const uint32_t* __restrict__ tokstart, const uint32_t* __restrict__ res_rep, uint32_t first, uint32_t count,
                                                              int n, uint32_t mask, uint32_t* __restrict__ keylen) {
     const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
     if (j < count) {
         const uint32_t p = res_rep[first + j];
         uint32_t       len = 0;
-        if (mask == 0) {
+        if (mask == kMaskFromClass) {
+            len = varint_len(p);
+        } else if (mask == 0) {
             len = tokstart[p + n] - tokstart[p];
         } else {  // a gapped token is the single byte 03 (reference src/pattern.cpp:886-908)
             for (int k = 0; k < n; ++k) len += ((mask >> k) & 1u) ? 1u : (tokstart[p + k + 1] - tokstart[p + k]);
@@ -754,7 +901,14 @@ __global__ __launch_bounds__(kBlock) void export_bytes_kernel(const uint8_t* __r
     if (j < count) {
         const uint32_t p = res_rep[first + j];
         uint8_t*       dst = out + keyoff[first + j];
-        if (mask == 0) {
+        if (mask == kMaskFromClass) {  // little-endian base 128, bit 7 set on every byte but the last
+            uint32_t c = p, o = 0;
+            while (c >= 128u) {
+                dst[o++] = (uint8_t)((c & 127u) | 128u);
+                c >>= 7;
+            }
+            dst[o] = (uint8_t)c;
+        } else if (mask == 0) {
             const uint8_t* src = bytes + tokstart[p];
             const uint32_t len = keylen[first + j];
             for (uint32_t b = 0; b < len; ++b) dst[b] = src[b];
@@ -1167,7 +1321,7 @@ __global__ __launch_bounds__(kBlock) void shard_apply_sparse_kernel(const uint32
                                                                      const uint32_t* __restrict__ reply_cnt, uint32_t n, const uint32_t* __restrict__ sp_rep,
                                                                      uint32_t* __restrict__ gid_of_sparse, DevState* __restrict__ st, uint32_t* __restrict__ res_rep,
                                                                      uint32_t* __restrict__ res_cnt, uint32_t* __restrict__ res_gid, uint32_t res_cap, uint32_t* __restrict__ mark,
-                                                                     uint32_t markbit) {
+                                                                     uint32_t markbit, const uint32_t* __restrict__ list /* item index -> corpus position, or NULL */) {
     __shared__ uint32_t baseL;
     const uint32_t      res_base = st->res_total;
     const uint32_t      ntiles   = (n + kEmitTile - 1) / kEmitTile;
@@ -1190,7 +1344,7 @@ __global__ __launch_bounds__(kBlock) void shard_apply_sparse_kernel(const uint32
                 const uint32_t h = handles[j0 + k];
                 if (g[k] != kInvalid && (g[k] & kExportBit)) {
                     if (r < res_cap) {
-                        const uint32_t rp = sp_rep[h];
+                        const uint32_t rp = list != nullptr ? list[sp_rep[h]] : sp_rep[h];
                         res_rep[r]        = rp;
                         res_cnt[r]        = reply_cnt[j0 + k];
                         res_gid[r]        = g[k] & ~kExportBit;
@@ -1240,7 +1394,7 @@ __global__ __launch_bounds__(kBlock) void shard_uni_finish_kernel(const uint32_t
         for (int q = 0; q < kPrunePer; ++q) {
             if (mine[q]) {
                 if (r < res_cap) {
-                    res_rep[r] = rep1[c0 + q];
+                    res_rep[r] = rep1 != nullptr ? rep1[c0 + q] : c0 + q;  // no representative recorded: the class itself (kMaskFromClass export)
                     res_cnt[r] = v[q];
                     res_gid[r] = c0 + q;  // the global id of a unigram is its class id
                     if (mark != nullptr) atomicOr(&mark[rep1[c0 + q]], 2u);  // bit 1 = order 1

@@ -88,14 +88,24 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
         uint32_t       posn[kCountPer];
         bool           adm[kCountPer];
         histL[threadIdx.x] = 0;
+        // three separate sweeps — list entries, then the key functor's loads, then the LDS writes — so that every global load of
+        // the tile is in flight before the first LDS access (the compiler does not move a load across an LDS operation)
 #pragma unroll
         for (int k = 0; k < kCountPer; ++k) {
-            const uint32_t e = k * kBlock + threadIdx.x, j = base + e;
-            key[k]  = 0;
-            hash[k] = 0;
-            posn[k] = LIST ? (j < nitems ? list[j] : 0u) : j;
-            adm[k]  = (j < nitems) && keyfn(posn[k], npos, key[k], hash[k]);
-            cntL[e] = 0;
+            const uint32_t j = base + k * kBlock + threadIdx.x;
+            posn[k]          = LIST ? (j < nitems ? list[j] : 0u) : j;
+        }
+#pragma unroll
+        for (int k = 0; k < kCountPer; ++k) {
+            const uint32_t j = base + k * kBlock + threadIdx.x;
+            key[k]           = 0;
+            hash[k]          = 0;
+            adm[k]           = (j < nitems) && keyfn(posn[k], npos, key[k], hash[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < kCountPer; ++k) {
+            const uint32_t e = k * kBlock + threadIdx.x;
+            cntL[e]          = 0;
             if (adm[k]) {
                 keyL[e]                                     = key[k];
                 winL[(uint32_t)hash[k] & (kCountLSlot - 1)] = e;
@@ -221,7 +231,19 @@ __global__ __launch_bounds__(kBlock) void bin_hist2_kernel(const Rec* __restrict
     histL[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t bsh = bs->bshift;
-    for (uint32_t j = begin + threadIdx.x; j < end; j += kBlock) atomicAdd(&histL[((recs[j].meta >> 16) & 255u) >> bsh], 1u);
+    // a tile is at most kScatTile records: all of a lane's loads are issued before its first LDS atomic (the compiler keeps the
+    // program order of a global load and a following LDS atomic, which would serialise them one by one)
+    uint32_t m[kScatPer];
+#pragma unroll
+    for (int q = 0; q < kScatPer; ++q) {
+        const uint32_t j = begin + q * kBlock + threadIdx.x;
+        m[q]             = (j < end) ? recs[j].meta : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < kScatPer; ++q) {
+        const uint32_t j = begin + q * kBlock + threadIdx.x;
+        if (j < end) atomicAdd(&histL[((m[q] >> 16) & 255u) >> bsh], 1u);
+    }
     __syncthreads();
     if (histL[threadIdx.x]) atomicAdd(&bs->hist2[a * kBins + threadIdx.x], histL[threadIdx.x]);
 }
@@ -250,10 +272,14 @@ __global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restri
     Rec      r[kScatPer];
     uint32_t rank[kScatPer];
 #pragma unroll
+    for (int q = 0; q < kScatPer; ++q) {  // loads first, LDS atomics after (see bin_hist2_kernel)
+        const uint32_t j = begin + q * kBlock + threadIdx.x;
+        if (j < end) r[q] = in[j];
+    }
+#pragma unroll
     for (int q = 0; q < kScatPer; ++q) {
         const uint32_t j = begin + q * kBlock + threadIdx.x;
         if (j < end) {
-            r[q]             = in[j];
             const uint32_t b = ((r[q].meta >> 16) & 255u) >> bsh;
             rank[q]          = atomicAdd(&histL[b], 1u);
         }
@@ -541,16 +567,24 @@ __global__ __launch_bounds__(kBlock) void bin_resolve_kernel(const uint32_t* __r
     uint32_t            nvalid = 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint32_t id[kResPer], pos[kResPer], c = 0;
+        uint32_t rp[kResPer];
+#pragma unroll
+        for (int q = 0; q < kResPer; ++q) {  // loads, then the dependent gathers, then the stores: kResPer independent chains per lane
+            const uint32_t j = tile * kResTile + q * kBlock + threadIdx.x;
+            rp[q]            = (j < nitems) ? rep_of[j] : kInvalid;
+            pos[q]           = (j < nitems) ? (LIST ? list_in[j] : j) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < kResPer; ++q) id[q] = (rp[q] != kInvalid) ? ids_at[rp[q]] : kInvalid;
+        if (remap != nullptr) {
+#pragma unroll
+            for (int q = 0; q < kResPer; ++q)
+                if (id[q] != kInvalid) id[q] = remap[id[q] - remap_base];  // sharded: local sparse id -> global survivor id
+        }
 #pragma unroll
         for (int q = 0; q < kResPer; ++q) {
             const uint32_t j = tile * kResTile + q * kBlock + threadIdx.x;
-            id[q]            = kInvalid;
-            pos[q]           = 0;
             if (j < nitems) {
-                const uint32_t r = rep_of[j];
-                pos[q]           = LIST ? list_in[j] : j;
-                if (r != kInvalid) id[q] = ids_at[r];
-                if (remap != nullptr && id[q] != kInvalid) id[q] = remap[id[q] - remap_base];  // sharded: local sparse id -> global survivor id
                 // LIST: every listed position is written, valid or not. The next order reads ids at i and i+1 only for i on the NEW
                 // list, and a surviving n-gram at i means the (n-1)-gram at i+1 survived, i.e. i+1 is on THIS list: no fill needed
                 // for that reader (callers that read ids at arbitrary positions pre-fill it with kInvalid).

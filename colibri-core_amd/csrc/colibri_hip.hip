@@ -55,6 +55,7 @@ struct colibri_ctx {
     DevBuf<uint32_t>  cnt1, rep1;       // order-1 fast path: count / representative position per class
     DevBuf<UniState>  unistate;         // ... its atomic-free variant: tail-bin sizes / offsets / cursors
     DevBuf<uint16_t>  uni_tail;         // ... and the tail tokens as 2-byte offsets inside their class-range bin
+    DevBuf<uint32_t>  uni_rows, uni_surv; // ... per-block head histograms (rows), survivor bitmap of the classes
     std::vector<uint64_t> lenhist;  // sentence-length histogram (host copy)
     uint64_t              windows_n[COLIBRI_MAX_ORDER] = {0};  // W_n = n-token windows inside sentences, from the histogram (once per upload)
 
@@ -378,6 +379,8 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->rep1);
     dev_free(c->unistate);
     dev_free(c->uni_tail);
+    dev_free(c->uni_rows);
+    dev_free(c->uni_surv);
     for (auto& b : c->ids) dev_free(b);
     dev_free(c->scratch[0]);
     dev_free(c->scratch[1]);
@@ -800,7 +803,9 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
         while (uni_shift <= 14 && ((uint64_t)c->maxclass >> uni_shift) >= (uint64_t)kUniBins) ++uni_shift;
         if (uni_shift > 14) uni_shift = 0;  // more than 4 M classes: keep the atomics kernel
     }
-    if (uni_shift && ((rc = dev_alloc(c, c->unistate, 1)) || (rc = dev_alloc(c, c->uni_tail, (size_t)c->npos + 1)))) return rc;
+    constexpr uint32_t kUniHeadGrid = 512;
+    if (uni_shift && ((rc = dev_alloc(c, c->unistate, 1)) || (rc = dev_alloc(c, c->uni_tail, (size_t)c->npos + 8)) || (rc = dev_alloc(c, c->uni_rows, (size_t)kUniHeadGrid * kUniHead)) ||
+                      (rc = dev_alloc(c, c->uni_surv, (size_t)c->maxclass / 32 + 4)))) return rc;
     // ---- HBM layout (sized once; nothing is allocated inside the unsynced order loop) ----------------
     // table: an order admits at most `npos` windows -> 1.5x slots; results: every survivor has >= 2 occurrences
     const uint64_t table_slots64 = (uint64_t)npos + (npos >> 1) + 2048;
@@ -865,7 +870,8 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                     // no per-token global atomics: head histogram in LDS, tail partitioned into 256 class ranges and counted per range in LDS
                     HIP_TRY(c, hipMemsetAsync(c->unistate.p, 0, sizeof(UniState), c->stream));
                     Prof p(c, COLIBRI_K_COUNT);
-                    hipLaunchKernelGGL(uni_head_kernel, dim3(512), dim3(kBlock), 0, c->stream, c->cls.p, npos, uni_shift, c->cnt1.p, c->unistate.p, c->state.p);
+                    hipLaunchKernelGGL(uni_head_kernel, dim3(kUniHeadGrid), dim3(kBlock), 0, c->stream, c->cls.p, npos, uni_shift, c->uni_rows.p, c->unistate.p, c->state.p);
+                    hipLaunchKernelGGL(uni_head_reduce_kernel, dim3(kUniHead / kBlock, 16), dim3(kBlock), 0, c->stream, c->uni_rows.p, kUniHeadGrid, c->cnt1.p, nclasses, c->state.p);
                     hipLaunchKernelGGL(uni_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->unistate.p);
                     hipLaunchKernelGGL(uni_partition_kernel, dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, c->cls.p, npos, uni_shift, c->unistate.p, c->uni_tail.p, c->state.p);
                     hipLaunchKernelGGL(uni_tail_count_kernel, dim3(kUniBins * kUniSlices), dim3(kBlock), sizeof(uint32_t) << uni_shift, c->stream, c->uni_tail.p, c->unistate.p,
@@ -877,11 +883,14 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                 {
                     Prof p(c, COLIBRI_K_PRUNE);
                     hipLaunchKernelGGL(uni_finish_kernel, dim3(stream_grid(nclasses)), dim3(kBlock), 0, c->stream, c->cnt1.p, uni_shift ? (const uint32_t*)nullptr : c->rep1.p, nclasses,
-                                       pl.thr, c->state.p, c->res_rep.p, c->res_cnt.p, pl.res_cap);
+                                       pl.thr, c->state.p, c->res_rep.p, c->res_cnt.p, pl.res_cap, uni_shift ? reinterpret_cast<uint16_t*>(c->uni_surv.p) : (uint16_t*)nullptr);
                 }
                 {
                     Prof p(c, COLIBRI_K_RESOLVE);
-                    hipLaunchKernelGGL(uni_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->cnt1.p, pl.thr, id_cur, c->state.p, npos);
+                    if (uni_shift)
+                        hipLaunchKernelGGL(uni_ids_bitmap_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_surv.p, (nclasses + 31) / 32, id_cur, c->state.p, npos);
+                    else
+                        hipLaunchKernelGGL(uni_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->cnt1.p, pl.thr, id_cur, c->state.p, npos);
                 }
             } else if (binned) {
                 // orders 1-2 scan every position (almost all are admissible); from order 3 on only the positions that still

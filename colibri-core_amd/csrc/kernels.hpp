@@ -503,8 +503,8 @@ struct UniState {
     uint32_t off[kUniBins + 1];  // exclusive scan
     uint32_t cur[kUniBins];      // partition cursors
 };
-__global__ __launch_bounds__(kBlock) void uni_head_kernel(const uint32_t* __restrict__ cls, uint32_t npos, uint32_t shift, uint32_t* __restrict__ cnt1, UniState* __restrict__ us,
-                                                           DevState* __restrict__ st) {
+__global__ __launch_bounds__(kBlock) void uni_head_kernel(const uint32_t* __restrict__ cls, uint32_t npos, uint32_t shift, uint32_t* __restrict__ head_rows /*[gridDim.x][kUniHead]*/,
+                                                           UniState* __restrict__ us, DevState* __restrict__ st) {
     if (st->done) return;
     __shared__ uint32_t histL[kUniHead], binL[kUniBins];
     __shared__ uint32_t redL[kBlock / kWave];
@@ -515,26 +515,26 @@ __global__ __launch_bounds__(kBlock) void uni_head_kernel(const uint32_t* __rest
     const uint32_t begin = blockIdx.x * per, end = min(npos, begin + per);
     uint32_t       nadm  = 0;
     for (uint32_t i0 = begin; i0 < end; i0 += kBlock * kUniPer) {
+        uint32_t c[kUniPer];  // all loads of the batch are issued before the first LDS atomic (the compiler will not hoist them itself)
 #pragma unroll
         for (int q = 0; q < kUniPer; ++q) {
             const uint32_t i = i0 + q * kBlock + threadIdx.x;
-            if (i < end) {
-                const uint32_t c = cls[i];
-                if (c != 0) {
-                    ++nadm;
-                    if (c < (uint32_t)kUniHead)
-                        atomicAdd(&histL[c], 1u);
-                    else
-                        atomicAdd(&binL[c >> shift], 1u);
-                }
+            c[q]             = (i < end) ? cls[i] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < kUniPer; ++q) {
+            if (c[q] != 0) {
+                ++nadm;
+                if (c[q] < (uint32_t)kUniHead)
+                    atomicAdd(&histL[c[q]], 1u);
+                else
+                    atomicAdd(&binL[c[q] >> shift], 1u);
             }
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < kUniHead; k += kBlock) {
-        const uint32_t h = histL[k];
-        if (h) atomicAdd(&cnt1[k], h);
-    }
+    // the block's head histogram leaves as one plain row (512 blocks x 8192 flush atomics would cost 0.16 ms at the memory-side atomic rate)
+    for (int k = threadIdx.x; k < kUniHead; k += kBlock) head_rows[(size_t)blockIdx.x * kUniHead + k] = histL[k];
     if (binL[threadIdx.x]) atomicAdd(&us->hist[threadIdx.x], binL[threadIdx.x]);
     for (int off = 32; off > 0; off >>= 1) nadm += __shfl_down(nadm, off, kWave);
     if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nadm;
@@ -543,6 +543,15 @@ __global__ __launch_bounds__(kBlock) void uni_head_kernel(const uint32_t* __rest
         const uint32_t a = redL[0] + redL[1] + redL[2] + redL[3];
         if (a) atomicAdd(&st->admitted, a);
     }
+}
+// column sums of the head rows -> cnt1[0 .. kUniHead): block (x, y) adds rows y, y + gridDim.y, ... of classes [x * 256, x * 256 + 256)
+__global__ __launch_bounds__(kBlock) void uni_head_reduce_kernel(const uint32_t* __restrict__ head_rows, uint32_t nrows, uint32_t* __restrict__ cnt1, uint32_t nclasses,
+                                                                  const DevState* __restrict__ st) {
+    if (st->done) return;
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t       s = 0;
+    for (uint32_t r = blockIdx.y; r < nrows; r += gridDim.y) s += head_rows[(size_t)r * kUniHead + k];
+    if (s && k < nclasses) atomicAdd(&cnt1[k], s);
 }
 __global__ __launch_bounds__(kBlock) void uni_offsets_kernel(UniState* __restrict__ us) {
     uint32_t       tot;
@@ -555,6 +564,7 @@ __global__ __launch_bounds__(kBlock) void uni_partition_kernel(const uint32_t* _
                                                                 uint16_t* __restrict__ tail, const DevState* __restrict__ st) {
     if (st->done) return;
     __shared__ uint16_t stageL[kUniTile];
+    __shared__ uint8_t  sbinL[kUniTile];
     __shared__ uint32_t cntL[kUniBins], offL[kUniBins + 1], curL[kUniBins], gbaseL[kUniBins];
     const uint32_t lowmask = (1u << shift) - 1u;
     const uint32_t ntiles  = (npos + kUniTile - 1) / kUniTile;
@@ -568,8 +578,10 @@ __global__ __launch_bounds__(kBlock) void uni_partition_kernel(const uint32_t* _
         for (int q = 0; q < kUniTilePer; ++q) {
             const uint32_t i = base + q * kBlock + threadIdx.x;
             c[q]             = (i < npos) ? cls[i] : 0u;
-            if (c[q] >= (uint32_t)kUniHead) atomicAdd(&cntL[c[q] >> shift], 1u);
         }
+#pragma unroll
+        for (int q = 0; q < kUniTilePer; ++q)
+            if (c[q] >= (uint32_t)kUniHead) atomicAdd(&cntL[c[q] >> shift], 1u);
         __syncthreads();
         {
             uint32_t       tot;
@@ -582,22 +594,16 @@ __global__ __launch_bounds__(kBlock) void uni_partition_kernel(const uint32_t* _
 #pragma unroll
         for (int q = 0; q < kUniTilePer; ++q) {
             if (c[q] >= (uint32_t)kUniHead) {
-                const uint32_t b                               = c[q] >> shift;
-                stageL[offL[b] + atomicAdd(&curL[b], 1u)] = (uint16_t)(c[q] & lowmask);
+                const uint32_t b = c[q] >> shift, slot = offL[b] + atomicAdd(&curL[b], 1u);
+                stageL[slot]     = (uint16_t)(c[q] & lowmask);
+                sbinL[slot]      = (uint8_t)b;
             }
         }
         __syncthreads();
         const uint32_t total = offL[kUniBins];
         for (uint32_t j = threadIdx.x; j < total; j += kBlock) {
-            uint32_t lo = 0, hi = kUniBins;  // last bin with offL[bin] <= j
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (offL[mid] <= j)
-                    lo = mid;
-                else
-                    hi = mid;
-            }
-            tail[gbaseL[lo] + (j - offL[lo])] = stageL[j];
+            const uint32_t b               = sbinL[j];
+            tail[gbaseL[b] + (j - offL[b])] = stageL[j];
         }
         __syncthreads();
     }
@@ -617,7 +623,23 @@ __global__ __launch_bounds__(kBlock) void uni_tail_count_kernel(const uint16_t* 
     const uint32_t width = 1u << shift;
     for (uint32_t k = threadIdx.x; k < width; k += kBlock) uniHistL[k] = 0;
     __syncthreads();
-    for (uint32_t j = begin + threadIdx.x; j < end; j += kBlock) atomicAdd(&uniHistL[tail[j]], 1u);
+    // 8 tokens (16 bytes) per load: the body of the slice is read as uint4, the unaligned ends token by token
+    const uint32_t vbegin = min(end, (begin + 7u) & ~7u), vend = max(vbegin, end & ~7u);
+    if (threadIdx.x < vbegin - begin) atomicAdd(&uniHistL[tail[begin + threadIdx.x]], 1u);
+    if (threadIdx.x < end - vend) atomicAdd(&uniHistL[tail[vend + threadIdx.x]], 1u);
+    const uint4* const v = reinterpret_cast<const uint4*>(tail + vbegin);
+    const uint32_t     nv = (vend - vbegin) >> 3;
+    for (uint32_t j = threadIdx.x; j < nv; j += kBlock) {
+        const uint4 x = v[j];
+        atomicAdd(&uniHistL[x.x & 0xFFFFu], 1u);
+        atomicAdd(&uniHistL[x.x >> 16], 1u);
+        atomicAdd(&uniHistL[x.y & 0xFFFFu], 1u);
+        atomicAdd(&uniHistL[x.y >> 16], 1u);
+        atomicAdd(&uniHistL[x.z & 0xFFFFu], 1u);
+        atomicAdd(&uniHistL[x.z >> 16], 1u);
+        atomicAdd(&uniHistL[x.w & 0xFFFFu], 1u);
+        atomicAdd(&uniHistL[x.w >> 16], 1u);
+    }
     __syncthreads();
     const uint32_t cbase = bin << shift;
     for (uint32_t k = threadIdx.x; k < width; k += kBlock) {
@@ -627,7 +649,8 @@ __global__ __launch_bounds__(kBlock) void uni_tail_count_kernel(const uint16_t* 
 }
 // classes -> result list (threshold), found / kept
 __global__ __launch_bounds__(kBlock) void uni_finish_kernel(const uint32_t* __restrict__ cnt1, const uint32_t* __restrict__ rep1, uint32_t nclasses, uint32_t threshold,
-                                                             DevState* __restrict__ st, uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap) {
+                                                             DevState* __restrict__ st, uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap,
+                                                             uint16_t* __restrict__ surv16 = nullptr /* optional: bit c = class c survives (16 classes per lane = one half word) */) {
     if (st->done) return;
     __shared__ uint32_t baseL, redL[kBlock / kWave];
     const uint32_t      res_base = st->res_total;
@@ -641,6 +664,13 @@ __global__ __launch_bounds__(kBlock) void uni_finish_kernel(const uint32_t* __re
             v[q] = (c0 + q < nclasses) ? cnt1[c0 + q] : 0u;
             nfound += v[q] != 0;
             k += v[q] >= threshold;
+        }
+        if (surv16 != nullptr && c0 < nclasses) {
+            static_assert(kPrunePer == 16, "one 16-bit store per lane");
+            uint32_t bits = 0;
+#pragma unroll
+            for (int q = 0; q < kPrunePer; ++q) bits |= (uint32_t)(v[q] >= threshold) << q;
+            surv16[c0 >> 4] = (uint16_t)bits;
         }
         uint32_t       total;
         const uint32_t excl = block_exclusive_scan(k, &total);
@@ -674,11 +704,68 @@ __global__ __launch_bounds__(kBlock) void uni_ids_kernel(const uint32_t* __restr
                                                           DevState* __restrict__ st, uint32_t npos) {
     if (st->done) return;
     uint32_t nvalid = 0;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npos; i += gridDim.x * kBlock) {
-        const uint32_t c  = cls[i];
-        const uint32_t id = (c != 0 && cnt1[c] >= threshold) ? c : kInvalid;
-        nvalid += id != kInvalid;
-        ids[i] = id;
+    constexpr int kPer = 8;  // loads, then gathers, then stores: eight independent chains per lane
+    for (uint32_t i0 = blockIdx.x * (kBlock * kPer); i0 < npos; i0 += gridDim.x * (kBlock * kPer)) {
+        uint32_t c[kPer], n1[kPer];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const uint32_t i = i0 + q * kBlock + threadIdx.x;
+            c[q]             = (i < npos) ? cls[i] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) n1[q] = c[q] ? cnt1[c[q]] : 0u;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const uint32_t i = i0 + q * kBlock + threadIdx.x;
+            if (i < npos) {
+                const uint32_t id = n1[q] >= threshold ? c[q] : kInvalid;
+                nvalid += id != kInvalid;
+                ids[i] = id;
+            }
+        }
+    }
+    __shared__ uint32_t redL[kBlock / kWave];
+    for (int off = 32; off > 0; off >>= 1) nvalid += __shfl_down(nvalid, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nvalid;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t v = redL[0] + redL[1] + redL[2] + redL[3];
+        if (v) atomicAdd(&st->valid, v);
+    }
+}
+
+// the same from the survivor bitmap uni_finish_kernel left behind: the first 262 144 classes (> 90 % of a Zipf corpus' tokens) are
+// answered from a 32 KB LDS copy, the rest by a gather into a bitmap 32x smaller than the count array
+constexpr uint32_t kSurvLdsWords = 8192;
+__global__ __launch_bounds__(kBlock) void uni_ids_bitmap_kernel(const uint32_t* __restrict__ cls, const uint32_t* __restrict__ surv, uint32_t nwords, uint32_t* __restrict__ ids,
+                                                                 DevState* __restrict__ st, uint32_t npos) {
+    if (st->done) return;
+    __shared__ uint32_t survL[kSurvLdsWords];
+    for (uint32_t w = threadIdx.x; w < kSurvLdsWords; w += kBlock) survL[w] = w < nwords ? surv[w] : 0u;
+    __syncthreads();
+    uint32_t      nvalid = 0;
+    constexpr int kPer   = 8;
+    for (uint32_t i0 = blockIdx.x * (kBlock * kPer); i0 < npos; i0 += gridDim.x * (kBlock * kPer)) {
+        uint32_t c[kPer], w[kPer];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const uint32_t i = i0 + q * kBlock + threadIdx.x;
+            c[q]             = (i < npos) ? cls[i] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const uint32_t word = c[q] >> 5;
+            w[q]                = word < kSurvLdsWords ? survL[word] : surv[word];
+        }
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const uint32_t i = i0 + q * kBlock + threadIdx.x;
+            if (i < npos) {
+                const uint32_t id = (c[q] != 0 && ((w[q] >> (c[q] & 31u)) & 1u)) ? c[q] : kInvalid;
+                nvalid += id != kInvalid;
+                ids[i] = id;
+            }
+        }
     }
     __shared__ uint32_t redL[kBlock / kWave];
     for (int off = 32; off > 0; off >>= 1) nvalid += __shfl_down(nvalid, off, kWave);

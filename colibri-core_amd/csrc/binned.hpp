@@ -28,6 +28,8 @@ struct __attribute__((aligned(16))) Rec {
 
 constexpr int      kBins       = 256;                // per level
 constexpr int      kFinalBins  = kBins * kBins;      // 65 536
+constexpr int      kSub        = 8;                  // level A: every A bin is fed through 8 sub-regions, one per group of emit blocks (see bin_emit_kernel)
+constexpr int      kASlots     = kBins * kSub;       // 2048 (A bin, sub-region) slots
 #ifndef COLIBRI_SCAT_TILE
 #define COLIBRI_SCAT_TILE 4096
 #endif
@@ -42,10 +44,11 @@ struct BinState {
     uint32_t overflow_bin;       // a final bin exceeded its LDS table -> host falls back to the global-table path
     uint32_t bshift;             // level B uses 256 >> bshift sub-bins: small orders get fewer, fuller final bins
     uint32_t kept_total;         // survivors of this order (written by bin_kept_scan_kernel)
-    uint32_t histA[kBins];       // records per A bin
-    uint32_t offA[kBins + 1];    // exclusive scan
-    uint32_t tprefA[kBins + 1];  // tiles per A bin, exclusive scan (for the level-B kernels)
-    uint32_t curA[kBins];        // scatter cursors
+    uint32_t histA[kASlots];       // records per A slot (slot = sub-region * kBins + A bin: the kSub cursors of a bin lie 1 KB apart, not in one cache line)
+    uint32_t offA[kASlots + 1];    // first record of the slot's region
+    uint32_t tprefA[kASlots + 1];  // level-B tiles per slot, exclusive scan
+    uint32_t curA[kASlots];        // emit cursors
+    uint32_t histAt[kBins];        // records per A bin (all its sub-regions)
     uint32_t hist2[kFinalBins];  // records per final bin, then (after the scan) their offsets
     uint32_t total2;             // sum (written by the scan)
     uint32_t cur2[kFinalBins];   // level-B scatter cursors; afterwards bin_count leaves each bin's survivor count here, and the scan turns them into dense offsets
@@ -63,7 +66,8 @@ struct BinState {
 // compact_bins / the shard kernels translate representatives back to corpus positions through the list.
 // The level-A partition is fused in: the tile's records are counting-sorted by A bin inside LDS (the election arrays are dead by
 // then and are reused as the staging buffer) and leave as one contiguous run per (tile, bin) into that bin's fixed-capacity
-// region [a * region, (a+1) * region) of `recs`. A region that would overflow raises st->radix_overflow (global-table rerun).
+// sub-region [slot * region, (slot+1) * region) of `recs`, slot = (block group) * kBins + A bin. A sub-region that would overflow raises
+// st->radix_overflow (global-table rerun).
 // ids_at (optional) is reset at every record position, which spares a fill of the whole array per order.
 template <class KeyFn, bool LIST>
 __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __restrict__ recs, uint32_t region, uint32_t* __restrict__ rep_of, DevState* __restrict__ st,
@@ -142,9 +146,13 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
             offL[threadIdx.x] = block_exclusive_scan(h, &tot);
             uint32_t g        = 0;
             if (h) {
-                const uint32_t at = atomicAdd(&bs->curA[threadIdx.x], h);  // one reservation per (tile, bin)
-                if (at + h > region) st->radix_overflow = 1;                        // region full: the host re-runs on the global table
-                g = threadIdx.x * region + min(at, region - min(region, h));
+                // one reservation per (tile, bin). An atomic on ONE address completes every ~12 ns on MI355X whatever the load, and
+                // every tile of the corpus reserves in all 256 bins: with a single cursor per bin that is 0.6 ms of serialised
+                // atomics per 100 M windows. Blocks are therefore split into kSub groups, each with its own cursor and sub-region.
+                const uint32_t slot = (blockIdx.x & (uint32_t)(kSub - 1)) * kBins + threadIdx.x;
+                const uint32_t at   = atomicAdd(&bs->curA[slot], h);
+                if (at + h > region) st->radix_overflow = 1;  // sub-region full: the host re-runs on the global table
+                g = slot * region + min(at, region - min(region, h));
             }
             gbaseL[threadIdx.x] = g;
         }
@@ -181,21 +189,30 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
     }
 }
 
-// one block: A-bin record counts (left in curA by the fused emit), region bases, and the tile prefix of the level-B kernels
+// one block: slot record counts (left in curA by the fused emit), region bases, per-A-bin totals and the tile prefix of the level-B kernels
 __global__ __launch_bounds__(kBlock) void bin_offsets_kernel(BinState* __restrict__ bs, uint32_t region) {
-    uint32_t       tot;
-    const uint32_t h = min(bs->curA[threadIdx.x], region);
-    block_exclusive_scan(h, &tot);
-    bs->histA[threadIdx.x] = h;
-    bs->offA[threadIdx.x]  = threadIdx.x * region;
-    const uint32_t t  = (h + kScatTile - 1) / kScatTile;
-    uint32_t       tt;
-    const uint32_t tp = block_exclusive_scan(t, &tt);
-    bs->tprefA[threadIdx.x] = tp;
+    // lane a owns the kSub slots of A bin a; slots are numbered sub-region-major, so the tile prefix is built one sub-region at a time
+    uint32_t hsum = 0, tbase = 0;
+    for (int g = 0; g < kSub; ++g) {
+        const uint32_t s = g * kBins + threadIdx.x;
+        const uint32_t h = min(bs->curA[s], region);
+        const uint32_t t = (h + kScatTile - 1) / kScatTile;
+        uint32_t       tt;
+        const uint32_t tp = block_exclusive_scan(t, &tt);
+        bs->histA[s]      = h;
+        bs->offA[s]       = s * region;
+        bs->tprefA[s]     = tbase + tp;
+        tbase += tt;
+        hsum += h;
+    }
+    uint32_t tot;
+    block_exclusive_scan(hsum, &tot);
+    bs->histAt[threadIdx.x] = hsum;
+    const uint32_t tt       = tbase;
     if (threadIdx.x == 0) {
-        bs->nrec          = tot;
-        bs->offA[kBins]   = kBins * region;
-        bs->tprefA[kBins] = tt;
+        bs->nrec            = tot;
+        bs->offA[kASlots]   = kASlots * region;
+        bs->tprefA[kASlots] = tt;
         // aim at <= ~1024 records per final bin: nB = smallest power of two >= nrec / (256 * 1024), at most 256
         uint32_t nb = 1;
         while (nb < (uint32_t)kBins && (uint64_t)nb * kBins * 1024u < tot) nb <<= 1;
@@ -205,10 +222,10 @@ __global__ __launch_bounds__(kBlock) void bin_offsets_kernel(BinState* __restric
     }
 }
 
-// which A bin / which tile of it does block `t` own?
+// which A bin / which tile of which of its sub-regions does block `t` own?
 __device__ __forceinline__ bool locate_tile(const BinState* bs, uint32_t t, uint32_t& a, uint32_t& begin, uint32_t& end) {
-    if (t >= bs->tprefA[kBins]) return false;
-    uint32_t lo = 0, hi = kBins;  // last a with tprefA[a] <= t
+    if (t >= bs->tprefA[kASlots]) return false;
+    uint32_t lo = 0, hi = kASlots;  // last slot with tprefA[slot] <= t
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         if (bs->tprefA[mid] <= t)
@@ -216,9 +233,9 @@ __device__ __forceinline__ bool locate_tile(const BinState* bs, uint32_t t, uint
         else
             hi = mid;
     }
-    a     = lo;
-    begin = bs->offA[a] + (t - bs->tprefA[a]) * kScatTile;
-    end   = min(bs->offA[a] + bs->histA[a], begin + (uint32_t)kScatTile);
+    a     = lo & (uint32_t)(kBins - 1);
+    begin = bs->offA[lo] + (t - bs->tprefA[lo]) * kScatTile;
+    end   = min(bs->offA[lo] + bs->histA[lo], begin + (uint32_t)kScatTile);
     return true;
 }
 
@@ -252,7 +269,7 @@ __global__ __launch_bounds__(kBlock) void bin_hist2_kernel(const Rec* __restrict
 __global__ __launch_bounds__(kBlock) void bin_scan2_kernel(BinState* __restrict__ bs) {
     const uint32_t a = blockIdx.x;
     uint32_t       before, tot;
-    block_exclusive_scan(threadIdx.x < a ? bs->histA[threadIdx.x] : 0u, &before);  // records in the A bins before this one
+    block_exclusive_scan(threadIdx.x < a ? bs->histAt[threadIdx.x] : 0u, &before);  // records in the A bins before this one
     const uint32_t h = bs->hist2[a * kBins + threadIdx.x];
     const uint32_t o = block_exclusive_scan(h, &tot);
     bs->hist2[a * kBins + threadIdx.x] = before + o;

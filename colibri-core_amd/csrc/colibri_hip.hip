@@ -549,13 +549,13 @@ BinnedIO binned_planes(colibri_ctx* c, const TrainPlan& pl, bool with_keys) {
 
 template <class KeyFn>
 int binned_count_stage(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, int n, bool use_list, uint32_t thr, bool with_keys, bool need_ids = true) {
-    const uint32_t  tiles    = blocks_for(pl.npos, kScatTile) + 1;
+    const uint32_t  tiles    = blocks_for(pl.npos, kScatTile) + 1 + kASlots;  // level-B tiles: every slot may end in a partial one
     const uint32_t* list_in  = c->alist[n & 1].p;
     const uint32_t* nlist_in = c->alist_n.p + (n & 1);
     HIP_TRY(c, hipMemsetAsync(c->binstate.p, 0, sizeof(BinState), c->stream));
     uint32_t* const ids_at = need_ids ? c->ids_at.p : nullptr;  // reset by the emit kernel at every record position; not needed when nobody resolves ids
-    // records leave the emit kernel already partitioned by A bin into fixed-capacity regions of recs[0]; level B moves them to recs[1]
-    const uint32_t region = (uint32_t)(c->recs[0].n / kBins);
+    // records leave the emit kernel already partitioned by A bin into fixed-capacity (sub-)regions of recs[0]; level B moves them to recs[1]
+    const uint32_t region = (uint32_t)(c->recs[0].n / kASlots);
     {
         Prof p(c, COLIBRI_K_EMIT);
         if (use_list)

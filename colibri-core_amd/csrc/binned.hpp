@@ -16,6 +16,7 @@
 // holds more distinct keys than its LDS table (adversarial hash skew), `st->overflow_bin` is raised and the host re-runs
 // the training with the global-table kernels.
 #pragma once
+#include <cstddef>
 #include "kernels.hpp"
 
 namespace colibri {
@@ -31,10 +32,10 @@ constexpr int      kFinalBins  = kBins * kBins;      // 65 536
 constexpr int      kSub        = 8;                  // level A: every A bin is fed through 8 sub-regions, one per group of emit blocks (see bin_emit_kernel)
 constexpr int      kASlots     = kBins * kSub;       // 2048 (A bin, sub-region) slots
 #ifndef COLIBRI_SCAT_TILE
-#define COLIBRI_SCAT_TILE 4096
+#define COLIBRI_SCAT_TILE 2048
 #endif
 constexpr int      kScatTile   = COLIBRI_SCAT_TILE;  // records per scatter tile (16 B each of LDS staging)
-constexpr int      kScatPer    = kScatTile / kBlock; // 16 per lane
+constexpr int      kScatPer    = kScatTile / kBlock; // 8 per lane (2048-record tiles: 32 KB of staging, 4 blocks per CU — 4096 ran 0.4 ms slower per order-2 pass)
 constexpr int      kBinSlots   = 2048;               // LDS table of one final bin
 constexpr uint32_t kBinMaxLoad = 1900;               // distinct keys a final bin may hold
 
@@ -44,9 +45,9 @@ struct BinState {
     uint32_t overflow_bin;       // a final bin exceeded its LDS table -> host falls back to the global-table path
     uint32_t bshift;             // level B uses 256 >> bshift sub-bins: small orders get fewer, fuller final bins
     uint32_t kept_total;         // survivors of this order (written by bin_kept_scan_kernel)
+    uint32_t tprefA[kASlots + 1];  // level-B tiles per slot, exclusive scan (first array: 16-byte aligned for locate_tile's vector loads)
     uint32_t histA[kASlots];       // records per A slot (slot = sub-region * kBins + A bin: the kSub cursors of a bin lie 1 KB apart, not in one cache line)
     uint32_t offA[kASlots + 1];    // first record of the slot's region
-    uint32_t tprefA[kASlots + 1];  // level-B tiles per slot, exclusive scan
     uint32_t curA[kASlots];        // emit cursors
     uint32_t histAt[kBins];        // records per A bin (all its sub-regions)
     uint32_t hist2[kFinalBins];  // records per final bin, then (after the scan) their offsets
@@ -222,20 +223,27 @@ __global__ __launch_bounds__(kBlock) void bin_offsets_kernel(BinState* __restric
     }
 }
 
-// which A bin / which tile of which of its sub-regions does block `t` own?
+// which A bin / which tile of which of its sub-regions does block `t` own? Block-cooperative: lane l looks at slots 8l .. 8l+7
+// (one round trip to the prefix table; a binary search from global memory is 11 dependent loads, ~10 us per block, which at
+// 23 000 short-lived blocks per order-2 pass was most of the level-B kernels' time). Must be called by the whole block.
 __device__ __forceinline__ bool locate_tile(const BinState* bs, uint32_t t, uint32_t& a, uint32_t& begin, uint32_t& end) {
-    if (t >= bs->tprefA[kASlots]) return false;
-    uint32_t lo = 0, hi = kASlots;  // last slot with tprefA[slot] <= t
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (bs->tprefA[mid] <= t)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    a     = lo & (uint32_t)(kBins - 1);
-    begin = bs->offA[lo] + (t - bs->tprefA[lo]) * kScatTile;
-    end   = min(bs->offA[lo] + bs->histA[lo], begin + (uint32_t)kScatTile);
+    static_assert(kASlots == kBlock * 8, "one lane per 8 slots");
+    static_assert(offsetof(BinState, tprefA) % 16 == 0, "vector loads");
+    __shared__ uint32_t slotL;
+    if (threadIdx.x == 0) slotL = kInvalid;
+    __syncthreads();
+    const uint4    lo4 = reinterpret_cast<const uint4*>(bs->tprefA)[threadIdx.x * 2], hi4 = reinterpret_cast<const uint4*>(bs->tprefA)[threadIdx.x * 2 + 1];
+    const uint32_t nxt = bs->tprefA[threadIdx.x * 8 + 8];
+    const uint32_t tp[9] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w, nxt};
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+        if (tp[g] <= t && t < tp[g + 1]) slotL = threadIdx.x * 8 + g;  // at most one (lane, g): empty slots have tp[g] == tp[g+1]
+    __syncthreads();
+    const uint32_t slot = slotL;
+    if (slot == kInvalid) return false;
+    a     = slot & (uint32_t)(kBins - 1);
+    begin = bs->offA[slot] + (t - bs->tprefA[slot]) * kScatTile;
+    end   = min(bs->offA[slot] + bs->histA[slot], begin + (uint32_t)kScatTile);
     return true;
 }
 

@@ -8,7 +8,20 @@ sizes = [int(x) for x in sys.argv[1:]] or [10**7, 10**8]
 MAXLEN = int(os.environ.get('PROBE_MAXLENGTH', '5'))
 for T in sizes:
     V, seed = 10**6, 43 if T == 10**7 else 44
-    t = time.time(); payload = synth.zipf_corpus(T, V, seed, header=False); print('gen', T, round(time.time()-t, 2), len(payload), flush=True)
+    t = time.time()
+    if os.environ.get('PROBE_PHRASES'):  # "nphrases,rate": overwrite that share of the stream with copies of a small phrase inventory (hot n-grams)
+        nph, rate = os.environ['PROBE_PHRASES'].split(',')
+        rng = np.random.default_rng(seed)
+        toks = synth.zipf_tokens(T, V, rng); lens = synth.sentence_lengths(T, rng)
+        nph = int(nph); plen = rng.integers(3, 9, size=nph); starts = np.concatenate([[0], np.cumsum(plen)]); pool = toks[:int(starts[-1])].copy()
+        ninj = int(T * float(rate) / plen.mean()); which = rng.integers(0, nph, size=ninj); where = rng.integers(0, T - 8, size=ninj)
+        for k in range(8):  # vectorised injection, token k of every injected phrase
+            m = plen[which] > k
+            toks[where[m] + k] = pool[starts[which[m]] + k]
+        sym = np.insert(toks, np.cumsum(lens), np.uint32(0)); payload = synth.encode_v2(sym).tobytes()
+    else:
+        payload = synth.zipf_corpus(T, V, seed, header=False)
+    print('gen', T, round(time.time()-t, 2), len(payload), flush=True)
     c = capi.Context(0)
     t = time.time(); c.upload(payload); print('upload+tokenise s', round(time.time()-t, 4), c.corpus_info(), flush=True)
     for rep in range(3):

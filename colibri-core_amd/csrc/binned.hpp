@@ -344,13 +344,15 @@ __global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restri
 // index — ids only have to be unique. bin_kept_scan_kernel + compact_bins_kernel turn the sparse arrays into the dense result list.
 // insert one record per lane into the bin's LDS table; returns the slot (kInvalid for lanes that are idle or were folded into
 // their wave's leader). Must be called by all lanes of the block together (wave ballots inside).
+// wide (owner-side merge only): a record count of 0xFFFF stands for "65 535 or more — read wide[pos]".
 __device__ __forceinline__ uint32_t bin_insert(const bool valid, const Rec& x, unsigned long long* keyT, uint32_t* cntT, uint32_t* repT, const uint32_t smask,
-                                               const uint32_t nslots, uint32_t& nnew, uint32_t* failL) {
+                                               const uint32_t nslots, uint32_t& nnew, uint32_t* failL, const uint32_t* __restrict__ wide = nullptr) {
     // Heavy hitters arrive as many records with the same key (one per 2048-window tile). Lanes that hold the same key as the
     // wave's first active lane fold into that lane before touching LDS: a hot bin then costs one LDS update per wave
     // instead of 64 serialised ones on the same address.
     uint32_t       cnt   = x.meta & 0xFFFFu;
     uint32_t       pos   = x.pos;
+    if (wide != nullptr && valid && cnt == 0xFFFFu) cnt = wide[pos];
     bool           alive = valid;
     const uint64_t act   = __ballot(valid);
     if (act) {
@@ -398,10 +400,17 @@ __device__ __forceinline__ uint32_t bin_insert(const bool valid, const Rec& x, u
 
 constexpr int kBinRegPer = 8;  // records per lane held in registers: bins of up to 2048 records are read from HBM exactly once
 
+// MERGE = the owner-side merge of a sharded pass: the "positions" are indices into the received candidate list, counts may be
+// wide, and instead of sparse result arrays the bin leaves, per candidate of a surviving key, (f << 11 | rank of the key among
+// the bin's survivors) — which shard_reply_radix_kernel turns into a dense global id once the per-bin survivor counts are
+// scanned — with kExportBitR on the lowest-numbered candidate of the key (the lowest contributing rank), whose cnt_at entry
+// also receives the summed count.
+constexpr uint32_t kExportBitR = 0x80000000u;
+template <bool MERGE>
 __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t begin, const uint32_t end, const Rec* __restrict__ recs, DevState* __restrict__ st,
                                               BinState* __restrict__ bs, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
                                               unsigned long long* __restrict__ sp_key, uint32_t* __restrict__ ids_at, unsigned long long* keyT, uint32_t* cntT,
-                                              uint32_t* repT, uint32_t* idT, uint32_t* redL, uint32_t* failL) {
+                                              uint32_t* repT, uint32_t* idT, uint32_t* redL, uint32_t* failL, const uint32_t* __restrict__ wide, uint32_t* __restrict__ cnt_at) {
     // all loads of the (first 2048) records are issued before anything else: a bin is latency-bound, not bandwidth-bound
     Rec xr[kBinRegPer];
 #pragma unroll
@@ -427,14 +436,14 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
     for (int q = 0; q < kBinRegPer; ++q) {
         const uint32_t j = begin + q * kBlock + threadIdx.x;
         sl[q]            = kInvalid;
-        if (begin + q * kBlock < end) sl[q] = bin_insert(j < end, xr[q], keyT, cntT, repT, smask, nslots, nnew, failL);  // block-uniform guard
+        if (begin + q * kBlock < end) sl[q] = bin_insert(j < end, xr[q], keyT, cntT, repT, smask, nslots, nnew, failL, MERGE ? wide : nullptr);  // block-uniform guard
     }
     const uint32_t rest = begin + kBinRegPer * kBlock;  // bins larger than the register window (hot bins) stream the remainder
     for (uint32_t j0 = rest; j0 < end; j0 += kBlock) {
         const uint32_t j = j0 + threadIdx.x;
         Rec            x{};
         if (j < end) x = recs[j];
-        bin_insert(j < end, x, keyT, cntT, repT, smask, nslots, nnew, failL);
+        bin_insert(j < end, x, keyT, cntT, repT, smask, nslots, nnew, failL, MERGE ? wide : nullptr);
     }
     // distinct keys of this bin
     for (int off = 32; off > 0; off >>= 1) nnew += __shfl_down(nnew, off, kWave);
@@ -468,15 +477,20 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
         const uint32_t s  = threadIdx.x * per + q;
         uint32_t       id = kInvalid;
         if (keyT[s] != kEmptyKey && cntT[s] >= threshold) {
-            sp_rep[r] = repT[s];
-            sp_cnt[r] = cntT[s];
-            if (sp_key != nullptr) sp_key[r] = keyT[s];  // sharded runs: the sparse arrays ARE the local candidate list
-            id = id_base + r;
+            if (MERGE) {
+                cnt_at[repT[s]] = cntT[s];
+                id              = (f << 11) | (r - begin);
+            } else {
+                sp_rep[r] = repT[s];
+                sp_cnt[r] = cntT[s];
+                if (sp_key != nullptr) sp_key[r] = keyT[s];  // sharded runs: the sparse arrays ARE the local candidate list
+                id = id_base + r;
+            }
             ++r;
         }
         idT[s] = id;
     }
-    if (sp_key != nullptr)  // sharded runs scan the whole sparse range for candidates: mark the unused tail of this bin's range
+    if (!MERGE && sp_key != nullptr)  // sharded runs scan the whole sparse range for candidates: mark the unused tail of this bin's range
         for (uint32_t j = begin + total + threadIdx.x; j < end; j += kBlock) sp_cnt[j] = 0;
     __syncthreads();
     if (total == 0 || ids_at == nullptr) return;  // nothing in this bin survives (ids_at keeps the kInvalid the emit kernel wrote), or nobody needs the ids
@@ -491,7 +505,7 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
                 while (keyT[s] != xr[q].key) s = (s + 1) & smask;
             }
             const uint32_t id = idT[s];
-            if (id != kInvalid) ids_at[xr[q].pos] = id;
+            if (id != kInvalid) ids_at[xr[q].pos] = (MERGE && xr[q].pos == repT[s]) ? (id | kExportBitR) : id;
         }
     }
     for (uint32_t j = rest + threadIdx.x; j < end; j += kBlock) {
@@ -499,13 +513,14 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
         uint32_t  s = (uint32_t)mix64(x.key) & smask;
         while (keyT[s] != x.key) s = (s + 1) & smask;
         const uint32_t id = idT[s];
-        if (id != kInvalid) ids_at[x.pos] = id;
+        if (id != kInvalid) ids_at[x.pos] = (MERGE && x.pos == repT[s]) ? (id | kExportBitR) : id;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
-                                                            uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt, unsigned long long* __restrict__ sp_key,
-                                                            uint32_t* __restrict__ ids_at) {
+template <bool MERGE>
+__device__ __forceinline__ void bin_count_body(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
+                                               uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt, unsigned long long* __restrict__ sp_key,
+                                               uint32_t* __restrict__ ids_at, const uint32_t* __restrict__ wide, uint32_t* __restrict__ cnt_at) {
     if (st->done) return;
     __shared__ unsigned long long keyT[kBinSlots];
     __shared__ uint32_t           cntT[kBinSlots], repT[kBinSlots], idT[kBinSlots];
@@ -519,10 +534,107 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict
         const uint32_t begin = bs->hist2[f];
         const uint32_t end   = (f + 1 < (uint32_t)kFinalBins) ? bs->hist2[f + 1] : bs->total2;
         if (begin >= end) continue;
-        bin_count_one(f, begin, end, recs, st, bs, threshold, sp_rep, sp_cnt, sp_key, ids_at, keyT, cntT, repT, idT, redL, &failL);
+        bin_count_one<MERGE>(f, begin, end, recs, st, bs, threshold, sp_rep, sp_cnt, sp_key, ids_at, keyT, cntT, repT, idT, redL, &failL, wide, cnt_at);
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
+                                                            uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt, unsigned long long* __restrict__ sp_key,
+                                                            uint32_t* __restrict__ ids_at) {
+    bin_count_body<false>(recs, st, bs, threshold, sp_rep, sp_cnt, sp_key, ids_at, nullptr, nullptr);
+}
+// owner-side merge of a sharded n-gram pass (see bin_count_one<MERGE>)
+__global__ __launch_bounds__(kBlock) void bin_merge_count_kernel(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
+                                                                  uint32_t* __restrict__ ids_at, const uint32_t* __restrict__ wide, uint32_t* __restrict__ cnt_at) {
+    bin_count_body<true>(recs, st, bs, threshold, nullptr, nullptr, nullptr, ids_at, wide, cnt_at);
+}
+
+// ---- owner-side merge, front and back end -----------------------------------------------------------------------------------
+// merge_emit: the received candidate list (keys, counts; sources concatenated in rank order) -> records, partitioned by A bin like
+// bin_emit_kernel does, but binned by a SALTED mix of the key: all keys an owner receives share their owner under the plain mix, a
+// different mix spreads them over all 65 536 final bins again. No election: a source sends every key once.
+constexpr uint64_t kMergeSalt = 0x9E3779B97F4A7C15ull;
+__global__ __launch_bounds__(kBlock) void merge_emit_kernel(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ counts, uint32_t n, Rec* __restrict__ recs,
+                                                             uint32_t region, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t* __restrict__ ids_at,
+                                                             uint32_t* __restrict__ cnt_at) {
+    __shared__ Rec      recL[kCountTile];
+    __shared__ uint32_t histL[kBins], offL[kBins], gbaseL[kBins];
+    const uint32_t      ntiles = (n + kCountTile - 1) / kCountTile;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t base = tile * kCountTile;
+        uint64_t       key[kCountPer], hash[kCountPer];
+        uint32_t       cnt[kCountPer], rank[kCountPer];
+        histL[threadIdx.x] = 0;
+#pragma unroll
+        for (int k = 0; k < kCountPer; ++k) {  // loads first
+            const uint32_t j = base + k * kBlock + threadIdx.x;
+            key[k]           = (j < n) ? keys[j] : 0ull;
+            cnt[k]           = (j < n) ? counts[j] : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kCountPer; ++k) {
+            const uint32_t j = base + k * kBlock + threadIdx.x;
+            rank[k]          = kInvalid;
+            if (j < n) {
+                hash[k]   = mix64(key[k] ^ kMergeSalt);
+                rank[k]   = atomicAdd(&histL[(uint32_t)(hash[k] >> 56)], 1u);
+                ids_at[j] = kInvalid;
+                cnt_at[j] = 0;
+            }
+        }
+        __syncthreads();
+        {
+            uint32_t       tot;
+            const uint32_t h  = histL[threadIdx.x];
+            offL[threadIdx.x] = block_exclusive_scan(h, &tot);
+            uint32_t g        = 0;
+            if (h) {
+                const uint32_t slot = (blockIdx.x & (uint32_t)(kSub - 1)) * kBins + threadIdx.x;
+                const uint32_t at   = atomicAdd(&bs->curA[slot], h);
+                if (at + h > region) st->radix_overflow = 1;
+                g = slot * region + min(at, region - min(region, h));
+            }
+            gbaseL[threadIdx.x] = g;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kCountPer; ++k) {
+            if (rank[k] != kInvalid) {
+                const uint32_t hb = (uint32_t)(hash[k] >> 48);
+                Rec            r;
+                r.key  = key[k];
+                r.pos  = base + k * kBlock + threadIdx.x;
+                r.meta = (hb << 16) | min(cnt[k], 0xFFFFu);
+                recL[offL[hb >> 8] + rank[k]] = r;
+            }
+        }
+        __syncthreads();
+        const uint32_t nrec_tile = offL[kBins - 1] + histL[kBins - 1];
+        for (uint32_t j = threadIdx.x; j < nrec_tile; j += kBlock) {
+            const Rec      x = recL[j];
+            const uint32_t a = x.meta >> 24;
+            recs[gbaseL[a] + (j - offL[a])] = x;
+        }
+        __syncthreads();
+    }
+}
+// replies: dense global id = gid_base + (survivors in the bins before the candidate's bin) + its key's rank inside the bin
+__global__ __launch_bounds__(kBlock) void shard_reply_radix_kernel(const uint32_t* __restrict__ ids_at, const uint32_t* __restrict__ cnt_at, uint32_t n,
+                                                                    const BinState* __restrict__ bs, uint32_t gid_base, uint32_t* __restrict__ reply_gid,
+                                                                    uint32_t* __restrict__ reply_cnt) {
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+        const uint32_t e = ids_at[j];
+        uint32_t       g = kInvalid;
+        if (e != kInvalid) {
+            const uint32_t v = e & ~kExportBitR;
+            g                = (gid_base + bs->cur2[v >> 11] + (v & 2047u)) | (e & kExportBitR);
+        }
+        reply_gid[j] = g;
+        reply_cnt[j] = cnt_at[j];
+    }
+}
+
 
 // per-bin survivor counts (left in cur2 by bin_count) -> dense result offsets, bin by bin; kept = their total. Block a scans A bin a.
 __global__ __launch_bounds__(kBlock) void bin_kept_scan_kernel(DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t res_cap) {

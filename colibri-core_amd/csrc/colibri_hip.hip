@@ -113,6 +113,10 @@ struct colibri_ctx {
         DevBuf<Slot>               otable;            // owner-side table
         DevBuf<uint32_t>           ominrank, oslot;   // per owner slot: lowest contributing rank; per received record: owner slot
         DevBuf<DevState>           ostate;
+        DevBuf<Rec>                orecs[2];          // owner-side merge on the radix path: records, bin bookkeeping, per received candidate
+        DevBuf<BinState>           obin;              // the encoded survivor rank (+ export bit) and, at the exporter's candidate, the global count
+        DevBuf<uint32_t>           oids_at, ocnt_at;
+        bool                       merge_radix = false;
         uint32_t                   ocap = 0;
     } sh;
 
@@ -410,6 +414,11 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->sh.ominrank);
     dev_free(c->sh.oslot);
     dev_free(c->sh.ostate);
+    dev_free(c->sh.orecs[0]);
+    dev_free(c->sh.orecs[1]);
+    dev_free(c->sh.obin);
+    dev_free(c->sh.oids_at);
+    dev_free(c->sh.ocnt_at);
     dev_free(c->sh.taux);
     dev_free(c->sh.paux);
     dev_free(c->sh.onsrc);
@@ -1397,9 +1406,51 @@ int colibri_shard_merge(colibri_ctx* c, const void* keys_dev, const void* counts
     if (n && (!keys_dev || !counts_dev)) return COLIBRI_ERR_ARG;
     const bool aux = sh.use_aux && aux_dev != nullptr;
     if (sh.use_aux && n && !aux_dev) return fail(c, COLIBRI_ERR_ARG, "this pass needs the distinct-source counts (aux buffer)");
+    int rc;
+    // n-gram passes of radix-mode runs merge on the radix path too: the received candidates are records, binned by a salted mix of
+    // the key, partitioned twice and summed per final bin in LDS (no table in HBM, no device atomics per candidate). A bin that
+    // outgrows its LDS table falls through to the table merge below.
+    sh.merge_radix = false;
+    if (sh.radix && sh.mask == 0 && !sh.use_aux && n != 0 && c->opt.table_mode != 1) {
+        const size_t cap0 = ((size_t)n + (n >> 2)) / kASlots * kASlots + (size_t)kASlots * 512;
+        if ((rc = dev_alloc(c, sh.orecs[0], cap0)) || (rc = dev_alloc(c, sh.orecs[1], (size_t)n + 1)) || (rc = dev_alloc(c, sh.obin, 1)) || (rc = dev_alloc(c, sh.oids_at, (size_t)n + 1)) ||
+            (rc = dev_alloc(c, sh.ocnt_at, (size_t)n + 1)))
+            return rc;
+        DevState os{};
+        HIP_TRY(c, hipMemcpyAsync(sh.ostate.p, &os, sizeof os, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemsetAsync(sh.obin.p, 0, sizeof(BinState), c->stream));
+        const uint32_t region = (uint32_t)(sh.orecs[0].n / kASlots), tiles = blocks_for(n, kScatTile) + 1 + kASlots;
+        {
+            Prof p(c, COLIBRI_K_EMIT);
+            hipLaunchKernelGGL(merge_emit_kernel, dim3(std::min<uint32_t>(blocks_for(n, kCountTile), 256u * 4u)), dim3(kBlock), 0, c->stream, (const unsigned long long*)keys_dev,
+                               (const uint32_t*)counts_dev, n, sh.orecs[0].p, region, sh.ostate.p, sh.obin.p, sh.oids_at.p, sh.ocnt_at.p);
+        }
+        {
+            Prof p(c, COLIBRI_K_SCATTER);
+            hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, sh.obin.p, region);
+            hipLaunchKernelGGL(bin_hist2_kernel, dim3(tiles), dim3(kBlock), 0, c->stream, sh.orecs[0].p, sh.ostate.p, sh.obin.p);
+            hipLaunchKernelGGL(bin_scan2_kernel, dim3(kBins), dim3(kBlock), 0, c->stream, sh.obin.p);
+            hipLaunchKernelGGL(bin_scatter_kernel, dim3(tiles), dim3(kBlock), 0, c->stream, sh.orecs[0].p, sh.orecs[1].p, sh.ostate.p, sh.obin.p);
+        }
+        {
+            Prof p(c, COLIBRI_K_BINCOUNT);
+            hipLaunchKernelGGL(bin_merge_count_kernel, dim3(256 * 12), dim3(kBlock), 0, c->stream, sh.orecs[1].p, sh.ostate.p, sh.obin.p, sh.thr, sh.oids_at.p, (const uint32_t*)counts_dev,
+                               sh.ocnt_at.p);
+            hipLaunchKernelGGL(bin_kept_scan_kernel, dim3(kBins), dim3(kBlock), 0, c->stream, sh.ostate.p, sh.obin.p, 0xFFFFFFFFu);
+            hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, sh.ostate.p, sh.obin.p);
+        }
+        HIP_TRY(c, hipMemcpyAsync(&os, sh.ostate.p, sizeof os, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+        if (!os.radix_overflow) {
+            sh.merge_radix = true;
+            *found         = os.found;
+            *kept          = os.kept;
+            return COLIBRI_OK;
+        }
+    }
     const uint32_t cap = n + (n >> 1) + 1024;
     sh.ocap            = cap;
-    int rc;
     if ((rc = dev_alloc(c, sh.otable, cap)) || (rc = dev_alloc(c, sh.ominrank, cap)) || (rc = dev_alloc(c, sh.oslot, (size_t)n + 1))) return rc;
     if (aux && (rc = dev_alloc(c, sh.onsrc, cap))) return rc;
     DevState os{};
@@ -1439,7 +1490,11 @@ int colibri_shard_reply(colibri_ctx* c, uint32_t gid_base, void* reply_gid_dev, 
     HIP_TRY(c, hipSetDevice(c->device));
     auto& sh = c->sh;
     if (sh.nrecv && (!reply_gid_dev || !reply_cnt_dev)) return COLIBRI_ERR_ARG;
-    {
+    if (sh.merge_radix) {
+        Prof p(c, COLIBRI_K_PRUNE);
+        hipLaunchKernelGGL(shard_reply_radix_kernel, dim3(stream_grid(sh.nrecv)), dim3(kBlock), 0, c->stream, sh.oids_at.p, sh.ocnt_at.p, sh.nrecv, sh.obin.p, gid_base,
+                           (uint32_t*)reply_gid_dev, (uint32_t*)reply_cnt_dev);
+    } else {
         Prof p(c, COLIBRI_K_PRUNE);
         hipLaunchKernelGGL(shard_owner_assign_kernel, dim3(stream_grid(sh.ocap)), dim3(kBlock), 0, c->stream, sh.otable.p, sh.ostate.p, sh.thr, gid_base,
                            sh.owner_aux ? sh.onsrc.p : (const uint32_t*)nullptr, sh.minsrc);

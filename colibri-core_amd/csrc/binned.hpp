@@ -490,8 +490,6 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
         }
         idT[s] = id;
     }
-    if (!MERGE && sp_key != nullptr)  // sharded runs scan the whole sparse range for candidates: mark the unused tail of this bin's range
-        for (uint32_t j = begin + total + threadIdx.x; j < end; j += kBlock) sp_cnt[j] = 0;
     __syncthreads();
     if (total == 0 || ids_at == nullptr) return;  // nothing in this bin survives (ids_at keeps the kInvalid the emit kernel wrote), or nobody needs the ids
     // survivor id at every representative position of a surviving key (ids_at was pre-filled with kInvalid)
@@ -547,6 +545,34 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict
 __global__ __launch_bounds__(kBlock) void bin_merge_count_kernel(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
                                                                   uint32_t* __restrict__ ids_at, const uint32_t* __restrict__ wide, uint32_t* __restrict__ cnt_at) {
     bin_count_body<true>(recs, st, bs, threshold, nullptr, nullptr, nullptr, ids_at, wide, cnt_at);
+}
+
+// ---- sharded radix passes: the sparse per-bin arrays ARE the local candidate list ---------------------------------------------
+// After bin_kept_scan_kernel (threshold 1: every distinct key "survives") cur2 holds dense offsets in bin order, and bins are
+// A-bin-major = owner-major (owner_of): one ordered compaction yields the send buffers already grouped by owner, and the owner
+// boundaries are cur2 at the first bin of each owner's A-bin block. handle = the candidate's sparse index.
+__global__ __launch_bounds__(kBlock) void shard_compact_bins_kernel(const unsigned long long* __restrict__ sp_key, const uint32_t* __restrict__ sp_cnt, const BinState* __restrict__ bs,
+                                                                     unsigned long long* __restrict__ keys, uint32_t* __restrict__ counts, uint32_t* __restrict__ handles) {
+    const uint32_t lane = threadIdx.x & (kWave - 1), nwaves = gridDim.x * (kBlock / kWave);
+    for (uint32_t g = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; g < (uint32_t)kFinalBins; g += nwaves) {
+        const uint32_t f   = ((g & (uint32_t)(kBins - 1)) << 8) | (g >> 8);
+        const uint32_t off = bs->cur2[f];
+        const uint32_t n   = ((f + 1 < (uint32_t)kFinalBins) ? bs->cur2[f + 1] : bs->kept_total) - off;
+        if (n == 0) continue;
+        const uint32_t src = bs->hist2[f];
+        for (uint32_t j = lane; j < n; j += kWave) {
+            keys[off + j]    = sp_key[src + j];
+            counts[off + j]  = sp_cnt[src + j];
+            handles[off + j] = src + j;
+        }
+    }
+}
+// bounds[r] = first candidate of owner r (r = 0 .. world), from the dense per-bin offsets
+__global__ void shard_owner_bounds_kernel(const BinState* __restrict__ bs, uint32_t world, uint32_t* __restrict__ bounds) {
+    const uint32_t r = threadIdx.x;
+    if (r > world) return;
+    const uint32_t a = (r * (uint32_t)kBins + world - 1) / world;  // smallest A bin with (a * world) >> 8 == r
+    bounds[r]        = a < (uint32_t)kBins ? bs->cur2[a * kBins] : bs->kept_total;
 }
 
 // ---- owner-side merge, front and back end -----------------------------------------------------------------------------------

@@ -1306,12 +1306,26 @@ int colibri_shard_count(colibri_ctx* c, int n, uint32_t mask, int level, uint64_
             return rc;
         HIP_TRY(c, hipMemsetAsync(sh.small.p, 0, sizeof(uint32_t) * kShSmall, c->stream));
         HIP_TRY(c, hipMemsetAsync(sh.gid_of_sparse.p, 0xFF, sizeof(uint32_t) * ((size_t)sh.nsparse + 1), c->stream));
-        if (D) {
+        {
+            // dense offsets of the candidates in bin order (= owner order), the owner boundaries, and the send buffers in one ordered copy
             const BinnedIO io = binned_planes(c, pl, true);
-            Prof           p(c, COLIBRI_K_PRUNE);
-            hipLaunchKernelGGL(shard_extract_sparse_kernel, dim3(stream_grid(sh.nsparse)), dim3(kBlock), 0, c->stream, io.sp_key, io.sp_cnt, sh.nsparse, (uint32_t)sh.world, sh.tkeys.p,
-                               sh.tcounts.p, sh.tslots.p, sh.small.p, sh.small.p + kShHist);
+            DevState       scratch{};
+            HIP_TRY(c, hipMemcpyAsync(sh.ostate.p, &scratch, sizeof scratch, hipMemcpyHostToDevice, c->stream));
+            Prof p(c, COLIBRI_K_PRUNE);
+            hipLaunchKernelGGL(bin_kept_scan_kernel, dim3(kBins), dim3(kBlock), 0, c->stream, sh.ostate.p, c->binstate.p, 0xFFFFFFFFu);
+            hipLaunchKernelGGL(shard_owner_bounds_kernel, dim3(1), dim3(128), 0, c->stream, c->binstate.p, (uint32_t)sh.world, sh.small.p + kShOff);
+            if (D)
+                hipLaunchKernelGGL(shard_compact_bins_kernel, dim3(1024), dim3(kBlock), 0, c->stream, io.sp_key, io.sp_cnt, c->binstate.p, sh.pkeys.p, sh.pcounts.p, sh.pslots.p);
         }
+        uint32_t bounds[65] = {0};
+        HIP_TRY(c, hipMemcpyAsync(bounds, sh.small.p + kShOff, sizeof(uint32_t) * (sh.world + 1), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+        if (bounds[sh.world] != D) return fail(c, COLIBRI_ERR_HIP, "candidate compaction lost records (%u of %u)", bounds[sh.world], D);
+        for (int r = 0; r < sh.world; ++r) per_owner[r] = bounds[r + 1] - bounds[r];
+        sh.out       = out;
+        *ncandidates = D;
+        return COLIBRI_OK;
     } else {
     launch_clear(c, pl);
     if (mask == 0) {

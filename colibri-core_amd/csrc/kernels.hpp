@@ -275,6 +275,10 @@ struct KeyUnigram {
     }
 };
 // 64-bit finaliser used wherever a table slot / radix bin has to be chosen from an exact 64-bit key
+// owner rank of a key in a sharded pass: contiguous blocks of the 256 top-byte values of its mix, so that the candidates of one
+// owner are a contiguous run of radix bins (A bin = the same top byte) and leave the sparse per-bin arrays already grouped by owner
+__device__ __forceinline__ uint64_t mix64(uint64_t x);
+__device__ __forceinline__ uint32_t owner_of(uint64_t key, uint32_t world) { return (uint32_t)(((mix64(key) >> 56) * world) >> 8); }
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     x ^= x >> 33;
     x *= 0xff51afd7ed558ccdULL;
@@ -1142,7 +1146,7 @@ __global__ __launch_bounds__(kBlock) void refs_kernel(const uint32_t* __restrict
 // =================================================================================================
 // 7. sentence-sharded multi-GPU: the per-order exchange step
 //    Every rank counts its own shard; because survivor ids are GLOBAL (assigned by the owner rank of each key), the 64-bit
-//    keys of all ranks are directly comparable. Candidates (key, local count) travel to owner = mix64(key) % world, the
+//    keys of all ranks are directly comparable. Candidates (key, local count) travel to owner = owner_of(key) (blocks of the top byte of mix64(key)), the
 //    owner sums exact global counts, applies the threshold, hands out global survivor ids and names ONE exporting rank
 //    (the lowest rank that saw the pattern: it has the bytes); the replies travel back and are applied to the local table.
 // =================================================================================================
@@ -1179,7 +1183,7 @@ __global__ __launch_bounds__(kBlock) void shard_extract_kernel(const Slot* __res
                 counts[o] = sl[k].count;
                 slots[o]  = t0 + k * kBlock + threadIdx.x;
                 if (aux != nullptr) aux[o] = nsrc[t0 + k * kBlock + threadIdx.x];
-                atomicAdd(&histL[(uint32_t)(mix64(sl[k].key) % world)], 1u);
+                atomicAdd(&histL[owner_of(sl[k].key, world)], 1u);
                 ++o;
             }
         }
@@ -1206,7 +1210,7 @@ __global__ __launch_bounds__(kBlock) void shard_partition_kernel(const unsigned 
             own[q]           = kInvalid;
             if (j < n) {
                 k[q]    = keys[j];
-                own[q]  = (uint32_t)(mix64(k[q]) % world);
+                own[q]  = owner_of(k[q], world);
                 rank[q] = atomicAdd(&histL[own[q]], 1u);
             }
         }
@@ -1367,42 +1371,6 @@ __global__ __launch_bounds__(kBlock) void shard_apply_kernel(const uint32_t* __r
 }
 // sharded radix path: the local candidates are the non-empty entries of the sparse per-bin arrays (bin_count with threshold 1);
 // the handle that travels with a candidate is its sparse index
-__global__ __launch_bounds__(kBlock) void shard_extract_sparse_kernel(const unsigned long long* __restrict__ sp_key, const uint32_t* __restrict__ sp_cnt, uint32_t n, uint32_t world,
-                                                                       unsigned long long* __restrict__ keys, uint32_t* __restrict__ counts, uint32_t* __restrict__ handles,
-                                                                       uint32_t* __restrict__ ncand, uint32_t* __restrict__ owner_hist) {
-    __shared__ uint32_t histL[64];
-    __shared__ uint32_t baseL;
-    if (threadIdx.x < 64) histL[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t ntiles = (n + kPruneTile - 1) / kPruneTile;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t j0 = tile * kPruneTile + threadIdx.x * kPrunePer;
-        uint32_t       c[kPrunePer], used = 0;
-#pragma unroll
-        for (int q = 0; q < kPrunePer; ++q) {
-            c[q] = (j0 + q < n) ? sp_cnt[j0 + q] : 0u;
-            used += c[q] != 0;
-        }
-        uint32_t       total;
-        const uint32_t excl = block_exclusive_scan(used, &total);
-        if (threadIdx.x == 0) baseL = total ? atomicAdd(ncand, total) : 0;
-        __syncthreads();
-        uint32_t o = baseL + excl;
-#pragma unroll
-        for (int q = 0; q < kPrunePer; ++q) {
-            if (c[q]) {
-                const unsigned long long k = sp_key[j0 + q];
-                keys[o]    = k;
-                counts[o]  = c[q];
-                handles[o] = j0 + q;
-                atomicAdd(&histL[(uint32_t)(mix64(k) % world)], 1u);
-                ++o;
-            }
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x < world && histL[threadIdx.x]) atomicAdd(&owner_hist[threadIdx.x], histL[threadIdx.x]);
-}
 // sharded radix path: replies -> global id per sparse index (+ exports on the exporting rank)
 __global__ __launch_bounds__(kBlock) void shard_apply_sparse_kernel(const uint32_t* __restrict__ handles, const uint32_t* __restrict__ reply_gid,
                                                                      const uint32_t* __restrict__ reply_cnt, uint32_t n, const uint32_t* __restrict__ sp_rep,

@@ -117,6 +117,7 @@ struct colibri_ctx {
         DevBuf<BinState>           obin;              // the encoded survivor rank (+ export bit) and, at the exporter's candidate, the global count
         DevBuf<uint32_t>           oids_at, ocnt_at;
         bool                       merge_radix = false;
+        bool                       uni_from_class = false;  // order 1 counted without representative positions
         uint32_t                   ocap = 0;
     } sh;
 
@@ -547,6 +548,35 @@ struct BinnedIO {
     uint32_t*           sp_cnt;
     unsigned long long* sp_key;  // only filled for sharded runs (the sparse arrays are then the local candidate list)
 };
+// class-range width of the atomic-free order 1 (kernels.hpp §2b): 256 ranges must cover every class and a range's counters must fit
+// in LDS (<= 2^14 classes); 0 = not applicable (more than 4 M classes): the atomics kernel is used
+constexpr uint32_t kUniHeadGrid = 512;
+uint32_t uni_range_shift(const colibri_ctx* c) {
+    uint32_t shift = 12;
+    while (shift <= 14 && ((uint64_t)c->maxclass >> shift) >= (uint64_t)kUniBins) ++shift;
+    return shift > 14 ? 0u : shift;
+}
+int uni_alloc(colibri_ctx* c) {
+    int rc;
+    if ((rc = dev_alloc(c, c->unistate, 1)) || (rc = dev_alloc(c, c->uni_tail, (size_t)c->npos + 8)) || (rc = dev_alloc(c, c->uni_rows, (size_t)kUniHeadGrid * kUniHead)) ||
+        (rc = dev_alloc(c, c->uni_surv, (size_t)c->maxclass / 32 + 4)))
+        return rc;
+    return COLIBRI_OK;
+}
+// dense per-class counts of the device's tokens into cnt (zeroed here), without a global atomic per token
+int uni_count_partitioned(colibri_ctx* c, uint32_t shift, uint32_t* cnt, uint32_t nclasses) {
+    HIP_TRY(c, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * nclasses, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->unistate.p, 0, sizeof(UniState), c->stream));
+    Prof p(c, COLIBRI_K_COUNT);
+    hipLaunchKernelGGL(uni_head_kernel, dim3(kUniHeadGrid), dim3(kBlock), 0, c->stream, c->cls.p, c->npos, shift, c->uni_rows.p, c->unistate.p, c->state.p);
+    hipLaunchKernelGGL(uni_head_reduce_kernel, dim3(kUniHead / kBlock, 16), dim3(kBlock), 0, c->stream, c->uni_rows.p, kUniHeadGrid, cnt, nclasses, c->state.p);
+    hipLaunchKernelGGL(uni_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->unistate.p);
+    hipLaunchKernelGGL(uni_partition_kernel, dim3(256 * 4), dim3(kBlock), 0, c->stream, c->cls.p, c->npos, shift, c->unistate.p, c->uni_tail.p, c->state.p);
+    hipLaunchKernelGGL(uni_tail_count_kernel, dim3(kUniBins * kUniSlices), dim3(kBlock), sizeof(uint32_t) << shift, c->stream, c->uni_tail.p, c->unistate.p, shift, cnt, nclasses,
+                       c->state.p);
+    return COLIBRI_OK;
+}
+
 BinnedIO binned_planes(colibri_ctx* c, const TrainPlan& pl, bool with_keys) {
     // the sparse survivor arrays of an order live in recs[0] (free again after scatter B): u32 planes of npos entries, then u64 keys
     BinnedIO io{};
@@ -805,16 +835,8 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     // space is small enough for a dense array; table_mode 1 / 2 force the generic table / radix implementations (tests)
     const bool uni_direct = !synced && o.table_mode == 0 && !(c->flags & kFlagNonCanonical) && c->maxclass < (1u << 28);
     if (uni_direct && ((rc = dev_alloc(c, c->cnt1, (size_t)c->maxclass + 2)) || (rc = dev_alloc(c, c->rep1, (size_t)c->maxclass + 2)))) return rc;
-    // class-range width of the atomic-free order 1: 256 bins must cover every class and a bin's counters must fit in LDS (<= 2^14)
-    uint32_t uni_shift = 0;
-    if (uni_direct && !synced) {
-        uni_shift = 12;
-        while (uni_shift <= 14 && ((uint64_t)c->maxclass >> uni_shift) >= (uint64_t)kUniBins) ++uni_shift;
-        if (uni_shift > 14) uni_shift = 0;  // more than 4 M classes: keep the atomics kernel
-    }
-    constexpr uint32_t kUniHeadGrid = 512;
-    if (uni_shift && ((rc = dev_alloc(c, c->unistate, 1)) || (rc = dev_alloc(c, c->uni_tail, (size_t)c->npos + 8)) || (rc = dev_alloc(c, c->uni_rows, (size_t)kUniHeadGrid * kUniHead)) ||
-                      (rc = dev_alloc(c, c->uni_surv, (size_t)c->maxclass / 32 + 4)))) return rc;
+    const uint32_t uni_shift = (uni_direct && !synced) ? uni_range_shift(c) : 0u;  // 0: more than 4 M classes, the atomics kernel stays
+    if (uni_shift && (rc = uni_alloc(c))) return rc;
     // ---- HBM layout (sized once; nothing is allocated inside the unsynced order loop) ----------------
     // table: an order admits at most `npos` windows -> 1.5x slots; results: every survivor has >= 2 occurrences
     const uint64_t table_slots64 = (uint64_t)npos + (npos >> 1) + 2048;
@@ -874,18 +896,11 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             if (n == 1 && uni_direct) {
                 // order 1 on the class-indexed count array (kernels.hpp §2b): no hashing, no table, LDS histogram for the Zipf head
                 const uint32_t nclasses = c->maxclass + 1;
-                HIP_TRY(c, hipMemsetAsync(c->cnt1.p, 0, sizeof(uint32_t) * nclasses, c->stream));
                 if (uni_shift) {
                     // no per-token global atomics: head histogram in LDS, tail partitioned into 256 class ranges and counted per range in LDS
-                    HIP_TRY(c, hipMemsetAsync(c->unistate.p, 0, sizeof(UniState), c->stream));
-                    Prof p(c, COLIBRI_K_COUNT);
-                    hipLaunchKernelGGL(uni_head_kernel, dim3(kUniHeadGrid), dim3(kBlock), 0, c->stream, c->cls.p, npos, uni_shift, c->uni_rows.p, c->unistate.p, c->state.p);
-                    hipLaunchKernelGGL(uni_head_reduce_kernel, dim3(kUniHead / kBlock, 16), dim3(kBlock), 0, c->stream, c->uni_rows.p, kUniHeadGrid, c->cnt1.p, nclasses, c->state.p);
-                    hipLaunchKernelGGL(uni_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->unistate.p);
-                    hipLaunchKernelGGL(uni_partition_kernel, dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, c->cls.p, npos, uni_shift, c->unistate.p, c->uni_tail.p, c->state.p);
-                    hipLaunchKernelGGL(uni_tail_count_kernel, dim3(kUniBins * kUniSlices), dim3(kBlock), sizeof(uint32_t) << uni_shift, c->stream, c->uni_tail.p, c->unistate.p,
-                                       uni_shift, c->cnt1.p, nclasses, c->state.p);
+                    if ((rc = uni_count_partitioned(c, uni_shift, c->cnt1.p, nclasses))) return rc;
                 } else {
+                    HIP_TRY(c, hipMemsetAsync(c->cnt1.p, 0, sizeof(uint32_t) * nclasses, c->stream));
                     Prof p(c, COLIBRI_K_COUNT);
                     hipLaunchKernelGGL(uni_count_kernel, dim3(512), dim3(kBlock), 0, c->stream, c->cls.p, npos, c->cnt1.p, c->rep1.p, c->state.p);
                 }
@@ -1652,10 +1667,17 @@ int colibri_shard_uni_count(colibri_ctx* c, void* cnt_dev, void* minrank_dev, ui
     hs.found = hs.kept = hs.admitted = hs.valid = 0;
     hs.res_total = sh.res_total;
     if ((rc = write_state(c))) return rc;
-    HIP_TRY(c, hipMemsetAsync(cnt_dev, 0, sizeof(uint32_t) * nclasses, c->stream));
-    {
+    // plain runs need no representative positions (unigram keys are exported from the class): the atomic-free count applies
+    sh.uni_from_class = !c->opt.doskipgrams && uni_range_shift(c) != 0;
+    if (sh.uni_from_class) {
+        if ((rc = uni_alloc(c)) || (rc = uni_count_partitioned(c, uni_range_shift(c), (uint32_t*)cnt_dev, nclasses))) return rc;
+    } else {
+        HIP_TRY(c, hipMemsetAsync(cnt_dev, 0, sizeof(uint32_t) * nclasses, c->stream));
         Prof p(c, COLIBRI_K_COUNT);
         hipLaunchKernelGGL(uni_count_kernel, dim3(512), dim3(kBlock), 0, c->stream, c->cls.p, pl.npos, (uint32_t*)cnt_dev, c->rep1.p, c->state.p);
+    }
+    {
+        Prof p(c, COLIBRI_K_COUNT);
         hipLaunchKernelGGL(shard_uni_minrank_kernel, dim3(stream_grid(nclasses)), dim3(kBlock), 0, c->stream, (const uint32_t*)cnt_dev, nclasses, (uint32_t)rank, (uint32_t*)minrank_dev);
     }
     if ((rc = read_state(c))) return rc;
@@ -1676,7 +1698,8 @@ int colibri_shard_uni_apply(colibri_ctx* c, const void* cnt_global_dev, const vo
     {
         Prof p(c, COLIBRI_K_PRUNE);
         hipLaunchKernelGGL(shard_uni_finish_kernel, dim3(stream_grid(nclasses)), dim3(kBlock), 0, c->stream, (const uint32_t*)cnt_global_dev, (const uint32_t*)minrank_global_dev,
-                           c->rep1.p, nclasses, (uint32_t)rank, pl.thr, c->state.p, c->res_rep.p, c->res_cnt.p, sh.res_gid.p, pl.res_cap, c->opt.doskipgrams ? sh.mark.p : (uint32_t*)nullptr);
+                           sh.uni_from_class ? (const uint32_t*)nullptr : c->rep1.p, nclasses, (uint32_t)rank, pl.thr, c->state.p, c->res_rep.p, c->res_cnt.p, sh.res_gid.p, pl.res_cap,
+                           c->opt.doskipgrams ? sh.mark.p : (uint32_t*)nullptr);
     }
     {
         Prof p(c, COLIBRI_K_RESOLVE);
@@ -1684,7 +1707,7 @@ int colibri_shard_uni_apply(colibri_ctx* c, const void* cnt_global_dev, const vo
     }
     if ((rc = read_state(c))) return rc;
     const uint32_t k = c->hstate.kept;  // exported by THIS rank
-    if (k) c->segments.push_back({sh.res_total, k, 1, 0u});
+    if (k) c->segments.push_back({sh.res_total, k, 1, sh.uni_from_class ? kMaskFromClass : 0u});
     sh.res_total += k;
     sh.valid_n[1]    = c->hstate.valid;
     sh.exported_n[1] = k;

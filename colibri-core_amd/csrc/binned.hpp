@@ -73,7 +73,7 @@ struct BinState {
 template <class KeyFn, bool LIST>
 __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __restrict__ recs, uint32_t region, uint32_t* __restrict__ rep_of, DevState* __restrict__ st,
                                                            BinState* __restrict__ bs, uint32_t npos, const uint32_t* __restrict__ list, const uint32_t* __restrict__ nlist,
-                                                           uint32_t* __restrict__ ids_at) {
+                                                           uint32_t* __restrict__ ids_at, uint8_t* __restrict__ flags_at = nullptr) {
     if (st->done) return;
     const uint32_t nitems = LIST ? *nlist : npos;
     // phase E (election): keyL u64[2048] | winL u32[4096]   -- 32 KB, later reused as recL Rec[2048]
@@ -170,6 +170,7 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
                 r.meta = (hb << 16) | (1u + cntL[e]);
                 recL[offL[hb >> 8] + rank[k]] = r;
                 if (ids_at != nullptr) ids_at[base + e] = kInvalid;  // "no survivor here" until bin_count says otherwise: only record positions are ever read back
+                if (flags_at != nullptr) flags_at[base + e] = 0;     // flag mode (see bin_count_kernel): one byte per item instead of an id
             }
         }
         __syncthreads();
@@ -410,7 +411,8 @@ template <bool MERGE>
 __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t begin, const uint32_t end, const Rec* __restrict__ recs, DevState* __restrict__ st,
                                               BinState* __restrict__ bs, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
                                               unsigned long long* __restrict__ sp_key, uint32_t* __restrict__ ids_at, unsigned long long* keyT, uint32_t* cntT,
-                                              uint32_t* repT, uint32_t* idT, uint32_t* redL, uint32_t* failL, const uint32_t* __restrict__ wide, uint32_t* __restrict__ cnt_at) {
+                                              uint32_t* repT, uint32_t* idT, uint32_t* redL, uint32_t* failL, const uint32_t* __restrict__ wide, uint32_t* __restrict__ cnt_at,
+                                              uint8_t* __restrict__ flags_at) {
     // all loads of the (first 2048) records are issued before anything else: a bin is latency-bound, not bandwidth-bound
     Rec xr[kBinRegPer];
 #pragma unroll
@@ -491,7 +493,7 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
         idT[s] = id;
     }
     __syncthreads();
-    if (total == 0 || ids_at == nullptr) return;  // nothing in this bin survives (ids_at keeps the kInvalid the emit kernel wrote), or nobody needs the ids
+    if (total == 0 || (ids_at == nullptr && flags_at == nullptr)) return;  // nothing in this bin survives (ids_at keeps the kInvalid the emit kernel wrote), or nobody needs the ids
     // survivor id at every representative position of a surviving key (ids_at was pre-filled with kInvalid)
 #pragma unroll
     for (int q = 0; q < kBinRegPer; ++q) {
@@ -503,7 +505,12 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
                 while (keyT[s] != xr[q].key) s = (s + 1) & smask;
             }
             const uint32_t id = idT[s];
-            if (id != kInvalid) ids_at[xr[q].pos] = (MERGE && xr[q].pos == repT[s]) ? (id | kExportBitR) : id;
+            if (id != kInvalid) {
+                if (!MERGE && flags_at != nullptr)
+                    flags_at[xr[q].pos] = 1;  // flag mode: the next order builds its keys without this order's ids (KeyTrigramCls)
+                else
+                    ids_at[xr[q].pos] = (MERGE && xr[q].pos == repT[s]) ? (id | kExportBitR) : id;
+            }
         }
     }
     for (uint32_t j = rest + threadIdx.x; j < end; j += kBlock) {
@@ -511,14 +518,19 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
         uint32_t  s = (uint32_t)mix64(x.key) & smask;
         while (keyT[s] != x.key) s = (s + 1) & smask;
         const uint32_t id = idT[s];
-        if (id != kInvalid) ids_at[x.pos] = (MERGE && x.pos == repT[s]) ? (id | kExportBitR) : id;
+        if (id != kInvalid) {
+            if (!MERGE && flags_at != nullptr)
+                flags_at[x.pos] = 1;
+            else
+                ids_at[x.pos] = (MERGE && x.pos == repT[s]) ? (id | kExportBitR) : id;
+        }
     }
 }
 
 template <bool MERGE>
 __device__ __forceinline__ void bin_count_body(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
                                                uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt, unsigned long long* __restrict__ sp_key,
-                                               uint32_t* __restrict__ ids_at, const uint32_t* __restrict__ wide, uint32_t* __restrict__ cnt_at) {
+                                               uint32_t* __restrict__ ids_at, const uint32_t* __restrict__ wide, uint32_t* __restrict__ cnt_at, uint8_t* __restrict__ flags_at) {
     if (st->done) return;
     __shared__ unsigned long long keyT[kBinSlots];
     __shared__ uint32_t           cntT[kBinSlots], repT[kBinSlots], idT[kBinSlots];
@@ -532,19 +544,19 @@ __device__ __forceinline__ void bin_count_body(const Rec* __restrict__ recs, Dev
         const uint32_t begin = bs->hist2[f];
         const uint32_t end   = (f + 1 < (uint32_t)kFinalBins) ? bs->hist2[f + 1] : bs->total2;
         if (begin >= end) continue;
-        bin_count_one<MERGE>(f, begin, end, recs, st, bs, threshold, sp_rep, sp_cnt, sp_key, ids_at, keyT, cntT, repT, idT, redL, &failL, wide, cnt_at);
+        bin_count_one<MERGE>(f, begin, end, recs, st, bs, threshold, sp_rep, sp_cnt, sp_key, ids_at, keyT, cntT, repT, idT, redL, &failL, wide, cnt_at, flags_at);
         __syncthreads();
     }
 }
 __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
                                                             uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt, unsigned long long* __restrict__ sp_key,
-                                                            uint32_t* __restrict__ ids_at) {
-    bin_count_body<false>(recs, st, bs, threshold, sp_rep, sp_cnt, sp_key, ids_at, nullptr, nullptr);
+                                                            uint32_t* __restrict__ ids_at, uint8_t* __restrict__ flags_at = nullptr) {
+    bin_count_body<false>(recs, st, bs, threshold, sp_rep, sp_cnt, sp_key, ids_at, nullptr, nullptr, flags_at);
 }
 // owner-side merge of a sharded n-gram pass (see bin_count_one<MERGE>)
 __global__ __launch_bounds__(kBlock) void bin_merge_count_kernel(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
                                                                   uint32_t* __restrict__ ids_at, const uint32_t* __restrict__ wide, uint32_t* __restrict__ cnt_at) {
-    bin_count_body<true>(recs, st, bs, threshold, nullptr, nullptr, nullptr, ids_at, wide, cnt_at);
+    bin_count_body<true>(recs, st, bs, threshold, nullptr, nullptr, nullptr, ids_at, wide, cnt_at, nullptr);
 }
 
 // ---- sharded radix passes: the sparse per-bin arrays ARE the local candidate list ---------------------------------------------
@@ -774,6 +786,55 @@ __global__ __launch_bounds__(kBlock) void bin_resolve_kernel(const uint32_t* __r
     if (threadIdx.x == 0) {
         const uint32_t v = redL[0] + redL[1] + redL[2] + redL[3];
         if (v) atomicAdd(&st->valid, v);
+    }
+}
+
+// flag mode of an all-positions order (order 2 when three class ids fit one key, see KeyTrigramCls): instead of survivor ids per
+// position, one byte "the window starting here survived" per position, plus the active list for the next order.
+__global__ __launch_bounds__(kBlock) void bin_resolve_flags_kernel(const uint32_t* __restrict__ rep_of, const uint8_t* __restrict__ flags_at, uint8_t* __restrict__ flags,
+                                                                    DevState* __restrict__ st, uint32_t npos, uint32_t* __restrict__ list_out, uint32_t* __restrict__ nlist_out) {
+    if (st->done) return;
+    __shared__ uint32_t baseL;
+    __shared__ uint32_t redL[kBlock / kWave];
+    const uint32_t      ntiles = (npos + kResTile - 1) / kResTile;
+    uint32_t            nvalid = 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t rp[kResPer], c = 0;
+        uint8_t  v[kResPer];
+#pragma unroll
+        for (int q = 0; q < kResPer; ++q) {
+            const uint32_t j = tile * kResTile + q * kBlock + threadIdx.x;
+            rp[q]            = (j < npos) ? rep_of[j] : kInvalid;
+        }
+#pragma unroll
+        for (int q = 0; q < kResPer; ++q) v[q] = (rp[q] != kInvalid) ? flags_at[rp[q]] : (uint8_t)0;
+#pragma unroll
+        for (int q = 0; q < kResPer; ++q) {
+            const uint32_t j = tile * kResTile + q * kBlock + threadIdx.x;
+            if (j < npos) {
+                flags[j] = v[q];
+                c += v[q];
+            }
+        }
+        nvalid += c;
+        if (list_out != nullptr) {
+            uint32_t       total;
+            const uint32_t excl = block_exclusive_scan(c, &total);
+            if (threadIdx.x == 0) baseL = total ? atomicAdd(nlist_out, total) : 0;
+            __syncthreads();
+            uint32_t o = baseL + excl;
+#pragma unroll
+            for (int q = 0; q < kResPer; ++q)
+                if (v[q]) list_out[o++] = tile * kResTile + q * kBlock + threadIdx.x;
+            __syncthreads();
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) nvalid += __shfl_down(nvalid, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nvalid;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = redL[0] + redL[1] + redL[2] + redL[3];
+        if (t) atomicAdd(&st->valid, t);
     }
 }
 

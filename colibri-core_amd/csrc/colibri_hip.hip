@@ -72,6 +72,7 @@ struct colibri_ctx {
     DevBuf<Slot>      table;
     DevBuf<Rec>       recs[2];          // binned path: record ping-pong
     DevBuf<uint32_t>  rep_of, ids_at;   // binned path: representative position per window; survivor id at representative positions
+    DevBuf<uint8_t>   flags_at, flag2;  // flag mode of order 2 (KeyTrigramCls): survivor byte at representative positions / per position
     DevBuf<uint32_t>  alist[2], alist_n; // binned path: active-position lists (ping-pong) and their lengths [2]
     DevBuf<BinState>  binstate;
     int               last_mode = 0;    // 1 = global table, 2 = binned (what the last train() actually ran)
@@ -393,6 +394,8 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->recs[0]);
     dev_free(c->recs[1]);
     dev_free(c->rep_of);
+    dev_free(c->flags_at);
+    dev_free(c->flag2);
     dev_free(c->ids_at);
     dev_free(c->alist[0]);
     dev_free(c->alist[1]);
@@ -587,22 +590,23 @@ BinnedIO binned_planes(colibri_ctx* c, const TrainPlan& pl, bool with_keys) {
 }
 
 template <class KeyFn>
-int binned_count_stage(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, int n, bool use_list, uint32_t thr, bool with_keys, bool need_ids = true) {
+int binned_count_stage(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, int n, bool use_list, uint32_t thr, bool with_keys, bool need_ids = true, bool flag_mode = false) {
     const uint32_t  tiles    = blocks_for(pl.npos, kScatTile) + 1 + kASlots;  // level-B tiles: every slot may end in a partial one
     const uint32_t* list_in  = c->alist[n & 1].p;
     const uint32_t* nlist_in = c->alist_n.p + (n & 1);
     HIP_TRY(c, hipMemsetAsync(c->binstate.p, 0, sizeof(BinState), c->stream));
-    uint32_t* const ids_at = need_ids ? c->ids_at.p : nullptr;  // reset by the emit kernel at every record position; not needed when nobody resolves ids
+    uint32_t* const ids_at   = (need_ids && !flag_mode) ? c->ids_at.p : nullptr;  // reset by the emit kernel at every record position; not needed when nobody resolves ids
+    uint8_t* const  flags_at = (need_ids && flag_mode) ? c->flags_at.p : nullptr;  // flag mode: a survivor byte instead of a survivor id
     // records leave the emit kernel already partitioned by A bin into fixed-capacity (sub-)regions of recs[0]; level B moves them to recs[1]
     const uint32_t region = (uint32_t)(c->recs[0].n / kASlots);
     {
         Prof p(c, COLIBRI_K_EMIT);
         if (use_list)
             hipLaunchKernelGGL((bin_emit_kernel<KeyFn, true>), dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, fn, c->recs[0].p, region, c->rep_of.p, c->state.p, c->binstate.p, pl.npos,
-                               list_in, nlist_in, ids_at);
+                               list_in, nlist_in, ids_at, flags_at);
         else
             hipLaunchKernelGGL((bin_emit_kernel<KeyFn, false>), dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, fn, c->recs[0].p, region, c->rep_of.p, c->state.p, c->binstate.p, pl.npos,
-                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, ids_at);
+                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, ids_at, flags_at);
     }
     {
         Prof p(c, COLIBRI_K_SCATTER);
@@ -614,7 +618,7 @@ int binned_count_stage(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, int
     const BinnedIO io = binned_planes(c, pl, with_keys);
     {
         Prof p(c, COLIBRI_K_BINCOUNT);
-        hipLaunchKernelGGL(bin_count_kernel, dim3(256 * 12), dim3(kBlock), 0, c->stream, c->recs[1].p, c->state.p, c->binstate.p, thr, io.sp_rep, io.sp_cnt, io.sp_key, ids_at);
+        hipLaunchKernelGGL(bin_count_kernel, dim3(256 * 12), dim3(kBlock), 0, c->stream, c->recs[1].p, c->state.p, c->binstate.p, thr, io.sp_rep, io.sp_cnt, io.sp_key, ids_at, flags_at);
     }
     return COLIBRI_OK;
 }
@@ -640,9 +644,9 @@ int binned_resolve_stage(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids_out,
 // one order of the plain (unsynced) run. need_ids = false at the last order: nothing reads its survivor ids, so the id scatter and
 // the resolve pass are skipped.
 template <class KeyFn>
-int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t* ids_out, int n, bool use_list, bool need_ids) {
+int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t* ids_out, int n, bool use_list, bool need_ids, bool flag_mode = false) {
     int rc;
-    if ((rc = binned_count_stage(c, pl, fn, n, use_list, pl.thr, false, need_ids))) return rc;
+    if ((rc = binned_count_stage(c, pl, fn, n, use_list, pl.thr, false, need_ids, flag_mode))) return rc;
     const BinnedIO io = binned_planes(c, pl, false);
     {
         Prof p(c, COLIBRI_K_PRUNE);
@@ -652,6 +656,14 @@ int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t*
         hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
     }
     if (!need_ids) return COLIBRI_OK;
+    if (flag_mode) {  // all-positions order whose successor builds its keys from class ids: a byte per position and the active list
+        uint32_t* nlist_out = c->alist_n.p + ((n + 1) & 1);
+        HIP_TRY(c, hipMemsetAsync(nlist_out, 0, sizeof(uint32_t), c->stream));
+        Prof p(c, COLIBRI_K_RESOLVE);
+        hipLaunchKernelGGL(bin_resolve_flags_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->rep_of.p, c->flags_at.p, c->flag2.p, c->state.p, pl.npos, c->alist[(n + 1) & 1].p,
+                           nlist_out);
+        return COLIBRI_OK;
+    }
     // the only later reader is the next order's emit kernel (ids at i and i+1 for i on the new active list): no fill of ids_out
     return binned_resolve_stage(c, pl, ids_out, n, use_list, /*build_list=*/n >= 2, nullptr, 0u, false);
 }
@@ -837,6 +849,9 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     if (uni_direct && ((rc = dev_alloc(c, c->cnt1, (size_t)c->maxclass + 2)) || (rc = dev_alloc(c, c->rep1, (size_t)c->maxclass + 2)))) return rc;
     const uint32_t uni_shift = (uni_direct && !synced) ? uni_range_shift(c) : 0u;  // 0: more than 4 M classes, the atomics kernel stays
     if (uni_shift && (rc = uni_alloc(c))) return rc;
+    // three class ids in one key: order 3 is keyed by classes, order 2 leaves survivor bytes instead of ids (KeyTrigramCls)
+    const bool tri_cls = binned && uni_direct && !synced && c->maxclass < (1u << 21) && o.maxlength >= 3;
+    if (tri_cls && ((rc = dev_alloc(c, c->flags_at, (size_t)npos + 1)) || (rc = dev_alloc(c, c->flag2, (size_t)npos + 4)))) return rc;
     // ---- HBM layout (sized once; nothing is allocated inside the unsynced order loop) ----------------
     // table: an order admits at most `npos` windows -> 1.5x slots; results: every survivor has >= 2 occurrences
     const uint64_t table_slots64 = (uint64_t)npos + (npos >> 1) + 2048;
@@ -921,6 +936,10 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                 // carry a survivor id are visited (the active list the previous order's resolve left behind)
                 if (n == 1)
                     rc = binned_order(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, id_cur, n, false, n < maxlength);
+                else if (n == 2 && tri_cls)
+                    rc = binned_order(c, pl, KeyNgram{id_prev, n}, id_cur, n, false, true, /*flag_mode=*/true);  // order 3 will not read order-2 ids
+                else if (n == 3 && tri_cls)
+                    rc = binned_order(c, pl, KeyTrigramCls{c->cls.p, c->flag2.p}, id_cur, n, true, n < maxlength);
                 else
                     rc = binned_order(c, pl, KeyNgram{id_prev, n}, id_cur, n, n >= 3, n < maxlength);
                 if (rc) return rc;

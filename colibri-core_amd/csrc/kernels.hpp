@@ -304,6 +304,22 @@ struct KeyNgram {
         return true;
     }
 };
+// order 3 straight from the class ids, when three of them fit one 64-bit key (maxclass < 2^21) and order 1 ran class-indexed
+// (the survivor id of a unigram IS its class): the key is exact without any order-2 survivor id, so order 2 only has to leave one
+// byte per position ("the bigram starting here survived") instead of scattering 4-byte ids into a 420 MB array.
+struct KeyTrigramCls {
+    const uint32_t* cls;
+    const uint8_t*  flag2;
+    __device__ __forceinline__ bool operator()(uint32_t i, uint32_t npos, uint64_t& key, uint64_t& hash) const {
+        if (i + 2 >= npos) return false;
+        const uint8_t  f0 = flag2[i], f1 = flag2[i + 1];
+        const uint32_t c0 = cls[i], c1 = cls[i + 1], c2 = cls[i + 2];
+        if (!(f0 && f1)) return false;
+        key  = (uint64_t)c0 | ((uint64_t)c1 << 21) | ((uint64_t)c2 << 42);
+        hash = mix64(key);
+        return true;
+    }
+};
 // skipgram passes: the key is a pair of ids taken at two offsets from the window start. `gate`/`gate2` say which windows take
 // part (exhaustive: both (n-1)-grams survived = gate[i], gate2[i+1]; indexed: the n-gram itself survived = gate[i]).
 // Level >= 2 of a multi-part skipgram pairs the previous level's slot index (left, offset 0) with the next part's id.

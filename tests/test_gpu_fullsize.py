@@ -110,3 +110,22 @@ def test_downward_closure_at_full_size(models):
         assert np.all(sorted_h[pos] == sub), f"a kept n-gram's {name} (n-1)-gram is missing from the model"
         assert np.all(sorted_c[pos] >= counts[multi]), f"{name} count below the n-gram's count"
     assert int(ntok.max()) == st.maxn
+
+
+@pytest.mark.parametrize("vocab,phrases", [(3_000_000, False), (6_000_000, False), (1_000_000, True)])
+def test_default_mode_agrees_on_other_class_spaces(vocab, phrases):
+    """20 M tokens; the default mode picks different order-1 / order-2 kernels by class-space size — 3 M classes: 2^14-class tail
+    ranges and no class-keyed order 3; 6 M classes: the atomics order 1; 1 M classes with 15 % of the stream overwritten by a phrase
+    inventory: hot n-grams up to order 5 — and must give the global-table model every time (multiset of (key, count) rows)."""
+    from colibri_amd import capi, synth
+    payload = synth.zipf_corpus(20_000_000, vocab, 46, phrases=phrases, header=False)
+    got = {}
+    with capi.Context(0) as ctx:
+        ctx.upload(payload)
+        for mode in (1, 0):
+            st = ctx.train(mintokens=2, maxlength=5, table_mode=mode)
+            key_off, key_bytes, counts, _ = ctx.export_arrays()
+            got[mode] = (summary(st), row_hashes(key_off, key_bytes, counts))
+    assert got[0][0] == got[1][0]
+    for x, y in zip(got[0][1], got[1][1]):
+        assert np.array_equal(np.sort(x), np.sort(y))

@@ -193,3 +193,56 @@ def ref_train(corpus_path: str, mode: str, maxlength: int, mintokens: int, *, mi
         with open(dump_path) as f:
             model = parse_dump(f.read(), indexed=mode in ("i", "is"))
     return model, info
+
+
+# ---- class encoder: oracle/classenc_oracle.cpp and the real reference -----------------------------------------------
+CLASSENC_LIB_PATH = os.path.join(HERE, "libclassenc_oracle.so")
+_cel = None
+
+
+def classenc_lib():
+    global _cel
+    if _cel is None:
+        if not os.path.exists(CLASSENC_LIB_PATH):
+            build()
+        L = C.CDLL(CLASSENC_LIB_PATH)
+        L.classenc_oracle_run.restype = C.c_int
+        L.classenc_oracle_run.argtypes = [C.c_char_p, C.c_uint64, C.c_uint, C.c_int, C.c_char_p, C.c_uint64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.classenc_oracle_free.argtypes = [C.c_void_p]
+        _cel = L
+    return _cel
+
+
+def classencode(text: bytes, threshold=0, allowunknown=False, cls: bytes = None, extend=False):
+    """-> (status, class file text, .colibri.dat bytes incl. the A2 02 header). status 1 = unknown token (strict mode)."""
+    L = classenc_lib()
+    co, cn, do, dn = C.c_void_p(), C.c_uint64(), C.c_void_p(), C.c_uint64()
+    rc = L.classenc_oracle_run(text, len(text), threshold, int(allowunknown), cls, len(cls) if cls is not None else 0, int(extend), C.byref(co), C.byref(cn), C.byref(do),
+                               C.byref(dn))
+    out = (rc, C.string_at(co, cn.value), C.string_at(do, dn.value))
+    L.classenc_oracle_free(co)
+    L.classenc_oracle_free(do)
+    return out
+
+
+def ref_classencode(text_path: str, prefix: str, threshold=0, allowunknown=False, cls_path=None, extend=False):
+    """the REAL reference's class encoder (build container only) -> exit status (4 = unknown token); writes <prefix>.colibri.{cls,dat}"""
+    cmd = [REF_DRIVER, "encode", text_path, prefix, "-t", str(threshold)]
+    if cls_path:
+        cmd += ["-c", cls_path]
+    if extend:
+        cmd.append("-e")
+    if allowunknown:
+        cmd.append("-U")
+    return subprocess.run(cmd, capture_output=True).returncode
+
+
+def parse_cls(text: bytes) -> dict:
+    """class file -> {word bytes: class}; line order in the file is unordered_map order and carries no meaning"""
+    out = {}
+    for ln in text.split(b"\n"):
+        if b"\t" in ln:
+            c, w = ln.split(b"\t", 1)
+            out[w] = int(c)
+    return out

@@ -92,6 +92,7 @@ int usage() {
                  "      us = unindexed + exhaustive skipgrams (preloaded corpus)\n"
                  "      i  = indexed (preloaded corpus);  is = indexed + skipgrams\n"
                  "  ref_driver load <model.colibri.patternmodel> <u|i> <dump.txt>\n"
+                 "  ref_driver encode <text> <outprefix> [-t threshold] [-c classfile] [-e] [-U]\n"
                  "  ref_driver view <model> <u|i> <print|report|simplereport|histogram|info> <classfile>\n"
                  "  ref_driver hash <hex> [<hex> ...]\n"
                  "  ref_driver encode <text file> <out prefix>\n"
@@ -129,14 +130,34 @@ int main(int argc, char** argv) {
         return 0;
     }
 
-    if (cmd == "encode") {
+    if (cmd == "encode") {  // the REFERENCE's class encoder, as colibri-classencode drives it (src/classencode.cpp:134-198)
+        // ref_driver encode <text> <outprefix> [-t threshold] [-c classfile] [-e] [-U]      exit code 4 = unknown token
         if (argc < 4) return usage();
         const std::string text = argv[2], prefix = argv[3];
-        ClassEncoder enc;
+        unsigned int threshold = 0;
+        std::string  classfile;
+        bool         extend = false, allowunknown = false;
+        for (int i = 4; i < argc; ++i) {
+            const std::string a = argv[i];
+            if (a == "-t" && i + 1 < argc) threshold = (unsigned int)atoi(argv[++i]);
+            else if (a == "-c" && i + 1 < argc) classfile = argv[++i];
+            else if (a == "-e") extend = true;
+            else if (a == "-U") allowunknown = true;
+        }
         std::vector<std::string> files{text};
-        enc.build(files, true, 0, "");
+        ClassEncoder             enc;
+        if (!classfile.empty()) {
+            enc = ClassEncoder(classfile);
+            if (extend) enc.build(files, true, threshold, "");
+        } else {
+            enc.build(files, true, threshold, "");
+        }
+        try {
+            enc.encodefile(text, prefix + ".colibri.dat", allowunknown, extend, false, false, true);
+        } catch (const UnknownTokenError&) {
+            return 4;
+        }
         enc.save(prefix + ".colibri.cls");
-        enc.encodefile(text, prefix + ".colibri.dat", false, false, false, false);
         return 0;
     }
 

@@ -18,6 +18,7 @@
 
 #include "colibri_hip.h"
 #include "binned.hpp"
+#include "textenc.hpp"
 #include "kernels.hpp"
 
 using namespace colibri;
@@ -73,6 +74,19 @@ struct colibri_ctx {
     DevBuf<Rec>       recs[2];          // binned path: record ping-pong
     DevBuf<uint32_t>  rep_of, ids_at;   // binned path: representative position per window; survivor id at representative positions
     DevBuf<uint8_t>   flags_at, flag2;  // flag mode of order 2 (KeyTrigramCls): survivor byte at representative positions / per position
+    struct TextState {                  // class encoder (textenc.hpp): the uploaded text, its word table, the encoded stream
+        DevBuf<uint8_t>            text, out;
+        DevBuf<uint32_t>           slot_of, first, widx, wstart, wlen, wcount, cls, repeat, outlen;
+        DevBuf<unsigned long long> outoff, bsum, ntok;
+        DevBuf<Slot>               table;
+        DevBuf<DevState>           state;
+        DevBuf<TextInfo>           info;
+        TextInfo                   hinfo{};
+        uint32_t                   n = 0, cap = 0, ndistinct = 0;
+        uint64_t                   outbytes = 0, nwords = 0;
+        int                        rules = -1;
+        bool                       encoded = false;
+    } tx;
     DevBuf<uint32_t>  alist[2], alist_n; // binned path: active-position lists (ping-pong) and their lengths [2]
     DevBuf<BinState>  binstate;
     int               last_mode = 0;    // 1 = global table, 2 = binned (what the last train() actually ran)
@@ -395,6 +409,9 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->recs[1]);
     dev_free(c->rep_of);
     dev_free(c->flags_at);
+    dev_free(c->tx.text); dev_free(c->tx.out); dev_free(c->tx.slot_of); dev_free(c->tx.first); dev_free(c->tx.widx); dev_free(c->tx.wstart); dev_free(c->tx.wlen);
+    dev_free(c->tx.wcount); dev_free(c->tx.cls); dev_free(c->tx.repeat); dev_free(c->tx.outlen); dev_free(c->tx.outoff); dev_free(c->tx.bsum); dev_free(c->tx.ntok);
+    dev_free(c->tx.table); dev_free(c->tx.state); dev_free(c->tx.info);
     dev_free(c->flag2);
     dev_free(c->ids_at);
     dev_free(c->alist[0]);
@@ -1773,6 +1790,150 @@ int colibri_shard_export_index(colibri_ctx* c, uint32_t* gids, uint64_t* ref_off
         HIP_TRY(c, hipMemcpy(ref_token, c->ref_token.p, sizeof(uint16_t) * N, hipMemcpyDeviceToHost));
     }
     return COLIBRI_OK;
+}
+
+// =====================================================================================================================
+// class encoder (kernels in textenc.hpp). The host side of the boundary decides the class of every DISTINCT word
+// (colibri-core_amd/host: ClassEncoder — the tie order among equally frequent words is the reference's container order and is
+// reproduced there); the device does everything that is proportional to the corpus.
+// =====================================================================================================================
+int colibri_text_upload(colibri_ctx* c, const uint8_t* text, uint64_t nbytes) {
+    if (!c || (!text && nbytes)) return COLIBRI_ERR_ARG;
+    if (nbytes >= 0x7FFFFFF0ull) return fail(c, COLIBRI_ERR_CORPUS, "text of %llu bytes: at most 2 GiB per call", (unsigned long long)nbytes);
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto& t = c->tx;
+    int   rc;
+    if ((rc = dev_alloc(c, t.text, (size_t)nbytes + 16)) || (rc = dev_alloc(c, t.info, 1)) || (rc = dev_alloc(c, t.state, 1)) || (rc = dev_alloc(c, t.ntok, 1))) return rc;
+    t.n       = (uint32_t)nbytes;
+    t.rules   = -1;
+    t.encoded = false;
+    if (nbytes) HIP_TRY(c, hipMemcpyAsync(t.text.p, text, nbytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(t.info.p, 0, sizeof(TextInfo), c->stream));
+    if (nbytes) hipLaunchKernelGGL(text_info_kernel, dim3(stream_grid(nbytes)), dim3(kBlock), 0, c->stream, t.text.p, t.n, t.info.p);
+    HIP_TRY(c, hipMemcpyAsync(&t.hinfo, t.info.p, sizeof(TextInfo), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return COLIBRI_OK;
+}
+
+int colibri_text_count(colibri_ctx* c, int rules, uint64_t* nwords, uint64_t* ndistinct) {
+    if (!c || !nwords || !ndistinct || (rules != 0 && rules != 1)) return COLIBRI_ERR_ARG;
+    auto& t = c->tx;
+    if (!t.text.p) return fail(c, COLIBRI_ERR_STATE, "colibri_text_upload first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int            rc;
+    const uint64_t cap64 = (uint64_t)t.hinfo.nsegments + (t.hinfo.nsegments >> 1) + 1024;
+    t.cap               = (uint32_t)cap64;
+    if ((rc = dev_alloc(c, t.table, t.cap)) || (rc = dev_alloc(c, t.slot_of, (size_t)t.n + 1)) || (rc = dev_alloc(c, t.first, t.cap)) || (rc = dev_alloc(c, t.widx, t.cap)) ||
+        (rc = dev_alloc(c, t.wstart, (size_t)t.hinfo.nsegments + 1)) || (rc = dev_alloc(c, t.wlen, (size_t)t.hinfo.nsegments + 1)) ||
+        (rc = dev_alloc(c, t.wcount, (size_t)t.hinfo.nsegments + 1)))
+        return rc;
+    for (int attempt = 0; attempt < 4; ++attempt) {  // a 64-bit hash collision between two words (never seen) is detected and retried with another seed
+        DevState st{};
+        st.cap = t.cap;
+        HIP_TRY(c, hipMemcpyAsync(t.state.p, &st, sizeof st, hipMemcpyHostToDevice, c->stream));
+        TextInfo reset = t.hinfo;
+        reset.collision = reset.ndistinct = 0;
+        HIP_TRY(c, hipMemcpyAsync(t.info.p, &reset, sizeof reset, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemsetAsync(t.first.p, 0xFF, sizeof(uint32_t) * t.cap, c->stream));
+        hipLaunchKernelGGL(clear_table_kernel, dim3(stream_grid(t.cap)), dim3(kBlock), 0, c->stream, t.table.p, t.state.p);
+        if (t.n) {
+            const KeyWord fn{t.text.p, rules, 0x5851F42D4C957F2Dull * (uint64_t)(attempt + 1)};
+            Prof          p(c, COLIBRI_K_COUNT);
+            hipLaunchKernelGGL((count_kernel<KeyWord>), dim3(std::max<uint32_t>(1, std::min<uint32_t>(blocks_for(t.n, kCountTile), 256u * 3u))), dim3(kBlock), 0, c->stream, fn, t.slot_of.p,
+                               t.table.p, t.state.p, t.n, 1);
+            hipLaunchKernelGGL(text_verify_kernel, dim3(stream_grid(t.n)), dim3(kBlock), 0, c->stream, t.text.p, t.n, rules, t.slot_of.p, t.table.p, t.first.p, t.info.p);
+            hipLaunchKernelGGL(text_words_kernel, dim3(stream_grid(t.cap)), dim3(kBlock), 0, c->stream, t.text.p, t.n, rules, t.table.p, t.cap, t.first.p, t.widx.p, t.wstart.p, t.wlen.p,
+                               t.wcount.p, t.info.p);
+        }
+        TextInfo got{};
+        HIP_TRY(c, hipMemcpyAsync(&got, t.info.p, sizeof got, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&st, t.state.p, sizeof st, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+        if (st.overflow) return fail(c, COLIBRI_ERR_OVERFLOW, "word table exhausted");
+        if (got.collision) continue;
+        t.ndistinct = got.ndistinct;
+        t.nwords    = st.admitted;
+        t.rules     = rules;
+        t.encoded   = false;
+        *nwords     = t.nwords;
+        *ndistinct  = t.ndistinct;
+        return COLIBRI_OK;
+    }
+    return fail(c, COLIBRI_ERR_HIP, "word hashes collided under four different seeds");
+}
+
+int colibri_text_words(colibri_ctx* c, uint32_t* first_start, uint32_t* length, uint32_t* count) {
+    if (!c) return COLIBRI_ERR_ARG;
+    auto& t = c->tx;
+    if (t.rules < 0) return fail(c, COLIBRI_ERR_STATE, "colibri_text_count first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (t.ndistinct) {
+        if (!first_start || !length || !count) return COLIBRI_ERR_ARG;
+        HIP_TRY(c, hipMemcpy(first_start, t.wstart.p, sizeof(uint32_t) * t.ndistinct, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(length, t.wlen.p, sizeof(uint32_t) * t.ndistinct, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(count, t.wcount.p, sizeof(uint32_t) * t.ndistinct, hipMemcpyDeviceToHost));
+    }
+    return COLIBRI_OK;
+}
+
+int colibri_text_encode(colibri_ctx* c, const uint32_t* cls, const uint32_t* repeat, uint64_t* outbytes, uint64_t* ntokens, uint64_t* nlines) {
+    if (!c || !outbytes || !ntokens || !nlines) return COLIBRI_ERR_ARG;
+    auto& t = c->tx;
+    if (t.rules != 1) return fail(c, COLIBRI_ERR_STATE, "colibri_text_count with the encoder's rules (1) first");
+    if (t.ndistinct && (!cls || !repeat)) return COLIBRI_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int            rc;
+    const uint32_t nb = std::max<uint32_t>(1, blocks_for(t.n, kBlock * 4));
+    if ((rc = dev_alloc(c, t.cls, (size_t)t.ndistinct + 1)) || (rc = dev_alloc(c, t.repeat, (size_t)t.ndistinct + 1)) || (rc = dev_alloc(c, t.outlen, (size_t)t.n + 1)) ||
+        (rc = dev_alloc(c, t.outoff, (size_t)t.n + 1)) || (rc = dev_alloc(c, t.bsum, (size_t)nb + 1)))
+        return rc;
+    if (t.ndistinct) {
+        HIP_TRY(c, hipMemcpyAsync(t.cls.p, cls, sizeof(uint32_t) * t.ndistinct, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(t.repeat.p, repeat, sizeof(uint32_t) * t.ndistinct, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(c, hipMemsetAsync(t.ntok.p, 0, sizeof(unsigned long long), c->stream));
+    unsigned long long total = 0, ntok = 0;
+    if (t.n) {
+        Prof p(c, COLIBRI_K_EXPORT);
+        hipLaunchKernelGGL(text_outlen_kernel, dim3(stream_grid(t.n)), dim3(kBlock), 0, c->stream, t.text.p, t.n, t.slot_of.p, t.widx.p, t.cls.p, t.repeat.p, t.hinfo.after_last_nl,
+                           t.outlen.p, t.ntok.p);
+        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, t.outlen.p, t.n, t.bsum.p);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, c->stream, t.bsum.p, nb, t.bsum.p + nb);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, t.outlen.p, t.n, t.bsum.p, t.outoff.p);
+        HIP_TRY(c, hipMemcpyAsync(&total, t.bsum.p + nb, sizeof total, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&ntok, t.ntok.p, sizeof ntok, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if ((rc = dev_alloc(c, t.out, (size_t)total + 16))) return rc;
+        hipLaunchKernelGGL(text_write_kernel, dim3(stream_grid(t.n)), dim3(kBlock), 0, c->stream, t.text.p, t.n, t.slot_of.p, t.widx.p, t.cls.p, t.repeat.p, t.outlen.p, t.outoff.p,
+                           t.out.p);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+    }
+    t.outbytes = total;
+    t.encoded  = true;
+    *outbytes  = total;
+    *ntokens   = ntok;
+    *nlines    = t.hinfo.nlines;
+    return COLIBRI_OK;
+}
+
+int colibri_text_fetch(colibri_ctx* c, uint8_t* out) {
+    if (!c) return COLIBRI_ERR_ARG;
+    if (!c->tx.encoded) return fail(c, COLIBRI_ERR_STATE, "colibri_text_encode first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->tx.outbytes) {
+        if (!out) return COLIBRI_ERR_ARG;
+        HIP_TRY(c, hipMemcpy(out, c->tx.out.p, c->tx.outbytes, hipMemcpyDeviceToHost));
+    }
+    return COLIBRI_OK;
+}
+
+int colibri_text_as_corpus(colibri_ctx* c, uint32_t first_sentence) {
+    if (!c) return COLIBRI_ERR_ARG;
+    if (!c->tx.encoded) return fail(c, COLIBRI_ERR_STATE, "colibri_text_encode first");
+    return colibri_upload_corpus_device(c, c->tx.out.p, c->tx.outbytes, first_sentence);
 }
 
 }  // extern "C"

@@ -23,6 +23,7 @@ EXPORTED = [
     "colibri_shard_begin", "colibri_shard_count", "colibri_shard_send", "colibri_shard_merge", "colibri_shard_reply", "colibri_shard_apply",
     "colibri_shard_finish", "colibri_shard_export_gids", "colibri_shard_index_sizes", "colibri_shard_export_index",
     "colibri_shard_uni_info", "colibri_shard_uni_count", "colibri_shard_uni_apply",
+    "colibri_text_upload", "colibri_text_count", "colibri_text_words", "colibri_text_encode", "colibri_text_fetch", "colibri_text_as_corpus",
 ]
 
 
@@ -75,6 +76,12 @@ def load():
         L.colibri_destroy.restype = None
         L.colibri_last_error.argtypes = [C.c_void_p]
         L.colibri_last_error.restype = C.c_char_p
+        L.colibri_text_upload.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+        L.colibri_text_count.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.colibri_text_words.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.colibri_text_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.colibri_text_fetch.argtypes = [C.c_void_p, C.c_void_p]
+        L.colibri_text_as_corpus.argtypes = [C.c_void_p, C.c_uint32]
         L.colibri_upload_corpus.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
         L.colibri_upload_corpus_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
         L.colibri_corpus_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 3

@@ -180,6 +180,24 @@ int colibri_hash_keys(colibri_ctx* ctx, const uint8_t* bytes, const uint64_t* of
  * (only when options.profile = 1; events are recorded on the library's own stream) */
 int colibri_kernel_time(const colibri_ctx* ctx, int kernel_class, double* total_ms, uint64_t* launches);
 
+/* ---- class encoder: plain text -> word frequency list -> class-encoded corpus -------------------------------------
+ * Replaces the corpus-proportional work of ClassEncoder::processcorpus (reference src/classencoder.cpp:156-188: the word frequency
+ * list) and ClassEncoder::encodefile / encodestring (:369-436, :550-600: words -> varint classes, one 00 per line). The class of
+ * every DISTINCT word is decided by the caller between colibri_text_words and colibri_text_encode (buildclasses :213-229, the
+ * unknown-word policy of encodestring :412-424) — that step is proportional to the vocabulary, not to the corpus.
+ * Word rules, `rules` = 0 (frequency list) / 1 (encoder): see colibri-core_amd/csrc/textenc.hpp. */
+int colibri_text_upload(colibri_ctx* ctx, const uint8_t* text, uint64_t nbytes);                 /* plain text, '\n' ends a line; < 2 GiB */
+int colibri_text_count(colibri_ctx* ctx, int rules, uint64_t* nwords, uint64_t* ndistinct);      /* counts every word under `rules` */
+/* one entry per distinct word, in no particular order: byte offset of its FIRST occurrence in the text, its byte length, its count.
+ * (The reference fills its unordered_map in first-occurrence order; sorting by first_start reproduces that insertion order.) */
+int colibri_text_words(colibri_ctx* ctx, uint32_t* first_start, uint32_t* length, uint32_t* count);
+/* cls[k], repeat[k] for distinct word k of the last colibri_text_count(rules = 1): the word becomes `repeat` copies of varint(cls)
+ * (0 drops it; "{*3*}" is 3 x class 3). Every '\n' becomes one 00; text after the last '\n' is not encoded (encodefile :569-570).
+ * The result is a .colibri.dat v2 payload (no A2 02 header) kept on the device. */
+int colibri_text_encode(colibri_ctx* ctx, const uint32_t* cls, const uint32_t* repeat, uint64_t* outbytes, uint64_t* ntokens, uint64_t* nlines);
+int colibri_text_fetch(colibri_ctx* ctx, uint8_t* out);                                          /* the encoded payload -> host */
+int colibri_text_as_corpus(colibri_ctx* ctx, uint32_t first_sentence);                           /* ... or straight into colibri_upload_corpus_device */
+
 #ifdef __cplusplus
 }
 #endif

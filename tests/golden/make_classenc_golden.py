@@ -25,6 +25,8 @@ QUIRKS = (b"the cat sat on the mat .\n"
           b" leading space and trailing space \n"
           b"\tleadingtab stays\t\t\n"                     # trim is a RIGHT trim: the leading tab belongs to the word
           b"\t\r \t\t \r\r x\n"                           # single \t / \r segments are skipped, multi-byte ones become the empty word
+          b"lone tab before the final space \t \n"   # "\t " is cut as one word by the frequency list, passes its filter and trims to ""
+          b"lone cr before two final spaces \r  \n"
           b"back\bspace\b \bx\b\n"                        # \b is trimmed by the encoder but not by the frequency list
           b"gaps {*} and {**} and {?} and {*3*} and {*0*} here\n"
           b"{*x*} {* {**}x {|} }{\n"

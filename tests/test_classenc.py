@@ -79,3 +79,107 @@ def test_oracle_matches_reference_on_random_texts(tmp_path):
         if rc == 0:
             assert odat == (tmp_path / f"r{k}.colibri.dat").read_bytes(), k
             assert ocls == (tmp_path / f"r{k}.colibri.cls").read_bytes(), k
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# GPU: the HIP path behind the C++ face (ClassEncoder) and the colibri-classencode CLI
+# ---------------------------------------------------------------------------------------------------------------------------------
+def run_cli(args, cwd):
+    if not os.path.exists(CLI):
+        pytest.fail(f"{CLI} is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    return subprocess.run([CLI] + args, capture_output=True, cwd=cwd, timeout=600)
+
+
+def cli_flags(case):
+    textfile, threshold, allowunknown, clsof, extend = CASES[case]
+    flags = ["-t", str(threshold)] if threshold else []
+    if allowunknown:
+        flags.append("-U")
+    if clsof:
+        flags += ["-c", os.path.join(G, clsof + ".colibri.cls")]
+    if extend:
+        flags.append("-e")
+    return flags, os.path.join(G, textfile)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", list(CASES))
+def test_cli_matches_reference_goldens(case, tmp_path):
+    flags, text = cli_flags(case)
+    p = run_cli(flags + ["-o", "out", text], str(tmp_path))
+    rc, gcls, gdat = golden(case)
+    assert (p.returncode != 0) == (rc != 0), p.stderr.decode()[-1500:]
+    if rc == 0:
+        stem = os.path.basename(text)[:-4]
+        assert (tmp_path / f"{stem}.colibri.dat").read_bytes() == gdat
+        if CASES[case][3] is None or CASES[case][4]:  # with -c and without -e colibri-classencode writes no class file (reference src/classencode.cpp:137-146)
+            got_cls = (tmp_path / "out.colibri.cls").read_bytes()
+            assert oracle.parse_cls(got_cls) == oracle.parse_cls(gcls)
+            assert got_cls == gcls  # same containers filled in the same order: even the line order of the class file agrees
+    else:
+        assert p.returncode == 4  # UnknownTokenError
+
+
+@pytest.mark.gpu
+def test_cli_matches_oracle_on_random_texts(tmp_path):
+    rng = np.random.default_rng(11)
+    for k in range(30):
+        text = random_text(rng, nlines=int(rng.integers(1, 120)))
+        (tmp_path / f"t{k}.txt").write_bytes(text)
+        allowunknown, threshold = bool(k % 2), k % 3
+        st, ocls, odat = oracle.classencode(text, threshold, allowunknown)
+        p = run_cli((["-U"] if allowunknown else []) + (["-t", str(threshold)] if threshold else []) + [f"t{k}.txt"], str(tmp_path))
+        assert (p.returncode != 0) == (st != 0), (k, p.stderr.decode()[-800:])
+        if st == 0:
+            assert (tmp_path / f"t{k}.colibri.dat").read_bytes() == odat, k
+            assert (tmp_path / f"t{k}.colibri.cls").read_bytes() == ocls, k
+
+
+@pytest.mark.gpu
+def test_text_to_model_end_to_end(tmp_path):
+    """colibri-classencode then colibri-patternmodeller, both on the device: the model of the reference's own apology.txt equals the
+    oracle's model of the reference-encoded corpus."""
+    p = run_cli([os.path.join(G, "apology.txt")], str(tmp_path))
+    assert p.returncode == 0, p.stderr.decode()
+    dat = (tmp_path / "apology.colibri.dat").read_bytes()
+    assert dat == golden("apology")[2]
+    modeller = os.path.join(ROOT, "colibri-core_amd", "bin", "colibri-patternmodeller")
+    out = subprocess.run([modeller, "-f", "apology.colibri.dat", "-u", "-t", "2", "-l", "5", "-o", "apology.colibri.patternmodel"], capture_output=True, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr.decode()
+    want = oracle.train(dat[2:], 2, 5)
+    from test_host_face import parse_model
+    mtype, tokens, types, counts, _ = parse_model(str(tmp_path / "apology.colibri.patternmodel"))
+    assert (mtype, tokens, types) == (10, want.tokens, want.types) and counts == want.counts
+
+
+@pytest.mark.gpu
+def test_c_abi_text_path_feeds_train_without_host_round_trip():
+    """colibri_text_upload / count / words / encode / as_corpus through ctypes: the encoded stream never leaves the device before train()"""
+    import ctypes as C
+    from colibri_amd import capi
+    text = open(os.path.join(G, "apology.txt"), "rb").read()
+    _, _, gdat = golden("apology")
+    L = capi.load()
+    with capi.Context(0) as ctx:
+        h = ctx.h
+        nwords, nd = C.c_uint64(), C.c_uint64()
+        assert L.colibri_text_upload(h, text, C.c_uint64(len(text))) == 0
+        assert L.colibri_text_count(h, 1, C.byref(nwords), C.byref(nd)) == 0
+        n = nd.value
+        start, length, count = (np.zeros(n, dtype=np.uint32) for _ in range(3))
+        assert L.colibri_text_words(h, start.ctypes.data_as(C.c_void_p), length.ctypes.data_as(C.c_void_p), count.ctypes.data_as(C.c_void_p)) == 0
+        assert int(count.sum()) == nwords.value == len(text.split())
+        gcls = oracle.parse_cls(golden("apology")[1])
+        cls = np.array([gcls[text[s:s + ln]] for s, ln in zip(start.tolist(), length.tolist())], dtype=np.uint32)
+        rep = np.ones(n, dtype=np.uint32)
+        ob, nt, nl = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        assert L.colibri_text_encode(h, cls.ctypes.data_as(C.c_void_p), rep.ctypes.data_as(C.c_void_p), C.byref(ob), C.byref(nt), C.byref(nl)) == 0
+        assert (ob.value, nt.value, nl.value) == (len(gdat) - 2, nwords.value, text.count(b"\n"))
+        out = np.zeros(ob.value, dtype=np.uint8)
+        assert L.colibri_text_fetch(h, out.ctypes.data_as(C.c_void_p)) == 0
+        assert out.tobytes() == gdat[2:]
+        assert L.colibri_text_as_corpus(h, 1) == 0
+        st = ctx.train(mintokens=2, maxlength=5)
+        got, _ = ctx.export_dict()
+    want = oracle.train(gdat[2:], 2, 5)
+    assert st.totaltokens == want.tokens and got == want.counts

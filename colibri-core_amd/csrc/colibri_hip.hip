@@ -76,7 +76,8 @@ struct colibri_ctx {
     DevBuf<uint8_t>   flags_at, flag2;  // flag mode of order 2 (KeyTrigramCls): survivor byte at representative positions / per position
     struct TextState {                  // class encoder (textenc.hpp): the uploaded text, its word table, the encoded stream
         DevBuf<uint8_t>            text, out;
-        DevBuf<uint32_t>           slot_of, first, widx, wstart, wlen, wcount, cls, repeat, outlen;
+        DevBuf<uint32_t>           slot_of, first, widx, wstart, wlen, wcount, cls, repeat, outlen, events, evcnt;
+        uint32_t                   nevents = 0;
         DevBuf<unsigned long long> outoff, bsum, ntok;
         DevBuf<Slot>               table;
         DevBuf<DevState>           state;
@@ -411,7 +412,7 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->flags_at);
     dev_free(c->tx.text); dev_free(c->tx.out); dev_free(c->tx.slot_of); dev_free(c->tx.first); dev_free(c->tx.widx); dev_free(c->tx.wstart); dev_free(c->tx.wlen);
     dev_free(c->tx.wcount); dev_free(c->tx.cls); dev_free(c->tx.repeat); dev_free(c->tx.outlen); dev_free(c->tx.outoff); dev_free(c->tx.bsum); dev_free(c->tx.ntok);
-    dev_free(c->tx.table); dev_free(c->tx.state); dev_free(c->tx.info);
+    dev_free(c->tx.table); dev_free(c->tx.state); dev_free(c->tx.info); dev_free(c->tx.events); dev_free(c->tx.evcnt);
     dev_free(c->flag2);
     dev_free(c->ids_at);
     dev_free(c->alist[0]);
@@ -1813,6 +1814,21 @@ int colibri_text_upload(colibri_ctx* c, const uint8_t* text, uint64_t nbytes) {
     HIP_TRY(c, hipMemcpyAsync(&t.hinfo, t.info.p, sizeof(TextInfo), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
+    // the event list (segment starts and newlines, in text order) every later pass walks
+    t.nevents = t.hinfo.nsegments + t.hinfo.nlines;
+    if (t.nevents) {
+        const uint32_t nblk = blocks_for(nbytes, kEvBytesPerBlock), nb = std::max<uint32_t>(1, blocks_for(nblk, kBlock * 4));
+        if ((rc = dev_alloc(c, t.events, (size_t)t.nevents + 1)) || (rc = dev_alloc(c, t.evcnt, (size_t)nblk + 1)) || (rc = dev_alloc(c, t.outoff, (size_t)nblk + 1)) ||
+            (rc = dev_alloc(c, t.bsum, (size_t)nb + 1)))
+            return rc;
+        hipLaunchKernelGGL(text_event_count_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, t.text.p, t.n, t.evcnt.p);
+        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, t.evcnt.p, nblk, t.bsum.p);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, c->stream, t.bsum.p, nb, t.bsum.p + nb);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, t.evcnt.p, nblk, t.bsum.p, t.outoff.p);
+        hipLaunchKernelGGL(text_event_write_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, t.text.p, t.n, t.outoff.p, t.events.p);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+    }
     return COLIBRI_OK;
 }
 
@@ -1824,7 +1840,7 @@ int colibri_text_count(colibri_ctx* c, int rules, uint64_t* nwords, uint64_t* nd
     int            rc;
     const uint64_t cap64 = (uint64_t)t.hinfo.nsegments + (t.hinfo.nsegments >> 1) + 1024;
     t.cap               = (uint32_t)cap64;
-    if ((rc = dev_alloc(c, t.table, t.cap)) || (rc = dev_alloc(c, t.slot_of, (size_t)t.n + 1)) || (rc = dev_alloc(c, t.first, t.cap)) || (rc = dev_alloc(c, t.widx, t.cap)) ||
+    if ((rc = dev_alloc(c, t.table, t.cap)) || (rc = dev_alloc(c, t.slot_of, (size_t)t.nevents + 1)) || (rc = dev_alloc(c, t.first, t.cap)) || (rc = dev_alloc(c, t.widx, t.cap)) ||
         (rc = dev_alloc(c, t.wstart, (size_t)t.hinfo.nsegments + 1)) || (rc = dev_alloc(c, t.wlen, (size_t)t.hinfo.nsegments + 1)) ||
         (rc = dev_alloc(c, t.wcount, (size_t)t.hinfo.nsegments + 1)))
         return rc;
@@ -1837,14 +1853,15 @@ int colibri_text_count(colibri_ctx* c, int rules, uint64_t* nwords, uint64_t* nd
         HIP_TRY(c, hipMemcpyAsync(t.info.p, &reset, sizeof reset, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemsetAsync(t.first.p, 0xFF, sizeof(uint32_t) * t.cap, c->stream));
         hipLaunchKernelGGL(clear_table_kernel, dim3(stream_grid(t.cap)), dim3(kBlock), 0, c->stream, t.table.p, t.state.p);
-        if (t.n) {
-            const KeyWord fn{t.text.p, rules, 0x5851F42D4C957F2Dull * (uint64_t)(attempt + 1)};
+        if (t.nevents) {
+            const KeyWord fn{t.text.p, t.n, t.events.p, rules, 0x5851F42D4C957F2Dull * (uint64_t)(attempt + 1)};
             Prof          p(c, COLIBRI_K_COUNT);
-            hipLaunchKernelGGL((count_kernel<KeyWord>), dim3(std::max<uint32_t>(1, std::min<uint32_t>(blocks_for(t.n, kCountTile), 256u * 3u))), dim3(kBlock), 0, c->stream, fn, t.slot_of.p,
-                               t.table.p, t.state.p, t.n, 1);
-            hipLaunchKernelGGL(text_verify_kernel, dim3(stream_grid(t.n)), dim3(kBlock), 0, c->stream, t.text.p, t.n, rules, t.slot_of.p, t.table.p, t.first.p, t.info.p);
-            hipLaunchKernelGGL(text_words_kernel, dim3(stream_grid(t.cap)), dim3(kBlock), 0, c->stream, t.text.p, t.n, rules, t.table.p, t.cap, t.first.p, t.widx.p, t.wstart.p, t.wlen.p,
-                               t.wcount.p, t.info.p);
+            hipLaunchKernelGGL((count_kernel<KeyWord>), dim3(std::max<uint32_t>(1, std::min<uint32_t>(blocks_for(t.nevents, kCountTile), 256u * 3u))), dim3(kBlock), 0, c->stream, fn,
+                               t.slot_of.p, t.table.p, t.state.p, t.nevents, 1);
+            hipLaunchKernelGGL(text_verify_kernel, dim3(stream_grid(t.nevents)), dim3(kBlock), 0, c->stream, t.text.p, t.n, t.events.p, t.nevents, rules, t.slot_of.p, t.table.p, t.first.p,
+                               t.info.p);
+            hipLaunchKernelGGL(text_words_kernel, dim3(stream_grid(t.cap)), dim3(kBlock), 0, c->stream, t.text.p, t.n, rules, t.events.p, t.table.p, t.cap, t.first.p, t.widx.p, t.wstart.p,
+                               t.wlen.p, t.wcount.p, t.info.p);
         }
         TextInfo got{};
         HIP_TRY(c, hipMemcpyAsync(&got, t.info.p, sizeof got, hipMemcpyDeviceToHost, c->stream));
@@ -1885,9 +1902,9 @@ int colibri_text_encode(colibri_ctx* c, const uint32_t* cls, const uint32_t* rep
     if (t.ndistinct && (!cls || !repeat)) return COLIBRI_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     int            rc;
-    const uint32_t nb = std::max<uint32_t>(1, blocks_for(t.n, kBlock * 4));
-    if ((rc = dev_alloc(c, t.cls, (size_t)t.ndistinct + 1)) || (rc = dev_alloc(c, t.repeat, (size_t)t.ndistinct + 1)) || (rc = dev_alloc(c, t.outlen, (size_t)t.n + 1)) ||
-        (rc = dev_alloc(c, t.outoff, (size_t)t.n + 1)) || (rc = dev_alloc(c, t.bsum, (size_t)nb + 1)))
+    const uint32_t nb = std::max<uint32_t>(1, blocks_for(t.nevents, kBlock * 4));
+    if ((rc = dev_alloc(c, t.cls, (size_t)t.ndistinct + 1)) || (rc = dev_alloc(c, t.repeat, (size_t)t.ndistinct + 1)) || (rc = dev_alloc(c, t.outlen, (size_t)t.nevents + 1)) ||
+        (rc = dev_alloc(c, t.outoff, (size_t)t.nevents + 1)) || (rc = dev_alloc(c, t.bsum, (size_t)nb + 1)))
         return rc;
     if (t.ndistinct) {
         HIP_TRY(c, hipMemcpyAsync(t.cls.p, cls, sizeof(uint32_t) * t.ndistinct, hipMemcpyHostToDevice, c->stream));
@@ -1895,21 +1912,23 @@ int colibri_text_encode(colibri_ctx* c, const uint32_t* cls, const uint32_t* rep
     }
     HIP_TRY(c, hipMemsetAsync(t.ntok.p, 0, sizeof(unsigned long long), c->stream));
     unsigned long long total = 0, ntok = 0;
-    if (t.n) {
+    if (t.nevents) {
         Prof p(c, COLIBRI_K_EXPORT);
-        hipLaunchKernelGGL(text_outlen_kernel, dim3(stream_grid(t.n)), dim3(kBlock), 0, c->stream, t.text.p, t.n, t.slot_of.p, t.widx.p, t.cls.p, t.repeat.p, t.hinfo.after_last_nl,
-                           t.outlen.p, t.ntok.p);
-        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, t.outlen.p, t.n, t.bsum.p);
+        hipLaunchKernelGGL(text_outlen_kernel, dim3(stream_grid(t.nevents)), dim3(kBlock), 0, c->stream, t.text.p, t.events.p, t.nevents, t.slot_of.p, t.widx.p, t.cls.p, t.repeat.p,
+                           t.hinfo.after_last_nl, t.outlen.p, t.ntok.p);
+        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, t.outlen.p, t.nevents, t.bsum.p);
         hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, c->stream, t.bsum.p, nb, t.bsum.p + nb);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, t.outlen.p, t.n, t.bsum.p, t.outoff.p);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, t.outlen.p, t.nevents, t.bsum.p, t.outoff.p);
         HIP_TRY(c, hipMemcpyAsync(&total, t.bsum.p + nb, sizeof total, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(&ntok, t.ntok.p, sizeof ntok, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if ((rc = dev_alloc(c, t.out, (size_t)total + 16))) return rc;
-        hipLaunchKernelGGL(text_write_kernel, dim3(stream_grid(t.n)), dim3(kBlock), 0, c->stream, t.text.p, t.n, t.slot_of.p, t.widx.p, t.cls.p, t.repeat.p, t.outlen.p, t.outoff.p,
+        hipLaunchKernelGGL(text_write_kernel, dim3(stream_grid(t.nevents)), dim3(kBlock), 0, c->stream, t.slot_of.p, t.nevents, t.widx.p, t.cls.p, t.repeat.p, t.outlen.p, t.outoff.p,
                            t.out.p);
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipGetLastError());
+    } else if ((rc = dev_alloc(c, t.out, 16))) {
+        return rc;
     }
     t.outbytes = total;
     t.encoded  = true;

@@ -9,8 +9,10 @@
 // text_verify_kernel compares every occurrence byte-for-byte with its table slot's representative, so that a hash collision is
 // detected (the host then re-runs with another seed) instead of merging two words.
 //
+// All passes walk the *event list* built at upload time — the byte offsets of the segment starts and of the '\n' bytes, in text
+// order (one entry per ~4.4 bytes of English-like text) — instead of every byte offset.
 // Counting reuses count_kernel<KeyFn> (kernels.hpp §2: block-local election for the Zipf head, open-addressed table in HBM), with
-// byte offsets as the "positions". The order in which words first occur — what decides ties between equally frequent words in
+// event indices as the "positions". The order in which words first occur — what decides ties between equally frequent words in
 // the reference, through the iteration order of its unordered_map — is returned per distinct word (first_start).
 #pragma once
 #include "kernels.hpp"
@@ -19,11 +21,24 @@ namespace colibri {
 
 __device__ __forceinline__ bool text_is_sep(uint8_t b) { return b == (uint8_t)' ' || b == (uint8_t)'\n'; }
 
-// segment starting at i -> trimmed word [i, e); false if i starts no word under `rules` (0 = frequency list, 1 = encoder)
-__device__ __forceinline__ bool text_word_at(const uint8_t* __restrict__ text, uint32_t n, uint32_t i, int rules, uint32_t& e) {
-    if (text_is_sep(text[i]) || (i != 0 && !text_is_sep(text[i - 1]))) return false;
-    uint32_t end = i + 1;
-    while (end < n && !text_is_sep(text[end])) ++end;
+// index of the first ' ' or '\n' byte in the 8 little-endian bytes of w (8 if none): SWAR zero-byte test on w ^ pattern
+__device__ __forceinline__ uint32_t text_first_sep8(uint64_t w) {
+    const uint64_t lo = 0x0101010101010101ull, hi = 0x8080808080808080ull;
+    const uint64_t a = w ^ 0x2020202020202020ull, b = w ^ 0x0A0A0A0A0A0A0A0Aull;
+    const uint64_t m = (((a - lo) & ~a) | ((b - lo) & ~b)) & hi;  // bit 7 of every byte at or before the first match is exact; later ones may be false positives
+    return m ? (uint32_t)(__builtin_ctzll(m) >> 3) : 8u;
+}
+// segment starting at i (i is not a separator and follows one or the start of the text) -> trimmed word [i, e); false if the
+// segment is no word under `rules` (0 = frequency list, 1 = encoder). The text buffer is readable 16 bytes past n.
+__device__ __forceinline__ bool text_word_of_segment(const uint8_t* __restrict__ text, uint32_t n, uint32_t i, int rules, uint32_t& e) {
+    // the segment end: 16 bytes in two unaligned loads cover almost every word; longer ones continue 8 bytes at a time
+    uint32_t end = i;
+    for (;;) {
+        const uint32_t k = text_first_sep8(ld64u(text + end));
+        end += k;
+        if (k < 8 || end >= n) break;
+    }
+    if (end > n) end = n;
     if (end - i == 1 && (text[i] == (uint8_t)'\r' || text[i] == (uint8_t)'\t')) {
         // no word — except under the frequency-list rules when the segment is followed by the LAST character of its line and that is
         // a space: the reference then cuts the word as "<segment><space>" (processcorpus :163-167, offset = 1), which passes its
@@ -42,6 +57,11 @@ __device__ __forceinline__ bool text_word_at(const uint8_t* __restrict__ text, u
     e = end;
     return true;
 }
+// the same for an arbitrary byte offset: false unless i starts a segment
+__device__ __forceinline__ bool text_word_at(const uint8_t* __restrict__ text, uint32_t n, uint32_t i, int rules, uint32_t& e) {
+    if (text_is_sep(text[i]) || (i != 0 && !text_is_sep(text[i - 1]))) return false;
+    return text_word_of_segment(text, n, i, rules, e);
+}
 __device__ __forceinline__ uint64_t text_hash(const uint8_t* __restrict__ p, uint32_t len, uint64_t seed) {
     uint64_t h = seed ^ ((uint64_t)len * 0x9E3779B97F4A7C15ull);
     uint32_t k = 0;
@@ -52,12 +72,15 @@ __device__ __forceinline__ uint64_t text_hash(const uint8_t* __restrict__ p, uin
     return h == kEmptyKey ? h ^ 1ull : h;
 }
 struct KeyWord {
-    const uint8_t* text;
-    int            rules;
-    uint64_t       seed;
-    __device__ __forceinline__ bool operator()(uint32_t i, uint32_t npos, uint64_t& key, uint64_t& hash) const {
-        uint32_t e;
-        if (!text_word_at(text, npos, i, rules, e)) return false;
+    const uint8_t*  text;
+    uint32_t        nbytes;
+    const uint32_t* events;  // byte offsets of segment starts and newlines, ascending
+    int             rules;
+    uint64_t        seed;
+    __device__ __forceinline__ bool operator()(uint32_t j, uint32_t /*nevents*/, uint64_t& key, uint64_t& hash) const {
+        const uint32_t i = events[j];
+        uint32_t       e;
+        if (text[i] == (uint8_t)'\n' || !text_word_of_segment(text, nbytes, i, rules, e)) return false;  // a newline event, or a segment that is no word
         key  = text_hash(text + i, e - i, seed);
         hash = mix64(key);
         return true;
@@ -106,55 +129,104 @@ __global__ __launch_bounds__(kBlock) void text_info_kernel(const uint8_t* __rest
         if (c) atomicMax(&info->after_last_nl, c);
     }
 }
+// event list = offsets of segment starts and of '\n' bytes, in order: per-block counts, (scan), ordered write
+constexpr int kEvBytesPerBlock = kBlock * 16;
+__device__ __forceinline__ bool text_is_event(const uint8_t* __restrict__ text, uint32_t i) {
+    const uint8_t b = text[i];
+    return b == (uint8_t)'\n' || (b != (uint8_t)' ' && (i == 0 || text_is_sep(text[i - 1])));
+}
+__global__ __launch_bounds__(kBlock) void text_event_count_kernel(const uint8_t* __restrict__ text, uint32_t n, uint32_t* __restrict__ blockcnt) {
+    const uint32_t base = blockIdx.x * kEvBytesPerBlock + threadIdx.x * 16;
+    uint32_t       c    = 0;
+    for (uint32_t k = 0; k < 16; ++k)
+        if (base + k < n) c += text_is_event(text, base + k);
+    uint32_t total;
+    block_exclusive_scan(c, &total);
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kBlock) void text_event_write_kernel(const uint8_t* __restrict__ text, uint32_t n, const unsigned long long* __restrict__ blockoff,
+                                                                   uint32_t* __restrict__ events) {
+    const uint32_t base = blockIdx.x * kEvBytesPerBlock + threadIdx.x * 16;
+    uint32_t       c = 0, m = 0;
+    for (uint32_t k = 0; k < 16; ++k)
+        if (base + k < n && text_is_event(text, base + k)) {
+            m |= 1u << k;
+            ++c;
+        }
+    uint32_t total;
+    uint32_t o = (uint32_t)blockoff[blockIdx.x] + block_exclusive_scan(c, &total);
+    for (uint32_t k = 0; k < 16; ++k)
+        if (m & (1u << k)) events[o++] = base + k;
+}
 // every occurrence against its slot's representative, byte for byte; first occurrence per slot
-__global__ __launch_bounds__(kBlock) void text_verify_kernel(const uint8_t* __restrict__ text, uint32_t n, int rules, const uint32_t* __restrict__ slot_of,
-                                                              const Slot* __restrict__ table, uint32_t* __restrict__ first, TextInfo* __restrict__ info) {
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const uint32_t s = slot_of[i];
+__global__ __launch_bounds__(kBlock) void text_verify_kernel(const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ events, uint32_t nevents, int rules,
+                                                              const uint32_t* __restrict__ slot_of, const Slot* __restrict__ table, uint32_t* __restrict__ first,
+                                                              TextInfo* __restrict__ info) {
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < nevents; j += gridDim.x * kBlock) {
+        const uint32_t s = slot_of[j];
         if (s == kInvalid) continue;
-        uint32_t e = 0, re = 0;
-        text_word_at(text, n, i, rules, e);
-        const uint32_t r = table[s].rep;
-        bool           same = text_word_at(text, n, r, rules, re) && (re - r) == (e - i);
-        for (uint32_t k = 0; same && k < e - i; ++k) same = text[i + k] == text[r + k];
+        const uint32_t i = events[j], r = events[table[s].rep];
+        uint32_t       e = 0, re = 0;
+        text_word_of_segment(text, n, i, rules, e);
+        bool           same = text_word_of_segment(text, n, r, rules, re) && (re - r) == (e - i);
+        const uint32_t len  = e - i;
+        uint32_t       k    = 0;
+        for (; same && k + 8 <= len; k += 8) same = ld64u(text + i + k) == ld64u(text + r + k);
+        if (same && k < len) {
+            const uint64_t keep = ~0ull >> (8 * (8 - (len - k)));
+            same                = ((ld64u(text + i + k) ^ ld64u(text + r + k)) & keep) == 0;
+        }
         if (!same) info->collision = 1;
-        if (i < first[s]) atomicMin(&first[s], i);  // the plain read spares the hot words' atomics after their first few occurrences
+        if (j < first[s]) atomicMin(&first[s], j);  // the plain read spares the hot words' atomics after their first few occurrences
     }
 }
 // table slots -> distinct word list (any order): first occurrence, byte length, count; widx[slot] = index in that list
-__global__ __launch_bounds__(kBlock) void text_words_kernel(const uint8_t* __restrict__ text, uint32_t n, int rules, const Slot* __restrict__ table, uint32_t cap,
-                                                             const uint32_t* __restrict__ first, uint32_t* __restrict__ widx, uint32_t* __restrict__ wstart,
+__global__ __launch_bounds__(kBlock) void text_words_kernel(const uint8_t* __restrict__ text, uint32_t n, int rules, const uint32_t* __restrict__ events, const Slot* __restrict__ table,
+                                                             uint32_t cap, const uint32_t* __restrict__ first, uint32_t* __restrict__ widx, uint32_t* __restrict__ wstart,
                                                              uint32_t* __restrict__ wlen, uint32_t* __restrict__ wcount, TextInfo* __restrict__ info) {
+    // 4096 slots per tile and reservation (one atomic on a single counter costs ~12 ns whatever else happens)
     __shared__ uint32_t baseL;
-    const uint32_t      ntiles = (cap + kBlock - 1) / kBlock;
+    const uint32_t      ntiles = (cap + kPruneTile - 1) / kPruneTile;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t s    = tile * kBlock + threadIdx.x;
-        const bool     used = s < cap && table[s].key != kEmptyKey;
+        const uint32_t s0 = tile * kPruneTile + threadIdx.x * kPrunePer;
+        uint32_t       used = 0, k = 0;
+#pragma unroll
+        for (int q = 0; q < kPrunePer; ++q)
+            if (s0 + q < cap && table[s0 + q].key != kEmptyKey) {
+                used |= 1u << q;
+                ++k;
+            }
         uint32_t       total;
-        const uint32_t excl = block_exclusive_scan(used ? 1u : 0u, &total);
+        const uint32_t excl = block_exclusive_scan(k, &total);
         if (threadIdx.x == 0) baseL = total ? atomicAdd(&info->ndistinct, total) : 0;
         __syncthreads();
-        if (used) {
-            const uint32_t w = baseL + excl, f = first[s];
+        uint32_t w = baseL + excl;
+#pragma unroll
+        for (int q = 0; q < kPrunePer; ++q) {
+            if (!(used & (1u << q))) continue;
+            const uint32_t s = s0 + q, f = events[first[s]];
             uint32_t       e = f;
-            text_word_at(text, n, f, rules, e);
+            text_word_of_segment(text, n, f, rules, e);
             widx[s]   = w;
             wstart[w] = f;
             wlen[w]   = e - f;
             wcount[w] = table[s].count;
+            ++w;
         }
         __syncthreads();
     }
 }
-// bytes each text position contributes to the encoded stream: a word -> repeat x varint(class), '\n' -> the 00 delimiter
-__global__ __launch_bounds__(kBlock) void text_outlen_kernel(const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ widx,
-                                                              const uint32_t* __restrict__ cls, const uint32_t* __restrict__ repeat, uint32_t limit, uint32_t* __restrict__ outlen,
+// bytes each event contributes to the encoded stream: a word -> repeat x varint(class), '\n' -> the 00 delimiter
+__global__ __launch_bounds__(kBlock) void text_outlen_kernel(const uint8_t* __restrict__ text, const uint32_t* __restrict__ events, uint32_t nevents,
+                                                              const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ widx, const uint32_t* __restrict__ cls,
+                                                              const uint32_t* __restrict__ repeat, uint32_t limit, uint32_t* __restrict__ outlen,
                                                               unsigned long long* __restrict__ ntokens) {
     unsigned long long tok = 0;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        uint32_t len = 0;
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < nevents; j += gridDim.x * kBlock) {
+        const uint32_t i   = events[j];
+        uint32_t       len = 0;
         if (i < limit) {
-            const uint32_t s = slot_of[i];
+            const uint32_t s = slot_of[j];
             if (s != kInvalid) {
                 const uint32_t w = widx[s], r = repeat[w];
                 len = r * varint_len(cls[w]);
@@ -163,17 +235,17 @@ __global__ __launch_bounds__(kBlock) void text_outlen_kernel(const uint8_t* __re
                 len = 1;
             }
         }
-        outlen[i] = len;
+        outlen[j] = len;
     }
     wave_add64(ntokens, tok);
 }
-__global__ __launch_bounds__(kBlock) void text_write_kernel(const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ widx,
-                                                             const uint32_t* __restrict__ cls, const uint32_t* __restrict__ repeat, const uint32_t* __restrict__ outlen,
+__global__ __launch_bounds__(kBlock) void text_write_kernel(const uint32_t* __restrict__ slot_of, uint32_t nevents, const uint32_t* __restrict__ widx, const uint32_t* __restrict__ cls,
+                                                             const uint32_t* __restrict__ repeat, const uint32_t* __restrict__ outlen,
                                                              const unsigned long long* __restrict__ outoff, uint8_t* __restrict__ out) {
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        if (outlen[i] == 0) continue;
-        uint8_t*       dst = out + outoff[i];
-        const uint32_t s   = slot_of[i];
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < nevents; j += gridDim.x * kBlock) {
+        if (outlen[j] == 0) continue;
+        uint8_t*       dst = out + outoff[j];
+        const uint32_t s   = slot_of[j];
         if (s == kInvalid) {
             dst[0] = 0;  // '\n'
             continue;

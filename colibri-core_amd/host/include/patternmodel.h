@@ -199,6 +199,9 @@ class PatternModel : public MapType, public PatternModelInterface {
     unsigned char type() const { return model_type; }
     unsigned char version() const { return model_version; }
     bool          hasskipgrams() const { return hasskipgrams_; }
+    /** what the reference's constrained in-place rebuild leaves in the type count: the number of patterns the model was loaded with
+     *  (it takes "total word types prior to pruning" from a map that already holds every pattern, patternmodel.h:1197-1201) */
+    void settypes_inplace_rebuild() { totaltypes = this->size(); }
 
     ValueType* getdata(const Pattern& pattern, bool makeifnew = false) {
         typename MapType::iterator it = this->find(pattern);

@@ -1,7 +1,7 @@
 // colibri-patternmodeller (MI355X build) — a drop-in for the reference's command-line driver on the accelerated path.
 // Same flags and flag meanings as reference src/patternmodeller.cpp:404-858 for: -f -c -o -i -u -t -l -m -b -W -s -y -T -P -R -r -H -e -D -h
-// (build a model from a .colibri.dat, save it, load a model, print / report / histogram). Flags that select paths outside the
-// accelerated subset (-j -I -2 -E -F -L -M -p -Q -q -g ...) are reported and rejected instead of being silently ignored.
+// (build a model from a .colibri.dat, save it, load a model, print / report / histogram), plus -2 (two-stage build). Flags that
+// select paths outside the accelerated subset (-j -I -E -F -L -M -p -Q -q -g ...) are reported and rejected instead of being silently ignored.
 // All counting happens in libcolibri_hip.so; this file only parses options and calls the C++ face.
 #include <getopt.h>
 
@@ -32,6 +32,7 @@ void usage() {
                  "\t-y|--skipthreshold <n>      occurrence threshold for skipgrams\n"
                  "\t-T|--skiptypes <n>          skip type threshold (default 2)\n"
                  "\t-e|--expand <n>             sentence offset given to the first sentence\n"
+                 "\t-2|--twostage               two-stage build of an indexed model (needs -o): same result as the reference's -2\n"
                  " Viewing:\n"
                  "\t-P|--print   -R|--report   -r|--simplereport   -H|--histogram\n"
                  "\t-D|--debug   -h|--help\n";
@@ -65,7 +66,7 @@ int run(ModelType& model, const std::string& corpusfile, const std::string& inpu
 int main(int argc, char** argv) {
     std::string         corpusfile, classfile, inputmodel, outputmodel;
     PatternModelOptions options;
-    bool                unindexed = false, doprint = false, doreport = false, nocoverage = false, dohistogram = false;
+    bool                unindexed = false, doprint = false, doreport = false, nocoverage = false, dohistogram = false, twostage = false;
     uint32_t            firstsentence = 1;
     static struct option longopts[] = {{"datafile", required_argument, 0, 'f'},    {"classfile", required_argument, 0, 'c'},      {"inputmodel", required_argument, 0, 'i'},
                                        {"outputmodel", required_argument, 0, 'o'}, {"threshold", required_argument, 0, 't'},      {"unindexed", no_argument, 0, 'u'},
@@ -73,9 +74,10 @@ int main(int argc, char** argv) {
                                        {"wordthreshold", required_argument, 0, 'W'}, {"skipgrams", no_argument, 0, 's'},          {"skipthreshold", required_argument, 0, 'y'},
                                        {"skiptypes", required_argument, 0, 'T'},   {"expand", required_argument, 0, 'e'},         {"print", no_argument, 0, 'P'},
                                        {"report", no_argument, 0, 'R'},            {"simplereport", no_argument, 0, 'r'},         {"histogram", no_argument, 0, 'H'},
-                                       {"debug", no_argument, 0, 'D'},             {"help", no_argument, 0, 'h'},                 {0, 0, 0, 0}};
+                                       {"debug", no_argument, 0, 'D'},             {"help", no_argument, 0, 'h'},                 {"twostage", no_argument, 0, '2'},
+                                       {0, 0, 0, 0}};
     int c;
-    while ((c = getopt_long(argc, argv, "f:c:i:o:t:ul:m:b:W:sy:T:e:PRrHDhj:I2EF:LMp:Qq:gZV", longopts, NULL)) != -1) {
+    while ((c = getopt_long(argc, argv, "f:c:i:o:t:ul:m:b:W:sy:T:e:PRrHDh2j:IEF:LMp:Qq:gZV", longopts, NULL)) != -1) {
         switch (c) {
             case 'f': corpusfile = optarg; break;
             case 'c': classfile = optarg; break;
@@ -99,6 +101,7 @@ int main(int argc, char** argv) {
                 break;
             case 'H': dohistogram = true; break;
             case 'D': options.DEBUG = true; break;
+            case '2': twostage = true; break;
             case 'h': usage(); return 0;
             default:
                 std::cerr << "ERROR: option -" << (char)(c == '?' ? optopt : c) << " selects a path that is not part of the MI355X-accelerated build (see DESIGN.md, out of scope)" << std::endl;
@@ -128,6 +131,36 @@ int main(int argc, char** argv) {
             }
             PatternModel<uint32_t> model;
             return run(model, corpusfile, inputmodel, outputmodel, options, firstsentence, doprint, doreport, nocoverage, dohistogram, decoder);
+        }
+        if (twostage && inputmodel.empty()) {
+            // The reference builds an unindexed model first (<out>.stage1) and then an indexed one constrained by it, to bound its memory
+            // (src/patternmodeller.cpp:627-663, :756-831). Here the indexed model is built directly — the device holds the forward index
+            // anyway — and the observable result of the reference's second stage is reproduced: the same patterns and references, no
+            // skipgrams even with -s, and a type count equal to the number of patterns (goldens: ref_driver train ... i2).
+            if (outputmodel.empty()) {
+                std::cerr << "ERROR: An output model file (--outputmodel) is mandatory for two-stage building!" << std::endl;
+                return 2;
+            }
+            std::cerr << "********* STARTING STAGE 1/2: Building intermediary unindexed patternmodel ******" << std::endl;
+            PatternModelOptions stage1 = options;
+            stage1.DOSKIPGRAMS = stage1.DOSKIPGRAMS_EXHAUSTIVE = false;
+            {
+                PatternModel<uint32_t> m1;
+                m1.train(corpusfile, stage1, NULL, NULL, false, firstsentence);
+                m1.write(outputmodel + ".stage1");
+            }
+            std::cerr << "********* STARTING STAGE 2/2: Building indexed patternmodel ******" << std::endl;
+            IndexedCorpus         corpus(corpusfile);
+            IndexedPatternModel<> model(&corpus);
+            model.train(corpusfile, stage1, NULL, NULL, false, firstsentence);
+            model.settypes_inplace_rebuild();
+            std::cerr << "Writing model to " << outputmodel << std::endl;
+            model.write(outputmodel);
+            std::cerr << "Generating desired views..." << std::endl;
+            if (doprint && decoder != NULL) model.print(std::cout, *decoder);
+            if (doreport) model.report(std::cout, nocoverage);
+            if (dohistogram) model.histogram(std::cout);
+            return 0;
         }
         if (inputmodel.empty()) {
             IndexedCorpus         corpus(corpusfile);  // indexed models are built on a loaded corpus (reference :735-737)

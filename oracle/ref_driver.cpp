@@ -91,11 +91,11 @@ int usage() {
                  "      U  = unindexed, corpus preloaded in an IndexedCorpus (benchmarks.cpp test 5)\n"
                  "      us = unindexed + exhaustive skipgrams (preloaded corpus)\n"
                  "      i  = indexed (preloaded corpus);  is = indexed + skipgrams\n"
+                 "      i2 / is2 = the same through the two-stage build of patternmodeller -2 (unindexed stage 1, constrained in-place stage 2)\n"
                  "  ref_driver load <model.colibri.patternmodel> <u|i> <dump.txt>\n"
                  "  ref_driver encode <text> <outprefix> [-t threshold] [-c classfile] [-e] [-U]\n"
                  "  ref_driver view <model> <u|i> <print|report|simplereport|histogram|info> <classfile>\n"
                  "  ref_driver hash <hex> [<hex> ...]\n"
-                 "  ref_driver encode <text file> <out prefix>\n"
                  "  ref_driver masks <n> <maxskips>\n";
     return 2;
 }
@@ -267,6 +267,32 @@ int main(int argc, char** argv) {
         types  = model.types();
         if (!modelout.empty()) model.write(modelout);
         if (!dumpout.empty()) collect_indexed(model, rows);
+    } else if (mode == "i2" || mode == "is2") {
+        // two-stage build as colibri-patternmodeller -2 does it (reference src/patternmodeller.cpp:627-663, :756-831): stage 1 an
+        // unindexed model written to <tmp>.stage1, stage 2 an indexed model loaded from it (DORESET) and rebuilt in place, constrained by itself
+        const std::string stage1 = (modelout.empty() ? dumpout : modelout) + ".stage1";
+        IndexedCorpus     corpus(corpusfile);
+        {
+            PatternModelOptions o1 = options;
+            o1.DOSKIPGRAMS         = false;
+            PatternModel<uint32_t> m1(&corpus);
+            m1.train(corpusfile, o1);
+            m1.write(stage1);
+        }
+        if (mode == "is2") options.DOSKIPGRAMS = true;
+        PatternModelOptions optionscopy = PatternModelOptions(options);
+        optionscopy.DORESET             = true;
+        IndexedPatternModel<> model(stage1, optionscopy, NULL, &corpus);
+        if (model.maxlength() > options.MAXLENGTH) options.MAXLENGTH = model.maxlength();
+        if (model.minlength() < options.MINLENGTH) options.MINLENGTH = model.minlength();
+        auto t0 = clk::now();
+        model.train(corpusfile, options, model.getinterface());
+        train_s = std::chrono::duration<double>(clk::now() - t0).count();
+        tokens  = model.tokens();
+        types   = model.types();
+        if (!modelout.empty()) model.write(modelout);
+        if (!dumpout.empty()) collect_indexed(model, rows);
+        std::remove(stage1.c_str());
     } else {
         return usage();
     }

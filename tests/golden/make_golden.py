@@ -96,6 +96,11 @@ def main():
         if mode == "is" and not reference_is_dump_is_stable(out, 1 if extra else 2, l):
             unstable.append(os.path.basename(out))
             os.remove(out)
+    # two-stage build (patternmodeller -2): what the reference's constrained in-place second stage leaves (with and without -s)
+    for name in ["hamlet.v2", "zipf20k"]:
+        for mode in ("i2", "is2"):
+            out = os.path.join(HERE, f"{name}.{mode}.l5.txt")
+            subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{name}.colibri.dat"), mode, "5", "2", "-q", "-d", out], stdout=subprocess.DEVNULL)
     with open(os.path.join(HERE, "unstable_reference_outputs.json"), "w") as f:
         json.dump({"note": "indexed+skipgram dumps of the reference that were NOT kept because the reference's insert-while-iterating "
                            "hazard (patternmodel.h:2986-2991) corrupted them (self-consistency check in make_golden.py)", "dropped": unstable}, f, indent=1)

@@ -132,3 +132,25 @@ def test_cli_indexed_and_skipgram_models_reference_can_load(tmp_path, corpus, fl
         subprocess.check_call([oracle.REF_DRIVER, "load", model, "i" if indexed else "u", dump])
         got = oracle.parse_dump(open(dump).read(), indexed=indexed)
         assert (got.tokens, got.types, got.counts, got.refs) == (want.tokens, want.types, want.counts, want.refs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("corpus,flags,tag", [("hamlet.v2", [], "i2"), ("hamlet.v2", ["-s"], "is2"), ("zipf20k", [], "i2"), ("zipf20k", ["-s"], "is2")])
+def test_cli_two_stage_build_matches_the_references(tmp_path, corpus, flags, tag):
+    """colibri-patternmodeller -2 [-s]: the model the reference's two-stage build leaves (goldens by ref_driver train ... i2 / is2): the
+    indexed n-grams with their references, no skipgrams, and a type count equal to the number of patterns; <out>.stage1 is the unindexed model."""
+    import oracle
+    model = str(tmp_path / "m.colibri.patternmodel")
+    out = subprocess.run([CLI, "-f", os.path.join(GOLDEN, corpus + ".colibri.dat"), "-2", "-t", "2", "-l", "5", "-o", model] + flags, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    want = oracle.parse_dump(open(os.path.join(GOLDEN, f"{corpus}.{tag}.l5.txt")).read(), indexed=True)
+    mtype, tokens, types, counts, refs = parse_model(model)
+    assert (mtype, tokens, types) == (20, want.tokens, want.types)
+    assert counts == want.counts and refs == want.refs
+    s1 = parse_model(model + ".stage1")
+    assert s1[0] == 10 and s1[3] == want.counts
+
+
+def test_cli_two_stage_needs_an_output_model():
+    out = subprocess.run([CLI, "-f", os.path.join(GOLDEN, "hamlet.v2.colibri.dat"), "-2"], capture_output=True, text=True)
+    assert out.returncode == 2 and "mandatory for two-stage building" in out.stderr

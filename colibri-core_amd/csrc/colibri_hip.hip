@@ -19,6 +19,7 @@
 #include "colibri_hip.h"
 #include "binned.hpp"
 #include "textenc.hpp"
+#include "constrained.hpp"
 #include "kernels.hpp"
 
 using namespace colibri;
@@ -74,6 +75,14 @@ struct colibri_ctx {
     DevBuf<Rec>       recs[2];          // binned path: record ping-pong
     DevBuf<uint32_t>  rep_of, ids_at;   // binned path: representative position per window; survivor id at representative positions
     DevBuf<uint8_t>   flags_at, flag2;  // flag mode of order 2 (KeyTrigramCls): survivor byte at representative positions / per position
+    struct ConstraintSet {              // constrained training (constrained.hpp): the pattern set J and its lookup table
+        DevBuf<uint8_t>            bytes;
+        DevBuf<unsigned long long> off;
+        DevBuf<CSlot>              table;
+        DevBuf<uint32_t>           rem;    // tokens left in the sentence per position (built per corpus)
+        uint32_t                   n = 0, cap = 0;
+        bool                       rem_valid = false;
+    } cs;
     struct TextState {                  // class encoder (textenc.hpp): the uploaded text, its word table, the encoded stream
         DevBuf<uint8_t>            text, out;
         DevBuf<uint32_t>           slot_of, first, widx, wstart, wlen, wcount, cls, repeat, outlen, events, evcnt;
@@ -254,6 +263,7 @@ int tokenise(colibri_ctx* c) {
     HIP_TRY(c, hipMemcpyAsync(&npos, total.p, sizeof npos, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->npos = npos;
+    c->cs.rem_valid = false;  // per-position sentence remainders belong to the previous corpus
     if ((rc = dev_alloc(c, c->tokstart, (size_t)npos + 2)) || (rc = dev_alloc(c, c->cls, (size_t)npos + 1))) {
         cleanup();
         return rc;
@@ -342,8 +352,12 @@ int check_options(colibri_ctx* c, colibri_options& o) {
     if (o.mintokens == 0) o.mintokens = 1;
     if (o.mintokens_skipgrams < o.mintokens) o.mintokens_skipgrams = o.mintokens;  // :887-888
     if (o.maxlength < 1) return fail(c, COLIBRI_ERR_ARG, "MAXLENGTH must be >= 1");
-    if (o.mintokens < 2) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINTOKENS=1 (single-pass, no look-back) is not on the accelerated path");
-    if (o.minlength > 1) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINLENGTH>1 is not on the accelerated path");
+    const bool constrained = c->cs.n != 0;  // a constraint set makes the run single-pass by definition: every threshold and minimum length is fine
+    if (constrained && (o.doskipgrams || o.doskipgrams_exhaustive)) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams in a constrained run are not on the accelerated path");
+    if (o.minlength < 1) o.minlength = 1;
+    if (o.mintokens < 2 && !constrained) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINTOKENS=1 (single-pass, no look-back) is not on the accelerated path");
+    if (o.minlength > 1 && !constrained) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINLENGTH>1 is not on the accelerated path");
+    if (o.minlength > o.maxlength) return fail(c, COLIBRI_ERR_ARG, "MINLENGTH > MAXLENGTH");
     if (o.maxbackofflength < o.maxlength) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MAXBACKOFFLENGTH < MAXLENGTH is not on the accelerated path");
     if (o.mintokens_unigrams > o.mintokens) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINTOKENS_UNIGRAMS > MINTOKENS is not on the accelerated path");
     if (o.dopatternperline || o.prunenonsubsumed || o.prunesubsumed)
@@ -412,6 +426,7 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->flags_at);
     dev_free(c->tx.text); dev_free(c->tx.out); dev_free(c->tx.slot_of); dev_free(c->tx.first); dev_free(c->tx.widx); dev_free(c->tx.wstart); dev_free(c->tx.wlen);
     dev_free(c->tx.wcount); dev_free(c->tx.cls); dev_free(c->tx.repeat); dev_free(c->tx.outlen); dev_free(c->tx.outoff); dev_free(c->tx.bsum); dev_free(c->tx.ntok);
+    dev_free(c->cs.bytes); dev_free(c->cs.off); dev_free(c->cs.table); dev_free(c->cs.rem);
     dev_free(c->tx.table); dev_free(c->tx.state); dev_free(c->tx.info); dev_free(c->tx.events); dev_free(c->tx.evcnt);
     dev_free(c->flag2);
     dev_free(c->ids_at);
@@ -857,7 +872,8 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     c->npairs = 0;
 
     const uint32_t npos   = c->npos;
-    const bool     synced = o.indexed || o.doskipgrams || o.doskipgrams_exhaustive;  // these modes keep every order's ids and talk to the host per order
+    const bool     constrained = c->cs.n != 0;  // train(..., constrainbymodel): one membership-filtered pass per length, no look-back (constrained.hpp)
+    const bool     synced = o.indexed || o.doskipgrams || o.doskipgrams_exhaustive || constrained;  // these modes keep every order's ids and talk to the host per order
     // radix-partition + LDS count (binned.hpp) for the plain n-gram path when every final bin fits its LDS table: 65 536 bins
     // x <= ~1000 distinct keys expected; beyond ~128 M tokens per device (or on request) the global open-addressed table is used
     bool binned = !synced && (o.table_mode == 2 || (o.table_mode == 0 && c->ntokens <= 128ull * 1000 * 1000));
@@ -1002,10 +1018,22 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
         std::vector<uint32_t> valid_n(maxlength + 2, 0), adm_n(maxlength + 2, 0);
         uint32_t              res_total = 0;
         const uint32_t        thr_skip  = o.minskiptypes > 1 ? (uint32_t)o.mintokens_skipgrams : pl.thr;  // base pruneskipgrams is a no-op when MINSKIPTYPES <= 1 (patternmodel.h:2167-2186)
-        for (int n = 1; n <= maxlength && !c->hstate.done; ++n) {
+        if (constrained) {
+            if (!c->cs.rem_valid) {
+                if ((rc = dev_alloc(c, c->cs.rem, (size_t)npos + 1))) return rc;
+                hipLaunchKernelGGL(sentence_rem_kernel, dim3(stream_grid(npos)), dim3(kBlock), 0, c->stream, c->delimpos.p, c->ndelim, npos, c->cs.rem.p);
+                c->cs.rem_valid = true;
+            }
+            // a length's distinct keys are patterns of J: the table never needs more slots than that
+            c->hstate.cap = (uint32_t)std::min<uint64_t>(pl.table_slots, (uint64_t)c->cs.n + (c->cs.n >> 1) + 1024u);
+            if ((rc = write_state(c))) return rc;
+        }
+        for (int n = constrained ? std::max(1, o.minlength) : 1; n <= maxlength && !c->hstate.done; ++n) {
             if ((rc = dev_alloc(c, c->ids[n], (size_t)npos + 1))) return rc;
             launch_clear(c, pl);
-            if (n == 1)
+            if (constrained)
+                launch_count(c, pl, KeyConstrained{c->bytes.p, c->tokstart.p, c->cs.rem.p, c->cs.table.p, c->cs.cap, c->cs.bytes.p, c->cs.off.p, n}, c->ids[n].p, 3, COLIBRI_K_COUNT);
+            else if (n == 1)
                 launch_count(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, c->ids[n].p, 3, COLIBRI_K_COUNT);
             else
                 launch_count(c, pl, KeyNgram{c->ids[n - 1].p, n}, c->ids[n].p, 3, COLIBRI_K_COUNT);
@@ -1016,8 +1044,8 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             adm_n[n]   = c->hstate.admitted;
             valid_n[n] = c->hstate.valid;
             s.admitted[n] = adm_n[n];
-            if (found == 0) break;  // "None found" (patternmodel.h:1189-1194)
-            s.maxn     = n;
+            if (found == 0 && !constrained) break;  // "None found" (patternmodel.h:1189-1194); a constrained run is one pass over all lengths
+            if (found) s.maxn = n;
             s.found[n] = found;
             s.kept[n]  = kept;
             if (kept) c->segments.push_back({res_total, kept, n, 0u});
@@ -1037,10 +1065,10 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                 }
             }
             // next order
-            c->hstate.cap   = (uint32_t)std::min<uint64_t>(pl.table_slots, (uint64_t)valid_n[n] + (valid_n[n] >> 1) + 1024u);
+            if (!constrained) c->hstate.cap = (uint32_t)std::min<uint64_t>(pl.table_slots, (uint64_t)valid_n[n] + (valid_n[n] >> 1) + 1024u);
             c->hstate.found = c->hstate.kept = c->hstate.admitted = c->hstate.valid = 0;
             if ((rc = write_state(c))) return rc;
-            if (valid_n[n] == 0) break;  // nothing can be admitted at n + 1
+            if (valid_n[n] == 0 && !constrained) break;  // nothing can be admitted at n + 1
         }
         if (o.doskipgrams) {  // IndexedPatternModel::trainskipgrams (patternmodel.h:2969-3010): from the SURVIVING n-grams, n = 3..
             for (int n = 3; n <= std::min<int>(maxlength, s.maxn); ++n) {
@@ -1079,7 +1107,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
         s.pruned[n] = s.found[n] - s.kept[n];
         s.windows[n] = (n <= o.maxlength) ? c->windows_n[n] : 0;
     }
-    s.totaltypes = s.found[1];  // distinct unigrams before pruning (patternmodel.h:1199-1201)
+    s.totaltypes = constrained ? 0 : s.found[1];  // distinct unigrams before pruning (patternmodel.h:1199-1201); a constrained run leaves it unset (:1197: constrainbymodel != NULL)
     c->trained   = true;
     c->keybytes  = 0;
 
@@ -1790,6 +1818,30 @@ int colibri_shard_export_index(colibri_ctx* c, uint32_t* gids, uint64_t* ref_off
         HIP_TRY(c, hipMemcpy(ref_sentence, c->ref_sentence.p, sizeof(uint32_t) * N, hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(ref_token, c->ref_token.p, sizeof(uint16_t) * N, hipMemcpyDeviceToHost));
     }
+    return COLIBRI_OK;
+}
+
+// constrained training (constrained.hpp): the pattern set the next colibri_train calls are restricted to
+int colibri_set_constraint(colibri_ctx* c, const uint64_t* key_off, const uint8_t* key_bytes, uint64_t npatterns) {
+    if (!c) return COLIBRI_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto& cs = c->cs;
+    cs.n     = 0;
+    if (npatterns == 0) return COLIBRI_OK;
+    if (!key_off || !key_bytes) return COLIBRI_ERR_ARG;
+    if (npatterns >= 0x7FFFFFF0ull) return fail(c, COLIBRI_ERR_OVERFLOW, "constraint set too large");
+    int            rc;
+    const uint64_t nbytes = key_off[npatterns];
+    const uint64_t cap64  = 2 * npatterns + 1024;
+    if ((rc = dev_alloc(c, cs.bytes, (size_t)nbytes + 16)) || (rc = dev_alloc(c, cs.off, (size_t)npatterns + 1)) || (rc = dev_alloc(c, cs.table, (size_t)cap64))) return rc;
+    cs.cap = (uint32_t)cap64;
+    HIP_TRY(c, hipMemcpyAsync(cs.bytes.p, key_bytes, nbytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(cs.off.p, key_off, sizeof(uint64_t) * (npatterns + 1), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(constraint_clear_kernel, dim3(stream_grid(cs.cap)), dim3(kBlock), 0, c->stream, cs.table.p, cs.cap);
+    hipLaunchKernelGGL(constraint_insert_kernel, dim3(stream_grid(npatterns)), dim3(kBlock), 0, c->stream, cs.bytes.p, cs.off.p, (uint32_t)npatterns, cs.table.p, cs.cap);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    cs.n = (uint32_t)npatterns;
     return COLIBRI_OK;
 }
 

@@ -71,6 +71,8 @@ class PatternModelInterface {
     virtual int          minlength() const                          = 0;
     virtual unsigned int types()                                    = 0;
     virtual unsigned int tokens() const                             = 0;
+    /** (this build) the keys of all patterns, for installing the model as a device-side constraint set; false = cannot enumerate */
+    virtual bool collect_keys(std::vector<uint64_t>&, std::vector<unsigned char>&) { return false; }
 };
 
 namespace colibri_host {
@@ -89,8 +91,13 @@ struct TrainResult {
 
 /** whole corpus file -> v2 payload (header stripped; v1 data converted, reference src/classencoder.cpp:602-647) */
 std::vector<unsigned char> read_corpus_payload(std::istream& in);
+/** the keys a run is constrained to (colibri_set_constraint), or NULL */
+struct ConstraintKeys {
+    std::vector<uint64_t>      off;
+    std::vector<unsigned char> bytes;
+};
 /** upload + train + export through the C ABI; prints the library's message on stderr and throws InternalError on any status != 0 */
-void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out);
+void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out, const ConstraintKeys* constraint = NULL);
 /** the per-order progress lines the reference prints while training (patternmodel.h:1005-1019, :1195-1245) */
 void print_training_log(const colibri_stats& s, const colibri_options& o, std::ostream& err);
 /** the tokens of a key as byte strings, gaps included (what the reference's pattern.ngrams(…, 1) yields, src/pattern.cpp:1284-1296) */
@@ -203,6 +210,21 @@ class PatternModel : public MapType, public PatternModelInterface {
      *  (it takes "total word types prior to pruning" from a map that already holds every pattern, patternmodel.h:1197-1201) */
     void settypes_inplace_rebuild() { totaltypes = this->size(); }
 
+    bool collect_keys(std::vector<uint64_t>& off, std::vector<unsigned char>& bytes) override {
+        off.assign(1, 0);
+        bytes.clear();
+        if (result) {  // device results not materialised yet: their flat arrays are exactly what is wanted
+            off   = result->key_off;
+            bytes = result->key_bytes;
+            return true;
+        }
+        for (typename MapType::iterator it = this->begin(); it != this->end(); ++it) {
+            const size_t n = it->first.bytesize();
+            bytes.insert(bytes.end(), it->first.data, it->first.data + n);
+            off.push_back(bytes.size());
+        }
+        return true;
+    }
     ValueType* getdata(const Pattern& pattern, bool makeifnew = false) {
         typename MapType::iterator it = this->find(pattern);
         if (it != this->end()) return &(it->second);
@@ -243,9 +265,37 @@ class PatternModel : public MapType, public PatternModelInterface {
         if (options.MINTOKENS == 0) options.MINTOKENS = 1;
         if (options.MINTOKENS_SKIPGRAMS < options.MINTOKENS) options.MINTOKENS_SKIPGRAMS = options.MINTOKENS;
         if (filter != NULL && filter->size() == 0) filter = NULL;  // cython passes empty sets (reference :902-903)
-        if (constrainbymodel != NULL || filter != NULL || continued) {
-            std::cerr << "ERROR: training constrained by another model, with a filter, or continued on a preloaded model is not on the MI355X-accelerated path" << std::endl;
+        if (filter != NULL || continued) {
+            std::cerr << "ERROR: training with a filter, or continued on a preloaded model, is not on the MI355X-accelerated path" << std::endl;
             throw InternalError();
+        }
+        // Constrained training (reference :1062-1072, :1088-1089): one pass over all lengths, a window counts iff the constraint model has it.
+        // The keys of the constraint model become a device-side set (colibri_set_constraint). constrainbymodel == this is the in-place
+        // rebuild of patternmodeller -I / -2: the model's own patterns are the constraint, then it is emptied and rebuilt.
+        const bool                   inplace = constrainbymodel == (PatternModelInterface*)this;
+        colibri_host::ConstraintKeys ck;
+        uint64_t                     constraint_tokens = 0, constraint_types = 0, loaded_patterns = 0;
+        if (constrainbymodel != NULL) {
+            if (options.DOSKIPGRAMS || options.DOSKIPGRAMS_EXHAUSTIVE) {
+                std::cerr << "ERROR: skipgrams in a constrained run are not on the MI355X-accelerated path" << std::endl;
+                throw InternalError();
+            }
+            if (!constrainbymodel->collect_keys(ck.off, ck.bytes)) {
+                std::cerr << "ERROR: the constraint model cannot enumerate its patterns; pass a PatternModel / PatternSetModel of this build" << std::endl;
+                throw InternalError();
+            }
+            if (inplace) {
+                loaded_patterns = this->size();
+                this->data.clear();
+                result.reset();
+                this->pending_fill = nullptr;
+                this->pending_size = nullptr;
+                maxn = 0;
+                minn = 999;
+            } else {
+                constraint_tokens = constrainbymodel->tokens();  // the reference starts its totals from the constraint model's (:892-895)
+                constraint_types  = constrainbymodel->types();
+            }
         }
         if (!this->data.empty() || result) {
             std::cerr << "ERROR: train() on a non-empty model is not on the MI355X-accelerated path" << std::endl;
@@ -271,14 +321,14 @@ class PatternModel : public MapType, public PatternModelInterface {
 
         std::shared_ptr<colibri_host::TrainResult> r = std::make_shared<colibri_host::TrainResult>();
         if (reverseindex != NULL && !reverseindex->empty()) {
-            colibri_host::device_train(reverseindex->beginpointer(), reverseindex->bytesize(), o, firstsentence, *r);
+            colibri_host::device_train(reverseindex->beginpointer(), reverseindex->bytesize(), o, firstsentence, *r, constrainbymodel ? &ck : NULL);
         } else if (in != NULL) {
             const std::vector<unsigned char> payload = colibri_host::read_corpus_payload(*in);
             if (payload.empty()) {
                 std::cerr << "ERROR: Attempting to read pattern from file, but file is empty?" << std::endl;  // reference src/pattern.cpp:520-523
                 throw InternalError();
             }
-            colibri_host::device_train(payload.data(), payload.size(), o, firstsentence, *r);
+            colibri_host::device_train(payload.data(), payload.size(), o, firstsentence, *r, constrainbymodel ? &ck : NULL);
         } else {
             std::cerr << "ERROR: No input stream and no reverse index (preloaded corpus) to train on" << std::endl;
             throw InternalError();
@@ -286,6 +336,25 @@ class PatternModel : public MapType, public PatternModelInterface {
         if (!options.QUIET) colibri_host::print_training_log(r->stats, o, std::cerr);
         totaltokens   = r->stats.totaltokens;
         totaltypes    = r->stats.totaltypes;
+        if (constrainbymodel != NULL) {
+            if (inplace) {
+                // "total word types prior to pruning" is taken from a map that still holds every loaded pattern (:1197-1205): their number when
+                // MINTOKENS > 1, the word types among the loaded unigrams when MINTOKENS == 1 (and MINLENGTH == 1), else left to types()
+                if (options.MINTOKENS > 1) {
+                    totaltypes = loaded_patterns;
+                } else if (options.MINLENGTH == 1) {
+                    uint64_t unigrams = 0;
+                    for (size_t k = 0; k + 1 < ck.off.size(); ++k)
+                        unigrams += colibri_host::token_count(ck.bytes.data() + ck.off[k], (size_t)(ck.off[k + 1] - ck.off[k])) == 1;
+                    totaltypes = unigrams;
+                } else {
+                    totaltypes = 0;
+                }
+            } else {
+                totaltokens += constraint_tokens;  // the corpus' tokens are added to the constraint model's total (:894, :1047-1048)
+                totaltypes = constraint_types;
+            }
+        }
         if (r->stats.maxn > maxn) maxn = r->stats.maxn;
         if (r->stats.npatterns && r->stats.minn < minn) minn = r->stats.minn;
         hasskipgrams_ = (options.DOSKIPGRAMS || options.DOSKIPGRAMS_EXHAUSTIVE);
@@ -652,6 +721,15 @@ class PatternModel : public MapType, public PatternModelInterface {
             first = false;
         }
     }
+};
+
+/** The patterns of a model file as a set — what the reference loads a constraint model as (include/patternmodel.h:283-530; colibri-patternmodeller -j,
+ *  src/patternmodeller.cpp:712-718). Here it is an unindexed model whose values are not looked at. */
+class PatternSetModel : public PatternModel<uint32_t> {
+  public:
+    PatternSetModel() : PatternModel<uint32_t>() {}
+    PatternSetModel(const std::string& filename, const PatternModelOptions& options, PatternModelInterface* constrainmodel = NULL) : PatternModel<uint32_t>(filename, options, constrainmodel) {}
+    int getmodeltype() const override { return PATTERNSETMODEL; }
 };
 
 /** Indexed model: pattern -> sorted list of (sentence, token). reference include/patternmodel.h:2682-3875. */

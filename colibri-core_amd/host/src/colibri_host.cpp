@@ -338,12 +338,31 @@ struct CtxGuard {
 }
 }  // namespace
 
-void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out) {
+void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out, const ConstraintKeys* constraint) {
     CtxGuard    g;
     const char* dev = std::getenv("COLIBRI_DEVICE");
     int         rc  = colibri_create(&g.c, dev ? std::atoi(dev) : 0);
     if (rc != COLIBRI_OK) raise(nullptr, rc, "colibri_create");
     if ((rc = colibri_upload_corpus(g.c, payload, nbytes, firstsentence)) != COLIBRI_OK) raise(g.c, rc, "colibri_upload_corpus");
+    if (constraint != NULL) {
+        const uint64_t np = constraint->off.empty() ? 0 : constraint->off.size() - 1;
+        if (np == 0) {  // nothing can be a member: the model stays empty, the totals are still the corpus'
+            colibri_options plain = opt;
+            if (plain.mintokens < 2) plain.mintokens = 2;
+            plain.minlength = 1;
+            plain.maxlength = 1;
+            if ((rc = colibri_train(g.c, &plain, &out.stats)) != COLIBRI_OK) raise(g.c, rc, "colibri_train");
+            out.stats.npatterns = 0;
+            out.stats.totaltypes = 0;
+            out.key_off.assign(1, 0);
+            out.key_bytes.assign(1, 0);
+            out.counts.clear();
+            out.ref_off.assign(1, 0);
+            return;
+        }
+        static const unsigned char none = 0;
+        if ((rc = colibri_set_constraint(g.c, constraint->off.data(), constraint->bytes.empty() ? &none : constraint->bytes.data(), np)) != COLIBRI_OK) raise(g.c, rc, "colibri_set_constraint");
+    }
     if ((rc = colibri_train(g.c, &opt, &out.stats)) != COLIBRI_OK) raise(g.c, rc, "colibri_train");
     uint64_t np = 0, kb = 0, nr = 0;
     if ((rc = colibri_result_sizes(g.c, &np, &kb, &nr)) != COLIBRI_OK) raise(g.c, rc, "colibri_result_sizes");

@@ -1,7 +1,8 @@
 // colibri-patternmodeller (MI355X build) — a drop-in for the reference's command-line driver on the accelerated path.
 // Same flags and flag meanings as reference src/patternmodeller.cpp:404-858 for: -f -c -o -i -u -t -l -m -b -W -s -y -T -P -R -r -H -e -D -h
 // (build a model from a .colibri.dat, save it, load a model, print / report / histogram), plus -2 (two-stage build). Flags that
-// select paths outside the accelerated subset (-j -I -E -F -L -M -p -Q -q -g ...) are reported and rejected instead of being silently ignored.
+// -j (constrain by a model) and -I (constrained in-place rebuild of the model given with -i). Flags that select paths outside the accelerated
+// subset (-E -F -L -M -p -Q -q -g ...) are reported and rejected instead of being silently ignored.
 // All counting happens in libcolibri_hip.so; this file only parses options and calls the C++ face.
 #include <getopt.h>
 
@@ -33,18 +34,31 @@ void usage() {
                  "\t-T|--skiptypes <n>          skip type threshold (default 2)\n"
                  "\t-e|--expand <n>             sentence offset given to the first sentence\n"
                  "\t-2|--twostage               two-stage build of an indexed model (needs -o): same result as the reference's -2\n"
+                 "\t-j|--constraints <file>     only count patterns that occur in this model (any threshold, any minimum length)\n"
+                 "\t-I|--constrained            in-place rebuild: recount the patterns of the model given with -i on the corpus given with -f\n"
                  " Viewing:\n"
                  "\t-P|--print   -R|--report   -r|--simplereport   -H|--histogram\n"
                  "\t-D|--debug   -h|--help\n";
 }
 
+PatternSetModel* g_constraint = NULL;  // -j
+bool             g_inplace    = false; // -I
+
 template <class ModelType>
-int run(ModelType& model, const std::string& corpusfile, const std::string& inputmodel, const std::string& outputmodel, const PatternModelOptions& options, uint32_t firstsentence,
+int run(ModelType& model, const std::string& corpusfile, const std::string& inputmodel, const std::string& outputmodel, const PatternModelOptions& options_in, uint32_t firstsentence,
         bool doprint, bool doreport, bool nocoverage, bool dohistogram, const ClassDecoder* decoder) {
-    if (!inputmodel.empty()) {
+    PatternModelOptions options = options_in;
+    if (g_inplace) {  // reference src/patternmodeller.cpp:756-831
+        std::cerr << "Constrained in-place rebuild (--constrained|-I) enabled, on " << corpusfile << std::endl;
+        model.load(inputmodel, options);
+        std::cerr << "(" << model.size() << " patterns)" << std::endl;
+        if (model.maxlength() > options.MAXLENGTH) options.MAXLENGTH = model.maxlength();
+        if (model.minlength() < options.MINLENGTH) options.MINLENGTH = model.minlength();
+        model.train(corpusfile, options, model.getinterface(), NULL, false, firstsentence);
+    } else if (!inputmodel.empty()) {
         model.load(inputmodel, options);
     } else {
-        model.train(corpusfile, options, NULL, NULL, false, firstsentence);
+        model.train(corpusfile, options, g_constraint, NULL, false, firstsentence);
     }
     if (!outputmodel.empty()) {
         std::cerr << "Writing model to " << outputmodel << std::endl;
@@ -64,7 +78,7 @@ int run(ModelType& model, const std::string& corpusfile, const std::string& inpu
 }  // namespace
 
 int main(int argc, char** argv) {
-    std::string         corpusfile, classfile, inputmodel, outputmodel;
+    std::string         corpusfile, classfile, inputmodel, outputmodel, constraintfile;
     PatternModelOptions options;
     bool                unindexed = false, doprint = false, doreport = false, nocoverage = false, dohistogram = false, twostage = false;
     uint32_t            firstsentence = 1;
@@ -74,7 +88,7 @@ int main(int argc, char** argv) {
                                        {"wordthreshold", required_argument, 0, 'W'}, {"skipgrams", no_argument, 0, 's'},          {"skipthreshold", required_argument, 0, 'y'},
                                        {"skiptypes", required_argument, 0, 'T'},   {"expand", required_argument, 0, 'e'},         {"print", no_argument, 0, 'P'},
                                        {"report", no_argument, 0, 'R'},            {"simplereport", no_argument, 0, 'r'},         {"histogram", no_argument, 0, 'H'},
-                                       {"debug", no_argument, 0, 'D'},             {"help", no_argument, 0, 'h'},                 {"twostage", no_argument, 0, '2'},
+                                       {"debug", no_argument, 0, 'D'},             {"help", no_argument, 0, 'h'},                 {"twostage", no_argument, 0, '2'},          {"constraints", required_argument, 0, 'j'},    {"constrained", no_argument, 0, 'I'},
                                        {0, 0, 0, 0}};
     int c;
     while ((c = getopt_long(argc, argv, "f:c:i:o:t:ul:m:b:W:sy:T:e:PRrHDh2j:IEF:LMp:Qq:gZV", longopts, NULL)) != -1) {
@@ -102,6 +116,8 @@ int main(int argc, char** argv) {
             case 'H': dohistogram = true; break;
             case 'D': options.DEBUG = true; break;
             case '2': twostage = true; break;
+            case 'j': constraintfile = optarg; break;
+            case 'I': g_inplace = true; break;
             case 'h': usage(); return 0;
             default:
                 std::cerr << "ERROR: option -" << (char)(c == '?' ? optopt : c) << " selects a path that is not part of the MI355X-accelerated build (see DESIGN.md, out of scope)" << std::endl;
@@ -118,6 +134,15 @@ int main(int argc, char** argv) {
         if (!classfile.empty()) {
             loaded.load(classfile);
             decoder = &loaded;
+        }
+        if (g_inplace && (inputmodel.empty() || corpusfile.empty())) {
+            std::cerr << "ERROR: Corpus data file (--datafile|-f) and input model (--inputmodel|-i) must be specified when --constrained|-I is set!." << std::endl;
+            return 2;
+        }
+        if (!constraintfile.empty()) {  // reference :712-718: the constraint is loaded as a pattern set under the run's own thresholds
+            std::cerr << "Loading constraint model (aka training/intersection model)" << std::endl;
+            g_constraint = new PatternSetModel(constraintfile, options);
+            std::cerr << " (Contains " << g_constraint->size() << " patterns)" << std::endl;
         }
         if (unindexed) {
             if (options.DOSKIPGRAMS) {  // unindexed models can only do this exhaustively, on a loaded corpus (reference src/patternmodeller.cpp:723-737)

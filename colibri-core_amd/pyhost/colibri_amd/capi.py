@@ -23,7 +23,7 @@ EXPORTED = [
     "colibri_shard_begin", "colibri_shard_count", "colibri_shard_send", "colibri_shard_merge", "colibri_shard_reply", "colibri_shard_apply",
     "colibri_shard_finish", "colibri_shard_export_gids", "colibri_shard_index_sizes", "colibri_shard_export_index",
     "colibri_shard_uni_info", "colibri_shard_uni_count", "colibri_shard_uni_apply",
-    "colibri_text_upload", "colibri_text_count", "colibri_text_words", "colibri_text_encode", "colibri_text_fetch", "colibri_text_as_corpus",
+    "colibri_set_constraint", "colibri_text_upload", "colibri_text_count", "colibri_text_words", "colibri_text_encode", "colibri_text_fetch", "colibri_text_as_corpus",
 ]
 
 

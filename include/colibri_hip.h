@@ -180,6 +180,14 @@ int colibri_hash_keys(colibri_ctx* ctx, const uint8_t* bytes, const uint64_t* of
  * (only when options.profile = 1; events are recorded on the library's own stream) */
 int colibri_kernel_time(const colibri_ctx* ctx, int kernel_class, double* total_ms, uint64_t* launches);
 
+/* ---- constrained training -------------------------------------------------------------------------------------------
+ * Replaces PatternModel::train(..., constrainbymodel) (reference include/patternmodel.h:1062-1072, :1088-1089, :1209-1217): while a
+ * constraint set is installed, colibri_train counts — in one pass per length MINLENGTH..MAXLENGTH, without look-back — exactly the
+ * windows whose key bytes are a member, and keeps those that reach MINTOKENS (any value >= 1). key_off[npatterns + 1] / key_bytes: the
+ * patterns' keys as in colibri_export_unindexed (skipgram / flexgram keys never equal a window and are simply never hit).
+ * npatterns = 0 removes the constraint. stats.totaltypes is 0 after a constrained run (the reference leaves it unset there). */
+int colibri_set_constraint(colibri_ctx* ctx, const uint64_t* key_off, const uint8_t* key_bytes, uint64_t npatterns);
+
 /* ---- class encoder: plain text -> word frequency list -> class-encoded corpus -------------------------------------
  * Replaces the corpus-proportional work of ClassEncoder::processcorpus (reference src/classencoder.cpp:156-188: the word frequency
  * list) and ClassEncoder::encodefile / encodestring (:369-436, :550-600: words -> varint classes, one 00 per line). The class of

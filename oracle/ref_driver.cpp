@@ -86,7 +86,7 @@ void dump(std::ostream& out, uint64_t tokens, uint64_t types, std::vector<Row>& 
 int usage() {
     std::cerr << "usage:\n"
                  "  ref_driver train <corpus.colibri.dat> <mode:u|U|us|i|is> <maxlength> <mintokens>\n"
-                 "             [-T minskiptypes] [-y mintokens_skipgrams] [-o model.out] [-d dump.txt] [-q]\n"
+                 "             [-T minskiptypes] [-y mintokens_skipgrams] [-o model.out] [-d dump.txt] [-q] [-j constraintmodel] [-m minlength]\n"
                  "      u  = unindexed, streaming from file (patternmodeller -u)\n"
                  "      U  = unindexed, corpus preloaded in an IndexedCorpus (benchmarks.cpp test 5)\n"
                  "      us = unindexed + exhaustive skipgrams (preloaded corpus)\n"
@@ -216,7 +216,7 @@ int main(int argc, char** argv) {
     options.MAXLENGTH = atoi(argv[4]);
     options.MINTOKENS = atoi(argv[5]);
     options.QUIET     = false;
-    std::string modelout, dumpout;
+    std::string modelout, dumpout, constraintfile, inplacemodel;
     for (int i = 6; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "-T" && i + 1 < argc) options.MINSKIPTYPES = atoi(argv[++i]);
@@ -224,18 +224,50 @@ int main(int argc, char** argv) {
         else if (a == "-o" && i + 1 < argc) modelout = argv[++i];
         else if (a == "-d" && i + 1 < argc) dumpout = argv[++i];
         else if (a == "-q") options.QUIET = true;
+        else if (a == "-j" && i + 1 < argc) constraintfile = argv[++i];  // constrain by this model (patternmodeller -j, loaded as a PatternSetModel as src/patternmodeller.cpp:712-718 does)
+        else if (a == "-m" && i + 1 < argc) options.MINLENGTH = atoi(argv[++i]);
+        else if (a == "-I" && i + 1 < argc) inplacemodel = argv[++i];  // constrained in-place rebuild of this model (patternmodeller -I -i <model>), modes u and i
         else return usage();
     }
 
+    PatternSetModel* constrain = NULL;
+    if (!constraintfile.empty()) {
+        PatternModelOptions co = PatternModelOptions(options);
+        co.DOREMOVEINDEX       = false;  // exactly what colibri-patternmodeller -j does: the set is loaded under the run's own thresholds
+        constrain              = new PatternSetModel(constraintfile, co);
+    }
     std::vector<Row> rows;
     uint64_t tokens = 0, types = 0;
     double load_s = 0, train_s = 0;
     using clk = std::chrono::steady_clock;
 
-    if (mode == "u") {
+    if (!inplacemodel.empty() && (mode == "u" || mode == "i")) {  // src/patternmodeller.cpp:756-831
+        PatternModelOptions optionscopy = PatternModelOptions(options);
+        optionscopy.DORESET             = true;
+        if (mode == "u") {
+            PatternModel<uint32_t> model(inplacemodel, optionscopy, NULL, NULL);
+            if (model.maxlength() > options.MAXLENGTH) options.MAXLENGTH = model.maxlength();
+            if (model.minlength() < options.MINLENGTH) options.MINLENGTH = model.minlength();
+            model.train(corpusfile, options, model.getinterface());
+            tokens = model.tokens();
+            types  = model.types();
+            if (!modelout.empty()) model.write(modelout);
+            if (!dumpout.empty()) collect_unindexed(model, rows);
+        } else {
+            IndexedCorpus         corpus(corpusfile);
+            IndexedPatternModel<> model(inplacemodel, optionscopy, NULL, &corpus);
+            if (model.maxlength() > options.MAXLENGTH) options.MAXLENGTH = model.maxlength();
+            if (model.minlength() < options.MINLENGTH) options.MINLENGTH = model.minlength();
+            model.train(corpusfile, options, model.getinterface());
+            tokens = model.tokens();
+            types  = model.types();
+            if (!modelout.empty()) model.write(modelout);
+            if (!dumpout.empty()) collect_indexed(model, rows);
+        }
+    } else if (mode == "u") {
         PatternModel<uint32_t> model;
         auto t0 = clk::now();
-        model.train(corpusfile, options);
+        model.train(corpusfile, options, constrain);
         train_s = std::chrono::duration<double>(clk::now() - t0).count();
         tokens = model.tokens();
         types  = model.types();
@@ -248,7 +280,7 @@ int main(int argc, char** argv) {
         if (mode == "us") options.DOSKIPGRAMS_EXHAUSTIVE = true;
         PatternModel<uint32_t> model(&corpus);
         t0 = clk::now();
-        model.train(corpusfile, options);
+        model.train(corpusfile, options, constrain);
         train_s = std::chrono::duration<double>(clk::now() - t0).count();
         tokens = model.tokens();
         types  = model.types();
@@ -261,7 +293,7 @@ int main(int argc, char** argv) {
         if (mode == "is") options.DOSKIPGRAMS = true;
         IndexedPatternModel<> model(&corpus);
         t0 = clk::now();
-        model.train(corpusfile, options);
+        model.train(corpusfile, options, constrain);
         train_s = std::chrono::duration<double>(clk::now() - t0).count();
         tokens = model.tokens();
         types  = model.types();

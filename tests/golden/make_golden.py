@@ -101,6 +101,19 @@ def main():
         for mode in ("i2", "is2"):
             out = os.path.join(HERE, f"{name}.{mode}.l5.txt")
             subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{name}.colibri.dat"), mode, "5", "2", "-q", "-d", out], stdout=subprocess.DEVNULL)
+    # constrained training (patternmodeller -j / -I): constraint models written by the reference itself, kept as fixtures
+    cj = os.path.join(HERE, "constraint.zipf20k.u.l5.patternmodel")
+    subprocess.check_call([DRIVER, "train", os.path.join(HERE, "zipf20k.colibri.dat"), "u", "5", "2", "-q", "-o", cj], stdout=subprocess.DEVNULL)
+    ch = os.path.join(HERE, "constraint.hamlet.i.l5.patternmodel")
+    subprocess.check_call([DRIVER, "train", os.path.join(HERE, "hamlet.v2.colibri.dat"), "i", "5", "2", "-q", "-o", ch], stdout=subprocess.DEVNULL)
+    for tag, corpus, mode, args in [("j_zipf.u.t1", "phrases15k", "u", ["4", "1", "-j", cj]), ("j_zipf.u.t2", "phrases15k", "u", ["4", "2", "-j", cj]),
+                                    ("j_zipf.u.t3", "phrases15k", "u", ["5", "3", "-j", cj]), ("j_zipf.u.t1m2", "phrases15k", "u", ["4", "1", "-m", "2", "-j", cj]),
+                                    ("j_zipf.i.t1", "phrases15k", "i", ["4", "1", "-j", cj]), ("j_zipf.i.t2", "phrases15k", "i", ["5", "2", "-j", cj]),
+                                    ("j_hamlet.u.t1", "edge", "u", ["5", "1", "-j", ch]), ("j_self.u.t2", "zipf20k", "u", ["5", "2", "-j", cj]),
+                                    ("I_zipf.u.t2", "phrases15k", "u", ["5", "2", "-I", cj]), ("I_zipf.i.t1", "phrases15k", "i", ["5", "1", "-I", cj]),
+                                    ("I_self.i.t2", "hamlet.v2", "i", ["5", "2", "-I", ch])]:
+        out = os.path.join(HERE, f"constrained.{tag}.txt")
+        subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{corpus}.colibri.dat"), mode] + args + ["-q", "-d", out], stdout=subprocess.DEVNULL)
     with open(os.path.join(HERE, "unstable_reference_outputs.json"), "w") as f:
         json.dump({"note": "indexed+skipgram dumps of the reference that were NOT kept because the reference's insert-while-iterating "
                            "hazard (patternmodel.h:2986-2991) corrupted them (self-consistency check in make_golden.py)", "dropped": unstable}, f, indent=1)

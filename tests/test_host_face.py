@@ -154,3 +154,38 @@ def test_cli_two_stage_build_matches_the_references(tmp_path, corpus, flags, tag
 def test_cli_two_stage_needs_an_output_model():
     out = subprocess.run([CLI, "-f", os.path.join(GOLDEN, "hamlet.v2.colibri.dat"), "-2"], capture_output=True, text=True)
     assert out.returncode == 2 and "mandatory for two-stage building" in out.stderr
+
+
+CONSTRAINED = {  # golden tag -> (corpus, unindexed?, CLI flags)
+    "j_zipf.u.t1": ("phrases15k", True, ["-l", "4", "-t", "1", "-j", "constraint.zipf20k.u.l5.patternmodel"]),
+    "j_zipf.u.t2": ("phrases15k", True, ["-l", "4", "-t", "2", "-j", "constraint.zipf20k.u.l5.patternmodel"]),
+    "j_zipf.u.t3": ("phrases15k", True, ["-l", "5", "-t", "3", "-j", "constraint.zipf20k.u.l5.patternmodel"]),
+    "j_zipf.u.t1m2": ("phrases15k", True, ["-l", "4", "-t", "1", "-m", "2", "-j", "constraint.zipf20k.u.l5.patternmodel"]),
+    "j_zipf.i.t1": ("phrases15k", False, ["-l", "4", "-t", "1", "-j", "constraint.zipf20k.u.l5.patternmodel"]),
+    "j_zipf.i.t2": ("phrases15k", False, ["-l", "5", "-t", "2", "-j", "constraint.zipf20k.u.l5.patternmodel"]),
+    "j_hamlet.u.t1": ("edge", True, ["-l", "5", "-t", "1", "-j", "constraint.hamlet.i.l5.patternmodel"]),
+    "j_self.u.t2": ("zipf20k", True, ["-l", "5", "-t", "2", "-j", "constraint.zipf20k.u.l5.patternmodel"]),
+    "I_zipf.u.t2": ("phrases15k", True, ["-l", "5", "-t", "2", "-I", "-i", "constraint.zipf20k.u.l5.patternmodel"]),
+    "I_zipf.i.t1": ("phrases15k", False, ["-l", "5", "-t", "1", "-I", "-i", "constraint.zipf20k.u.l5.patternmodel"]),
+    "I_self.i.t2": ("hamlet.v2", False, ["-l", "5", "-t", "2", "-I", "-i", "constraint.hamlet.i.l5.patternmodel"]),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(CONSTRAINED))
+def test_cli_constrained_training_matches_the_references(tmp_path, tag):
+    """colibri-patternmodeller -j <model> / -I -i <model>: a membership-filtered single pass on the device — any threshold incl. 1,
+    any minimum length, unindexed and indexed; goldens by the real reference (ref_driver train ... -j / -I), incl. its totals (tokens of the
+    constraint model + the corpus', types of the constraint model; in place: the number of loaded patterns)."""
+    import oracle
+    corpus, unindexed, flags = CONSTRAINED[tag]
+    flags = [os.path.join(GOLDEN, f) if f.endswith(".patternmodel") else f for f in flags]
+    model = str(tmp_path / "m.colibri.patternmodel")
+    out = subprocess.run([CLI, "-f", os.path.join(GOLDEN, corpus + ".colibri.dat"), "-o", model] + (["-u"] if unindexed else []) + flags, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    want = oracle.parse_dump(open(os.path.join(GOLDEN, f"constrained.{tag}.txt")).read(), indexed=not unindexed)
+    mtype, tokens, types, counts, refs = parse_model(model)
+    assert (mtype, tokens, types) == (10 if unindexed else 20, want.tokens, want.types)
+    assert counts == want.counts
+    if not unindexed:
+        assert refs == want.refs

@@ -161,7 +161,7 @@ int main(int argc, char** argv) {
             // The reference builds an unindexed model first (<out>.stage1) and then an indexed one constrained by it, to bound its memory
             // (src/patternmodeller.cpp:627-663, :756-831). Here the indexed model is built directly — the device holds the forward index
             // anyway — and the observable result of the reference's second stage is reproduced: the same patterns and references, no
-            // skipgrams even with -s, and a type count equal to the number of patterns (goldens: ref_driver train ... i2).
+            // skipgrams even with -s, and a type count equal to the number of patterns.
             if (outputmodel.empty()) {
                 std::cerr << "ERROR: An output model file (--outputmodel) is mandatory for two-stage building!" << std::endl;
                 return 2;

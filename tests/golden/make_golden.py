@@ -99,7 +99,7 @@ def main():
     # two-stage build (patternmodeller -2): what the reference's constrained in-place second stage leaves (with and without -s)
     for name in ["hamlet.v2", "zipf20k"]:
         for mode in ("i2", "is2"):
-            out = os.path.join(HERE, f"{name}.{mode}.l5.txt")
+            out = os.path.join(HERE, f"twostage.{name}.{mode}.txt")
             subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{name}.colibri.dat"), mode, "5", "2", "-q", "-d", out], stdout=subprocess.DEVNULL)
     # constrained training (patternmodeller -j / -I): constraint models written by the reference itself, kept as fixtures
     cj = os.path.join(HERE, "constraint.zipf20k.u.l5.patternmodel")

@@ -54,8 +54,9 @@ def test_host_selftest_cpu():
 
 
 def test_cli_rejects_out_of_scope_flags():
-    out = subprocess.run([CLI, "-f", os.path.join(GOLDEN, "hamlet.v2.colibri.dat"), "-j", "x"], capture_output=True, text=True)
-    assert out.returncode == 2 and "not part of the MI355X-accelerated build" in out.stderr
+    for flag in (["-g"], ["-E"], ["-F", "S"], ["-Q"]):  # relations, self-expansion, flexgrams, query mode
+        out = subprocess.run([CLI, "-f", os.path.join(GOLDEN, "hamlet.v2.colibri.dat")] + flag, capture_output=True, text=True)
+        assert out.returncode == 2 and "not part of the MI355X-accelerated build" in out.stderr
 
 
 def test_cli_prints_the_references_golden_model(tmp_path):
@@ -143,7 +144,7 @@ def test_cli_two_stage_build_matches_the_references(tmp_path, corpus, flags, tag
     model = str(tmp_path / "m.colibri.patternmodel")
     out = subprocess.run([CLI, "-f", os.path.join(GOLDEN, corpus + ".colibri.dat"), "-2", "-t", "2", "-l", "5", "-o", model] + flags, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
-    want = oracle.parse_dump(open(os.path.join(GOLDEN, f"{corpus}.{tag}.l5.txt")).read(), indexed=True)
+    want = oracle.parse_dump(open(os.path.join(GOLDEN, f"twostage.{corpus}.{tag}.txt")).read(), indexed=True)
     mtype, tokens, types, counts, refs = parse_model(model)
     assert (mtype, tokens, types) == (20, want.tokens, want.types)
     assert counts == want.counts and refs == want.refs

@@ -885,6 +885,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     if (uni_shift && (rc = uni_alloc(c))) return rc;
     // three class ids in one key: order 3 is keyed by classes, order 2 leaves survivor bytes instead of ids (KeyTrigramCls)
     const bool tri_cls = binned && uni_direct && !synced && c->maxclass < (1u << 21) && o.maxlength >= 3;
+    const bool bi_cls = tri_cls && uni_shift != 0;  // ... and order 2 is keyed by classes + the order-1 survivor bitmap: no per-position order-1 ids at all
     if (tri_cls && ((rc = dev_alloc(c, c->flags_at, (size_t)npos + 1)) || (rc = dev_alloc(c, c->flag2, (size_t)npos + 4)))) return rc;
     // ---- HBM layout (sized once; nothing is allocated inside the unsynced order loop) ----------------
     // table: an order admits at most `npos` windows -> 1.5x slots; results: every survivor has >= 2 occurrences
@@ -956,9 +957,9 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                 {
                     Prof p(c, COLIBRI_K_PRUNE);
                     hipLaunchKernelGGL(uni_finish_kernel, dim3(stream_grid(nclasses)), dim3(kBlock), 0, c->stream, c->cnt1.p, uni_shift ? (const uint32_t*)nullptr : c->rep1.p, nclasses,
-                                       pl.thr, c->state.p, c->res_rep.p, c->res_cnt.p, pl.res_cap, uni_shift ? reinterpret_cast<uint16_t*>(c->uni_surv.p) : (uint16_t*)nullptr);
+                                       pl.thr, c->state.p, c->res_rep.p, c->res_cnt.p, pl.res_cap, uni_shift ? reinterpret_cast<uint16_t*>(c->uni_surv.p) : (uint16_t*)nullptr, bi_cls);
                 }
-                {
+                if (!bi_cls) {  // with class-keyed orders 2 and 3 nothing reads order-1 ids per position
                     Prof p(c, COLIBRI_K_RESOLVE);
                     if (uni_shift)
                         hipLaunchKernelGGL(uni_ids_bitmap_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_surv.p, (nclasses + 31) / 32, id_cur, c->state.p, npos);
@@ -970,6 +971,8 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                 // carry a survivor id are visited (the active list the previous order's resolve left behind)
                 if (n == 1)
                     rc = binned_order(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, id_cur, n, false, n < maxlength);
+                else if (n == 2 && bi_cls)
+                    rc = binned_order(c, pl, KeyBigramCls{c->cls.p, c->uni_surv.p}, id_cur, n, false, true, /*flag_mode=*/true);
                 else if (n == 2 && tri_cls)
                     rc = binned_order(c, pl, KeyNgram{id_prev, n}, id_cur, n, false, true, /*flag_mode=*/true);  // order 3 will not read order-2 ids
                 else if (n == 3 && tri_cls)

@@ -304,6 +304,22 @@ struct KeyNgram {
         return true;
     }
 };
+// order 2 straight from the class ids and the survivor bitmap of order 1 (class-indexed order 1: the survivor id of a unigram IS its
+// class): the same key as KeyNgram over the order-1 ids, without materialising them per position
+struct KeyBigramCls {
+    const uint32_t* cls;
+    const uint32_t* surv;  // bit c = class c survived order 1
+    __device__ __forceinline__ bool operator()(uint32_t i, uint32_t npos, uint64_t& key, uint64_t& hash) const {
+        if (i + 1 >= npos) return false;
+        const uint32_t c0 = cls[i], c1 = cls[i + 1];
+        if (c0 == 0 || c1 == 0) return false;
+        const uint32_t w0 = surv[c0 >> 5], w1 = surv[c1 >> 5];
+        if (!((w0 >> (c0 & 31u)) & (w1 >> (c1 & 31u)) & 1u)) return false;
+        key  = ((uint64_t)c0 << 32) | c1;
+        hash = mix64(key);
+        return true;
+    }
+};
 // order 3 straight from the class ids, when three of them fit one 64-bit key (maxclass < 2^21) and order 1 ran class-indexed
 // (the survivor id of a unigram IS its class): the key is exact without any order-2 survivor id, so order 2 only has to leave one
 // byte per position ("the bigram starting here survived") instead of scattering 4-byte ids into a 420 MB array.
@@ -670,12 +686,14 @@ __global__ __launch_bounds__(kBlock) void uni_tail_count_kernel(const uint16_t* 
 // classes -> result list (threshold), found / kept
 __global__ __launch_bounds__(kBlock) void uni_finish_kernel(const uint32_t* __restrict__ cnt1, const uint32_t* __restrict__ rep1, uint32_t nclasses, uint32_t threshold,
                                                              DevState* __restrict__ st, uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap,
-                                                             uint16_t* __restrict__ surv16 = nullptr /* optional: bit c = class c survives (16 classes per lane = one half word) */) {
+                                                             uint16_t* __restrict__ surv16 = nullptr /* optional: bit c = class c survives (16 classes per lane = one half word) */,
+                                                             bool count_valid = false /* also st->valid += occurrences of the surviving classes (when no id pass follows) */) {
     if (st->done) return;
     __shared__ uint32_t baseL, redL[kBlock / kWave];
     const uint32_t      res_base = st->res_total;
     const uint32_t      ntiles   = (nclasses + kPruneTile - 1) / kPruneTile;
     uint32_t            nfound   = 0;
+    unsigned long long  nvalid   = 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t c0 = tile * kPruneTile + threadIdx.x * kPrunePer;
         uint32_t       v[kPrunePer], k = 0;
@@ -684,6 +702,7 @@ __global__ __launch_bounds__(kBlock) void uni_finish_kernel(const uint32_t* __re
             v[q] = (c0 + q < nclasses) ? cnt1[c0 + q] : 0u;
             nfound += v[q] != 0;
             k += v[q] >= threshold;
+            if (v[q] >= threshold) nvalid += v[q];
         }
         if (surv16 != nullptr && c0 < nclasses) {
             static_assert(kPrunePer == 16, "one 16-bit store per lane");
@@ -717,6 +736,10 @@ __global__ __launch_bounds__(kBlock) void uni_finish_kernel(const uint32_t* __re
     if (threadIdx.x == 0) {
         const uint32_t f = redL[0] + redL[1] + redL[2] + redL[3];
         if (f) atomicAdd(&st->found, f);
+    }
+    if (count_valid) {
+        for (int off = 32; off > 0; off >>= 1) nvalid += __shfl_down(nvalid, off, kWave);
+        if ((threadIdx.x & (kWave - 1)) == 0 && nvalid) atomicAdd(&st->valid, (uint32_t)nvalid);
     }
 }
 // survivor id per position = the class id of a surviving unigram

@@ -146,14 +146,17 @@ def main():
     t0 = time.time()
     ctx.upload_device(dev_payload.data_ptr(), payload.size, first_sentence)  # tokenise on device
     tokenise_ms = (time.time() - t0) * 1e3
-    opt = capi.Options.defaults(mintokens=MINTOKENS, maxlength=MAXLENGTH, profile=1)
+    # timed steps bracket only the counting classes with HIP events (the dominant kernel is one of them); the full per-class breakdown
+    # comes from extra, untimed steps afterwards, so that ~110 event records per step do not sit inside the timed region
+    opt = capi.Options.defaults(mintokens=MINTOKENS, maxlength=MAXLENGTH, profile=2)
+    opt_all = capi.Options.defaults(mintokens=MINTOKENS, maxlength=MAXLENGTH, profile=1)
 
     if dist is not None:
         from colibri_amd import dist as cdist
         trainer = cdist.ShardedTrainer(capi.HipShardEngine(ctx, torch, device), dist, torch, device)
-        step = lambda: trainer.train(opt)
+        step = lambda o=opt: trainer.train(o)
     else:
-        step = lambda: ctx.train(opt)
+        step = lambda o=opt: ctx.train(o)
 
     for _ in range(args.warmup):
         st = step()
@@ -174,6 +177,16 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # untimed: the per-class breakdown of a step (every kernel class bracketed with events)
+    EXTRA = 2
+    kms_all = {k: 0.0 for k in kclasses}
+    kn_all = {k: 0 for k in kclasses}
+    for _ in range(EXTRA):
+        step(opt_all)
+        for k in kclasses:
+            ms, n = ctx.kernel_time(k)
+            kms_all[k] += ms
+            kn_all[k] += n
     windows = sum(st.windows[1:MAXLENGTH + 1])
     npatterns = int(st.npatterns)
     if dist is not None:
@@ -202,7 +215,7 @@ def main():
     avg_launch_ms = kms[dom] / max(1, kn[dom])
     achieved = (dom_bytes / max(1.0, launches_per_step)) / (avg_launch_ms * 1e-3) / 1e9 if kn[dom] else 0.0
     stage = (capi.K_COUNT, capi.K_EMIT, capi.K_SCATTER, capi.K_BINCOUNT) if binned else (capi.K_COUNT,)
-    stage_ms = sum(kms[k] for k in stage) / max(1, args.steps)
+    stage_ms = sum(kms_all[k] for k in stage) / EXTRA
     stage_gbs = (scan_b + build_b) / (stage_ms * 1e-3) / 1e9 if stage_ms else 0.0
     out = {
         "metric": "M patterns counted/sec at n<=5 thr=2; identical pattern set vs reference",
@@ -243,7 +256,9 @@ def main():
             "counting_stage": {"kernels": [capi.KERNEL_CLASSES[k] for k in stage], "ms_per_step": round(stage_ms, 4),
                                "algorithmic_bytes_per_step": round(scan_b + build_b), "achieved_GBps": round(stage_gbs, 2),
                                "frac": round(stage_gbs / HBM_PEAK_GBS, 5)},
-            "kernel_ms_per_step": {capi.KERNEL_CLASSES[k]: round(kms[k] / max(1, args.steps), 4) for k in kclasses if kn[k]},
+            "kernel_ms_per_step": {capi.KERNEL_CLASSES[k]: round(kms_all[k] / EXTRA, 4) for k in kclasses if kn_all[k]},
+            "note": f"achieved / avg_launch_ms: HIP events around the dominant kernel's launches inside the {args.steps} timed steps; counting_stage and "
+                    f"kernel_ms_per_step: {EXTRA} extra untimed steps with every kernel class bracketed",
         },
     }
     if args.gpus == 1 and args.cpu_sample > 0:

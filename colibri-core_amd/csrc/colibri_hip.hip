@@ -202,6 +202,7 @@ struct Prof {
     size_t       idx = (size_t)-1;
     Prof(colibri_ctx* c_, int cls_) : c(c_), cls(cls_) {
         if (!c->profile) return;
+        if (c->profile == 2 && cls != COLIBRI_K_BINCOUNT && cls != COLIBRI_K_COUNT) return;  // only the classes that can hold the dominant kernel
         EventPair ev{};
         ev.cls = cls;
         auto take = [&](hipEvent_t& e) {
@@ -864,7 +865,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     HIP_TRY(c, hipSetDevice(c->device));
     c->opt     = o;
     c->trained = false;
-    c->profile = o.profile != 0;
+    c->profile = o.profile;
     collect_events(c);
     std::fill(std::begin(c->k_ms), std::end(c->k_ms), 0.0);
     std::fill(std::begin(c->k_launches), std::end(c->k_launches), 0);
@@ -1269,7 +1270,7 @@ int colibri_shard_begin(colibri_ctx* c, const colibri_options* opt_in, int world
     HIP_TRY(c, hipSetDevice(c->device));
     c->opt     = o;
     c->trained = false;
-    c->profile = o.profile != 0;
+    c->profile = o.profile;
     collect_events(c);
     std::fill(std::begin(c->k_ms), std::end(c->k_ms), 0.0);
     std::fill(std::begin(c->k_launches), std::end(c->k_launches), 0);

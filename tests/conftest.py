@@ -61,6 +61,15 @@ def small_corpora():
     out["repeat"] = (b"\x06\x07\x08\x09\x0a\x0b\x0c\x00") * 5
     out["one_long_sentence"] = bytes([6, 7, 8, 9] * 300) + b"\x00"
     out["multibyte"] = synth.encode_v2(np.array([200, 300, 20000, 200, 300, 20000, 0, 3000000, 200, 300, 0, 300000000, 300000000, 0], dtype=np.uint32)).tobytes()
+    # class-space boundaries of the default mode's kernel choices: three classes in one key needs maxclass < 2^21 (KeyBigramCls / KeyTrigramCls),
+    # the partitioned order 1 uses 2^12 / 2^13 / 2^14-class ranges up to 2^22 classes and the atomics kernel beyond
+    for tag, top in (("cls_2p21m1", (1 << 21) - 1), ("cls_2p21", 1 << 21), ("cls_2p20", 1 << 20), ("cls_2p22m1", (1 << 22) - 1), ("cls_2p22", 1 << 22)):
+        pool = np.array([6, 7, 8, 9, 100, 5000, top - 3, top - 1, top], dtype=np.uint32)
+        toks = pool[np.minimum(rng.pareto(0.9, size=1500).astype(np.int64), pool.size - 1)]
+        lens = rng.integers(1, 12, size=400)
+        ends = np.cumsum(lens)
+        ends = ends[ends < toks.size]
+        out[tag] = synth.encode_v2(np.insert(toks, ends, np.uint32(0))).tobytes() + b"\x00"
     out["zipf20k"] = synth.zipf_corpus(20000, 500, 5, header=False)
     out["zipf200k_phrases"] = synth.zipf_corpus(200000, 5000, 7, phrases=True, header=False)
     return out

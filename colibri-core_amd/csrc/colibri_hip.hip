@@ -356,7 +356,10 @@ int check_options(colibri_ctx* c, colibri_options& o) {
     const bool constrained = c->cs.n != 0;  // a constraint set makes the run single-pass by definition: every threshold and minimum length is fine
     if (constrained && (o.doskipgrams || o.doskipgrams_exhaustive)) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams in a constrained run are not on the accelerated path");
     if (o.minlength < 1) o.minlength = 1;
-    if (o.mintokens < 2 && !constrained) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINTOKENS=1 (single-pass, no look-back) is not on the accelerated path");
+    // MINTOKENS = 1: the reference counts all lengths in one pass without look-back (patternmodel.h:1069-1072); nothing is ever pruned, so the
+    // order loop admits every window and yields the same model. Skipgrams at threshold 1 follow other rules there and stay unsupported.
+    if (o.mintokens < 2 && !constrained && (o.doskipgrams || o.doskipgrams_exhaustive))
+        return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams with MINTOKENS=1 are not on the accelerated path");
     if (o.minlength > 1 && !constrained) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINLENGTH>1 is not on the accelerated path");
     if (o.minlength > o.maxlength) return fail(c, COLIBRI_ERR_ARG, "MINLENGTH > MAXLENGTH");
     if (o.maxbackofflength < o.maxlength) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MAXBACKOFFLENGTH < MAXLENGTH is not on the accelerated path");
@@ -895,7 +898,8 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     TrainPlan pl{};
     pl.npos        = npos;
     pl.table_slots = (uint32_t)table_slots64;
-    pl.res_cap     = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)npos * (synced ? 4 : 2) + 1024);
+    // results: every survivor has >= MINTOKENS occurrences; at MINTOKENS = 1 every window may be its own pattern (exhaustion is reported, never silent)
+    pl.res_cap     = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)npos * (o.mintokens < 2 ? (uint64_t)std::min(o.maxlength, 8) : (synced ? 4u : 2u)) + 1024);
     pl.thr         = (uint32_t)o.mintokens;
     constexpr uint32_t kCountLdsBytes    = kCountTile * 16u + kCountLSlot * 4u + 64u;  // keyL + cntL + slotL + winL
     constexpr uint32_t kCountBlocksPerCU = (160u * 1024u / kCountLdsBytes) < 8u ? (160u * 1024u / kCountLdsBytes) : 8u;

@@ -432,7 +432,9 @@ co_model* co_train(const uint8_t* payload, uint64_t nbytes, const co_options* op
     if (opt.mintokens == -1) opt.mintokens = 2; /* :883-886 */
     if (opt.mintokens == 0) opt.mintokens = 1;
     if (opt.mintokens_skipgrams < opt.mintokens) opt.mintokens_skipgrams = opt.mintokens; /* :887-888 */
-    if (opt.mintokens < 2) return NULL; /* outside the restated subset */
+    /* MINTOKENS == 1 makes the reference count all lengths in one pass without look-back (:1069-1072); with nothing ever pruned the
+     * order loop below admits every window and gives the same model. Skipgrams at threshold 1 stay outside the restated subset. */
+    if (opt.mintokens < 1 || (opt.mintokens < 2 && (opt.doskipgrams || opt.doskipgrams_exhaustive))) return NULL;
     const uint32_t thr = (uint32_t)opt.mintokens;
 
     co_model* m = (co_model*)calloc(1, sizeof(co_model));

@@ -96,6 +96,11 @@ def main():
         if mode == "is" and not reference_is_dump_is_stable(out, 1 if extra else 2, l):
             unstable.append(os.path.basename(out))
             os.remove(out)
+    # MINTOKENS = 1 (the reference's single pass over all lengths)
+    for name, l in [("hamlet.v2", 5), ("edge", 5), ("zipf20k", 3)]:
+        for mode in ("u", "i"):
+            out = os.path.join(HERE, f"{name}.{mode}t1.l{l}.txt")
+            subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{name}.colibri.dat"), mode, str(l), "1", "-q", "-d", out], stdout=subprocess.DEVNULL)
     # two-stage build (patternmodeller -2): what the reference's constrained in-place second stage leaves (with and without -s)
     for name in ["hamlet.v2", "zipf20k"]:
         for mode in ("i2", "is2"):

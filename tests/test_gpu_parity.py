@@ -91,8 +91,8 @@ def test_train_matches_oracle(ctx, name, maxlength, table_mode):
     _compare(ctx, small_corpora()[name], maxlength, table_mode=table_mode)
 
 
-@pytest.mark.parametrize("mintokens", [2, 3, 5, -1, 10])
-def test_thresholds(ctx, mintokens):
+@pytest.mark.parametrize("mintokens", [1, 0, 2, 3, 5, -1, 10])
+def test_thresholds(ctx, mintokens):  # 1 = the reference's single pass over all lengths
     _compare(ctx, small_corpora()["zipf20k"], 5, mintokens)
 
 
@@ -121,7 +121,7 @@ def test_unsupported_options_fail_loudly(ctx):
     from colibri_amd import capi
     ctx.upload(small_corpora()["rand0"])
     with pytest.raises(capi.ColibriError):
-        ctx.train(mintokens=1)
+        ctx.train(mintokens=1, doskipgrams_exhaustive=1)
     with pytest.raises(capi.ColibriError):
         ctx.train(minlength=2)
     with pytest.raises(capi.ColibriError):

@@ -20,6 +20,7 @@ from colibri_amd import synth
 MODES = {
     "u": {}, "us": dict(doskipgrams_exhaustive=True), "usy3": dict(doskipgrams_exhaustive=True, mintokens_skipgrams=3),
     "i": dict(indexed=True), "is": dict(indexed=True, doskipgrams=True), "isT1": dict(indexed=True, doskipgrams=True, minskiptypes=1),
+    "ut1": dict(mintokens=1), "it1": dict(indexed=True, mintokens=1),  # MINTOKENS = 1: the reference's single pass over all lengths
 }
 
 
@@ -58,9 +59,9 @@ def golden_cases():
 
 @pytest.mark.parametrize("corpus,tag,maxlength,path", list(golden_cases()))
 def test_oracle_matches_reference_goldens(corpus, tag, maxlength, path):
-    kw = MODES[tag]
+    kw = dict(MODES[tag])
     want = oracle.parse_dump(open(path).read(), indexed=kw.get("indexed", False))
-    got = oracle.train(read_payload(corpus), 2, maxlength, **kw)
+    got = oracle.train(read_payload(corpus), kw.pop("mintokens", 2), maxlength, **kw)
     assert (got.tokens, got.types) == (want.tokens, want.types)
     assert got.counts == want.counts
     if want.refs is not None:

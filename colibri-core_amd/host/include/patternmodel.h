@@ -89,6 +89,9 @@ struct TrainResult {
     size_t                     size() const { return counts.size(); }
 };
 
+/** MINLENGTH > 1 in an unconstrained run: the reference counts the shorter orders (the look-back needs them) and prunes them away afterwards
+ *  (patternmodel.h:1221-1230, :1339-1343), so the model is the full one without its patterns of fewer than `minlength` tokens */
+void drop_short_patterns(TrainResult& r, int minlength);
 /** whole corpus file -> v2 payload (header stripped; v1 data converted, reference src/classencoder.cpp:602-647) */
 std::vector<unsigned char> read_corpus_payload(std::istream& in);
 /** the keys a run is constrained to (colibri_set_constraint), or NULL */
@@ -306,7 +309,7 @@ class PatternModel : public MapType, public PatternModelInterface {
         colibri_options o{};
         o.mintokens              = options.MINTOKENS;
         o.maxlength              = options.MAXLENGTH;
-        o.minlength              = options.MINLENGTH;
+        o.minlength              = (constrainbymodel == NULL) ? 1 : options.MINLENGTH;  // unconstrained: shorter patterns are dropped after the run (drop_short_patterns)
         o.maxbackofflength       = options.MAXBACKOFFLENGTH;
         o.mintokens_unigrams     = options.MINTOKENS_UNIGRAMS;
         o.mintokens_skipgrams    = options.MINTOKENS_SKIPGRAMS;
@@ -333,6 +336,7 @@ class PatternModel : public MapType, public PatternModelInterface {
             std::cerr << "ERROR: No input stream and no reverse index (preloaded corpus) to train on" << std::endl;
             throw InternalError();
         }
+        if (constrainbymodel == NULL && options.MINLENGTH > 1) colibri_host::drop_short_patterns(*r, options.MINLENGTH);
         if (!options.QUIET) colibri_host::print_training_log(r->stats, o, std::cerr);
         totaltokens   = r->stats.totaltokens;
         totaltypes    = r->stats.totaltypes;

@@ -382,6 +382,37 @@ void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_o
     }
 }
 
+void drop_short_patterns(TrainResult& r, int minlength) {
+    const size_t n = r.size();
+    const bool   indexed = !r.ref_off.empty();
+    size_t       w = 0;
+    uint64_t     kb = 0, nr = 0;
+    for (size_t j = 0; j < n; ++j) {
+        const uint64_t a = r.key_off[j], b = r.key_off[j + 1];
+        if ((int)token_count(r.key_bytes.data() + a, (size_t)(b - a)) < minlength) continue;
+        std::memmove(r.key_bytes.data() + kb, r.key_bytes.data() + a, (size_t)(b - a));
+        r.counts[w]  = r.counts[j];
+        if (indexed) {
+            const uint64_t ra = r.ref_off[j], rb = r.ref_off[j + 1];
+            std::memmove(r.ref_sentence.data() + nr, r.ref_sentence.data() + ra, (size_t)(rb - ra) * sizeof(uint32_t));
+            std::memmove(r.ref_token.data() + nr, r.ref_token.data() + ra, (size_t)(rb - ra) * sizeof(uint16_t));
+            r.ref_off[w] = nr;
+            nr += rb - ra;
+        }
+        r.key_off[w] = kb;
+        kb += b - a;
+        ++w;
+    }
+    r.key_off[w] = kb;
+    r.key_off.resize(w + 1);
+    r.counts.resize(w);
+    if (indexed) {
+        r.ref_off[w] = nr;
+        r.ref_off.resize(w + 1);
+    }
+    r.stats.npatterns = w;
+}
+
 void print_training_log(const colibri_stats& s, const colibri_options& o, std::ostream& err) {
     for (int n = 1; n <= o.maxlength && n < COLIBRI_MAX_ORDER; ++n) {
         err << "Counting " << n << "-grams" << std::endl;

@@ -101,6 +101,11 @@ def main():
         for mode in ("u", "i"):
             out = os.path.join(HERE, f"{name}.{mode}t1.l{l}.txt")
             subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{name}.colibri.dat"), mode, str(l), "1", "-q", "-d", out], stdout=subprocess.DEVNULL)
+    # MINLENGTH = 3: the shorter orders are counted for the look-back and pruned away afterwards
+    for name in ["hamlet.v2", "zipf20k"]:
+        for mode in ("u", "i", "is", "us"):
+            out = os.path.join(HERE, f"minlength.{name}.{mode}.m3.txt")
+            subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{name}.colibri.dat"), mode, "5", "2", "-q", "-m", "3", "-d", out], stdout=subprocess.DEVNULL)
     # two-stage build (patternmodeller -2): what the reference's constrained in-place second stage leaves (with and without -s)
     for name in ["hamlet.v2", "zipf20k"]:
         for mode in ("i2", "is2"):

@@ -190,3 +190,21 @@ def test_cli_constrained_training_matches_the_references(tmp_path, tag):
     assert counts == want.counts
     if not unindexed:
         assert refs == want.refs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("corpus", ["hamlet.v2", "zipf20k"])
+@pytest.mark.parametrize("mode,flags", [("u", ["-u"]), ("i", []), ("is", ["-s"]), ("us", ["-u", "-s"])])
+def test_cli_minimum_length(tmp_path, corpus, mode, flags):
+    """-m 3: the model without its patterns of fewer than three tokens, same totals (goldens by the real reference, all four kinds of model)"""
+    import oracle
+    model = str(tmp_path / "m.colibri.patternmodel")
+    out = subprocess.run([CLI, "-f", os.path.join(GOLDEN, corpus + ".colibri.dat"), "-t", "2", "-l", "5", "-m", "3", "-o", model] + flags, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    indexed = "-u" not in flags
+    want = oracle.parse_dump(open(os.path.join(GOLDEN, f"minlength.{corpus}.{mode}.m3.txt")).read(), indexed=indexed)
+    mtype, tokens, types, counts, refs = parse_model(model)
+    assert (mtype, tokens, types) == (20 if indexed else 10, want.tokens, want.types)
+    assert counts == want.counts
+    if indexed:
+        assert refs == want.refs

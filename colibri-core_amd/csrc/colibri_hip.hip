@@ -54,10 +54,14 @@ struct colibri_ctx {
     DevBuf<uint32_t>  tokstart;
     DevBuf<uint32_t>  delimpos;
     DevBuf<uint32_t>  cls;              // class id per position (0 = delimiter)
+    DevBuf<uint32_t>  pos_sentence;     // sentence ordinal per position and ...
+    DevBuf<uint16_t>  pos_token;        // ... token offset inside it (built at the first indexed run on a corpus)
+    bool              pos_refs_valid = false;
     DevBuf<uint32_t>  cnt1, rep1;       // order-1 fast path: count / representative position per class
     DevBuf<UniState>  unistate;         // ... its atomic-free variant: tail-bin sizes / offsets / cursors
     DevBuf<uint16_t>  uni_tail;         // ... and the tail tokens as 2-byte offsets inside their class-range bin
     DevBuf<uint32_t>  uni_rows, uni_surv; // ... per-block head histograms (rows), survivor bitmap of the classes
+    DevBuf<uint32_t>  uni_resid;          // per-pass modes: result index per class
     std::vector<uint64_t> lenhist;  // sentence-length histogram (host copy)
     uint64_t              windows_n[COLIBRI_MAX_ORDER] = {0};  // W_n = n-token windows inside sentences, from the histogram (once per upload)
 
@@ -265,6 +269,7 @@ int tokenise(colibri_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->npos = npos;
     c->cs.rem_valid = false;  // per-position sentence remainders belong to the previous corpus
+    c->pos_refs_valid = false;
     if ((rc = dev_alloc(c, c->tokstart, (size_t)npos + 2)) || (rc = dev_alloc(c, c->cls, (size_t)npos + 1))) {
         cleanup();
         return rc;
@@ -413,6 +418,8 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->bytes);
     dev_free(c->tokstart);
     dev_free(c->delimpos);
+    dev_free(c->pos_sentence);
+    dev_free(c->pos_token);
     dev_free(c->cls);
     dev_free(c->cnt1);
     dev_free(c->rep1);
@@ -420,6 +427,7 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->uni_tail);
     dev_free(c->uni_rows);
     dev_free(c->uni_surv);
+    dev_free(c->uni_resid);
     for (auto& b : c->ids) dev_free(b);
     dev_free(c->scratch[0]);
     dev_free(c->scratch[1]);
@@ -837,8 +845,13 @@ int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = fal
                                c->pair_pos[cur ^ 1].p);
             cur ^= 1;
         }
-        hipLaunchKernelGGL(refs_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, c->stream, c->pair_pos[cur].p, n, c->delimpos.p, c->ndelim, c->first_sentence, c->ref_sentence.p,
-                           c->ref_token.p);
+        if (!c->pos_refs_valid) {
+            if ((rc = dev_alloc(c, c->pos_sentence, (size_t)c->npos + 1)) || (rc = dev_alloc(c, c->pos_token, (size_t)c->npos + 1))) return rc;
+            hipLaunchKernelGGL(position_refs_kernel, dim3(stream_grid(c->npos)), dim3(kBlock), 0, c->stream, c->delimpos.p, c->ndelim, c->npos, c->pos_sentence.p, c->pos_token.p);
+            c->pos_refs_valid = true;
+        }
+        hipLaunchKernelGGL(refs_table_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, c->stream, c->pair_pos[cur].p, n, c->pos_sentence.p, c->pos_token.p, c->first_sentence,
+                           c->ref_sentence.p, c->ref_token.p);
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
@@ -1023,6 +1036,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     } else {
         // ---------- skipgram / indexed modes: one host round trip per pass (sizes, lazily grown per-order id arrays) ----------
         if ((int)c->ids.size() < maxlength + 2) c->ids.resize(maxlength + 2);
+        const bool uni_synced = !constrained && o.table_mode == 0 && !(c->flags & kFlagNonCanonical) && c->maxclass < (1u << 28);
         std::vector<uint32_t> valid_n(maxlength + 2, 0), adm_n(maxlength + 2, 0);
         uint32_t              res_total = 0;
         const uint32_t        thr_skip  = o.minskiptypes > 1 ? (uint32_t)o.mintokens_skipgrams : pl.thr;  // base pruneskipgrams is a no-op when MINSKIPTYPES <= 1 (patternmodel.h:2167-2186)
@@ -1039,14 +1053,38 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
         for (int n = constrained ? std::max(1, o.minlength) : 1; n <= maxlength && !c->hstate.done; ++n) {
             if ((rc = dev_alloc(c, c->ids[n], (size_t)npos + 1))) return rc;
             launch_clear(c, pl);
-            if (constrained)
-                launch_count(c, pl, KeyConstrained{c->bytes.p, c->tokstart.p, c->cs.rem.p, c->cs.table.p, c->cs.cap, c->cs.bytes.p, c->cs.off.p, n}, c->ids[n].p, 3, COLIBRI_K_COUNT);
-            else if (n == 1)
-                launch_count(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, c->ids[n].p, 3, COLIBRI_K_COUNT);
-            else
-                launch_count(c, pl, KeyNgram{c->ids[n - 1].p, n}, c->ids[n].p, 3, COLIBRI_K_COUNT);
-            launch_prune(c, pl, pl.thr, nullptr, 0);
-            launch_resolve(c, pl, c->ids[n].p);
+            if (n == 1 && uni_synced) {
+                // order 1 on the class-indexed count array (as in the plain mode): no hashing, no table; the survivor id of a unigram is its
+                // RESULT index here, read per position through a class -> result table
+                const uint32_t nclasses = c->maxclass + 1;
+                const uint32_t shift    = uni_range_shift(c);
+                if ((rc = dev_alloc(c, c->cnt1, (size_t)nclasses + 1)) || (rc = dev_alloc(c, c->rep1, (size_t)nclasses + 1)) || (rc = dev_alloc(c, c->uni_resid, (size_t)nclasses + 1))) return rc;
+                if (shift) {
+                    if ((rc = uni_alloc(c)) || (rc = uni_count_partitioned(c, shift, c->cnt1.p, nclasses))) return rc;
+                } else {
+                    HIP_TRY(c, hipMemsetAsync(c->cnt1.p, 0, sizeof(uint32_t) * nclasses, c->stream));
+                    Prof p(c, COLIBRI_K_COUNT);
+                    hipLaunchKernelGGL(uni_count_kernel, dim3(512), dim3(kBlock), 0, c->stream, c->cls.p, npos, c->cnt1.p, c->rep1.p, c->state.p);
+                }
+                {
+                    Prof p(c, COLIBRI_K_PRUNE);
+                    hipLaunchKernelGGL(uni_finish_kernel, dim3(stream_grid(nclasses)), dim3(kBlock), 0, c->stream, c->cnt1.p, (const uint32_t*)nullptr, nclasses, pl.thr, c->state.p,
+                                       c->res_rep.p, c->res_cnt.p, pl.res_cap, (uint16_t*)nullptr, false, c->uni_resid.p);
+                }
+                {
+                    Prof p(c, COLIBRI_K_RESOLVE);
+                    hipLaunchKernelGGL(uni_resid_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_resid.p, c->ids[n].p, c->state.p, npos);
+                }
+            } else {
+                if (constrained)
+                    launch_count(c, pl, KeyConstrained{c->bytes.p, c->tokstart.p, c->cs.rem.p, c->cs.table.p, c->cs.cap, c->cs.bytes.p, c->cs.off.p, n}, c->ids[n].p, 3, COLIBRI_K_COUNT);
+                else if (n == 1)
+                    launch_count(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, c->ids[n].p, 3, COLIBRI_K_COUNT);
+                else
+                    launch_count(c, pl, KeyNgram{c->ids[n - 1].p, n}, c->ids[n].p, 3, COLIBRI_K_COUNT);
+                launch_prune(c, pl, pl.thr, nullptr, 0);
+                launch_resolve(c, pl, c->ids[n].p);
+            }
             if ((rc = read_state(c))) return rc;
             const uint32_t found = c->hstate.found, kept = c->hstate.kept;
             adm_n[n]   = c->hstate.admitted;
@@ -1056,7 +1094,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             if (found) s.maxn = n;
             s.found[n] = found;
             s.kept[n]  = kept;
-            if (kept) c->segments.push_back({res_total, kept, n, 0u});
+            if (kept) c->segments.push_back({res_total, kept, n, (n == 1 && uni_synced) ? kMaskFromClass : 0u});
             res_total += kept;
             c->hstate.res_total = res_total;
             if (o.indexed && kept && (rc = emit_pairs(c, pl, c->ids[n].p))) return rc;  // occurrences of the surviving n-grams

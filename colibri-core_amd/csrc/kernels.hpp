@@ -687,7 +687,8 @@ __global__ __launch_bounds__(kBlock) void uni_tail_count_kernel(const uint16_t* 
 __global__ __launch_bounds__(kBlock) void uni_finish_kernel(const uint32_t* __restrict__ cnt1, const uint32_t* __restrict__ rep1, uint32_t nclasses, uint32_t threshold,
                                                              DevState* __restrict__ st, uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap,
                                                              uint16_t* __restrict__ surv16 = nullptr /* optional: bit c = class c survives (16 classes per lane = one half word) */,
-                                                             bool count_valid = false /* also st->valid += occurrences of the surviving classes (when no id pass follows) */) {
+                                                             bool count_valid = false /* also st->valid += occurrences of the surviving classes (when no id pass follows) */,
+                                                             uint32_t* __restrict__ resid = nullptr /* optional: result index of every class (kInvalid if it did not survive) */) {
     if (st->done) return;
     __shared__ uint32_t baseL, redL[kBlock / kWave];
     const uint32_t      res_base = st->res_total;
@@ -718,6 +719,7 @@ __global__ __launch_bounds__(kBlock) void uni_finish_kernel(const uint32_t* __re
         uint32_t r = res_base + baseL + excl;
 #pragma unroll
         for (int q = 0; q < kPrunePer; ++q) {
+            if (resid != nullptr && c0 + q < nclasses) resid[c0 + q] = v[q] >= threshold ? r : kInvalid;
             if (v[q] >= threshold) {
                 if (r < res_cap) {
                     res_rep[r] = rep1 != nullptr ? rep1[c0 + q] : c0 + q;  // no representative recorded: the class itself (kMaskFromClass export)
@@ -777,6 +779,39 @@ __global__ __launch_bounds__(kBlock) void uni_ids_kernel(const uint32_t* __restr
     }
 }
 
+// result index per position (the per-pass modes use result indices as survivor ids: they double as the pattern number of the forward index)
+__global__ __launch_bounds__(kBlock) void uni_resid_ids_kernel(const uint32_t* __restrict__ cls, const uint32_t* __restrict__ resid, uint32_t* __restrict__ ids,
+                                                                DevState* __restrict__ st, uint32_t npos) {
+    if (st->done) return;
+    uint32_t      nvalid = 0;
+    constexpr int kPer   = 8;
+    for (uint32_t i0 = blockIdx.x * (kBlock * kPer); i0 < npos; i0 += gridDim.x * (kBlock * kPer)) {
+        uint32_t c[kPer], r[kPer];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const uint32_t i = i0 + q * kBlock + threadIdx.x;
+            c[q]             = (i < npos) ? cls[i] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) r[q] = c[q] ? resid[c[q]] : kInvalid;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const uint32_t i = i0 + q * kBlock + threadIdx.x;
+            if (i < npos) {
+                ids[i] = r[q];
+                nvalid += r[q] != kInvalid;
+            }
+        }
+    }
+    __shared__ uint32_t redL[kBlock / kWave];
+    for (int off = 32; off > 0; off >>= 1) nvalid += __shfl_down(nvalid, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nvalid;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t v = redL[0] + redL[1] + redL[2] + redL[3];
+        if (v) atomicAdd(&st->valid, v);
+    }
+}
 // the same from the survivor bitmap uni_finish_kernel left behind: the first 262 144 classes (> 90 % of a Zipf corpus' tokens) are
 // answered from a 32 KB LDS copy, the rest by a gather into a bitmap 32x smaller than the count array
 constexpr uint32_t kSurvLdsWords = 8192;
@@ -1179,6 +1214,52 @@ __global__ __launch_bounds__(kBlock) void refs_kernel(const uint32_t* __restrict
         const uint32_t begin = lo ? delimpos[lo - 1] + 1 : 0;
         ref_sentence[j]      = first_sentence + lo;
         ref_token[j]         = (uint16_t)(p - begin);
+    }
+}
+
+// the same through a per-position table (sentence ordinal, token offset): built once per corpus — it is the sentence index the reference's
+// IndexedCorpus keeps (pattern.cpp:1942-1958) — so that a model's 10^8 references cost two gathers each instead of a binary search each
+__global__ __launch_bounds__(kBlock) void position_refs_kernel(const uint32_t* __restrict__ delimpos, uint32_t ndelim, uint32_t npos, uint32_t* __restrict__ pos_sentence,
+                                                                uint16_t* __restrict__ pos_token) {
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < npos; p += gridDim.x * kBlock) {
+        uint32_t lo = 0, hi = ndelim;  // first delimiter position >= p
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (delimpos[mid] < p)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        const uint32_t begin = lo ? delimpos[lo - 1] + 1 : 0;
+        pos_sentence[p]      = lo;
+        pos_token[p]         = (uint16_t)(p - begin);
+    }
+}
+__global__ __launch_bounds__(kBlock) void refs_table_kernel(const uint32_t* __restrict__ pos, uint64_t n, const uint32_t* __restrict__ pos_sentence,
+                                                             const uint16_t* __restrict__ pos_token, uint32_t first_sentence, uint32_t* __restrict__ ref_sentence,
+                                                             uint16_t* __restrict__ ref_token) {
+    constexpr int kPer = 4;  // gathers in flight per lane
+    for (uint64_t j0 = (uint64_t)blockIdx.x * kBlock * kPer; j0 < n; j0 += (uint64_t)gridDim.x * kBlock * kPer) {
+        uint32_t p[kPer], s[kPer];
+        uint16_t t[kPer];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const uint64_t j = j0 + (uint64_t)q * kBlock + threadIdx.x;
+            p[q]             = j < n ? pos[j] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            s[q] = pos_sentence[p[q]];
+            t[q] = pos_token[p[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const uint64_t j = j0 + (uint64_t)q * kBlock + threadIdx.x;
+            if (j < n) {
+                ref_sentence[j] = first_sentence + s[q];
+                ref_token[j]    = t[q];
+            }
+        }
     }
 }
 

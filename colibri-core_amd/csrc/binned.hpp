@@ -412,7 +412,7 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
                                               BinState* __restrict__ bs, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
                                               unsigned long long* __restrict__ sp_key, uint32_t* __restrict__ ids_at, unsigned long long* keyT, uint32_t* cntT,
                                               uint32_t* repT, uint32_t* idT, uint32_t* redL, uint32_t* failL, const uint32_t* __restrict__ wide, uint32_t* __restrict__ cnt_at,
-                                              uint8_t* __restrict__ flags_at) {
+                                              uint8_t* __restrict__ flags_at, bool dense_code) {
     // all loads of the (first 2048) records are issued before anything else: a bin is latency-bound, not bandwidth-bound
     Rec xr[kBinRegPer];
 #pragma unroll
@@ -486,7 +486,9 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
                 sp_rep[r] = repT[s];
                 sp_cnt[r] = cntT[s];
                 if (sp_key != nullptr) sp_key[r] = keyT[s];  // sharded runs: the sparse arrays ARE the local candidate list
-                id = id_base + r;
+                // dense_code: (bin, rank among the bin's survivors) — bin_resolve_kernel turns it into the survivor's RESULT index once the per-bin
+                // survivor counts are scanned (the per-pass modes use result indices as ids: they are the pattern numbers of the forward index)
+                id = dense_code ? ((f << 11) | (r - begin)) : id_base + r;
             }
             ++r;
         }
@@ -530,7 +532,8 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
 template <bool MERGE>
 __device__ __forceinline__ void bin_count_body(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
                                                uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt, unsigned long long* __restrict__ sp_key,
-                                               uint32_t* __restrict__ ids_at, const uint32_t* __restrict__ wide, uint32_t* __restrict__ cnt_at, uint8_t* __restrict__ flags_at) {
+                                               uint32_t* __restrict__ ids_at, const uint32_t* __restrict__ wide, uint32_t* __restrict__ cnt_at, uint8_t* __restrict__ flags_at,
+                                               bool dense_code) {
     if (st->done) return;
     __shared__ unsigned long long keyT[kBinSlots];
     __shared__ uint32_t           cntT[kBinSlots], repT[kBinSlots], idT[kBinSlots];
@@ -544,19 +547,19 @@ __device__ __forceinline__ void bin_count_body(const Rec* __restrict__ recs, Dev
         const uint32_t begin = bs->hist2[f];
         const uint32_t end   = (f + 1 < (uint32_t)kFinalBins) ? bs->hist2[f + 1] : bs->total2;
         if (begin >= end) continue;
-        bin_count_one<MERGE>(f, begin, end, recs, st, bs, threshold, sp_rep, sp_cnt, sp_key, ids_at, keyT, cntT, repT, idT, redL, &failL, wide, cnt_at, flags_at);
+        bin_count_one<MERGE>(f, begin, end, recs, st, bs, threshold, sp_rep, sp_cnt, sp_key, ids_at, keyT, cntT, repT, idT, redL, &failL, wide, cnt_at, flags_at, dense_code);
         __syncthreads();
     }
 }
 __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
                                                             uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt, unsigned long long* __restrict__ sp_key,
-                                                            uint32_t* __restrict__ ids_at, uint8_t* __restrict__ flags_at = nullptr) {
-    bin_count_body<false>(recs, st, bs, threshold, sp_rep, sp_cnt, sp_key, ids_at, nullptr, nullptr, flags_at);
+                                                            uint32_t* __restrict__ ids_at, uint8_t* __restrict__ flags_at = nullptr, bool dense_code = false) {
+    bin_count_body<false>(recs, st, bs, threshold, sp_rep, sp_cnt, sp_key, ids_at, nullptr, nullptr, flags_at, dense_code);
 }
 // owner-side merge of a sharded n-gram pass (see bin_count_one<MERGE>)
 __global__ __launch_bounds__(kBlock) void bin_merge_count_kernel(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
                                                                   uint32_t* __restrict__ ids_at, const uint32_t* __restrict__ wide, uint32_t* __restrict__ cnt_at) {
-    bin_count_body<true>(recs, st, bs, threshold, nullptr, nullptr, nullptr, ids_at, wide, cnt_at, nullptr);
+    bin_count_body<true>(recs, st, bs, threshold, nullptr, nullptr, nullptr, ids_at, wide, cnt_at, nullptr, false);
 }
 
 // ---- sharded radix passes: the sparse per-bin arrays ARE the local candidate list ---------------------------------------------
@@ -733,7 +736,8 @@ template <bool LIST>
 __global__ __launch_bounds__(kBlock) void bin_resolve_kernel(const uint32_t* __restrict__ rep_of, const uint32_t* __restrict__ ids_at, uint32_t* __restrict__ ids,
                                                               DevState* __restrict__ st, uint32_t npos, const uint32_t* __restrict__ list_in,
                                                               const uint32_t* __restrict__ nlist_in, uint32_t* __restrict__ list_out, uint32_t* __restrict__ nlist_out,
-                                                              const uint32_t* __restrict__ remap, uint32_t remap_base) {
+                                                              const uint32_t* __restrict__ remap, uint32_t remap_base, const BinState* __restrict__ decode = nullptr,
+                                                              uint32_t decode_base = 0) {
     if (st->done) return;
     __shared__ uint32_t baseL;
     __shared__ uint32_t redL[kBlock / kWave];
@@ -755,6 +759,11 @@ __global__ __launch_bounds__(kBlock) void bin_resolve_kernel(const uint32_t* __r
 #pragma unroll
             for (int q = 0; q < kResPer; ++q)
                 if (id[q] != kInvalid) id[q] = remap[id[q] - remap_base];  // sharded: local sparse id -> global survivor id
+        }
+        if (decode != nullptr) {
+#pragma unroll
+            for (int q = 0; q < kResPer; ++q)
+                if (id[q] != kInvalid) id[q] = decode_base + decode->cur2[id[q] >> 11] + (id[q] & 2047u);  // (bin, rank) -> result index
         }
 #pragma unroll
         for (int q = 0; q < kResPer; ++q) {

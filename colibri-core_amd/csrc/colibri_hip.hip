@@ -635,7 +635,8 @@ BinnedIO binned_planes(colibri_ctx* c, const TrainPlan& pl, bool with_keys) {
 }
 
 template <class KeyFn>
-int binned_count_stage(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, int n, bool use_list, uint32_t thr, bool with_keys, bool need_ids = true, bool flag_mode = false) {
+int binned_count_stage(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, int n, bool use_list, uint32_t thr, bool with_keys, bool need_ids = true, bool flag_mode = false,
+                       bool dense_code = false) {
     const uint32_t  tiles    = blocks_for(pl.npos, kScatTile) + 1 + kASlots;  // level-B tiles: every slot may end in a partial one
     const uint32_t* list_in  = c->alist[n & 1].p;
     const uint32_t* nlist_in = c->alist_n.p + (n & 1);
@@ -663,13 +664,13 @@ int binned_count_stage(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, int
     const BinnedIO io = binned_planes(c, pl, with_keys);
     {
         Prof p(c, COLIBRI_K_BINCOUNT);
-        hipLaunchKernelGGL(bin_count_kernel, dim3(256 * 12), dim3(kBlock), 0, c->stream, c->recs[1].p, c->state.p, c->binstate.p, thr, io.sp_rep, io.sp_cnt, io.sp_key, ids_at, flags_at);
+        hipLaunchKernelGGL(bin_count_kernel, dim3(256 * 12), dim3(kBlock), 0, c->stream, c->recs[1].p, c->state.p, c->binstate.p, thr, io.sp_rep, io.sp_cnt, io.sp_key, ids_at, flags_at, dense_code);
     }
     return COLIBRI_OK;
 }
 
 int binned_resolve_stage(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids_out, int n, bool use_list, bool build_list, const uint32_t* remap, uint32_t remap_base,
-                         bool prefill_ids = true) {
+                         bool prefill_ids = true, bool decode = false, uint32_t decode_base = 0) {
     const uint32_t* list_in   = c->alist[n & 1].p;
     const uint32_t* nlist_in  = c->alist_n.p + (n & 1);
     uint32_t*       list_out  = build_list ? c->alist[(n + 1) & 1].p : nullptr;
@@ -679,10 +680,10 @@ int binned_resolve_stage(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids_out,
     Prof p(c, COLIBRI_K_RESOLVE);
     if (use_list)
         hipLaunchKernelGGL((bin_resolve_kernel<true>), dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->rep_of.p, c->ids_at.p, ids_out, c->state.p, pl.npos, list_in, nlist_in, list_out,
-                           nlist_out, remap, remap_base);
+                           nlist_out, remap, remap_base, decode ? (const BinState*)c->binstate.p : (const BinState*)nullptr, decode_base);
     else
         hipLaunchKernelGGL((bin_resolve_kernel<false>), dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->rep_of.p, c->ids_at.p, ids_out, c->state.p, pl.npos, (const uint32_t*)nullptr,
-                           (const uint32_t*)nullptr, list_out, nlist_out, remap, remap_base);
+                           (const uint32_t*)nullptr, list_out, nlist_out, remap, remap_base, decode ? (const BinState*)c->binstate.p : (const BinState*)nullptr, decode_base);
     return COLIBRI_OK;
 }
 
@@ -924,14 +925,15 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     if (c->ids.size() < 2) c->ids.resize(2);
     if ((rc = dev_alloc(c, c->ids[0], (size_t)npos + 1))) return rc;
     if ((rc = dev_alloc(c, c->ids[1], (size_t)npos + 1))) return rc;
-    if (binned) {
+    // the per-pass modes count their n-gram passes of order >= 2 on the radix path too (result indices as ids, see bin_count's dense codes)
+    const bool radix_synced = synced && !constrained && o.table_mode == 0 && c->ntokens <= 128ull * 1000 * 1000;
+    if (binned || radix_synced) {
         // recs[0]: 256 fixed-capacity A-bin regions (25 % slack over a uniform split + one scatter tile each); recs[1]: exact
         if ((rc = dev_alloc(c, c->recs[0], ((size_t)npos + (npos >> 2)) / kBins * kBins + (size_t)kBins * kScatTile)) || (rc = dev_alloc(c, c->recs[1], (size_t)npos + 1))) return rc;
         if ((rc = dev_alloc(c, c->rep_of, (size_t)npos + 1)) || (rc = dev_alloc(c, c->ids_at, (size_t)npos + 1)) || (rc = dev_alloc(c, c->binstate, 1))) return rc;
         if ((rc = dev_alloc(c, c->alist[0], (size_t)npos + 1)) || (rc = dev_alloc(c, c->alist[1], (size_t)npos + 1)) || (rc = dev_alloc(c, c->alist_n, 2))) return rc;
-    } else if ((rc = dev_alloc(c, c->table, pl.table_slots))) {
-        return rc;
     }
+    if (!binned && (rc = dev_alloc(c, c->table, pl.table_slots))) return rc;  // the plain radix run needs no table (a bin overflow re-runs with table_mode = 1)
     if ((rc = dev_alloc(c, c->res_rep, pl.res_cap))) return rc;
     if ((rc = dev_alloc(c, c->res_cnt, pl.res_cap))) return rc;
     if ((rc = dev_alloc(c, c->state, 1))) return rc;
@@ -1036,6 +1038,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     } else {
         // ---------- skipgram / indexed modes: one host round trip per pass (sizes, lazily grown per-order id arrays) ----------
         if ((int)c->ids.size() < maxlength + 2) c->ids.resize(maxlength + 2);
+        bool       list_valid = false;  // the active list of the previous radix pass exists
         const bool uni_synced = !constrained && o.table_mode == 0 && !(c->flags & kFlagNonCanonical) && c->maxclass < (1u << 28);
         std::vector<uint32_t> valid_n(maxlength + 2, 0), adm_n(maxlength + 2, 0);
         uint32_t              res_total = 0;
@@ -1052,7 +1055,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
         }
         for (int n = constrained ? std::max(1, o.minlength) : 1; n <= maxlength && !c->hstate.done; ++n) {
             if ((rc = dev_alloc(c, c->ids[n], (size_t)npos + 1))) return rc;
-            launch_clear(c, pl);
+            if (!(n == 1 && uni_synced) && !(radix_synced && n >= 2)) launch_clear(c, pl);  // only the table passes need the table cleared
             if (n == 1 && uni_synced) {
                 // order 1 on the class-indexed count array (as in the plain mode): no hashing, no table; the survivor id of a unigram is its
                 // RESULT index here, read per position through a class -> result table
@@ -1075,6 +1078,23 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                     Prof p(c, COLIBRI_K_RESOLVE);
                     hipLaunchKernelGGL(uni_resid_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_resid.p, c->ids[n].p, c->state.p, npos);
                 }
+            } else if (radix_synced && n >= 2) {
+                // n-gram pass on the radix path: emit -> level B -> per-bin LDS count; survivors leave as (bin, rank) codes that the resolve turns
+                // into result indices (= the ids the skipgram passes and the forward index work with); from order 3 on only the active list is walked
+                const bool use_list = n >= 3 && list_valid;
+                c->hstate.radix_overflow = 0;
+                if ((rc = write_state(c))) return rc;
+                if ((rc = binned_count_stage(c, pl, KeyNgram{c->ids[n - 1].p, n}, n, use_list, pl.thr, false, true, false, /*dense_code=*/true))) return rc;
+                const BinnedIO io = binned_planes(c, pl, false);
+                {
+                    Prof p(c, COLIBRI_K_PRUNE);
+                    hipLaunchKernelGGL(bin_kept_scan_kernel, dim3(kBins), dim3(kBlock), 0, c->stream, c->state.p, c->binstate.p, pl.res_cap);
+                    hipLaunchKernelGGL(compact_bins_kernel, dim3(1024), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, c->binstate.p, c->res_rep.p, c->res_cnt.p, pl.res_cap,
+                                       use_list ? (const uint32_t*)c->alist[n & 1].p : (const uint32_t*)nullptr);
+                    hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
+                }
+                if ((rc = binned_resolve_stage(c, pl, c->ids[n].p, n, use_list, true, nullptr, 0u, /*prefill_ids=*/true, /*decode=*/true, res_total))) return rc;
+                list_valid = true;
             } else {
                 if (constrained)
                     launch_count(c, pl, KeyConstrained{c->bytes.p, c->tokstart.p, c->cs.rem.p, c->cs.table.p, c->cs.cap, c->cs.bytes.p, c->cs.off.p, n}, c->ids[n].p, 3, COLIBRI_K_COUNT);
@@ -1086,6 +1106,11 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                 launch_resolve(c, pl, c->ids[n].p);
             }
             if ((rc = read_state(c))) return rc;
+            if (radix_synced && c->hstate.radix_overflow) {  // a bin outgrew its LDS table: the whole run again on the table path (loud, exact, rare)
+                colibri_options again = o;
+                again.table_mode      = 1;
+                return colibri_train(c, &again, stats_out);
+            }
             const uint32_t found = c->hstate.found, kept = c->hstate.kept;
             adm_n[n]   = c->hstate.admitted;
             valid_n[n] = c->hstate.valid;

@@ -54,8 +54,7 @@ struct colibri_ctx {
     DevBuf<uint32_t>  tokstart;
     DevBuf<uint32_t>  delimpos;
     DevBuf<uint32_t>  cls;              // class id per position (0 = delimiter)
-    DevBuf<uint32_t>  pos_sentence;     // sentence ordinal per position and ...
-    DevBuf<uint16_t>  pos_token;        // ... token offset inside it (built at the first indexed run on a corpus)
+    DevBuf<uint2>     pos_ref;          // (sentence ordinal, token offset) per position (built at the first indexed run on a corpus)
     bool              pos_refs_valid = false;
     DevBuf<uint32_t>  cnt1, rep1;       // order-1 fast path: count / representative position per class
     DevBuf<UniState>  unistate;         // ... its atomic-free variant: tail-bin sizes / offsets / cursors
@@ -418,8 +417,7 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->bytes);
     dev_free(c->tokstart);
     dev_free(c->delimpos);
-    dev_free(c->pos_sentence);
-    dev_free(c->pos_token);
+    dev_free(c->pos_ref);
     dev_free(c->cls);
     dev_free(c->cnt1);
     dev_free(c->rep1);
@@ -847,11 +845,11 @@ int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = fal
             cur ^= 1;
         }
         if (!c->pos_refs_valid) {
-            if ((rc = dev_alloc(c, c->pos_sentence, (size_t)c->npos + 1)) || (rc = dev_alloc(c, c->pos_token, (size_t)c->npos + 1))) return rc;
-            hipLaunchKernelGGL(position_refs_kernel, dim3(stream_grid(c->npos)), dim3(kBlock), 0, c->stream, c->delimpos.p, c->ndelim, c->npos, c->pos_sentence.p, c->pos_token.p);
+            if ((rc = dev_alloc(c, c->pos_ref, (size_t)c->npos + 1))) return rc;
+            hipLaunchKernelGGL(position_refs_kernel, dim3(stream_grid(c->npos)), dim3(kBlock), 0, c->stream, c->delimpos.p, c->ndelim, c->npos, c->pos_ref.p);
             c->pos_refs_valid = true;
         }
-        hipLaunchKernelGGL(refs_table_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, c->stream, c->pair_pos[cur].p, n, c->pos_sentence.p, c->pos_token.p, c->first_sentence,
+        hipLaunchKernelGGL(refs_table_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, c->stream, c->pair_pos[cur].p, n, c->pos_ref.p, c->first_sentence,
                            c->ref_sentence.p, c->ref_token.p);
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -1219,8 +1219,7 @@ __global__ __launch_bounds__(kBlock) void refs_kernel(const uint32_t* __restrict
 
 // the same through a per-position table (sentence ordinal, token offset): built once per corpus — it is the sentence index the reference's
 // IndexedCorpus keeps (pattern.cpp:1942-1958) — so that a model's 10^8 references cost two gathers each instead of a binary search each
-__global__ __launch_bounds__(kBlock) void position_refs_kernel(const uint32_t* __restrict__ delimpos, uint32_t ndelim, uint32_t npos, uint32_t* __restrict__ pos_sentence,
-                                                                uint16_t* __restrict__ pos_token) {
+__global__ __launch_bounds__(kBlock) void position_refs_kernel(const uint32_t* __restrict__ delimpos, uint32_t ndelim, uint32_t npos, uint2* __restrict__ pos_ref) {
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < npos; p += gridDim.x * kBlock) {
         uint32_t lo = 0, hi = ndelim;  // first delimiter position >= p
         while (lo < hi) {
@@ -1231,33 +1230,28 @@ __global__ __launch_bounds__(kBlock) void position_refs_kernel(const uint32_t* _
                 hi = mid;
         }
         const uint32_t begin = lo ? delimpos[lo - 1] + 1 : 0;
-        pos_sentence[p]      = lo;
-        pos_token[p]         = (uint16_t)(p - begin);
+        pos_ref[p]           = make_uint2(lo, p - begin);  // (sentence ordinal, token offset): one 8-byte gather per reference later
     }
 }
-__global__ __launch_bounds__(kBlock) void refs_table_kernel(const uint32_t* __restrict__ pos, uint64_t n, const uint32_t* __restrict__ pos_sentence,
-                                                             const uint16_t* __restrict__ pos_token, uint32_t first_sentence, uint32_t* __restrict__ ref_sentence,
-                                                             uint16_t* __restrict__ ref_token) {
+__global__ __launch_bounds__(kBlock) void refs_table_kernel(const uint32_t* __restrict__ pos, uint64_t n, const uint2* __restrict__ pos_ref, uint32_t first_sentence,
+                                                             uint32_t* __restrict__ ref_sentence, uint16_t* __restrict__ ref_token) {
     constexpr int kPer = 4;  // gathers in flight per lane
     for (uint64_t j0 = (uint64_t)blockIdx.x * kBlock * kPer; j0 < n; j0 += (uint64_t)gridDim.x * kBlock * kPer) {
-        uint32_t p[kPer], s[kPer];
-        uint16_t t[kPer];
+        uint32_t p[kPer];
+        uint2    r[kPer];
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
             const uint64_t j = j0 + (uint64_t)q * kBlock + threadIdx.x;
             p[q]             = j < n ? pos[j] : 0u;
         }
 #pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-            s[q] = pos_sentence[p[q]];
-            t[q] = pos_token[p[q]];
-        }
+        for (int q = 0; q < kPer; ++q) r[q] = pos_ref[p[q]];
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
             const uint64_t j = j0 + (uint64_t)q * kBlock + threadIdx.x;
             if (j < n) {
-                ref_sentence[j] = first_sentence + s[q];
-                ref_token[j]    = t[q];
+                ref_sentence[j] = first_sentence + r[q].x;
+                ref_token[j]    = (uint16_t)r[q].y;
             }
         }
     }

@@ -76,6 +76,7 @@ struct colibri_ctx {
     DevBuf<uint16_t>  ref_token;
     DevBuf<Slot>      table;
     DevBuf<Rec>       recs[2];          // binned path: record ping-pong
+    DevBuf<uint32_t>  sklist, sklist_n; // skipgram passes: the positions that can take part in the current order
     DevBuf<uint32_t>  rep_of, ids_at;   // binned path: representative position per window; survivor id at representative positions
     DevBuf<uint8_t>   flags_at, flag2;  // flag mode of order 2 (KeyTrigramCls): survivor byte at representative positions / per position
     struct ConstraintSet {              // constrained training (constrained.hpp): the pattern set J and its lookup table
@@ -433,6 +434,8 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->recs[0]);
     dev_free(c->recs[1]);
     dev_free(c->rep_of);
+    dev_free(c->sklist);
+    dev_free(c->sklist_n);
     dev_free(c->flags_at);
     dev_free(c->tx.text); dev_free(c->tx.out); dev_free(c->tx.slot_of); dev_free(c->tx.first); dev_free(c->tx.widx); dev_free(c->tx.wstart); dev_free(c->tx.wlen);
     dev_free(c->tx.wcount); dev_free(c->tx.cls); dev_free(c->tx.repeat); dev_free(c->tx.outlen); dev_free(c->tx.outoff); dev_free(c->tx.bsum); dev_free(c->tx.ntok);
@@ -569,9 +572,9 @@ int write_state(colibri_ctx* c) {
 }
 
 template <class KeyFn>
-void launch_count(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t* slot_of, int track, int cls) {
+void launch_count(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t* slot_of, int track, int cls, const uint32_t* list = nullptr, const uint32_t* nlist = nullptr) {
     Prof p(c, cls);
-    hipLaunchKernelGGL((count_kernel<KeyFn>), dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, fn, slot_of, c->table.p, c->state.p, pl.npos, track);
+    hipLaunchKernelGGL((count_kernel<KeyFn>), dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, fn, slot_of, c->table.p, c->state.p, pl.npos, track, list, nlist);
 }
 void launch_clear(colibri_ctx* c, const TrainPlan& pl) {
     Prof p(c, COLIBRI_K_CLEAR);
@@ -715,6 +718,17 @@ int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t*
 // One (order, gap mask) skipgram pass. Exact identity of a skipgram = the survivor ids of its contiguous parts, paired
 // left to right: level 1 interns (part1, part2) into slot numbers, level j pairs those with part j+1; the last level counts.
 // gate/gate2 select the windows that take part (exhaustive: both (n-1)-grams survived; indexed: the n-gram survived).
+// the positions whose `gate` entry is valid -> c->sklist / c->sklist_n: the skipgram passes of an order walk this list (at orders 4 and 5 a
+// few percent of the positions) instead of the whole corpus
+int build_skip_list(colibri_ctx* c, const TrainPlan& pl, const uint32_t* gate) {
+    int rc;
+    if ((rc = dev_alloc(c, c->sklist, (size_t)pl.npos + 1)) || (rc = dev_alloc(c, c->sklist_n, 1))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->sklist_n.p, 0, sizeof(uint32_t), c->stream));
+    Prof p(c, COLIBRI_K_SKIPGRAM);
+    hipLaunchKernelGGL(list_from_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, gate, pl.npos, c->sklist.p, c->sklist_n.p);
+    return COLIBRI_OK;
+}
+
 int skipgram_pass(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, const uint32_t* gate, const uint32_t* gate2, uint32_t participants, uint32_t thr, bool count_sources,
                   uint32_t minsrc, uint32_t* found_out, uint32_t* kept_out, int* final_scratch) {
     const std::vector<std::pair<int, int>> parts = mask_parts(mask, n);
@@ -730,8 +744,9 @@ int skipgram_pass(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, con
         if ((rc = write_state(c))) return rc;
         launch_clear(c, pl);
         out = c->scratch[j & 1].p;
+        HIP_TRY(c, hipMemsetAsync(out, 0xFF, sizeof(uint32_t) * (size_t)pl.npos, c->stream));  // only the listed positions are written
         KeyPair fn{gate, gate2, left, offl, c->ids[parts[j].second].p, (uint32_t)parts[j].first};
-        launch_count(c, pl, fn, out, last ? 2 : 0, COLIBRI_K_SKIPGRAM);
+        launch_count(c, pl, fn, out, last ? 2 : 0, COLIBRI_K_SKIPGRAM, c->sklist.p, c->sklist_n.p);
         left = out;
         offl = 0;
     }
@@ -1123,6 +1138,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             if (o.indexed && kept && (rc = emit_pairs(c, pl, c->ids[n].p))) return rc;  // occurrences of the surviving n-grams
             if (o.doskipgrams_exhaustive && n >= 3) {  // patternmodel.h:1163-1171 -> computeskipgrams :1370-1527, for every admissible window
                 if (n > 13) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 13 tokens are not on the accelerated path (set MAXLENGTH)");
+                if ((rc = build_skip_list(c, pl, c->ids[n - 1].p))) return rc;
                 for (uint32_t mask : gap_masks(n, o.maxskips)) {
                     uint32_t f = 0, k = 0;
                     if ((rc = skipgram_pass(c, pl, n, mask, c->ids[n - 1].p, c->ids[n - 1].p, adm_n[n], thr_skip, false, 0, &f, &k, nullptr))) return rc;
@@ -1143,6 +1159,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             for (int n = 3; n <= std::min<int>(maxlength, s.maxn); ++n) {
                 if (n > 13) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 13 tokens are not on the accelerated path (set MAXLENGTH)");
                 uint32_t found_n = 0;
+                if ((rc = build_skip_list(c, pl, c->ids[n].p))) return rc;
                 for (uint32_t mask : gap_masks(n, o.maxskips)) {
                     uint32_t f = 0, k = 0;
                     int fs = 0;

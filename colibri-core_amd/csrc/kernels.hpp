@@ -357,9 +357,38 @@ struct KeyPair {
     }
 };
 
+// positions whose entry of `ids` is valid (one reservation per 4096 positions)
+__global__ __launch_bounds__(kBlock) void list_from_ids_kernel(const uint32_t* __restrict__ ids, uint32_t npos, uint32_t* __restrict__ list, uint32_t* __restrict__ nlist) {
+    __shared__ uint32_t baseL;
+    constexpr int       kPer = 16;
+    const uint32_t      ntiles = (npos + kBlock * kPer - 1) / (kBlock * kPer);
+    // ascending inside a tile; the order of the tiles in the list is whatever the reservations give (no consumer relies on it)
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t i0 = tile * kBlock * kPer + threadIdx.x * kPer;
+        uint32_t       m = 0, c = 0;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q)
+            if (i0 + q < npos && ids[i0 + q] != kInvalid) {
+                m |= 1u << q;
+                ++c;
+            }
+        uint32_t       total;
+        const uint32_t excl = block_exclusive_scan(c, &total);
+        if (threadIdx.x == 0) baseL = total ? atomicAdd(nlist, total) : 0;
+        __syncthreads();
+        uint32_t o = baseL + excl;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q)
+            if (m & (1u << q)) list[o++] = i0 + q;
+        __syncthreads();
+    }
+}
 template <class KeyFn>
 __global__ __launch_bounds__(kBlock) void count_kernel(KeyFn keyfn, uint32_t* __restrict__ slot_of, Slot* __restrict__ table, DevState* __restrict__ st, uint32_t npos,
-                                                        int track) {  // track: bit 0 = add to st->admitted, bit 1 = add CAS wins to st->found
+                                                        int track,  // track: bit 0 = add to st->admitted, bit 1 = add CAS wins to st->found
+                                                        const uint32_t* __restrict__ list = nullptr, const uint32_t* __restrict__ nlist = nullptr) {
+    // list / nlist (optional): visit only these positions instead of all npos — the passes of the higher orders, where few
+    // positions can start a window. slot_of stays indexed by POSITION; the caller pre-fills it with kInvalid when a list is used.
     if (st->done) return;
     __shared__ uint64_t keyL[kCountTile];
     __shared__ uint32_t winL[kCountLSlot];
@@ -368,19 +397,26 @@ __global__ __launch_bounds__(kBlock) void count_kernel(KeyFn keyfn, uint32_t* __
     __shared__ uint32_t redL[2][kBlock / kWave];
 
     const uint32_t cap    = st->cap;
-    const uint32_t ntiles = (npos + kCountTile - 1) / kCountTile;
+    const uint32_t nitems = list != nullptr ? *nlist : npos;
+    const uint32_t ntiles = (nitems + kCountTile - 1) / kCountTile;
     uint32_t       nadm = 0, nins = 0;
 
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t base = tile * kCountTile;
         uint64_t       key[kCountPer], hash[kCountPer];
+        uint32_t       posn[kCountPer];
         bool           adm[kCountPer];
 #pragma unroll
         for (int k = 0; k < kCountPer; ++k) {
-            const uint32_t e = k * kBlock + threadIdx.x, i = base + e;
+            const uint32_t j = base + k * kBlock + threadIdx.x;
+            posn[k]          = list != nullptr ? (j < nitems ? list[j] : 0u) : j;
+        }
+#pragma unroll
+        for (int k = 0; k < kCountPer; ++k) {
+            const uint32_t e = k * kBlock + threadIdx.x, i = posn[k];
             key[k]  = 0;
             hash[k] = 0;
-            adm[k]  = (i < npos) && keyfn(i, npos, key[k], hash[k]);
+            adm[k]  = (base + e < nitems) && keyfn(i, npos, key[k], hash[k]);
             cntL[e] = 0;
             if (adm[k]) {
                 keyL[e]                                     = key[k];
@@ -409,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void count_kernel(KeyFn keyfn, uint32_t* __
                 ++nadm;
                 if (rep[k] == e) {
                     uint32_t ins = 0;
-                    slotL[e]     = table_find_or_insert(table, cap, key[k], hash[k], base + e, 1u + cntL[e], &ins, st);
+                    slotL[e]     = table_find_or_insert(table, cap, key[k], hash[k], posn[k], 1u + cntL[e], &ins, st);
                     nins += ins;
                 }
             }
@@ -417,8 +453,8 @@ __global__ __launch_bounds__(kBlock) void count_kernel(KeyFn keyfn, uint32_t* __
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kCountPer; ++k) {
-            const uint32_t e = k * kBlock + threadIdx.x, i = base + e;
-            if (i < npos) slot_of[i] = adm[k] ? slotL[rep[k]] : kInvalid;
+            const uint32_t e = k * kBlock + threadIdx.x;
+            if (base + e < nitems) slot_of[posn[k]] = adm[k] ? slotL[rep[k]] : kInvalid;
         }
         // no barrier needed here: the next tile does not touch slotL before its second barrier
     }

@@ -1320,777 +1320,7 @@ int colibri_kernel_time(const colibri_ctx* c, int cls, double* total_ms, uint64_
 
 }  // extern "C"
 
-// =====================================================================================================
-// sentence-sharded multi-GPU entry points (see include/colibri_hip.h)
-// =====================================================================================================
-namespace {
-constexpr int kShHist = 1, kShOff = 65, kShCur = 130, kShSrc = 200, kShSmall = 272;
-
-TrainPlan shard_plan(colibri_ctx* c) {
-    TrainPlan pl{};
-    pl.npos        = c->npos;
-    pl.table_slots = (uint32_t)c->table.n;
-    pl.res_cap     = (uint32_t)c->res_rep.n;
-    pl.thr         = (uint32_t)c->opt.mintokens;
-    constexpr uint32_t kCountLdsBytes    = kCountTile * 16u + kCountLSlot * 4u + 64u;
-    constexpr uint32_t kCountBlocksPerCU = (160u * 1024u / kCountLdsBytes) < 8u ? (160u * 1024u / kCountLdsBytes) : 8u;
-    pl.cnt_grid = std::max<uint32_t>(1, std::min<uint32_t>(blocks_for(c->npos, kCountTile), 256u * kCountBlocksPerCU));
-    pl.tab_grid = stream_grid(pl.table_slots);
-    pl.pos_grid = stream_grid(c->npos);
-    return pl;
-}
-}  // namespace
-
-extern "C" {
-
-int colibri_shard_begin(colibri_ctx* c, const colibri_options* opt_in, int world) {
-    if (!c || !opt_in || world < 1 || world > 64) return COLIBRI_ERR_ARG;
-    if (!c->have_corpus) return fail(c, COLIBRI_ERR_STATE, "no corpus uploaded");
-    colibri_options o = *opt_in;
-    int             rc;
-    if ((rc = check_options(c, o))) return rc;
-    HIP_TRY(c, hipSetDevice(c->device));
-    c->opt     = o;
-    c->trained = false;
-    c->profile = o.profile;
-    collect_events(c);
-    std::fill(std::begin(c->k_ms), std::end(c->k_ms), 0.0);
-    std::fill(std::begin(c->k_launches), std::end(c->k_launches), 0);
-    c->segments.clear();
-    c->npairs = 0;
-    const uint32_t npos          = c->npos;
-    const uint64_t table_slots64 = (uint64_t)npos + (npos >> 1) + 2048;
-    if (table_slots64 >= 0x7FFFFFFFull) return fail(c, COLIBRI_ERR_CORPUS, "corpus shard too large for one device table");
-    if ((rc = dev_alloc(c, c->table, (size_t)table_slots64))) return rc;
-    const bool   skips   = o.doskipgrams || o.doskipgrams_exhaustive;
-    const size_t res_cap = (size_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)npos * (skips ? 4 : 2) + 1024);
-    if ((rc = dev_alloc(c, c->res_rep, res_cap)) || (rc = dev_alloc(c, c->res_cnt, res_cap)) || (rc = dev_alloc(c, c->sh.res_gid, res_cap))) return rc;
-    if ((rc = dev_alloc(c, c->state, 1)) || (rc = dev_alloc(c, c->sh.ostate, 1)) || (rc = dev_alloc(c, c->sh.small, kShSmall))) return rc;
-    if (skips) {
-        if ((rc = dev_alloc(c, c->scratch[0], (size_t)npos + 1)) || (rc = dev_alloc(c, c->scratch[1], (size_t)npos + 1))) return rc;
-    }
-    if (o.doskipgrams) {
-        if ((rc = dev_alloc(c, c->nsrc, (size_t)table_slots64)) || (rc = dev_alloc(c, c->sh.mark, (size_t)npos + 1))) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->sh.mark.p, 0, sizeof(uint32_t) * ((size_t)npos + 1), c->stream));
-    }
-    auto& sh      = c->sh;
-    sh.radix      = o.table_mode != 1 && c->ntokens <= 128ull * 1000 * 1000;
-    if (sh.radix) {
-        if ((rc = dev_alloc(c, c->recs[0], ((size_t)npos + (npos >> 2)) / kBins * kBins + (size_t)kBins * kScatTile)) || (rc = dev_alloc(c, c->recs[1], (size_t)npos + 1))) return rc;
-        if ((rc = dev_alloc(c, c->rep_of, (size_t)npos + 1)) || (rc = dev_alloc(c, c->ids_at, (size_t)npos + 1)) || (rc = dev_alloc(c, c->binstate, 1))) return rc;
-        if ((rc = dev_alloc(c, c->alist[0], (size_t)npos + 1)) || (rc = dev_alloc(c, c->alist[1], (size_t)npos + 1)) || (rc = dev_alloc(c, c->alist_n, 2))) return rc;
-        if ((rc = dev_alloc(c, sh.gid_of_sparse, (size_t)npos + 1))) return rc;
-    }
-    sh.list_valid = false;
-    sh.active     = true;
-    sh.world      = world;
-    sh.n          = 0;
-    sh.mask       = 0;
-    sh.res_total  = 0;
-    std::fill(std::begin(sh.exported_n), std::end(sh.exported_n), 0);
-    std::fill(std::begin(sh.admitted_n), std::end(sh.admitted_n), 0);
-    std::fill(std::begin(sh.valid_n), std::end(sh.valid_n), 0);
-    std::memset(&c->hstate, 0, sizeof c->hstate);
-    std::memset(&c->stats, 0, sizeof c->stats);
-    return COLIBRI_OK;
-}
-
-// one pass = the local count of (n, mask, level): mask 0 = the n-gram pass; otherwise level j (1-based) of the skipgram
-// (n, mask), whose identity is built by pairing the global ids of its parts left to right (levels = parts - 1)
-int colibri_shard_count(colibri_ctx* c, int n, uint32_t mask, int level, uint64_t* ncandidates, uint64_t* per_owner) {
-    if (!c || !ncandidates || !per_owner || n < 1 || n >= COLIBRI_MAX_ORDER) return COLIBRI_ERR_ARG;
-    if (!c->sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
-    HIP_TRY(c, hipSetDevice(c->device));
-    auto&                  sh = c->sh;
-    const TrainPlan        pl = shard_plan(c);
-    const colibri_options& o  = c->opt;
-    int                    rc;
-    if ((int)c->ids.size() < n + 2) c->ids.resize(n + 2);
-    if ((rc = dev_alloc(c, c->ids[n], (size_t)c->npos + 1))) return rc;
-    sh.n = n;
-    sh.mask = mask;
-    sh.level = level;
-    sh.final_level = true;
-    sh.use_aux = false;
-    sh.thr = pl.thr;
-    sh.minsrc = 0;
-    uint64_t  cap;
-    uint32_t* out;
-    if (mask == 0) {
-        if (n == 1) {
-            cap = (uint64_t)c->ntokens + (c->ntokens >> 1) + 1024;
-            if (!(c->flags & kFlagNonCanonical)) cap = std::min<uint64_t>(cap, 2ull * ((uint64_t)c->maxclass + 1) + 1024);
-        } else {
-            cap = (uint64_t)sh.valid_n[n - 1] + (sh.valid_n[n - 1] >> 1) + 1024;
-        }
-        out = c->ids[n].p;
-    } else {
-        if (n < 3 || n > 13 || !(o.doskipgrams || o.doskipgrams_exhaustive)) return fail(c, COLIBRI_ERR_ARG, "skipgram pass needs 3 <= n <= 13 and a skipgram mode");
-        const auto parts = mask_parts(mask, n);
-        if (level < 1 || level >= (int)parts.size()) return fail(c, COLIBRI_ERR_ARG, "skipgram pass level out of range");
-        sh.final_level = level + 1 == (int)parts.size();
-        const uint32_t participants = o.doskipgrams ? sh.valid_n[n] : (uint32_t)sh.admitted_n[n];
-        cap = (uint64_t)participants + (participants >> 1) + 1024;
-        out = c->scratch[level & 1].p;
-        if (!sh.final_level) {
-            sh.thr = 1;  // intermediate levels only intern pairs of ids: everything survives, nothing is exported
-        } else if (o.doskipgrams) {
-            sh.use_aux = true;
-            sh.minsrc  = o.minskiptypes > 1 ? (uint32_t)o.minskiptypes : 0u;
-        } else {
-            sh.thr = o.minskiptypes > 1 ? (uint32_t)o.mintokens_skipgrams : pl.thr;
-        }
-    }
-    DevState& hs = c->hstate;
-    hs.cap       = (uint32_t)std::min<uint64_t>(cap, pl.table_slots);
-    hs.done      = 0;
-    hs.found = hs.kept = hs.admitted = hs.valid = 0;
-    hs.res_total = sh.res_total;
-    if ((rc = write_state(c))) return rc;
-    // n-gram passes of order >= 2 count locally on the radix path (threshold 1: every distinct local key is a candidate); order 1
-    // and the skipgram passes use the global table
-    sh.pass_radix = sh.radix && mask == 0 && n >= 2;
-    uint32_t hist[64] = {0};
-    uint32_t D        = 0;
-    if (sh.pass_radix) {
-        hs.radix_overflow = 0;
-        hs.id_base = 0;  // sparse ids restart at 0 every pass: they are remapped to global ids when the replies arrive
-        if ((rc = write_state(c))) return rc;
-        const bool use_list = n >= 3 && sh.list_valid;
-        if ((rc = binned_count_stage(c, pl, KeyNgram{c->ids[n - 1].p, n}, n, use_list, 1u, true))) return rc;
-        hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
-        sh.pass_list = use_list;
-        if ((rc = read_state(c))) return rc;
-        if (hs.radix_overflow) return fail(c, COLIBRI_ERR_OVERFLOW, "a radix bin outgrew its LDS table in a sharded pass; rerun with table_mode = 1");
-        HIP_TRY(c, hipMemcpy(&sh.nsparse, &c->binstate.p->nrec, sizeof(uint32_t), hipMemcpyDeviceToHost));
-        sh.admitted_n[n] = hs.admitted;
-        D                = hs.found;
-        sh.ncand         = D;
-        if ((rc = dev_alloc(c, sh.tkeys, (size_t)D + 1)) || (rc = dev_alloc(c, sh.tcounts, (size_t)D + 1)) || (rc = dev_alloc(c, sh.tslots, (size_t)D + 1)) ||
-            (rc = dev_alloc(c, sh.pkeys, (size_t)D + 1)) || (rc = dev_alloc(c, sh.pcounts, (size_t)D + 1)) || (rc = dev_alloc(c, sh.pslots, (size_t)D + 1)) ||
-            (rc = dev_alloc(c, sh.taux, (size_t)D + 1)) || (rc = dev_alloc(c, sh.paux, (size_t)D + 1)))
-            return rc;
-        HIP_TRY(c, hipMemsetAsync(sh.small.p, 0, sizeof(uint32_t) * kShSmall, c->stream));
-        HIP_TRY(c, hipMemsetAsync(sh.gid_of_sparse.p, 0xFF, sizeof(uint32_t) * ((size_t)sh.nsparse + 1), c->stream));
-        {
-            // dense offsets of the candidates in bin order (= owner order), the owner boundaries, and the send buffers in one ordered copy
-            const BinnedIO io = binned_planes(c, pl, true);
-            DevState       scratch{};
-            HIP_TRY(c, hipMemcpyAsync(sh.ostate.p, &scratch, sizeof scratch, hipMemcpyHostToDevice, c->stream));
-            Prof p(c, COLIBRI_K_PRUNE);
-            hipLaunchKernelGGL(bin_kept_scan_kernel, dim3(kBins), dim3(kBlock), 0, c->stream, sh.ostate.p, c->binstate.p, 0xFFFFFFFFu);
-            hipLaunchKernelGGL(shard_owner_bounds_kernel, dim3(1), dim3(128), 0, c->stream, c->binstate.p, (uint32_t)sh.world, sh.small.p + kShOff);
-            if (D)
-                hipLaunchKernelGGL(shard_compact_bins_kernel, dim3(1024), dim3(kBlock), 0, c->stream, io.sp_key, io.sp_cnt, c->binstate.p, sh.pkeys.p, sh.pcounts.p, sh.pslots.p);
-        }
-        uint32_t bounds[65] = {0};
-        HIP_TRY(c, hipMemcpyAsync(bounds, sh.small.p + kShOff, sizeof(uint32_t) * (sh.world + 1), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipGetLastError());
-        if (bounds[sh.world] != D) return fail(c, COLIBRI_ERR_HIP, "candidate compaction lost records (%u of %u)", bounds[sh.world], D);
-        for (int r = 0; r < sh.world; ++r) per_owner[r] = bounds[r + 1] - bounds[r];
-        sh.out       = out;
-        *ncandidates = D;
-        return COLIBRI_OK;
-    } else {
-    launch_clear(c, pl);
-    if (mask == 0) {
-        if (n == 1)
-            launch_count(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, out, 3, COLIBRI_K_COUNT);
-        else
-            launch_count(c, pl, KeyNgram{c->ids[n - 1].p, n}, out, 3, COLIBRI_K_COUNT);
-    } else {
-        const auto      parts = mask_parts(mask, n);
-        const uint32_t* gate  = o.doskipgrams ? c->ids[n].p : c->ids[n - 1].p;
-        const uint32_t* gate2 = o.doskipgrams ? nullptr : c->ids[n - 1].p;
-        const uint32_t* left  = level == 1 ? c->ids[parts[0].second].p : c->scratch[(level - 1) & 1].p;
-        const uint32_t  offl  = level == 1 ? (uint32_t)parts[0].first : 0u;
-        KeyPair         fn{gate, gate2, left, offl, c->ids[parts[level].second].p, (uint32_t)parts[level].first};
-        launch_count(c, pl, fn, out, 2, COLIBRI_K_SKIPGRAM);
-        if (sh.use_aux) {
-            HIP_TRY(c, hipMemsetAsync(c->nsrc.p, 0, sizeof(uint32_t) * hs.cap, c->stream));
-            Prof p(c, COLIBRI_K_SKIPGRAM);
-            hipLaunchKernelGGL(shard_skip_sources_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->sh.mark.p, 1u << n, out, c->nsrc.p, pl.npos);
-        }
-    }
-    sh.out = out;
-    if ((rc = read_state(c))) return rc;
-    if (mask == 0) sh.admitted_n[n] = hs.admitted;
-    D        = hs.found;  // distinct local candidates
-    sh.ncand = D;
-    if ((rc = dev_alloc(c, sh.tkeys, (size_t)D + 1)) || (rc = dev_alloc(c, sh.tcounts, (size_t)D + 1)) || (rc = dev_alloc(c, sh.tslots, (size_t)D + 1)) ||
-        (rc = dev_alloc(c, sh.pkeys, (size_t)D + 1)) || (rc = dev_alloc(c, sh.pcounts, (size_t)D + 1)) || (rc = dev_alloc(c, sh.pslots, (size_t)D + 1)) ||
-        (rc = dev_alloc(c, sh.taux, (size_t)D + 1)) || (rc = dev_alloc(c, sh.paux, (size_t)D + 1)))
-        return rc;
-    HIP_TRY(c, hipMemsetAsync(sh.small.p, 0, sizeof(uint32_t) * kShSmall, c->stream));
-    if (D) {
-        Prof p(c, COLIBRI_K_PRUNE);
-        hipLaunchKernelGGL(shard_extract_kernel, dim3(stream_grid(hs.cap)), dim3(kBlock), 0, c->stream, c->table.p, hs.cap, (uint32_t)sh.world, sh.tkeys.p, sh.tcounts.p, sh.tslots.p,
-                           sh.small.p, sh.small.p + kShHist, sh.use_aux ? c->nsrc.p : (const uint32_t*)nullptr, sh.use_aux ? sh.taux.p : (uint32_t*)nullptr);
-    }
-    }
-    sh.out = out;
-    HIP_TRY(c, hipMemcpyAsync(hist, sh.small.p + kShHist, sizeof(uint32_t) * 64, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    uint32_t off[65] = {0};
-    for (int r = 0; r < sh.world; ++r) {
-        per_owner[r] = hist[r];
-        off[r + 1]   = off[r] + hist[r];
-    }
-    if (off[sh.world] != D) return fail(c, COLIBRI_ERR_HIP, "candidate extraction lost records (%u of %u)", off[sh.world], D);
-    HIP_TRY(c, hipMemcpyAsync(sh.small.p + kShOff, off, sizeof(uint32_t) * 65, hipMemcpyHostToDevice, c->stream));
-    if (D) {
-        Prof p(c, COLIBRI_K_PRUNE);
-        hipLaunchKernelGGL(shard_partition_kernel, dim3(stream_grid(D)), dim3(kBlock), 0, c->stream, sh.tkeys.p, sh.tcounts.p, sh.tslots.p, D, (uint32_t)sh.world, sh.small.p + kShOff,
-                           sh.small.p + kShCur, sh.pkeys.p, sh.pcounts.p, sh.pslots.p, sh.use_aux ? sh.taux.p : (const uint32_t*)nullptr, sh.use_aux ? sh.paux.p : (uint32_t*)nullptr);
-    }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipGetLastError());
-    *ncandidates = D;
-    return COLIBRI_OK;
-}
-
-int colibri_shard_send(colibri_ctx* c, void* keys_dev, void* counts_dev, void* aux_dev) {
-    if (!c) return COLIBRI_ERR_ARG;
-    if (!c->sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
-    HIP_TRY(c, hipSetDevice(c->device));
-    if (c->sh.ncand) {
-        if (!keys_dev || !counts_dev) return COLIBRI_ERR_ARG;
-        HIP_TRY(c, hipMemcpyAsync(keys_dev, c->sh.pkeys.p, sizeof(uint64_t) * c->sh.ncand, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(counts_dev, c->sh.pcounts.p, sizeof(uint32_t) * c->sh.ncand, hipMemcpyDeviceToDevice, c->stream));
-        if (aux_dev) {
-            if (c->sh.use_aux)
-                HIP_TRY(c, hipMemcpyAsync(aux_dev, c->sh.paux.p, sizeof(uint32_t) * c->sh.ncand, hipMemcpyDeviceToDevice, c->stream));
-            else
-                HIP_TRY(c, hipMemsetAsync(aux_dev, 0, sizeof(uint32_t) * c->sh.ncand, c->stream));
-        }
-    }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return COLIBRI_OK;
-}
-
-int colibri_shard_merge(colibri_ctx* c, const void* keys_dev, const void* counts_dev, const void* aux_dev, const uint64_t* per_src, uint64_t* found, uint64_t* kept) {
-    if (!c || !per_src || !found || !kept) return COLIBRI_ERR_ARG;
-    if (!c->sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
-    HIP_TRY(c, hipSetDevice(c->device));
-    auto&    sh       = c->sh;
-    uint32_t off[65]  = {0};
-    uint64_t total    = 0;
-    for (int r = 0; r < sh.world; ++r) {
-        total += per_src[r];
-        if (total >= 0x7FFFFFFFull) return fail(c, COLIBRI_ERR_OVERFLOW, "too many records for one owner");
-        off[r + 1] = (uint32_t)total;
-    }
-    const uint32_t n = (uint32_t)total;
-    sh.nrecv         = n;
-    if (n && (!keys_dev || !counts_dev)) return COLIBRI_ERR_ARG;
-    const bool aux = sh.use_aux && aux_dev != nullptr;
-    if (sh.use_aux && n && !aux_dev) return fail(c, COLIBRI_ERR_ARG, "this pass needs the distinct-source counts (aux buffer)");
-    int rc;
-    // n-gram passes of radix-mode runs merge on the radix path too: the received candidates are records, binned by a salted mix of
-    // the key, partitioned twice and summed per final bin in LDS (no table in HBM, no device atomics per candidate). A bin that
-    // outgrows its LDS table falls through to the table merge below.
-    sh.merge_radix = false;
-    if (sh.radix && sh.mask == 0 && !sh.use_aux && n != 0 && c->opt.table_mode != 1) {
-        const size_t cap0 = ((size_t)n + (n >> 2)) / kASlots * kASlots + (size_t)kASlots * 512;
-        if ((rc = dev_alloc(c, sh.orecs[0], cap0)) || (rc = dev_alloc(c, sh.orecs[1], (size_t)n + 1)) || (rc = dev_alloc(c, sh.obin, 1)) || (rc = dev_alloc(c, sh.oids_at, (size_t)n + 1)) ||
-            (rc = dev_alloc(c, sh.ocnt_at, (size_t)n + 1)))
-            return rc;
-        DevState os{};
-        HIP_TRY(c, hipMemcpyAsync(sh.ostate.p, &os, sizeof os, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemsetAsync(sh.obin.p, 0, sizeof(BinState), c->stream));
-        const uint32_t region = (uint32_t)(sh.orecs[0].n / kASlots), tiles = blocks_for(n, kScatTile) + 1 + kASlots;
-        {
-            Prof p(c, COLIBRI_K_EMIT);
-            hipLaunchKernelGGL(merge_emit_kernel, dim3(std::min<uint32_t>(blocks_for(n, kCountTile), 256u * 4u)), dim3(kBlock), 0, c->stream, (const unsigned long long*)keys_dev,
-                               (const uint32_t*)counts_dev, n, sh.orecs[0].p, region, sh.ostate.p, sh.obin.p, sh.oids_at.p, sh.ocnt_at.p);
-        }
-        {
-            Prof p(c, COLIBRI_K_SCATTER);
-            hipLaunchKernelGGL(bin_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, sh.obin.p, region);
-            hipLaunchKernelGGL(bin_hist2_kernel, dim3(tiles), dim3(kBlock), 0, c->stream, sh.orecs[0].p, sh.ostate.p, sh.obin.p);
-            hipLaunchKernelGGL(bin_scan2_kernel, dim3(kBins), dim3(kBlock), 0, c->stream, sh.obin.p);
-            hipLaunchKernelGGL(bin_scatter_kernel, dim3(tiles), dim3(kBlock), 0, c->stream, sh.orecs[0].p, sh.orecs[1].p, sh.ostate.p, sh.obin.p);
-        }
-        {
-            Prof p(c, COLIBRI_K_BINCOUNT);
-            hipLaunchKernelGGL(bin_merge_count_kernel, dim3(256 * 12), dim3(kBlock), 0, c->stream, sh.orecs[1].p, sh.ostate.p, sh.obin.p, sh.thr, sh.oids_at.p, (const uint32_t*)counts_dev,
-                               sh.ocnt_at.p);
-            hipLaunchKernelGGL(bin_kept_scan_kernel, dim3(kBins), dim3(kBlock), 0, c->stream, sh.ostate.p, sh.obin.p, 0xFFFFFFFFu);
-            hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, sh.ostate.p, sh.obin.p);
-        }
-        HIP_TRY(c, hipMemcpyAsync(&os, sh.ostate.p, sizeof os, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipGetLastError());
-        if (!os.radix_overflow) {
-            sh.merge_radix = true;
-            *found         = os.found;
-            *kept          = os.kept;
-            return COLIBRI_OK;
-        }
-    }
-    const uint32_t cap = n + (n >> 1) + 1024;
-    sh.ocap            = cap;
-    if ((rc = dev_alloc(c, sh.otable, cap)) || (rc = dev_alloc(c, sh.ominrank, cap)) || (rc = dev_alloc(c, sh.oslot, (size_t)n + 1))) return rc;
-    if (aux && (rc = dev_alloc(c, sh.onsrc, cap))) return rc;
-    DevState os{};
-    os.cap = cap;
-    HIP_TRY(c, hipMemcpyAsync(sh.ostate.p, &os, sizeof os, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(sh.small.p + kShSrc, off, sizeof(uint32_t) * 65, hipMemcpyHostToDevice, c->stream));
-    {
-        Prof p(c, COLIBRI_K_CLEAR);
-        hipLaunchKernelGGL(clear_table_kernel, dim3(stream_grid(cap)), dim3(kBlock), 0, c->stream, sh.otable.p, sh.ostate.p);
-        hipLaunchKernelGGL(fill_u32_kernel, dim3(stream_grid(cap)), dim3(kBlock), 0, c->stream, sh.ominrank.p, 0xFFFFFFFFu, (uint64_t)cap);
-        if (aux) HIP_TRY(c, hipMemsetAsync(sh.onsrc.p, 0, sizeof(uint32_t) * cap, c->stream));
-    }
-    if (n) {
-        Prof p(c, COLIBRI_K_COUNT);
-        hipLaunchKernelGGL(shard_merge_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, c->stream, (const unsigned long long*)keys_dev, (const uint32_t*)counts_dev, n, (uint32_t)sh.world,
-                           sh.small.p + kShSrc, sh.otable.p, sh.ominrank.p, sh.oslot.p, sh.ostate.p, aux ? (const uint32_t*)aux_dev : (const uint32_t*)nullptr,
-                           aux ? sh.onsrc.p : (uint32_t*)nullptr);
-    }
-    sh.owner_aux = aux;
-    {
-        Prof p(c, COLIBRI_K_PRUNE);
-        hipLaunchKernelGGL(shard_owner_count_kernel, dim3(stream_grid(cap)), dim3(kBlock), 0, c->stream, sh.otable.p, sh.ostate.p, sh.thr, aux ? sh.onsrc.p : (const uint32_t*)nullptr,
-                           sh.minsrc);
-    }
-    HIP_TRY(c, hipMemcpyAsync(&os, sh.ostate.p, sizeof os, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipGetLastError());
-    if (os.overflow) return fail(c, COLIBRI_ERR_OVERFLOW, "owner table exhausted");
-    *found = os.found;
-    *kept  = os.kept;
-    return COLIBRI_OK;
-}
-
-int colibri_shard_reply(colibri_ctx* c, uint32_t gid_base, void* reply_gid_dev, void* reply_cnt_dev) {
-    if (!c) return COLIBRI_ERR_ARG;
-    if (!c->sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
-    HIP_TRY(c, hipSetDevice(c->device));
-    auto& sh = c->sh;
-    if (sh.nrecv && (!reply_gid_dev || !reply_cnt_dev)) return COLIBRI_ERR_ARG;
-    if (sh.merge_radix) {
-        Prof p(c, COLIBRI_K_PRUNE);
-        hipLaunchKernelGGL(shard_reply_radix_kernel, dim3(stream_grid(sh.nrecv)), dim3(kBlock), 0, c->stream, sh.oids_at.p, sh.ocnt_at.p, sh.nrecv, sh.obin.p, gid_base,
-                           (uint32_t*)reply_gid_dev, (uint32_t*)reply_cnt_dev);
-    } else {
-        Prof p(c, COLIBRI_K_PRUNE);
-        hipLaunchKernelGGL(shard_owner_assign_kernel, dim3(stream_grid(sh.ocap)), dim3(kBlock), 0, c->stream, sh.otable.p, sh.ostate.p, sh.thr, gid_base,
-                           sh.owner_aux ? sh.onsrc.p : (const uint32_t*)nullptr, sh.minsrc);
-        if (sh.nrecv)
-            hipLaunchKernelGGL(shard_reply_kernel, dim3(stream_grid(sh.nrecv)), dim3(kBlock), 0, c->stream, sh.oslot.p, sh.nrecv, (uint32_t)sh.world, sh.small.p + kShSrc, sh.otable.p,
-                               sh.ominrank.p, (uint32_t*)reply_gid_dev, (uint32_t*)reply_cnt_dev);
-    }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipGetLastError());
-    return COLIBRI_OK;
-}
-
-int colibri_shard_apply(colibri_ctx* c, const void* reply_gid_dev, const void* reply_cnt_dev, uint64_t* exported, uint64_t* admitted) {
-    if (!c) return COLIBRI_ERR_ARG;
-    if (!c->sh.active || c->sh.n < 1) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_apply out of order");
-    HIP_TRY(c, hipSetDevice(c->device));
-    auto&           sh = c->sh;
-    const TrainPlan pl = shard_plan(c);
-    const int       n  = sh.n;
-    int             rc;
-    if (sh.ncand && (!reply_gid_dev || !reply_cnt_dev)) return COLIBRI_ERR_ARG;
-    c->hstate.kept = c->hstate.valid = 0;
-    if ((rc = write_state(c))) return rc;
-    // only final passes export; replies of intermediate skipgram levels carry ids only. The exporter of an n-gram also marks its
-    // representative position (distinct-source counting of indexed skipgrams).
-    uint32_t* mark = (sh.mask == 0 && c->opt.doskipgrams && n < 32) ? sh.mark.p : nullptr;
-    if (sh.pass_radix) {
-        if (sh.ncand) {
-            const BinnedIO io = binned_planes(c, pl, true);
-            Prof           p(c, COLIBRI_K_PRUNE);
-            hipLaunchKernelGGL(shard_apply_sparse_kernel, dim3(stream_grid(sh.ncand)), dim3(kBlock), 0, c->stream, sh.pslots.p, (const uint32_t*)reply_gid_dev,
-                               (const uint32_t*)reply_cnt_dev, sh.ncand, io.sp_rep, sh.gid_of_sparse.p, c->state.p, c->res_rep.p, c->res_cnt.p, sh.res_gid.p, pl.res_cap, mark,
-                               1u << (n & 31), sh.pass_list ? (const uint32_t*)c->alist[n & 1].p : (const uint32_t*)nullptr);
-        }
-        // ids[n][i] = global id of the survivor at the window's representative (sparse id -> gid), and the active list for order n+1
-        if ((rc = binned_resolve_stage(c, pl, sh.out, n, sh.pass_list, true, sh.gid_of_sparse.p, 0u))) return rc;
-        sh.list_valid = true;
-    } else {
-        if (sh.ncand) {
-            Prof p(c, COLIBRI_K_PRUNE);
-            if (sh.final_level)
-                hipLaunchKernelGGL(shard_apply_kernel, dim3(stream_grid(sh.ncand)), dim3(kBlock), 0, c->stream, sh.pslots.p, (const uint32_t*)reply_gid_dev, (const uint32_t*)reply_cnt_dev,
-                                   sh.ncand, c->table.p, c->state.p, c->res_rep.p, c->res_cnt.p, sh.res_gid.p, pl.res_cap, mark, 1u << (n & 31));
-            else
-                hipLaunchKernelGGL(shard_tag_kernel, dim3(stream_grid(sh.ncand)), dim3(kBlock), 0, c->stream, sh.pslots.p, (const uint32_t*)reply_gid_dev, sh.ncand, c->table.p);
-        }
-        launch_resolve(c, pl, sh.out);
-        if (sh.mask == 0) sh.list_valid = false;  // the global-table pass leaves no active list behind
-    }
-    if ((rc = read_state(c))) return rc;
-    const uint32_t k = sh.final_level ? c->hstate.kept : 0;
-    if (k) c->segments.push_back({sh.res_total, k, n, sh.mask});
-    sh.res_total += k;
-    if (sh.mask == 0) sh.valid_n[n] = c->hstate.valid;
-    sh.exported_n[n] += k;
-    // forward index: the local occurrences of every surviving pattern of this pass, keyed by its GLOBAL id
-    if (c->opt.indexed && sh.final_level && c->hstate.valid && (rc = emit_pairs(c, pl, sh.out))) return rc;
-    if (exported) *exported = k;
-    if (admitted) *admitted = sh.admitted_n[n];
-    return COLIBRI_OK;
-}
-
-int colibri_shard_finish(colibri_ctx* c, const uint64_t* found_global, const uint64_t* kept_global, uint64_t totaltokens_global, int maxn, colibri_stats* stats_out) {
-    if (!c || !found_global || !kept_global) return COLIBRI_ERR_ARG;
-    if (!c->sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
-    HIP_TRY(c, hipSetDevice(c->device));
-    auto&          sh = c->sh;
-    colibri_stats& s  = c->stats;
-    std::memset(&s, 0, sizeof s);
-    s.totaltokens = totaltokens_global;
-    s.nsentences  = c->nsent;
-    s.npatterns   = sh.res_total;  // patterns THIS rank exports; the model is the union over ranks
-    s.maxn        = maxn;
-    s.minn        = maxn > 0 ? 1 : 0;
-    for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) {
-        s.found[n]    = found_global[n];
-        s.kept[n]     = kept_global[n];
-        s.pruned[n]   = s.found[n] - s.kept[n];
-        s.admitted[n] = sh.admitted_n[n];
-        s.windows[n] = (n <= c->opt.maxlength) ? c->windows_n[n] : 0;
-    }
-    s.totaltypes        = s.found[1];
-    c->hstate.res_total = sh.res_total;
-    c->trained          = true;
-    sh.active           = false;
-    int rc;
-    if ((rc = prepare_export(c))) return rc;
-    if (c->opt.indexed) {  // local forward index keyed by global id: sort the pairs, then one run per distinct id
-        const uint64_t npairs = c->npairs;
-        if ((rc = finalize_index(c, 0x7FFFFFFFu, true))) return rc;
-        sh.index_gids = 0;
-        if (npairs) {
-            const uint32_t   nblk = (uint32_t)((npairs + kEmitTile - 1) / kEmitTile);
-            DevBuf<uint32_t> cnt;
-            if ((rc = dev_alloc(c, cnt, (size_t)nblk + 2))) return rc;
-            hipLaunchKernelGGL(rle_count_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, sh.sorted_gid.p, npairs, cnt.p);
-            hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, cnt.p, nblk, cnt.p + nblk);
-            uint32_t total = 0;
-            HIP_TRY(c, hipMemcpyAsync(&total, cnt.p + nblk, sizeof total, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            if ((rc = dev_alloc(c, sh.ugid, (size_t)total + 1)) || (rc = dev_alloc(c, sh.uoff, (size_t)total + 1))) return rc;
-            hipLaunchKernelGGL(rle_write_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, sh.sorted_gid.p, npairs, cnt.p, sh.ugid.p, sh.uoff.p);
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            HIP_TRY(c, hipGetLastError());
-            dev_free(cnt);
-            sh.index_gids = total;
-        }
-    }
-    collect_events(c);
-    s.keybytes = c->keybytes;
-    s.nrefs    = c->opt.indexed ? c->npairs : 0;
-    if (stats_out) *stats_out = s;
-    return COLIBRI_OK;
-}
-
-// ---- order 1 on the class-indexed arrays (canonical encodings): local counts -> [all-reduce SUM / MIN by the caller] -> apply
-int colibri_shard_uni_info(const colibri_ctx* c, int* eligible, uint64_t* maxclass) {
-    if (!c || !eligible || !maxclass) return COLIBRI_ERR_ARG;
-    if (!c->have_corpus) return COLIBRI_ERR_STATE;
-    *eligible = (!(c->flags & kFlagNonCanonical) && c->maxclass < (1u << 28) && c->opt.table_mode != 1) ? 1 : 0;
-    *maxclass = c->maxclass;
-    return COLIBRI_OK;
-}
-
-int colibri_shard_uni_count(colibri_ctx* c, void* cnt_dev, void* minrank_dev, uint32_t nclasses, int rank) {
-    if (!c || !cnt_dev || !minrank_dev || nclasses <= c->maxclass) return COLIBRI_ERR_ARG;
-    if (!c->sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
-    HIP_TRY(c, hipSetDevice(c->device));
-    auto&           sh = c->sh;
-    const TrainPlan pl = shard_plan(c);
-    int             rc;
-    if ((int)c->ids.size() < 3) c->ids.resize(3);
-    if ((rc = dev_alloc(c, c->ids[1], (size_t)c->npos + 1)) || (rc = dev_alloc(c, c->rep1, (size_t)nclasses + 1))) return rc;
-    sh.n = 1;
-    sh.mask = 0;
-    sh.level = 1;
-    sh.final_level = true;
-    sh.pass_radix = false;
-    DevState& hs = c->hstate;
-    hs.done      = 0;
-    hs.found = hs.kept = hs.admitted = hs.valid = 0;
-    hs.res_total = sh.res_total;
-    if ((rc = write_state(c))) return rc;
-    // plain runs need no representative positions (unigram keys are exported from the class): the atomic-free count applies
-    sh.uni_from_class = !c->opt.doskipgrams && uni_range_shift(c) != 0;
-    if (sh.uni_from_class) {
-        if ((rc = uni_alloc(c)) || (rc = uni_count_partitioned(c, uni_range_shift(c), (uint32_t*)cnt_dev, nclasses))) return rc;
-    } else {
-        HIP_TRY(c, hipMemsetAsync(cnt_dev, 0, sizeof(uint32_t) * nclasses, c->stream));
-        Prof p(c, COLIBRI_K_COUNT);
-        hipLaunchKernelGGL(uni_count_kernel, dim3(512), dim3(kBlock), 0, c->stream, c->cls.p, pl.npos, (uint32_t*)cnt_dev, c->rep1.p, c->state.p);
-    }
-    {
-        Prof p(c, COLIBRI_K_COUNT);
-        hipLaunchKernelGGL(shard_uni_minrank_kernel, dim3(stream_grid(nclasses)), dim3(kBlock), 0, c->stream, (const uint32_t*)cnt_dev, nclasses, (uint32_t)rank, (uint32_t*)minrank_dev);
-    }
-    if ((rc = read_state(c))) return rc;
-    sh.admitted_n[1] = hs.admitted;
-    return COLIBRI_OK;
-}
-
-int colibri_shard_uni_apply(colibri_ctx* c, const void* cnt_global_dev, const void* minrank_global_dev, uint32_t nclasses, int rank, uint64_t* found, uint64_t* kept,
-                            uint64_t* exported) {
-    if (!c || !cnt_global_dev || !minrank_global_dev || !found || !kept) return COLIBRI_ERR_ARG;
-    if (!c->sh.active || c->sh.n != 1) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_uni_apply out of order");
-    HIP_TRY(c, hipSetDevice(c->device));
-    auto&           sh = c->sh;
-    const TrainPlan pl = shard_plan(c);
-    int             rc;
-    c->hstate.found = c->hstate.kept = c->hstate.admitted = c->hstate.valid = 0;
-    if ((rc = write_state(c))) return rc;
-    {
-        Prof p(c, COLIBRI_K_PRUNE);
-        hipLaunchKernelGGL(shard_uni_finish_kernel, dim3(stream_grid(nclasses)), dim3(kBlock), 0, c->stream, (const uint32_t*)cnt_global_dev, (const uint32_t*)minrank_global_dev,
-                           sh.uni_from_class ? (const uint32_t*)nullptr : c->rep1.p, nclasses, (uint32_t)rank, pl.thr, c->state.p, c->res_rep.p, c->res_cnt.p, sh.res_gid.p, pl.res_cap,
-                           c->opt.doskipgrams ? sh.mark.p : (uint32_t*)nullptr);
-    }
-    {
-        Prof p(c, COLIBRI_K_RESOLVE);
-        hipLaunchKernelGGL(uni_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, (const uint32_t*)cnt_global_dev, pl.thr, c->ids[1].p, c->state.p, pl.npos);
-    }
-    if ((rc = read_state(c))) return rc;
-    const uint32_t k = c->hstate.kept;  // exported by THIS rank
-    if (k) c->segments.push_back({sh.res_total, k, 1, sh.uni_from_class ? kMaskFromClass : 0u});
-    sh.res_total += k;
-    sh.valid_n[1]    = c->hstate.valid;
-    sh.exported_n[1] = k;
-    sh.list_valid    = false;
-    sh.out           = c->ids[1].p;
-    if (c->opt.indexed && c->hstate.valid && (rc = emit_pairs(c, pl, sh.out))) return rc;
-    *found = c->hstate.found;     // global: every rank sees the same reduced array
-    *kept  = c->hstate.admitted;  // (the finish kernel parks the global kept count here)
-    if (exported) *exported = k;
-    return COLIBRI_OK;
-}
-
-int colibri_shard_export_gids(colibri_ctx* c, uint32_t* gids) {
-    if (!c || !gids) return COLIBRI_ERR_ARG;
-    if (!c->trained) return fail(c, COLIBRI_ERR_STATE, "export before finish");
-    HIP_TRY(c, hipSetDevice(c->device));
-    const uint32_t R = c->hstate.res_total;
-    if (R) HIP_TRY(c, hipMemcpy(gids, c->sh.res_gid.p, sizeof(uint32_t) * R, hipMemcpyDeviceToHost));
-    return COLIBRI_OK;
-}
-
-int colibri_shard_index_sizes(const colibri_ctx* c, uint64_t* ngids, uint64_t* nrefs) {
-    if (!c || !ngids || !nrefs) return COLIBRI_ERR_ARG;
-    if (!c->trained || !c->opt.indexed) return COLIBRI_ERR_STATE;
-    *ngids = c->sh.index_gids;
-    *nrefs = c->npairs;
-    return COLIBRI_OK;
-}
-
-int colibri_shard_export_index(colibri_ctx* c, uint32_t* gids, uint64_t* ref_off, uint32_t* ref_sentence, uint16_t* ref_token) {
-    if (!c || !ref_off) return COLIBRI_ERR_ARG;
-    if (!c->trained || !c->opt.indexed) return fail(c, COLIBRI_ERR_STATE, "no sharded indexed model");
-    HIP_TRY(c, hipSetDevice(c->device));
-    const uint64_t G = c->sh.index_gids, N = c->npairs;
-    ref_off[G]       = N;
-    if (G) {
-        if (!gids) return COLIBRI_ERR_ARG;
-        HIP_TRY(c, hipMemcpy(gids, c->sh.ugid.p, sizeof(uint32_t) * G, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(ref_off, c->sh.uoff.p, sizeof(uint64_t) * G, hipMemcpyDeviceToHost));
-    }
-    if (N) {
-        if (!ref_sentence || !ref_token) return COLIBRI_ERR_ARG;
-        HIP_TRY(c, hipMemcpy(ref_sentence, c->ref_sentence.p, sizeof(uint32_t) * N, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(ref_token, c->ref_token.p, sizeof(uint16_t) * N, hipMemcpyDeviceToHost));
-    }
-    return COLIBRI_OK;
-}
-
-// constrained training (constrained.hpp): the pattern set the next colibri_train calls are restricted to
-int colibri_set_constraint(colibri_ctx* c, const uint64_t* key_off, const uint8_t* key_bytes, uint64_t npatterns) {
-    if (!c) return COLIBRI_ERR_ARG;
-    HIP_TRY(c, hipSetDevice(c->device));
-    auto& cs = c->cs;
-    cs.n     = 0;
-    if (npatterns == 0) return COLIBRI_OK;
-    if (!key_off || !key_bytes) return COLIBRI_ERR_ARG;
-    if (npatterns >= 0x7FFFFFF0ull) return fail(c, COLIBRI_ERR_OVERFLOW, "constraint set too large");
-    int            rc;
-    const uint64_t nbytes = key_off[npatterns];
-    const uint64_t cap64  = 2 * npatterns + 1024;
-    if ((rc = dev_alloc(c, cs.bytes, (size_t)nbytes + 16)) || (rc = dev_alloc(c, cs.off, (size_t)npatterns + 1)) || (rc = dev_alloc(c, cs.table, (size_t)cap64))) return rc;
-    cs.cap = (uint32_t)cap64;
-    HIP_TRY(c, hipMemcpyAsync(cs.bytes.p, key_bytes, nbytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(cs.off.p, key_off, sizeof(uint64_t) * (npatterns + 1), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(constraint_clear_kernel, dim3(stream_grid(cs.cap)), dim3(kBlock), 0, c->stream, cs.table.p, cs.cap);
-    hipLaunchKernelGGL(constraint_insert_kernel, dim3(stream_grid(npatterns)), dim3(kBlock), 0, c->stream, cs.bytes.p, cs.off.p, (uint32_t)npatterns, cs.table.p, cs.cap);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipGetLastError());
-    cs.n = (uint32_t)npatterns;
-    return COLIBRI_OK;
-}
-
-// =====================================================================================================================
-// class encoder (kernels in textenc.hpp). The host side of the boundary decides the class of every DISTINCT word
-// (colibri-core_amd/host: ClassEncoder — the tie order among equally frequent words is the reference's container order and is
-// reproduced there); the device does everything that is proportional to the corpus.
-// =====================================================================================================================
-int colibri_text_upload(colibri_ctx* c, const uint8_t* text, uint64_t nbytes) {
-    if (!c || (!text && nbytes)) return COLIBRI_ERR_ARG;
-    if (nbytes >= 0x7FFFFFF0ull) return fail(c, COLIBRI_ERR_CORPUS, "text of %llu bytes: at most 2 GiB per call", (unsigned long long)nbytes);
-    HIP_TRY(c, hipSetDevice(c->device));
-    auto& t = c->tx;
-    int   rc;
-    if ((rc = dev_alloc(c, t.text, (size_t)nbytes + 16)) || (rc = dev_alloc(c, t.info, 1)) || (rc = dev_alloc(c, t.state, 1)) || (rc = dev_alloc(c, t.ntok, 1))) return rc;
-    t.n       = (uint32_t)nbytes;
-    t.rules   = -1;
-    t.encoded = false;
-    if (nbytes) HIP_TRY(c, hipMemcpyAsync(t.text.p, text, nbytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync(t.info.p, 0, sizeof(TextInfo), c->stream));
-    if (nbytes) hipLaunchKernelGGL(text_info_kernel, dim3(stream_grid(nbytes)), dim3(kBlock), 0, c->stream, t.text.p, t.n, t.info.p);
-    HIP_TRY(c, hipMemcpyAsync(&t.hinfo, t.info.p, sizeof(TextInfo), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipGetLastError());
-    // the event list (segment starts and newlines, in text order) every later pass walks
-    t.nevents = t.hinfo.nsegments + t.hinfo.nlines;
-    if (t.nevents) {
-        const uint32_t nblk = blocks_for(nbytes, kEvBytesPerBlock), nb = std::max<uint32_t>(1, blocks_for(nblk, kBlock * 4));
-        if ((rc = dev_alloc(c, t.events, (size_t)t.nevents + 1)) || (rc = dev_alloc(c, t.evcnt, (size_t)nblk + 1)) || (rc = dev_alloc(c, t.outoff, (size_t)nblk + 1)) ||
-            (rc = dev_alloc(c, t.bsum, (size_t)nb + 1)))
-            return rc;
-        hipLaunchKernelGGL(text_event_count_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, t.text.p, t.n, t.evcnt.p);
-        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, t.evcnt.p, nblk, t.bsum.p);
-        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, c->stream, t.bsum.p, nb, t.bsum.p + nb);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, t.evcnt.p, nblk, t.bsum.p, t.outoff.p);
-        hipLaunchKernelGGL(text_event_write_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, t.text.p, t.n, t.outoff.p, t.events.p);
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipGetLastError());
-    }
-    return COLIBRI_OK;
-}
-
-int colibri_text_count(colibri_ctx* c, int rules, uint64_t* nwords, uint64_t* ndistinct) {
-    if (!c || !nwords || !ndistinct || (rules != 0 && rules != 1)) return COLIBRI_ERR_ARG;
-    auto& t = c->tx;
-    if (!t.text.p) return fail(c, COLIBRI_ERR_STATE, "colibri_text_upload first");
-    HIP_TRY(c, hipSetDevice(c->device));
-    int            rc;
-    const uint64_t cap64 = (uint64_t)t.hinfo.nsegments + (t.hinfo.nsegments >> 1) + 1024;
-    t.cap               = (uint32_t)cap64;
-    if ((rc = dev_alloc(c, t.table, t.cap)) || (rc = dev_alloc(c, t.slot_of, (size_t)t.nevents + 1)) || (rc = dev_alloc(c, t.first, t.cap)) || (rc = dev_alloc(c, t.widx, t.cap)) ||
-        (rc = dev_alloc(c, t.wstart, (size_t)t.hinfo.nsegments + 1)) || (rc = dev_alloc(c, t.wlen, (size_t)t.hinfo.nsegments + 1)) ||
-        (rc = dev_alloc(c, t.wcount, (size_t)t.hinfo.nsegments + 1)))
-        return rc;
-    for (int attempt = 0; attempt < 4; ++attempt) {  // a 64-bit hash collision between two words (never seen) is detected and retried with another seed
-        DevState st{};
-        st.cap = t.cap;
-        HIP_TRY(c, hipMemcpyAsync(t.state.p, &st, sizeof st, hipMemcpyHostToDevice, c->stream));
-        TextInfo reset = t.hinfo;
-        reset.collision = reset.ndistinct = 0;
-        HIP_TRY(c, hipMemcpyAsync(t.info.p, &reset, sizeof reset, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemsetAsync(t.first.p, 0xFF, sizeof(uint32_t) * t.cap, c->stream));
-        hipLaunchKernelGGL(clear_table_kernel, dim3(stream_grid(t.cap)), dim3(kBlock), 0, c->stream, t.table.p, t.state.p);
-        if (t.nevents) {
-            const KeyWord fn{t.text.p, t.n, t.events.p, rules, 0x5851F42D4C957F2Dull * (uint64_t)(attempt + 1)};
-            Prof          p(c, COLIBRI_K_COUNT);
-            hipLaunchKernelGGL((count_kernel<KeyWord>), dim3(std::max<uint32_t>(1, std::min<uint32_t>(blocks_for(t.nevents, kCountTile), 256u * 3u))), dim3(kBlock), 0, c->stream, fn,
-                               t.slot_of.p, t.table.p, t.state.p, t.nevents, 1);
-            hipLaunchKernelGGL(text_verify_kernel, dim3(stream_grid(t.nevents)), dim3(kBlock), 0, c->stream, t.text.p, t.n, t.events.p, t.nevents, rules, t.slot_of.p, t.table.p, t.first.p,
-                               t.info.p);
-            hipLaunchKernelGGL(text_words_kernel, dim3(stream_grid(t.cap)), dim3(kBlock), 0, c->stream, t.text.p, t.n, rules, t.events.p, t.table.p, t.cap, t.first.p, t.widx.p, t.wstart.p,
-                               t.wlen.p, t.wcount.p, t.info.p);
-        }
-        TextInfo got{};
-        HIP_TRY(c, hipMemcpyAsync(&got, t.info.p, sizeof got, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(&st, t.state.p, sizeof st, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipGetLastError());
-        if (st.overflow) return fail(c, COLIBRI_ERR_OVERFLOW, "word table exhausted");
-        if (got.collision) continue;
-        t.ndistinct = got.ndistinct;
-        t.nwords    = st.admitted;
-        t.rules     = rules;
-        t.encoded   = false;
-        *nwords     = t.nwords;
-        *ndistinct  = t.ndistinct;
-        return COLIBRI_OK;
-    }
-    return fail(c, COLIBRI_ERR_HIP, "word hashes collided under four different seeds");
-}
-
-int colibri_text_words(colibri_ctx* c, uint32_t* first_start, uint32_t* length, uint32_t* count) {
-    if (!c) return COLIBRI_ERR_ARG;
-    auto& t = c->tx;
-    if (t.rules < 0) return fail(c, COLIBRI_ERR_STATE, "colibri_text_count first");
-    HIP_TRY(c, hipSetDevice(c->device));
-    if (t.ndistinct) {
-        if (!first_start || !length || !count) return COLIBRI_ERR_ARG;
-        HIP_TRY(c, hipMemcpy(first_start, t.wstart.p, sizeof(uint32_t) * t.ndistinct, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(length, t.wlen.p, sizeof(uint32_t) * t.ndistinct, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(count, t.wcount.p, sizeof(uint32_t) * t.ndistinct, hipMemcpyDeviceToHost));
-    }
-    return COLIBRI_OK;
-}
-
-int colibri_text_encode(colibri_ctx* c, const uint32_t* cls, const uint32_t* repeat, uint64_t* outbytes, uint64_t* ntokens, uint64_t* nlines) {
-    if (!c || !outbytes || !ntokens || !nlines) return COLIBRI_ERR_ARG;
-    auto& t = c->tx;
-    if (t.rules != 1) return fail(c, COLIBRI_ERR_STATE, "colibri_text_count with the encoder's rules (1) first");
-    if (t.ndistinct && (!cls || !repeat)) return COLIBRI_ERR_ARG;
-    HIP_TRY(c, hipSetDevice(c->device));
-    int            rc;
-    const uint32_t nb = std::max<uint32_t>(1, blocks_for(t.nevents, kBlock * 4));
-    if ((rc = dev_alloc(c, t.cls, (size_t)t.ndistinct + 1)) || (rc = dev_alloc(c, t.repeat, (size_t)t.ndistinct + 1)) || (rc = dev_alloc(c, t.outlen, (size_t)t.nevents + 1)) ||
-        (rc = dev_alloc(c, t.outoff, (size_t)t.nevents + 1)) || (rc = dev_alloc(c, t.bsum, (size_t)nb + 1)))
-        return rc;
-    if (t.ndistinct) {
-        HIP_TRY(c, hipMemcpyAsync(t.cls.p, cls, sizeof(uint32_t) * t.ndistinct, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(t.repeat.p, repeat, sizeof(uint32_t) * t.ndistinct, hipMemcpyHostToDevice, c->stream));
-    }
-    HIP_TRY(c, hipMemsetAsync(t.ntok.p, 0, sizeof(unsigned long long), c->stream));
-    unsigned long long total = 0, ntok = 0;
-    if (t.nevents) {
-        Prof p(c, COLIBRI_K_EXPORT);
-        hipLaunchKernelGGL(text_outlen_kernel, dim3(stream_grid(t.nevents)), dim3(kBlock), 0, c->stream, t.text.p, t.events.p, t.nevents, t.slot_of.p, t.widx.p, t.cls.p, t.repeat.p,
-                           t.hinfo.after_last_nl, t.outlen.p, t.ntok.p);
-        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, t.outlen.p, t.nevents, t.bsum.p);
-        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, c->stream, t.bsum.p, nb, t.bsum.p + nb);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, t.outlen.p, t.nevents, t.bsum.p, t.outoff.p);
-        HIP_TRY(c, hipMemcpyAsync(&total, t.bsum.p + nb, sizeof total, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(&ntok, t.ntok.p, sizeof ntok, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if ((rc = dev_alloc(c, t.out, (size_t)total + 16))) return rc;
-        hipLaunchKernelGGL(text_write_kernel, dim3(stream_grid(t.nevents)), dim3(kBlock), 0, c->stream, t.slot_of.p, t.nevents, t.widx.p, t.cls.p, t.repeat.p, t.outlen.p, t.outoff.p,
-                           t.out.p);
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipGetLastError());
-    } else if ((rc = dev_alloc(c, t.out, 16))) {
-        return rc;
-    }
-    t.outbytes = total;
-    t.encoded  = true;
-    *outbytes  = total;
-    *ntokens   = ntok;
-    *nlines    = t.hinfo.nlines;
-    return COLIBRI_OK;
-}
-
-int colibri_text_fetch(colibri_ctx* c, uint8_t* out) {
-    if (!c) return COLIBRI_ERR_ARG;
-    if (!c->tx.encoded) return fail(c, COLIBRI_ERR_STATE, "colibri_text_encode first");
-    HIP_TRY(c, hipSetDevice(c->device));
-    if (c->tx.outbytes) {
-        if (!out) return COLIBRI_ERR_ARG;
-        HIP_TRY(c, hipMemcpy(out, c->tx.out.p, c->tx.outbytes, hipMemcpyDeviceToHost));
-    }
-    return COLIBRI_OK;
-}
-
-int colibri_text_as_corpus(colibri_ctx* c, uint32_t first_sentence) {
-    if (!c) return COLIBRI_ERR_ARG;
-    if (!c->tx.encoded) return fail(c, COLIBRI_ERR_STATE, "colibri_text_encode first");
-    return colibri_upload_corpus_device(c, c->tx.out.p, c->tx.outbytes, first_sentence);
-}
+#include "shard_api.inc"  // colibri_shard_*: opens extern "C"
+#include "text_api.inc"   // colibri_set_constraint, colibri_text_*
 
 }  // extern "C"

@@ -183,3 +183,28 @@ def test_c_abi_text_path_feeds_train_without_host_round_trip():
         got, _ = ctx.export_dict()
     want = oracle.train(gdat[2:], 2, 5)
     assert st.totaltokens == want.tokens and got == want.counts
+
+
+@pytest.mark.gpu
+def test_cli_matches_oracle_on_a_two_million_word_text(tmp_path):
+    """Zipf text, 2 M words, 200 k word forms, every frequency tie in it: the class file and the encoded corpus equal the oracle's byte for byte"""
+    rng = np.random.default_rng(12)
+    vocab = 200_000
+    p = 1.0 / np.arange(1, vocab + 1)
+    ranks = np.searchsorted(np.cumsum(p / p.sum()), rng.random(2_000_000))
+    lens = rng.integers(1, 30, size=150_000)
+    ends = np.cumsum(lens)
+    ends = ends[ends < ranks.size]
+    words = np.array([f"w{r:x}" for r in range(vocab)], dtype=object)[ranks]
+    lines, start = [], 0
+    for e in ends.tolist():
+        lines.append(" ".join(words[start:e]))
+        start = e
+    text = ("\n".join(lines) + "\n").encode()
+    (tmp_path / "big.txt").write_bytes(text)
+    st, ocls, odat = oracle.classencode(text)
+    assert st == 0
+    out = run_cli(["big.txt"], str(tmp_path))
+    assert out.returncode == 0, out.stderr.decode()[-800:]
+    assert (tmp_path / "big.colibri.dat").read_bytes() == odat
+    assert (tmp_path / "big.colibri.cls").read_bytes() == ocls

@@ -368,7 +368,8 @@ int check_options(colibri_ctx* c, colibri_options& o) {
     if (o.minlength > 1 && !constrained) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINLENGTH>1 is not on the accelerated path");
     if (o.minlength > o.maxlength) return fail(c, COLIBRI_ERR_ARG, "MINLENGTH > MAXLENGTH");
     if (o.maxbackofflength < o.maxlength) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MAXBACKOFFLENGTH < MAXLENGTH is not on the accelerated path");
-    if (o.mintokens_unigrams > o.mintokens) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINTOKENS_UNIGRAMS > MINTOKENS is not on the accelerated path");
+    if (o.mintokens_unigrams > o.mintokens && (o.doskipgrams || o.doskipgrams_exhaustive || constrained || o.mintokens < 2 || o.table_mode == 2))
+        return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINTOKENS_UNIGRAMS > MINTOKENS with skipgrams, a constraint set, MINTOKENS = 1 or table_mode 2 is not on the accelerated path");
     if (o.dopatternperline || o.prunenonsubsumed || o.prunesubsumed)
         return fail(c, COLIBRI_ERR_UNSUPPORTED, "DOPATTERNPERLINE / PRUNE(NON)SUBSUMED are not on the accelerated path");
     if (o.doskipgrams && o.doskipgrams_exhaustive)
@@ -928,6 +929,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     // results: every survivor has >= MINTOKENS occurrences; at MINTOKENS = 1 every window may be its own pattern (exhaustion is reported, never silent)
     pl.res_cap     = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)npos * (o.mintokens < 2 ? (uint64_t)std::min(o.maxlength, 8) : (synced ? 4u : 2u)) + 1024);
     pl.thr         = (uint32_t)o.mintokens;
+    const uint32_t wthr = o.mintokens_unigrams > o.mintokens ? (uint32_t)o.mintokens_unigrams : 0u;  // secondary word threshold (-W), 0 = none
     constexpr uint32_t kCountLdsBytes    = kCountTile * 16u + kCountLSlot * 4u + 64u;  // keyL + cntL + slotL + winL
     constexpr uint32_t kCountBlocksPerCU = (160u * 1024u / kCountLdsBytes) < 8u ? (160u * 1024u / kCountLdsBytes) : 8u;
     pl.cnt_grid = std::max<uint32_t>(1, std::min<uint32_t>(blocks_for(npos, kCountTile), 256u * kCountBlocksPerCU));  // persistent blocks: all resident
@@ -990,14 +992,15 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                 {
                     Prof p(c, COLIBRI_K_PRUNE);
                     hipLaunchKernelGGL(uni_finish_kernel, dim3(stream_grid(nclasses)), dim3(kBlock), 0, c->stream, c->cnt1.p, uni_shift ? (const uint32_t*)nullptr : c->rep1.p, nclasses,
-                                       pl.thr, c->state.p, c->res_rep.p, c->res_cnt.p, pl.res_cap, uni_shift ? reinterpret_cast<uint16_t*>(c->uni_surv.p) : (uint16_t*)nullptr, bi_cls);
+                                       pl.thr, c->state.p, c->res_rep.p, c->res_cnt.p, pl.res_cap, uni_shift ? reinterpret_cast<uint16_t*>(c->uni_surv.p) : (uint16_t*)nullptr, bi_cls,
+                                       (uint32_t*)nullptr, wthr);
                 }
                 if (!bi_cls) {  // with class-keyed orders 2 and 3 nothing reads order-1 ids per position
                     Prof p(c, COLIBRI_K_RESOLVE);
                     if (uni_shift)
                         hipLaunchKernelGGL(uni_ids_bitmap_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_surv.p, (nclasses + 31) / 32, id_cur, c->state.p, npos);
                     else
-                        hipLaunchKernelGGL(uni_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->cnt1.p, pl.thr, id_cur, c->state.p, npos);
+                        hipLaunchKernelGGL(uni_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->cnt1.p, std::max(pl.thr, wthr), id_cur, c->state.p, npos);
                 }
             } else if (binned) {
                 // orders 1-2 scan every position (almost all are admissible); from order 3 on only the positions that still
@@ -1021,6 +1024,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                     launch_count(c, pl, KeyNgram{id_prev, n}, id_cur, 3, COLIBRI_K_COUNT);
                 launch_prune(c, pl, pl.thr, nullptr, 0);
                 launch_resolve(c, pl, id_cur);
+                if (n == 1 && wthr > pl.thr) hipLaunchKernelGGL(ids_min_count_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, id_cur, c->res_cnt.p, wthr, npos);
             }
             hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, n, pl.table_slots);
             cur ^= 1;
@@ -1136,6 +1140,8 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             res_total += kept;
             c->hstate.res_total = res_total;
             if (o.indexed && kept && (rc = emit_pairs(c, pl, c->ids[n].p))) return rc;  // occurrences of the surviving n-grams
+            // secondary word threshold: the unigrams below it keep their place (and references) in the model, but take no part in longer patterns
+            if (n == 1 && wthr > pl.thr) hipLaunchKernelGGL(ids_min_count_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->ids[n].p, c->res_cnt.p, wthr, npos);
             if (o.doskipgrams_exhaustive && n >= 3) {  // patternmodel.h:1163-1171 -> computeskipgrams :1370-1527, for every admissible window
                 if (n > 13) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 13 tokens are not on the accelerated path (set MAXLENGTH)");
                 if ((rc = build_skip_list(c, pl, c->ids[n - 1].p))) return rc;

@@ -724,7 +724,9 @@ __global__ __launch_bounds__(kBlock) void uni_finish_kernel(const uint32_t* __re
                                                              DevState* __restrict__ st, uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap,
                                                              uint16_t* __restrict__ surv16 = nullptr /* optional: bit c = class c survives (16 classes per lane = one half word) */,
                                                              bool count_valid = false /* also st->valid += occurrences of the surviving classes (when no id pass follows) */,
-                                                             uint32_t* __restrict__ resid = nullptr /* optional: result index of every class (kInvalid if it did not survive) */) {
+                                                             uint32_t* __restrict__ resid = nullptr /* optional: result index of every class (kInvalid if it did not survive) */,
+                                                             uint32_t thr_ids = 0 /* MINTOKENS_UNIGRAMS (>= threshold): what a word needs to be part of longer patterns (bitmap, resid, valid) */) {
+    if (thr_ids < threshold) thr_ids = threshold;
     if (st->done) return;
     __shared__ uint32_t baseL, redL[kBlock / kWave];
     const uint32_t      res_base = st->res_total;
@@ -739,13 +741,13 @@ __global__ __launch_bounds__(kBlock) void uni_finish_kernel(const uint32_t* __re
             v[q] = (c0 + q < nclasses) ? cnt1[c0 + q] : 0u;
             nfound += v[q] != 0;
             k += v[q] >= threshold;
-            if (v[q] >= threshold) nvalid += v[q];
+            if (v[q] >= thr_ids) nvalid += v[q];
         }
         if (surv16 != nullptr && c0 < nclasses) {
             static_assert(kPrunePer == 16, "one 16-bit store per lane");
             uint32_t bits = 0;
 #pragma unroll
-            for (int q = 0; q < kPrunePer; ++q) bits |= (uint32_t)(v[q] >= threshold) << q;
+            for (int q = 0; q < kPrunePer; ++q) bits |= (uint32_t)(v[q] >= thr_ids) << q;
             surv16[c0 >> 4] = (uint16_t)bits;
         }
         uint32_t       total;
@@ -755,7 +757,7 @@ __global__ __launch_bounds__(kBlock) void uni_finish_kernel(const uint32_t* __re
         uint32_t r = res_base + baseL + excl;
 #pragma unroll
         for (int q = 0; q < kPrunePer; ++q) {
-            if (resid != nullptr && c0 + q < nclasses) resid[c0 + q] = v[q] >= threshold ? r : kInvalid;
+            if (resid != nullptr && c0 + q < nclasses) resid[c0 + q] = (v[q] >= threshold && v[q] >= thr_ids) ? r : kInvalid;
             if (v[q] >= threshold) {
                 if (r < res_cap) {
                     res_rep[r] = rep1 != nullptr ? rep1[c0 + q] : c0 + q;  // no representative recorded: the class itself (kMaskFromClass export)
@@ -846,6 +848,14 @@ __global__ __launch_bounds__(kBlock) void uni_resid_ids_kernel(const uint32_t* _
     if (threadIdx.x == 0) {
         const uint32_t v = redL[0] + redL[1] + redL[2] + redL[3];
         if (v) atomicAdd(&st->valid, v);
+    }
+}
+// MINTOKENS_UNIGRAMS > MINTOKENS on the table path: the unigrams below the word threshold stay in the model but take no part in longer
+// patterns (reference patternmodel.h:1093-1104) — their ids (result indices) are withdrawn from the per-position array
+__global__ __launch_bounds__(kBlock) void ids_min_count_kernel(uint32_t* __restrict__ ids, const uint32_t* __restrict__ res_cnt, uint32_t wthr, uint32_t npos) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npos; i += gridDim.x * kBlock) {
+        const uint32_t r = ids[i];
+        if (r != kInvalid && res_cnt[r] < wthr) ids[i] = kInvalid;
     }
 }
 // the same from the survivor bitmap uni_finish_kernel left behind: the first 262 144 classes (> 90 % of a Zipf corpus' tokens) are

@@ -425,7 +425,7 @@ static void train_indexed_skipgrams(co_model* m, const co_options* opt, uint32_t
 /* ------------------------------------------------------------------------------------------------
  * PatternModel::train — reference include/patternmodel.h:880-1345, accelerated subset
  * (constrainbymodel==NULL, filter==NULL, continued==false, DOPATTERNPERLINE==false, MINTOKENS>=2,
- * MINLENGTH==1, MAXBACKOFFLENGTH>=MAXLENGTH, MINTOKENS_UNIGRAMS<=MINTOKENS).
+ * MINLENGTH==1, MAXBACKOFFLENGTH>=MAXLENGTH; MINTOKENS_UNIGRAMS > MINTOKENS without skipgrams).
  * ---------------------------------------------------------------------------------------------- */
 co_model* co_train(const uint8_t* payload, uint64_t nbytes, const co_options* opt_in, uint32_t firstsentence) {
     co_options opt = *opt_in;
@@ -436,6 +436,10 @@ co_model* co_train(const uint8_t* payload, uint64_t nbytes, const co_options* op
      * order loop below admits every window and gives the same model. Skipgrams at threshold 1 stay outside the restated subset. */
     if (opt.mintokens < 1 || (opt.mintokens < 2 && (opt.doskipgrams || opt.doskipgrams_exhaustive))) return NULL;
     const uint32_t thr = (uint32_t)opt.mintokens;
+    /* secondary word threshold (:1090-1104): with MINLENGTH == 1 and MINTOKENS > 1 the unigrams themselves are still pruned at MINTOKENS
+     * (:1220), but a longer window is only counted if every one of its words occurs at least MINTOKENS_UNIGRAMS times */
+    const uint32_t wthr = (opt.mintokens_unigrams > opt.mintokens) ? (uint32_t)opt.mintokens_unigrams : 0u;
+    if (wthr && (opt.mintokens < 2 || opt.doskipgrams || opt.doskipgrams_exhaustive)) return NULL;
 
     co_model* m = (co_model*)calloc(1, sizeof(co_model));
     m->indexed  = opt.indexed;
@@ -460,7 +464,15 @@ co_model* co_train(const uint8_t* payload, uint64_t nbytes, const co_options* op
                 const uint8_t* w    = payload + t.start[i];
                 const uint32_t wlen = (uint32_t)(t.start[i + n] - t.start[i]);
                 int            found = 1;
-                if (n > 1) { /* look-back: both (n-1)-grams must be in the model :1139-1152 */
+                if (n > 1 && wthr) { /* unigram check :1093-1104 */
+                    for (int k = 0; k < n && found; ++k) {
+                        const uint8_t*  u  = payload + t.start[i + k];
+                        const uint32_t  ul = (uint32_t)(t.start[i + k + 1] - t.start[i + k]);
+                        const co_entry* e  = map_find(m, u, ul, co_spooky64(u, ul));
+                        if (!(e && e->alive && e->count >= wthr)) found = 0;
+                    }
+                }
+                if (found && n > 1) { /* look-back: both (n-1)-grams must be in the model :1139-1152 */
                     const uint32_t l1 = (uint32_t)(t.start[i + n - 1] - t.start[i]);
                     const uint32_t l2 = (uint32_t)(t.start[i + n] - t.start[i + 1]);
                     found = map_has(m, w, l1) && map_has(m, payload + t.start[i + 1], l2);

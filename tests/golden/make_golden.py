@@ -106,6 +106,11 @@ def main():
         for mode in ("u", "i", "is", "us"):
             out = os.path.join(HERE, f"minlength.{name}.{mode}.m3.txt")
             subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{name}.colibri.dat"), mode, "5", "2", "-q", "-m", "3", "-d", out], stdout=subprocess.DEVNULL)
+    # MINTOKENS_UNIGRAMS = 4 (-W): longer patterns need every word to occur at least four times
+    for name in ["hamlet.v2", "zipf20k"]:
+        for mode in ("u", "i"):
+            out = os.path.join(HERE, f"wordthreshold.{name}.{mode}.W4.txt")
+            subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{name}.colibri.dat"), mode, "5", "2", "-q", "-W", "4", "-d", out], stdout=subprocess.DEVNULL)
     # two-stage build (patternmodeller -2): what the reference's constrained in-place second stage leaves (with and without -s)
     for name in ["hamlet.v2", "zipf20k"]:
         for mode in ("i2", "is2"):

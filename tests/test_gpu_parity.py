@@ -96,6 +96,14 @@ def test_thresholds(ctx, mintokens):  # 1 = the reference's single pass over all
     _compare(ctx, small_corpora()["zipf20k"], 5, mintokens)
 
 
+@pytest.mark.parametrize("table_mode", [0, 1])
+@pytest.mark.parametrize("name", ["zipf20k", "rand1", "cls_2p21", "zipf200k_phrases"])
+@pytest.mark.parametrize("indexed", [0, 1])
+def test_word_threshold(ctx, name, table_mode, indexed):
+    """MINTOKENS_UNIGRAMS > MINTOKENS (-W): every kernel family that produces order-1 ids (class-indexed, table; plain and per-pass)"""
+    _compare(ctx, small_corpora()[name], 5, 2, mintokens_unigrams=5, table_mode=table_mode, indexed=indexed)
+
+
 def test_hamlet_fixture_known_answers(ctx, hamlet_payload):
     """reference src/test.cpp:1214-1221: 111 patterns / 186 types / 354 tokens with default options;
     config 1 of BASELINE.json: n <= 3 -> 81 patterns (45/22/14)."""

@@ -208,3 +208,21 @@ def test_cli_minimum_length(tmp_path, corpus, mode, flags):
     assert counts == want.counts
     if indexed:
         assert refs == want.refs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("corpus", ["hamlet.v2", "zipf20k"])
+@pytest.mark.parametrize("mode,flags", [("u", ["-u"]), ("i", [])])
+def test_cli_word_threshold(tmp_path, corpus, mode, flags):
+    """-W 4 (MINTOKENS_UNIGRAMS): unigrams stay at the pattern threshold, longer patterns need every word to occur four times (goldens by the reference)"""
+    import oracle
+    model = str(tmp_path / "m.colibri.patternmodel")
+    out = subprocess.run([CLI, "-f", os.path.join(GOLDEN, corpus + ".colibri.dat"), "-t", "2", "-l", "5", "-W", "4", "-o", model] + flags, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    indexed = "-u" not in flags
+    want = oracle.parse_dump(open(os.path.join(GOLDEN, f"wordthreshold.{corpus}.{mode}.W4.txt")).read(), indexed=indexed)
+    mtype, tokens, types, counts, refs = parse_model(model)
+    assert (mtype, tokens, types) == (20 if indexed else 10, want.tokens, want.types)
+    assert counts == want.counts
+    if indexed:
+        assert refs == want.refs

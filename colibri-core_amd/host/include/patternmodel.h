@@ -318,8 +318,8 @@ class PatternModel : public MapType, public PatternModelInterface {
         o.doskipgrams            = options.DOSKIPGRAMS;
         o.doskipgrams_exhaustive = options.DOSKIPGRAMS_EXHAUSTIVE;
         o.dopatternperline       = options.DOPATTERNPERLINE;
-        o.prunenonsubsumed       = options.PRUNENONSUBSUMED;
-        o.prunesubsumed          = options.PRUNESUBSUMED;
+        o.prunenonsubsumed       = 0;  // both subsumption prunes are post-hoc passes over the finished model (reference :1280-1330): done below, on the host
+        o.prunesubsumed          = 0;
         o.indexed                = colibri_host::is_indexed_value<ValueType>::value ? 1 : 0;
 
         std::shared_ptr<colibri_host::TrainResult> r = std::make_shared<colibri_host::TrainResult>();
@@ -363,7 +363,64 @@ class PatternModel : public MapType, public PatternModelInterface {
         if (r->stats.npatterns && r->stats.minn < minn) minn = r->stats.minn;
         hasskipgrams_ = (options.DOSKIPGRAMS || options.DOSKIPGRAMS_EXHAUSTIVE);
         install_result(r);
+        if (options.PRUNENONSUBSUMED || options.PRUNESUBSUMED) prune_by_subsumption(options);
     }
+
+    /** erase the patterns of _n tokens (0 = any) that are not / are in the set (reference :2194-2242) */
+    unsigned int prunenotinset(const std::unordered_set<Pattern>& s, int _n) { return prune_set(s, _n, false); }
+    unsigned int pruneinset(const std::unordered_set<Pattern>& s, int _n) { return prune_set(s, _n, true); }
+
+  protected:
+    unsigned int prune_set(const std::unordered_set<Pattern>& s, int _n, bool erase_members) {
+        unsigned int pruned = 0;
+        if (s.empty()) return pruned;
+        for (typename MapType::iterator it = this->begin(); it != this->end();) {
+            if ((_n == 0 || (int)it->first.n() == _n) && ((s.find(it->first) != s.end()) == erase_members)) {
+                it = this->data.erase(it);
+                ++pruned;
+            } else {
+                ++it;
+            }
+        }
+        return pruned;
+    }
+    /** the (n-1)-token sub-patterns of every pattern of n tokens */
+    void subsumed_by(int n, std::unordered_set<Pattern>& out) {
+        for (typename MapType::iterator it = this->begin(); it != this->end(); ++it) {
+            if ((int)it->first.n() != n) continue;
+            std::vector<std::string> toks;
+            colibri_host::token_slices(it->first.data, it->first.bytesize(), toks);
+            for (int first = 0; first + (n - 1) <= n; ++first) {
+                std::string sub;
+                for (int k = first; k < first + n - 1; ++k) sub += toks[(size_t)k];
+                out.insert(Pattern((const unsigned char*)sub.data(), sub.size()));
+            }
+        }
+    }
+    /** PRUNENONSUBSUMED: from the longest patterns down, drop the (n-1)-grams no n-gram contains; PRUNESUBSUMED: from the shortest up, drop the
+     *  (n-1)-grams some n-gram contains (reference :1280-1330). Post-hoc passes over the finished model, on the host. */
+    void prune_by_subsumption(const PatternModelOptions& options) {
+        if (options.PRUNENONSUBSUMED) {
+            if (!options.QUIET) std::cerr << "Pruning non-subsumed n-grams" << std::endl;
+            for (int n = std::min(options.PRUNENONSUBSUMED, options.MAXLENGTH); n > 1; n--) {
+                std::unordered_set<Pattern> subsumed;
+                subsumed_by(n, subsumed);
+                const unsigned int k = prunenotinset(subsumed, n - 1);
+                if (!options.QUIET) std::cerr << " pruned " << k << " non-subsumed " << (n - 1) << "-grams" << std::endl;
+            }
+        }
+        if (options.PRUNESUBSUMED) {
+            if (!options.QUIET) std::cerr << "Pruning subsumed n-grams" << std::endl;
+            for (int n = 2; n <= std::min(options.PRUNESUBSUMED, options.MAXLENGTH); ++n) {
+                std::unordered_set<Pattern> subsumed;
+                subsumed_by(n, subsumed);
+                const unsigned int k = pruneinset(subsumed, n - 1);
+                if (!options.QUIET) std::cerr << " pruned " << k << " subsumed " << (n - 1) << "-grams" << std::endl;
+            }
+        }
+    }
+
+  public:
 
     /** same, from a file name (reference :1353-1364); `.bz2` corpora are not accepted by this build */
     virtual void train(const std::string& filename, const PatternModelOptions& options, PatternModelInterface* constrainbymodel = NULL, PatternSet<>* filter = NULL,

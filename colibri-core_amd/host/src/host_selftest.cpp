@@ -65,6 +65,10 @@ int main(int argc, char** argv) {
         options.MAXLENGTH = std::atoi(argv[5]);
         options.MINTOKENS = std::atoi(argv[6]);
         options.QUIET     = false;
+        for (int a = 7; a < argc; ++a) {  // optional: p<N> = PRUNENONSUBSUMED, S<N> = PRUNESUBSUMED
+            if (argv[a][0] == 'p') options.PRUNENONSUBSUMED = std::atoi(argv[a] + 1);
+            if (argv[a][0] == 'S') options.PRUNESUBSUMED = std::atoi(argv[a] + 1);
+        }
         const std::string kind = argv[4];
         try {
             if (kind == "u") {

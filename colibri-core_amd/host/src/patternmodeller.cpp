@@ -34,6 +34,7 @@ void usage() {
                  "\t-T|--skiptypes <n>          skip type threshold (default 2)\n"
                  "\t-e|--expand <n>             sentence offset given to the first sentence\n"
                  "\t-2|--twostage               two-stage build of an indexed model (needs -o): same result as the reference's -2\n"
+                 "\t-p|--prune <n>              prune the (k-1)-grams that no k-gram of the model contains, from k = n downwards\n"
                  "\t-j|--constraints <file>     only count patterns that occur in this model (any threshold, any minimum length)\n"
                  "\t-I|--constrained            in-place rebuild: recount the patterns of the model given with -i on the corpus given with -f\n"
                  " Viewing:\n"
@@ -91,7 +92,7 @@ int main(int argc, char** argv) {
                                        {"debug", no_argument, 0, 'D'},             {"help", no_argument, 0, 'h'},                 {"twostage", no_argument, 0, '2'},          {"constraints", required_argument, 0, 'j'},    {"constrained", no_argument, 0, 'I'},
                                        {0, 0, 0, 0}};
     int c;
-    while ((c = getopt_long(argc, argv, "f:c:i:o:t:ul:m:b:W:sy:T:e:PRrHDh2j:IEF:LMp:Qq:gZV", longopts, NULL)) != -1) {
+    while ((c = getopt_long(argc, argv, "f:c:i:o:t:ul:m:b:W:sy:T:e:PRrHDh2j:Ip:EF:LMQq:gZV", longopts, NULL)) != -1) {
         switch (c) {
             case 'f': corpusfile = optarg; break;
             case 'c': classfile = optarg; break;
@@ -116,6 +117,7 @@ int main(int argc, char** argv) {
             case 'H': dohistogram = true; break;
             case 'D': options.DEBUG = true; break;
             case '2': twostage = true; break;
+            case 'p': options.PRUNENONSUBSUMED = std::atoi(optarg); break;
             case 'j': constraintfile = optarg; break;
             case 'I': g_inplace = true; break;
             case 'h': usage(); return 0;

@@ -227,6 +227,8 @@ int main(int argc, char** argv) {
         else if (a == "-j" && i + 1 < argc) constraintfile = argv[++i];  // constrain by this model (patternmodeller -j, loaded as a PatternSetModel as src/patternmodeller.cpp:712-718 does)
         else if (a == "-m" && i + 1 < argc) options.MINLENGTH = atoi(argv[++i]);
         else if (a == "-W" && i + 1 < argc) options.MINTOKENS_UNIGRAMS = atoi(argv[++i]);
+        else if (a == "-p" && i + 1 < argc) options.PRUNENONSUBSUMED = atoi(argv[++i]);
+        else if (a == "-S" && i + 1 < argc) options.PRUNESUBSUMED = atoi(argv[++i]);
         else if (a == "-I" && i + 1 < argc) inplacemodel = argv[++i];  // constrained in-place rebuild of this model (patternmodeller -I -i <model>), modes u and i
         else return usage();
     }

@@ -111,6 +111,12 @@ def main():
         for mode in ("u", "i"):
             out = os.path.join(HERE, f"wordthreshold.{name}.{mode}.W4.txt")
             subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{name}.colibri.dat"), mode, "5", "2", "-q", "-W", "4", "-d", out], stdout=subprocess.DEVNULL)
+    # PRUNENONSUBSUMED = 4 (-p) / PRUNESUBSUMED = 3: post-hoc passes over the finished model
+    for name in ["hamlet.v2", "zipf20k"]:
+        for mode in ("u", "i"):
+            for flag, tag in (("-p", "p4"), ("-S", "S3")):
+                out = os.path.join(HERE, f"subsumption.{name}.{mode}.{tag}.txt")
+                subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{name}.colibri.dat"), mode, "5", "2", "-q", flag, tag[1:], "-d", out], stdout=subprocess.DEVNULL)
     # two-stage build (patternmodeller -2): what the reference's constrained in-place second stage leaves (with and without -s)
     for name in ["hamlet.v2", "zipf20k"]:
         for mode in ("i2", "is2"):

@@ -226,3 +226,26 @@ def test_cli_word_threshold(tmp_path, corpus, mode, flags):
     assert counts == want.counts
     if indexed:
         assert refs == want.refs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("corpus", ["hamlet.v2", "zipf20k"])
+@pytest.mark.parametrize("kind", ["u", "i"])
+@pytest.mark.parametrize("tag", ["p4", "S3"])
+def test_cxx_api_subsumption_prunes(tmp_path, corpus, kind, tag):
+    """PRUNENONSUBSUMED = 4 (colibri-patternmodeller -p 4) / PRUNESUBSUMED = 3 through the C++ face: goldens by the real reference"""
+    import oracle
+    model = str(tmp_path / "m.colibri.patternmodel")
+    out = subprocess.run([SELFTEST, "gpu", os.path.join(GOLDEN, corpus + ".colibri.dat"), model, "u" if kind == "u" else "i", "5", "2", tag], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    indexed = kind == "i"
+    want = oracle.parse_dump(open(os.path.join(GOLDEN, f"subsumption.{corpus}.{kind}.{tag}.txt")).read(), indexed=indexed)
+    mtype, tokens, types, counts, refs = parse_model(model)
+    assert (tokens, types) == (want.tokens, want.types)
+    assert counts == want.counts
+    if indexed:
+        assert refs == want.refs
+    if tag == "p4":  # the CLI flag
+        out = subprocess.run([CLI, "-f", os.path.join(GOLDEN, corpus + ".colibri.dat"), "-t", "2", "-l", "5", "-p", "4", "-o", model] + (["-u"] if kind == "u" else []), capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        assert parse_model(model)[3] == want.counts

@@ -20,6 +20,7 @@
 #include "binned.hpp"
 #include "textenc.hpp"
 #include "constrained.hpp"
+#include "flexgrams.hpp"
 #include "kernels.hpp"
 
 using namespace colibri;
@@ -101,6 +102,14 @@ struct colibri_ctx {
         int                        rules = -1;
         bool                       encoded = false;
     } tx;
+    struct FlexState {                  // flexgrams from skipgrams (flexgrams.hpp): the result of the last colibri_flexgrams call
+        DevBuf<uint8_t>            keys;
+        DevBuf<unsigned long long> keyoff, refoff;
+        DevBuf<uint32_t>           cnt, sentence;
+        DevBuf<uint16_t>           token;
+        uint64_t                   ngroups = 0, keybytes = 0, nrefs = 0;
+        bool                       valid = false;
+    } fx;
     DevBuf<uint32_t>  alist[2], alist_n; // binned path: active-position lists (ping-pong) and their lengths [2]
     DevBuf<BinState>  binstate;
     int               last_mode = 0;    // 1 = global table, 2 = binned (what the last train() actually ran)
@@ -151,7 +160,7 @@ struct colibri_ctx {
     } sh;
 
     // profiling
-    bool                   profile = false;
+    int                    profile = 0;    // 0 off, 1 every kernel class, 2 only the dominant-kernel classes
     std::vector<EventPair> events;
     std::vector<hipEvent_t> event_pool;  // events are recycled: creating/destroying ~60 of them per train() costs milliseconds
     double                 k_ms[COLIBRI_K_NCLASSES]{};
@@ -441,6 +450,7 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->tx.text); dev_free(c->tx.out); dev_free(c->tx.slot_of); dev_free(c->tx.first); dev_free(c->tx.widx); dev_free(c->tx.wstart); dev_free(c->tx.wlen);
     dev_free(c->tx.wcount); dev_free(c->tx.cls); dev_free(c->tx.repeat); dev_free(c->tx.outlen); dev_free(c->tx.outoff); dev_free(c->tx.bsum); dev_free(c->tx.ntok);
     dev_free(c->cs.bytes); dev_free(c->cs.off); dev_free(c->cs.table); dev_free(c->cs.rem);
+    dev_free(c->fx.keys); dev_free(c->fx.keyoff); dev_free(c->fx.refoff); dev_free(c->fx.cnt); dev_free(c->fx.sentence); dev_free(c->fx.token);
     dev_free(c->tx.table); dev_free(c->tx.state); dev_free(c->tx.info); dev_free(c->tx.events); dev_free(c->tx.evcnt);
     dev_free(c->flag2);
     dev_free(c->ids_at);
@@ -833,6 +843,54 @@ int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids) {
     return COLIBRI_OK;
 }
 
+// two-level exclusive scan of n u32 values into u64 offsets (out[0..n-1]); *total (optional) = their sum, read back after a sync
+int scan_u32(colibri_ctx* c, const uint32_t* in, uint32_t n, unsigned long long* out, unsigned long long* total) {
+    const uint32_t nb = std::max<uint32_t>(1, blocks_for(n, kBlock * 4));
+    int            rc;
+    if ((rc = dev_alloc(c, c->bsum, (size_t)nb + 1))) return rc;
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, in, n, c->bsum.p);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->bsum.p, nb, c->bsum.p + nb);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, in, n, c->bsum.p, out);
+    if (total) {
+        HIP_TRY(c, hipMemcpyAsync(total, c->bsum.p + nb, sizeof *total, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+    }
+    return COLIBRI_OK;
+}
+
+// stable LSD radix sort of (key, value) pairs by the low `bits` bits of the key, 8 bits per pass, ping-pong between key[0/1], val[0/1];
+// `cur` names the buffers holding the input and, on return, the output
+int radix_sort_pairs(colibri_ctx* c, uint32_t* const key[2], uint32_t* const val[2], uint64_t n, int bits, int& cur) {
+    if (!n) return COLIBRI_OK;
+    const uint32_t             nblocks = (uint32_t)((n + kSortTile - 1) / kSortTile);
+    const uint32_t             nh      = 256u * nblocks;
+    const uint32_t             nb      = blocks_for(nh, kBlock * 4);
+    DevBuf<uint32_t>           ghist;
+    DevBuf<unsigned long long> goff, bsum;
+    int                        rc;
+    if ((rc = dev_alloc(c, ghist, nh)) || (rc = dev_alloc(c, goff, nh)) || (rc = dev_alloc(c, bsum, (size_t)nb + 1))) return rc;
+    for (int shift = 0; shift < bits; shift += 8) {
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(kBlock), 0, c->stream, key[cur], n, shift, nblocks, ghist.p);
+        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, ghist.p, nh, bsum.p);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, c->stream, bsum.p, nb, bsum.p + nb);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, ghist.p, nh, bsum.p, goff.p);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(kBlock), 0, c->stream, key[cur], val[cur], n, shift, nblocks, goff.p, key[cur ^ 1], val[cur ^ 1]);
+        cur ^= 1;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the scratch below must outlive the passes
+    HIP_TRY(c, hipGetLastError());
+    dev_free(ghist);
+    dev_free(goff);
+    dev_free(bsum);
+    return COLIBRI_OK;
+}
+inline int bits_for(uint64_t nvalues) {
+    int bits = 1;
+    while (bits < 32 && (1ull << bits) < nvalues) ++bits;
+    return bits;
+}
+
 // group the pairs by result id (stable LSD radix sort) and turn positions into (sentence, token)
 int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = false) {
     const uint64_t n = c->npairs;
@@ -840,26 +898,12 @@ int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = fal
     if ((rc = dev_alloc(c, c->ref_sentence, (size_t)n + 1)) || (rc = dev_alloc(c, c->ref_token, (size_t)n + 1))) return rc;
     if (!n) return COLIBRI_OK;
     if ((rc = dev_alloc(c, c->pair_id[1], (size_t)n)) || (rc = dev_alloc(c, c->pair_pos[1], (size_t)n))) return rc;
-    int bits = 1;
-    while (bits < 32 && (1ull << bits) < (uint64_t)nresults) ++bits;
-    const uint32_t             nblocks = (uint32_t)((n + kSortTile - 1) / kSortTile);
-    const uint32_t             nh      = 256u * nblocks;
-    const uint32_t             nb      = blocks_for(nh, kBlock * 4);
-    DevBuf<uint32_t>           ghist;
-    DevBuf<unsigned long long> goff, bsum;
-    if ((rc = dev_alloc(c, ghist, nh)) || (rc = dev_alloc(c, goff, nh)) || (rc = dev_alloc(c, bsum, (size_t)nb + 1))) return rc;
     int cur = 0;
     {
-        Prof p(c, COLIBRI_K_INDEX);
-        for (int shift = 0; shift < bits; shift += 8) {
-            hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(kBlock), 0, c->stream, c->pair_id[cur].p, n, shift, nblocks, ghist.p);
-            hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, ghist.p, nh, bsum.p);
-            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, c->stream, bsum.p, nb, bsum.p + nb);
-            hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, ghist.p, nh, bsum.p, goff.p);
-            hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(kBlock), 0, c->stream, c->pair_id[cur].p, c->pair_pos[cur].p, n, shift, nblocks, goff.p, c->pair_id[cur ^ 1].p,
-                               c->pair_pos[cur ^ 1].p);
-            cur ^= 1;
-        }
+        Prof            p(c, COLIBRI_K_INDEX);
+        uint32_t* const keys[2] = {c->pair_id[0].p, c->pair_id[1].p};
+        uint32_t* const vals[2] = {c->pair_pos[0].p, c->pair_pos[1].p};
+        if ((rc = radix_sort_pairs(c, keys, vals, n, bits_for(nresults), cur))) return rc;
         if (!c->pos_refs_valid) {
             if ((rc = dev_alloc(c, c->pos_ref, (size_t)c->npos + 1))) return rc;
             hipLaunchKernelGGL(position_refs_kernel, dim3(stream_grid(c->npos)), dim3(kBlock), 0, c->stream, c->delimpos.p, c->ndelim, c->npos, c->pos_ref.p);
@@ -870,9 +914,6 @@ int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = fal
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
-    dev_free(ghist);
-    dev_free(goff);
-    dev_free(bsum);
     if (keep_sorted_ids) {  // sharded mode: the caller still needs the (sorted) global ids to cut the references into runs
         dev_free(c->sh.sorted_gid);
         c->sh.sorted_gid = c->pair_id[cur];
@@ -1328,5 +1369,6 @@ int colibri_kernel_time(const colibri_ctx* c, int cls, double* total_ms, uint64_
 
 #include "shard_api.inc"  // colibri_shard_*: opens extern "C"
 #include "text_api.inc"   // colibri_set_constraint, colibri_text_*
+#include "flex_api.inc"   // colibri_flexgrams, colibri_flexgrams_fetch
 
 }  // extern "C"

@@ -101,6 +101,9 @@ struct ConstraintKeys {
 };
 /** upload + train + export through the C ABI; prints the library's message on stderr and throws InternalError on any status != 0 */
 void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out, const ConstraintKeys* constraint = NULL);
+/** flexgrams abstracted from the skipgrams of an indexed model given in export layout (colibri_flexgrams + colibri_flexgrams_fetch) */
+void device_flexgrams(const std::vector<uint64_t>& key_off, const unsigned char* key_bytes, const std::vector<uint64_t>& ref_off, const uint32_t* ref_sentence,
+                      const uint16_t* ref_token, TrainResult& out);
 /** the per-order progress lines the reference prints while training (patternmodel.h:1005-1019, :1195-1245) */
 void print_training_log(const colibri_stats& s, const colibri_options& o, std::ostream& err);
 /** the tokens of a key as byte strings, gaps included (what the reference's pattern.ngrams(…, 1) yields, src/pattern.cpp:1284-1296) */
@@ -209,6 +212,8 @@ class PatternModel : public MapType, public PatternModelInterface {
     unsigned char type() const { return model_type; }
     unsigned char version() const { return model_version; }
     bool          hasskipgrams() const { return hasskipgrams_; }
+    /** does nothing for unindexed models (reference :2653-2655); IndexedPatternModel abstracts its skipgrams on the device */
+    virtual int computeflexgrams_fromskipgrams() { return 0; }
     /** what the reference's constrained in-place rebuild leaves in the type count: the number of patterns the model was loaded with
      *  (it takes "total word types prior to pruning" from a map that already holds every pattern, patternmodel.h:1197-1201) */
     void settypes_inplace_rebuild() { totaltypes = this->size(); }
@@ -825,6 +830,43 @@ class IndexedPatternModel : public PatternModel<IndexedData, IndexedDataHandler,
     void coverage_finish() override { covered_.clear(); }
 
   public:
+    /** Compute flexgrams by abstracting from the skipgrams in the model (reference :3724-3744): every skipgram's references are appended to
+     *  the flexgram it abstracts to (Pattern::toflexgram). The group-by and the merge of the reference lists run on the device
+     *  (colibri_flexgrams); each flexgram's new references arrive ascending. @return the number of flexgrams that were not in the model */
+    int computeflexgrams_fromskipgrams() override {
+        colibri_host::TrainResult flex;
+        if (this->result) {  // device results not materialised yet: their flat arrays are the input
+            std::shared_ptr<colibri_host::TrainResult> r = this->result;
+            colibri_host::device_flexgrams(r->key_off, r->key_bytes.data(), r->ref_off, r->ref_sentence.data(), r->ref_token.data(), flex);
+        } else {
+            std::vector<uint64_t>      key_off(1, 0), ref_off(1, 0);
+            std::vector<unsigned char> key_bytes;
+            std::vector<uint32_t>      rs;
+            std::vector<uint16_t>      rt;
+            for (typename MapType::iterator it = this->begin(); it != this->end(); ++it) {
+                if (it->first.category() != SKIPGRAM) continue;
+                key_bytes.insert(key_bytes.end(), it->first.data, it->first.data + it->first.bytesize());
+                key_off.push_back(key_bytes.size());
+                for (const IndexReference& ref : it->second.data) {
+                    rs.push_back(ref.sentence);
+                    rt.push_back(ref.token);
+                }
+                ref_off.push_back(rs.size());
+            }
+            rs.push_back(0);
+            rt.push_back(0);
+            colibri_host::device_flexgrams(key_off, key_bytes.data(), ref_off, rs.data(), rt.data(), flex);
+        }
+        int count = 0;
+        for (size_t j = 0; j < flex.size(); ++j) {
+            const Pattern flexgram(flex.key_bytes.data() + flex.key_off[j], (size_t)(flex.key_off[j + 1] - flex.key_off[j]));
+            if (!this->has(flexgram)) ++count;
+            IndexedData& d = (*this)[flexgram];
+            d.data.reserve(d.data.size() + (size_t)(flex.ref_off[j + 1] - flex.ref_off[j]));
+            for (uint64_t k = flex.ref_off[j]; k < flex.ref_off[j + 1]; ++k) d.data.push_back(IndexReference(flex.ref_sentence[k], flex.ref_token[k]));
+        }
+        return count;
+    }
     void train(std::istream* in, const PatternModelOptions& options, PatternModelInterface* constrainbymodel = NULL, PatternSet<>* filter = NULL, bool continued = false,
                uint32_t firstsentence = 1, bool ignoreerrors = false) override {
         if (options.DOSKIPGRAMS && this->reverseindex == NULL) {  // reference :2828-2833

@@ -382,6 +382,28 @@ void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_o
     }
 }
 
+void device_flexgrams(const std::vector<uint64_t>& key_off, const unsigned char* key_bytes, const std::vector<uint64_t>& ref_off, const uint32_t* ref_sentence,
+                      const uint16_t* ref_token, TrainResult& out) {
+    CtxGuard    g;
+    const char* dev = std::getenv("COLIBRI_DEVICE");
+    int         rc  = colibri_create(&g.c, dev ? std::atoi(dev) : 0);
+    if (rc != COLIBRI_OK) raise(nullptr, rc, "colibri_create");
+    const uint64_t np = key_off.empty() ? 0 : key_off.size() - 1;
+    uint64_t       nf = 0, kb = 0, nr = 0;
+    static const unsigned char none = 0;
+    if ((rc = colibri_flexgrams(g.c, key_off.data(), key_bytes ? key_bytes : &none, ref_off.data(), ref_sentence, ref_token, np, &nf, &kb, &nr)) != COLIBRI_OK)
+        raise(g.c, rc, "colibri_flexgrams");
+    out.key_off.assign(nf + 1, 0);
+    out.key_bytes.assign(kb + 1, 0);
+    out.counts.assign(nf + 1, 0);
+    out.ref_off.assign(nf + 1, 0);
+    out.ref_sentence.assign(nr + 1, 0);
+    out.ref_token.assign(nr + 1, 0);
+    if ((rc = colibri_flexgrams_fetch(g.c, out.key_off.data(), out.key_bytes.data(), out.counts.data(), out.ref_off.data(), out.ref_sentence.data(), out.ref_token.data())) != COLIBRI_OK)
+        raise(g.c, rc, "colibri_flexgrams_fetch");
+    out.counts.resize(nf);
+}
+
 void drop_short_patterns(TrainResult& r, int minlength) {
     const size_t n = r.size();
     const bool   indexed = !r.ref_off.empty();

@@ -1,8 +1,9 @@
 // colibri-patternmodeller (MI355X build) — a drop-in for the reference's command-line driver on the accelerated path.
 // Same flags and flag meanings as reference src/patternmodeller.cpp:404-858 for: -f -c -o -i -u -t -l -m -b -W -s -y -T -P -R -r -H -e -D -h
-// (build a model from a .colibri.dat, save it, load a model, print / report / histogram), plus -2 (two-stage build). Flags that
-// -j (constrain by a model) and -I (constrained in-place rebuild of the model given with -i). Flags that select paths outside the accelerated
-// subset (-E -F -L -M -p -Q -q -g ...) are reported and rejected instead of being silently ignored.
+// (build a model from a .colibri.dat, save it, load a model, print / report / histogram), plus -2 (two-stage build), -p (prune by
+// subsumption), -j (constrain by a model), -I (constrained in-place rebuild of the model given with -i) and -F S (flexgrams abstracted from the
+// skipgrams of a freshly built indexed model). Flags that select paths outside the accelerated subset (-E -L -M -Q -q -g, -F <npmi> ...) are
+// reported and rejected instead of being silently ignored.
 // All counting happens in libcolibri_hip.so; this file only parses options and calls the C++ face.
 #include <getopt.h>
 
@@ -36,6 +37,7 @@ void usage() {
                  "\t-2|--twostage               two-stage build of an indexed model (needs -o): same result as the reference's -2\n"
                  "\t-p|--prune <n>              prune the (k-1)-grams that no k-gram of the model contains, from k = n downwards\n"
                  "\t-j|--constraints <file>     only count patterns that occur in this model (any threshold, any minimum length)\n"
+                 "\t-F|--flexgrams S            flexgrams by abstracting over skipgrams (implies -s); indexed models built from a corpus\n"
                  "\t-I|--constrained            in-place rebuild: recount the patterns of the model given with -i on the corpus given with -f\n"
                  " Viewing:\n"
                  "\t-P|--print   -R|--report   -r|--simplereport   -H|--histogram\n"
@@ -44,6 +46,7 @@ void usage() {
 
 PatternSetModel* g_constraint = NULL;  // -j
 bool             g_inplace    = false; // -I
+bool             g_flexfromskip = false; // -F S
 
 template <class ModelType>
 int run(ModelType& model, const std::string& corpusfile, const std::string& inputmodel, const std::string& outputmodel, const PatternModelOptions& options_in, uint32_t firstsentence,
@@ -60,6 +63,11 @@ int run(ModelType& model, const std::string& corpusfile, const std::string& inpu
         model.load(inputmodel, options);
     } else {
         model.train(corpusfile, options, g_constraint, NULL, false, firstsentence);
+        if (g_flexfromskip && options.DOSKIPGRAMS) {  // reference src/patternmodeller.cpp:337-341, :790-794 (messages as there, file name glued on)
+            std::cerr << "Computing flexgrams from skipgrams" << corpusfile << std::endl;
+            const int found = model.computeflexgrams_fromskipgrams();
+            std::cerr << found << " flexgrams found" << corpusfile << std::endl;
+        }
     }
     if (!outputmodel.empty()) {
         std::cerr << "Writing model to " << outputmodel << std::endl;
@@ -89,7 +97,7 @@ int main(int argc, char** argv) {
                                        {"wordthreshold", required_argument, 0, 'W'}, {"skipgrams", no_argument, 0, 's'},          {"skipthreshold", required_argument, 0, 'y'},
                                        {"skiptypes", required_argument, 0, 'T'},   {"expand", required_argument, 0, 'e'},         {"print", no_argument, 0, 'P'},
                                        {"report", no_argument, 0, 'R'},            {"simplereport", no_argument, 0, 'r'},         {"histogram", no_argument, 0, 'H'},
-                                       {"debug", no_argument, 0, 'D'},             {"help", no_argument, 0, 'h'},                 {"twostage", no_argument, 0, '2'},          {"constraints", required_argument, 0, 'j'},    {"constrained", no_argument, 0, 'I'},
+                                       {"debug", no_argument, 0, 'D'},             {"help", no_argument, 0, 'h'},                 {"twostage", no_argument, 0, '2'},          {"constraints", required_argument, 0, 'j'},    {"constrained", no_argument, 0, 'I'},    {"flexgrams", required_argument, 0, 'F'},
                                        {0, 0, 0, 0}};
     int c;
     while ((c = getopt_long(argc, argv, "f:c:i:o:t:ul:m:b:W:sy:T:e:PRrHDh2j:Ip:EF:LMQq:gZV", longopts, NULL)) != -1) {
@@ -120,6 +128,14 @@ int main(int argc, char** argv) {
             case 'p': options.PRUNENONSUBSUMED = std::atoi(optarg); break;
             case 'j': constraintfile = optarg; break;
             case 'I': g_inplace = true; break;
+            case 'F':  // reference :550-559: "S" = from skipgrams (implies -s); a number = from co-occurrence (not in this build)
+                if (std::string(optarg) != "S") {
+                    std::cerr << "ERROR: option -F " << optarg << " (flexgrams from co-occurrence) is not part of the MI355X-accelerated build (see DESIGN.md, out of scope)" << std::endl;
+                    return 2;
+                }
+                g_flexfromskip      = true;
+                options.DOSKIPGRAMS = true;
+                break;
             case 'h': usage(); return 0;
             default:
                 std::cerr << "ERROR: option -" << (char)(c == '?' ? optopt : c) << " selects a path that is not part of the MI355X-accelerated build (see DESIGN.md, out of scope)" << std::endl;
@@ -136,6 +152,10 @@ int main(int argc, char** argv) {
         if (!classfile.empty()) {
             loaded.load(classfile);
             decoder = &loaded;
+        }
+        if (g_flexfromskip && !inputmodel.empty()) {
+            std::cerr << "ERROR: -F S on a loaded model needs the reference's trainskipgrams on that model, which is not part of this build; build the model from the corpus (-f) with -F S" << std::endl;
+            return 2;
         }
         if (g_inplace && (inputmodel.empty() || corpusfile.empty())) {
             std::cerr << "ERROR: Corpus data file (--datafile|-f) and input model (--inputmodel|-i) must be specified when --constrained|-I is set!." << std::endl;

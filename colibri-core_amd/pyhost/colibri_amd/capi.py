@@ -24,6 +24,7 @@ EXPORTED = [
     "colibri_shard_finish", "colibri_shard_export_gids", "colibri_shard_index_sizes", "colibri_shard_export_index",
     "colibri_shard_uni_info", "colibri_shard_uni_count", "colibri_shard_uni_apply",
     "colibri_set_constraint", "colibri_text_upload", "colibri_text_count", "colibri_text_words", "colibri_text_encode", "colibri_text_fetch", "colibri_text_as_corpus",
+    "colibri_flexgrams", "colibri_flexgrams_fetch",
 ]
 
 
@@ -82,6 +83,8 @@ def load():
         L.colibri_text_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.colibri_text_fetch.argtypes = [C.c_void_p, C.c_void_p]
         L.colibri_text_as_corpus.argtypes = [C.c_void_p, C.c_uint32]
+        L.colibri_flexgrams.argtypes = [C.c_void_p] * 6 + [C.c_uint64] + [C.POINTER(C.c_uint64)] * 3
+        L.colibri_flexgrams_fetch.argtypes = [C.c_void_p] * 7
         L.colibri_upload_corpus.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
         L.colibri_upload_corpus_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
         L.colibri_corpus_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 3
@@ -206,6 +209,29 @@ class Context:
             rs, rt = rs.tolist(), rt.tolist()
             rd = {kb[off[j]: off[j + 1]]: list(zip(rs[ro[j]: ro[j + 1]], rt[ro[j]: ro[j + 1]])) for j in range(len(counts))}
         return cd, rd
+
+    # -- flexgrams from skipgrams -------------------------------------------------
+    def flexgrams(self, key_off, key_bytes, ref_off, ref_s, ref_t):
+        """colibri_flexgrams + colibri_flexgrams_fetch on an indexed model in export layout; returns the flexgrams in the same
+        layout: (key_off, key_bytes, counts, (ref_off, ref_sentence, ref_token))."""
+        npat = len(key_off) - 1
+        key_off = np.ascontiguousarray(key_off, dtype=np.uint64)
+        ref_off = np.ascontiguousarray(ref_off, dtype=np.uint64)
+        kb_in = np.ascontiguousarray(key_bytes, dtype=np.uint8) if len(key_bytes) else np.zeros(1, dtype=np.uint8)
+        rs_in = np.ascontiguousarray(ref_s, dtype=np.uint32) if len(ref_s) else np.zeros(1, dtype=np.uint32)
+        rt_in = np.ascontiguousarray(ref_t, dtype=np.uint16) if len(ref_t) else np.zeros(1, dtype=np.uint16)
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.L.colibri_flexgrams(self.h, key_off.ctypes.data, kb_in.ctypes.data, ref_off.ctypes.data, rs_in.ctypes.data, rt_in.ctypes.data, npat,
+                                             C.byref(a), C.byref(b), C.byref(c)))
+        nf, kb, nr = a.value, b.value, c.value
+        fo = np.zeros(nf + 1, dtype=np.uint64)
+        fk = np.zeros(max(1, kb), dtype=np.uint8)
+        fc = np.zeros(max(1, nf), dtype=np.uint32)
+        fro = np.zeros(nf + 1, dtype=np.uint64)
+        frs = np.zeros(max(1, nr), dtype=np.uint32)
+        frt = np.zeros(max(1, nr), dtype=np.uint16)
+        self._check(self.L.colibri_flexgrams_fetch(self.h, fo.ctypes.data, fk.ctypes.data, fc.ctypes.data, fro.ctypes.data, frs.ctypes.data, frt.ctypes.data))
+        return fo, fk[:kb], fc[:nf], (fro, frs[:nr], frt[:nr])
 
     # -- parity / measurement hooks --------------------------------------------------------------
     def hash_windows(self, n):

@@ -207,6 +207,21 @@ int colibri_text_encode(colibri_ctx* ctx, const uint32_t* cls, const uint32_t* r
 int colibri_text_fetch(colibri_ctx* ctx, uint8_t* out);                                          /* the encoded payload -> host */
 int colibri_text_as_corpus(colibri_ctx* ctx, uint32_t first_sentence);                           /* ... or straight into colibri_upload_corpus_device */
 
+/* ---- flexgrams abstracted from skipgrams ---------------------------------------------------------
+ * Replaces IndexedPatternModel::computeflexgrams_fromskipgrams (reference include/patternmodel.h:3724-3744) with
+ * Pattern::toflexgram (src/pattern.cpp:145-180) and Pattern::category (:107-127): every SKIPGRAM among the given patterns hands
+ * all its references to the flexgram whose key is the skipgram's with each run of {*} (03) tokens replaced by one {**} (04).
+ * Input = an indexed model in the layout colibri_export_indexed writes (patterns of other categories are ignored; no corpus is
+ * needed). Result, kept on the device until the next call: one entry per distinct flexgram, count = number of references,
+ * references ascending by (sentence, token) with duplicates kept (IndexedData::insert is a push_back, datatypes.h:117-119; the
+ * reference's own order is its unordered_map's iteration order, and its loop inserts into the map it iterates — the specification
+ * here is the loop without that hazard). Grouping is exact (64-bit hash of the collapsed bytes, bytes verified, reseeded on a
+ * collision). colibri_flexgrams_fetch copies the result into caller-allocated buffers sized from the three totals
+ * (key_off / ref_off: nflexgrams + 1 entries). */
+int colibri_flexgrams(colibri_ctx* ctx, const uint64_t* key_off, const uint8_t* key_bytes, const uint64_t* ref_off, const uint32_t* ref_sentence, const uint16_t* ref_token,
+                      uint64_t npatterns, uint64_t* nflexgrams, uint64_t* keybytes, uint64_t* nrefs);
+int colibri_flexgrams_fetch(colibri_ctx* ctx, uint64_t* key_off, uint8_t* key_bytes, uint32_t* counts, uint64_t* ref_off, uint32_t* ref_sentence, uint16_t* ref_token);
+
 #ifdef __cplusplus
 }
 #endif

@@ -196,6 +196,59 @@ def ref_train(corpus_path: str, mode: str, maxlength: int, mintokens: int, *, mi
     return model, info
 
 
+# ---- flexgrams from skipgrams ---------------------------------------------------------------------------------------
+def key_tokens(key: bytes):
+    """The tokens of a pattern key (each a varint: bytes >= 128 continue, a byte < 128 ends the token)."""
+    out, start = [], 0
+    for j, b in enumerate(key):
+        if b < 128:
+            out.append(key[start:j + 1])
+            start = j + 1
+    return out
+
+
+def key_category(key: bytes) -> int:
+    """Pattern::category (reference src/pattern.cpp:107-127): 3 = flexgram (any {**}), 2 = skipgram (any {*}), 1 = n-gram."""
+    toks = key_tokens(key)
+    return 3 if b"\x04" in toks else 2 if b"\x03" in toks else 1
+
+
+def toflexgram(key: bytes) -> bytes:
+    """Pattern::toflexgram (reference src/pattern.cpp:145-180): every run of {*} tokens becomes one {**}."""
+    out, gap = [], False
+    for t in key_tokens(key):
+        if t == b"\x03":
+            if not gap:
+                out.append(b"\x04")
+            gap = True
+        else:
+            out.append(t)
+            gap = False
+    return b"".join(out)
+
+
+def flexgrams_from_skipgrams(m: "Model"):
+    """IndexedPatternModel::computeflexgrams_fromskipgrams (reference include/patternmodel.h:3724-3744) without its
+    insert-while-iterating hazard: every skipgram's references are appended to the flexgram it abstracts to (IndexedData::insert
+    is a push_back: duplicates stay). Canonical form: references ascending. Returns (model with the flexgrams added, number of
+    new flexgrams)."""
+    counts, refs = dict(m.counts), {k: list(v) for k, v in m.refs.items()}
+    found = 0
+    for k in m.refs:
+        if key_category(k) != 2:
+            continue
+        f = toflexgram(k)
+        if f not in refs:
+            found += 1
+            refs[f] = []
+        refs[f].extend(m.refs[k])
+    for k in refs:
+        if key_category(k) == 3:
+            refs[k].sort()
+        counts[k] = len(refs[k])
+    return Model(m.tokens, m.types, counts, refs, m.stats, m.maxn, m.windows), found
+
+
 # ---- class encoder (SURVEY §8 f-2): oracle/classenc_oracle.cpp and the real reference -----------------------------------------------
 CLASSENC_LIB_PATH = os.path.join(HERE, "libclassenc_oracle.so")
 _cel = None

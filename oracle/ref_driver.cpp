@@ -57,7 +57,7 @@ void collect_unindexed(Model& model, std::vector<Row>& rows) {
     }
 }
 
-void collect_indexed(IndexedPatternModel<>& model, std::vector<Row>& rows) {
+void collect_indexed(IndexedPatternModel<>& model, std::vector<Row>& rows, bool sortrefs = false) {
     for (auto it = model.begin(); it != model.end(); ++it) {
         const Pattern& p = it->first;
         Row r;
@@ -65,6 +65,7 @@ void collect_indexed(IndexedPatternModel<>& model, std::vector<Row>& rows) {
         std::ostringstream os;
         os << "\t" << it->second.count() << "\t";
         bool first = true;
+        if (sortrefs) it->second.sort();  // flexgram references arrive in map iteration order: canonical form = ascending, duplicates kept
         for (auto ref = it->second.begin(); ref != it->second.end(); ++ref) {
             if (!first) os << ' ';
             os << ref->sentence << ':' << ref->token;
@@ -86,7 +87,7 @@ void dump(std::ostream& out, uint64_t tokens, uint64_t types, std::vector<Row>& 
 int usage() {
     std::cerr << "usage:\n"
                  "  ref_driver train <corpus.colibri.dat> <mode:u|U|us|i|is> <maxlength> <mintokens>\n"
-                 "             [-T minskiptypes] [-y mintokens_skipgrams] [-o model.out] [-d dump.txt] [-q] [-j constraintmodel] [-m minlength]\n"
+                 "             [-T minskiptypes] [-y mintokens_skipgrams] [-o model.out] [-d dump.txt] [-q] [-j constraintmodel] [-m minlength] [-F]\n"
                  "      u  = unindexed, streaming from file (patternmodeller -u)\n"
                  "      U  = unindexed, corpus preloaded in an IndexedCorpus (benchmarks.cpp test 5)\n"
                  "      us = unindexed + exhaustive skipgrams (preloaded corpus)\n"
@@ -217,6 +218,7 @@ int main(int argc, char** argv) {
     options.MINTOKENS = atoi(argv[5]);
     options.QUIET     = false;
     std::string modelout, dumpout, constraintfile, inplacemodel;
+    bool flexfromskip = false;
     for (int i = 6; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "-T" && i + 1 < argc) options.MINSKIPTYPES = atoi(argv[++i]);
@@ -229,6 +231,7 @@ int main(int argc, char** argv) {
         else if (a == "-W" && i + 1 < argc) options.MINTOKENS_UNIGRAMS = atoi(argv[++i]);
         else if (a == "-p" && i + 1 < argc) options.PRUNENONSUBSUMED = atoi(argv[++i]);
         else if (a == "-S" && i + 1 < argc) options.PRUNESUBSUMED = atoi(argv[++i]);
+        else if (a == "-F") flexfromskip = true;  // computeflexgrams_fromskipgrams after training (patternmodeller -F S, src/patternmodeller.cpp:790-794), mode is
         else if (a == "-I" && i + 1 < argc) inplacemodel = argv[++i];  // constrained in-place rebuild of this model (patternmodeller -I -i <model>), modes u and i
         else return usage();
     }
@@ -298,10 +301,11 @@ int main(int argc, char** argv) {
         t0 = clk::now();
         model.train(corpusfile, options, constrain);
         train_s = std::chrono::duration<double>(clk::now() - t0).count();
+        if (flexfromskip) std::cerr << "flexgrams " << model.computeflexgrams_fromskipgrams() << std::endl;
         tokens = model.tokens();
         types  = model.types();
         if (!modelout.empty()) model.write(modelout);
-        if (!dumpout.empty()) collect_indexed(model, rows);
+        if (!dumpout.empty()) collect_indexed(model, rows, flexfromskip);
     } else if (mode == "i2" || mode == "is2") {
         // two-stage build as colibri-patternmodeller -2 does it (reference src/patternmodeller.cpp:627-663, :756-831): stage 1 an
         // unindexed model written to <tmp>.stage1, stage 2 an indexed model loaded from it (DORESET) and rebuilt in place, constrained by itself

@@ -54,7 +54,7 @@ def test_host_selftest_cpu():
 
 
 def test_cli_rejects_out_of_scope_flags():
-    for flag in (["-g"], ["-E"], ["-F", "S"], ["-Q"]):  # relations, self-expansion, flexgrams, query mode
+    for flag in (["-g"], ["-E"], ["-F", "0.5"], ["-Q"]):  # relations, self-expansion, flexgrams from co-occurrence, query mode
         out = subprocess.run([CLI, "-f", os.path.join(GOLDEN, "hamlet.v2.colibri.dat")] + flag, capture_output=True, text=True)
         assert out.returncode == 2 and "not part of the MI355X-accelerated build" in out.stderr
 
@@ -133,6 +133,35 @@ def test_cli_indexed_and_skipgram_models_reference_can_load(tmp_path, corpus, fl
         subprocess.check_call([oracle.REF_DRIVER, "load", model, "i" if indexed else "u", dump])
         got = oracle.parse_dump(open(dump).read(), indexed=indexed)
         assert (got.tokens, got.types, got.counts, got.refs) == (want.tokens, want.types, want.counts, want.refs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("corpus,flags,tag", [("hamlet.v2", [], "is"), ("phrases15k", [], "is"), ("zipf20k", [], "is"), ("zipf20k", ["-T", "1"], "isT1")])
+def test_cli_flexgrams_from_skipgrams(tmp_path, corpus, flags, tag):
+    """-F S (implies -s): the model gains the flexgrams its skipgrams abstract to (reference computeflexgrams_fromskipgrams,
+    include/patternmodel.h:3724-3744; goldens = the reference's own output where its loop stayed stable). The written model is loaded
+    back by the real reference."""
+    import oracle
+    model = str(tmp_path / "m.colibri.patternmodel")
+    data = os.path.join(GOLDEN, corpus + ".colibri.dat")
+    out = subprocess.run([CLI, "-f", data, "-t", "2", "-l", "5", "-F", "S", "-o", model] + flags, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    want = oracle.parse_dump(open(os.path.join(GOLDEN, f"flex.{corpus}.{tag}.txt")).read(), indexed=True)
+    before = oracle.parse_dump(open(os.path.join(GOLDEN, f"{corpus}.{tag}.l5.txt")).read(), indexed=True)
+    assert f"{len(want) - len(before)} flexgrams found" in out.stderr
+    mtype, tokens, types, counts, refs = parse_model(model)
+    assert (mtype, tokens, types) == (20, want.tokens, want.types)
+    assert counts == want.counts and refs == want.refs
+    if oracle.have_ref():
+        dump = str(tmp_path / "d.txt")
+        subprocess.check_call([oracle.REF_DRIVER, "load", model, "i", dump])
+        got = oracle.parse_dump(open(dump).read(), indexed=True)
+        assert (got.tokens, got.types, got.counts, got.refs) == (want.tokens, want.types, want.counts, want.refs)
+
+
+def test_cli_flexgrams_need_a_fresh_build():
+    out = subprocess.run([CLI, "-i", os.path.join(GOLDEN, "hamlet.v1.colibri.patternmodel"), "-F", "S"], capture_output=True, text=True)
+    assert out.returncode == 2 and "-F S on a loaded model" in out.stderr
 
 
 @pytest.mark.gpu

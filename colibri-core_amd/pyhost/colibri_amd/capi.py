@@ -270,6 +270,8 @@ class HipShardEngine:
         self.ctx._check(self.L.colibri_shard_begin(self.ctx.h, C.byref(opt), world))
         self.ctx.indexed = False  # exports of a sharded run go through export_local()
         self.indexed = bool(opt.indexed)
+        self.doskipgrams = bool(opt.doskipgrams)
+        self.use_aux = False
 
     # -- order 1 on class-indexed arrays (dense all-reduce instead of a key exchange) -----------------
     def uni_info(self):
@@ -294,21 +296,24 @@ class HipShardEngine:
         per = np.zeros(self.world, dtype=np.uint64)
         self.ctx._check(self.L.colibri_shard_count(self.ctx.h, n, mask, level, C.byref(nc), per.ctypes.data))
         self.ncand = int(nc.value)
+        # the distinct-source counts only travel in the skipgram passes of indexed models (colibri_shard_count: use_aux); every rank
+        # derives this from the same options, so all ranks agree on whether the third buffer is exchanged
+        self.use_aux = bool(mask) and self.doskipgrams
         return self.ncand, [int(x) for x in per]
 
     def send_buffers(self):
         t = self.torch
         keys = t.empty(max(1, self.ncand), dtype=t.int64, device=self.device)
         cnts = t.empty(max(1, self.ncand), dtype=t.int32, device=self.device)
-        aux = t.empty(max(1, self.ncand), dtype=t.int32, device=self.device)
-        self.ctx._check(self.L.colibri_shard_send(self.ctx.h, C.c_void_p(keys.data_ptr()), C.c_void_p(cnts.data_ptr()), C.c_void_p(aux.data_ptr())))
-        return keys[: self.ncand], cnts[: self.ncand], aux[: self.ncand]
+        aux = t.empty(max(1, self.ncand), dtype=t.int32, device=self.device) if self.use_aux else None
+        self.ctx._check(self.L.colibri_shard_send(self.ctx.h, C.c_void_p(keys.data_ptr()), C.c_void_p(cnts.data_ptr()), C.c_void_p(aux.data_ptr()) if self.use_aux else None))
+        return keys[: self.ncand], cnts[: self.ncand], (aux[: self.ncand] if self.use_aux else None)
 
     def merge(self, keys, cnts, aux, per_src):
         per = np.asarray(per_src, dtype=np.uint64)
         f, k = C.c_uint64(), C.c_uint64()
         self.nrecv = int(per.sum())
-        self.ctx._check(self.L.colibri_shard_merge(self.ctx.h, C.c_void_p(keys.data_ptr()), C.c_void_p(cnts.data_ptr()), C.c_void_p(aux.data_ptr()), per.ctypes.data,
+        self.ctx._check(self.L.colibri_shard_merge(self.ctx.h, C.c_void_p(keys.data_ptr()), C.c_void_p(cnts.data_ptr()), C.c_void_p(aux.data_ptr()) if aux is not None else None, per.ctypes.data,
                                                    C.byref(f), C.byref(k)))
         return int(f.value), int(k.value)
 

@@ -98,7 +98,7 @@ class ShardedTrainer:
         keys, cnts, aux = eng.send_buffers()
         rkeys = self._all_to_all_v(keys, per_owner, recv_sizes)
         rcnts = self._all_to_all_v(cnts, per_owner, recv_sizes)
-        raux = self._all_to_all_v(aux, per_owner, recv_sizes)
+        raux = self._all_to_all_v(aux, per_owner, recv_sizes) if aux is not None else None  # distinct-source counts: indexed skipgram passes only
         found, kept = eng.merge(rkeys, rcnts, raux, recv_sizes)
         everyone = self._all_gather_ints([found, kept])
         found_all, kept_all = sum(v[0] for v in everyone), sum(v[1] for v in everyone)

@@ -91,3 +91,24 @@ def test_merge_exports_concatenates_in_rank_order():
     for n in range(3, 9):
         assert gap_masks(n, 3) == oracle.skip_configurations(n, 3)
     assert mask_parts(0b01010, 5) == [(0, 1), (2, 1), (4, 1)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 5, 8])
+def test_hip_shard_engine_ranks_as_threads(world):
+    """`world` ranks as threads of one process, each with its own device context on cuda:0, exchanging through an in-process stand-in
+    for the process group with device tensors (no host staging): the same buffers RCCL would move (tools/fuzz_sharded.py)."""
+    import numpy as np
+    import oracle
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from colibri_amd import capi
+    from colibri_amd import dist as cdist
+    from fuzz_parity import make_corpus
+    from fuzz_sharded import run_case
+    for case in range(12):
+        rng = np.random.default_rng(977 * world + case)
+        payload = make_corpus(rng)
+        mode = case % 4
+        o = dict(mintokens=2 + case % 2, maxlength=5, indexed=int(mode in (2, 3)), doskipgrams=int(mode == 3), doskipgrams_exhaustive=int(mode == 1))
+        assert run_case(case, world, payload, o, capi, oracle, torch, cdist) is None

@@ -86,6 +86,7 @@ struct TrainResult {
     std::vector<uint64_t>      ref_off;
     std::vector<uint32_t>      ref_sentence;
     std::vector<uint16_t>      ref_token;
+    std::shared_ptr<void>      device;  ///< (optional) the device context that still holds this model in HBM, for follow-up passes that need no host round trip
     size_t                     size() const { return counts.size(); }
 };
 
@@ -100,10 +101,13 @@ struct ConstraintKeys {
     std::vector<unsigned char> bytes;
 };
 /** upload + train + export through the C ABI; prints the library's message on stderr and throws InternalError on any status != 0 */
-void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out, const ConstraintKeys* constraint = NULL);
+void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out, const ConstraintKeys* constraint = NULL,
+                  bool keep_device = false);
 /** flexgrams abstracted from the skipgrams of an indexed model given in export layout (colibri_flexgrams + colibri_flexgrams_fetch) */
 void device_flexgrams(const std::vector<uint64_t>& key_off, const unsigned char* key_bytes, const std::vector<uint64_t>& ref_off, const uint32_t* ref_sentence,
                       const uint16_t* ref_token, TrainResult& out);
+/** the same on the model a device_train(..., keep_device = true) left resident (colibri_flexgrams_resident) */
+void device_flexgrams_resident(const std::shared_ptr<void>& device, TrainResult& out);
 /** the per-order progress lines the reference prints while training (patternmodel.h:1005-1019, :1195-1245) */
 void print_training_log(const colibri_stats& s, const colibri_options& o, std::ostream& err);
 /** the tokens of a key as byte strings, gaps included (what the reference's pattern.ngrams(…, 1) yields, src/pattern.cpp:1284-1296) */
@@ -328,15 +332,17 @@ class PatternModel : public MapType, public PatternModelInterface {
         o.indexed                = colibri_host::is_indexed_value<ValueType>::value ? 1 : 0;
 
         std::shared_ptr<colibri_host::TrainResult> r = std::make_shared<colibri_host::TrainResult>();
+        // an indexed skipgram model stays resident on the device until it is materialised on the host: computeflexgrams_fromskipgrams works on it there
+        const bool keep_device = o.indexed && o.doskipgrams && constrainbymodel == NULL && options.MINLENGTH <= 1;
         if (reverseindex != NULL && !reverseindex->empty()) {
-            colibri_host::device_train(reverseindex->beginpointer(), reverseindex->bytesize(), o, firstsentence, *r, constrainbymodel ? &ck : NULL);
+            colibri_host::device_train(reverseindex->beginpointer(), reverseindex->bytesize(), o, firstsentence, *r, constrainbymodel ? &ck : NULL, keep_device);
         } else if (in != NULL) {
             const std::vector<unsigned char> payload = colibri_host::read_corpus_payload(*in);
             if (payload.empty()) {
                 std::cerr << "ERROR: Attempting to read pattern from file, but file is empty?" << std::endl;  // reference src/pattern.cpp:520-523
                 throw InternalError();
             }
-            colibri_host::device_train(payload.data(), payload.size(), o, firstsentence, *r, constrainbymodel ? &ck : NULL);
+            colibri_host::device_train(payload.data(), payload.size(), o, firstsentence, *r, constrainbymodel ? &ck : NULL, keep_device);
         } else {
             std::cerr << "ERROR: No input stream and no reverse index (preloaded corpus) to train on" << std::endl;
             throw InternalError();
@@ -835,7 +841,10 @@ class IndexedPatternModel : public PatternModel<IndexedData, IndexedDataHandler,
      *  (colibri_flexgrams); each flexgram's new references arrive ascending. @return the number of flexgrams that were not in the model */
     int computeflexgrams_fromskipgrams() override {
         colibri_host::TrainResult flex;
-        if (this->result) {  // device results not materialised yet: their flat arrays are the input
+        if (this->result && this->result->device) {  // the model is still in HBM: group and merge there, only the flexgrams come back
+            colibri_host::device_flexgrams_resident(this->result->device, flex);
+            this->result->device.reset();
+        } else if (this->result) {  // device results not materialised yet: their flat arrays are the input
             std::shared_ptr<colibri_host::TrainResult> r = this->result;
             colibri_host::device_flexgrams(r->key_off, r->key_bytes.data(), r->ref_off, r->ref_sentence.data(), r->ref_token.data(), flex);
         } else {

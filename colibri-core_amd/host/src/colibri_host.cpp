@@ -338,7 +338,30 @@ struct CtxGuard {
 }
 }  // namespace
 
-void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out, const ConstraintKeys* constraint) {
+namespace {
+void fetch_flexgrams(colibri_ctx* c, uint64_t nf, uint64_t kb, uint64_t nr, TrainResult& out) {
+    out.key_off.assign(nf + 1, 0);
+    out.key_bytes.assign(kb + 1, 0);
+    out.counts.assign(nf + 1, 0);
+    out.ref_off.assign(nf + 1, 0);
+    out.ref_sentence.assign(nr + 1, 0);
+    out.ref_token.assign(nr + 1, 0);
+    const int rc = colibri_flexgrams_fetch(c, out.key_off.data(), out.key_bytes.data(), out.counts.data(), out.ref_off.data(), out.ref_sentence.data(), out.ref_token.data());
+    if (rc != COLIBRI_OK) raise(c, rc, "colibri_flexgrams_fetch");
+    out.counts.resize(nf);
+}
+}  // namespace
+
+void device_flexgrams_resident(const std::shared_ptr<void>& device, TrainResult& out) {
+    colibri_ctx* c  = static_cast<colibri_ctx*>(device.get());
+    uint64_t     nf = 0, kb = 0, nr = 0;
+    const int    rc = colibri_flexgrams_resident(c, &nf, &kb, &nr);
+    if (rc != COLIBRI_OK) raise(c, rc, "colibri_flexgrams_resident");
+    fetch_flexgrams(c, nf, kb, nr, out);
+}
+
+void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out, const ConstraintKeys* constraint,
+                  bool keep_device) {
     CtxGuard    g;
     const char* dev = std::getenv("COLIBRI_DEVICE");
     int         rc  = colibri_create(&g.c, dev ? std::atoi(dev) : 0);
@@ -375,6 +398,10 @@ void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_o
         out.ref_token.assign(nr + 1, 0);
         rc = colibri_export_indexed(g.c, out.key_off.data(), out.key_bytes.data(), out.counts.data(), out.ref_off.data(), out.ref_sentence.data(), out.ref_token.data());
         if (rc != COLIBRI_OK) raise(g.c, rc, "colibri_export_indexed");
+        if (keep_device) {  // the caller may follow up on the resident model (computeflexgrams_fromskipgrams); released with the pending result
+            out.device = std::shared_ptr<void>(g.c, [](void* p) { colibri_destroy(static_cast<colibri_ctx*>(p)); });
+            g.c        = nullptr;
+        }
     } else {
         uint32_t dummy = 0;
         rc = colibri_export_unindexed(g.c, out.key_off.data(), out.key_bytes.data(), np ? out.counts.data() : &dummy);
@@ -393,15 +420,7 @@ void device_flexgrams(const std::vector<uint64_t>& key_off, const unsigned char*
     static const unsigned char none = 0;
     if ((rc = colibri_flexgrams(g.c, key_off.data(), key_bytes ? key_bytes : &none, ref_off.data(), ref_sentence, ref_token, np, &nf, &kb, &nr)) != COLIBRI_OK)
         raise(g.c, rc, "colibri_flexgrams");
-    out.key_off.assign(nf + 1, 0);
-    out.key_bytes.assign(kb + 1, 0);
-    out.counts.assign(nf + 1, 0);
-    out.ref_off.assign(nf + 1, 0);
-    out.ref_sentence.assign(nr + 1, 0);
-    out.ref_token.assign(nr + 1, 0);
-    if ((rc = colibri_flexgrams_fetch(g.c, out.key_off.data(), out.key_bytes.data(), out.counts.data(), out.ref_off.data(), out.ref_sentence.data(), out.ref_token.data())) != COLIBRI_OK)
-        raise(g.c, rc, "colibri_flexgrams_fetch");
-    out.counts.resize(nf);
+    fetch_flexgrams(g.c, nf, kb, nr, out);
 }
 
 void drop_short_patterns(TrainResult& r, int minlength) {

@@ -24,7 +24,7 @@ EXPORTED = [
     "colibri_shard_finish", "colibri_shard_export_gids", "colibri_shard_index_sizes", "colibri_shard_export_index",
     "colibri_shard_uni_info", "colibri_shard_uni_count", "colibri_shard_uni_apply",
     "colibri_set_constraint", "colibri_text_upload", "colibri_text_count", "colibri_text_words", "colibri_text_encode", "colibri_text_fetch", "colibri_text_as_corpus",
-    "colibri_flexgrams", "colibri_flexgrams_fetch",
+    "colibri_flexgrams", "colibri_flexgrams_resident", "colibri_flexgrams_fetch",
 ]
 
 
@@ -85,6 +85,7 @@ def load():
         L.colibri_text_as_corpus.argtypes = [C.c_void_p, C.c_uint32]
         L.colibri_flexgrams.argtypes = [C.c_void_p] * 6 + [C.c_uint64] + [C.POINTER(C.c_uint64)] * 3
         L.colibri_flexgrams_fetch.argtypes = [C.c_void_p] * 7
+        L.colibri_flexgrams_resident.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 3
         L.colibri_upload_corpus.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
         L.colibri_upload_corpus_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
         L.colibri_corpus_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 3
@@ -223,7 +224,15 @@ class Context:
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._check(self.L.colibri_flexgrams(self.h, key_off.ctypes.data, kb_in.ctypes.data, ref_off.ctypes.data, rs_in.ctypes.data, rt_in.ctypes.data, npat,
                                              C.byref(a), C.byref(b), C.byref(c)))
-        nf, kb, nr = a.value, b.value, c.value
+        return self._flexgrams_fetch(a.value, b.value, c.value)
+
+    def flexgrams_resident(self):
+        """colibri_flexgrams_resident: the same on the indexed model of the last train() of this context, without leaving the device."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.L.colibri_flexgrams_resident(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return self._flexgrams_fetch(a.value, b.value, c.value)
+
+    def _flexgrams_fetch(self, nf, kb, nr):
         fo = np.zeros(nf + 1, dtype=np.uint64)
         fk = np.zeros(max(1, kb), dtype=np.uint8)
         fc = np.zeros(max(1, nf), dtype=np.uint32)

@@ -220,6 +220,10 @@ int colibri_text_as_corpus(colibri_ctx* ctx, uint32_t first_sentence);          
  * (key_off / ref_off: nflexgrams + 1 entries). */
 int colibri_flexgrams(colibri_ctx* ctx, const uint64_t* key_off, const uint8_t* key_bytes, const uint64_t* ref_off, const uint32_t* ref_sentence, const uint16_t* ref_token,
                       uint64_t npatterns, uint64_t* nflexgrams, uint64_t* keybytes, uint64_t* nrefs);
+/* The same on the indexed model of the last colibri_train of this context, which is still resident in HBM (keys, counts and the forward
+ * index never leave the device; only the flexgrams come back through colibri_flexgrams_fetch). COLIBRI_ERR_STATE unless the context holds
+ * a trained indexed model of a non-sharded run. */
+int colibri_flexgrams_resident(colibri_ctx* ctx, uint64_t* nflexgrams, uint64_t* keybytes, uint64_t* nrefs);
 int colibri_flexgrams_fetch(colibri_ctx* ctx, uint64_t* key_off, uint8_t* key_bytes, uint32_t* counts, uint64_t* ref_off, uint32_t* ref_sentence, uint16_t* ref_token);
 
 #ifdef __cplusplus

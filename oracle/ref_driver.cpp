@@ -301,7 +301,17 @@ int main(int argc, char** argv) {
         t0 = clk::now();
         model.train(corpusfile, options, constrain);
         train_s = std::chrono::duration<double>(clk::now() - t0).count();
-        if (flexfromskip) std::cerr << "flexgrams " << model.computeflexgrams_fromskipgrams() << std::endl;
+        if (flexfromskip) {
+            const size_t before = model.size();
+            uint64_t     skiprefs = 0;
+            for (auto it = model.begin(); it != model.end(); ++it)
+                if (it->first.category() == SKIPGRAM) skiprefs += it->second.count();
+            t0 = clk::now();
+            const int found = model.computeflexgrams_fromskipgrams();
+            const double flex_s = std::chrono::duration<double>(clk::now() - t0).count();
+            std::cerr << "flexgrams " << found << std::endl;
+            std::cerr << "flexgram_timing {\"patterns_before\": " << before << ", \"skipgram_refs\": " << skiprefs << ", \"flexgrams\": " << found << ", \"seconds\": " << flex_s << "}" << std::endl;
+        }
         tokens = model.tokens();
         types  = model.types();
         if (!modelout.empty()) model.write(modelout);

@@ -112,6 +112,21 @@ def test_device_flexgrams_after_device_training(ctx, corpus, maxlength, minskipt
     got = {kb[off[j]: off[j + 1]]: list(zip(frs[ro[j]: ro[j + 1]].tolist(), frt[ro[j]: ro[j + 1]].tolist())) for j in range(len(fc))}
     assert got == _flex_only(want) and len(got) == found
     assert fc.tolist() == [len(got[kb[off[j]: off[j + 1]]]) for j in range(len(fc))]
+    # the same without the host round trip: on the model still resident in HBM
+    ro, rk, rc, (rro, rrs, rrt) = ctx.flexgrams_resident()
+    assert (ro.tolist(), rk.tobytes(), rc.tolist(), rro.tolist(), rrs.tolist(), rrt.tolist()) == (fo.tolist(), fk.tobytes(), fc.tolist(), fro.tolist(), frs.tolist(), frt.tolist())
+
+
+@pytest.mark.gpu
+def test_resident_flexgrams_need_an_indexed_model(ctx):
+    from colibri_amd import capi
+    ctx.upload(small_corpora()["rand1"])
+    ctx.train(mintokens=2, maxlength=5)
+    with pytest.raises(capi.ColibriError):
+        ctx.flexgrams_resident()
+    ctx.train(mintokens=2, maxlength=5, indexed=1)  # indexed, no skipgrams: nothing to abstract
+    fo, fk, fc, _ = ctx.flexgrams_resident()
+    assert fc.size == 0 and fo.tolist() == [0]
 
 
 @pytest.mark.gpu

@@ -83,6 +83,7 @@ def load():
         L.colibri_text_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.colibri_text_fetch.argtypes = [C.c_void_p, C.c_void_p]
         L.colibri_text_as_corpus.argtypes = [C.c_void_p, C.c_uint32]
+        L.colibri_set_constraint.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.colibri_flexgrams.argtypes = [C.c_void_p] * 6 + [C.c_uint64] + [C.POINTER(C.c_uint64)] * 3
         L.colibri_flexgrams_fetch.argtypes = [C.c_void_p] * 7
         L.colibri_flexgrams_resident.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 3
@@ -167,6 +168,14 @@ class Context:
         n = C.c_uint64()
         self._check(self.L.colibri_positions(self.h, C.byref(n)))
         return n.value
+
+    def set_constraint(self, keys):
+        """colibri_set_constraint: the next train() calls only count patterns whose key bytes are in `keys` (an empty list lifts it)."""
+        keys = list(keys)
+        off = np.zeros(len(keys) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(k) for k in keys])
+        blob = np.frombuffer(b"".join(keys) or b"\0", dtype=np.uint8)
+        self._check(self.L.colibri_set_constraint(self.h, off.ctypes.data, blob.ctypes.data, len(keys)))
 
     # -- training --------------------------------------------------------------------------------
     def train(self, options=None, **kw):

@@ -196,6 +196,44 @@ def ref_train(corpus_path: str, mode: str, maxlength: int, mintokens: int, *, mi
     return model, info
 
 
+# ---- constrained training ------------------------------------------------------------------------------------------
+def train_constrained(payload: bytes, constraint, mintokens=2, maxlength=100, minlength=1, indexed=False, firstsentence=1) -> "Model":
+    """PatternModel::train(..., constrainbymodel) restated (reference include/patternmodel.h:1062-1072: every n-gram of every length
+    MINLENGTH..MAXLENGTH of every sentence in ONE pass; :1088-1089: counted iff the constraint model has it, no look-back; :1209-1217:
+    prune(MINTOKENS) regardless of size). `constraint` = the key bytes of the constraint model's patterns. Pure Python: small inputs.
+    tokens = the corpus' tokens, types = 0 (what the C ABI reports; the totals quirks of the reference are the C++ face's)."""
+    constraint = set(constraint)
+    thr = 2 if mintokens == -1 else max(1, mintokens)
+    counts, refs = {}, {}
+    sentence, tokens = firstsentence - 1, 0
+    toks, start, prevhigh = [], 0, False
+    sentences = []
+    for j, b in enumerate(payload):
+        if b >= 128:
+            continue
+        tok = payload[start:j + 1]
+        start = j + 1
+        if tok == b"\x00":
+            sentences.append(toks)
+            toks = []
+        else:
+            toks.append(tok)
+    if toks:
+        sentences.append(toks)
+    for toks in sentences:
+        sentence += 1
+        tokens += len(toks)
+        for n in range(max(1, minlength), min(maxlength, len(toks)) + 1):
+            for i in range(len(toks) - n + 1):
+                k = b"".join(toks[i:i + n])
+                if k in constraint:
+                    counts[k] = counts.get(k, 0) + 1
+                    if indexed:
+                        refs.setdefault(k, []).append((sentence, i))
+    counts = {k: c for k, c in counts.items() if c >= thr}
+    return Model(tokens, 0, counts, {k: sorted(refs[k]) for k in counts} if indexed else None)
+
+
 # ---- flexgrams from skipgrams (SURVEY §8 f-4) ---------------------------------------------------------------------------------------
 def key_tokens(key: bytes):
     """The tokens of a pattern key (each a varint: bytes >= 128 continue, a byte < 128 ends the token)."""

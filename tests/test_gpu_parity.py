@@ -199,3 +199,48 @@ def test_indexed_skipgrams_match_oracle(ctx, name, extra):
 def test_indexed_skipgrams_hamlet_known_answer(ctx, hamlet_payload):
     st = _compare(ctx, hamlet_payload, 100, mintokens=-1, indexed=1, doskipgrams=1)
     assert st.npatterns == 133  # reference src/test.cpp:1327-1337, test.py:289
+
+
+# ---- constrained training through the C ABI: colibri_set_constraint + colibri_train against oracle.train_constrained ----
+def _random_constraint(rng, payload, maxlength):
+    """a pattern set that partly overlaps the corpus: some of its own n-grams, some n-grams it does not contain, some junk"""
+    import oracle
+    toks = [t for t in oracle.key_tokens(payload) if t != b"\x00"]
+    keys = set()
+    for _ in range(int(rng.integers(0, 400))):
+        n = int(rng.integers(1, maxlength + 2))
+        if toks and rng.random() < 0.8:
+            i = int(rng.integers(0, len(toks)))
+            keys.add(b"".join(toks[i:i + n]))
+        else:
+            keys.add(bytes(int(x) for x in rng.integers(6, 40, size=n)))
+    keys.discard(b"")
+    if not keys:
+        keys.add(b"\x06")  # an empty set LIFTS the constraint at the C ABI (the C++ face handles the empty model itself)
+    return sorted(keys)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_constrained_training_matches_the_restatement(ctx, seed):
+    import oracle
+    rng = np.random.default_rng(5150 + seed)
+    corpora = small_corpora()
+    name = sorted(corpora)[seed % len(corpora)]
+    payload = corpora[name]
+    maxlength = int(rng.choice([1, 3, 5, 8]))
+    minlength = int(rng.integers(1, maxlength + 1))
+    mintokens = int(rng.choice([1, 1, 2, 3]))
+    indexed = bool(seed % 2)
+    keys = _random_constraint(rng, payload, maxlength)
+    want = oracle.train_constrained(payload, keys, mintokens, maxlength, minlength, indexed=indexed, firstsentence=1 + seed % 3)
+    ctx.upload(payload, first_sentence=1 + seed % 3)
+    try:
+        ctx.set_constraint(keys)
+        st = ctx.train(mintokens=mintokens, maxlength=maxlength, minlength=minlength, indexed=int(indexed))
+        got, gotrefs = ctx.export_dict()
+    finally:
+        ctx.set_constraint([])
+    assert got == want.counts, name
+    if indexed:
+        assert gotrefs == want.refs
+    assert st.totaltokens == want.tokens and st.npatterns == len(want)

@@ -158,3 +158,52 @@ def test_indexed_skipgrams_reference_hazard_documented(tmp_path):
         assert any(len(set(r)) != len(r) for r in want.refs.values()), "reference differs without duplicate refs: not the known hazard"
     ngr = {k: v for k, v in got.counts.items() if 3 not in k}
     assert ngr == {k: v for k, v in want.counts.items() if 3 not in k}
+
+
+# ---- constrained training: the restatement against the real reference's dumps ------------------------------------------
+def _model_keys(path, mincount=1):
+    """key bytes of every pattern of a .colibri.patternmodel (v2) file that occurs at least `mincount` times"""
+    import struct
+    raw = open(path, "rb").read()
+    mtype = raw[1]
+    npat = struct.unpack_from("<Q", raw, 19)[0]
+    pos, keys = 27, []
+    for _ in range(npat):
+        start, prevhigh = pos, False
+        while prevhigh or raw[pos] != 0:
+            prevhigh = raw[pos] >= 128
+            pos += 1
+        (c,) = struct.unpack_from("<I", raw, pos + 1)
+        if c >= mincount:
+            keys.append(raw[start:pos])
+        pos += 5 + (6 * c if mtype == 20 else 0)
+    return keys
+
+
+CONSTRAINED_GOLDENS = {  # tag -> (corpus, constraint model, indexed, mintokens, maxlength, minlength)
+    "j_zipf.u.t1": ("phrases15k", "constraint.zipf20k.u.l5.patternmodel", False, 1, 4, 1),
+    "j_zipf.u.t2": ("phrases15k", "constraint.zipf20k.u.l5.patternmodel", False, 2, 4, 1),
+    "j_zipf.u.t3": ("phrases15k", "constraint.zipf20k.u.l5.patternmodel", False, 3, 5, 1),
+    "j_zipf.u.t1m2": ("phrases15k", "constraint.zipf20k.u.l5.patternmodel", False, 1, 4, 2),
+    "j_zipf.i.t1": ("phrases15k", "constraint.zipf20k.u.l5.patternmodel", True, 1, 4, 1),
+    "j_zipf.i.t2": ("phrases15k", "constraint.zipf20k.u.l5.patternmodel", True, 2, 5, 1),
+    "j_hamlet.u.t1": ("edge", "constraint.hamlet.i.l5.patternmodel", False, 1, 5, 1),
+    "j_self.u.t2": ("zipf20k", "constraint.zipf20k.u.l5.patternmodel", False, 2, 5, 1),
+    "I_zipf.u.t2": ("phrases15k", "constraint.zipf20k.u.l5.patternmodel", False, 2, 5, 1),
+    "I_zipf.i.t1": ("phrases15k", "constraint.zipf20k.u.l5.patternmodel", True, 1, 5, 1),
+    "I_self.i.t2": ("hamlet.v2", "constraint.hamlet.i.l5.patternmodel", True, 2, 5, 1),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(CONSTRAINED_GOLDENS))
+def test_constrained_restatement_matches_reference_dumps(tag):
+    """oracle.train_constrained against ref_driver train ... -j / -I (pattern set, counts, reference lists; the totals are the C++ face's)"""
+    import oracle
+    corpus, cmodel, indexed, mintokens, maxlength, minlength = CONSTRAINED_GOLDENS[tag]
+    payload = open(os.path.join(GOLDEN, corpus + ".colibri.dat"), "rb").read()[2:]
+    want = oracle.parse_dump(open(os.path.join(GOLDEN, f"constrained.{tag}.txt")).read(), indexed=indexed)
+    # the constraint model is loaded under the run's own options (src/patternmodeller.cpp:712-718): its patterns below MINTOKENS are not read
+    got = oracle.train_constrained(payload, _model_keys(os.path.join(GOLDEN, cmodel), mintokens), mintokens, maxlength, minlength, indexed=indexed)
+    assert got.counts == want.counts
+    if indexed:
+        assert got.refs == want.refs

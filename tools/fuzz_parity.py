@@ -43,7 +43,7 @@ def make_corpus(rng):
 
 
 def make_options(rng):
-    mode = int(rng.integers(0, 5))  # 0 plain, 1 exhaustive skipgrams, 2 indexed, 3 indexed + skipgrams, 4 plain with word threshold / threshold 1
+    mode = int(rng.integers(0, 6))  # 0 plain, 1 exhaustive skipgrams, 2 indexed, 3 indexed + skipgrams, 4 plain with word threshold / threshold 1, 5 constrained
     o = dict(mintokens=int(rng.choice([2, 2, 2, 3, 5])), maxlength=int(rng.choice([1, 2, 3, 4, 5, 5, 6, 8])), indexed=0, doskipgrams=0, doskipgrams_exhaustive=0)
     if mode == 1:
         o["doskipgrams_exhaustive"] = 1
@@ -63,10 +63,31 @@ def make_options(rng):
         else:
             o["mintokens_unigrams"] = o["mintokens"] + int(rng.integers(1, 4))
         o["indexed"] = int(rng.integers(0, 2))
+    elif mode == 5:
+        o["constrained"] = 1
+        o["mintokens"] = int(rng.choice([1, 1, 2, 3]))
+        o["minlength"] = int(rng.integers(1, o["maxlength"] + 1))
+        o["indexed"] = int(rng.integers(0, 2))
     if mode in (1, 3):
         o["maxlength"] = min(o["maxlength"], 6)
     o["table_mode"] = int(rng.choice([0, 0, 0, 1, 2])) if mode == 0 else 0
     return o
+
+
+def random_constraint(rng, payload, maxlength, oracle):
+    toks = [t for t in oracle.key_tokens(payload) if t != b"\x00"]
+    keys = set()
+    for _ in range(int(rng.integers(0, 600))):
+        n = int(rng.integers(1, maxlength + 2))
+        if toks and rng.random() < 0.8:
+            i = int(rng.integers(0, len(toks)))
+            keys.add(b"".join(toks[i:i + n]))
+        else:
+            keys.add(bytes(int(x) for x in rng.integers(6, 40, size=n)))
+    keys.discard(b"")
+    if not keys:
+        keys.add(b"\x06")  # an empty set LIFTS the constraint at the C ABI (the C++ face handles the empty model itself)
+    return sorted(keys)
 
 
 def main():
@@ -86,6 +107,22 @@ def main():
         case += 1
         try:
             ctx.upload(payload)
+            if o.pop("constrained", 0):
+                if len(payload) > 60000:
+                    payload = payload[:60000]
+                    ctx.upload(payload)
+                keys = random_constraint(rng, payload, o["maxlength"], oracle)
+                want = oracle.train_constrained(payload, keys, o["mintokens"], o["maxlength"], o["minlength"], indexed=bool(o["indexed"]))
+                try:
+                    ctx.set_constraint(keys)
+                    st = ctx.train(capi.Options.defaults(**o))
+                    cd, rd = ctx.export_dict()
+                finally:
+                    ctx.set_constraint([])
+                if not (cd == want.counts and (rd is None or rd == want.refs) and int(st.totaltokens) == want.tokens):
+                    failures.append({"seed": seed, "options": o, "constrained": len(keys), "bytes": len(payload), "got": len(cd), "want": len(want.counts)})
+                by_mode["constrained"] = by_mode.get("constrained", 0) + 1
+                continue
             st = ctx.train(capi.Options.defaults(**o))
             cd, rd = ctx.export_dict()
             oo = {k: v for k, v in o.items() if k != "table_mode"}

@@ -218,6 +218,8 @@ class PatternModel : public MapType, public PatternModelInterface {
     bool          hasskipgrams() const { return hasskipgrams_; }
     /** does nothing for unindexed models (reference :2653-2655); IndexedPatternModel abstracts its skipgrams on the device */
     virtual int computeflexgrams_fromskipgrams() { return 0; }
+    /** does nothing for unindexed models (reference :2628) */
+    virtual void outputrelations(const Pattern&, const ClassDecoder&, std::ostream&, const std::string& = "", bool = true) {}
     /** what the reference's constrained in-place rebuild leaves in the type count: the number of patterns the model was loaded with
      *  (it takes "total word types prior to pruning" from a map that already holds every pattern, patternmodel.h:1197-1201) */
     void settypes_inplace_rebuild() { totaltypes = this->size(); }
@@ -804,6 +806,9 @@ class PatternSetModel : public PatternModel<uint32_t> {
     int getmodeltype() const override { return PATTERNSETMODEL; }
 };
 
+/** pattern -> relation count (reference include/patternmodel.h:220) */
+typedef PatternMap<uint32_t> t_relationmap;
+
 /** Indexed model: pattern -> sorted list of (sentence, token). reference include/patternmodel.h:2682-3875. */
 template <class MapType = PatternMap<IndexedData>>
 class IndexedPatternModel : public PatternModel<IndexedData, IndexedDataHandler, MapType> {
@@ -835,7 +840,139 @@ class IndexedPatternModel : public PatternModel<IndexedData, IndexedDataHandler,
     }
     void coverage_finish() override { covered_.clear(); }
 
+    // (length, gap mask) of every skipgram in the model, by length: what the reference's matchskipgramhelper (:1722-1744) is used for — a
+    // skipgram of the model can only match a window if its first word is the window's, so testing every mask of that length with has() finds the same set
+    std::map<int, std::vector<uint32_t>> skipmasks_;
+    size_t                                skipmasks_size_ = (size_t)-1;
+    void compute_skipmasks() {
+        if (skipmasks_size_ == this->size()) return;
+        skipmasks_.clear();
+        std::set<std::pair<int, uint32_t>> seen;
+        for (typename MapType::iterator it = this->begin(); it != this->end(); ++it) {
+            if (it->first.category() != SKIPGRAM) continue;
+            std::vector<std::string> toks;
+            colibri_host::token_slices(it->first.data, it->first.bytesize(), toks);
+            uint32_t mask = 0;
+            for (size_t k = 0; k < toks.size() && k < 31; ++k)
+                if (toks[k].size() == 1 && (unsigned char)toks[k][0] == colibri_classes::skipclass) mask |= (1u << k);
+            if (seen.insert(std::make_pair((int)toks.size(), mask)).second) skipmasks_[(int)toks.size()].push_back(mask);
+        }
+        skipmasks_size_ = this->size();
+    }
+    void need_reverseindex() const {
+        if (this->reverseindex == NULL || this->reverseindex->empty()) {
+            std::cerr << "ERROR: No reverse index present" << std::endl;
+            throw InternalError();
+        }
+    }
+    static void prunerelations(t_relationmap& relations, unsigned int occurrencethreshold) {  // reference :3066-3078
+        for (t_relationmap::iterator it = relations.begin(); it != relations.end();) {
+            if (it->second < occurrencethreshold) it = relations.erase(it);
+            else ++it;
+        }
+    }
+
   public:
+    /** The skip content of a skipgram (or flexgram): for every occurrence, the tokens of the corpus from the pattern's first gap to its last
+     *  gap, as a plain n-gram — the slice drops the mask (reference :3029-3059; src/pattern.cpp:853-855). Plain host code over the forward
+     *  index and the loaded corpus, as in the reference: a per-pattern query, not a corpus pass. */
+    t_relationmap getskipcontent(const Pattern& pattern) {
+        t_relationmap skipcontent;
+        if (this->reverseindex == NULL) {
+            std::cerr << "ERROR: No corpus data loaded! (in PatternModel::getskipcontent)" << std::endl;
+            throw InternalError();
+        }
+        if (pattern.category() == NGRAM) return skipcontent;
+        IndexedData* data = this->getdata(pattern);
+        if (data == NULL) throw NoSuchPattern();
+        std::vector<std::string> toks;
+        colibri_host::token_slices(pattern.data, pattern.bytesize(), toks);
+        const int n = (int)toks.size();
+        auto      isgap = [&](int k) { return toks[(size_t)k].size() == 1 && ((unsigned char)toks[(size_t)k][0] == colibri_classes::skipclass || (unsigned char)toks[(size_t)k][0] == colibri_classes::flexclass); };
+        int       head = 0, tail = 0;  // leading / trailing tokens that are no gaps (maskheadskip / masktailskip of the reversed mask, src/algorithms.cpp:56-77)
+        while (head < n && !isgap(head)) ++head;
+        while (tail < n - head && !isgap(n - tail - 1)) ++tail;
+        for (const IndexReference& ref : data->data) {
+            const PatternPointer     raw = this->reverseindex->getpattern(ref, n);
+            std::vector<std::string> w;
+            colibri_host::token_slices(raw.data, raw.bytesize(), w);
+            std::string content;
+            for (int k = head; k < n - tail; ++k) content += w[(size_t)k];
+            skipcontent[Pattern((const unsigned char*)content.data(), content.size())] += 1;
+        }
+        return skipcontent;
+    }
+    /** the n-grams of the model that instantiate the given skipgram / flexgram at its occurrences (reference :3127-3165 over getreverseindex
+     *  :1746-1824 with category NGRAM: the window of the pattern's own length at each occurrence, if the model has it) */
+    t_relationmap getinstances(const Pattern& pattern, unsigned int occurrencethreshold = 0) {
+        need_reverseindex();
+        IndexedData* data = this->getdata(pattern);
+        if (data == NULL) throw NoSuchPattern();
+        t_relationmap instances;
+        const int     n = (int)pattern.n();
+        if (n >= this->minlength() && n <= this->maxlength()) {
+            for (const IndexReference& ref : data->data) {
+                if (ref.token + (unsigned int)n > this->reverseindex->sentencelength((int)ref.sentence)) continue;
+                const Pattern candidate(this->reverseindex->getpattern(ref, n));
+                if (candidate.category() != NGRAM || candidate == pattern) continue;
+                if (occurrencethreshold == 0 ? !this->has(candidate) : this->occurrencecount(candidate) < occurrencethreshold) continue;
+                instances[candidate] += 1;
+            }
+        }
+        if (occurrencethreshold > 0) prunerelations(instances, occurrencethreshold);
+        return instances;
+    }
+    /** the skipgrams of the model that abstract over the given pattern at its occurrences (reference :3086-3118): every gap mask a skipgram
+     *  of this length has in the model, laid over the window at each occurrence */
+    t_relationmap gettemplates(const Pattern& pattern, unsigned int occurrencethreshold = 0) {
+        need_reverseindex();
+        IndexedData* data = this->getdata(pattern);
+        if (data == NULL) throw NoSuchPattern();
+        t_relationmap templates;
+        const int     n = (int)pattern.n();
+        if (this->hasskipgrams() && n >= 3 && n >= this->minlength() && n <= this->maxlength() &&
+            (occurrencethreshold == 0 || this->occurrencecount(pattern) >= occurrencethreshold)) {
+            compute_skipmasks();
+            const std::vector<uint32_t>& masks = skipmasks_[n];
+            for (const IndexReference& ref : data->data) {
+                if (ref.token + (unsigned int)n > this->reverseindex->sentencelength((int)ref.sentence)) continue;
+                PatternPointer window = this->reverseindex->getpattern(ref, n);
+                for (uint32_t mask : masks) {
+                    window.mask = mask;
+                    const Pattern candidate(window);
+                    if (candidate == pattern || candidate.category() != SKIPGRAM || !this->has(candidate)) continue;
+                    templates[candidate] += 1;
+                }
+            }
+        }
+        if (occurrencethreshold > 0) prunerelations(templates, occurrencethreshold);
+        return templates;
+    }
+    /** one row per related pattern (reference :3595-3609) */
+    void outputrelations(const Pattern& pattern, t_relationmap& relations, const ClassDecoder& classdecoder, std::ostream& OUT, const std::string& label = "RELATED-TO") {
+        int total = 0;
+        for (t_relationmap::iterator it = relations.begin(); it != relations.end(); ++it) total += (int)it->second;
+        if (total == 0) return;
+        const double      total_f   = total;
+        const std::string pattern_s = pattern.tostring(classdecoder);
+        for (t_relationmap::iterator it = relations.begin(); it != relations.end(); ++it)
+            OUT << "\t" << pattern_s << "\t" << label << "\t" << it->first.tostring(classdecoder) << "\t" << it->second << "\t" << it->second / total_f << "\t"
+                << this->occurrencecount(it->first) << std::endl;
+    }
+    /** the relations of a pattern selected by `filter` (reference :3622-3662). Built here: skipcontent. "instances" and "templates" print
+     *  nothing through this entry point in the reference either — its call with a PatternPointer resolves to the base class's empty
+     *  getinstances / gettemplates(const PatternPointer&) (:2635-2640), the working ones take a Pattern (used directly, src/test.cpp:1457) */
+    void outputrelations(const Pattern& pattern, const ClassDecoder& classdecoder, std::ostream& OUT, const std::string& filter = "", bool outputheader = true) override {
+        if (filter != "skipcontent" && filter != "instances" && filter != "templates") {
+            std::cerr << "ERROR: relation '" << (filter.empty() ? "all" : filter) << "' is not part of the MI355X-accelerated build (see DESIGN.md, out of scope)" << std::endl;
+            throw InternalError();
+        }
+        if (outputheader) OUT << "#\tPATTERN1\tRELATION\tPATTERN2\tREL.COUNT\tREL.FREQUENCY\tCOUNT2" << std::endl;
+        if (filter == "skipcontent") {
+            t_relationmap relations = this->getskipcontent(pattern);
+            this->outputrelations(pattern, relations, classdecoder, OUT, "INSTANTIATED-BY");
+        }
+    }
     /** Compute flexgrams by abstracting from the skipgrams in the model (reference :3724-3744): every skipgram's references are appended to
      *  the flexgram it abstracts to (Pattern::toflexgram). The group-by and the merge of the reference lists run on the device
      *  (colibri_flexgrams); each flexgram's new references arrive ascending. @return the number of flexgrams that were not in the model */

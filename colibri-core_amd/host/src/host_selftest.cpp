@@ -60,6 +60,43 @@ int main(int argc, char** argv) {
         std::cout << (fails ? "FAILED" : "OK") << std::endl;
         return fails ? 1 : 0;
     }
+    if (mode == "relations" && argc >= 9) {  // relations <corpus> <classfile> <maxlength> <mintokens> <minskiptypes> <filter> <out>: the C++ API of the relation
+        // queries on a freshly trained indexed skipgram model (the same walk as oracle/ref_driver.cpp's `relations`)
+        try {
+            PatternModelOptions options;
+            options.MAXLENGTH    = std::atoi(argv[4]);
+            options.MINTOKENS    = std::atoi(argv[5]);
+            options.MINSKIPTYPES = std::atoi(argv[6]);
+            options.DOSKIPGRAMS  = true;
+            options.QUIET        = true;
+            const std::string filter = argv[7];
+            ClassDecoder          decoder;
+            decoder.load(std::string(argv[3]));
+            IndexedCorpus         corpus{std::string(argv[2])};
+            IndexedPatternModel<> model(&corpus);
+            model.train(std::string(argv[2]), options);
+            std::ofstream out(argv[8]);
+            bool          first = true;
+            for (IndexedPatternModel<>::iterator it = model.begin(); it != model.end(); ++it) {
+                out << it->first.tostring(decoder) << std::endl;
+                if (filter == "instances_api") {
+                    t_relationmap rel = model.getinstances(it->first);
+                    model.outputrelations(it->first, rel, decoder, out, "INSTANCE-OF");
+                } else if (filter == "templates_api") {
+                    t_relationmap rel = model.gettemplates(it->first);
+                    model.outputrelations(it->first, rel, decoder, out, "TEMPLATE-OF");
+                } else {
+                    model.outputrelations(it->first, decoder, out, filter, first);
+                }
+                first = false;
+            }
+            std::cout << "OK" << std::endl;
+            return 0;
+        } catch (const std::exception& e) {
+            std::cout << "FAILED: " << e.what() << std::endl;
+            return 1;
+        }
+    }
     if (mode == "gpu" && argc >= 7) {
         PatternModelOptions options;
         options.MAXLENGTH = std::atoi(argv[5]);

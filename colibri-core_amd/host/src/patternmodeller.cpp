@@ -39,6 +39,8 @@ void usage() {
                  "\t-j|--constraints <file>     only count patterns that occur in this model (any threshold, any minimum length)\n"
                  "\t-F|--flexgrams S            flexgrams by abstracting over skipgrams (implies -s); indexed models built from a corpus\n"
                  "\t-I|--constrained            in-place rebuild: recount the patterns of the model given with -i on the corpus given with -f\n"
+                 "\t--skipcontent               after the views: every pattern, then the skip content of the skipgrams (needs -c and a corpus)\n"
+                 "\t--instances | --templates   as in the reference, these print the patterns only (its relation getters are not reached from here)\n"
                  " Viewing:\n"
                  "\t-P|--print   -R|--report   -r|--simplereport   -H|--histogram\n"
                  "\t-D|--debug   -h|--help\n";
@@ -47,6 +49,7 @@ void usage() {
 PatternSetModel* g_constraint = NULL;  // -j
 bool             g_inplace    = false; // -I
 bool             g_flexfromskip = false; // -F S
+std::string      g_relations;            // --skipcontent / --instances / --templates
 
 template <class ModelType>
 int run(ModelType& model, const std::string& corpusfile, const std::string& inputmodel, const std::string& outputmodel, const PatternModelOptions& options_in, uint32_t firstsentence,
@@ -81,6 +84,14 @@ int run(ModelType& model, const std::string& corpusfile, const std::string& inpu
     }
     if (doreport) model.report(std::cout, nocoverage);
     if (dohistogram) model.histogram(std::cout);
+    if (!g_relations.empty()) {  // every pattern of the model, then its relations (reference src/patternmodeller.cpp:274-285)
+        bool first = true;
+        for (typename ModelType::iterator it = model.begin(); it != model.end(); ++it) {
+            std::cout << it->first.tostring(*decoder) << std::endl;
+            model.outputrelations(it->first, *decoder, std::cout, g_relations, first);
+            first = false;
+        }
+    }
     return 0;
 }
 
@@ -98,6 +109,7 @@ int main(int argc, char** argv) {
                                        {"skiptypes", required_argument, 0, 'T'},   {"expand", required_argument, 0, 'e'},         {"print", no_argument, 0, 'P'},
                                        {"report", no_argument, 0, 'R'},            {"simplereport", no_argument, 0, 'r'},         {"histogram", no_argument, 0, 'H'},
                                        {"debug", no_argument, 0, 'D'},             {"help", no_argument, 0, 'h'},                 {"twostage", no_argument, 0, '2'},          {"constraints", required_argument, 0, 'j'},    {"constrained", no_argument, 0, 'I'},    {"flexgrams", required_argument, 0, 'F'},
+                                       {"skipcontent", no_argument, 0, 1001},      {"instances", no_argument, 0, 1002},           {"templates", no_argument, 0, 1003},
                                        {0, 0, 0, 0}};
     int c;
     while ((c = getopt_long(argc, argv, "f:c:i:o:t:ul:m:b:W:sy:T:e:PRrHDh2j:Ip:EF:LMQq:gZV", longopts, NULL)) != -1) {
@@ -136,6 +148,9 @@ int main(int argc, char** argv) {
                 g_flexfromskip      = true;
                 options.DOSKIPGRAMS = true;
                 break;
+            case 1001: g_relations = "skipcontent"; break;
+            case 1002: g_relations = "instances"; break;
+            case 1003: g_relations = "templates"; break;
             case 'h': usage(); return 0;
             default:
                 std::cerr << "ERROR: option -" << (char)(c == '?' ? optopt : c) << " selects a path that is not part of the MI355X-accelerated build (see DESIGN.md, out of scope)" << std::endl;
@@ -152,6 +167,10 @@ int main(int argc, char** argv) {
         if (!classfile.empty()) {
             loaded.load(classfile);
             decoder = &loaded;
+        }
+        if (!g_relations.empty() && decoder == NULL) {  // the reference needs the class encoder here (src/patternmodeller.cpp:275-277)
+            std::cerr << "ERROR: --" << g_relations << " needs a class file (--classfile)" << std::endl;
+            return 2;
         }
         if (g_flexfromskip && !inputmodel.empty()) {
             std::cerr << "ERROR: -F S on a loaded model needs the reference's trainskipgrams on that model, which is not part of this build; build the model from the corpus (-f) with -F S" << std::endl;

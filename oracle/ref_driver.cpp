@@ -96,6 +96,7 @@ int usage() {
                  "  ref_driver load <model.colibri.patternmodel> <u|i> <dump.txt>\n"
                  "  ref_driver encode <text> <outprefix> [-t threshold] [-c classfile] [-e] [-U]\n"
                  "  ref_driver view <model> <u|i> <print|report|simplereport|histogram|info> <classfile>\n"
+                 "  ref_driver relations <corpus> <classfile> <maxlength> <mintokens> <minskiptypes> <skipcontent|instances|templates> <out.txt>\n"
                  "  ref_driver hash <hex> [<hex> ...]\n"
                  "  ref_driver masks <n> <maxskips>\n";
     return 2;
@@ -210,6 +211,40 @@ int main(int argc, char** argv) {
         return 0;
     }
 
+    if (cmd == "relations") {  // ref_driver relations <corpus> <classfile> <maxlength> <mintokens> <minskiptypes> <skipcontent|instances|templates> <out.txt>
+        // = colibri-patternmodeller -f corpus -c classfile -s -l .. -t .. -T .. --<filter>: every pattern of the model, then its relations
+        // (src/patternmodeller.cpp:274-285, include/patternmodel.h:3595-3662)
+        if (argc < 9) return usage();
+        PatternModelOptions options;
+        options.MAXLENGTH    = atoi(argv[4]);
+        options.MINTOKENS    = atoi(argv[5]);
+        options.MINSKIPTYPES = atoi(argv[6]);
+        options.DOSKIPGRAMS  = true;
+        options.QUIET        = true;
+        const std::string filter = argv[7];
+        ClassDecoder          decoder(argv[3]);
+        IndexedCorpus         corpus(argv[2]);
+        IndexedPatternModel<> model(&corpus);
+        model.train(std::string(argv[2]), options);
+        std::ofstream out(argv[8]);
+        bool          first = true;
+        for (auto it = model.begin(); it != model.end(); ++it) {
+            const PatternPointer pp(it->first);
+            out << pp.tostring(decoder) << std::endl;
+            if (filter == "instances_api") {  // the C++ API proper (getinstances(const Pattern&), as src/test.cpp:1457-1460 uses it): through
+                // outputrelations(PatternPointer, ...) the reference resolves to the PatternPointer overloads of the base class, which return nothing
+                t_relationmap rel = model.getinstances(it->first);
+                model.outputrelations(pp, rel, decoder, out, "INSTANCE-OF");
+            } else if (filter == "templates_api") {
+                t_relationmap rel = model.gettemplates(it->first);
+                model.outputrelations(pp, rel, decoder, out, "TEMPLATE-OF");
+            } else {
+                model.outputrelations(pp, decoder, out, filter, first);
+            }
+            first = false;
+        }
+        return 0;
+    }
     if (cmd != "train" || argc < 6) return usage();
     const std::string corpusfile = argv[2];
     const std::string mode       = argv[3];

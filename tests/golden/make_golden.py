@@ -151,6 +151,19 @@ def main():
         if mine.refs != got.refs:
             unstable.append(os.path.basename(out))
             os.remove(out)
+    # relation queries on indexed skipgram models: skipcontent as colibri-patternmodeller --skipcontent walks the model, instances / templates
+    # through the C++ API proper (getinstances / gettemplates(const Pattern&)); kept only where the model itself is a stable golden
+    for name, T in [("hamlet.v2", 1), ("hamlet.v2", 2), ("phrases15k", 2), ("zipf20k", 2)]:
+        tag = "isT1" if T == 1 else "is"
+        if not os.path.exists(os.path.join(HERE, f"{name}.{tag}.l5.txt")):
+            continue
+        for flt in ("skipcontent", "instances_api", "templates_api"):
+            out = os.path.join(HERE, f"relations.{name}.{tag}.{flt}.txt")
+            subprocess.check_call([DRIVER, "relations", os.path.join(HERE, f"{name}.colibri.dat"), os.path.join(HERE, "hamlet.colibri.cls" if name.startswith("hamlet") else "synthetic.colibri.cls"),
+                                   "5", "2", str(T), flt, out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            lines = sorted(open(out).read().splitlines())  # canonical form: the reference walks its unordered_map
+            with open(out, "w") as f:
+                f.write("\n".join(lines) + "\n")
     with open(os.path.join(HERE, "unstable_reference_outputs.json"), "w") as f:
         json.dump({"note": "indexed+skipgram / flexgram dumps of the reference that were NOT kept because the reference's insert-while-iterating "
                            "hazard (patternmodel.h:2986-2991, :3727-3738) corrupted them (self-consistency checks in make_golden.py)", "dropped": unstable}, f, indent=1)

@@ -278,3 +278,47 @@ def test_cxx_api_subsumption_prunes(tmp_path, corpus, kind, tag):
         out = subprocess.run([CLI, "-f", os.path.join(GOLDEN, corpus + ".colibri.dat"), "-t", "2", "-l", "5", "-p", "4", "-o", model] + (["-u"] if kind == "u" else []), capture_output=True, text=True)
         assert out.returncode == 0, out.stderr
         assert parse_model(model)[3] == want.counts
+
+
+# ---- relation queries on indexed skipgram models -------------------------------------------------------------------------
+RELATIONS = [("hamlet.v2", 1, "isT1"), ("hamlet.v2", 2, "is"), ("phrases15k", 2, "is"), ("zipf20k", 2, "is")]
+
+
+def _cls_for(corpus):
+    return os.path.join(GOLDEN, "hamlet.colibri.cls" if corpus.startswith("hamlet") else "synthetic.colibri.cls")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("corpus,T,tag", RELATIONS)
+@pytest.mark.parametrize("flt", ["skipcontent", "instances_api", "templates_api"])
+def test_cxx_api_relation_queries(tmp_path, corpus, T, tag, flt):
+    """getskipcontent / getinstances / gettemplates + outputrelations of the C++ face on a model trained on the device, against the real
+    reference walking its own model the same way (ref_driver relations); the reference iterates an unordered_map: lines are compared sorted"""
+    out = str(tmp_path / "rel.txt")
+    p = subprocess.run([SELFTEST, "relations", os.path.join(GOLDEN, corpus + ".colibri.dat"), _cls_for(corpus), "5", "2", str(T), flt, out], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.strip() == "OK", p.stdout + p.stderr
+    want = open(os.path.join(GOLDEN, f"relations.{corpus}.{tag}.{flt}.txt")).read().splitlines()
+    assert sorted(open(out).read().splitlines()) == want
+
+
+@pytest.mark.gpu
+def test_cli_skipcontent_and_the_silent_relation_flags(tmp_path):
+    """--skipcontent after building: every pattern, then its skip content rows; --instances / --templates print the patterns only, as the
+    reference does from its CLI (its call resolves to the base class's empty getters, include/patternmodel.h:2635-2640)"""
+    data = os.path.join(GOLDEN, "hamlet.v2.colibri.dat")
+    base = [CLI, "-f", data, "-c", _cls_for("hamlet.v2"), "-s", "-T", "1", "-t", "2", "-l", "5"]
+    out = subprocess.run(base + ["--skipcontent"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    want = open(os.path.join(GOLDEN, "relations.hamlet.v2.isT1.skipcontent.txt")).read().splitlines()
+    assert sorted(out.stdout.splitlines()) == want
+    for flag in ("--instances", "--templates"):
+        out = subprocess.run(base + [flag], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        lines = out.stdout.splitlines()
+        assert len(lines) == 202 and lines.count("#\tPATTERN1\tRELATION\tPATTERN2\tREL.COUNT\tREL.FREQUENCY\tCOUNT2") == 1
+        assert not [ln for ln in lines if ln.startswith("\t")]
+
+
+def test_cli_relations_need_a_class_file():
+    out = subprocess.run([CLI, "-f", os.path.join(GOLDEN, "hamlet.v2.colibri.dat"), "-s", "--skipcontent"], capture_output=True, text=True)
+    assert out.returncode == 2 and "needs a class file" in out.stderr

@@ -865,6 +865,28 @@ class IndexedPatternModel : public PatternModel<IndexedData, IndexedDataHandler,
             throw InternalError();
         }
     }
+    /** PatternPointer::operator==(const Pattern&) of the reference for a skipgram pointer (src/pattern.cpp:1009-1041), byte for byte */
+    static bool masked_pointer_equals(const unsigned char* data, size_t bytes, uint32_t mask, const Pattern& other) {
+        const size_t obytes = other.bytesize();
+        auto         at     = [&](size_t i) -> unsigned char { return i < obytes ? other.data[i] : 0; };
+        if (bytes == 0 || data[0] == 0) return obytes == 0;
+        if (obytes == 0) return false;
+        size_t tok = 0;
+        for (size_t i = 0; i < bytes; ++i) {
+            if (i > 0 && at(i - 1) >= 128 && at(i) == 0) return false;
+            if (mask != 0 && data[i] < 128) {
+                if (tok <= 30 && (mask & (1u << tok))) {
+                    if (at(i) != colibri_classes::skipclass) return false;
+                } else if (data[i] != at(i)) {
+                    return false;
+                }
+                ++tok;
+            } else if (data[i] != at(i)) {
+                return false;
+            }
+        }
+        return at(bytes) == colibri_classes::delimiterclass;
+    }
     static void prunerelations(t_relationmap& relations, unsigned int occurrencethreshold) {  // reference :3066-3078
         for (t_relationmap::iterator it = relations.begin(); it != relations.end();) {
             if (it->second < occurrencethreshold) it = relations.erase(it);
@@ -940,7 +962,12 @@ class IndexedPatternModel : public PatternModel<IndexedData, IndexedDataHandler,
                 for (uint32_t mask : masks) {
                     window.mask = mask;
                     const Pattern candidate(window);
-                    if (candidate == pattern || candidate.category() != SKIPGRAM || !this->has(candidate)) continue;
+                    if (candidate.category() != SKIPGRAM || !this->has(candidate)) continue;
+                    // The reference drops the pattern itself with `candidate != pattern`: a masked pointer into the corpus against the
+                    // materialised pattern, compared byte by byte AT THE SAME INDEX (src/pattern.cpp:1009-1041). That recognises the pattern only
+                    // where every token under a gap is a single byte (elsewhere a skipgram is listed as its own template), and it takes an
+                    // n-gram for the candidate when the low byte of the token under the gap happens to be 03 — reproduced, not corrected.
+                    if (masked_pointer_equals(window.data, (size_t)window.bytesize(), mask, pattern)) continue;
                     templates[candidate] += 1;
                 }
             }

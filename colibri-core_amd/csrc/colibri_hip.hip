@@ -377,8 +377,8 @@ int check_options(colibri_ctx* c, colibri_options& o) {
     if (o.minlength > 1 && !constrained) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINLENGTH>1 is not on the accelerated path");
     if (o.minlength > o.maxlength) return fail(c, COLIBRI_ERR_ARG, "MINLENGTH > MAXLENGTH");
     if (o.maxbackofflength < o.maxlength) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MAXBACKOFFLENGTH < MAXLENGTH is not on the accelerated path");
-    if (o.mintokens_unigrams > o.mintokens && (o.doskipgrams || o.doskipgrams_exhaustive || constrained || o.mintokens < 2 || o.table_mode == 2))
-        return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINTOKENS_UNIGRAMS > MINTOKENS with skipgrams, a constraint set, MINTOKENS = 1 or table_mode 2 is not on the accelerated path");
+    if (o.mintokens_unigrams > o.mintokens && (constrained || o.mintokens < 2 || o.table_mode == 2))
+        return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINTOKENS_UNIGRAMS > MINTOKENS with a constraint set, MINTOKENS = 1 or table_mode 2 is not on the accelerated path");
     if (o.dopatternperline || o.prunenonsubsumed || o.prunesubsumed)
         return fail(c, COLIBRI_ERR_UNSUPPORTED, "DOPATTERNPERLINE / PRUNE(NON)SUBSUMED are not on the accelerated path");
     if (o.doskipgrams && o.doskipgrams_exhaustive)

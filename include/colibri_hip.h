@@ -44,7 +44,7 @@ typedef struct colibri_options {
     int32_t maxlength;              /* MAXLENGTH (default 100)                                                    */
     int32_t minlength;              /* MINLENGTH (default 1; only 1 is accelerated)                               */
     int32_t maxbackofflength;       /* MAXBACKOFFLENGTH (must be >= maxlength)                                    */
-    int32_t mintokens_unigrams;     /* MINTOKENS_UNIGRAMS (must be <= mintokens)                                  */
+    int32_t mintokens_unigrams;     /* MINTOKENS_UNIGRAMS (-W): > mintokens = secondary word threshold (not sharded / constrained) */
     int32_t mintokens_skipgrams;    /* MINTOKENS_SKIPGRAMS (raised to mintokens when lower, :887-888)             */
     int32_t minskiptypes;           /* MINSKIPTYPES (default 2)                                                   */
     int32_t maxskips;               /* MAXSKIPS (default 3)                                                       */

@@ -439,7 +439,7 @@ co_model* co_train(const uint8_t* payload, uint64_t nbytes, const co_options* op
     /* secondary word threshold (:1090-1104): with MINLENGTH == 1 and MINTOKENS > 1 the unigrams themselves are still pruned at MINTOKENS
      * (:1220), but a longer window is only counted if every one of its words occurs at least MINTOKENS_UNIGRAMS times */
     const uint32_t wthr = (opt.mintokens_unigrams > opt.mintokens) ? (uint32_t)opt.mintokens_unigrams : 0u;
-    if (wthr && (opt.mintokens < 2 || opt.doskipgrams || opt.doskipgrams_exhaustive)) return NULL;
+    if (wthr && opt.mintokens < 2) return NULL;
 
     co_model* m = (co_model*)calloc(1, sizeof(co_model));
     m->indexed  = opt.indexed;

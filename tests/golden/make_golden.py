@@ -108,7 +108,7 @@ def main():
             subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{name}.colibri.dat"), mode, "5", "2", "-q", "-m", "3", "-d", out], stdout=subprocess.DEVNULL)
     # MINTOKENS_UNIGRAMS = 4 (-W): longer patterns need every word to occur at least four times
     for name in ["hamlet.v2", "zipf20k"]:
-        for mode in ("u", "i"):
+        for mode in ("u", "i", "us", "is"):
             out = os.path.join(HERE, f"wordthreshold.{name}.{mode}.W4.txt")
             subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{name}.colibri.dat"), mode, "5", "2", "-q", "-W", "4", "-d", out], stdout=subprocess.DEVNULL)
     # PRUNENONSUBSUMED = 4 (-p) / PRUNESUBSUMED = 3: post-hoc passes over the finished model

@@ -104,6 +104,14 @@ def test_word_threshold(ctx, name, table_mode, indexed):
     _compare(ctx, small_corpora()[name], 5, 2, mintokens_unigrams=5, table_mode=table_mode, indexed=indexed)
 
 
+@pytest.mark.parametrize("name", ["zipf20k", "rand2", "zipf200k_phrases"])
+@pytest.mark.parametrize("mode", [dict(doskipgrams_exhaustive=1), dict(doskipgrams_exhaustive=1, mintokens_skipgrams=3), dict(indexed=1, doskipgrams=1),
+                                  dict(indexed=1, doskipgrams=1, minskiptypes=1)], ids=["us", "usy3", "is", "isT1"])
+def test_word_threshold_with_skipgrams(ctx, name, mode):
+    """-W together with skipgrams: a window that fails the word threshold contributes neither its n-gram nor its skipgrams"""
+    _compare(ctx, small_corpora()[name], 5, 2, mintokens_unigrams=4, **mode)
+
+
 def test_hamlet_fixture_known_answers(ctx, hamlet_payload):
     """reference src/test.cpp:1214-1221: 111 patterns / 186 types / 354 tokens with default options;
     config 1 of BASELINE.json: n <= 3 -> 81 patterns (45/22/14)."""

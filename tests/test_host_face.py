@@ -241,7 +241,7 @@ def test_cli_minimum_length(tmp_path, corpus, mode, flags):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("corpus", ["hamlet.v2", "zipf20k"])
-@pytest.mark.parametrize("mode,flags", [("u", ["-u"]), ("i", [])])
+@pytest.mark.parametrize("mode,flags", [("u", ["-u"]), ("i", []), ("us", ["-u", "-s"]), ("is", ["-s"])])
 def test_cli_word_threshold(tmp_path, corpus, mode, flags):
     """-W 4 (MINTOKENS_UNIGRAMS): unigrams stay at the pattern threshold, longer patterns need every word to occur four times (goldens by the reference)"""
     import oracle

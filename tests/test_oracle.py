@@ -68,6 +68,18 @@ def test_oracle_matches_reference_goldens(corpus, tag, maxlength, path):
         assert got.refs == want.refs
 
 
+@pytest.mark.parametrize("corpus", ["hamlet.v2", "zipf20k"])
+@pytest.mark.parametrize("mode", ["u", "i", "us", "is"])
+def test_oracle_matches_reference_word_threshold_goldens(corpus, mode):
+    """-W 4 (MINTOKENS_UNIGRAMS) in all four kinds of model, skipgrams included: dumps of the real reference"""
+    kw = {"u": {}, "i": dict(indexed=True), "us": dict(doskipgrams_exhaustive=True), "is": dict(indexed=True, doskipgrams=True)}[mode]
+    want = oracle.parse_dump(open(os.path.join(GOLDEN, f"wordthreshold.{corpus}.{mode}.W4.txt")).read(), indexed=kw.get("indexed", False))
+    got = oracle.train(read_payload(corpus), 2, 5, mintokens_unigrams=4, **kw)
+    assert (got.tokens, got.types, got.counts) == (want.tokens, want.types, want.counts)
+    if want.refs is not None:
+        assert got.refs == want.refs
+
+
 def test_hamlet_fixture_model_file():
     """exp/hamlet.v1.colibri.patternmodel (the reference's only committed golden model): 111 patterns, tokens 354, types 186."""
     raw = open(os.path.join(GOLDEN, "hamlet.v1.colibri.patternmodel"), "rb").read()

@@ -70,6 +70,8 @@ def make_options(rng):
         o["indexed"] = int(rng.integers(0, 2))
     if mode in (1, 3):
         o["maxlength"] = min(o["maxlength"], 6)
+        if rng.integers(0, 3) == 0:  # secondary word threshold together with skipgrams
+            o["mintokens_unigrams"] = o["mintokens"] + int(rng.integers(1, 4))
     o["table_mode"] = int(rng.choice([0, 0, 0, 1, 2])) if mode == 0 else 0
     return o
 

@@ -371,9 +371,8 @@ int check_options(colibri_ctx* c, colibri_options& o) {
     if (constrained && (o.doskipgrams || o.doskipgrams_exhaustive)) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams in a constrained run are not on the accelerated path");
     if (o.minlength < 1) o.minlength = 1;
     // MINTOKENS = 1: the reference counts all lengths in one pass without look-back (patternmodel.h:1069-1072); nothing is ever pruned, so the
-    // order loop admits every window and yields the same model. Skipgrams at threshold 1 follow other rules there and stay unsupported.
-    if (o.mintokens < 2 && !constrained && (o.doskipgrams || o.doskipgrams_exhaustive))
-        return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams with MINTOKENS=1 are not on the accelerated path");
+    // order loop admits every window and yields the same model — with skipgrams too: every window of three or more tokens then counts all its
+    // masked forms (checked against the reference: oracle/colibri_oracle.c, tests/golden/*.t1s.*).
     if (o.minlength > 1 && !constrained) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINLENGTH>1 is not on the accelerated path");
     if (o.minlength > o.maxlength) return fail(c, COLIBRI_ERR_ARG, "MINLENGTH > MAXLENGTH");
     if (o.maxbackofflength < o.maxlength) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MAXBACKOFFLENGTH < MAXLENGTH is not on the accelerated path");
@@ -968,7 +967,10 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     pl.npos        = npos;
     pl.table_slots = (uint32_t)table_slots64;
     // results: every survivor has >= MINTOKENS occurrences; at MINTOKENS = 1 every window may be its own pattern (exhaustion is reported, never silent)
-    pl.res_cap     = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)npos * (o.mintokens < 2 ? (uint64_t)std::min(o.maxlength, 8) : (synced ? 4u : 2u)) + 1024);
+    uint64_t per_pos = o.mintokens < 2 ? (uint64_t)std::min(o.maxlength, 8) : (synced ? 4u : 2u);  // results per corpus position the run can produce
+    if (o.mintokens < 2 && (o.doskipgrams || o.doskipgrams_exhaustive))  // threshold 1 keeps every masked form of every window as well
+        for (int n = 3; n <= std::min(o.maxlength, 13); ++n) per_pos += gap_masks(n, o.maxskips).size();
+    pl.res_cap     = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)npos * per_pos + 1024);
     pl.thr         = (uint32_t)o.mintokens;
     const uint32_t wthr = o.mintokens_unigrams > o.mintokens ? (uint32_t)o.mintokens_unigrams : 0u;  // secondary word threshold (-W), 0 = none
     constexpr uint32_t kCountLdsBytes    = kCountTile * 16u + kCountLSlot * 4u + 64u;  // keyL + cntL + slotL + winL

@@ -102,7 +102,8 @@ int main(int argc, char** argv) {
         options.MAXLENGTH = std::atoi(argv[5]);
         options.MINTOKENS = std::atoi(argv[6]);
         options.QUIET     = false;
-        for (int a = 7; a < argc; ++a) {  // optional: p<N> = PRUNENONSUBSUMED, S<N> = PRUNESUBSUMED
+        for (int a = 7; a < argc; ++a) {  // optional: p<N> = PRUNENONSUBSUMED, S<N> = PRUNESUBSUMED, b<N> = MAXBACKOFFLENGTH
+            if (argv[a][0] == 'b') options.MAXBACKOFFLENGTH = std::atoi(argv[a] + 1);
             if (argv[a][0] == 'p') options.PRUNENONSUBSUMED = std::atoi(argv[a] + 1);
             if (argv[a][0] == 'S') options.PRUNESUBSUMED = std::atoi(argv[a] + 1);
         }

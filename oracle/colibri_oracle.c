@@ -434,7 +434,7 @@ co_model* co_train(const uint8_t* payload, uint64_t nbytes, const co_options* op
     if (opt.mintokens_skipgrams < opt.mintokens) opt.mintokens_skipgrams = opt.mintokens; /* :887-888 */
     /* MINTOKENS == 1 makes the reference count all lengths in one pass without look-back (:1069-1072); with nothing ever pruned the
      * order loop below admits every window and gives the same model. Skipgrams at threshold 1 stay outside the restated subset. */
-    if (opt.mintokens < 1 || (opt.mintokens < 2 && (opt.doskipgrams || opt.doskipgrams_exhaustive))) return NULL;
+    if (opt.mintokens < 1) return NULL;
     const uint32_t thr = (uint32_t)opt.mintokens;
     /* secondary word threshold (:1090-1104): with MINLENGTH == 1 and MINTOKENS > 1 the unigrams themselves are still pruned at MINTOKENS
      * (:1220), but a longer window is only counted if every one of its words occurs at least MINTOKENS_UNIGRAMS times */

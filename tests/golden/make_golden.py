@@ -101,6 +101,14 @@ def main():
         for mode in ("u", "i"):
             out = os.path.join(HERE, f"{name}.{mode}t1.l{l}.txt")
             subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{name}.colibri.dat"), mode, str(l), "1", "-q", "-d", out], stdout=subprocess.DEVNULL)
+    # ... and with skipgrams: every window of three or more tokens counts all its masked forms (indexed dumps only where the reference's loop stayed stable)
+    for name, l, mode, extra, tag in [("hamlet.v2", 4, "us", [], "ust1"), ("hamlet.v2", 4, "us", ["-y", "3"], "usy3t1"), ("edge", 4, "us", [], "ust1"),
+                                      ("edge", 4, "us", ["-y", "3"], "usy3t1"), ("hamlet.v2", 3, "is", [], "ist1"), ("hamlet.v2", 3, "is", ["-T", "1"], "isT1t1")]:
+        out = os.path.join(HERE, f"{name}.{tag}.l{l}.txt")
+        subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{name}.colibri.dat"), mode, str(l), "1", "-q", "-d", out] + extra, stdout=subprocess.DEVNULL)
+        if mode == "is" and not reference_is_dump_is_stable(out, 1 if extra else 2, l):
+            unstable.append(os.path.basename(out))
+            os.remove(out)
     # MINLENGTH = 3: the shorter orders are counted for the look-back and pruned away afterwards
     for name in ["hamlet.v2", "zipf20k"]:
         for mode in ("u", "i", "is", "us"):

@@ -112,6 +112,14 @@ def test_word_threshold_with_skipgrams(ctx, name, mode):
     _compare(ctx, small_corpora()[name], 5, 2, mintokens_unigrams=4, **mode)
 
 
+@pytest.mark.parametrize("name", ["rand1", "short_sentences", "zipf20k", "multibyte"])
+@pytest.mark.parametrize("mode", [dict(doskipgrams_exhaustive=1), dict(doskipgrams_exhaustive=1, mintokens_skipgrams=3), dict(indexed=1, doskipgrams=1),
+                                  dict(indexed=1, doskipgrams=1, minskiptypes=1)], ids=["us", "usy3", "is", "isT1"])
+def test_threshold_one_with_skipgrams(ctx, name, mode):
+    """MINTOKENS = 1 with skipgrams: every window of three or more tokens keeps all its masked forms"""
+    _compare(ctx, small_corpora()[name], 4, 1, **mode)
+
+
 def test_hamlet_fixture_known_answers(ctx, hamlet_payload):
     """reference src/test.cpp:1214-1221: 111 patterns / 186 types / 354 tokens with default options;
     config 1 of BASELINE.json: n <= 3 -> 81 patterns (45/22/14)."""
@@ -137,7 +145,9 @@ def test_unsupported_options_fail_loudly(ctx):
     from colibri_amd import capi
     ctx.upload(small_corpora()["rand0"])
     with pytest.raises(capi.ColibriError):
-        ctx.train(mintokens=1, doskipgrams_exhaustive=1)
+        ctx.train(maxlength=5, maxbackofflength=2)
+    with pytest.raises(capi.ColibriError):
+        ctx.train(dopatternperline=1)
     with pytest.raises(capi.ColibriError):
         ctx.train(minlength=2)
     with pytest.raises(capi.ColibriError):

@@ -107,8 +107,8 @@ def test_cxx_api_preloaded_corpus(tmp_path):
 
 @pytest.mark.gpu
 def test_cxx_api_errors_are_internalerror(tmp_path):
-    out = subprocess.run([SELFTEST, "gpu", os.path.join(GOLDEN, "hamlet.v2.colibri.dat"), str(tmp_path / "m"), "is", "5", "1"], capture_output=True, text=True)
-    assert out.returncode == 1 and "EXCEPTION" in out.stdout  # skipgrams at MINTOKENS=1 are outside the accelerated subset: loud failure, no fallback
+    out = subprocess.run([SELFTEST, "gpu", os.path.join(GOLDEN, "hamlet.v2.colibri.dat"), str(tmp_path / "m"), "is", "5", "2", "b2"], capture_output=True, text=True)
+    assert out.returncode == 1 and "EXCEPTION" in out.stdout  # MAXBACKOFFLENGTH < MAXLENGTH is outside the accelerated subset: loud failure, no fallback
 
 
 @pytest.mark.gpu

@@ -21,6 +21,8 @@ MODES = {
     "u": {}, "us": dict(doskipgrams_exhaustive=True), "usy3": dict(doskipgrams_exhaustive=True, mintokens_skipgrams=3),
     "i": dict(indexed=True), "is": dict(indexed=True, doskipgrams=True), "isT1": dict(indexed=True, doskipgrams=True, minskiptypes=1),
     "ut1": dict(mintokens=1), "it1": dict(indexed=True, mintokens=1),  # MINTOKENS = 1: the reference's single pass over all lengths
+    "ust1": dict(doskipgrams_exhaustive=True, mintokens=1), "usy3t1": dict(doskipgrams_exhaustive=True, mintokens_skipgrams=3, mintokens=1),  # ... with skipgrams
+    "ist1": dict(indexed=True, doskipgrams=True, mintokens=1), "isT1t1": dict(indexed=True, doskipgrams=True, minskiptypes=1, mintokens=1),
 }
 
 

@@ -70,8 +70,15 @@ def make_options(rng):
         o["indexed"] = int(rng.integers(0, 2))
     if mode in (1, 3):
         o["maxlength"] = min(o["maxlength"], 6)
-        if rng.integers(0, 3) == 0:  # secondary word threshold together with skipgrams
+        pick = rng.integers(0, 4)
+        if pick == 0:  # secondary word threshold together with skipgrams
             o["mintokens_unigrams"] = o["mintokens"] + int(rng.integers(1, 4))
+        elif pick == 1:  # threshold 1: every window and every masked form of it is kept
+            o["mintokens"] = 1
+            o["maxlength"] = min(o["maxlength"], 5)
+            o.pop("mintokens_skipgrams", None)
+            if rng.integers(0, 2) and o["doskipgrams_exhaustive"]:
+                o["mintokens_skipgrams"] = int(rng.integers(1, 4))
     o["table_mode"] = int(rng.choice([0, 0, 0, 1, 2])) if mode == 0 else 0
     return o
 

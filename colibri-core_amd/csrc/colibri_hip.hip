@@ -372,7 +372,7 @@ int check_options(colibri_ctx* c, colibri_options& o) {
     if (o.minlength < 1) o.minlength = 1;
     // MINTOKENS = 1: the reference counts all lengths in one pass without look-back (patternmodel.h:1069-1072); nothing is ever pruned, so the
     // order loop admits every window and yields the same model — with skipgrams too: every window of three or more tokens then counts all its
-    // masked forms (checked against the reference: oracle/colibri_oracle.c, tests/golden/*.t1s.*).
+    // masked forms (goldens of the reference: tests/golden/*.ust1.*, *.ist1.*).
     if (o.minlength > 1 && !constrained) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINLENGTH>1 is not on the accelerated path");
     if (o.minlength > o.maxlength) return fail(c, COLIBRI_ERR_ARG, "MINLENGTH > MAXLENGTH");
     if (o.maxbackofflength < o.maxlength) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MAXBACKOFFLENGTH < MAXLENGTH is not on the accelerated path");

@@ -61,7 +61,7 @@ int main(int argc, char** argv) {
         return fails ? 1 : 0;
     }
     if (mode == "relations" && argc >= 9) {  // relations <corpus> <classfile> <maxlength> <mintokens> <minskiptypes> <filter> <out>: the C++ API of the relation
-        // queries on a freshly trained indexed skipgram model (the same walk as oracle/ref_driver.cpp's `relations`)
+        // queries on a freshly trained indexed skipgram model, pattern by pattern in model order
         try {
             PatternModelOptions options;
             options.MAXLENGTH    = std::atoi(argv[4]);

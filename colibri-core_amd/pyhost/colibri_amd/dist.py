@@ -139,6 +139,8 @@ class ShardedTrainer:
         tokens_g = sum(v[0] for v in self._all_gather_ints([eng.local_tokens()]))
         for n in range(1, maxlength + 1):
             dense = self._unigram_pass_dense(state) if n == 1 else None
+            if n == 1 and dense is None and int(opt.mintokens_unigrams) > max(1, int(opt.mintokens)):
+                raise ValueError("MINTOKENS_UNIGRAMS > MINTOKENS in a sharded run needs the class-indexed order 1 (canonical class encoding on every rank)")
             found_all, kept_all = dense if dense is not None else self._pass(n, 0, 1, state)
             if found_all == 0:
                 break

@@ -40,11 +40,11 @@ typedef struct colibri_ctx colibri_ctx;
 /* POD mirror of the PatternModelOptions fields PatternModel::train reads on this path
  * (reference include/patternmodel.h:103-213; defaults :153-180). */
 typedef struct colibri_options {
-    int32_t mintokens;              /* MINTOKENS: -1 -> 2, 0 -> 1 (patternmodel.h:883-886); any value >= 1 (1 not in sharded runs) */
+    int32_t mintokens;              /* MINTOKENS: -1 -> 2, 0 -> 1 (patternmodel.h:883-886); any value >= 1                              */
     int32_t maxlength;              /* MAXLENGTH (default 100)                                                    */
     int32_t minlength;              /* MINLENGTH (default 1; only 1 is accelerated)                               */
     int32_t maxbackofflength;       /* MAXBACKOFFLENGTH (must be >= maxlength)                                    */
-    int32_t mintokens_unigrams;     /* MINTOKENS_UNIGRAMS (-W): > mintokens = secondary word threshold (not sharded / constrained) */
+    int32_t mintokens_unigrams;     /* MINTOKENS_UNIGRAMS (-W): > mintokens = secondary word threshold (not with a constraint set) */
     int32_t mintokens_skipgrams;    /* MINTOKENS_SKIPGRAMS (raised to mintokens when lower, :887-888)             */
     int32_t minskiptypes;           /* MINSKIPTYPES (default 2)                                                   */
     int32_t maxskips;               /* MAXSKIPS (default 3)                                                       */

@@ -111,4 +111,6 @@ def test_hip_shard_engine_ranks_as_threads(world):
         payload = make_corpus(rng)
         mode = case % 4
         o = dict(mintokens=2 + case % 2, maxlength=5, indexed=int(mode in (2, 3)), doskipgrams=int(mode == 3), doskipgrams_exhaustive=int(mode == 1))
+        if case >= 8:  # threshold 1 (everything survives on every rank) and the secondary word threshold, in every kind of model
+            o.update(dict(mintokens=1, maxlength=4) if case % 2 else dict(mintokens_unigrams=o["mintokens"] + 2))
         assert run_case(case, world, payload, o, capi, oracle, torch, cdist) is None

@@ -153,6 +153,13 @@ def main():
             o["mintokens_skipgrams"] = o["mintokens"] + int(rng.integers(0, 3))
         if mode == 0:
             o["table_mode"] = int(rng.choice([0, 0, 1]))
+        extra = int(rng.integers(0, 5))
+        if extra == 0:  # threshold 1: everything survives everywhere
+            o["mintokens"] = 1
+            o["maxlength"] = min(o["maxlength"], 5)
+            o.pop("mintokens_skipgrams", None)
+        elif extra == 1 and o.get("table_mode", 0) == 0:  # secondary word threshold
+            o["mintokens_unigrams"] = o["mintokens"] + int(rng.integers(1, 4))
         case += 1
         bad = run_case(seed, world, payload, o, capi, oracle, torch, cdist)
         if bad:

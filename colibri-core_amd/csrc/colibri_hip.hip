@@ -21,6 +21,7 @@
 #include "textenc.hpp"
 #include "constrained.hpp"
 #include "flexgrams.hpp"
+#include "patternlist.hpp"
 #include "kernels.hpp"
 
 using namespace colibri;
@@ -378,8 +379,11 @@ int check_options(colibri_ctx* c, colibri_options& o) {
     if (o.maxbackofflength < o.maxlength) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MAXBACKOFFLENGTH < MAXLENGTH is not on the accelerated path");
     if (o.mintokens_unigrams > o.mintokens && (constrained || o.mintokens < 2 || o.table_mode == 2))
         return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINTOKENS_UNIGRAMS > MINTOKENS with a constraint set, MINTOKENS = 1 or table_mode 2 is not on the accelerated path");
-    if (o.dopatternperline || o.prunenonsubsumed || o.prunesubsumed)
-        return fail(c, COLIBRI_ERR_UNSUPPORTED, "DOPATTERNPERLINE / PRUNE(NON)SUBSUMED are not on the accelerated path");
+    if (o.prunenonsubsumed || o.prunesubsumed) return fail(c, COLIBRI_ERR_UNSUPPORTED, "PRUNE(NON)SUBSUMED are post-hoc passes of the caller, not of colibri_train");
+    // one pattern per line: the CLI's -L implies MINTOKENS = 1 and an unindexed model (src/patternmodeller.cpp:571-574, :677-678); with a higher
+    // threshold the reference re-counts every line once per order until nothing new turns up — not reproduced
+    if (o.dopatternperline && (o.mintokens != 1 || o.indexed || o.doskipgrams || o.doskipgrams_exhaustive || constrained || o.minlength > 1))
+        return fail(c, COLIBRI_ERR_UNSUPPORTED, "DOPATTERNPERLINE is on the accelerated path with MINTOKENS = 1, MINLENGTH = 1, unindexed, without skipgrams or a constraint set");
     if (o.doskipgrams && o.doskipgrams_exhaustive)
         return fail(c, COLIBRI_ERR_ARG, "Both DOSKIPGRAMS as well as DOSKIPGRAMS_EXHAUSTIVE are set, this shouldn't happen, choose one.");  // :958-963
     if (o.doskipgrams && !o.indexed)
@@ -925,6 +929,105 @@ int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = fal
     return COLIBRI_OK;
 }
 
+// DOPATTERNPERLINE (patternlist.hpp): one grouping pass over the lines per line length that occurs
+int train_pattern_list(colibri_ctx* c, const colibri_options& o, colibri_stats* stats_out) {
+    const auto     t0 = std::chrono::steady_clock::now();
+    int            rc;
+    colibri_stats& s = c->stats;
+    std::memset(&s, 0, sizeof s);
+    c->segments.clear();
+    c->npairs           = 0;
+    c->hstate           = DevState{};
+    const uint32_t npos = c->npos, nlines = c->ndelim;
+    if (npos) {
+        uint32_t last = 0;
+        if (nlines) HIP_TRY(c, hipMemcpy(&last, c->delimpos.p + (nlines - 1), sizeof last, hipMemcpyDeviceToHost));
+        if (!nlines || last + 1 != npos) return fail(c, COLIBRI_ERR_CORPUS, "pattern list: the last line lacks its end-of-line marker");
+    }
+    const uint32_t res_cap = nlines + 1;
+    if ((rc = dev_alloc(c, c->res_rep, res_cap)) || (rc = dev_alloc(c, c->res_cnt, res_cap)) || (rc = dev_alloc(c, c->state, 1))) return rc;
+    uint32_t res_total = 0;
+    if (nlines) {
+        DevBuf<uint32_t>           line_pos, line_ntok, flen, slot_of, isrep;
+        DevBuf<unsigned long long> line_off, unit, rank;
+        DevBuf<FSlot>              table;
+        DevBuf<FlexInfo>           info;
+        auto                       cleanup = [&]() {
+            dev_free(line_pos); dev_free(line_ntok); dev_free(flen); dev_free(slot_of); dev_free(isrep); dev_free(line_off); dev_free(unit); dev_free(rank); dev_free(table); dev_free(info);
+        };
+        struct Guard {
+            decltype(cleanup)& f;
+            ~Guard() { f(); }
+        } guard{cleanup};
+        if ((rc = dev_alloc(c, line_pos, nlines)) || (rc = dev_alloc(c, line_ntok, nlines)) || (rc = dev_alloc(c, flen, (size_t)nlines + 1)) || (rc = dev_alloc(c, slot_of, nlines)) ||
+            (rc = dev_alloc(c, isrep, (size_t)nlines + 1)) || (rc = dev_alloc(c, line_off, nlines)) || (rc = dev_alloc(c, unit, (size_t)nlines + 1)) ||
+            (rc = dev_alloc(c, rank, (size_t)nlines + 1)) || (rc = dev_alloc(c, info, 1)))
+            return rc;
+        uint64_t most = 0;  // the most lines any one length has: sizes the table
+        for (size_t n = 1; n < c->lenhist.size() && n <= (size_t)o.maxlength; ++n) most = std::max<uint64_t>(most, c->lenhist[n]);
+        const uint32_t cap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, most + (most >> 1) + 1024);
+        if ((rc = dev_alloc(c, table, cap))) return rc;
+        {
+            Prof p(c, COLIBRI_K_COUNT);
+            hipLaunchKernelGGL(ppl_lines_kernel, dim3(stream_grid((uint64_t)nlines + 1)), dim3(kBlock), 0, c->stream, c->delimpos.p, nlines, c->tokstart.p, line_pos.p, line_ntok.p, line_off.p,
+                               unit.p);
+        }
+        for (int n = 1; n <= o.maxlength && n < COLIBRI_MAX_ORDER && (size_t)n < c->lenhist.size(); ++n) {
+            if (c->lenhist[(size_t)n] == 0) continue;
+            unsigned long long groups = 0;
+            bool               grouped = false;
+            for (int attempt = 0; attempt < 4 && !grouped; ++attempt) {
+                const uint64_t seed = 0xBB67AE8584CAA73Bull + 0x9E3779B97F4A7C15ull * (uint64_t)attempt;
+                HIP_TRY(c, hipMemsetAsync(info.p, 0, sizeof(FlexInfo), c->stream));
+                {
+                    Prof p(c, COLIBRI_K_COUNT);
+                    hipLaunchKernelGGL(ppl_select_kernel, dim3(stream_grid(nlines)), dim3(kBlock), 0, c->stream, line_pos.p, line_ntok.p, nlines, c->tokstart.p, (uint32_t)n, flen.p);
+                    hipLaunchKernelGGL(flex_clear_kernel, dim3(stream_grid(cap)), dim3(kBlock), 0, c->stream, table.p, cap);
+                    hipLaunchKernelGGL(flex_insert_kernel, dim3(stream_grid(nlines)), dim3(kBlock), 0, c->stream, c->bytes.p, line_off.p, flen.p, unit.p, nlines, seed, table.p, cap, slot_of.p);
+                    hipLaunchKernelGGL(flex_verify_kernel, dim3(stream_grid(nlines)), dim3(kBlock), 0, c->stream, c->bytes.p, line_off.p, flen.p, nlines, table.p, slot_of.p, isrep.p, info.p);
+                }
+                FlexInfo got{};
+                HIP_TRY(c, hipMemcpyAsync(&got, info.p, sizeof got, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                HIP_TRY(c, hipGetLastError());
+                grouped = !got.collision;
+            }
+            if (!grouped) return fail(c, COLIBRI_ERR_OVERFLOW, "pattern list: hash collisions under four seeds");
+            if ((rc = scan_u32(c, isrep.p, nlines, rank.p, &groups))) return rc;
+            const uint32_t k = (uint32_t)groups;
+            {
+                Prof p(c, COLIBRI_K_PRUNE);
+                hipLaunchKernelGGL(ppl_results_kernel, dim3(stream_grid(nlines)), dim3(kBlock), 0, c->stream, isrep.p, rank.p, table.p, slot_of.p, line_pos.p, nlines, res_total, res_cap,
+                                   c->res_rep.p, c->res_cnt.p);
+            }
+            s.found[n] = s.kept[n] = k;
+            s.admitted[n]          = c->lenhist[(size_t)n];
+            if (k) {
+                c->segments.push_back({res_total, k, n, 0u});
+                if (!s.minn) s.minn = n;
+                s.maxn = n;
+            }
+            res_total += k;
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+    }
+    c->hstate.res_total = res_total;
+    collect_events(c);
+    s.totaltokens = c->ntokens;  // every token of the corpus, the lines that are too long included (patternmodel.h:1047-1048 comes before :1056)
+    s.totaltypes  = s.kept[1];   // the distinct one-token lines (totalwordtypesingroup(NGRAM, 1) at :1201-1207)
+    s.nsentences  = c->nsent;
+    s.npatterns   = res_total;
+    s.train_ms    = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c->trained    = true;
+    c->keybytes   = 0;
+    c->last_mode  = 0;
+    if ((rc = prepare_export(c))) return rc;
+    s.keybytes = c->keybytes;
+    if (stats_out) *stats_out = s;
+    return COLIBRI_OK;
+}
+
 }  // namespace
 
 extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, colibri_stats* stats_out) {
@@ -942,6 +1045,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     std::fill(std::begin(c->k_launches), std::end(c->k_launches), 0);
     c->segments.clear();
     c->npairs = 0;
+    if (o.dopatternperline) return train_pattern_list(c, o, stats_out);
 
     const uint32_t npos   = c->npos;
     const bool     constrained = c->cs.n != 0;  // train(..., constrainbymodel): one membership-filtered pass per length, no look-back (constrained.hpp)

@@ -151,6 +151,8 @@ class PatternModel : public MapType, public PatternModelInterface {
     uint64_t      totaltokens, totaltypes;
     int           maxn, minn;
     bool          hasskipgrams_;
+    bool          types_settled_ = false;  // a threshold-1 run already asked for its word types (reference :1201-1207): its statistics cache is no longer
+                                           // empty, so types() does not compute them again — a pattern list without one-token lines keeps 0 types
     ValueHandler  valuehandler;
     std::shared_ptr<colibri_host::TrainResult> result;  // device results not yet turned into map nodes
 
@@ -209,7 +211,7 @@ class PatternModel : public MapType, public PatternModelInterface {
     int          maxlength() const override { return maxn; }
     int          minlength() const override { return minn; }
     unsigned int types() override {  // a loaded model without a type count falls back to the word types its patterns hold (reference :1700-1704)
-        if (totaltypes == 0 && this->size() != 0) totaltypes = this->totalwordtypesingroup(0, 0);
+        if (totaltypes == 0 && this->size() != 0 && !types_settled_) totaltypes = this->totalwordtypesingroup(0, 0);
         return (unsigned int)totaltypes;
     }
     unsigned int tokens() const override { return (unsigned int)totaltokens; }
@@ -375,6 +377,7 @@ class PatternModel : public MapType, public PatternModelInterface {
         if (r->stats.maxn > maxn) maxn = r->stats.maxn;
         if (r->stats.npatterns && r->stats.minn < minn) minn = r->stats.minn;
         hasskipgrams_ = (options.DOSKIPGRAMS || options.DOSKIPGRAMS_EXHAUSTIVE);
+        types_settled_ = options.DOPATTERNPERLINE;
         install_result(r);
         if (options.PRUNENONSUBSUMED || options.PRUNESUBSUMED) prune_by_subsumption(options);
     }

@@ -455,6 +455,15 @@ void drop_short_patterns(TrainResult& r, int minlength) {
 }
 
 void print_training_log(const colibri_stats& s, const colibri_options& o, std::ostream& err) {
+    if (o.dopatternperline) {  // one pass (reference include/patternmodel.h:1008-1009, :1196-1245)
+        err << "Counting patterns from list, one per line" << std::endl;
+        if (s.npatterns == 0) {
+            err << "None found" << std::endl;
+            return;
+        }
+        err << " Found " << s.npatterns << " ngrams... computing total word types prior to pruning..." << s.totaltypes << "...pruned 0...total kept: " << s.npatterns << std::endl;
+        return;
+    }
     for (int n = 1; n <= o.maxlength && n < COLIBRI_MAX_ORDER; ++n) {
         err << "Counting " << n << "-grams" << std::endl;
         if (s.found[n] == 0) {

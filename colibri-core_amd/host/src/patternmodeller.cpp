@@ -2,7 +2,7 @@
 // Same flags and flag meanings as reference src/patternmodeller.cpp:404-858 for: -f -c -o -i -u -t -l -m -b -W -s -y -T -P -R -r -H -e -D -h
 // (build a model from a .colibri.dat, save it, load a model, print / report / histogram), plus -2 (two-stage build), -p (prune by
 // subsumption), -j (constrain by a model), -I (constrained in-place rebuild of the model given with -i) and -F S (flexgrams abstracted from the
-// skipgrams of a freshly built indexed model). Flags that select paths outside the accelerated subset (-E -L -M -Q -q -g, -F <npmi> ...) are
+// skipgrams of a freshly built indexed model) and -L (one pattern per line). Flags that select paths outside the accelerated subset (-E -M -Q -q -g, -F <npmi> ...) are
 // reported and rejected instead of being silently ignored.
 // All counting happens in libcolibri_hip.so; this file only parses options and calls the C++ face.
 #include <getopt.h>
@@ -37,6 +37,7 @@ void usage() {
                  "\t-2|--twostage               two-stage build of an indexed model (needs -o): same result as the reference's -2\n"
                  "\t-p|--prune <n>              prune the (k-1)-grams that no k-gram of the model contains, from k = n downwards\n"
                  "\t-j|--constraints <file>     only count patterns that occur in this model (any threshold, any minimum length)\n"
+                 "\t-L|--patternlist            the data file is a list of one pattern per line: no sub-n-grams, implies -t 1 and -u\n"
                  "\t-F|--flexgrams S            flexgrams by abstracting over skipgrams (implies -s); indexed models built from a corpus\n"
                  "\t-I|--constrained            in-place rebuild: recount the patterns of the model given with -i on the corpus given with -f\n"
                  "\t--skipcontent               after the views: every pattern, then the skip content of the skipgrams (needs -c and a corpus)\n"
@@ -108,7 +109,7 @@ int main(int argc, char** argv) {
                                        {"wordthreshold", required_argument, 0, 'W'}, {"skipgrams", no_argument, 0, 's'},          {"skipthreshold", required_argument, 0, 'y'},
                                        {"skiptypes", required_argument, 0, 'T'},   {"expand", required_argument, 0, 'e'},         {"print", no_argument, 0, 'P'},
                                        {"report", no_argument, 0, 'R'},            {"simplereport", no_argument, 0, 'r'},         {"histogram", no_argument, 0, 'H'},
-                                       {"debug", no_argument, 0, 'D'},             {"help", no_argument, 0, 'h'},                 {"twostage", no_argument, 0, '2'},          {"constraints", required_argument, 0, 'j'},    {"constrained", no_argument, 0, 'I'},    {"flexgrams", required_argument, 0, 'F'},
+                                       {"debug", no_argument, 0, 'D'},             {"help", no_argument, 0, 'h'},                 {"twostage", no_argument, 0, '2'},          {"constraints", required_argument, 0, 'j'},    {"constrained", no_argument, 0, 'I'},    {"flexgrams", required_argument, 0, 'F'},    {"patternlist", no_argument, 0, 'L'},
                                        {"skipcontent", no_argument, 0, 1001},      {"instances", no_argument, 0, 1002},           {"templates", no_argument, 0, 1003},
                                        {0, 0, 0, 0}};
     int c;
@@ -140,6 +141,10 @@ int main(int argc, char** argv) {
             case 'p': options.PRUNENONSUBSUMED = std::atoi(optarg); break;
             case 'j': constraintfile = optarg; break;
             case 'I': g_inplace = true; break;
+            case 'L':  // reference :571-574: the data file is a list of one pattern per line; unindexed, and -t 1 (:677-678)
+                options.DOPATTERNPERLINE = true;
+                unindexed                = true;
+                break;
             case 'F':  // reference :550-559: "S" = from skipgrams (implies -s); a number = from co-occurrence (not in this build)
                 if (std::string(optarg) != "S") {
                     std::cerr << "ERROR: option -F " << optarg << " (flexgrams from co-occurrence) is not part of the MI355X-accelerated build (see DESIGN.md, out of scope)" << std::endl;
@@ -161,6 +166,7 @@ int main(int argc, char** argv) {
         usage();
         return 2;
     }
+    if (options.DOPATTERNPERLINE) options.MINTOKENS = 1;
     try {
         ClassDecoder* decoder = NULL;
         ClassDecoder  loaded;

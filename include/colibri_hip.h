@@ -50,7 +50,7 @@ typedef struct colibri_options {
     int32_t maxskips;               /* MAXSKIPS (default 3)                                                       */
     int32_t doskipgrams;            /* DOSKIPGRAMS (indexed models)                                               */
     int32_t doskipgrams_exhaustive; /* DOSKIPGRAMS_EXHAUSTIVE                                                     */
-    int32_t dopatternperline;       /* DOPATTERNPERLINE (must be 0)                                               */
+    int32_t dopatternperline;       /* DOPATTERNPERLINE (-L): every line is one pattern; needs mintokens = 1, unindexed, no skipgrams */
     int32_t prunenonsubsumed;       /* PRUNENONSUBSUMED (must be 0)                                               */
     int32_t prunesubsumed;          /* PRUNESUBSUMED (must be 0)                                                  */
     int32_t indexed;                /* 0: PatternModel<uint32_t> (model type 10), 1: IndexedPatternModel<> (20)   */

@@ -234,6 +234,35 @@ def train_constrained(payload: bytes, constraint, mintokens=2, maxlength=100, mi
     return Model(tokens, 0, counts, {k: sorted(refs[k]) for k in counts} if indexed else None)
 
 
+# ---- one pattern per line (PatternModelOptions::DOPATTERNPERLINE, colibri-patternmodeller -L) -----------------------------------------
+def train_patternperline(payload: bytes, maxlength=100) -> "Model":
+    """PatternModel::train with DOPATTERNPERLINE at MINTOKENS = 1 (the CLI's -L implies -t 1, src/patternmodeller.cpp:677-678) restated:
+    every non-empty line of at most MAXLENGTH tokens is one pattern — the whole line, no sub-n-grams (include/patternmodel.h:1055-1058);
+    tokens = all tokens of the corpus (:1047-1048, counted before the length check), types = the distinct one-token lines
+    (totalwordtypesingroup(NGRAM, 1) at :1201-1207). Pure Python: small inputs."""
+    counts, tokens, toks, start = {}, 0, [], 0
+    lines = []
+    for j, b in enumerate(payload):
+        if b >= 128:
+            continue
+        tok = payload[start:j + 1]
+        start = j + 1
+        if tok == b"\x00":
+            lines.append(toks)
+            toks = []
+        else:
+            toks.append(tok)
+    if toks:
+        lines.append(toks)
+    for toks in lines:
+        tokens += len(toks)
+        if 1 <= len(toks) <= maxlength:
+            k = b"".join(toks)
+            counts[k] = counts.get(k, 0) + 1
+    types = sum(1 for k in counts if len(key_tokens(k)) == 1)
+    return Model(tokens, types, counts, None)
+
+
 # ---- flexgrams from skipgrams (SURVEY §8 f-4) ---------------------------------------------------------------------------------------
 def key_tokens(key: bytes):
     """The tokens of a pattern key (each a varint: bytes >= 128 continue, a byte < 128 ends the token)."""

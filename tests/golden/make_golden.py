@@ -109,6 +109,13 @@ def main():
         if mode == "is" and not reference_is_dump_is_stable(out, 1 if extra else 2, l):
             unstable.append(os.path.basename(out))
             os.remove(out)
+    # one pattern per line (patternmodeller -L, implies -t 1): a list of short lines with many repeats, and the ordinary corpora
+    rng = np.random.default_rng(23)
+    with open(os.path.join(HERE, "shortlines.colibri.dat"), "wb") as f:
+        f.write(synth.HEADER + synth.random_corpus(rng, nsent=400, maxlen=4, vocab=4, big_classes=True, empty_rate=0.2))
+    for name, l in [("shortlines", 2), ("shortlines", 100), ("edge", 3), ("edge", 100), ("zipf20k", 100), ("hamlet.v2", 100)]:
+        out = os.path.join(HERE, f"patternlist.{name}.L{l}.txt")
+        subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{name}.colibri.dat"), "u", str(l), "1", "-q", "-L", "-d", out], stdout=subprocess.DEVNULL)
     # MINLENGTH = 3: the shorter orders are counted for the look-back and pruned away afterwards
     for name in ["hamlet.v2", "zipf20k"]:
         for mode in ("u", "i", "is", "us"):

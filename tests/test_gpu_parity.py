@@ -120,6 +120,30 @@ def test_threshold_one_with_skipgrams(ctx, name, mode):
     _compare(ctx, small_corpora()[name], 4, 1, **mode)
 
 
+@pytest.mark.parametrize("name", ["rand0", "rand3", "short_sentences", "repeat", "only_delims", "empty", "one_token", "multibyte", "zipf20k", "zipf200k_phrases"])
+@pytest.mark.parametrize("maxlength", [1, 3, 100])
+def test_pattern_per_line(ctx, name, maxlength):
+    """DOPATTERNPERLINE (patternmodeller -L): every line of at most MAXLENGTH tokens is one pattern, threshold 1"""
+    import oracle
+    payload = small_corpora()[name]
+    want = oracle.train_patternperline(payload, maxlength)
+    ctx.upload(payload)
+    st = ctx.train(mintokens=1, maxlength=maxlength, dopatternperline=1)
+    got, _ = ctx.export_dict()
+    assert got == want.counts
+    assert (st.totaltokens, st.totaltypes, st.npatterns) == (want.tokens, want.types, len(want))
+
+
+def test_pattern_per_line_needs_terminated_lines_and_threshold_one(ctx):
+    from colibri_amd import capi
+    ctx.upload(small_corpora()["no_trailing_delim"])
+    with pytest.raises(capi.ColibriError):
+        ctx.train(mintokens=1, dopatternperline=1)
+    ctx.upload(small_corpora()["rand0"])
+    with pytest.raises(capi.ColibriError):
+        ctx.train(mintokens=2, dopatternperline=1)
+
+
 def test_hamlet_fixture_known_answers(ctx, hamlet_payload):
     """reference src/test.cpp:1214-1221: 111 patterns / 186 types / 354 tokens with default options;
     config 1 of BASELINE.json: n <= 3 -> 81 patterns (45/22/14)."""
@@ -147,7 +171,7 @@ def test_unsupported_options_fail_loudly(ctx):
     with pytest.raises(capi.ColibriError):
         ctx.train(maxlength=5, maxbackofflength=2)
     with pytest.raises(capi.ColibriError):
-        ctx.train(dopatternperline=1)
+        ctx.train(dopatternperline=1, indexed=1, mintokens=1)
     with pytest.raises(capi.ColibriError):
         ctx.train(minlength=2)
     with pytest.raises(capi.ColibriError):

@@ -322,3 +322,22 @@ def test_cli_skipcontent_and_the_silent_relation_flags(tmp_path):
 def test_cli_relations_need_a_class_file():
     out = subprocess.run([CLI, "-f", os.path.join(GOLDEN, "hamlet.v2.colibri.dat"), "-s", "--skipcontent"], capture_output=True, text=True)
     assert out.returncode == 2 and "needs a class file" in out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("corpus,l", [("shortlines", 2), ("shortlines", 100), ("edge", 3), ("edge", 100), ("zipf20k", 100), ("hamlet.v2", 100)])
+def test_cli_pattern_list(tmp_path, corpus, l):
+    """-L: the data file is a list of one pattern per line (implies -t 1, unindexed); goldens by the real reference, which also loads the model back"""
+    import oracle
+    model = str(tmp_path / "m.colibri.patternmodel")
+    out = subprocess.run([CLI, "-f", os.path.join(GOLDEN, corpus + ".colibri.dat"), "-L", "-l", str(l), "-o", model], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "Counting patterns from list, one per line" in out.stderr
+    want = oracle.parse_dump(open(os.path.join(GOLDEN, f"patternlist.{corpus}.L{l}.txt")).read())
+    mtype, tokens, types, counts, _ = parse_model(model)
+    assert (mtype, tokens, types, counts) == (10, want.tokens, want.types, want.counts)
+    if oracle.have_ref():
+        dump = str(tmp_path / "d.txt")
+        subprocess.check_call([oracle.REF_DRIVER, "load", model, "u", dump])
+        got = oracle.parse_dump(open(dump).read())
+        assert (got.tokens, got.counts) == (want.tokens, want.counts)

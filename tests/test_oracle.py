@@ -82,6 +82,15 @@ def test_oracle_matches_reference_word_threshold_goldens(corpus, mode):
         assert got.refs == want.refs
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "patternlist.*.txt"))), ids=os.path.basename)
+def test_patternlist_restatement_matches_reference_dumps(path):
+    """DOPATTERNPERLINE (patternmodeller -L, implies -t 1): dumps of the real reference"""
+    name, l = os.path.basename(path)[len("patternlist."):-len(".txt")].rsplit(".", 1)
+    want = oracle.parse_dump(open(path).read())
+    got = oracle.train_patternperline(read_payload(name), int(l[1:]))
+    assert (got.tokens, got.types, got.counts) == (want.tokens, want.types, want.counts)
+
+
 def test_hamlet_fixture_model_file():
     """exp/hamlet.v1.colibri.patternmodel (the reference's only committed golden model): 111 patterns, tokens 354, types 186."""
     raw = open(os.path.join(GOLDEN, "hamlet.v1.colibri.patternmodel"), "rb").read()

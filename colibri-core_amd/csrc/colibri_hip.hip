@@ -1089,7 +1089,9 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     if ((rc = dev_alloc(c, c->ids[1], (size_t)npos + 1))) return rc;
     // the per-pass modes count their n-gram passes of order >= 2 on the radix path too (result indices as ids, see bin_count's dense codes)
     const bool radix_synced = synced && !constrained && o.table_mode == 0 && c->ntokens <= 128ull * 1000 * 1000;
-    if (binned || radix_synced) {
+    // ... and so do the passes of a constrained run: a member window's key is its pattern number in the constraint set, counted in LDS like any other key
+    const bool radix_constrained = constrained && o.table_mode == 0 && c->ntokens <= 128ull * 1000 * 1000;
+    if (binned || radix_synced || radix_constrained) {
         // recs[0]: 256 fixed-capacity A-bin regions (25 % slack over a uniform split + one scatter tile each); recs[1]: exact
         if ((rc = dev_alloc(c, c->recs[0], ((size_t)npos + (npos >> 2)) / kBins * kBins + (size_t)kBins * kScatTile)) || (rc = dev_alloc(c, c->recs[1], (size_t)npos + 1))) return rc;
         if ((rc = dev_alloc(c, c->rep_of, (size_t)npos + 1)) || (rc = dev_alloc(c, c->ids_at, (size_t)npos + 1)) || (rc = dev_alloc(c, c->binstate, 1))) return rc;
@@ -1219,7 +1221,8 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
         }
         for (int n = constrained ? std::max(1, o.minlength) : 1; n <= maxlength && !c->hstate.done; ++n) {
             if ((rc = dev_alloc(c, c->ids[n], (size_t)npos + 1))) return rc;
-            if (!(n == 1 && uni_synced) && !(radix_synced && n >= 2)) launch_clear(c, pl);  // only the table passes need the table cleared
+            const bool radix_pass = radix_constrained || (radix_synced && n >= 2);
+            if (!(n == 1 && uni_synced) && !radix_pass) launch_clear(c, pl);  // only the table passes need the table cleared
             if (n == 1 && uni_synced) {
                 // order 1 on the class-indexed count array (as in the plain mode): no hashing, no table; the survivor id of a unigram is its
                 // RESULT index here, read per position through a class -> result table
@@ -1242,13 +1245,19 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                     Prof p(c, COLIBRI_K_RESOLVE);
                     hipLaunchKernelGGL(uni_resid_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_resid.p, c->ids[n].p, c->state.p, npos);
                 }
-            } else if (radix_synced && n >= 2) {
+            } else if (radix_pass) {
                 // n-gram pass on the radix path: emit -> level B -> per-bin LDS count; survivors leave as (bin, rank) codes that the resolve turns
                 // into result indices (= the ids the skipgram passes and the forward index work with); from order 3 on only the active list is walked
-                const bool use_list = n >= 3 && list_valid;
+                // (a constrained pass has no look-back, hence no list: every position is asked whether its window is a member)
+                const bool use_list = !constrained && n >= 3 && list_valid;
                 c->hstate.radix_overflow = 0;
                 if ((rc = write_state(c))) return rc;
-                if ((rc = binned_count_stage(c, pl, KeyNgram{c->ids[n - 1].p, n}, n, use_list, pl.thr, false, true, false, /*dense_code=*/true))) return rc;
+                if (constrained)
+                    rc = binned_count_stage(c, pl, KeyConstrained{c->bytes.p, c->tokstart.p, c->cs.rem.p, c->cs.table.p, c->cs.cap, c->cs.bytes.p, c->cs.off.p, n}, n, false, pl.thr, false, true, false,
+                                            /*dense_code=*/true);
+                else
+                    rc = binned_count_stage(c, pl, KeyNgram{c->ids[n - 1].p, n}, n, use_list, pl.thr, false, true, false, /*dense_code=*/true);
+                if (rc) return rc;
                 const BinnedIO io = binned_planes(c, pl, false);
                 {
                     Prof p(c, COLIBRI_K_PRUNE);
@@ -1257,8 +1266,8 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                                        use_list ? (const uint32_t*)c->alist[n & 1].p : (const uint32_t*)nullptr);
                     hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
                 }
-                if ((rc = binned_resolve_stage(c, pl, c->ids[n].p, n, use_list, true, nullptr, 0u, /*prefill_ids=*/true, /*decode=*/true, res_total))) return rc;
-                list_valid = true;
+                if ((rc = binned_resolve_stage(c, pl, c->ids[n].p, n, use_list, !constrained, nullptr, 0u, /*prefill_ids=*/true, /*decode=*/true, res_total))) return rc;
+                list_valid = !constrained;
             } else {
                 if (constrained)
                     launch_count(c, pl, KeyConstrained{c->bytes.p, c->tokstart.p, c->cs.rem.p, c->cs.table.p, c->cs.cap, c->cs.bytes.p, c->cs.off.p, n}, c->ids[n].p, 3, COLIBRI_K_COUNT);
@@ -1270,7 +1279,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                 launch_resolve(c, pl, c->ids[n].p);
             }
             if ((rc = read_state(c))) return rc;
-            if (radix_synced && c->hstate.radix_overflow) {  // a bin outgrew its LDS table: the whole run again on the table path (loud, exact, rare)
+            if ((radix_synced || radix_constrained) && c->hstate.radix_overflow) {  // a bin outgrew its LDS table: the whole run again on the table path (loud, exact, rare)
                 colibri_options again = o;
                 again.table_mode      = 1;
                 return colibri_train(c, &again, stats_out);

@@ -86,6 +86,7 @@ struct colibri_ctx {
         DevBuf<unsigned long long> off;
         DevBuf<CSlot>              table;
         DevBuf<uint32_t>           rem;    // tokens left in the sentence per position (built per corpus)
+        DevBuf<uint32_t>           memb;   // pattern number of the window at each position, kProbeLengths lengths at a time
         uint32_t                   n = 0, cap = 0;
         bool                       rem_valid = false;
     } cs;
@@ -452,7 +453,7 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->flags_at);
     dev_free(c->tx.text); dev_free(c->tx.out); dev_free(c->tx.slot_of); dev_free(c->tx.first); dev_free(c->tx.widx); dev_free(c->tx.wstart); dev_free(c->tx.wlen);
     dev_free(c->tx.wcount); dev_free(c->tx.cls); dev_free(c->tx.repeat); dev_free(c->tx.outlen); dev_free(c->tx.outoff); dev_free(c->tx.bsum); dev_free(c->tx.ntok);
-    dev_free(c->cs.bytes); dev_free(c->cs.off); dev_free(c->cs.table); dev_free(c->cs.rem);
+    dev_free(c->cs.bytes); dev_free(c->cs.off); dev_free(c->cs.table); dev_free(c->cs.rem); dev_free(c->cs.memb);
     dev_free(c->fx.keys); dev_free(c->fx.keyoff); dev_free(c->fx.refoff); dev_free(c->fx.cnt); dev_free(c->fx.sentence); dev_free(c->fx.token);
     dev_free(c->tx.table); dev_free(c->tx.state); dev_free(c->tx.info); dev_free(c->tx.events); dev_free(c->tx.evcnt);
     dev_free(c->flag2);
@@ -1218,10 +1219,20 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             // a length's distinct keys are patterns of J: the table never needs more slots than that
             c->hstate.cap = (uint32_t)std::min<uint64_t>(pl.table_slots, (uint64_t)c->cs.n + (c->cs.n >> 1) + 1024u);
             if ((rc = write_state(c))) return rc;
+            if ((rc = dev_alloc(c, c->cs.memb, (size_t)kProbeLengths * ((size_t)npos + 1)))) return rc;
         }
+        int probed_from = 0, probed_to = -1;  // window lengths whose membership arrays are current
         for (int n = constrained ? std::max(1, o.minlength) : 1; n <= maxlength && !c->hstate.done; ++n) {
             if ((rc = dev_alloc(c, c->ids[n], (size_t)npos + 1))) return rc;
             const bool radix_pass = radix_constrained || (radix_synced && n >= 2);
+            if (constrained && n > probed_to) {  // which pattern of the constraint set is the window at each position, for the next lengths
+                probed_from = n;
+                probed_to   = std::min(maxlength, n + kProbeLengths - 1);
+                Prof p(c, COLIBRI_K_COUNT);
+                hipLaunchKernelGGL(constraint_probe_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, c->cs.rem.p, c->cs.table.p, c->cs.cap, c->cs.bytes.p,
+                                   c->cs.off.p, npos, probed_from, probed_to - probed_from + 1, c->cs.memb.p, (size_t)npos + 1);
+            }
+            const KeyMember member{c->cs.memb.p + (size_t)(constrained ? n - probed_from : 0) * ((size_t)npos + 1)};
             if (!(n == 1 && uni_synced) && !radix_pass) launch_clear(c, pl);  // only the table passes need the table cleared
             if (n == 1 && uni_synced) {
                 // order 1 on the class-indexed count array (as in the plain mode): no hashing, no table; the survivor id of a unigram is its
@@ -1253,8 +1264,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                 c->hstate.radix_overflow = 0;
                 if ((rc = write_state(c))) return rc;
                 if (constrained)
-                    rc = binned_count_stage(c, pl, KeyConstrained{c->bytes.p, c->tokstart.p, c->cs.rem.p, c->cs.table.p, c->cs.cap, c->cs.bytes.p, c->cs.off.p, n}, n, false, pl.thr, false, true, false,
-                                            /*dense_code=*/true);
+                    rc = binned_count_stage(c, pl, member, n, false, pl.thr, false, true, false, /*dense_code=*/true);
                 else
                     rc = binned_count_stage(c, pl, KeyNgram{c->ids[n - 1].p, n}, n, use_list, pl.thr, false, true, false, /*dense_code=*/true);
                 if (rc) return rc;
@@ -1270,7 +1280,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                 list_valid = !constrained;
             } else {
                 if (constrained)
-                    launch_count(c, pl, KeyConstrained{c->bytes.p, c->tokstart.p, c->cs.rem.p, c->cs.table.p, c->cs.cap, c->cs.bytes.p, c->cs.off.p, n}, c->ids[n].p, 3, COLIBRI_K_COUNT);
+                    launch_count(c, pl, member, c->ids[n].p, 3, COLIBRI_K_COUNT);
                 else if (n == 1)
                     launch_count(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, c->ids[n].p, 3, COLIBRI_K_COUNT);
                 else

@@ -2,12 +2,14 @@
 // (include/patternmodel.h:1062-1072: every n-gram of every length MINLENGTH..MAXLENGTH of every sentence, in ONE pass;
 // :1088-1089: `if (!constrainbymodel->has(pattern)) continue;` — no look-back at shorter patterns; :1209-1217: prune(MINTOKENS)
 // regardless of size). On the device that is a membership-filtered scan: the constraint set J lives in an open-addressed table in
-// HBM (64-bit hash of the key bytes -> pattern number, the bytes themselves verify a hit), a window is admissible iff its bytes are a
-// member, and its exact identity is then J's pattern number — so counting, pruning, survivor ids and the forward index are the
-// ordinary count_kernel / prune / resolve / emit_pairs of the table path with another key functor. gfx950 only.
+// HBM (64-bit hash of the key -> pattern number, the bytes themselves verify a hit). The hash folds the key token by token, so one
+// thread derives the hashes of all window lengths at a position from one walk over its tokens: constraint_probe_kernel answers
+// "which pattern of J is the window of n tokens at i" for up to eight lengths per pass, with all first probes of a position in
+// flight together (the look-up is a chain of dependent random gathers — latency, not bandwidth). A member window's exact identity
+// is then J's pattern number, so counting, pruning, survivor ids and the forward index are the ordinary counting path (radix or
+// table) with the key functor KeyMember. gfx950 only.
 #pragma once
 #include "kernels.hpp"
-#include "textenc.hpp"  // text_hash
 
 namespace colibri {
 
@@ -17,6 +19,26 @@ struct CSlot {
     uint32_t len;   // key bytes
 };
 constexpr uint64_t kConstraintSeed = 0x2545F4914F6CDD1Dull;
+constexpr int      kProbeLengths   = 8;  // window lengths answered per probe pass
+
+__device__ __forceinline__ uint64_t fold_chunk(uint64_t h, const uint8_t* __restrict__ p, uint32_t nbytes /*1..8*/) {
+    uint64_t v = 0;
+    for (uint32_t b = 0; b < nbytes; ++b) v |= (uint64_t)p[b] << (8 * b);
+    return mix64(h ^ v ^ ((uint64_t)nbytes << 59));
+}
+// hash of a key, folded token by token (a token longer than 8 bytes — never a corpus token — continues in 8-byte chunks)
+__device__ __forceinline__ uint64_t fold_hash_key(const uint8_t* __restrict__ p, uint32_t len) {
+    uint64_t h = kConstraintSeed;
+    uint32_t start = 0;
+    for (uint32_t i = 0; i < len; ++i) {
+        const bool last = p[i] < 128 || i + 1 == len;
+        if (last || i + 1 - start == 8) {
+            h     = fold_chunk(h, p + start, i + 1 - start);
+            start = i + 1;
+        }
+    }
+    return h == kEmptyKey ? h ^ 1ull : h;
+}
 
 __global__ __launch_bounds__(kBlock) void constraint_clear_kernel(CSlot* __restrict__ table, uint32_t cap) {
     for (uint32_t s = blockIdx.x * kBlock + threadIdx.x; s < cap; s += gridDim.x * kBlock) table[s].hash = kEmptyKey;
@@ -27,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void constraint_insert_kernel(const uint8_t
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < npatterns; p += gridDim.x * kBlock) {
         const uint32_t len = (uint32_t)(joff[p + 1] - joff[p]);
         if (len == 0) continue;
-        const uint64_t h = text_hash(jbytes + joff[p], len, kConstraintSeed);
+        const uint64_t h = fold_hash_key(jbytes + joff[p], len);
         uint32_t       s = slot_of_hash(mix64(h), cap);
         for (;;) {
             const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[s].hash), (unsigned long long)kEmptyKey, (unsigned long long)h);
@@ -54,39 +76,90 @@ __global__ __launch_bounds__(kBlock) void sentence_rem_kernel(const uint32_t* __
         rem[i] = (lo < ndelim ? delimpos[lo] : npos) - i;
     }
 }
-// key functor of order n: admissible iff the window's bytes are a pattern of J; key = its pattern number
-struct KeyConstrained {
-    const uint8_t*            bytes;
-    const uint32_t*           tokstart;
-    const uint32_t*           rem;
-    const CSlot*              table;
-    uint32_t                  cap;
-    const uint8_t*            jbytes;
-    const unsigned long long* joff;
-    int                       n;
-    __device__ __forceinline__ bool operator()(uint32_t i, uint32_t /*npos*/, uint64_t& key, uint64_t& hash) const {
-        if (rem[i] < (uint32_t)n) return false;
-        const uint32_t a = tokstart[i], len = tokstart[i + n] - a;
-        const uint64_t h = text_hash(bytes + a, len, kConstraintSeed);
-        uint32_t       s = slot_of_hash(mix64(h), cap);
-        for (uint32_t probe = 0; probe < cap; ++probe) {
-            const CSlot c = table[s];
-            if (c.hash == kEmptyKey) return false;
-            if (c.hash == h && c.len == len) {
-                const uint8_t* j    = jbytes + joff[c.idx];
-                bool           same = true;
-                uint32_t       k    = 0;
-                for (; same && k + 8 <= len; k += 8) same = ld64u(bytes + a + k) == ld64u(j + k);
-                for (; same && k < len; ++k) same = bytes[a + k] == j[k];
-                if (same) {
-                    key  = c.idx;
-                    hash = mix64(key ^ 0xC0FFEE123456789ull);
-                    return true;
+// memb[(n - n0) * stride + i] = pattern number in J of the window of n tokens at position i (n0 <= n < n0 + nlen), kInvalid if it is none
+__global__ __launch_bounds__(kBlock) void constraint_probe_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ tokstart, const uint32_t* __restrict__ rem,
+                                                                   const CSlot* __restrict__ table, uint32_t cap, const uint8_t* __restrict__ jbytes,
+                                                                   const unsigned long long* __restrict__ joff, uint32_t npos, int n0, int nlen, uint32_t* __restrict__ memb,
+                                                                   size_t stride) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npos; i += gridDim.x * kBlock) {
+        const uint32_t r = rem[i];  // tokens left in the sentence (0 at a delimiter)
+        uint64_t       hs[kProbeLengths];
+        uint32_t       bl[kProbeLengths], sl[kProbeLengths];
+        CSlot          first[kProbeLengths];
+        const uint32_t a0 = tokstart[i];
+        uint64_t       h  = kConstraintSeed;
+        uint32_t       a  = a0;
+        for (int k = 1; k < n0; ++k) {  // the tokens before the first length of interest (only when MINLENGTH > 1 or beyond the first eight lengths)
+            if ((uint32_t)k > r) break;
+            const uint32_t e = tokstart[i + k];
+            h                = fold_chunk(h, bytes + a, e - a);
+            a                = e;
+        }
+        // token ends, then token values, then the hash chain: every load of a stage is independent of the others of that stage
+        uint32_t te[kProbeLengths];
+        uint64_t tv[kProbeLengths];
+#pragma unroll
+        for (int j = 0; j < kProbeLengths; ++j) te[j] = (j < nlen && (uint32_t)(n0 + j) <= r) ? tokstart[i + n0 + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < kProbeLengths; ++j) {
+            const uint32_t b = j == 0 ? a : te[j - 1];
+            tv[j]            = (j < nlen && (uint32_t)(n0 + j) <= r) ? ld64u(bytes + b) : 0ull;  // a corpus token has at most 8 bytes; the buffer is padded
+        }
+#pragma unroll
+        for (int j = 0; j < kProbeLengths; ++j) {
+            if (j < nlen && (uint32_t)(n0 + j) <= r) {
+                const uint32_t b = j == 0 ? a : te[j - 1], nb = te[j] - b;
+                const uint64_t v = nb >= 8 ? tv[j] : (tv[j] & ((1ull << (8 * nb)) - 1ull));
+                h                = mix64(h ^ v ^ ((uint64_t)nb << 59));
+                hs[j]            = h == kEmptyKey ? h ^ 1ull : h;
+                bl[j]            = te[j] - a0;
+            }
+        }
+        // all first probes of this position are issued before any is looked at
+#pragma unroll
+        for (int j = 0; j < kProbeLengths; ++j) {
+            if (j < nlen && (uint32_t)(n0 + j) <= r) {
+                sl[j]    = slot_of_hash(mix64(hs[j]), cap);
+                first[j] = table[sl[j]];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kProbeLengths; ++j) {
+            if (j >= nlen) break;
+            uint32_t found = kInvalid;
+            if ((uint32_t)(n0 + j) <= r) {
+                CSlot    c = first[j];
+                uint32_t s = sl[j];
+                for (uint32_t probe = 0; probe < cap; ++probe) {
+                    if (c.hash == kEmptyKey) break;
+                    if (c.hash == hs[j] && c.len == bl[j]) {
+                        const uint8_t* q    = jbytes + joff[c.idx];
+                        bool           same = true;
+                        uint32_t       k    = 0;
+                        for (; same && k + 8 <= bl[j]; k += 8) same = ld64u(bytes + a0 + k) == ld64u(q + k);
+                        for (; same && k < bl[j]; ++k) same = bytes[a0 + k] == q[k];
+                        if (same) {
+                            found = c.idx;
+                            break;
+                        }
+                    }
+                    s = (s + 1 == cap) ? 0 : s + 1;
+                    c = table[s];
                 }
             }
-            s = (s + 1 == cap) ? 0 : s + 1;
+            memb[(size_t)j * stride + i] = found;
         }
-        return false;
+    }
+}
+// key functor of one length: admissible iff the probe found the window in J; key = its pattern number
+struct KeyMember {
+    const uint32_t* memb;
+    __device__ __forceinline__ bool operator()(uint32_t i, uint32_t /*npos*/, uint64_t& key, uint64_t& hash) const {
+        const uint32_t m = memb[i];
+        if (m == kInvalid) return false;
+        key  = m;
+        hash = mix64(key ^ 0xC0FFEE123456789ull);
+        return true;
     }
 };
 

@@ -131,6 +131,33 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
                 }
             }
         }
+        // second chance for the windows whose election slot is held by a DIFFERENT key (two frequent keys sharing a slot would otherwise make
+        // every occurrence of the loser its own record, tile after tile, and flood one A-bin sub-region): the losers elect among themselves in
+        // another slot of the same array (stale first-round winners there carry other keys and are ignored by the key check)
+        bool lost[kCountPer];
+        bool anylost = false;
+#pragma unroll
+        for (int k = 0; k < kCountPer; ++k) {
+            const uint32_t e = k * kBlock + threadIdx.x;
+            lost[k]          = adm[k] && rep[k] == e && winL[(uint32_t)hash[k] & (kCountLSlot - 1)] != e;
+            anylost |= lost[k];
+        }
+        if (__syncthreads_or(anylost)) {  // (also orders the first-round reads before the second-round writes)
+#pragma unroll
+            for (int k = 0; k < kCountPer; ++k)
+                if (lost[k]) winL[(uint32_t)(hash[k] >> 20) & (kCountLSlot - 1)] = k * kBlock + threadIdx.x;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kCountPer; ++k) {
+                if (!lost[k]) continue;
+                const uint32_t e = k * kBlock + threadIdx.x;
+                const uint32_t w = winL[(uint32_t)(hash[k] >> 20) & (kCountLSlot - 1)];
+                if (w != e && keyL[w] == key[k]) {
+                    rep[k] = w;
+                    atomicAdd(&cntL[w], 1u);
+                }
+            }
+        }
         __syncthreads();  // election done: keyL / winL are dead from here, cntL is complete
         uint32_t rank[kCountPer];
 #pragma unroll
@@ -152,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
                 // atomics per 100 M windows. Blocks are therefore split into kSub groups, each with its own cursor and sub-region.
                 const uint32_t slot = (blockIdx.x & (uint32_t)(kSub - 1)) * kBins + threadIdx.x;
                 const uint32_t at   = atomicAdd(&bs->curA[slot], h);
-                if (at + h > region) st->radix_overflow = 1;  // sub-region full: the host re-runs on the global table
+                if (at + h > region) st->radix_overflow = 1;  // sub-region full: the host re-runs on the global table (1 = A region, 2 = final bin, 3 = id range)
                 g = slot * region + min(at, region - min(region, h));
             }
             gbaseL[threadIdx.x] = g;
@@ -455,7 +482,7 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
     if (*failL || distinct > kBinMaxLoad) {
         if (threadIdx.x == 0) {
             bs->overflow_bin = 1;
-            st->radix_overflow       = 1;  // sticky across orders: BinState is zeroed per order
+            st->radix_overflow       = 2;  // sticky across orders: BinState is zeroed per order
         }
         return;
     }
@@ -724,7 +751,7 @@ __global__ void bin_advance_prepare_kernel(DevState* __restrict__ st, const BinS
     for (int a = 0; a < kBins; ++a) f += bs->found_part[a];
     st->found = f;
     const uint64_t next = (uint64_t)st->id_base + bs->nrec;
-    if (next >= 0xFFFFFFF0ull) st->radix_overflow = 1;  // survivor ids would wrap: the host re-runs on the global table
+    if (next >= 0xFFFFFFF0ull) st->radix_overflow = 3;  // survivor ids would wrap: the host re-runs on the global table
     st->id_base = (uint32_t)next;
 }
 

@@ -377,7 +377,9 @@ int check_options(colibri_ctx* c, colibri_options& o) {
     // masked forms (goldens of the reference: tests/golden/*.ust1.*, *.ist1.*).
     if (o.minlength > 1 && !constrained) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINLENGTH>1 is not on the accelerated path");
     if (o.minlength > o.maxlength) return fail(c, COLIBRI_ERR_ARG, "MINLENGTH > MAXLENGTH");
-    if (o.maxbackofflength < o.maxlength) return fail(c, COLIBRI_ERR_UNSUPPORTED, "MAXBACKOFFLENGTH < MAXLENGTH is not on the accelerated path");
+    // MAXBACKOFFLENGTH < MAXLENGTH: above order MAXBACKOFFLENGTH + 1 the look-back consults the sub-patterns of MAXBACKOFFLENGTH tokens only (patternlist.hpp)
+    if (o.maxbackofflength < o.maxlength && (o.maxbackofflength < 1 || o.mintokens < 2 || o.doskipgrams || o.doskipgrams_exhaustive || constrained || c->npos >= 0x7FFFFFF0u))
+        return fail(c, COLIBRI_ERR_UNSUPPORTED, "MAXBACKOFFLENGTH < MAXLENGTH is on the accelerated path for MAXBACKOFFLENGTH >= 1, MINTOKENS >= 2, without skipgrams or a constraint set");
     if (o.mintokens_unigrams > o.mintokens && (constrained || o.mintokens < 2 || o.table_mode == 2))
         return fail(c, COLIBRI_ERR_UNSUPPORTED, "MINTOKENS_UNIGRAMS > MINTOKENS with a constraint set, MINTOKENS = 1 or table_mode 2 is not on the accelerated path");
     if (o.prunenonsubsumed || o.prunesubsumed) return fail(c, COLIBRI_ERR_UNSUPPORTED, "PRUNE(NON)SUBSUMED are post-hoc passes of the caller, not of colibri_train");
@@ -1050,7 +1052,8 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
 
     const uint32_t npos   = c->npos;
     const bool     constrained = c->cs.n != 0;  // train(..., constrainbymodel): one membership-filtered pass per length, no look-back (constrained.hpp)
-    const bool     synced = o.indexed || o.doskipgrams || o.doskipgrams_exhaustive || constrained;  // these modes keep every order's ids and talk to the host per order
+    const int      backoff = (o.maxbackofflength >= 1 && o.maxbackofflength + 1 < std::min<int>(o.maxlength, COLIBRI_MAX_ORDER - 1)) ? o.maxbackofflength : 0;  // orders above backoff + 1 differ
+    const bool     synced = o.indexed || o.doskipgrams || o.doskipgrams_exhaustive || constrained || backoff;  // these modes keep every order's ids and talk to the host per order
     // radix-partition + LDS count (binned.hpp) for the plain n-gram path when every final bin fits its LDS table: 65 536 bins
     // x <= ~1000 distinct keys expected; beyond ~128 M tokens per device (or on request) the global open-addressed table is used
     bool binned = !synced && (o.table_mode == 2 || (o.table_mode == 0 && c->ntokens <= 128ull * 1000 * 1000));
@@ -1188,7 +1191,10 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
         }
         if ((rc = read_state(c))) return rc;
         if (binned && c->hstate.radix_overflow) {  // a final bin outgrew its LDS table (hash skew): run again on the global table — loud, exact, rare
-            if (o.table_mode == 2) return fail(c, COLIBRI_ERR_OVERFLOW, "a radix bin outgrew its LDS table (table_mode = 2 forbids the global-table rerun)");
+            if (o.table_mode == 2)
+                return fail(c, COLIBRI_ERR_OVERFLOW, "the radix path overflowed (%s; region %llu records, %u positions; table_mode = 2 forbids the global-table rerun)",
+                            c->hstate.radix_overflow == 1 ? "an A-bin region" : c->hstate.radix_overflow == 2 ? "a final bin outgrew its LDS table" : "survivor id range",
+                            (unsigned long long)(c->recs[0].n / kASlots), npos);
             colibri_options again = o;
             again.table_mode      = 1;
             return colibri_train(c, &again, stats_out);
@@ -1222,9 +1228,22 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             if ((rc = dev_alloc(c, c->cs.memb, (size_t)kProbeLengths * ((size_t)npos + 1)))) return rc;
         }
         int probed_from = 0, probed_to = -1;  // window lengths whose membership arrays are current
+        // back-off passes (MAXBACKOFFLENGTH): per-position scratch of the byte-grouping kernels
+        DevBuf<uint32_t>           bo_run, bo_flen, bo_slot, bo_isrep, bo_keep;
+        DevBuf<unsigned long long> bo_off, bo_unit, bo_rank;
+        DevBuf<FSlot>              bo_table;
+        DevBuf<FlexInfo>           bo_info;
+        auto                       bo_cleanup = [&]() {
+            dev_free(bo_run); dev_free(bo_flen); dev_free(bo_slot); dev_free(bo_isrep); dev_free(bo_keep); dev_free(bo_off); dev_free(bo_unit); dev_free(bo_rank); dev_free(bo_table); dev_free(bo_info);
+        };
+        struct BoGuard {
+            decltype(bo_cleanup)& f;
+            ~BoGuard() { f(); }
+        } bo_guard{bo_cleanup};
+        bool bo_runs_valid = false;
         for (int n = constrained ? std::max(1, o.minlength) : 1; n <= maxlength && !c->hstate.done; ++n) {
             if ((rc = dev_alloc(c, c->ids[n], (size_t)npos + 1))) return rc;
-            const bool radix_pass = radix_constrained || (radix_synced && n >= 2);
+            const bool radix_pass = (radix_constrained || (radix_synced && n >= 2)) && !(backoff && n > backoff + 1);
             if (constrained && n > probed_to) {  // which pattern of the constraint set is the window at each position, for the next lengths
                 probed_from = n;
                 probed_to   = std::min(maxlength, n + kProbeLengths - 1);
@@ -1234,7 +1253,64 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             }
             const KeyMember member{c->cs.memb.p + (size_t)(constrained ? n - probed_from : 0) * ((size_t)npos + 1)};
             if (!(n == 1 && uni_synced) && !radix_pass) launch_clear(c, pl);  // only the table passes need the table cleared
-            if (n == 1 && uni_synced) {
+            const bool backoff_pass = backoff && n > backoff + 1;
+            if (backoff_pass) {
+                // every window whose sub-patterns of `backoff` tokens all survived is a candidate; its identity is its bytes (patternlist.hpp)
+                if (!bo_runs_valid) {
+                    if ((rc = dev_alloc(c, bo_run, (size_t)npos + 1)) || (rc = dev_alloc(c, bo_flen, (size_t)npos + 1)) || (rc = dev_alloc(c, bo_slot, (size_t)npos + 1)) ||
+                        (rc = dev_alloc(c, bo_isrep, (size_t)npos + 1)) || (rc = dev_alloc(c, bo_keep, (size_t)npos + 1)) || (rc = dev_alloc(c, bo_off, (size_t)npos + 1)) ||
+                        (rc = dev_alloc(c, bo_unit, (size_t)npos + 1)) || (rc = dev_alloc(c, bo_rank, (size_t)npos + 1)) || (rc = dev_alloc(c, bo_info, 1)))
+                        return rc;
+                    Prof p(c, COLIBRI_K_COUNT);
+                    hipLaunchKernelGGL(backoff_runs_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->ids[backoff].p, npos, bo_run.p);
+                    bo_runs_valid = true;
+                }
+                {
+                    Prof p(c, COLIBRI_K_COUNT);
+                    hipLaunchKernelGGL(backoff_select_kernel, dim3(stream_grid((uint64_t)npos + 1)), dim3(kBlock), 0, c->stream, bo_run.p, c->tokstart.p, npos, (uint32_t)n,
+                                       (uint32_t)(n - backoff + 1), bo_flen.p, bo_off.p, bo_unit.p, c->state.p);
+                }
+                if ((rc = read_state(c))) return rc;
+                const uint32_t cand = c->hstate.admitted;
+                uint32_t       kept_here = 0;
+                if (cand) {
+                    const uint32_t cap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)cand + (cand >> 1) + 1024);
+                    if ((rc = dev_alloc(c, bo_table, cap))) return rc;
+                    bool grouped = false;
+                    for (int attempt = 0; attempt < 4 && !grouped; ++attempt) {
+                        const uint64_t seed = 0x3C6EF372FE94F82Bull + 0x9E3779B97F4A7C15ull * (uint64_t)attempt;
+                        HIP_TRY(c, hipMemsetAsync(bo_info.p, 0, sizeof(FlexInfo), c->stream));
+                        {
+                            Prof p(c, COLIBRI_K_COUNT);
+                            hipLaunchKernelGGL(flex_clear_kernel, dim3(stream_grid(cap)), dim3(kBlock), 0, c->stream, bo_table.p, cap);
+                            hipLaunchKernelGGL(flex_insert_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->bytes.p, bo_off.p, bo_flen.p, bo_unit.p, npos, seed, bo_table.p, cap, bo_slot.p);
+                            hipLaunchKernelGGL(flex_verify_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->bytes.p, bo_off.p, bo_flen.p, npos, bo_table.p, bo_slot.p, bo_isrep.p, bo_info.p);
+                        }
+                        FlexInfo got{};
+                        HIP_TRY(c, hipMemcpyAsync(&got, bo_info.p, sizeof got, hipMemcpyDeviceToHost, c->stream));
+                        HIP_TRY(c, hipStreamSynchronize(c->stream));
+                        HIP_TRY(c, hipGetLastError());
+                        grouped = !got.collision;
+                    }
+                    if (!grouped) return fail(c, COLIBRI_ERR_OVERFLOW, "back-off pass: hash collisions under four seeds");
+                    {
+                        Prof p(c, COLIBRI_K_PRUNE);
+                        hipLaunchKernelGGL(backoff_keep_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, bo_isrep.p, bo_table.p, bo_slot.p, npos, pl.thr, bo_keep.p, c->state.p);
+                    }
+                    unsigned long long kk = 0;
+                    if ((rc = scan_u32(c, bo_keep.p, npos, bo_rank.p, &kk))) return rc;
+                    kept_here = (uint32_t)kk;
+                    Prof p(c, COLIBRI_K_PRUNE);
+                    hipLaunchKernelGGL(backoff_results_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, bo_keep.p, bo_rank.p, bo_table.p, bo_slot.p, npos, res_total, pl.res_cap,
+                                       c->res_rep.p, c->res_cnt.p, c->state.p);
+                    hipLaunchKernelGGL(backoff_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, bo_flen.p, bo_table.p, bo_slot.p, npos, c->ids[n].p, c->state.p);
+                } else {
+                    HIP_TRY(c, hipMemsetAsync(c->ids[n].p, 0xFF, sizeof(uint32_t) * (size_t)npos, c->stream));
+                }
+                HIP_TRY(c, hipMemcpyAsync(&c->state.p->kept, &kept_here, sizeof kept_here, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                list_valid = false;
+            } else if (n == 1 && uni_synced) {
                 // order 1 on the class-indexed count array (as in the plain mode): no hashing, no table; the survivor id of a unigram is its
                 // RESULT index here, read per position through a class -> result table
                 const uint32_t nclasses = c->maxclass + 1;
@@ -1325,7 +1401,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             if (!constrained) c->hstate.cap = (uint32_t)std::min<uint64_t>(pl.table_slots, (uint64_t)valid_n[n] + (valid_n[n] >> 1) + 1024u);
             c->hstate.found = c->hstate.kept = c->hstate.admitted = c->hstate.valid = 0;
             if ((rc = write_state(c))) return rc;
-            if (valid_n[n] == 0 && !constrained) break;  // nothing can be admitted at n + 1
+            if (valid_n[n] == 0 && !constrained && !(backoff && n >= backoff + 1)) break;  // nothing can be admitted at n + 1 (a back-off order asks the order-b survivors instead)
         }
         if (o.doskipgrams) {  // IndexedPatternModel::trainskipgrams (patternmodel.h:2969-3010): from the SURVIVING n-grams, n = 3..
             for (int n = 3; n <= std::min<int>(maxlength, s.maxn); ++n) {

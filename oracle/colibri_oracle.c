@@ -472,10 +472,14 @@ co_model* co_train(const uint8_t* payload, uint64_t nbytes, const co_options* op
                         if (!(e && e->alive && e->count >= wthr)) found = 0;
                     }
                 }
-                if (found && n > 1) { /* look-back: both (n-1)-grams must be in the model :1139-1152 */
-                    const uint32_t l1 = (uint32_t)(t.start[i + n - 1] - t.start[i]);
-                    const uint32_t l2 = (uint32_t)(t.start[i + n] - t.start[i + 1]);
-                    found = map_has(m, w, l1) && map_has(m, payload + t.start[i + 1], l2);
+                if (found && n > 1 && thr > 1) { /* look-back :1139-1152: every sub-pattern of backoffn = min(n-1, MAXBACKOFFLENGTH) tokens must be in the model
+                                                    (both (n-1)-grams when the back-off length does not bite); no look-back at MINTOKENS = 1 */
+                    int backoffn = n - 1;
+                    if (opt.maxbackofflength > 0 && backoffn > opt.maxbackofflength) backoffn = opt.maxbackofflength;
+                    for (int k = 0; k + backoffn <= n && found; ++k) {
+                        const uint32_t l = (uint32_t)(t.start[i + k + backoffn] - t.start[i + k]);
+                        found = map_has(m, payload + t.start[i + k], l);
+                    }
                 }
                 const co_ref ref = {sentence, (uint16_t)i}; /* :1155 */
                 if (found) entry_add(m, map_get_or_insert(m, w, wlen, (uint16_t)n, 0), ref); /* :1160 */

@@ -29,7 +29,8 @@ typedef struct co_options {
     int32_t doskipgrams;            /* DOSKIPGRAMS (indexed models only)                   */
     int32_t doskipgrams_exhaustive; /* DOSKIPGRAMS_EXHAUSTIVE                              */
     int32_t indexed;                /* 0: PatternModel<uint32_t>, 1: IndexedPatternModel<> */
-    int32_t mintokens_unigrams;     /* MINTOKENS_UNIGRAMS (-W): words of longer patterns must occur this often (no skipgrams) */
+    int32_t mintokens_unigrams;     /* MINTOKENS_UNIGRAMS (-W): words of longer patterns must occur this often */
+    int32_t maxbackofflength;       /* MAXBACKOFFLENGTH (-b): the look-back checks the sub-patterns of min(n-1, this) tokens; 0 = no limit */
 } co_options;
 
 typedef struct co_model co_model;

@@ -27,6 +27,7 @@ class Options(C.Structure):
         ("doskipgrams_exhaustive", C.c_int32),
         ("indexed", C.c_int32),
         ("mintokens_unigrams", C.c_int32),
+        ("maxbackofflength", C.c_int32),
     ]
 
 
@@ -96,13 +97,13 @@ class Model:
         return len(self.counts)
 
 
-def train(payload: bytes, mintokens=2, maxlength=100, *, mintokens_unigrams=0, indexed=False, doskipgrams=False, doskipgrams_exhaustive=False,
+def train(payload: bytes, mintokens=2, maxlength=100, *, mintokens_unigrams=0, maxbackofflength=0, indexed=False, doskipgrams=False, doskipgrams_exhaustive=False,
           minskiptypes=2, maxskips=3, mintokens_skipgrams=-1, firstsentence=1) -> Model:
     """PatternModel::train on a v2 payload (header stripped) with the C restatement."""
     L = lib()
     src = np.frombuffer(payload, dtype=np.uint8) if len(payload) else np.zeros(0, dtype=np.uint8)
     opt = Options(mintokens, maxlength, mintokens_skipgrams, minskiptypes, maxskips, int(doskipgrams), int(doskipgrams_exhaustive),
-                  int(indexed), mintokens_unigrams)
+                  int(indexed), mintokens_unigrams, maxbackofflength)
     ptr = src.ctypes.data if src.size else None
     m = L.co_train(ptr, src.size, C.byref(opt), firstsentence)
     if not m:

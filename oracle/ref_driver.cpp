@@ -266,6 +266,7 @@ int main(int argc, char** argv) {
         else if (a == "-W" && i + 1 < argc) options.MINTOKENS_UNIGRAMS = atoi(argv[++i]);
         else if (a == "-p" && i + 1 < argc) options.PRUNENONSUBSUMED = atoi(argv[++i]);
         else if (a == "-S" && i + 1 < argc) options.PRUNESUBSUMED = atoi(argv[++i]);
+        else if (a == "-b" && i + 1 < argc) options.MAXBACKOFFLENGTH = atoi(argv[++i]);
         else if (a == "-L") { options.DOPATTERNPERLINE = true; options.MINTOKENS = 1; }  // patternmodeller -L: one pattern per line, implies -t 1 (src/patternmodeller.cpp:571-574, :677-678)
         else if (a == "-F") flexfromskip = true;  // computeflexgrams_fromskipgrams after training (patternmodeller -F S, src/patternmodeller.cpp:790-794), mode is
         else if (a == "-I" && i + 1 < argc) inplacemodel = argv[++i];  // constrained in-place rebuild of this model (patternmodeller -I -i <model>), modes u and i

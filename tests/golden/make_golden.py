@@ -116,6 +116,12 @@ def main():
     for name, l in [("shortlines", 2), ("shortlines", 100), ("edge", 3), ("edge", 100), ("zipf20k", 100), ("hamlet.v2", 100)]:
         out = os.path.join(HERE, f"patternlist.{name}.L{l}.txt")
         subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{name}.colibri.dat"), "u", str(l), "1", "-q", "-L", "-d", out], stdout=subprocess.DEVNULL)
+    # MAXBACKOFFLENGTH (-b) below the longest pattern: same model, other candidate counts per order
+    for name in ["hamlet.v2", "edge"]:
+        for mode in ("u", "i"):
+            for b in (1, 2):
+                out = os.path.join(HERE, f"backoff.{name}.{mode}.b{b}.txt")
+                subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{name}.colibri.dat"), mode, "8", "2", "-q", "-b", str(b), "-d", out], stdout=subprocess.DEVNULL)
     # MINLENGTH = 3: the shorter orders are counted for the look-back and pruned away afterwards
     for name in ["hamlet.v2", "zipf20k"]:
         for mode in ("u", "i", "is", "us"):

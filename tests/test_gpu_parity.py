@@ -144,6 +144,16 @@ def test_pattern_per_line_needs_terminated_lines_and_threshold_one(ctx):
         ctx.train(mintokens=2, dopatternperline=1)
 
 
+@pytest.mark.parametrize("name", ["rand1", "rand3", "repeat", "one_long_sentence", "zipf20k", "zipf200k_phrases", "cls_2p21"])
+@pytest.mark.parametrize("backoff", [1, 2, 3])
+@pytest.mark.parametrize("indexed", [0, 1])
+def test_max_backoff_length(ctx, name, backoff, indexed):
+    """MAXBACKOFFLENGTH below the longest pattern: above order backoff + 1 the look-back only asks for the sub-patterns of `backoff` tokens. The model is
+    the same as without it (a pattern that reaches the threshold has sub-patterns that do); the candidates found and pruned per order, and the
+    last order that found any, are not — all compared."""
+    _compare(ctx, small_corpora()[name], 7, 2, maxbackofflength=backoff, indexed=indexed)
+
+
 def test_hamlet_fixture_known_answers(ctx, hamlet_payload):
     """reference src/test.cpp:1214-1221: 111 patterns / 186 types / 354 tokens with default options;
     config 1 of BASELINE.json: n <= 3 -> 81 patterns (45/22/14)."""
@@ -169,7 +179,7 @@ def test_unsupported_options_fail_loudly(ctx):
     from colibri_amd import capi
     ctx.upload(small_corpora()["rand0"])
     with pytest.raises(capi.ColibriError):
-        ctx.train(maxlength=5, maxbackofflength=2)
+        ctx.train(maxlength=5, maxbackofflength=2, doskipgrams_exhaustive=1)
     with pytest.raises(capi.ColibriError):
         ctx.train(dopatternperline=1, indexed=1, mintokens=1)
     with pytest.raises(capi.ColibriError):

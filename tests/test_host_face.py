@@ -108,7 +108,24 @@ def test_cxx_api_preloaded_corpus(tmp_path):
 @pytest.mark.gpu
 def test_cxx_api_errors_are_internalerror(tmp_path):
     out = subprocess.run([SELFTEST, "gpu", os.path.join(GOLDEN, "hamlet.v2.colibri.dat"), str(tmp_path / "m"), "is", "5", "2", "b2"], capture_output=True, text=True)
-    assert out.returncode == 1 and "EXCEPTION" in out.stdout  # MAXBACKOFFLENGTH < MAXLENGTH is outside the accelerated subset: loud failure, no fallback
+    assert out.returncode == 1 and "EXCEPTION" in out.stdout  # MAXBACKOFFLENGTH < MAXLENGTH with skipgrams is outside the accelerated subset: loud failure, no fallback
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("corpus", ["hamlet.v2", "edge"])
+@pytest.mark.parametrize("mode,flags", [("u", ["-u"]), ("i", [])])
+@pytest.mark.parametrize("b", [1, 2])
+def test_cli_max_backoff_length(tmp_path, corpus, mode, flags, b):
+    """-b: goldens by the real reference (the model; the per-order candidate counts are compared through the C ABI in test_gpu_parity.py)"""
+    import oracle
+    model = str(tmp_path / "m.colibri.patternmodel")
+    out = subprocess.run([CLI, "-f", os.path.join(GOLDEN, corpus + ".colibri.dat"), "-t", "2", "-l", "8", "-b", str(b), "-o", model] + flags, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    want = oracle.parse_dump(open(os.path.join(GOLDEN, f"backoff.{corpus}.{mode}.b{b}.txt")).read(), indexed=mode == "i")
+    mtype, tokens, types, counts, refs = parse_model(model)
+    assert (tokens, types, counts) == (want.tokens, want.types, want.counts)
+    if mode == "i":
+        assert refs == want.refs
 
 
 @pytest.mark.gpu

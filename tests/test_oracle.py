@@ -91,6 +91,17 @@ def test_patternlist_restatement_matches_reference_dumps(path):
     assert (got.tokens, got.types, got.counts) == (want.tokens, want.types, want.counts)
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "backoff.*.txt"))), ids=os.path.basename)
+def test_oracle_matches_reference_backoff_goldens(path):
+    """MAXBACKOFFLENGTH (-b) 1 and 2 at MAXLENGTH 8: dumps of the real reference"""
+    name, mode, b = os.path.basename(path)[len("backoff."):-len(".txt")].rsplit(".", 2)
+    want = oracle.parse_dump(open(path).read(), indexed=mode == "i")
+    got = oracle.train(read_payload(name), 2, 8, indexed=mode == "i", maxbackofflength=int(b[1:]))
+    assert (got.tokens, got.types, got.counts) == (want.tokens, want.types, want.counts)
+    if mode == "i":
+        assert got.refs == want.refs
+
+
 def test_hamlet_fixture_model_file():
     """exp/hamlet.v1.colibri.patternmodel (the reference's only committed golden model): 111 patterns, tokens 354, types 186."""
     raw = open(os.path.join(GOLDEN, "hamlet.v1.colibri.patternmodel"), "rb").read()

@@ -80,6 +80,8 @@ def make_options(rng):
             if rng.integers(0, 2) and o["doskipgrams_exhaustive"]:
                 o["mintokens_skipgrams"] = int(rng.integers(1, 4))
     o["table_mode"] = int(rng.choice([0, 0, 0, 1, 2])) if mode == 0 else 0
+    if mode in (0, 2) and o["mintokens"] >= 2 and o["table_mode"] != 2 and rng.integers(0, 3) == 0:  # back-off length below the longest pattern
+        o["maxbackofflength"] = int(rng.integers(1, max(2, o["maxlength"])))
     return o
 
 

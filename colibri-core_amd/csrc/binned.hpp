@@ -117,32 +117,31 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
             }
         }
         __syncthreads();
+        // A window whose election slot is held by a DIFFERENT key gets a second chance below: two frequent keys sharing a slot would otherwise make
+        // every occurrence of the loser its own record, tile after tile, and flood one A-bin sub-region. The losers elect among themselves in another
+        // slot of the same array (stale first-round winners there carry other keys and are ignored by the key check).
         uint32_t rep[kCountPer];
+        bool     lost[kCountPer];
+        bool     anylost = false;
 #pragma unroll
         for (int k = 0; k < kCountPer; ++k) {
             const uint32_t e = k * kBlock + threadIdx.x;
             rep[k]           = e;
+            lost[k]          = false;
             if (adm[k]) {
                 ++nadm;
                 const uint32_t w = winL[(uint32_t)hash[k] & (kCountLSlot - 1)];
-                if (w != e && keyL[w] == key[k]) {
-                    rep[k] = w;
-                    atomicAdd(&cntL[w], 1u);
+                if (w != e) {
+                    if (keyL[w] == key[k]) {
+                        rep[k] = w;
+                        atomicAdd(&cntL[w], 1u);
+                    } else {
+                        lost[k] = anylost = true;
+                    }
                 }
             }
         }
-        // second chance for the windows whose election slot is held by a DIFFERENT key (two frequent keys sharing a slot would otherwise make
-        // every occurrence of the loser its own record, tile after tile, and flood one A-bin sub-region): the losers elect among themselves in
-        // another slot of the same array (stale first-round winners there carry other keys and are ignored by the key check)
-        bool lost[kCountPer];
-        bool anylost = false;
-#pragma unroll
-        for (int k = 0; k < kCountPer; ++k) {
-            const uint32_t e = k * kBlock + threadIdx.x;
-            lost[k]          = adm[k] && rep[k] == e && winL[(uint32_t)hash[k] & (kCountLSlot - 1)] != e;
-            anylost |= lost[k];
-        }
-        if (__syncthreads_or(anylost)) {  // (also orders the first-round reads before the second-round writes)
+        if (__syncthreads_or(anylost)) {  // the barrier that ends the election — unless some window lost its slot to another key (rare): then a second round
 #pragma unroll
             for (int k = 0; k < kCountPer; ++k)
                 if (lost[k]) winL[(uint32_t)(hash[k] >> 20) & (kCountLSlot - 1)] = k * kBlock + threadIdx.x;
@@ -157,8 +156,9 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
                     atomicAdd(&cntL[w], 1u);
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();  // election done: keyL / winL are dead from here, cntL is complete
+        // election done: keyL / winL are dead from here, cntL is complete
         uint32_t rank[kCountPer];
 #pragma unroll
         for (int k = 0; k < kCountPer; ++k) {

@@ -424,20 +424,45 @@ __global__ __launch_bounds__(kBlock) void count_kernel(KeyFn keyfn, uint32_t* __
             }
         }
         __syncthreads();
+        // a window that finds a DIFFERENT key in its election slot gets a second round in another slot: two frequent keys sharing a slot would
+        // otherwise send every occurrence of the loser to the table on its own (same-address atomics, ~12 ns each)
         uint32_t rep[kCountPer];
+        bool     lost[kCountPer];
+        bool     anylost = false;
 #pragma unroll
         for (int k = 0; k < kCountPer; ++k) {
             const uint32_t e = k * kBlock + threadIdx.x;
             rep[k]           = e;
+            lost[k]          = false;
             if (adm[k]) {
                 const uint32_t w = winL[(uint32_t)hash[k] & (kCountLSlot - 1)];
+                if (w != e) {
+                    if (keyL[w] == key[k]) {
+                        rep[k] = w;
+                        atomicAdd(&cntL[w], 1u);
+                    } else {
+                        lost[k] = anylost = true;
+                    }
+                }
+            }
+        }
+        if (__syncthreads_or(anylost)) {
+#pragma unroll
+            for (int k = 0; k < kCountPer; ++k)
+                if (lost[k]) winL[(uint32_t)(hash[k] >> 20) & (kCountLSlot - 1)] = k * kBlock + threadIdx.x;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kCountPer; ++k) {
+                if (!lost[k]) continue;
+                const uint32_t e = k * kBlock + threadIdx.x;
+                const uint32_t w = winL[(uint32_t)(hash[k] >> 20) & (kCountLSlot - 1)];
                 if (w != e && keyL[w] == key[k]) {
                     rep[k] = w;
                     atomicAdd(&cntL[w], 1u);
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
 #pragma unroll
         for (int k = 0; k < kCountPer; ++k) {
             const uint32_t e = k * kBlock + threadIdx.x;

@@ -1033,6 +1033,29 @@ class IndexedPatternModel : public PatternModel<IndexedData, IndexedDataHandler,
             rt.push_back(0);
             colibri_host::device_flexgrams(key_off, key_bytes.data(), ref_off, rs.data(), rt.data(), flex);
         }
+        if (this->result) {
+            // the model has not been turned into map nodes yet: the flexgrams are appended to its flat arrays (no pattern of a freshly trained model
+            // is a flexgram — a corpus with a literal {**} token is refused at upload — so every one of them is new)
+            colibri_host::TrainResult& r   = *this->result;
+            const size_t               np  = r.size(), nf = flex.size();
+            const uint64_t             kb  = r.key_off[np], nr = r.ref_off[np], fkb = flex.key_off[nf], fnr = flex.ref_off[nf];
+            r.key_bytes.resize((size_t)(kb + fkb) + 1);
+            std::memcpy(r.key_bytes.data() + kb, flex.key_bytes.data(), (size_t)fkb);
+            r.ref_sentence.resize((size_t)(nr + fnr) + 1);
+            r.ref_token.resize((size_t)(nr + fnr) + 1);
+            std::memcpy(r.ref_sentence.data() + nr, flex.ref_sentence.data(), (size_t)fnr * sizeof(uint32_t));
+            std::memcpy(r.ref_token.data() + nr, flex.ref_token.data(), (size_t)fnr * sizeof(uint16_t));
+            r.key_off.resize(np + nf + 1);
+            r.ref_off.resize(np + nf + 1);
+            r.counts.resize(np + nf);
+            for (size_t j = 0; j < nf; ++j) {
+                r.key_off[np + j + 1] = kb + flex.key_off[j + 1];
+                r.ref_off[np + j + 1] = nr + flex.ref_off[j + 1];
+                r.counts[np + j]      = flex.counts[j];
+            }
+            r.stats.npatterns = np + nf;
+            return (int)nf;
+        }
         int count = 0;
         for (size_t j = 0; j < flex.size(); ++j) {
             const Pattern flexgram(flex.key_bytes.data() + flex.key_off[j], (size_t)(flex.key_off[j + 1] - flex.key_off[j]));

@@ -128,7 +128,19 @@ inline void write_value_from_result(std::ostream& out, const TrainResult& r, siz
 inline void write_value_from_result(std::ostream& out, const TrainResult& r, size_t j, const IndexedData*) {
     const uint32_t c = r.ref_off.empty() ? 0 : (uint32_t)(r.ref_off[j + 1] - r.ref_off[j]);
     out.write((const char*)&c, sizeof(uint32_t));
-    for (uint32_t k = 0; k < c; ++k) IndexReference(r.ref_sentence[r.ref_off[j] + k], r.ref_token[r.ref_off[j] + k]).write(out);
+    // the 6-byte (u32 sentence, u16 token) records of the file format (reference include/datatypes.h:60-63), packed in blocks: one stream write per block
+    // instead of two per reference
+    unsigned char  buf[6 * 1024];
+    const uint64_t a = r.ref_off.empty() ? 0 : r.ref_off[j];
+    for (uint32_t k = 0; k < c;) {
+        const uint32_t n = std::min<uint32_t>(c - k, 1024u);
+        for (uint32_t q = 0; q < n; ++q) {
+            std::memcpy(buf + 6 * q, &r.ref_sentence[a + k + q], 4);
+            std::memcpy(buf + 6 * q + 4, &r.ref_token[a + k + q], 2);
+        }
+        out.write((const char*)buf, (std::streamsize)(6 * n));
+        k += n;
+    }
 }
 template <class V>
 struct is_indexed_value {

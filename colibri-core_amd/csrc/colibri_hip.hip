@@ -89,6 +89,7 @@ struct colibri_ctx {
         DevBuf<uint32_t>           memb;   // pattern number of the window at each position, kProbeLengths lengths at a time
         uint32_t                   n = 0, cap = 0;
         bool                       rem_valid = false;
+        bool                       closed = false;  // every pattern's prefix (without its last token) is a pattern too: the probe may stop at the first miss
     } cs;
     struct TextState {                  // class encoder (textenc.hpp): the uploaded text, its word table, the encoded stream
         DevBuf<uint8_t>            text, out;
@@ -1225,7 +1226,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             // a length's distinct keys are patterns of J: the table never needs more slots than that
             c->hstate.cap = (uint32_t)std::min<uint64_t>(pl.table_slots, (uint64_t)c->cs.n + (c->cs.n >> 1) + 1024u);
             if ((rc = write_state(c))) return rc;
-            if ((rc = dev_alloc(c, c->cs.memb, (size_t)kProbeLengths * ((size_t)npos + 1)))) return rc;
+            if ((rc = dev_alloc(c, c->cs.memb, (size_t)(kProbeLengths + 1) * ((size_t)npos + 1)))) return rc;  // + one array: who was alive after the previous block of lengths
         }
         int probed_from = 0, probed_to = -1;  // window lengths whose membership arrays are current
         // back-off passes (MAXBACKOFFLENGTH): per-position scratch of the byte-grouping kernels
@@ -1248,8 +1249,18 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                 probed_from = n;
                 probed_to   = std::min(maxlength, n + kProbeLengths - 1);
                 Prof p(c, COLIBRI_K_COUNT);
-                hipLaunchKernelGGL(constraint_probe_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, c->cs.rem.p, c->cs.table.p, c->cs.cap, c->cs.bytes.p,
-                                   c->cs.off.p, npos, probed_from, probed_to - probed_from + 1, c->cs.memb.p, (size_t)npos + 1);
+                // a prefix-closed set probed from length 1 on stops at the first miss; the last length of a block of eight tells the next block who is still alive
+                const bool early = c->cs.closed && (std::max(1, o.minlength) == 1);
+                if (early && probed_from > 1)
+                    HIP_TRY(c, hipMemcpyAsync(c->cs.memb.p + (size_t)kProbeLengths * ((size_t)npos + 1), c->cs.memb.p + (size_t)(kProbeLengths - 1) * ((size_t)npos + 1),
+                                              sizeof(uint32_t) * (size_t)npos, hipMemcpyDeviceToDevice, c->stream));
+                if (early)
+                    hipLaunchKernelGGL(constraint_probe_kernel<true>, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, c->cs.rem.p, c->cs.table.p, c->cs.cap,
+                                       c->cs.bytes.p, c->cs.off.p, npos, probed_from, probed_to - probed_from + 1, c->cs.memb.p, (size_t)npos + 1,
+                                       probed_from > 1 ? (const uint32_t*)(c->cs.memb.p + (size_t)kProbeLengths * ((size_t)npos + 1)) : (const uint32_t*)nullptr);
+                else
+                    hipLaunchKernelGGL(constraint_probe_kernel<false>, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, c->cs.rem.p, c->cs.table.p, c->cs.cap,
+                                       c->cs.bytes.p, c->cs.off.p, npos, probed_from, probed_to - probed_from + 1, c->cs.memb.p, (size_t)npos + 1, (const uint32_t*)nullptr);
             }
             const KeyMember member{c->cs.memb.p + (size_t)(constrained ? n - probed_from : 0) * ((size_t)npos + 1)};
             if (!(n == 1 && uni_synced) && !radix_pass) launch_clear(c, pl);  // only the table passes need the table cleared

@@ -62,6 +62,41 @@ __global__ __launch_bounds__(kBlock) void constraint_insert_kernel(const uint8_t
         }
     }
 }
+// pattern number of the key (bytes, len) with hash h, kInvalid if J does not hold it; `c` = the slot at `s`, already loaded
+__device__ __forceinline__ uint32_t constraint_lookup(const uint8_t* __restrict__ key, uint32_t len, uint64_t h, CSlot c, uint32_t s, const CSlot* __restrict__ table, uint32_t cap,
+                                                      const uint8_t* __restrict__ jbytes, const unsigned long long* __restrict__ joff) {
+    for (uint32_t probe = 0; probe < cap; ++probe) {
+        if (c.hash == kEmptyKey) return kInvalid;
+        if (c.hash == h && c.len == len) {
+            const uint8_t* q    = jbytes + joff[c.idx];
+            bool           same = true;
+            uint32_t       k    = 0;
+            for (; same && k + 8 <= len; k += 8) same = ld64u(key + k) == ld64u(q + k);
+            for (; same && k < len; ++k) same = key[k] == q[k];
+            if (same) return c.idx;
+        }
+        s = (s + 1 == cap) ? 0 : s + 1;
+        c = table[s];
+    }
+    return kInvalid;
+}
+// Is J prefix-closed — does every pattern of two or more tokens have its pattern without the last token in J too? A model built with the
+// look-back is. Then a window can only be a member if the window one token shorter is, and the probe stops at the first miss.
+__global__ __launch_bounds__(kBlock) void constraint_closed_kernel(const uint8_t* __restrict__ jbytes, const unsigned long long* __restrict__ joff, uint32_t npatterns,
+                                                                    const CSlot* __restrict__ table, uint32_t cap, uint32_t* __restrict__ open_flag) {
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < npatterns; p += gridDim.x * kBlock) {
+        const uint8_t* key = jbytes + joff[p];
+        const uint32_t len = (uint32_t)(joff[p + 1] - joff[p]);
+        if (len == 0) continue;
+        uint32_t cut = 0;  // start of the last token
+        for (uint32_t i = 0; i + 1 < len; ++i)
+            if (key[i] < 128) cut = i + 1;
+        if (cut == 0) continue;  // one token
+        const uint64_t h = fold_hash_key(key, cut);
+        const uint32_t s = slot_of_hash(mix64(h), cap);
+        if (constraint_lookup(key, cut, h, table[s], s, table, cap, jbytes, joff) == kInvalid) *open_flag = 1;
+    }
+}
 // tokens left in the sentence from position i on (0 at a delimiter): a window of n tokens at i exists iff rem[i] >= n
 __global__ __launch_bounds__(kBlock) void sentence_rem_kernel(const uint32_t* __restrict__ delimpos, uint32_t ndelim, uint32_t npos, uint32_t* __restrict__ rem) {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npos; i += gridDim.x * kBlock) {
@@ -77,10 +112,11 @@ __global__ __launch_bounds__(kBlock) void sentence_rem_kernel(const uint32_t* __
     }
 }
 // memb[(n - n0) * stride + i] = pattern number in J of the window of n tokens at position i (n0 <= n < n0 + nlen), kInvalid if it is none
+template <bool CLOSED>
 __global__ __launch_bounds__(kBlock) void constraint_probe_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ tokstart, const uint32_t* __restrict__ rem,
                                                                    const CSlot* __restrict__ table, uint32_t cap, const uint8_t* __restrict__ jbytes,
                                                                    const unsigned long long* __restrict__ joff, uint32_t npos, int n0, int nlen, uint32_t* __restrict__ memb,
-                                                                   size_t stride) {
+                                                                   size_t stride, const uint32_t* __restrict__ alive_in /* CLOSED: the window of n0 - 1 tokens was a member */) {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npos; i += gridDim.x * kBlock) {
         const uint32_t r = rem[i];  // tokens left in the sentence (0 at a delimiter)
         uint64_t       hs[kProbeLengths];
@@ -115,6 +151,23 @@ __global__ __launch_bounds__(kBlock) void constraint_probe_kernel(const uint8_t*
                 bl[j]            = te[j] - a0;
             }
         }
+        if (CLOSED) {
+            // prefix-closed J: one look-up after the other, and none after the first miss (fewer look-ups beat having them all in flight:
+            // the probe is bound by the number of random 16-byte requests)
+            bool alive = alive_in == nullptr || alive_in[i] != kInvalid;
+#pragma unroll
+            for (int j = 0; j < kProbeLengths; ++j) {
+                if (j >= nlen) break;
+                uint32_t found = kInvalid;
+                if (alive && (uint32_t)(n0 + j) <= r) {
+                    const uint32_t s = slot_of_hash(mix64(hs[j]), cap);
+                    found            = constraint_lookup(bytes + a0, bl[j], hs[j], table[s], s, table, cap, jbytes, joff);
+                }
+                alive                        = found != kInvalid;
+                memb[(size_t)j * stride + i] = found;
+            }
+            continue;
+        }
         // all first probes of this position are issued before any is looked at
 #pragma unroll
         for (int j = 0; j < kProbeLengths; ++j) {
@@ -127,26 +180,7 @@ __global__ __launch_bounds__(kBlock) void constraint_probe_kernel(const uint8_t*
         for (int j = 0; j < kProbeLengths; ++j) {
             if (j >= nlen) break;
             uint32_t found = kInvalid;
-            if ((uint32_t)(n0 + j) <= r) {
-                CSlot    c = first[j];
-                uint32_t s = sl[j];
-                for (uint32_t probe = 0; probe < cap; ++probe) {
-                    if (c.hash == kEmptyKey) break;
-                    if (c.hash == hs[j] && c.len == bl[j]) {
-                        const uint8_t* q    = jbytes + joff[c.idx];
-                        bool           same = true;
-                        uint32_t       k    = 0;
-                        for (; same && k + 8 <= bl[j]; k += 8) same = ld64u(bytes + a0 + k) == ld64u(q + k);
-                        for (; same && k < bl[j]; ++k) same = bytes[a0 + k] == q[k];
-                        if (same) {
-                            found = c.idx;
-                            break;
-                        }
-                    }
-                    s = (s + 1 == cap) ? 0 : s + 1;
-                    c = table[s];
-                }
-            }
+            if ((uint32_t)(n0 + j) <= r) found = constraint_lookup(bytes + a0, bl[j], hs[j], first[j], sl[j], table, cap, jbytes, joff);
             memb[(size_t)j * stride + i] = found;
         }
     }

@@ -96,6 +96,11 @@ def random_constraint(rng, payload, maxlength, oracle):
         else:
             keys.add(bytes(int(x) for x in rng.integers(6, 40, size=n)))
     keys.discard(b"")
+    if rng.integers(0, 2):  # a prefix-closed set (what a model built with the look-back is): the probe then stops at a position's first miss
+        for k in list(keys):
+            t = oracle.key_tokens(k)
+            for n in range(1, len(t)):
+                keys.add(b"".join(t[:n]))
     if not keys:
         keys.add(b"\x06")  # an empty set LIFTS the constraint at the C ABI (the C++ face handles the empty model itself)
     return sorted(keys)

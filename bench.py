@@ -124,6 +124,9 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
+            # RCCL's version banner goes to stdout through C stdio and would land after the JSON line: keep stdout to that one line
+            if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
+                os.environ["NCCL_DEBUG"] = "NONE"
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)

@@ -322,18 +322,23 @@ __global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restri
     const uint32_t bsh = bs->bshift;
     histL[threadIdx.x] = 0;
     __syncthreads();
-    Rec      r[kScatPer];
+    // the records travel as plain 16-byte vectors (x, y = key; z = pos; w = meta): a Rec array here ended up in scratch memory
+    static_assert(sizeof(Rec) == sizeof(uint4), "a record is one 16-byte vector");
+    const uint4* const in4   = reinterpret_cast<const uint4*>(in);
+    uint4* const       recL4 = reinterpret_cast<uint4*>(recL);
+    uint4    r[kScatPer];
     uint32_t rank[kScatPer];
 #pragma unroll
     for (int q = 0; q < kScatPer; ++q) {  // loads first, LDS atomics after (see bin_hist2_kernel)
         const uint32_t j = begin + q * kBlock + threadIdx.x;
-        if (j < end) r[q] = in[j];
+        r[q]             = (j < end) ? in4[j] : make_uint4(0u, 0u, 0u, 0u);
     }
 #pragma unroll
     for (int q = 0; q < kScatPer; ++q) {
         const uint32_t j = begin + q * kBlock + threadIdx.x;
+        rank[q]          = 0;
         if (j < end) {
-            const uint32_t b = ((r[q].meta >> 16) & 255u) >> bsh;
+            const uint32_t b = ((r[q].w >> 16) & 255u) >> bsh;
             rank[q]          = atomicAdd(&histL[b], 1u);
         }
     }
@@ -351,16 +356,17 @@ __global__ __launch_bounds__(kBlock) void bin_scatter_kernel(const Rec* __restri
     for (int q = 0; q < kScatPer; ++q) {
         const uint32_t j = begin + q * kBlock + threadIdx.x;
         if (j < end) {
-            const uint32_t b       = ((r[q].meta >> 16) & 255u) >> bsh;
-            recL[offL[b] + rank[q]] = r[q];
+            const uint32_t b         = ((r[q].w >> 16) & 255u) >> bsh;
+            recL4[offL[b] + rank[q]] = r[q];
         }
     }
     __syncthreads();
-    const uint32_t n = end - begin;
+    const uint32_t n    = end - begin;
+    uint4* const   out4 = reinterpret_cast<uint4*>(out);
     for (uint32_t j = threadIdx.x; j < n; j += kBlock) {
-        const Rec      x = recL[j];
-        const uint32_t b = ((x.meta >> 16) & 255u) >> bsh;
-        out[gbaseL[b] + (j - offL[b])] = x;
+        const uint4    x = recL4[j];
+        const uint32_t b = ((x.w >> 16) & 255u) >> bsh;
+        out4[gbaseL[b] + (j - offL[b])] = x;
     }
 }
 

@@ -1,0 +1,982 @@
+// bigram2.hpp — order 2 of the plain run, second generation of the radix path (gfx950, wave64).
+//
+// Order 2 is the heaviest pass of PatternModel::train on a class-encoded corpus (reference include/patternmodel.h:1078-1178: window loop,
+// look-back :1139-1152, add :2059-2073, prune :2107-2128): nearly every window is admissible and half of them are singletons. The first
+// generation (binned.hpp) moved every window five times across HBM as a 16-byte record, elected representatives per tile and scattered
+// survivor bytes back to representative positions (one 32-byte sector per record). This file does the same pass with
+//   * 8-byte records: the key (two class ids, 42 bits) travels as its BIJECTIVE 42-bit mix; 8 bits of it are implied by the level-A bin the
+//     record lies in, the other 34 share the word with the 27-bit corpus position. Distinct bigrams can never merge: inside a final bin the
+//     31 low bits of the mix identify the key exactly (the bin fixes the rest);
+//   * no election and no rep_of array: the Zipf head (both classes < 64; class ids are frequency-ranked, reference src/classencoder.cpp:220-224)
+//     is counted in a dense 64 x 64 LDS histogram per block and never becomes a record, so no bin and no region is skewed by a hot key;
+//   * level B without histogram pass and without atomics: every (sub-region, A bin) slot is partitioned by ONE block (histogram sweep, then a
+//     move sweep that re-reads the slot from L2 / Infinity Cache), so a final bin is the concatenation of nsub short runs;
+//   * no scatter back to positions: the count kernel appends the positions of the windows whose bigram survived to per-position-bucket lists
+//     through LDS write-combining queues, bi2_bitmap_kernel turns each bucket's list into a bitmap (built in LDS, one bit per position), and
+//     bi2_list3_kernel streams over the corpus once to emit the active list of order 3 (positions i with surviving bigrams at i and i + 1).
+// The kernels that walk bins or tiles are software-pipelined (the loads of the next bin / tile are in flight while the current one is in LDS):
+// a bin is latency-bound, not bandwidth-bound.
+// Results (representative position + count per surviving bigram) go to the same result arrays as every other order.
+// Anything this path cannot hold (a slot, a final bin's LDS table) raises Bi2State::overflow; the host then re-runs on the first-generation kernels.
+#pragma once
+#include "binned.hpp"
+
+namespace colibri {
+
+// ---- the bijective 42-bit mix ---------------------------------------------------------------------------------------------------
+constexpr uint64_t kMix42Mask = (1ull << 42) - 1;
+constexpr uint64_t kMix42C1   = 0xff51afd7ed558ccdULL & kMix42Mask;  // odd
+constexpr uint64_t kMix42C2   = 0xc4ceb9fe1a85ec53ULL & kMix42Mask;  // odd
+__host__ __device__ __forceinline__ uint64_t mix42(uint64_t x) {  // x < 2^42; xor-shifts and odd multiplications mod 2^42 are bijections
+    x ^= x >> 21;
+    x = (x * kMix42C1) & kMix42Mask;
+    x ^= x >> 20;
+    x = (x * kMix42C2) & kMix42Mask;
+    x ^= x >> 21;
+    return x;
+}
+
+constexpr int      kBi2Threads  = 1024;                   // emit / level-B block (wide blocks, few items per lane: short LDS chains, 32 waves per CU)
+constexpr int      kBi2Per      = 4;                      // items per lane
+constexpr int      kBi2Tile     = kBi2Threads * kBi2Per;  // 4096 windows (records) per tile
+constexpr int      kBi2Head     = 64;                     // classes < 64 on both sides: dense histogram
+constexpr int      kBi2HeadN    = kBi2Head * kBi2Head;
+constexpr int      kBi2MaxSub   = 32;                     // sub-regions per A bin (a multiple of 8: sub-region = block index mod nsub, XCD = block index mod 8)
+constexpr int      kBi2MaxSlots = kBins * kBi2MaxSub;
+constexpr uint32_t kBi2PosBits  = 27;                     // corpus positions per device on this path: < 2^27
+constexpr uint64_t kBi2PosMask  = (1ull << kBi2PosBits) - 1;
+constexpr int      kBi2BBins    = 512;                    // level-B bins per A bin: ~660 records per final bin at 100 M tokens (one wave counts a bin)
+constexpr int      kBi2Final    = kBins * kBi2BBins;      // 131 072 final bins
+constexpr int      kBi2Buckets  = 256;                    // position buckets (one LDS bitmap each in bi2_bitmap_kernel)
+constexpr int      kBi2Shards   = 8;                      // cursor shards per bucket (a single cursor would serialise ~12 ns per reservation)
+constexpr int      kBi2Slots    = 1024;                   // LDS table of one final bin: 256 buckets of 4 slots
+constexpr uint32_t kBi2MaxLoad  = 900;
+constexpr uint32_t kBi2Empty    = 0xFFFFFFFFu;            // keys are 31 bits
+constexpr int      kBi2HeadSplit = 32;                    // row groups of the head reduction
+constexpr int      kBi2BmThreads = 1024;                  // bitmap kernels: one block per position bucket
+
+struct Bi2State {
+    uint32_t curA[kBi2MaxSlots];  // emit cursors = records per slot (beyond `region`: overflow)
+    uint32_t cntA[kBins];         // records per A bin
+    uint32_t offAt[kBins + 1];    // exclusive scan of cntA
+    uint32_t found_part[kBins], kept_part[kBins];
+    uint32_t binoff[kBi2Final + 1];  // first sparse index of final bin f = a * 512 + b (a bin owns as many sparse entries as it has records)
+    uint32_t binkept[kBi2Final];     // survivors of the bin; after bi2_kept_scan_kernel: their dense offsets
+    uint32_t headcnt[kBi2HeadN], headposinv[kBi2HeadN];  // the reduced head histogram: count and ~(lowest position) per (c0, c1)
+    uint32_t headsurv[kBi2HeadN / 32];                   // bit k = head bigram k survived
+    uint32_t headbase[kBlock];                           // first result rank of the head survivors of lane t (16 head keys per lane)
+    uint32_t pcur[kBi2Shards * kBi2Buckets];             // position-list cursors
+    uint32_t nrec, bshift, overflow, kept_bins, kept_head, pad[3];
+};
+
+// exclusive scan of 256 LDS values by the first 256 threads of a block of any size; every thread of the block must call it
+__device__ __forceinline__ uint32_t bi2_scan256(const uint32_t* inL, uint32_t* outL, uint32_t* wsumL) {
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t       v = 0, incl = 0;
+    if (threadIdx.x < 256) {
+        v    = inL[threadIdx.x];
+        incl = v;
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, kWave);
+            if ((int)lane >= off) incl += t;
+        }
+        if (lane == kWave - 1) wsumL[wave] = incl;
+    }
+    __syncthreads();
+    const uint32_t s0 = wsumL[0], s1 = wsumL[1], s2 = wsumL[2], s3 = wsumL[3];
+    if (threadIdx.x < 256) outL[threadIdx.x] = (wave > 0 ? s0 : 0u) + (wave > 1 ? s1 : 0u) + (wave > 2 ? s2 : 0u) + incl - v;
+    __syncthreads();
+    return s0 + s1 + s2 + s3;
+}
+// exclusive scan of one value per thread over a block of T threads (T / 64 <= 16 waves); wsumL: T / 64 words
+template <int T>
+__device__ __forceinline__ uint32_t bi2_block_scan(uint32_t v, uint32_t* total, uint32_t* wsumL) {
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t       incl = v;
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, kWave);
+        if ((int)lane >= off) incl += t;
+    }
+    if (lane == kWave - 1) wsumL[wave] = incl;
+    __syncthreads();
+    uint32_t ws = lane < (uint32_t)(T / kWave) ? wsumL[lane] : 0u, wincl = ws;  // every wave scans the (<= 16) wave sums itself
+    for (int off = 1; off < T / kWave; off <<= 1) {
+        const uint32_t t = __shfl_up(wincl, off, kWave);
+        if ((int)lane >= off) wincl += t;
+    }
+    const uint32_t base = __shfl(wincl - ws, (int)wave, kWave);
+    *total              = __shfl(wincl, T / kWave - 1, kWave);
+    __syncthreads();
+    return base + incl - v;
+}
+
+// ---- emit: windows -> head histogram | 8-byte records partitioned by A bin -------------------------------------------------------------
+// grid: a multiple of nsub persistent blocks; head_rows: [gridDim.x][2][kBi2HeadN] (counts, lowest positions).
+// Wide blocks with few items per lane: every phase of a tile is a short chain of LDS operations, and 32 waves per CU hide each other's latencies.
+constexpr int kBi2SurvLds = 2048;  // words of the order-1 survivor bitmap kept in LDS: the first 65 536 classes (> 80 % of a Zipf corpus' tokens)
+__global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kernel(const uint32_t* cls, const uint32_t* __restrict__ surv, uint32_t nsurvwords, uint32_t npos,
+                                                                                   unsigned long long* __restrict__ recsA, uint32_t region, uint32_t nsub, Bi2State* __restrict__ bs,
+                                                                                   DevState* __restrict__ st, uint32_t* __restrict__ head_rows) {
+    if (st->done) return;
+    __shared__ unsigned long long stgL[kBi2Tile];
+    __shared__ uint8_t            binL[kBi2Tile];
+    __shared__ uint32_t           histL[kBins], offL[kBins], gbaseL[kBins], wsumL[4];
+    __shared__ uint32_t           headL[kBi2HeadN], hposL[kBi2HeadN], survL[kBi2SurvLds];
+    __shared__ uint32_t           redL[kBi2Threads / kWave];
+    for (int k = threadIdx.x; k < kBi2HeadN; k += kBi2Threads) {
+        headL[k] = 0;
+        hposL[k] = 0xFFFFFFFFu;
+    }
+    for (int k = threadIdx.x; k < kBi2SurvLds; k += kBi2Threads) survL[k] = (uint32_t)k < nsurvwords ? surv[k] : 0u;
+    const uint32_t ntiles = (npos + kBi2Tile - 1) / kBi2Tile;
+    const uint32_t sub    = blockIdx.x % nsub;
+    const uint32_t lane   = threadIdx.x & (kWave - 1);
+    uint32_t       nadm   = 0;
+    uint32_t       c0[kBi2Per], cx[kBi2Per];  // class at the lane's positions; cx: lane 63 only, the class after its position
+    auto           load_tile = [&](uint32_t tile) {
+#pragma unroll
+        for (int k = 0; k < kBi2Per; ++k) {
+            const uint32_t i = tile * kBi2Tile + k * kBi2Threads + threadIdx.x;
+            c0[k]            = (tile < ntiles && i < npos) ? cls[i] : 0u;
+            cx[k]            = (lane == kWave - 1 && tile < ntiles && i + 1 < npos) ? cls[i + 1] : 0u;
+        }
+    };
+    auto alive = [&](uint32_t c) -> uint32_t {  // class c survived order 1 (c = 0, the delimiter, never does: bit 0 is clear)
+        const uint32_t w = c >> 5;
+        return ((w < (uint32_t)kBi2SurvLds ? survL[w] : surv[w]) >> (c & 31u)) & 1u;
+    };
+    load_tile(blockIdx.x);
+    __syncthreads();
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t base = tile * kBi2Tile;
+        uint32_t       d0[kBi2Per], d1[kBi2Per], ok[kBi2Per];
+        if (threadIdx.x < kBins) histL[threadIdx.x] = 0;
+#pragma unroll
+        for (int k = 0; k < kBi2Per; ++k) {
+            d0[k]             = c0[k];
+            const uint32_t nb = __shfl_down(c0[k], 1, kWave);  // the next position's class lives in the next lane (lane 63 loaded its own)
+            d1[k]             = lane == kWave - 1 ? cx[k] : nb;
+        }
+#pragma unroll
+        for (int k = 0; k < kBi2Per; ++k) {
+            const uint32_t a0 = d0[k] ? alive(d0[k]) : 0u;
+            const uint32_t an = __shfl_down(a0, 1, kWave);
+            const uint32_t a1 = lane == kWave - 1 ? (d1[k] ? alive(d1[k]) : 0u) : an;
+            ok[k]             = a0 & a1;
+        }
+        load_tile(tile + gridDim.x);  // the next tile's class ids are in flight while this one is partitioned in LDS
+        __syncthreads();
+        unsigned long long rec[kBi2Per];
+        uint32_t           rank[kBi2Per];  // [11:0] rank inside the tile's A bin, [23:16] the A bin; kInvalid: no record
+#pragma unroll
+        for (int k = 0; k < kBi2Per; ++k) {
+            const uint32_t i = base + k * kBi2Threads + threadIdx.x;
+            rank[k]          = kInvalid;
+            rec[k]           = 0;
+            if (ok[k]) {
+                ++nadm;
+                if (d0[k] < (uint32_t)kBi2Head && d1[k] < (uint32_t)kBi2Head) {
+                    const uint32_t h = d0[k] * kBi2Head + d1[k];
+                    atomicAdd(&headL[h], 1u);
+                    atomicMin(&hposL[h], i);
+                } else {
+                    const uint64_t m = mix42(((uint64_t)d0[k] << 21) | d1[k]);
+                    const uint32_t a = (uint32_t)(m >> 34);
+                    rec[k]           = ((m & ((1ull << 34) - 1)) << kBi2PosBits) | i;
+                    rank[k]          = atomicAdd(&histL[a], 1u) | (a << 16);
+                }
+            }
+        }
+        __syncthreads();
+        bi2_scan256(histL, offL, wsumL);
+        if (threadIdx.x < kBins) {
+            const uint32_t h = histL[threadIdx.x];
+            uint32_t       g = 0;
+            if (h) {
+                const uint32_t slot = sub * kBins + threadIdx.x;
+                const uint32_t at   = atomicAdd(&bs->curA[slot], h);  // one reservation per (tile, A bin), on the cursor of this block's sub-region
+                if (at + h > region) bs->overflow = 1;
+                g = slot * region + min(at, region - min(region, h));
+            }
+            gbaseL[threadIdx.x] = g;
+        }
+#pragma unroll
+        for (int k = 0; k < kBi2Per; ++k) {
+            if (rank[k] != kInvalid) {
+                const uint32_t a = rank[k] >> 16, p = offL[a] + (rank[k] & 0xFFFFu);
+                stgL[p]          = rec[k];
+                binL[p]          = (uint8_t)a;
+            }
+        }
+        __syncthreads();
+        const uint32_t n = offL[kBins - 1] + histL[kBins - 1];
+        for (uint32_t j = threadIdx.x; j < n; j += kBi2Threads) {
+            const uint32_t a                         = binL[j];
+            recsA[(size_t)gbaseL[a] + (j - offL[a])] = stgL[j];
+        }
+        __syncthreads();
+    }
+    uint32_t* const row = head_rows + (size_t)blockIdx.x * (2 * kBi2HeadN);
+    for (int k = threadIdx.x; k < kBi2HeadN; k += kBi2Threads) {
+        row[k]             = headL[k];
+        row[kBi2HeadN + k] = hposL[k];
+    }
+    for (int off = 32; off > 0; off >>= 1) nadm += __shfl_down(nadm, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nadm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0;
+        for (int w = 0; w < kBi2Threads / kWave; ++w) a += redL[w];
+        if (a) atomicAdd(&st->admitted, a);
+    }
+}
+
+// column sums / minima of the head rows: grid (kBi2HeadN / 256, kBi2HeadSplit), block (x, y) reduces rows y, y + kBi2HeadSplit, ... of 256 head keys
+// into the zeroed Bi2State arrays (the lowest position travels inverted so that zero means "none")
+__global__ __launch_bounds__(kBlock) void bi2_head_reduce_kernel(const uint32_t* __restrict__ head_rows, uint32_t nrows, Bi2State* __restrict__ bs, const DevState* __restrict__ st) {
+    if (st->done) return;
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t       s = 0, p = 0xFFFFFFFFu;
+    for (uint32_t r = blockIdx.y; r < nrows; r += gridDim.y) {
+        s += head_rows[(size_t)r * (2 * kBi2HeadN) + k];
+        p = min(p, head_rows[(size_t)r * (2 * kBi2HeadN) + kBi2HeadN + k]);
+    }
+    if (s) {
+        atomicAdd(&bs->headcnt[k], s);
+        atomicMax(&bs->headposinv[k], ~p);
+    }
+}
+
+// one block: records per A bin, their scan, the B-bin shift for this record count
+__global__ __launch_bounds__(kBlock) void bi2_offsets_kernel(Bi2State* __restrict__ bs, uint32_t region, uint32_t nsub, const DevState* __restrict__ st) {
+    if (st->done) return;
+    uint32_t s = 0;
+    for (uint32_t g = 0; g < nsub; ++g) {
+        const uint32_t h = bs->curA[g * kBins + threadIdx.x];
+        if (h > region) bs->overflow = 1;
+        s += min(h, region);
+    }
+    uint32_t       tot;
+    const uint32_t o       = block_exclusive_scan(s, &tot);
+    bs->cntA[threadIdx.x]  = s;
+    bs->offAt[threadIdx.x] = o;
+    if (threadIdx.x == 0) {
+        bs->offAt[kBins] = tot;
+        bs->nrec         = tot;
+        // aim at <= ~700 records per final bin; at least 8 B bins (the 31-bit in-bin key needs three mix bits fixed by the B bin)
+        uint32_t nb = 8;
+        while (nb < (uint32_t)kBi2BBins && (uint64_t)nb * kBins * 700u < tot) nb <<= 1;
+        uint32_t sh = 0;
+        while ((uint32_t)kBi2BBins >> sh > nb) ++sh;
+        bs->bshift = sh;
+    }
+}
+
+// exclusive scan of 512 LDS values by the first 512 threads of a block (>= 512 threads); every thread of the block must call it
+__device__ __forceinline__ uint32_t bi2_scan512(const uint32_t* inL, uint32_t* outL, uint32_t* wsumL) {
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t       v = 0, incl = 0;
+    if (threadIdx.x < 512) {
+        v    = inL[threadIdx.x];
+        incl = v;
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, kWave);
+            if ((int)lane >= off) incl += t;
+        }
+        if (lane == kWave - 1) wsumL[wave] = incl;
+    }
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const uint32_t t = wsumL[w];
+        if (w < (int)wave) base += t;
+        tot += t;
+    }
+    if (threadIdx.x < 512) outL[threadIdx.x] = base + incl - v;
+    __syncthreads();
+    return tot;
+}
+
+// ---- level B: one block partitions one slot by B bin ------------------------------------------------------------------------------
+// boff: [nslots][513] exclusive offsets of the slot's B bins inside the slot (same slot layout in recsB as in recsA).
+// B bin of a record: mix bits [33:25] = record bits [60:52], shifted down by bshift when an order has few records.
+__global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_levelB_kernel(const unsigned long long* recsA, unsigned long long* __restrict__ recsB, uint32_t region,
+                                                                                     const Bi2State* __restrict__ bs, uint32_t* __restrict__ boff, const DevState* __restrict__ st) {
+    if (st->done) return;
+    __shared__ unsigned long long stgL[kBi2Tile];
+    __shared__ uint16_t           binL[kBi2Tile];
+    __shared__ uint32_t           histL[kBi2BBins], offL[kBi2BBins], curL[kBi2BBins], gbL[kBi2BBins], wsumL[8];
+    const uint32_t  slot = blockIdx.x;
+    const uint32_t  n    = min(bs->curA[slot], region);
+    const uint32_t  bsh  = bs->bshift;
+    const size_t    base = (size_t)slot * region;
+    uint32_t* const bo   = boff + (size_t)slot * (kBi2BBins + 1);
+    if (threadIdx.x < kBi2BBins) histL[threadIdx.x] = 0;
+    __syncthreads();
+    // sweep 1: histogram of the slot, two tiles of loads ahead of their LDS atomics
+    for (uint32_t j0 = 0; j0 < n; j0 += 2 * kBi2Tile) {
+        unsigned long long r[2 * kBi2Per];
+#pragma unroll
+        for (int k = 0; k < 2 * kBi2Per; ++k) {
+            const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
+            r[k]             = (j < n) ? recsA[base + j] : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < 2 * kBi2Per; ++k) {
+            const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
+            if (j < n) atomicAdd(&histL[((uint32_t)(r[k] >> 52) & 511u) >> bsh], 1u);
+        }
+    }
+    __syncthreads();
+    bi2_scan512(histL, offL, wsumL);
+    if (threadIdx.x < kBi2BBins) {
+        bo[threadIdx.x]   = offL[threadIdx.x];
+        curL[threadIdx.x] = offL[threadIdx.x];
+    }
+    if (threadIdx.x == 0) bo[kBi2BBins] = n;
+    // sweep 2: tile-local counting sort, runs appended at the block's own cursors (nobody else writes this slot); the next tile is prefetched
+    unsigned long long r[kBi2Per];
+    auto               load_tile = [&](uint32_t j0) {
+#pragma unroll
+        for (int k = 0; k < kBi2Per; ++k) {
+            const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
+            r[k]             = (j < n) ? recsA[base + j] : 0ull;
+        }
+    };
+    load_tile(0);
+    for (uint32_t j0 = 0; j0 < n; j0 += kBi2Tile) {
+        unsigned long long x[kBi2Per];
+        uint32_t           rank[kBi2Per];
+        if (threadIdx.x < kBi2BBins) histL[threadIdx.x] = 0;
+#pragma unroll
+        for (int k = 0; k < kBi2Per; ++k) x[k] = r[k];
+        load_tile(j0 + kBi2Tile);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kBi2Per; ++k) {
+            const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
+            rank[k]          = kInvalid;
+            if (j < n) {
+                const uint32_t b = ((uint32_t)(x[k] >> 52) & 511u) >> bsh;
+                rank[k]          = atomicAdd(&histL[b], 1u) | (b << 16);
+            }
+        }
+        __syncthreads();
+        bi2_scan512(histL, offL, wsumL);
+        if (threadIdx.x < kBi2BBins) {
+            gbL[threadIdx.x] = curL[threadIdx.x];
+            curL[threadIdx.x] += histL[threadIdx.x];
+        }
+#pragma unroll
+        for (int k = 0; k < kBi2Per; ++k) {
+            if (rank[k] != kInvalid) {
+                const uint32_t b = rank[k] >> 16, p = offL[b] + (rank[k] & 0xFFFFu);
+                stgL[p]          = x[k];
+                binL[p]          = (uint16_t)b;
+            }
+        }
+        __syncthreads();
+        const uint32_t m = min(n - j0, (uint32_t)kBi2Tile);
+        for (uint32_t j = threadIdx.x; j < m; j += kBi2Threads) {
+            const uint32_t b                     = binL[j];
+            recsB[base + gbL[b] + (j - offL[b])] = stgL[j];
+        }
+        __syncthreads();
+    }
+}
+
+// sparse ranges of the final bins: block a, lane b: records of bin (a, b) over all sub-regions, scanned inside the A bin
+__global__ __launch_bounds__(kBi2BBins) void bi2_binoff_kernel(Bi2State* __restrict__ bs, const uint32_t* __restrict__ boff, uint32_t nsub, const DevState* __restrict__ st) {
+    if (st->done) return;
+    __shared__ uint32_t inL[kBi2BBins], outL[kBi2BBins], wsumL[8];
+    const uint32_t      a = blockIdx.x, b = threadIdx.x, nB = (uint32_t)kBi2BBins >> bs->bshift;
+    uint32_t            t = 0;
+    if (b < nB)
+        for (uint32_t s = 0; s < nsub; ++s) {
+            const uint32_t* bo = boff + (size_t)(s * kBins + a) * (kBi2BBins + 1);
+            t += bo[b + 1] - bo[b];
+        }
+    inL[b] = t;
+    __syncthreads();
+    bi2_scan512(inL, outL, wsumL);
+    bs->binoff[a * kBi2BBins + b] = bs->offAt[a] + outL[b];
+    if (a == kBins - 1 && b == 0) bs->binoff[kBi2Final] = bs->offAt[kBins];
+}
+
+// ---- count: one WAVE per final bin --------------------------------------------------------------------------------------------------
+// A final bin holds ~660 records of ~400 distinct keys. Measured on MI355X (tools/bigram2_bench.hip): a workgroup per bin is bound by control
+// code and barriers (16 waves run ~1500 instructions each to insert one or two records per lane: 1.2 ms per 87 M records), and a wave inserting a
+// row of 64 records pays the LONGEST probe sequence of its lanes (linear probing: ~2600 cycles per row). Here a wave owns a bin from start to end —
+// no barrier, one copy of the control code per bin, the bin's records (up to 12 per lane) in registers — and needs only 9 KB of LDS, so 16 waves
+// per CU hide each other's LDS round trips. The table has buckets of 4 slots read as one 16-byte vector; slots of a bucket fill left to right and
+// are never freed, so the first slot that holds the key or is empty decides; a full bucket continues in the next one. Two rows are inserted per
+// round (their compare-and-swaps are in flight together). Survivors go to the bin's own range of the sparse result arrays; the positions of
+// the windows of surviving keys are appended, unsorted, to the wave's private list (ballot-compacted, coalesced): bi2_pospart_kernel sorts them
+// into position buckets afterwards.
+constexpr int      kBi2WRows = 12;   // records per lane in registers (bins of up to 768 records are read once)
+constexpr int      kBi2WReps = 256;  // survivors of a bin whose lowest position is tracked in LDS (beyond: device atomics on the result array)
+constexpr uint32_t kBi2Kept  = 0x80000000u;
+__device__ __forceinline__ uint32_t bi2_wave_excl_scan(uint32_t v, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    uint32_t       incl = v;
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, kWave);
+        if ((int)lane >= off) incl += t;
+    }
+    *total = __shfl(incl, kWave - 1, kWave);
+    return incl - v;
+}
+__device__ __forceinline__ uint32_t bi2_scan4(const uint4& v, uint32_t key, bool& hit) {  // index (0..3) of the first slot holding `key` or empty; 4: none
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t       idx  = 4;
+    hit                 = false;
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+        if (w[i] == key || w[i] == kBi2Empty) {
+            idx = (uint32_t)i;
+            hit = w[i] == key;
+        }
+    }
+    return idx;
+}
+__device__ __forceinline__ uint32_t bi2_bucket_of(uint32_t key, int lgb, uint32_t bmask) { return ((key * 0x9E3779B1u) >> (32 - lgb)) & bmask; }
+// finds or inserts two keys per lane (A and B, each optional); slots are returned through sa / sb (kInvalid: table full)
+__device__ __forceinline__ void bi2_insert2(uint32_t* keyT, uint32_t bmask, bool actA, uint32_t keyA, uint32_t bkA, uint4 vA, uint32_t& sa, bool actB, uint32_t keyB, uint32_t bkB, uint4 vB,
+                                            uint32_t& sb) {
+    uint32_t walkedA = 0, walkedB = 0;
+    sa = sb = kInvalid;
+    while (actA || actB) {
+        bool           hitA = false, hitB = false;
+        const uint32_t iA = actA ? bi2_scan4(vA, keyA, hitA) : 4u, iB = actB ? bi2_scan4(vB, keyB, hitB) : 4u;
+        const bool     casA = actA && iA < 4 && !hitA, casB = actB && iB < 4 && !hitB;
+        uint32_t       oldA = 0, oldB = 0;
+        if (casA) oldA = atomicCAS(&keyT[bkA * 4 + iA], kBi2Empty, keyA);
+        if (casB) oldB = atomicCAS(&keyT[bkB * 4 + iB], kBi2Empty, keyB);
+        if (actA) {
+            if (iA < 4) {
+                if (hitA || oldA == kBi2Empty || oldA == keyA) {
+                    sa   = bkA * 4 + iA;
+                    actA = false;
+                }
+            } else {
+                bkA = (bkA + 1) & bmask;
+                if (++walkedA > bmask) actA = false;
+            }
+        }
+        if (actB) {
+            if (iB < 4) {
+                if (hitB || oldB == kBi2Empty || oldB == keyB) {
+                    sb   = bkB * 4 + iB;
+                    actB = false;
+                }
+            } else {
+                bkB = (bkB + 1) & bmask;
+                if (++walkedB > bmask) actB = false;
+            }
+        }
+        if (actA) vA = *reinterpret_cast<const uint4*>(keyT + bkA * 4);
+        if (actB) vB = *reinterpret_cast<const uint4*>(keyT + bkB * 4);
+    }
+}
+// slot of a key that is known to be in the table
+__device__ __forceinline__ uint32_t bi2_find(const uint32_t* keyT, uint32_t key, uint32_t bk, uint32_t bmask) {
+    for (;;) {
+        const uint4    v = *reinterpret_cast<const uint4*>(keyT + bk * 4);
+        bool           hit;
+        const uint32_t i = bi2_scan4(v, key, hit);
+        if (i < 4 && hit) return bk * 4 + i;
+        bk = (bk + 1) & bmask;
+    }
+}
+#ifdef BI2_PROF
+__device__ unsigned long long bi2_prof[16];
+#endif
+template <int NSUB>
+__global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const uint32_t* __restrict__ boff, Bi2State* __restrict__ bs,
+                                                              DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
+                                                              uint32_t* __restrict__ wlist, uint32_t* __restrict__ wcnt, uint32_t wcap, bool want_positions) {
+    if (st->done) return;
+    static_assert(2 * NSUB + 1 <= kWave, "bound loaders are lanes of the wave");
+    __shared__ __attribute__((aligned(16))) uint32_t keyT[kBi2Slots];
+    __shared__ __attribute__((aligned(16))) uint32_t cntT[kBi2Slots];
+    __shared__ uint32_t                              repS[kBi2WReps];
+    const uint32_t bsh = bs->bshift, nB = (uint32_t)kBi2BBins >> bsh, nfinal = (uint32_t)kBins * nB;
+    const uint32_t lane = threadIdx.x, wid = blockIdx.x, nwaves = gridDim.x;
+    uint32_t* const mylist = wlist + (size_t)wid * wcap;
+    uint32_t        cursor = 0;     // entries in this wave's position list (wave-uniform)
+    bool            lost   = false;  // the list ran out of room
+#ifdef BI2_PROF
+    unsigned long long tacc[12] = {0}, tlast = wall_clock64();
+#define BI2_W(k) do { const unsigned long long t_ = wall_clock64(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define BI2_W(k) do {} while (0)
+#endif
+    for (uint32_t g = wid; g < nfinal; g += nwaves) {
+        const uint32_t a = g & (uint32_t)(kBins - 1), b = g >> 8;
+        BI2_W(0);
+        // run bounds: 2 NSUB + 1 lanes load, v_readlane broadcasts (scalar registers)
+        uint32_t v = 0;
+        if (lane < (uint32_t)(2 * NSUB))
+            v = boff[(size_t)((lane % NSUB) * kBins + a) * (kBi2BBins + 1) + b + (lane >= (uint32_t)NSUB ? 1u : 0u)];
+        else if (lane == (uint32_t)(2 * NSUB))
+            v = bs->binoff[a * kBi2BBins + b];
+        uint32_t rs[NSUB], rn[NSUB], total = 0;
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            rs[s] = (uint32_t)__builtin_amdgcn_readlane((int)v, s);
+            rn[s] = (uint32_t)__builtin_amdgcn_readlane((int)v, NSUB + s) - rs[s];
+            total += rn[s];
+        }
+        const uint32_t spo = (uint32_t)__builtin_amdgcn_readlane((int)v, 2 * NSUB);
+        BI2_W(1);
+        if (total == 0) continue;
+        auto locate = [&](uint32_t j) -> size_t {  // record j (< total) of the bin -> its index in recsB
+            uint32_t off = 0, slot = 0;
+            bool     ok  = false;
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) {
+                if (!ok && j < rn[s]) {
+                    ok   = true;
+                    off  = rs[s] + j;
+                    slot = (uint32_t)s * kBins + a;
+                }
+                if (!ok) j -= rn[s];
+            }
+            return (size_t)slot * region + off;
+        };
+        unsigned long long x[kBi2WRows];
+#pragma unroll
+        for (int q = 0; q < kBi2WRows; ++q) {
+            const uint32_t j = q * kWave + lane;
+            x[q]             = j < total ? recsB[locate(j)] : 0ull;
+        }
+        BI2_W(2);
+        uint32_t nslots = 256;
+        while (nslots < (uint32_t)kBi2Slots && nslots < total + (total >> 1)) nslots <<= 1;
+        int lgb = 6;  // log2 of the number of buckets
+        while ((4u << lgb) < nslots) ++lgb;
+        const uint32_t bmask = (1u << lgb) - 1u;
+        for (uint32_t s = lane * 4; s < nslots; s += kWave * 4) {
+            *reinterpret_cast<uint4*>(keyT + s) = make_uint4(kBi2Empty, kBi2Empty, kBi2Empty, kBi2Empty);
+            *reinterpret_cast<uint4*>(cntT + s) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        BI2_W(3);
+        // pass 1: two rows per round
+        uint32_t sl[kBi2WRows];
+        bool     fail = false;
+#pragma unroll
+        for (int q = 0; q < kBi2WRows; q += 2) {
+            sl[q] = sl[q + 1] = kInvalid;
+            if ((uint32_t)(q * kWave) < total) {
+                const bool     actA = (uint32_t)(q * kWave) + lane < total, actB = (uint32_t)((q + 1) * kWave) + lane < total;
+                const uint32_t keyA = (uint32_t)(x[q] >> kBi2PosBits) & 0x7FFFFFFFu, keyB = (uint32_t)(x[q + 1] >> kBi2PosBits) & 0x7FFFFFFFu;
+                const uint32_t bkA = bi2_bucket_of(keyA, lgb, bmask), bkB = bi2_bucket_of(keyB, lgb, bmask);
+                const uint4    vA = *reinterpret_cast<const uint4*>(keyT + bkA * 4), vB = *reinterpret_cast<const uint4*>(keyT + bkB * 4);
+                bi2_insert2(keyT, bmask, actA, keyA, bkA, vA, sl[q], actB, keyB, bkB, vB, sl[q + 1]);
+                if (actA) {
+                    if (sl[q] == kInvalid)
+                        fail = true;
+                    else
+                        atomicAdd(&cntT[sl[q]], 1u);
+                }
+                if (actB) {
+                    if (sl[q + 1] == kInvalid)
+                        fail = true;
+                    else
+                        atomicAdd(&cntT[sl[q + 1]], 1u);
+                }
+            }
+        }
+        BI2_W(4);
+        for (uint32_t j0 = kBi2WRows * kWave; j0 < total; j0 += 2 * kWave) {  // larger bins stream the remainder, two rows per round
+            const uint32_t           jA = j0 + lane, jB = j0 + kWave + lane;
+            const bool               actA = jA < total, actB = jB < total;
+            const unsigned long long yA = actA ? recsB[locate(jA)] : 0ull, yB = actB ? recsB[locate(jB)] : 0ull;
+            const uint32_t           keyA = (uint32_t)(yA >> kBi2PosBits) & 0x7FFFFFFFu, keyB = (uint32_t)(yB >> kBi2PosBits) & 0x7FFFFFFFu;
+            const uint32_t           bkA = bi2_bucket_of(keyA, lgb, bmask), bkB = bi2_bucket_of(keyB, lgb, bmask);
+            uint32_t                 tA, tB;
+            bi2_insert2(keyT, bmask, actA, keyA, bkA, *reinterpret_cast<const uint4*>(keyT + bkA * 4), tA, actB, keyB, bkB, *reinterpret_cast<const uint4*>(keyT + bkB * 4), tB);
+            if (actA) {
+                if (tA == kInvalid)
+                    fail = true;
+                else
+                    atomicAdd(&cntT[tA], 1u);
+            }
+            if (actB) {
+                if (tB == kInvalid)
+                    fail = true;
+                else
+                    atomicAdd(&cntT[tB], 1u);
+            }
+        }
+        BI2_W(5);
+        if (__any(fail)) {
+            if (lane == 0) bs->overflow = 2;
+            continue;
+        }
+        // survivors: lane l looks at the nslots / 64 consecutive slots from l * (nslots / 64), four at a time
+        const uint32_t per  = nslots / kWave;
+        uint32_t       used = 0, keep = 0;
+        for (uint32_t k = 0; k < per; k += 4) {
+            const uint32_t s  = lane * per + k;
+            const uint4    kk = *reinterpret_cast<const uint4*>(keyT + s), cc = *reinterpret_cast<const uint4*>(cntT + s);
+            used += (kk.x != kBi2Empty) + (kk.y != kBi2Empty) + (kk.z != kBi2Empty) + (kk.w != kBi2Empty);
+            keep += (cc.x >= threshold) + (cc.y >= threshold) + (cc.z >= threshold) + (cc.w >= threshold);  // an empty slot counts 0 (threshold >= 1)
+        }
+        uint32_t       distinct, ktotal;
+        const uint32_t excl = bi2_wave_excl_scan(keep, &ktotal);
+        bi2_wave_excl_scan(used, &distinct);
+        if (distinct > kBi2MaxLoad) {
+            if (lane == 0) bs->overflow = 2;
+            continue;
+        }
+        if (lane == 0) {
+            atomicAdd(&bs->found_part[a], distinct);
+            bs->binkept[a * kBi2BBins + b] = ktotal;
+            if (ktotal) atomicAdd(&bs->kept_part[a], ktotal);
+        }
+        BI2_W(6);
+        if (ktotal == 0) continue;
+        const bool reps_lds = ktotal <= (uint32_t)kBi2WReps;
+        {
+            uint32_t r = excl;
+            for (uint32_t k = 0; k < per; k += 4) {
+                const uint32_t s0 = lane * per + k;
+                const uint4    cc = *reinterpret_cast<const uint4*>(cntT + s0);
+                const uint32_t c4[4] = {cc.x, cc.y, cc.z, cc.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (c4[i] >= threshold) {
+                        sp_cnt[spo + r] = c4[i];
+                        cntT[s0 + i]    = kBi2Kept | r;  // from here on: the key survived, and which survivor of the bin it is
+                        if (reps_lds)
+                            repS[r] = 0xFFFFFFFFu;
+                        else
+                            sp_rep[spo + r] = 0xFFFFFFFFu;
+                        ++r;
+                    }
+                }
+            }
+        }
+        BI2_W(7);
+        if (!reps_lds) __threadfence();  // the initial values of the result entries precede the atomics below
+        // pass 2: every window of a surviving key: lowest position of the key; the position joins the wave's list
+        auto settle = [&](bool valid, uint32_t pos, uint32_t s) {
+            uint32_t c = 0;
+            if (valid) c = cntT[s];
+            const bool kept = (c & kBi2Kept) != 0;
+            if (kept) {
+                const uint32_t r = c & ~kBi2Kept;
+                if (reps_lds)
+                    atomicMin(&repS[r], pos);
+                else
+                    atomicMin(&sp_rep[spo + r], pos);
+            }
+            if (want_positions) {
+                const uint64_t m = __ballot(kept);
+                const uint32_t n = (uint32_t)__popcll(m);
+                if (kept) {
+                    const uint32_t at = cursor + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (at < wcap)
+                        mylist[at] = pos;
+                    else
+                        lost = true;
+                }
+                cursor += n;
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < kBi2WRows; ++q)
+            if ((uint32_t)(q * kWave) < total) settle(sl[q] != kInvalid, (uint32_t)(x[q] & kBi2PosMask), sl[q]);
+        BI2_W(8);
+        for (uint32_t j0 = kBi2WRows * kWave; j0 < total; j0 += kWave) {
+            const uint32_t           j = j0 + lane;
+            const bool               valid = j < total;
+            const unsigned long long y = valid ? recsB[locate(j)] : 0ull;
+            const uint32_t           key = (uint32_t)(y >> kBi2PosBits) & 0x7FFFFFFFu;
+            settle(valid, (uint32_t)(y & kBi2PosMask), valid ? bi2_find(keyT, key, bi2_bucket_of(key, lgb, bmask), bmask) : 0u);
+        }
+        BI2_W(9);
+        if (reps_lds)
+            for (uint32_t r = lane; r < ktotal; r += kWave) sp_rep[spo + r] = repS[r];
+        BI2_W(10);
+    }
+#ifdef BI2_PROF
+    if (lane == 0)
+        for (int q = 0; q < 12; ++q) atomicAdd(&bi2_prof[q], tacc[q]);
+#endif
+    if (want_positions && lane == 0) wcnt[wid] = min(cursor, wcap);
+    if (__any(lost) && lane == 0) bs->overflow = 3;
+}
+
+// per-bin survivor counts -> dense result offsets, bin by bin; block a scans A bin a
+__global__ __launch_bounds__(kBi2BBins) void bi2_kept_scan_kernel(Bi2State* __restrict__ bs, const DevState* __restrict__ st) {
+    if (st->done) return;
+    __shared__ uint32_t inL[kBi2BBins], outL[kBi2BBins], wsumL[8], beforeL;
+    const uint32_t      a = blockIdx.x;
+    inL[threadIdx.x]      = threadIdx.x < a ? bs->kept_part[threadIdx.x] : 0u;  // (kBins <= kBi2BBins: entries beyond 255 are zero)
+    __syncthreads();
+    const uint32_t before = bi2_scan512(inL, outL, wsumL);
+    if (threadIdx.x == 0) beforeL = before;
+    __syncthreads();
+    inL[threadIdx.x] = bs->binkept[a * kBi2BBins + threadIdx.x];
+    __syncthreads();
+    const uint32_t tot                        = bi2_scan512(inL, outL, wsumL);
+    bs->binkept[a * kBi2BBins + threadIdx.x] = beforeL + outL[threadIdx.x];
+    if (a == kBins - 1 && threadIdx.x == 0) bs->kept_bins = beforeL + tot;
+}
+// head bigrams -> survivors; found / kept of the order
+__global__ __launch_bounds__(kBlock) void bi2_finish_kernel(DevState* __restrict__ st, Bi2State* __restrict__ bs, uint32_t threshold, uint32_t res_cap) {
+    if (st->done) return;
+    uint32_t htot, ftot, hftot;
+    block_exclusive_scan(bs->found_part[threadIdx.x], &ftot);
+    static_assert(kBi2HeadN == kBlock * 16, "16 head keys per lane");
+    uint32_t hk = 0, hf = 0, bits = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const uint32_t c = bs->headcnt[threadIdx.x * 16 + q];
+        hf += c != 0;
+        if (c >= threshold) {
+            ++hk;
+            bits |= 1u << q;
+        }
+    }
+    reinterpret_cast<uint16_t*>(bs->headsurv)[threadIdx.x] = (uint16_t)bits;
+    const uint32_t ho = block_exclusive_scan(hk, &htot);
+    bs->headbase[threadIdx.x] = ho;
+    block_exclusive_scan(hf, &hftot);
+    if (threadIdx.x == 0) {
+        const uint32_t tot = bs->kept_bins;
+        bs->kept_head      = htot;
+        st->found          = ftot + hftot;
+        st->kept           = tot + htot;
+        if ((uint64_t)st->res_total + tot + htot > res_cap) st->overflow = 1;
+        if (bs->overflow) st->radix_overflow = 4;  // the host re-runs on the first-generation kernels
+        const uint64_t next = (uint64_t)st->id_base + bs->nrec;  // keeps the id space of the later orders disjoint, as bin_advance_prepare_kernel does
+        if (next >= 0xFFFFFFF0ull) st->radix_overflow = 3;
+        st->id_base = (uint32_t)next;
+    }
+}
+// sparse per-bin survivors -> dense result list: one wave copies one bin's run; the last block appends the head survivors
+__global__ __launch_bounds__(kBlock) void bi2_compact_kernel(const uint32_t* __restrict__ sp_rep, const uint32_t* __restrict__ sp_cnt, const DevState* __restrict__ st,
+                                                              const Bi2State* __restrict__ bs, uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap) {
+    if (st->done) return;
+    const uint32_t res_base = st->res_total, lane = threadIdx.x & (kWave - 1);
+    if (blockIdx.x + 1 < gridDim.x) {
+        const uint32_t nwaves = (gridDim.x - 1) * (kBlock / kWave);
+        for (uint32_t g = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; g < (uint32_t)kBi2Final; g += nwaves) {
+            const uint32_t f   = ((g & (uint32_t)(kBins - 1)) * kBi2BBins) + (g >> 8);  // a fastest: the non-empty bins of a small order spread over all waves
+            const uint32_t off = bs->binkept[f];
+            const uint32_t n   = ((f + 1 < (uint32_t)kBi2Final) ? bs->binkept[f + 1] : bs->kept_bins) - off;
+            if (n == 0) continue;
+            const uint32_t src = bs->binoff[f];
+            for (uint32_t j = lane; j < n; j += kWave) {
+                const uint32_t r = res_base + off + j;
+                if (r < res_cap) {
+                    res_rep[r] = sp_rep[src + j];
+                    res_cnt[r] = sp_cnt[src + j];
+                }
+            }
+        }
+    } else {
+        uint32_t       r    = res_base + bs->kept_bins + bs->headbase[threadIdx.x];
+        const uint32_t bits = reinterpret_cast<const uint16_t*>(bs->headsurv)[threadIdx.x];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (bits & (1u << q)) {
+                if (r < res_cap) {
+                    res_rep[r] = ~bs->headposinv[threadIdx.x * 16 + q];
+                    res_cnt[r] = bs->headcnt[threadIdx.x * 16 + q];
+                }
+                ++r;
+            }
+    }
+}
+
+// ---- positions: the waves' unsorted lists -> one list per (shard, position bucket) ------------------------------------------------------------
+struct Bi2Lists {
+    uint32_t pcap;    // entries per (shard, bucket) list, a multiple of 4
+    uint32_t pshift;  // bucket = position >> pshift
+};
+// tile-local counting sort by bucket in LDS, one reserved run per (tile, bucket); block x takes the lists x, x + gridDim.x, ...
+__global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_pospart_kernel(const uint32_t* __restrict__ wlist, const uint32_t* __restrict__ wcnt, uint32_t nlists, uint32_t wcap,
+                                                                                      Bi2State* __restrict__ bs, const DevState* __restrict__ st, uint32_t* __restrict__ plist, Bi2Lists pl) {
+    if (st->done) return;
+    __shared__ uint32_t stgL[kBi2Tile];
+    __shared__ uint8_t  binL[kBi2Tile];
+    __shared__ uint32_t histL[kBi2Buckets], offL[kBi2Buckets], gbaseL[kBi2Buckets], wsumL[4];
+    const uint32_t      shard = blockIdx.x & (uint32_t)(kBi2Shards - 1);
+    for (uint32_t w = blockIdx.x; w < nlists; w += gridDim.x) {
+        const uint32_t        n   = min(wcnt[w], wcap);
+        const uint32_t* const src = wlist + (size_t)w * wcap;
+        for (uint32_t j0 = 0; j0 < n; j0 += kBi2Tile) {
+            uint32_t p[kBi2Per], rank[kBi2Per];
+            if (threadIdx.x < kBi2Buckets) histL[threadIdx.x] = 0;
+#pragma unroll
+            for (int k = 0; k < kBi2Per; ++k) {
+                const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
+                p[k]             = j < n ? src[j] : 0xFFFFFFFFu;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kBi2Per; ++k) {
+                rank[k] = kInvalid;
+                if (p[k] != 0xFFFFFFFFu) {
+                    const uint32_t b = p[k] >> pl.pshift;
+                    rank[k]          = atomicAdd(&histL[b], 1u) | (b << 16);
+                }
+            }
+            __syncthreads();
+            bi2_scan256(histL, offL, wsumL);
+            if (threadIdx.x < kBi2Buckets) {
+                const uint32_t h = histL[threadIdx.x];
+                uint32_t       g = 0;
+                if (h) {
+                    const uint32_t l  = shard * kBi2Buckets + threadIdx.x;
+                    const uint32_t at = atomicAdd(&bs->pcur[l], h);
+                    if (at + h > pl.pcap) bs->overflow = 3;
+                    g = l * pl.pcap + min(at, pl.pcap - min(pl.pcap, h));  // (fits 32 bits: shards * buckets * pcap <= 8 * positions)
+                }
+                gbaseL[threadIdx.x] = g;
+            }
+#pragma unroll
+            for (int k = 0; k < kBi2Per; ++k) {
+                if (rank[k] != kInvalid) {
+                    const uint32_t b = rank[k] >> 16, q = offL[b] + (rank[k] & 0xFFFFu);
+                    stgL[q]          = p[k];
+                    binL[q]          = (uint8_t)b;
+                }
+            }
+            __syncthreads();
+            const uint32_t m = min(n - j0, (uint32_t)kBi2Tile);
+            for (uint32_t j = threadIdx.x; j < m; j += kBi2Threads) {
+                const uint32_t b                      = binL[j];
+                plist[(size_t)gbaseL[b] + (j - offL[b])] = stgL[j];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- bitmap: per position bucket, the listed positions -> one bit each (built in LDS, written as whole words) -----------------------------
+__global__ __launch_bounds__(kBi2BmThreads) void bi2_bitmap_kernel(uint32_t npos, const Bi2State* __restrict__ bs, const uint32_t* __restrict__ plist, Bi2Lists pl,
+                                                                    const DevState* __restrict__ st, uint32_t* __restrict__ bitmap) {
+    if (st->done) return;
+    extern __shared__ uint32_t bmL[];  // (1 << pshift) / 32 words
+    const uint32_t b = blockIdx.x, start = b << pl.pshift;
+    if (start >= npos) return;
+    const uint32_t size   = min(1u << pl.pshift, npos - start);
+    const uint32_t nwords = (size + 31) / 32;
+    for (uint32_t w = threadIdx.x; w < nwords; w += kBi2BmThreads) bmL[w] = 0;
+    __syncthreads();
+    for (uint32_t x = 0; x < (uint32_t)kBi2Shards; ++x) {
+        const uint32_t     l = x * kBi2Buckets + b, n = min(bs->pcur[l], pl.pcap);
+        const uint32_t*    p = plist + (size_t)l * pl.pcap;  // 16-byte aligned: pcap is a multiple of 4
+        const uint4* const v = reinterpret_cast<const uint4*>(p);
+        const uint32_t     nv = n >> 2;
+        for (uint32_t j = threadIdx.x; j < nv; j += kBi2BmThreads) {
+            const uint4    e  = v[j];
+            const uint32_t o0 = e.x - start, o1 = e.y - start, o2 = e.z - start, o3 = e.w - start;
+            atomicOr(&bmL[o0 >> 5], 1u << (o0 & 31u));
+            atomicOr(&bmL[o1 >> 5], 1u << (o1 & 31u));
+            atomicOr(&bmL[o2 >> 5], 1u << (o2 & 31u));
+            atomicOr(&bmL[o3 >> 5], 1u << (o3 & 31u));
+        }
+        if (threadIdx.x < (n & 3u)) {
+            const uint32_t o = p[(nv << 2) + threadIdx.x] - start;
+            atomicOr(&bmL[o >> 5], 1u << (o & 31u));
+        }
+    }
+    __syncthreads();
+    for (uint32_t w = threadIdx.x; w < nwords; w += kBi2BmThreads) bitmap[(start >> 5) + w] = bmL[w];
+}
+
+// ---- list3: one streaming pass over the corpus: bitmap | head survivors -> active list of order 3 ----------------------------------------
+// entry i of the list: bigrams at i and at i + 1 both survived. st->valid += positions with a surviving bigram.
+// cls must be readable (zeros) up to index npos + 63 rounded up to a multiple of 32; bitmap up to word npos / 32 + 1 (zeros beyond the corpus).
+constexpr int kBi2L3Tile = kBlock * 32;  // one bitmap word per lane
+__global__ __launch_bounds__(kBlock) void bi2_list3_kernel(const uint32_t* __restrict__ cls, const uint32_t* __restrict__ surv, uint32_t npos, const Bi2State* __restrict__ bs,
+                                                            const uint32_t* __restrict__ bitmap, DevState* __restrict__ st, uint32_t* __restrict__ list_out,
+                                                            uint32_t* __restrict__ nlist_out) {
+    if (st->done) return;
+    __shared__ uint32_t hsL[kBi2HeadN / 32], stageL[kBi2L3Tile], baseL, redL[kBlock / kWave];
+    if (threadIdx.x < kBi2HeadN / 32) hsL[threadIdx.x] = bs->headsurv[threadIdx.x];
+    __syncthreads();
+    const uint32_t sw0 = surv[0], sw1 = surv[1];
+    const uint32_t ntiles = (npos + kBi2L3Tile - 1) / kBi2L3Tile;
+    uint32_t       nvalid = 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t w  = tile * kBlock + threadIdx.x;  // this lane's bitmap word = positions [32 w, 32 w + 32)
+        const uint32_t p0 = w * 32;
+        uint32_t       x = 0, nx = 0;
+        uint32_t       c[36];
+        if (p0 < npos) {
+            x  = bitmap[w];
+            nx = bitmap[w + 1];
+            const uint4* const v = reinterpret_cast<const uint4*>(cls + p0);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const uint4 e = v[k];
+                c[4 * k]     = e.x;
+                c[4 * k + 1] = e.y;
+                c[4 * k + 2] = e.z;
+                c[4 * k + 3] = e.w;
+            }
+            // head bigrams never became records: their windows are evaluated here, against the head survivor bits
+            uint32_t hb = 0, hnx = 0;
+#pragma unroll
+            for (int k = 0; k < 33; ++k) {
+                const uint32_t c0 = c[k], c1 = c[k + 1];
+                if (c0 - 1u < (uint32_t)(kBi2Head - 1) && c1 - 1u < (uint32_t)(kBi2Head - 1)) {
+                    const uint32_t s0 = (c0 < 32 ? sw0 >> c0 : sw1 >> (c0 - 32)) & 1u, s1 = (c1 < 32 ? sw0 >> c1 : sw1 >> (c1 - 32)) & 1u;
+                    const uint32_t h  = c0 * kBi2Head + c1;
+                    const uint32_t on = s0 & s1 & (hsL[h >> 5] >> (h & 31u));
+                    if (k < 32)
+                        hb |= on << k;
+                    else
+                        hnx = on;
+                }
+            }
+            x |= hb;
+            nx |= hnx;
+        }
+        const uint32_t y = x & ((x >> 1) | (nx << 31));
+        const uint32_t n = __popc(y);
+        nvalid += __popc(x);
+        uint32_t       total;
+        const uint32_t excl = block_exclusive_scan(n, &total);
+        if (threadIdx.x == 0) baseL = total ? atomicAdd(nlist_out, total) : 0u;
+        uint32_t o = excl, yy = y;
+        while (yy) {
+            const int bit = __builtin_ctz(yy);
+            yy &= yy - 1;
+            stageL[o++] = p0 + (uint32_t)bit;
+        }
+        __syncthreads();
+        const uint32_t gb = baseL;
+        for (uint32_t j = threadIdx.x; j < total; j += kBlock) list_out[gb + j] = stageL[j];
+        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) nvalid += __shfl_down(nvalid, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nvalid;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t v = redL[0] + redL[1] + redL[2] + redL[3];
+        if (v) atomicAdd(&st->valid, v);
+    }
+}
+
+// order 3 over the list bi2_list3_kernel leaves: every listed window is admissible (both bigrams survived), the key is its three class ids
+struct KeyTrigramClsListed {
+    const uint32_t* cls;
+    __device__ __forceinline__ bool operator()(uint32_t i, uint32_t npos, uint64_t& key, uint64_t& hash) const {
+        if (i + 2 >= npos) return false;
+        const uint32_t c0 = cls[i], c1 = cls[i + 1], c2 = cls[i + 2];
+        key  = (uint64_t)c0 | ((uint64_t)c1 << 21) | ((uint64_t)c2 << 42);
+        hash = mix64(key);
+        return true;
+    }
+};
+
+}  // namespace colibri

@@ -18,6 +18,7 @@
 
 #include "colibri_hip.h"
 #include "binned.hpp"
+#include "bigram2.hpp"
 #include "textenc.hpp"
 #include "constrained.hpp"
 #include "flexgrams.hpp"
@@ -113,6 +114,12 @@ struct colibri_ctx {
         uint64_t                   ngroups = 0, keybytes = 0, nrefs = 0;
         bool                       valid = false;
     } fx;
+    struct Bigram2 {                    // second-generation order 2 (bigram2.hpp)
+        DevBuf<Bi2State> state;
+        DevBuf<uint32_t> boff, head_rows, wlist, wcnt, plist, bitmap;
+        bool             disabled = false;  // set for the rerun after this path could not hold an order (region / bin / list overflow)
+        bool             attr_set = false;
+    } b2;
     DevBuf<uint32_t>  alist[2], alist_n; // binned path: active-position lists (ping-pong) and their lengths [2]
     DevBuf<BinState>  binstate;
     int               last_mode = 0;    // 1 = global table, 2 = binned (what the last train() actually ran)
@@ -282,11 +289,12 @@ int tokenise(colibri_ctx* c) {
     c->npos = npos;
     c->cs.rem_valid = false;  // per-position sentence remainders belong to the previous corpus
     c->pos_refs_valid = false;
-    if ((rc = dev_alloc(c, c->tokstart, (size_t)npos + 2)) || (rc = dev_alloc(c, c->cls, (size_t)npos + 1))) {
+    if ((rc = dev_alloc(c, c->tokstart, (size_t)npos + 2)) || (rc = dev_alloc(c, c->cls, (size_t)npos + 128))) {  // class ids are read as whole 16-byte vectors past the end (zeros)
         cleanup();
         return rc;
     }
     HIP_TRY(c, hipMemsetAsync(c->tokstart.p, 0, sizeof(uint32_t), c->stream));  // tokstart[0] = 0
+    HIP_TRY(c, hipMemsetAsync(c->cls.p + npos, 0, sizeof(uint32_t) * 128, c->stream));
     HIP_TRY(c, hipMemsetAsync(info.p, 0, sizeof(CorpusInfo), c->stream));
     HIP_TRY(c, hipMemsetAsync(hist.p, 0, sizeof(unsigned long long) * kLenHistBins, c->stream));
     const uint32_t   pblk = std::max<uint32_t>(1, blocks_for(npos, kBlock));
@@ -460,6 +468,7 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->fx.keys); dev_free(c->fx.keyoff); dev_free(c->fx.refoff); dev_free(c->fx.cnt); dev_free(c->fx.sentence); dev_free(c->fx.token);
     dev_free(c->tx.table); dev_free(c->tx.state); dev_free(c->tx.info); dev_free(c->tx.events); dev_free(c->tx.evcnt);
     dev_free(c->flag2);
+    dev_free(c->b2.state); dev_free(c->b2.boff); dev_free(c->b2.head_rows); dev_free(c->b2.wlist); dev_free(c->b2.wcnt); dev_free(c->b2.plist); dev_free(c->b2.bitmap);
     dev_free(c->ids_at);
     dev_free(c->alist[0]);
     dev_free(c->alist[1]);
@@ -706,10 +715,89 @@ int binned_resolve_stage(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids_out,
     return COLIBRI_OK;
 }
 
+// ---- order 2, second generation (bigram2.hpp): class-keyed 8-byte records, dense head, per-slot level B, one wave per final bin, position
+// lists -> bitmap -> the active list of order 3. `want_list`: order 3 follows. Everything is enqueued; nothing is read back.
+constexpr uint32_t kBi2Sub = 8, kBi2EmitGrid = 512, kBi2Waves = 256 * 16;
+struct Bigram2Plan {
+    uint32_t nslots, region, pshift, nbuckets, wcap;
+    Bi2Lists pl;
+};
+Bigram2Plan bigram2_plan(const colibri_ctx* c, uint32_t npos) {
+    Bigram2Plan b{};
+    b.nslots = kBins * kBi2Sub;
+    // records are 8 bytes: recs[0] (level-A output) and recs[1] (level-B output) hold twice their Rec capacity
+    b.region = (uint32_t)(std::min<uint64_t>(2ull * c->recs[0].n, 2ull * c->recs[1].n) / b.nslots);
+    b.pshift = 12;
+    while (((uint64_t)npos >> b.pshift) > (uint64_t)kBi2Buckets - 1) ++b.pshift;
+    b.nbuckets  = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)npos + (1u << b.pshift) - 1) >> b.pshift));
+    b.pl.pshift = b.pshift;
+    b.pl.pcap   = ((1u << b.pshift) / 2 + 64 + 3) & ~3u;
+    b.wcap      = (uint32_t)(((uint64_t)npos * 6 / 10 / kBi2Waves) * 2 + 4096);
+    return b;
+}
+int bigram2_alloc(colibri_ctx* c, uint32_t npos) {
+    const Bigram2Plan b = bigram2_plan(c, npos);
+    int               rc;
+    if ((rc = dev_alloc(c, c->b2.state, 1)) || (rc = dev_alloc(c, c->b2.boff, (size_t)b.nslots * (kBi2BBins + 1))) ||
+        (rc = dev_alloc(c, c->b2.head_rows, (size_t)kBi2EmitGrid * 2 * kBi2HeadN)) || (rc = dev_alloc(c, c->b2.wlist, (size_t)kBi2Waves * b.wcap)) ||
+        (rc = dev_alloc(c, c->b2.wcnt, kBi2Waves)) || (rc = dev_alloc(c, c->b2.plist, (size_t)kBi2Shards * kBi2Buckets * b.pl.pcap)) ||
+        (rc = dev_alloc(c, c->b2.bitmap, (size_t)npos / 32 + 16)))
+        return rc;
+    if (!c->b2.attr_set) {
+        HIP_TRY(c, hipFuncSetAttribute((const void*)bi2_bitmap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)1 << 27) / kBi2Buckets / 8)));
+        c->b2.attr_set = true;
+    }
+    return COLIBRI_OK;
+}
+int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list) {
+    const uint32_t    npos = pl.npos, nsurv = c->maxclass / 32 + 1;
+    const Bigram2Plan b    = bigram2_plan(c, npos);
+    Bi2State* const   bs   = c->b2.state.p;
+    auto* const       recsA = reinterpret_cast<unsigned long long*>(c->recs[0].p);
+    auto* const       recsB = reinterpret_cast<unsigned long long*>(c->recs[1].p);
+    uint32_t* const   nlist = c->alist_n.p + 1;  // order 3 reads alist[3 & 1]
+    HIP_TRY(c, hipMemsetAsync(bs, 0, sizeof(Bi2State), c->stream));
+    HIP_TRY(c, hipMemsetAsync(nlist, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->b2.wcnt.p, 0, sizeof(uint32_t) * kBi2Waves, c->stream));
+    {
+        Prof p(c, COLIBRI_K_EMIT);
+        hipLaunchKernelGGL(bi2_emit_kernel, dim3(kBi2EmitGrid), dim3(kBi2Threads), 0, c->stream, c->cls.p, c->uni_surv.p, nsurv, npos, recsA, b.region, kBi2Sub, bs, c->state.p,
+                           c->b2.head_rows.p);
+        hipLaunchKernelGGL(bi2_head_reduce_kernel, dim3(kBi2HeadN / kBlock, kBi2HeadSplit), dim3(kBlock), 0, c->stream, c->b2.head_rows.p, kBi2EmitGrid, bs, c->state.p);
+        hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, b.region, kBi2Sub, c->state.p);
+    }
+    {
+        Prof p(c, COLIBRI_K_SCATTER);
+        hipLaunchKernelGGL(bi2_levelB_kernel, dim3(b.nslots), dim3(kBi2Threads), 0, c->stream, recsA, recsB, b.region, bs, c->b2.boff.p, c->state.p);
+        hipLaunchKernelGGL(bi2_binoff_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->b2.boff.p, kBi2Sub, c->state.p);
+    }
+    const BinnedIO io = binned_planes(c, pl, false);  // the sparse survivor arrays live in recs[0], free again after level B
+    {
+        Prof p(c, COLIBRI_K_BINCOUNT);
+        hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr, io.sp_rep, io.sp_cnt,
+                           c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list);
+    }
+    {
+        Prof p(c, COLIBRI_K_PRUNE);
+        hipLaunchKernelGGL(bi2_kept_scan_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->state.p);
+        hipLaunchKernelGGL(bi2_finish_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->state.p, bs, pl.thr, pl.res_cap);
+        hipLaunchKernelGGL(bi2_compact_kernel, dim3(1025), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, bs, c->res_rep.p, c->res_cnt.p, pl.res_cap);
+    }
+    if (!want_list) return COLIBRI_OK;
+    HIP_TRY(c, hipMemsetAsync(c->b2.bitmap.p + npos / 32, 0, sizeof(uint32_t) * 16, c->stream));  // words beyond the corpus read as zero
+    {
+        Prof p(c, COLIBRI_K_RESOLVE);
+        hipLaunchKernelGGL(bi2_pospart_kernel, dim3(512), dim3(kBi2Threads), 0, c->stream, c->b2.wlist.p, c->b2.wcnt.p, kBi2Waves, b.wcap, bs, c->state.p, c->b2.plist.p, b.pl);
+        hipLaunchKernelGGL(bi2_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, bs, c->b2.plist.p, b.pl, c->state.p, c->b2.bitmap.p);
+        hipLaunchKernelGGL(bi2_list3_kernel, dim3(2048), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_surv.p, npos, bs, c->b2.bitmap.p, c->state.p, c->alist[1].p, nlist);
+    }
+    return COLIBRI_OK;
+}
+
 // one order of the plain (unsynced) run. need_ids = false at the last order: nothing reads its survivor ids, so the id scatter and
 // the resolve pass are skipped.
 template <class KeyFn>
-int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t* ids_out, int n, bool use_list, bool need_ids, bool flag_mode = false) {
+int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t* ids_out, int n, bool use_list, bool need_ids, bool flag_mode = false, bool prefill_ids = false) {
     int rc;
     if ((rc = binned_count_stage(c, pl, fn, n, use_list, pl.thr, false, need_ids, flag_mode))) return rc;
     const BinnedIO io = binned_planes(c, pl, false);
@@ -729,8 +817,10 @@ int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t*
                            nlist_out);
         return COLIBRI_OK;
     }
-    // the only later reader is the next order's emit kernel (ids at i and i+1 for i on the new active list): no fill of ids_out
-    return binned_resolve_stage(c, pl, ids_out, n, use_list, /*build_list=*/n >= 2, nullptr, 0u, false);
+    // the only later reader is the next order's emit kernel (ids at i and i+1 for i on the new active list): no fill of ids_out when this order's list
+    // covers every position whose (n-1)-gram survived. (prefill_ids: the list holds only the admissible windows — a survivor at i then says nothing
+    // about i + 1 being listed, so the unlisted positions must read as "no survivor")
+    return binned_resolve_stage(c, pl, ids_out, n, use_list, /*build_list=*/n >= 2, nullptr, 0u, prefill_ids);
 }
 
 // One (order, gap mask) skipgram pass. Exact identity of a skipgram = the survivor ids of its contiguous parts, paired
@@ -1067,7 +1157,10 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     // three class ids in one key: order 3 is keyed by classes, order 2 leaves survivor bytes instead of ids (KeyTrigramCls)
     const bool tri_cls = binned && uni_direct && !synced && c->maxclass < (1u << 21) && o.maxlength >= 3;
     const bool bi_cls = tri_cls && uni_shift != 0;  // ... and order 2 is keyed by classes + the order-1 survivor bitmap: no per-position order-1 ids at all
-    if (tri_cls && ((rc = dev_alloc(c, c->flags_at, (size_t)npos + 1)) || (rc = dev_alloc(c, c->flag2, (size_t)npos + 4)))) return rc;
+    // second-generation order 2 (bigram2.hpp): same preconditions as the class-keyed order 2, positions in 27 bits; a run that it could not hold
+    // (c->b2.disabled, set below) repeats on the first-generation kernels
+    const bool bi2 = binned && uni_direct && !synced && uni_shift != 0 && c->maxclass < (1u << 21) && o.maxlength >= 2 && npos < (1u << kBi2PosBits) && !c->b2.disabled;
+    if (tri_cls && !bi2 && ((rc = dev_alloc(c, c->flags_at, (size_t)npos + 1)) || (rc = dev_alloc(c, c->flag2, (size_t)npos + 4)))) return rc;
     // ---- HBM layout (sized once; nothing is allocated inside the unsynced order loop) ----------------
     // table: an order admits at most `npos` windows -> 1.5x slots; results: every survivor has >= 2 occurrences
     const uint64_t table_slots64 = (uint64_t)npos + (npos >> 1) + 2048;
@@ -1101,6 +1194,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
         if ((rc = dev_alloc(c, c->recs[0], ((size_t)npos + (npos >> 2)) / kBins * kBins + (size_t)kBins * kScatTile)) || (rc = dev_alloc(c, c->recs[1], (size_t)npos + 1))) return rc;
         if ((rc = dev_alloc(c, c->rep_of, (size_t)npos + 1)) || (rc = dev_alloc(c, c->ids_at, (size_t)npos + 1)) || (rc = dev_alloc(c, c->binstate, 1))) return rc;
         if ((rc = dev_alloc(c, c->alist[0], (size_t)npos + 1)) || (rc = dev_alloc(c, c->alist[1], (size_t)npos + 1)) || (rc = dev_alloc(c, c->alist_n, 2))) return rc;
+        if (bi2 && (rc = bigram2_alloc(c, npos))) return rc;
     }
     if (!binned && (rc = dev_alloc(c, c->table, pl.table_slots))) return rc;  // the plain radix run needs no table (a bin overflow re-runs with table_mode = 1)
     if ((rc = dev_alloc(c, c->res_rep, pl.res_cap))) return rc;
@@ -1146,10 +1240,10 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                 {
                     Prof p(c, COLIBRI_K_PRUNE);
                     hipLaunchKernelGGL(uni_finish_kernel, dim3(stream_grid(nclasses)), dim3(kBlock), 0, c->stream, c->cnt1.p, uni_shift ? (const uint32_t*)nullptr : c->rep1.p, nclasses,
-                                       pl.thr, c->state.p, c->res_rep.p, c->res_cnt.p, pl.res_cap, uni_shift ? reinterpret_cast<uint16_t*>(c->uni_surv.p) : (uint16_t*)nullptr, bi_cls,
+                                       pl.thr, c->state.p, c->res_rep.p, c->res_cnt.p, pl.res_cap, uni_shift ? reinterpret_cast<uint16_t*>(c->uni_surv.p) : (uint16_t*)nullptr, bi_cls || bi2,
                                        (uint32_t*)nullptr, wthr);
                 }
-                if (!bi_cls) {  // with class-keyed orders 2 and 3 nothing reads order-1 ids per position
+                if (!bi_cls && !bi2) {  // with class-keyed orders 2 and 3 nothing reads order-1 ids per position
                     Prof p(c, COLIBRI_K_RESOLVE);
                     if (uni_shift)
                         hipLaunchKernelGGL(uni_ids_bitmap_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_surv.p, (nclasses + 31) / 32, id_cur, c->state.p, npos);
@@ -1161,6 +1255,10 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                 // carry a survivor id are visited (the active list the previous order's resolve left behind)
                 if (n == 1)
                     rc = binned_order(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, id_cur, n, false, n < maxlength);
+                else if (n == 2 && bi2)
+                    rc = bigram2_order(c, pl, /*want_list=*/n < maxlength);
+                else if (n == 3 && bi2)
+                    rc = binned_order(c, pl, KeyTrigramClsListed{c->cls.p}, id_cur, n, true, n < maxlength, false, /*prefill_ids=*/true);  // over the list bigram2 left: every listed window is admissible
                 else if (n == 2 && bi_cls)
                     rc = binned_order(c, pl, KeyBigramCls{c->cls.p, c->uni_surv.p}, id_cur, n, false, true, /*flag_mode=*/true);
                 else if (n == 2 && tri_cls)
@@ -1191,6 +1289,12 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             }
         }
         if ((rc = read_state(c))) return rc;
+        if (binned && c->hstate.radix_overflow == 4) {  // the second-generation order 2 could not hold this corpus (a hot bigram outside the dense head): first-generation kernels
+            c->b2.disabled = true;
+            const int rc2  = colibri_train(c, &o, stats_out);
+            c->b2.disabled = false;
+            return rc2;
+        }
         if (binned && c->hstate.radix_overflow) {  // a final bin outgrew its LDS table (hash skew): run again on the global table — loud, exact, rare
             if (o.table_mode == 2)
                 return fail(c, COLIBRI_ERR_OVERFLOW, "the radix path overflowed (%s; region %llu records, %u positions; table_mode = 2 forbids the global-table rerun)",

@@ -54,6 +54,8 @@ constexpr uint32_t kBi2MaxLoad  = 900;
 constexpr uint32_t kBi2Empty    = 0xFFFFFFFFu;            // keys are 31 bits
 constexpr int      kBi2HeadSplit = 32;                    // row groups of the head reduction
 constexpr int      kBi2BmThreads = 1024;                  // bitmap kernels: one block per position bucket
+constexpr uint32_t kBi2BigBin    = 1536;                  // records from which a final bin counts as big
+constexpr int      kBi2BigCap    = 8192;
 
 struct Bi2State {
     uint32_t curA[kBi2MaxSlots];  // emit cursors = records per slot (beyond `region`: overflow)
@@ -66,7 +68,9 @@ struct Bi2State {
     uint32_t headsurv[kBi2HeadN / 32];                   // bit k = head bigram k survived
     uint32_t headbase[kBlock];                           // first result rank of the head survivors of lane t (16 head keys per lane)
     uint32_t pcur[kBi2Shards * kBi2Buckets];             // position-list cursors
-    uint32_t nrec, bshift, overflow, kept_bins, kept_head, pad[3];
+    uint32_t nrec, bshift, overflow, kept_bins, kept_head, nbig, pad[2];
+    uint32_t nextbin[kBi2Shards * 16];  // work queues of the count kernel (one per shard, 64 bytes apart): next group of bins to hand out
+    uint32_t big[kBi2BigCap];           // final bins with more than kBi2BigBin records: counted first (one wave each), so that none of them starts late
 };
 
 // exclusive scan of 256 LDS values by the first 256 threads of a block of any size; every thread of the block must call it
@@ -398,6 +402,10 @@ __global__ __launch_bounds__(kBi2BBins) void bi2_binoff_kernel(Bi2State* __restr
             t += bo[b + 1] - bo[b];
         }
     inL[b] = t;
+    if (t > kBi2BigBin) {
+        const uint32_t k = atomicAdd(&bs->nbig, 1u);
+        if (k < (uint32_t)kBi2BigCap) bs->big[k] = a * kBi2BBins + b;
+    }
     __syncthreads();
     bi2_scan512(inL, outL, wsumL);
     bs->binoff[a * kBi2BBins + b] = bs->offAt[a] + outL[b];
@@ -413,7 +421,8 @@ __global__ __launch_bounds__(kBi2BBins) void bi2_binoff_kernel(Bi2State* __restr
 // are never freed, so the first slot that holds the key or is empty decides; a full bucket continues in the next one. Two rows are inserted per
 // round (their compare-and-swaps are in flight together). Survivors go to the bin's own range of the sparse result arrays; the positions of
 // the windows of surviving keys are appended, unsorted, to the wave's private list (ballot-compacted, coalesced): bi2_pospart_kernel sorts them
-// into position buckets afterwards.
+// into position buckets afterwards. Bins are handed out dynamically, the big ones (a hot key outside the dense head) first; their records
+// beyond the register window are streamed four rows at a time with the next four in flight.
 constexpr int      kBi2WRows = 12;   // records per lane in registers (bins of up to 768 records are read once)
 constexpr int      kBi2WReps = 256;  // survivors of a bin whose lowest position is tracked in LDS (beyond: device atomics on the result array)
 constexpr uint32_t kBi2Kept  = 0x80000000u;
@@ -512,8 +521,8 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
 #else
 #define BI2_W(k) do {} while (0)
 #endif
-    for (uint32_t g = wid; g < nfinal; g += nwaves) {
-        const uint32_t a = g & (uint32_t)(kBins - 1), b = g >> 8;
+    // one final bin (a, b), start to end; `big_pass`: the bin comes from the list of big bins (the regular walk skips those)
+    auto process_bin = [&](const uint32_t a, const uint32_t b, const bool big_pass, const bool skip_big) {
         BI2_W(0);
         // run bounds: 2 NSUB + 1 lanes load, v_readlane broadcasts (scalar registers)
         uint32_t v = 0;
@@ -530,7 +539,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
         }
         const uint32_t spo = (uint32_t)__builtin_amdgcn_readlane((int)v, 2 * NSUB);
         BI2_W(1);
-        if (total == 0) continue;
+        if (total == 0 || (!big_pass && skip_big && total > kBi2BigBin)) return;
         auto locate = [&](uint32_t j) -> size_t {  // record j (< total) of the bin -> its index in recsB
             uint32_t off = 0, slot = 0;
             bool     ok  = false;
@@ -589,31 +598,47 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
             }
         }
         BI2_W(4);
-        for (uint32_t j0 = kBi2WRows * kWave; j0 < total; j0 += 2 * kWave) {  // larger bins stream the remainder, two rows per round
-            const uint32_t           jA = j0 + lane, jB = j0 + kWave + lane;
-            const bool               actA = jA < total, actB = jB < total;
-            const unsigned long long yA = actA ? recsB[locate(jA)] : 0ull, yB = actB ? recsB[locate(jB)] : 0ull;
-            const uint32_t           keyA = (uint32_t)(yA >> kBi2PosBits) & 0x7FFFFFFFu, keyB = (uint32_t)(yB >> kBi2PosBits) & 0x7FFFFFFFu;
-            const uint32_t           bkA = bi2_bucket_of(keyA, lgb, bmask), bkB = bi2_bucket_of(keyB, lgb, bmask);
-            uint32_t                 tA, tB;
-            bi2_insert2(keyT, bmask, actA, keyA, bkA, *reinterpret_cast<const uint4*>(keyT + bkA * 4), tA, actB, keyB, bkB, *reinterpret_cast<const uint4*>(keyT + bkB * 4), tB);
-            if (actA) {
-                if (tA == kInvalid)
-                    fail = true;
-                else
-                    atomicAdd(&cntT[tA], 1u);
-            }
-            if (actB) {
-                if (tB == kInvalid)
-                    fail = true;
-                else
-                    atomicAdd(&cntT[tB], 1u);
+        if (total > (uint32_t)(kBi2WRows * kWave)) {  // larger bins stream the remainder: four rows per round, the next four already in flight
+            unsigned long long y[4];
+            auto               load4 = [&](uint32_t j0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t j = j0 + k * kWave + lane;
+                    y[k]             = j < total ? recsB[locate(j)] : ~0ull;
+                }
+            };
+            load4(kBi2WRows * kWave);
+            for (uint32_t j0 = kBi2WRows * kWave; j0 < total; j0 += 4 * kWave) {
+                unsigned long long z[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) z[k] = y[k];
+                load4(j0 + 4 * kWave);
+#pragma unroll
+                for (int k = 0; k < 4; k += 2) {
+                    const bool     actA = z[k] != ~0ull, actB = z[k + 1] != ~0ull;
+                    const uint32_t keyA = (uint32_t)(z[k] >> kBi2PosBits) & 0x7FFFFFFFu, keyB = (uint32_t)(z[k + 1] >> kBi2PosBits) & 0x7FFFFFFFu;
+                    const uint32_t bkA = bi2_bucket_of(keyA, lgb, bmask), bkB = bi2_bucket_of(keyB, lgb, bmask);
+                    uint32_t       tA, tB;
+                    bi2_insert2(keyT, bmask, actA, keyA, bkA, *reinterpret_cast<const uint4*>(keyT + bkA * 4), tA, actB, keyB, bkB, *reinterpret_cast<const uint4*>(keyT + bkB * 4), tB);
+                    if (actA) {
+                        if (tA == kInvalid)
+                            fail = true;
+                        else
+                            atomicAdd(&cntT[tA], 1u);
+                    }
+                    if (actB) {
+                        if (tB == kInvalid)
+                            fail = true;
+                        else
+                            atomicAdd(&cntT[tB], 1u);
+                    }
+                }
             }
         }
         BI2_W(5);
         if (__any(fail)) {
             if (lane == 0) bs->overflow = 2;
-            continue;
+            return;
         }
         // survivors: lane l looks at the nslots / 64 consecutive slots from l * (nslots / 64), four at a time
         const uint32_t per  = nslots / kWave;
@@ -629,7 +654,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
         bi2_wave_excl_scan(used, &distinct);
         if (distinct > kBi2MaxLoad) {
             if (lane == 0) bs->overflow = 2;
-            continue;
+            return;
         }
         if (lane == 0) {
             atomicAdd(&bs->found_part[a], distinct);
@@ -637,7 +662,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
             if (ktotal) atomicAdd(&bs->kept_part[a], ktotal);
         }
         BI2_W(6);
-        if (ktotal == 0) continue;
+        if (ktotal == 0) return;
         const bool reps_lds = ktotal <= (uint32_t)kBi2WReps;
         {
             uint32_t r = excl;
@@ -665,9 +690,9 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
         auto settle = [&](bool valid, uint32_t pos, uint32_t s) {
             uint32_t c = 0;
             if (valid) c = cntT[s];
-            const bool kept = (c & kBi2Kept) != 0;
+            const bool     kept = (c & kBi2Kept) != 0;
+            const uint32_t r    = c & ~kBi2Kept;
             if (kept) {
-                const uint32_t r = c & ~kBi2Kept;
                 if (reps_lds)
                     atomicMin(&repS[r], pos);
                 else
@@ -690,17 +715,57 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
         for (int q = 0; q < kBi2WRows; ++q)
             if ((uint32_t)(q * kWave) < total) settle(sl[q] != kInvalid, (uint32_t)(x[q] & kBi2PosMask), sl[q]);
         BI2_W(8);
-        for (uint32_t j0 = kBi2WRows * kWave; j0 < total; j0 += kWave) {
-            const uint32_t           j = j0 + lane;
-            const bool               valid = j < total;
-            const unsigned long long y = valid ? recsB[locate(j)] : 0ull;
-            const uint32_t           key = (uint32_t)(y >> kBi2PosBits) & 0x7FFFFFFFu;
-            settle(valid, (uint32_t)(y & kBi2PosMask), valid ? bi2_find(keyT, key, bi2_bucket_of(key, lgb, bmask), bmask) : 0u);
+        if (total > (uint32_t)(kBi2WRows * kWave)) {
+            unsigned long long y[4];
+            auto               load4 = [&](uint32_t j0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t j = j0 + k * kWave + lane;
+                    y[k]             = j < total ? recsB[locate(j)] : ~0ull;
+                }
+            };
+            load4(kBi2WRows * kWave);
+            for (uint32_t j0 = kBi2WRows * kWave; j0 < total; j0 += 4 * kWave) {
+                unsigned long long z[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) z[k] = y[k];
+                load4(j0 + 4 * kWave);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if ((uint32_t)(j0 + k * kWave) < total) {
+                        const bool     valid = z[k] != ~0ull;
+                        const uint32_t key   = (uint32_t)(z[k] >> kBi2PosBits) & 0x7FFFFFFFu;
+                        settle(valid, (uint32_t)(z[k] & kBi2PosMask), valid ? bi2_find(keyT, key, bi2_bucket_of(key, lgb, bmask), bmask) : 0u);
+                    }
+                }
+            }
         }
         BI2_W(9);
         if (reps_lds)
             for (uint32_t r = lane; r < ktotal; r += kWave) sp_rep[spo + r] = repS[r];
         BI2_W(10);
+    };
+    // the big bins first, one per wave, so that none of them starts when the others are about to finish; then the regular walk
+    const uint32_t nbig = bs->nbig;
+    const bool     skip_big = nbig <= (uint32_t)kBi2BigCap;  // (more big bins than the list holds: the regular walk takes them all)
+    if (skip_big)
+        for (uint32_t k = wid; k < nbig; k += nwaves) {
+            const uint32_t f = bs->big[k];
+            process_bin(f / kBi2BBins, f % kBi2BBins, true, true);
+        }
+    // bins are handed out four at a time from 8 queues (queue q = the bins g with g mod 8 == q; a single counter would serialise ~12 ns per request):
+    // a wave that drew a big bin simply takes fewer of the others
+    const uint32_t q = wid & (uint32_t)(kBi2Shards - 1);
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&bs->nextbin[q * 16], 4u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t * kBi2Shards + q >= nfinal) break;
+#pragma unroll 1
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t g = (t + k) * kBi2Shards + q;
+            if (g < nfinal) process_bin(g & (uint32_t)(kBins - 1), g >> 8, false, skip_big);
+        }
     }
 #ifdef BI2_PROF
     if (lane == 0)

@@ -7,8 +7,11 @@
 A "step" is one complete train() (all five orders: scan + SpookyHash + hash build + prune + resolve) over one
 synthetic class-encoded corpus that is already resident in HBM when the timed region starts.
   N = 1 : BASELINE.json configs[1] — 100M-token Zipf(1.0, V = 1e6) corpus, unindexed, n <= 5, threshold 2.
-  N > 1 : the corpus is sharded by sentence, 100M tokens PER RANK (weak scaling), with the per-order exchange of
-          candidate counts over RCCL (colibri_amd.dist).
+  N > 1 : the corpus is sharded by sentence, 100M tokens PER RANK (weak scaling; N = 8: 125M per rank = the 1B-token corpus of
+          configs[2]), with the per-order exchange of candidate counts over RCCL (colibri_amd.dist).
+The run checks what it timed: for the default corpus (seed 44) the model must be the known one (tests/test_gpu_fullsize.py) or the exit
+status is non-zero. `other_configs` reports the other model kinds of BASELINE.json (configs[3], configs[4]) on the same corpus from extra,
+untimed steps.
 Metric (BASELINE.json): M patterns counted / s, patterns counted = sum_{n<=5} W_n = the n-token windows inside
 sentences that the reference enumerates in line.ngrams() (include/patternmodel.h:1063) — a property of the input.
 Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (count) against HBM peak with the algorithmic
@@ -75,6 +78,29 @@ def cpu_baseline(sample_tokens, vocab):
             "seconds": round(dt, 3), "host_cores": os.cpu_count()}
 
 
+def other_configs(ctx, capi, nbytes, tokens):
+    """The other model kinds of BASELINE.json on the corpus that is resident: configs[3] (skipgrams: the exhaustive unindexed variant and the
+    indexed one with MINSKIPTYPES = 2) and configs[4] (indexed model = forward index on the device). Untimed steps after the timed region: best of
+    three train() calls each, with the kernel classes bracketed by HIP events in a fourth. Algorithmic bytes: the counting stage of the n-gram
+    passes as in `roofline` plus, for indexed models, 8 bytes per reference written once and read once per 8-bit sort pass."""
+    res = {}
+    kinds = (("exhaustive_skipgrams", dict(doskipgrams_exhaustive=1)), ("indexed", dict(indexed=1)), ("indexed_skipgrams_T2", dict(indexed=1, doskipgrams=1, minskiptypes=2)))
+    for name, kw in kinds:
+        best, st = None, None
+        for _ in range(3):
+            st = ctx.train(maxlength=MAXLENGTH, mintokens=MINTOKENS, **kw)
+            best = st.train_ms if best is None else min(best, st.train_ms)
+        stp = ctx.train(maxlength=MAXLENGTH, mintokens=MINTOKENS, profile=1, **kw)
+        kms = {capi.KERNEL_CLASSES[k]: round(ctx.kernel_time(k)[0], 3) for k in range(len(capi.KERNEL_CLASSES)) if ctx.kernel_time(k)[1]}
+        dom = max(kms, key=kms.get) if kms else None
+        scan_n, build_n = algorithmic_bytes(nbytes, ctx.positions(), st, MAXLENGTH)
+        algo = sum(scan_n) + sum(build_n) + (8.0 * st.nrefs * 2 if kw.get("indexed") else 0.0)
+        res[name] = {"ms_per_step": round(best, 3), "patterns_in_model": int(st.npatterns), "references": int(st.nrefs), "dominant_kernel_class": dom,
+                     "kernel_ms_per_step": kms, "algorithmic_bytes_per_step": round(algo), "achieved_GBps": round(algo / (best * 1e-3) / 1e9, 1),
+                     "frac_of_hbm_peak": round(algo / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+    return res
+
+
 def measured_traffic(workload_tokens, kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
     path = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
@@ -93,13 +119,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--tokens", type=int, default=100_000_000, help="tokens per GPU (default: the 100M-token config)")
+    ap.add_argument("--tokens", type=int, default=0, help="tokens per GPU (default: 100M — the 100M-token config —, 125M with --gpus 8 = the 1B-token corpus of config 3)")
     ap.add_argument("--vocab", type=int, default=1_000_000)
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="tokens of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="tokens of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the untimed steps of the other model kinds (skipgrams, indexed)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for debugging)")
     ap.add_argument("--share-gpu", action="store_true", help="debugging: all ranks use cuda:0 (needs --backend gloo)")
     ap.add_argument("--force-shard", action="store_true", help="debugging: run the sharded trainer even with one rank (prices the exchange machinery)")
     args = ap.parse_args()
+    if args.tokens <= 0:
+        args.tokens = 125_000_000 if args.gpus == 8 else 100_000_000
 
     import torch
     from colibri_amd import capi, synth
@@ -167,7 +196,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    kclasses = (capi.K_CLEAR, capi.K_COUNT, capi.K_PRUNE, capi.K_RESOLVE, capi.K_EMIT, capi.K_SCATTER, capi.K_BINCOUNT)
+    kclasses = (capi.K_CLEAR, capi.K_COUNT, capi.K_PRUNE, capi.K_RESOLVE, capi.K_EMIT, capi.K_SCATTER, capi.K_BINCOUNT, capi.K_EMIT2, capi.K_LEVELB2, capi.K_COUNT2, capi.K_LISTS2)
     kms = {k: 0.0 for k in kclasses}
     kn = {k: 0 for k in kclasses}
     for _ in range(args.steps):
@@ -207,19 +236,42 @@ def main():
     value = windows * args.steps / elapsed / 1e6
     scan_n, build_n = algorithmic_bytes(payload.size, ctx.positions(), st, MAXLENGTH)
     scan_b, build_b = sum(scan_n), sum(build_n)
-    binned = kn[capi.K_BINCOUNT] > 0
-    # Which kernels ran: global-table path -> count_kernel does scan + hash + build for every order. Radix path -> order 1 is the
-    # class-indexed uni_count_kernel (class K_COUNT, one launch), orders >= 2 are emit / scatter / bin_count; the dominant kernel
-    # (largest total time in the rocprofv3 stats) is bin_count_kernel, whose algorithmic bytes are the build share of ITS orders.
+    binned = kn[capi.K_BINCOUNT] > 0 or kn[capi.K_COUNT2] > 0
+    # Which kernels ran. Global-table path: count_kernel does scan + hash + build for every order. Radix path: order 1 is the class-indexed count
+    # (class K_COUNT), order 2 the second-generation pipeline (emit2 / levelB2 / count2 / lists2: bigram2.hpp), orders >= 3 emit / scatter / bincount.
+    # The dominant kernel (largest total time in the rocprofv3 stats) is then bi2_count_kernel — one launch per step, the table build of order 2 —
+    # and its algorithmic bytes are the build share of ITS order; without it (a corpus the second generation cannot take) bin_count_kernel with the
+    # build share of orders 2..5, as in round 1.
     uni = binned and kn[capi.K_COUNT] > 0
-    dom = capi.K_BINCOUNT if binned else capi.K_COUNT
-    dom_bytes = (sum(build_n[1:]) if uni else build_b) if binned else scan_b + build_b
+    second = kn[capi.K_COUNT2] > 0
+    if second:
+        dom, dom_bytes = capi.K_COUNT2, build_n[1]
+    elif binned:
+        dom, dom_bytes = capi.K_BINCOUNT, (sum(build_n[1:]) if uni else build_b)
+    else:
+        dom, dom_bytes = capi.K_COUNT, scan_b + build_b
     launches_per_step = kn[dom] / max(1, args.steps)
     avg_launch_ms = kms[dom] / max(1, kn[dom])
     achieved = (dom_bytes / max(1.0, launches_per_step)) / (avg_launch_ms * 1e-3) / 1e9 if kn[dom] else 0.0
-    stage = (capi.K_COUNT, capi.K_EMIT, capi.K_SCATTER, capi.K_BINCOUNT) if binned else (capi.K_COUNT,)
+    stage = (capi.K_COUNT, capi.K_EMIT, capi.K_SCATTER, capi.K_BINCOUNT, capi.K_EMIT2, capi.K_LEVELB2, capi.K_COUNT2) if binned else (capi.K_COUNT,)
     stage_ms = sum(kms_all[k] for k in stage) / EXTRA
     stage_gbs = (scan_b + build_b) / (stage_ms * 1e-3) / 1e9 if stage_ms else 0.0
+    kept = [int(st.kept[n]) for n in range(1, MAXLENGTH + 1)]
+    # ---- self-check: the model of the default corpus is known (seed 44: tests/test_gpu_fullsize.py; the reference's CPU run gives the same counts on the 1M / 10M corpora) ----
+    KNOWN = {(100_000_000, 1_000_000, 1): ([999003, 6003382, 2066683, 298710, 18788], 9386566)}
+    check = KNOWN.get((args.tokens, args.vocab, args.gpus))
+    check_ok = None
+    if check is not None:
+        check_ok = kept == check[0] and npatterns == check[1]
+    # ---- export, reported separately ----
+    export_ms = None
+    if dist is None:
+        t0 = time.perf_counter()
+        arrays = ctx.export_arrays()
+        export_ms = (time.perf_counter() - t0) * 1e3
+        if check is not None:
+            check_ok = check_ok and len(arrays[2]) == check[1] and int(np.asarray(arrays[2], dtype=np.uint64).sum()) > 0
+        del arrays
     out = {
         "metric": "M patterns counted/sec at n<=5 thr=2; identical pattern set vs reference",
         "value": round(value, 3),
@@ -239,20 +291,23 @@ def main():
             "tokens_per_gpu": args.tokens,
             "patterns_counted_per_step": int(windows),
             "patterns_in_model": npatterns,
-            "kept_per_order": [int(st.kept[n]) for n in range(1, MAXLENGTH + 1)],
+            "kept_per_order": kept,
+            "self_check": ("ok" if check_ok else "FAILED") if check_ok is not None else "no known answer for this configuration",
+            "export_ms_untimed": round(export_ms, 2) if export_ms is not None else None,
             "parallelism": "single device" if args.gpus == 1 else f"sentence-sharded x{args.gpus}, per-order candidate exchange over RCCL",
             "tokenise_ms_untimed": round(tokenise_ms, 3),
             "corpus_generation_s_untimed": round(gen_s, 2),
         },
         "roofline": {
-            "kernel": ("colibri::bin_count_kernel (per-bin LDS hash build + threshold + survivor ids; one launch per order >= 2)" if binned else
+            "kernel": ("colibri::bi2_count_kernel (order 2: one wave per final bin — LDS table build, threshold, survivors, positions; one launch per step)" if second else
+                       "colibri::bin_count_kernel (per-bin LDS hash build + threshold + survivor ids; one launch per order >= 2)" if binned else
                        "colibri::count_kernel (scan + SpookyHash + global hash-table build; one launch per order)"),
             "bound": "hbm",
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": measured_traffic(args.tokens, "bin_count_kernel" if binned else "count_kernel") if args.gpus == 1 else None,
+            "traffic": measured_traffic(args.tokens, "bi2_count_kernel" if second else "bin_count_kernel" if binned else "count_kernel") if args.gpus == 1 else None,
             "algorithmic_bytes_per_launch": round(dom_bytes / max(1.0, launches_per_step)),
             "avg_launch_ms": round(avg_launch_ms, 4),
             "launches_per_step": launches_per_step,
@@ -264,12 +319,17 @@ def main():
                     f"kernel_ms_per_step: {EXTRA} extra untimed steps with every kernel class bracketed",
         },
     }
+    if dist is None and not args.no_other_configs:
+        out["other_configs"] = other_configs(ctx, capi, payload.size, args.tokens)
     if args.gpus == 1 and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.vocab)
     print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    if check_ok is False:
+        sys.stderr.write("bench.py: the timed run did not produce the known model of this corpus: %r / %d patterns\n" % (kept, npatterns))
+        sys.exit(3)
 
 
 if __name__ == "__main__":

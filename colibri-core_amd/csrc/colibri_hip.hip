@@ -73,7 +73,10 @@ struct colibri_ctx {
     std::vector<DevBuf<uint32_t>> ids;  // plain mode: 2 ping-pong buffers; skipgram / indexed modes: one per order
     DevBuf<uint32_t>  scratch[2];       // per-position slot arrays of the skipgram passes
     DevBuf<uint32_t>  nsrc;             // per-slot distinct-source counter (indexed skipgrams)
-    DevBuf<uint32_t>  pair_id[2], pair_pos[2];  // forward index: (result id, position) pairs, ping-pong for the radix sort
+    DevBuf<uint32_t>  pair_id[2], pair_pos[2];  // forward index: (result id, position) pairs, ping-pong for the radix sort (kept between runs: a release and a
+                                                // new reservation of these GB-sized buffers per train() cost more than the kernels)
+    DevBuf<uint32_t>  idx_cnt, sort_hist;       // ... per-block pair counts of a pass; per-block digit histograms of a sort pass
+    DevBuf<unsigned long long> sort_off, sort_bsum;
     uint64_t          npairs = 0;
     DevBuf<uint32_t>  ref_sentence;
     DevBuf<uint16_t>  ref_token;
@@ -130,6 +133,8 @@ struct colibri_ctx {
     };
     std::vector<Segment> segments;      // result ranges: one per order (n-grams) and one per (order, gap mask) pass
     DevBuf<uint32_t>  res_rep, res_cnt;
+    uint64_t          res_cap_used = 0;  // result capacity of the last run
+    uint32_t          res_scale = 1;  // multiplier of the result capacity: raised (and the run repeated) when a corpus keeps more patterns per position than the usual bound
     DevBuf<DevState>  state;
     DevState          hstate{};
     colibri_stats     stats{};
@@ -225,7 +230,7 @@ struct Prof {
     size_t       idx = (size_t)-1;
     Prof(colibri_ctx* c_, int cls_) : c(c_), cls(cls_) {
         if (!c->profile) return;
-        if (c->profile == 2 && cls != COLIBRI_K_BINCOUNT && cls != COLIBRI_K_COUNT) return;  // only the classes that can hold the dominant kernel
+        if (c->profile == 2 && cls != COLIBRI_K_BINCOUNT && cls != COLIBRI_K_COUNT && cls != COLIBRI_K_COUNT2) return;  // only the classes that can hold the dominant kernel
         EventPair ev{};
         ev.cls = cls;
         auto take = [&](hipEvent_t& e) {
@@ -478,6 +483,7 @@ void colibri_destroy(colibri_ctx* c) {
         dev_free(c->pair_id[k]);
         dev_free(c->pair_pos[k]);
     }
+    dev_free(c->idx_cnt); dev_free(c->sort_hist); dev_free(c->sort_off); dev_free(c->sort_bsum);
     dev_free(c->ref_sentence);
     dev_free(c->ref_token);
     dev_free(c->sh.tkeys);
@@ -760,20 +766,20 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list) {
     HIP_TRY(c, hipMemsetAsync(nlist, 0, sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->b2.wcnt.p, 0, sizeof(uint32_t) * kBi2Waves, c->stream));
     {
-        Prof p(c, COLIBRI_K_EMIT);
+        Prof p(c, COLIBRI_K_EMIT2);
         hipLaunchKernelGGL(bi2_emit_kernel, dim3(kBi2EmitGrid), dim3(kBi2Threads), 0, c->stream, c->cls.p, c->uni_surv.p, nsurv, npos, recsA, b.region, kBi2Sub, bs, c->state.p,
                            c->b2.head_rows.p);
         hipLaunchKernelGGL(bi2_head_reduce_kernel, dim3(kBi2HeadN / kBlock, kBi2HeadSplit), dim3(kBlock), 0, c->stream, c->b2.head_rows.p, kBi2EmitGrid, bs, c->state.p);
         hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, b.region, kBi2Sub, c->state.p);
     }
     {
-        Prof p(c, COLIBRI_K_SCATTER);
+        Prof p(c, COLIBRI_K_LEVELB2);
         hipLaunchKernelGGL(bi2_levelB_kernel, dim3(b.nslots), dim3(kBi2Threads), 0, c->stream, recsA, recsB, b.region, bs, c->b2.boff.p, c->state.p);
         hipLaunchKernelGGL(bi2_binoff_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->b2.boff.p, kBi2Sub, c->state.p);
     }
     const BinnedIO io = binned_planes(c, pl, false);  // the sparse survivor arrays live in recs[0], free again after level B
     {
-        Prof p(c, COLIBRI_K_BINCOUNT);
+        Prof p(c, COLIBRI_K_COUNT2);
         hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr, io.sp_rep, io.sp_cnt,
                            c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list);
     }
@@ -786,7 +792,7 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list) {
     if (!want_list) return COLIBRI_OK;
     HIP_TRY(c, hipMemsetAsync(c->b2.bitmap.p + npos / 32, 0, sizeof(uint32_t) * 16, c->stream));  // words beyond the corpus read as zero
     {
-        Prof p(c, COLIBRI_K_RESOLVE);
+        Prof p(c, COLIBRI_K_LISTS2);
         hipLaunchKernelGGL(bi2_pospart_kernel, dim3(512), dim3(kBi2Threads), 0, c->stream, c->b2.wlist.p, c->b2.wcnt.p, kBi2Waves, b.wcap, bs, c->state.p, c->b2.plist.p, b.pl);
         hipLaunchKernelGGL(bi2_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, bs, c->b2.plist.p, b.pl, c->state.p, c->b2.bitmap.p);
         hipLaunchKernelGGL(bi2_list3_kernel, dim3(2048), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_surv.p, npos, bs, c->b2.bitmap.p, c->state.p, c->alist[1].p, nlist);
@@ -911,32 +917,36 @@ int grow_keep(colibri_ctx* c, DevBuf<uint32_t>& b, uint64_t need, uint64_t keep)
     return COLIBRI_OK;
 }
 
-// append (result id, position) for every position of `ids` that carries a result id, in position order
-int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids) {
-    const uint32_t   nblk = std::max<uint32_t>(1, blocks_for(pl.npos, kEmitTile));
-    DevBuf<uint32_t> cnt;
-    int              rc;
-    if ((rc = dev_alloc(c, cnt, (size_t)nblk + 2))) return rc;
-    uint32_t total = 0;
+// append (result id, position) for every position of `ids` that carries a result id, in position order. known_total: how many there are, when the
+// caller already has that number from the device (the n-gram passes do: it is the order's `valid` count) — no read-back, no synchronisation then
+int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, uint64_t known_total = ~0ull) {
+    const uint32_t nblk = std::max<uint32_t>(1, blocks_for(pl.npos, kEmitTile));
+    int            rc;
+    if ((rc = dev_alloc(c, c->idx_cnt, (size_t)nblk + 2))) return rc;
+    uint32_t* const cnt = c->idx_cnt.p;
     {
         Prof p(c, COLIBRI_K_INDEX);
-        hipLaunchKernelGGL(emit_count_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, ids, pl.npos, cnt.p);
-        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, cnt.p, nblk, cnt.p + nblk);
+        hipLaunchKernelGGL(emit_count_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, ids, pl.npos, cnt);
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, cnt, nblk, cnt + nblk);
     }
-    HIP_TRY(c, hipMemcpyAsync(&total, cnt.p + nblk, sizeof total, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint64_t total = known_total;
+    if (known_total == ~0ull) {
+        uint32_t t32 = 0;
+        HIP_TRY(c, hipMemcpyAsync(&t32, cnt + nblk, sizeof t32, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        total = t32;
+    }
     if (total) {
-        if ((rc = grow_keep(c, c->pair_id[0], c->npairs + total, c->npairs)) || (rc = grow_keep(c, c->pair_pos[0], c->npairs + total, c->npairs))) {
-            dev_free(cnt);
-            return rc;
-        }
+        const uint64_t want = std::max<uint64_t>(c->npairs + total, 2ull * pl.npos);  // room for the usual model right away (n <= 5: ~1.6 pairs per position)
+        if ((rc = grow_keep(c, c->pair_id[0], want, c->npairs)) || (rc = grow_keep(c, c->pair_pos[0], want, c->npairs))) return rc;
         Prof p(c, COLIBRI_K_INDEX);
-        hipLaunchKernelGGL(emit_write_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, ids, pl.npos, cnt.p, c->npairs, c->pair_id[0].p, c->pair_pos[0].p);
+        hipLaunchKernelGGL(emit_write_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, ids, pl.npos, cnt, c->npairs, c->pair_id[0].p, c->pair_pos[0].p);
         c->npairs += total;
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipGetLastError());
-    dev_free(cnt);
+    if (known_total == ~0ull) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+    }
     return COLIBRI_OK;
 }
 
@@ -963,10 +973,10 @@ int radix_sort_pairs(colibri_ctx* c, uint32_t* const key[2], uint32_t* const val
     const uint32_t             nblocks = (uint32_t)((n + kSortTile - 1) / kSortTile);
     const uint32_t             nh      = 256u * nblocks;
     const uint32_t             nb      = blocks_for(nh, kBlock * 4);
-    DevBuf<uint32_t>           ghist;
-    DevBuf<unsigned long long> goff, bsum;
     int                        rc;
-    if ((rc = dev_alloc(c, ghist, nh)) || (rc = dev_alloc(c, goff, nh)) || (rc = dev_alloc(c, bsum, (size_t)nb + 1))) return rc;
+    if ((rc = dev_alloc(c, c->sort_hist, nh)) || (rc = dev_alloc(c, c->sort_off, nh)) || (rc = dev_alloc(c, c->sort_bsum, (size_t)nb + 1))) return rc;
+    DevBuf<uint32_t>&           ghist = c->sort_hist;
+    DevBuf<unsigned long long>& goff = c->sort_off, &bsum = c->sort_bsum;
     for (int shift = 0; shift < bits; shift += 8) {
         hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(kBlock), 0, c->stream, key[cur], n, shift, nblocks, ghist.p);
         hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, ghist.p, nh, bsum.p);
@@ -975,12 +985,7 @@ int radix_sort_pairs(colibri_ctx* c, uint32_t* const key[2], uint32_t* const val
         hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(kBlock), 0, c->stream, key[cur], val[cur], n, shift, nblocks, goff.p, key[cur ^ 1], val[cur ^ 1]);
         cur ^= 1;
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the scratch below must outlive the passes
-    HIP_TRY(c, hipGetLastError());
-    dev_free(ghist);
-    dev_free(goff);
-    dev_free(bsum);
-    return COLIBRI_OK;
+    return COLIBRI_OK;  // (the scratch belongs to the context: nothing to wait for)
 }
 inline int bits_for(uint64_t nvalues) {
     int bits = 1;
@@ -1016,10 +1021,6 @@ int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = fal
         c->sh.sorted_gid = c->pair_id[cur];
         c->pair_id[cur]  = DevBuf<uint32_t>{};
     }
-    dev_free(c->pair_id[1]);  // the pair buffers are only needed until the references exist
-    dev_free(c->pair_pos[1]);
-    dev_free(c->pair_id[0]);
-    dev_free(c->pair_pos[0]);
     return COLIBRI_OK;
 }
 
@@ -1124,7 +1125,21 @@ int train_pattern_list(colibri_ctx* c, const colibri_options& o, colibri_stats* 
 
 }  // namespace
 
+static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, colibri_stats* stats_out);
 extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, colibri_stats* stats_out) {
+    if (!c || !opt_in) return COLIBRI_ERR_ARG;
+    for (;;) {
+        const int rc = colibri_train_once(c, opt_in, stats_out);
+        // a result buffer ran out (a corpus that keeps unusually many patterns per position: duplicated text): more room, again
+        const uint64_t bound = (uint64_t)std::max(1, std::min<int>(opt_in->maxlength, COLIBRI_MAX_ORDER - 1)) * ((uint64_t)c->npos + 1);
+        if (rc != COLIBRI_ERR_OVERFLOW || !c->hstate.overflow || c->res_cap_used >= std::min<uint64_t>(0x7FFFFFF0ull, bound)) {
+            c->res_scale = 1;
+            return rc;
+        }
+        c->res_scale *= 4;
+    }
+}
+static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, colibri_stats* stats_out) {
     if (!c || !opt_in) return COLIBRI_ERR_ARG;
     if (!c->have_corpus) return fail(c, COLIBRI_ERR_STATE, "no corpus uploaded");
     colibri_options o = *opt_in;
@@ -1172,8 +1187,12 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     uint64_t per_pos = o.mintokens < 2 ? (uint64_t)std::min(o.maxlength, 8) : (synced ? 4u : 2u);  // results per corpus position the run can produce
     if (o.mintokens < 2 && (o.doskipgrams || o.doskipgrams_exhaustive))  // threshold 1 keeps every masked form of every window as well
         for (int n = 3; n <= std::min(o.maxlength, 13); ++n) per_pos += gap_masks(n, o.maxskips).size();
-    pl.res_cap     = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)npos * per_pos + 1024);
+    // the usual bound (a survivor has >= MINTOKENS occurrences, and few orders keep many) is not a bound for repetitive corpora — every distinct sentence
+    // of L tokens occurring twice keeps L (L + 1) / 2 patterns per pair —: exhaustion is reported by the kernels and colibri_train repeats the run with
+    // res_scale x 4 (up to one result per position and order)
+    pl.res_cap     = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, (uint64_t)npos * per_pos * c->res_scale + 1024);
     pl.thr         = (uint32_t)o.mintokens;
+    c->res_cap_used = pl.res_cap;
     const uint32_t wthr = o.mintokens_unigrams > o.mintokens ? (uint32_t)o.mintokens_unigrams : 0u;  // secondary word threshold (-W), 0 = none
     constexpr uint32_t kCountLdsBytes    = kCountTile * 16u + kCountLSlot * 4u + 64u;  // keyL + cntL + slotL + winL
     constexpr uint32_t kCountBlocksPerCU = (160u * 1024u / kCountLdsBytes) < 8u ? (160u * 1024u / kCountLdsBytes) : 8u;
@@ -1291,7 +1310,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
         if ((rc = read_state(c))) return rc;
         if (binned && c->hstate.radix_overflow == 4) {  // the second-generation order 2 could not hold this corpus (a hot bigram outside the dense head): first-generation kernels
             c->b2.disabled = true;
-            const int rc2  = colibri_train(c, &o, stats_out);
+            const int rc2  = colibri_train_once(c, &o, stats_out);
             c->b2.disabled = false;
             return rc2;
         }
@@ -1302,7 +1321,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                             (unsigned long long)(c->recs[0].n / kASlots), npos);
             colibri_options again = o;
             again.table_mode      = 1;
-            return colibri_train(c, &again, stats_out);
+            return colibri_train_once(c, &again, stats_out);
         }
         c->last_mode = binned ? 2 : 1;
         s.maxn = (int32_t)c->hstate.maxn;
@@ -1483,7 +1502,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             if ((radix_synced || radix_constrained) && c->hstate.radix_overflow) {  // a bin outgrew its LDS table: the whole run again on the table path (loud, exact, rare)
                 colibri_options again = o;
                 again.table_mode      = 1;
-                return colibri_train(c, &again, stats_out);
+                return colibri_train_once(c, &again, stats_out);
             }
             const uint32_t found = c->hstate.found, kept = c->hstate.kept;
             adm_n[n]   = c->hstate.admitted;
@@ -1496,7 +1515,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
             if (kept) c->segments.push_back({res_total, kept, n, (n == 1 && uni_synced) ? kMaskFromClass : 0u});
             res_total += kept;
             c->hstate.res_total = res_total;
-            if (o.indexed && kept && (rc = emit_pairs(c, pl, c->ids[n].p))) return rc;  // occurrences of the surviving n-grams
+            if (o.indexed && kept && (rc = emit_pairs(c, pl, c->ids[n].p, valid_n[n]))) return rc;  // occurrences of the surviving n-grams (as many as positions with an id)
             // secondary word threshold: the unigrams below it keep their place (and references) in the model, but take no part in longer patterns
             if (n == 1 && wthr > pl.thr) hipLaunchKernelGGL(ids_min_count_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->ids[n].p, c->res_cnt.p, wthr, npos);
             if (o.doskipgrams_exhaustive && n >= 3) {  // patternmodel.h:1163-1171 -> computeskipgrams :1370-1527, for every admissible window

@@ -13,8 +13,8 @@ PKG_ROOT = os.path.dirname(os.path.dirname(HERE))  # colibri-core_amd/
 LIB_PATH = os.environ.get("COLIBRI_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libcolibri_hip.so")  # env override: kernel experiments only
 
 MAX_ORDER = 128
-K_TOKENISE, K_CLEAR, K_COUNT, K_PRUNE, K_RESOLVE, K_SKIPGRAM, K_INDEX, K_EXPORT, K_EMIT, K_SCATTER, K_BINCOUNT = range(11)
-KERNEL_CLASSES = ["tokenise", "clear", "count", "prune", "resolve", "skipgram", "index", "export", "emit", "scatter", "bincount"]
+K_TOKENISE, K_CLEAR, K_COUNT, K_PRUNE, K_RESOLVE, K_SKIPGRAM, K_INDEX, K_EXPORT, K_EMIT, K_SCATTER, K_BINCOUNT, K_EMIT2, K_LEVELB2, K_COUNT2, K_LISTS2 = range(15)
+KERNEL_CLASSES = ["tokenise", "clear", "count", "prune", "resolve", "skipgram", "index", "export", "emit", "scatter", "bincount", "emit2", "levelB2", "count2", "lists2"]
 
 EXPORTED = [
     "colibri_abi_version", "colibri_create", "colibri_destroy", "colibri_last_error", "colibri_upload_corpus",

@@ -90,7 +90,11 @@ enum {
     COLIBRI_K_EMIT     = 8,  /* binned path: scan + SpookyHash + block-local reduce -> (key, position, count) records */
     COLIBRI_K_SCATTER  = 9,  /* binned path: two-level radix partition of the records by hash bits            */
     COLIBRI_K_BINCOUNT = 10, /* binned path: per-bin LDS hash build + threshold + survivor ids                */
-    COLIBRI_K_NCLASSES = 11
+    COLIBRI_K_EMIT2    = 11, /* order 2, second generation: scan -> dense head histogram | 8-byte records by A bin */
+    COLIBRI_K_LEVELB2  = 12, /* ... one block partitions one (sub-region, A bin) slot by B bin                  */
+    COLIBRI_K_COUNT2   = 13, /* ... one wave per final bin: LDS table, threshold, survivors, positions          */
+    COLIBRI_K_LISTS2   = 14, /* ... survivor positions -> bucket lists -> bitmap -> active list of order 3      */
+    COLIBRI_K_NCLASSES = 15
 };
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */

@@ -301,3 +301,25 @@ def test_constrained_training_matches_the_restatement(ctx, seed):
     if indexed:
         assert gotrefs == want.refs
     assert st.totaltokens == want.tokens and st.npatterns == len(want)
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["auto", "table"])
+def test_duplicated_sentences_outgrow_the_usual_result_capacity(ctx, mode):
+    """A corpus in which every distinct sentence occurs twice keeps L (L + 1) / 2 patterns per pair of sentences: more than the two results per
+    position the result buffers start with. The reference builds that model (include/patternmodel.h:981-1270 has no such bound); here the run notices
+    the exhausted buffer and repeats with more room."""
+    import oracle
+    from colibri_amd import synth
+    L, nsent = 12, 1500
+    rng = np.random.default_rng(11)
+    sent = rng.permutation(np.arange(6, 6 + L * nsent, dtype=np.uint32)).reshape(nsent, L)  # all tokens distinct: nothing repeats across sentences
+    rows = np.concatenate([sent, sent], axis=0)
+    sym = np.concatenate([rows, np.zeros((2 * nsent, 1), dtype=np.uint32)], axis=1).reshape(-1)
+    payload = synth.encode_v2(sym).tobytes()
+    want = oracle.train(payload, 2, L)
+    assert len(want.counts) == nsent * L * (L + 1) // 2 > 2 * len(sym) + 1024
+    ctx.upload(payload)
+    st = ctx.train(mintokens=2, maxlength=L, table_mode=mode)
+    got, _ = ctx.export_dict()
+    assert got == want.counts
+    assert st.totaltokens == want.tokens and st.totaltypes == want.types

@@ -44,7 +44,8 @@ def launches(pattern):
 
 
 binned = any("bin_count_kernel" in k for k in agg)
-dom = "bin_count_kernel" if binned else "count_kernel"
+second = any("bi2_count_kernel" in k for k in agg)  # the second-generation order 2 (bigram2.hpp): its count kernel is the dominant one
+dom = "bi2_count_kernel" if second else "bin_count_kernel" if binned else "count_kernel"
 fetch, write, nl = tot(dom, "FETCH_SIZE"), tot(dom, "WRITE_SIZE"), launches(dom)
 # MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming read; other access
 # widths must be calibrated on a known byte count in the same run. Calibration kernels of this run:
@@ -53,7 +54,13 @@ cal = {}
 for name in ("bin_resolve_kernel", "resolve_kernel", "clear_table_kernel", "prune_kernel", "compact_results_kernel"):
     if any(name in k for k in agg):
         cal[name] = {"FETCH_SIZE_KiB_per_launch": round(tot(name, "FETCH_SIZE") / launches(name), 1), "WRITE_SIZE_KiB_per_launch": round(tot(name, "WRITE_SIZE") / launches(name), 1)}
-if binned:
+if second:
+    # bi2_count reads its 8-byte records with coalesced 8 B/lane loads (once) and writes 4-byte positions coalesced: the documented gfx950 halving is
+    # for 16 B/lane reads; 8 B/lane is uncalibrated, so both readings are kept and the larger one is reported
+    corrected = (2 * fetch + write) * 1024 / nl
+    note = ("bi2_count_kernel reads coalesced 8 B/lane records; FETCH_SIZE is documented to report half the bytes of wide coalesced reads on gfx950 (16 B/lane; "
+            "8 B/lane uncalibrated): reported = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the raw sum is kept beside it")
+elif binned:
     # bin_count reads its records with coalesced 16 B/lane loads (twice: build sweep + id sweep, the second mostly from L2):
     # the streamed-read share is under-counted by 1/2 of ONE sweep = 8 B per record; records per launch ~ admitted windows
     streamed = None  # filled by the caller-provided record count if given

@@ -77,6 +77,18 @@ class Pattern {
     std::string tostring(const ClassDecoder& decoder) const;
     std::string tohex() const;
 
+    /** all windows of n tokens, left to right (skipgram windows included: a gap is a token); returns how many were added
+     *  (reference include/pattern.h:251-273, src/pattern.cpp:1216-1282). The pair forms carry the token offset of the window. */
+    int ngrams(std::vector<Pattern>& container, const int n) const;
+    int ngrams(std::vector<PatternPointer>& container, const int n) const;
+    int ngrams(std::vector<std::pair<Pattern, int>>& container, const int n) const;
+    int ngrams(std::vector<std::pair<PatternPointer, int>>& container, const int n) const;
+    /** the windows of every size minn..maxn (maxn clipped to the pattern's length), size by size (include/pattern.h:259-282, src/pattern.cpp:1298-1374) */
+    int subngrams(std::vector<Pattern>& container, int minn = 1, int maxn = 99) const;
+    int subngrams(std::vector<PatternPointer>& container, int minn = 1, int maxn = 99) const;
+    int subngrams(std::vector<std::pair<Pattern, int>>& container, int minn = 1, int maxn = 9) const;
+    int subngrams(std::vector<std::pair<PatternPointer, int>>& container, int minn = 1, int maxn = 9) const;
+
   private:
     void assign(const unsigned char* bytes, size_t size) {
         if (bytes == NULL || size == 0) {
@@ -111,6 +123,9 @@ class PatternPointer {
     /** all n-token windows with their token offset (reference src/pattern.cpp:1284-1296) */
     int ngrams(std::vector<std::pair<PatternPointer, int>>& container, const int n) const;
     int ngrams(std::vector<PatternPointer>& container, const int n) const;
+    /** the windows of every size minn..maxn, size by size (reference include/pattern.h:503-506, src/pattern.cpp:1324-1374) */
+    int subngrams(std::vector<PatternPointer>& container, int minn = 1, int maxn = 9) const;
+    int subngrams(std::vector<std::pair<PatternPointer, int>>& container, int minn = 1, int maxn = 9) const;
     bool operator==(const PatternPointer& o) const { return Pattern(*this) == Pattern(o); }
     std::string tostring(const ClassDecoder& decoder) const { return Pattern(*this).tostring(decoder); }
 };

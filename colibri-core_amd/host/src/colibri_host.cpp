@@ -9,6 +9,7 @@
 #include <map>
 #include <sstream>
 
+#include "algorithms.h"
 #include "patternmodel.h"
 #include "spooky_device.hpp"  // the same SpookyHash routine the kernels use, compiled for the host
 
@@ -185,6 +186,100 @@ int PatternPointer::ngrams(std::vector<PatternPointer>& container, const int n) 
     const int                                   r = ngrams(tmp, n);
     for (const auto& p : tmp) container.push_back(p.first);
     return r;
+}
+namespace {
+// the sizes minn..maxn one after the other, each through the container's own ngrams()
+template <class Source, class Container>
+int sub_windows(const Source& src, Container& container, int minn, int maxn) {
+    const int ntok = (int)src.n();
+    if (maxn > ntok) maxn = ntok;
+    if (minn > ntok) return 0;
+    int found = 0;
+    for (int k = minn; k <= maxn; ++k) found += src.ngrams(container, k);
+    return found;
+}
+}  // namespace
+int PatternPointer::subngrams(std::vector<PatternPointer>& container, int minn, int maxn) const { return sub_windows(*this, container, minn, maxn); }
+int PatternPointer::subngrams(std::vector<std::pair<PatternPointer, int>>& container, int minn, int maxn) const { return sub_windows(*this, container, minn, maxn); }
+
+// Pattern: the windows are views into (or copies of) this pattern's own bytes; a gap token (the byte 03) stays what it is
+int Pattern::ngrams(std::vector<std::pair<PatternPointer, int>>& container, const int n) const {
+    if (data == NULL) return 0;
+    return PatternPointer(data, bytesize()).ngrams(container, n);
+}
+int Pattern::ngrams(std::vector<PatternPointer>& container, const int n) const {
+    if (data == NULL) return 0;
+    return PatternPointer(data, bytesize()).ngrams(container, n);
+}
+int Pattern::ngrams(std::vector<std::pair<Pattern, int>>& container, const int n) const {
+    std::vector<std::pair<PatternPointer, int>> tmp;
+    const int                                   r = ngrams(tmp, n);
+    for (const auto& p : tmp) container.push_back(std::make_pair(Pattern(p.first.data, p.first.bytes), p.second));
+    return r;
+}
+int Pattern::ngrams(std::vector<Pattern>& container, const int n) const {
+    std::vector<std::pair<PatternPointer, int>> tmp;
+    const int                                   r = ngrams(tmp, n);
+    for (const auto& p : tmp) container.push_back(Pattern(p.first.data, p.first.bytes));
+    return r;
+}
+int Pattern::subngrams(std::vector<Pattern>& container, int minn, int maxn) const { return sub_windows(*this, container, minn, maxn); }
+int Pattern::subngrams(std::vector<PatternPointer>& container, int minn, int maxn) const { return sub_windows(*this, container, minn, maxn); }
+int Pattern::subngrams(std::vector<std::pair<Pattern, int>>& container, int minn, int maxn) const { return sub_windows(*this, container, minn, maxn); }
+int Pattern::subngrams(std::vector<std::pair<PatternPointer, int>>& container, int minn, int maxn) const { return sub_windows(*this, container, minn, maxn); }
+
+// ---------------------------------------------------------------------------------------------------
+// gap masks (algorithms.h)
+// ---------------------------------------------------------------------------------------------------
+uint32_t vector2mask(const std::vector<std::pair<int, int>>& skips) {
+    uint32_t mask = 0;
+    for (const auto& gap : skips)
+        for (int i = gap.first; i < gap.first + gap.second && i < 31; ++i) mask |= bitmask_of(i);
+    return mask;
+}
+std::vector<std::pair<int, int>> mask2vector(const uint32_t mask, const int n) {
+    std::vector<std::pair<int, int>> gaps;
+    int                              k = 0;
+    while (k < n) {
+        if (!(mask & bitmask_of(k))) {
+            ++k;
+            continue;
+        }
+        const int begin = k;
+        while (k < n && (mask & bitmask_of(k))) ++k;
+        gaps.push_back(std::make_pair(begin, k - begin));
+    }
+    return gaps;
+}
+std::vector<std::pair<int, int>> get_consecutive_gaps(const int n, const int leftmargin, const int rightmargin) {
+    std::vector<std::pair<int, int>> gaps;
+    for (int begin = leftmargin; begin < n; ++begin)
+        for (int length = (n - rightmargin) - begin; length > 0; --length) gaps.push_back(std::make_pair(begin, length));
+    return gaps;
+}
+uint32_t reversemask(uint32_t mask, const unsigned int n) {
+    const uint32_t inverted = ~mask;
+    return n >= 32 ? 0u : (uint32_t)(inverted << n) >> n;  // the reference's arithmetic: n bits up, n bits down, in 32 bits
+}
+int maskheadskip(uint32_t mask, const unsigned int) {
+    unsigned int i = 0;
+    while (i < 31 && (mask & bitmask_of((int)i))) ++i;
+    return (int)i;
+}
+int masktailskip(uint32_t mask, const unsigned int n) {
+    unsigned int i = 0;
+    while (i < n && (mask & bitmask_of((int)(n - i - 1)))) ++i;
+    return (int)i;
+}
+std::vector<uint32_t> compute_skip_configurations(const int n, const int maxskips) {
+    std::vector<uint32_t> masks;
+    if (n < 3) return masks;
+    for (uint32_t inner = 1; inner < (uint32_t(1) << (n - 2)); ++inner) {
+        const uint32_t mask = inner << 1;  // never the first or the last token
+        if (n - 2 >= maxskips && mask2vector(mask, n).size() > (size_t)maxskips) continue;
+        masks.push_back(mask);
+    }
+    return masks;
 }
 
 // ---------------------------------------------------------------------------------------------------

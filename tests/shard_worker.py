@@ -133,7 +133,13 @@ MODES = {"u": {}, "ug": dict(table_mode=1), "us": dict(doskipgrams_exhaustive=1)
 def main():
     engine_kind, corpus_kind, maxlength, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     mode = sys.argv[5] if len(sys.argv) > 5 else "u"
-    dist.init_process_group("gloo")
+    backend = os.environ.get("COLIBRI_TEST_BACKEND", "gloo")
+    if backend == "nccl":  # RCCL: device tensors in every collective (one rank per GPU; the GPU box has one)
+        os.environ.setdefault("NCCL_DEBUG", "NONE")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     if corpus_kind == "zipf":
         payload = synth.zipf_corpus(60000, 2000, 3, phrases=True, header=False)
@@ -153,7 +159,7 @@ def main():
         ctx = capi.Context(0)
         ctx.upload(shard, first_sentence=first)
         eng = capi.HipShardEngine(ctx, torch, torch.device("cuda", 0))
-        trainer = ShardedTrainer(eng, dist, torch)
+        trainer = ShardedTrainer(eng, dist, torch, torch.device("cuda", 0) if backend == "nccl" else None)
         st = trainer.train(opt)
         mine = eng.export_local()
     gathered = [None] * world

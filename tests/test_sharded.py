@@ -19,11 +19,11 @@ ORACLE_MODES = {"u": {}, "ug": {}, "us": dict(doskipgrams_exhaustive=True), "i":
                 "isT1": dict(indexed=True, doskipgrams=True, minskiptypes=1), "usy3": dict(doskipgrams_exhaustive=True, mintokens_skipgrams=3)}
 
 
-def run_workers(tmp_path, world, engine, corpus, maxlength, mode="u"):
+def run_workers(tmp_path, world, engine, corpus, maxlength, mode="u", backend="gloo"):
     import oracle
-    out = str(tmp_path / f"res_{engine}_{corpus}_{world}_{mode}.pkl")
+    out = str(tmp_path / f"res_{engine}_{corpus}_{world}_{mode}_{backend}.pkl")
     _port[0] += 1
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", COLIBRI_TEST_BACKEND=backend)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(_port[0]),
            WORKER, engine, corpus, str(maxlength), out, mode]
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
@@ -114,3 +114,29 @@ def test_hip_shard_engine_ranks_as_threads(world):
         if case >= 8:  # threshold 1 (everything survives on every rank) and the secondary word threshold, in every kind of model
             o.update(dict(mintokens=1, maxlength=4) if case % 2 else dict(mintokens_unigrams=o["mintokens"] + 2))
         assert run_case(case, world, payload, o, capi, oracle, torch, cdist) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["u", "ug", "us", "i", "is"])
+def test_hip_shard_engine_over_rccl(tmp_path, mode):
+    """The exchange with torch.distributed's "nccl" backend (= RCCL): device tensors in all_to_all_single / all_reduce / all_gather, the hand-over
+    between torch's stream and the library's. One rank (the GPU box has one device): every collective still runs through RCCL."""
+    run_workers(tmp_path, 1, "hip", "zipf", 5, mode, backend="nccl")
+
+
+@pytest.mark.gpu
+def test_bench_sharded_path_over_rccl_matches_oracle(tmp_path):
+    """bench.py --force-shard --backend nccl: the sharded trainer exactly as the driver's multi-GPU run uses it, one rank; its model against the oracle."""
+    import json
+    import oracle
+    from colibri_amd import synth
+    tokens, vocab = 2_000_000, 1_000_000
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port[0] + 500))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-shard", "--backend", "nccl", "--tokens", str(tokens), "--vocab", str(vocab), "--steps", "2", "--warmup", "1",
+                        "--cpu-sample", "0"], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    got = json.loads(line)
+    want = oracle.train(synth.zipf_corpus(tokens, vocab, 44, header=False), 2, 5)
+    assert got["config"]["kept_per_order"] == [want.stats[n][2] for n in range(1, 6)]
+    assert got["config"]["patterns_in_model"] == len(want.counts)

@@ -23,16 +23,21 @@
 
 namespace colibri {
 
-// ---- the bijective 42-bit mix ---------------------------------------------------------------------------------------------------
-constexpr uint64_t kMix42Mask = (1ull << 42) - 1;
-constexpr uint64_t kMix42C1   = 0xff51afd7ed558ccdULL & kMix42Mask;  // odd
-constexpr uint64_t kMix42C2   = 0xc4ceb9fe1a85ec53ULL & kMix42Mask;  // odd
-__host__ __device__ __forceinline__ uint64_t mix42(uint64_t x) {  // x < 2^42; xor-shifts and odd multiplications mod 2^42 are bijections
-    x ^= x >> 21;
-    x = (x * kMix42C1) & kMix42Mask;
-    x ^= x >> 20;
-    x = (x * kMix42C2) & kMix42Mask;
-    x ^= x >> 21;
+// ---- the bijective K-bit mix ----------------------------------------------------------------------------------------------------
+// x < 2^K, K >= 17: xor-shifts and odd multiplications mod 2^K are bijections of the K-bit integers.
+// Bits of the mix, from the top: [s slice bits][8 A-bin bits][9 B-bin bits][the rest]. A record keeps the bits below the A bin next to the corpus
+// position: (K - s - 8) + posbits <= 64. The slice bits exist for corpora beyond ~128 M tokens per device: the order is then counted in 2^s passes,
+// each over the keys of one slice (every pass scans the corpus and keeps its share of the windows), so that a final bin stays within one wave's LDS
+// table and a 30-bit position fits the record.
+constexpr uint64_t kBi2MixC1 = 0xff51afd7ed558ccdULL, kBi2MixC2 = 0xc4ceb9fe1a85ec53ULL;  // odd
+__host__ __device__ __forceinline__ uint64_t bi2_mix(uint64_t x, uint32_t K) {
+    const uint64_t M = (1ull << K) - 1;
+    const uint32_t h = K >> 1;
+    x ^= x >> h;
+    x = (x * kBi2MixC1) & M;
+    x ^= x >> (h - 1);
+    x = (x * kBi2MixC2) & M;
+    x ^= x >> h;
     return x;
 }
 
@@ -43,11 +48,10 @@ constexpr int      kBi2Head     = 64;                     // classes < 64 on bot
 constexpr int      kBi2HeadN    = kBi2Head * kBi2Head;
 constexpr int      kBi2MaxSub   = 32;                     // sub-regions per A bin (a multiple of 8: sub-region = block index mod nsub, XCD = block index mod 8)
 constexpr int      kBi2MaxSlots = kBins * kBi2MaxSub;
-constexpr uint32_t kBi2PosBits  = 27;                     // corpus positions per device on this path: < 2^27
-constexpr uint64_t kBi2PosMask  = (1ull << kBi2PosBits) - 1;
+constexpr uint32_t kBi2MaxPosBits = 30;                   // corpus positions per device on this path: < 2^30
 constexpr int      kBi2BBins    = 512;                    // level-B bins per A bin: ~660 records per final bin at 100 M tokens (one wave counts a bin)
 constexpr int      kBi2Final    = kBins * kBi2BBins;      // 131 072 final bins
-constexpr int      kBi2Buckets  = 256;                    // position buckets (one LDS bitmap each in bi2_bitmap_kernel)
+constexpr int      kBi2Buckets  = 1024;                   // position buckets at most (one LDS bitmap each in bi2_bitmap_kernel)
 constexpr int      kBi2Shards   = 8;                      // cursor shards per bucket (a single cursor would serialise ~12 ns per reservation)
 constexpr int      kBi2Slots    = 1024;                   // LDS table of one final bin: 256 buckets of 4 slots
 constexpr uint32_t kBi2MaxLoad  = 900;
@@ -68,7 +72,10 @@ struct Bi2State {
     uint32_t headsurv[kBi2HeadN / 32];                   // bit k = head bigram k survived
     uint32_t headbase[kBlock];                           // first result rank of the head survivors of lane t (16 head keys per lane)
     uint32_t pcur[kBi2Shards * kBi2Buckets];             // position-list cursors
-    uint32_t nrec, bshift, overflow, kept_bins, kept_head, nbig, pad[2];
+    uint32_t nrec, bshift, overflow, kept_bins, kept_head, nbig;
+    uint32_t kbits;     // key bits below the slice bits (K - s): A bin = bits [kbits-1 : kbits-8], B bin = the nine below
+    uint32_t posbits;   // position bits of a record
+    uint32_t res_base;  // first result index of this pass's survivors (an order counted in slices appends pass after pass)
     uint32_t nextbin[kBi2Shards * 16];  // work queues of the count kernel (one per shard, 64 bytes apart): next group of bins to hand out
     uint32_t big[kBi2BigCap];           // final bins with more than kBi2BigBin records: counted first (one wave each), so that none of them starts late
 };
@@ -119,9 +126,16 @@ __device__ __forceinline__ uint32_t bi2_block_scan(uint32_t v, uint32_t* total, 
 // Wide blocks with few items per lane: every phase of a tile is a short chain of LDS operations, and 32 waves per CU hide each other's latencies.
 constexpr int kBi2SurvLds = 2048;  // words of the order-1 survivor bitmap kept in LDS: the first 65 536 classes (> 80 % of a Zipf corpus' tokens)
 __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kernel(const uint32_t* cls, const uint32_t* __restrict__ surv, uint32_t nsurvwords, uint32_t npos,
+                                                                                   uint32_t clsbits, uint32_t sbits, uint32_t slice, uint32_t pb,
                                                                                    unsigned long long* __restrict__ recsA, uint32_t region, uint32_t nsub, Bi2State* __restrict__ bs,
                                                                                    DevState* __restrict__ st, uint32_t* __restrict__ head_rows) {
     if (st->done) return;
+    const uint32_t K  = max(2u * clsbits, 17u + sbits);  // key = (class at i) << clsbits | class at i + 1
+    const uint32_t Kp = K - sbits;                      // ... of which the slice fixes the top sbits
+    if (threadIdx.x == 0) {
+        bs->kbits   = Kp;
+        bs->posbits = pb;
+    }
     __shared__ unsigned long long stgL[kBi2Tile];
     __shared__ uint8_t            binL[kBi2Tile];
     __shared__ uint32_t           histL[kBins], offL[kBins], gbaseL[kBins], wsumL[4];
@@ -178,16 +192,20 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kerne
             rank[k]          = kInvalid;
             rec[k]           = 0;
             if (ok[k]) {
-                ++nadm;
+                nadm += slice == 0;  // every pass sees every window: the first one counts them
                 if (d0[k] < (uint32_t)kBi2Head && d1[k] < (uint32_t)kBi2Head) {
-                    const uint32_t h = d0[k] * kBi2Head + d1[k];
-                    atomicAdd(&headL[h], 1u);
-                    atomicMin(&hposL[h], i);
+                    if (slice == 0) {  // the head is counted by the first pass only
+                        const uint32_t h = d0[k] * kBi2Head + d1[k];
+                        atomicAdd(&headL[h], 1u);
+                        atomicMin(&hposL[h], i);
+                    }
                 } else {
-                    const uint64_t m = mix42(((uint64_t)d0[k] << 21) | d1[k]);
-                    const uint32_t a = (uint32_t)(m >> 34);
-                    rec[k]           = ((m & ((1ull << 34) - 1)) << kBi2PosBits) | i;
-                    rank[k]          = atomicAdd(&histL[a], 1u) | (a << 16);
+                    const uint64_t m = bi2_mix(((uint64_t)d0[k] << clsbits) | d1[k], K);
+                    if ((uint32_t)(m >> Kp) == slice) {
+                        const uint32_t a = (uint32_t)(m >> (Kp - 8)) & 255u;
+                        rec[k]           = ((m & ((1ull << (Kp - 8)) - 1)) << pb) | i;
+                        rank[k]          = atomicAdd(&histL[a], 1u) | (a << 16);
+                    }
                 }
             }
         }
@@ -272,6 +290,9 @@ __global__ __launch_bounds__(kBlock) void bi2_offsets_kernel(Bi2State* __restric
         while (nb < (uint32_t)kBi2BBins && (uint64_t)nb * kBins * 700u < tot) nb <<= 1;
         uint32_t sh = 0;
         while ((uint32_t)kBi2BBins >> sh > nb) ++sh;
+        // the 31-bit in-bin key must hold every mix bit the bin does not fix: kbits - 17 + bshift <= 31
+        const uint32_t K = bs->kbits;
+        if (sh + K > 48u) sh = K >= 48u ? 0u : 48u - K;
         bs->bshift = sh;
     }
 }
@@ -304,7 +325,7 @@ __device__ __forceinline__ uint32_t bi2_scan512(const uint32_t* inL, uint32_t* o
 
 // ---- level B: one block partitions one slot by B bin ------------------------------------------------------------------------------
 // boff: [nslots][513] exclusive offsets of the slot's B bins inside the slot (same slot layout in recsB as in recsA).
-// B bin of a record: mix bits [33:25] = record bits [60:52], shifted down by bshift when an order has few records.
+// B bin of a record: the nine mix bits below the A bin, shifted down by bshift when an order has few records.
 __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_levelB_kernel(const unsigned long long* recsA, unsigned long long* __restrict__ recsB, uint32_t region,
                                                                                      const Bi2State* __restrict__ bs, uint32_t* __restrict__ boff, const DevState* __restrict__ st) {
     if (st->done) return;
@@ -314,6 +335,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_levelB_ker
     const uint32_t  slot = blockIdx.x;
     const uint32_t  n    = min(bs->curA[slot], region);
     const uint32_t  bsh  = bs->bshift;
+    const uint32_t  bbit = bs->posbits + bs->kbits - 17;  // the B bin = the nine mix bits below the A bin = record bits [bbit + 8 : bbit]
     const size_t    base = (size_t)slot * region;
     uint32_t* const bo   = boff + (size_t)slot * (kBi2BBins + 1);
     if (threadIdx.x < kBi2BBins) histL[threadIdx.x] = 0;
@@ -329,7 +351,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_levelB_ker
 #pragma unroll
         for (int k = 0; k < 2 * kBi2Per; ++k) {
             const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
-            if (j < n) atomicAdd(&histL[((uint32_t)(r[k] >> 52) & 511u) >> bsh], 1u);
+            if (j < n) atomicAdd(&histL[((uint32_t)(r[k] >> bbit) & 511u) >> bsh], 1u);
         }
     }
     __syncthreads();
@@ -362,7 +384,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_levelB_ker
             const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
             rank[k]          = kInvalid;
             if (j < n) {
-                const uint32_t b = ((uint32_t)(x[k] >> 52) & 511u) >> bsh;
+                const uint32_t b = ((uint32_t)(x[k] >> bbit) & 511u) >> bsh;
                 rank[k]          = atomicAdd(&histL[b], 1u) | (b << 16);
             }
         }
@@ -512,8 +534,10 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
     __shared__ uint32_t                              repS[kBi2WReps];
     const uint32_t bsh = bs->bshift, nB = (uint32_t)kBi2BBins >> bsh, nfinal = (uint32_t)kBins * nB;
     const uint32_t lane = threadIdx.x, wid = blockIdx.x, nwaves = gridDim.x;
+    const uint32_t pb = bs->posbits;
+    const unsigned long long pmask = (1ull << pb) - 1;
     uint32_t* const mylist = wlist + (size_t)wid * wcap;
-    uint32_t        cursor = 0;     // entries in this wave's position list (wave-uniform)
+    uint32_t        cursor = want_positions ? wcnt[wid] : 0u;  // entries in this wave's position list (wave-uniform); the passes of a sliced order append
     bool            lost   = false;  // the list ran out of room
 #ifdef BI2_PROF
     unsigned long long tacc[12] = {0}, tlast = wall_clock64();
@@ -579,7 +603,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
             sl[q] = sl[q + 1] = kInvalid;
             if ((uint32_t)(q * kWave) < total) {
                 const bool     actA = (uint32_t)(q * kWave) + lane < total, actB = (uint32_t)((q + 1) * kWave) + lane < total;
-                const uint32_t keyA = (uint32_t)(x[q] >> kBi2PosBits) & 0x7FFFFFFFu, keyB = (uint32_t)(x[q + 1] >> kBi2PosBits) & 0x7FFFFFFFu;
+                const uint32_t keyA = (uint32_t)(x[q] >> pb) & 0x7FFFFFFFu, keyB = (uint32_t)(x[q + 1] >> pb) & 0x7FFFFFFFu;
                 const uint32_t bkA = bi2_bucket_of(keyA, lgb, bmask), bkB = bi2_bucket_of(keyB, lgb, bmask);
                 const uint4    vA = *reinterpret_cast<const uint4*>(keyT + bkA * 4), vB = *reinterpret_cast<const uint4*>(keyT + bkB * 4);
                 bi2_insert2(keyT, bmask, actA, keyA, bkA, vA, sl[q], actB, keyB, bkB, vB, sl[q + 1]);
@@ -616,7 +640,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
 #pragma unroll
                 for (int k = 0; k < 4; k += 2) {
                     const bool     actA = z[k] != ~0ull, actB = z[k + 1] != ~0ull;
-                    const uint32_t keyA = (uint32_t)(z[k] >> kBi2PosBits) & 0x7FFFFFFFu, keyB = (uint32_t)(z[k + 1] >> kBi2PosBits) & 0x7FFFFFFFu;
+                    const uint32_t keyA = (uint32_t)(z[k] >> pb) & 0x7FFFFFFFu, keyB = (uint32_t)(z[k + 1] >> pb) & 0x7FFFFFFFu;
                     const uint32_t bkA = bi2_bucket_of(keyA, lgb, bmask), bkB = bi2_bucket_of(keyB, lgb, bmask);
                     uint32_t       tA, tB;
                     bi2_insert2(keyT, bmask, actA, keyA, bkA, *reinterpret_cast<const uint4*>(keyT + bkA * 4), tA, actB, keyB, bkB, *reinterpret_cast<const uint4*>(keyT + bkB * 4), tB);
@@ -713,7 +737,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
         };
 #pragma unroll
         for (int q = 0; q < kBi2WRows; ++q)
-            if ((uint32_t)(q * kWave) < total) settle(sl[q] != kInvalid, (uint32_t)(x[q] & kBi2PosMask), sl[q]);
+            if ((uint32_t)(q * kWave) < total) settle(sl[q] != kInvalid, (uint32_t)(x[q] & pmask), sl[q]);
         BI2_W(8);
         if (total > (uint32_t)(kBi2WRows * kWave)) {
             unsigned long long y[4];
@@ -734,8 +758,8 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
                 for (int k = 0; k < 4; ++k) {
                     if ((uint32_t)(j0 + k * kWave) < total) {
                         const bool     valid = z[k] != ~0ull;
-                        const uint32_t key   = (uint32_t)(z[k] >> kBi2PosBits) & 0x7FFFFFFFu;
-                        settle(valid, (uint32_t)(z[k] & kBi2PosMask), valid ? bi2_find(keyT, key, bi2_bucket_of(key, lgb, bmask), bmask) : 0u);
+                        const uint32_t key   = (uint32_t)(z[k] >> pb) & 0x7FFFFFFFu;
+                        settle(valid, (uint32_t)(z[k] & pmask), valid ? bi2_find(keyT, key, bi2_bucket_of(key, lgb, bmask), bmask) : 0u);
                     }
                 }
             }
@@ -792,7 +816,8 @@ __global__ __launch_bounds__(kBi2BBins) void bi2_kept_scan_kernel(Bi2State* __re
     if (a == kBins - 1 && threadIdx.x == 0) bs->kept_bins = beforeL + tot;
 }
 // head bigrams -> survivors; found / kept of the order
-__global__ __launch_bounds__(kBlock) void bi2_finish_kernel(DevState* __restrict__ st, Bi2State* __restrict__ bs, uint32_t threshold, uint32_t res_cap) {
+__global__ __launch_bounds__(kBlock) void bi2_finish_kernel(DevState* __restrict__ st, Bi2State* __restrict__ bs, uint32_t threshold, uint32_t res_cap,
+                                                             uint32_t* __restrict__ headsurv_keep /* first pass: the head survivor bits, kept for the list kernel; else NULL */) {
     if (st->done) return;
     uint32_t htot, ftot, hftot;
     block_exclusive_scan(bs->found_part[threadIdx.x], &ftot);
@@ -808,15 +833,17 @@ __global__ __launch_bounds__(kBlock) void bi2_finish_kernel(DevState* __restrict
         }
     }
     reinterpret_cast<uint16_t*>(bs->headsurv)[threadIdx.x] = (uint16_t)bits;
+    if (headsurv_keep != nullptr) reinterpret_cast<uint16_t*>(headsurv_keep)[threadIdx.x] = (uint16_t)bits;
     const uint32_t ho = block_exclusive_scan(hk, &htot);
     bs->headbase[threadIdx.x] = ho;
     block_exclusive_scan(hf, &hftot);
     if (threadIdx.x == 0) {
         const uint32_t tot = bs->kept_bins;
         bs->kept_head      = htot;
-        st->found          = ftot + hftot;
-        st->kept           = tot + htot;
-        if ((uint64_t)st->res_total + tot + htot > res_cap) st->overflow = 1;
+        bs->res_base       = st->res_total + st->kept;  // (st->found / st->kept are zero at the start of an order: the passes of a sliced order add up)
+        st->found += ftot + hftot;
+        st->kept += tot + htot;
+        if ((uint64_t)bs->res_base + tot + htot > res_cap) st->overflow = 1;
         if (bs->overflow) st->radix_overflow = 4;  // the host re-runs on the first-generation kernels
         const uint64_t next = (uint64_t)st->id_base + bs->nrec;  // keeps the id space of the later orders disjoint, as bin_advance_prepare_kernel does
         if (next >= 0xFFFFFFF0ull) st->radix_overflow = 3;
@@ -827,7 +854,7 @@ __global__ __launch_bounds__(kBlock) void bi2_finish_kernel(DevState* __restrict
 __global__ __launch_bounds__(kBlock) void bi2_compact_kernel(const uint32_t* __restrict__ sp_rep, const uint32_t* __restrict__ sp_cnt, const DevState* __restrict__ st,
                                                               const Bi2State* __restrict__ bs, uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap) {
     if (st->done) return;
-    const uint32_t res_base = st->res_total, lane = threadIdx.x & (kWave - 1);
+    const uint32_t res_base = bs->res_base, lane = threadIdx.x & (kWave - 1);
     if (blockIdx.x + 1 < gridDim.x) {
         const uint32_t nwaves = (gridDim.x - 1) * (kBlock / kWave);
         for (uint32_t g = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; g < (uint32_t)kBi2Final; g += nwaves) {
@@ -866,18 +893,19 @@ struct Bi2Lists {
 };
 // tile-local counting sort by bucket in LDS, one reserved run per (tile, bucket); block x takes the lists x, x + gridDim.x, ...
 __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_pospart_kernel(const uint32_t* __restrict__ wlist, const uint32_t* __restrict__ wcnt, uint32_t nlists, uint32_t wcap,
-                                                                                      Bi2State* __restrict__ bs, const DevState* __restrict__ st, uint32_t* __restrict__ plist, Bi2Lists pl) {
+                                                                                      Bi2State* __restrict__ bs, DevState* __restrict__ st, uint32_t* __restrict__ plist, Bi2Lists pl) {
     if (st->done) return;
+    static_assert(kBi2Buckets == kBi2Threads, "one lane per position bucket");
     __shared__ uint32_t stgL[kBi2Tile];
-    __shared__ uint8_t  binL[kBi2Tile];
-    __shared__ uint32_t histL[kBi2Buckets], offL[kBi2Buckets], gbaseL[kBi2Buckets], wsumL[4];
+    __shared__ uint16_t binL[kBi2Tile];
+    __shared__ uint32_t histL[kBi2Buckets], offL[kBi2Buckets], gbaseL[kBi2Buckets], wsumL[kBi2Threads / kWave];
     const uint32_t      shard = blockIdx.x & (uint32_t)(kBi2Shards - 1);
     for (uint32_t w = blockIdx.x; w < nlists; w += gridDim.x) {
         const uint32_t        n   = min(wcnt[w], wcap);
         const uint32_t* const src = wlist + (size_t)w * wcap;
         for (uint32_t j0 = 0; j0 < n; j0 += kBi2Tile) {
             uint32_t p[kBi2Per], rank[kBi2Per];
-            if (threadIdx.x < kBi2Buckets) histL[threadIdx.x] = 0;
+            histL[threadIdx.x] = 0;
 #pragma unroll
             for (int k = 0; k < kBi2Per; ++k) {
                 const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
@@ -893,14 +921,18 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_pospart_ke
                 }
             }
             __syncthreads();
-            bi2_scan256(histL, offL, wsumL);
-            if (threadIdx.x < kBi2Buckets) {
+            {
+                uint32_t tot;
+                offL[threadIdx.x] = bi2_block_scan<kBi2Threads>(histL[threadIdx.x], &tot, wsumL);
+            }
+            __syncthreads();  // every bucket's offset is written
+            {
                 const uint32_t h = histL[threadIdx.x];
                 uint32_t       g = 0;
                 if (h) {
                     const uint32_t l  = shard * kBi2Buckets + threadIdx.x;
                     const uint32_t at = atomicAdd(&bs->pcur[l], h);
-                    if (at + h > pl.pcap) bs->overflow = 3;
+                    if (at + h > pl.pcap) st->radix_overflow = 4;  // (the order's finish kernel has run: the flag goes straight to the run's state)
                     g = l * pl.pcap + min(at, pl.pcap - min(pl.pcap, h));  // (fits 32 bits: shards * buckets * pcap <= 8 * positions)
                 }
                 gbaseL[threadIdx.x] = g;
@@ -910,7 +942,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_pospart_ke
                 if (rank[k] != kInvalid) {
                     const uint32_t b = rank[k] >> 16, q = offL[b] + (rank[k] & 0xFFFFu);
                     stgL[q]          = p[k];
-                    binL[q]          = (uint8_t)b;
+                    binL[q]          = (uint16_t)b;
                 }
             }
             __syncthreads();
@@ -961,12 +993,12 @@ __global__ __launch_bounds__(kBi2BmThreads) void bi2_bitmap_kernel(uint32_t npos
 // entry i of the list: bigrams at i and at i + 1 both survived. st->valid += positions with a surviving bigram.
 // cls must be readable (zeros) up to index npos + 63 rounded up to a multiple of 32; bitmap up to word npos / 32 + 1 (zeros beyond the corpus).
 constexpr int kBi2L3Tile = kBlock * 32;  // one bitmap word per lane
-__global__ __launch_bounds__(kBlock) void bi2_list3_kernel(const uint32_t* __restrict__ cls, const uint32_t* __restrict__ surv, uint32_t npos, const Bi2State* __restrict__ bs,
+__global__ __launch_bounds__(kBlock) void bi2_list3_kernel(const uint32_t* __restrict__ cls, const uint32_t* __restrict__ surv, uint32_t npos, const uint32_t* __restrict__ headsurv,
                                                             const uint32_t* __restrict__ bitmap, DevState* __restrict__ st, uint32_t* __restrict__ list_out,
                                                             uint32_t* __restrict__ nlist_out) {
     if (st->done) return;
     __shared__ uint32_t hsL[kBi2HeadN / 32], stageL[kBi2L3Tile], baseL, redL[kBlock / kWave];
-    if (threadIdx.x < kBi2HeadN / 32) hsL[threadIdx.x] = bs->headsurv[threadIdx.x];
+    if (threadIdx.x < kBi2HeadN / 32) hsL[threadIdx.x] = headsurv[threadIdx.x];
     __syncthreads();
     const uint32_t sw0 = surv[0], sw1 = surv[1];
     const uint32_t ntiles = (npos + kBi2L3Tile - 1) / kBi2L3Tile;

@@ -55,6 +55,7 @@ struct BinState {
     uint32_t cur2[kFinalBins];   // level-B scatter cursors; afterwards bin_count leaves each bin's survivor count here, and the scan turns them into dense offsets
     uint32_t found_part[kBins];  // distinct keys, accumulated per A bin (a single counter would serialise 65 536 atomics)
     uint32_t kept_part[kBins];   // survivors, accumulated per A bin
+    uint32_t res_base;           // first result index of this pass's survivors (written by bin_kept_scan_kernel)
 };
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -73,9 +74,13 @@ struct BinState {
 template <class KeyFn, bool LIST>
 __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __restrict__ recs, uint32_t region, uint32_t* __restrict__ rep_of, DevState* __restrict__ st,
                                                            BinState* __restrict__ bs, uint32_t npos, const uint32_t* __restrict__ list, const uint32_t* __restrict__ nlist,
-                                                           uint32_t* __restrict__ ids_at, uint8_t* __restrict__ flags_at = nullptr) {
+                                                           uint32_t* __restrict__ ids_at, uint8_t* __restrict__ flags_at = nullptr, uint32_t sbits = 0, uint32_t slice = 0) {
+    // sbits / slice: an order of a corpus beyond ~128 M tokens is counted in 2^sbits passes, each over the windows whose hash bits [47:40] (the ones
+    // below the bin bits) select `slice`: a final bin then stays within its LDS table. Every pass walks all items; rep_of is written where the window
+    // belongs to the pass (and, by the first pass, where it is not admissible at all).
     if (st->done) return;
     const uint32_t nitems = LIST ? *nlist : npos;
+    const uint32_t smask  = (1u << sbits) - 1u;
     // phase E (election): keyL u64[2048] | winL u32[4096]   -- 32 KB, later reused as recL Rec[2048]
     __shared__ __attribute__((aligned(16))) unsigned char rawL[kCountTile * sizeof(Rec)];
     static_assert(kCountTile * sizeof(Rec) >= kCountTile * sizeof(uint64_t) + kCountLSlot * sizeof(uint32_t), "staging buffer must cover the election arrays");
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
         const uint32_t base = tile * kCountTile;
         uint64_t       key[kCountPer], hash[kCountPer];
         uint32_t       posn[kCountPer];
-        bool           adm[kCountPer];
+        bool           adm[kCountPer], other[kCountPer];  // other: admissible, but a window of another pass
         histL[threadIdx.x] = 0;
         // three separate sweeps — list entries, then the key functor's loads, then the LDS writes — so that every global load of
         // the tile is in flight before the first LDS access (the compiler does not move a load across an LDS operation)
@@ -106,6 +111,9 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
             key[k]           = 0;
             hash[k]          = 0;
             adm[k]           = (j < nitems) && keyfn(posn[k], npos, key[k], hash[k]);
+            other[k]         = adm[k] && ((uint32_t)(hash[k] >> 40) & smask) != slice;
+            if (adm[k] && slice == 0) ++nadm;  // every pass sees every window: the first one counts them
+            adm[k] = adm[k] && !other[k];
         }
 #pragma unroll
         for (int k = 0; k < kCountPer; ++k) {
@@ -129,7 +137,6 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
             rep[k]           = e;
             lost[k]          = false;
             if (adm[k]) {
-                ++nadm;
                 const uint32_t w = winL[(uint32_t)hash[k] & (kCountLSlot - 1)];
                 if (w != e) {
                     if (keyL[w] == key[k]) {
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void bin_emit_kernel(KeyFn keyfn, Rec* __re
 #pragma unroll
         for (int k = 0; k < kCountPer; ++k) {
             const uint32_t e = k * kBlock + threadIdx.x, j = base + e;
-            if (j < nitems) rep_of[j] = adm[k] ? base + rep[k] : kInvalid;  // an ITEM index: the corpus position, or the list entry (LIST)
+            if (j < nitems && (adm[k] || (!other[k] && slice == 0))) rep_of[j] = adm[k] ? base + rep[k] : kInvalid;  // an ITEM index: the corpus position, or the list entry (LIST)
             rank[k] = kInvalid;
             if (adm[k] && rep[k] == e) rank[k] = atomicAdd(&histL[(uint32_t)(hash[k] >> 56)], 1u);
         }
@@ -711,7 +718,8 @@ __global__ __launch_bounds__(kBlock) void shard_reply_radix_kernel(const uint32_
 
 
 // per-bin survivor counts (left in cur2 by bin_count) -> dense result offsets, bin by bin; kept = their total. Block a scans A bin a.
-__global__ __launch_bounds__(kBlock) void bin_kept_scan_kernel(DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t res_cap) {
+// accumulate: this pass is one of several of its order (a sliced order): its survivors follow those of the passes before it
+__global__ __launch_bounds__(kBlock) void bin_kept_scan_kernel(DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t res_cap, bool accumulate = false) {
     if (st->done) return;
     const uint32_t a = blockIdx.x;
     uint32_t       before, tot;
@@ -722,8 +730,9 @@ __global__ __launch_bounds__(kBlock) void bin_kept_scan_kernel(DevState* __restr
     if (a == kBins - 1 && threadIdx.x == 0) {
         const uint32_t kept = before + tot;
         bs->kept_total      = kept;
-        st->kept            = kept;
-        if ((uint64_t)st->res_total + kept > res_cap) st->overflow = 1;
+        bs->res_base        = st->res_total + (accumulate ? st->kept : 0u);
+        st->kept            = (accumulate ? st->kept : 0u) + kept;
+        if ((uint64_t)bs->res_base + kept > res_cap) st->overflow = 1;
     }
 }
 // sparse per-bin survivors -> dense result list: one wave copies one bin's run (no atomics, no scan over dead entries)
@@ -731,7 +740,7 @@ __global__ __launch_bounds__(kBlock) void compact_bins_kernel(const uint32_t* __
                                                                const BinState* __restrict__ bs, uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap,
                                                                const uint32_t* __restrict__ list /* item index -> corpus position, or NULL */) {
     if (st->done) return;
-    const uint32_t res_base = st->res_total, lane = threadIdx.x & (kWave - 1);
+    const uint32_t res_base = bs->res_base, lane = threadIdx.x & (kWave - 1);
     const uint32_t nwaves = gridDim.x * (kBlock / kWave);
     for (uint32_t g = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; g < (uint32_t)kFinalBins; g += nwaves) {
         const uint32_t f   = ((g & (uint32_t)(kBins - 1)) << 8) | (g >> 8);  // transposed walk, as in bin_count_kernel
@@ -751,9 +760,9 @@ __global__ __launch_bounds__(kBlock) void compact_bins_kernel(const uint32_t* __
 }
 
 // bookkeeping between orders on the binned path: found = sum of the partial counters; survivor-id base moves on by nrec
-__global__ void bin_advance_prepare_kernel(DevState* __restrict__ st, const BinState* __restrict__ bs) {
+__global__ void bin_advance_prepare_kernel(DevState* __restrict__ st, const BinState* __restrict__ bs, bool accumulate = false) {
     if (st->done) return;
-    uint32_t f = 0;
+    uint32_t f = accumulate ? st->found : 0u;
     for (int a = 0; a < kBins; ++a) f += bs->found_part[a];
     st->found = f;
     const uint64_t next = (uint64_t)st->id_base + bs->nrec;

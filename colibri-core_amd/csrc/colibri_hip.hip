@@ -119,13 +119,14 @@ struct colibri_ctx {
     } fx;
     struct Bigram2 {                    // second-generation order 2 (bigram2.hpp)
         DevBuf<Bi2State> state;
-        DevBuf<uint32_t> boff, head_rows, wlist, wcnt, plist, bitmap;
+        DevBuf<uint32_t> boff, head_rows, wlist, wcnt, plist, bitmap, headsurv;
         bool             disabled = false;  // set for the rerun after this path could not hold an order (region / bin / list overflow)
         bool             attr_set = false;
     } b2;
     DevBuf<uint32_t>  alist[2], alist_n; // binned path: active-position lists (ping-pong) and their lengths [2]
     DevBuf<BinState>  binstate;
     int               last_mode = 0;    // 1 = global table, 2 = binned (what the last train() actually ran)
+    int               last_passes = 1;  // passes over key slices of the order-2 stage of that run
     struct Segment {
         uint32_t first, count;
         int      n;
@@ -473,7 +474,7 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->fx.keys); dev_free(c->fx.keyoff); dev_free(c->fx.refoff); dev_free(c->fx.cnt); dev_free(c->fx.sentence); dev_free(c->fx.token);
     dev_free(c->tx.table); dev_free(c->tx.state); dev_free(c->tx.info); dev_free(c->tx.events); dev_free(c->tx.evcnt);
     dev_free(c->flag2);
-    dev_free(c->b2.state); dev_free(c->b2.boff); dev_free(c->b2.head_rows); dev_free(c->b2.wlist); dev_free(c->b2.wcnt); dev_free(c->b2.plist); dev_free(c->b2.bitmap);
+    dev_free(c->b2.state); dev_free(c->b2.boff); dev_free(c->b2.head_rows); dev_free(c->b2.wlist); dev_free(c->b2.wcnt); dev_free(c->b2.plist); dev_free(c->b2.bitmap); dev_free(c->b2.headsurv);
     dev_free(c->ids_at);
     dev_free(c->alist[0]);
     dev_free(c->alist[1]);
@@ -538,6 +539,12 @@ int colibri_corpus_info(const colibri_ctx* c, uint64_t* ntokens, uint64_t* nsent
     if (nsentences) *nsentences = c->nsent;
     if (maxclass) *maxclass = c->maxclass;
     return COLIBRI_OK;
+}
+
+int colibri_last_mode(const colibri_ctx* c, int* passes) {
+    if (!c) return 0;
+    if (passes) *passes = c->last_passes;
+    return c->trained ? c->last_mode : 0;
 }
 
 int colibri_positions(const colibri_ctx* c, uint64_t* npositions) {
@@ -670,7 +677,7 @@ BinnedIO binned_planes(colibri_ctx* c, const TrainPlan& pl, bool with_keys) {
 
 template <class KeyFn>
 int binned_count_stage(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, int n, bool use_list, uint32_t thr, bool with_keys, bool need_ids = true, bool flag_mode = false,
-                       bool dense_code = false) {
+                       bool dense_code = false, uint32_t sbits = 0, uint32_t slice = 0) {
     const uint32_t  tiles    = blocks_for(pl.npos, kScatTile) + 1 + kASlots;  // level-B tiles: every slot may end in a partial one
     const uint32_t* list_in  = c->alist[n & 1].p;
     const uint32_t* nlist_in = c->alist_n.p + (n & 1);
@@ -683,10 +690,10 @@ int binned_count_stage(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, int
         Prof p(c, COLIBRI_K_EMIT);
         if (use_list)
             hipLaunchKernelGGL((bin_emit_kernel<KeyFn, true>), dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, fn, c->recs[0].p, region, c->rep_of.p, c->state.p, c->binstate.p, pl.npos,
-                               list_in, nlist_in, ids_at, flags_at);
+                               list_in, nlist_in, ids_at, flags_at, sbits, slice);
         else
             hipLaunchKernelGGL((bin_emit_kernel<KeyFn, false>), dim3(pl.cnt_grid), dim3(kBlock), 0, c->stream, fn, c->recs[0].p, region, c->rep_of.p, c->state.p, c->binstate.p, pl.npos,
-                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, ids_at, flags_at);
+                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, ids_at, flags_at, sbits, slice);
     }
     {
         Prof p(c, COLIBRI_K_SCATTER);
@@ -724,8 +731,26 @@ int binned_resolve_stage(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids_out,
 // ---- order 2, second generation (bigram2.hpp): class-keyed 8-byte records, dense head, per-slot level B, one wave per final bin, position
 // lists -> bitmap -> the active list of order 3. `want_list`: order 3 follows. Everything is enqueued; nothing is read back.
 constexpr uint32_t kBi2Sub = 8, kBi2EmitGrid = 512, kBi2Waves = 256 * 16;
+// records a pass of the radix path takes on (final bins of ~700-1500 records). COLIBRI_SLICE_POSITIONS (tests): a smaller number, so that small corpora
+// exercise the sliced passes of the path for corpora beyond ~128 M tokens per device
+inline uint64_t slice_positions() {
+    static const uint64_t v = [] {
+        const char* e = getenv("COLIBRI_SLICE_POSITIONS");
+        const unsigned long long x = e ? strtoull(e, nullptr, 10) : 0ull;
+        return x ? (uint64_t)x : 110ull * 1000 * 1000;
+    }();
+    return v;
+}
+inline uint64_t big_corpus_tokens() { return getenv("COLIBRI_SLICE_POSITIONS") ? slice_positions() : 128ull * 1000 * 1000; }
+inline uint32_t slice_bits(uint64_t records) {  // passes needed for that many records, as a power of two (at most 64)
+    if (records <= slice_positions()) return 0;
+    // once an order is sliced, fuller passes are cheaper (the per-bin cost of the count kernels is mostly fixed): up to 14/11 of the single-pass size each
+    uint32_t s = 1;
+    while (s < 6 && ((slice_positions() * 14 / 11) << s) < records) ++s;
+    return s;
+}
 struct Bigram2Plan {
-    uint32_t nslots, region, pshift, nbuckets, wcap;
+    uint32_t nslots, region, pshift, nbuckets, wcap, clsbits, posbits, sbits;
     Bi2Lists pl;
 };
 Bigram2Plan bigram2_plan(const colibri_ctx* c, uint32_t npos) {
@@ -733,28 +758,42 @@ Bigram2Plan bigram2_plan(const colibri_ctx* c, uint32_t npos) {
     b.nslots = kBins * kBi2Sub;
     // records are 8 bytes: recs[0] (level-A output) and recs[1] (level-B output) hold twice their Rec capacity
     b.region = (uint32_t)(std::min<uint64_t>(2ull * c->recs[0].n, 2ull * c->recs[1].n) / b.nslots);
+    // a pass over one slice of a big corpus fills a fraction of that: keep its slots close together (a bin's eight runs then lie ~MBs, not ~GBs, apart)
+    if (slice_bits(npos)) b.region = (uint32_t)std::min<uint64_t>(b.region, (slice_positions() * 5 / 2) / b.nslots + 8192);
     b.pshift = 12;
     while (((uint64_t)npos >> b.pshift) > (uint64_t)kBi2Buckets - 1) ++b.pshift;
     b.nbuckets  = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)npos + (1u << b.pshift) - 1) >> b.pshift));
     b.pl.pshift = b.pshift;
-    b.pl.pcap   = ((1u << b.pshift) / 2 + 64 + 3) & ~3u;
+    b.pl.pcap   = ((1u << b.pshift) / 4 + 4096 + 3) & ~3u;  // a bucket's entries spread evenly over the 8 shards: twice the expected worst case
     b.wcap      = (uint32_t)(((uint64_t)npos * 6 / 10 / kBi2Waves) * 2 + 4096);
+    b.clsbits   = 1;
+    while ((1ull << b.clsbits) <= (uint64_t)c->maxclass) ++b.clsbits;
+    b.posbits = 1;
+    while ((1ull << b.posbits) < (uint64_t)npos + 1) ++b.posbits;
+    b.posbits = std::max(b.posbits, 27u);
+    b.sbits   = slice_bits(npos);
     return b;
+}
+// the record must hold the mix bits below the A bin next to the position
+bool bigram2_fits(const colibri_ctx* c, uint32_t npos) {
+    const Bigram2Plan b = bigram2_plan(c, npos);
+    return npos < (1u << kBi2MaxPosBits) && 2 * b.clsbits - b.sbits - 8 + b.posbits <= 64;
 }
 int bigram2_alloc(colibri_ctx* c, uint32_t npos) {
     const Bigram2Plan b = bigram2_plan(c, npos);
     int               rc;
     if ((rc = dev_alloc(c, c->b2.state, 1)) || (rc = dev_alloc(c, c->b2.boff, (size_t)b.nslots * (kBi2BBins + 1))) ||
         (rc = dev_alloc(c, c->b2.head_rows, (size_t)kBi2EmitGrid * 2 * kBi2HeadN)) || (rc = dev_alloc(c, c->b2.wlist, (size_t)kBi2Waves * b.wcap)) ||
-        (rc = dev_alloc(c, c->b2.wcnt, kBi2Waves)) || (rc = dev_alloc(c, c->b2.plist, (size_t)kBi2Shards * kBi2Buckets * b.pl.pcap)) ||
-        (rc = dev_alloc(c, c->b2.bitmap, (size_t)npos / 32 + 16)))
+        (rc = dev_alloc(c, c->b2.wcnt, kBi2Waves)) || (rc = dev_alloc(c, c->b2.plist, (size_t)kBi2Shards * kBi2Buckets * b.pl.pcap + 64)) ||
+        (rc = dev_alloc(c, c->b2.bitmap, (size_t)npos / 32 + 16)) || (rc = dev_alloc(c, c->b2.headsurv, kBi2HeadN / 32)))
         return rc;
     if (!c->b2.attr_set) {
-        HIP_TRY(c, hipFuncSetAttribute((const void*)bi2_bitmap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)1 << 27) / kBi2Buckets / 8)));
+        HIP_TRY(c, hipFuncSetAttribute((const void*)bi2_bitmap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)1 << kBi2MaxPosBits) / kBi2Buckets / 8)));
         c->b2.attr_set = true;
     }
     return COLIBRI_OK;
 }
+#define B2DBG(name) do { if (getenv("COLIBRI_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(c->stream); fprintf(stderr, "[b2] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
 int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list) {
     const uint32_t    npos = pl.npos, nsurv = c->maxclass / 32 + 1;
     const Bigram2Plan b    = bigram2_plan(c, npos);
@@ -762,57 +801,73 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list) {
     auto* const       recsA = reinterpret_cast<unsigned long long*>(c->recs[0].p);
     auto* const       recsB = reinterpret_cast<unsigned long long*>(c->recs[1].p);
     uint32_t* const   nlist = c->alist_n.p + 1;  // order 3 reads alist[3 & 1]
-    HIP_TRY(c, hipMemsetAsync(bs, 0, sizeof(Bi2State), c->stream));
     HIP_TRY(c, hipMemsetAsync(nlist, 0, sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->b2.wcnt.p, 0, sizeof(uint32_t) * kBi2Waves, c->stream));
-    {
-        Prof p(c, COLIBRI_K_EMIT2);
-        hipLaunchKernelGGL(bi2_emit_kernel, dim3(kBi2EmitGrid), dim3(kBi2Threads), 0, c->stream, c->cls.p, c->uni_surv.p, nsurv, npos, recsA, b.region, kBi2Sub, bs, c->state.p,
-                           c->b2.head_rows.p);
-        hipLaunchKernelGGL(bi2_head_reduce_kernel, dim3(kBi2HeadN / kBlock, kBi2HeadSplit), dim3(kBlock), 0, c->stream, c->b2.head_rows.p, kBi2EmitGrid, bs, c->state.p);
-        hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, b.region, kBi2Sub, c->state.p);
-    }
-    {
-        Prof p(c, COLIBRI_K_LEVELB2);
-        hipLaunchKernelGGL(bi2_levelB_kernel, dim3(b.nslots), dim3(kBi2Threads), 0, c->stream, recsA, recsB, b.region, bs, c->b2.boff.p, c->state.p);
-        hipLaunchKernelGGL(bi2_binoff_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->b2.boff.p, kBi2Sub, c->state.p);
-    }
     const BinnedIO io = binned_planes(c, pl, false);  // the sparse survivor arrays live in recs[0], free again after level B
-    {
-        Prof p(c, COLIBRI_K_COUNT2);
-        hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr, io.sp_rep, io.sp_cnt,
-                           c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list);
-    }
-    {
-        Prof p(c, COLIBRI_K_PRUNE);
-        hipLaunchKernelGGL(bi2_kept_scan_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->state.p);
-        hipLaunchKernelGGL(bi2_finish_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->state.p, bs, pl.thr, pl.res_cap);
-        hipLaunchKernelGGL(bi2_compact_kernel, dim3(1025), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, bs, c->res_rep.p, c->res_cnt.p, pl.res_cap);
+    for (uint32_t slice = 0; slice < (1u << b.sbits); ++slice) {  // one pass per slice of the keys (one pass unless the corpus exceeds ~110 M positions)
+        HIP_TRY(c, hipMemsetAsync(bs, 0, sizeof(Bi2State), c->stream));
+        {
+            Prof p(c, COLIBRI_K_EMIT2);
+            hipLaunchKernelGGL(bi2_emit_kernel, dim3(kBi2EmitGrid), dim3(kBi2Threads), 0, c->stream, c->cls.p, c->uni_surv.p, nsurv, npos, b.clsbits, b.sbits, slice, b.posbits, recsA, b.region,
+                               kBi2Sub, bs, c->state.p, c->b2.head_rows.p);
+        B2DBG("bi2_emit_kernel");
+            if (slice == 0)
+                hipLaunchKernelGGL(bi2_head_reduce_kernel, dim3(kBi2HeadN / kBlock, kBi2HeadSplit), dim3(kBlock), 0, c->stream, c->b2.head_rows.p, kBi2EmitGrid, bs, c->state.p);
+        B2DBG("bi2_head_reduce_kernel");
+            hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, b.region, kBi2Sub, c->state.p);
+        B2DBG("bi2_offsets_kernel");
+        }
+        {
+            Prof p(c, COLIBRI_K_LEVELB2);
+            hipLaunchKernelGGL(bi2_levelB_kernel, dim3(b.nslots), dim3(kBi2Threads), 0, c->stream, recsA, recsB, b.region, bs, c->b2.boff.p, c->state.p);
+        B2DBG("bi2_levelB_kernel");
+            hipLaunchKernelGGL(bi2_binoff_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->b2.boff.p, kBi2Sub, c->state.p);
+        B2DBG("bi2_binoff_kernel");
+        }
+        {
+            Prof p(c, COLIBRI_K_COUNT2);
+            hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr, io.sp_rep, io.sp_cnt,
+                               c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list);
+        B2DBG("bi2_count_kernel");
+        }
+        {
+            Prof p(c, COLIBRI_K_PRUNE);
+            hipLaunchKernelGGL(bi2_kept_scan_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->state.p);
+        B2DBG("bi2_kept_scan_kernel");
+            hipLaunchKernelGGL(bi2_finish_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->state.p, bs, pl.thr, pl.res_cap, slice == 0 ? c->b2.headsurv.p : (uint32_t*)nullptr);
+        B2DBG("bi2_finish_kernel");
+            hipLaunchKernelGGL(bi2_compact_kernel, dim3(1025), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, bs, c->res_rep.p, c->res_cnt.p, pl.res_cap);
+        B2DBG("bi2_compact_kernel");
+        }
     }
     if (!want_list) return COLIBRI_OK;
     HIP_TRY(c, hipMemsetAsync(c->b2.bitmap.p + npos / 32, 0, sizeof(uint32_t) * 16, c->stream));  // words beyond the corpus read as zero
     {
         Prof p(c, COLIBRI_K_LISTS2);
         hipLaunchKernelGGL(bi2_pospart_kernel, dim3(512), dim3(kBi2Threads), 0, c->stream, c->b2.wlist.p, c->b2.wcnt.p, kBi2Waves, b.wcap, bs, c->state.p, c->b2.plist.p, b.pl);
+        B2DBG("bi2_pospart_kernel");
         hipLaunchKernelGGL(bi2_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, bs, c->b2.plist.p, b.pl, c->state.p, c->b2.bitmap.p);
-        hipLaunchKernelGGL(bi2_list3_kernel, dim3(2048), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_surv.p, npos, bs, c->b2.bitmap.p, c->state.p, c->alist[1].p, nlist);
+        B2DBG("bi2_bitmap_kernel");
+        hipLaunchKernelGGL(bi2_list3_kernel, dim3(2048), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_surv.p, npos, c->b2.headsurv.p, c->b2.bitmap.p, c->state.p, c->alist[1].p, nlist);
+        B2DBG("bi2_list3_kernel");
     }
     return COLIBRI_OK;
 }
 
-// one order of the plain (unsynced) run. need_ids = false at the last order: nothing reads its survivor ids, so the id scatter and
-// the resolve pass are skipped.
+// sbits: the order is counted in 2^sbits passes over disjoint slices of its keys (corpora beyond ~128 M tokens per device: a final bin must fit its LDS table);
+// the passes append their survivors, the ids are resolved once at the end.
 template <class KeyFn>
-int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t* ids_out, int n, bool use_list, bool need_ids, bool flag_mode = false, bool prefill_ids = false) {
+int binned_order(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uint32_t* ids_out, int n, bool use_list, bool need_ids, bool flag_mode = false, bool prefill_ids = false,
+                 uint32_t sbits = 0) {
     int rc;
-    if ((rc = binned_count_stage(c, pl, fn, n, use_list, pl.thr, false, need_ids, flag_mode))) return rc;
     const BinnedIO io = binned_planes(c, pl, false);
-    {
+    for (uint32_t slice = 0; slice < (1u << sbits); ++slice) {
+        if ((rc = binned_count_stage(c, pl, fn, n, use_list, pl.thr, false, need_ids, flag_mode, false, sbits, slice))) return rc;
         Prof p(c, COLIBRI_K_PRUNE);
-        hipLaunchKernelGGL(bin_kept_scan_kernel, dim3(kBins), dim3(kBlock), 0, c->stream, c->state.p, c->binstate.p, pl.res_cap);
+        hipLaunchKernelGGL(bin_kept_scan_kernel, dim3(kBins), dim3(kBlock), 0, c->stream, c->state.p, c->binstate.p, pl.res_cap, sbits != 0);
         hipLaunchKernelGGL(compact_bins_kernel, dim3(1024), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, c->binstate.p, c->res_rep.p, c->res_cnt.p, pl.res_cap,
                            use_list ? (const uint32_t*)c->alist[n & 1].p : (const uint32_t*)nullptr);
-        hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
+        hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p, sbits != 0);
     }
     if (!need_ids) return COLIBRI_OK;
     if (flag_mode) {  // all-positions order whose successor builds its keys from class ids: a byte per position and the active list
@@ -1160,21 +1215,24 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     const bool     constrained = c->cs.n != 0;  // train(..., constrainbymodel): one membership-filtered pass per length, no look-back (constrained.hpp)
     const int      backoff = (o.maxbackofflength >= 1 && o.maxbackofflength + 1 < std::min<int>(o.maxlength, COLIBRI_MAX_ORDER - 1)) ? o.maxbackofflength : 0;  // orders above backoff + 1 differ
     const bool     synced = o.indexed || o.doskipgrams || o.doskipgrams_exhaustive || constrained || backoff;  // these modes keep every order's ids and talk to the host per order
-    // radix-partition + LDS count (binned.hpp) for the plain n-gram path when every final bin fits its LDS table: 65 536 bins
-    // x <= ~1000 distinct keys expected; beyond ~128 M tokens per device (or on request) the global open-addressed table is used
-    bool binned = !synced && (o.table_mode == 2 || (o.table_mode == 0 && c->ntokens <= 128ull * 1000 * 1000));
     // order 1 counted per class id when the encoding is canonical (class id <-> token bytes is then a bijection) and the class
     // space is small enough for a dense array; table_mode 1 / 2 force the generic table / radix implementations (tests)
     const bool uni_direct = !synced && o.table_mode == 0 && !(c->flags & kFlagNonCanonical) && c->maxclass < (1u << 28);
     if (uni_direct && ((rc = dev_alloc(c, c->cnt1, (size_t)c->maxclass + 2)) || (rc = dev_alloc(c, c->rep1, (size_t)c->maxclass + 2)))) return rc;
     const uint32_t uni_shift = (uni_direct && !synced) ? uni_range_shift(c) : 0u;  // 0: more than 4 M classes, the atomics kernel stays
     if (uni_shift && (rc = uni_alloc(c))) return rc;
+    // second-generation order 2 (bigram2.hpp): class-keyed, positions in up to 30 bits; a run that it could not hold (c->b2.disabled, set below) repeats on
+    // the first-generation kernels
+    const bool bi2_ok = uni_direct && !synced && uni_shift != 0 && c->maxclass < (1u << 21) && o.maxlength >= 2 && bigram2_fits(c, npos) && !c->b2.disabled;
+    // radix-partition + LDS count for the plain n-gram path: every final bin must fit its LDS table. Up to ~128 M tokens per device one pass per order does;
+    // beyond, an order is counted in passes over slices of its keys (bigram2_order / binned_order: `big`) — which needs the class-keyed orders 2 and 3;
+    // otherwise (or on request) the global open-addressed table
+    const bool big = c->ntokens > big_corpus_tokens();
+    bool binned = !synced && (o.table_mode == 2 || (o.table_mode == 0 && (!big || bi2_ok)));
     // three class ids in one key: order 3 is keyed by classes, order 2 leaves survivor bytes instead of ids (KeyTrigramCls)
     const bool tri_cls = binned && uni_direct && !synced && c->maxclass < (1u << 21) && o.maxlength >= 3;
     const bool bi_cls = tri_cls && uni_shift != 0;  // ... and order 2 is keyed by classes + the order-1 survivor bitmap: no per-position order-1 ids at all
-    // second-generation order 2 (bigram2.hpp): same preconditions as the class-keyed order 2, positions in 27 bits; a run that it could not hold
-    // (c->b2.disabled, set below) repeats on the first-generation kernels
-    const bool bi2 = binned && uni_direct && !synced && uni_shift != 0 && c->maxclass < (1u << 21) && o.maxlength >= 2 && npos < (1u << kBi2PosBits) && !c->b2.disabled;
+    const bool bi2 = binned && bi2_ok;
     if (tri_cls && !bi2 && ((rc = dev_alloc(c, c->flags_at, (size_t)npos + 1)) || (rc = dev_alloc(c, c->flag2, (size_t)npos + 4)))) return rc;
     // ---- HBM layout (sized once; nothing is allocated inside the unsynced order loop) ----------------
     // table: an order admits at most `npos` windows -> 1.5x slots; results: every survivor has >= 2 occurrences
@@ -1241,7 +1299,8 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
 
     if (!synced) {
         // ---------- the headline path: all orders enqueued back to back, no host round trip per order ----------
-        int cur = 0;  // ids[cur] = survivor ids of order n-1; ids[cur^1] receives order n
+        int      cur = 0;  // ids[cur] = survivor ids of order n-1; ids[cur^1] receives order n
+        uint32_t sbits_next = 0;  // passes (as a power of two) of the next first-generation order: more than one only for corpora beyond ~128 M tokens
         for (int n = 1; n <= maxlength; ++n) {
             uint32_t* id_prev = c->ids[cur].p;
             uint32_t* id_cur  = c->ids[cur ^ 1].p;
@@ -1277,7 +1336,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                 else if (n == 2 && bi2)
                     rc = bigram2_order(c, pl, /*want_list=*/n < maxlength);
                 else if (n == 3 && bi2)
-                    rc = binned_order(c, pl, KeyTrigramClsListed{c->cls.p}, id_cur, n, true, n < maxlength, false, /*prefill_ids=*/true);  // over the list bigram2 left: every listed window is admissible
+                    rc = binned_order(c, pl, KeyTrigramClsListed{c->cls.p}, id_cur, n, true, n < maxlength, false, /*prefill_ids=*/true, sbits_next);  // over the list bigram2 left: every listed window is admissible
                 else if (n == 2 && bi_cls)
                     rc = binned_order(c, pl, KeyBigramCls{c->cls.p, c->uni_surv.p}, id_cur, n, false, true, /*flag_mode=*/true);
                 else if (n == 2 && tri_cls)
@@ -1285,7 +1344,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                 else if (n == 3 && tri_cls)
                     rc = binned_order(c, pl, KeyTrigramCls{c->cls.p, c->flag2.p}, id_cur, n, true, n < maxlength);
                 else
-                    rc = binned_order(c, pl, KeyNgram{id_prev, n}, id_cur, n, n >= 3, n < maxlength);
+                    rc = binned_order(c, pl, KeyNgram{id_prev, n}, id_cur, n, n >= 3, n < maxlength, false, false, sbits_next);
                 if (rc) return rc;
             } else {
                 launch_clear(c, pl);
@@ -1299,6 +1358,12 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             }
             hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, n, pl.table_slots);
             cur ^= 1;
+            if (big && binned && n >= 2 && n < maxlength) {  // a big corpus: how many passes the next order needs follows from how many positions still carry a survivor
+                uint32_t valid = 0;
+                HIP_TRY(c, hipMemcpyAsync(&valid, &c->state.p->s_valid[n], sizeof valid, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                sbits_next = slice_bits(valid);
+            }
             // peek at the termination flag only every 8 orders (MAXLENGTH defaults to 100)
             if ((n % 8) == 0 && n < maxlength) {
                 uint32_t done = 0;
@@ -1323,7 +1388,8 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             again.table_mode      = 1;
             return colibri_train_once(c, &again, stats_out);
         }
-        c->last_mode = binned ? 2 : 1;
+        c->last_mode   = binned ? 2 : 1;
+        c->last_passes = bi2 ? (1 << bigram2_plan(c, npos).sbits) : 1;
         s.maxn = (int32_t)c->hstate.maxn;
         for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) {
             s.found[n]    = c->hstate.s_found[n];

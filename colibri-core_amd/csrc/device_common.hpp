@@ -41,6 +41,7 @@ struct DevState {
     uint32_t s_kept[COLIBRI_MAX_ORDER];
     uint32_t s_admitted[COLIBRI_MAX_ORDER];
     uint32_t res_off[COLIBRI_MAX_ORDER + 1];  // res_off[n] = first result index of order n
+    uint32_t s_valid[COLIBRI_MAX_ORDER];      // positions that carried a survivor id after order n (what order n + 1 can admit at most)
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }

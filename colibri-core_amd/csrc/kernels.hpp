@@ -1029,6 +1029,7 @@ __global__ void advance_kernel(DevState* __restrict__ st, int n, uint32_t table_
         st->s_found[n]    = st->found;
         st->s_kept[n]     = st->kept;
         st->s_admitted[n] = st->admitted;
+        st->s_valid[n]    = st->valid;
     }
     if (st->found == 0) {  // reference: "None found" -> break (patternmodel.h:1189-1194)
         st->done = 1;

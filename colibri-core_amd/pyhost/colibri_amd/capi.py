@@ -19,7 +19,7 @@ KERNEL_CLASSES = ["tokenise", "clear", "count", "prune", "resolve", "skipgram", 
 EXPORTED = [
     "colibri_abi_version", "colibri_create", "colibri_destroy", "colibri_last_error", "colibri_upload_corpus",
     "colibri_upload_corpus_device", "colibri_corpus_info", "colibri_train", "colibri_result_sizes", "colibri_export_unindexed",
-    "colibri_export_indexed", "colibri_hash_windows", "colibri_positions", "colibri_hash_keys", "colibri_kernel_time",
+    "colibri_export_indexed", "colibri_hash_windows", "colibri_positions", "colibri_last_mode", "colibri_hash_keys", "colibri_kernel_time",
     "colibri_shard_begin", "colibri_shard_count", "colibri_shard_send", "colibri_shard_merge", "colibri_shard_reply", "colibri_shard_apply",
     "colibri_shard_finish", "colibri_shard_export_gids", "colibri_shard_index_sizes", "colibri_shard_export_index",
     "colibri_shard_uni_info", "colibri_shard_uni_count", "colibri_shard_uni_apply",
@@ -96,6 +96,7 @@ def load():
         L.colibri_export_indexed.argtypes = [C.c_void_p] * 7
         L.colibri_hash_windows.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.colibri_positions.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.colibri_last_mode.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.colibri_hash_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.colibri_kernel_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.colibri_shard_begin.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int]
@@ -168,6 +169,12 @@ class Context:
         n = C.c_uint64()
         self._check(self.L.colibri_positions(self.h, C.byref(n)))
         return n.value
+
+    def last_mode(self, with_passes=False):
+        """1 = the last train() counted on the global table, 2 = on the radix path (and in how many passes over key slices its order 2 ran)"""
+        p = C.c_int(1)
+        m = self.L.colibri_last_mode(self.h, C.byref(p))
+        return (m, p.value) if with_passes else m
 
     def set_constraint(self, keys):
         """colibri_set_constraint: the next train() calls only count patterns whose key bytes are in `keys` (an empty list lifts it)."""

@@ -179,6 +179,10 @@ int colibri_shard_export_index(colibri_ctx* ctx, uint32_t* gids, uint64_t* ref_o
  * 0 where no n-token window starts. out has colibri_positions() entries. */
 int colibri_hash_windows(colibri_ctx* ctx, int n, uint64_t* out_host);
 int colibri_positions(const colibri_ctx* ctx, uint64_t* npositions);
+/* Which implementation of the counting stage the last colibri_train ran (the reference has one, include/patternmodel.h:1078-1178; here the choice follows
+ * the corpus and colibri_options.table_mode, and an overflow of the radix path repeats the run on the table): 1 = global open-addressed table,
+ * 2 = radix partition + LDS count, 0 = neither (pattern list, or nothing trained). *passes (optional) = passes over key slices the order-2 stage used. */
+int colibri_last_mode(const colibri_ctx* ctx, int* passes);
 /* SpookyHash::Hash64 of nkeys independent byte strings (off[nkeys+1] into bytes) on the device */
 int colibri_hash_keys(colibri_ctx* ctx, const uint8_t* bytes, const uint64_t* off, uint64_t nkeys, uint64_t* out_host);
 /* accumulated HIP-event time and launch count of one kernel class since the last colibri_train() began

@@ -1,0 +1,39 @@
+"""Worker of tests/test_gpu_sliced.py: trains corpora with COLIBRI_SLICE_POSITIONS set in the environment (so that the library counts every order of a
+small corpus in passes over slices of its keys, the way it treats corpora beyond ~128 M tokens per device) and compares each model with the oracle."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "colibri-core_amd", "pyhost"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle  # noqa: E402
+from colibri_amd import capi, synth  # noqa: E402
+
+
+def main():
+    assert os.environ.get("COLIBRI_SLICE_POSITIONS")
+    rng = np.random.default_rng(5)
+    corpora = {"zipf_phrases_300k": synth.zipf_corpus(300_000, 20_000, 7, phrases=True, header=False),
+               "zipf_120k_small_vocab": synth.zipf_corpus(120_000, 40, 8, header=False),  # every bigram in the dense head
+               "random_long_sentences": synth.random_corpus(rng, nsent=4000, maxlen=40, vocab=300, big_classes=False)}
+    with capi.Context(0) as ctx:
+        for name, payload in corpora.items():
+            ctx.upload(payload)
+            for thr, maxlength in ((2, 5), (3, 8), (2, 2)):
+                want = oracle.train(payload, thr, maxlength)
+                st = ctx.train(mintokens=thr, maxlength=maxlength)
+                got, _ = ctx.export_dict()
+                assert got == want.counts, (name, thr, maxlength, len(got), len(want.counts))
+                assert (st.totaltokens, st.totaltypes, st.maxn) == (want.tokens, want.types, want.maxn), (name, thr, maxlength)
+                for n in range(1, maxlength + 1):
+                    assert (st.found[n], st.kept[n]) == (want.stats[n][0], want.stats[n][2]), (name, thr, maxlength, n)
+                assert ctx.last_mode() == 2, ("the radix path must have run (not the global-table fallback)", name, thr, maxlength, ctx.last_mode(True))
+    print("SLICED_OK")
+
+
+if __name__ == "__main__":
+    main()

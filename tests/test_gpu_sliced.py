@@ -1,0 +1,40 @@
+"""The radix path beyond ~128 M tokens per device: an order is counted in passes over slices of its keys (bigram2_order / binned_order in
+colibri_hip.hip), survivors appended pass after pass, positions / ids resolved once. The reference has one code path for any size
+(include/patternmodel.h:880-1345); here the sliced passes must give the same model as the single pass.
+  * small corpora with the slice size turned down through COLIBRI_SLICE_POSITIONS (a subprocess: the library reads it once): against the oracle;
+  * 300 M tokens: the sliced radix path against the global-table path as multisets of (key bytes, count) rows (two independent row hashes)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("slice_positions", ["30000", "7000"])
+def test_sliced_passes_match_the_oracle(slice_positions):
+    env = dict(os.environ, COLIBRI_SLICE_POSITIONS=slice_positions)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sliced_worker.py")], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0 and "SLICED_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+def test_sliced_radix_path_agrees_with_the_table_at_300m_tokens():
+    from colibri_amd import capi, synth
+    from test_gpu_fullsize import row_hashes, summary
+    payload = np.concatenate([np.frombuffer(synth.zipf_corpus(100_000_000, 1_000_000, 200 + k, header=False), dtype=np.uint8) for k in range(3)])
+    got = {}
+    with capi.Context(0) as ctx:
+        ctx.upload(payload)
+        for mode in (0, 1):
+            st = ctx.train(mintokens=2, maxlength=5, table_mode=mode)
+            assert ctx.last_mode() == (2 if mode == 0 else 1)
+            key_off, key_bytes, counts, _ = ctx.export_arrays()
+            got[mode] = (summary(st), row_hashes(key_off, key_bytes, counts))
+    assert got[0][0] == got[1][0]
+    assert got[0][0][0] == 300_000_000
+    for x, y in zip(got[0][1], got[1][1]):
+        assert np.array_equal(np.sort(x), np.sort(y))

@@ -40,7 +40,7 @@ int main(int argc,char**argv){
   CK(hipMalloc(&list3,(size_t)n*4+64)); CK(hipMalloc(&nlist3,64));
   uint32_t pshift=12; while(((uint64_t)n>>pshift) > (uint64_t)kBi2Buckets-1) ++pshift;
   const uint32_t nbuckets=(uint32_t)(((uint64_t)n+(1u<<pshift)-1)>>pshift);
-  Bi2Lists pl; pl.pshift=pshift; pl.pcap=(1u<<pshift)/2+64; uint32_t* plist; CK(hipMalloc(&plist,(size_t)kBi2Shards*kBi2Buckets*pl.pcap*4));
+  Bi2Lists pl; pl.pshift=pshift; pl.pcap=(1u<<pshift)/4+4096; uint32_t* plist; CK(hipMalloc(&plist,(size_t)kBi2Shards*kBi2Buckets*pl.pcap*4));
   const uint32_t egrid=256*gpc/ nsub * nsub; uint32_t* head_rows; CK(hipMalloc(&head_rows,(size_t)egrid*2*kBi2HeadN*4));
   DevState* st; CK(hipMalloc(&st,sizeof(DevState))); Bi2State* bs; CK(hipMalloc(&bs,sizeof(Bi2State)));
   const uint32_t W = 256*(argc>5?atoi(argv[5]):16);
@@ -48,6 +48,7 @@ int main(int argc,char**argv){
   uint32_t *wlist,*wcnt; CK(hipMalloc(&wlist,(size_t)W*wcap*4)); CK(hipMalloc(&wcnt,(size_t)W*4)); CK(hipMemset(wcnt,0,(size_t)W*4));
   const size_t bm_bytes=((size_t)(1u<<pshift)/32)*4;
   CK(hipFuncSetAttribute((const void*)bi2_bitmap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes));
+  uint32_t clsbits=1; while((1u<<clsbits)<ncls) ++clsbits; uint32_t* headsurv; CK(hipMalloc(&headsurv,kBi2HeadN/8));
   uint32_t* bitmap; CK(hipMalloc(&bitmap,((size_t)n/32+8)*4)); CK(hipMemset(bitmap,0,((size_t)n/32+8)*4));
   printf("npos %u nsub %u region %u nslots %u pshift %u nbuckets %u egrid %u waves %u wcap %u sizeof(Bi2State) %zu\n",n,nsub,region,nslots,pshift,nbuckets,egrid,W,wcap,sizeof(Bi2State));
   if(nsub!=8){printf("count kernel is instantiated for nsub = 8\n"); return 1;}
@@ -60,7 +61,7 @@ int main(int argc,char**argv){
     CK(hipEventRecord(ev[e++]));
     CK(hipMemsetAsync(bs,0,sizeof(Bi2State))); CK(hipMemsetAsync(nlist3,0,64));
     CK(hipEventRecord(ev[e++]));
-    hipLaunchKernelGGL(bi2_emit_kernel,dim3(egrid),dim3(kBi2Threads),0,0,cls,surv,ncls/32+4,n,recsA,region,nsub,bs,st,head_rows);
+    hipLaunchKernelGGL(bi2_emit_kernel,dim3(egrid),dim3(kBi2Threads),0,0,cls,surv,ncls/32+4,n,clsbits,0u,0u,27u,recsA,region,nsub,bs,st,head_rows);
     CK(hipEventRecord(ev[e++]));
     hipLaunchKernelGGL(bi2_head_reduce_kernel,dim3(kBi2HeadN/kBlock,kBi2HeadSplit),dim3(kBlock),0,0,head_rows,egrid,bs,st);
     hipLaunchKernelGGL(bi2_offsets_kernel,dim3(1),dim3(kBlock),0,0,bs,region,nsub,st);
@@ -72,14 +73,14 @@ int main(int argc,char**argv){
     hipLaunchKernelGGL((bi2_count_kernel<8>),dim3(W),dim3(kWave),0,0,recsB,region,boff,bs,st,thr,sp_rep,sp_cnt,wlist,wcnt,wcap,true);
     CK(hipEventRecord(ev[e++]));
     hipLaunchKernelGGL(bi2_kept_scan_kernel,dim3(kBins),dim3(kBi2BBins),0,0,bs,st);
-    hipLaunchKernelGGL(bi2_finish_kernel,dim3(1),dim3(kBlock),0,0,st,bs,thr,n);
+    hipLaunchKernelGGL(bi2_finish_kernel,dim3(1),dim3(kBlock),0,0,st,bs,thr,n,headsurv);
     hipLaunchKernelGGL(bi2_compact_kernel,dim3(1025),dim3(kBlock),0,0,sp_rep,sp_cnt,st,bs,res_rep,res_cnt,n);
     CK(hipEventRecord(ev[e++]));
     hipLaunchKernelGGL(bi2_pospart_kernel,dim3(512),dim3(kBi2Threads),0,0,wlist,wcnt,W,wcap,bs,st,plist,pl);
     CK(hipEventRecord(ev[e++]));
     hipLaunchKernelGGL(bi2_bitmap_kernel,dim3(nbuckets),dim3(kBi2BmThreads),bm_bytes,0,n,bs,plist,pl,st,bitmap);
     CK(hipEventRecord(ev[e++]));
-    hipLaunchKernelGGL(bi2_list3_kernel,dim3(2048),dim3(kBlock),0,0,cls,surv,n,bs,bitmap,st,list3,nlist3);
+    hipLaunchKernelGGL(bi2_list3_kernel,dim3(2048),dim3(kBlock),0,0,cls,surv,n,headsurv,bitmap,st,list3,nlist3);
     CK(hipEventRecord(ev[e++]));
     CK(hipDeviceSynchronize()); CK(hipGetLastError());
     float tot; CK(hipEventElapsedTime(&tot,ev[0],ev[e-1])); if(tot<best_total)best_total=tot;

@@ -57,8 +57,8 @@ struct colibri_ctx {
     DevBuf<uint32_t>  tokstart;
     DevBuf<uint32_t>  delimpos;
     DevBuf<uint32_t>  cls;              // class id per position (0 = delimiter)
-    DevBuf<uint2>     pos_ref;          // (sentence ordinal, token offset) per position (built at the first indexed run on a corpus)
-    bool              pos_refs_valid = false;
+    DevBuf<PosBlock>  pos_blocks;       // per 64 positions: sentences before, start of the running sentence, delimiter bits (built at the first indexed run on a corpus)
+    bool              pos_blocks_valid = false;
     DevBuf<uint32_t>  cnt1, rep1;       // order-1 fast path: count / representative position per class
     DevBuf<UniState>  unistate;         // ... its atomic-free variant: tail-bin sizes / offsets / cursors
     DevBuf<uint16_t>  uni_tail;         // ... and the tail tokens as 2-byte offsets inside their class-range bin
@@ -73,7 +73,7 @@ struct colibri_ctx {
     std::vector<DevBuf<uint32_t>> ids;  // plain mode: 2 ping-pong buffers; skipgram / indexed modes: one per order
     DevBuf<uint32_t>  scratch[2];       // per-position slot arrays of the skipgram passes
     DevBuf<uint32_t>  nsrc;             // per-slot distinct-source counter (indexed skipgrams)
-    DevBuf<uint32_t>  pair_id[2], pair_pos[2];  // forward index: (result id, position) pairs, ping-pong for the radix sort (kept between runs: a release and a
+    DevBuf<unsigned long long> pairs[2];        // forward index: (result id << 32 | position) pairs, ping-pong for the radix sort (kept between runs: a release and a
                                                 // new reservation of these GB-sized buffers per train() cost more than the kernels)
     DevBuf<uint32_t>  idx_cnt, sort_hist;       // ... per-block pair counts of a pass; per-block digit histograms of a sort pass
     DevBuf<unsigned long long> sort_off, sort_bsum;
@@ -294,7 +294,7 @@ int tokenise(colibri_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->npos = npos;
     c->cs.rem_valid = false;  // per-position sentence remainders belong to the previous corpus
-    c->pos_refs_valid = false;
+    c->pos_blocks_valid = false;
     if ((rc = dev_alloc(c, c->tokstart, (size_t)npos + 2)) || (rc = dev_alloc(c, c->cls, (size_t)npos + 128))) {  // class ids are read as whole 16-byte vectors past the end (zeros)
         cleanup();
         return rc;
@@ -449,7 +449,7 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->bytes);
     dev_free(c->tokstart);
     dev_free(c->delimpos);
-    dev_free(c->pos_ref);
+    dev_free(c->pos_blocks);
     dev_free(c->cls);
     dev_free(c->cnt1);
     dev_free(c->rep1);
@@ -480,10 +480,8 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->alist[1]);
     dev_free(c->alist_n);
     dev_free(c->binstate);
-    for (int k = 0; k < 2; ++k) {
-        dev_free(c->pair_id[k]);
-        dev_free(c->pair_pos[k]);
-    }
+    dev_free(c->pairs[0]);
+    dev_free(c->pairs[1]);
     dev_free(c->idx_cnt); dev_free(c->sort_hist); dev_free(c->sort_off); dev_free(c->sort_bsum);
     dev_free(c->ref_sentence);
     dev_free(c->ref_token);
@@ -960,12 +958,13 @@ int prepare_export(colibri_ctx* c) {
 }
 
 // grow a pair buffer keeping its first `keep` elements
-int grow_keep(colibri_ctx* c, DevBuf<uint32_t>& b, uint64_t need, uint64_t keep) {
+template <class T>
+int grow_keep(colibri_ctx* c, DevBuf<T>& b, uint64_t need, uint64_t keep) {
     if (b.p && b.n >= need) return COLIBRI_OK;
-    DevBuf<uint32_t> nb;
+    DevBuf<T> nb;
     int              rc;
     if ((rc = dev_alloc(c, nb, (size_t)std::max<uint64_t>(need, b.n * 2)))) return rc;
-    if (b.p && keep) HIP_TRY(c, hipMemcpyAsync(nb.p, b.p, keep * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    if (b.p && keep) HIP_TRY(c, hipMemcpyAsync(nb.p, b.p, keep * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     dev_free(b);
     b = nb;
@@ -975,13 +974,13 @@ int grow_keep(colibri_ctx* c, DevBuf<uint32_t>& b, uint64_t need, uint64_t keep)
 // append (result id, position) for every position of `ids` that carries a result id, in position order. known_total: how many there are, when the
 // caller already has that number from the device (the n-gram passes do: it is the order's `valid` count) — no read-back, no synchronisation then
 int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, uint64_t known_total = ~0ull) {
-    const uint32_t nblk = std::max<uint32_t>(1, blocks_for(pl.npos, kEmitTile));
+    const uint32_t nblk = std::max<uint32_t>(1, blocks_for(pl.npos, kPairTile));
     int            rc;
     if ((rc = dev_alloc(c, c->idx_cnt, (size_t)nblk + 2))) return rc;
     uint32_t* const cnt = c->idx_cnt.p;
     {
         Prof p(c, COLIBRI_K_INDEX);
-        hipLaunchKernelGGL(emit_count_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, ids, pl.npos, cnt);
+        hipLaunchKernelGGL(emit_count_kernel, dim3(nblk), dim3(kPairThreads), 0, c->stream, ids, pl.npos, cnt);
         hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, cnt, nblk, cnt + nblk);
     }
     uint64_t total = known_total;
@@ -993,9 +992,9 @@ int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, uint64_
     }
     if (total) {
         const uint64_t want = std::max<uint64_t>(c->npairs + total, 2ull * pl.npos);  // room for the usual model right away (n <= 5: ~1.6 pairs per position)
-        if ((rc = grow_keep(c, c->pair_id[0], want, c->npairs)) || (rc = grow_keep(c, c->pair_pos[0], want, c->npairs))) return rc;
+        if ((rc = grow_keep(c, c->pairs[0], want, c->npairs))) return rc;
         Prof p(c, COLIBRI_K_INDEX);
-        hipLaunchKernelGGL(emit_write_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, ids, pl.npos, cnt, c->npairs, c->pair_id[0].p, c->pair_pos[0].p);
+        hipLaunchKernelGGL(emit_write_kernel, dim3(nblk), dim3(kPairThreads), 0, c->stream, ids, pl.npos, cnt, c->npairs, c->pairs[0].p);
         c->npairs += total;
     }
     if (known_total == ~0ull) {
@@ -1054,28 +1053,35 @@ int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = fal
     int            rc;
     if ((rc = dev_alloc(c, c->ref_sentence, (size_t)n + 1)) || (rc = dev_alloc(c, c->ref_token, (size_t)n + 1))) return rc;
     if (!n) return COLIBRI_OK;
-    if ((rc = dev_alloc(c, c->pair_id[1], (size_t)n)) || (rc = dev_alloc(c, c->pair_pos[1], (size_t)n))) return rc;
+    if ((rc = dev_alloc(c, c->pairs[1], (size_t)n))) return rc;
     int cur = 0;
     {
-        Prof            p(c, COLIBRI_K_INDEX);
-        uint32_t* const keys[2] = {c->pair_id[0].p, c->pair_id[1].p};
-        uint32_t* const vals[2] = {c->pair_pos[0].p, c->pair_pos[1].p};
-        if ((rc = radix_sort_pairs(c, keys, vals, n, bits_for(nresults), cur))) return rc;
-        if (!c->pos_refs_valid) {
-            if ((rc = dev_alloc(c, c->pos_ref, (size_t)c->npos + 1))) return rc;
-            hipLaunchKernelGGL(position_refs_kernel, dim3(stream_grid(c->npos)), dim3(kBlock), 0, c->stream, c->delimpos.p, c->ndelim, c->npos, c->pos_ref.p);
-            c->pos_refs_valid = true;
+        Prof p(c, COLIBRI_K_INDEX);
+        // stable LSD passes over the id (high word), 8 bits each
+        const uint32_t nblocks = (uint32_t)((n + kS64Tile - 1) / kS64Tile);
+        const uint32_t nh = 256u * nblocks, nb = blocks_for(nh, kBlock * 4);
+        if ((rc = dev_alloc(c, c->sort_hist, nh)) || (rc = dev_alloc(c, c->sort_off, nh)) || (rc = dev_alloc(c, c->sort_bsum, (size_t)nb + 1))) return rc;
+        for (int shift = 0; shift < bits_for(nresults); shift += 8) {
+            hipLaunchKernelGGL(sort64_hist_kernel, dim3(nblocks), dim3(kS64Threads), 0, c->stream, c->pairs[cur].p, n, 32 + shift, nblocks, c->sort_hist.p);
+            hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->sort_hist.p, nh, c->sort_bsum.p);
+            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->sort_bsum.p, nb, c->sort_bsum.p + nb);
+            hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->sort_hist.p, nh, c->sort_bsum.p, c->sort_off.p);
+            hipLaunchKernelGGL(sort64_scatter_kernel, dim3(nblocks), dim3(kS64Threads), 0, c->stream, c->pairs[cur].p, n, 32 + shift, nblocks, c->sort_off.p, c->pairs[cur ^ 1].p);
+            cur ^= 1;
         }
-        hipLaunchKernelGGL(refs_table_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, c->stream, c->pair_pos[cur].p, n, c->pos_ref.p, c->first_sentence,
-                           c->ref_sentence.p, c->ref_token.p);
+        if (!c->pos_blocks_valid) {
+            if ((rc = dev_alloc(c, c->pos_blocks, (size_t)c->npos / 64 + 2))) return rc;
+            hipLaunchKernelGGL(position_blocks_kernel, dim3(stream_grid((uint64_t)c->npos / 16 + 1)), dim3(kBlock), 0, c->stream, c->cls.p, c->delimpos.p, c->ndelim, c->npos, c->pos_blocks.p);
+            c->pos_blocks_valid = true;
+        }
+        hipLaunchKernelGGL(refs_blocks_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, c->stream, c->pairs[cur].p, n, c->pos_blocks.p, c->first_sentence, c->ref_sentence.p, c->ref_token.p);
+        if (keep_sorted_ids) {  // sharded mode: the caller still needs the (sorted) global ids to cut the references into runs
+            if ((rc = dev_alloc(c, c->sh.sorted_gid, (size_t)n))) return rc;
+            hipLaunchKernelGGL(pair_ids_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, c->stream, c->pairs[cur].p, n, c->sh.sorted_gid.p);
+        }
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
-    if (keep_sorted_ids) {  // sharded mode: the caller still needs the (sorted) global ids to cut the references into runs
-        dev_free(c->sh.sorted_gid);
-        c->sh.sorted_gid = c->pair_id[cur];
-        c->pair_id[cur]  = DevBuf<uint32_t>{};
-    }
     return COLIBRI_OK;
 }
 

@@ -1184,31 +1184,59 @@ __global__ __launch_bounds__(kBlock) void skip_result_ids_kernel(const uint32_t*
 }
 constexpr int kEmitPer  = 4;
 constexpr int kEmitTile = kBlock * kEmitPer;
-__global__ __launch_bounds__(kBlock) void emit_count_kernel(const uint32_t* __restrict__ ids, uint32_t npos, uint32_t* __restrict__ blockcnt) {
-    const uint32_t base = blockIdx.x * kEmitTile + threadIdx.x * kEmitPer;
-    uint32_t       c    = 0;
+constexpr int kPairThreads = 1024, kPairPer = 8, kPairTile = kPairThreads * kPairPer;  // 8192 positions per block: 12.8 K block counts for 10^8 positions (one short scan)
+__device__ __forceinline__ void pair_load(const uint32_t* __restrict__ ids, uint32_t npos, uint32_t base, uint32_t (&v)[kPairPer]) {
+    if (base + kPairPer <= npos) {
+        const uint4 a = *reinterpret_cast<const uint4*>(ids + base), b = *reinterpret_cast<const uint4*>(ids + base + 4);
+        v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+    } else {
 #pragma unroll
-    for (int k = 0; k < kEmitPer; ++k) c += (base + k < npos) && ids[base + k] != kInvalid;
+        for (int k = 0; k < kPairPer; ++k) v[k] = (base + k < npos) ? ids[base + k] : kInvalid;
+    }
+}
+__device__ __forceinline__ uint32_t pair_block_scan(uint32_t c, uint32_t* total) {  // exclusive scan over the block's 1024 threads
+    __shared__ uint32_t wsum[kPairThreads / kWave];
+    const uint32_t      lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    uint32_t            inc = c;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d);
+        if ((int)lane >= d) inc += t;
+    }
+    if (lane == kWave - 1) wsum[w] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int q = 0; q < kPairThreads / kWave; ++q) {
+        const uint32_t t = wsum[q];
+        before += (uint32_t)q < w ? t : 0u;
+        all += t;
+    }
+    *total = all;
+    return before + inc - c;
+}
+__global__ __launch_bounds__(kPairThreads) void emit_count_kernel(const uint32_t* __restrict__ ids, uint32_t npos, uint32_t* __restrict__ blockcnt) {
+    uint32_t v[kPairPer], c = 0;
+    pair_load(ids, npos, blockIdx.x * kPairTile + threadIdx.x * kPairPer, v);
+#pragma unroll
+    for (int k = 0; k < kPairPer; ++k) c += v[k] != kInvalid;
     uint32_t total;
-    block_exclusive_scan(c, &total);
+    pair_block_scan(c, &total);
     if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
 }
-__global__ __launch_bounds__(kBlock) void emit_write_kernel(const uint32_t* __restrict__ ids, uint32_t npos, const uint32_t* __restrict__ blockoff, uint64_t out_base,
-                                                             uint32_t* __restrict__ pair_id, uint32_t* __restrict__ pair_pos) {
-    const uint32_t base = blockIdx.x * kEmitTile + threadIdx.x * kEmitPer;
-    uint32_t       v[kEmitPer], c = 0;
+__global__ __launch_bounds__(kPairThreads) void emit_write_kernel(const uint32_t* __restrict__ ids, uint32_t npos, const uint32_t* __restrict__ blockoff, uint64_t out_base,
+                                                                   unsigned long long* __restrict__ pairs /* result id << 32 | position */) {
+    const uint32_t base = blockIdx.x * kPairTile + threadIdx.x * kPairPer;
+    uint32_t       v[kPairPer], c = 0;
+    pair_load(ids, npos, base, v);
 #pragma unroll
-    for (int k = 0; k < kEmitPer; ++k) {
-        v[k] = (base + k < npos) ? ids[base + k] : kInvalid;
-        c += v[k] != kInvalid;
-    }
+    for (int k = 0; k < kPairPer; ++k) c += v[k] != kInvalid;
     uint32_t total;
-    uint64_t o = out_base + blockoff[blockIdx.x] + block_exclusive_scan(c, &total);
+    uint64_t o = out_base + blockoff[blockIdx.x] + pair_block_scan(c, &total);
 #pragma unroll
-    for (int k = 0; k < kEmitPer; ++k) {
+    for (int k = 0; k < kPairPer; ++k) {
         if (v[k] != kInvalid) {
-            pair_id[o]  = v[k];
-            pair_pos[o] = base + k;
+            pairs[o] = ((unsigned long long)v[k] << 32) | (base + k);
             ++o;
         }
     }
@@ -1269,6 +1297,107 @@ __global__ __launch_bounds__(kBlock) void sort_scatter_kernel(const uint32_t* __
     }
 }
 
+// ---- stable LSD radix sort of packed 64-bit (result id << 32 | position) pairs by 8 bits of the id per pass ----
+// The forward index groups 1.6 x 10^8 pairs by pattern with positions ascending: three stable passes over the id. sort_scatter_kernel above writes every
+// element to its own address (two 4-byte arrays: 3 x 10^8 uncoalesced stores per pass, 4.7 ms); here a 4096-element tile is ranked stably — lanes of a
+// wave with the same digit by ballots, waves and rows by an LDS table of their digit counts —, staged in LDS in output order and written as one
+// coalesced run per digit.
+constexpr int kS64Threads = 1024, kS64Per = 4, kS64Tile = kS64Threads * kS64Per, kS64Groups = kS64Per * (kS64Threads / kWave);  // 64 (row, wave) groups per tile
+__global__ __launch_bounds__(kS64Threads) void sort64_hist_kernel(const unsigned long long* __restrict__ in, uint64_t n, int shift, uint32_t nblocks, uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t h[256];
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t     t0 = (uint64_t)blockIdx.x * kS64Tile;
+    unsigned long long x[kS64Per];
+#pragma unroll
+    for (int r = 0; r < kS64Per; ++r) {
+        const uint64_t i = t0 + (uint64_t)r * kS64Threads + threadIdx.x;
+        x[r]             = i < n ? in[i] : 0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < kS64Per; ++r)
+        if (t0 + (uint64_t)r * kS64Threads + threadIdx.x < n) atomicAdd(&h[(uint32_t)(x[r] >> shift) & 255u], 1u);
+    __syncthreads();
+    if (threadIdx.x < 256) ghist[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];  // digit-major so that one scan yields global offsets
+}
+__global__ __launch_bounds__(kS64Threads, kS64Threads / 128) void sort64_scatter_kernel(const unsigned long long* __restrict__ in, uint64_t n, int shift, uint32_t nblocks,
+                                                                                         const unsigned long long* __restrict__ goff, unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long stgL[kS64Tile];
+    __shared__ uint16_t           gcntL[kS64Groups][256];  // elements of digit d in group (row, wave); then: elements of digit d in the groups before it
+    __shared__ uint32_t           histL[256], offL[256], wsumL[4];
+    __shared__ unsigned long long gbaseL[256];
+    for (uint32_t k = threadIdx.x; k < (uint32_t)(kS64Groups * 256 / 2); k += kS64Threads) reinterpret_cast<uint32_t*>(&gcntL[0][0])[k] = 0;
+    if (threadIdx.x < 256) gbaseL[threadIdx.x] = goff[(uint64_t)threadIdx.x * nblocks + blockIdx.x];
+    const uint32_t     lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint64_t     t0   = (uint64_t)blockIdx.x * kS64Tile;
+    unsigned long long x[kS64Per];
+    uint32_t           rank[kS64Per];
+#pragma unroll
+    for (int r = 0; r < kS64Per; ++r) {
+        const uint64_t i = t0 + (uint64_t)r * kS64Threads + threadIdx.x;
+        x[r]             = i < n ? in[i] : ~0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kS64Per; ++r) {
+        const bool     valid = t0 + (uint64_t)r * kS64Threads + threadIdx.x < n;
+        const uint32_t d     = (uint32_t)(x[r] >> shift) & 255u;
+        uint64_t       peers = __ballot(valid);  // lanes of this wave with the same digit, in lane order (stable)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        rank[r] = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        if (valid && rank[r] == 0) gcntL[r * (kS64Threads / kWave) + wave][d] = (uint16_t)__popcll(peers);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {  // digit t: counts of the 64 groups -> exclusive prefixes, in element order (row-major, then wave)
+        uint32_t run = 0;
+#pragma unroll 8
+        for (int g = 0; g < kS64Groups; ++g) {
+            const uint32_t c      = gcntL[g][threadIdx.x];
+            gcntL[g][threadIdx.x] = (uint16_t)run;
+            run += c;
+        }
+        histL[threadIdx.x] = run;
+    }
+    __syncthreads();
+    {  // exclusive scan of the 256 digit totals (first four waves)
+        uint32_t v = 0, incl = 0;
+        if (threadIdx.x < 256) {
+            v    = histL[threadIdx.x];
+            incl = v;
+            for (int off = 1; off < kWave; off <<= 1) {
+                const uint32_t t = __shfl_up(incl, off, kWave);
+                if ((int)lane >= off) incl += t;
+            }
+            if (lane == kWave - 1) wsumL[wave] = incl;
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) offL[threadIdx.x] = (wave > 0 ? wsumL[0] : 0u) + (wave > 1 ? wsumL[1] : 0u) + (wave > 2 ? wsumL[2] : 0u) + incl - v;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < kS64Per; ++r) {
+        if (t0 + (uint64_t)r * kS64Threads + threadIdx.x < n) {
+            const uint32_t d = (uint32_t)(x[r] >> shift) & 255u;
+            stgL[offL[d] + gcntL[r * (kS64Threads / kWave) + wave][d] + rank[r]] = x[r];
+        }
+    }
+    __syncthreads();
+    const uint32_t cnt = (uint32_t)min((uint64_t)kS64Tile, n - t0);
+    for (uint32_t j = threadIdx.x; j < cnt; j += kS64Threads) {
+        const unsigned long long y = stgL[j];
+        const uint32_t           d = (uint32_t)(y >> shift) & 255u;
+        out[gbaseL[d] + (j - offL[d])] = y;
+    }
+}
+// the ids (high words) of sorted pairs, as their own array (the sharded index cuts the references into runs by global id)
+__global__ __launch_bounds__(kBlock) void pair_ids_kernel(const unsigned long long* __restrict__ pairs, uint64_t n, uint32_t* __restrict__ ids) {
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (uint64_t)gridDim.x * kBlock) ids[j] = (uint32_t)(pairs[j] >> 32);
+}
+
 // position -> (sentence, token): sentence = first_sentence + #delimiters before the position (empty sentences are numbered,
 // reference src/pattern.cpp:1947-1958); token = offset inside the sentence, truncated to u16 like IndexReference (datatypes.h:36)
 __global__ __launch_bounds__(kBlock) void refs_kernel(const uint32_t* __restrict__ pos, uint64_t n, const uint32_t* __restrict__ delimpos, uint32_t ndelim, uint32_t first_sentence,
@@ -1289,41 +1418,57 @@ __global__ __launch_bounds__(kBlock) void refs_kernel(const uint32_t* __restrict
     }
 }
 
-// the same through a per-position table (sentence ordinal, token offset): built once per corpus — it is the sentence index the reference's
-// IndexedCorpus keeps (pattern.cpp:1942-1958) — so that a model's 10^8 references cost two gathers each instead of a binary search each
-__global__ __launch_bounds__(kBlock) void position_refs_kernel(const uint32_t* __restrict__ delimpos, uint32_t ndelim, uint32_t npos, uint2* __restrict__ pos_ref) {
-    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < npos; p += gridDim.x * kBlock) {
-        uint32_t lo = 0, hi = ndelim;  // first delimiter position >= p
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (delimpos[mid] < p)
-                lo = mid + 1;
-            else
-                hi = mid;
+// the same with a table 30 x smaller (16 bytes per 64 positions instead of 8 bytes per position): { sentences that end before the block, position where
+// the sentence running at the block's first position starts, one bit per position of the block that is a delimiter }. A model's 1.6 x 10^8 references
+// are sorted by pattern, i.e. their positions are random: gathers from the 0.8 GB per-position table went to HBM (3.5 ms), the 26 MB one stays in cache.
+struct __attribute__((aligned(16))) PosBlock {
+    uint32_t           sent_before, sent_start;
+    unsigned long long delim;
+};
+__global__ __launch_bounds__(kBlock) void position_blocks_kernel(const uint32_t* __restrict__ cls, const uint32_t* __restrict__ delimpos, uint32_t ndelim, uint32_t npos,
+                                                                  PosBlock* __restrict__ blocks) {
+    const uint32_t nblk = (npos + 63) / 64, lane = threadIdx.x & (kWave - 1);
+    for (uint32_t b = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; b < nblk; b += gridDim.x * (kBlock / kWave)) {
+        const uint32_t p = b * 64 + lane;
+        const uint64_t m = __ballot(p < npos && cls[p] == 0u);
+        if (lane == 0) {
+            uint32_t lo = 0, hi = ndelim;  // delimiters before the block's first position
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (delimpos[mid] < b * 64)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            PosBlock x;
+            x.sent_before = lo;
+            x.sent_start  = lo ? delimpos[lo - 1] + 1 : 0u;
+            x.delim       = m;
+            blocks[b]     = x;
         }
-        const uint32_t begin = lo ? delimpos[lo - 1] + 1 : 0;
-        pos_ref[p]           = make_uint2(lo, p - begin);  // (sentence ordinal, token offset): one 8-byte gather per reference later
     }
 }
-__global__ __launch_bounds__(kBlock) void refs_table_kernel(const uint32_t* __restrict__ pos, uint64_t n, const uint2* __restrict__ pos_ref, uint32_t first_sentence,
-                                                             uint32_t* __restrict__ ref_sentence, uint16_t* __restrict__ ref_token) {
+__global__ __launch_bounds__(kBlock) void refs_blocks_kernel(const unsigned long long* __restrict__ pairs /* position in the low word */, uint64_t n, const PosBlock* __restrict__ blocks,
+                                                              uint32_t first_sentence, uint32_t* __restrict__ ref_sentence, uint16_t* __restrict__ ref_token) {
     constexpr int kPer = 4;  // gathers in flight per lane
     for (uint64_t j0 = (uint64_t)blockIdx.x * kBlock * kPer; j0 < n; j0 += (uint64_t)gridDim.x * kBlock * kPer) {
         uint32_t p[kPer];
-        uint2    r[kPer];
+        uint4    r[kPer];
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
             const uint64_t j = j0 + (uint64_t)q * kBlock + threadIdx.x;
-            p[q]             = j < n ? pos[j] : 0u;
+            p[q]             = j < n ? (uint32_t)pairs[j] : 0u;
         }
 #pragma unroll
-        for (int q = 0; q < kPer; ++q) r[q] = pos_ref[p[q]];
+        for (int q = 0; q < kPer; ++q) r[q] = *reinterpret_cast<const uint4*>(blocks + (p[q] >> 6));
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
             const uint64_t j = j0 + (uint64_t)q * kBlock + threadIdx.x;
             if (j < n) {
-                ref_sentence[j] = first_sentence + r[q].x;
-                ref_token[j]    = (uint16_t)r[q].y;
+                const uint32_t bit   = p[q] & 63u;
+                const uint64_t below = (((uint64_t)r[q].w << 32) | r[q].z) & ((1ull << bit) - 1ull);  // delimiters of the block before this position
+                ref_sentence[j]      = first_sentence + r[q].x + (uint32_t)__popcll(below);
+                ref_token[j]         = (uint16_t)(below ? bit - (64u - (uint32_t)__clzll(below)) : p[q] - r[q].y);
             }
         }
     }

@@ -675,10 +675,10 @@ BinnedIO binned_planes(colibri_ctx* c, const TrainPlan& pl, bool with_keys) {
 
 template <class KeyFn>
 int binned_count_stage(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, int n, bool use_list, uint32_t thr, bool with_keys, bool need_ids = true, bool flag_mode = false,
-                       bool dense_code = false, uint32_t sbits = 0, uint32_t slice = 0) {
+                       bool dense_code = false, uint32_t sbits = 0, uint32_t slice = 0, const uint32_t* list_other = nullptr, const uint32_t* nlist_other = nullptr) {
     const uint32_t  tiles    = blocks_for(pl.npos, kScatTile) + 1 + kASlots;  // level-B tiles: every slot may end in a partial one
-    const uint32_t* list_in  = c->alist[n & 1].p;
-    const uint32_t* nlist_in = c->alist_n.p + (n & 1);
+    const uint32_t* list_in  = list_other ? list_other : c->alist[n & 1].p;  // list_other: a list of the caller's (the skipgram passes walk c->sklist)
+    const uint32_t* nlist_in = list_other ? nlist_other : c->alist_n.p + (n & 1);
     HIP_TRY(c, hipMemsetAsync(c->binstate.p, 0, sizeof(BinState), c->stream));
     uint32_t* const ids_at   = (need_ids && !flag_mode) ? c->ids_at.p : nullptr;  // reset by the emit kernel at every record position; not needed when nobody resolves ids
     uint8_t* const  flags_at = (need_ids && flag_mode) ? c->flags_at.p : nullptr;  // flag mode: a survivor byte instead of a survivor id
@@ -709,12 +709,12 @@ int binned_count_stage(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, int
 }
 
 int binned_resolve_stage(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids_out, int n, bool use_list, bool build_list, const uint32_t* remap, uint32_t remap_base,
-                         bool prefill_ids = true, bool decode = false, uint32_t decode_base = 0) {
-    const uint32_t* list_in   = c->alist[n & 1].p;
-    const uint32_t* nlist_in  = c->alist_n.p + (n & 1);
+                         bool prefill_ids = true, bool decode = false, uint32_t decode_base = 0, const uint32_t* list_other = nullptr, const uint32_t* nlist_other = nullptr) {
+    const uint32_t* list_in   = list_other ? list_other : c->alist[n & 1].p;
+    const uint32_t* nlist_in  = list_other ? nlist_other : c->alist_n.p + (n & 1);
     uint32_t*       list_out  = build_list ? c->alist[(n + 1) & 1].p : nullptr;
     uint32_t*       nlist_out = c->alist_n.p + ((n + 1) & 1);
-    HIP_TRY(c, hipMemsetAsync(nlist_out, 0, sizeof(uint32_t), c->stream));
+    if (build_list || !list_other) HIP_TRY(c, hipMemsetAsync(nlist_out, 0, sizeof(uint32_t), c->stream));
     if (use_list && prefill_ids) HIP_TRY(c, hipMemsetAsync(ids_out, 0xFF, sizeof(uint32_t) * (size_t)pl.npos, c->stream));
     Prof p(c, COLIBRI_K_RESOLVE);
     if (use_list)
@@ -929,6 +929,46 @@ int skipgram_pass(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, con
     *found_out = c->hstate.found;
     *kept_out  = c->hstate.kept;
     if (final_scratch) *final_scratch = (int)((parts.size() - 1) & 1);
+    return COLIBRI_OK;
+}
+
+// The same pass on the radix path (emit -> level B -> per-bin LDS count -> resolve, over c->sklist): no global atomics. A level that is not the last
+// interns every pair (threshold 1) and hands dense ids to the next one; the last level appends its survivors to the results and, when `ids_out` is
+// given (indexed models), leaves every window's RESULT index there. kRerunOnTable: a bin outgrew its LDS table (the caller re-runs on the global table).
+constexpr int kRerunOnTable = 1000;
+int skipgram_pass_radix(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, const uint32_t* gate, const uint32_t* gate2, uint32_t thr, uint32_t res_total, uint32_t* found_out,
+                        uint32_t* kept_out, uint32_t** ids_out) {
+    const std::vector<std::pair<int, int>> parts = mask_parts(mask, n);
+    const uint32_t* left = c->ids[parts[0].second].p;
+    uint32_t        offl = (uint32_t)parts[0].first;
+    int             rc;
+    for (size_t j = 1; j < parts.size(); ++j) {
+        const bool last     = j + 1 == parts.size();
+        const bool need_ids = !last || ids_out != nullptr;
+        c->hstate.found = c->hstate.kept = c->hstate.admitted = c->hstate.valid = 0;
+        c->hstate.radix_overflow = 0;
+        if ((rc = write_state(c))) return rc;
+        uint32_t* const out = c->scratch[j & 1].p;
+        KeyPair fn{gate, gate2, left, offl, c->ids[parts[j].second].p, (uint32_t)parts[j].first};
+        if ((rc = binned_count_stage(c, pl, fn, n, true, last ? thr : 1u, false, need_ids, false, /*dense_code=*/true, 0, 0, c->sklist.p, c->sklist_n.p))) return rc;
+        const BinnedIO io = binned_planes(c, pl, false);
+        {
+            Prof p(c, COLIBRI_K_PRUNE);
+            hipLaunchKernelGGL(bin_kept_scan_kernel, dim3(kBins), dim3(kBlock), 0, c->stream, c->state.p, c->binstate.p, last ? pl.res_cap : 0xFFFFFFFFu);
+            if (last)
+                hipLaunchKernelGGL(compact_bins_kernel, dim3(1024), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, c->binstate.p, c->res_rep.p, c->res_cnt.p, pl.res_cap,
+                                   (const uint32_t*)c->sklist.p);
+            hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
+        }
+        if (need_ids && (rc = binned_resolve_stage(c, pl, out, n, true, false, nullptr, 0u, /*prefill_ids=*/true, /*decode=*/true, last ? res_total : 0u, c->sklist.p, c->sklist_n.p))) return rc;
+        if (last && ids_out) *ids_out = out;
+        left = out;
+        offl = 0;
+    }
+    if ((rc = read_state(c))) return rc;
+    if (c->hstate.radix_overflow) return kRerunOnTable;
+    *found_out = c->hstate.found;
+    *kept_out  = c->hstate.kept;
     return COLIBRI_OK;
 }
 
@@ -1595,7 +1635,16 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                 if ((rc = build_skip_list(c, pl, c->ids[n - 1].p))) return rc;
                 for (uint32_t mask : gap_masks(n, o.maxskips)) {
                     uint32_t f = 0, k = 0;
-                    if ((rc = skipgram_pass(c, pl, n, mask, c->ids[n - 1].p, c->ids[n - 1].p, adm_n[n], thr_skip, false, 0, &f, &k, nullptr))) return rc;
+                    if (radix_synced)
+                        rc = skipgram_pass_radix(c, pl, n, mask, c->ids[n - 1].p, c->ids[n - 1].p, thr_skip, res_total, &f, &k, nullptr);
+                    else
+                        rc = skipgram_pass(c, pl, n, mask, c->ids[n - 1].p, c->ids[n - 1].p, adm_n[n], thr_skip, false, 0, &f, &k, nullptr);
+                    if (rc == kRerunOnTable) {
+                        colibri_options again = o;
+                        again.table_mode      = 1;
+                        return colibri_train_once(c, &again, stats_out);
+                    }
+                    if (rc) return rc;
                     s.found[n] += f;
                     s.kept[n] += k;
                     if (k) c->segments.push_back({res_total, k, n, mask});
@@ -1617,10 +1666,22 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                 for (uint32_t mask : gap_masks(n, o.maxskips)) {
                     uint32_t f = 0, k = 0;
                     int fs = 0;
-                    if ((rc = skipgram_pass(c, pl, n, mask, c->ids[n].p, nullptr, valid_n[n], pl.thr, true, o.minskiptypes > 1 ? (uint32_t)o.minskiptypes : 0u, &f, &k, &fs))) return rc;
-                    if (k) {  // occurrences of the kept skipgrams of this pass -> forward index
-                        hipLaunchKernelGGL(skip_result_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->scratch[fs].p, c->table.p, c->scratch[fs ^ 1].p, npos);
-                        if ((rc = emit_pairs(c, pl, c->scratch[fs ^ 1].p))) return rc;
+                    if (radix_synced && o.minskiptypes <= 1) {  // (a minimum number of distinct fillers needs the per-slot source counts of the table pass)
+                        uint32_t* ids = nullptr;
+                        rc = skipgram_pass_radix(c, pl, n, mask, c->ids[n].p, nullptr, pl.thr, res_total, &f, &k, &ids);
+                        if (rc == kRerunOnTable) {
+                            colibri_options again = o;
+                            again.table_mode      = 1;
+                            return colibri_train_once(c, &again, stats_out);
+                        }
+                        if (rc) return rc;
+                        if (k && (rc = emit_pairs(c, pl, ids, c->hstate.valid))) return rc;  // occurrences of the kept skipgrams of this pass -> forward index
+                    } else {
+                        if ((rc = skipgram_pass(c, pl, n, mask, c->ids[n].p, nullptr, valid_n[n], pl.thr, true, o.minskiptypes > 1 ? (uint32_t)o.minskiptypes : 0u, &f, &k, &fs))) return rc;
+                        if (k) {  // occurrences of the kept skipgrams of this pass -> forward index
+                            hipLaunchKernelGGL(skip_result_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->scratch[fs].p, c->table.p, c->scratch[fs ^ 1].p, npos);
+                            if ((rc = emit_pairs(c, pl, c->scratch[fs ^ 1].p))) return rc;
+                        }
                     }
                     found_n += f;
                     s.found[n] += f;

@@ -73,6 +73,10 @@ struct colibri_ctx {
     std::vector<DevBuf<uint32_t>> ids;  // plain mode: 2 ping-pong buffers; skipgram / indexed modes: one per order
     DevBuf<uint32_t>  scratch[2];       // per-position slot arrays of the skipgram passes
     DevBuf<uint32_t>  nsrc;             // per-slot distinct-source counter (indexed skipgrams)
+    const uint32_t*   skl = nullptr;    // the list the skipgram passes of the current order walk (c->sklist, or the order's own active list), and its length
+    const uint32_t*   skl_n = nullptr;
+    DevBuf<uint32_t>  skip_tmp;         // radix skipgram passes: the survivors of the distinct-fillers filter on their way back into the results
+    DevBuf<unsigned long long> skip_off;
     DevBuf<unsigned long long> pairs[2];        // forward index: (result id << 32 | position) pairs, ping-pong for the radix sort (kept between runs: a release and a
                                                 // new reservation of these GB-sized buffers per train() cost more than the kernels)
     DevBuf<uint32_t>  idx_cnt, sort_hist;       // ... per-block pair counts of a pass; per-block digit histograms of a sort pass
@@ -462,6 +466,8 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->scratch[0]);
     dev_free(c->scratch[1]);
     dev_free(c->nsrc);
+    dev_free(c->skip_tmp);
+    dev_free(c->skip_off);
     dev_free(c->recs[0]);
     dev_free(c->recs[1]);
     dev_free(c->rep_of);
@@ -893,6 +899,8 @@ int build_skip_list(colibri_ctx* c, const TrainPlan& pl, const uint32_t* gate) {
     HIP_TRY(c, hipMemsetAsync(c->sklist_n.p, 0, sizeof(uint32_t), c->stream));
     Prof p(c, COLIBRI_K_SKIPGRAM);
     hipLaunchKernelGGL(list_from_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, gate, pl.npos, c->sklist.p, c->sklist_n.p);
+    c->skl   = c->sklist.p;
+    c->skl_n = c->sklist_n.p;
     return COLIBRI_OK;
 }
 
@@ -913,7 +921,7 @@ int skipgram_pass(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, con
         out = c->scratch[j & 1].p;
         HIP_TRY(c, hipMemsetAsync(out, 0xFF, sizeof(uint32_t) * (size_t)pl.npos, c->stream));  // only the listed positions are written
         KeyPair fn{gate, gate2, left, offl, c->ids[parts[j].second].p, (uint32_t)parts[j].first};
-        launch_count(c, pl, fn, out, last ? 2 : 0, COLIBRI_K_SKIPGRAM, c->sklist.p, c->sklist_n.p);
+        launch_count(c, pl, fn, out, last ? 2 : 0, COLIBRI_K_SKIPGRAM, c->skl, c->skl_n);
         left = out;
         offl = 0;
     }
@@ -936,8 +944,11 @@ int skipgram_pass(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, con
 // interns every pair (threshold 1) and hands dense ids to the next one; the last level appends its survivors to the results and, when `ids_out` is
 // given (indexed models), leaves every window's RESULT index there. kRerunOnTable: a bin outgrew its LDS table (the caller re-runs on the global table).
 constexpr int kRerunOnTable = 1000;
+int scan_u32(colibri_ctx* c, const uint32_t* in, uint32_t n, unsigned long long* out, unsigned long long* total);
+// minsrc > 0 (indexed models, MINSKIPTYPES): a skipgram also needs that many distinct fillers = distinct surviving n-grams [src_first, src_first + src_count) of the
+// results; *valid_out = the positions left with a result index (~0: not known without a read-back)
 int skipgram_pass_radix(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, const uint32_t* gate, const uint32_t* gate2, uint32_t thr, uint32_t res_total, uint32_t* found_out,
-                        uint32_t* kept_out, uint32_t** ids_out) {
+                        uint32_t* kept_out, uint32_t** ids_out, uint32_t minsrc = 0, uint32_t src_first = 0, uint32_t src_count = 0, uint64_t* valid_out = nullptr) {
     const std::vector<std::pair<int, int>> parts = mask_parts(mask, n);
     const uint32_t* left = c->ids[parts[0].second].p;
     uint32_t        offl = (uint32_t)parts[0].first;
@@ -950,17 +961,17 @@ int skipgram_pass_radix(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mas
         if ((rc = write_state(c))) return rc;
         uint32_t* const out = c->scratch[j & 1].p;
         KeyPair fn{gate, gate2, left, offl, c->ids[parts[j].second].p, (uint32_t)parts[j].first};
-        if ((rc = binned_count_stage(c, pl, fn, n, true, last ? thr : 1u, false, need_ids, false, /*dense_code=*/true, 0, 0, c->sklist.p, c->sklist_n.p))) return rc;
+        if ((rc = binned_count_stage(c, pl, fn, n, true, last ? thr : 1u, false, need_ids, false, /*dense_code=*/true, 0, 0, c->skl, c->skl_n))) return rc;
         const BinnedIO io = binned_planes(c, pl, false);
         {
             Prof p(c, COLIBRI_K_PRUNE);
             hipLaunchKernelGGL(bin_kept_scan_kernel, dim3(kBins), dim3(kBlock), 0, c->stream, c->state.p, c->binstate.p, last ? pl.res_cap : 0xFFFFFFFFu);
             if (last)
                 hipLaunchKernelGGL(compact_bins_kernel, dim3(1024), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, c->binstate.p, c->res_rep.p, c->res_cnt.p, pl.res_cap,
-                                   (const uint32_t*)c->sklist.p);
+                                   (const uint32_t*)c->skl);
             hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
         }
-        if (need_ids && (rc = binned_resolve_stage(c, pl, out, n, true, false, nullptr, 0u, /*prefill_ids=*/true, /*decode=*/true, last ? res_total : 0u, c->sklist.p, c->sklist_n.p))) return rc;
+        if (need_ids && (rc = binned_resolve_stage(c, pl, out, n, true, false, nullptr, 0u, /*prefill_ids=*/true, /*decode=*/true, last ? res_total : 0u, c->skl, c->skl_n))) return rc;
         if (last && ids_out) *ids_out = out;
         left = out;
         offl = 0;
@@ -969,6 +980,30 @@ int skipgram_pass_radix(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mas
     if (c->hstate.radix_overflow) return kRerunOnTable;
     *found_out = c->hstate.found;
     *kept_out  = c->hstate.kept;
+    if (valid_out) *valid_out = c->hstate.valid;
+    const uint32_t k1 = c->hstate.kept;
+    if (minsrc > 1 && k1 && ids_out) {
+        uint32_t* const ids = *ids_out;
+        if ((rc = dev_alloc(c, c->nsrc, (size_t)k1 + 1)) || (rc = dev_alloc(c, c->skip_off, (size_t)k1 + 1)) || (rc = dev_alloc(c, c->skip_tmp, 2 * (size_t)k1 + 2))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->nsrc.p, 0, sizeof(uint32_t) * k1, c->stream));
+        unsigned long long k2 = 0;
+        {
+            Prof p(c, COLIBRI_K_SKIPGRAM);
+            if (src_count)
+                hipLaunchKernelGGL(skip_sources_results_kernel, dim3(stream_grid(src_count)), dim3(kBlock), 0, c->stream, c->res_rep.p, src_first, src_count, ids, res_total, c->nsrc.p);
+            hipLaunchKernelGGL(skip_keep_flags_kernel, dim3(stream_grid(k1)), dim3(kBlock), 0, c->stream, c->nsrc.p, k1, minsrc);
+        }
+        if ((rc = scan_u32(c, c->nsrc.p, k1, c->skip_off.p, &k2))) return rc;
+        if (k2 != k1) {
+            Prof p(c, COLIBRI_K_SKIPGRAM);
+            hipLaunchKernelGGL(skip_filter_gather_kernel, dim3(stream_grid(k1)), dim3(kBlock), 0, c->stream, c->nsrc.p, c->skip_off.p, k1, c->res_rep.p, c->res_cnt.p, res_total, c->skip_tmp.p);
+            if (k2) hipLaunchKernelGGL(skip_filter_store_kernel, dim3(stream_grid(k2)), dim3(kBlock), 0, c->stream, c->skip_tmp.p, k1, (uint32_t)k2, c->res_rep.p, c->res_cnt.p, res_total);
+            hipLaunchKernelGGL(skip_remap_ids_kernel, dim3(stream_grid(pl.npos / 4 + 1)), dim3(kBlock), 0, c->stream, c->skl, c->skl_n, ids, c->nsrc.p, c->skip_off.p, res_total);
+            if (valid_out) *valid_out = ~0ull;
+        }
+        *kept_out     = (uint32_t)k2;
+        c->hstate.kept = (uint32_t)k2;
+    }
     return COLIBRI_OK;
 }
 
@@ -1449,7 +1484,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
         if ((int)c->ids.size() < maxlength + 2) c->ids.resize(maxlength + 2);
         bool       list_valid = false;  // the active list of the previous radix pass exists
         const bool uni_synced = !constrained && o.table_mode == 0 && !(c->flags & kFlagNonCanonical) && c->maxclass < (1u << 28);
-        std::vector<uint32_t> valid_n(maxlength + 2, 0), adm_n(maxlength + 2, 0);
+        std::vector<uint32_t> valid_n(maxlength + 2, 0), adm_n(maxlength + 2, 0), ngram_first(maxlength + 2, 0), ngram_kept(maxlength + 2, 0);
         uint32_t              res_total = 0;
         const uint32_t        thr_skip  = o.minskiptypes > 1 ? (uint32_t)o.mintokens_skipgrams : pl.thr;  // base pruneskipgrams is a no-op when MINSKIPTYPES <= 1 (patternmodel.h:2167-2186)
         if (constrained) {
@@ -1479,6 +1514,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
         bool bo_runs_valid = false;
         for (int n = constrained ? std::max(1, o.minlength) : 1; n <= maxlength && !c->hstate.done; ++n) {
             if ((rc = dev_alloc(c, c->ids[n], (size_t)npos + 1))) return rc;
+            bool       listed_order = false;  // this order walked the active list (alist[n & 1])
             const bool radix_pass = (radix_constrained || (radix_synced && n >= 2)) && !(backoff && n > backoff + 1);
             if (constrained && n > probed_to) {  // which pattern of the constraint set is the window at each position, for the next lengths
                 probed_from = n;
@@ -1583,6 +1619,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                 // into result indices (= the ids the skipgram passes and the forward index work with); from order 3 on only the active list is walked
                 // (a constrained pass has no look-back, hence no list: every position is asked whether its window is a member)
                 const bool use_list = !constrained && n >= 3 && list_valid;
+                listed_order        = use_list;
                 c->hstate.radix_overflow = 0;
                 if ((rc = write_state(c))) return rc;
                 if (constrained)
@@ -1625,6 +1662,8 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             s.found[n] = found;
             s.kept[n]  = kept;
             if (kept) c->segments.push_back({res_total, kept, n, (n == 1 && uni_synced) ? kMaskFromClass : 0u});
+            ngram_first[n] = res_total;
+            ngram_kept[n]  = kept;
             res_total += kept;
             c->hstate.res_total = res_total;
             if (o.indexed && kept && (rc = emit_pairs(c, pl, c->ids[n].p, valid_n[n]))) return rc;  // occurrences of the surviving n-grams (as many as positions with an id)
@@ -1632,7 +1671,11 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             if (n == 1 && wthr > pl.thr) hipLaunchKernelGGL(ids_min_count_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->ids[n].p, c->res_cnt.p, wthr, npos);
             if (o.doskipgrams_exhaustive && n >= 3) {  // patternmodel.h:1163-1171 -> computeskipgrams :1370-1527, for every admissible window
                 if (n > 13) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 13 tokens are not on the accelerated path (set MAXLENGTH)");
-                if ((rc = build_skip_list(c, pl, c->ids[n - 1].p))) return rc;
+                if (radix_synced && listed_order) {  // the order's own active list IS the list of positions whose (n-1)-gram survived
+                    c->skl   = c->alist[n & 1].p;
+                    c->skl_n = c->alist_n.p + (n & 1);
+                } else if ((rc = build_skip_list(c, pl, c->ids[n - 1].p)))
+                    return rc;
                 for (uint32_t mask : gap_masks(n, o.maxskips)) {
                     uint32_t f = 0, k = 0;
                     if (radix_synced)
@@ -1666,16 +1709,18 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                 for (uint32_t mask : gap_masks(n, o.maxskips)) {
                     uint32_t f = 0, k = 0;
                     int fs = 0;
-                    if (radix_synced && o.minskiptypes <= 1) {  // (a minimum number of distinct fillers needs the per-slot source counts of the table pass)
+                    if (radix_synced) {
                         uint32_t* ids = nullptr;
-                        rc = skipgram_pass_radix(c, pl, n, mask, c->ids[n].p, nullptr, pl.thr, res_total, &f, &k, &ids);
+                        uint64_t  nvalid = ~0ull;
+                        rc = skipgram_pass_radix(c, pl, n, mask, c->ids[n].p, nullptr, pl.thr, res_total, &f, &k, &ids, o.minskiptypes > 1 ? (uint32_t)o.minskiptypes : 0u, ngram_first[n],
+                                                 ngram_kept[n], &nvalid);
                         if (rc == kRerunOnTable) {
                             colibri_options again = o;
                             again.table_mode      = 1;
                             return colibri_train_once(c, &again, stats_out);
                         }
                         if (rc) return rc;
-                        if (k && (rc = emit_pairs(c, pl, ids, c->hstate.valid))) return rc;  // occurrences of the kept skipgrams of this pass -> forward index
+                        if (k && (rc = emit_pairs(c, pl, ids, nvalid))) return rc;  // occurrences of the kept skipgrams of this pass -> forward index
                     } else {
                         if ((rc = skipgram_pass(c, pl, n, mask, c->ids[n].p, nullptr, valid_n[n], pl.thr, true, o.minskiptypes > 1 ? (uint32_t)o.minskiptypes : 0u, &f, &k, &fs))) return rc;
                         if (k) {  // occurrences of the kept skipgrams of this pass -> forward index

@@ -515,6 +515,43 @@ __global__ __launch_bounds__(kBlock) void skip_sources_kernel(const uint32_t* __
     }
 }
 
+// the same on the radix path, where a finished pass has left the RESULT index of every window's skipgram in skip_id: one item per surviving n-gram
+// of the order (results [first, first + count)); its representative position names the skipgram it fills. Then the skipgrams with too few distinct
+// fillers leave the results again (flags -> scan -> gather / store) and the per-position indices follow (remap).
+__global__ __launch_bounds__(kBlock) void skip_sources_results_kernel(const uint32_t* __restrict__ res_rep, uint32_t first, uint32_t count, const uint32_t* __restrict__ skip_id,
+                                                                       uint32_t base, uint32_t* __restrict__ nsrc) {
+    for (uint32_t r = blockIdx.x * kBlock + threadIdx.x; r < count; r += gridDim.x * kBlock) {
+        const uint32_t s = skip_id[res_rep[first + r]];
+        if (s != kInvalid) atomicAdd(&nsrc[s - base], 1u);
+    }
+}
+__global__ __launch_bounds__(kBlock) void skip_keep_flags_kernel(uint32_t* __restrict__ nsrc, uint32_t n, uint32_t minsrc) {
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) nsrc[j] = nsrc[j] >= minsrc ? 1u : 0u;
+}
+__global__ __launch_bounds__(kBlock) void skip_filter_gather_kernel(const uint32_t* __restrict__ flag, const unsigned long long* __restrict__ off, uint32_t n,
+                                                                     const uint32_t* __restrict__ res_rep, const uint32_t* __restrict__ res_cnt, uint32_t base, uint32_t* __restrict__ tmp) {
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock)
+        if (flag[j]) {
+            tmp[off[j]]     = res_rep[base + j];
+            tmp[n + off[j]] = res_cnt[base + j];
+        }
+}
+__global__ __launch_bounds__(kBlock) void skip_filter_store_kernel(const uint32_t* __restrict__ tmp, uint32_t n, uint32_t kept, uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt,
+                                                                    uint32_t base) {
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < kept; j += gridDim.x * kBlock) {
+        res_rep[base + j] = tmp[j];
+        res_cnt[base + j] = tmp[n + j];
+    }
+}
+__global__ __launch_bounds__(kBlock) void skip_remap_ids_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ nlist, uint32_t* __restrict__ ids,
+                                                                 const uint32_t* __restrict__ flag, const unsigned long long* __restrict__ off, uint32_t base) {
+    const uint32_t n = *nlist;
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+        const uint32_t p = list[j], s = ids[p];
+        if (s != kInvalid) ids[p] = flag[s - base] ? base + (uint32_t)off[s - base] : kInvalid;
+    }
+}
+
 // table reset for the capacity the current order uses
 __global__ __launch_bounds__(kBlock) void clear_table_kernel(Slot* __restrict__ table, const DevState* __restrict__ st) {
     if (st->done) return;

@@ -82,6 +82,8 @@ struct colibri_ctx {
     DevBuf<uint32_t>  idx_cnt, sort_hist;       // ... per-block pair counts of a pass; per-block digit histograms of a sort pass
     DevBuf<unsigned long long> sort_off, sort_bsum;
     uint64_t          npairs = 0;
+    DevBuf<unsigned long long> pair_chain;  // the pair counters (kernels.hpp: emit_write_kernel)
+    int               pair_pass = 0;
     DevBuf<uint32_t>  ref_sentence;
     DevBuf<uint16_t>  ref_token;
     DevBuf<Slot>      table;
@@ -466,6 +468,7 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->scratch[0]);
     dev_free(c->scratch[1]);
     dev_free(c->nsrc);
+    dev_free(c->pair_chain);
     dev_free(c->skip_tmp);
     dev_free(c->skip_off);
     dev_free(c->recs[0]);
@@ -946,9 +949,9 @@ int skipgram_pass(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, con
 constexpr int kRerunOnTable = 1000;
 int scan_u32(colibri_ctx* c, const uint32_t* in, uint32_t n, unsigned long long* out, unsigned long long* total);
 // minsrc > 0 (indexed models, MINSKIPTYPES): a skipgram also needs that many distinct fillers = distinct surviving n-grams [src_first, src_first + src_count) of the
-// results; *valid_out = the positions left with a result index (~0: not known without a read-back)
+// results
 int skipgram_pass_radix(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, const uint32_t* gate, const uint32_t* gate2, uint32_t thr, uint32_t res_total, uint32_t* found_out,
-                        uint32_t* kept_out, uint32_t** ids_out, uint32_t minsrc = 0, uint32_t src_first = 0, uint32_t src_count = 0, uint64_t* valid_out = nullptr) {
+                        uint32_t* kept_out, uint32_t** ids_out, uint32_t minsrc = 0, uint32_t src_first = 0, uint32_t src_count = 0) {
     const std::vector<std::pair<int, int>> parts = mask_parts(mask, n);
     const uint32_t* left = c->ids[parts[0].second].p;
     uint32_t        offl = (uint32_t)parts[0].first;
@@ -980,7 +983,6 @@ int skipgram_pass_radix(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mas
     if (c->hstate.radix_overflow) return kRerunOnTable;
     *found_out = c->hstate.found;
     *kept_out  = c->hstate.kept;
-    if (valid_out) *valid_out = c->hstate.valid;
     const uint32_t k1 = c->hstate.kept;
     if (minsrc > 1 && k1 && ids_out) {
         uint32_t* const ids = *ids_out;
@@ -999,7 +1001,6 @@ int skipgram_pass_radix(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mas
             hipLaunchKernelGGL(skip_filter_gather_kernel, dim3(stream_grid(k1)), dim3(kBlock), 0, c->stream, c->nsrc.p, c->skip_off.p, k1, c->res_rep.p, c->res_cnt.p, res_total, c->skip_tmp.p);
             if (k2) hipLaunchKernelGGL(skip_filter_store_kernel, dim3(stream_grid(k2)), dim3(kBlock), 0, c->stream, c->skip_tmp.p, k1, (uint32_t)k2, c->res_rep.p, c->res_cnt.p, res_total);
             hipLaunchKernelGGL(skip_remap_ids_kernel, dim3(stream_grid(pl.npos / 4 + 1)), dim3(kBlock), 0, c->stream, c->skl, c->skl_n, ids, c->nsrc.p, c->skip_off.p, res_total);
-            if (valid_out) *valid_out = ~0ull;
         }
         *kept_out     = (uint32_t)k2;
         c->hstate.kept = (uint32_t)k2;
@@ -1046,37 +1047,56 @@ int grow_keep(colibri_ctx* c, DevBuf<T>& b, uint64_t need, uint64_t keep) {
     return COLIBRI_OK;
 }
 
-// append (result id, position) for every position of `ids` that carries a result id, in position order. known_total: how many there are, when the
-// caller already has that number from the device (the n-gram passes do: it is the order's `valid` count) — no read-back, no synchronisation then
-int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, uint64_t known_total = ~0ull) {
-    const uint32_t nblk = std::max<uint32_t>(1, blocks_for(pl.npos, kPairTile));
-    int            rc;
-    if ((rc = dev_alloc(c, c->idx_cnt, (size_t)nblk + 2))) return rc;
-    uint32_t* const cnt = c->idx_cnt.p;
-    {
-        Prof p(c, COLIBRI_K_INDEX);
-        hipLaunchKernelGGL(emit_count_kernel, dim3(nblk), dim3(kPairThreads), 0, c->stream, ids, pl.npos, cnt);
-        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, cnt, nblk, cnt + nblk);
-    }
-    uint64_t total = known_total;
-    if (known_total == ~0ull) {
-        uint32_t t32 = 0;
-        HIP_TRY(c, hipMemcpyAsync(&t32, cnt + nblk, sizeof t32, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        total = t32;
-    }
-    if (total) {
-        const uint64_t want = std::max<uint64_t>(c->npairs + total, 2ull * pl.npos);  // room for the usual model right away (n <= 5: ~1.6 pairs per position)
-        if ((rc = grow_keep(c, c->pairs[0], want, c->npairs))) return rc;
-        Prof p(c, COLIBRI_K_INDEX);
-        hipLaunchKernelGGL(emit_write_kernel, dim3(nblk), dim3(kPairThreads), 0, c->stream, ids, pl.npos, cnt, c->npairs, c->pairs[0].p);
-        c->npairs += total;
-    }
-    if (known_total == ~0ull) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipGetLastError());
-    }
+// append (result id, position) for every position of `ids` that carries a result id, in position order; nothing is read back — the number of
+// pairs lives on the device (c->pair_chain) until pairs_count() fetches it. Pairs beyond the buffer's room are counted, not written; `ensure` (the
+// sharded levels, which cannot be run again as a whole): wait, and when the room was short grow the buffer and repeat the pass.
+int pairs_begin(colibri_ctx* c, uint32_t npos) {
+    int rc;
+    if ((rc = dev_alloc(c, c->pair_chain, (size_t)kChainHead + 1))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->pair_chain.p, 0, sizeof(unsigned long long) * kChainHead, c->stream));
+    c->pair_pass = 0;
+    c->npairs    = 0;
+    if (c->pairs[0].n < 2ull * npos && (rc = dev_alloc(c, c->pairs[0], (size_t)(2ull * npos) + 1))) return rc;  // the usual model: ~1.6 pairs per position at n <= 5
     return COLIBRI_OK;
+}
+// pairs so far; *overflowed: the buffer was too small for them
+int pairs_count(colibri_ctx* c, uint64_t* n, bool* overflowed) {
+    unsigned long long h[3] = {0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(h, c->pair_chain.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    *n          = h[c->pair_pass];
+    *overflowed = h[2] != 0;
+    return COLIBRI_OK;
+}
+int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool ensure = false) {
+    const uint32_t ntiles = std::max<uint32_t>(1, blocks_for(pl.npos, kPairTile));
+    int            rc0;
+    if ((rc0 = dev_alloc(c, c->idx_cnt, (size_t)ntiles + 2))) return rc0;
+    uint32_t* const cnt = c->idx_cnt.p;
+    for (;;) {
+        {
+            Prof p(c, COLIBRI_K_INDEX);
+            const uint64_t cap = c->pairs[0].n;
+            hipLaunchKernelGGL(emit_count_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, pl.npos, cnt);
+            hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, cnt, ntiles, cnt + ntiles);
+            hipLaunchKernelGGL(pairs_advance_kernel, dim3(1), dim3(1), 0, c->stream, c->pair_chain.p, c->pair_pass, cnt + ntiles, cap);
+            hipLaunchKernelGGL(emit_write_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, pl.npos, cnt, c->pair_chain.p, c->pair_pass, cap, c->pairs[0].p);
+        }
+        c->pair_pass ^= 1;
+        if (!ensure) return COLIBRI_OK;
+        uint64_t n = 0;
+        bool     over = false;
+        int      rc;
+        if ((rc = pairs_count(c, &n, &over))) return rc;
+        if (!over) {
+            c->npairs = n;
+            return COLIBRI_OK;
+        }
+        if ((rc = grow_keep(c, c->pairs[0], n, c->npairs))) return rc;  // the pairs of the passes before this one stay; the pass itself runs again
+        HIP_TRY(c, hipMemsetAsync(c->pair_chain.p + 2, 0, sizeof(unsigned long long), c->stream));
+        c->pair_pass ^= 1;
+    }
 }
 
 // two-level exclusive scan of n u32 values into u64 offsets (out[0..n-1]); *total (optional) = their sum, read back after a sync
@@ -1123,9 +1143,18 @@ inline int bits_for(uint64_t nvalues) {
 }
 
 // group the pairs by result id (stable LSD radix sort) and turn positions into (sentence, token)
+constexpr int kRerunPairs = 1001;  // the pair buffer was too small (it has been enlarged): the run again
 int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = false) {
-    const uint64_t n = c->npairs;
-    int            rc;
+    int      rc;
+    uint64_t n = 0;
+    bool     over = false;
+    if ((rc = pairs_count(c, &n, &over))) return rc;
+    if (over) {
+        dev_free(c->pairs[0]);
+        if ((rc = dev_alloc(c, c->pairs[0], (size_t)(n + n / 8) + 1))) return rc;
+        return kRerunPairs;
+    }
+    c->npairs = n;
     if ((rc = dev_alloc(c, c->ref_sentence, (size_t)n + 1)) || (rc = dev_alloc(c, c->ref_token, (size_t)n + 1))) return rc;
     if (!n) return COLIBRI_OK;
     if ((rc = dev_alloc(c, c->pairs[1], (size_t)n))) return rc;
@@ -1339,6 +1368,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     pl.tab_grid = stream_grid(pl.table_slots);
     pl.pos_grid = stream_grid(npos);
     const int maxlength = std::min<int>(o.maxlength, COLIBRI_MAX_ORDER - 1);
+    if (o.indexed && (rc = pairs_begin(c, npos))) return rc;
 
     if (c->ids.size() < 2) c->ids.resize(2);
     if ((rc = dev_alloc(c, c->ids[0], (size_t)npos + 1))) return rc;
@@ -1666,7 +1696,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             ngram_kept[n]  = kept;
             res_total += kept;
             c->hstate.res_total = res_total;
-            if (o.indexed && kept && (rc = emit_pairs(c, pl, c->ids[n].p, valid_n[n]))) return rc;  // occurrences of the surviving n-grams (as many as positions with an id)
+            if (o.indexed && kept && (rc = emit_pairs(c, pl, c->ids[n].p))) return rc;  // occurrences of the surviving n-grams (as many as positions with an id)
             // secondary word threshold: the unigrams below it keep their place (and references) in the model, but take no part in longer patterns
             if (n == 1 && wthr > pl.thr) hipLaunchKernelGGL(ids_min_count_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->ids[n].p, c->res_cnt.p, wthr, npos);
             if (o.doskipgrams_exhaustive && n >= 3) {  // patternmodel.h:1163-1171 -> computeskipgrams :1370-1527, for every admissible window
@@ -1711,16 +1741,15 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                     int fs = 0;
                     if (radix_synced) {
                         uint32_t* ids = nullptr;
-                        uint64_t  nvalid = ~0ull;
                         rc = skipgram_pass_radix(c, pl, n, mask, c->ids[n].p, nullptr, pl.thr, res_total, &f, &k, &ids, o.minskiptypes > 1 ? (uint32_t)o.minskiptypes : 0u, ngram_first[n],
-                                                 ngram_kept[n], &nvalid);
+                                                 ngram_kept[n]);
                         if (rc == kRerunOnTable) {
                             colibri_options again = o;
                             again.table_mode      = 1;
                             return colibri_train_once(c, &again, stats_out);
                         }
                         if (rc) return rc;
-                        if (k && (rc = emit_pairs(c, pl, ids, nvalid))) return rc;  // occurrences of the kept skipgrams of this pass -> forward index
+                        if (k && (rc = emit_pairs(c, pl, ids))) return rc;  // occurrences of the kept skipgrams of this pass -> forward index
                     } else {
                         if ((rc = skipgram_pass(c, pl, n, mask, c->ids[n].p, nullptr, valid_n[n], pl.thr, true, o.minskiptypes > 1 ? (uint32_t)o.minskiptypes : 0u, &f, &k, &fs))) return rc;
                         if (k) {  // occurrences of the kept skipgrams of this pass -> forward index
@@ -1739,7 +1768,10 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             }
         }
         c->hstate.res_total = res_total;
-        if (o.indexed && (rc = finalize_index(c, res_total))) return rc;
+        if (o.indexed && (rc = finalize_index(c, res_total))) {
+            if (rc == kRerunPairs) return colibri_train_once(c, opt_in, stats_out);  // (a model with more than two references per position)
+            return rc;
+        }
     }
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     collect_events(c);

@@ -1252,6 +1252,10 @@ __device__ __forceinline__ uint32_t pair_block_scan(uint32_t c, uint32_t* total)
     *total = all;
     return before + inc - c;
 }
+// Two sweeps over the ids (count per tile, short scan, write); the number of pairs lives on the device. chain[0], chain[1]: pairs so far, before / after
+// this pass (which = the one to read); chain[2]: set when the pairs outgrew `cap` (the count goes on, the writes stop: the host then knows how much room
+// the model needs). (A one-sweep version with a decoupled look-back over the 12.8 K tiles was 2 x slower: too few tiles in flight to hide the chain.)
+constexpr int kChainHead = 3;
 __global__ __launch_bounds__(kPairThreads) void emit_count_kernel(const uint32_t* __restrict__ ids, uint32_t npos, uint32_t* __restrict__ blockcnt) {
     uint32_t v[kPairPer], c = 0;
     pair_load(ids, npos, blockIdx.x * kPairTile + threadIdx.x * kPairPer, v);
@@ -1261,19 +1265,26 @@ __global__ __launch_bounds__(kPairThreads) void emit_count_kernel(const uint32_t
     pair_block_scan(c, &total);
     if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
 }
-__global__ __launch_bounds__(kPairThreads) void emit_write_kernel(const uint32_t* __restrict__ ids, uint32_t npos, const uint32_t* __restrict__ blockoff, uint64_t out_base,
+__global__ void pairs_advance_kernel(unsigned long long* __restrict__ chain, int which, const uint32_t* __restrict__ total, uint64_t cap) {
+    const unsigned long long after = chain[which] + *total;
+    chain[which ^ 1]               = after;
+    if (after > cap) chain[2] = 1ull;
+}
+__global__ __launch_bounds__(kPairThreads) void emit_write_kernel(const uint32_t* __restrict__ ids, uint32_t npos, const uint32_t* __restrict__ blockoff,
+                                                                   const unsigned long long* __restrict__ chain, int which, uint64_t cap,
                                                                    unsigned long long* __restrict__ pairs /* result id << 32 | position */) {
+    if (blockoff[blockIdx.x + 1] == blockoff[blockIdx.x]) return;  // nothing in this tile (the passes of the high orders are sparse); [ntiles] holds the total
     const uint32_t base = blockIdx.x * kPairTile + threadIdx.x * kPairPer;
     uint32_t       v[kPairPer], c = 0;
     pair_load(ids, npos, base, v);
 #pragma unroll
     for (int k = 0; k < kPairPer; ++k) c += v[k] != kInvalid;
     uint32_t total;
-    uint64_t o = out_base + blockoff[blockIdx.x] + pair_block_scan(c, &total);
+    uint64_t o = chain[which] + blockoff[blockIdx.x] + pair_block_scan(c, &total);
 #pragma unroll
     for (int k = 0; k < kPairPer; ++k) {
         if (v[k] != kInvalid) {
-            pairs[o] = ((unsigned long long)v[k] << 32) | (base + k);
+            if (o < cap) pairs[o] = ((unsigned long long)v[k] << 32) | (base + k);
             ++o;
         }
     }

@@ -323,3 +323,26 @@ def test_duplicated_sentences_outgrow_the_usual_result_capacity(ctx, mode):
     got, _ = ctx.export_dict()
     assert got == want.counts
     assert st.totaltokens == want.tokens and st.totaltypes == want.types
+
+
+def test_an_index_with_more_references_than_the_pair_buffer_starts_with(ctx):
+    """An indexed model of a repetitive corpus holds L (L + 1) / 2 references per sentence of L tokens, more than the two pairs per position the
+    forward-index buffer starts with: the run counts what it could not write, enlarges the buffer and repeats (reference: IndexedPatternModel::add,
+    include/patternmodel.h:2390-2410, has no such bound)."""
+    import oracle
+    from colibri_amd import synth
+    L, nsent = 10, 600
+    rng = np.random.default_rng(12)
+    sent = rng.permutation(np.arange(6, 6 + L * nsent, dtype=np.uint32)).reshape(nsent, L)
+    rows = np.concatenate([sent, sent], axis=0)
+    sym = np.concatenate([rows, np.zeros((2 * nsent, 1), dtype=np.uint32)], axis=1).reshape(-1)
+    payload = synth.encode_v2(sym).tobytes()
+    want = oracle.train(payload, 2, L, indexed=True)
+    assert sum(len(r) for r in want.refs.values()) > 2 * len(sym) + 1024
+    with type(ctx)(0) as fresh:  # a context whose buffers have not grown yet
+        fresh.upload(payload)
+        st = fresh.train(mintokens=2, maxlength=L, indexed=1)
+        got, gotrefs = fresh.export_dict()
+    assert got == want.counts
+    assert gotrefs == want.refs
+    assert st.nrefs == sum(len(r) for r in want.refs.values())

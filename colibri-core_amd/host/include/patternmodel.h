@@ -9,6 +9,7 @@
 #ifndef COLIBRI_AMD_PATTERNMODEL_H
 #define COLIBRI_AMD_PATTERNMODEL_H
 #include <cstdint>
+#include <cstdlib>
 #include <algorithm>
 #include <fstream>
 #include <iomanip>
@@ -103,6 +104,12 @@ struct ConstraintKeys {
 /** upload + train + export through the C ABI; prints the library's message on stderr and throws InternalError on any status != 0 */
 void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out, const ConstraintKeys* constraint = NULL,
                   bool keep_device = false);
+/** the same across `world` GPUs of this node (src/sharded.cpp): the corpus cut into contiguous sentence ranges, one device context and host thread per rank,
+ *  RCCL for the exchange of candidate counts; the result is the union of the ranks' exports. Not for constrained runs and pattern lists. */
+void device_train_sharded(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out, int world);
+/** how many GPUs train() uses: set_gpus(n) (the CLI's --gpus), else the environment's COLIBRI_GPUS, else 1 */
+void set_gpus(int n);
+int  gpus();
 /** flexgrams abstracted from the skipgrams of an indexed model given in export layout (colibri_flexgrams + colibri_flexgrams_fetch) */
 void device_flexgrams(const std::vector<uint64_t>& key_off, const unsigned char* key_bytes, const std::vector<uint64_t>& ref_off, const uint32_t* ref_sentence,
                       const uint16_t* ref_token, TrainResult& out);
@@ -349,8 +356,26 @@ class PatternModel : public MapType, public PatternModelInterface {
 
         std::shared_ptr<colibri_host::TrainResult> r = std::make_shared<colibri_host::TrainResult>();
         // an indexed skipgram model stays resident on the device until it is materialised on the host: computeflexgrams_fromskipgrams works on it there
-        const bool keep_device = o.indexed && o.doskipgrams && constrainbymodel == NULL && options.MINLENGTH <= 1;
-        if (reverseindex != NULL && !reverseindex->empty()) {
+        const int  world = (constrainbymodel == NULL && !options.DOPATTERNPERLINE) ? colibri_host::gpus() : 1;  // sentence-sharded over that many GPUs (src/sharded.cpp)
+        const bool keep_device = world == 1 && o.indexed && o.doskipgrams && constrainbymodel == NULL && options.MINLENGTH <= 1;
+        if (world > 1 || (world == 1 && constrainbymodel == NULL && !options.DOPATTERNPERLINE && std::getenv("COLIBRI_GPUS_FORCE_SHARDED") != NULL)) {  // (forced: the sharded protocol on one rank, for tests)
+            std::vector<unsigned char> owned;
+            const unsigned char*       p = NULL;
+            uint64_t                   nb = 0;
+            if (reverseindex != NULL && !reverseindex->empty()) {
+                p  = reverseindex->beginpointer();
+                nb = reverseindex->bytesize();
+            } else if (in != NULL) {
+                owned = colibri_host::read_corpus_payload(*in);
+                p     = owned.data();
+                nb    = owned.size();
+            }
+            if (p == NULL || nb == 0) {
+                std::cerr << "ERROR: No corpus data to train on" << std::endl;
+                throw InternalError();
+            }
+            colibri_host::device_train_sharded(p, nb, o, firstsentence, *r, world);
+        } else if (reverseindex != NULL && !reverseindex->empty()) {
             colibri_host::device_train(reverseindex->beginpointer(), reverseindex->bytesize(), o, firstsentence, *r, constrainbymodel ? &ck : NULL, keep_device);
         } else if (in != NULL) {
             const std::vector<unsigned char> payload = colibri_host::read_corpus_payload(*in);

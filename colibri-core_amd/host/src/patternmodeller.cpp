@@ -40,6 +40,7 @@ void usage() {
                  "\t-L|--patternlist            the data file is a list of one pattern per line: no sub-n-grams, implies -t 1 and -u\n"
                  "\t-F|--flexgrams S            flexgrams by abstracting over skipgrams (implies -s); indexed models built from a corpus\n"
                  "\t-I|--constrained            in-place rebuild: recount the patterns of the model given with -i on the corpus given with -f\n"
+                 "\t--gpus <n>                  train sentence-sharded across n GPUs of this node (RCCL; not with -j, -I, -L)\n"
                  "\t--skipcontent               after the views: every pattern, then the skip content of the skipgrams (needs -c and a corpus)\n"
                  "\t--instances | --templates   as in the reference, these print the patterns only (its relation getters are not reached from here)\n"
                  " Viewing:\n"
@@ -111,10 +112,12 @@ int main(int argc, char** argv) {
                                        {"report", no_argument, 0, 'R'},            {"simplereport", no_argument, 0, 'r'},         {"histogram", no_argument, 0, 'H'},
                                        {"debug", no_argument, 0, 'D'},             {"help", no_argument, 0, 'h'},                 {"twostage", no_argument, 0, '2'},          {"constraints", required_argument, 0, 'j'},    {"constrained", no_argument, 0, 'I'},    {"flexgrams", required_argument, 0, 'F'},    {"patternlist", no_argument, 0, 'L'},
                                        {"skipcontent", no_argument, 0, 1001},      {"instances", no_argument, 0, 1002},           {"templates", no_argument, 0, 1003},
+                                       {"gpus", required_argument, 0, 1004},
                                        {0, 0, 0, 0}};
     int c;
     while ((c = getopt_long(argc, argv, "f:c:i:o:t:ul:m:b:W:sy:T:e:PRrHDh2j:Ip:EF:LMQq:gZV", longopts, NULL)) != -1) {
         switch (c) {
+            case 1004: colibri_host::set_gpus(std::atoi(optarg)); break;
             case 'f': corpusfile = optarg; break;
             case 'c': classfile = optarg; break;
             case 'i': inputmodel = optarg; break;

@@ -40,23 +40,30 @@ typedef struct colibri_ctx colibri_ctx;
 /* POD mirror of the PatternModelOptions fields PatternModel::train reads on this path
  * (reference include/patternmodel.h:103-213; defaults :153-180). */
 typedef struct colibri_options {
-    int32_t mintokens;              /* MINTOKENS: -1 -> 2, 0 -> 1 (patternmodel.h:883-886); any value >= 1                              */
-    int32_t maxlength;              /* MAXLENGTH (default 100)                                                    */
-    int32_t minlength;              /* MINLENGTH (default 1; only 1 is accelerated)                               */
-    int32_t maxbackofflength;       /* MAXBACKOFFLENGTH (must be >= maxlength)                                    */
-    int32_t mintokens_unigrams;     /* MINTOKENS_UNIGRAMS (-W): > mintokens = secondary word threshold (not with a constraint set) */
-    int32_t mintokens_skipgrams;    /* MINTOKENS_SKIPGRAMS (raised to mintokens when lower, :887-888)             */
-    int32_t minskiptypes;           /* MINSKIPTYPES (default 2)                                                   */
-    int32_t maxskips;               /* MAXSKIPS (default 3)                                                       */
-    int32_t doskipgrams;            /* DOSKIPGRAMS (indexed models)                                               */
-    int32_t doskipgrams_exhaustive; /* DOSKIPGRAMS_EXHAUSTIVE                                                     */
-    int32_t dopatternperline;       /* DOPATTERNPERLINE (-L): every line is one pattern; needs mintokens = 1, unindexed, no skipgrams */
-    int32_t prunenonsubsumed;       /* PRUNENONSUBSUMED (must be 0)                                               */
-    int32_t prunesubsumed;          /* PRUNESUBSUMED (must be 0)                                                  */
-    int32_t indexed;                /* 0: PatternModel<uint32_t> (model type 10), 1: IndexedPatternModel<> (20)   */
+    /* Every combination colibri_train does not run is refused with COLIBRI_ERR_UNSUPPORTED / _ARG and a message (check_options in
+     * csrc/colibri_hip.hip is the authority; the comments below follow it). "constraint set" = colibri_set_constraint is in force. */
+    int32_t mintokens;              /* MINTOKENS: -1 -> 2, 0 -> 1 (patternmodel.h:883-886); any value >= 1 (1: every window is kept)    */
+    int32_t maxlength;              /* MAXLENGTH (default 100), >= 1; per-order statistics are kept below COLIBRI_MAX_ORDER              */
+    int32_t minlength;              /* MINLENGTH (default 1): > 1 only with a constraint set (the C++ face drops the short patterns of an
+                                       unconstrained run itself, after the run)                                                        */
+    int32_t maxbackofflength;       /* MAXBACKOFFLENGTH: >= maxlength (no effect), or 1 <= b < maxlength with mintokens >= 2, without
+                                       skipgrams or a constraint set: orders above b + 1 look back at the b-token sub-patterns only     */
+    int32_t mintokens_unigrams;     /* MINTOKENS_UNIGRAMS (-W): > mintokens = secondary word threshold; needs mintokens >= 2, no
+                                       constraint set, table_mode != 2                                                                 */
+    int32_t mintokens_skipgrams;    /* MINTOKENS_SKIPGRAMS (raised to mintokens when lower, :887-888)                                   */
+    int32_t minskiptypes;           /* MINSKIPTYPES (default 2): distinct fillers a skipgram of an indexed model needs                  */
+    int32_t maxskips;               /* MAXSKIPS (default 3), >= 1                                                                       */
+    int32_t doskipgrams;            /* DOSKIPGRAMS: indexed models only (the reference's rule, :1558); not with a constraint set        */
+    int32_t doskipgrams_exhaustive; /* DOSKIPGRAMS_EXHAUSTIVE: unindexed models only; not together with doskipgrams (:958-963); not with
+                                       a constraint set. Either kind: patterns of more than 13 tokens stop the run when they turn up     */
+    int32_t dopatternperline;       /* DOPATTERNPERLINE (-L): every line is one pattern; needs mintokens = 1, minlength = 1, unindexed,
+                                       no skipgrams, no constraint set                                                                 */
+    int32_t prunenonsubsumed;       /* PRUNENONSUBSUMED: must be 0 here (a post-hoc pass over the finished model: the C++ face does it) */
+    int32_t prunesubsumed;          /* PRUNESUBSUMED: must be 0 here (same)                                                             */
+    int32_t indexed;                /* 0: PatternModel<uint32_t> (model type 10), 1: IndexedPatternModel<> (20)                         */
     int32_t profile;                /* 1: bracket every kernel class with HIP events (colibri_kernel_time); 2: only the
-                                       counting classes K_COUNT / K_BINCOUNT (8-18 events per train instead of ~120)  */
-    int32_t table_mode;             /* 0: automatic; 1: force the global open-addressed table; 2: force radix-partition + LDS count */
+                                       counting classes K_COUNT / K_BINCOUNT (8-18 events per train instead of ~120)                   */
+    int32_t table_mode;             /* 0: automatic; 1: force the global open-addressed table; 2: force radix-partition + LDS count     */
 } colibri_options;
 
 /* What train() reports: the numbers the reference keeps in the model (totaltokens/totaltypes/maxn/minn,

@@ -153,6 +153,43 @@ def test_cli_indexed_and_skipgram_models_reference_can_load(tmp_path, corpus, fl
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gpus,devices", [(2, "0,0"), (3, "0,0,0"), (1, None)], ids=["two-ranks-one-device", "three-ranks-one-device", "one-rank-rccl"])
+@pytest.mark.parametrize("corpus,flags,tag", [("hamlet.v2", ["-u"], "u"), ("hamlet.v2", [], "i"), ("hamlet.v2", ["-s"], "is"), ("zipf20k", [], "i"), ("phrases15k", ["-s"], "is"),
+                                              ("phrases15k", ["-u", "-s"], "us"), ("zipf20k", ["-u", "-s", "-y", "3"], "usy3")])
+def test_cli_sharded_across_gpus(tmp_path, corpus, flags, tag, gpus, devices):
+    """colibri-patternmodeller --gpus N: the C++ sharded driver (host/src/sharded.cpp) — N rank threads, each with its own device context and sentence
+    range; candidates and replies exchanged between the contexts. On a one-GPU box the ranks share device 0 (COLIBRI_DEVICES=0,0: device-to-device
+    copies between the contexts); --gpus 1 with COLIBRI_GPUS_FORCE_SHARDED runs the same protocol through RCCL (ncclCommInitAll on one device). The
+    model must be the reference's (goldens by ref_driver train) and load back in the reference."""
+    import oracle
+    model = str(tmp_path / "m.colibri.patternmodel")
+    data = os.path.join(GOLDEN, corpus + ".colibri.dat")
+    env = dict(os.environ)
+    if devices:
+        env["COLIBRI_DEVICES"] = devices
+    else:
+        env["COLIBRI_GPUS_FORCE_SHARDED"] = "1"
+    out = subprocess.run([CLI, "-f", data, "-t", "2", "-l", "5", "-o", model, "--gpus", str(gpus)] + flags, capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stderr
+    assert f"sentence-sharded over {gpus} GPU" in out.stderr and ("RCCL" in out.stderr) == (devices is None), out.stderr
+    indexed = "-u" not in flags
+    golden = os.path.join(GOLDEN, f"{corpus}.{tag}.l5.txt")
+    if not os.path.exists(golden):
+        golden = os.path.join(GOLDEN, f"{corpus}.{tag}.txt")
+    want = oracle.parse_dump(open(golden).read(), indexed=indexed)
+    mtype, tokens, types, counts, refs = parse_model(model)
+    assert (mtype, tokens, types) == (20 if indexed else 10, want.tokens, want.types)
+    assert counts == want.counts
+    if indexed:
+        assert refs == want.refs
+    if oracle.have_ref():
+        dump = str(tmp_path / "d.txt")
+        subprocess.check_call([oracle.REF_DRIVER, "load", model, "i" if indexed else "u", dump])
+        got = oracle.parse_dump(open(dump).read(), indexed=indexed)
+        assert (got.tokens, got.types, got.counts, got.refs) == (want.tokens, want.types, want.counts, want.refs)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("corpus,flags,tag", [("hamlet.v2", [], "is"), ("phrases15k", [], "is"), ("zipf20k", [], "is"), ("zipf20k", ["-T", "1"], "isT1")])
 def test_cli_flexgrams_from_skipgrams(tmp_path, corpus, flags, tag):
     """-F S (implies -s): the model gains the flexgrams its skipgrams abstract to (reference computeflexgrams_fromskipgrams,

@@ -100,6 +100,11 @@ struct colibri_ctx {
         uint32_t                   n = 0, cap = 0;
         bool                       rem_valid = false;
         bool                       closed = false;  // every pattern's prefix (without its last token) is a pattern too: the probe may stop at the first miss
+        // colibri_set_continuation: the set is not a constraint but the model a continued run starts from (train(..., continued = true)): the orders it has
+        // n-grams of are not counted again, their windows only get the patterns' numbers as survivor ids for the look-back of the next order
+        bool                       continuation = false;
+        uint64_t                   orders[2]    = {0, 0};  // bit n: the set has n-grams of n tokens (n < 128)
+        bool has_order(int n) const { return n >= 1 && n < 128 && ((orders[n >> 6] >> (n & 63)) & 1ull); }
     } cs;
     struct TextState {                  // class encoder (textenc.hpp): the uploaded text, its word table, the encoded stream
         DevBuf<uint8_t>            text, out;
@@ -390,7 +395,11 @@ int check_options(colibri_ctx* c, colibri_options& o) {
     if (o.mintokens == 0) o.mintokens = 1;
     if (o.mintokens_skipgrams < o.mintokens) o.mintokens_skipgrams = o.mintokens;  // :887-888
     if (o.maxlength < 1) return fail(c, COLIBRI_ERR_ARG, "MAXLENGTH must be >= 1");
-    const bool constrained = c->cs.n != 0;  // a constraint set makes the run single-pass by definition: every threshold and minimum length is fine
+    const bool constrained = c->cs.n != 0 && !c->cs.continuation;  // a constraint set makes the run single-pass by definition: every threshold and minimum length is fine
+    // a continued run (patternmodel.h:983-995): the orders the loaded model lacks are counted with the usual look-back, which asks the loaded patterns too
+    if (c->cs.n != 0 && c->cs.continuation &&
+        (o.mintokens < 2 || o.doskipgrams || o.doskipgrams_exhaustive || o.dopatternperline || o.minlength > 1 || o.maxbackofflength < o.maxlength || o.mintokens_unigrams > o.mintokens))
+        return fail(c, COLIBRI_ERR_UNSUPPORTED, "continued training is on the accelerated path for MINTOKENS >= 2, MINLENGTH = 1, without skipgrams, back-off length, word threshold or pattern list");
     if (constrained && (o.doskipgrams || o.doskipgrams_exhaustive)) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams in a constrained run are not on the accelerated path");
     if (o.minlength < 1) o.minlength = 1;
     // MINTOKENS = 1: the reference counts all lengths in one pass without look-back (patternmodel.h:1069-1072); nothing is ever pruned, so the
@@ -1322,9 +1331,10 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     if (o.dopatternperline) return train_pattern_list(c, o, stats_out);
 
     const uint32_t npos   = c->npos;
-    const bool     constrained = c->cs.n != 0;  // train(..., constrainbymodel): one membership-filtered pass per length, no look-back (constrained.hpp)
+    const bool     constrained = c->cs.n != 0 && !c->cs.continuation;  // train(..., constrainbymodel): one membership-filtered pass per length, no look-back (constrained.hpp)
+    const bool     continued   = c->cs.n != 0 && c->cs.continuation;   // train(..., continued = true): the set is the model the run starts from
     const int      backoff = (o.maxbackofflength >= 1 && o.maxbackofflength + 1 < std::min<int>(o.maxlength, COLIBRI_MAX_ORDER - 1)) ? o.maxbackofflength : 0;  // orders above backoff + 1 differ
-    const bool     synced = o.indexed || o.doskipgrams || o.doskipgrams_exhaustive || constrained || backoff;  // these modes keep every order's ids and talk to the host per order
+    const bool     synced = o.indexed || o.doskipgrams || o.doskipgrams_exhaustive || constrained || backoff || continued;  // these modes keep every order's ids and talk to the host per order
     // order 1 counted per class id when the encoding is canonical (class id <-> token bytes is then a bijection) and the class
     // space is small enough for a dense array; table_mode 1 / 2 force the generic table / radix implementations (tests)
     const bool uni_direct = !synced && o.table_mode == 0 && !(c->flags & kFlagNonCanonical) && c->maxclass < (1u << 28);
@@ -1517,7 +1527,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
         std::vector<uint32_t> valid_n(maxlength + 2, 0), adm_n(maxlength + 2, 0), ngram_first(maxlength + 2, 0), ngram_kept(maxlength + 2, 0);
         uint32_t              res_total = 0;
         const uint32_t        thr_skip  = o.minskiptypes > 1 ? (uint32_t)o.mintokens_skipgrams : pl.thr;  // base pruneskipgrams is a no-op when MINSKIPTYPES <= 1 (patternmodel.h:2167-2186)
-        if (constrained) {
+        if (constrained || continued) {
             if (!c->cs.rem_valid) {
                 if ((rc = dev_alloc(c, c->cs.rem, (size_t)npos + 1))) return rc;
                 hipLaunchKernelGGL(sentence_rem_kernel, dim3(stream_grid(npos)), dim3(kBlock), 0, c->stream, c->delimpos.p, c->ndelim, npos, c->cs.rem.p);
@@ -1544,6 +1554,16 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
         bool bo_runs_valid = false;
         for (int n = constrained ? std::max(1, o.minlength) : 1; n <= maxlength && !c->hstate.done; ++n) {
             if ((rc = dev_alloc(c, c->ids[n], (size_t)npos + 1))) return rc;
+            if (continued && c->cs.has_order(n)) {
+                // "Skipping n-grams, already in model" (patternmodel.h:983-995): nothing is counted; the windows that ARE patterns of the loaded model get
+                // the pattern's number as their survivor id, which is all the look-back of the next order asks for (:1139-1152: this->has(subngram))
+                Prof p(c, COLIBRI_K_COUNT);
+                hipLaunchKernelGGL(constraint_probe_kernel<false>, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, c->cs.rem.p, c->cs.table.p, c->cs.cap,
+                                   c->cs.bytes.p, c->cs.off.p, npos, n, 1, c->ids[n].p, (size_t)npos + 1, (const uint32_t*)nullptr);
+                list_valid = false;
+                valid_n[n] = 1;  // (not counted: the order above simply finds no candidate when there is none)
+                continue;
+            }
             bool       listed_order = false;  // this order walked the active list (alist[n & 1])
             const bool radix_pass = (radix_constrained || (radix_synced && n >= 2)) && !(backoff && n > backoff + 1);
             if (constrained && n > probed_to) {  // which pattern of the constraint set is the window at each position, for the next lengths
@@ -1687,7 +1707,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             adm_n[n]   = c->hstate.admitted;
             valid_n[n] = c->hstate.valid;
             s.admitted[n] = adm_n[n];
-            if (found == 0 && !constrained) break;  // "None found" (patternmodel.h:1189-1194); a constrained run is one pass over all lengths
+            if (found == 0 && !constrained && !continued) break;  // "None found" (patternmodel.h:1189-1194: `if (!continued) break`); a constrained run is one pass over all lengths
             if (found) s.maxn = n;
             s.found[n] = found;
             s.kept[n]  = kept;
@@ -1729,7 +1749,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             if (!constrained) c->hstate.cap = (uint32_t)std::min<uint64_t>(pl.table_slots, (uint64_t)valid_n[n] + (valid_n[n] >> 1) + 1024u);
             c->hstate.found = c->hstate.kept = c->hstate.admitted = c->hstate.valid = 0;
             if ((rc = write_state(c))) return rc;
-            if (valid_n[n] == 0 && !constrained && !(backoff && n >= backoff + 1)) break;  // nothing can be admitted at n + 1 (a back-off order asks the order-b survivors instead)
+            if (valid_n[n] == 0 && !constrained && !continued && !(backoff && n >= backoff + 1)) break;  // nothing can be admitted at n + 1 (a back-off order asks the order-b survivors instead)
         }
         if (o.doskipgrams) {  // IndexedPatternModel::trainskipgrams (patternmodel.h:2969-3010): from the SURVIVING n-grams, n = 3..
             for (int n = 3; n <= std::min<int>(maxlength, s.maxn); ++n) {

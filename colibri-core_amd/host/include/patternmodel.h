@@ -103,7 +103,7 @@ struct ConstraintKeys {
 };
 /** upload + train + export through the C ABI; prints the library's message on stderr and throws InternalError on any status != 0 */
 void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out, const ConstraintKeys* constraint = NULL,
-                  bool keep_device = false);
+                  bool keep_device = false, bool continuation = false /* the keys are the model a continued run starts from (colibri_set_continuation) */);
 /** the same across `world` GPUs of this node (src/sharded.cpp): the corpus cut into contiguous sentence ranges, one device context and host thread per rank,
  *  RCCL for the exchange of candidate counts; the result is the union of the ranks' exports. Not for constrained runs and pattern lists. */
 void device_train_sharded(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out, int world);
@@ -300,9 +300,14 @@ class PatternModel : public MapType, public PatternModelInterface {
         if (options.MINTOKENS == 0) options.MINTOKENS = 1;
         if (options.MINTOKENS_SKIPGRAMS < options.MINTOKENS) options.MINTOKENS_SKIPGRAMS = options.MINTOKENS;
         if (filter != NULL && filter->size() == 0) filter = NULL;  // cython passes empty sets (reference :902-903)
-        if (filter != NULL || continued) {
-            std::cerr << "ERROR: training with a filter, or continued on a preloaded model, is not on the MI355X-accelerated path" << std::endl;
+        if (filter != NULL) {
+            std::cerr << "ERROR: training with a filter is not on the MI355X-accelerated path" << std::endl;
             throw InternalError();
+        }
+        if (continued && (constrainbymodel != NULL || (this->data.empty() && !result))) continued = false;  // nothing to continue from / a constrained run counts everything anyway (:985)
+        if (continued) {
+            train_continued(in, options, firstsentence);
+            return;
         }
         // Constrained training (reference :1062-1072, :1088-1089): one pass over all lengths, a window counts iff the constraint model has it.
         // The keys of the constraint model become a device-side set (colibri_set_constraint). constrainbymodel == this is the in-place
@@ -419,6 +424,62 @@ class PatternModel : public MapType, public PatternModelInterface {
         if (options.PRUNENONSUBSUMED || options.PRUNESUBSUMED) prune_by_subsumption(options);
     }
 
+  protected:
+    /** train(..., continued = true) on a model that holds patterns (reference :983-995, colibri-patternmodeller -E): the orders the model already has n-grams
+     *  of are skipped, the others are counted on the device with a look-back that finds the loaded patterns (colibri_set_continuation); the new patterns
+     *  join the map, the totals stay the model's (:1047-1048 and :1197 are guarded by !continued). */
+    void train_continued(std::istream* in, const PatternModelOptions& options, uint32_t firstsentence) {
+        this->materialise();  // (a model trained a moment ago: its patterns into the map first)
+        if (options.DOSKIPGRAMS || options.DOSKIPGRAMS_EXHAUSTIVE || options.MINTOKENS < 2 || options.MINLENGTH > 1 || options.DOPATTERNPERLINE ||
+            options.MAXBACKOFFLENGTH < options.MAXLENGTH || options.MINTOKENS_UNIGRAMS > options.MINTOKENS) {
+            std::cerr << "ERROR: continued training is on the MI355X-accelerated path for MINTOKENS >= 2, MINLENGTH = 1, without skipgrams, back-off length, word threshold or "
+                         "pattern list" << std::endl;
+            throw InternalError();
+        }
+        if (!options.QUIET) std::cerr << "Continuing training on preloaded model, computing statistics..." << std::endl;
+        colibri_host::ConstraintKeys known;
+        known.off.push_back(0);
+        for (typename MapType::iterator it = this->data.begin(); it != this->data.end(); ++it) {
+            if (it->first.category() != NGRAM) continue;
+            known.bytes.insert(known.bytes.end(), it->first.data, it->first.data + it->first.bytesize());
+            known.off.push_back(known.bytes.size());
+        }
+        colibri_options o{};
+        o.mintokens           = options.MINTOKENS;
+        o.maxlength           = options.MAXLENGTH;
+        o.minlength           = 1;
+        o.maxbackofflength    = options.MAXBACKOFFLENGTH;
+        o.mintokens_unigrams  = options.MINTOKENS_UNIGRAMS;
+        o.mintokens_skipgrams = options.MINTOKENS_SKIPGRAMS;
+        o.minskiptypes        = options.MINSKIPTYPES;
+        o.maxskips            = options.MAXSKIPS;
+        o.indexed             = colibri_host::is_indexed_value<ValueType>::value ? 1 : 0;
+        colibri_host::TrainResult r;
+        if (reverseindex != NULL && !reverseindex->empty()) {
+            colibri_host::device_train(reverseindex->beginpointer(), reverseindex->bytesize(), o, firstsentence, r, &known, false, /*continuation=*/true);
+        } else if (in != NULL) {
+            const std::vector<unsigned char> payload = colibri_host::read_corpus_payload(*in);
+            if (payload.empty()) {
+                std::cerr << "ERROR: Attempting to read pattern from file, but file is empty?" << std::endl;
+                throw InternalError();
+            }
+            colibri_host::device_train(payload.data(), payload.size(), o, firstsentence, r, &known, false, /*continuation=*/true);
+        } else {
+            std::cerr << "ERROR: No input stream and no reverse index (preloaded corpus) to train on" << std::endl;
+            throw InternalError();
+        }
+        if (!options.QUIET) colibri_host::print_training_log(r.stats, o, std::cerr);
+        for (size_t j = 0; j < r.size(); ++j) {
+            ValueType v{};
+            colibri_host::value_from_result(r, j, v);
+            this->data[Pattern(r.key_bytes.data() + r.key_off[j], (size_t)(r.key_off[j + 1] - r.key_off[j]))] = std::move(v);
+        }
+        if (r.stats.npatterns && r.stats.maxn > maxn) maxn = r.stats.maxn;
+        for (int n = 1; n < COLIBRI_MAX_ORDER; ++n)
+            if (r.stats.kept[n] && n < minn) minn = n;
+    }
+
+  public:
     /** erase the patterns of _n tokens (0 = any) that are not / are in the set (reference :2194-2242) */
     unsigned int prunenotinset(const std::unordered_set<Pattern>& s, int _n) { return prune_set(s, _n, false); }
     unsigned int pruneinset(const std::unordered_set<Pattern>& s, int _n) { return prune_set(s, _n, true); }

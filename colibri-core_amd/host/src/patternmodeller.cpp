@@ -33,7 +33,8 @@ void usage() {
                  "\t-s|--skipgrams              compute skipgrams\n"
                  "\t-y|--skipthreshold <n>      occurrence threshold for skipgrams\n"
                  "\t-T|--skiptypes <n>          skip type threshold (default 2)\n"
-                 "\t-e|--expand <n>             sentence offset given to the first sentence\n"
+                 "\t-e|--expand <n>             sentence offset given to the first sentence; with -i and -f: train on the loaded model (needs -E)\n"
+                 "\t-E|--selfexpand             continued training: only the pattern lengths the loaded model lacks are counted (e.g. -i m -f corpus -e 1 -E -l 8)\n"
                  "\t-2|--twostage               two-stage build of an indexed model (needs -o): same result as the reference's -2\n"
                  "\t-p|--prune <n>              prune the (k-1)-grams that no k-gram of the model contains, from k = n downwards\n"
                  "\t-j|--constraints <file>     only count patterns that occur in this model (any threshold, any minimum length)\n"
@@ -51,6 +52,8 @@ void usage() {
 PatternSetModel* g_constraint = NULL;  // -j
 bool             g_inplace    = false; // -I
 bool             g_flexfromskip = false; // -F S
+bool             g_continued  = false; // -E: train(..., continued = true) on the loaded model
+bool             g_expand     = false; // -e: train on the loaded model at all (reference src/patternmodeller.cpp:356)
 std::string      g_relations;            // --skipcontent / --instances / --templates
 
 template <class ModelType>
@@ -66,6 +69,10 @@ int run(ModelType& model, const std::string& corpusfile, const std::string& inpu
         model.train(corpusfile, options, model.getinterface(), NULL, false, firstsentence);
     } else if (!inputmodel.empty()) {
         model.load(inputmodel, options);
+        if (!corpusfile.empty() && g_expand) {  // reference src/patternmodeller.cpp:356-358; only the continued form (-E: add the orders the model lacks) runs here
+            std::cerr << "Expanding model on  " << corpusfile << std::endl;
+            model.train(corpusfile, options, g_constraint, NULL, g_continued, firstsentence);
+        }
     } else {
         model.train(corpusfile, options, g_constraint, NULL, false, firstsentence);
         if (g_flexfromskip && options.DOSKIPGRAMS) {  // reference src/patternmodeller.cpp:337-341, :790-794 (messages as there, file name glued on)
@@ -112,7 +119,7 @@ int main(int argc, char** argv) {
                                        {"report", no_argument, 0, 'R'},            {"simplereport", no_argument, 0, 'r'},         {"histogram", no_argument, 0, 'H'},
                                        {"debug", no_argument, 0, 'D'},             {"help", no_argument, 0, 'h'},                 {"twostage", no_argument, 0, '2'},          {"constraints", required_argument, 0, 'j'},    {"constrained", no_argument, 0, 'I'},    {"flexgrams", required_argument, 0, 'F'},    {"patternlist", no_argument, 0, 'L'},
                                        {"skipcontent", no_argument, 0, 1001},      {"instances", no_argument, 0, 1002},           {"templates", no_argument, 0, 1003},
-                                       {"gpus", required_argument, 0, 1004},
+                                       {"gpus", required_argument, 0, 1004},         {"selfexpand", no_argument, 0, 'E'},
                                        {0, 0, 0, 0}};
     int c;
     while ((c = getopt_long(argc, argv, "f:c:i:o:t:ul:m:b:W:sy:T:e:PRrHDh2j:Ip:EF:LMQq:gZV", longopts, NULL)) != -1) {
@@ -131,7 +138,11 @@ int main(int argc, char** argv) {
             case 's': options.DOSKIPGRAMS = true; break;
             case 'y': options.MINTOKENS_SKIPGRAMS = std::atoi(optarg); break;
             case 'T': options.MINSKIPTYPES = std::atoi(optarg); break;
-            case 'e': firstsentence = (uint32_t)std::atoi(optarg); break;
+            case 'e':
+                firstsentence = (uint32_t)std::atoi(optarg);
+                g_expand      = true;
+                break;
+            case 'E': g_continued = true; break;
             case 'P': doprint = true; break;
             case 'R': doreport = true; break;
             case 'r':  // report without the coverage columns (reference :603-606)

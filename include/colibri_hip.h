@@ -203,6 +203,13 @@ int colibri_kernel_time(const colibri_ctx* ctx, int kernel_class, double* total_
  * patterns' keys as in colibri_export_unindexed (skipgram / flexgram keys never equal a window and are simply never hit).
  * npatterns = 0 removes the constraint. stats.totaltypes is 0 after a constrained run (the reference leaves it unset there). */
 int colibri_set_constraint(colibri_ctx* ctx, const uint64_t* key_off, const uint8_t* key_bytes, uint64_t npatterns);
+/* Continued training: replaces PatternModel::train(..., continued = true) on a model that already holds patterns (reference
+ * include/patternmodel.h:983-995 "Skipping n-grams, already in model", colibri-patternmodeller -E). The patterns of that model are installed
+ * like a constraint set; the next colibri_train then counts only the orders the model has no n-grams of, and the look-back of those orders
+ * (:1139-1152) finds the loaded patterns as well as the new survivors. The results are the NEW patterns only (the caller already has the
+ * others); stats.totaltokens is the corpus' (the reference leaves the model's total untouched: the C++ face ignores it). MINTOKENS >= 2,
+ * no skipgrams. npatterns = 0 (or colibri_set_constraint) ends the mode. */
+int colibri_set_continuation(colibri_ctx* ctx, const uint64_t* key_off, const uint8_t* key_bytes, uint64_t npatterns);
 
 /* ---- class encoder: plain text -> word frequency list -> class-encoded corpus -------------------------------------
  * Replaces the corpus-proportional work of ClassEncoder::processcorpus (reference src/classencoder.cpp:156-188: the word frequency

@@ -235,6 +235,65 @@ def train_constrained(payload: bytes, constraint, mintokens=2, maxlength=100, mi
     return Model(tokens, 0, counts, {k: sorted(refs[k]) for k in counts} if indexed else None)
 
 
+def _sentences(payload: bytes):
+    toks, start, out = [], 0, []
+    for j, b in enumerate(payload):
+        if b >= 128:
+            continue
+        tok = payload[start:j + 1]
+        start = j + 1
+        if tok == b"\x00":
+            out.append(toks)
+            toks = []
+        else:
+            toks.append(tok)
+    if toks:
+        out.append(toks)
+    return out
+
+
+def key_ntokens(k: bytes) -> int:
+    return sum(1 for b in k if b < 128)
+
+
+# ---- continued training (train(..., continued = true), colibri-patternmodeller -E) ----------------------------------------------------
+def train_continued(payload: bytes, loaded: "Model", mintokens=2, maxlength=100, indexed=False, firstsentence=1) -> "Model":
+    """PatternModel::train(in, options, NULL, NULL, continued = true) on a model that already holds patterns, restated for MINTOKENS > 1 without
+    skipgrams (reference include/patternmodel.h:983-995: an order the model already has n-grams of is skipped — "Skipping n-grams, already in model";
+    :1139-1152: the look-back of every other order asks the model, i.e. the loaded patterns and the new survivors alike; :1047-1048: the token total
+    is not touched; :1189-1194: "None found" does not end a continued run; :1197: neither is the type total). Returns the whole model: the loaded
+    patterns unchanged plus the new orders. Pure Python: small inputs."""
+    thr = 2 if mintokens == -1 else max(1, mintokens)
+    assert thr > 1
+    counts = dict(loaded.counts)
+    refs = {k: list(v) for k, v in loaded.refs.items()} if indexed else None
+    have = {}
+    for k in counts:
+        if 2 not in k and 3 not in [b for b in k if b < 128]:  # n-grams only (02 / 03 as a token are the gap classes)
+            have[key_ntokens(k)] = True
+    sentences = _sentences(payload)
+    for n in range(1, maxlength + 1):
+        if have.get(n):
+            continue
+        new, newrefs = {}, {}
+        sentence = firstsentence - 1
+        for toks in sentences:
+            sentence += 1
+            for i in range(len(toks) - n + 1):
+                if n > 1 and not (b"".join(toks[i:i + n - 1]) in counts and b"".join(toks[i + 1:i + n]) in counts):
+                    continue
+                k = b"".join(toks[i:i + n])
+                new[k] = new.get(k, 0) + 1
+                if indexed:
+                    newrefs.setdefault(k, []).append((sentence, i))
+        for k, c in new.items():
+            if c >= thr:
+                counts[k] = c
+                if indexed:
+                    refs[k] = sorted(newrefs[k])
+    return Model(loaded.tokens, loaded.types, counts, refs)
+
+
 # ---- one pattern per line (PatternModelOptions::DOPATTERNPERLINE, colibri-patternmodeller -L) -----------------------------------------
 def train_patternperline(payload: bytes, maxlength=100) -> "Model":
     """PatternModel::train with DOPATTERNPERLINE at MINTOKENS = 1 (the CLI's -L implies -t 1, src/patternmodeller.cpp:677-678) restated:

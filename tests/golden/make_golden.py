@@ -156,6 +156,16 @@ def main():
                                     ("I_self.i.t2", "hamlet.v2", "i", ["5", "2", "-I", ch])]:
         out = os.path.join(HERE, f"constrained.{tag}.txt")
         subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{corpus}.colibri.dat"), mode] + args + ["-q", "-d", out], stdout=subprocess.DEVNULL)
+    # continued training (patternmodeller -i <model> -f <corpus> -e 1 -E = train(..., continued = true)): models written by the reference, kept as fixtures, then
+    # continued by the reference to longer patterns — on the same corpus under another threshold, and on a different corpus
+    ez = os.path.join(HERE, "continued.zipf20k.u.t3l2.patternmodel")
+    subprocess.check_call([DRIVER, "train", os.path.join(HERE, "zipf20k.colibri.dat"), "u", "2", "3", "-q", "-o", ez], stdout=subprocess.DEVNULL)
+    eh = os.path.join(HERE, "continued.hamlet.i.t2l3.patternmodel")
+    subprocess.check_call([DRIVER, "train", os.path.join(HERE, "hamlet.v2.colibri.dat"), "i", "3", "2", "-q", "-o", eh], stdout=subprocess.DEVNULL)
+    for tag, corpus, mode, args in [("E_zipf.u", "zipf20k", "u", ["5", "2", "-E", ez]), ("E_hamlet.i", "hamlet.v2", "i", ["6", "2", "-E", eh]),
+                                    ("E_cross.u", "phrases15k", "u", ["4", "2", "-E", ez])]:
+        out = os.path.join(HERE, f"continued.{tag}.txt")
+        subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{corpus}.colibri.dat"), mode] + args + ["-q", "-d", out], stdout=subprocess.DEVNULL)
     # flexgrams from skipgrams (ref_driver -F = computeflexgrams_fromskipgrams after training, src/patternmodeller.cpp:790-794). The loop
     # inserts into the map it iterates (patternmodel.h:3727-3738): a dump is kept only where it equals the hazard-free restatement
     # applied to the reference's own model before the call

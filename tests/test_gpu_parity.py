@@ -346,3 +346,50 @@ def test_an_index_with_more_references_than_the_pair_buffer_starts_with(ctx):
     assert got == want.counts
     assert gotrefs == want.refs
     assert st.nrefs == sum(len(r) for r in want.refs.values())
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_continued_training_matches_the_restatement(ctx, seed):
+    """colibri_set_continuation + colibri_train = train(..., continued = true) (reference include/patternmodel.h:983-995): the orders the loaded model
+    has n-grams of are skipped, the others counted with a look-back that finds loaded and new patterns alike. Loaded models: the oracle's own, under
+    another threshold / a shorter maximum length / from another corpus, and with an order knocked out (that order is then counted again)."""
+    import oracle
+    rng = np.random.default_rng(9100 + seed)
+    corpora = small_corpora()
+    names = sorted(corpora)
+    payload = corpora[names[seed % len(names)]]
+    source = corpora[names[(seed * 7 + 3) % len(names)]] if seed % 4 == 3 else payload  # every fourth case: a model of another corpus
+    indexed = bool(seed % 2)
+    loaded = oracle.train(source, int(rng.choice([2, 3])), int(rng.choice([1, 2, 3])), indexed=indexed)
+    if seed % 5 == 4 and loaded.maxn >= 2:  # a model that lacks an order in the middle
+        drop = int(rng.integers(1, loaded.maxn + 1))
+        keep = {k for k in loaded.counts if oracle.key_ntokens(k) != drop}
+        loaded = oracle.Model(loaded.tokens, loaded.types, {k: loaded.counts[k] for k in keep}, {k: loaded.refs[k] for k in keep} if indexed else None)
+    if not loaded.counts:
+        pytest.skip("nothing to continue from")
+    mintokens, maxlength = int(rng.choice([2, 2, 3])), int(rng.choice([3, 5, 8]))
+    want = oracle.train_continued(payload, loaded, mintokens, maxlength, indexed=indexed, firstsentence=1 + seed % 3)
+    new = {k: v for k, v in want.counts.items() if k not in loaded.counts}
+    ctx.upload(payload, first_sentence=1 + seed % 3)
+    try:
+        ctx.set_continuation(sorted(loaded.counts))
+        st = ctx.train(mintokens=mintokens, maxlength=maxlength, indexed=int(indexed))
+        got, gotrefs = ctx.export_dict()
+    finally:
+        ctx.set_continuation([])
+    assert got == new
+    if indexed:
+        assert gotrefs == {k: want.refs[k] for k in new}
+    assert st.npatterns == len(new)
+
+
+def test_continued_training_refuses_what_it_does_not_reproduce(ctx):
+    from colibri_amd import capi
+    ctx.upload(small_corpora()["zipf20k"])
+    try:
+        ctx.set_continuation([b"\x06"])
+        for kw in (dict(mintokens=1), dict(doskipgrams_exhaustive=1), dict(indexed=1, doskipgrams=1), dict(maxbackofflength=1, maxlength=4), dict(mintokens_unigrams=5)):
+            with pytest.raises(capi.ColibriError):
+                ctx.train(**{"mintokens": 2, "maxlength": 5, **kw})
+    finally:
+        ctx.set_continuation([])

@@ -275,6 +275,33 @@ def test_cli_constrained_training_matches_the_references(tmp_path, tag):
         assert refs == want.refs
 
 
+CONTINUED = {  # golden tag -> (corpus, loaded model, unindexed?, -l, -t)
+    "E_zipf.u": ("zipf20k", "continued.zipf20k.u.t3l2.patternmodel", True, 5, 2),
+    "E_hamlet.i": ("hamlet.v2", "continued.hamlet.i.t2l3.patternmodel", False, 6, 2),
+    "E_cross.u": ("phrases15k", "continued.zipf20k.u.t3l2.patternmodel", True, 4, 2),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(CONTINUED))
+def test_cli_continued_training_matches_the_references(tmp_path, tag):
+    """colibri-patternmodeller -i <model> -f <corpus> -e 1 -E: train(..., continued = true) — the pattern lengths the loaded model lacks are counted on the
+    device, with a look-back that finds the loaded patterns; the model written is the loaded one plus the new lengths, totals untouched. Goldens: the real
+    reference continuing models it wrote itself (ref_driver train ... -E), on the same corpus under another threshold and on a different corpus."""
+    import oracle
+    corpus, fixture, unindexed, l, t = CONTINUED[tag]
+    model = str(tmp_path / "m.colibri.patternmodel")
+    out = subprocess.run([CLI, "-i", os.path.join(GOLDEN, fixture), "-f", os.path.join(GOLDEN, corpus + ".colibri.dat"), "-e", "1", "-E", "-l", str(l), "-t", str(t), "-o", model] +
+                         (["-u"] if unindexed else []), capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    want = oracle.parse_dump(open(os.path.join(GOLDEN, f"continued.{tag}.txt")).read(), indexed=not unindexed)
+    mtype, tokens, types, counts, refs = parse_model(model)
+    assert (mtype, tokens, types) == (10 if unindexed else 20, want.tokens, want.types)
+    assert counts == want.counts
+    if not unindexed:
+        assert refs == want.refs
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("corpus", ["hamlet.v2", "zipf20k"])
 @pytest.mark.parametrize("mode,flags", [("u", ["-u"]), ("i", []), ("is", ["-s"]), ("us", ["-u", "-s"])])

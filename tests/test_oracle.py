@@ -241,3 +241,50 @@ def test_constrained_restatement_matches_reference_dumps(tag):
     assert got.counts == want.counts
     if indexed:
         assert got.refs == want.refs
+
+
+CONTINUED = {  # golden tag -> (corpus, loaded model fixture, indexed, mintokens, maxlength)
+    "E_zipf.u": ("zipf20k", "continued.zipf20k.u.t3l2.patternmodel", False, 2, 5),
+    "E_hamlet.i": ("hamlet.v2", "continued.hamlet.i.t2l3.patternmodel", True, 2, 6),
+    "E_cross.u": ("phrases15k", "continued.zipf20k.u.t3l2.patternmodel", False, 2, 4),
+}
+
+
+def load_model_file(path):
+    """a .colibri.patternmodel written by the reference -> oracle.Model (file format: reference include/patternmodel.h:781-861)"""
+    import struct
+    raw = open(path, "rb").read()
+    assert raw[0] == 0 and raw[2] == 2
+    mtype = raw[1]
+    tokens, types, npat = struct.unpack_from("<QQQ", raw, 3)
+    pos, counts, refs = 27, {}, {}
+    for _ in range(npat):
+        start, prevhigh = pos, False
+        while prevhigh or raw[pos] != 0:
+            prevhigh = raw[pos] >= 128
+            pos += 1
+        key = raw[start:pos]
+        pos += 1
+        (c,) = struct.unpack_from("<I", raw, pos)
+        pos += 4
+        counts[key] = c
+        if mtype == 20:
+            refs[key] = [struct.unpack_from("<IH", raw, pos + 6 * k) for k in range(c)]
+            pos += 6 * c
+    assert pos == len(raw)
+    return oracle.Model(tokens, types, counts, refs if mtype == 20 else None)
+
+
+@pytest.mark.parametrize("tag", list(CONTINUED))
+def test_continued_training_restatement_matches_the_reference(tag):
+    """train(..., continued = true) (include/patternmodel.h:983-995): the restatement against dumps of the real reference continuing models it wrote itself"""
+    corpus, fixture, indexed, mintokens, maxlength = CONTINUED[tag]
+    payload = open(os.path.join(GOLDEN, corpus + ".colibri.dat"), "rb").read()[2:]
+    loaded = load_model_file(os.path.join(GOLDEN, fixture))
+    want = oracle.parse_dump(open(os.path.join(GOLDEN, f"continued.{tag}.txt")).read(), indexed=indexed)
+    got = oracle.train_continued(payload, loaded, mintokens, maxlength, indexed=indexed)
+    assert (got.tokens, got.types) == (want.tokens, want.types)
+    assert got.counts == want.counts
+    if indexed:
+        assert got.refs == want.refs
+    assert len(got.counts) > len(loaded.counts)  # the run did add longer patterns

@@ -400,7 +400,10 @@ int check_options(colibri_ctx* c, colibri_options& o) {
     if (c->cs.n != 0 && c->cs.continuation &&
         (o.mintokens < 2 || o.doskipgrams || o.doskipgrams_exhaustive || o.dopatternperline || o.minlength > 1 || o.maxbackofflength < o.maxlength || o.mintokens_unigrams > o.mintokens))
         return fail(c, COLIBRI_ERR_UNSUPPORTED, "continued training is on the accelerated path for MINTOKENS >= 2, MINLENGTH = 1, without skipgrams, back-off length, word threshold or pattern list");
-    if (constrained && (o.doskipgrams || o.doskipgrams_exhaustive)) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams in a constrained run are not on the accelerated path");
+    // skipgrams in a constrained run (patternmodel.h:941-956 turns DOSKIPGRAMS into the exhaustive kind there, for either model type): both flags mean the same
+    // thing, and only a run at MINTOKENS = 1 ever computes any (:1163)
+    if (constrained && (o.doskipgrams || o.doskipgrams_exhaustive) && (c->flags & kFlagSkipClass))
+        return fail(c, COLIBRI_ERR_UNSUPPORTED, "corpus contains the literal skip class {*} (03): skipgrams are not accelerated for it");
     if (o.minlength < 1) o.minlength = 1;
     // MINTOKENS = 1: the reference counts all lengths in one pass without look-back (patternmodel.h:1069-1072); nothing is ever pruned, so the
     // order loop admits every window and yields the same model — with skipgrams too: every window of three or more tokens then counts all its
@@ -417,11 +420,11 @@ int check_options(colibri_ctx* c, colibri_options& o) {
     // threshold the reference re-counts every line once per order until nothing new turns up — not reproduced
     if (o.dopatternperline && (o.mintokens != 1 || o.indexed || o.doskipgrams || o.doskipgrams_exhaustive || constrained || o.minlength > 1))
         return fail(c, COLIBRI_ERR_UNSUPPORTED, "DOPATTERNPERLINE is on the accelerated path with MINTOKENS = 1, MINLENGTH = 1, unindexed, without skipgrams or a constraint set");
-    if (o.doskipgrams && o.doskipgrams_exhaustive)
+    if (o.doskipgrams && o.doskipgrams_exhaustive && !constrained)
         return fail(c, COLIBRI_ERR_ARG, "Both DOSKIPGRAMS as well as DOSKIPGRAMS_EXHAUSTIVE are set, this shouldn't happen, choose one.");  // :958-963
-    if (o.doskipgrams && !o.indexed)
+    if (o.doskipgrams && !o.indexed && !constrained)
         return fail(c, COLIBRI_ERR_UNSUPPORTED, "Can not compute skipgrams on unindexed model (except exhaustively during train() )");  // reference patternmodel.h:1558
-    if (o.doskipgrams_exhaustive && o.indexed) return fail(c, COLIBRI_ERR_UNSUPPORTED, "exhaustive skipgrams on an indexed model are not on the accelerated path");
+    if (o.doskipgrams_exhaustive && o.indexed && !constrained) return fail(c, COLIBRI_ERR_UNSUPPORTED, "exhaustive skipgrams on an indexed model are not on the accelerated path");
     if ((o.doskipgrams || o.doskipgrams_exhaustive) && (c->flags & kFlagSkipClass))
         return fail(c, COLIBRI_ERR_UNSUPPORTED, "corpus contains the literal skip class {*} (03): skipgram validity then follows the reference's extra checks, not accelerated");
     if (o.maxskips < 1) return fail(c, COLIBRI_ERR_ARG, "MAXSKIPS must be >= 1");
@@ -952,11 +955,39 @@ int skipgram_pass(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, con
     return COLIBRI_OK;
 }
 
+int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool ensure);
+// MINSKIPTYPES of an indexed model: a skipgram needs that many distinct fillers = distinct surviving n-grams (results [src_first, src_first + src_count)) whose
+// representative window it masks. `ids`: the RESULT index of every window's skipgram (the k1 survivors of the count threshold sit at res_total..); the ones
+// with too few fillers leave the results again and the per-position indices follow (over `list`, or over every position when there is none).
+int scan_u32(colibri_ctx* c, const uint32_t* in, uint32_t n, unsigned long long* out, unsigned long long* total);
+int filter_by_fillers(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids, uint32_t res_total, uint32_t k1, uint32_t minsrc, uint32_t src_first, uint32_t src_count, const uint32_t* list,
+                      const uint32_t* nlist, uint32_t* kept_out) {
+    int rc;
+    if ((rc = dev_alloc(c, c->nsrc, (size_t)k1 + 1)) || (rc = dev_alloc(c, c->skip_off, (size_t)k1 + 1)) || (rc = dev_alloc(c, c->skip_tmp, 2 * (size_t)k1 + 2))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->nsrc.p, 0, sizeof(uint32_t) * k1, c->stream));
+    unsigned long long k2 = 0;
+    {
+        Prof p(c, COLIBRI_K_SKIPGRAM);
+        if (src_count)
+            hipLaunchKernelGGL(skip_sources_results_kernel, dim3(stream_grid(src_count)), dim3(kBlock), 0, c->stream, c->res_rep.p, src_first, src_count, ids, res_total, c->nsrc.p);
+        hipLaunchKernelGGL(skip_keep_flags_kernel, dim3(stream_grid(k1)), dim3(kBlock), 0, c->stream, c->nsrc.p, k1, minsrc);
+    }
+    if ((rc = scan_u32(c, c->nsrc.p, k1, c->skip_off.p, &k2))) return rc;
+    if (k2 != k1) {
+        Prof p(c, COLIBRI_K_SKIPGRAM);
+        hipLaunchKernelGGL(skip_filter_gather_kernel, dim3(stream_grid(k1)), dim3(kBlock), 0, c->stream, c->nsrc.p, c->skip_off.p, k1, c->res_rep.p, c->res_cnt.p, res_total, c->skip_tmp.p);
+        if (k2) hipLaunchKernelGGL(skip_filter_store_kernel, dim3(stream_grid(k2)), dim3(kBlock), 0, c->stream, c->skip_tmp.p, k1, (uint32_t)k2, c->res_rep.p, c->res_cnt.p, res_total);
+        hipLaunchKernelGGL(skip_remap_ids_kernel, dim3(stream_grid(pl.npos / 4 + 1)), dim3(kBlock), 0, c->stream, list, nlist, pl.npos, ids, c->nsrc.p, c->skip_off.p, res_total);
+    }
+    *kept_out      = (uint32_t)k2;
+    c->hstate.kept = (uint32_t)k2;
+    return COLIBRI_OK;
+}
+
 // The same pass on the radix path (emit -> level B -> per-bin LDS count -> resolve, over c->sklist): no global atomics. A level that is not the last
 // interns every pair (threshold 1) and hands dense ids to the next one; the last level appends its survivors to the results and, when `ids_out` is
 // given (indexed models), leaves every window's RESULT index there. kRerunOnTable: a bin outgrew its LDS table (the caller re-runs on the global table).
 constexpr int kRerunOnTable = 1000;
-int scan_u32(colibri_ctx* c, const uint32_t* in, uint32_t n, unsigned long long* out, unsigned long long* total);
 // minsrc > 0 (indexed models, MINSKIPTYPES): a skipgram also needs that many distinct fillers = distinct surviving n-grams [src_first, src_first + src_count) of the
 // results
 int skipgram_pass_radix(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, const uint32_t* gate, const uint32_t* gate2, uint32_t thr, uint32_t res_total, uint32_t* found_out,
@@ -994,26 +1025,57 @@ int skipgram_pass_radix(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mas
     *kept_out  = c->hstate.kept;
     const uint32_t k1 = c->hstate.kept;
     if (minsrc > 1 && k1 && ids_out) {
-        uint32_t* const ids = *ids_out;
-        if ((rc = dev_alloc(c, c->nsrc, (size_t)k1 + 1)) || (rc = dev_alloc(c, c->skip_off, (size_t)k1 + 1)) || (rc = dev_alloc(c, c->skip_tmp, 2 * (size_t)k1 + 2))) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->nsrc.p, 0, sizeof(uint32_t) * k1, c->stream));
-        unsigned long long k2 = 0;
-        {
-            Prof p(c, COLIBRI_K_SKIPGRAM);
-            if (src_count)
-                hipLaunchKernelGGL(skip_sources_results_kernel, dim3(stream_grid(src_count)), dim3(kBlock), 0, c->stream, c->res_rep.p, src_first, src_count, ids, res_total, c->nsrc.p);
-            hipLaunchKernelGGL(skip_keep_flags_kernel, dim3(stream_grid(k1)), dim3(kBlock), 0, c->stream, c->nsrc.p, k1, minsrc);
-        }
-        if ((rc = scan_u32(c, c->nsrc.p, k1, c->skip_off.p, &k2))) return rc;
-        if (k2 != k1) {
-            Prof p(c, COLIBRI_K_SKIPGRAM);
-            hipLaunchKernelGGL(skip_filter_gather_kernel, dim3(stream_grid(k1)), dim3(kBlock), 0, c->stream, c->nsrc.p, c->skip_off.p, k1, c->res_rep.p, c->res_cnt.p, res_total, c->skip_tmp.p);
-            if (k2) hipLaunchKernelGGL(skip_filter_store_kernel, dim3(stream_grid(k2)), dim3(kBlock), 0, c->stream, c->skip_tmp.p, k1, (uint32_t)k2, c->res_rep.p, c->res_cnt.p, res_total);
-            hipLaunchKernelGGL(skip_remap_ids_kernel, dim3(stream_grid(pl.npos / 4 + 1)), dim3(kBlock), 0, c->stream, c->skl, c->skl_n, ids, c->nsrc.p, c->skip_off.p, res_total);
-        }
-        *kept_out     = (uint32_t)k2;
-        c->hstate.kept = (uint32_t)k2;
+        uint32_t k2 = k1;
+        if ((rc = filter_by_fillers(c, pl, *ids_out, res_total, k1, minsrc, src_first, src_count, c->skl, c->skl_n, &k2))) return rc;
+        *kept_out = k2;
     }
+    return COLIBRI_OK;
+}
+
+// One (length, gap mask) skipgram pass of a CONSTRAINED run (reference include/patternmodel.h:1163-1171 -> computeskipgrams :1410-1411): the masked form of a
+// member window counts iff the constraint set holds it; its identity is then its pattern number there (constraint_probe_masked_kernel + KeyMember), counted
+// on the radix path or on the table like the n-gram passes of the run. `gate`: the pattern numbers of the unmasked windows of this length.
+// Pruning is the BASE pruneskipgrams (:2167-2186) for either model type — train() calls it with an unsigned threshold, which the indexed model's
+// pruneskipgrams(int, int, int) (:3362) does not override —: nothing when MINSKIPTYPES <= 1, else the occurrence threshold MINTOKENS_SKIPGRAMS
+// (checked against the reference: tests/golden/constrained.js_*).
+int constrained_skipgram_pass(colibri_ctx* c, const TrainPlan& pl, const colibri_options& o, int n, uint32_t mask, const uint32_t* gate, bool radix, uint32_t res_total,
+                              uint32_t* found_out, uint32_t* kept_out) {
+    int rc;
+    if ((rc = dev_alloc(c, c->scratch[0], (size_t)pl.npos + 1)) || (rc = dev_alloc(c, c->scratch[1], (size_t)pl.npos + 1))) return rc;
+    uint32_t* const memb = c->scratch[0].p;
+    uint32_t* const ids  = c->scratch[1].p;
+    {
+        Prof p(c, COLIBRI_K_SKIPGRAM);
+        hipLaunchKernelGGL(constraint_probe_masked_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, gate, c->cs.table.p, c->cs.cap, c->cs.bytes.p, c->cs.off.p,
+                           pl.npos, n, mask, memb);
+    }
+    const uint32_t thr = o.minskiptypes > 1 ? (uint32_t)std::max(1, o.mintokens_skipgrams) : 1u;
+    c->hstate.found = c->hstate.kept = c->hstate.admitted = c->hstate.valid = 0;
+    c->hstate.radix_overflow = 0;
+    if ((rc = write_state(c))) return rc;
+    const KeyMember km{memb};
+    if (radix) {
+        if ((rc = binned_count_stage(c, pl, km, n, false, thr, false, true, false, /*dense_code=*/true))) return rc;
+        const BinnedIO io = binned_planes(c, pl, false);
+        {
+            Prof p(c, COLIBRI_K_PRUNE);
+            hipLaunchKernelGGL(bin_kept_scan_kernel, dim3(kBins), dim3(kBlock), 0, c->stream, c->state.p, c->binstate.p, pl.res_cap);
+            hipLaunchKernelGGL(compact_bins_kernel, dim3(1024), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, c->binstate.p, c->res_rep.p, c->res_cnt.p, pl.res_cap,
+                               (const uint32_t*)nullptr);
+            hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
+        }
+        if ((rc = binned_resolve_stage(c, pl, ids, n, false, false, nullptr, 0u, /*prefill_ids=*/true, /*decode=*/true, res_total))) return rc;
+    } else {
+        launch_clear(c, pl);
+        launch_count(c, pl, km, ids, 3, COLIBRI_K_SKIPGRAM);
+        launch_prune(c, pl, thr, nullptr, 0);
+        launch_resolve(c, pl, ids);
+    }
+    if ((rc = read_state(c))) return rc;
+    if (c->hstate.radix_overflow) return kRerunOnTable;
+    *found_out = c->hstate.found;
+    *kept_out  = c->hstate.kept;
+    if (o.indexed && *kept_out && (rc = emit_pairs(c, pl, ids, false))) return rc;
     return COLIBRI_OK;
 }
 
@@ -1078,7 +1140,7 @@ int pairs_count(colibri_ctx* c, uint64_t* n, bool* overflowed) {
     *overflowed = h[2] != 0;
     return COLIBRI_OK;
 }
-int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool ensure = false) {
+int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool ensure) {
     const uint32_t ntiles = std::max<uint32_t>(1, blocks_for(pl.npos, kPairTile));
     int            rc0;
     if ((rc0 = dev_alloc(c, c->idx_cnt, (size_t)ntiles + 2))) return rc0;
@@ -1716,10 +1778,29 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             ngram_kept[n]  = kept;
             res_total += kept;
             c->hstate.res_total = res_total;
-            if (o.indexed && kept && (rc = emit_pairs(c, pl, c->ids[n].p))) return rc;  // occurrences of the surviving n-grams (as many as positions with an id)
+            if (o.indexed && kept && (rc = emit_pairs(c, pl, c->ids[n].p, false))) return rc;  // occurrences of the surviving n-grams (as many as positions with an id)
             // secondary word threshold: the unigrams below it keep their place (and references) in the model, but take no part in longer patterns
             if (n == 1 && wthr > pl.thr) hipLaunchKernelGGL(ids_min_count_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->ids[n].p, c->res_cnt.p, wthr, npos);
-            if (o.doskipgrams_exhaustive && n >= 3) {  // patternmodel.h:1163-1171 -> computeskipgrams :1370-1527, for every admissible window
+            if (constrained && (o.doskipgrams || o.doskipgrams_exhaustive) && pl.thr == 1 && n >= 3) {
+                // skipgrams of a constrained run: the reference reaches computeskipgrams only in its single pass at MINTOKENS = 1 (:1163: `(n >= 3) || (MINTOKENS == 1)`
+                // with n == 1 in that pass); with a higher threshold a constrained run has no skipgrams at all, and neither has this one
+                if (n > kMaskedMaxTokens) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 13 tokens are not on the accelerated path (set MAXLENGTH)");
+                for (uint32_t mask : gap_masks(n, o.maxskips)) {
+                    uint32_t f = 0, k = 0;
+                    rc = constrained_skipgram_pass(c, pl, o, n, mask, member.memb, radix_constrained, res_total, &f, &k);
+                    if (rc == kRerunOnTable) {
+                        colibri_options again = o;
+                        again.table_mode      = 1;
+                        return colibri_train_once(c, &again, stats_out);
+                    }
+                    if (rc) return rc;
+                    s.found[n] += f;
+                    s.kept[n] += k;
+                    if (k) c->segments.push_back({res_total, k, n, mask});
+                    res_total += k;
+                    c->hstate.res_total = res_total;
+                }
+            } else if (!constrained && o.doskipgrams_exhaustive && n >= 3) {  // patternmodel.h:1163-1171 -> computeskipgrams :1370-1527, for every admissible window
                 if (n > 13) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 13 tokens are not on the accelerated path (set MAXLENGTH)");
                 if (radix_synced && listed_order) {  // the order's own active list IS the list of positions whose (n-1)-gram survived
                     c->skl   = c->alist[n & 1].p;
@@ -1751,7 +1832,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             if ((rc = write_state(c))) return rc;
             if (valid_n[n] == 0 && !constrained && !continued && !(backoff && n >= backoff + 1)) break;  // nothing can be admitted at n + 1 (a back-off order asks the order-b survivors instead)
         }
-        if (o.doskipgrams) {  // IndexedPatternModel::trainskipgrams (patternmodel.h:2969-3010): from the SURVIVING n-grams, n = 3..
+        if (o.doskipgrams && !constrained) {  // IndexedPatternModel::trainskipgrams (patternmodel.h:2969-3010): from the SURVIVING n-grams, n = 3..
             for (int n = 3; n <= std::min<int>(maxlength, s.maxn); ++n) {
                 if (n > 13) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 13 tokens are not on the accelerated path (set MAXLENGTH)");
                 uint32_t found_n = 0;
@@ -1769,12 +1850,12 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                             return colibri_train_once(c, &again, stats_out);
                         }
                         if (rc) return rc;
-                        if (k && (rc = emit_pairs(c, pl, ids))) return rc;  // occurrences of the kept skipgrams of this pass -> forward index
+                        if (k && (rc = emit_pairs(c, pl, ids, false))) return rc;  // occurrences of the kept skipgrams of this pass -> forward index
                     } else {
                         if ((rc = skipgram_pass(c, pl, n, mask, c->ids[n].p, nullptr, valid_n[n], pl.thr, true, o.minskiptypes > 1 ? (uint32_t)o.minskiptypes : 0u, &f, &k, &fs))) return rc;
                         if (k) {  // occurrences of the kept skipgrams of this pass -> forward index
                             hipLaunchKernelGGL(skip_result_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->scratch[fs].p, c->table.p, c->scratch[fs ^ 1].p, npos);
-                            if ((rc = emit_pairs(c, pl, c->scratch[fs ^ 1].p))) return rc;
+                            if ((rc = emit_pairs(c, pl, c->scratch[fs ^ 1].p, false))) return rc;
                         }
                     }
                     found_n += f;

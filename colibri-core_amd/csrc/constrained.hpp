@@ -185,6 +185,39 @@ __global__ __launch_bounds__(kBlock) void constraint_probe_kernel(const uint8_t*
         }
     }
 }
+// Skipgrams in a constrained run (reference include/patternmodel.h:1163-1171 -> computeskipgrams :1410-1411: `if (constrainbymodel != NULL &&
+// !constrainbymodel->has(skipgram)) continue;`): the masked form of a member window counts iff J holds it. out[i] = pattern number in J of the window of n
+// tokens at i with the tokens of `mask` replaced by the skip class (one byte, 03), for the positions whose unmasked window is a member (gate); kInvalid
+// elsewhere. The masked key is materialised in a small per-lane buffer (the look-up verifies bytes): at most 13 tokens of at most 8 bytes.
+constexpr int kMaskedMaxTokens = 13;
+__global__ __launch_bounds__(kBlock) void constraint_probe_masked_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ tokstart, const uint32_t* __restrict__ gate,
+                                                                          const CSlot* __restrict__ table, uint32_t cap, const uint8_t* __restrict__ jbytes,
+                                                                          const unsigned long long* __restrict__ joff, uint32_t npos, int n, uint32_t mask, uint32_t* __restrict__ out) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npos; i += gridDim.x * kBlock) {
+        uint32_t found = kInvalid;
+        if (gate[i] != kInvalid) {
+            uint8_t  key[kMaskedMaxTokens * 8 + 8];
+            uint32_t len = 0;
+            uint64_t h   = kConstraintSeed;
+            for (int k = 0; k < n; ++k) {
+                if ((mask >> k) & 1u) {
+                    key[len] = 3;  // ClassDecoder::skipclass (reference include/classencoder.h:61)
+                    h        = fold_chunk(h, key + len, 1);
+                    len += 1;
+                } else {
+                    const uint32_t a = tokstart[i + k], nb = tokstart[i + k + 1] - a;
+                    for (uint32_t b = 0; b < nb; ++b) key[len + b] = bytes[a + b];
+                    h = fold_chunk(h, key + len, nb);
+                    len += nb;
+                }
+            }
+            if (h == kEmptyKey) h ^= 1ull;
+            const uint32_t s = slot_of_hash(mix64(h), cap);
+            found            = constraint_lookup(key, len, h, table[s], s, table, cap, jbytes, joff);
+        }
+        out[i] = found;
+    }
+}
 // key functor of one length: admissible iff the probe found the window in J; key = its pattern number
 struct KeyMember {
     const uint32_t* memb;

@@ -543,11 +543,11 @@ __global__ __launch_bounds__(kBlock) void skip_filter_store_kernel(const uint32_
         res_cnt[base + j] = tmp[n + j];
     }
 }
-__global__ __launch_bounds__(kBlock) void skip_remap_ids_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ nlist, uint32_t* __restrict__ ids,
-                                                                 const uint32_t* __restrict__ flag, const unsigned long long* __restrict__ off, uint32_t base) {
-    const uint32_t n = *nlist;
+__global__ __launch_bounds__(kBlock) void skip_remap_ids_kernel(const uint32_t* __restrict__ list /* NULL: every position */, const uint32_t* __restrict__ nlist, uint32_t npos,
+                                                                 uint32_t* __restrict__ ids, const uint32_t* __restrict__ flag, const unsigned long long* __restrict__ off, uint32_t base) {
+    const uint32_t n = list != nullptr ? *nlist : npos;
     for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
-        const uint32_t p = list[j], s = ids[p];
+        const uint32_t p = list != nullptr ? list[j] : j, s = ids[p];
         if (s != kInvalid) ids[p] = flag[s - base] ? base + (uint32_t)off[s - base] : kInvalid;
     }
 }

@@ -316,8 +316,17 @@ class PatternModel : public MapType, public PatternModelInterface {
         colibri_host::ConstraintKeys ck;
         uint64_t                     constraint_tokens = 0, constraint_types = 0, loaded_patterns = 0;
         if (constrainbymodel != NULL) {
-            if (options.DOSKIPGRAMS || options.DOSKIPGRAMS_EXHAUSTIVE) {
-                std::cerr << "ERROR: skipgrams in a constrained run are not on the MI355X-accelerated path" << std::endl;
+            if (options.DOSKIPGRAMS && !options.DOSKIPGRAMS_EXHAUSTIVE && !inplace) {  // reference :941-956
+                options.DOSKIPGRAMS            = false;
+                options.DOSKIPGRAMS_EXHAUSTIVE = true;
+                if (!options.QUIET)
+                    std::cerr << "WARNING: Skipgrams will be extracted exhaustively on the basis of the ngrams found; the constraint model will be applied only afterwards. "
+                                 "This implies some skipgrams in the constraint model that are present may be missed, and it will not be most efficient. Use in-place "
+                                 "rebuilding of your constraint model instead."
+                              << std::endl;
+            }
+            if (inplace && (options.DOSKIPGRAMS || options.DOSKIPGRAMS_EXHAUSTIVE)) {
+                std::cerr << "ERROR: skipgrams in an in-place constrained rebuild (trainskipgrams_selfconstrained) are not on the MI355X-accelerated path" << std::endl;
                 throw InternalError();
             }
             if (!constrainbymodel->collect_keys(ck.off, ck.bytes)) {

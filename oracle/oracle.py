@@ -198,14 +198,18 @@ def ref_train(corpus_path: str, mode: str, maxlength: int, mintokens: int, *, mi
 
 
 # ---- constrained training ------------------------------------------------------------------------------------------
-def train_constrained(payload: bytes, constraint, mintokens=2, maxlength=100, minlength=1, indexed=False, firstsentence=1) -> "Model":
+def train_constrained(payload: bytes, constraint, mintokens=2, maxlength=100, minlength=1, indexed=False, firstsentence=1, doskipgrams=False, mintokens_skipgrams=-1,
+                      minskiptypes=2, maxskips=3) -> "Model":
     """PatternModel::train(..., constrainbymodel) restated (reference include/patternmodel.h:1062-1072: every n-gram of every length
     MINLENGTH..MAXLENGTH of every sentence in ONE pass; :1088-1089: counted iff the constraint model has it, no look-back; :1209-1217:
     prune(MINTOKENS) regardless of size). `constraint` = the key bytes of the constraint model's patterns. Pure Python: small inputs.
-    tokens = the corpus' tokens, types = 0 (what the C ABI reports; the totals quirks of the reference are the C++ face's)."""
+    tokens = the corpus' tokens, types = 0 (what the C ABI reports; the totals quirks of the reference are the C++ face's).
+    doskipgrams (either kind: :941-956 makes it the exhaustive one): at MINTOKENS = 1 — the only threshold at which the single pass reaches computeskipgrams
+    (:1163) — every member window of three or more tokens also counts each of its masked forms the constraint model holds (:1410-1411); they are pruned by the
+    BASE pruneskipgrams for either model type (:1236, :2167-2186): below MINTOKENS_SKIPGRAMS when MINSKIPTYPES > 1, not at all otherwise."""
     constraint = set(constraint)
     thr = 2 if mintokens == -1 else max(1, mintokens)
-    counts, refs = {}, {}
+    counts, refs, skips = {}, {}, {}
     sentence, tokens = firstsentence - 1, 0
     toks, start, prevhigh = [], 0, False
     sentences = []
@@ -231,7 +235,16 @@ def train_constrained(payload: bytes, constraint, mintokens=2, maxlength=100, mi
                     counts[k] = counts.get(k, 0) + 1
                     if indexed:
                         refs.setdefault(k, []).append((sentence, i))
+                    if doskipgrams and thr == 1 and n >= 3:
+                        for mask in skip_configurations(n, maxskips):
+                            sk = b"".join(b"\x03" if (mask >> j) & 1 else toks[i + j] for j in range(n))
+                            if sk in constraint:
+                                skips[sk] = skips.get(sk, 0) + 1
+                                if indexed:
+                                    refs.setdefault(sk, []).append((sentence, i))
     counts = {k: c for k, c in counts.items() if c >= thr}
+    skipthr = max(thr, mintokens_skipgrams) if minskiptypes > 1 else 1
+    counts.update({k: c for k, c in skips.items() if c >= skipthr})
     return Model(tokens, 0, counts, {k: sorted(refs[k]) for k in counts} if indexed else None)
 
 
@@ -269,7 +282,7 @@ def train_continued(payload: bytes, loaded: "Model", mintokens=2, maxlength=100,
     refs = {k: list(v) for k, v in loaded.refs.items()} if indexed else None
     have = {}
     for k in counts:
-        if 2 not in k and 3 not in [b for b in k if b < 128]:  # n-grams only (02 / 03 as a token are the gap classes)
+        if not any(t in (b"\x03", b"\x04") for t in key_tokens(k)):  # n-grams only (the one-byte tokens 03 / 04 are the skip / flex classes, classencoder.h:61-62)
             have[key_ntokens(k)] = True
     sentences = _sentences(payload)
     for n in range(1, maxlength + 1):

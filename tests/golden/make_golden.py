@@ -156,6 +156,20 @@ def main():
                                     ("I_self.i.t2", "hamlet.v2", "i", ["5", "2", "-I", ch])]:
         out = os.path.join(HERE, f"constrained.{tag}.txt")
         subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{corpus}.colibri.dat"), mode] + args + ["-q", "-d", out], stdout=subprocess.DEVNULL)
+    # skipgrams in a constrained run (-j with -s): constraint models WITH skipgrams, written by the reference; only a run at -t 1 computes any (patternmodel.h:1163)
+    chs = os.path.join(HERE, "constraint.hamlet.us.l5.patternmodel")
+    subprocess.check_call([DRIVER, "train", os.path.join(HERE, "hamlet.v2.colibri.dat"), "us", "5", "2", "-q", "-o", chs], stdout=subprocess.DEVNULL)
+    czs = os.path.join(HERE, "constraint.zipf20k.us.l4t3.patternmodel")
+    subprocess.check_call([DRIVER, "train", os.path.join(HERE, "zipf20k.colibri.dat"), "us", "4", "3", "-q", "-o", czs], stdout=subprocess.DEVNULL)
+    for tag, corpus, mode, args in [("js_hamlet.us.t1", "hamlet.v2", "us", ["5", "1", "-j", chs]), ("js_hamlet.us.t1T1", "hamlet.v2", "us", ["5", "1", "-T", "1", "-j", chs]),
+                                    ("js_hamlet.us.t1y3", "hamlet.v2", "us", ["5", "1", "-y", "3", "-j", chs]), ("js_hamlet.is.t1", "hamlet.v2", "is", ["5", "1", "-j", chs]),
+                                    ("js_hamlet.is.t1T1", "hamlet.v2", "is", ["5", "1", "-T", "1", "-j", chs]), ("js_edge.us.t1", "edge", "us", ["5", "1", "-j", chs]),
+                                    ("js_hamlet.us.t2", "hamlet.v2", "us", ["5", "2", "-j", chs]), ("js_hamlet.is.t2", "hamlet.v2", "is", ["4", "2", "-j", chs]),
+                                    ("js_zipf.us.t1", "phrases15k", "us", ["4", "1", "-j", czs]), ("js_zipf.us.t1y4", "phrases15k", "us", ["4", "1", "-y", "4", "-j", czs]),
+                                    ("js_zipf.is.t1", "phrases15k", "is", ["4", "1", "-j", czs]), ("js_zipf.is.t1y4", "phrases15k", "is", ["4", "1", "-y", "4", "-j", czs]),
+                                    ("js_zipf.is.t1y4T1", "phrases15k", "is", ["4", "1", "-y", "4", "-T", "1", "-j", czs])]:
+        out = os.path.join(HERE, f"constrained.{tag}.txt")
+        subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{corpus}.colibri.dat"), mode] + args + ["-q", "-d", out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     # continued training (patternmodeller -i <model> -f <corpus> -e 1 -E = train(..., continued = true)): models written by the reference, kept as fixtures, then
     # continued by the reference to longer patterns — on the same corpus under another threshold, and on a different corpus
     ez = os.path.join(HERE, "continued.zipf20k.u.t3l2.patternmodel")

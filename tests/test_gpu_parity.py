@@ -393,3 +393,41 @@ def test_continued_training_refuses_what_it_does_not_reproduce(ctx):
                 ctx.train(**{"mintokens": 2, "maxlength": 5, **kw})
     finally:
         ctx.set_continuation([])
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_constrained_skipgrams_match_the_restatement(ctx, seed):
+    """Skipgrams in a constrained run (reference include/patternmodel.h:1163-1171, computeskipgrams :1410-1411): at MINTOKENS = 1 the masked forms of member
+    windows count iff the constraint set holds them; with a higher threshold the run has none. Constraint sets: random windows of the corpus plus random
+    masked forms of them (and some that occur nowhere)."""
+    import oracle
+    rng = np.random.default_rng(7300 + seed)
+    corpora = small_corpora()
+    name = sorted(corpora)[seed % len(corpora)]
+    payload = corpora[name]
+    maxlength = int(rng.choice([3, 4, 5, 7]))
+    mintokens = 1 if seed % 4 else 2
+    indexed = bool(seed % 2)
+    keys = set(_random_constraint(rng, payload, maxlength))
+    for k in list(keys):  # masked forms of some member windows
+        t = oracle.key_tokens(k)
+        if len(t) >= 3 and rng.random() < 0.7:
+            masks = oracle.skip_configurations(len(t), 3)
+            for mask in rng.choice(masks, size=min(len(masks), 2), replace=False):
+                keys.add(b"".join(b"\x03" if (int(mask) >> j) & 1 else t[j] for j in range(len(t))))
+    keys.add(b"\x06\x03\x06")
+    keys = sorted(keys)
+    y, T = int(rng.choice([-1, 2, 3])), int(rng.choice([1, 2]))
+    want = oracle.train_constrained(payload, keys, mintokens, maxlength, 1, indexed=indexed, doskipgrams=True, mintokens_skipgrams=y, minskiptypes=T)
+    ctx.upload(payload)
+    try:
+        ctx.set_constraint(keys)
+        for table_mode in (0, 1):
+            st = ctx.train(mintokens=mintokens, maxlength=maxlength, indexed=int(indexed), doskipgrams_exhaustive=1, mintokens_skipgrams=y, minskiptypes=T, table_mode=table_mode)
+            got, gotrefs = ctx.export_dict()
+            assert got == want.counts, (name, table_mode)
+            if indexed:
+                assert gotrefs == want.refs
+            assert st.npatterns == len(want)
+    finally:
+        ctx.set_constraint([])

@@ -252,6 +252,19 @@ CONSTRAINED = {  # golden tag -> (corpus, unindexed?, CLI flags)
     "I_zipf.u.t2": ("phrases15k", True, ["-l", "5", "-t", "2", "-I", "-i", "constraint.zipf20k.u.l5.patternmodel"]),
     "I_zipf.i.t1": ("phrases15k", False, ["-l", "5", "-t", "1", "-I", "-i", "constraint.zipf20k.u.l5.patternmodel"]),
     "I_self.i.t2": ("hamlet.v2", False, ["-l", "5", "-t", "2", "-I", "-i", "constraint.hamlet.i.l5.patternmodel"]),
+    # -s with -j: the masked forms of member windows that the constraint model holds — computed only by a run at -t 1 (reference include/patternmodel.h:1163)
+    "js_hamlet.us.t1": ("hamlet.v2", True, ["-l", "5", "-t", "1", "-s", "-j", "constraint.hamlet.us.l5.patternmodel"]),
+    "js_hamlet.us.t1T1": ("hamlet.v2", True, ["-l", "5", "-t", "1", "-s", "-T", "1", "-j", "constraint.hamlet.us.l5.patternmodel"]),
+    "js_hamlet.us.t1y3": ("hamlet.v2", True, ["-l", "5", "-t", "1", "-s", "-y", "3", "-j", "constraint.hamlet.us.l5.patternmodel"]),
+    "js_hamlet.is.t1": ("hamlet.v2", False, ["-l", "5", "-t", "1", "-s", "-j", "constraint.hamlet.us.l5.patternmodel"]),
+    "js_edge.us.t1": ("edge", True, ["-l", "5", "-t", "1", "-s", "-j", "constraint.hamlet.us.l5.patternmodel"]),
+    "js_hamlet.us.t2": ("hamlet.v2", True, ["-l", "5", "-t", "2", "-s", "-j", "constraint.hamlet.us.l5.patternmodel"]),
+    "js_hamlet.is.t2": ("hamlet.v2", False, ["-l", "4", "-t", "2", "-s", "-j", "constraint.hamlet.us.l5.patternmodel"]),
+    "js_zipf.us.t1": ("phrases15k", True, ["-l", "4", "-t", "1", "-s", "-j", "constraint.zipf20k.us.l4t3.patternmodel"]),
+    "js_zipf.us.t1y4": ("phrases15k", True, ["-l", "4", "-t", "1", "-s", "-y", "4", "-j", "constraint.zipf20k.us.l4t3.patternmodel"]),
+    "js_zipf.is.t1": ("phrases15k", False, ["-l", "4", "-t", "1", "-s", "-j", "constraint.zipf20k.us.l4t3.patternmodel"]),
+    "js_zipf.is.t1y4": ("phrases15k", False, ["-l", "4", "-t", "1", "-s", "-y", "4", "-j", "constraint.zipf20k.us.l4t3.patternmodel"]),
+    "js_zipf.is.t1y4T1": ("phrases15k", False, ["-l", "4", "-t", "1", "-s", "-y", "4", "-T", "1", "-j", "constraint.zipf20k.us.l4t3.patternmodel"]),
 }
 
 

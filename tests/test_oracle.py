@@ -226,6 +226,20 @@ CONSTRAINED_GOLDENS = {  # tag -> (corpus, constraint model, indexed, mintokens,
     "I_zipf.u.t2": ("phrases15k", "constraint.zipf20k.u.l5.patternmodel", False, 2, 5, 1),
     "I_zipf.i.t1": ("phrases15k", "constraint.zipf20k.u.l5.patternmodel", True, 1, 5, 1),
     "I_self.i.t2": ("hamlet.v2", "constraint.hamlet.i.l5.patternmodel", True, 2, 5, 1),
+    # with skipgrams (ref_driver modes us / is with -j): only a run at MINTOKENS = 1 computes any; extra = (MINTOKENS_SKIPGRAMS, MINSKIPTYPES)
+    "js_hamlet.us.t1": ("hamlet.v2", "constraint.hamlet.us.l5.patternmodel", False, 1, 5, 1, (-1, 2)),
+    "js_hamlet.us.t1T1": ("hamlet.v2", "constraint.hamlet.us.l5.patternmodel", False, 1, 5, 1, (-1, 1)),
+    "js_hamlet.us.t1y3": ("hamlet.v2", "constraint.hamlet.us.l5.patternmodel", False, 1, 5, 1, (3, 2)),
+    "js_hamlet.is.t1": ("hamlet.v2", "constraint.hamlet.us.l5.patternmodel", True, 1, 5, 1, (-1, 2)),
+    "js_hamlet.is.t1T1": ("hamlet.v2", "constraint.hamlet.us.l5.patternmodel", True, 1, 5, 1, (-1, 1)),
+    "js_edge.us.t1": ("edge", "constraint.hamlet.us.l5.patternmodel", False, 1, 5, 1, (-1, 2)),
+    "js_hamlet.us.t2": ("hamlet.v2", "constraint.hamlet.us.l5.patternmodel", False, 2, 5, 1, (-1, 2)),
+    "js_hamlet.is.t2": ("hamlet.v2", "constraint.hamlet.us.l5.patternmodel", True, 2, 4, 1, (-1, 2)),
+    "js_zipf.us.t1": ("phrases15k", "constraint.zipf20k.us.l4t3.patternmodel", False, 1, 4, 1, (-1, 2)),
+    "js_zipf.us.t1y4": ("phrases15k", "constraint.zipf20k.us.l4t3.patternmodel", False, 1, 4, 1, (4, 2)),
+    "js_zipf.is.t1": ("phrases15k", "constraint.zipf20k.us.l4t3.patternmodel", True, 1, 4, 1, (-1, 2)),
+    "js_zipf.is.t1y4": ("phrases15k", "constraint.zipf20k.us.l4t3.patternmodel", True, 1, 4, 1, (4, 2)),
+    "js_zipf.is.t1y4T1": ("phrases15k", "constraint.zipf20k.us.l4t3.patternmodel", True, 1, 4, 1, (4, 1)),
 }
 
 
@@ -233,11 +247,13 @@ CONSTRAINED_GOLDENS = {  # tag -> (corpus, constraint model, indexed, mintokens,
 def test_constrained_restatement_matches_reference_dumps(tag):
     """oracle.train_constrained against ref_driver train ... -j / -I (pattern set, counts, reference lists; the totals are the C++ face's)"""
     import oracle
-    corpus, cmodel, indexed, mintokens, maxlength, minlength = CONSTRAINED_GOLDENS[tag]
+    corpus, cmodel, indexed, mintokens, maxlength, minlength = CONSTRAINED_GOLDENS[tag][:6]
+    skip = CONSTRAINED_GOLDENS[tag][6] if len(CONSTRAINED_GOLDENS[tag]) > 6 else None
     payload = open(os.path.join(GOLDEN, corpus + ".colibri.dat"), "rb").read()[2:]
     want = oracle.parse_dump(open(os.path.join(GOLDEN, f"constrained.{tag}.txt")).read(), indexed=indexed)
     # the constraint model is loaded under the run's own options (src/patternmodeller.cpp:712-718): its patterns below MINTOKENS are not read
-    got = oracle.train_constrained(payload, _model_keys(os.path.join(GOLDEN, cmodel), mintokens), mintokens, maxlength, minlength, indexed=indexed)
+    kw = dict(doskipgrams=True, mintokens_skipgrams=skip[0], minskiptypes=skip[1]) if skip else {}
+    got = oracle.train_constrained(payload, _model_keys(os.path.join(GOLDEN, cmodel), mintokens), mintokens, maxlength, minlength, indexed=indexed, **kw)
     assert got.counts == want.counts
     if indexed:
         assert got.refs == want.refs

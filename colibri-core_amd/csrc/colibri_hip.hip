@@ -103,6 +103,10 @@ struct colibri_ctx {
         // colibri_set_continuation: the set is not a constraint but the model a continued run starts from (train(..., continued = true)): the orders it has
         // n-grams of are not counted again, their windows only get the patterns' numbers as survivor ids for the look-back of the next order
         bool                       continuation = false;
+        // colibri_set_filter: the set is train()'s `filter` (patternmodel.h:1106-1133): a window is counted iff it contains one of the set's n-grams or is an
+        // instance of one of its skipgrams; no look-back. shapes = the (length, gap mask) pairs of the set's skipgrams
+        bool                       filter = false;
+        std::vector<std::pair<int, uint32_t>> shapes;
         uint64_t                   orders[2]    = {0, 0};  // bit n: the set has n-grams of n tokens (n < 128)
         bool has_order(int n) const { return n >= 1 && n < 128 && ((orders[n >> 6] >> (n & 63)) & 1ull); }
     } cs;
@@ -395,7 +399,11 @@ int check_options(colibri_ctx* c, colibri_options& o) {
     if (o.mintokens == 0) o.mintokens = 1;
     if (o.mintokens_skipgrams < o.mintokens) o.mintokens_skipgrams = o.mintokens;  // :887-888
     if (o.maxlength < 1) return fail(c, COLIBRI_ERR_ARG, "MAXLENGTH must be >= 1");
-    const bool constrained = c->cs.n != 0 && !c->cs.continuation;  // a constraint set makes the run single-pass by definition: every threshold and minimum length is fine
+    const bool constrained = c->cs.n != 0 && !c->cs.continuation && !c->cs.filter;  // a constraint set makes the run single-pass by definition: every threshold and minimum length is fine
+    // a filtered run (patternmodel.h:1106-1133): every order counts the windows that match the filter, by their bytes, without look-back
+    if (c->cs.n != 0 && c->cs.filter &&
+        (o.doskipgrams || o.doskipgrams_exhaustive || o.dopatternperline || o.minlength > 1 || o.maxbackofflength < o.maxlength || o.mintokens_unigrams > o.mintokens || c->npos >= 0x7FFFFFF0u))
+        return fail(c, COLIBRI_ERR_UNSUPPORTED, "training with a filter is on the accelerated path for MINLENGTH = 1, without skipgrams, back-off length, word threshold or pattern list");
     // a continued run (patternmodel.h:983-995): the orders the loaded model lacks are counted with the usual look-back, which asks the loaded patterns too
     if (c->cs.n != 0 && c->cs.continuation &&
         (o.mintokens < 2 || o.doskipgrams || o.doskipgrams_exhaustive || o.dopatternperline || o.minlength > 1 || o.maxbackofflength < o.maxlength || o.mintokens_unigrams > o.mintokens))
@@ -1393,10 +1401,11 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     if (o.dopatternperline) return train_pattern_list(c, o, stats_out);
 
     const uint32_t npos   = c->npos;
-    const bool     constrained = c->cs.n != 0 && !c->cs.continuation;  // train(..., constrainbymodel): one membership-filtered pass per length, no look-back (constrained.hpp)
+    const bool     constrained = c->cs.n != 0 && !c->cs.continuation && !c->cs.filter;  // train(..., constrainbymodel): one membership-filtered pass per length, no look-back (constrained.hpp)
+    const bool     filtered    = c->cs.n != 0 && c->cs.filter;         // train(..., filter): only the windows that match the set are counted, without look-back
     const bool     continued   = c->cs.n != 0 && c->cs.continuation;   // train(..., continued = true): the set is the model the run starts from
     const int      backoff = (o.maxbackofflength >= 1 && o.maxbackofflength + 1 < std::min<int>(o.maxlength, COLIBRI_MAX_ORDER - 1)) ? o.maxbackofflength : 0;  // orders above backoff + 1 differ
-    const bool     synced = o.indexed || o.doskipgrams || o.doskipgrams_exhaustive || constrained || backoff || continued;  // these modes keep every order's ids and talk to the host per order
+    const bool     synced = o.indexed || o.doskipgrams || o.doskipgrams_exhaustive || constrained || backoff || continued || filtered;  // these modes keep every order's ids and talk to the host per order
     // order 1 counted per class id when the encoding is canonical (class id <-> token bytes is then a bijection) and the class
     // space is small enough for a dense array; table_mode 1 / 2 force the generic table / radix implementations (tests)
     const bool uni_direct = !synced && o.table_mode == 0 && !(c->flags & kFlagNonCanonical) && c->maxclass < (1u << 28);
@@ -1589,7 +1598,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
         std::vector<uint32_t> valid_n(maxlength + 2, 0), adm_n(maxlength + 2, 0), ngram_first(maxlength + 2, 0), ngram_kept(maxlength + 2, 0);
         uint32_t              res_total = 0;
         const uint32_t        thr_skip  = o.minskiptypes > 1 ? (uint32_t)o.mintokens_skipgrams : pl.thr;  // base pruneskipgrams is a no-op when MINSKIPTYPES <= 1 (patternmodel.h:2167-2186)
-        if (constrained || continued) {
+        if (constrained || continued || filtered) {
             if (!c->cs.rem_valid) {
                 if ((rc = dev_alloc(c, c->cs.rem, (size_t)npos + 1))) return rc;
                 hipLaunchKernelGGL(sentence_rem_kernel, dim3(stream_grid(npos)), dim3(kBlock), 0, c->stream, c->delimpos.p, c->ndelim, npos, c->cs.rem.p);
@@ -1606,7 +1615,10 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
         DevBuf<unsigned long long> bo_off, bo_unit, bo_rank;
         DevBuf<FSlot>              bo_table;
         DevBuf<FlexInfo>           bo_info;
+        DevBuf<uint8_t>            flt_cont[2];            // filtered runs: "the window at i contains a filter n-gram", this length / the one below
+        DevBuf<uint32_t>           flt_exists, flt_memb;   // ... gate and result of the probes for the filter's skipgram shapes
         auto                       bo_cleanup = [&]() {
+            dev_free(flt_cont[0]); dev_free(flt_cont[1]); dev_free(flt_exists); dev_free(flt_memb);
             dev_free(bo_run); dev_free(bo_flen); dev_free(bo_slot); dev_free(bo_isrep); dev_free(bo_keep); dev_free(bo_off); dev_free(bo_unit); dev_free(bo_rank); dev_free(bo_table); dev_free(bo_info);
         };
         struct BoGuard {
@@ -1647,22 +1659,43 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             }
             const KeyMember member{c->cs.memb.p + (size_t)(constrained ? n - probed_from : 0) * ((size_t)npos + 1)};
             if (!(n == 1 && uni_synced) && !radix_pass) launch_clear(c, pl);  // only the table passes need the table cleared
-            const bool backoff_pass = backoff && n > backoff + 1;
+            const bool backoff_pass = (backoff && n > backoff + 1) || filtered;
             if (backoff_pass) {
-                // every window whose sub-patterns of `backoff` tokens all survived is a candidate; its identity is its bytes (patternlist.hpp)
+                // back-off: every window whose sub-patterns of `backoff` tokens all survived is a candidate; filtered run: every window that matches the filter
+                // is (no look-back, patternmodel.h:1106-1137). Either way a candidate's identity is its bytes (patternlist.hpp)
                 if (!bo_runs_valid) {
                     if ((rc = dev_alloc(c, bo_run, (size_t)npos + 1)) || (rc = dev_alloc(c, bo_flen, (size_t)npos + 1)) || (rc = dev_alloc(c, bo_slot, (size_t)npos + 1)) ||
                         (rc = dev_alloc(c, bo_isrep, (size_t)npos + 1)) || (rc = dev_alloc(c, bo_keep, (size_t)npos + 1)) || (rc = dev_alloc(c, bo_off, (size_t)npos + 1)) ||
                         (rc = dev_alloc(c, bo_unit, (size_t)npos + 1)) || (rc = dev_alloc(c, bo_rank, (size_t)npos + 1)) || (rc = dev_alloc(c, bo_info, 1)))
                         return rc;
-                    Prof p(c, COLIBRI_K_COUNT);
-                    hipLaunchKernelGGL(backoff_runs_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->ids[backoff].p, npos, bo_run.p);
+                    if (!filtered) {
+                        Prof p(c, COLIBRI_K_COUNT);
+                        hipLaunchKernelGGL(backoff_runs_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->ids[backoff].p, npos, bo_run.p);
+                    }
                     bo_runs_valid = true;
+                }
+                if (filtered) {  // bo_run[i] = 1 where the window of n tokens at i matches the filter
+                    if ((rc = dev_alloc(c, flt_cont[0], (size_t)npos + 1)) || (rc = dev_alloc(c, flt_cont[1], (size_t)npos + 1)) || (rc = dev_alloc(c, flt_exists, (size_t)npos + 1)) ||
+                        (rc = dev_alloc(c, flt_memb, (size_t)npos + 1)))
+                        return rc;
+                    Prof p(c, COLIBRI_K_COUNT);
+                    const bool have_n = c->cs.has_order(n);
+                    if (have_n)
+                        hipLaunchKernelGGL(constraint_probe_kernel<false>, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, c->cs.rem.p, c->cs.table.p, c->cs.cap,
+                                           c->cs.bytes.p, c->cs.off.p, npos, n, 1, c->cs.memb.p, (size_t)npos + 1, (const uint32_t*)nullptr);
+                    hipLaunchKernelGGL(filter_contains_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cs.rem.p, have_n ? (const uint32_t*)c->cs.memb.p : (const uint32_t*)nullptr,
+                                       n > 1 ? (const uint8_t*)flt_cont[(n - 1) & 1].p : (const uint8_t*)nullptr, npos, (uint32_t)n, flt_cont[n & 1].p, bo_run.p, flt_exists.p);
+                    for (const auto& shape : c->cs.shapes) {
+                        if (shape.first != n) continue;
+                        hipLaunchKernelGGL(constraint_probe_masked_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->bytes.p, c->tokstart.p, flt_exists.p, c->cs.table.p, c->cs.cap,
+                                           c->cs.bytes.p, c->cs.off.p, npos, n, shape.second, flt_memb.p);
+                        hipLaunchKernelGGL(filter_or_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, flt_memb.p, npos, bo_run.p);
+                    }
                 }
                 {
                     Prof p(c, COLIBRI_K_COUNT);
                     hipLaunchKernelGGL(backoff_select_kernel, dim3(stream_grid((uint64_t)npos + 1)), dim3(kBlock), 0, c->stream, bo_run.p, c->tokstart.p, npos, (uint32_t)n,
-                                       (uint32_t)(n - backoff + 1), bo_flen.p, bo_off.p, bo_unit.p, c->state.p);
+                                       filtered ? 1u : (uint32_t)(n - backoff + 1), bo_flen.p, bo_off.p, bo_unit.p, c->state.p);
                 }
                 if ((rc = read_state(c))) return rc;
                 const uint32_t cand = c->hstate.admitted;
@@ -1769,11 +1802,11 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             adm_n[n]   = c->hstate.admitted;
             valid_n[n] = c->hstate.valid;
             s.admitted[n] = adm_n[n];
-            if (found == 0 && !constrained && !continued) break;  // "None found" (patternmodel.h:1189-1194: `if (!continued) break`); a constrained run is one pass over all lengths
+            if (found == 0 && !constrained && !continued && !(filtered && pl.thr == 1)) break;  // "None found" (patternmodel.h:1189-1194: `if (!continued) break`); a constrained run is one pass over all lengths
             if (found) s.maxn = n;
             s.found[n] = found;
             s.kept[n]  = kept;
-            if (kept) c->segments.push_back({res_total, kept, n, (n == 1 && uni_synced) ? kMaskFromClass : 0u});
+            if (kept) c->segments.push_back({res_total, kept, n, (n == 1 && uni_synced && !backoff_pass) ? kMaskFromClass : 0u});
             ngram_first[n] = res_total;
             ngram_kept[n]  = kept;
             res_total += kept;
@@ -1830,7 +1863,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             if (!constrained) c->hstate.cap = (uint32_t)std::min<uint64_t>(pl.table_slots, (uint64_t)valid_n[n] + (valid_n[n] >> 1) + 1024u);
             c->hstate.found = c->hstate.kept = c->hstate.admitted = c->hstate.valid = 0;
             if ((rc = write_state(c))) return rc;
-            if (valid_n[n] == 0 && !constrained && !continued && !(backoff && n >= backoff + 1)) break;  // nothing can be admitted at n + 1 (a back-off order asks the order-b survivors instead)
+            if (valid_n[n] == 0 && !constrained && !continued && !filtered && !(backoff && n >= backoff + 1)) break;  // nothing can be admitted at n + 1 (a back-off order asks the order-b survivors instead)
         }
         if (o.doskipgrams && !constrained) {  // IndexedPatternModel::trainskipgrams (patternmodel.h:2969-3010): from the SURVIVING n-grams, n = 3..
             for (int n = 3; n <= std::min<int>(maxlength, s.maxn); ++n) {

@@ -218,6 +218,29 @@ __global__ __launch_bounds__(kBlock) void constraint_probe_masked_kernel(const u
         out[i] = found;
     }
 }
+// ---- train(..., filter) (reference include/patternmodel.h:1106-1133): a window of n tokens is counted iff one of its sub-n-grams (any length 1..n) is in the
+// filter set, or it is an instance of one of the set's skipgrams (same length, the non-gap tokens equal: src/pattern.cpp:1760-1785). Containment follows
+// the recurrence "a proper sub-n-gram lies in the first n-1 or in the last n-1 tokens": cont_n[i] = exists_n[i] && (member_n[i] || cont_{n-1}[i] ||
+// cont_{n-1}[i+1]); instances are looked up per gap shape with constraint_probe_masked_kernel.
+__global__ __launch_bounds__(kBlock) void filter_contains_kernel(const uint32_t* __restrict__ rem, const uint32_t* __restrict__ memb /* pattern numbers of this length, or NULL */,
+                                                                  const uint8_t* __restrict__ prev /* cont of the length below, or NULL */, uint32_t npos, uint32_t n,
+                                                                  uint8_t* __restrict__ cont, uint32_t* __restrict__ sel, uint32_t* __restrict__ exists) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npos; i += gridDim.x * kBlock) {
+        const bool e = rem[i] >= n;
+        bool       m = false;
+        if (e) {
+            m = memb != nullptr && memb[i] != kInvalid;
+            if (!m && prev != nullptr) m = prev[i] != 0 || (i + 1 < npos && prev[i + 1] != 0);
+        }
+        cont[i]   = m ? 1 : 0;
+        sel[i]    = m ? 1u : 0u;
+        exists[i] = e ? 0u : kInvalid;  // gate of the masked probes: kInvalid = no window of n tokens starts here
+    }
+}
+__global__ __launch_bounds__(kBlock) void filter_or_kernel(const uint32_t* __restrict__ memb, uint32_t npos, uint32_t* __restrict__ sel) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npos; i += gridDim.x * kBlock)
+        if (memb[i] != kInvalid) sel[i] = 1u;
+}
 // key functor of one length: admissible iff the probe found the window in J; key = its pattern number
 struct KeyMember {
     const uint32_t* memb;

@@ -103,7 +103,8 @@ struct ConstraintKeys {
 };
 /** upload + train + export through the C ABI; prints the library's message on stderr and throws InternalError on any status != 0 */
 void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out, const ConstraintKeys* constraint = NULL,
-                  bool keep_device = false, bool continuation = false /* the keys are the model a continued run starts from (colibri_set_continuation) */);
+                  bool keep_device = false, bool continuation = false /* the keys are the model a continued run starts from (colibri_set_continuation) */,
+                  bool as_filter = false /* the keys are train()'s filter (colibri_set_filter) */);
 /** the same across `world` GPUs of this node (src/sharded.cpp): the corpus cut into contiguous sentence ranges, one device context and host thread per rank,
  *  RCCL for the exchange of candidate counts; the result is the union of the ranks' exports. Not for constrained runs and pattern lists. */
 void device_train_sharded(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out, int world);
@@ -300,10 +301,7 @@ class PatternModel : public MapType, public PatternModelInterface {
         if (options.MINTOKENS == 0) options.MINTOKENS = 1;
         if (options.MINTOKENS_SKIPGRAMS < options.MINTOKENS) options.MINTOKENS_SKIPGRAMS = options.MINTOKENS;
         if (filter != NULL && filter->size() == 0) filter = NULL;  // cython passes empty sets (reference :902-903)
-        if (filter != NULL) {
-            std::cerr << "ERROR: training with a filter is not on the MI355X-accelerated path" << std::endl;
-            throw InternalError();
-        }
+        if (filter != NULL && constrainbymodel != NULL) filter = NULL;  // the reference only consults the filter in unconstrained runs (:1106)
         if (continued && (constrainbymodel != NULL || (this->data.empty() && !result))) continued = false;  // nothing to continue from / a constrained run counts everything anyway (:985)
         if (continued) {
             train_continued(in, options, firstsentence);
@@ -350,6 +348,25 @@ class PatternModel : public MapType, public PatternModelInterface {
             std::cerr << "ERROR: train() on a non-empty model is not on the MI355X-accelerated path" << std::endl;
             throw InternalError();
         }
+        colibri_host::ConstraintKeys fk;  // train(..., filter): the filter's patterns (reference :899-914, :1106-1133)
+        if (filter != NULL) {
+            if (options.DOSKIPGRAMS || options.DOSKIPGRAMS_EXHAUSTIVE || options.MINLENGTH > 1 || options.DOPATTERNPERLINE || options.MAXBACKOFFLENGTH < options.MAXLENGTH ||
+                options.MINTOKENS_UNIGRAMS > options.MINTOKENS) {
+                std::cerr << "ERROR: training with a filter is on the MI355X-accelerated path for MINLENGTH = 1, without skipgrams, back-off length, word threshold or pattern list"
+                          << std::endl;
+                throw InternalError();
+            }
+            bool hasngrams = false, hasother = false;
+            fk.off.push_back(0);
+            for (typename PatternSet<>::iterator it = filter->begin(); it != filter->end(); ++it) {
+                (it->category() == NGRAM ? hasngrams : hasother) = true;
+                fk.bytes.insert(fk.bytes.end(), it->data, it->data + it->bytesize());
+                fk.off.push_back(fk.bytes.size());
+            }
+            if (!options.QUIET && hasngrams)
+                std::cerr << "Filter with ngrams provided, only patterns that either match a filtered pattern or contain a smaller filtered pattern will be included..." << std::endl;
+            if (!options.QUIET && hasother) std::cerr << "Filter with skipgrams provided, only matching instances will be included..." << std::endl;
+        }
         if (!options.QUIET) std::cerr << "Training patternmodel, occurrence threshold: " << options.MINTOKENS << std::endl;
 
         colibri_options o{};
@@ -370,7 +387,7 @@ class PatternModel : public MapType, public PatternModelInterface {
 
         std::shared_ptr<colibri_host::TrainResult> r = std::make_shared<colibri_host::TrainResult>();
         // an indexed skipgram model stays resident on the device until it is materialised on the host: computeflexgrams_fromskipgrams works on it there
-        const int  world = (constrainbymodel == NULL && !options.DOPATTERNPERLINE) ? colibri_host::gpus() : 1;  // sentence-sharded over that many GPUs (src/sharded.cpp)
+        const int  world = (constrainbymodel == NULL && filter == NULL && !options.DOPATTERNPERLINE) ? colibri_host::gpus() : 1;  // sentence-sharded over that many GPUs (src/sharded.cpp)
         const bool keep_device = world == 1 && o.indexed && o.doskipgrams && constrainbymodel == NULL && options.MINLENGTH <= 1;
         if (world > 1 || (world == 1 && constrainbymodel == NULL && !options.DOPATTERNPERLINE && std::getenv("COLIBRI_GPUS_FORCE_SHARDED") != NULL)) {  // (forced: the sharded protocol on one rank, for tests)
             std::vector<unsigned char> owned;
@@ -390,14 +407,15 @@ class PatternModel : public MapType, public PatternModelInterface {
             }
             colibri_host::device_train_sharded(p, nb, o, firstsentence, *r, world);
         } else if (reverseindex != NULL && !reverseindex->empty()) {
-            colibri_host::device_train(reverseindex->beginpointer(), reverseindex->bytesize(), o, firstsentence, *r, constrainbymodel ? &ck : NULL, keep_device);
+            colibri_host::device_train(reverseindex->beginpointer(), reverseindex->bytesize(), o, firstsentence, *r, constrainbymodel ? &ck : (filter ? &fk : NULL), keep_device,
+                                       false, filter != NULL);
         } else if (in != NULL) {
             const std::vector<unsigned char> payload = colibri_host::read_corpus_payload(*in);
             if (payload.empty()) {
                 std::cerr << "ERROR: Attempting to read pattern from file, but file is empty?" << std::endl;  // reference src/pattern.cpp:520-523
                 throw InternalError();
             }
-            colibri_host::device_train(payload.data(), payload.size(), o, firstsentence, *r, constrainbymodel ? &ck : NULL, keep_device);
+            colibri_host::device_train(payload.data(), payload.size(), o, firstsentence, *r, constrainbymodel ? &ck : (filter ? &fk : NULL), keep_device, false, filter != NULL);
         } else {
             std::cerr << "ERROR: No input stream and no reverse index (preloaded corpus) to train on" << std::endl;
             throw InternalError();
@@ -428,7 +446,7 @@ class PatternModel : public MapType, public PatternModelInterface {
         if (r->stats.maxn > maxn) maxn = r->stats.maxn;
         if (r->stats.npatterns && r->stats.minn < minn) minn = r->stats.minn;
         hasskipgrams_ = (options.DOSKIPGRAMS || options.DOSKIPGRAMS_EXHAUSTIVE);
-        types_settled_ = options.DOPATTERNPERLINE;
+        types_settled_ = options.DOPATTERNPERLINE || (filter != NULL && options.MINTOKENS == 1);  // (a filter without one-token matches at threshold 1: 0 types, as above)
         install_result(r);
         if (options.PRUNENONSUBSUMED || options.PRUNESUBSUMED) prune_by_subsumption(options);
     }

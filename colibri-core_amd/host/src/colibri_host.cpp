@@ -456,13 +456,17 @@ void device_flexgrams_resident(const std::shared_ptr<void>& device, TrainResult&
 }
 
 void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out, const ConstraintKeys* constraint,
-                  bool keep_device, bool continuation) {
+                  bool keep_device, bool continuation, bool as_filter) {
     CtxGuard    g;
     const char* dev = std::getenv("COLIBRI_DEVICE");
     int         rc  = colibri_create(&g.c, dev ? std::atoi(dev) : 0);
     if (rc != COLIBRI_OK) raise(nullptr, rc, "colibri_create");
     if ((rc = colibri_upload_corpus(g.c, payload, nbytes, firstsentence)) != COLIBRI_OK) raise(g.c, rc, "colibri_upload_corpus");
-    if (constraint != NULL && continuation) {
+    if (constraint != NULL && as_filter) {
+        const uint64_t             np   = constraint->off.empty() ? 0 : constraint->off.size() - 1;
+        static const unsigned char none = 0;
+        if (np && (rc = colibri_set_filter(g.c, constraint->off.data(), constraint->bytes.empty() ? &none : constraint->bytes.data(), np)) != COLIBRI_OK) raise(g.c, rc, "colibri_set_filter");
+    } else if (constraint != NULL && continuation) {
         const uint64_t             np   = constraint->off.empty() ? 0 : constraint->off.size() - 1;
         static const unsigned char none = 0;
         if (np && (rc = colibri_set_continuation(g.c, constraint->off.data(), constraint->bytes.empty() ? &none : constraint->bytes.data(), np)) != COLIBRI_OK)

@@ -109,7 +109,29 @@ int main(int argc, char** argv) {
         }
         const std::string kind = argv[4];
         try {
-            if (kind == "u") {
+            // f<model file>: train(..., filter) with the patterns of that file as the PatternSet<> (what the Python binding of the reference passes)
+            PatternSet<> filter;
+            for (int a = 7; a < argc; ++a) {
+                if (argv[a][0] != 'f') continue;
+                PatternModelOptions lo;
+                lo.MINTOKENS   = 1;
+                lo.DOSKIPGRAMS = true;
+                lo.QUIET       = true;
+                PatternSetModel source(std::string(argv[a] + 1), lo);
+                for (PatternSetModel::iterator it = source.begin(); it != source.end(); ++it) filter.insert(it->first);
+            }
+            if (filter.size() && kind == "u") {
+                PatternModel<uint32_t> model;
+                model.train(std::string(argv[2]), options, NULL, &filter);
+                model.write(std::string(argv[3]));
+                std::cout << model.size() << " " << model.tokens() << " " << model.types() << " " << model.maxlength() << std::endl;
+            } else if (filter.size()) {
+                IndexedCorpus         corpus{std::string(argv[2])};
+                IndexedPatternModel<> model(&corpus);
+                model.train(std::string(argv[2]), options, NULL, &filter);
+                model.write(std::string(argv[3]));
+                std::cout << model.size() << " " << model.tokens() << " " << model.types() << " " << model.maxlength() << std::endl;
+            } else if (kind == "u") {
                 PatternModel<uint32_t> model;
                 model.train(std::string(argv[2]), options);
                 model.write(std::string(argv[3]));

@@ -23,7 +23,7 @@ EXPORTED = [
     "colibri_shard_begin", "colibri_shard_count", "colibri_shard_send", "colibri_shard_merge", "colibri_shard_reply", "colibri_shard_apply",
     "colibri_shard_finish", "colibri_shard_export_gids", "colibri_shard_index_sizes", "colibri_shard_export_index",
     "colibri_shard_uni_info", "colibri_shard_uni_count", "colibri_shard_uni_apply",
-    "colibri_set_constraint", "colibri_set_continuation", "colibri_text_upload", "colibri_text_count", "colibri_text_words", "colibri_text_encode", "colibri_text_fetch", "colibri_text_as_corpus",
+    "colibri_set_constraint", "colibri_set_continuation", "colibri_set_filter", "colibri_text_upload", "colibri_text_count", "colibri_text_words", "colibri_text_encode", "colibri_text_fetch", "colibri_text_as_corpus",
     "colibri_flexgrams", "colibri_flexgrams_resident", "colibri_flexgrams_fetch",
 ]
 
@@ -85,6 +85,7 @@ def load():
         L.colibri_text_as_corpus.argtypes = [C.c_void_p, C.c_uint32]
         L.colibri_set_constraint.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.colibri_set_continuation.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.colibri_set_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.colibri_flexgrams.argtypes = [C.c_void_p] * 6 + [C.c_uint64] + [C.POINTER(C.c_uint64)] * 3
         L.colibri_flexgrams_fetch.argtypes = [C.c_void_p] * 7
         L.colibri_flexgrams_resident.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 3
@@ -193,6 +194,15 @@ class Context:
         off[1:] = np.cumsum([len(k) for k in keys])
         blob = np.frombuffer(b"".join(keys) or b"\0", dtype=np.uint8)
         self._check(self.L.colibri_set_continuation(self.h, off.ctypes.data, blob.ctypes.data, len(keys)))
+
+    def set_filter(self, keys):
+        """colibri_set_filter: the next train() calls count only the windows that contain one of these n-grams or are an instance of one of these skipgrams
+        (train(..., filter)); an empty list ends the mode."""
+        keys = list(keys)
+        off = np.zeros(len(keys) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(k) for k in keys])
+        blob = np.frombuffer(b"".join(keys) or b"\0", dtype=np.uint8)
+        self._check(self.L.colibri_set_filter(self.h, off.ctypes.data, blob.ctypes.data, len(keys)))
 
     # -- training --------------------------------------------------------------------------------
     def train(self, options=None, **kw):

@@ -210,6 +210,11 @@ int colibri_set_constraint(colibri_ctx* ctx, const uint64_t* key_off, const uint
  * others); stats.totaltokens is the corpus' (the reference leaves the model's total untouched: the C++ face ignores it). MINTOKENS >= 2,
  * no skipgrams. npatterns = 0 (or colibri_set_constraint) ends the mode. */
 int colibri_set_continuation(colibri_ctx* ctx, const uint64_t* key_off, const uint8_t* key_bytes, uint64_t npatterns);
+/* Filtered training: replaces PatternModel::train(..., filter) (reference include/patternmodel.h:899-914, :1106-1137). While a filter set is installed, colibri_train
+ * counts at every order exactly the windows that contain one of the set's n-grams (as a sub-n-gram of any length) or are an instance of one of its skipgrams
+ * (same length, non-gap tokens equal; flexgrams match nothing, src/pattern.cpp:1760-1785) — without look-back, then prunes by MINTOKENS per order; the run ends at
+ * the first order that finds nothing (MINTOKENS = 1: after MAXLENGTH). MINLENGTH = 1, no skipgrams. npatterns = 0 (or colibri_set_constraint) ends the mode. */
+int colibri_set_filter(colibri_ctx* ctx, const uint64_t* key_off, const uint8_t* key_bytes, uint64_t npatterns);
 
 /* ---- class encoder: plain text -> word frequency list -> class-encoded corpus -------------------------------------
  * Replaces the corpus-proportional work of ClassEncoder::processcorpus (reference src/classencoder.cpp:156-188: the word frequency

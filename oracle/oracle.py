@@ -307,6 +307,58 @@ def train_continued(payload: bytes, loaded: "Model", mintokens=2, maxlength=100,
     return Model(loaded.tokens, loaded.types, counts, refs)
 
 
+# ---- filtered training (train(..., filter)) --------------------------------------------------------------------------------------------
+def train_filtered(payload: bytes, filterkeys, mintokens=2, maxlength=100, indexed=False, firstsentence=1) -> "Model":
+    """PatternModel::train(in, options, NULL, filter) restated for MINLENGTH = 1 without skipgram options (reference include/patternmodel.h:899-914: which kinds of
+    patterns the filter holds; :1106-1133: a window passes iff one of its sub-n-grams of any length is in the filter, or it is an instance of one of the filter's
+    skipgrams — src/pattern.cpp:1760-1785: same length, every non-gap token equal; flexgrams match nothing; :1137-1152: a filtered order has NO look-back;
+    :1189-1194: the order loop ends at the first order that finds nothing; MINTOKENS = 1: one pass over all lengths, :1069-1072). Pure Python: small inputs."""
+    thr = 2 if mintokens == -1 else max(1, mintokens)
+    F = set(filterkeys)
+    ngrams = {k for k in F if key_category(k) == 1}
+    skipgrams = [key_tokens(k) for k in F if key_category(k) == 2]
+    has_ngrams, has_skip = bool(ngrams), any(key_category(k) != 1 for k in F)
+
+    def matches(toks):
+        n = len(toks)
+        if has_ngrams:
+            for m in range(1, n + 1):
+                for j in range(n - m + 1):
+                    if b"".join(toks[j:j + m]) in ngrams:
+                        return True
+        if has_skip:
+            for sk in skipgrams:
+                if len(sk) == n and all(a == b or a == b"\x03" for a, b in zip(sk, toks)):
+                    return True
+        return False
+
+    sentences = _sentences(payload)
+    counts, refs, tokens, types = {}, {}, sum(len(t) for t in sentences), 0
+    for n in range(1, maxlength + 1):
+        new, newrefs = {}, {}
+        sentence = firstsentence - 1
+        for toks in sentences:
+            sentence += 1
+            for i in range(len(toks) - n + 1):
+                w = toks[i:i + n]
+                if not matches(w):
+                    continue
+                k = b"".join(w)
+                new[k] = new.get(k, 0) + 1
+                if indexed:
+                    newrefs.setdefault(k, []).append((sentence, i))
+        if n == 1:
+            types = len(new)  # the unigrams that were counted, before pruning (:1199-1201)
+        if not new and thr > 1:
+            break
+        for k, c in new.items():
+            if c >= thr:
+                counts[k] = c
+                if indexed:
+                    refs[k] = sorted(newrefs[k])
+    return Model(tokens, types, counts, refs if indexed else None)
+
+
 # ---- one pattern per line (PatternModelOptions::DOPATTERNPERLINE, colibri-patternmodeller -L) -----------------------------------------
 def train_patternperline(payload: bytes, maxlength=100) -> "Model":
     """PatternModel::train with DOPATTERNPERLINE at MINTOKENS = 1 (the CLI's -L implies -t 1, src/patternmodeller.cpp:677-678) restated:

@@ -252,7 +252,7 @@ int main(int argc, char** argv) {
     options.MAXLENGTH = atoi(argv[4]);
     options.MINTOKENS = atoi(argv[5]);
     options.QUIET     = false;
-    std::string modelout, dumpout, constraintfile, inplacemodel, continuemodel;
+    std::string modelout, dumpout, constraintfile, inplacemodel, continuemodel, filterfile;
     bool flexfromskip = false;
     for (int i = 6; i < argc; ++i) {
         const std::string a = argv[i];
@@ -269,6 +269,7 @@ int main(int argc, char** argv) {
         else if (a == "-b" && i + 1 < argc) options.MAXBACKOFFLENGTH = atoi(argv[++i]);
         else if (a == "-L") { options.DOPATTERNPERLINE = true; options.MINTOKENS = 1; }  // patternmodeller -L: one pattern per line, implies -t 1 (src/patternmodeller.cpp:571-574, :677-678)
         else if (a == "-F") flexfromskip = true;  // computeflexgrams_fromskipgrams after training (patternmodeller -F S, src/patternmodeller.cpp:790-794), mode is
+        else if (a == "-f" && i + 1 < argc) filterfile = argv[++i];  // train(..., filter): the patterns of this model file as a PatternSet<> (modes u and i)
         else if (a == "-E" && i + 1 < argc) continuemodel = argv[++i];  // continue training on this loaded model (train(..., continued = true): patternmodeller -i <model> -E), modes u and i
         else if (a == "-I" && i + 1 < argc) inplacemodel = argv[++i];  // constrained in-place rebuild of this model (patternmodeller -I -i <model>), modes u and i
         else return usage();
@@ -285,7 +286,31 @@ int main(int argc, char** argv) {
     double load_s = 0, train_s = 0;
     using clk = std::chrono::steady_clock;
 
-    if (!continuemodel.empty() && (mode == "u" || mode == "i")) {  // src/patternmodeller.cpp:350-358 with continued = true
+    if (!filterfile.empty() && (mode == "u" || mode == "i")) {  // what the Python binding does with its `filter` argument (include/patternmodel.h:880, :899-914)
+        PatternModelOptions lo;
+        lo.MINTOKENS = 1;
+        lo.DOSKIPGRAMS = true;
+        lo.QUIET = true;
+        PatternSetModel source(filterfile, lo);
+        PatternSet<>    filter;
+        for (auto it = source.begin(); it != source.end(); ++it) filter.insert(*it);
+        if (mode == "u") {
+            PatternModel<uint32_t> model;
+            model.train(corpusfile, options, NULL, &filter);
+            tokens = model.tokens();
+            types  = model.types();
+            if (!modelout.empty()) model.write(modelout);
+            if (!dumpout.empty()) collect_unindexed(model, rows);
+        } else {
+            IndexedCorpus         corpus(corpusfile);
+            IndexedPatternModel<> model(&corpus);
+            model.train(corpusfile, options, NULL, &filter);
+            tokens = model.tokens();
+            types  = model.types();
+            if (!modelout.empty()) model.write(modelout);
+            if (!dumpout.empty()) collect_indexed(model, rows);
+        }
+    } else if (!continuemodel.empty() && (mode == "u" || mode == "i")) {  // src/patternmodeller.cpp:350-358 with continued = true
         if (mode == "u") {
             PatternModel<uint32_t> model(continuemodel, options, NULL, NULL);
             model.train(corpusfile, options, NULL, NULL, true);

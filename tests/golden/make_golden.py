@@ -170,6 +170,22 @@ def main():
                                     ("js_zipf.is.t1y4T1", "phrases15k", "is", ["4", "1", "-y", "4", "-T", "1", "-j", czs])]:
         out = os.path.join(HERE, f"constrained.{tag}.txt")
         subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{corpus}.colibri.dat"), mode] + args + ["-q", "-d", out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    # filtered training (train(..., filter), the Python binding's argument): filter sets as small hand-made model files (type 10), goldens by ref_driver train -f
+    def write_model(path, keys):
+        import struct
+        with open(path, "wb") as f:
+            f.write(bytes([0, 10, 2]) + struct.pack("<QQQ", 0, 0, len(keys)))
+            for k in keys:
+                f.write(k + b"\x00" + struct.pack("<I", 1))
+    write_model(os.path.join(HERE, "filter.ngrams.patternmodel"), [bytes([9]), bytes([6, 12]), bytes([7, 8, 10])])
+    write_model(os.path.join(HERE, "filter.skipgrams.patternmodel"), [bytes([6, 3, 8]), bytes([7, 3, 3, 10]), bytes([11, 3, 6])])
+    write_model(os.path.join(HERE, "filter.mixed.patternmodel"), [bytes([15]), bytes([6, 7]), bytes([6, 3, 9]), bytes([8, 3, 6, 3, 7]), bytes([10, 4, 11])])
+    for tag, corpus, mode, l, t, flt in [("f_ngrams.u.t2", "zipf20k", "u", 5, 2, "ngrams"), ("f_ngrams.i.t2", "zipf20k", "i", 4, 2, "ngrams"), ("f_skip.u.t2", "zipf20k", "u", 5, 2, "skipgrams"),
+                                         ("f_mixed.u.t2", "zipf20k", "u", 6, 2, "mixed"), ("f_mixed.i.t3", "phrases15k", "i", 5, 3, "mixed"), ("f_mixed.u.t1", "hamlet.v2", "u", 4, 1, "mixed"),
+                                         ("f_ngrams.u.t1", "zipf20k", "u", 3, 1, "ngrams"), ("f_skip.u.t1", "zipf20k", "u", 4, 1, "skipgrams"), ("f_skip.i.t1", "zipf20k", "i", 4, 1, "skipgrams")]:
+        out = os.path.join(HERE, f"filtered.{tag}.txt")
+        subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{corpus}.colibri.dat"), mode, str(l), str(t), "-q", "-f", os.path.join(HERE, f"filter.{flt}.patternmodel"), "-d", out],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     # continued training (patternmodeller -i <model> -f <corpus> -e 1 -E = train(..., continued = true)): models written by the reference, kept as fixtures, then
     # continued by the reference to longer patterns — on the same corpus under another threshold, and on a different corpus
     ez = os.path.join(HERE, "continued.zipf20k.u.t3l2.patternmodel")

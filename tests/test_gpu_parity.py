@@ -431,3 +431,48 @@ def test_constrained_skipgrams_match_the_restatement(ctx, seed):
             assert st.npatterns == len(want)
     finally:
         ctx.set_constraint([])
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_filtered_training_matches_the_restatement(ctx, seed):
+    """colibri_set_filter + colibri_train = train(..., filter) (reference include/patternmodel.h:1106-1137): every order counts the windows that contain a filter
+    n-gram or instantiate a filter skipgram, by their bytes and without look-back. Filters: random windows of the corpus (lengths 1-4), skipgrams made of them,
+    a flexgram (matches nothing) and patterns that occur nowhere."""
+    import oracle
+    rng = np.random.default_rng(8800 + seed)
+    corpora = small_corpora()
+    name = sorted(corpora)[seed % len(corpora)]
+    payload = corpora[name]
+    sents = [t for t in oracle._sentences(payload) if t]
+    keys = set()
+    kinds = seed % 3  # 0: n-grams only, 1: skipgrams only, 2: both
+    for _ in range(int(rng.integers(1, 6))):
+        if not sents:
+            break
+        t = sents[int(rng.integers(0, len(sents)))]
+        n = int(rng.integers(1, min(len(t), 4) + 1))
+        i = int(rng.integers(0, len(t) - n + 1))
+        w = t[i:i + n]
+        if kinds != 1:
+            keys.add(b"".join(w))
+        if kinds != 0 and n >= 3:
+            masks = oracle.skip_configurations(n, 3)
+            mask = int(masks[int(rng.integers(0, len(masks)))])
+            keys.add(b"".join(b"\x03" if (mask >> j) & 1 else w[j] for j in range(n)))
+    keys.add(b"\x7e\x7d" if kinds != 1 else b"\x7e\x03\x7d")  # occurs nowhere
+    if seed % 4 == 0:
+        keys.add(b"\x06\x04\x07")  # a flexgram: instanceof() is false for it
+    keys = sorted(keys)
+    mintokens, maxlength, indexed = int(rng.choice([1, 2, 2, 3])), int(rng.choice([2, 4, 6])), bool(seed % 2)
+    want = oracle.train_filtered(payload, keys, mintokens, maxlength, indexed=indexed, firstsentence=1 + seed % 3)
+    ctx.upload(payload, first_sentence=1 + seed % 3)
+    try:
+        ctx.set_filter(keys)
+        st = ctx.train(mintokens=mintokens, maxlength=maxlength, indexed=int(indexed))
+        got, gotrefs = ctx.export_dict()
+    finally:
+        ctx.set_filter([])
+    assert got == want.counts, name
+    if indexed:
+        assert gotrefs == want.refs
+    assert (st.totaltokens, st.totaltypes, st.npatterns) == (want.tokens, want.types, len(want))

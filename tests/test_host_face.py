@@ -288,6 +288,32 @@ def test_cli_constrained_training_matches_the_references(tmp_path, tag):
         assert refs == want.refs
 
 
+FILTERED = {  # golden tag -> (corpus, filter fixture, kind, maxlength, mintokens)
+    "f_ngrams.u.t2": ("zipf20k", "ngrams", "u", 5, 2), "f_ngrams.i.t2": ("zipf20k", "ngrams", "i", 4, 2), "f_skip.u.t2": ("zipf20k", "skipgrams", "u", 5, 2),
+    "f_mixed.u.t2": ("zipf20k", "mixed", "u", 6, 2), "f_mixed.i.t3": ("phrases15k", "mixed", "i", 5, 3), "f_mixed.u.t1": ("hamlet.v2", "mixed", "u", 4, 1),
+    "f_ngrams.u.t1": ("zipf20k", "ngrams", "u", 3, 1), "f_skip.u.t1": ("zipf20k", "skipgrams", "u", 4, 1), "f_skip.i.t1": ("zipf20k", "skipgrams", "i", 4, 1),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(FILTERED))
+def test_cxx_api_filtered_training_matches_the_references(tmp_path, tag):
+    """model.train(file, options, NULL, &filter) through the C++ face (the argument the reference's Python binding passes, include/patternmodel.h:880): only the
+    windows that contain a filter n-gram or instantiate a filter skipgram are counted, on the device. Goldens: the real reference (ref_driver train -f)."""
+    import oracle
+    corpus, flt, kind, l, t = FILTERED[tag]
+    model = str(tmp_path / "m.colibri.patternmodel")
+    out = subprocess.run([SELFTEST, "gpu", os.path.join(GOLDEN, corpus + ".colibri.dat"), model, kind, str(l), str(t), "f" + os.path.join(GOLDEN, f"filter.{flt}.patternmodel")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    want = oracle.parse_dump(open(os.path.join(GOLDEN, f"filtered.{tag}.txt")).read(), indexed=kind == "i")
+    mtype, tokens, types, counts, refs = parse_model(model)
+    assert (mtype, tokens, types) == (20 if kind == "i" else 10, want.tokens, want.types)
+    assert counts == want.counts
+    if kind == "i":
+        assert refs == want.refs
+
+
 CONTINUED = {  # golden tag -> (corpus, loaded model, unindexed?, -l, -t)
     "E_zipf.u": ("zipf20k", "continued.zipf20k.u.t3l2.patternmodel", True, 5, 2),
     "E_hamlet.i": ("hamlet.v2", "continued.hamlet.i.t2l3.patternmodel", False, 6, 2),

@@ -304,3 +304,24 @@ def test_continued_training_restatement_matches_the_reference(tag):
     if indexed:
         assert got.refs == want.refs
     assert len(got.counts) > len(loaded.counts)  # the run did add longer patterns
+
+
+FILTERED = {  # golden tag -> (corpus, filter fixture, indexed, mintokens, maxlength)
+    "f_ngrams.u.t2": ("zipf20k", "ngrams", False, 2, 5), "f_ngrams.i.t2": ("zipf20k", "ngrams", True, 2, 4), "f_skip.u.t2": ("zipf20k", "skipgrams", False, 2, 5),
+    "f_mixed.u.t2": ("zipf20k", "mixed", False, 2, 6), "f_mixed.i.t3": ("phrases15k", "mixed", True, 3, 5), "f_mixed.u.t1": ("hamlet.v2", "mixed", False, 1, 4),
+    "f_ngrams.u.t1": ("zipf20k", "ngrams", False, 1, 3), "f_skip.u.t1": ("zipf20k", "skipgrams", False, 1, 4), "f_skip.i.t1": ("zipf20k", "skipgrams", True, 1, 4),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(FILTERED))
+def test_filtered_training_restatement_matches_the_reference(tag):
+    """train(..., filter) (include/patternmodel.h:899-914, :1106-1137): the restatement against dumps of the real reference (ref_driver train -f)"""
+    corpus, flt, indexed, mintokens, maxlength = FILTERED[tag]
+    payload = open(os.path.join(GOLDEN, corpus + ".colibri.dat"), "rb").read()[2:]
+    keys = _model_keys(os.path.join(GOLDEN, f"filter.{flt}.patternmodel"))
+    want = oracle.parse_dump(open(os.path.join(GOLDEN, f"filtered.{tag}.txt")).read(), indexed=indexed)
+    got = oracle.train_filtered(payload, keys, mintokens, maxlength, indexed=indexed)
+    assert (got.tokens, got.types) == (want.tokens, want.types)
+    assert got.counts == want.counts
+    if indexed:
+        assert got.refs == want.refs

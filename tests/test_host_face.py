@@ -54,7 +54,7 @@ def test_host_selftest_cpu():
 
 
 def test_cli_rejects_out_of_scope_flags():
-    for flag in (["-g"], ["-E"], ["-F", "0.5"], ["-Q"]):  # relations, self-expansion, flexgrams from co-occurrence, query mode
+    for flag in (["-g"], ["-F", "0.5"], ["-Q"]):  # relations, flexgrams from co-occurrence, query mode
         out = subprocess.run([CLI, "-f", os.path.join(GOLDEN, "hamlet.v2.colibri.dat")] + flag, capture_output=True, text=True)
         assert out.returncode == 2 and "not part of the MI355X-accelerated build" in out.stderr
 

@@ -30,7 +30,8 @@ def build(tmp_path, source, name, extra=()):
     (tmp_path / "config.h").write_text('#define VERSION "0"\n')  # what the autotools build would generate: a version string for the usage text
     exe = str(tmp_path / name)
     cmd = ["g++", "-std=c++17", "-O1", "-I" + str(tmp_path), "-I" + os.path.join(HOST, "include"), "-I" + os.path.join(ROOT, "include"), *extra, source,
-           os.path.join(LIB, "libcolibri_amd_host.a"), "-L" + LIB, "-lcolibri_hip", "-Wl,-rpath," + LIB, "-o", exe]
+           os.path.join(LIB, "libcolibri_amd_host.a"), "-L" + LIB, "-lcolibri_hip", "-Wl,-rpath," + LIB, "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib",
+           "-lpthread", "-o", exe]  # (the sharded driver in the host library talks to RCCL and the HIP runtime directly)
     p = subprocess.run(cmd, capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-4000:]
     return exe

@@ -526,7 +526,9 @@ __device__ unsigned long long bi2_prof[16];
 template <int NSUB>
 __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const uint32_t* __restrict__ boff, Bi2State* __restrict__ bs,
                                                               DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
-                                                              uint32_t* __restrict__ wlist, uint32_t* __restrict__ wcnt, uint32_t wcap, bool want_positions) {
+                                                              uint32_t* __restrict__ wlist, uint32_t* __restrict__ wcnt, uint32_t wcap, bool want_positions,
+                                                              uint32_t* __restrict__ wcode = nullptr /* optional, beside wlist: (final bin << 10) | rank of the window's key among the
+                                                                                                        bin's survivors — what bi2_ids_kernel turns into the window's RESULT index */) {
     if (st->done) return;
     static_assert(2 * NSUB + 1 <= kWave, "bound loaders are lanes of the wave");
     __shared__ __attribute__((aligned(16))) uint32_t keyT[kBi2Slots];
@@ -537,6 +539,8 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
     const uint32_t pb = bs->posbits;
     const unsigned long long pmask = (1ull << pb) - 1;
     uint32_t* const mylist = wlist + (size_t)wid * wcap;
+    uint32_t* const mycode = wcode != nullptr ? wcode + (size_t)wid * wcap : nullptr;
+    static_assert(kBi2MaxLoad < 1024 && kBi2Final <= (1 << 22), "a (bin, rank) code fits 32 bits");
     uint32_t        cursor = want_positions ? wcnt[wid] : 0u;  // entries in this wave's position list (wave-uniform); the passes of a sliced order append
     bool            lost   = false;  // the list ran out of room
 #ifdef BI2_PROF
@@ -711,6 +715,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
         BI2_W(7);
         if (!reps_lds) __threadfence();  // the initial values of the result entries precede the atomics below
         // pass 2: every window of a surviving key: lowest position of the key; the position joins the wave's list
+        const uint32_t fcode = (a * (uint32_t)kBi2BBins + b) << 10;
         auto settle = [&](bool valid, uint32_t pos, uint32_t s) {
             uint32_t c = 0;
             if (valid) c = cntT[s];
@@ -727,10 +732,12 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
                 const uint32_t n = (uint32_t)__popcll(m);
                 if (kept) {
                     const uint32_t at = cursor + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (at < wcap)
+                    if (at < wcap) {
                         mylist[at] = pos;
-                    else
+                        if (mycode != nullptr) mycode[at] = fcode | r;
+                    } else {
                         lost = true;
+                    }
                 }
                 cursor += n;
             }
@@ -893,23 +900,27 @@ struct Bi2Lists {
 };
 // tile-local counting sort by bucket in LDS, one reserved run per (tile, bucket); block x takes the lists x, x + gridDim.x, ...
 __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_pospart_kernel(const uint32_t* __restrict__ wlist, const uint32_t* __restrict__ wcnt, uint32_t nlists, uint32_t wcap,
-                                                                                      Bi2State* __restrict__ bs, DevState* __restrict__ st, uint32_t* __restrict__ plist, Bi2Lists pl) {
+                                                                                      Bi2State* __restrict__ bs, DevState* __restrict__ st, uint32_t* __restrict__ plist, Bi2Lists pl,
+                                                                                      const uint32_t* __restrict__ wcode = nullptr, uint32_t* __restrict__ pcode = nullptr) {
+    // wcode / pcode (optional): the (bin, rank) codes travel with their positions
     if (st->done) return;
     static_assert(kBi2Buckets == kBi2Threads, "one lane per position bucket");
-    __shared__ uint32_t stgL[kBi2Tile];
+    __shared__ uint32_t stgL[kBi2Tile], stgC[kBi2Tile];
     __shared__ uint16_t binL[kBi2Tile];
     __shared__ uint32_t histL[kBi2Buckets], offL[kBi2Buckets], gbaseL[kBi2Buckets], wsumL[kBi2Threads / kWave];
     const uint32_t      shard = blockIdx.x & (uint32_t)(kBi2Shards - 1);
     for (uint32_t w = blockIdx.x; w < nlists; w += gridDim.x) {
         const uint32_t        n   = min(wcnt[w], wcap);
-        const uint32_t* const src = wlist + (size_t)w * wcap;
+        const uint32_t* const src  = wlist + (size_t)w * wcap;
+        const uint32_t* const csrc = wcode != nullptr ? wcode + (size_t)w * wcap : nullptr;
         for (uint32_t j0 = 0; j0 < n; j0 += kBi2Tile) {
-            uint32_t p[kBi2Per], rank[kBi2Per];
+            uint32_t p[kBi2Per], rank[kBi2Per], code[kBi2Per];
             histL[threadIdx.x] = 0;
 #pragma unroll
             for (int k = 0; k < kBi2Per; ++k) {
                 const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
                 p[k]             = j < n ? src[j] : 0xFFFFFFFFu;
+                code[k]          = (csrc != nullptr && j < n) ? csrc[j] : 0u;
             }
             __syncthreads();
 #pragma unroll
@@ -942,6 +953,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_pospart_ke
                 if (rank[k] != kInvalid) {
                     const uint32_t b = rank[k] >> 16, q = offL[b] + (rank[k] & 0xFFFFu);
                     stgL[q]          = p[k];
+                    stgC[q]          = code[k];
                     binL[q]          = (uint16_t)b;
                 }
             }
@@ -950,6 +962,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_pospart_ke
             for (uint32_t j = threadIdx.x; j < m; j += kBi2Threads) {
                 const uint32_t b                      = binL[j];
                 plist[(size_t)gbaseL[b] + (j - offL[b])] = stgL[j];
+                if (pcode != nullptr) pcode[(size_t)gbaseL[b] + (j - offL[b])] = stgC[j];
             }
             __syncthreads();
         }
@@ -989,13 +1002,40 @@ __global__ __launch_bounds__(kBi2BmThreads) void bi2_bitmap_kernel(uint32_t npos
     for (uint32_t w = threadIdx.x; w < nwords; w += kBi2BmThreads) bitmap[(start >> 5) + w] = bmL[w];
 }
 
+// ---- result indices per position (the modes that keep every order's ids: forward index, skipgram passes) ------------------------------------
+// per position bucket: the listed (position, code) pairs -> ids[position] = RESULT index of the window's bigram (the array is pre-filled with kInvalid;
+// the scatter stays inside the bucket's window of 2^pshift positions). Head bigrams: bi2_list3_kernel writes theirs from the table bi2_headids_kernel leaves.
+__global__ __launch_bounds__(kBi2BmThreads) void bi2_ids_kernel(uint32_t npos, const Bi2State* __restrict__ bs, const uint32_t* __restrict__ plist, const uint32_t* __restrict__ pcode,
+                                                                 Bi2Lists pl, const DevState* __restrict__ st, uint32_t* __restrict__ ids) {
+    if (st->done) return;
+    const uint32_t b = blockIdx.x;
+    if ((b << pl.pshift) >= npos) return;
+    const uint32_t res_base = bs->res_base;
+    for (uint32_t x = 0; x < (uint32_t)kBi2Shards; ++x) {
+        const uint32_t l = x * kBi2Buckets + b, n = min(bs->pcur[l], pl.pcap);
+        const size_t   o = (size_t)l * pl.pcap;
+        for (uint32_t j = threadIdx.x; j < n; j += kBi2BmThreads) {
+            const uint32_t code = pcode[o + j];
+            ids[plist[o + j]]   = res_base + bs->binkept[code >> 10] + (code & 1023u);
+        }
+    }
+}
+__global__ __launch_bounds__(kBlock) void bi2_headids_kernel(const Bi2State* __restrict__ bs, const DevState* __restrict__ st, uint32_t* __restrict__ headid /* [kBi2HeadN] */) {
+    if (st->done) return;
+    uint32_t       r    = bs->res_base + bs->kept_bins + bs->headbase[threadIdx.x];  // as bi2_compact_kernel numbers them
+    const uint32_t bits = reinterpret_cast<const uint16_t*>(bs->headsurv)[threadIdx.x];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) headid[threadIdx.x * 16 + q] = (bits & (1u << q)) ? r++ : kInvalid;
+}
+
 // ---- list3: one streaming pass over the corpus: bitmap | head survivors -> active list of order 3 ----------------------------------------
 // entry i of the list: bigrams at i and at i + 1 both survived. st->valid += positions with a surviving bigram.
 // cls must be readable (zeros) up to index npos + 63 rounded up to a multiple of 32; bitmap up to word npos / 32 + 1 (zeros beyond the corpus).
 constexpr int kBi2L3Tile = kBlock * 32;  // one bitmap word per lane
 __global__ __launch_bounds__(kBlock) void bi2_list3_kernel(const uint32_t* __restrict__ cls, const uint32_t* __restrict__ surv, uint32_t npos, const uint32_t* __restrict__ headsurv,
                                                             const uint32_t* __restrict__ bitmap, DevState* __restrict__ st, uint32_t* __restrict__ list_out,
-                                                            uint32_t* __restrict__ nlist_out) {
+                                                            uint32_t* __restrict__ nlist_out, uint32_t* __restrict__ ids = nullptr /* optional: result index per position */,
+                                                            const uint32_t* __restrict__ headid = nullptr /* ... of the head bigrams (bi2_headids_kernel) */) {
     if (st->done) return;
     __shared__ uint32_t hsL[kBi2HeadN / 32], stageL[kBi2L3Tile], baseL, redL[kBlock / kWave];
     if (threadIdx.x < kBi2HeadN / 32) hsL[threadIdx.x] = headsurv[threadIdx.x];
@@ -1029,10 +1069,12 @@ __global__ __launch_bounds__(kBlock) void bi2_list3_kernel(const uint32_t* __res
                     const uint32_t s0 = (c0 < 32 ? sw0 >> c0 : sw1 >> (c0 - 32)) & 1u, s1 = (c1 < 32 ? sw0 >> c1 : sw1 >> (c1 - 32)) & 1u;
                     const uint32_t h  = c0 * kBi2Head + c1;
                     const uint32_t on = s0 & s1 & (hsL[h >> 5] >> (h & 31u));
-                    if (k < 32)
+                    if (k < 32) {
                         hb |= on << k;
-                    else
+                        if (ids != nullptr && on && p0 + (uint32_t)k < npos) ids[p0 + (uint32_t)k] = headid[h];  // (a 16 KB table: cache-resident)
+                    } else {
                         hnx = on;
+                    }
                 }
             }
             x |= hb;

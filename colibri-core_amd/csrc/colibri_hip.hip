@@ -135,6 +135,7 @@ struct colibri_ctx {
     struct Bigram2 {                    // second-generation order 2 (bigram2.hpp)
         DevBuf<Bi2State> state;
         DevBuf<uint32_t> boff, head_rows, wlist, wcnt, plist, bitmap, headsurv;
+        DevBuf<uint32_t> wcode, pcode, headid;  // the modes that keep ids: (bin, rank) codes beside the positions, result index of every head bigram
         bool             disabled = false;  // set for the rerun after this path could not hold an order (region / bin / list overflow)
         bool             attr_set = false;
     } b2;
@@ -503,6 +504,7 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->fx.keys); dev_free(c->fx.keyoff); dev_free(c->fx.refoff); dev_free(c->fx.cnt); dev_free(c->fx.sentence); dev_free(c->fx.token);
     dev_free(c->tx.table); dev_free(c->tx.state); dev_free(c->tx.info); dev_free(c->tx.events); dev_free(c->tx.evcnt);
     dev_free(c->flag2);
+    dev_free(c->b2.wcode); dev_free(c->b2.pcode); dev_free(c->b2.headid);
     dev_free(c->b2.state); dev_free(c->b2.boff); dev_free(c->b2.head_rows); dev_free(c->b2.wlist); dev_free(c->b2.wcnt); dev_free(c->b2.plist); dev_free(c->b2.bitmap); dev_free(c->b2.headsurv);
     dev_free(c->ids_at);
     dev_free(c->alist[0]);
@@ -821,9 +823,18 @@ int bigram2_alloc(colibri_ctx* c, uint32_t npos) {
     return COLIBRI_OK;
 }
 #define B2DBG(name) do { if (getenv("COLIBRI_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(c->stream); fprintf(stderr, "[b2] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
-int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list) {
+// ids_out (the modes that keep every order's ids; one pass only): also the RESULT index of the bigram at every position, kInvalid where it did not survive
+int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t* ids_out = nullptr) {
     const uint32_t    npos = pl.npos, nsurv = c->maxclass / 32 + 1;
     const Bigram2Plan b    = bigram2_plan(c, npos);
+    if (ids_out != nullptr) {
+        int rc;
+        if (b.sbits != 0 || !want_list) return fail(c, COLIBRI_ERR_STATE, "bigram2_order: ids need the single-pass form with lists");
+        if ((rc = dev_alloc(c, c->b2.wcode, (size_t)kBi2Waves * b.wcap)) || (rc = dev_alloc(c, c->b2.pcode, (size_t)kBi2Shards * kBi2Buckets * b.pl.pcap + 64)) ||
+            (rc = dev_alloc(c, c->b2.headid, kBi2HeadN)))
+            return rc;
+        HIP_TRY(c, hipMemsetAsync(ids_out, 0xFF, sizeof(uint32_t) * (size_t)npos, c->stream));
+    }
     Bi2State* const   bs   = c->b2.state.p;
     auto* const       recsA = reinterpret_cast<unsigned long long*>(c->recs[0].p);
     auto* const       recsB = reinterpret_cast<unsigned long long*>(c->recs[1].p);
@@ -854,7 +865,7 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list) {
         {
             Prof p(c, COLIBRI_K_COUNT2);
             hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr, io.sp_rep, io.sp_cnt,
-                               c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list);
+                               c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list, ids_out != nullptr ? c->b2.wcode.p : (uint32_t*)nullptr);
         B2DBG("bi2_count_kernel");
         }
         {
@@ -871,11 +882,17 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list) {
     HIP_TRY(c, hipMemsetAsync(c->b2.bitmap.p + npos / 32, 0, sizeof(uint32_t) * 16, c->stream));  // words beyond the corpus read as zero
     {
         Prof p(c, COLIBRI_K_LISTS2);
-        hipLaunchKernelGGL(bi2_pospart_kernel, dim3(512), dim3(kBi2Threads), 0, c->stream, c->b2.wlist.p, c->b2.wcnt.p, kBi2Waves, b.wcap, bs, c->state.p, c->b2.plist.p, b.pl);
+        hipLaunchKernelGGL(bi2_pospart_kernel, dim3(512), dim3(kBi2Threads), 0, c->stream, c->b2.wlist.p, c->b2.wcnt.p, kBi2Waves, b.wcap, bs, c->state.p, c->b2.plist.p, b.pl,
+                           ids_out != nullptr ? (const uint32_t*)c->b2.wcode.p : (const uint32_t*)nullptr, ids_out != nullptr ? c->b2.pcode.p : (uint32_t*)nullptr);
         B2DBG("bi2_pospart_kernel");
+        if (ids_out != nullptr) {
+            hipLaunchKernelGGL(bi2_ids_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), 0, c->stream, npos, bs, c->b2.plist.p, c->b2.pcode.p, b.pl, c->state.p, ids_out);
+            hipLaunchKernelGGL(bi2_headids_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, c->state.p, c->b2.headid.p);
+        }
         hipLaunchKernelGGL(bi2_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, bs, c->b2.plist.p, b.pl, c->state.p, c->b2.bitmap.p);
         B2DBG("bi2_bitmap_kernel");
-        hipLaunchKernelGGL(bi2_list3_kernel, dim3(2048), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_surv.p, npos, c->b2.headsurv.p, c->b2.bitmap.p, c->state.p, c->alist[1].p, nlist);
+        hipLaunchKernelGGL(bi2_list3_kernel, dim3(2048), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_surv.p, npos, c->b2.headsurv.p, c->b2.bitmap.p, c->state.p, c->alist[1].p, nlist, ids_out,
+                           ids_out != nullptr ? (const uint32_t*)c->b2.headid.p : (const uint32_t*)nullptr);
         B2DBG("bi2_list3_kernel");
     }
     return COLIBRI_OK;
@@ -1465,6 +1482,11 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
         if ((rc = dev_alloc(c, c->alist[0], (size_t)npos + 1)) || (rc = dev_alloc(c, c->alist[1], (size_t)npos + 1)) || (rc = dev_alloc(c, c->alist_n, 2))) return rc;
         if (bi2 && (rc = bigram2_alloc(c, npos))) return rc;
     }
+    // the modes that keep every order's ids run order 2 on the second-generation kernels as well, which then also leave the result index of the bigram at
+    // every position (bi2_ids_kernel); one pass only, class-keyed, no word threshold (its cut of the order-1 ids comes after their references are emitted)
+    const bool bi2_synced = radix_synced && !continued && !filtered && !backoff && wthr == 0 && o.table_mode == 0 && !(c->flags & kFlagNonCanonical) && uni_range_shift(c) != 0 &&
+                            c->maxclass < (1u << 21) && o.maxlength >= 2 && bigram2_fits(c, npos) && bigram2_plan(c, npos).sbits == 0 && !c->b2.disabled;
+    if (bi2_synced && (rc = bigram2_alloc(c, npos))) return rc;
     if (!binned && (rc = dev_alloc(c, c->table, pl.table_slots))) return rc;  // the plain radix run needs no table (a bin overflow re-runs with table_mode = 1)
     if ((rc = dev_alloc(c, c->res_rep, pl.res_cap))) return rc;
     if ((rc = dev_alloc(c, c->res_cnt, pl.res_cap))) return rc;
@@ -1753,12 +1775,18 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                 {
                     Prof p(c, COLIBRI_K_PRUNE);
                     hipLaunchKernelGGL(uni_finish_kernel, dim3(stream_grid(nclasses)), dim3(kBlock), 0, c->stream, c->cnt1.p, (const uint32_t*)nullptr, nclasses, pl.thr, c->state.p,
-                                       c->res_rep.p, c->res_cnt.p, pl.res_cap, (uint16_t*)nullptr, false, c->uni_resid.p);
+                                       c->res_rep.p, c->res_cnt.p, pl.res_cap, bi2_synced ? reinterpret_cast<uint16_t*>(c->uni_surv.p) : (uint16_t*)nullptr, false, c->uni_resid.p);
                 }
                 {
                     Prof p(c, COLIBRI_K_RESOLVE);
                     hipLaunchKernelGGL(uni_resid_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_resid.p, c->ids[n].p, c->state.p, npos);
                 }
+            } else if (n == 2 && bi2_synced) {
+                // order 2 on the second-generation kernels (bigram2.hpp), which also leave the bigrams' result indices per position and the active list of order 3
+                c->hstate.radix_overflow = 0;
+                if ((rc = write_state(c))) return rc;
+                if ((rc = bigram2_order(c, pl, /*want_list=*/true, c->ids[n].p))) return rc;
+                list_valid = true;
             } else if (radix_pass) {
                 // n-gram pass on the radix path: emit -> level B -> per-bin LDS count; survivors leave as (bin, rank) codes that the resolve turns
                 // into result indices (= the ids the skipgram passes and the forward index work with); from order 3 on only the active list is walked
@@ -1793,6 +1821,12 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                 launch_resolve(c, pl, c->ids[n].p);
             }
             if ((rc = read_state(c))) return rc;
+            if (bi2_synced && c->hstate.radix_overflow == 4) {  // the second-generation order 2 could not hold this corpus: again, on the first-generation kernels
+                c->b2.disabled = true;
+                const int rc2  = colibri_train_once(c, &o, stats_out);
+                c->b2.disabled = false;
+                return rc2;
+            }
             if ((radix_synced || radix_constrained) && c->hstate.radix_overflow) {  // a bin outgrew its LDS table: the whole run again on the table path (loud, exact, rare)
                 colibri_options again = o;
                 again.table_mode      = 1;

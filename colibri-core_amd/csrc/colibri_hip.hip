@@ -237,6 +237,15 @@ void dev_free(DevBuf<T>& b) {
     b.n = 0;
 }
 
+// a temporary of one function: freed on every way out of it (the HIP_TRY early returns included)
+template <class T>
+struct ScopedBuf : DevBuf<T> {
+    ScopedBuf() = default;
+    ScopedBuf(const ScopedBuf&) = delete;
+    ScopedBuf& operator=(const ScopedBuf&) = delete;
+    ~ScopedBuf() { dev_free(static_cast<DevBuf<T>&>(*this)); }
+};
+
 inline uint32_t blocks_for(uint64_t n, uint32_t per) { return (uint32_t)((n + per - 1) / per); }
 // grid for grid-stride streaming kernels: enough waves to fill 256 CUs x 8 blocks, no more
 inline uint32_t stream_grid(uint64_t n) { return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, 256ull * 16)); }
@@ -286,20 +295,14 @@ int tokenise(colibri_ctx* c) {
     const uint64_t B = c->nbytes;
     // upper bound of positions = bytes; sized exactly after the count pass
     const uint32_t   nblk = std::max<uint32_t>(1, blocks_for(B, kTokBytesPerBlock));
-    DevBuf<uint32_t> blockcnt, total;
-    DevBuf<CorpusInfo> info;
-    DevBuf<unsigned long long> hist;
+    ScopedBuf<uint32_t> blockcnt, total, dcnt;  // (freed on every way out)
+    ScopedBuf<CorpusInfo> info;
+    ScopedBuf<unsigned long long> hist;
     int rc;
     if ((rc = dev_alloc(c, blockcnt, nblk + 1))) return rc;
     if ((rc = dev_alloc(c, total, 1))) return rc;
     if ((rc = dev_alloc(c, info, 1))) return rc;
     if ((rc = dev_alloc(c, hist, kLenHistBins))) return rc;
-    auto cleanup = [&]() {
-        dev_free(blockcnt);
-        dev_free(total);
-        dev_free(info);
-        dev_free(hist);
-    };
     {
         Prof p(c, COLIBRI_K_TOKENISE);
         hipLaunchKernelGGL(tokenise_count_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, c->bytes.p, B, blockcnt.p);
@@ -311,20 +314,13 @@ int tokenise(colibri_ctx* c) {
     c->npos = npos;
     c->cs.rem_valid = false;  // per-position sentence remainders belong to the previous corpus
     c->pos_blocks_valid = false;
-    if ((rc = dev_alloc(c, c->tokstart, (size_t)npos + 2)) || (rc = dev_alloc(c, c->cls, (size_t)npos + 128))) {  // class ids are read as whole 16-byte vectors past the end (zeros)
-        cleanup();
-        return rc;
-    }
+    if ((rc = dev_alloc(c, c->tokstart, (size_t)npos + 2)) || (rc = dev_alloc(c, c->cls, (size_t)npos + 128))) return rc;  // class ids are read as whole 16-byte vectors past the end (zeros)
     HIP_TRY(c, hipMemsetAsync(c->tokstart.p, 0, sizeof(uint32_t), c->stream));  // tokstart[0] = 0
     HIP_TRY(c, hipMemsetAsync(c->cls.p + npos, 0, sizeof(uint32_t) * 128, c->stream));
     HIP_TRY(c, hipMemsetAsync(info.p, 0, sizeof(CorpusInfo), c->stream));
     HIP_TRY(c, hipMemsetAsync(hist.p, 0, sizeof(unsigned long long) * kLenHistBins, c->stream));
     const uint32_t   pblk = std::max<uint32_t>(1, blocks_for(npos, kBlock));
-    DevBuf<uint32_t> dcnt;
-    if ((rc = dev_alloc(c, dcnt, pblk + 1))) {
-        cleanup();
-        return rc;
-    }
+    if ((rc = dev_alloc(c, dcnt, pblk + 1))) return rc;
     {
         Prof p(c, COLIBRI_K_TOKENISE);
         hipLaunchKernelGGL(tokenise_write_kernel, dim3(nblk), dim3(kBlock), 0, c->stream, c->bytes.p, B, blockcnt.p, c->tokstart.p);
@@ -340,11 +336,7 @@ int tokenise(colibri_ctx* c) {
     c->maxclass = hinfo.maxclass;
     c->flags    = hinfo.flags;
     c->ntokens  = (uint64_t)npos - ndelim;
-    if ((rc = dev_alloc(c, c->delimpos, (size_t)ndelim + 1))) {
-        dev_free(dcnt);
-        cleanup();
-        return rc;
-    }
+    if ((rc = dev_alloc(c, c->delimpos, (size_t)ndelim + 1))) return rc;
     uint32_t last_delim = 0;
     {
         Prof p(c, COLIBRI_K_TOKENISE);
@@ -358,9 +350,9 @@ int tokenise(colibri_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     {  // W_n = sum_len hist[len] * (len - n + 1) for len >= n, via suffix sums: S0(n) = #sentences with len >= n, S1(n) = sum of their lengths
-        uint64_t s0 = 0, s1 = 0;
+        uint64_t s0 = c->lenhist[65536], s1 = c->lenhist[65537];  // the sentences of 65536 tokens and more: their number and total length
         std::fill(std::begin(c->windows_n), std::end(c->windows_n), 0);
-        for (size_t len = c->lenhist.size(); len-- > 1;) {
+        for (size_t len = 65536; len-- > 1;) {
             s0 += c->lenhist[len];
             s1 += c->lenhist[len] * (uint64_t)len;
             if (len < COLIBRI_MAX_ORDER) c->windows_n[len] = s1 - s0 * (uint64_t)(len - 1);
@@ -368,8 +360,6 @@ int tokenise(colibri_ctx* c) {
     }
     const uint32_t trailing = ndelim ? npos - (last_delim + 1) : npos;
     c->nsent                = ndelim + (trailing ? 1u : 0u);
-    dev_free(dcnt);
-    cleanup();
     if (c->flags & kFlagTokenTooLong) return fail(c, COLIBRI_ERR_CORPUS, "corpus has a token longer than 8 bytes; not a valid class encoding for the accelerated path");
     if (c->flags & kFlagFlexClass)
         return fail(c, COLIBRI_ERR_CORPUS, "corpus contains the literal flexgram class {**} (04); the reference collapses these while counting, not accelerated");

@@ -175,7 +175,9 @@ __global__ __launch_bounds__(kBlock) void delimiter_write_kernel(const uint8_t* 
 }
 
 // histogram of sentence lengths (in tokens): W_n = sum_len hist[len]*max(0,len-n+1) is finished on the host
-constexpr int kLenHistBins = 65537;  // a sentence has at most 65535 tokens in the reference (IndexReference.token is u16)
+// bins 0..65535 by length; longer sentences (the reference's token offsets, u16, wrap there; its counts do not): [65536] = how many, [65537] = the sum of their lengths,
+// which is all W_n needs of them (every such sentence holds len - n + 1 windows of n < 128 tokens)
+constexpr int kLenHistBins = 65538;
 constexpr int kLenHistLds  = 2048;
 __global__ __launch_bounds__(kBlock) void sentence_length_kernel(const uint32_t* __restrict__ delimpos, uint32_t ndelim, uint32_t npos,
                                                                   unsigned long long* __restrict__ hist) {
@@ -189,9 +191,11 @@ __global__ __launch_bounds__(kBlock) void sentence_length_kernel(const uint32_t*
         uint32_t       len   = end - begin;
         if (len < (uint32_t)kLenHistLds) {
             atomicAdd(&lh[len], 1u);
-        } else {
-            if (len > 65536u) len = 65536u;
+        } else if (len < 65536u) {
             atomicAdd(&hist[len], 1ull);
+        } else {
+            atomicAdd(&hist[65536], 1ull);
+            atomicAdd(&hist[65537], (unsigned long long)len);
         }
     }
     __syncthreads();

@@ -481,6 +481,8 @@ void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_o
             if ((rc = colibri_train(g.c, &plain, &out.stats)) != COLIBRI_OK) raise(g.c, rc, "colibri_train");
             out.stats.npatterns = 0;
             out.stats.totaltypes = 0;
+            out.stats.maxn = out.stats.minn = 0;  // an empty model: nothing of the plain order-1 run that only served the totals stays
+            for (int n = 0; n < COLIBRI_MAX_ORDER; ++n) out.stats.found[n] = out.stats.kept[n] = out.stats.pruned[n] = out.stats.admitted[n] = 0;
             out.key_off.assign(1, 0);
             out.key_bytes.assign(1, 0);
             out.counts.clear();

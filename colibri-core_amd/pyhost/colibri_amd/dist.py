@@ -17,6 +17,7 @@ distinct candidate out, 8 B back; xGMI is point-to-point (7 links per GPU), and 
 import numpy as np
 
 MAX_ORDER = 128
+FAILED = (1 << 62) - 1  # a partition size no rank can have: "my local count failed" (ShardedTrainer._pass)
 
 
 class ShardedTrainer:
@@ -92,15 +93,31 @@ class ShardedTrainer:
 
     # ---- one pass: local count -> exchange -> owner merge -> global ids back ---------------------------------
     def _pass(self, n, mask, level, state):
+        """A rank whose engine raises (a radix bin or a result buffer outgrown: loud, `table_mode = 1` / more room fixes it) must not leave the others waiting in
+        a collective: its failure travels in the exchanges the pass does anyway — the size all-to-all (a sentinel size) and the (found, kept) all-gather — and every
+        rank raises."""
         eng = self.engine
-        ncand, per_owner = eng.count(n, mask, level)
+        err = None
+        try:
+            ncand, per_owner = eng.count(n, mask, level)
+        except Exception as e:  # noqa: BLE001 — reported on every rank below
+            err, per_owner = e, [FAILED] * self.world
         recv_sizes = self._exchange_sizes(per_owner)
+        if err is not None or FAILED in recv_sizes:
+            raise RuntimeError(f"sharded pass (n={n}, mask={mask}, level={level}): local count failed on rank(s) "
+                               f"{[r for r, v in enumerate(recv_sizes) if v == FAILED]}" + (f": {err}" if err is not None else ""))
         keys, cnts, aux = eng.send_buffers()
         rkeys = self._all_to_all_v(keys, per_owner, recv_sizes)
         rcnts = self._all_to_all_v(cnts, per_owner, recv_sizes)
         raux = self._all_to_all_v(aux, per_owner, recv_sizes) if aux is not None else None  # distinct-source counts: indexed skipgram passes only
-        found, kept = eng.merge(rkeys, rcnts, raux, recv_sizes)
-        everyone = self._all_gather_ints([found, kept])
+        try:
+            found, kept = eng.merge(rkeys, rcnts, raux, recv_sizes)
+        except Exception as e:  # noqa: BLE001
+            err, found, kept = e, 0, 0
+        everyone = self._all_gather_ints([found, kept, int(err is not None)])
+        if any(v[2] for v in everyone):
+            raise RuntimeError(f"sharded pass (n={n}, mask={mask}, level={level}): owner merge failed on rank(s) {[r for r, v in enumerate(everyone) if v[2]]}"
+                               + (f": {err}" if err is not None else ""))
         found_all, kept_all = sum(v[0] for v in everyone), sum(v[1] for v in everyone)
         if found_all == 0:  # nothing anywhere: every rank sees it at once (reference "None found", patternmodel.h:1189-1194)
             return 0, 0

@@ -149,6 +149,22 @@ def main():
         payload = synth.random_corpus(np.random.default_rng(int(corpus_kind)), nsent=300, maxlen=12, vocab=12)
     shard, first = shard_payload(payload, world)[rank]
     opt = capi.Options.defaults(mintokens=2, maxlength=maxlength, **MODES[mode])
+    if engine_kind == "numpy_fail":  # rank 1's local count of order 3 raises: every rank must learn of it instead of waiting in a collective
+        class Failing(NumpyShardEngine):
+            def count(self, n, mask=0, level=1):
+                if n == 3 and rank == 1:
+                    raise RuntimeError("radix path overflowed (simulated)")
+                return super().count(n, mask, level)
+        msg = ""
+        try:
+            ShardedTrainer(Failing(shard), dist, torch).train(opt)
+        except RuntimeError as e:
+            msg = str(e)
+        with open(f"{out}.rank{rank}", "w") as f:
+            f.write(msg)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if engine_kind == "numpy":
         eng = NumpyShardEngine(shard)
         trainer = ShardedTrainer(eng, dist, torch)

@@ -476,3 +476,22 @@ def test_filtered_training_matches_the_restatement(ctx, seed):
     if indexed:
         assert gotrefs == want.refs
     assert (st.totaltokens, st.totaltypes, st.npatterns) == (want.tokens, want.types, len(want))
+
+
+def test_sentences_longer_than_the_u16_token_offset(ctx):
+    """A sentence of more than 65 535 tokens: the reference's counts are unaffected (only its u16 token offsets wrap, include/datatypes.h:60-63); the window counts
+    W_n the statistics report (bench.py's numerator) must stay exact too — the length histogram used to clamp such sentences into its last bin."""
+    import oracle
+    from colibri_amd import synth
+    rng = np.random.default_rng(3)
+    long_one = rng.integers(6, 10, size=70_000).astype(np.uint32)
+    short = rng.integers(6, 10, size=50).astype(np.uint32)
+    sym = np.concatenate([long_one, [0], short, [0], long_one[:66_000], [0]]).astype(np.uint32)
+    payload = synth.encode_v2(sym).tobytes()
+    want = oracle.train(payload, 2, 4)
+    ctx.upload(payload)
+    st = ctx.train(mintokens=2, maxlength=4)
+    got, _ = ctx.export_dict()
+    assert got == want.counts
+    for n in range(1, 5):
+        assert st.windows[n] == (70_000 - n + 1) + (50 - n + 1) + (66_000 - n + 1)

@@ -45,6 +45,21 @@ def test_exchange_protocol_gloo_cpu(tmp_path, world, corpus, maxlength):
     run_workers(tmp_path, world, "numpy", corpus, maxlength)
 
 
+def test_a_failing_rank_is_reported_on_every_rank(tmp_path):
+    """A rank whose local count raises (e.g. a radix bin outgrown under table_mode = 2) must not leave the others blocked in the next all-to-all: the failure
+    travels with the size exchange and every rank raises ('nothing in dist.py shares error status across ranks')."""
+    out = str(tmp_path / "fail")
+    _port[0] += 1
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", COLIBRI_TEST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1", "--master-port", str(_port[0]), WORKER, "numpy_fail", "1",
+           "5", out, "u"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    msgs = [open(f"{out}.rank{r}").read() for r in range(3)]
+    assert all("local count failed on rank(s) [1]" in m for m in msgs), msgs
+    assert "simulated" in msgs[1]
+
+
 def test_shard_payload_keeps_global_sentence_numbers():
     from colibri_amd.dist import shard_payload
     payload = b"\x06\x00\x00\x07\x08\x00\x09\x00\x0a\x0b"  # 5 sentences (one empty, last unterminated)

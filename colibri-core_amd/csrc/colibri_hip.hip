@@ -142,6 +142,7 @@ struct colibri_ctx {
     DevBuf<uint32_t>  alist[2], alist_n; // binned path: active-position lists (ping-pong) and their lengths [2]
     DevBuf<BinState>  binstate;
     int               last_mode = 0;    // 1 = global table, 2 = binned (what the last train() actually ran)
+    int               profile_class = COLIBRI_K_COUNT;  // profile = 2: the one kernel class that is bracketed with events
     int               last_passes = 1;  // passes over key slices of the order-2 stage of that run
     struct Segment {
         uint32_t first, count;
@@ -256,7 +257,7 @@ struct Prof {
     size_t       idx = (size_t)-1;
     Prof(colibri_ctx* c_, int cls_) : c(c_), cls(cls_) {
         if (!c->profile) return;
-        if (c->profile == 2 && cls != COLIBRI_K_BINCOUNT && cls != COLIBRI_K_COUNT && cls != COLIBRI_K_COUNT2) return;  // only the classes that can hold the dominant kernel
+        if (c->profile == 2 && cls != c->profile_class) return;  // only the class that holds the dominant kernel of the path this run takes (one event pair per step)
         EventPair ev{};
         ev.cls = cls;
         auto take = [&](hipEvent_t& e) {
@@ -1463,6 +1464,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     if ((rc = dev_alloc(c, c->ids[1], (size_t)npos + 1))) return rc;
     // the per-pass modes count their n-gram passes of order >= 2 on the radix path too (result indices as ids, see bin_count's dense codes)
     const bool radix_synced = synced && !constrained && o.table_mode == 0 && c->ntokens <= 128ull * 1000 * 1000;
+    c->profile_class = bi2 ? COLIBRI_K_COUNT2 : (binned || radix_synced) ? COLIBRI_K_BINCOUNT : COLIBRI_K_COUNT;
     // ... and so do the passes of a constrained run: a member window's key is its pattern number in the constraint set, counted in LDS like any other key
     const bool radix_constrained = constrained && o.table_mode == 0 && c->ntokens <= 128ull * 1000 * 1000;
     if (binned || radix_synced || radix_constrained) {

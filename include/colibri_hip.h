@@ -61,8 +61,8 @@ typedef struct colibri_options {
     int32_t prunenonsubsumed;       /* PRUNENONSUBSUMED: must be 0 here (a post-hoc pass over the finished model: the C++ face does it) */
     int32_t prunesubsumed;          /* PRUNESUBSUMED: must be 0 here (same)                                                             */
     int32_t indexed;                /* 0: PatternModel<uint32_t> (model type 10), 1: IndexedPatternModel<> (20)                         */
-    int32_t profile;                /* 1: bracket every kernel class with HIP events (colibri_kernel_time); 2: only the
-                                       counting classes K_COUNT / K_BINCOUNT (8-18 events per train instead of ~120)                   */
+    int32_t profile;                /* 1: bracket every kernel class with HIP events (colibri_kernel_time); 2: only the class that holds the
+                                       dominant kernel of the path the run takes (K_COUNT2 / K_BINCOUNT / K_COUNT): 2 events per step   */
     int32_t table_mode;             /* 0: automatic; 1: force the global open-addressed table; 2: force radix-partition + LDS count     */
 } colibri_options;
 

@@ -813,7 +813,6 @@ int bigram2_alloc(colibri_ctx* c, uint32_t npos) {
     }
     return COLIBRI_OK;
 }
-#define B2DBG(name) do { if (getenv("COLIBRI_DEBUG_SYNC")) { hipError_t e_ = hipStreamSynchronize(c->stream); fprintf(stderr, "[b2] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
 // ids_out (the modes that keep every order's ids; one pass only): also the RESULT index of the bigram at every position, kInvalid where it did not survive
 int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t* ids_out = nullptr) {
     const uint32_t    npos = pl.npos, nsurv = c->maxclass / 32 + 1;
@@ -839,34 +838,25 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
             Prof p(c, COLIBRI_K_EMIT2);
             hipLaunchKernelGGL(bi2_emit_kernel, dim3(kBi2EmitGrid), dim3(kBi2Threads), 0, c->stream, c->cls.p, c->uni_surv.p, nsurv, npos, b.clsbits, b.sbits, slice, b.posbits, recsA, b.region,
                                kBi2Sub, bs, c->state.p, c->b2.head_rows.p);
-        B2DBG("bi2_emit_kernel");
             if (slice == 0)
                 hipLaunchKernelGGL(bi2_head_reduce_kernel, dim3(kBi2HeadN / kBlock, kBi2HeadSplit), dim3(kBlock), 0, c->stream, c->b2.head_rows.p, kBi2EmitGrid, bs, c->state.p);
-        B2DBG("bi2_head_reduce_kernel");
             hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, b.region, kBi2Sub, c->state.p);
-        B2DBG("bi2_offsets_kernel");
         }
         {
             Prof p(c, COLIBRI_K_LEVELB2);
             hipLaunchKernelGGL(bi2_levelB_kernel, dim3(b.nslots), dim3(kBi2Threads), 0, c->stream, recsA, recsB, b.region, bs, c->b2.boff.p, c->state.p);
-        B2DBG("bi2_levelB_kernel");
             hipLaunchKernelGGL(bi2_binoff_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->b2.boff.p, kBi2Sub, c->state.p);
-        B2DBG("bi2_binoff_kernel");
         }
         {
             Prof p(c, COLIBRI_K_COUNT2);
             hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr, io.sp_rep, io.sp_cnt,
                                c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list, ids_out != nullptr ? c->b2.wcode.p : (uint32_t*)nullptr);
-        B2DBG("bi2_count_kernel");
         }
         {
             Prof p(c, COLIBRI_K_PRUNE);
             hipLaunchKernelGGL(bi2_kept_scan_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->state.p);
-        B2DBG("bi2_kept_scan_kernel");
             hipLaunchKernelGGL(bi2_finish_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->state.p, bs, pl.thr, pl.res_cap, slice == 0 ? c->b2.headsurv.p : (uint32_t*)nullptr);
-        B2DBG("bi2_finish_kernel");
             hipLaunchKernelGGL(bi2_compact_kernel, dim3(1025), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, bs, c->res_rep.p, c->res_cnt.p, pl.res_cap);
-        B2DBG("bi2_compact_kernel");
         }
     }
     if (!want_list) return COLIBRI_OK;
@@ -875,16 +865,13 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
         Prof p(c, COLIBRI_K_LISTS2);
         hipLaunchKernelGGL(bi2_pospart_kernel, dim3(512), dim3(kBi2Threads), 0, c->stream, c->b2.wlist.p, c->b2.wcnt.p, kBi2Waves, b.wcap, bs, c->state.p, c->b2.plist.p, b.pl,
                            ids_out != nullptr ? (const uint32_t*)c->b2.wcode.p : (const uint32_t*)nullptr, ids_out != nullptr ? c->b2.pcode.p : (uint32_t*)nullptr);
-        B2DBG("bi2_pospart_kernel");
         if (ids_out != nullptr) {
             hipLaunchKernelGGL(bi2_ids_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), 0, c->stream, npos, bs, c->b2.plist.p, c->b2.pcode.p, b.pl, c->state.p, ids_out);
             hipLaunchKernelGGL(bi2_headids_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, c->state.p, c->b2.headid.p);
         }
         hipLaunchKernelGGL(bi2_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, bs, c->b2.plist.p, b.pl, c->state.p, c->b2.bitmap.p);
-        B2DBG("bi2_bitmap_kernel");
         hipLaunchKernelGGL(bi2_list3_kernel, dim3(2048), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_surv.p, npos, c->b2.headsurv.p, c->b2.bitmap.p, c->state.p, c->alist[1].p, nlist, ids_out,
                            ids_out != nullptr ? (const uint32_t*)c->b2.headid.p : (const uint32_t*)nullptr);
-        B2DBG("bi2_list3_kernel");
     }
     return COLIBRI_OK;
 }

@@ -135,6 +135,7 @@ struct colibri_ctx {
     struct Bigram2 {                    // second-generation order 2 (bigram2.hpp)
         DevBuf<Bi2State> state;
         DevBuf<uint32_t> boff, head_rows, wlist, wcnt, plist, bitmap, headsurv;
+        DevBuf<uint8_t>  sid;                    // sliced orders: the key slice of the window at every position (first pass), read by the later passes
         DevBuf<uint32_t> wcode, pcode, headid;  // the modes that keep ids: (bin, rank) codes beside the positions, result index of every head bigram
         bool             disabled = false;  // set for the rerun after this path could not hold an order (region / bin / list overflow)
         bool             attr_set = false;
@@ -495,7 +496,7 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->fx.keys); dev_free(c->fx.keyoff); dev_free(c->fx.refoff); dev_free(c->fx.cnt); dev_free(c->fx.sentence); dev_free(c->fx.token);
     dev_free(c->tx.table); dev_free(c->tx.state); dev_free(c->tx.info); dev_free(c->tx.events); dev_free(c->tx.evcnt);
     dev_free(c->flag2);
-    dev_free(c->b2.wcode); dev_free(c->b2.pcode); dev_free(c->b2.headid);
+    dev_free(c->b2.wcode); dev_free(c->b2.pcode); dev_free(c->b2.headid); dev_free(c->b2.sid);
     dev_free(c->b2.state); dev_free(c->b2.boff); dev_free(c->b2.head_rows); dev_free(c->b2.wlist); dev_free(c->b2.wcnt); dev_free(c->b2.plist); dev_free(c->b2.bitmap); dev_free(c->b2.headsurv);
     dev_free(c->ids_at);
     dev_free(c->alist[0]);
@@ -807,6 +808,10 @@ int bigram2_alloc(colibri_ctx* c, uint32_t npos) {
         (rc = dev_alloc(c, c->b2.wcnt, kBi2Waves)) || (rc = dev_alloc(c, c->b2.plist, (size_t)kBi2Shards * kBi2Buckets * b.pl.pcap + 64)) ||
         (rc = dev_alloc(c, c->b2.bitmap, (size_t)npos / 32 + 16)) || (rc = dev_alloc(c, c->b2.headsurv, kBi2HeadN / 32)))
         return rc;
+    if (b.sbits) {
+        if ((rc = dev_alloc(c, c->b2.sid, (size_t)npos + 64))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->b2.sid.p + (npos & ~15u), 0xFF, 64, c->stream));  // the 16-byte loads of the last positions read "no window" beyond the corpus
+    }
     if (!c->b2.attr_set) {
         HIP_TRY(c, hipFuncSetAttribute((const void*)bi2_bitmap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)1 << kBi2MaxPosBits) / kBi2Buckets / 8)));
         c->b2.attr_set = true;
@@ -836,8 +841,12 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
         HIP_TRY(c, hipMemsetAsync(bs, 0, sizeof(Bi2State), c->stream));
         {
             Prof p(c, COLIBRI_K_EMIT2);
-            hipLaunchKernelGGL(bi2_emit_kernel, dim3(kBi2EmitGrid), dim3(kBi2Threads), 0, c->stream, c->cls.p, c->uni_surv.p, nsurv, npos, b.clsbits, b.sbits, slice, b.posbits, recsA, b.region,
-                               kBi2Sub, bs, c->state.p, c->b2.head_rows.p);
+            if (slice == 0 || b.sbits < 2 || getenv("COLIBRI_SLICED_EMIT_OFF"))  // (two slices: a step of 16 384 positions would fill the queue)
+                hipLaunchKernelGGL(bi2_emit_kernel, dim3(kBi2EmitGrid), dim3(kBi2Threads), 0, c->stream, c->cls.p, c->uni_surv.p, nsurv, npos, b.clsbits, b.sbits, slice, b.posbits, recsA,
+                                   b.region, kBi2Sub, bs, c->state.p, c->b2.head_rows.p, b.sbits ? c->b2.sid.p : (uint8_t*)nullptr);
+            else  // the first pass left every window's slice in sid: the later ones only touch their own windows
+                hipLaunchKernelGGL(bi2_emit_sliced_kernel, dim3(kBi2EmitGrid), dim3(kBi2Threads), 0, c->stream, c->cls.p, (const uint8_t*)c->b2.sid.p, npos, b.clsbits, b.sbits, slice, b.posbits,
+                                   std::max(1u, std::min(8u, 1u << b.sbits) / 4u), recsA, b.region, kBi2Sub, bs, c->state.p);
             if (slice == 0)
                 hipLaunchKernelGGL(bi2_head_reduce_kernel, dim3(kBi2HeadN / kBlock, kBi2HeadSplit), dim3(kBlock), 0, c->stream, c->b2.head_rows.p, kBi2EmitGrid, bs, c->state.p);
             hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, b.region, kBi2Sub, c->state.p);

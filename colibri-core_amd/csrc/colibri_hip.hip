@@ -1562,7 +1562,9 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             cur ^= 1;
             if (big && binned && n >= 2 && n < maxlength) {  // a big corpus: how many passes the next order needs follows from how many positions still carry a survivor
                 uint32_t valid = 0;
-                HIP_TRY(c, hipMemcpyAsync(&valid, &c->state.p->s_valid[n], sizeof valid, hipMemcpyDeviceToHost, c->stream));
+                // (after the second-generation order 2 the next order's records are exactly the entries of the list it left: windows whose two bigrams both survived)
+                const uint32_t* src = (n == 2 && bi2) ? (const uint32_t*)(c->alist_n.p + 1) : (const uint32_t*)&c->state.p->s_valid[n];
+                HIP_TRY(c, hipMemcpyAsync(&valid, src, sizeof valid, hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
                 sbits_next = slice_bits(valid);
             }

@@ -142,6 +142,7 @@ struct colibri_ctx {
     } b2;
     DevBuf<uint32_t>  alist[2], alist_n; // binned path: active-position lists (ping-pong) and their lengths [2]
     DevBuf<BinState>  binstate;
+    bool              export_ready = false;  // keylen / keyoff / keybytes of the trained model are computed
     int               last_mode = 0;    // 1 = global table, 2 = binned (what the last train() actually ran)
     int               profile_class = COLIBRI_K_COUNT;  // profile = 2: the one kernel class that is bracketed with events
     int               last_passes = 1;  // passes over key slices of the order-2 stage of that run
@@ -1365,8 +1366,7 @@ int train_pattern_list(colibri_ctx* c, const colibri_options& o, colibri_stats* 
     c->trained    = true;
     c->keybytes   = 0;
     c->last_mode  = 0;
-    if ((rc = prepare_export(c))) return rc;
-    s.keybytes = c->keybytes;
+    c->export_ready = false;  // key lengths / offsets: computed when the results are first asked for (colibri_result_sizes)
     if (stats_out) *stats_out = s;
     return COLIBRI_OK;
 }
@@ -1946,10 +1946,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     s.totaltypes = constrained ? 0 : s.found[1];  // distinct unigrams before pruning (patternmodel.h:1199-1201); a constrained run leaves it unset (:1197: constrainbymodel != NULL)
     c->trained   = true;
     c->keybytes  = 0;
-
-    if ((rc = prepare_export(c))) return rc;
-    collect_events(c);
-    s.keybytes = c->keybytes;
+    c->export_ready = false;  // key lengths / offsets: computed when the results are first asked for (colibri_result_sizes), not part of counting
     s.nrefs    = o.indexed ? c->npairs : 0;
     if (stats_out) *stats_out = s;
     return COLIBRI_OK;
@@ -1957,9 +1954,23 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
 
 extern "C" {
 
-int colibri_result_sizes(const colibri_ctx* c, uint64_t* npatterns, uint64_t* keybytes, uint64_t* nrefs) {
+// key byte lengths and offsets of the results, once per trained model
+static int ensure_export(colibri_ctx* c) {
+    if (c->export_ready) return COLIBRI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = prepare_export(c);
+    if (rc) return rc;
+    collect_events(c);
+    c->stats.keybytes = c->keybytes;
+    c->export_ready   = true;
+    return COLIBRI_OK;
+}
+
+int colibri_result_sizes(colibri_ctx* c, uint64_t* npatterns, uint64_t* keybytes, uint64_t* nrefs) {
     if (!c) return COLIBRI_ERR_ARG;
     if (!c->trained) return COLIBRI_ERR_STATE;
+    int rc0 = ensure_export(c);
+    if (rc0) return rc0;
     if (npatterns) *npatterns = c->hstate.res_total;
     if (keybytes) *keybytes = c->keybytes;
     if (nrefs) *nrefs = c->opt.indexed ? c->npairs : 0;
@@ -1967,8 +1978,11 @@ int colibri_result_sizes(const colibri_ctx* c, uint64_t* npatterns, uint64_t* ke
 }
 
 int colibri_export_unindexed(colibri_ctx* c, uint64_t* key_off, uint8_t* key_bytes, uint32_t* counts) {
-    if (!c || !key_off || !counts || (!key_bytes && c->keybytes)) return COLIBRI_ERR_ARG;
+    if (!c || !key_off || !counts) return COLIBRI_ERR_ARG;
     if (!c->trained) return fail(c, COLIBRI_ERR_STATE, "export before train");
+    int rc0 = ensure_export(c);
+    if (rc0) return rc0;
+    if (!key_bytes && c->keybytes) return COLIBRI_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     const uint32_t R = c->hstate.res_total;
     key_off[R]       = c->keybytes;

@@ -72,7 +72,8 @@ typedef struct colibri_stats {
     uint64_t totaltokens;                  /* sum of sentence lengths (patternmodel.h:1047-1048)            */
     uint64_t totaltypes;                   /* distinct unigrams BEFORE pruning (:1199-1201)                  */
     uint64_t npatterns;                    /* size of the final model                                        */
-    uint64_t keybytes;                     /* sum of key byte lengths over the final model                   */
+    uint64_t keybytes;                     /* sum of key byte lengths over the final model: 0 in what colibri_train returns (serialised sizes
+                                              are not part of counting); colibri_result_sizes computes and reports it                       */
     uint64_t nrefs;                        /* indexed: total index entries                                   */
     uint64_t nsentences;                   /* sentences incl. empty ones                                     */
     int32_t  maxn, minn;                   /* as PatternModel::maxlength()/minlength()                       */
@@ -132,7 +133,7 @@ int colibri_train(colibri_ctx* ctx, const colibri_options* opt, colibri_stats* s
  *   indexed: ref_off[npatterns+1], ref_sentence[nrefs], ref_token[nrefs]; refs sorted by (sentence, token).
  * Keys are the pattern's bytes without the trailing 00 (a skipgram's gaps are the byte 03). Order: by
  * pattern length n, unspecified inside an order (the reference's order is unordered_map order). */
-int colibri_result_sizes(const colibri_ctx* ctx, uint64_t* npatterns, uint64_t* keybytes, uint64_t* nrefs);
+int colibri_result_sizes(colibri_ctx* ctx, uint64_t* npatterns, uint64_t* keybytes, uint64_t* nrefs); /* the first call after a train computes the key lengths on the device */
 int colibri_export_unindexed(colibri_ctx* ctx, uint64_t* key_off, uint8_t* key_bytes, uint32_t* counts);
 int colibri_export_indexed(colibri_ctx* ctx, uint64_t* key_off, uint8_t* key_bytes, uint32_t* counts, uint64_t* ref_off,
                            uint32_t* ref_sentence, uint16_t* ref_token);

@@ -214,15 +214,15 @@ class RankDriver {
         uint64_t nrecv = 0;
         for (uint64_t v : per_src) nrecv += v;
         const size_t ns = std::max<uint64_t>(ncand, 1), nr = std::max<uint64_t>(nrecv, 1);
-        keys.reserve(ns * 8), cnts.reserve(ns * 4);
-        if (use_aux) aux.reserve(ns * 4);
-        chk(colibri_shard_send(c, keys.p, cnts.p, use_aux ? aux.p : nullptr), "colibri_shard_send");
+        void *skeys = nullptr, *scnts = nullptr, *saux = nullptr;  // the library's own partitioned buffers: sent from where they lie
+        chk(colibri_shard_send_view(c, &skeys, &scnts, &saux), "colibri_shard_send_view");
+        if (use_aux && saux == nullptr) throw std::runtime_error("the pass has no distinct-filler counts to send");
         rkeys.reserve(nr * 8), rcnts.reserve(nr * 4);
-        all_to_all(keys.p, per_owner, rkeys.p, per_src, 8);
-        all_to_all(cnts.p, per_owner, rcnts.p, per_src, 4);
+        all_to_all(skeys, per_owner, rkeys.p, per_src, 8);
+        all_to_all(scnts, per_owner, rcnts.p, per_src, 4);
         if (use_aux) {
             raux.reserve(nr * 4);
-            all_to_all(aux.p, per_owner, raux.p, per_src, 4);
+            all_to_all(saux, per_owner, raux.p, per_src, 4);
         }
         uint64_t found = 0, kept = 0;
         chk(colibri_shard_merge(c, rkeys.p, rcnts.p, use_aux ? raux.p : nullptr, per_src.data(), &found, &kept), "colibri_shard_merge");
@@ -271,7 +271,7 @@ class RankDriver {
             uint64_t  f = 0, k = 0;
             bool      complete = true;
             for (int level = 1; level <= levels; ++level) {
-                pass(n, mask, level, o.doskipgrams != 0, f, k);
+                pass(n, mask, level, o.doskipgrams != 0 && level == levels, f, k);  // the distinct-filler counts travel at the last level only
                 if (f == 0) {
                     complete = false;
                     break;

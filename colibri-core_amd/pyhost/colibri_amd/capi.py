@@ -20,7 +20,7 @@ EXPORTED = [
     "colibri_abi_version", "colibri_create", "colibri_destroy", "colibri_last_error", "colibri_upload_corpus",
     "colibri_upload_corpus_device", "colibri_corpus_info", "colibri_train", "colibri_result_sizes", "colibri_export_unindexed",
     "colibri_export_indexed", "colibri_hash_windows", "colibri_positions", "colibri_last_mode", "colibri_hash_keys", "colibri_kernel_time",
-    "colibri_shard_begin", "colibri_shard_count", "colibri_shard_send", "colibri_shard_merge", "colibri_shard_reply", "colibri_shard_apply",
+    "colibri_shard_begin", "colibri_shard_count", "colibri_shard_send", "colibri_shard_send_view", "colibri_shard_merge", "colibri_shard_reply", "colibri_shard_apply",
     "colibri_shard_finish", "colibri_shard_export_gids", "colibri_shard_index_sizes", "colibri_shard_export_index",
     "colibri_shard_uni_info", "colibri_shard_uni_count", "colibri_shard_uni_apply",
     "colibri_set_constraint", "colibri_set_continuation", "colibri_set_filter", "colibri_text_upload", "colibri_text_count", "colibri_text_words", "colibri_text_encode", "colibri_text_fetch", "colibri_text_as_corpus",
@@ -104,6 +104,7 @@ def load():
         L.colibri_shard_begin.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int]
         L.colibri_shard_count.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.c_void_p]
         L.colibri_shard_send.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.colibri_shard_send_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         L.colibri_shard_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.colibri_shard_reply.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.colibri_shard_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -343,11 +344,40 @@ class HipShardEngine:
         self.ncand = int(nc.value)
         # the distinct-source counts only travel in the skipgram passes of indexed models (colibri_shard_count: use_aux); every rank
         # derives this from the same options, so all ranks agree on whether the third buffer is exchanged
-        self.use_aux = bool(mask) and self.doskipgrams
+        if mask and self.doskipgrams:  # ... and only at the last level of the mask (the earlier ones intern pairs of ids: nothing is pruned there)
+            parts, k = 0, 0
+            while k < n:
+                if (mask >> k) & 1:
+                    k += 1
+                    continue
+                parts += 1
+                while k < n and not (mask >> k) & 1:
+                    k += 1
+            self.use_aux = level == parts - 1
+        else:
+            self.use_aux = False
         return self.ncand, [int(x) for x in per]
+
+    class _DeviceView:  # a torch tensor over device memory of the library (no copy): the CUDA array interface, which PyTorch-ROCm speaks too
+        def __init__(self, ptr, n, typestr):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+    _views_ok = True
 
     def send_buffers(self):
         t = self.torch
+        if HipShardEngine._views_ok and self.ncand:
+            try:
+                k, cn, a = C.c_void_p(), C.c_void_p(), C.c_void_p()
+                self.ctx._check(self.L.colibri_shard_send_view(self.ctx.h, C.byref(k), C.byref(cn), C.byref(a)))
+                keys = t.as_tensor(HipShardEngine._DeviceView(k.value, self.ncand, "<i8"), device=self.device)
+                cnts = t.as_tensor(HipShardEngine._DeviceView(cn.value, self.ncand, "<i4"), device=self.device)
+                aux = t.as_tensor(HipShardEngine._DeviceView(a.value, self.ncand, "<i4"), device=self.device) if (self.use_aux and a.value) else None
+                if self.use_aux and aux is None:
+                    raise RuntimeError("no aux view")
+                return keys, cnts, aux
+            except Exception:  # noqa: BLE001 — a torch build without the interface: copy instead
+                HipShardEngine._views_ok = False
         keys = t.empty(max(1, self.ncand), dtype=t.int64, device=self.device)
         cnts = t.empty(max(1, self.ncand), dtype=t.int32, device=self.device)
         aux = t.empty(max(1, self.ncand), dtype=t.int32, device=self.device) if self.use_aux else None

@@ -46,13 +46,15 @@ class ShardedTrainer:
         if tensor.is_cuda:
             self.torch.cuda.current_stream(tensor.device).synchronize()
 
-    def _all_to_all_v(self, tensor, send_sizes, recv_sizes):
+    def _all_to_all_v(self, tensor, send_sizes, recv_sizes, sync=True):
+        """sync=False: another collective follows on the same stream before the library reads anything (one wait for the group instead of one each)"""
         home = tensor.device
         src = tensor.contiguous().cpu() if (self.stage_host and tensor.is_cuda) else tensor.contiguous()
         out = self.torch.empty(sum(recv_sizes), dtype=src.dtype, device=src.device)
         self.dist.all_to_all_single(out, src, recv_sizes, send_sizes)
         out = out.to(home) if out.device != home else out
-        self._sync(out)
+        if sync:
+            self._sync(out)
         return out
 
     def _all_reduce(self, tensor, op):
@@ -107,8 +109,8 @@ class ShardedTrainer:
             raise RuntimeError(f"sharded pass (n={n}, mask={mask}, level={level}): local count failed on rank(s) "
                                f"{[r for r, v in enumerate(recv_sizes) if v == FAILED]}" + (f": {err}" if err is not None else ""))
         keys, cnts, aux = eng.send_buffers()
-        rkeys = self._all_to_all_v(keys, per_owner, recv_sizes)
-        rcnts = self._all_to_all_v(cnts, per_owner, recv_sizes)
+        rkeys = self._all_to_all_v(keys, per_owner, recv_sizes, sync=False)
+        rcnts = self._all_to_all_v(cnts, per_owner, recv_sizes, sync=aux is None)
         raux = self._all_to_all_v(aux, per_owner, recv_sizes) if aux is not None else None  # distinct-source counts: indexed skipgram passes only
         try:
             found, kept = eng.merge(rkeys, rcnts, raux, recv_sizes)
@@ -125,7 +127,7 @@ class ShardedTrainer:
         if state["gid_total"] + kept_all >= (1 << 31):
             raise OverflowError("more than 2^31 surviving patterns")
         rgid, rtot = eng.reply(base)
-        gid = self._all_to_all_v(rgid, recv_sizes, per_owner)
+        gid = self._all_to_all_v(rgid, recv_sizes, per_owner, sync=False)
         tot = self._all_to_all_v(rtot, recv_sizes, per_owner)
         eng.apply(gid, tot)
         state["gid_total"] += kept_all

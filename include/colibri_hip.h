@@ -157,6 +157,8 @@ int colibri_shard_count(colibri_ctx* ctx, int n, uint32_t mask, int level, uint6
 /* copy the partitioned candidates into the caller's send buffers: keys u64[ncandidates], counts u32[ncandidates],
  * aux u32[ncandidates] (distinct-source counts of indexed skipgrams; zeros otherwise; may be NULL when not wanted) */
 int colibri_shard_send(colibri_ctx* ctx, void* keys_dev, void* counts_dev, void* aux_dev);
+/* the same without a copy: the library's own partitioned buffers (device pointers, valid until the next colibri_shard_count; *aux_dev = NULL when the pass has none) */
+int colibri_shard_send_view(colibri_ctx* ctx, void** keys_dev, void** counts_dev, void** aux_dev);
 /* owner side: merge the records received from every rank (concatenated in rank order; per_src[r] records from rank r) */
 int colibri_shard_merge(colibri_ctx* ctx, const void* keys_dev, const void* counts_dev, const void* aux_dev, const uint64_t* per_src /* [world] */,
                         uint64_t* found, uint64_t* kept);

@@ -132,7 +132,7 @@ class RankDriver {
     const int    rank, world, dev;
     colibri_ctx* c      = nullptr;
     hipStream_t  stream = nullptr;
-    DevMem       keys, cnts, aux, rkeys, rcnts, raux, rgid, rtot, gid, tot, ucnt, umr;
+    DevMem       rkeys, rcnts, raux, rgid, rtot, gid, tot, ucnt, umr;  // receive / reply buffers (the candidates are sent from the library's own buffers)
     uint64_t     gid_total = 0;
 
     void chk(int rc, const char* what) {

@@ -1926,6 +1926,8 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             }
         }
         c->hstate.res_total = res_total;
+        c->last_mode        = (radix_synced || radix_constrained) ? 2 : 1;
+        c->last_passes      = 1;
         if (o.indexed && (rc = finalize_index(c, res_total))) {
             if (rc == kRerunPairs) return colibri_train_once(c, opt_in, stats_out);  // (a model with more than two references per position)
             return rc;

@@ -129,3 +129,40 @@ def test_default_mode_agrees_on_other_class_spaces(vocab, phrases):
     assert got[0][0] == got[1][0]
     for x, y in zip(got[0][1], got[1][1]):
         assert np.array_equal(np.sort(x), np.sort(y))
+
+
+def _refs_digest(refs):
+    """per pattern: an order-dependent 64-bit digest of its reference list (sentence, token)"""
+    ref_off, rs, rt = refs
+    n = ref_off.size - 1
+    v = (rs.astype(np.uint64) << np.uint64(16)) | rt.astype(np.uint64)
+    pos = np.arange(v.size, dtype=np.uint64) - np.repeat(ref_off[:-1], (ref_off[1:] - ref_off[:-1]).astype(np.int64))  # index inside the pattern's list
+    with np.errstate(over="ignore"):
+        w = (v + np.uint64(0x9E3779B97F4A7C15)) * (np.uint64(2) * pos + np.uint64(0x100000001B3))
+        csum = np.concatenate([[np.uint64(0)], np.cumsum(w, dtype=np.uint64)])
+    return csum[ref_off[1:].astype(np.int64)] - csum[ref_off[:-1].astype(np.int64)]
+
+
+@pytest.mark.parametrize("kw", [dict(indexed=1), dict(doskipgrams_exhaustive=1), dict(indexed=1, doskipgrams=1), dict(indexed=1, doskipgrams=1, minskiptypes=1)],
+                         ids=["indexed", "exhaustive-skipgrams", "indexed-skipgrams", "indexed-skipgrams-T1"])
+def test_id_keeping_modes_default_kernels_against_the_global_table(kw):
+    """20 M tokens — far beyond what the oracle does in seconds: the default kernels of the modes that keep every order's ids (second-generation order 2 with the
+    (bin, rank) -> result index hand-over, radix skipgram passes, packed forward-index sort) against the global-table implementation of the same modes (table_mode = 1:
+    device atomics, table skipgram passes): identical models as multisets of (key bytes, count, digest of the whole reference list)."""
+    from colibri_amd import capi, synth
+    payload = synth.zipf_corpus(20_000_000, 300_000, 7, phrases=True, header=False)
+    out = []
+    with capi.Context(0) as ctx:
+        ctx.upload(payload)
+        for mode in (0, 1):
+            st = ctx.train(mintokens=2, maxlength=5, table_mode=mode, **kw)
+            key_off, key_bytes, counts, refs = ctx.export_arrays()
+            extra = counts.astype(np.uint64)
+            if refs is not None:
+                with np.errstate(over="ignore"):
+                    extra = extra * np.uint64(0xD6E8FEB86659FD93) + _refs_digest(refs)
+            h1, h2 = row_hashes(key_off, key_bytes, extra)
+            out.append((summary(st)[:6], int(st.nrefs), np.sort(h1), np.sort(h2), ctx.last_mode()))
+    assert out[0][4] == 2 and out[1][4] == 1  # the two runs really took different implementations
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])

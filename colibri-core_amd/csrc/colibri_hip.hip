@@ -1249,23 +1249,27 @@ int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = fal
         const uint32_t nblocks = (uint32_t)((n + kS64Tile - 1) / kS64Tile);
         const uint32_t nh = 256u * nblocks, nb = blocks_for(nh, kBlock * 4);
         if ((rc = dev_alloc(c, c->sort_hist, nh)) || (rc = dev_alloc(c, c->sort_off, nh)) || (rc = dev_alloc(c, c->sort_bsum, (size_t)nb + 1))) return rc;
-        for (int shift = 0; shift < bits_for(nresults); shift += 8) {
-            hipLaunchKernelGGL(sort64_hist_kernel, dim3(nblocks), dim3(kS64Threads), 0, c->stream, c->pairs[cur].p, n, 32 + shift, nblocks, c->sort_hist.p);
-            hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->sort_hist.p, nh, c->sort_bsum.p);
-            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->sort_bsum.p, nb, c->sort_bsum.p + nb);
-            hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->sort_hist.p, nh, c->sort_bsum.p, c->sort_off.p);
-            hipLaunchKernelGGL(sort64_scatter_kernel, dim3(nblocks), dim3(kS64Threads), 0, c->stream, c->pairs[cur].p, n, 32 + shift, nblocks, c->sort_off.p, c->pairs[cur ^ 1].p);
-            cur ^= 1;
-        }
         if (!c->pos_blocks_valid) {
             if ((rc = dev_alloc(c, c->pos_blocks, (size_t)c->npos / 64 + 2))) return rc;
             hipLaunchKernelGGL(position_blocks_kernel, dim3(stream_grid((uint64_t)c->npos / 16 + 1)), dim3(kBlock), 0, c->stream, c->cls.p, c->delimpos.p, c->ndelim, c->npos, c->pos_blocks.p);
             c->pos_blocks_valid = true;
         }
-        hipLaunchKernelGGL(refs_blocks_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, c->stream, c->pairs[cur].p, n, c->pos_blocks.p, c->first_sentence, c->ref_sentence.p, c->ref_token.p);
-        if (keep_sorted_ids) {  // sharded mode: the caller still needs the (sorted) global ids to cut the references into runs
-            if ((rc = dev_alloc(c, c->sh.sorted_gid, (size_t)n))) return rc;
-            hipLaunchKernelGGL(pair_ids_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, c->stream, c->pairs[cur].p, n, c->sh.sorted_gid.p);
+        if (keep_sorted_ids && (rc = dev_alloc(c, c->sh.sorted_gid, (size_t)n))) return rc;  // sharded mode: the caller still needs the (sorted) global ids to cut the references into runs
+        const int nbits = bits_for(nresults);
+        for (int shift = 0; shift < nbits; shift += 8) {
+            const bool last = shift + 8 >= nbits;  // the last pass writes (sentence, token) [and the ids] instead of pairs
+            hipLaunchKernelGGL(sort64_hist_kernel, dim3(nblocks), dim3(kS64Threads), 0, c->stream, c->pairs[cur].p, n, 32 + shift, nblocks, c->sort_hist.p);
+            hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->sort_hist.p, nh, c->sort_bsum.p);
+            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->sort_bsum.p, nb, c->sort_bsum.p + nb);
+            hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->sort_hist.p, nh, c->sort_bsum.p, c->sort_off.p);
+            if (!last)
+                hipLaunchKernelGGL((sort64_scatter_kernel<false>), dim3(nblocks), dim3(kS64Threads), 0, c->stream, c->pairs[cur].p, n, 32 + shift, nblocks, c->sort_off.p, c->pairs[cur ^ 1].p,
+                                   (const PosBlock*)nullptr, 0u, (uint32_t*)nullptr, (uint16_t*)nullptr, (uint32_t*)nullptr);
+            else
+                hipLaunchKernelGGL((sort64_scatter_kernel<true>), dim3(nblocks), dim3(kS64Threads), 0, c->stream, c->pairs[cur].p, n, 32 + shift, nblocks, c->sort_off.p,
+                                   (unsigned long long*)nullptr, (const PosBlock*)c->pos_blocks.p, c->first_sentence, c->ref_sentence.p, c->ref_token.p,
+                                   keep_sorted_ids ? c->sh.sorted_gid.p : (uint32_t*)nullptr);
+            cur ^= 1;
         }
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -1294,6 +1294,13 @@ __global__ __launch_bounds__(kPairThreads) void emit_write_kernel(const uint32_t
     }
 }
 
+// the same with a table 30 x smaller (16 bytes per 64 positions instead of 8 bytes per position): { sentences that end before the block, position where
+// the sentence running at the block's first position starts, one bit per position of the block that is a delimiter }. A model's 1.6 x 10^8 references
+// are sorted by pattern, i.e. their positions are random: gathers from the 0.8 GB per-position table went to HBM (3.5 ms), the 26 MB one stays in cache.
+struct __attribute__((aligned(16))) PosBlock {
+    uint32_t           sent_before, sent_start;
+    unsigned long long delim;
+};
 // ---- stable LSD radix sort of (key, value) u32 pairs, 8 bits per pass ----
 constexpr int kSortTile = 4096;  // elements per block per pass
 __global__ __launch_bounds__(kBlock) void sort_hist_kernel(const uint32_t* __restrict__ keys, uint64_t n, int shift, uint32_t nblocks, uint32_t* __restrict__ ghist) {
@@ -1372,8 +1379,14 @@ __global__ __launch_bounds__(kS64Threads) void sort64_hist_kernel(const unsigned
     __syncthreads();
     if (threadIdx.x < 256) ghist[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];  // digit-major so that one scan yields global offsets
 }
+// FINAL (the last pass): the elements do not leave as pairs again but as what the forward index is made of — (sentence, token) of the position, looked up in the
+// position-block table, and optionally the id (sharded runs cut the references into runs by global id) — which saves one read and one write of all pairs.
+template <bool FINAL>
 __global__ __launch_bounds__(kS64Threads, kS64Threads / 128) void sort64_scatter_kernel(const unsigned long long* __restrict__ in, uint64_t n, int shift, uint32_t nblocks,
-                                                                                         const unsigned long long* __restrict__ goff, unsigned long long* __restrict__ out) {
+                                                                                         const unsigned long long* __restrict__ goff, unsigned long long* __restrict__ out,
+                                                                                         const PosBlock* __restrict__ blocks = nullptr, uint32_t first_sentence = 0,
+                                                                                         uint32_t* __restrict__ ref_sentence = nullptr, uint16_t* __restrict__ ref_token = nullptr,
+                                                                                         uint32_t* __restrict__ sorted_id = nullptr) {
     __shared__ unsigned long long stgL[kS64Tile];
     __shared__ uint16_t           gcntL[kS64Groups][256];  // elements of digit d in group (row, wave); then: elements of digit d in the groups before it
     __shared__ uint32_t           histL[256], offL[256], wsumL[4];
@@ -1439,15 +1452,34 @@ __global__ __launch_bounds__(kS64Threads, kS64Threads / 128) void sort64_scatter
     }
     __syncthreads();
     const uint32_t cnt = (uint32_t)min((uint64_t)kS64Tile, n - t0);
-    for (uint32_t j = threadIdx.x; j < cnt; j += kS64Threads) {
-        const unsigned long long y = stgL[j];
-        const uint32_t           d = (uint32_t)(y >> shift) & 255u;
-        out[gbaseL[d] + (j - offL[d])] = y;
+    if (!FINAL) {
+        for (uint32_t j = threadIdx.x; j < cnt; j += kS64Threads) {
+            const unsigned long long y = stgL[j];
+            const uint32_t           d = (uint32_t)(y >> shift) & 255u;
+            out[gbaseL[d] + (j - offL[d])] = y;
+        }
+    } else {
+        unsigned long long y[kS64Per];
+        uint4              r[kS64Per];
+#pragma unroll
+        for (int q = 0; q < kS64Per; ++q) {  // all look-ups of the lane in flight together
+            const uint32_t j = q * kS64Threads + threadIdx.x;
+            y[q]             = j < cnt ? stgL[j] : 0ull;
+            r[q]             = *reinterpret_cast<const uint4*>(blocks + ((uint32_t)y[q] >> 6));
+        }
+#pragma unroll
+        for (int q = 0; q < kS64Per; ++q) {
+            const uint32_t j = q * kS64Threads + threadIdx.x;
+            if (j < cnt) {
+                const uint32_t d = (uint32_t)(y[q] >> shift) & 255u, p = (uint32_t)y[q], bit = p & 63u;
+                const uint64_t dst   = gbaseL[d] + (j - offL[d]);
+                const uint64_t below = (((uint64_t)r[q].w << 32) | r[q].z) & ((1ull << bit) - 1ull);
+                ref_sentence[dst]    = first_sentence + r[q].x + (uint32_t)__popcll(below);
+                ref_token[dst]       = (uint16_t)(below ? bit - (64u - (uint32_t)__clzll(below)) : p - r[q].y);
+                if (sorted_id != nullptr) sorted_id[dst] = (uint32_t)(y[q] >> 32);
+            }
+        }
     }
-}
-// the ids (high words) of sorted pairs, as their own array (the sharded index cuts the references into runs by global id)
-__global__ __launch_bounds__(kBlock) void pair_ids_kernel(const unsigned long long* __restrict__ pairs, uint64_t n, uint32_t* __restrict__ ids) {
-    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (uint64_t)gridDim.x * kBlock) ids[j] = (uint32_t)(pairs[j] >> 32);
 }
 
 // position -> (sentence, token): sentence = first_sentence + #delimiters before the position (empty sentences are numbered,
@@ -1470,13 +1502,6 @@ __global__ __launch_bounds__(kBlock) void refs_kernel(const uint32_t* __restrict
     }
 }
 
-// the same with a table 30 x smaller (16 bytes per 64 positions instead of 8 bytes per position): { sentences that end before the block, position where
-// the sentence running at the block's first position starts, one bit per position of the block that is a delimiter }. A model's 1.6 x 10^8 references
-// are sorted by pattern, i.e. their positions are random: gathers from the 0.8 GB per-position table went to HBM (3.5 ms), the 26 MB one stays in cache.
-struct __attribute__((aligned(16))) PosBlock {
-    uint32_t           sent_before, sent_start;
-    unsigned long long delim;
-};
 __global__ __launch_bounds__(kBlock) void position_blocks_kernel(const uint32_t* __restrict__ cls, const uint32_t* __restrict__ delimpos, uint32_t ndelim, uint32_t npos,
                                                                   PosBlock* __restrict__ blocks) {
     const uint32_t nblk = (npos + 63) / 64, lane = threadIdx.x & (kWave - 1);
@@ -1497,31 +1522,6 @@ __global__ __launch_bounds__(kBlock) void position_blocks_kernel(const uint32_t*
             x.sent_start  = lo ? delimpos[lo - 1] + 1 : 0u;
             x.delim       = m;
             blocks[b]     = x;
-        }
-    }
-}
-__global__ __launch_bounds__(kBlock) void refs_blocks_kernel(const unsigned long long* __restrict__ pairs /* position in the low word */, uint64_t n, const PosBlock* __restrict__ blocks,
-                                                              uint32_t first_sentence, uint32_t* __restrict__ ref_sentence, uint16_t* __restrict__ ref_token) {
-    constexpr int kPer = 4;  // gathers in flight per lane
-    for (uint64_t j0 = (uint64_t)blockIdx.x * kBlock * kPer; j0 < n; j0 += (uint64_t)gridDim.x * kBlock * kPer) {
-        uint32_t p[kPer];
-        uint4    r[kPer];
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-            const uint64_t j = j0 + (uint64_t)q * kBlock + threadIdx.x;
-            p[q]             = j < n ? (uint32_t)pairs[j] : 0u;
-        }
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) r[q] = *reinterpret_cast<const uint4*>(blocks + (p[q] >> 6));
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-            const uint64_t j = j0 + (uint64_t)q * kBlock + threadIdx.x;
-            if (j < n) {
-                const uint32_t bit   = p[q] & 63u;
-                const uint64_t below = (((uint64_t)r[q].w << 32) | r[q].z) & ((1ull << bit) - 1ull);  // delimiters of the block before this position
-                ref_sentence[j]      = first_sentence + r[q].x + (uint32_t)__popcll(below);
-                ref_token[j]         = (uint16_t)(below ? bit - (64u - (uint32_t)__clzll(below)) : p[q] - r[q].y);
-            }
         }
     }
 }

@@ -143,6 +143,7 @@ struct colibri_ctx {
     DevBuf<uint32_t>  alist[2], alist_n; // binned path: active-position lists (ping-pong) and their lengths [2]
     DevBuf<BinState>  binstate;
     bool              export_ready = false;  // keylen / keyoff / keybytes of the trained model are computed
+    bool              ids1_is_cls = false;   // this run keeps no per-position order-1 ids: one-token skipgram parts are named by their class ids (part_ids)
     int               last_mode = 0;    // 1 = global table, 2 = binned (what the last train() actually ran)
     int               profile_class = COLIBRI_K_COUNT;  // profile = 2: the one kernel class that is bracketed with events
     int               last_passes = 1;  // passes over key slices of the order-2 stage of that run
@@ -932,11 +933,15 @@ int build_skip_list(colibri_ctx* c, const TrainPlan& pl, const uint32_t* gate) {
     return COLIBRI_OK;
 }
 
+// identity of a skipgram part of `len` tokens at a position: the survivor id of that n-gram — or, for one-token parts of a run that keeps no order-1 ids
+// (c->ids1_is_cls: unindexed, class-keyed order 2), the token's class id, which names a surviving word just as well
+inline const uint32_t* part_ids(const colibri_ctx* c, int len) { return (len == 1 && c->ids1_is_cls) ? (const uint32_t*)c->cls.p : (const uint32_t*)c->ids[(size_t)len].p; }
+
 int skipgram_pass(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, const uint32_t* gate, const uint32_t* gate2, uint32_t participants, uint32_t thr, bool count_sources,
                   uint32_t minsrc, uint32_t* found_out, uint32_t* kept_out, int* final_scratch) {
     const std::vector<std::pair<int, int>> parts = mask_parts(mask, n);
     const uint32_t cap = (uint32_t)std::min<uint64_t>(pl.table_slots, (uint64_t)participants + (participants >> 1) + 1024u);
-    const uint32_t* left = c->ids[parts[0].second].p;
+    const uint32_t* left = part_ids(c, parts[0].second);
     uint32_t        offl = (uint32_t)parts[0].first;
     uint32_t*       out  = nullptr;
     int             rc;
@@ -948,7 +953,7 @@ int skipgram_pass(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, con
         launch_clear(c, pl);
         out = c->scratch[j & 1].p;
         HIP_TRY(c, hipMemsetAsync(out, 0xFF, sizeof(uint32_t) * (size_t)pl.npos, c->stream));  // only the listed positions are written
-        KeyPair fn{gate, gate2, left, offl, c->ids[parts[j].second].p, (uint32_t)parts[j].first};
+        KeyPair fn{gate, gate2, left, offl, part_ids(c, parts[j].second), (uint32_t)parts[j].first};
         launch_count(c, pl, fn, out, last ? 2 : 0, COLIBRI_K_SKIPGRAM, c->skl, c->skl_n);
         left = out;
         offl = 0;
@@ -1006,7 +1011,7 @@ constexpr int kRerunOnTable = 1000;
 int skipgram_pass_radix(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, const uint32_t* gate, const uint32_t* gate2, uint32_t thr, uint32_t res_total, uint32_t* found_out,
                         uint32_t* kept_out, uint32_t** ids_out, uint32_t minsrc = 0, uint32_t src_first = 0, uint32_t src_count = 0) {
     const std::vector<std::pair<int, int>> parts = mask_parts(mask, n);
-    const uint32_t* left = c->ids[parts[0].second].p;
+    const uint32_t* left = part_ids(c, parts[0].second);
     uint32_t        offl = (uint32_t)parts[0].first;
     int             rc;
     for (size_t j = 1; j < parts.size(); ++j) {
@@ -1016,7 +1021,7 @@ int skipgram_pass_radix(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mas
         c->hstate.radix_overflow = 0;
         if ((rc = write_state(c))) return rc;
         uint32_t* const out = c->scratch[j & 1].p;
-        KeyPair fn{gate, gate2, left, offl, c->ids[parts[j].second].p, (uint32_t)parts[j].first};
+        KeyPair fn{gate, gate2, left, offl, part_ids(c, parts[j].second), (uint32_t)parts[j].first};
         if ((rc = binned_count_stage(c, pl, fn, n, true, last ? thr : 1u, false, need_ids, false, /*dense_code=*/true, 0, 0, c->skl, c->skl_n))) return rc;
         const BinnedIO io = binned_planes(c, pl, false);
         {
@@ -1609,6 +1614,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     } else {
         // ---------- skipgram / indexed modes: one host round trip per pass (sizes, lazily grown per-order id arrays) ----------
         if ((int)c->ids.size() < maxlength + 2) c->ids.resize(maxlength + 2);
+        c->ids1_is_cls        = false;
         bool       list_valid = false;  // the active list of the previous radix pass exists
         const bool uni_synced = !constrained && o.table_mode == 0 && !(c->flags & kFlagNonCanonical) && c->maxclass < (1u << 28);
         std::vector<uint32_t> valid_n(maxlength + 2, 0), adm_n(maxlength + 2, 0), ngram_first(maxlength + 2, 0), ngram_kept(maxlength + 2, 0);
@@ -1769,9 +1775,13 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                 {
                     Prof p(c, COLIBRI_K_PRUNE);
                     hipLaunchKernelGGL(uni_finish_kernel, dim3(stream_grid(nclasses)), dim3(kBlock), 0, c->stream, c->cnt1.p, (const uint32_t*)nullptr, nclasses, pl.thr, c->state.p,
-                                       c->res_rep.p, c->res_cnt.p, pl.res_cap, bi2_synced ? reinterpret_cast<uint16_t*>(c->uni_surv.p) : (uint16_t*)nullptr, false, c->uni_resid.p);
+                                       c->res_rep.p, c->res_cnt.p, pl.res_cap, bi2_synced ? reinterpret_cast<uint16_t*>(c->uni_surv.p) : (uint16_t*)nullptr,
+                                       /*count_valid=*/bi2_synced && !o.indexed /* no id pass follows then, see below */, c->uni_resid.p);
                 }
-                {
+                // per-position order-1 ids (result indices): read by the forward index and by a first-generation order 2; the skipgram passes of an unindexed run
+                // name their one-token parts by class id instead (part_ids)
+                c->ids1_is_cls = bi2_synced && !o.indexed;
+                if (!c->ids1_is_cls) {
                     Prof p(c, COLIBRI_K_RESOLVE);
                     hipLaunchKernelGGL(uni_resid_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_resid.p, c->ids[n].p, c->state.p, npos);
                 }

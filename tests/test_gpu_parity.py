@@ -373,14 +373,15 @@ def test_continued_training_matches_the_restatement(ctx, seed):
     ctx.upload(payload, first_sentence=1 + seed % 3)
     try:
         ctx.set_continuation(sorted(loaded.counts))
-        st = ctx.train(mintokens=mintokens, maxlength=maxlength, indexed=int(indexed))
-        got, gotrefs = ctx.export_dict()
+        for table_mode in (0, 1):  # the counted orders on the radix path / on the global table
+            st = ctx.train(mintokens=mintokens, maxlength=maxlength, indexed=int(indexed), table_mode=table_mode)
+            got, gotrefs = ctx.export_dict()
+            assert got == new, table_mode
+            if indexed:
+                assert gotrefs == {k: want.refs[k] for k in new}
+            assert st.npatterns == len(new)
     finally:
         ctx.set_continuation([])
-    assert got == new
-    if indexed:
-        assert gotrefs == {k: want.refs[k] for k in new}
-    assert st.npatterns == len(new)
 
 
 def test_continued_training_refuses_what_it_does_not_reproduce(ctx):

@@ -314,6 +314,26 @@ def test_cxx_api_filtered_training_matches_the_references(tmp_path, tag):
         assert refs == want.refs
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [["-u"], []], ids=["unindexed", "indexed"])
+def test_cli_sharded_matches_the_single_device_model_on_a_larger_corpus(tmp_path, flags):
+    """--gpus 3 (three rank threads sharing device 0) against the single-device run of the same CLI on 3 M tokens: exchange buffers of millions of candidates,
+    every order on the radix path, the forward index merged from the ranks' runs."""
+    from colibri_amd import synth
+    data = str(tmp_path / "c.colibri.dat")
+    with open(data, "wb") as f:
+        f.write(synth.zipf_corpus(3_000_000, 50_000, 9, phrases=True))
+    one, three = str(tmp_path / "one.patternmodel"), str(tmp_path / "three.patternmodel")
+    a = subprocess.run([CLI, "-f", data, "-t", "2", "-l", "5", "-o", one] + flags, capture_output=True, text=True)
+    assert a.returncode == 0, a.stderr
+    b = subprocess.run([CLI, "-f", data, "-t", "2", "-l", "5", "-o", three, "--gpus", "3"] + flags, capture_output=True, text=True, env=dict(os.environ, COLIBRI_DEVICES="0,0,0"))
+    assert b.returncode == 0, b.stderr
+    ma, mb = parse_model(one), parse_model(three)
+    assert ma[:3] == mb[:3] and len(ma[3]) > 100_000
+    assert ma[3] == mb[3]
+    assert ma[4] == mb[4]
+
+
 CONTINUED = {  # golden tag -> (corpus, loaded model, unindexed?, -l, -t)
     "E_zipf.u": ("zipf20k", "continued.zipf20k.u.t3l2.patternmodel", True, 5, 2),
     "E_hamlet.i": ("hamlet.v2", "continued.hamlet.i.t2l3.patternmodel", False, 6, 2),

@@ -117,8 +117,8 @@ def measured_traffic(workload_tokens, kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--tokens", type=int, default=0, help="tokens per GPU (default: 100M — the 100M-token config —, 125M with --gpus 8 = the 1B-token corpus of config 3)")
     ap.add_argument("--vocab", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="tokens of the CPU-baseline sample (0 = skip)")

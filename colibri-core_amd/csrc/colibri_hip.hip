@@ -1474,7 +1474,9 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     const bool radix_constrained = constrained && o.table_mode == 0 && c->ntokens <= 128ull * 1000 * 1000;
     if (binned || radix_synced || radix_constrained) {
         // recs[0]: 256 fixed-capacity A-bin regions (25 % slack over a uniform split + one scatter tile each); recs[1]: exact
-        if ((rc = dev_alloc(c, c->recs[0], ((size_t)npos + (npos >> 2)) / kBins * kBins + (size_t)kBins * kScatTile)) || (rc = dev_alloc(c, c->recs[1], (size_t)npos + 1))) return rc;
+        if ((rc = dev_alloc(c, c->recs[0], ((size_t)npos + (npos >> 2)) / kBins * kBins + (size_t)kBins * kScatTile * 4)) ||
+            (rc = dev_alloc(c, c->recs[1], std::max<size_t>((size_t)npos + 1, (size_t)kBins * kScatTile * 4))))  // (floors: a small corpus with one hot bigram still fits its slot of the order-2 records)
+            return rc;
         if ((rc = dev_alloc(c, c->rep_of, (size_t)npos + 1)) || (rc = dev_alloc(c, c->ids_at, (size_t)npos + 1)) || (rc = dev_alloc(c, c->binstate, 1))) return rc;
         if ((rc = dev_alloc(c, c->alist[0], (size_t)npos + 1)) || (rc = dev_alloc(c, c->alist[1], (size_t)npos + 1)) || (rc = dev_alloc(c, c->alist_n, 2))) return rc;
         if (bi2 && (rc = bigram2_alloc(c, npos))) return rc;

@@ -75,6 +75,7 @@ struct colibri_ctx {
     DevBuf<uint32_t>  nsrc;             // per-slot distinct-source counter (indexed skipgrams)
     const uint32_t*   skl = nullptr;    // the list the skipgram passes of the current order walk (c->sklist, or the order's own active list), and its length
     const uint32_t*   skl_n = nullptr;
+    DevBuf<uint32_t>  seglog;           // skipgram passes enqueued without read-backs: what each left (kernels.hpp: skip_pass_end_kernel)
     DevBuf<uint32_t>  skip_tmp;         // radix skipgram passes: the survivors of the distinct-fillers filter on their way back into the results
     DevBuf<unsigned long long> skip_off;
     DevBuf<unsigned long long> pairs[2];        // forward index: (result id << 32 | position) pairs, ping-pong for the radix sort (kept between runs: a release and a
@@ -485,6 +486,7 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->nsrc);
     dev_free(c->pair_chain);
     dev_free(c->skip_tmp);
+    dev_free(c->seglog);
     dev_free(c->skip_off);
     dev_free(c->recs[0]);
     dev_free(c->recs[1]);
@@ -1008,18 +1010,25 @@ int filter_by_fillers(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids, uint32
 constexpr int kRerunOnTable = 1000;
 // minsrc > 0 (indexed models, MINSKIPTYPES): a skipgram also needs that many distinct fillers = distinct surviving n-grams [src_first, src_first + src_count) of the
 // results
+// seglog (unindexed passes only: nothing of the pass is needed on the host before the order's other passes have run): no read-back — the pass is reset, logged and
+// added to the run's state on the device (skip_pass_begin / skip_pass_end); *found_out / *kept_out stay untouched, the caller reads the log after the order.
 int skipgram_pass_radix(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, const uint32_t* gate, const uint32_t* gate2, uint32_t thr, uint32_t res_total, uint32_t* found_out,
-                        uint32_t* kept_out, uint32_t** ids_out, uint32_t minsrc = 0, uint32_t src_first = 0, uint32_t src_count = 0) {
+                        uint32_t* kept_out, uint32_t** ids_out, uint32_t minsrc = 0, uint32_t src_first = 0, uint32_t src_count = 0, uint32_t* seglog = nullptr) {
     const std::vector<std::pair<int, int>> parts = mask_parts(mask, n);
+    if (seglog != nullptr && (ids_out != nullptr || minsrc > 1)) return fail(c, COLIBRI_ERR_STATE, "skipgram_pass_radix: a logged pass keeps no ids");
     const uint32_t* left = part_ids(c, parts[0].second);
     uint32_t        offl = (uint32_t)parts[0].first;
     int             rc;
     for (size_t j = 1; j < parts.size(); ++j) {
         const bool last     = j + 1 == parts.size();
         const bool need_ids = !last || ids_out != nullptr;
-        c->hstate.found = c->hstate.kept = c->hstate.admitted = c->hstate.valid = 0;
-        c->hstate.radix_overflow = 0;
-        if ((rc = write_state(c))) return rc;
+        if (seglog != nullptr) {
+            hipLaunchKernelGGL(skip_pass_begin_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p);
+        } else {
+            c->hstate.found = c->hstate.kept = c->hstate.admitted = c->hstate.valid = 0;
+            c->hstate.radix_overflow = 0;
+            if ((rc = write_state(c))) return rc;
+        }
         uint32_t* const out = c->scratch[j & 1].p;
         KeyPair fn{gate, gate2, left, offl, part_ids(c, parts[j].second), (uint32_t)parts[j].first};
         if ((rc = binned_count_stage(c, pl, fn, n, true, last ? thr : 1u, false, need_ids, false, /*dense_code=*/true, 0, 0, c->skl, c->skl_n))) return rc;
@@ -1036,6 +1045,10 @@ int skipgram_pass_radix(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mas
         if (last && ids_out) *ids_out = out;
         left = out;
         offl = 0;
+    }
+    if (seglog != nullptr) {
+        hipLaunchKernelGGL(skip_pass_end_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, seglog, (uint32_t)n, mask);
+        return COLIBRI_OK;
     }
     if ((rc = read_state(c))) return rc;
     if (c->hstate.radix_overflow) return kRerunOnTable;
@@ -1880,10 +1893,18 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                     c->skl_n = c->alist_n.p + (n & 1);
                 } else if ((rc = build_skip_list(c, pl, c->ids[n - 1].p)))
                     return rc;
-                for (uint32_t mask : gap_masks(n, o.maxskips)) {
+                const std::vector<uint32_t> masks = gap_masks(n, o.maxskips);
+                const bool logged = radix_synced && masks.size() <= kSegLogCap;  // the order's passes are enqueued without a read-back each; one look at the log afterwards
+                if (logged) {
+                    if ((rc = dev_alloc(c, c->seglog, 4 + 5 * (size_t)kSegLogCap))) return rc;
+                    HIP_TRY(c, hipMemsetAsync(c->seglog.p, 0, sizeof(uint32_t) * 4, c->stream));
+                    c->hstate.radix_overflow = 0;
+                    if ((rc = write_state(c))) return rc;  // (res_total of the orders so far; the passes advance it on the device)
+                }
+                for (uint32_t mask : masks) {
                     uint32_t f = 0, k = 0;
                     if (radix_synced)
-                        rc = skipgram_pass_radix(c, pl, n, mask, c->ids[n - 1].p, c->ids[n - 1].p, thr_skip, res_total, &f, &k, nullptr);
+                        rc = skipgram_pass_radix(c, pl, n, mask, c->ids[n - 1].p, c->ids[n - 1].p, thr_skip, res_total, &f, &k, nullptr, 0, 0, 0, logged ? c->seglog.p : (uint32_t*)nullptr);
                     else
                         rc = skipgram_pass(c, pl, n, mask, c->ids[n - 1].p, c->ids[n - 1].p, adm_n[n], thr_skip, false, 0, &f, &k, nullptr);
                     if (rc == kRerunOnTable) {
@@ -1892,10 +1913,29 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                         return colibri_train_once(c, &again, stats_out);
                     }
                     if (rc) return rc;
+                    if (logged) continue;
                     s.found[n] += f;
                     s.kept[n] += k;
                     if (k) c->segments.push_back({res_total, k, n, mask});
                     res_total += k;
+                    c->hstate.res_total = res_total;
+                }
+                if (logged && !masks.empty()) {
+                    std::vector<uint32_t> log(4 + 5 * masks.size());
+                    HIP_TRY(c, hipMemcpyAsync(log.data(), c->seglog.p, sizeof(uint32_t) * log.size(), hipMemcpyDeviceToHost, c->stream));
+                    if ((rc = read_state(c))) return rc;
+                    if (c->hstate.radix_overflow) {
+                        colibri_options again = o;
+                        again.table_mode      = 1;
+                        return colibri_train_once(c, &again, stats_out);
+                    }
+                    for (size_t e = 0; e < masks.size() && e < log[0]; ++e) {
+                        const uint32_t* x = log.data() + 4 + 5 * e;
+                        s.found[n] += x[4];
+                        s.kept[n] += x[1];
+                        if (x[1]) c->segments.push_back({x[0], x[1], (int)x[2], x[3]});
+                    }
+                    res_total           = c->hstate.res_total;
                     c->hstate.res_total = res_total;
                 }
             }

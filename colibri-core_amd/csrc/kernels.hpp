@@ -556,6 +556,20 @@ __global__ __launch_bounds__(kBlock) void skip_remap_ids_kernel(const uint32_t* 
     }
 }
 
+// Skipgram passes without a host round trip each (unindexed models): the pass's counters are reset and, at its end, logged and folded into the run's state on
+// the device; the host reads the log once per order. log[0] = entries so far; entry e = log[4 + 5 e ..]: first result, results, order, gap mask, distinct found.
+constexpr uint32_t kSegLogCap = 4096;
+__global__ void skip_pass_begin_kernel(DevState* __restrict__ st) { st->found = st->kept = st->admitted = st->valid = 0; }
+__global__ void skip_pass_end_kernel(DevState* __restrict__ st, uint32_t* __restrict__ log, uint32_t n, uint32_t mask) {
+    const uint32_t e = log[0];
+    if (e < kSegLogCap) {
+        uint32_t* const x = log + 4 + 5 * (size_t)e;
+        x[0] = st->res_total, x[1] = st->kept, x[2] = n, x[3] = mask, x[4] = st->found;
+    }
+    log[0] = e + 1;
+    st->res_total += st->kept;
+}
+
 // table reset for the capacity the current order uses
 __global__ __launch_bounds__(kBlock) void clear_table_kernel(Slot* __restrict__ table, const DevState* __restrict__ st) {
     if (st->done) return;

@@ -130,9 +130,10 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kerne
                                                                                    unsigned long long* __restrict__ recsA, uint32_t region, uint32_t nsub, Bi2State* __restrict__ bs,
                                                                                    DevState* __restrict__ st, uint32_t* __restrict__ head_rows,
                                                                                    uint8_t* __restrict__ sid = nullptr /* optional (first pass of a sliced order): the key slice of the
-                                                                                       window at every position, 0xFF where no record will ever start (not admissible, or a head bigram) */) {
+                                                                                       window at every position, 0xFF where no record will ever start (not admissible, or a head bigram) */,
+                                                                                   uint32_t kmin = 0 /* key-sharded runs (kshard.hpp): at least this many key bits (17 + owner bits) */) {
     if (st->done) return;
-    const uint32_t K  = max(2u * clsbits, 17u + sbits);  // key = (class at i) << clsbits | class at i + 1
+    const uint32_t K  = max(max(2u * clsbits, 17u + sbits), kmin);  // key = (class at i) << clsbits | class at i + 1
     const uint32_t Kp = K - sbits;                      // ... of which the slice fixes the top sbits
     if (threadIdx.x == 0) {
         bs->kbits   = Kp;
@@ -431,8 +432,10 @@ __device__ __forceinline__ uint32_t bi2_scan512(const uint32_t* inL, uint32_t* o
 // ---- level B: one block partitions one slot by B bin ------------------------------------------------------------------------------
 // boff: [nslots][513] exclusive offsets of the slot's B bins inside the slot (same slot layout in recsB as in recsA).
 // B bin of a record: the nine mix bits below the A bin, shifted down by bshift when an order has few records.
+// slotbase (optional; key-sharded runs, kshard.hpp): the slots are the chunks of a receive buffer — slot s starts at record slotbase[s] instead of s * region
 __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_levelB_kernel(const unsigned long long* recsA, unsigned long long* __restrict__ recsB, uint32_t region,
-                                                                                     const Bi2State* __restrict__ bs, uint32_t* __restrict__ boff, const DevState* __restrict__ st) {
+                                                                                     const Bi2State* __restrict__ bs, uint32_t* __restrict__ boff, const DevState* __restrict__ st,
+                                                                                     const uint32_t* __restrict__ slotbase = nullptr) {
     if (st->done) return;
     __shared__ unsigned long long stgL[kBi2Tile];
     __shared__ uint16_t           binL[kBi2Tile];
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_levelB_ker
     const uint32_t  n    = min(bs->curA[slot], region);
     const uint32_t  bsh  = bs->bshift;
     const uint32_t  bbit = bs->posbits + bs->kbits - 17;  // the B bin = the nine mix bits below the A bin = record bits [bbit + 8 : bbit]
-    const size_t    base = (size_t)slot * region;
+    const size_t    base = slotbase != nullptr ? (size_t)slotbase[slot] : (size_t)slot * region;
     uint32_t* const bo   = boff + (size_t)slot * (kBi2BBins + 1);
     if (threadIdx.x < kBi2BBins) histL[threadIdx.x] = 0;
     __syncthreads();
@@ -628,14 +631,16 @@ __device__ __forceinline__ uint32_t bi2_find(const uint32_t* keyT, uint32_t key,
 #ifdef BI2_PROF
 __device__ unsigned long long bi2_prof[16];
 #endif
-template <int NSUB>
+// BASED (key-sharded runs, kshard.hpp): slot s starts at record slotbase[s] of recsB instead of s * region
+template <int NSUB, bool BASED = false>
 __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const uint32_t* __restrict__ boff, Bi2State* __restrict__ bs,
                                                               DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
                                                               uint32_t* __restrict__ wlist, uint32_t* __restrict__ wcnt, uint32_t wcap, bool want_positions,
                                                               uint32_t* __restrict__ wcode = nullptr /* optional, beside wlist: (final bin << 10) | rank of the window's key among the
-                                                                                                        bin's survivors — what bi2_ids_kernel turns into the window's RESULT index */) {
+                                                                                                        bin's survivors — what bi2_ids_kernel turns into the window's RESULT index */,
+                                                              const uint32_t* __restrict__ slotbase = nullptr) {
     if (st->done) return;
-    static_assert(2 * NSUB + 1 <= kWave, "bound loaders are lanes of the wave");
+    static_assert(3 * NSUB + 1 <= kWave, "bound loaders are lanes of the wave");
     __shared__ __attribute__((aligned(16))) uint32_t keyT[kBi2Slots];
     __shared__ __attribute__((aligned(16))) uint32_t cntT[kBi2Slots];
     __shared__ uint32_t                              repS[kBi2WReps];
@@ -663,29 +668,33 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
             v = boff[(size_t)((lane % NSUB) * kBins + a) * (kBi2BBins + 1) + b + (lane >= (uint32_t)NSUB ? 1u : 0u)];
         else if (lane == (uint32_t)(2 * NSUB))
             v = bs->binoff[a * kBi2BBins + b];
-        uint32_t rs[NSUB], rn[NSUB], total = 0;
+        else if (BASED && lane < (uint32_t)(3 * NSUB + 1))
+            v = slotbase[(lane - (uint32_t)(2 * NSUB + 1)) * kBins + a];
+        uint32_t rs[NSUB], rn[NSUB], sb[NSUB], total = 0;
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
             rs[s] = (uint32_t)__builtin_amdgcn_readlane((int)v, s);
             rn[s] = (uint32_t)__builtin_amdgcn_readlane((int)v, NSUB + s) - rs[s];
+            sb[s] = BASED ? (uint32_t)__builtin_amdgcn_readlane((int)v, 2 * NSUB + 1 + s) : 0u;
             total += rn[s];
         }
         const uint32_t spo = (uint32_t)__builtin_amdgcn_readlane((int)v, 2 * NSUB);
         BI2_W(1);
         if (total == 0 || (!big_pass && skip_big && total > kBi2BigBin)) return;
         auto locate = [&](uint32_t j) -> size_t {  // record j (< total) of the bin -> its index in recsB
-            uint32_t off = 0, slot = 0;
+            uint32_t off = 0, slot = 0, sbase = 0;
             bool     ok  = false;
 #pragma unroll
             for (int s = 0; s < NSUB; ++s) {
                 if (!ok && j < rn[s]) {
-                    ok   = true;
-                    off  = rs[s] + j;
-                    slot = (uint32_t)s * kBins + a;
+                    ok    = true;
+                    off   = rs[s] + j;
+                    slot  = (uint32_t)s * kBins + a;
+                    sbase = sb[s];
                 }
                 if (!ok) j -= rn[s];
             }
-            return (size_t)slot * region + off;
+            return BASED ? (size_t)sbase + off : (size_t)slot * region + off;
         };
         unsigned long long x[kBi2WRows];
 #pragma unroll
@@ -1006,8 +1015,10 @@ struct Bi2Lists {
 // tile-local counting sort by bucket in LDS, one reserved run per (tile, bucket); block x takes the lists x, x + gridDim.x, ...
 __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_pospart_kernel(const uint32_t* __restrict__ wlist, const uint32_t* __restrict__ wcnt, uint32_t nlists, uint32_t wcap,
                                                                                       Bi2State* __restrict__ bs, DevState* __restrict__ st, uint32_t* __restrict__ plist, Bi2Lists pl,
-                                                                                      const uint32_t* __restrict__ wcode = nullptr, uint32_t* __restrict__ pcode = nullptr) {
+                                                                                      const uint32_t* __restrict__ wcode = nullptr, uint32_t* __restrict__ pcode = nullptr,
+                                                                                      uint32_t flat_n = 0) {
     // wcode / pcode (optional): the (bin, rank) codes travel with their positions
+    // flat_n (key-sharded runs: the positions the owners sent back, one array): wlist holds flat_n entries, cut into nlists pieces of wcap; wcnt is not read
     if (st->done) return;
     static_assert(kBi2Buckets == kBi2Threads, "one lane per position bucket");
     __shared__ uint32_t stgL[kBi2Tile], stgC[kBi2Tile];
@@ -1015,7 +1026,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_pospart_ke
     __shared__ uint32_t histL[kBi2Buckets], offL[kBi2Buckets], gbaseL[kBi2Buckets], wsumL[kBi2Threads / kWave];
     const uint32_t      shard = blockIdx.x & (uint32_t)(kBi2Shards - 1);
     for (uint32_t w = blockIdx.x; w < nlists; w += gridDim.x) {
-        const uint32_t        n   = min(wcnt[w], wcap);
+        const uint32_t        n   = flat_n ? min(wcap, flat_n - min(flat_n, w * wcap)) : min(wcnt[w], wcap);
         const uint32_t* const src  = wlist + (size_t)w * wcap;
         const uint32_t* const csrc = wcode != nullptr ? wcode + (size_t)w * wcap : nullptr;
         for (uint32_t j0 = 0; j0 < n; j0 += kBi2Tile) {

@@ -447,12 +447,14 @@ constexpr int kBinRegPer = 8;  // records per lane held in registers: bins of up
 // scanned — with kExportBitR on the lowest-numbered candidate of the key (the lowest contributing rank), whose cnt_at entry
 // also receives the summed count.
 constexpr uint32_t kExportBitR = 0x80000000u;
-template <bool MERGE>
+// REPLY = the owner side of a key-sharded pass (kshard.hpp): `ids_at` is indexed by the record's place j in `recs` (not by its item), and the survivor id carries
+// the owner's rank tag `idtag` above the sparse index — ks_route_* sends (item, id) back to the record's source, whose ids_at then looks as after a local count
+template <bool MERGE, bool REPLY = false>
 __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t begin, const uint32_t end, const Rec* __restrict__ recs, DevState* __restrict__ st,
                                               BinState* __restrict__ bs, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
                                               unsigned long long* __restrict__ sp_key, uint32_t* __restrict__ ids_at, unsigned long long* keyT, uint32_t* cntT,
                                               uint32_t* repT, uint32_t* idT, uint32_t* redL, uint32_t* failL, const uint32_t* __restrict__ wide, uint32_t* __restrict__ cnt_at,
-                                              uint8_t* __restrict__ flags_at, bool dense_code) {
+                                              uint8_t* __restrict__ flags_at, bool dense_code, uint32_t idtag = 0) {
     // all loads of the (first 2048) records are issued before anything else: a bin is latency-bound, not bandwidth-bound
     Rec xr[kBinRegPer];
 #pragma unroll
@@ -528,7 +530,7 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
                 if (sp_key != nullptr) sp_key[r] = keyT[s];  // sharded runs: the sparse arrays ARE the local candidate list
                 // dense_code: (bin, rank among the bin's survivors) — bin_resolve_kernel turns it into the survivor's RESULT index once the per-bin
                 // survivor counts are scanned (the per-pass modes use result indices as ids: they are the pattern numbers of the forward index)
-                id = dense_code ? ((f << 11) | (r - begin)) : id_base + r;
+                id = dense_code ? ((f << 11) | (r - begin)) : (REPLY ? (idtag | (id_base + r)) : id_base + r);
             }
             ++r;
         }
@@ -548,7 +550,9 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
             }
             const uint32_t id = idT[s];
             if (id != kInvalid) {
-                if (!MERGE && flags_at != nullptr)
+                if (REPLY)
+                    ids_at[j] = id;
+                else if (!MERGE && flags_at != nullptr)
                     flags_at[xr[q].pos] = 1;  // flag mode: the next order builds its keys without this order's ids (KeyTrigramCls)
                 else
                     ids_at[xr[q].pos] = (MERGE && xr[q].pos == repT[s]) ? (id | kExportBitR) : id;
@@ -561,7 +565,9 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
         while (keyT[s] != x.key) s = (s + 1) & smask;
         const uint32_t id = idT[s];
         if (id != kInvalid) {
-            if (!MERGE && flags_at != nullptr)
+            if (REPLY)
+                ids_at[j] = id;
+            else if (!MERGE && flags_at != nullptr)
                 flags_at[x.pos] = 1;
             else
                 ids_at[x.pos] = (MERGE && x.pos == repT[s]) ? (id | kExportBitR) : id;
@@ -569,11 +575,11 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
     }
 }
 
-template <bool MERGE>
+template <bool MERGE, bool REPLY = false>
 __device__ __forceinline__ void bin_count_body(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
                                                uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt, unsigned long long* __restrict__ sp_key,
                                                uint32_t* __restrict__ ids_at, const uint32_t* __restrict__ wide, uint32_t* __restrict__ cnt_at, uint8_t* __restrict__ flags_at,
-                                               bool dense_code) {
+                                               bool dense_code, uint32_t idtag = 0) {
     if (st->done) return;
     __shared__ unsigned long long keyT[kBinSlots];
     __shared__ uint32_t           cntT[kBinSlots], repT[kBinSlots], idT[kBinSlots];
@@ -587,7 +593,7 @@ __device__ __forceinline__ void bin_count_body(const Rec* __restrict__ recs, Dev
         const uint32_t begin = bs->hist2[f];
         const uint32_t end   = (f + 1 < (uint32_t)kFinalBins) ? bs->hist2[f + 1] : bs->total2;
         if (begin >= end) continue;
-        bin_count_one<MERGE>(f, begin, end, recs, st, bs, threshold, sp_rep, sp_cnt, sp_key, ids_at, keyT, cntT, repT, idT, redL, &failL, wide, cnt_at, flags_at, dense_code);
+        bin_count_one<MERGE, REPLY>(f, begin, end, recs, st, bs, threshold, sp_rep, sp_cnt, sp_key, ids_at, keyT, cntT, repT, idT, redL, &failL, wide, cnt_at, flags_at, dense_code, idtag);
         __syncthreads();
     }
 }
@@ -595,6 +601,11 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict
                                                             uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt, unsigned long long* __restrict__ sp_key,
                                                             uint32_t* __restrict__ ids_at, uint8_t* __restrict__ flags_at = nullptr, bool dense_code = false) {
     bin_count_body<false>(recs, st, bs, threshold, sp_rep, sp_cnt, sp_key, ids_at, nullptr, nullptr, flags_at, dense_code);
+}
+// owner side of a key-sharded pass (kshard.hpp): reply_at[j] = global survivor id of record j's key (pre-filled with kInvalid by the caller)
+__global__ __launch_bounds__(kBlock) void bin_count_reply_kernel(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
+                                                                  uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt, uint32_t* __restrict__ reply_at, uint32_t idtag) {
+    bin_count_body<false, true>(recs, st, bs, threshold, sp_rep, sp_cnt, nullptr, reply_at, nullptr, nullptr, nullptr, false, idtag);
 }
 // owner-side merge of a sharded n-gram pass (see bin_count_one<MERGE>)
 __global__ __launch_bounds__(kBlock) void bin_merge_count_kernel(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,

@@ -19,6 +19,7 @@
 #include "colibri_hip.h"
 #include "binned.hpp"
 #include "bigram2.hpp"
+#include "kshard.hpp"
 #include "textenc.hpp"
 #include "constrained.hpp"
 #include "flexgrams.hpp"
@@ -195,6 +196,23 @@ struct colibri_ctx {
         bool                       uni_from_class = false;  // order 1 counted without representative positions
         uint32_t                   ocap = 0;
     } sh;
+
+    // key-sharded multi-GPU state (kshard.hpp, kshard_api.inc)
+    struct KShard {
+        bool     active = false, first_gen = false, pending_uni = false;
+        int      world = 1, rank = 0, n = 0, cur = 0;
+        uint32_t w = 0, nclasses = 0, uni_shift = 0, clsbits = 0, posbits = 0, kbits = 0, owcap = 0, fin_total = 0, syncs = 0;
+        DevBuf<KsSplitState> split;
+        DevBuf<KsRouteState> rstate;  // [0] feedback, [1] exports
+        DevBuf<KsStats>      stats;
+        DevBuf<DevState>     ostate;  // the owner side's run state
+        DevBuf<Bi2State>     obs;
+        DevBuf<BinState>     obin;
+        DevBuf<uint32_t>     slotbase, tab_recv, headg, oboff, owcnt, owlist, lcnt, loff, reply_at;
+        DevBuf<uint32_t>     osp_rep, osp_cnt, ores_rep, ores_cnt;  // owner: sparse per-bin survivors, dense survivors of the order
+        DevBuf<uint32_t>     fin_rep, fin_cnt;                      // this rank's share of the model
+        DevBuf<unsigned char> sbuf, rbuf[2], fbs, exs, fbr, exr;    // records out / in (+ level-B output); feedback and exports out / in
+    } ks;
 
     // profiling
     int                    profile = 0;    // 0 off, 1 every kernel class, 2 only the dominant-kernel classes
@@ -537,6 +555,13 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->sh.ugid);
     dev_free(c->sh.uoff);
     dev_free(c->sh.gid_of_sparse);
+    {
+        auto& k = c->ks;
+        dev_free(k.split); dev_free(k.rstate); dev_free(k.stats); dev_free(k.ostate); dev_free(k.obs); dev_free(k.obin); dev_free(k.slotbase); dev_free(k.tab_recv); dev_free(k.headg);
+        dev_free(k.oboff); dev_free(k.owcnt); dev_free(k.owlist); dev_free(k.lcnt); dev_free(k.loff); dev_free(k.reply_at); dev_free(k.osp_rep); dev_free(k.osp_cnt); dev_free(k.ores_rep);
+        dev_free(k.ores_cnt); dev_free(k.fin_rep); dev_free(k.fin_cnt); dev_free(k.sbuf); dev_free(k.rbuf[0]); dev_free(k.rbuf[1]); dev_free(k.fbs); dev_free(k.exs); dev_free(k.fbr);
+        dev_free(k.exr);
+    }
     dev_free(c->table);
     dev_free(c->res_rep);
     dev_free(c->res_cnt);
@@ -2143,6 +2168,7 @@ int colibri_kernel_time(const colibri_ctx* c, int cls, double* total_ms, uint64_
 }  // extern "C"
 
 #include "shard_api.inc"  // colibri_shard_*: opens extern "C"
+#include "kshard_api.inc" // colibri_kshard_*
 #include "text_api.inc"   // colibri_set_constraint, colibri_text_*
 #include "flex_api.inc"   // colibri_flexgrams, colibri_flexgrams_fetch
 

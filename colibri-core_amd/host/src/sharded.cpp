@@ -1,14 +1,19 @@
-// sharded.cpp — PatternModel::train across the GPUs of one node, from the C++ face: one host thread and one device context per rank, the corpus cut into
-// contiguous sentence ranges, RCCL (linked directly) for the exchange steps. The reference is single-threaded (include/patternmodel.h:880-1345 is one loop
-// over one map); what is distributed is that loop's only cross-shard dependency: the GLOBAL count of a candidate pattern before the prune of each order.
-// The protocol is the one of colibri_amd/dist.py (include/colibri_hip.h, "sentence-sharded multi-GPU training"), per pass:
-//     colibri_shard_count -> all-to-all sizes -> colibri_shard_send -> all-to-all (key, count [, distinct fillers]) -> colibri_shard_merge ->
-//     all-gather (found, kept) -> colibri_shard_reply -> all-to-all replies -> colibri_shard_apply
-// and order 1 as an all-reduce (SUM / MIN) of the dense per-class arrays. Exchange back ends:
-//     RCCL   every rank has a device of its own: ncclCommInitAll, ncclSend/ncclRecv groups (all seven xGMI links of a GPU at once), ncclAllReduce;
-//     copies two ranks share a device (tests on a one-GPU box; COLIBRI_DEVICES=0,0): device-to-device copies out of the peers' send buffers between two
-//            barriers, and the two dense arrays of order 1 reduced on the host.
-// Afterwards every rank exports the patterns it was named exporter of and its local forward index; the union is the model.
+// sharded.cpp — PatternModel::train across the GPUs of one node: the corpus cut into contiguous sentence ranges, one device context per rank, RCCL (linked
+// directly) for the exchange steps. The reference is single-threaded (include/patternmodel.h:880-1345 is one loop over one map); what is distributed is that loop's
+// only cross-shard dependency: the GLOBAL count of a candidate pattern before the prune of each order (:1195-1245). Two protocols over the C ABI:
+//   key-sharded counting (include/colibri_hip.h "colibri_kshard_*", csrc/kshard.hpp) — the plain unindexed n-gram model, 1 / 2 / 4 / 8 ranks: order 1 is an
+//     all-reduce of the dense per-class count array; at every higher order the RECORDS of the windows travel to the rank that owns their key, are counted there by
+//     the single-device kernels against the exact global threshold, and only the survivors' feedback returns. Two host look-ups per order, everything else enqueued
+//     on one stream per rank (the library's, which RCCL is handed too);
+//   candidate exchange (include/colibri_hip.h "colibri_shard_*") — every other model kind (skipgrams, indexed models) and every other rank count: local count at
+//     threshold 1, distinct candidates to their owner, global ids back.
+// A trainer lives as long as its corpus shards should stay resident in HBM: colibri_sharded_* (include/colibri_sharded.h) is its C face — what bench.py --gpus N
+// and the tests drive — and device_train_sharded() is PatternModel::train's use of it (colibri-patternmodeller --gpus N).
+// Ranks and processes: `nlocal == world`: one host thread per rank in this process (ncclCommInitAll; or, when ranks are made to share a device — the one-GPU test
+// boxes, COLIBRI_DEVICES=0,0 — device-to-device copies between the contexts instead of RCCL); `nlocal == 1`: one process per rank (ncclCommInitRank from an id the
+// caller distributed, e.g. over torch.distributed), host values exchanged through RCCL as well.
+// A rank that fails reports through the exchange every step begins with, so that no peer is left waiting in a collective; a failure in between aborts the
+// communicators (ncclCommAbort) and the rendezvous.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -18,6 +23,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -26,6 +32,7 @@
 
 #include "algorithms.h"
 #include "colibri_hip.h"
+#include "colibri_sharded.h"
 #include "patternmodel.h"
 
 namespace colibri_host {
@@ -34,22 +41,25 @@ namespace {
 int g_gpus = 0;  // 0: not set (COLIBRI_GPUS or 1)
 
 struct Aborted {};
+struct AgreedFailure : std::runtime_error {  // every rank of the run throws it at the same step (RankDriver::agree)
+    using std::runtime_error::runtime_error;
+};
 
 // barrier of the rank threads; abort() releases everyone (a rank that failed must not leave the others waiting)
 class Rendezvous {
     std::mutex              m;
     std::condition_variable cv;
-    int                     world, waiting = 0;
+    int                     parties, waiting = 0;
     uint64_t                generation = 0;
     bool                    aborted    = false;
 
   public:
-    explicit Rendezvous(int w) : world(w) {}
+    explicit Rendezvous(int w) : parties(w) {}
     void wait() {
         std::unique_lock<std::mutex> l(m);
         if (aborted) throw Aborted();
         const uint64_t g = generation;
-        if (++waiting == world) {
+        if (++waiting == parties) {
             waiting = 0;
             ++generation;
             cv.notify_all();
@@ -62,6 +72,11 @@ class Rendezvous {
         std::lock_guard<std::mutex> l(m);
         aborted = true;
         cv.notify_all();
+    }
+    void reset() {
+        std::lock_guard<std::mutex> l(m);
+        aborted = false;
+        waiting = 0;
     }
 };
 
@@ -85,35 +100,12 @@ struct DevMem {  // a device buffer that only grows (belongs to the device curre
 };
 
 struct RankExport {
-    colibri_stats              stats{};
     std::vector<uint64_t>      key_off;
     std::vector<unsigned char> key_bytes;
     std::vector<uint32_t>      counts, gids;
     std::vector<uint32_t>      ugid, ref_sentence;  // local forward index, keyed by global id
     std::vector<uint64_t>      ref_off;
     std::vector<uint16_t>      ref_token;
-};
-
-struct Shared {
-    int                                world;
-    Rendezvous                         rv;
-    bool                               use_rccl = false;
-    std::vector<ncclComm_t>            comms;
-    std::vector<int>                   device;
-    std::vector<std::vector<uint64_t>> sizes;    // [src][dst]: elements src sends to dst in the running all-to-all
-    std::vector<const void*>           sendptr;  // [src]: its send buffer
-    std::vector<std::vector<uint64_t>> ints;     // all-gather slots
-    std::vector<std::vector<uint32_t>> host_a, host_b;  // copies back end: the dense arrays of order 1
-    std::mutex                         errm;
-    std::string                        error;
-    explicit Shared(int w) : world(w), rv(w), device(w, 0), sizes(w, std::vector<uint64_t>(w, 0)), sendptr(w, nullptr), ints(w), host_a(w), host_b(w) {}
-    void fail(const std::string& what) {
-        {
-            std::lock_guard<std::mutex> l(errm);
-            if (error.empty()) error = what;
-        }
-        rv.abort();
-    }
 };
 
 #define HIPCHK(call)                                                                                                          \
@@ -127,119 +119,319 @@ struct Shared {
         if (e_ != ncclSuccess) throw std::runtime_error(std::string(#call) + ": " + ncclGetErrorString(e_));                  \
     } while (0)
 
+struct A2A {  // one all-to-all of a group: send_n[p] elements to rank p (in rank order in `send`), recv_n[p] from rank p (in rank order in `recv`)
+    const void*                  send;
+    const std::vector<uint64_t>* send_n;
+    void*                        recv;
+    const std::vector<uint64_t>* recv_n;
+    size_t                       elem;
+};
+struct Reduce {  // in-place all-reduce of n u32
+    void*  buf;
+    size_t n;
+    bool   minimum;
+};
+
+struct Shared {
+    const int                          world, nlocal, first_rank;
+    Rendezvous                         rv;
+    bool                               use_rccl = false;
+    std::vector<ncclComm_t>            comms;   // [nlocal]
+    std::vector<int>                   device;  // [nlocal]
+    // thread back ends: what the ranks show each other between two barriers
+    std::vector<std::vector<uint64_t>>              ints;      // all-gather slots
+    std::vector<std::vector<A2A>>                   ops;       // [rank]: the all-to-alls of the running group
+    std::vector<std::vector<std::vector<uint32_t>>> hostred;   // [rank][reduction]: host copies (copies back end)
+    std::mutex                                      errm;
+    std::string                                     error;
+    Shared(int w, int nl, int first) : world(w), nlocal(nl), first_rank(first), rv(nl), comms((size_t)nl, nullptr), device((size_t)nl, 0), ints((size_t)w), ops((size_t)w), hostred((size_t)w) {}
+    bool threads() const { return nlocal == world; }
+    void fail(const std::string& what) {
+        {
+            std::lock_guard<std::mutex> l(errm);
+            if (error.empty()) error = what;
+        }
+        rv.abort();
+        if (use_rccl)  // peers inside (or about to enter) a collective return with an error instead of waiting for this rank
+            for (auto& cm : comms)
+                if (cm) (void)ncclCommAbort(cm), cm = nullptr;
+    }
+};
+
 class RankDriver {
     Shared&      sh;
-    const int    rank, world, dev;
+    const int    li, rank, world, dev;  // local index, global rank
     colibri_ctx* c      = nullptr;
-    hipStream_t  stream = nullptr;
-    DevMem       rkeys, rcnts, raux, rgid, rtot, gid, tot, ucnt, umr;  // receive / reply buffers (the candidates are sent from the library's own buffers)
+    hipStream_t  stream = nullptr;      // the candidate-exchange protocol's own stream (the key-sharded one runs on the library's)
+    DevMem       rkeys, rcnts, raux, rgid, rtot, gid, tot, ucnt, umr, gather_dev;
     uint64_t     gid_total = 0;
+    uint64_t*    gather_host = nullptr;  // pinned: host values of the process back end's all-gather
 
     void chk(int rc, const char* what) {
         if (rc != COLIBRI_OK) throw std::runtime_error(std::string(what) + ": " + (c ? colibri_last_error(c) : "no context") + " (status " + std::to_string(rc) + ")");
     }
+    ncclComm_t comm() const { return sh.comms[(size_t)li]; }
 
     // ---- collectives ----------------------------------------------------------------------------------------------------
-    std::vector<std::vector<uint64_t>> all_gather(const std::vector<uint64_t>& mine) {
-        sh.ints[rank] = mine;
-        sh.rv.wait();
-        std::vector<std::vector<uint64_t>> all = sh.ints;
-        sh.rv.wait();
+    // host values of every rank, [rank][k]. Threads: through shared memory; one process per rank: an RCCL all-gather on `s`
+    std::vector<std::vector<uint64_t>> all_gather(const std::vector<uint64_t>& mine, hipStream_t s) {
+        if (sh.threads()) {
+            sh.ints[(size_t)rank] = mine;
+            sh.rv.wait();
+            std::vector<std::vector<uint64_t>> all = sh.ints;
+            sh.rv.wait();
+            return all;
+        }
+        const size_t k = mine.size();
+        if (!gather_host) HIPCHK(hipHostMalloc((void**)&gather_host, sizeof(uint64_t) * 4096, hipHostMallocDefault));
+        if (k * (size_t)(world + 1) > 4096) throw std::runtime_error("all_gather: too many host values");
+        uint64_t* const d = (uint64_t*)gather_dev.reserve(sizeof(uint64_t) * 4096);
+        std::memcpy(gather_host, mine.data(), k * sizeof(uint64_t));
+        HIPCHK(hipMemcpyAsync(d, gather_host, k * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        NCCLCHK(ncclAllGather(d, d + k, k, ncclUint64, comm(), s));
+        HIPCHK(hipMemcpyAsync(gather_host + k, d + k, k * (size_t)world * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        std::vector<std::vector<uint64_t>> all((size_t)world);
+        for (int r = 0; r < world; ++r) all[(size_t)r].assign(gather_host + k + (size_t)r * k, gather_host + k + (size_t)(r + 1) * k);
         return all;
     }
-    // per_owner[p] elements of `send` (partitioned by destination, in rank order) go to rank p; returns what arrives, concatenated in rank order
-    void publish_sizes(const std::vector<uint64_t>& per_owner, std::vector<uint64_t>& per_src) {
-        sh.sizes[rank] = per_owner;
-        sh.rv.wait();
-        per_src.resize(world);
-        for (int s = 0; s < world; ++s) per_src[s] = sh.sizes[s][rank];
-        sh.rv.wait();
-    }
-    void all_to_all(const void* send, const std::vector<uint64_t>& send_n, void* recv, const std::vector<uint64_t>& recv_n, size_t elem) {
+    // a group of all-to-alls and all-reduces. RCCL: enqueued on `s` (one ncclGroup: all seven xGMI links of a GPU at once), nothing waits unless `sync`.
+    // Copies (ranks sharing a device): the sources must be complete (every caller has waited for its stream), the copies are waited for, then a barrier.
+    void exchange(const std::vector<A2A>& a2a, const std::vector<Reduce>& reds, hipStream_t s, bool sync) {
         if (sh.use_rccl) {
-            NCCLCHK(ncclGroupStart());
-            uint64_t so = 0, ro = 0;
-            for (int p = 0; p < world; ++p) {
-                if (send_n[p]) NCCLCHK(ncclSend((const char*)send + so * elem, send_n[p] * elem, ncclUint8, p, sh.comms[rank], stream));
-                if (recv_n[p]) NCCLCHK(ncclRecv((char*)recv + ro * elem, recv_n[p] * elem, ncclUint8, p, sh.comms[rank], stream));
-                so += send_n[p];
-                ro += recv_n[p];
+            if (!a2a.empty()) {
+                NCCLCHK(ncclGroupStart());
+                for (const A2A& op : a2a) {
+                    uint64_t so = 0, ro = 0;
+                    for (int p = 0; p < world; ++p) {
+                        const uint64_t sn = (*op.send_n)[(size_t)p], rn = (*op.recv_n)[(size_t)p];
+                        if (sn) NCCLCHK(ncclSend((const char*)op.send + so * op.elem, sn * op.elem, ncclUint8, p, comm(), s));
+                        if (rn) NCCLCHK(ncclRecv((char*)op.recv + ro * op.elem, rn * op.elem, ncclUint8, p, comm(), s));
+                        so += sn;
+                        ro += rn;
+                    }
+                }
+                NCCLCHK(ncclGroupEnd());
             }
-            NCCLCHK(ncclGroupEnd());
-            HIPCHK(hipStreamSynchronize(stream));
+            for (const Reduce& r : reds) NCCLCHK(ncclAllReduce(r.buf, r.buf, r.n, ncclUint32, r.minimum ? ncclMin : ncclSum, comm(), s));
+            if (sync) HIPCHK(hipStreamSynchronize(s));
             return;
         }
-        // copies: every rank publishes its send buffer and its partition sizes, then pulls its share out of everyone's buffer
-        sh.sendptr[rank] = send;
-        sh.sizes[rank]   = send_n;
-        sh.rv.wait();
-        uint64_t ro = 0;
-        for (int s = 0; s < world; ++s) {
-            uint64_t so = 0;
-            for (int p = 0; p < rank; ++p) so += sh.sizes[s][p];
-            const uint64_t n = sh.sizes[s][rank];
-            if (n) {
-                if (sh.device[s] == dev)
-                    HIPCHK(hipMemcpyAsync((char*)recv + ro * elem, (const char*)sh.sendptr[s] + so * elem, n * elem, hipMemcpyDeviceToDevice, stream));
-                else
-                    HIPCHK(hipMemcpyPeerAsync((char*)recv + ro * elem, dev, (const char*)sh.sendptr[s] + so * elem, sh.device[s], n * elem, stream));
-            }
-            ro += n;
+        sh.ops[(size_t)rank] = a2a;
+        auto& mine = sh.hostred[(size_t)rank];
+        mine.resize(reds.size());
+        for (size_t k = 0; k < reds.size(); ++k) {
+            mine[k].resize(reds[k].n);
+            HIPCHK(hipMemcpyAsync(mine[k].data(), reds[k].buf, reds[k].n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         }
-        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipStreamSynchronize(s));
+        sh.rv.wait();
+        for (size_t k = 0; k < a2a.size(); ++k) {
+            uint64_t ro = 0;
+            for (int src = 0; src < world; ++src) {
+                const A2A& theirs = sh.ops[(size_t)src][k];
+                uint64_t   so = 0;
+                for (int p = 0; p < rank; ++p) so += (*theirs.send_n)[(size_t)p];
+                const uint64_t n = (*theirs.send_n)[(size_t)rank];
+                if (n) {
+                    const int sdev = sh.device[(size_t)src];
+                    if (sdev == dev)
+                        HIPCHK(hipMemcpyAsync((char*)a2a[k].recv + ro * a2a[k].elem, (const char*)theirs.send + so * theirs.elem, n * theirs.elem, hipMemcpyDeviceToDevice, s));
+                    else
+                        HIPCHK(hipMemcpyPeerAsync((char*)a2a[k].recv + ro * a2a[k].elem, dev, (const char*)theirs.send + so * theirs.elem, sdev, n * theirs.elem, s));
+                }
+                ro += n;
+            }
+        }
+        for (size_t k = 0; k < reds.size(); ++k) {
+            std::vector<uint32_t> red(sh.hostred[0][k]);
+            for (int src = 1; src < world; ++src) {
+                const auto& o = sh.hostred[(size_t)src][k];
+                for (size_t j = 0; j < red.size(); ++j) red[j] = reds[k].minimum ? std::min(red[j], o[j]) : red[j] + o[j];
+            }
+            HIPCHK(hipMemcpy(reds[k].buf, red.data(), red.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        HIPCHK(hipStreamSynchronize(s));
         sh.rv.wait();  // nobody reuses a send buffer before everyone has read it
     }
-    void all_reduce_u32(void* buf, size_t n, bool minimum, std::vector<std::vector<uint32_t>>& slots) {
-        if (sh.use_rccl) {
-            NCCLCHK(ncclAllReduce(buf, buf, n, ncclUint32, minimum ? ncclMin : ncclSum, sh.comms[rank], stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            return;
+    // every step that can fail on one rank alone begins with this: the ranks agree that all are fine, or all throw
+    std::vector<std::vector<uint64_t>> agree(std::vector<uint64_t> mine, const std::string& err, const char* what, hipStream_t s) {
+        mine.push_back(err.empty() ? 0 : 1);
+        const auto all = all_gather(mine, s);
+        std::string bad;
+        for (int r = 0; r < world; ++r)
+            if (all[(size_t)r].back()) bad += (bad.empty() ? "" : ", ") + std::to_string(r);
+        if (!bad.empty()) throw AgreedFailure(std::string(what) + " failed on rank(s) " + bad + (err.empty() ? "" : ": " + err));
+        return all;
+    }
+    // the same for steps that fail only when memory runs out: threads agree (a barrier); one process per rank: no extra collective — a rank that fails
+    // aborts its communicator, and its peers' next collective returns with an error
+    void agree_cheap(const std::string& err, const char* what, hipStream_t s) {
+        if (sh.threads()) {
+            agree({}, err, what, s);
+        } else if (!err.empty()) {
+            throw std::runtime_error(std::string(what) + ": " + err);
         }
-        slots[rank].resize(n);
-        HIPCHK(hipMemcpy(slots[rank].data(), buf, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        sh.rv.wait();
-        std::vector<uint32_t> red(slots[0]);
-        for (int s = 1; s < world; ++s)
-            for (size_t k = 0; k < n; ++k) red[k] = minimum ? std::min(red[k], slots[s][k]) : red[k] + slots[s][k];
-        HIPCHK(hipMemcpy(buf, red.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
-        sh.rv.wait();
     }
 
-    // ---- one pass: local count -> exchange -> owner merge -> global ids back (dist.py: ShardedTrainer._pass) ----------------
+    // ---- key-sharded counting (colibri_kshard_*) ---------------------------------------------------------------------------------
+    // false: not applicable to this run (some rank's corpus or the options are outside it): the caller takes the candidate exchange
+    bool train_kshard(const colibri_options& o, colibri_stats& stats) {
+        if (world > 8 || (world & (world - 1))) return false;
+        hipStream_t const s = (hipStream_t)colibri_stream(c);
+        int               ok = 0;
+        uint64_t          maxclass = 0, npos = 0, tokens = 0;
+        chk(colibri_kshard_info(c, &o, &ok, &maxclass, &npos), "colibri_kshard_info");
+        chk(colibri_corpus_info(c, &tokens, nullptr, nullptr), "colibri_corpus_info");
+        uint64_t tokens_g = 0, maxclass_g = 0, npos_g = 0;
+        bool     all_ok = true;
+        for (const auto& v : all_gather({(uint64_t)ok, maxclass, npos, tokens}, s)) {
+            all_ok = all_ok && v[0] != 0;
+            maxclass_g = std::max(maxclass_g, v[1]);
+            npos_g     = std::max(npos_g, v[2]);
+            tokens_g += v[3];
+        }
+        if (!all_ok || maxclass_g >= (1u << 21) || npos_g >= (1u << 28)) return false;
+        std::string err;
+        auto        step = [&](int rc, const char* what) {
+            if (rc != COLIBRI_OK && err.empty()) err = std::string(what) + ": " + colibri_last_error(c) + " (status " + std::to_string(rc) + ")";
+            return rc == COLIBRI_OK;
+        };
+        step(colibri_kshard_begin(c, &o, world, rank, maxclass_g, npos_g), "colibri_kshard_begin");
+        agree({}, err, "key-sharded run: begin", s);
+        const int maxlength = std::min<int>(o.maxlength, COLIBRI_MAX_ORDER - 1);
+        // order 1: all-reduce of the dense per-class counts
+        {
+            void*    cnt = nullptr;
+            uint32_t nclasses = 0;
+            step(colibri_kshard_uni_count(c, &cnt, &nclasses), "colibri_kshard_uni_count");
+            agree_cheap(err, "key-sharded run: order 1", s);
+            exchange({}, {{cnt, nclasses, false}}, s, false);
+            chk(colibri_kshard_uni_apply(c), "colibri_kshard_uni_apply");
+        }
+        int maxn = tokens_g ? 1 : 0;
+        for (int n = 2; n <= maxlength && tokens_g; ++n) {
+            void *                send = nullptr, *tab = nullptr, *head = nullptr;
+            std::vector<uint64_t> per_owner((size_t)world, 0), per_src((size_t)world, 0), one((size_t)world, 1);
+            uint32_t              recbytes = 0;
+            uint64_t              admitted = 0;
+            step(colibri_kshard_emit(c, n, &send, &tab, per_owner.data(), &recbytes, &head, &admitted), "colibri_kshard_emit");
+            std::vector<uint64_t> mine = per_owner;
+            mine.push_back(admitted);
+            const auto everyone = agree(mine, err, "key-sharded run: window scan", s);
+            uint64_t   admitted_g = 0, nrecv = 0;
+            for (int r = 0; r < world; ++r) {
+                admitted_g += everyone[(size_t)r][(size_t)world];
+                per_src[(size_t)r] = everyone[(size_t)r][(size_t)rank];
+                nrecv += per_src[(size_t)r];
+            }
+            if (admitted_g == 0) break;  // "None found" (patternmodel.h:1189-1194): no rank has a window of this order left
+            maxn = n;
+            void *recv = nullptr, *tab_recv = nullptr;
+            step(colibri_kshard_recv_buffers(c, nrecv, &recv, &tab_recv), "colibri_kshard_recv_buffers");
+            agree_cheap(err, "key-sharded run: receive buffers", s);
+            std::vector<uint64_t> tabn((size_t)world, 256);
+            std::vector<Reduce>   reds;
+            if (head) {
+                reds.push_back({head, 4096, false});
+                reds.push_back({(uint32_t*)head + 4096, 4096, true});
+            }
+            exchange({{send, &per_owner, recv, &per_src, recbytes}, {tab, &tabn, tab_recv, &tabn, sizeof(uint32_t)}}, reds, s, false);
+            const int             more = n < maxlength;
+            void *                fb = nullptr, *ex = nullptr;
+            std::vector<uint64_t> fb_dst((size_t)world, 0), ex_dst((size_t)world, 0), fb_src((size_t)world, 0), ex_src((size_t)world, 0);
+            uint32_t              fb_bytes = 0;
+            step(colibri_kshard_count(c, n, per_src.data(), more, &fb, fb_dst.data(), &fb_bytes, &ex, ex_dst.data()), "colibri_kshard_count");
+            mine = fb_dst;
+            mine.insert(mine.end(), ex_dst.begin(), ex_dst.end());
+            const auto back = agree(mine, err, "key-sharded run: count", s);
+            uint64_t   nfb = 0, nex = 0;
+            for (int r = 0; r < world; ++r) {
+                fb_src[(size_t)r] = back[(size_t)r][(size_t)rank];
+                ex_src[(size_t)r] = back[(size_t)r][(size_t)(world + rank)];
+                nfb += fb_src[(size_t)r];
+                nex += ex_src[(size_t)r];
+            }
+            void *fb_recv = nullptr, *ex_recv = nullptr;
+            step(colibri_kshard_feedback_buffers(c, nfb, nex, &fb_recv, &ex_recv), "colibri_kshard_feedback_buffers");
+            agree_cheap(err, "key-sharded run: feedback buffers", s);
+            exchange({{fb, &fb_dst, fb_recv, &fb_src, fb_bytes}, {ex, &ex_dst, ex_recv, &ex_src, 8}}, {}, s, false);
+            chk(colibri_kshard_apply(c, n, nfb, nex, more), "colibri_kshard_apply");
+        }
+        std::vector<uint64_t> mine(3 * COLIBRI_MAX_ORDER, 0), found_g(COLIBRI_MAX_ORDER, 0), kept_g(COLIBRI_MAX_ORDER, 0), adm_g(COLIBRI_MAX_ORDER, 0);
+        uint32_t              syncs = 0;
+        step(colibri_kshard_local_stats(c, mine.data(), mine.data() + COLIBRI_MAX_ORDER, mine.data() + 2 * COLIBRI_MAX_ORDER, &syncs), "colibri_kshard_local_stats");
+        // (only the orders that ran travel: the process back end's gather buffer is small)
+        std::vector<uint64_t> brief;
+        for (int n = 1; n <= std::max(maxn, 1) && n < COLIBRI_MAX_ORDER; ++n) {
+            brief.push_back(mine[(size_t)n]);
+            brief.push_back(mine[(size_t)(COLIBRI_MAX_ORDER + n)]);
+            brief.push_back(mine[(size_t)(2 * COLIBRI_MAX_ORDER + n)]);
+        }
+        const auto figs = agree(brief, err, "key-sharded run: statistics", s);
+        for (int r = 0; r < world; ++r)
+            for (int n = 1; n <= std::max(maxn, 1) && n < COLIBRI_MAX_ORDER; ++n) {
+                found_g[(size_t)n] += figs[(size_t)r][(size_t)(3 * (n - 1))];
+                kept_g[(size_t)n] += figs[(size_t)r][(size_t)(3 * (n - 1) + 1)];
+                adm_g[(size_t)n] += figs[(size_t)r][(size_t)(3 * (n - 1) + 2)];
+            }
+        while (maxn > 0 && found_g[(size_t)maxn] == 0) --maxn;
+        chk(colibri_kshard_finish(c, found_g.data(), kept_g.data(), adm_g.data(), tokens_g, maxn, &stats), "colibri_kshard_finish");
+        last_syncs = syncs;
+        return true;
+    }
+
+    // ---- candidate exchange (colibri_shard_*): one pass = local count -> exchange -> owner merge -> global ids back -------------------------------
+    void all_to_all(const void* send, const std::vector<uint64_t>& send_n, void* recv, const std::vector<uint64_t>& recv_n, size_t elem) {
+        exchange({{send, &send_n, recv, &recv_n, elem}}, {}, stream, true);
+    }
     void pass(int n, uint32_t mask, int level, bool use_aux, uint64_t& found_all, uint64_t& kept_all) {
         uint64_t              ncand = 0;
-        std::vector<uint64_t> per_owner(world, 0), per_src;
-        chk(colibri_shard_count(c, n, mask, level, &ncand, per_owner.data()), "colibri_shard_count");
-        publish_sizes(per_owner, per_src);
-        uint64_t nrecv = 0;
-        for (uint64_t v : per_src) nrecv += v;
-        const size_t ns = std::max<uint64_t>(ncand, 1), nr = std::max<uint64_t>(nrecv, 1);
-        void *skeys = nullptr, *scnts = nullptr, *saux = nullptr;  // the library's own partitioned buffers: sent from where they lie
-        chk(colibri_shard_send_view(c, &skeys, &scnts, &saux), "colibri_shard_send_view");
-        if (use_aux && saux == nullptr) throw std::runtime_error("the pass has no distinct-filler counts to send");
-        rkeys.reserve(nr * 8), rcnts.reserve(nr * 4);
-        all_to_all(skeys, per_owner, rkeys.p, per_src, 8);
-        all_to_all(scnts, per_owner, rcnts.p, per_src, 4);
-        if (use_aux) {
-            raux.reserve(nr * 4);
-            all_to_all(saux, per_owner, raux.p, per_src, 4);
+        std::vector<uint64_t> per_owner((size_t)world, 0), per_src((size_t)world, 0);
+        std::string           err;
+        const int             rc0 = colibri_shard_count(c, n, mask, level, &ncand, per_owner.data());
+        if (rc0 != COLIBRI_OK) err = std::string("colibri_shard_count: ") + colibri_last_error(c);
+        const auto sizes = agree(per_owner, err, "sharded pass: local count", stream);
+        uint64_t   nrecv = 0;
+        for (int r = 0; r < world; ++r) {
+            per_src[(size_t)r] = sizes[(size_t)r][(size_t)rank];
+            nrecv += per_src[(size_t)r];
         }
+        const size_t ns = std::max<uint64_t>(ncand, 1), nr = std::max<uint64_t>(nrecv, 1);
+        void *       skeys = nullptr, *scnts = nullptr, *saux = nullptr;  // the library's own partitioned buffers: sent from where they lie
+        try {
+            chk(colibri_shard_send_view(c, &skeys, &scnts, &saux), "colibri_shard_send_view");
+            if (use_aux && saux == nullptr) throw std::runtime_error("the pass has no distinct-filler counts to send");
+            rkeys.reserve(nr * 8), rcnts.reserve(nr * 4);
+            if (use_aux) raux.reserve(nr * 4);
+        } catch (const std::exception& e) {
+            err = e.what();
+        }
+        agree({}, err, "sharded pass: exchange buffers", stream);
+        std::vector<A2A> ops{{skeys, &per_owner, rkeys.p, &per_src, 8}, {scnts, &per_owner, rcnts.p, &per_src, 4}};
+        if (use_aux) ops.push_back({saux, &per_owner, raux.p, &per_src, 4});
+        exchange(ops, {}, stream, true);
         uint64_t found = 0, kept = 0;
-        chk(colibri_shard_merge(c, rkeys.p, rcnts.p, use_aux ? raux.p : nullptr, per_src.data(), &found, &kept), "colibri_shard_merge");
-        const auto everyone = all_gather({found, kept});
+        const int rc1 = colibri_shard_merge(c, rkeys.p, rcnts.p, use_aux ? raux.p : nullptr, per_src.data(), &found, &kept);
+        if (rc1 != COLIBRI_OK) err = std::string("colibri_shard_merge: ") + colibri_last_error(c);
+        try {
+            rgid.reserve(nr * 4), rtot.reserve(nr * 4), gid.reserve(ns * 4), tot.reserve(ns * 4);
+        } catch (const std::exception& e) {
+            if (err.empty()) err = e.what();
+        }
+        const auto everyone = agree({found, kept}, err, "sharded pass: owner merge", stream);
         found_all = kept_all = 0;
         uint64_t base = gid_total;
         for (int r = 0; r < world; ++r) {
-            found_all += everyone[r][0];
-            kept_all += everyone[r][1];
-            if (r < rank) base += everyone[r][1];
+            found_all += everyone[(size_t)r][0];
+            kept_all += everyone[(size_t)r][1];
+            if (r < rank) base += everyone[(size_t)r][1];
         }
         if (found_all == 0) return;  // nothing anywhere: every rank sees it at once (reference "None found", patternmodel.h:1189-1194)
-        if (gid_total + kept_all >= (1ull << 31)) throw std::runtime_error("more than 2^31 surviving patterns");
-        rgid.reserve(nr * 4), rtot.reserve(nr * 4), gid.reserve(ns * 4), tot.reserve(ns * 4);
-        chk(colibri_shard_reply(c, (uint32_t)base, rgid.p, rtot.p), "colibri_shard_reply");
-        all_to_all(rgid.p, per_src, gid.p, per_owner, 4);
-        all_to_all(rtot.p, per_src, tot.p, per_owner, 4);
+        if (gid_total + kept_all >= (1ull << 31)) err = "more than 2^31 surviving patterns";
+        if (err.empty() && colibri_shard_reply(c, (uint32_t)base, rgid.p, rtot.p) != COLIBRI_OK) err = std::string("colibri_shard_reply: ") + colibri_last_error(c);
+        agree({}, err, "sharded pass: replies", stream);
+        exchange({{rgid.p, &per_src, gid.p, &per_owner, 4}, {rtot.p, &per_src, tot.p, &per_owner, 4}}, {}, stream, true);
         uint64_t exported = 0, admitted = 0;
         chk(colibri_shard_apply(c, gid.p, tot.p, &exported, &admitted), "colibri_shard_apply");
         gid_total += kept_all;
@@ -249,16 +441,21 @@ class RankDriver {
         int      ok = 0;
         uint64_t maxclass = 0;
         chk(colibri_shard_uni_info(c, &ok, &maxclass), "colibri_shard_uni_info");
-        const auto everyone = all_gather({(uint64_t)ok, maxclass});
+        const auto everyone = all_gather({(uint64_t)ok, maxclass}, stream);
         uint64_t   nclasses = 0;
         for (const auto& v : everyone) {
             if (!v[0]) return false;
             nclasses = std::max(nclasses, v[1] + 1);
         }
-        ucnt.reserve(nclasses * 4), umr.reserve(nclasses * 4);
-        chk(colibri_shard_uni_count(c, ucnt.p, umr.p, (uint32_t)nclasses, rank), "colibri_shard_uni_count");
-        all_reduce_u32(ucnt.p, nclasses, false, sh.host_a);
-        all_reduce_u32(umr.p, nclasses, true, sh.host_b);
+        std::string err;
+        try {
+            ucnt.reserve(nclasses * 4), umr.reserve(nclasses * 4);
+            chk(colibri_shard_uni_count(c, ucnt.p, umr.p, (uint32_t)nclasses, rank), "colibri_shard_uni_count");
+        } catch (const std::exception& e) {
+            err = e.what();
+        }
+        agree({}, err, "sharded run: order 1", stream);
+        exchange({}, {{ucnt.p, (size_t)nclasses, false}, {umr.p, (size_t)nclasses, true}}, stream, true);
         uint64_t exported = 0;
         chk(colibri_shard_uni_apply(c, ucnt.p, umr.p, (uint32_t)nclasses, rank, &found, &kept, &exported), "colibri_shard_uni_apply");
         gid_total = std::max<uint64_t>(gid_total, nclasses);  // unigram ids are class ids: later passes number from nclasses on
@@ -266,6 +463,7 @@ class RankDriver {
     }
     void skipgram_order(int n, const colibri_options& o, uint64_t& found_n, uint64_t& kept_n) {
         found_n = kept_n = 0;
+        if (n > 13) throw std::runtime_error("skipgrams of patterns longer than 13 tokens are not on the accelerated path (set MAXLENGTH)");  // (before 2^(n-2) masks are enumerated)
         for (uint32_t mask : compute_skip_configurations(n, o.maxskips)) {
             const int levels = (int)mask2vector(mask, n).size();  // gaps = parts - 1 = levels
             uint64_t  f = 0, k = 0;
@@ -283,43 +481,34 @@ class RankDriver {
             }
         }
     }
-
-  public:
-    RankExport out;
-    RankDriver(Shared& s, int r) : sh(s), rank(r), world(s.world), dev(s.device[(size_t)r]) {}
-    ~RankDriver() {
-        if (c) colibri_destroy(c);
-        if (stream) (void)hipStreamDestroy(stream);
-    }
-    void run(const unsigned char* payload, uint64_t nbytes, uint32_t first_sentence, colibri_options o) {
-        HIPCHK(hipSetDevice(dev));
-        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        chk(colibri_create(&c, dev), "colibri_create");
-        chk(colibri_upload_corpus(c, payload, nbytes, first_sentence), "colibri_upload_corpus");
-        chk(colibri_shard_begin(c, &o, world), "colibri_shard_begin");
+    void train_candidates(colibri_options o, colibri_stats& stats) {
+        gid_total = 0;
+        std::string err;
+        if (colibri_shard_begin(c, &o, world) != COLIBRI_OK) err = std::string("colibri_shard_begin: ") + colibri_last_error(c);
+        agree({}, err, "sharded run: begin", stream);
         if (o.mintokens == -1) o.mintokens = 2;
         if (o.mintokens == 0) o.mintokens = 1;
         const int             maxlength = std::min<int>(o.maxlength, COLIBRI_MAX_ORDER - 1);
         std::vector<uint64_t> found_g(COLIBRI_MAX_ORDER, 0), kept_g(COLIBRI_MAX_ORDER, 0);
         uint64_t              tokens = 0, tokens_g = 0;
         chk(colibri_corpus_info(c, &tokens, nullptr, nullptr), "colibri_corpus_info");
-        for (const auto& v : all_gather({tokens})) tokens_g += v[0];
+        for (const auto& v : all_gather({tokens}, stream)) tokens_g += v[0];
         int maxn = 0;
         for (int n = 1; n <= maxlength; ++n) {
-            uint64_t found_all = 0, kept_all = 0;
+            uint64_t   found_all = 0, kept_all = 0;
             const bool dense = n == 1 && unigrams_dense(found_all, kept_all);
             if (n == 1 && !dense && o.mintokens_unigrams > std::max(1, o.mintokens))
                 throw std::runtime_error("MINTOKENS_UNIGRAMS > MINTOKENS in a sharded run needs the class-indexed order 1 (canonical class encoding on every rank)");
             if (!dense) pass(n, 0, 1, false, found_all, kept_all);
             if (found_all == 0) break;
             maxn       = n;
-            found_g[n] = found_all;
-            kept_g[n]  = kept_all;
+            found_g[(size_t)n] = found_all;
+            kept_g[(size_t)n]  = kept_all;
             if (o.doskipgrams_exhaustive && n >= 3) {  // every admissible window also counts its masked forms (patternmodel.h:1163-1171)
                 uint64_t f = 0, k = 0;
                 skipgram_order(n, o, f, k);
-                found_g[n] += f;
-                kept_g[n] += k;
+                found_g[(size_t)n] += f;
+                kept_g[(size_t)n] += k;
             }
             if (kept_all == 0) break;  // nothing can be admitted at n + 1
         }
@@ -327,23 +516,82 @@ class RankDriver {
             for (int n = 3; n <= std::min(maxlength, maxn); ++n) {
                 uint64_t f = 0, k = 0;
                 skipgram_order(n, o, f, k);
-                found_g[n] += f;
-                kept_g[n] += k;
+                found_g[(size_t)n] += f;
+                kept_g[(size_t)n] += k;
                 if (f == 0) break;
             }
         }
-        chk(colibri_shard_finish(c, found_g.data(), kept_g.data(), tokens_g, maxn, &out.stats), "colibri_shard_finish");
-        // this rank's share of the model
+        chk(colibri_shard_finish(c, found_g.data(), kept_g.data(), tokens_g, maxn, &stats), "colibri_shard_finish");
+        has_gids = true;
+    }
+
+  public:
+    RankExport    out;
+    colibri_stats stats{};
+    bool          has_gids = false, uploaded = false, trained = false, took_kshard = false;
+    uint32_t      last_syncs = 0;
+    RankDriver(Shared& s, int local_index) : sh(s), li(local_index), rank(s.first_rank + local_index), world(s.world), dev(s.device[(size_t)local_index]) {}
+    ~RankDriver() {
+        (void)hipSetDevice(dev);
+        if (c) colibri_destroy(c);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (gather_host) (void)hipHostFree(gather_host);
+    }
+    int global_rank() const { return rank; }
+    void open() {
+        HIPCHK(hipSetDevice(dev));
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        chk(colibri_create(&c, dev), "colibri_create");
+    }
+    void upload(const unsigned char* payload, uint64_t nbytes, uint32_t first_sentence) {
+        HIPCHK(hipSetDevice(dev));
+        chk(colibri_upload_corpus(c, payload, nbytes, first_sentence), "colibri_upload_corpus");
+        uploaded = true;
+    }
+    void train(const colibri_options& o, bool force_candidates) {
+        HIPCHK(hipSetDevice(dev));
+        if (!uploaded) throw std::runtime_error("no corpus uploaded");
+        trained     = false;
+        has_gids    = false;
+        last_syncs  = 0;
+        took_kshard = false;
+        if (!force_candidates) {
+            try {
+                took_kshard = train_kshard(o, stats);
+            } catch (const AgreedFailure& e) {  // (every rank is here: e.g. a record region or a final bin overflowed on one of them) — the other protocol has its own fallbacks
+                if (rank == 0) std::cerr << "key-sharded counting gave up (" << e.what() << "); repeating the run with the candidate exchange" << std::endl;
+            }
+        }
+        if (!took_kshard) train_candidates(o, stats);
+        uint64_t ns = 0;
+        chk(colibri_corpus_info(c, nullptr, &ns, nullptr), "colibri_corpus_info");
+        stats.nsentences = ns;
+        trained          = true;
+    }
+    void sizes(uint64_t* np, uint64_t* kb, uint64_t* nr) {
+        HIPCHK(hipSetDevice(dev));
+        chk(colibri_result_sizes(c, np, kb, nr), "colibri_result_sizes");
+    }
+    void export_unindexed(uint64_t* key_off, uint8_t* key_bytes, uint32_t* counts) {
+        HIPCHK(hipSetDevice(dev));
+        chk(colibri_export_unindexed(c, key_off, key_bytes, counts), "colibri_export_unindexed");
+    }
+    // this rank's share of the model into `out`
+    void fetch(bool indexed) {
+        HIPCHK(hipSetDevice(dev));
         uint64_t np = 0, kb = 0, nr = 0;
         chk(colibri_result_sizes(c, &np, &kb, &nr), "colibri_result_sizes");
+        out = RankExport();
         out.key_off.assign(np + 1, 0);
         out.key_bytes.assign(kb + 1, 0);
         out.counts.assign(np, 0);
-        out.gids.assign(np + 1, 0);
         chk(colibri_export_unindexed(c, out.key_off.data(), out.key_bytes.data(), out.counts.data()), "colibri_export_unindexed");
-        chk(colibri_shard_export_gids(c, out.gids.data()), "colibri_shard_export_gids");
-        out.gids.resize(np);
-        if (o.indexed) {
+        if (has_gids) {
+            out.gids.assign(np + 1, 0);
+            chk(colibri_shard_export_gids(c, out.gids.data()), "colibri_shard_export_gids");
+            out.gids.resize(np);
+        }
+        if (indexed) {
             uint64_t ng = 0, nrefs = 0;
             chk(colibri_shard_index_sizes(c, &ng, &nrefs), "colibri_shard_index_sizes");
             out.ugid.assign(ng + 1, 0);
@@ -353,15 +601,10 @@ class RankDriver {
             chk(colibri_shard_export_index(c, out.ugid.data(), out.ref_off.data(), out.ref_sentence.data(), out.ref_token.data()), "colibri_shard_export_index");
             out.ugid.resize(ng);
         }
-        out.stats.nsentences = 0;
-        uint64_t ns = 0;
-        chk(colibri_corpus_info(c, nullptr, &ns, nullptr), "colibri_corpus_info");
-        out.stats.nsentences = ns;
-        sh.rv.wait();  // the contexts (and their exchange buffers) go away together
     }
 };
 
-// contiguous sentence ranges of about equal bytes: [(begin, end, first sentence)] (dist.py: shard_payload)
+// contiguous sentence ranges of about equal bytes: [(begin, end, first sentence)]
 struct Cut {
     uint64_t begin, end;
     uint32_t first_sentence;
@@ -388,6 +631,92 @@ std::vector<Cut> cut_sentences(const unsigned char* p, uint64_t n, int world, ui
 
 }  // namespace
 
+// ---- the trainer: contexts, communicators and the corpus shards live as long as it does ---------------------------------------------------------------
+class ShardedTrainer {
+  public:
+    Shared                                   sh;
+    std::vector<std::unique_ptr<RankDriver>> ranks;
+    std::string                              error;
+    double                                   last_ms = 0;
+    bool                                     force_candidates = false;
+
+    ShardedTrainer(int world, int nlocal, int first_rank) : sh(world, nlocal, first_rank) {}
+    ~ShardedTrainer() {
+        ranks.clear();
+        if (sh.use_rccl)
+            for (auto& cm : sh.comms)
+                if (cm) (void)ncclCommDestroy(cm);
+    }
+    // devices: [nlocal] or NULL (local rank i -> device i; COLIBRI_DEVICES overrides). unique_id: 128 bytes from colibri_sharded_unique_id when nlocal < world
+    void open(const int* devices, const void* unique_id) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device visible");
+        for (int r = 0; r < sh.nlocal; ++r) sh.device[(size_t)r] = devices ? devices[r] : r;
+        if (!devices)
+            if (const char* e = std::getenv("COLIBRI_DEVICES")) {
+                std::stringstream ss(e);
+                std::string       tok;
+                for (int r = 0; r < sh.nlocal && std::getline(ss, tok, ','); ++r) sh.device[(size_t)r] = std::atoi(tok.c_str());
+            }
+        bool distinct = true;
+        for (int r = 0; r < sh.nlocal; ++r) {
+            if (sh.device[(size_t)r] < 0 || sh.device[(size_t)r] >= ndev)
+                throw std::runtime_error("rank " + std::to_string(sh.first_rank + r) + " asks for device " + std::to_string(sh.device[(size_t)r]) + ", " + std::to_string(ndev) +
+                                         " visible (set COLIBRI_DEVICES)");
+            for (int q = 0; q < r; ++q) distinct = distinct && sh.device[(size_t)q] != sh.device[(size_t)r];
+        }
+        if (!sh.threads()) {
+            if (sh.nlocal != 1 || !unique_id) throw std::runtime_error("a trainer holds either every rank of the run or exactly one (with the run's unique id)");
+            ncclUniqueId id;
+            static_assert(sizeof(ncclUniqueId) == COLIBRI_SHARDED_ID_BYTES, "unique id size");
+            std::memcpy(&id, unique_id, sizeof id);
+            HIPCHK(hipSetDevice(sh.device[0]));
+            NCCLCHK(ncclCommInitRank(&sh.comms[0], sh.world, id, sh.first_rank));
+            sh.use_rccl = true;
+        } else {
+            sh.use_rccl = distinct && !std::getenv("COLIBRI_NO_RCCL");
+            if (sh.use_rccl) {
+                NCCLCHK(ncclCommInitAll(sh.comms.data(), sh.world, sh.device.data()));
+            } else {
+                for (int r = 0; r < sh.world; ++r)  // peer copies between distinct devices need peer access
+                    for (int q = 0; q < sh.world; ++q)
+                        if (sh.device[(size_t)q] != sh.device[(size_t)r] && hipSetDevice(sh.device[(size_t)r]) == hipSuccess) (void)hipDeviceEnablePeerAccess(sh.device[(size_t)q], 0);
+            }
+        }
+        for (int r = 0; r < sh.nlocal; ++r) {
+            ranks.emplace_back(new RankDriver(sh, r));
+            ranks.back()->open();
+        }
+    }
+    const char* exchange_name() const { return sh.use_rccl ? "RCCL" : "device copies between contexts"; }
+    // one host thread per local rank runs `f(rank driver)`; the first failure is the trainer's error
+    template <class F>
+    bool run(F f) {
+        sh.rv.reset();
+        sh.error.clear();
+        std::vector<std::thread> threads;
+        for (size_t r = 0; r < ranks.size(); ++r)
+            threads.emplace_back([&, r] {
+                try {
+                    f(*ranks[r]);
+                } catch (const Aborted&) {
+                } catch (const std::exception& e) {
+                    sh.fail("rank " + std::to_string(ranks[r]->global_rank()) + ": " + e.what());
+                }
+            });
+        for (auto& t : threads) t.join();
+        error = sh.error;
+        return error.empty();
+    }
+    bool train(const colibri_options& o) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const bool fc = force_candidates || std::getenv("COLIBRI_NO_KSHARD") != nullptr;
+        const bool ok = run([&](RankDriver& rk) { rk.train(o, fc); });
+        last_ms       = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return ok;
+    }
+};
+
 void set_gpus(int n) { g_gpus = n; }
 int  gpus() {
     if (g_gpus > 0) return g_gpus;
@@ -401,65 +730,32 @@ void device_train_sharded(const unsigned char* payload, uint64_t nbytes, const c
         std::cerr << "ERROR: --gpus must be between 1 and 64" << std::endl;
         throw InternalError();
     }
-    const auto t0 = std::chrono::steady_clock::now();
-    Shared     sh(world);
-    // rank -> device: 0..world-1, or the list in COLIBRI_DEVICES (a device may appear twice: the copies back end is used then)
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-        std::cerr << "ERROR: no HIP device visible" << std::endl;
+    const auto     t0 = std::chrono::steady_clock::now();
+    ShardedTrainer tr(world, world, 0);
+    try {
+        tr.open(nullptr, nullptr);
+    } catch (const std::exception& e) {
+        std::cerr << "ERROR: " << e.what() << std::endl;
         throw InternalError();
     }
-    for (int r = 0; r < world; ++r) sh.device[(size_t)r] = r;
-    if (const char* e = std::getenv("COLIBRI_DEVICES")) {
-        std::stringstream ss(e);
-        std::string       tok;
-        for (int r = 0; r < world && std::getline(ss, tok, ','); ++r) sh.device[(size_t)r] = std::atoi(tok.c_str());
-    }
-    bool distinct = true;
-    for (int r = 0; r < world; ++r) {
-        if (sh.device[(size_t)r] < 0 || sh.device[(size_t)r] >= ndev) {
-            std::cerr << "ERROR: rank " << r << " asks for device " << sh.device[(size_t)r] << ", " << ndev << " visible (set COLIBRI_DEVICES)" << std::endl;
-            throw InternalError();
-        }
-        for (int q = 0; q < r; ++q) distinct = distinct && sh.device[(size_t)q] != sh.device[(size_t)r];
-    }
-    sh.use_rccl = distinct && !std::getenv("COLIBRI_NO_RCCL");
-    if (sh.use_rccl) {
-        sh.comms.resize((size_t)world);
-        const ncclResult_t e = ncclCommInitAll(sh.comms.data(), world, sh.device.data());
-        if (e != ncclSuccess) {
-            std::cerr << "ERROR: ncclCommInitAll: " << ncclGetErrorString(e) << std::endl;
-            throw InternalError();
-        }
-    } else {
-        for (int r = 0; r < world; ++r)  // peer copies between distinct devices need peer access
-            for (int q = 0; q < world; ++q)
-                if (sh.device[(size_t)q] != sh.device[(size_t)r] && hipSetDevice(sh.device[(size_t)r]) == hipSuccess) (void)hipDeviceEnablePeerAccess(sh.device[(size_t)q], 0);
-    }
-    std::cerr << "Training sentence-sharded over " << world << " GPU" << (world > 1 ? "s" : "") << " (exchange: " << (sh.use_rccl ? "RCCL" : "device copies between contexts") << ")" << std::endl;
-    const std::vector<Cut>                   cuts = cut_sentences(payload, nbytes, world, firstsentence);
-    std::vector<std::unique_ptr<RankDriver>> ranks;
-    for (int r = 0; r < world; ++r) ranks.emplace_back(new RankDriver(sh, r));
-    std::vector<std::thread> threads;
-    for (int r = 0; r < world; ++r)
-        threads.emplace_back([&, r] {
-            try {
-                ranks[(size_t)r]->run(payload + cuts[(size_t)r].begin, cuts[(size_t)r].end - cuts[(size_t)r].begin, cuts[(size_t)r].first_sentence, opt);
-            } catch (const Aborted&) {
-            } catch (const std::exception& e) {
-                sh.fail("rank " + std::to_string(r) + ": " + e.what());
-            }
-        });
-    for (auto& t : threads) t.join();
-    if (sh.use_rccl)
-        for (auto& cm : sh.comms) (void)ncclCommDestroy(cm);
-    if (!sh.error.empty()) {
-        std::cerr << "ERROR: " << sh.error << std::endl;
+    std::cerr << "Training sentence-sharded over " << world << " GPU" << (world > 1 ? "s" : "") << " (exchange: " << tr.exchange_name() << ")" << std::endl;
+    const std::vector<Cut> cuts = cut_sentences(payload, nbytes, world, firstsentence);
+    auto&                  ranks = tr.ranks;
+    bool ok = tr.run([&](RankDriver& rk) {
+        const Cut& ct = cuts[(size_t)rk.global_rank()];
+        rk.upload(payload + ct.begin, ct.end - ct.begin, ct.first_sentence);
+    });
+    ok = ok && tr.train(opt);
+    ok = ok && tr.run([&](RankDriver& rk) { rk.fetch(opt.indexed != 0); });
+    if (!ok) {
+        std::cerr << "ERROR: " << tr.error << std::endl;
         throw InternalError();
     }
+    if (ranks[0]->took_kshard) std::cerr << "Counted key-sharded: every rank counts the keys it owns (" << ranks[0]->last_syncs << " host look-ups)" << std::endl;
     // ---- the union of the ranks' exports is the model ---------------------------------------------------------------------
-    out.stats = ranks[0]->out.stats;  // global found / kept / totals are the same on every rank
-    uint64_t np = 0, kb = 0, gid_max = 0;
+    out.stats = ranks[0]->stats;  // global found / kept / totals are the same on every rank
+    const bool have_gids = ranks[0]->has_gids;
+    uint64_t   np = 0, kb = 0, gid_max = 0;
     for (auto& rk : ranks) {
         np += rk->out.counts.size();
         kb += rk->out.key_off.empty() ? 0 : rk->out.key_off.back();
@@ -468,10 +764,12 @@ void device_train_sharded(const unsigned char* payload, uint64_t nbytes, const c
     out.key_off.assign(np + 1, 0);
     out.key_bytes.assign(kb + 1, 0);
     out.counts.assign(np, 0);
-    std::vector<uint32_t> where(gid_max + 2, 0xFFFFFFFFu);  // global id -> pattern number
+    std::vector<uint32_t> where(have_gids ? gid_max + 2 : 0, 0xFFFFFFFFu);  // global id -> pattern number
     uint64_t              j = 0, b = 0;
     out.stats.nsentences = 0;
-    for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) out.stats.windows[n] = out.stats.admitted[n] = 0;
+    if (have_gids)
+        for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) out.stats.admitted[n] = 0;
+    for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) out.stats.windows[n] = 0;
     for (auto& rk : ranks) {
         const RankExport& e = rk->out;
         for (size_t k = 0; k < e.counts.size(); ++k, ++j) {
@@ -480,16 +778,18 @@ void device_train_sharded(const unsigned char* payload, uint64_t nbytes, const c
             std::memcpy(out.key_bytes.data() + b, e.key_bytes.data() + e.key_off[k], len);
             b += len;
             out.counts[j] = e.counts[k];
-            if (where[e.gids[k]] != 0xFFFFFFFFu) {
-                std::cerr << "ERROR: a pattern was exported by more than one rank" << std::endl;
-                throw InternalError();
+            if (have_gids) {
+                if (where[e.gids[k]] != 0xFFFFFFFFu) {
+                    std::cerr << "ERROR: a pattern was exported by more than one rank" << std::endl;
+                    throw InternalError();
+                }
+                where[e.gids[k]] = (uint32_t)j;
             }
-            where[e.gids[k]] = (uint32_t)j;
         }
-        out.stats.nsentences += e.stats.nsentences;
+        out.stats.nsentences += rk->stats.nsentences;
         for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) {
-            out.stats.windows[n] += e.stats.windows[n];
-            out.stats.admitted[n] += e.stats.admitted[n];
+            out.stats.windows[n] += rk->stats.windows[n];
+            if (have_gids) out.stats.admitted[n] += rk->stats.admitted[n];  // (the key-sharded run reports global figures already)
         }
     }
     out.key_off[np]     = b;
@@ -530,3 +830,121 @@ void device_train_sharded(const unsigned char* payload, uint64_t nbytes, const c
 }
 
 }  // namespace colibri_host
+
+// ---- C face (include/colibri_sharded.h) ------------------------------------------------------------------------------------------------------------------
+struct colibri_sharded {
+    colibri_host::ShardedTrainer tr;
+    std::string                  err;
+    colibri_sharded(int world, int nlocal, int first) : tr(world, nlocal, first) {}
+};
+
+extern "C" {
+
+int colibri_sharded_unique_id(void* out) {
+    if (!out) return COLIBRI_ERR_ARG;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return COLIBRI_ERR_HIP;
+    std::memcpy(out, &id, sizeof id);
+    return COLIBRI_OK;
+}
+
+int colibri_sharded_create(colibri_sharded** out, int world, int nlocal, int first_rank, const int* devices, const void* unique_id) {
+    if (!out || world < 1 || world > 64 || nlocal < 1 || nlocal > world || first_rank < 0 || first_rank + nlocal > world) return COLIBRI_ERR_ARG;
+    *out = nullptr;
+    colibri_sharded* t = new (std::nothrow) colibri_sharded(world, nlocal, first_rank);
+    if (!t) return COLIBRI_ERR_ARG;
+    try {
+        t->tr.open(devices, unique_id);
+    } catch (const std::exception& e) {
+        std::cerr << "colibri_sharded_create: " << e.what() << std::endl;
+        delete t;
+        return COLIBRI_ERR_HIP;
+    }
+    *out = t;
+    return COLIBRI_OK;
+}
+void colibri_sharded_destroy(colibri_sharded* t) { delete t; }
+const char* colibri_sharded_last_error(const colibri_sharded* t) { return t ? t->err.c_str() : "null trainer"; }
+
+int colibri_sharded_upload(colibri_sharded* t, int local_rank, const uint8_t* payload, uint64_t nbytes, uint32_t first_sentence) {
+    if (!t || local_rank < 0 || local_rank >= (int)t->tr.ranks.size()) return COLIBRI_ERR_ARG;
+    try {
+        t->tr.ranks[(size_t)local_rank]->upload(payload, nbytes, first_sentence);
+    } catch (const std::exception& e) {
+        t->err = e.what();
+        return COLIBRI_ERR_HIP;
+    }
+    return COLIBRI_OK;
+}
+int colibri_sharded_upload_split(colibri_sharded* t, const uint8_t* payload, uint64_t nbytes, uint32_t first_sentence) {
+    if (!t || (!payload && nbytes)) return COLIBRI_ERR_ARG;
+    if (!t->tr.sh.threads()) {
+        t->err = "colibri_sharded_upload_split needs a trainer that holds every rank";
+        return COLIBRI_ERR_STATE;
+    }
+    const auto cuts = colibri_host::cut_sentences(payload, nbytes, t->tr.sh.world, first_sentence);
+    const bool ok   = t->tr.run([&](colibri_host::RankDriver& rk) {
+        const auto& ct = cuts[(size_t)rk.global_rank()];
+        rk.upload(payload + ct.begin, ct.end - ct.begin, ct.first_sentence);
+    });
+    if (!ok) t->err = t->tr.error;
+    return ok ? COLIBRI_OK : COLIBRI_ERR_HIP;
+}
+int colibri_sharded_set_protocol(colibri_sharded* t, int protocol) {
+    if (!t || protocol < 0 || protocol > 1) return COLIBRI_ERR_ARG;
+    t->tr.force_candidates = protocol == 1;
+    return COLIBRI_OK;
+}
+int colibri_sharded_train(colibri_sharded* t, const colibri_options* opt, colibri_stats* stats, colibri_sharded_info* info) {
+    if (!t || !opt) return COLIBRI_ERR_ARG;
+    const bool ok = t->tr.train(*opt);
+    if (!ok) {
+        t->err = t->tr.error;
+        return COLIBRI_ERR_HIP;
+    }
+    const auto& r0 = *t->tr.ranks[0];
+    if (stats) {
+        *stats = r0.stats;  // found / kept / tokens / types are global on every rank; patterns and sentences are this trainer's ranks'
+        stats->npatterns = stats->nsentences = 0;
+        for (auto& rk : t->tr.ranks) {
+            stats->npatterns += rk->stats.npatterns;
+            stats->nsentences += rk->stats.nsentences;
+            if (&*rk != &r0)
+                for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) {
+                    stats->windows[n] += rk->stats.windows[n];
+                    if (!r0.took_kshard) stats->admitted[n] += rk->stats.admitted[n];  // (the key-sharded run reports the global figure on every rank)
+                }
+        }
+        stats->train_ms = t->tr.last_ms;
+    }
+    if (info) {
+        info->protocol     = r0.took_kshard ? 0 : 1;
+        info->rccl         = t->tr.sh.use_rccl ? 1 : 0;
+        info->host_lookups = r0.last_syncs;
+        info->wall_ms      = t->tr.last_ms;
+    }
+    return COLIBRI_OK;
+}
+int colibri_sharded_result_sizes(colibri_sharded* t, int local_rank, uint64_t* npatterns, uint64_t* keybytes) {
+    if (!t || local_rank < 0 || local_rank >= (int)t->tr.ranks.size()) return COLIBRI_ERR_ARG;
+    try {
+        uint64_t nr = 0;
+        t->tr.ranks[(size_t)local_rank]->sizes(npatterns, keybytes, &nr);
+    } catch (const std::exception& e) {
+        t->err = e.what();
+        return COLIBRI_ERR_HIP;
+    }
+    return COLIBRI_OK;
+}
+int colibri_sharded_export_unindexed(colibri_sharded* t, int local_rank, uint64_t* key_off, uint8_t* key_bytes, uint32_t* counts) {
+    if (!t || local_rank < 0 || local_rank >= (int)t->tr.ranks.size()) return COLIBRI_ERR_ARG;
+    try {
+        t->tr.ranks[(size_t)local_rank]->export_unindexed(key_off, key_bytes, counts);
+    } catch (const std::exception& e) {
+        t->err = e.what();
+        return COLIBRI_ERR_HIP;
+    }
+    return COLIBRI_OK;
+}
+
+}  // extern "C"

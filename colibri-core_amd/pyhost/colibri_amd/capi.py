@@ -23,6 +23,8 @@ EXPORTED = [
     "colibri_shard_begin", "colibri_shard_count", "colibri_shard_send", "colibri_shard_send_view", "colibri_shard_merge", "colibri_shard_reply", "colibri_shard_apply",
     "colibri_shard_finish", "colibri_shard_export_gids", "colibri_shard_index_sizes", "colibri_shard_export_index",
     "colibri_shard_uni_info", "colibri_shard_uni_count", "colibri_shard_uni_apply",
+    "colibri_stream", "colibri_kshard_info", "colibri_kshard_begin", "colibri_kshard_uni_count", "colibri_kshard_uni_apply", "colibri_kshard_emit", "colibri_kshard_recv_buffers",
+    "colibri_kshard_count", "colibri_kshard_feedback_buffers", "colibri_kshard_apply", "colibri_kshard_local_stats", "colibri_kshard_finish",
     "colibri_set_constraint", "colibri_set_continuation", "colibri_set_filter", "colibri_text_upload", "colibri_text_count", "colibri_text_words", "colibri_text_encode", "colibri_text_fetch", "colibri_text_as_corpus",
     "colibri_flexgrams", "colibri_flexgrams_resident", "colibri_flexgrams_fetch",
 ]
@@ -53,6 +55,17 @@ class Stats(C.Structure):
         ("windows", C.c_uint64 * MAX_ORDER), ("admitted", C.c_uint64 * MAX_ORDER), ("found", C.c_uint64 * MAX_ORDER),
         ("pruned", C.c_uint64 * MAX_ORDER), ("kept", C.c_uint64 * MAX_ORDER), ("train_ms", C.c_double),
     ]
+
+
+SHARDED_LIB_PATH = os.path.join(PKG_ROOT, "lib", "libcolibri_sharded.so")
+SHARDED_EXPORTED = [
+    "colibri_sharded_unique_id", "colibri_sharded_create", "colibri_sharded_destroy", "colibri_sharded_last_error", "colibri_sharded_upload", "colibri_sharded_upload_split",
+    "colibri_sharded_set_protocol", "colibri_sharded_train", "colibri_sharded_result_sizes", "colibri_sharded_export_unindexed",
+]
+
+
+class ShardedInfo(C.Structure):
+    _fields_ = [("protocol", C.c_int32), ("rccl", C.c_int32), ("host_lookups", C.c_uint32), ("pad", C.c_uint32), ("wall_ms", C.c_double)]
 
 
 class ColibriError(RuntimeError):
@@ -433,3 +446,113 @@ class HipShardEngine:
             ro, rs, rt = ro.tolist(), rs.tolist(), rt.tolist()
             index = {int(g): list(zip(rs[ro[j]: ro[j + 1]], rt[ro[j]: ro[j + 1]])) for j, g in enumerate(ug[: ng.value].tolist())}
         return {"patterns": patterns, "index": index}
+
+
+# ---- the multi-GPU trainer (include/colibri_sharded.h; host/src/sharded.cpp: C++ over the C ABI, RCCL linked directly) ---------------------------------
+_shlib = None
+
+
+def load_sharded():
+    global _shlib
+    if _shlib is None:
+        load()  # libcolibri_hip.so first (the trainer links it)
+        if not os.path.exists(SHARDED_LIB_PATH):
+            raise ImportError(f"{SHARDED_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        S = C.CDLL(SHARDED_LIB_PATH)
+        S.colibri_sharded_unique_id.argtypes = [C.c_void_p]
+        S.colibri_sharded_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        S.colibri_sharded_destroy.argtypes = [C.c_void_p]
+        S.colibri_sharded_destroy.restype = None
+        S.colibri_sharded_last_error.argtypes = [C.c_void_p]
+        S.colibri_sharded_last_error.restype = C.c_char_p
+        S.colibri_sharded_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32]
+        S.colibri_sharded_upload_split.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+        S.colibri_sharded_set_protocol.argtypes = [C.c_void_p, C.c_int]
+        S.colibri_sharded_train.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Stats), C.POINTER(ShardedInfo)]
+        S.colibri_sharded_result_sizes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        S.colibri_sharded_export_unindexed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _shlib = S
+    return _shlib
+
+
+def sharded_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    rc = load_sharded().colibri_sharded_unique_id(buf)
+    if rc != 0:
+        raise ColibriError(rc, "colibri_sharded_unique_id failed")
+    return buf.raw
+
+
+class ShardedTrainer:
+    """`nlocal` ranks of a `world`-rank run held by this process: all of them (one host thread each), or one (one process per rank; `unique_id` from
+    sharded_unique_id(), the same bytes in every process). devices: HIP ordinal per local rank (two ranks on one device exchange by device copies: tests)."""
+
+    def __init__(self, world, nlocal=None, first_rank=0, devices=None, unique_id=None):
+        self.S = load_sharded()
+        self.world = world
+        self.nlocal = world if nlocal is None else nlocal
+        h = C.c_void_p()
+        dev = (C.c_int * self.nlocal)(*devices) if devices is not None else None
+        uid = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
+        rc = self.S.colibri_sharded_create(C.byref(h), world, self.nlocal, first_rank, dev, uid)
+        if rc != 0:
+            raise ColibriError(rc, "colibri_sharded_create failed (devices visible? RCCL?)")
+        self.h = h
+        self.stats = None
+        self.info = None
+
+    def close(self):
+        if self.h:
+            self.S.colibri_sharded_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ColibriError(rc, (self.S.colibri_sharded_last_error(self.h) or b"").decode(errors="replace"))
+
+    def upload(self, local_rank, payload, first_sentence=1):
+        buf = np.frombuffer(payload, dtype=np.uint8)
+        self._check(self.S.colibri_sharded_upload(self.h, local_rank, buf.ctypes.data if buf.size else None, buf.size, first_sentence))
+
+    def upload_split(self, payload, first_sentence=1):
+        buf = np.frombuffer(payload, dtype=np.uint8)
+        self._check(self.S.colibri_sharded_upload_split(self.h, buf.ctypes.data if buf.size else None, buf.size, first_sentence))
+
+    def set_protocol(self, protocol):
+        """0: key-sharded counting where the run allows it (default); 1: always the candidate exchange"""
+        self._check(self.S.colibri_sharded_set_protocol(self.h, protocol))
+
+    def train(self, **kw):
+        opt = Options.defaults(**kw)
+        st, info = Stats(), ShardedInfo()
+        self._check(self.S.colibri_sharded_train(self.h, C.byref(opt), C.byref(st), C.byref(info)))
+        self.stats, self.info = st, info
+        return st
+
+    def export_arrays(self, local_rank):
+        npat, kb = C.c_uint64(), C.c_uint64()
+        self._check(self.S.colibri_sharded_result_sizes(self.h, local_rank, C.byref(npat), C.byref(kb)))
+        key_off = np.zeros(npat.value + 1, dtype=np.uint64)
+        key_bytes = np.zeros(max(1, kb.value), dtype=np.uint8)
+        counts = np.zeros(max(1, npat.value), dtype=np.uint32)
+        self._check(self.S.colibri_sharded_export_unindexed(self.h, local_rank, key_off.ctypes.data, key_bytes.ctypes.data, counts.ctypes.data))
+        return key_off, key_bytes[: kb.value], counts[: npat.value]
+
+    def export_dict(self):
+        """the union of the local ranks' shares: {key bytes: count} (every pattern is exported by exactly one rank: a duplicate raises)"""
+        out = {}
+        for r in range(self.nlocal):
+            key_off, key_bytes, counts = self.export_arrays(r)
+            raw = key_bytes.tobytes()
+            for j in range(counts.size):
+                k = raw[int(key_off[j]): int(key_off[j + 1])]
+                if k in out:
+                    raise ValueError(f"pattern {k.hex()} exported by more than one rank")
+                out[k] = int(counts[j])
+        return out

@@ -183,6 +183,41 @@ int colibri_shard_export_gids(colibri_ctx* ctx, uint32_t* gids);
 int colibri_shard_index_sizes(const colibri_ctx* ctx, uint64_t* ngids, uint64_t* nrefs);
 int colibri_shard_export_index(colibri_ctx* ctx, uint32_t* gids, uint64_t* ref_off, uint32_t* ref_sentence, uint16_t* ref_token);
 
+/* ---- key-sharded multi-GPU training of the plain n-gram model (BASELINE.json configs[2]; csrc/kshard.hpp). The reference has no counterpart (it is
+ * single-threaded); what is distributed is PatternModel::train's order loop (include/patternmodel.h:981-1270) at its only cross-shard dependency, the GLOBAL count
+ * of a candidate before the prune of its order (:1195-1245). Unlike colibri_shard_* above, no rank counts candidates it does not own: every rank scans its own
+ * sentences into RECORDS (the single-device emit kernels), the records travel to the owner of their key (owner = top bits of the key's mix), the owner counts them
+ * with the single-device kernels and applies the threshold to the exact global count, and only what survived travels back (order 2: positions of surviving windows;
+ * order >= 3: global survivor ids of surviving records; plus one (representative, count) per kept pattern to the rank that exports it). Order 1 is an all-reduce
+ * (SUM) of the dense per-class count array — the north star's "all-reduce of the per-bucket count tables before the prune". world = 1, 2, 4 or 8.
+ * The collectives are the caller's (host/src/sharded.cpp: RCCL, or device copies); all device work is enqueued on colibri_stream(ctx), which the caller hands to
+ * its collectives too: an order costs two host look-ups (the sizes of the two exchanges). All *_dev arguments are DEVICE pointers owned by the library.
+ *   colibri_kshard_info on every rank -> [the caller checks that all ranks are eligible, takes the maxima] -> colibri_kshard_begin
+ *   order 1:    colibri_kshard_uni_count -> [all-reduce SUM, u32 x nclasses, in place] -> colibri_kshard_uni_apply
+ *   order n>=2: colibri_kshard_emit -> [sizes] -> colibri_kshard_recv_buffers -> [all-to-all records, tables; order 2: all-reduce head rows SUM / MIN] ->
+ *               colibri_kshard_count -> [sizes] -> colibri_kshard_feedback_buffers -> [all-to-all feedback, exports] -> colibri_kshard_apply
+ *               (the loop ends after the order at which no rank admitted a window: the reference's "None found", :1189-1194)
+ *   end:        colibri_kshard_local_stats -> [sums over ranks] -> colibri_kshard_finish; then colibri_result_sizes / colibri_export_unindexed on every rank:
+ *               each pattern of the model is exported by exactly one rank (the lowest that holds an occurrence; rank 0 for unigrams). */
+void* colibri_stream(colibri_ctx* ctx); /* the hipStream_t all of the context's device work is enqueued on */
+int colibri_kshard_info(colibri_ctx* ctx, const colibri_options* opt, int* eligible, uint64_t* maxclass, uint64_t* npositions);
+int colibri_kshard_begin(colibri_ctx* ctx, const colibri_options* opt, int world, int rank, uint64_t maxclass_global, uint64_t maxpositions_global);
+int colibri_kshard_uni_count(colibri_ctx* ctx, void** cnt_dev, uint32_t* nclasses);
+int colibri_kshard_uni_apply(colibri_ctx* ctx);
+/* per_owner[world]: records for each rank, laid out in rank order in *send_dev (*recbytes each: 8 at order 2, 16 above); *tab_dev: u32[world][256], row d goes to rank d;
+ * *head_dev: order 2: u32[2][4096] (row 0: all-reduce SUM, row 1: all-reduce MIN, in place), else NULL; *admitted: windows this rank counted at order n */
+int colibri_kshard_emit(colibri_ctx* ctx, int n, void** send_dev, void** tab_dev, uint64_t* per_owner, uint32_t* recbytes, void** head_dev, uint64_t* admitted);
+int colibri_kshard_recv_buffers(colibri_ctx* ctx, uint64_t nrecords, void** recv_dev /* records, concatenated in source order */, void** tab_recv_dev /* u32[world][256], row s from rank s */);
+/* per_src[world]: records received from each rank. more: order n + 1 follows (feedback is produced). fb_per_dst / ex_per_dst [world]: entries for each rank, in rank
+ * order in *fb_dev (*fb_bytes each) / *ex_dev (8 bytes each) */
+int colibri_kshard_count(colibri_ctx* ctx, int n, const uint64_t* per_src, int more, void** fb_dev, uint64_t* fb_per_dst, uint32_t* fb_bytes, void** ex_dev, uint64_t* ex_per_dst);
+int colibri_kshard_feedback_buffers(colibri_ctx* ctx, uint64_t nfeedback, uint64_t nexports, void** fb_recv_dev, void** ex_recv_dev); /* each concatenated in owner order */
+int colibri_kshard_apply(colibri_ctx* ctx, int n, uint64_t nfeedback, uint64_t nexports, int more);
+/* arrays of COLIBRI_MAX_ORDER: distinct keys / survivors among the keys this rank OWNS (order 1: global, on rank 0 only), windows it counted; *syncs: host look-ups so far */
+int colibri_kshard_local_stats(colibri_ctx* ctx, uint64_t* found, uint64_t* kept, uint64_t* admitted, uint32_t* syncs);
+int colibri_kshard_finish(colibri_ctx* ctx, const uint64_t* found_global, const uint64_t* kept_global, const uint64_t* admitted_global, uint64_t totaltokens_global, int maxn,
+                          colibri_stats* stats);
+
 /* ---- parity / measurement hooks ------------------------------------------------------------------ */
 /* SpookyHash::Hash64 (reference include/SpookyV2.h:59-66) of every n-token window, computed by the same
  * device routine the count kernel uses: out[i] for token position i (delimiters are positions too);

@@ -1,0 +1,133 @@
+"""GPU: key-sharded counting — the multi-GPU form of the plain n-gram run (csrc/kshard.hpp, colibri_kshard_* in include/colibri_hip.h) driven by the product's own
+C++ trainer (host/src/sharded.cpp through include/colibri_sharded.h): 1 / 2 / 4 / 8 ranks, here all on cuda:0 (ranks sharing a device exchange by device copies; one
+rank runs the RCCL back end against itself). The union of the ranks' exports must be the oracle's single-process model of the WHOLE corpus — every key, every count,
+tokens, types, per-order found / kept — and no pattern may be exported twice. What only real devices can add (RCCL between two GPUs) is the driver's scaling run."""
+import numpy as np
+import pytest
+
+from conftest import small_corpora
+
+pytestmark = pytest.mark.gpu
+
+CORPORA = small_corpora()
+PLAIN = ["rand0", "rand1", "rand2", "rand3", "rand_noempty", "empty", "only_delims", "one_token", "no_trailing_delim", "short_sentences", "repeat", "one_long_sentence", "cls_2p20",
+         "cls_2p21m1", "zipf20k", "zipf200k_phrases"]
+
+
+BIG_CLASSES = {"rand0", "rand1", "rand2", "rand3"}
+
+
+def run(world, payload, devices=None, protocol=0, **kw):
+    from colibri_amd import capi
+    with capi.ShardedTrainer(world, devices=devices) as tr:
+        tr.upload_split(payload)
+        if protocol:
+            tr.set_protocol(protocol)
+        st = tr.train(**kw)
+        return st, tr.info.protocol, tr.info.host_lookups, tr.info.rccl, tr.export_dict()
+
+
+def check(st, got, want, maxlength):
+    assert got == want.counts
+    assert (st.totaltokens, st.totaltypes, st.maxn, st.npatterns) == (want.tokens, want.types, want.maxn, len(want.counts))
+    for n in range(1, min(maxlength, 20) + 1):
+        assert (st.found[n], st.kept[n]) == (want.stats[n][0], want.stats[n][2]), n
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+@pytest.mark.parametrize("name", PLAIN)
+def test_key_sharded_model_is_the_oracles(name, world):
+    import oracle
+    payload = CORPORA[name]
+    for maxlength, thr in ((5, 2), (2, 2), (8, 3), (4, 1)):
+        want = oracle.train(payload, thr, maxlength)
+        st, protocol, lookups, rccl, got = run(world, payload, devices=[0] * world, mintokens=thr, maxlength=maxlength)
+        check(st, got, want, maxlength)
+        if name in BIG_CLASSES:  # class ids of 2^21 and more: every rank sees it in the first exchange and the run takes the candidate exchange
+            assert protocol == 1
+            continue
+        assert protocol == 0 and rccl == (1 if world == 1 else 0), "the run did not take the key-sharded path"
+        assert lookups <= 2 * max(1, st.maxn) + 2
+
+
+def test_one_rank_over_rccl():
+    """ncclCommInitAll with one device: send / recv to itself and the all-reduces run through RCCL"""
+    import oracle
+    payload = CORPORA["zipf200k_phrases"]
+    want = oracle.train(payload, 2, 5)
+    st, protocol, lookups, rccl, got = run(1, payload, mintokens=2, maxlength=5)
+    assert protocol == 0 and rccl == 1
+    check(st, got, want, 5)
+    assert lookups <= 10
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_word_threshold_and_admitted_counts(world):
+    """-W: unigrams stay at MINTOKENS, longer windows need every word at the word threshold; the admitted windows are the single-device run's"""
+    import oracle
+    from colibri_amd import capi
+    payload = CORPORA["zipf200k_phrases"]
+    want = oracle.train(payload, 2, 5, mintokens_unigrams=4)
+    st, protocol, _, _, got = run(world, payload, devices=[0] * world, mintokens=2, maxlength=5, mintokens_unigrams=4)
+    assert protocol == 0
+    check(st, got, want, 5)
+    with capi.Context(0) as ctx:
+        ctx.upload(payload)
+        one = ctx.train(mintokens=2, maxlength=5, mintokens_unigrams=4)
+    for n in range(1, 6):
+        assert (st.admitted[n], st.windows[n]) == (one.admitted[n], one.windows[n]), n
+
+
+@pytest.mark.parametrize("name", ["cls_2p21", "cls_2p22", "multibyte"])
+def test_runs_outside_the_key_sharded_subset_take_the_candidate_exchange(name):
+    """class ids of 2^21 and more do not fit three to a key: every rank sees it in the first exchange and the run takes the other protocol — same model"""
+    import oracle
+    payload = CORPORA[name]
+    want = oracle.train(payload, 2, 5)
+    st, protocol, _, _, got = run(2, payload, devices=[0, 0], mintokens=2, maxlength=5)
+    assert protocol == 1
+    assert got == want.counts and (st.totaltokens, st.totaltypes) == (want.tokens, want.types)
+
+
+def test_candidate_exchange_on_request_gives_the_same_model():
+    import oracle
+    payload = CORPORA["zipf20k"]
+    want = oracle.train(payload, 2, 5)
+    for world in (2, 3):
+        st, protocol, _, _, got = run(world, payload, devices=[0] * world, protocol=1, mintokens=2, maxlength=5)
+        assert protocol == 1 and got == want.counts
+
+
+def test_trainer_keeps_its_shards_between_runs():
+    """the benchmark's use: upload once, train repeatedly (other options in between), export at the end"""
+    import oracle
+    from colibri_amd import capi
+    payload = CORPORA["zipf200k_phrases"]
+    with capi.ShardedTrainer(4, devices=[0, 0, 0, 0]) as tr:
+        tr.upload_split(payload)
+        for maxlength, thr in ((5, 2), (3, 2), (5, 3), (5, 2)):
+            st = tr.train(mintokens=thr, maxlength=maxlength)
+            want = oracle.train(payload, thr, maxlength)
+            assert tr.info.protocol == 0
+            check(st, tr.export_dict(), want, maxlength)
+
+
+def test_2m_tokens_two_ranks_against_the_single_device_model():
+    """beyond what the oracle does in seconds: 2 ranks x 1 M tokens against the single-device run of the whole corpus (multiset of (key, count) rows)"""
+    from colibri_amd import capi, digest, synth
+    payload = synth.zipf_corpus(2_000_000, 100_000, 11, phrases=True, header=False)
+    with capi.Context(0) as ctx:
+        ctx.upload(payload)
+        one = ctx.train(mintokens=2, maxlength=5)
+        key_off, key_bytes, counts, _ = ctx.export_arrays()
+        want = digest.model_digest(key_off, key_bytes, counts)
+    with capi.ShardedTrainer(2, devices=[0, 0]) as tr:
+        tr.upload_split(payload)
+        st = tr.train(mintokens=2, maxlength=5)
+        assert tr.info.protocol == 0
+        parts = [tr.export_arrays(r) for r in range(2)]
+    lens = [p[1].size for p in parts]
+    key_off = np.concatenate([parts[0][0][:-1], parts[1][0] + np.uint64(lens[0])])
+    got = digest.model_digest(key_off, np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts]))
+    assert got == want
+    assert [st.found[n] for n in range(1, 6)] == [one.found[n] for n in range(1, 6)] and [st.kept[n] for n in range(1, 6)] == [one.kept[n] for n in range(1, 6)]

@@ -1,27 +1,31 @@
 #!/usr/bin/env python
 """bench.py — the driver's benchmark contract for the hot path (PatternModel::train, n <= 5, thr = 2).
 
-  python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W                    (any N: the N ranks are host threads of this one process, RCCL linked by the C++ trainer)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...   (one process per rank)
 
-A "step" is one complete train() (all five orders: scan + SpookyHash + hash build + prune + resolve) over one
-synthetic class-encoded corpus that is already resident in HBM when the timed region starts.
-  N = 1 : BASELINE.json configs[1] — 100M-token Zipf(1.0, V = 1e6) corpus, unindexed, n <= 5, threshold 2.
-  N > 1 : the corpus is sharded by sentence, 100M tokens PER RANK (weak scaling; N = 8: 125M per rank = the 1B-token corpus of
-          configs[2]), with the per-order exchange of candidate counts over RCCL (colibri_amd.dist).
-The run checks what it timed: for the default corpus (seed 44) the model must be the known one (tests/test_gpu_fullsize.py) or the exit
-status is non-zero. `other_configs` reports the other model kinds of BASELINE.json (configs[3], configs[4]) on the same corpus from extra,
-untimed steps.
-Metric (BASELINE.json): M patterns counted / s, patterns counted = sum_{n<=5} W_n = the n-token windows inside
-sentences that the reference enumerates in line.ngrams() (include/patternmodel.h:1063) — a property of the input.
-Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (count) against HBM peak with the algorithmic
-bytes of SURVEY.md §8(d) (stated in DESIGN.md §4); `cpu_baseline` times the real reference (oracle/_ref/ref_driver,
-built from the reference's own sources) on a bounded sample of the same distribution on this box's host cores.
+A "step" is one complete train() (all five orders: scan + key + count + prune + look-back state for the next order) over one synthetic class-encoded corpus that
+is already resident in HBM when the timed region starts.
+  N = 1 : BASELINE.json configs[1] — 100M-token Zipf(1.0, V = 1e6) corpus, unindexed, n <= 5, threshold 2, one device (colibri_train).
+  N > 1 : BASELINE.json configs[2] — the corpus is sharded by sentence, 100M tokens PER RANK (weak scaling; N = 8: 125M per rank = the 1B-token corpus), trained by
+          the product's own multi-GPU trainer (colibri-core_amd/host/src/sharded.cpp through include/colibri_sharded.h — what colibri-patternmodeller --gpus N
+          runs): order 1 an RCCL all-reduce of the dense class counts, orders >= 2 key-sharded counting (records to the owner of their key, csrc/kshard.hpp).
+          --force-shard runs that trainer with one rank (prices the exchange machinery against the single-device step on the same corpus).
+The run checks what it timed: the model of the default corpus (seed 44) must be the one the REAL reference built from the same bytes — per-order kept counts, pattern
+total and the multiset digest of (key, count) rows in tests/golden/fullsize/z100m_seed44_plain.json (made by tests/golden/make_fullsize_golden.py) — or the exit
+status is non-zero. `other_configs` reports the other model kinds of BASELINE.json (configs[3], configs[4]) and the phrase-injected corpus of SURVEY 8(d) from
+extra, untimed steps.
+Metric (BASELINE.json): M patterns counted / s, patterns counted = sum_{n<=5} W_n = the n-token windows inside sentences that the reference enumerates in
+line.ngrams() (include/patternmodel.h:1063) — a property of the input.
+Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (count) against HBM peak with the algorithmic bytes of SURVEY.md 8(d) (stated in DESIGN.md 4);
+`cpu_baseline` times the real reference (oracle/_ref/ref_driver, built from the reference's own sources) on a bounded sample of the same distribution on this
+box's host cores.
 """
 import argparse
+import concurrent.futures
 import json
+import multiprocessing
 import os
-import subprocess
 import sys
 import tempfile
 import time
@@ -32,11 +36,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "colibri-core_amd", "pyhost"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+XGMI_A2A_GBS = 270.0   # assumed all-to-all rate per GPU and direction for the N = 8 prediction: half of 7 links x 76.8 GB/s (153.6 GB/s bidirectional each)
 MAXLENGTH, MINTOKENS = 5, 2
+FIXTURES = os.path.join(ROOT, "tests", "golden", "fullsize")
+
+
+def make_corpus(spec):
+    """(tokens, vocab, seed, phrases) -> v2 payload bytes (worker process: numpy only)"""
+    from colibri_amd import synth
+    tokens, vocab, seed, phrases = spec
+    return synth.zipf_corpus(tokens, vocab, seed, phrases=phrases, header=False)
 
 
 def algorithmic_bytes(nbytes, npos, stats, maxlength):
-    """SURVEY.md §8(d), per order n, for the counting stage (scan + hash + table build):
+    """SURVEY.md 8(d), per order n, for the counting stage (scan + key + table build):
          scan share   B + 4*(T+S)            corpus bytes + token-start vector, read once
                     + [n>1] * W_n * 2/8      two survivor bits per window (look-back)
          build share  P_n * (8 + 4 + 4)      per admitted window: key read, count read, count write
@@ -50,9 +63,29 @@ def algorithmic_bytes(nbytes, npos, stats, maxlength):
     return scan, build
 
 
+def load_fixture(name):
+    try:
+        with open(os.path.join(FIXTURES, name + ".json")) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def check_against_reference(fixture, kept, npatterns, arrays=None):
+    """per-order kept counts, pattern total and — when the exported model is given — the multiset digest of its (key, count) rows, against what the real
+    reference left for the same corpus (tests/golden/fullsize/*.json)"""
+    from colibri_amd import digest
+    want_kept = [o["kept"] for o in fixture["orders"] if o["kind"] == "ngrams"]
+    ok = kept[:len(want_kept)] == want_kept and npatterns == fixture["npatterns"]
+    if ok and arrays is not None:
+        d = digest.model_digest(arrays[0], arrays[1], arrays[2])
+        ok = all(d[k] == fixture[k] for k in ("sum1", "xor1", "sum2", "xor2", "npatterns", "occurrences", "keybytes"))
+    return ok
+
+
 def cpu_baseline(sample_tokens, vocab):
-    """Time the reference's PatternModel<uint32_t>::train on a preloaded IndexedCorpus (src/benchmarks.cpp test 5
-    style), 1 thread (the reference is single-threaded), on a bounded sample of the bench distribution."""
+    """Time the reference's PatternModel<uint32_t>::train on a preloaded IndexedCorpus (src/benchmarks.cpp test 5 style), 1 thread (the reference is
+    single-threaded), on a bounded sample of the bench distribution; beside it the committed figure of the same reference on the FULL corpus of the timed run."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     from colibri_amd import synth
@@ -65,6 +98,12 @@ def cpu_baseline(sample_tokens, vocab):
     lens = np.diff(np.concatenate([[-1], dpos])) - 1
     windows = int(sum(np.maximum(0, lens - n + 1).sum() for n in range(1, MAXLENGTH + 1)))
     sample = f"{sample_tokens}-token Zipf(1.0,V={vocab}) corpus, seed 45, same generator as the GPU workload; train() only, corpus preloaded"
+    full = None
+    fx = load_fixture("z100m_seed44_plain")
+    if fx is not None:
+        full = {"value": round(450005710 / fx["reference_train_s"] / 1e6, 4), "unit": "M patterns counted/s", "seconds": fx["reference_train_s"], "cores": 1,
+                "host": f"build container ({fx['host']['cores']} cores), tests/golden/make_fullsize_golden.py — not this box",
+                "workload": "the timed run's own 100M-token corpus (seed 44), the real reference's train() on a preloaded IndexedCorpus"}
     if oracle.have_ref():
         with tempfile.TemporaryDirectory() as td:
             path = os.path.join(td, "sample.colibri.dat")
@@ -72,13 +111,13 @@ def cpu_baseline(sample_tokens, vocab):
                 f.write(data)
             _, info = oracle.ref_train(path, "U", MAXLENGTH, MINTOKENS)
         return {"value": round(windows / info["train_s"] / 1e6, 4), "unit": "M patterns counted/s", "cores": 1, "kind": "reference",
-                "sample": sample, "seconds": round(info["train_s"], 3), "host_cores": os.cpu_count()}
+                "sample": sample, "seconds": round(info["train_s"], 3), "host_cores": os.cpu_count(), "full_size_reference": full}
     dt, w, _ = oracle.train_timed(data[2:], MINTOKENS, MAXLENGTH)
     return {"value": round(w / dt / 1e6, 4), "unit": "M patterns counted/s", "cores": 1, "kind": "port", "sample": sample,
-            "seconds": round(dt, 3), "host_cores": os.cpu_count()}
+            "seconds": round(dt, 3), "host_cores": os.cpu_count(), "full_size_reference": full}
 
 
-def other_configs(ctx, capi, nbytes, tokens):
+def other_configs(ctx, capi, nbytes):
     """The other model kinds of BASELINE.json on the corpus that is resident: configs[3] (skipgrams: the exhaustive unindexed variant and the
     indexed one with MINSKIPTYPES = 2) and configs[4] (indexed model = forward index on the device). Untimed steps after the timed region: best of
     three train() calls each, with the kernel classes bracketed by HIP events in a fourth. Algorithmic bytes: the counting stage of the n-gram
@@ -90,7 +129,7 @@ def other_configs(ctx, capi, nbytes, tokens):
         for _ in range(3):
             st = ctx.train(maxlength=MAXLENGTH, mintokens=MINTOKENS, **kw)
             best = st.train_ms if best is None else min(best, st.train_ms)
-        stp = ctx.train(maxlength=MAXLENGTH, mintokens=MINTOKENS, profile=1, **kw)
+        ctx.train(maxlength=MAXLENGTH, mintokens=MINTOKENS, profile=1, **kw)
         kms = {capi.KERNEL_CLASSES[k]: round(ctx.kernel_time(k)[0], 3) for k in range(len(capi.KERNEL_CLASSES)) if ctx.kernel_time(k)[1]}
         dom = max(kms, key=kms.get) if kms else None
         scan_n, build_n = algorithmic_bytes(nbytes, ctx.positions(), st, MAXLENGTH)
@@ -101,17 +140,41 @@ def other_configs(ctx, capi, nbytes, tokens):
     return res
 
 
+def phrases_config(ctx, capi, payload):
+    """the same size with repeated phrases injected (orders 4 and 5 do real work), self-checked against the real reference's model of the same bytes"""
+    ctx.upload(payload)
+    best, st = None, None
+    for _ in range(4):
+        st = ctx.train(maxlength=MAXLENGTH, mintokens=MINTOKENS)
+        best = st.train_ms if best is None else min(best, st.train_ms)
+    kept = [int(st.kept[n]) for n in range(1, MAXLENGTH + 1)]
+    fx = load_fixture("z100m_seed44_phrases_plain")
+    ok = None
+    if fx is not None:
+        arrays = ctx.export_arrays()
+        ok = check_against_reference(fx, kept, int(st.npatterns), arrays)
+        del arrays
+    scan_n, build_n = algorithmic_bytes(len(payload), ctx.positions(), st, MAXLENGTH)
+    windows = sum(st.windows[1:MAXLENGTH + 1])
+    algo = sum(scan_n) + sum(build_n)
+    return {"workload": "the timed corpus' tokens and sentences with 15 % of the stream overwritten by copies of 2000 phrases of 3-8 tokens (synth.zipf_corpus(..., phrases=True))",
+            "ms_per_step": round(best, 3), "M_patterns_counted_per_s": round(windows / best / 1e3, 1), "patterns_in_model": int(st.npatterns), "kept_per_order": kept,
+            "admitted_per_order": [int(st.admitted[n]) for n in range(1, MAXLENGTH + 1)],
+            "self_check": ("ok" if ok else "FAILED") if ok is not None else "no fixture", "algorithmic_bytes_per_step": round(algo),
+            "frac_of_hbm_peak": round(algo / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}, ok
+
+
 def measured_traffic(workload_tokens, kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or None — NOT measured by this run"""
     path = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
     try:
         with open(path) as f:
             d = json.load(f)
         if int(d.get("tokens", 0)) == int(workload_tokens) and d.get("kernel") == kernel:
-            return d.get("hbm_bytes_per_launch")
+            return d.get("hbm_bytes_per_launch"), d.get("source", "profiles/pmc_dominant_kernel.json")
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def main():
@@ -122,156 +185,179 @@ def main():
     ap.add_argument("--tokens", type=int, default=0, help="tokens per GPU (default: 100M — the 100M-token config —, 125M with --gpus 8 = the 1B-token corpus of config 3)")
     ap.add_argument("--vocab", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="tokens of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the untimed steps of the other model kinds (skipgrams, indexed)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for debugging)")
-    ap.add_argument("--share-gpu", action="store_true", help="debugging: all ranks use cuda:0 (needs --backend gloo)")
-    ap.add_argument("--force-shard", action="store_true", help="debugging: run the sharded trainer even with one rank (prices the exchange machinery)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the untimed steps of the other model kinds (skipgrams, indexed) and of the phrase corpus")
+    ap.add_argument("--share-gpu", action="store_true", help="debugging: all ranks of --gpus N on device 0 (they exchange by device copies, not RCCL)")
+    ap.add_argument("--force-shard", action="store_true", help="run the multi-GPU trainer even with one rank (prices the exchange machinery)")
+    ap.add_argument("--candidates", action="store_true", help="multi-GPU runs: the candidate-exchange protocol instead of key-sharded counting (comparison)")
     args = ap.parse_args()
     if args.tokens <= 0:
         args.tokens = 125_000_000 if args.gpus == 8 else 100_000_000
 
-    import torch
-    from colibri_amd import capi, synth
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    per_process = world_env > 1  # launched by torch.distributed.run: one process per rank
+    if per_process and world_env != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} under a launcher with WORLD_SIZE={world_env}")
+    sharded = args.gpus > 1 or args.force_shard
+    nlocal = 1 if per_process else args.gpus
+
+    # ---- synthetic input: generated by worker processes (numpy) before this process touches the GPU ----------------
+    my_ranks = [rank] if per_process else list(range(args.gpus))
+    specs = [(args.tokens, args.vocab, 44 + r, False) for r in my_ranks]
+    want_phrases = not sharded and not args.no_other_configs and args.tokens == 100_000_000 and args.vocab == 1_000_000
+    if want_phrases:
+        specs.append((args.tokens, args.vocab, 44, True))
+    t0 = time.time()
+    pool = concurrent.futures.ProcessPoolExecutor(max_workers=min(len(specs), max(1, (os.cpu_count() or 2) - 1)), mp_context=multiprocessing.get_context("fork"))
+    futures = [pool.submit(make_corpus, s) for s in specs]
+    payloads = [np.frombuffer(f.result(), dtype=np.uint8) for f in futures[:len(my_ranks)]]
+    gen_s = time.time() - t0
+
+    import torch
+    from colibri_amd import capi
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU path to measure")
-    if args.share_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if sharded and not per_process and not args.share_gpu and args.gpus > ndev:
+        raise SystemExit(f"--gpus {args.gpus}: only {ndev} device(s) visible (--share-gpu puts all ranks on device 0, exchanging by device copies)")
+    if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
+        os.environ["NCCL_DEBUG"] = "NONE"  # RCCL's version banner goes to stdout through C stdio and would land beside the JSON line
     dist = None
-    if world > 1 or args.force_shard:
+    if per_process:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            # RCCL's version banner goes to stdout through C stdio and would land after the JSON line: keep stdout to that one line
-            if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
-                os.environ["NCCL_DEBUG"] = "NONE"
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world_env)  # host values only (unique id, sentence counts, timing); the data path is the trainer's own RCCL
 
-    # ---- synthetic input, resident in HBM before the timed region ---------------------------------
-    seed = 44 + rank
-    t0 = time.time()
-    payload = np.frombuffer(synth.zipf_corpus(args.tokens, args.vocab, seed, header=False), dtype=np.uint8)
-    gen_s = time.time() - t0
-    ctx = capi.Context(local_rank)
-    dev_payload = torch.from_numpy(payload.copy()).cuda()  # H2D outside the timed region
-    torch.cuda.synchronize()
-    first_sentence = 1
-    if dist is not None:  # global sentence numbers: this rank's shard starts after the sentences of the lower ranks
-        prev_low = np.concatenate([[True], payload[:-1] < 128])
-        nsent = int(((payload == 0) & prev_low).sum())
-        counts = [None] * world
-        dist.all_gather_object(counts, nsent)
-        first_sentence = 1 + sum(counts[:rank])
-    t0 = time.time()
-    ctx.upload_device(dev_payload.data_ptr(), payload.size, first_sentence)  # tokenise on device
-    tokenise_ms = (time.time() - t0) * 1e3
-    # timed steps bracket only the class of the dominant kernel with HIP events (two events per step); the full per-class breakdown
-    # comes from extra, untimed steps afterwards, so that ~110 event records per step do not sit inside the timed region
+    def sentences_of(p):
+        prev_low = np.concatenate([[True], p[:-1] < 128])
+        return int(((p == 0) & prev_low).sum())
+
     opt = capi.Options.defaults(mintokens=MINTOKENS, maxlength=MAXLENGTH, profile=2)
     opt_all = capi.Options.defaults(mintokens=MINTOKENS, maxlength=MAXLENGTH, profile=1)
-
-    if dist is not None:
-        from colibri_amd import dist as cdist
-        trainer = cdist.ShardedTrainer(capi.HipShardEngine(ctx, torch, device), dist, torch, device)
-        step = lambda o=opt: trainer.train(o)
-    else:
+    ctx = tr = None
+    t0 = time.time()
+    if not sharded:
+        torch.cuda.set_device(0)
+        ctx = capi.Context(0)
+        dev_payload = torch.from_numpy(payloads[0].copy()).cuda()  # H2D outside the timed region
+        torch.cuda.synchronize()
+        t0 = time.time()
+        ctx.upload_device(dev_payload.data_ptr(), payloads[0].size, 1)  # tokenise on device
         step = lambda o=opt: ctx.train(o)
+        ktime = ctx.kernel_time
+        npos0 = None
+    else:
+        if per_process:
+            uid = [capi.sharded_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            counts = [None] * world_env
+            dist.all_gather_object(counts, sentences_of(payloads[0]))
+            firsts = [1 + sum(counts[:rank])]
+            tr = capi.ShardedTrainer(args.gpus, nlocal=1, first_rank=rank, devices=[0 if args.share_gpu else local_rank], unique_id=uid[0])
+        else:
+            nsent = [sentences_of(p) for p in payloads]
+            firsts = [1 + sum(nsent[:r]) for r in range(args.gpus)]
+            tr = capi.ShardedTrainer(args.gpus, devices=[0] * args.gpus if args.share_gpu else None)
+        if args.candidates:
+            tr.set_protocol(1)
+        for lr, (p, first) in enumerate(zip(payloads, firsts)):
+            tr.upload(lr, p, first)
+        step = lambda o=opt: tr.train(o)
+        ktime = lambda k: tr.kernel_time(k, 0)
+    tokenise_ms = (time.time() - t0) * 1e3
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
 
     for _ in range(args.warmup):
         st = step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     kclasses = (capi.K_CLEAR, capi.K_COUNT, capi.K_PRUNE, capi.K_RESOLVE, capi.K_EMIT, capi.K_SCATTER, capi.K_BINCOUNT, capi.K_EMIT2, capi.K_LEVELB2, capi.K_COUNT2, capi.K_LISTS2)
     kms = {k: 0.0 for k in kclasses}
     kn = {k: 0 for k in kclasses}
     for _ in range(args.steps):
         st = step()
-        for k in kclasses:  # HIP events on the library's own stream, this step
-            ms, n = ctx.kernel_time(k)
+        for k in (capi.K_COUNT2, capi.K_BINCOUNT, capi.K_COUNT):  # HIP events on the library's own stream, this step (profile = 2: only the dominant kernel's class has any)
+            ms, n = ktime(k)
             kms[k] += ms
             kn[k] += n
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    barrier()
     elapsed = time.perf_counter() - t0
+    info = tr.info if tr is not None else None
     # untimed: the per-class breakdown of a step (every kernel class bracketed with events)
     EXTRA = 2
     kms_all = {k: 0.0 for k in kclasses}
     kn_all = {k: 0 for k in kclasses}
     for _ in range(EXTRA):
-        step(opt_all)
+        st_all = step(opt_all)
         for k in kclasses:
-            ms, n = ctx.kernel_time(k)
+            ms, n = ktime(k)
             kms_all[k] += ms
             kn_all[k] += n
     windows = sum(st.windows[1:MAXLENGTH + 1])
     npatterns = int(st.npatterns)
     if dist is not None:
-        where = device if args.backend == "nccl" else "cpu"
-        t = torch.tensor([elapsed, float(windows), float(npatterns)], dtype=torch.float64, device=where)
+        t = torch.tensor([elapsed, float(windows), float(npatterns)], dtype=torch.float64)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed, windows, npatterns = float(tmax[0]), float(t[1]), int(t[2])
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        tr.close()
+        dist.destroy_process_group()
+        pool.shutdown(wait=False, cancel_futures=True)
         return
 
     value = windows * args.steps / elapsed / 1e6
-    scan_n, build_n = algorithmic_bytes(payload.size, ctx.positions(), st, MAXLENGTH)
+    nbytes_all = sum(p.size for p in payloads) * (args.gpus if per_process else 1)
+    # positions = tokens + sentence delimiters of the WHOLE job (per-process launches: this rank's, times N — the shards are the same size)
+    npos_all = sum(int((p < 128).sum()) for p in payloads) * (args.gpus if per_process else 1)
+    scan_n, build_n = algorithmic_bytes(nbytes_all, npos_all, st, MAXLENGTH)
     scan_b, build_b = sum(scan_n), sum(build_n)
-    binned = kn_all[capi.K_BINCOUNT] > 0 or kn_all[capi.K_COUNT2] > 0  # (which kernels a step runs: from the fully bracketed extra steps; the timed ones bracket one class only)
-    # Which kernels ran. Global-table path: count_kernel does scan + hash + build for every order. Radix path: order 1 is the class-indexed count
-    # (class K_COUNT), order 2 the second-generation pipeline (emit2 / levelB2 / count2 / lists2: bigram2.hpp), orders >= 3 emit / scatter / bincount.
-    # The dominant kernel (largest total time in the rocprofv3 stats) is then bi2_count_kernel — one launch per step, the table build of order 2 —
-    # and its algorithmic bytes are the build share of ITS order; without it (a corpus the second generation cannot take) bin_count_kernel with the
-    # build share of orders 2..5, as in round 1.
+    binned = kn_all[capi.K_BINCOUNT] > 0 or kn_all[capi.K_COUNT2] > 0
+    # Which kernels ran. Global-table path: count_kernel does scan + key + build for every order. Radix path: order 1 is the class-indexed count (class K_COUNT),
+    # order 2 the second-generation pipeline (emit2 / levelB2 / count2 / lists2: bigram2.hpp), orders >= 3 emit / scatter / bincount. The dominant kernel (largest
+    # total time in the rocprofv3 stats) is then bi2_count_kernel — one launch per step and rank, the table build of order 2 — priced by what it PROCESSES: the
+    # 8-byte records it reads (the windows whose two classes are both < 64 are counted in the scan's LDS histogram and never reach it) and the distinct keys it
+    # writes; in a multi-GPU run rank 0's launch, which counts the keys rank 0 owns (1 / N of the job's).
     uni = binned and kn_all[capi.K_COUNT] > 0
     second = kn_all[capi.K_COUNT2] > 0
+    records = head_windows = None
+    if second and ctx is not None:
+        records, head_windows = ctx.order2_records()
     if second:
-        dom, dom_bytes = capi.K_COUNT2, build_n[1]
+        dom = capi.K_COUNT2
+        if records is not None:
+            dom_bytes = records * 16.0 + st.found[2] * 12.0
+        else:
+            dom_bytes = build_n[1] / args.gpus
     elif binned:
-        dom, dom_bytes = capi.K_BINCOUNT, (sum(build_n[1:]) if uni else build_b)
+        dom, dom_bytes = capi.K_BINCOUNT, (sum(build_n[1:]) if uni else build_b) / args.gpus
     else:
-        dom, dom_bytes = capi.K_COUNT, scan_b + build_b
+        dom, dom_bytes = capi.K_COUNT, (scan_b + build_b) / args.gpus
     launches_per_step = kn[dom] / max(1, args.steps)
     avg_launch_ms = kms[dom] / max(1, kn[dom])
     achieved = (dom_bytes / max(1.0, launches_per_step)) / (avg_launch_ms * 1e-3) / 1e9 if kn[dom] else 0.0
     stage = (capi.K_COUNT, capi.K_EMIT, capi.K_SCATTER, capi.K_BINCOUNT, capi.K_EMIT2, capi.K_LEVELB2, capi.K_COUNT2) if binned else (capi.K_COUNT,)
     stage_ms = sum(kms_all[k] for k in stage) / EXTRA
-    stage_gbs = (scan_b + build_b) / (stage_ms * 1e-3) / 1e9 if stage_ms else 0.0
+    stage_gbs = (scan_b + build_b) / args.gpus / (stage_ms * 1e-3) / 1e9 if stage_ms else 0.0
     kept = [int(st.kept[n]) for n in range(1, MAXLENGTH + 1)]
-    # ---- self-check: the model of the default corpus is known (seed 44: tests/test_gpu_fullsize.py; the reference's CPU run gives the same counts on the 1M / 10M corpora) ----
-    KNOWN = {(100_000_000, 1_000_000, 1): ([999003, 6003382, 2066683, 298710, 18788], 9386566)}
-    check = KNOWN.get((args.tokens, args.vocab, args.gpus))
+    # ---- self-check against the real reference's model of the same corpus (one shard of seed 44: N = 1, sharded or not) ----
+    fixture = load_fixture("z100m_seed44_plain") if (args.tokens, args.vocab, args.gpus) == (100_000_000, 1_000_000, 1) else None
     check_ok = None
-    if check is not None:
-        check_ok = kept == check[0] and npatterns == check[1]
-    # ---- export, reported separately ----
     export_ms = None
-    if dist is None:
-        t0 = time.perf_counter()
-        arrays = ctx.export_arrays()
+    t0 = time.perf_counter()
+    arrays = ctx.export_arrays()[:3] if ctx is not None else (tr.export_arrays(0) if (tr is not None and args.gpus == 1) else None)
+    if arrays is not None:
         export_ms = (time.perf_counter() - t0) * 1e3
-        if check is not None:
-            check_ok = check_ok and len(arrays[2]) == check[1] and int(np.asarray(arrays[2], dtype=np.uint64).sum()) > 0
-        del arrays
+    if fixture is not None:
+        check_ok = check_against_reference(fixture, kept, npatterns, arrays)
+    del arrays
+    traffic, traffic_src = measured_traffic(args.tokens, "bi2_count_kernel" if second else "bin_count_kernel" if binned else "count_kernel") if not sharded else (None, None)
     out = {
         "metric": "M patterns counted/sec at n<=5 thr=2; identical pattern set vs reference",
         "value": round(value, 3),
@@ -292,43 +378,72 @@ def main():
             "patterns_counted_per_step": int(windows),
             "patterns_in_model": npatterns,
             "kept_per_order": kept,
-            "self_check": ("ok" if check_ok else "FAILED") if check_ok is not None else "no known answer for this configuration",
+            "self_check": (("ok" if check_ok else "FAILED") + ": kept per order, pattern total and the multiset digest of (key, count) rows equal the real reference's model of this corpus "
+                           "(tests/golden/fullsize/z100m_seed44_plain.json)") if check_ok is not None else "no reference model for this configuration",
             "export_ms_untimed": round(export_ms, 2) if export_ms is not None else None,
-            "parallelism": "single device" if args.gpus == 1 else f"sentence-sharded x{args.gpus}, per-order candidate exchange over RCCL",
+            "step_excludes": "the serialised key sizes / key bytes of the model (colibri_result_sizes / colibri_export_*: export_ms_untimed), H2D upload and tokenising",
+            "parallelism": "single device" if not sharded else (
+                f"sentence-sharded x{args.gpus}, " + ("candidate exchange" if (info is not None and info.protocol == 1) else
+                                                      "key-sharded counting: all-reduce of the dense class counts (order 1), records to the owner of their key (orders >= 2)")
+                + (", RCCL" if (info is not None and info.rccl) else ", device copies between contexts") + (", one process per rank" if per_process else ", one host thread per rank")),
             "tokenise_ms_untimed": round(tokenise_ms, 3),
             "corpus_generation_s_untimed": round(gen_s, 2),
         },
         "roofline": {
-            "kernel": ("colibri::bi2_count_kernel (order 2: one wave per final bin — LDS table build, threshold, survivors, positions; one launch per step)" if second else
+            "kernel": ("colibri::bi2_count_kernel (order 2: one wave per final bin — LDS table build, threshold, survivors, positions; one launch per step and rank)" if second else
                        "colibri::bin_count_kernel (per-bin LDS hash build + threshold + survivor ids; one launch per order >= 2)" if binned else
-                       "colibri::count_kernel (scan + SpookyHash + global hash-table build; one launch per order)"),
+                       "colibri::count_kernel (scan + key + global hash-table build; one launch per order)"),
             "bound": "hbm",
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": measured_traffic(args.tokens, "bi2_count_kernel" if second else "bin_count_kernel" if binned else "count_kernel") if args.gpus == 1 else None,
+            "traffic": traffic,
+            "traffic_source": (f"NOT measured by this run: {traffic_src} (separate rocprofv3 --pmc passes of the same command, committed)" if traffic is not None else None),
             "algorithmic_bytes_per_launch": round(dom_bytes / max(1.0, launches_per_step)),
+            "records_per_launch": int(records) if records is not None else None,
+            "head_windows_not_records": int(head_windows) if head_windows is not None else None,
             "avg_launch_ms": round(avg_launch_ms, 4),
             "launches_per_step": launches_per_step,
             "counting_stage": {"kernels": [capi.KERNEL_CLASSES[k] for k in stage], "ms_per_step": round(stage_ms, 4),
-                               "algorithmic_bytes_per_step": round(scan_b + build_b), "achieved_GBps": round(stage_gbs, 2),
+                               "algorithmic_bytes_per_step": round((scan_b + build_b) / args.gpus), "achieved_GBps": round(stage_gbs, 2),
                                "frac": round(stage_gbs / HBM_PEAK_GBS, 5)},
             "kernel_ms_per_step": {capi.KERNEL_CLASSES[k]: round(kms_all[k] / EXTRA, 4) for k in kclasses if kn_all[k]},
-            "note": f"achieved / avg_launch_ms: HIP events around the dominant kernel's launches inside the {args.steps} timed steps; counting_stage and "
-                    f"kernel_ms_per_step: {EXTRA} extra untimed steps with every kernel class bracketed",
+            "note": f"achieved / avg_launch_ms: HIP events around the dominant kernel's launches inside the {args.steps} timed steps (rank 0); counting_stage and "
+                    f"kernel_ms_per_step: {EXTRA} extra untimed steps with every kernel class bracketed; per-rank figures price 1 / n_gpus of the job's algorithmic bytes",
         },
     }
-    if dist is None and not args.no_other_configs:
-        out["other_configs"] = other_configs(ctx, capi, payload.size, args.tokens)
+    if info is not None:
+        sh = {"protocol": "candidate exchange" if info.protocol == 1 else "key-sharded counting", "host_lookups_per_step": int(info.host_lookups),
+              "alltoall_bytes_per_rank_and_step": int(info.alltoall_bytes), "of_which_to_self": int(info.alltoall_bytes_to_self), "allreduce_bytes_per_rank_and_step": int(info.allreduce_bytes)}
+        if args.gpus == 1:
+            # what one rank of the 8-GPU, 1 B-token run (125 M tokens per rank) will take: this step's device work scaled by the shard size, the copies a rank makes to
+            # itself replaced by 7/8 of the bytes crossing xGMI at the assumed all-to-all rate (stated above; not measurable on a one-GPU box)
+            ms1 = elapsed / args.steps * 1e3
+            xg = 1.25 * info.alltoall_bytes * 7 / 8 / (XGMI_A2A_GBS * 1e9) * 1e3
+            sh["predicted_ms_per_rank_at_8"] = round(1.25 * ms1 + xg, 2)
+            sh["prediction"] = (f"1.25 x this step ({ms1:.2f} ms: 125 M tokens per rank) + 7/8 of 1.25 x {info.alltoall_bytes / 1e9:.2f} GB over xGMI at an assumed {XGMI_A2A_GBS:.0f} GB/s "
+                                f"per GPU and direction ({xg:.2f} ms, not overlapped)")
+        out["sharded"] = sh
+    if ctx is not None and not args.no_other_configs:
+        out["other_configs"] = other_configs(ctx, capi, payloads[0].size)
+        if want_phrases:
+            ph, ph_ok = phrases_config(ctx, capi, futures[-1].result())
+            out["other_configs"]["phrases"] = ph
+            if ph_ok is False:
+                check_ok = False
+    pool.shutdown(wait=False, cancel_futures=True)
     if args.gpus == 1 and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.vocab)
     print(json.dumps(out), flush=True)
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
+    if tr is not None:
+        tr.close()
     if dist is not None:
         dist.destroy_process_group()
     if check_ok is False:
-        sys.stderr.write("bench.py: the timed run did not produce the known model of this corpus: %r / %d patterns\n" % (kept, npatterns))
+        sys.stderr.write("bench.py: the timed run did not produce the reference's model of this corpus: %r / %d patterns\n" % (kept, npatterns))
         sys.exit(3)
 
 

@@ -199,7 +199,7 @@ struct colibri_ctx {
 
     // key-sharded multi-GPU state (kshard.hpp, kshard_api.inc)
     struct KShard {
-        bool     active = false, first_gen = false, pending_uni = false;
+        bool     active = false, first_gen = false, pending_uni = false, ran = false;  // ran: the context's trained model comes from a key-sharded run
         int      world = 1, rank = 0, n = 0, cur = 0;
         uint32_t w = 0, nclasses = 0, uni_shift = 0, clsbits = 0, posbits = 0, kbits = 0, owcap = 0, fin_total = 0, syncs = 0;
         DevBuf<KsSplitState> split;
@@ -595,6 +595,21 @@ int colibri_last_mode(const colibri_ctx* c, int* passes) {
     if (!c) return 0;
     if (passes) *passes = c->last_passes;
     return c->trained ? c->last_mode : 0;
+}
+
+// what the dominant kernel of a plain run on the second-generation order 2 processed (the 64 x 64 most frequent class pairs are counted in the scan's dense LDS
+// histogram and never become records): *records = 8-byte records bi2_count_kernel read in its (last) launch, *head_windows = admitted bigram windows counted in the head
+int colibri_order2_records(colibri_ctx* c, uint64_t* records, uint64_t* head_windows) {
+    if (!c || !records || !head_windows) return COLIBRI_ERR_ARG;
+    if (!c->trained || c->last_mode != 2 || !c->b2.state.p || c->profile_class != COLIBRI_K_COUNT2) return fail(c, COLIBRI_ERR_STATE, "the last run did not count order 2 on the second-generation kernels");
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t nrec = 0;
+    // (a key-sharded run: the records this rank counted as an OWNER; the head is global there and reported as 0)
+    Bi2State* const bs = c->ks.ran ? c->ks.obs.p : c->b2.state.p;
+    HIP_TRY(c, hipMemcpy(&nrec, &bs->nrec, sizeof nrec, hipMemcpyDeviceToHost));
+    *records      = nrec;
+    *head_windows = (!c->ks.ran && c->stats.admitted[2] >= nrec) ? c->stats.admitted[2] - nrec : 0;
+    return COLIBRI_OK;
 }
 
 int colibri_positions(const colibri_ctx* c, uint64_t* npositions) {
@@ -1443,6 +1458,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     HIP_TRY(c, hipSetDevice(c->device));
     c->opt     = o;
     c->trained = false;
+    c->ks.ran  = false;
     c->profile = o.profile;
     collect_events(c);
     std::fill(std::begin(c->k_ms), std::end(c->k_ms), 0.0);

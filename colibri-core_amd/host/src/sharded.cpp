@@ -166,6 +166,7 @@ class RankDriver {
     DevMem       rkeys, rcnts, raux, rgid, rtot, gid, tot, ucnt, umr, gather_dev;
     uint64_t     gid_total = 0;
     uint64_t*    gather_host = nullptr;  // pinned: host values of the process back end's all-gather
+    uint64_t     bytes_a2a = 0, bytes_self = 0, bytes_reduce = 0;  // what this rank put into all-to-alls (of which to itself) and all-reduces in the running train()
 
     void chk(int rc, const char* what) {
         if (rc != COLIBRI_OK) throw std::runtime_error(std::string(what) + ": " + (c ? colibri_last_error(c) : "no context") + " (status " + std::to_string(rc) + ")");
@@ -198,6 +199,12 @@ class RankDriver {
     // a group of all-to-alls and all-reduces. RCCL: enqueued on `s` (one ncclGroup: all seven xGMI links of a GPU at once), nothing waits unless `sync`.
     // Copies (ranks sharing a device): the sources must be complete (every caller has waited for its stream), the copies are waited for, then a barrier.
     void exchange(const std::vector<A2A>& a2a, const std::vector<Reduce>& reds, hipStream_t s, bool sync) {
+        for (const A2A& op : a2a)
+            for (int p = 0; p < world; ++p) {
+                bytes_a2a += (*op.send_n)[(size_t)p] * op.elem;
+                if (p == rank) bytes_self += (*op.send_n)[(size_t)p] * op.elem;
+            }
+        for (const Reduce& r : reds) bytes_reduce += r.n * sizeof(uint32_t);
         if (sh.use_rccl) {
             if (!a2a.empty()) {
                 NCCLCHK(ncclGroupStart());
@@ -554,6 +561,7 @@ class RankDriver {
         trained     = false;
         has_gids    = false;
         last_syncs  = 0;
+        bytes_a2a = bytes_self = bytes_reduce = 0;
         took_kshard = false;
         if (!force_candidates) {
             try {
@@ -572,6 +580,8 @@ class RankDriver {
         HIPCHK(hipSetDevice(dev));
         chk(colibri_result_sizes(c, np, kb, nr), "colibri_result_sizes");
     }
+    void traffic(uint64_t* a2a, uint64_t* self, uint64_t* reduce) const { *a2a = bytes_a2a, *self = bytes_self, *reduce = bytes_reduce; }
+    void kernel_time(int cls, double* ms, uint64_t* launches) { chk(colibri_kernel_time(c, cls, ms, launches), "colibri_kernel_time"); }
     void export_unindexed(uint64_t* key_off, uint8_t* key_bytes, uint32_t* counts) {
         HIPCHK(hipSetDevice(dev));
         chk(colibri_export_unindexed(c, key_off, key_bytes, counts), "colibri_export_unindexed");
@@ -922,6 +932,7 @@ int colibri_sharded_train(colibri_sharded* t, const colibri_options* opt, colibr
         info->rccl         = t->tr.sh.use_rccl ? 1 : 0;
         info->host_lookups = r0.last_syncs;
         info->wall_ms      = t->tr.last_ms;
+        r0.traffic(&info->alltoall_bytes, &info->alltoall_bytes_to_self, &info->allreduce_bytes);
     }
     return COLIBRI_OK;
 }
@@ -933,6 +944,16 @@ int colibri_sharded_result_sizes(colibri_sharded* t, int local_rank, uint64_t* n
     } catch (const std::exception& e) {
         t->err = e.what();
         return COLIBRI_ERR_HIP;
+    }
+    return COLIBRI_OK;
+}
+int colibri_sharded_kernel_time(colibri_sharded* t, int local_rank, int kernel_class, double* total_ms, uint64_t* launches) {
+    if (!t || local_rank < 0 || local_rank >= (int)t->tr.ranks.size()) return COLIBRI_ERR_ARG;
+    try {
+        t->tr.ranks[(size_t)local_rank]->kernel_time(kernel_class, total_ms, launches);
+    } catch (const std::exception& e) {
+        t->err = e.what();
+        return COLIBRI_ERR_ARG;
     }
     return COLIBRI_OK;
 }

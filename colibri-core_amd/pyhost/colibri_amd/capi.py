@@ -23,7 +23,7 @@ EXPORTED = [
     "colibri_shard_begin", "colibri_shard_count", "colibri_shard_send", "colibri_shard_send_view", "colibri_shard_merge", "colibri_shard_reply", "colibri_shard_apply",
     "colibri_shard_finish", "colibri_shard_export_gids", "colibri_shard_index_sizes", "colibri_shard_export_index",
     "colibri_shard_uni_info", "colibri_shard_uni_count", "colibri_shard_uni_apply",
-    "colibri_stream", "colibri_kshard_info", "colibri_kshard_begin", "colibri_kshard_uni_count", "colibri_kshard_uni_apply", "colibri_kshard_emit", "colibri_kshard_recv_buffers",
+    "colibri_order2_records", "colibri_stream", "colibri_kshard_info", "colibri_kshard_begin", "colibri_kshard_uni_count", "colibri_kshard_uni_apply", "colibri_kshard_emit", "colibri_kshard_recv_buffers",
     "colibri_kshard_count", "colibri_kshard_feedback_buffers", "colibri_kshard_apply", "colibri_kshard_local_stats", "colibri_kshard_finish",
     "colibri_set_constraint", "colibri_set_continuation", "colibri_set_filter", "colibri_text_upload", "colibri_text_count", "colibri_text_words", "colibri_text_encode", "colibri_text_fetch", "colibri_text_as_corpus",
     "colibri_flexgrams", "colibri_flexgrams_resident", "colibri_flexgrams_fetch",
@@ -60,12 +60,13 @@ class Stats(C.Structure):
 SHARDED_LIB_PATH = os.path.join(PKG_ROOT, "lib", "libcolibri_sharded.so")
 SHARDED_EXPORTED = [
     "colibri_sharded_unique_id", "colibri_sharded_create", "colibri_sharded_destroy", "colibri_sharded_last_error", "colibri_sharded_upload", "colibri_sharded_upload_split",
-    "colibri_sharded_set_protocol", "colibri_sharded_train", "colibri_sharded_result_sizes", "colibri_sharded_export_unindexed",
+    "colibri_sharded_set_protocol", "colibri_sharded_train", "colibri_sharded_kernel_time", "colibri_sharded_result_sizes", "colibri_sharded_export_unindexed",
 ]
 
 
 class ShardedInfo(C.Structure):
-    _fields_ = [("protocol", C.c_int32), ("rccl", C.c_int32), ("host_lookups", C.c_uint32), ("pad", C.c_uint32), ("wall_ms", C.c_double)]
+    _fields_ = [("protocol", C.c_int32), ("rccl", C.c_int32), ("host_lookups", C.c_uint32), ("pad", C.c_uint32), ("wall_ms", C.c_double),
+                ("alltoall_bytes", C.c_uint64), ("alltoall_bytes_to_self", C.c_uint64), ("allreduce_bytes", C.c_uint64)]
 
 
 class ColibriError(RuntimeError):
@@ -114,6 +115,7 @@ def load():
         L.colibri_last_mode.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.colibri_hash_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.colibri_kernel_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.colibri_order2_records.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.colibri_shard_begin.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int]
         L.colibri_shard_count.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.c_void_p]
         L.colibri_shard_send.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -311,6 +313,12 @@ class Context:
         self._check(self.L.colibri_kernel_time(self.h, cls, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def order2_records(self):
+        """(records bi2_count_kernel read, admitted bigram windows counted in the dense head instead) of the last plain run"""
+        rec, head = C.c_uint64(), C.c_uint64()
+        self._check(self.L.colibri_order2_records(self.h, C.byref(rec), C.byref(head)))
+        return rec.value, head.value
+
 
 class HipShardEngine:
     """Per-rank engine of the sentence-sharded trainer (colibri_amd.dist.ShardedTrainer): thin marshalling over the
@@ -469,6 +477,7 @@ def load_sharded():
         S.colibri_sharded_upload_split.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
         S.colibri_sharded_set_protocol.argtypes = [C.c_void_p, C.c_int]
         S.colibri_sharded_train.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Stats), C.POINTER(ShardedInfo)]
+        S.colibri_sharded_kernel_time.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         S.colibri_sharded_result_sizes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         S.colibri_sharded_export_unindexed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _shlib = S
@@ -528,12 +537,17 @@ class ShardedTrainer:
         """0: key-sharded counting where the run allows it (default); 1: always the candidate exchange"""
         self._check(self.S.colibri_sharded_set_protocol(self.h, protocol))
 
-    def train(self, **kw):
-        opt = Options.defaults(**kw)
+    def train(self, opt=None, **kw):
+        opt = opt if opt is not None else Options.defaults(**kw)
         st, info = Stats(), ShardedInfo()
         self._check(self.S.colibri_sharded_train(self.h, C.byref(opt), C.byref(st), C.byref(info)))
         self.stats, self.info = st, info
         return st
+
+    def kernel_time(self, cls, local_rank=0):
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self.S.colibri_sharded_kernel_time(self.h, local_rank, cls, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def export_arrays(self, local_rank):
         npat, kb = C.c_uint64(), C.c_uint64()

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define COLIBRI_ABI_VERSION 1
+#define COLIBRI_ABI_VERSION 2 /* 2: colibri_train leaves stats.keybytes at 0 (colibri_result_sizes computes it), kernel classes 11..14, colibri_kshard_*, colibri_stream */
 #define COLIBRI_MAX_ORDER 128 /* per-order statistics are kept for n < 128; MAXLENGTH defaults to 100 in the reference */
 
 enum {
@@ -228,6 +228,10 @@ int colibri_positions(const colibri_ctx* ctx, uint64_t* npositions);
  * the corpus and colibri_options.table_mode, and an overflow of the radix path repeats the run on the table): 1 = global open-addressed table,
  * 2 = radix partition + LDS count, 0 = neither (pattern list, or nothing trained). *passes (optional) = passes over key slices the order-2 stage used. */
 int colibri_last_mode(const colibri_ctx* ctx, int* passes);
+/* What the dominant kernel of the last plain run processed at order 2 (second-generation kernels, colibri_last_mode = 2): *records = the 8-byte records
+ * bi2_count_kernel read (in a key-sharded run: the records this rank counted as an owner); *head_windows = the admitted bigram windows whose two classes are both
+ * < 64 — counted in the scan's dense LDS histogram, never records (0 in a key-sharded run). bench.py prices the kernel by these. */
+int colibri_order2_records(colibri_ctx* ctx, uint64_t* records, uint64_t* head_windows);
 /* SpookyHash::Hash64 of nkeys independent byte strings (off[nkeys+1] into bytes) on the device */
 int colibri_hash_keys(colibri_ctx* ctx, const uint8_t* bytes, const uint64_t* off, uint64_t nkeys, uint64_t* out_host);
 /* accumulated HIP-event time and launch count of one kernel class since the last colibri_train() began

@@ -31,6 +31,9 @@ typedef struct colibri_sharded_info {
     uint32_t host_lookups;  /* times a rank's host waited for its device during the run (key-sharded protocol: two per order + two)        */
     uint32_t pad;
     double   wall_ms;       /* host clock around the whole collective call                                                                */
+    uint64_t alltoall_bytes;         /* bytes the first local rank put into all-to-alls during the run (records, tables, feedback, exports) ...     */
+    uint64_t alltoall_bytes_to_self; /* ... of which addressed to itself (never leave the device)                                                  */
+    uint64_t allreduce_bytes;        /* bytes it put into all-reduces (dense class counts, dense head)                                             */
 } colibri_sharded_info;
 
 int         colibri_sharded_unique_id(void* out128);
@@ -45,6 +48,8 @@ int colibri_sharded_upload_split(colibri_sharded* t, const uint8_t* payload, uin
 int colibri_sharded_set_protocol(colibri_sharded* t, int protocol);
 /* stats: found / kept / admitted / tokens / types are the model's (global); npatterns, nsentences, windows are summed over this trainer's local ranks */
 int colibri_sharded_train(colibri_sharded* t, const colibri_options* opt, colibri_stats* stats, colibri_sharded_info* info);
+/* colibri_kernel_time of one local rank's context (options.profile = 1 or 2 in the last colibri_sharded_train) */
+int colibri_sharded_kernel_time(colibri_sharded* t, int local_rank, int kernel_class, double* total_ms, uint64_t* launches);
 int colibri_sharded_result_sizes(colibri_sharded* t, int local_rank, uint64_t* npatterns, uint64_t* keybytes);
 int colibri_sharded_export_unindexed(colibri_sharded* t, int local_rank, uint64_t* key_off, uint8_t* key_bytes, uint32_t* counts);
 

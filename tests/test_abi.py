@@ -27,7 +27,19 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/colibri_hip.h but not exported"
     assert sorted(capi.EXPORTED) == names
-    assert L.colibri_abi_version() == 1
+    assert L.colibri_abi_version() == 2
+
+
+def test_sharded_library_exports_every_declared_symbol():
+    """include/colibri_sharded.h: the multi-GPU trainer's C face (lib/libcolibri_sharded.so: host code over the C ABI, RCCL linked directly)"""
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "colibri_sharded.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(colibri_sharded_[a-z_0-9]+)\s*\(", text)))
+    S = capi.load_sharded()
+    for n in names:
+        assert hasattr(S, n), f"{n} declared in include/colibri_sharded.h but not exported"
+    assert sorted(capi.SHARDED_EXPORTED) == names
+    assert C.sizeof(capi.ShardedInfo) == 48
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "include", "colibri_sharded.h")])
 
 
 def test_struct_layouts_match_the_header(tmp_path):

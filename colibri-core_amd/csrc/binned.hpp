@@ -447,8 +447,9 @@ constexpr int kBinRegPer = 8;  // records per lane held in registers: bins of up
 // scanned — with kExportBitR on the lowest-numbered candidate of the key (the lowest contributing rank), whose cnt_at entry
 // also receives the summed count.
 constexpr uint32_t kExportBitR = 0x80000000u;
-// REPLY = the owner side of a key-sharded pass (kshard.hpp): `ids_at` is indexed by the record's place j in `recs` (not by its item), and the survivor id carries
-// the owner's rank tag `idtag` above the sparse index — ks_route_* sends (item, id) back to the record's source, whose ids_at then looks as after a local count
+// REPLY = the owner side of a key-sharded pass (kshard.hpp): `ids_at` is an array of 64-bit replies indexed by the record's place j in `recs` (pre-filled with
+// all-ones = "the key did not survive"): (the record's tagged item | survivor id << 32), the id carrying the owner's rank tag `idtag` above the sparse index —
+// ks_route_* sends (item, id) back to the record's source, whose ids_at then looks as after a local count
 template <bool MERGE, bool REPLY = false>
 __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t begin, const uint32_t end, const Rec* __restrict__ recs, DevState* __restrict__ st,
                                               BinState* __restrict__ bs, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
@@ -551,7 +552,7 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
             const uint32_t id = idT[s];
             if (id != kInvalid) {
                 if (REPLY)
-                    ids_at[j] = id;
+                    reinterpret_cast<unsigned long long*>(ids_at)[j] = (unsigned long long)xr[q].pos | ((unsigned long long)id << 32);
                 else if (!MERGE && flags_at != nullptr)
                     flags_at[xr[q].pos] = 1;  // flag mode: the next order builds its keys without this order's ids (KeyTrigramCls)
                 else
@@ -566,7 +567,7 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
         const uint32_t id = idT[s];
         if (id != kInvalid) {
             if (REPLY)
-                ids_at[j] = id;
+                reinterpret_cast<unsigned long long*>(ids_at)[j] = (unsigned long long)x.pos | ((unsigned long long)id << 32);
             else if (!MERGE && flags_at != nullptr)
                 flags_at[x.pos] = 1;
             else
@@ -602,10 +603,10 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict
                                                             uint32_t* __restrict__ ids_at, uint8_t* __restrict__ flags_at = nullptr, bool dense_code = false) {
     bin_count_body<false>(recs, st, bs, threshold, sp_rep, sp_cnt, sp_key, ids_at, nullptr, nullptr, flags_at, dense_code);
 }
-// owner side of a key-sharded pass (kshard.hpp): reply_at[j] = global survivor id of record j's key (pre-filled with kInvalid by the caller)
+// owner side of a key-sharded pass (kshard.hpp): reply[j] = (tagged item | global survivor id << 32) of record j if its key survived (pre-filled with all-ones)
 __global__ __launch_bounds__(kBlock) void bin_count_reply_kernel(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
-                                                                  uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt, uint32_t* __restrict__ reply_at, uint32_t idtag) {
-    bin_count_body<false, true>(recs, st, bs, threshold, sp_rep, sp_cnt, nullptr, reply_at, nullptr, nullptr, nullptr, false, idtag);
+                                                                  uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt, unsigned long long* __restrict__ reply, uint32_t idtag) {
+    bin_count_body<false, true>(recs, st, bs, threshold, sp_rep, sp_cnt, nullptr, reinterpret_cast<uint32_t*>(reply), nullptr, nullptr, nullptr, false, idtag);
 }
 // owner-side merge of a sharded n-gram pass (see bin_count_one<MERGE>)
 __global__ __launch_bounds__(kBlock) void bin_merge_count_kernel(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,

@@ -178,17 +178,19 @@ __global__ __launch_bounds__(kKsThreads) void ks_split_scan_kernel(KsSplitState*
     __shared__ uint32_t wsumL[kKsThreads / kWave];
     const uint32_t      e0 = threadIdx.x * 16, nent = world * (uint32_t)(kBins * kKsWorld);
     uint32_t            v[16], idx[16], s = 0;
+    // (all sixteen loads of a lane are issued before the first is used: no branch between them — entries beyond the run's ranks read slot 0 and count as zero)
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const uint32_t e = e0 + k;
-        v[k]             = 0;
-        idx[k]           = 0;
-        if (e < nent) {
-            const uint32_t dap = e >> 3, sub = e & 7u, d = dap >> 8, ap = dap & 255u, a = ap >> w, c = ap & ((1u << w) - 1u);
-            const uint32_t A = (d << (8 - w)) | a;  // the sender's A bin: owner bits on top
-            idx[k]           = (sub * kBins + A) * kKsWorld + c;
-            v[k]             = ss->hcnt[idx[k]];
-        }
+        const uint32_t e = min(e0 + k, nent - 1);
+        const uint32_t dap = e >> 3, sub = e & 7u, d = dap >> 8, ap = dap & 255u, a = ap >> w, c = ap & ((1u << w) - 1u);
+        const uint32_t A = (d << (8 - w)) | a;  // the sender's A bin: owner bits on top
+        idx[k]           = (sub * kBins + A) * kKsWorld + c;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = ss->hcnt[idx[k]];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (e0 + k >= nent) v[k] = 0;
         s += v[k];
     }
     uint32_t       total;
@@ -400,24 +402,23 @@ struct KsRouteWaveLists {
         return true;
     }
 };
-// orders >= 3: the records of surviving keys (reply_at[j] = the key's global survivor id, kInvalid otherwise; j = the record's place after level B)
-// -> (item index | id << 32), to the record's source
+// orders >= 3: the records of surviving keys (reply[j] = tagged item | the key's global survivor id << 32, all-ones otherwise; j = the record's place after
+// level B) -> (item index | id << 32), to the record's source
 struct KsRouteReplies {
-    const Rec*      recs;
-    const uint32_t* reply_at;
-    const uint32_t* n_dev;
-    uint32_t        len, tagshift;  // tagshift = 32 - w (32: one rank, no tag)
+    const unsigned long long* reply;
+    const uint32_t*           n_dev;
+    uint32_t                  len, tagshift;  // tagshift = 32 - w (32: one rank, no tag)
     typedef unsigned long long Out;
     __device__ __forceinline__ uint32_t count(uint32_t l) const {
         const uint32_t n = *n_dev, b = l * len;
         return b < n ? min(len, n - b) : 0u;
     }
     __device__ __forceinline__ bool get(uint32_t l, uint32_t j, uint32_t& dst, Out& out) const {
-        const uint32_t at = l * len + j, id = reply_at[at];
-        if (id == kInvalid) return false;
-        const uint32_t p = recs[at].pos;
+        const unsigned long long e = reply[l * len + j];
+        if (e == ~0ull) return false;
+        const uint32_t p = (uint32_t)e;
         dst              = tagshift < 32 ? p >> tagshift : 0u;
-        out              = (unsigned long long)(tagshift < 32 ? p & ((1u << tagshift) - 1u) : p) | ((unsigned long long)id << 32);
+        out              = tagshift < 32 ? (e & ~((unsigned long long)(~0u << tagshift) & 0xFFFFFFFFull)) : e;
         return true;
     }
 };

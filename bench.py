@@ -196,7 +196,7 @@ def main():
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    per_process = world_env > 1  # launched by torch.distributed.run: one process per rank
+    per_process = world_env > 1 or (os.environ.get("COLIBRI_BENCH_PER_PROCESS") == "1" and "RANK" in os.environ)  # launched by torch.distributed.run: one process per rank
     if per_process and world_env != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} under a launcher with WORLD_SIZE={world_env}")
     sharded = args.gpus > 1 or args.force_shard

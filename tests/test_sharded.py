@@ -45,6 +45,28 @@ def test_exchange_protocol_gloo_cpu(tmp_path, world, corpus, maxlength):
     run_workers(tmp_path, world, "numpy", corpus, maxlength)
 
 
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("corpus,maxlength,thr", [("rand_noempty", 5, 2), ("zipf20k", 5, 2), ("short_sentences", 4, 2), ("repeat", 9, 3), ("one_token", 3, 2), ("empty", 3, 2), ("zipf20k", 3, 1)])
+def test_key_sharded_protocol_gloo_cpu(tmp_path, world, corpus, maxlength, thr):
+    """the protocol host/src/sharded.cpp drives through colibri_kshard_* (records to the owner of their key; survivors' positions and the exports back; the
+    dense class counts all-reduced), on a numpy stand-in over gloo: the union of the ranks' exports is the oracle's model of the whole corpus"""
+    import oracle
+    out = str(tmp_path / "k.pkl")
+    _port[0] += 1
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(_port[0]),
+           os.path.join(ROOT, "tests", "kshard_worker.py"), corpus, str(maxlength), str(thr), out]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    res = pickle.load(open(out, "rb"))
+    want = oracle.train(res["payload"], thr, maxlength)
+    assert res["dup"] == 0, "a pattern was exported by two ranks"
+    assert res["union"] == want.counts
+    assert res["maxn"] == want.maxn
+    for n in range(1, want.maxn + 1):
+        assert (res["stats"][n][0], res["stats"][n][1]) == (want.stats[n][0], want.stats[n][2]), n
+
+
 def test_a_failing_rank_is_reported_on_every_rank(tmp_path):
     """A rank whose local count raises (e.g. a radix bin outgrown under table_mode = 2) must not leave the others blocked in the next all-to-all: the failure
     travels with the size exchange and every rank raises ('nothing in dist.py shares error status across ranks')."""
@@ -139,19 +161,58 @@ def test_hip_shard_engine_over_rccl(tmp_path, mode):
     run_workers(tmp_path, 1, "hip", "zipf", 5, mode, backend="nccl")
 
 
-@pytest.mark.gpu
-def test_bench_sharded_path_over_rccl_matches_oracle(tmp_path):
-    """bench.py --force-shard --backend nccl: the sharded trainer exactly as the driver's multi-GPU run uses it, one rank; its model against the oracle."""
+def _bench(args, env_extra=None, launcher=None):
     import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **(env_extra or {}))
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args + ["--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--no-other-configs"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_of_the_multi_gpu_trainer_over_rccl_matches_oracle():
+    """bench.py --force-shard: the product's multi-GPU trainer (host/src/sharded.cpp: key-sharded counting, RCCL linked directly) with one rank — every
+    exchange still runs through RCCL (send / recv to itself, the all-reduces); its model against the oracle."""
     import oracle
     from colibri_amd import synth
     tokens, vocab = 2_000_000, 1_000_000
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port[0] + 500))
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-shard", "--backend", "nccl", "--tokens", str(tokens), "--vocab", str(vocab), "--steps", "2", "--warmup", "1",
-                        "--cpu-sample", "0"], capture_output=True, text=True, env=env, timeout=900)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
-    got = json.loads(line)
+    got = _bench(["--force-shard", "--tokens", str(tokens), "--vocab", str(vocab)])
     want = oracle.train(synth.zipf_corpus(tokens, vocab, 44, header=False), 2, 5)
     assert got["config"]["kept_per_order"] == [want.stats[n][2] for n in range(1, 6)]
     assert got["config"]["patterns_in_model"] == len(want.counts)
+    assert got["sharded"]["protocol"] == "key-sharded counting" and ", RCCL" in got["config"]["parallelism"]
+    assert got["sharded"]["host_lookups_per_step"] <= 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [2, 4])
+def test_bench_gpus_n_started_like_the_single_gpu_command(gpus):
+    """`python bench.py --gpus N` with no launcher (it used to exit at once): the N ranks are host threads of the one process. Here all ranks share
+    device 0 (--share-gpu: they exchange by device copies; with N devices the same command runs RCCL over xGMI). rc 0 and the model of the N shards (seeds
+    44 .. 44 + N - 1, concatenated in rank order) must be the oracle's."""
+    import oracle
+    from colibri_amd import synth
+    tokens, vocab = 1_000_000, 200_000
+    got = _bench(["--gpus", str(gpus), "--share-gpu", "--tokens", str(tokens), "--vocab", str(vocab)])
+    whole = b"".join(synth.zipf_corpus(tokens, vocab, 44 + r, header=False) for r in range(gpus))
+    want = oracle.train(whole, 2, 5)
+    assert got["n_gpus"] == gpus and got["config"]["kept_per_order"] == [want.stats[n][2] for n in range(1, 6)]
+    assert got["config"]["patterns_in_model"] == len(want.counts)
+    assert got["config"]["patterns_counted_per_step"] == want.windows  # the windows of all N shards: what the reference enumerates in line.ngrams()
+    assert got["sharded"]["protocol"] == "key-sharded counting"
+
+
+@pytest.mark.gpu
+def test_bench_one_process_per_rank_path(tmp_path):
+    """the driver's multi-GPU launch (torch.distributed.run, one process per rank): ncclCommInitRank from an id rank 0 hands out, host values through RCCL
+    all-gathers. One device here, hence one rank — COLIBRI_BENCH_PER_PROCESS makes bench.py take that path for it."""
+    import oracle
+    from colibri_amd import synth
+    tokens, vocab = 1_000_000, 200_000
+    _port[0] += 1
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(_port[0])]
+    got = _bench(["--gpus", "1", "--force-shard", "--tokens", str(tokens), "--vocab", str(vocab)], env_extra={"COLIBRI_BENCH_PER_PROCESS": "1"}, launcher=launcher)
+    want = oracle.train(synth.zipf_corpus(tokens, vocab, 44, header=False), 2, 5)
+    assert got["config"]["kept_per_order"] == [want.stats[n][2] for n in range(1, 6)] and got["config"]["patterns_in_model"] == len(want.counts)
+    assert "one process per rank" in got["config"]["parallelism"]

@@ -212,6 +212,9 @@ struct colibri_ctx {
         DevBuf<uint32_t>     osp_rep, osp_cnt, ores_rep, ores_cnt;  // owner: sparse per-bin survivors, dense survivors of the order
         DevBuf<uint32_t>     fin_rep, fin_cnt;                      // this rank's share of the model
         DevBuf<unsigned char> sbuf, rbuf[2], fbs, exs, fbr, exr;    // records out / in (+ level-B output); feedback and exports out / in
+        hipStream_t side = nullptr;   // the host's early looks at exchange sizes (kshard_api.inc: ks_peek_*)
+        hipEvent_t  ev = nullptr;
+        uint32_t*   pinned = nullptr;
     } ks;
 
     // profiling
@@ -561,6 +564,9 @@ void colibri_destroy(colibri_ctx* c) {
         dev_free(k.oboff); dev_free(k.owcnt); dev_free(k.owlist); dev_free(k.lcnt); dev_free(k.loff); dev_free(k.reply_at); dev_free(k.osp_rep); dev_free(k.osp_cnt); dev_free(k.ores_rep);
         dev_free(k.ores_cnt); dev_free(k.fin_rep); dev_free(k.fin_cnt); dev_free(k.sbuf); dev_free(k.rbuf[0]); dev_free(k.rbuf[1]); dev_free(k.fbs); dev_free(k.exs); dev_free(k.fbr);
         dev_free(k.exr);
+        if (k.side) (void)hipStreamDestroy(k.side);
+        if (k.ev) (void)hipEventDestroy(k.ev);
+        if (k.pinned) (void)hipHostFree(k.pinned);
     }
     dev_free(c->table);
     dev_free(c->res_rep);

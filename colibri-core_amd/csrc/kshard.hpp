@@ -546,6 +546,9 @@ __global__ __launch_bounds__(kBlock) void ks_append_exports_kernel(const unsigne
 struct KsStats {
     uint32_t found[COLIBRI_MAX_ORDER], kept[COLIBRI_MAX_ORDER], admitted[COLIBRI_MAX_ORDER];
 };
+__global__ void ks_idcheck_kernel(DevState* __restrict__ ost, uint32_t idlimit) {
+    if (ost->id_base >= idlimit) ost->radix_overflow = 3;
+}
 __global__ void ks_order_end_kernel(DevState* __restrict__ ost, DevState* __restrict__ st, KsStats* __restrict__ ks, int n, uint32_t idlimit) {
     if (n < COLIBRI_MAX_ORDER) {
         ks->found[n]    = ost->found;

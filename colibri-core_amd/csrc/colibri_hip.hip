@@ -86,6 +86,7 @@ struct colibri_ctx {
     uint64_t          npairs = 0;
     DevBuf<unsigned long long> pair_chain;  // the pair counters (kernels.hpp: emit_write_kernel)
     int               pair_pass = 0;
+    uint32_t          pair_sb = 0, pair_tb = 0;  // packed pairs (id << (sb + tb) | sentence << tb | token): bits of the sentence / token fields; 0 / 0: id << 32 | position
     DevBuf<uint32_t>  ref_sentence;
     DevBuf<uint16_t>  ref_token;
     DevBuf<Slot>      table;
@@ -1205,6 +1206,31 @@ int pairs_begin(colibri_ctx* c, uint32_t npos) {
     c->pair_pass = 0;
     c->npairs    = 0;
     if (c->pairs[0].n < 2ull * npos && (rc = dev_alloc(c, c->pairs[0], (size_t)(2ull * npos) + 1))) return rc;  // the usual model: ~1.6 pairs per position at n <= 5
+    // position -> (sentence, token) table of the corpus (once per upload)
+    if (!c->pos_blocks_valid) {
+        if ((rc = dev_alloc(c, c->pos_blocks, (size_t)c->npos / 64 + 2))) return rc;
+        Prof p(c, COLIBRI_K_INDEX);
+        hipLaunchKernelGGL(position_blocks_kernel, dim3(stream_grid((uint64_t)c->npos / 16 + 1)), dim3(kBlock), 0, c->stream, c->cls.p, c->delimpos.p, c->ndelim, c->npos, c->pos_blocks.p);
+        c->pos_blocks_valid = true;
+    }
+    // packed pairs: a 31-bit id, the sentence (counted from the shard's first) and the token offset (u16 in the reference, datatypes.h:36) in one word —
+    // possible whenever sentence count and longest sentence leave the room, i.e. always in practice; else id << 32 | position and the look-up after the sort
+    uint64_t longest = 0;
+    for (size_t len = c->lenhist.size(); len-- > 0;)
+        if (c->lenhist[len]) {
+            longest = len;
+            break;
+        }
+    uint32_t sb = 1, tb = 1;
+    while ((1ull << sb) < (uint64_t)c->nsent + 2) ++sb;
+    while (tb < 16 && (1ull << tb) < longest + 1) ++tb;
+    if (longest >= 65536) tb = 16;
+    if (sb + tb <= 33 && !getenv("COLIBRI_UNPACKED_PAIRS")) {
+        c->pair_sb = sb;
+        c->pair_tb = tb;
+    } else {
+        c->pair_sb = c->pair_tb = 0;
+    }
     return COLIBRI_OK;
 }
 // pairs so far; *overflowed: the buffer was too small for them
@@ -1229,7 +1255,9 @@ int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool en
             hipLaunchKernelGGL(emit_count_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, pl.npos, cnt);
             hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, cnt, ntiles, cnt + ntiles);
             hipLaunchKernelGGL(pairs_advance_kernel, dim3(1), dim3(1), 0, c->stream, c->pair_chain.p, c->pair_pass, cnt + ntiles, cap);
-            hipLaunchKernelGGL(emit_write_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, pl.npos, cnt, c->pair_chain.p, c->pair_pass, cap, c->pairs[0].p);
+            const bool packed = c->pair_sb != 0;
+            hipLaunchKernelGGL(emit_write_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, pl.npos, cnt, c->pair_chain.p, c->pair_pass, cap, c->pairs[0].p,
+                               packed ? (const PosBlock*)c->pos_blocks.p : (const PosBlock*)nullptr, c->pair_sb, c->pair_tb);
         }
         c->pair_pass ^= 1;
         if (!ensure) return COLIBRI_OK;
@@ -1313,26 +1341,23 @@ int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = fal
         const uint32_t nblocks = (uint32_t)((n + kS64Tile - 1) / kS64Tile);
         const uint32_t nh = 256u * nblocks, nb = blocks_for(nh, kBlock * 4);
         if ((rc = dev_alloc(c, c->sort_hist, nh)) || (rc = dev_alloc(c, c->sort_off, nh)) || (rc = dev_alloc(c, c->sort_bsum, (size_t)nb + 1))) return rc;
-        if (!c->pos_blocks_valid) {
-            if ((rc = dev_alloc(c, c->pos_blocks, (size_t)c->npos / 64 + 2))) return rc;
-            hipLaunchKernelGGL(position_blocks_kernel, dim3(stream_grid((uint64_t)c->npos / 16 + 1)), dim3(kBlock), 0, c->stream, c->cls.p, c->delimpos.p, c->ndelim, c->npos, c->pos_blocks.p);
-            c->pos_blocks_valid = true;
-        }
         if (keep_sorted_ids && (rc = dev_alloc(c, c->sh.sorted_gid, (size_t)n))) return rc;  // sharded mode: the caller still needs the (sorted) global ids to cut the references into runs
-        const int nbits = bits_for(nresults);
+        const int  nbits  = bits_for(nresults);
+        const bool packed = c->pair_sb != 0;
+        const int  idshift = packed ? (int)(c->pair_sb + c->pair_tb) : 32;
         for (int shift = 0; shift < nbits; shift += 8) {
             const bool last = shift + 8 >= nbits;  // the last pass writes (sentence, token) [and the ids] instead of pairs
-            hipLaunchKernelGGL(sort64_hist_kernel, dim3(nblocks), dim3(kS64Threads), 0, c->stream, c->pairs[cur].p, n, 32 + shift, nblocks, c->sort_hist.p);
+            hipLaunchKernelGGL(sort64_hist_kernel, dim3(nblocks), dim3(kS64Threads), 0, c->stream, c->pairs[cur].p, n, idshift + shift, nblocks, c->sort_hist.p);
             hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->sort_hist.p, nh, c->sort_bsum.p);
             hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->sort_bsum.p, nb, c->sort_bsum.p + nb);
             hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->sort_hist.p, nh, c->sort_bsum.p, c->sort_off.p);
             if (!last)
-                hipLaunchKernelGGL((sort64_scatter_kernel<false>), dim3(nblocks), dim3(kS64Threads), 0, c->stream, c->pairs[cur].p, n, 32 + shift, nblocks, c->sort_off.p, c->pairs[cur ^ 1].p,
-                                   (const PosBlock*)nullptr, 0u, (uint32_t*)nullptr, (uint16_t*)nullptr, (uint32_t*)nullptr);
+                hipLaunchKernelGGL((sort64_scatter_kernel<false>), dim3(nblocks), dim3(kS64Threads), 0, c->stream, c->pairs[cur].p, n, idshift + shift, nblocks, c->sort_off.p,
+                                   c->pairs[cur ^ 1].p, (const PosBlock*)nullptr, 0u, (uint32_t*)nullptr, (uint16_t*)nullptr, (uint32_t*)nullptr, 0u, 0u);
             else
-                hipLaunchKernelGGL((sort64_scatter_kernel<true>), dim3(nblocks), dim3(kS64Threads), 0, c->stream, c->pairs[cur].p, n, 32 + shift, nblocks, c->sort_off.p,
-                                   (unsigned long long*)nullptr, (const PosBlock*)c->pos_blocks.p, c->first_sentence, c->ref_sentence.p, c->ref_token.p,
-                                   keep_sorted_ids ? c->sh.sorted_gid.p : (uint32_t*)nullptr);
+                hipLaunchKernelGGL((sort64_scatter_kernel<true>), dim3(nblocks), dim3(kS64Threads), 0, c->stream, c->pairs[cur].p, n, idshift + shift, nblocks, c->sort_off.p,
+                                   (unsigned long long*)nullptr, packed ? (const PosBlock*)nullptr : (const PosBlock*)c->pos_blocks.p, c->first_sentence, c->ref_sentence.p,
+                                   c->ref_token.p, keep_sorted_ids ? c->sh.sorted_gid.p : (uint32_t*)nullptr, c->pair_sb, c->pair_tb);
             cur ^= 1;
         }
     }

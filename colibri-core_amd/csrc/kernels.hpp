@@ -1288,33 +1288,51 @@ __global__ void pairs_advance_kernel(unsigned long long* __restrict__ chain, int
     chain[which ^ 1]               = after;
     if (after > cap) chain[2] = 1ull;
 }
-__global__ __launch_bounds__(kPairThreads) void emit_write_kernel(const uint32_t* __restrict__ ids, uint32_t npos, const uint32_t* __restrict__ blockoff,
-                                                                   const unsigned long long* __restrict__ chain, int which, uint64_t cap,
-                                                                   unsigned long long* __restrict__ pairs /* result id << 32 | position */) {
-    if (blockoff[blockIdx.x + 1] == blockoff[blockIdx.x]) return;  // nothing in this tile (the passes of the high orders are sparse); [ntiles] holds the total
-    const uint32_t base = blockIdx.x * kPairTile + threadIdx.x * kPairPer;
-    uint32_t       v[kPairPer], c = 0;
-    pair_load(ids, npos, base, v);
-#pragma unroll
-    for (int k = 0; k < kPairPer; ++k) c += v[k] != kInvalid;
-    uint32_t total;
-    uint64_t o = chain[which] + blockoff[blockIdx.x] + pair_block_scan(c, &total);
-#pragma unroll
-    for (int k = 0; k < kPairPer; ++k) {
-        if (v[k] != kInvalid) {
-            if (o < cap) pairs[o] = ((unsigned long long)v[k] << 32) | (base + k);
-            ++o;
-        }
-    }
-}
-
-// the same with a table 30 x smaller (16 bytes per 64 positions instead of 8 bytes per position): { sentences that end before the block, position where
+// position -> (sentence, token) through a table 30 x smaller than one entry per position (16 bytes per 64 positions instead of 8 bytes per position): { sentences that end before the block, position where
 // the sentence running at the block's first position starts, one bit per position of the block that is a delimiter }. A model's 1.6 x 10^8 references
 // are sorted by pattern, i.e. their positions are random: gathers from the 0.8 GB per-position table went to HBM (3.5 ms), the 26 MB one stays in cache.
 struct __attribute__((aligned(16))) PosBlock {
     uint32_t           sent_before, sent_start;
     unsigned long long delim;
 };
+// `blocks` (the usual case: sentence count and longest sentence leave room beside a 31-bit id): the pair carries the reference itself instead of the position —
+// id << (sb + tb) | (sentences before the position) << tb | token — looked up HERE, where the positions of a tile are consecutive (one 16-byte table entry per lane,
+// coalesced), not after the sort, where they are random (161 M gathers: 1.7 ms of the last sort pass). Without: id << 32 | position.
+__global__ __launch_bounds__(kPairThreads) void emit_write_kernel(const uint32_t* __restrict__ ids, uint32_t npos, const uint32_t* __restrict__ blockoff,
+                                                                   const unsigned long long* __restrict__ chain, int which, uint64_t cap,
+                                                                   unsigned long long* __restrict__ pairs, const PosBlock* __restrict__ blocks = nullptr, uint32_t sb = 0,
+                                                                   uint32_t tb = 0) {
+    if (blockoff[blockIdx.x + 1] == blockoff[blockIdx.x]) return;  // nothing in this tile (the passes of the high orders are sparse); [ntiles] holds the total
+    const uint32_t base = blockIdx.x * kPairTile + threadIdx.x * kPairPer;
+    uint32_t       v[kPairPer], c = 0;
+    pair_load(ids, npos, base, v);
+#pragma unroll
+    for (int k = 0; k < kPairPer; ++k) c += v[k] != kInvalid;
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    static_assert(kPairPer == 8, "a lane's positions lie in one 64-position block");
+    if (blocks != nullptr && c) r = *reinterpret_cast<const uint4*>(blocks + (base >> 6));
+    uint32_t total;
+    uint64_t o = chain[which] + blockoff[blockIdx.x] + pair_block_scan(c, &total);
+    const uint64_t delim = ((uint64_t)r.w << 32) | r.z;
+    const uint32_t tmask = tb >= 32 ? 0xFFFFFFFFu : (1u << tb) - 1u;
+#pragma unroll
+    for (int k = 0; k < kPairPer; ++k) {
+        if (v[k] != kInvalid) {
+            if (o < cap) {
+                if (blocks != nullptr) {
+                    const uint32_t p = base + k, bit = p & 63u;
+                    const uint64_t below = delim & ((1ull << bit) - 1ull);
+                    const uint32_t sent = r.x + (uint32_t)__popcll(below), tok = below ? bit - (64u - (uint32_t)__clzll(below)) : p - r.y;
+                    pairs[o] = ((unsigned long long)v[k] << (sb + tb)) | ((unsigned long long)sent << tb) | (tok & tmask);
+                } else {
+                    pairs[o] = ((unsigned long long)v[k] << 32) | (base + k);
+                }
+            }
+            ++o;
+        }
+    }
+}
+
 // ---- stable LSD radix sort of (key, value) u32 pairs, 8 bits per pass ----
 constexpr int kSortTile = 4096;  // elements per block per pass
 __global__ __launch_bounds__(kBlock) void sort_hist_kernel(const uint32_t* __restrict__ keys, uint64_t n, int shift, uint32_t nblocks, uint32_t* __restrict__ ghist) {
@@ -1400,7 +1418,8 @@ __global__ __launch_bounds__(kS64Threads, kS64Threads / 128) void sort64_scatter
                                                                                          const unsigned long long* __restrict__ goff, unsigned long long* __restrict__ out,
                                                                                          const PosBlock* __restrict__ blocks = nullptr, uint32_t first_sentence = 0,
                                                                                          uint32_t* __restrict__ ref_sentence = nullptr, uint16_t* __restrict__ ref_token = nullptr,
-                                                                                         uint32_t* __restrict__ sorted_id = nullptr) {
+                                                                                         uint32_t* __restrict__ sorted_id = nullptr, uint32_t sb = 0, uint32_t tb = 0) {
+    // FINAL with blocks == NULL: the pairs are packed (emit_write_kernel): id << (sb + tb) | sentence << tb | token — unpack, no look-up
     __shared__ unsigned long long stgL[kS64Tile];
     __shared__ uint16_t           gcntL[kS64Groups][256];  // elements of digit d in group (row, wave); then: elements of digit d in the groups before it
     __shared__ uint32_t           histL[256], offL[256], wsumL[4];
@@ -1471,6 +1490,16 @@ __global__ __launch_bounds__(kS64Threads, kS64Threads / 128) void sort64_scatter
             const unsigned long long y = stgL[j];
             const uint32_t           d = (uint32_t)(y >> shift) & 255u;
             out[gbaseL[d] + (j - offL[d])] = y;
+        }
+    } else if (blocks == nullptr) {
+        const unsigned long long smask = (1ull << sb) - 1ull, tmask = (1ull << tb) - 1ull;
+        for (uint32_t j = threadIdx.x; j < cnt; j += kS64Threads) {
+            const unsigned long long y   = stgL[j];
+            const uint32_t           d   = (uint32_t)(y >> shift) & 255u;
+            const uint64_t           dst = gbaseL[d] + (j - offL[d]);
+            ref_sentence[dst]            = first_sentence + (uint32_t)((y >> tb) & smask);
+            ref_token[dst]               = (uint16_t)(y & tmask);
+            if (sorted_id != nullptr) sorted_id[dst] = (uint32_t)(y >> (sb + tb));
         }
     } else {
         unsigned long long y[kS64Per];

@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <string>
 #include <vector>
@@ -631,6 +632,7 @@ int colibri_positions(const colibri_ctx* c, uint64_t* npositions) {
 // ---- helpers of colibri_train ---------------------------------------------------------------------------------
 namespace {
 
+constexpr int kMaxSkipgramTokens = 31;  // a gap mask is a uint32_t that never covers either end (reference include/pattern.h:368, src/algorithms.cpp:79-94)
 struct TrainPlan {
     uint32_t npos, table_slots, res_cap, thr;
     uint32_t cnt_grid, tab_grid, pos_grid;
@@ -640,18 +642,43 @@ struct TrainPlan {
 // n - 2 >= maxskips (reference src/algorithms.cpp:79-94)
 std::vector<uint32_t> gap_masks(int n, int maxskips) {
     std::vector<uint32_t> out;
-    if (n < 3) return out;
-    for (uint32_t i = 1; i < (1u << (n - 2)); ++i) {
-        const uint32_t mask = i << 1;
-        int            runs = 0, in = 0;
-        for (int k = 0; k < n; ++k) {
-            const int g = (mask >> k) & 1;
-            runs += (g && !in);
-            in = g;
+    if (n < 3 || n > kMaxSkipgramTokens) return out;
+    if (n - 2 < maxskips || n <= 16) {  // short patterns: the reference's own enumeration (all 2^(n-2) candidates, in its order)
+        for (uint32_t i = 1; i < (1u << (n - 2)); ++i) {
+            const uint32_t mask = i << 1;
+            int            runs = 0, in = 0;
+            for (int k = 0; k < n; ++k) {
+                const int g = (mask >> k) & 1;
+                runs += (g && !in);
+                in = g;
+            }
+            if (n - 2 >= maxskips && runs > maxskips) continue;
+            out.push_back(mask);
         }
-        if (n - 2 >= maxskips && runs > maxskips) continue;
-        out.push_back(mask);
+        return out;
     }
+    // long patterns (up to 31 tokens: a gap mask is a uint32_t, include/pattern.h:368): the same set built from its runs — 2^(n-2) candidates are 5 x 10^8 at n = 31,
+    // the masks with at most `maxskips` gaps a few hundred thousand. Ascending, which is the reference's order.
+    std::vector<int> b;  // run boundaries: gap runs [b0, b1), [b2, b3), ... over the inner tokens 1 .. n-2
+    std::function<void(int, int)> rec = [&](int from, int runs_left) {
+        if (!b.empty() && b.size() % 2 == 0) {
+            uint32_t mask = 0;
+            for (size_t q = 0; q < b.size(); q += 2)
+                for (int k = b[q]; k < b[q + 1]; ++k) mask |= 1u << k;
+            out.push_back(mask);
+        }
+        if (runs_left == 0) return;
+        for (int s = from; s <= n - 2; ++s)
+            for (int e = s + 1; e <= n - 1; ++e) {
+                b.push_back(s);
+                b.push_back(e);
+                rec(e + 1, runs_left - 1);
+                b.pop_back();
+                b.pop_back();
+            }
+    };
+    rec(1, maxskips);
+    std::sort(out.begin(), out.end());
     return out;
 }
 // contiguous runs of non-gap tokens: (first token, length)
@@ -1533,7 +1560,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     // results: every survivor has >= MINTOKENS occurrences; at MINTOKENS = 1 every window may be its own pattern (exhaustion is reported, never silent)
     uint64_t per_pos = o.mintokens < 2 ? (uint64_t)std::min(o.maxlength, 8) : (synced ? 4u : 2u);  // results per corpus position the run can produce
     if (o.mintokens < 2 && (o.doskipgrams || o.doskipgrams_exhaustive))  // threshold 1 keeps every masked form of every window as well
-        for (int n = 3; n <= std::min(o.maxlength, 13); ++n) per_pos += gap_masks(n, o.maxskips).size();
+        for (int n = 3; n <= std::min(o.maxlength, 13); ++n) per_pos += gap_masks(n, o.maxskips).size();  // (longer orders: the run repeats with more room if they turn up)
     // the usual bound (a survivor has >= MINTOKENS occurrences, and few orders keep many) is not a bound for repetitive corpora — every distinct sentence
     // of L tokens occurring twice keeps L (L + 1) / 2 patterns per pair —: exhaustion is reported by the kernels and colibri_train repeats the run with
     // res_scale x 4 (up to one result per position and order)
@@ -1959,7 +1986,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                     c->hstate.res_total = res_total;
                 }
             } else if (!constrained && o.doskipgrams_exhaustive && n >= 3) {  // patternmodel.h:1163-1171 -> computeskipgrams :1370-1527, for every admissible window
-                if (n > 13) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 13 tokens are not on the accelerated path (set MAXLENGTH)");
+                if (n > kMaxSkipgramTokens) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 31 tokens do not exist (a gap mask has 32 bits; set MAXLENGTH)");
                 if (radix_synced && listed_order) {  // the order's own active list IS the list of positions whose (n-1)-gram survived
                     c->skl   = c->alist[n & 1].p;
                     c->skl_n = c->alist_n.p + (n & 1);
@@ -2019,7 +2046,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
         }
         if (o.doskipgrams && !constrained) {  // IndexedPatternModel::trainskipgrams (patternmodel.h:2969-3010): from the SURVIVING n-grams, n = 3..
             for (int n = 3; n <= std::min<int>(maxlength, s.maxn); ++n) {
-                if (n > 13) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 13 tokens are not on the accelerated path (set MAXLENGTH)");
+                if (n > kMaxSkipgramTokens) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 31 tokens do not exist (a gap mask has 32 bits; set MAXLENGTH)");
                 uint32_t found_n = 0;
                 if ((rc = build_skip_list(c, pl, c->ids[n].p))) return rc;
                 for (uint32_t mask : gap_masks(n, o.maxskips)) {

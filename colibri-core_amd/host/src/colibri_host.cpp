@@ -273,7 +273,7 @@ int masktailskip(uint32_t mask, const unsigned int n) {
 }
 std::vector<uint32_t> compute_skip_configurations(const int n, const int maxskips) {
     std::vector<uint32_t> masks;
-    if (n < 3) return masks;
+    if (n < 3 || n > 32) return masks;  // (a gap mask is a uint32_t that covers neither end: beyond 32 tokens the reference's own loop is undefined)
     for (uint32_t inner = 1; inner < (uint32_t(1) << (n - 2)); ++inner) {
         const uint32_t mask = inner << 1;  // never the first or the last token
         if (n - 2 >= maxskips && mask2vector(mask, n).size() > (size_t)maxskips) continue;

@@ -470,7 +470,7 @@ class RankDriver {
     }
     void skipgram_order(int n, const colibri_options& o, uint64_t& found_n, uint64_t& kept_n) {
         found_n = kept_n = 0;
-        if (n > 13) throw std::runtime_error("skipgrams of patterns longer than 13 tokens are not on the accelerated path (set MAXLENGTH)");  // (before 2^(n-2) masks are enumerated)
+        if (n > 31) throw std::runtime_error("skipgrams of patterns longer than 31 tokens do not exist (a gap mask has 32 bits; set MAXLENGTH)");
         for (uint32_t mask : compute_skip_configurations(n, o.maxskips)) {
             const int levels = (int)mask2vector(mask, n).size();  // gaps = parts - 1 = levels
             uint64_t  f = 0, k = 0;

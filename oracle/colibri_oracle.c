@@ -378,11 +378,13 @@ static int cmp_ref(const void* a, const void* b) {
  * the map it iterates; the specification followed here is the clean one (iterate the n-grams that
  * existed when the order started), see SURVEY.md §8 a-10. */
 static void train_indexed_skipgrams(co_model* m, const co_options* opt, uint32_t thr) {
-    uint32_t masks[1 << 12];
+    uint32_t* masks = NULL;
     uint8_t  keybuf[4096];
     uint64_t tokstart[128];
-    for (int n = 3; n <= opt->maxlength && n < 14; ++n) {
-        const int      nmasks = co_skip_configurations(n, opt->maxskips, masks, 1 << 12);
+    for (int n = 3; n <= opt->maxlength && n < 32; ++n) { /* a gap mask is a uint32_t: patterns of up to 31 tokens (include/pattern.h:368) */
+        const int nmasks = co_skip_configurations(n, opt->maxskips, NULL, 0);
+        masks            = (uint32_t*)realloc(masks, sizeof(uint32_t) * (size_t)(nmasks + 1));
+        co_skip_configurations(n, opt->maxskips, masks, nmasks);
         const uint64_t ne0    = m->ne; /* the n-grams that exist when this order starts */
         uint64_t       found  = 0;
         for (uint64_t i = 0; i < ne0; ++i) {
@@ -420,6 +422,7 @@ static void train_indexed_skipgrams(co_model* m, const co_options* opt, uint32_t
         }
         if (n > m->maxn) m->maxn = n;
     }
+    free(masks);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -444,14 +447,18 @@ co_model* co_train(const uint8_t* payload, uint64_t nbytes, const co_options* op
     co_model* m = (co_model*)calloc(1, sizeof(co_model));
     m->indexed  = opt.indexed;
     tokbuf   t  = {0};
-    uint32_t masks[1 << 12];
+    uint32_t* masks = NULL;
     uint8_t  keybuf[4096];
     uint64_t prevsize = 0;
 
     for (int n = 1; n <= opt.maxlength; ++n) { /* ORDER LOOP :981 */
         uint64_t foundskipgrams = 0;
         int      nmasks         = 0;
-        if (opt.doskipgrams_exhaustive && n >= 3 && n < 14) nmasks = co_skip_configurations(n, opt.maxskips, masks, 1 << 12); /* :1021-1022 */
+        if (opt.doskipgrams_exhaustive && n >= 3 && n < 32) { /* :1021-1022; a gap mask is a uint32_t: up to 31 tokens */
+            nmasks = co_skip_configurations(n, opt.maxskips, NULL, 0);
+            masks  = (uint32_t*)realloc(masks, sizeof(uint32_t) * (size_t)(nmasks + 1));
+            co_skip_configurations(n, opt.maxskips, masks, nmasks);
+        }
         uint32_t sentence = firstsentence - 1;
         uint64_t pos      = 0;
         while (next_sentence(payload, nbytes, &pos, &t)) { /* SENTENCE LOOP :1030 */
@@ -518,6 +525,7 @@ co_model* co_train(const uint8_t* payload, uint64_t nbytes, const co_options* op
             if (m->e[i].alive) qsort(m->e[i].refs, m->e[i].count, sizeof(co_ref), cmp_ref);
     }
     free(t.start);
+    free(masks);
     return m;
 }
 

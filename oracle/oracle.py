@@ -72,8 +72,9 @@ def spooky64(data: bytes) -> int:
 
 
 def skip_configurations(n: int, maxskips: int = 3):
-    out = np.zeros(1 << 14, dtype=np.uint32)
-    k = lib().co_skip_configurations(n, maxskips, out.ctypes.data, out.size)
+    k = lib().co_skip_configurations(n, maxskips, None, 0)
+    out = np.zeros(max(1, k), dtype=np.uint32)
+    lib().co_skip_configurations(n, maxskips, out.ctypes.data, out.size)
     return [int(x) for x in out[:k]]
 
 

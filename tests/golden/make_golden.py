@@ -66,11 +66,37 @@ def reference_is_dump_is_stable(path, minskiptypes, maxlength):
     return exp == skip
 
 
+def longspan():
+    """patterns beyond 13 tokens (the device path's former limit; the reference's gap masks reach 31 tokens, include/pattern.h:368): a 14-token sentence
+    four times — twice verbatim, twice with one word changed, so that skipgrams with two distinct fillers exist — among short ones"""
+    span = list(range(6, 20))
+    near = list(span)
+    near[6] = 40
+    syms = []
+    for sent in (span, [30, 31, 32], near, [33, 30, 31], span, [6, 7, 8, 50], near, [30, 31, 32, 33]):
+        syms += sent + [0]
+    with open(os.path.join(HERE, "longspan.colibri.dat"), "wb") as f:
+        f.write(synth.HEADER + synth.encode_v2(np.array(syms, dtype=np.uint32)).tobytes())
+    out = []
+    for mode, l, extra in [("us", 14, []), ("is", 14, ["-T", "1"]), ("is", 14, []), ("u", 14, [])]:
+        tag = mode + "".join(extra).replace("-", "")
+        path = os.path.join(HERE, f"longspan.{tag}.l{l}.txt")
+        subprocess.check_call([DRIVER, "train", os.path.join(HERE, "longspan.colibri.dat"), mode, str(l), "2", "-q", "-d", path] + extra, stdout=subprocess.DEVNULL)
+        if mode == "is" and not reference_is_dump_is_stable(path, 1 if extra else 2, l):
+            out.append(os.path.basename(path))
+            os.remove(path)
+    return out
+
+
 def main():
+    if sys.argv[1:] == ["longspan"]:
+        print("unstable:", longspan())
+        return
     unstable = []
     for name, data in corpora().items():
         with open(os.path.join(HERE, f"{name}.colibri.dat"), "wb") as f:
             f.write(data)
+    unstable += longspan()
     jobs = []
     for name in ["hamlet.v1", "edge", "zipf20k", "phrases15k"]:
         path = os.path.join(HERE, f"{name}.colibri.dat")

@@ -220,6 +220,22 @@ def test_exhaustive_skipgrams_longer_patterns(ctx, hamlet_payload):
     _compare(ctx, small_corpora()["repeat"], 8, doskipgrams_exhaustive=1)
 
 
+@pytest.mark.parametrize("mode", [dict(doskipgrams_exhaustive=1), dict(indexed=1, doskipgrams=1), dict(indexed=1, doskipgrams=1, minskiptypes=1), dict(doskipgrams_exhaustive=1, maxskips=2)],
+                         ids=["exhaustive", "indexed", "indexed-T1", "exhaustive-maxskips2"])
+def test_skipgrams_of_patterns_beyond_13_tokens(ctx, mode):
+    """a gap mask is a uint32_t: patterns of up to 31 tokens have skipgrams in the reference (include/pattern.h:368, src/algorithms.cpp:79-94); rounds 1-2 stopped at
+    13. A 14-token sentence that recurs (tests/golden/longspan.colibri.dat: 2509 masks at n = 14; the exhaustive model is also pinned to the real reference's dump,
+    tests/golden/longspan.us.l14.txt) and a 17-token one (10 591 masks at n = 17: the run-built mask list) against the oracle."""
+    from test_oracle import read_payload
+    from colibri_amd import synth
+    st = _compare(ctx, read_payload("longspan"), 14, **mode)
+    assert st.maxn == 14
+    if mode.get("maxskips") == 2:
+        span = list(range(6, 23))
+        st = _compare(ctx, synth.encode_v2(np.array((span + [0]) * 2 + [6, 7, 0], dtype=np.uint32)).tobytes(), 17, **mode)
+        assert st.maxn == 17
+
+
 def test_skipgrams_rejected_when_corpus_has_literal_skip_tokens(ctx):
     from colibri_amd import capi
     ctx.upload(b"\x06\x03\x07\x00\x06\x03\x07\x00")

@@ -1499,7 +1499,9 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     for (;;) {
         const int rc = colibri_train_once(c, opt_in, stats_out);
         // a result buffer ran out (a corpus that keeps unusually many patterns per position: duplicated text): more room, again
-        const uint64_t bound = (uint64_t)std::max(1, std::min<int>(opt_in->maxlength, COLIBRI_MAX_ORDER - 1)) * ((uint64_t)c->npos + 1);
+        // (one result per position and order — with skipgrams one per gap mask as well: up to ~6 x 10^5 masks for a window of 31 tokens)
+        const uint64_t per_window = (opt_in->doskipgrams || opt_in->doskipgrams_exhaustive) ? 700000ull : 1ull;
+        const uint64_t bound = (uint64_t)std::max(1, std::min<int>(opt_in->maxlength, COLIBRI_MAX_ORDER - 1)) * ((uint64_t)c->npos + 1) * per_window;
         if (rc != COLIBRI_ERR_OVERFLOW || !c->hstate.overflow || c->res_cap_used >= std::min<uint64_t>(0x7FFFFFF0ull, bound)) {
             c->res_scale = 1;
             return rc;

@@ -76,6 +76,7 @@ struct Bi2State {
     uint32_t kbits;     // key bits below the slice bits (K - s): A bin = bits [kbits-1 : kbits-8], B bin = the nine below
     uint32_t posbits;   // position bits of a record
     uint32_t res_base;  // first result index of this pass's survivors (an order counted in slices appends pass after pass)
+    uint32_t nextchunk;                 // owner passes of key-sharded runs: next free chunk of the position-list pool (bi2_count_kernel<.., BASED>)
     uint32_t nextbin[kBi2Shards * 16];  // work queues of the count kernel (one per shard, 64 bytes apart): next group of bins to hand out
     uint32_t big[kBi2BigCap];           // final bins with more than kBi2BigBin records: counted first (one wave each), so that none of them starts late
 };
@@ -631,7 +632,11 @@ __device__ __forceinline__ uint32_t bi2_find(const uint32_t* keyT, uint32_t key,
 #ifdef BI2_PROF
 __device__ unsigned long long bi2_prof[16];
 #endif
-// BASED (key-sharded runs, kshard.hpp): slot s starts at record slotbase[s] of recsB instead of s * region
+// BASED (key-sharded runs, kshard.hpp): slot s starts at record slotbase[s] of recsB instead of s * region, and the position lists are CHUNKS of a pool:
+// wlist = [wcap chunks][kBi2Chunk], wcnt = entries per chunk, a wave takes a fresh chunk (one atomic) whenever its current one cannot hold a row. How many
+// windows a wave ends up listing depends on how many bins it drew, i.e. on how the waves were scheduled — ranks sharing a device (tests) starve each other's
+// late waves —, so a fixed capacity per wave is no bound there; the pool needs room for the survivors plus one partly filled chunk per wave.
+constexpr uint32_t kBi2Chunk = 4096;
 template <int NSUB, bool BASED = false>
 __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const uint32_t* __restrict__ boff, Bi2State* __restrict__ bs,
                                                               DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
@@ -651,7 +656,8 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
     uint32_t* const mylist = wlist + (size_t)wid * wcap;
     uint32_t* const mycode = wcode != nullptr ? wcode + (size_t)wid * wcap : nullptr;
     static_assert(kBi2MaxLoad < 1024 && kBi2Final <= (1 << 22), "a (bin, rank) code fits 32 bits");
-    uint32_t        cursor = want_positions ? wcnt[wid] : 0u;  // entries in this wave's position list (wave-uniform); the passes of a sliced order append
+    uint32_t        cursor = (want_positions && !BASED) ? wcnt[wid] : 0u;  // entries in this wave's position list (wave-uniform); the passes of a sliced order append
+    uint32_t        chunk  = kInvalid;                                      // BASED: the chunk being filled (cursor = entries in it)
     bool            lost   = false;  // the list ran out of room
 #ifdef BI2_PROF
     unsigned long long tacc[12] = {0}, tlast = wall_clock64();
@@ -844,16 +850,30 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
             if (want_positions) {
                 const uint64_t m = __ballot(kept);
                 const uint32_t n = (uint32_t)__popcll(m);
-                if (kept) {
-                    const uint32_t at = cursor + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (at < wcap) {
-                        mylist[at] = pos;
-                        if (mycode != nullptr) mycode[at] = fcode | r;
-                    } else {
-                        lost = true;
+                if (BASED) {
+                    if (n && (chunk == kInvalid || cursor + n > kBi2Chunk)) {  // (wave-uniform) this row does not fit: close the chunk, take the next one of the pool
+                        if (chunk != kInvalid && lane == 0) wcnt[chunk] = cursor;
+                        uint32_t c = 0;
+                        if (lane == 0) c = atomicAdd(&bs->nextchunk, 1u);
+                        c      = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                        chunk  = c < wcap ? c : kInvalid;
+                        cursor = 0;
+                        if (chunk == kInvalid) lost = true;
                     }
+                    if (kept && chunk != kInvalid) wlist[(size_t)chunk * kBi2Chunk + cursor + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pos;
+                    if (chunk != kInvalid) cursor += n;
+                } else {
+                    if (kept) {
+                        const uint32_t at = cursor + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        if (at < wcap) {
+                            mylist[at] = pos;
+                            if (mycode != nullptr) mycode[at] = fcode | r;
+                        } else {
+                            lost = true;
+                        }
+                    }
+                    cursor += n;
                 }
-                cursor += n;
             }
         };
 #pragma unroll
@@ -916,7 +936,11 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
     if (lane == 0)
         for (int q = 0; q < 12; ++q) atomicAdd(&bi2_prof[q], tacc[q]);
 #endif
-    if (want_positions && lane == 0) wcnt[wid] = min(cursor, wcap);
+    if (BASED) {
+        if (want_positions && chunk != kInvalid && lane == 0) wcnt[chunk] = cursor;
+    } else if (want_positions && lane == 0) {
+        wcnt[wid] = min(cursor, wcap);
+    }
     if (__any(lost) && lane == 0) bs->overflow = 3;
 }
 

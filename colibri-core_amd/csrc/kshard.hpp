@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kBlock) void ks_finish2_kernel(DevState* __restrict
         ost->found += ftot + (rank == 0 ? hftot : 0u);
         ost->kept += tot + htot;
         if ((uint64_t)obs->res_base + tot + htot > res_cap) ost->overflow = 1;
-        if (obs->overflow) ost->radix_overflow = 4;
+        if (obs->overflow) ost->radix_overflow = 4 + obs->overflow;  // 5: a slot, 6: a final bin's LDS table, 7: a wave's position list
     }
 }
 // bi2_compact_kernel for an owner: representatives are tagged positions already; the head survivors this rank exports get its own lowest position

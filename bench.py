@@ -418,13 +418,15 @@ def main():
         sh = {"protocol": "candidate exchange" if info.protocol == 1 else "key-sharded counting", "host_lookups_per_step": int(info.host_lookups),
               "alltoall_bytes_per_rank_and_step": int(info.alltoall_bytes), "of_which_to_self": int(info.alltoall_bytes_to_self), "allreduce_bytes_per_rank_and_step": int(info.allreduce_bytes)}
         if args.gpus == 1:
-            # what one rank of the 8-GPU, 1 B-token run (125 M tokens per rank) will take: this step's device work scaled by the shard size, the copies a rank makes to
-            # itself replaced by 7/8 of the bytes crossing xGMI at the assumed all-to-all rate (stated above; not measurable on a one-GPU box)
+            # what one rank of the 8-GPU, 1 B-token run (125 M tokens per rank) will take: this step's device work scaled to that shard, plus 7/8 of the exchanged
+            # bytes crossing xGMI at the assumed all-to-all rate (stated above; not measurable on a one-GPU box). A lower bound on the bytes: at 10^9 tokens more
+            # windows survive, and the survivors' feedback grows (profiles/r03d: 2.5 GB per rank and step with 8 ranks sharing one device)
             ms1 = elapsed / args.steps * 1e3
-            xg = 1.25 * info.alltoall_bytes * 7 / 8 / (XGMI_A2A_GBS * 1e9) * 1e3
-            sh["predicted_ms_per_rank_at_8"] = round(1.25 * ms1 + xg, 2)
-            sh["prediction"] = (f"1.25 x this step ({ms1:.2f} ms: 125 M tokens per rank) + 7/8 of 1.25 x {info.alltoall_bytes / 1e9:.2f} GB over xGMI at an assumed {XGMI_A2A_GBS:.0f} GB/s "
-                                f"per GPU and direction ({xg:.2f} ms, not overlapped)")
+            scale = 125_000_000 / args.tokens
+            xg = scale * info.alltoall_bytes * 7 / 8 / (XGMI_A2A_GBS * 1e9) * 1e3
+            sh["predicted_ms_per_rank_at_8"] = round(scale * ms1 + xg, 2)
+            sh["prediction"] = (f"{scale:.2f} x this step ({ms1:.2f} ms at {args.tokens} tokens -> 125 M tokens per rank) + 7/8 of {scale:.2f} x {info.alltoall_bytes / 1e9:.2f} GB over xGMI at an "
+                                f"assumed {XGMI_A2A_GBS:.0f} GB/s per GPU and direction ({xg:.2f} ms, not overlapped)")
         out["sharded"] = sh
     if ctx is not None and not args.no_other_configs:
         out["other_configs"] = other_configs(ctx, capi, payloads[0].size)

@@ -164,6 +164,46 @@ def phrases_config(ctx, capi, payload):
             "frac_of_hbm_peak": round(algo / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}, ok
 
 
+def z1b_configs(capi, shards):
+    """BASELINE.json configs[2]'s corpus — 10^9 tokens, the eight 125 M-token shards an 8-GPU run holds — on ONE device, two ways (untimed extras, best of three):
+    one context over the concatenation (the radix path in passes over key slices: an order of more than ~110 M records does not fit one pass), and the multi-GPU
+    trainer with its eight ranks all on this device (key-sharded counting; the ranks exchange by device copies). Both must build the same model."""
+    def sentences_of(p):
+        prev_low = np.concatenate([[True], p[:-1] < 128])
+        return int(((p == 0) & prev_low).sum())
+    res = {}
+    whole = np.concatenate(shards)
+    with capi.Context(0) as c:
+        c.upload(whole)
+        del whole
+        best, st = None, None
+        for _ in range(3):
+            st = c.train(maxlength=MAXLENGTH, mintokens=MINTOKENS)
+            best = st.train_ms if best is None else min(best, st.train_ms)
+        mode, passes = c.last_mode(with_passes=True)
+    windows = sum(st.windows[1:MAXLENGTH + 1])
+    one = (int(st.npatterns), [int(st.kept[n]) for n in range(1, MAXLENGTH + 1)])
+    res["z1b_single_device"] = {"workload": "configs[2]'s 1 B-token corpus (8 x 125 M tokens, seeds 44..51) in one context", "ms_per_step": round(best, 2),
+                                "M_patterns_counted_per_s": round(windows / best / 1e3, 1), "patterns_in_model": one[0], "kept_per_order": one[1],
+                                "passes_over_key_slices_at_order_2": passes}
+    nsent = [sentences_of(p) for p in shards]
+    with capi.ShardedTrainer(8, devices=[0] * 8) as tr:
+        for r, p in enumerate(shards):
+            tr.upload(r, p, 1 + sum(nsent[:r]))
+        best = None
+        for _ in range(3):
+            st = tr.train(maxlength=MAXLENGTH, mintokens=MINTOKENS)
+            best = tr.info.wall_ms if best is None else min(best, tr.info.wall_ms)
+        info = tr.info
+        eight = (int(st.npatterns), [int(st.kept[n]) for n in range(1, MAXLENGTH + 1)])
+    res["z1b_eight_ranks_on_one_device"] = {"workload": "the same shards, one rank each, all eight ranks on this device (what `--gpus 8` runs on eight devices, minus xGMI)",
+                                            "ms_per_step": round(best, 2), "M_patterns_counted_per_s": round(windows / best / 1e3, 1), "patterns_in_model": eight[0],
+                                            "kept_per_order": eight[1], "protocol": "candidate exchange" if info.protocol == 1 else "key-sharded counting",
+                                            "alltoall_bytes_per_rank_and_step": int(info.alltoall_bytes), "of_which_to_self": int(info.alltoall_bytes_to_self),
+                                            "same_model_as_z1b_single_device": eight == one}
+    return res
+
+
 def measured_traffic(workload_tokens, kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or None — NOT measured by this run"""
     path = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
@@ -189,6 +229,7 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="debugging: all ranks of --gpus N on device 0 (they exchange by device copies, not RCCL)")
     ap.add_argument("--force-shard", action="store_true", help="run the multi-GPU trainer even with one rank (prices the exchange machinery)")
     ap.add_argument("--candidates", action="store_true", help="multi-GPU runs: the candidate-exchange protocol instead of key-sharded counting (comparison)")
+    ap.add_argument("--no-z1b", action="store_true", help="skip other_configs.z1b_*: the 1 B-token corpus of configs[2] on this ONE device (two untimed extras, ~1 minute)")
     args = ap.parse_args()
     if args.tokens <= 0:
         args.tokens = 125_000_000 if args.gpus == 8 else 100_000_000
@@ -208,11 +249,16 @@ def main():
     want_phrases = not sharded and not args.no_other_configs and args.tokens == 100_000_000 and args.vocab == 1_000_000
     if want_phrases:
         specs.append((args.tokens, args.vocab, 44, True))
+    # configs[2]'s corpus (8 x 125 M tokens, the shards an 8-GPU run would hold) on this one device: only where generating it is a matter of seconds
+    want_z1b = want_phrases and not args.no_z1b and (os.cpu_count() or 1) >= 16
+    if want_z1b:
+        specs += [(125_000_000, args.vocab, 44 + r, False) for r in range(8)]
     t0 = time.time()
     pool = concurrent.futures.ProcessPoolExecutor(max_workers=min(len(specs), max(1, (os.cpu_count() or 2) - 1)), mp_context=multiprocessing.get_context("fork"))
     futures = [pool.submit(make_corpus, s) for s in specs]
     payloads = [np.frombuffer(f.result(), dtype=np.uint8) for f in futures[:len(my_ranks)]]
-    phrase_payload = futures[-1].result() if want_phrases else None  # (every worker is done before anything is timed: a busy host core next to the timed loop cost 2 ms per step)
+    phrase_payload = futures[len(my_ranks)].result() if want_phrases else None  # (every worker is done before anything is timed: a busy host core next to the timed loop cost 2 ms per step)
+    z1b_shards = [np.frombuffer(f.result(), dtype=np.uint8) for f in futures[len(my_ranks) + 1:]] if want_z1b else None
     pool.shutdown(wait=True)
     gen_s = time.time() - t0
 
@@ -435,6 +481,10 @@ def main():
             out["other_configs"]["phrases"] = ph
             if ph_ok is False:
                 check_ok = False
+    if want_z1b and "other_configs" in out:
+        ctx.close()
+        ctx = None
+        out["other_configs"].update(z1b_configs(capi, z1b_shards))
     if args.gpus == 1 and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.vocab)
     print(json.dumps(out), flush=True)

@@ -389,7 +389,7 @@ class PatternModel : public MapType, public PatternModelInterface {
         // an indexed skipgram model stays resident on the device until it is materialised on the host: computeflexgrams_fromskipgrams works on it there
         const int  world = (constrainbymodel == NULL && filter == NULL && !options.DOPATTERNPERLINE) ? colibri_host::gpus() : 1;  // sentence-sharded over that many GPUs (src/sharded.cpp)
         const bool keep_device = world == 1 && o.indexed && o.doskipgrams && constrainbymodel == NULL && options.MINLENGTH <= 1;
-        if (world > 1 || (world == 1 && constrainbymodel == NULL && !options.DOPATTERNPERLINE && std::getenv("COLIBRI_GPUS_FORCE_SHARDED") != NULL)) {  // (forced: the sharded protocol on one rank, for tests)
+        if (world > 1 || (world == 1 && constrainbymodel == NULL && filter == NULL && !options.DOPATTERNPERLINE && std::getenv("COLIBRI_GPUS_FORCE_SHARDED") != NULL)) {  // (forced: the sharded protocol on one rank, for tests; a filtered run has no sharded form)
             std::vector<unsigned char> owned;
             const unsigned char*       p = NULL;
             uint64_t                   nb = 0;

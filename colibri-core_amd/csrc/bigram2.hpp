@@ -1145,18 +1145,31 @@ __global__ __launch_bounds__(kBi2BmThreads) void bi2_bitmap_kernel(uint32_t npos
 // ---- result indices per position (the modes that keep every order's ids: forward index, skipgram passes) ------------------------------------
 // per position bucket: the listed (position, code) pairs -> ids[position] = RESULT index of the window's bigram (the array is pre-filled with kInvalid;
 // the scatter stays inside the bucket's window of 2^pshift positions). Head bigrams: bi2_list3_kernel writes theirs from the table bi2_headids_kernel leaves.
+// Persistent blocks, each walking whole buckets: the 4-byte stores of a bucket land in one window of 2^pshift positions (512 KB at 10^8 positions), and with few
+// enough windows open at a time they meet in L2 and leave as whole lines — one block per bucket (1024 windows open) wrote a partial line per store.
 __global__ __launch_bounds__(kBi2BmThreads) void bi2_ids_kernel(uint32_t npos, const Bi2State* __restrict__ bs, const uint32_t* __restrict__ plist, const uint32_t* __restrict__ pcode,
-                                                                 Bi2Lists pl, const DevState* __restrict__ st, uint32_t* __restrict__ ids) {
+                                                                 Bi2Lists pl, const DevState* __restrict__ st, uint32_t* __restrict__ ids, uint32_t nbuckets) {
     if (st->done) return;
-    const uint32_t b = blockIdx.x;
-    if ((b << pl.pshift) >= npos) return;
     const uint32_t res_base = bs->res_base;
-    for (uint32_t x = 0; x < (uint32_t)kBi2Shards; ++x) {
-        const uint32_t l = x * kBi2Buckets + b, n = min(bs->pcur[l], pl.pcap);
-        const size_t   o = (size_t)l * pl.pcap;
-        for (uint32_t j = threadIdx.x; j < n; j += kBi2BmThreads) {
-            const uint32_t code = pcode[o + j];
-            ids[plist[o + j]]   = res_base + bs->binkept[code >> 10] + (code & 1023u);
+    for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
+        if ((b << pl.pshift) >= npos) break;
+        for (uint32_t x = 0; x < (uint32_t)kBi2Shards; ++x) {
+            const uint32_t l = x * kBi2Buckets + b, n = min(bs->pcur[l], pl.pcap);
+            const size_t   o = (size_t)l * pl.pcap;
+            for (uint32_t j0 = 0; j0 < n; j0 += 4 * kBi2BmThreads) {
+                uint32_t code[4], pos[4], off[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {  // loads, then the gathers from the 512 KB offset table, then the stores
+                    const uint32_t j = j0 + k * kBi2BmThreads + threadIdx.x;
+                    code[k]          = j < n ? pcode[o + j] : 0u;
+                    pos[k]           = j < n ? plist[o + j] : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) off[k] = bs->binkept[code[k] >> 10];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (j0 + k * kBi2BmThreads + threadIdx.x < n) ids[pos[k]] = res_base + off[k] + (code[k] & 1023u);
+            }
         }
     }
 }

@@ -953,7 +953,13 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
         hipLaunchKernelGGL(bi2_pospart_kernel, dim3(512), dim3(kBi2Threads), 0, c->stream, c->b2.wlist.p, c->b2.wcnt.p, kBi2Waves, b.wcap, bs, c->state.p, c->b2.plist.p, b.pl,
                            ids_out != nullptr ? (const uint32_t*)c->b2.wcode.p : (const uint32_t*)nullptr, ids_out != nullptr ? c->b2.pcode.p : (uint32_t*)nullptr);
         if (ids_out != nullptr) {
-            hipLaunchKernelGGL(bi2_ids_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), 0, c->stream, npos, bs, c->b2.plist.p, c->b2.pcode.p, b.pl, c->state.p, ids_out);
+            static const uint32_t ids_grid = [] {
+                const char* e = getenv("COLIBRI_IDS_GRID");
+                const long  v = e ? strtol(e, nullptr, 10) : 0;
+                return v > 0 ? (uint32_t)v : 64u;  // eight blocks per XCD: eight 512 KB windows share a 4 MB L2
+            }();
+            hipLaunchKernelGGL(bi2_ids_kernel, dim3(std::min(b.nbuckets, ids_grid)), dim3(kBi2BmThreads), 0, c->stream, npos, bs, c->b2.plist.p, c->b2.pcode.p, b.pl, c->state.p, ids_out,
+                               b.nbuckets);
             hipLaunchKernelGGL(bi2_headids_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, c->state.p, c->b2.headid.p);
         }
         hipLaunchKernelGGL(bi2_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, bs, c->b2.plist.p, b.pl, c->state.p, c->b2.bitmap.p);

@@ -1145,8 +1145,8 @@ __global__ __launch_bounds__(kBi2BmThreads) void bi2_bitmap_kernel(uint32_t npos
 // ---- result indices per position (the modes that keep every order's ids: forward index, skipgram passes) ------------------------------------
 // per position bucket: the listed (position, code) pairs -> ids[position] = RESULT index of the window's bigram (the array is pre-filled with kInvalid;
 // the scatter stays inside the bucket's window of 2^pshift positions). Head bigrams: bi2_list3_kernel writes theirs from the table bi2_headids_kernel leaves.
-// Persistent blocks, each walking whole buckets: the 4-byte stores of a bucket land in one window of 2^pshift positions (512 KB at 10^8 positions), and with few
-// enough windows open at a time they meet in L2 and leave as whole lines — one block per bucket (1024 windows open) wrote a partial line per store.
+// The 4-byte stores of a bucket land in one window of 2^pshift positions (512 KB at 10^8 positions). (Round 3 tried fewer, persistent blocks so that few windows
+// are open at a time and the stores meet in L2: slower at every grid size below one block per bucket — the kernel is bound by loads in flight.)
 __global__ __launch_bounds__(kBi2BmThreads) void bi2_ids_kernel(uint32_t npos, const Bi2State* __restrict__ bs, const uint32_t* __restrict__ plist, const uint32_t* __restrict__ pcode,
                                                                  Bi2Lists pl, const DevState* __restrict__ st, uint32_t* __restrict__ ids, uint32_t nbuckets) {
     if (st->done) return;

@@ -956,7 +956,8 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
             static const uint32_t ids_grid = [] {
                 const char* e = getenv("COLIBRI_IDS_GRID");
                 const long  v = e ? strtol(e, nullptr, 10) : 0;
-                return v > 0 ? (uint32_t)v : 64u;  // eight blocks per XCD: eight 512 KB windows share a 4 MB L2
+                return v > 0 ? (uint32_t)v : 0xFFFFFFFFu;  // one block per bucket: fewer, persistent blocks (fewer windows open, hoping for whole lines out of L2) measured slower —
+                                                              // 32 / 64 / 128 / 256 / 1024 blocks: indexed run 15.1 / 13.5 / 12.8 / 12.5 / 12.4 ms: the kernel wants parallelism, not locality
             }();
             hipLaunchKernelGGL(bi2_ids_kernel, dim3(std::min(b.nbuckets, ids_grid)), dim3(kBi2BmThreads), 0, c->stream, npos, bs, c->b2.plist.p, c->b2.pcode.p, b.pl, c->state.p, ids_out,
                                b.nbuckets);

@@ -637,7 +637,8 @@ __device__ unsigned long long bi2_prof[16];
 // windows a wave ends up listing depends on how many bins it drew, i.e. on how the waves were scheduled — ranks sharing a device (tests) starve each other's
 // late waves —, so a fixed capacity per wave is no bound there; the pool needs room for the survivors plus one partly filled chunk per wave.
 constexpr uint32_t kBi2Chunk = 4096;
-template <int NSUB, bool BASED = false>
+// ROWS: records per lane held in registers (bins of up to 64 x ROWS records are read once; an owner of a 125 M-token-per-rank run holds ~810 per bin: 16 rows)
+template <int NSUB, bool BASED = false, int ROWS = kBi2WRows>
 __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const uint32_t* __restrict__ boff, Bi2State* __restrict__ bs,
                                                               DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
                                                               uint32_t* __restrict__ wlist, uint32_t* __restrict__ wcnt, uint32_t wcap, bool want_positions,
@@ -702,9 +703,9 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
             }
             return BASED ? (size_t)sbase + off : (size_t)slot * region + off;
         };
-        unsigned long long x[kBi2WRows];
+        unsigned long long x[ROWS];
 #pragma unroll
-        for (int q = 0; q < kBi2WRows; ++q) {
+        for (int q = 0; q < ROWS; ++q) {
             const uint32_t j = q * kWave + lane;
             x[q]             = j < total ? recsB[locate(j)] : 0ull;
         }
@@ -720,10 +721,10 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
         }
         BI2_W(3);
         // pass 1: two rows per round
-        uint32_t sl[kBi2WRows];
+        uint32_t sl[ROWS];
         bool     fail = false;
 #pragma unroll
-        for (int q = 0; q < kBi2WRows; q += 2) {
+        for (int q = 0; q < ROWS; q += 2) {
             sl[q] = sl[q + 1] = kInvalid;
             if ((uint32_t)(q * kWave) < total) {
                 const bool     actA = (uint32_t)(q * kWave) + lane < total, actB = (uint32_t)((q + 1) * kWave) + lane < total;
@@ -746,7 +747,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
             }
         }
         BI2_W(4);
-        if (total > (uint32_t)(kBi2WRows * kWave)) {  // larger bins stream the remainder: four rows per round, the next four already in flight
+        if (total > (uint32_t)(ROWS * kWave)) {  // larger bins stream the remainder: four rows per round, the next four already in flight
             unsigned long long y[4];
             auto               load4 = [&](uint32_t j0) {
 #pragma unroll
@@ -755,8 +756,8 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
                     y[k]             = j < total ? recsB[locate(j)] : ~0ull;
                 }
             };
-            load4(kBi2WRows * kWave);
-            for (uint32_t j0 = kBi2WRows * kWave; j0 < total; j0 += 4 * kWave) {
+            load4(ROWS * kWave);
+            for (uint32_t j0 = ROWS * kWave; j0 < total; j0 += 4 * kWave) {
                 unsigned long long z[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) z[k] = y[k];
@@ -877,10 +878,10 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
             }
         };
 #pragma unroll
-        for (int q = 0; q < kBi2WRows; ++q)
+        for (int q = 0; q < ROWS; ++q)
             if ((uint32_t)(q * kWave) < total) settle(sl[q] != kInvalid, (uint32_t)(x[q] & pmask), sl[q]);
         BI2_W(8);
-        if (total > (uint32_t)(kBi2WRows * kWave)) {
+        if (total > (uint32_t)(ROWS * kWave)) {
             unsigned long long y[4];
             auto               load4 = [&](uint32_t j0) {
 #pragma unroll
@@ -889,8 +890,8 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
                     y[k]             = j < total ? recsB[locate(j)] : ~0ull;
                 }
             };
-            load4(kBi2WRows * kWave);
-            for (uint32_t j0 = kBi2WRows * kWave; j0 < total; j0 += 4 * kWave) {
+            load4(ROWS * kWave);
+            for (uint32_t j0 = ROWS * kWave; j0 < total; j0 += 4 * kWave) {
                 unsigned long long z[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) z[k] = y[k];

@@ -784,6 +784,7 @@ __global__ void bin_advance_prepare_kernel(DevState* __restrict__ st, const BinS
 
 // ids[i] = survivor id found at the window's representative position; also builds the active list for the next order
 // (positions whose window survived), tile by tile with one reservation per 8192 items.
+constexpr uint32_t kDecodeBaseOnDevice = 0xFFFFFFFFu;
 constexpr int kResPer  = 32;
 constexpr int kResTile = kBlock * kResPer;
 template <bool LIST>
@@ -815,9 +816,10 @@ __global__ __launch_bounds__(kBlock) void bin_resolve_kernel(const uint32_t* __r
                 if (id[q] != kInvalid) id[q] = remap[id[q] - remap_base];  // sharded: local sparse id -> global survivor id
         }
         if (decode != nullptr) {
+            const uint32_t dbase = decode_base == kDecodeBaseOnDevice ? decode->res_base : decode_base;  // (enqueued id-keeping runs: the pass's first result index is only known on the device)
 #pragma unroll
             for (int q = 0; q < kResPer; ++q)
-                if (id[q] != kInvalid) id[q] = decode_base + decode->cur2[id[q] >> 11] + (id[q] & 2047u);  // (bin, rank) -> result index
+                if (id[q] != kInvalid) id[q] = dbase + decode->cur2[id[q] >> 11] + (id[q] & 2047u);  // (bin, rank) -> result index
         }
 #pragma unroll
         for (int q = 0; q < kResPer; ++q) {

@@ -1286,7 +1286,7 @@ int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool en
         {
             Prof p(c, COLIBRI_K_INDEX);
             const uint64_t cap = c->pairs[0].n;
-            hipLaunchKernelGGL(emit_count_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, pl.npos, cnt);
+            hipLaunchKernelGGL(emit_count_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, pl.npos, cnt, (const DevState*)c->state.p);
             hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, cnt, ntiles, cnt + ntiles);
             hipLaunchKernelGGL(pairs_advance_kernel, dim3(1), dim3(1), 0, c->stream, c->pair_chain.p, c->pair_pass, cnt + ntiles, cap);
             const bool packed = c->pair_sb != 0;
@@ -1771,7 +1771,115 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             ~BoGuard() { f(); }
         } bo_guard{bo_cleanup};
         bool bo_runs_valid = false;
-        for (int n = constrained ? std::max(1, o.minlength) : 1; n <= maxlength && !c->hstate.done; ++n) {
+        // ---- the benchmark's id-keeping modes (indexed model, exhaustive skipgrams; class-keyed second-generation order 2, no rarer option) with the order loop
+        // ENQUEUED, as the plain mode's is: every per-order quantity lives in DevState (idm_ngram_end / idm_order_end / skip_pass_end), the host looks once, after
+        // the last order (north star: "no host round-trip per iteration"; reference loop: include/patternmodel.h:981-1270, skipgram call site :1163-1171)
+        bool enq = bi2_synced && !getenv("COLIBRI_SYNCED_LOOP");
+        if (enq && o.doskipgrams_exhaustive) {  // the skipgram passes of ALL orders share one device log: a run that may reach orders with thousands of masks keeps the per-order loop
+            size_t total = 0;
+            for (int n = 3; n <= maxlength && total <= kSegLogCap; ++n) total += n > 16 ? (size_t)kSegLogCap + 1 : gap_masks(n, o.maxskips).size();
+            enq = total <= kSegLogCap;
+        }
+        if (enq) {
+            c->ids1_is_cls = !o.indexed;
+            const uint32_t nclasses = c->maxclass + 1;
+            if ((rc = dev_alloc(c, c->cnt1, (size_t)nclasses + 1)) || (rc = dev_alloc(c, c->rep1, (size_t)nclasses + 1)) || (rc = dev_alloc(c, c->uni_resid, (size_t)nclasses + 1)) ||
+                (rc = uni_alloc(c)))
+                return rc;
+            for (int n = 1; n <= maxlength; ++n)
+                if ((rc = dev_alloc(c, c->ids[n], (size_t)npos + 1))) return rc;
+            if (o.doskipgrams_exhaustive) {
+                if ((rc = dev_alloc(c, c->seglog, 4 + 5 * (size_t)kSegLogCap))) return rc;
+                HIP_TRY(c, hipMemsetAsync(c->seglog.p, 0, sizeof(uint32_t) * 4, c->stream));
+            }
+            size_t nlogged = 0;
+            int    nmax = 0;  // orders enqueued
+            for (int n = 1; n <= maxlength; ++n) {
+                nmax = n;
+                if (n == 1) {
+                    if ((rc = uni_count_partitioned(c, uni_range_shift(c), c->cnt1.p, nclasses))) return rc;
+                    {
+                        Prof p(c, COLIBRI_K_PRUNE);
+                        hipLaunchKernelGGL(uni_finish_kernel, dim3(stream_grid(nclasses)), dim3(kBlock), 0, c->stream, c->cnt1.p, (const uint32_t*)nullptr, nclasses, pl.thr, c->state.p,
+                                           c->res_rep.p, c->res_cnt.p, pl.res_cap, reinterpret_cast<uint16_t*>(c->uni_surv.p), /*count_valid=*/!o.indexed, c->uni_resid.p);
+                    }
+                    if (!c->ids1_is_cls) {
+                        Prof p(c, COLIBRI_K_RESOLVE);
+                        hipLaunchKernelGGL(uni_resid_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_resid.p, c->ids[1].p, c->state.p, npos);
+                    }
+                } else if (n == 2) {
+                    if ((rc = bigram2_order(c, pl, /*want_list=*/true, c->ids[2].p))) return rc;
+                } else {
+                    if ((rc = binned_count_stage(c, pl, KeyNgram{c->ids[n - 1].p, n}, n, true, pl.thr, false, true, false, /*dense_code=*/true))) return rc;
+                    const BinnedIO io = binned_planes(c, pl, false);
+                    {
+                        Prof p(c, COLIBRI_K_PRUNE);
+                        hipLaunchKernelGGL(bin_kept_scan_kernel, dim3(kBins), dim3(kBlock), 0, c->stream, c->state.p, c->binstate.p, pl.res_cap);
+                        hipLaunchKernelGGL(compact_bins_kernel, dim3(1024), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, c->binstate.p, c->res_rep.p, c->res_cnt.p, pl.res_cap,
+                                           (const uint32_t*)c->alist[n & 1].p);
+                        hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
+                    }
+                    if ((rc = binned_resolve_stage(c, pl, c->ids[n].p, n, true, true, nullptr, 0u, /*prefill_ids=*/true, /*decode=*/true, kDecodeBaseOnDevice))) return rc;
+                }
+                hipLaunchKernelGGL(idm_ngram_end_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, n);
+                if (o.indexed && (rc = emit_pairs(c, pl, c->ids[n].p, false))) return rc;
+                if (o.doskipgrams_exhaustive && n >= 3) {  // patternmodel.h:1163-1171 -> computeskipgrams :1370-1527, for every admissible window: the order's own active list
+                    if (n > kMaxSkipgramTokens) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 31 tokens do not exist (a gap mask has 32 bits; set MAXLENGTH)");
+                    c->skl   = c->alist[n & 1].p;
+                    c->skl_n = c->alist_n.p + (n & 1);
+                    const std::vector<uint32_t> masks = gap_masks(n, o.maxskips);
+                    for (uint32_t mask : masks) {
+                        uint32_t f = 0, k = 0;
+                        if ((rc = skipgram_pass_radix(c, pl, n, mask, c->ids[n - 1].p, c->ids[n - 1].p, thr_skip, 0u, &f, &k, nullptr, 0, 0, 0, c->seglog.p))) return rc;
+                    }
+                    nlogged += masks.size();
+                }
+                hipLaunchKernelGGL(idm_order_end_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, n);
+                if ((n % 8) == 0 && n < maxlength) {  // peek at the termination flag only every 8 orders (MAXLENGTH defaults to 100)
+                    uint32_t done = 0;
+                    HIP_TRY(c, hipMemcpyAsync(&done, &c->state.p->done, sizeof done, hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    if (done) break;
+                }
+            }
+            std::vector<uint32_t> log(4 + 5 * nlogged, 0);
+            if (nlogged) HIP_TRY(c, hipMemcpyAsync(log.data(), c->seglog.p, sizeof(uint32_t) * log.size(), hipMemcpyDeviceToHost, c->stream));
+            if ((rc = read_state(c))) return rc;
+            if (c->hstate.radix_overflow == 4) {  // the second-generation order 2 could not hold this corpus: again, on the first-generation kernels
+                c->b2.disabled = true;
+                const int rc2  = colibri_train_once(c, &o, stats_out);
+                c->b2.disabled = false;
+                return rc2;
+            }
+            if (c->hstate.radix_overflow) {  // a bin outgrew its LDS table: the whole run again on the table path (loud, exact, rare)
+                colibri_options again = o;
+                again.table_mode      = 1;
+                return colibri_train_once(c, &again, stats_out);
+            }
+            s.maxn = (int32_t)c->hstate.maxn;
+            for (int n = 1; n <= std::min<int>(s.maxn, maxlength); ++n) {
+                s.found[n]     = c->hstate.s_found[n];
+                s.kept[n]      = c->hstate.s_kept[n];
+                s.admitted[n]  = c->hstate.s_admitted[n];
+                adm_n[n]       = c->hstate.s_admitted[n];
+                valid_n[n]     = c->hstate.s_valid[n];
+                ngram_first[n] = c->hstate.res_off[n];
+                ngram_kept[n]  = c->hstate.s_kept[n];
+                if (s.kept[n]) c->segments.push_back({c->hstate.res_off[n], c->hstate.s_kept[n], n, n == 1 ? kMaskFromClass : 0u});
+                for (size_t e = 0; e < nlogged && e < log[0]; ++e) {  // the order's skipgram passes, in the order they ran: their result ranges follow the n-grams'
+                    const uint32_t* x = log.data() + 4 + 5 * e;
+                    if ((int)x[2] != n) continue;
+                    s.found[n] += x[4];
+                    s.kept[n] += x[1];
+                    if (x[1]) c->segments.push_back({x[0], x[1], (int)x[2], x[3]});
+                }
+            }
+            if (s.maxn < maxlength && s.maxn + 1 < COLIBRI_MAX_ORDER) s.admitted[s.maxn + 1] = c->hstate.s_admitted[s.maxn + 1];  // (the order that found nothing still counted its windows: 0)
+            res_total = c->hstate.res_total;
+            (void)nmax;
+            if (c->ntokens) c->hstate.done = 0;  // (the passes that follow — skipgrams of an indexed model — write the host's copy of the state back: the loop's end is not theirs)
+        }
+        for (int n = constrained ? std::max(1, o.minlength) : 1; n <= maxlength && !c->hstate.done && !enq; ++n) {
             if ((rc = dev_alloc(c, c->ids[n], (size_t)npos + 1))) return rc;
             if (continued && c->cs.has_order(n)) {
                 // "Skipping n-grams, already in model" (patternmodel.h:983-995): nothing is counted; the windows that ARE patterns of the loaded model get

@@ -559,8 +559,12 @@ __global__ __launch_bounds__(kBlock) void skip_remap_ids_kernel(const uint32_t* 
 // Skipgram passes without a host round trip each (unindexed models): the pass's counters are reset and, at its end, logged and folded into the run's state on
 // the device; the host reads the log once per order. log[0] = entries so far; entry e = log[4 + 5 e ..]: first result, results, order, gap mask, distinct found.
 constexpr uint32_t kSegLogCap = 4096;
-__global__ void skip_pass_begin_kernel(DevState* __restrict__ st) { st->found = st->kept = st->admitted = st->valid = 0; }
+__global__ void skip_pass_begin_kernel(DevState* __restrict__ st) {
+    if (st->done) return;
+    st->found = st->kept = st->admitted = st->valid = 0;
+}
 __global__ void skip_pass_end_kernel(DevState* __restrict__ st, uint32_t* __restrict__ log, uint32_t n, uint32_t mask) {
+    if (st->done) return;
     const uint32_t e = log[0];
     if (e < kSegLogCap) {
         uint32_t* const x = log + 4 + 5 * (size_t)e;
@@ -1101,6 +1105,32 @@ __global__ void advance_kernel(DevState* __restrict__ st, int n, uint32_t table_
     st->found = st->kept = st->admitted = st->valid = 0;
 }
 
+// The id-keeping modes (forward index, skipgram passes) with their order loop enqueued like the plain mode's: idm_ngram_end closes the n-gram pass of order n
+// (figures, result range, "None found"), the skipgram passes of the order follow (skip_pass_begin / _end), idm_order_end decides whether order n + 1 can admit
+// anything and clears the counters.
+__global__ void idm_ngram_end_kernel(DevState* __restrict__ st, int n) {
+    if (st->done) return;
+    if (n < COLIBRI_MAX_ORDER) {
+        st->s_found[n]    = st->found;
+        st->s_kept[n]     = st->kept;
+        st->s_admitted[n] = st->admitted;
+        st->s_valid[n]    = st->valid;
+        st->res_off[n]    = st->res_total;
+    }
+    if (st->found == 0) {  // reference: "None found" -> break (patternmodel.h:1189-1194)
+        st->done = 1;
+        return;
+    }
+    st->maxn = (uint32_t)n;
+    st->res_total += st->kept;
+    if (n + 1 <= COLIBRI_MAX_ORDER) st->res_off[n + 1] = st->res_total;
+}
+__global__ void idm_order_end_kernel(DevState* __restrict__ st, int n) {
+    if (st->done) return;
+    if (n < COLIBRI_MAX_ORDER && st->s_valid[n] == 0) st->done = 1;  // nothing can be admitted at n + 1
+    st->found = st->kept = st->admitted = st->valid = 0;
+}
+
 // =================================================================================================
 // 5. export: survivors (representative position, order, count) -> key bytes
 //    replaces Pattern::write / BaseValueHandler::write over the map (pattern.cpp:268-277, datatypes.h:219-221)
@@ -1274,7 +1304,12 @@ __device__ __forceinline__ uint32_t pair_block_scan(uint32_t c, uint32_t* total)
 // this pass (which = the one to read); chain[2]: set when the pairs outgrew `cap` (the count goes on, the writes stop: the host then knows how much room
 // the model needs). (A one-sweep version with a decoupled look-back over the 12.8 K tiles was 2 x slower: too few tiles in flight to hide the chain.)
 constexpr int kChainHead = 3;
-__global__ __launch_bounds__(kPairThreads) void emit_count_kernel(const uint32_t* __restrict__ ids, uint32_t npos, uint32_t* __restrict__ blockcnt) {
+__global__ __launch_bounds__(kPairThreads) void emit_count_kernel(const uint32_t* __restrict__ ids, uint32_t npos, uint32_t* __restrict__ blockcnt,
+                                                                   const DevState* __restrict__ st = nullptr /* optional: an enqueued run that is over (st->done) emits nothing */) {
+    if (st != nullptr && st->done) {
+        if (threadIdx.x == 0) blockcnt[blockIdx.x] = 0;
+        return;
+    }
     uint32_t v[kPairPer], c = 0;
     pair_load(ids, npos, blockIdx.x * kPairTile + threadIdx.x * kPairPer, v);
 #pragma unroll

@@ -236,6 +236,22 @@ def test_skipgrams_of_patterns_beyond_13_tokens(ctx, mode):
         assert st.maxn == 17
 
 
+@pytest.mark.parametrize("mode", [dict(indexed=1), dict(doskipgrams_exhaustive=1), dict(indexed=1, doskipgrams=1), dict(doskipgrams_exhaustive=1, mintokens_skipgrams=3)],
+                         ids=["indexed", "exhaustive", "indexed-skipgrams", "exhaustive-y3"])
+@pytest.mark.parametrize("name", ["zipf200k_phrases", "zipf20k", "rand_noempty", "repeat", "one_token", "empty"])
+def test_enqueued_and_per_order_loops_of_the_id_keeping_modes_agree(ctx, name, mode, monkeypatch):
+    """round 3: the id-keeping modes run their order loop enqueued on the device like the plain mode (no look at the device per order); COLIBRI_SYNCED_LOOP keeps
+    the per-order loop of rounds 1-2. Both against the oracle, every statistic included."""
+    payload = small_corpora()[name]
+    for maxlength in (5, 3, 8):
+        monkeypatch.delenv("COLIBRI_SYNCED_LOOP", raising=False)
+        a = _compare(ctx, payload, maxlength, **mode)
+        monkeypatch.setenv("COLIBRI_SYNCED_LOOP", "1")
+        b = _compare(ctx, payload, maxlength, **mode)
+        assert [a.admitted[n] for n in range(1, 10)] == [b.admitted[n] for n in range(1, 10)]
+    monkeypatch.delenv("COLIBRI_SYNCED_LOOP", raising=False)
+
+
 def test_skipgrams_rejected_when_corpus_has_literal_skip_tokens(ctx):
     from colibri_amd import capi
     ctx.upload(b"\x06\x03\x07\x00\x06\x03\x07\x00")

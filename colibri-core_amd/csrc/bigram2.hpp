@@ -19,6 +19,9 @@
 // Results (representative position + count per surviving bigram) go to the same result arrays as every other order.
 // Anything this path cannot hold (a slot, a final bin's LDS table) raises Bi2State::overflow; the host then re-runs on the first-generation kernels.
 #pragma once
+#ifndef COLIBRI_BI2_HUGE
+#define COLIBRI_BI2_HUGE 16384
+#endif
 #include "binned.hpp"
 
 namespace colibri {
@@ -59,7 +62,9 @@ constexpr uint32_t kBi2Empty    = 0xFFFFFFFFu;            // keys are 31 bits
 constexpr int      kBi2HeadSplit = 32;                    // row groups of the head reduction
 constexpr int      kBi2BmThreads = 1024;                  // bitmap kernels: one block per position bucket
 constexpr uint32_t kBi2BigBin    = 1536;                  // records from which a final bin counts as big
-constexpr int      kBi2BigCap    = 8192;
+constexpr uint32_t kBi2HugeBin   = COLIBRI_BI2_HUGE;      // ... and as huge: counted by a workgroup (bi2_count_big_kernel), not by a wave
+constexpr int      kBi2HugeCap   = 4096;
+constexpr int      kBi2BigCap    = 32768;                 // (a 10^9-token corpus counted in 8 key slices: ~7000 per slice)
 
 struct Bi2State {
     uint32_t curA[kBi2MaxSlots];  // emit cursors = records per slot (beyond `region`: overflow)
@@ -72,13 +77,14 @@ struct Bi2State {
     uint32_t headsurv[kBi2HeadN / 32];                   // bit k = head bigram k survived
     uint32_t headbase[kBlock];                           // first result rank of the head survivors of lane t (16 head keys per lane)
     uint32_t pcur[kBi2Shards * kBi2Buckets];             // position-list cursors
-    uint32_t nrec, bshift, overflow, kept_bins, kept_head, nbig;
+    uint32_t nrec, bshift, overflow, kept_bins, kept_head, nbig, nhuge;
     uint32_t kbits;     // key bits below the slice bits (K - s): A bin = bits [kbits-1 : kbits-8], B bin = the nine below
     uint32_t posbits;   // position bits of a record
     uint32_t res_base;  // first result index of this pass's survivors (an order counted in slices appends pass after pass)
     uint32_t nextchunk;                 // owner passes of key-sharded runs: next free chunk of the position-list pool (bi2_count_kernel<.., BASED>)
     uint32_t nextbin[kBi2Shards * 16];  // work queues of the count kernel (one per shard, 64 bytes apart): next group of bins to hand out
     uint32_t big[kBi2BigCap];           // final bins with more than kBi2BigBin records: counted first (one wave each), so that none of them starts late
+    uint32_t huge[kBi2HugeCap];         // ... with more than kBi2HugeBin records: one workgroup each
 };
 
 // exclusive scan of 256 LDS values by the first 256 threads of a block of any size; every thread of the block must call it
@@ -533,6 +539,10 @@ __global__ __launch_bounds__(kBi2BBins) void bi2_binoff_kernel(Bi2State* __restr
             t += bo[b + 1] - bo[b];
         }
     inL[b] = t;
+    if (t > kBi2HugeBin) {
+        const uint32_t k = atomicAdd(&bs->nhuge, 1u);
+        if (k < (uint32_t)kBi2HugeCap) bs->huge[k] = a * kBi2BBins + b;
+    }
     if (t > kBi2BigBin) {
         const uint32_t k = atomicAdd(&bs->nbig, 1u);
         if (k < (uint32_t)kBi2BigCap) bs->big[k] = a * kBi2BBins + b;
@@ -644,7 +654,8 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
                                                               uint32_t* __restrict__ wlist, uint32_t* __restrict__ wcnt, uint32_t wcap, bool want_positions,
                                                               uint32_t* __restrict__ wcode = nullptr /* optional, beside wlist: (final bin << 10) | rank of the window's key among the
                                                                                                         bin's survivors — what bi2_ids_kernel turns into the window's RESULT index */,
-                                                              const uint32_t* __restrict__ slotbase = nullptr) {
+                                                              const uint32_t* __restrict__ slotbase = nullptr,
+                                                              bool big_elsewhere = false /* bi2_count_big_kernel has counted the huge bins */) {
     if (st->done) return;
     static_assert(3 * NSUB + 1 <= kWave, "bound loaders are lanes of the wave");
     __shared__ __attribute__((aligned(16))) uint32_t keyT[kBi2Slots];
@@ -660,6 +671,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
     uint32_t        cursor = (want_positions && !BASED) ? wcnt[wid] : 0u;  // entries in this wave's position list (wave-uniform); the passes of a sliced order append
     uint32_t        chunk  = kInvalid;                                      // BASED: the chunk being filled (cursor = entries in it)
     bool            lost   = false;  // the list ran out of room
+    const bool      skip_huge = big_elsewhere && bs->nhuge <= (uint32_t)kBi2HugeCap;  // bi2_count_big_kernel has counted those
 #ifdef BI2_PROF
     unsigned long long tacc[12] = {0}, tlast = wall_clock64();
 #define BI2_W(k) do { const unsigned long long t_ = wall_clock64(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
@@ -687,7 +699,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
         }
         const uint32_t spo = (uint32_t)__builtin_amdgcn_readlane((int)v, 2 * NSUB);
         BI2_W(1);
-        if (total == 0 || (!big_pass && skip_big && total > kBi2BigBin)) return;
+        if (total == 0 || (!big_pass && skip_big && total > kBi2BigBin) || (skip_huge && total > kBi2HugeBin)) return;
         auto locate = [&](uint32_t j) -> size_t {  // record j (< total) of the bin -> its index in recsB
             uint32_t off = 0, slot = 0, sbase = 0;
             bool     ok  = false;
@@ -842,11 +854,12 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
             if (valid) c = cntT[s];
             const bool     kept = (c & kBi2Kept) != 0;
             const uint32_t r    = c & ~kBi2Kept;
-            if (kept) {
-                if (reps_lds)
-                    atomicMin(&repS[r], pos);
-                else
+            if (kept) {  // (read first: a hot key's windows all aim at one word, and after the first rows hardly any of them lowers it)
+                if (reps_lds) {
+                    if (pos < repS[r]) atomicMin(&repS[r], pos);
+                } else if (pos < __hip_atomic_load(&sp_rep[spo + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     atomicMin(&sp_rep[spo + r], pos);
+                }
             }
             if (want_positions) {
                 const uint64_t m = __ballot(kept);
@@ -941,6 +954,233 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
         if (want_positions && chunk != kInvalid && lane == 0) wcnt[chunk] = cursor;
     } else if (want_positions && lane == 0) {
         wcnt[wid] = min(cursor, wcap);
+    }
+    if (__any(lost) && lane == 0) bs->overflow = 3;
+}
+
+// The huge final bins (more than kBi2HugeBin records: a hot key outside the dense head), one WORKGROUP each. A wave that owns such a bin alone streams it four
+// rows at a time with four more in flight — 2 KB per memory round trip: the hottest bigram of a 10^9-token corpus (~76 000 windows) kept one wave busy for ~2 ms
+// while the kernel's other 4095 waves needed 0.9 ms for everything else (measured: 16.5 ms of count kernels per step with the big bins, 7.0 ms without). Here
+// eight waves share the bin's LDS table (same buckets, same compare-and-swap insert, same ranks) and keep 32 rows in flight. Runs BEFORE bi2_count_kernel
+// (launched with big_elsewhere = true): the position lists of this kernel's waves (list g = block * 8 + wave, or chunks of the pool) are simply continued there.
+constexpr int kBi2BigThreads = 512, kBi2BigRows = 8;  // (rows of 512 records a block keeps in flight)
+// A big final bin is big because of ONE hot key, and a row of 64 records of that key is 64 atomics on one LDS word, executed one after the other. The lanes whose
+// key equals the key of the row's first active lane stand back (act = false) and that lane counts for all of them (weight): one atomic per row for the hot key.
+__device__ __forceinline__ void bi2_merge_leader(bool& act, uint32_t key, uint32_t& weight, uint32_t lane) {
+    weight                 = 1u;
+    const uint64_t actives = __ballot(act);
+    if (actives == 0) return;
+    const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)key, __builtin_amdgcn_readfirstlane(__ffsll((long long)actives) - 1));
+    const bool     same = act && key == lead;
+    const uint64_t m    = __ballot(same);
+    const uint32_t n    = (uint32_t)__popcll(m);
+    if (n >= 4u && same) {
+        if (lane == (uint32_t)(__ffsll((long long)m) - 1))
+            weight = n;
+        else
+            act = false;
+    }
+}
+template <int NSUB, bool BASED = false>
+__global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const uint32_t* __restrict__ boff, Bi2State* __restrict__ bs,
+                                                                       DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
+                                                                       uint32_t* __restrict__ wlist, uint32_t* __restrict__ wcnt, uint32_t wcap, bool want_positions,
+                                                                       uint32_t* __restrict__ wcode, const uint32_t* __restrict__ slotbase) {
+    if (st->done) return;
+    const uint32_t nbig = bs->nhuge;
+    if (nbig == 0 || nbig > (uint32_t)kBi2HugeCap) return;  // (more than the list holds: bi2_count_kernel walks every bin itself)
+    constexpr int                                    kW = kBi2BigThreads / kWave;
+    __shared__ __attribute__((aligned(16))) uint32_t keyT[kBi2Slots];
+    __shared__ __attribute__((aligned(16))) uint32_t cntT[kBi2Slots];
+    __shared__ uint32_t                              repS[kBi2WReps];
+    __shared__ uint32_t                              rsL[NSUB], rnL[NSUB], sbL[NSUB], wsumL[kW], failL;
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), g = blockIdx.x * kW + tid / kWave;
+    const uint32_t pb = bs->posbits;
+    const unsigned long long pmask = (1ull << pb) - 1;
+    uint32_t* const mylist = wlist + (size_t)g * wcap;
+    uint32_t* const mycode = wcode != nullptr ? wcode + (size_t)g * wcap : nullptr;
+    uint32_t        cursor = (want_positions && !BASED) ? wcnt[g] : 0u;
+    uint32_t        chunk  = kInvalid;
+    bool            lost   = false;
+    constexpr int      lgb   = 8;  // kBi2Slots / 4 buckets: a big bin always takes the whole table
+    constexpr uint32_t bmask = (1u << lgb) - 1u;
+    static_assert(kBi2Slots == 1024 && kBi2BigBin + (kBi2BigBin >> 1) >= kBi2Slots, "big bins use all 256 buckets, as they do in bi2_count_kernel");
+    for (uint32_t k = blockIdx.x; k < nbig; k += gridDim.x) {
+        const uint32_t f = bs->huge[k], a = f / kBi2BBins, b = f % kBi2BBins;
+        __syncthreads();  // the bin before is done with the tables
+        if (tid < (uint32_t)NSUB) {
+            const uint32_t* bo = boff + (size_t)(tid * kBins + a) * (kBi2BBins + 1) + b;
+            rsL[tid]           = bo[0];
+            rnL[tid]           = bo[1] - bo[0];
+            sbL[tid]           = BASED ? slotbase[tid * kBins + a] : 0u;
+        }
+        if (tid == 0) failL = 0;
+        for (uint32_t s = tid; s < (uint32_t)kBi2Slots; s += kBi2BigThreads) {
+            keyT[s] = kBi2Empty;
+            cntT[s] = 0u;
+        }
+        __syncthreads();
+        uint32_t rs[NSUB], rn[NSUB], sb[NSUB], total = 0;
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            rs[s] = rsL[s];
+            rn[s] = rnL[s];
+            sb[s] = sbL[s];
+            total += rn[s];
+        }
+        const uint32_t spo    = bs->binoff[a * kBi2BBins + b];
+        auto           locate = [&](uint32_t j) -> size_t {
+            uint32_t off = 0, slot = 0, sbase = 0;
+            bool     ok  = false;
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) {
+                if (!ok && j < rn[s]) {
+                    ok    = true;
+                    off   = rs[s] + j;
+                    slot  = (uint32_t)s * kBins + a;
+                    sbase = sb[s];
+                }
+                if (!ok) j -= rn[s];
+            }
+            return BASED ? (size_t)sbase + off : (size_t)slot * region + off;
+        };
+        unsigned long long y[kBi2BigRows];
+        auto               load4 = [&](uint32_t j0) {
+#pragma unroll
+            for (int q = 0; q < kBi2BigRows; ++q) {
+                const uint32_t j = j0 + q * kBi2BigThreads + tid;
+                y[q]             = j < total ? recsB[locate(j)] : ~0ull;
+            }
+        };
+        // pass 1: find or insert, count
+        bool fail = false;
+        for (uint32_t j0 = 0; j0 < total; j0 += kBi2BigRows * kBi2BigThreads) {
+            load4(j0);
+#pragma unroll
+            for (int q = 0; q < kBi2BigRows; q += 2) {
+                bool           actA = y[q] != ~0ull, actB = y[q + 1] != ~0ull;
+                const uint32_t keyA = (uint32_t)(y[q] >> pb) & 0x7FFFFFFFu, keyB = (uint32_t)(y[q + 1] >> pb) & 0x7FFFFFFFu;
+                uint32_t       wA, wB;
+                bi2_merge_leader(actA, keyA, wA, lane);
+                bi2_merge_leader(actB, keyB, wB, lane);
+                const uint32_t bkA = bi2_bucket_of(keyA, lgb, bmask), bkB = bi2_bucket_of(keyB, lgb, bmask);
+                uint32_t       tA, tB;
+                bi2_insert2(keyT, bmask, actA, keyA, bkA, *reinterpret_cast<const uint4*>(keyT + bkA * 4), tA, actB, keyB, bkB, *reinterpret_cast<const uint4*>(keyT + bkB * 4), tB);
+                if (actA) {
+                    if (tA == kInvalid)
+                        fail = true;
+                    else
+                        atomicAdd(&cntT[tA], wA);
+                }
+                if (actB) {
+                    if (tB == kInvalid)
+                        fail = true;
+                    else
+                        atomicAdd(&cntT[tB], wB);
+                }
+            }
+        }
+        if (fail) failL = 1;
+        __syncthreads();
+        if (failL) {
+            if (tid == 0) bs->overflow = 2;
+            continue;
+        }
+        // survivors: thread t looks at the two slots from 2 t — ranks in slot order, as in bi2_count_kernel
+        constexpr uint32_t per = kBi2Slots / kBi2BigThreads;
+        static_assert(per == 2, "two slots per thread");
+        const uint32_t s0 = tid * per;
+        const uint32_t k0 = keyT[s0], k1 = keyT[s0 + 1], c0 = cntT[s0], c1 = cntT[s0 + 1];
+        uint32_t       distinct, ktotal;
+        const uint32_t excl = bi2_block_scan<kBi2BigThreads>((c0 >= threshold) + (c1 >= threshold), &ktotal, wsumL);
+        bi2_block_scan<kBi2BigThreads>((k0 != kBi2Empty) + (k1 != kBi2Empty), &distinct, wsumL);
+        if (distinct > kBi2MaxLoad) {
+            if (tid == 0) bs->overflow = 2;
+            continue;
+        }
+        if (tid == 0) {
+            atomicAdd(&bs->found_part[a], distinct);
+            bs->binkept[a * kBi2BBins + b] = ktotal;
+            if (ktotal) atomicAdd(&bs->kept_part[a], ktotal);
+        }
+        if (ktotal == 0) continue;
+        const bool reps_lds = ktotal <= (uint32_t)kBi2WReps;
+        {
+            uint32_t       r     = excl;
+            const uint32_t c2[2] = {c0, c1};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (c2[i] >= threshold) {
+                    sp_cnt[spo + r] = c2[i];
+                    cntT[s0 + i]    = kBi2Kept | r;
+                    if (reps_lds)
+                        repS[r] = 0xFFFFFFFFu;
+                    else
+                        sp_rep[spo + r] = 0xFFFFFFFFu;
+                    ++r;
+                }
+            }
+        }
+        if (!reps_lds) __threadfence();
+        __syncthreads();
+        // pass 2: every window of a surviving key: lowest position of the key; the position joins the wave's list
+        const uint32_t fcode = (a * (uint32_t)kBi2BBins + b) << 10;
+        for (uint32_t j0 = 0; j0 < total; j0 += kBi2BigRows * kBi2BigThreads) {
+            load4(j0);
+#pragma unroll
+            for (int q = 0; q < kBi2BigRows; ++q) {
+                if (j0 + q * kBi2BigThreads + (tid & ~(uint32_t)(kWave - 1)) >= total) continue;  // (wave-uniform)
+                const bool     valid = y[q] != ~0ull;
+                const uint32_t key = (uint32_t)(y[q] >> pb) & 0x7FFFFFFFu, pos = (uint32_t)(y[q] & pmask);
+                uint32_t       c = 0;
+                if (valid) c = cntT[bi2_find(keyT, key, bi2_bucket_of(key, lgb, bmask), bmask)];
+                const bool     kept = (c & kBi2Kept) != 0;
+                const uint32_t r    = c & ~kBi2Kept;
+                if (kept) {
+                    if (reps_lds) {
+                        if (pos < repS[r]) atomicMin(&repS[r], pos);
+                    } else if (pos < __hip_atomic_load(&sp_rep[spo + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        atomicMin(&sp_rep[spo + r], pos);
+                    }
+                }
+                if (want_positions) {
+                    const uint64_t m = __ballot(kept);
+                    const uint32_t n = (uint32_t)__popcll(m);
+                    if (BASED) {
+                        if (n && (chunk == kInvalid || cursor + n > kBi2Chunk)) {
+                            if (chunk != kInvalid && lane == 0) wcnt[chunk] = cursor;
+                            uint32_t cc = 0;
+                            if (lane == 0) cc = atomicAdd(&bs->nextchunk, 1u);
+                            cc     = (uint32_t)__builtin_amdgcn_readfirstlane((int)cc);
+                            chunk  = cc < wcap ? cc : kInvalid;
+                            cursor = 0;
+                            if (chunk == kInvalid) lost = true;
+                        }
+                        if (kept && chunk != kInvalid) wlist[(size_t)chunk * kBi2Chunk + cursor + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pos;
+                        if (chunk != kInvalid) cursor += n;
+                    } else {
+                        if (kept) {
+                            const uint32_t at = cursor + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                            if (at < wcap) {
+                                mylist[at] = pos;
+                                if (mycode != nullptr) mycode[at] = fcode | r;
+                            } else {
+                                lost = true;
+                            }
+                        }
+                        cursor += n;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (reps_lds)
+            for (uint32_t r = tid; r < ktotal; r += kBi2BigThreads) sp_rep[spo + r] = repS[r];
+    }
+    if (BASED) {
+        if (want_positions && chunk != kInvalid && lane == 0) wcnt[chunk] = cursor;
+    } else if (want_positions && lane == 0) {
+        wcnt[g] = min(cursor, wcap);
     }
     if (__any(lost) && lane == 0) bs->overflow = 3;
 }

@@ -38,6 +38,9 @@ constexpr int      kScatTile   = COLIBRI_SCAT_TILE;  // records per scatter tile
 constexpr int      kScatPer    = kScatTile / kBlock; // 8 per lane (2048-record tiles: 32 KB of staging, 4 blocks per CU — 4096 ran 0.4 ms slower per order-2 pass)
 constexpr int      kBinSlots   = 2048;               // LDS table of one final bin
 constexpr uint32_t kBinMaxLoad = 1900;               // distinct keys a final bin may hold
+constexpr uint32_t kBinBigBin  = 4096;               // records from which a final bin counts as big (twice what the count kernel holds in registers)
+constexpr int      kBinBigCap  = 4096;
+constexpr int      kBinQueues  = 8;
 
 // small device-side bookkeeping of one binned pass
 struct BinState {
@@ -56,6 +59,11 @@ struct BinState {
     uint32_t found_part[kBins];  // distinct keys, accumulated per A bin (a single counter would serialise 65 536 atomics)
     uint32_t kept_part[kBins];   // survivors, accumulated per A bin
     uint32_t res_base;           // first result index of this pass's survivors (written by bin_kept_scan_kernel)
+    uint32_t nbig;               // final bins with more than kBinBigBin records (hot keys): listed by bin_scan2_kernel, counted first by bin_count_body
+    uint32_t big[kBinBigCap];
+    uint32_t nextbin[kBinQueues * 16];  // the count kernel's bin queues (one counter per 64 bytes)
+    uint32_t walk_mode;          // (experiments) 1 / 2: the count kernel walks the bins in a fixed order per block / takes them from the queues, whatever their sizes
+    uint32_t maxbin;             // records of the largest final bin (bin_scan2_kernel)
 };
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -317,6 +325,11 @@ __global__ __launch_bounds__(kBlock) void bin_scan2_kernel(BinState* __restrict_
     const uint32_t o = block_exclusive_scan(h, &tot);
     bs->hist2[a * kBins + threadIdx.x] = before + o;
     if (a == kBins - 1 && threadIdx.x == 0) bs->total2 = before + tot;
+    if (h > kBinBigBin) {
+        const uint32_t k = atomicAdd(&bs->nbig, 1u);
+        if (k < (uint32_t)kBinBigCap) bs->big[k] = a * kBins + threadIdx.x;
+        atomicMax(&bs->maxbin, h);
+    }
 }
 
 // level B: tile-local counting sort + one reserved output run per (tile, sub-bin), inside each A region
@@ -440,6 +453,8 @@ __device__ __forceinline__ uint32_t bin_insert(const bool valid, const Rec& x, u
 }
 
 constexpr int kBinRegPer = 8;  // records per lane held in registers: bins of up to 2048 records are read from HBM exactly once
+constexpr int kBinStream = 8;  // rows of 256 records in flight while a bigger bin streams the rest (one row per memory round trip: the hottest trigram of a 10^9-token
+                               // corpus — ~200 000 records, one per emit tile — held its block for ~2.6 ms of a 2.8 ms kernel)
 
 // MERGE = the owner-side merge of a sharded pass: the "positions" are indices into the received candidate list, counts may be
 // wide, and instead of sparse result arrays the bin leaves, per candidate of a surviving key, (f << 11 | rank of the key among
@@ -483,12 +498,18 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
         sl[q]            = kInvalid;
         if (begin + q * kBlock < end) sl[q] = bin_insert(j < end, xr[q], keyT, cntT, repT, smask, nslots, nnew, failL, MERGE ? wide : nullptr);  // block-uniform guard
     }
-    const uint32_t rest = begin + kBinRegPer * kBlock;  // bins larger than the register window (hot bins) stream the remainder
-    for (uint32_t j0 = rest; j0 < end; j0 += kBlock) {
-        const uint32_t j = j0 + threadIdx.x;
-        Rec            x{};
-        if (j < end) x = recs[j];
-        bin_insert(j < end, x, keyT, cntT, repT, smask, nslots, nnew, failL, MERGE ? wide : nullptr);
+    const uint32_t rest = begin + kBinRegPer * kBlock;  // bins larger than the register window (hot bins) stream the remainder, kBinStream rows in flight
+    for (uint32_t j0 = rest; j0 < end; j0 += kBinStream * kBlock) {
+        Rec x[kBinStream];
+#pragma unroll
+        for (int q = 0; q < kBinStream; ++q) {
+            const uint32_t j = j0 + q * kBlock + threadIdx.x;
+            x[q]             = Rec{};
+            if (j < end) x[q] = recs[j];
+        }
+#pragma unroll
+        for (int q = 0; q < kBinStream; ++q)
+            if (j0 + q * kBlock < end) bin_insert(j0 + q * kBlock + threadIdx.x < end, x[q], keyT, cntT, repT, smask, nslots, nnew, failL, MERGE ? wide : nullptr);  // block-uniform guard
     }
     // distinct keys of this bin
     for (int off = 32; off > 0; off >>= 1) nnew += __shfl_down(nnew, off, kWave);
@@ -560,18 +581,30 @@ __device__ __forceinline__ void bin_count_one(const uint32_t f, const uint32_t b
             }
         }
     }
-    for (uint32_t j = rest + threadIdx.x; j < end; j += kBlock) {
-        const Rec x = recs[j];
-        uint32_t  s = (uint32_t)mix64(x.key) & smask;
-        while (keyT[s] != x.key) s = (s + 1) & smask;
-        const uint32_t id = idT[s];
-        if (id != kInvalid) {
-            if (REPLY)
-                reinterpret_cast<unsigned long long*>(ids_at)[j] = (unsigned long long)x.pos | ((unsigned long long)id << 32);
-            else if (!MERGE && flags_at != nullptr)
-                flags_at[x.pos] = 1;
-            else
-                ids_at[x.pos] = (MERGE && x.pos == repT[s]) ? (id | kExportBitR) : id;
+    for (uint32_t j0 = rest; j0 < end; j0 += kBinStream * kBlock) {
+        Rec x[kBinStream];
+#pragma unroll
+        for (int q = 0; q < kBinStream; ++q) {
+            const uint32_t j = j0 + q * kBlock + threadIdx.x;
+            x[q]             = Rec{};
+            if (j < end) x[q] = recs[j];
+        }
+#pragma unroll
+        for (int q = 0; q < kBinStream; ++q) {
+            const uint32_t j = j0 + q * kBlock + threadIdx.x;
+            if (j < end) {
+                uint32_t s = (uint32_t)mix64(x[q].key) & smask;
+                while (keyT[s] != x[q].key) s = (s + 1) & smask;
+                const uint32_t id = idT[s];
+                if (id != kInvalid) {
+                    if (REPLY)
+                        reinterpret_cast<unsigned long long*>(ids_at)[j] = (unsigned long long)x[q].pos | ((unsigned long long)id << 32);
+                    else if (!MERGE && flags_at != nullptr)
+                        flags_at[x[q].pos] = 1;
+                    else
+                        ids_at[x[q].pos] = (MERGE && x[q].pos == repT[s]) ? (id | kExportBitR) : id;
+                }
+            }
         }
     }
 }
@@ -585,19 +618,48 @@ __device__ __forceinline__ void bin_count_body(const Rec* __restrict__ recs, Dev
     __shared__ unsigned long long keyT[kBinSlots];
     __shared__ uint32_t           cntT[kBinSlots], repT[kBinSlots], idT[kBinSlots];
     __shared__ uint32_t           redL[kBlock / kWave], failL;
-    // persistent blocks walk the final bins. Small orders use only the first (256 >> bshift) sub-bins of every A bin, i.e. the
-    // non-empty bins are f = a * 256 + b with b small: walked in f order, they would all land on the few blocks with
-    // blockIdx = a * 256 mod gridDim (12 of 3072), 21 bins in a row each — 0.2 ms of serial latency per order. Walking the
-    // transposed index (a fastest) hands consecutive non-empty bins to consecutive blocks.
-    for (uint32_t g = blockIdx.x; g < (uint32_t)kFinalBins; g += gridDim.x) {
-        const uint32_t f     = ((g & (uint32_t)(kBins - 1)) << 8) | (g >> 8);
+    __shared__ uint32_t           nextL;
+    auto one = [&](const uint32_t f, const bool big_pass, const bool skip_big) {
         const uint32_t begin = bs->hist2[f];
         const uint32_t end   = (f + 1 < (uint32_t)kFinalBins) ? bs->hist2[f + 1] : bs->total2;
-        if (begin >= end) continue;
+        if (begin >= end || (!big_pass && skip_big && end - begin > kBinBigBin)) return;  // (block-uniform)
         bin_count_one<MERGE, REPLY>(f, begin, end, recs, st, bs, threshold, sp_rep, sp_cnt, sp_key, ids_at, keyT, cntT, repT, idT, redL, &failL, wide, cnt_at, flags_at, dense_code, idtag);
         __syncthreads();
+    };
+    // the big bins first (a hot key: one record per emit tile, ~200 000 records for the hottest trigram of 10^9 tokens), so that none of them starts when the
+    // other blocks are about to finish; then the rest, handed out dynamically — the block that drew a big bin simply takes fewer of the others
+    const uint32_t nbig     = bs->nbig;
+    const bool     skip_big = nbig <= (uint32_t)kBinBigCap;  // (more big bins than the list holds: the walk below takes them all)
+    if (skip_big)
+        for (uint32_t k = blockIdx.x; k < nbig; k += gridDim.x) one(bs->big[k], true, true);
+    // persistent blocks walk the final bins, eight at a time from kBinQueues queues (queue q = the walk indices g with g mod 8 == q). Small orders use only the
+    // first (256 >> bshift) sub-bins of every A bin, i.e. the non-empty bins are f = a * 256 + b with b small: the walk index is the transposed one
+    // (a fastest), so that consecutive non-empty bins go to different blocks.
+    // A fixed share per block (walk index g = block, block + grid, ...) is balanced to one bin and costs nothing; handing the bins out from queues costs ~40 us per
+    // launch at 100 M tokens (8192 tickets on 8 counters: measured 5.38 -> 5.50 ms per step) and pays only when one bin outweighs a block's whole share:
+    // the queues are used when the largest bin holds more than twice the records of an average share.
+    const uint32_t mode = bs->walk_mode;
+    if (mode == 1 || (mode == 0 && (unsigned long long)bs->maxbin * gridDim.x <= 2ull * bs->total2)) {
+        for (uint32_t g = blockIdx.x; g < (uint32_t)kFinalBins; g += gridDim.x) one(((g & (uint32_t)(kBins - 1)) << 8) | (g >> 8), false, skip_big);
+        return;
+    }
+    const uint32_t q = blockIdx.x & (uint32_t)(kBinQueues - 1);
+    if (threadIdx.x == 0) nextL = atomicAdd(&bs->nextbin[q * 16], 8u);
+    __syncthreads();
+    uint32_t t = nextL;
+    while (t * kBinQueues + q < (uint32_t)kFinalBins) {
+        __syncthreads();  // everybody has read nextL
+        if (threadIdx.x == 0) nextL = atomicAdd(&bs->nextbin[q * 16], 8u);  // the ticket after this one: on its way while these eight bins are counted
+#pragma unroll 1
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t g = (t + k) * kBinQueues + q;
+            if (g < (uint32_t)kFinalBins) one(((g & (uint32_t)(kBins - 1)) << 8) | (g >> 8), false, skip_big);
+        }
+        __syncthreads();
+        t = nextL;
     }
 }
+
 __global__ __launch_bounds__(kBlock) void bin_count_kernel(const Rec* __restrict__ recs, DevState* __restrict__ st, BinState* __restrict__ bs, uint32_t threshold,
                                                             uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt, unsigned long long* __restrict__ sp_key,
                                                             uint32_t* __restrict__ ids_at, uint8_t* __restrict__ flags_at = nullptr, bool dense_code = false) {

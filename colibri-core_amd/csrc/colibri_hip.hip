@@ -803,6 +803,8 @@ int binned_count_stage(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, int
     }
     const BinnedIO io = binned_planes(c, pl, with_keys);
     {
+        static const int walk_mode = getenv("COLIBRI_BIN_WALK") ? atoi(getenv("COLIBRI_BIN_WALK")) : 0;  // (experiments: 1 = fixed shares, 2 = queues; default: by the largest bin)
+        if (walk_mode) HIP_TRY(c, hipMemcpyAsync(&c->binstate.p->walk_mode, &walk_mode, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         Prof p(c, COLIBRI_K_BINCOUNT);
         hipLaunchKernelGGL(bin_count_kernel, dim3(256 * 12), dim3(kBlock), 0, c->stream, c->recs[1].p, c->state.p, c->binstate.p, thr, io.sp_rep, io.sp_cnt, io.sp_key, ids_at, flags_at, dense_code);
     }
@@ -936,8 +938,10 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
         }
         {
             Prof p(c, COLIBRI_K_COUNT2);
+            hipLaunchKernelGGL((bi2_count_big_kernel<(int)kBi2Sub>), dim3(kBi2Waves * kWave / kBi2BigThreads), dim3(kBi2BigThreads), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p,
+                               pl.thr, io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list, ids_out != nullptr ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr);
             hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr, io.sp_rep, io.sp_cnt,
-                               c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list, ids_out != nullptr ? c->b2.wcode.p : (uint32_t*)nullptr);
+                               c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list, ids_out != nullptr ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr, true);
         }
         {
             Prof p(c, COLIBRI_K_PRUNE);
@@ -966,6 +970,100 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
         hipLaunchKernelGGL(bi2_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, bs, c->b2.plist.p, b.pl, c->state.p, c->b2.bitmap.p);
         hipLaunchKernelGGL(bi2_list3_kernel, dim3(2048), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_surv.p, npos, c->b2.headsurv.p, c->b2.bitmap.p, c->state.p, c->alist[1].p, nlist, ids_out,
                            ids_out != nullptr ? (const uint32_t*)c->b2.headid.p : (const uint32_t*)nullptr);
+    }
+    return COLIBRI_OK;
+}
+
+// Order 2 of a corpus beyond one pass (more than ~110 M records: 10^9 tokens on one device), round 3: the windows are scanned ONCE and their records cut ONCE into 2^s key
+// slices (ks_split_*: the split of the multi-GPU protocol with the slices as "owners" and the sub-regions of the one source as "source ranks"); every slice then
+// runs level B and the count on its own dense segment. Rounds 1-2 re-scanned the corpus per slice (bi2_emit_sliced_kernel: 1.4 ms per pass on 10^9 positions,
+// 8 passes) and counted bins of ~810 records on the count kernel's streaming path. Plain mode only (no ids).
+constexpr uint32_t kSplitMaxBits = 3;
+bool bigram2_split_fits(const colibri_ctx* c, uint32_t npos) {
+    const Bigram2Plan b = bigram2_plan(c, npos);
+    return b.sbits >= 1 && b.sbits <= kSplitMaxBits && std::max(2u * b.clsbits, 17u + b.sbits) - 8 + b.posbits <= 64 && !getenv("COLIBRI_RESCAN_SLICES");
+}
+int bigram2_order_split(colibri_ctx* c, const TrainPlan& pl, bool want_list) {
+    const uint32_t    npos = pl.npos, nsurv = c->maxclass / 32 + 1;
+    const Bigram2Plan b    = bigram2_plan(c, npos);
+    const uint32_t    s    = b.sbits, V = 1u << s;
+    auto&             ks   = c->ks;
+    int               rc;
+    if ((rc = dev_alloc(c, ks.split, 1)) || (rc = dev_alloc(c, ks.obs, 1)) || (rc = dev_alloc(c, ks.slotbase, kKsSlots)) || (rc = dev_alloc(c, ks.oboff, (size_t)kKsSlots * (kBi2BBins + 1))) ||
+        (rc = dev_alloc(c, ks.lcnt, 64)))
+        return rc;
+    const uint32_t K       = std::max(2u * b.clsbits, 17u + s);
+    const uint32_t region  = (uint32_t)(2ull * c->recs[0].n / b.nslots);  // every record of the order at once: the emit kernel's regions are not cut down to a slice
+    // the count kernel's position lists: a pool of chunks with room for every position plus one partly filled chunk per wave (of either count kernel) and slice
+    if ((rc = dev_alloc(c, c->b2.wlist, (size_t)npos + ((size_t)V * 2 * kBi2Waves + 64) * kBi2Chunk))) return rc;
+    const uint32_t nchunks = (uint32_t)(c->b2.wlist.n / kBi2Chunk);
+    if ((rc = dev_alloc(c, c->b2.wcnt, std::max<size_t>(kBi2Waves, nchunks)))) return rc;
+    Bi2State* const sbs   = c->b2.state.p;
+    Bi2State* const obs   = ks.obs.p;
+    auto* const     recsA = reinterpret_cast<unsigned long long*>(c->recs[0].p);
+    auto* const     seg   = reinterpret_cast<unsigned long long*>(c->recs[1].p);        // the slices' segments (8 bytes x records) ...
+    auto* const     segB  = seg + c->recs[1].n;                                          // ... and their level-B output: the two halves of recs[1] (16 bytes x positions)
+    uint32_t* const nlist = c->alist_n.p + 1;
+    uint32_t* const keep  = ks.lcnt.p;  // the position-list pool's cursor between slices
+    HIP_TRY(c, hipMemsetAsync(nlist, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->b2.wcnt.p, 0, sizeof(uint32_t) * nchunks, c->stream));
+    HIP_TRY(c, hipMemsetAsync(keep, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(sbs, 0, sizeof(Bi2State), c->stream));
+    HIP_TRY(c, hipMemsetAsync(ks.split.p, 0, sizeof(KsSplitState), c->stream));
+    {
+        Prof p(c, COLIBRI_K_EMIT2);
+        hipLaunchKernelGGL(bi2_emit_kernel, dim3(kBi2EmitGrid), dim3(kBi2Threads), 0, c->stream, c->cls.p, c->uni_surv.p, nsurv, npos, b.clsbits, 0u, 0u, b.posbits, recsA, region, kBi2Sub, sbs,
+                           c->state.p, c->b2.head_rows.p, (uint8_t*)nullptr, K);
+        hipLaunchKernelGGL(bi2_head_reduce_kernel, dim3(kBi2HeadN / kBlock, kBi2HeadSplit), dim3(kBlock), 0, c->stream, c->b2.head_rows.p, kBi2EmitGrid, sbs, c->state.p);
+    }
+    {
+        Prof           p(c, COLIBRI_K_SCATTER);
+        const KsSplit8 sp{s, b.posbits + K - 8 - s, b.posbits, 0u};
+        hipLaunchKernelGGL((ks_split_hist_kernel<unsigned long long, KsSplit8>), dim3(kKsSlots), dim3(kKsThreads), 0, c->stream, (const unsigned long long*)recsA, region,
+                           (const uint32_t*)sbs->curA, sp, ks.split.p);
+        hipLaunchKernelGGL(ks_split_scan_kernel, dim3(1), dim3(kKsThreads), 0, c->stream, ks.split.p, s, V, (const DevState*)c->state.p);
+        hipLaunchKernelGGL((ks_split_move_kernel<unsigned long long, KsSplit8, 4>), dim3(kKsSlots), dim3(kKsThreads), 0, c->stream, (const unsigned long long*)recsA, region,
+                           (const uint32_t*)sbs->curA, sp, (const KsSplitState*)ks.split.p, seg);
+        hipLaunchKernelGGL(ks_split_flag_kernel, dim3(1), dim3(1), 0, c->stream, (const KsSplitState*)ks.split.p, c->state.p);
+    }
+    const BinnedIO io = binned_planes(c, pl, false);  // the sparse survivor arrays live in recs[0]: the emit kernel's regions are free once the split has moved them
+    for (uint32_t v = 0; v < V; ++v) {
+        HIP_TRY(c, hipMemsetAsync(obs, 0, sizeof(Bi2State), c->stream));
+        if (v == 0)  // the dense head was counted by the scan: it belongs to the first slice's figures
+            HIP_TRY(c, hipMemcpyAsync(obs->headcnt, sbs->headcnt, 2 * sizeof(uint32_t) * kBi2HeadN, hipMemcpyDeviceToDevice, c->stream));
+        {
+            Prof p(c, COLIBRI_K_LEVELB2);
+            hipLaunchKernelGGL(ks_local_init2_kernel, dim3(1), dim3(kKsThreads), 0, c->stream, obs, ks.slotbase.p, (const KsSplitState*)ks.split.p, v, s, K - s, b.posbits + s, (const uint32_t*)keep);
+            hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, obs, 0xFFFFFFFFu, kBi2Sub, (const DevState*)c->state.p);
+            hipLaunchKernelGGL(bi2_levelB_kernel, dim3(kKsSlots), dim3(kBi2Threads), 0, c->stream, (const unsigned long long*)seg, segB, 0xFFFFFFFFu, (const Bi2State*)obs, ks.oboff.p,
+                               (const DevState*)c->state.p, (const uint32_t*)ks.slotbase.p);
+            hipLaunchKernelGGL(bi2_binoff_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, obs, (const uint32_t*)ks.oboff.p, kBi2Sub, (const DevState*)c->state.p);
+        }
+        {
+            Prof p(c, COLIBRI_K_COUNT2);
+            hipLaunchKernelGGL((bi2_count_big_kernel<(int)kBi2Sub, true>), dim3(kBi2Waves * kWave / kBi2BigThreads), dim3(kBi2BigThreads), 0, c->stream, (const unsigned long long*)segB, 0u,
+                               (const uint32_t*)ks.oboff.p, obs, c->state.p, pl.thr, io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, nchunks, want_list, (uint32_t*)nullptr,
+                               (const uint32_t*)ks.slotbase.p);
+            hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub, true, 16>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, (const unsigned long long*)segB, 0u, (const uint32_t*)ks.oboff.p, obs,
+                               c->state.p, pl.thr, io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, nchunks, want_list, (uint32_t*)nullptr, (const uint32_t*)ks.slotbase.p, true);
+            hipLaunchKernelGGL(ks_keep_chunk_kernel, dim3(1), dim3(1), 0, c->stream, (const Bi2State*)obs, keep);
+        }
+        {
+            Prof p(c, COLIBRI_K_PRUNE);
+            hipLaunchKernelGGL(bi2_kept_scan_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, obs, c->state.p);
+            hipLaunchKernelGGL(bi2_finish_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->state.p, obs, pl.thr, pl.res_cap, v == 0 ? c->b2.headsurv.p : (uint32_t*)nullptr);
+            hipLaunchKernelGGL(bi2_compact_kernel, dim3(1025), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, obs, c->res_rep.p, c->res_cnt.p, pl.res_cap);
+        }
+    }
+    if (!want_list) return COLIBRI_OK;
+    HIP_TRY(c, hipMemsetAsync(c->b2.bitmap.p + npos / 32, 0, sizeof(uint32_t) * 16, c->stream));
+    {
+        Prof p(c, COLIBRI_K_LISTS2);
+        hipLaunchKernelGGL(bi2_pospart_kernel, dim3(512), dim3(kBi2Threads), 0, c->stream, c->b2.wlist.p, c->b2.wcnt.p, nchunks, kBi2Chunk, sbs, c->state.p, c->b2.plist.p, b.pl,
+                           (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
+        hipLaunchKernelGGL(bi2_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, sbs, c->b2.plist.p, b.pl, c->state.p, c->b2.bitmap.p);
+        hipLaunchKernelGGL(bi2_list3_kernel, dim3(2048), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_surv.p, npos, c->b2.headsurv.p, c->b2.bitmap.p, c->state.p, c->alist[1].p, nlist,
+                           (uint32_t*)nullptr, (const uint32_t*)nullptr);
     }
     return COLIBRI_OK;
 }
@@ -1668,7 +1766,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                 if (n == 1)
                     rc = binned_order(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, id_cur, n, false, n < maxlength);
                 else if (n == 2 && bi2)
-                    rc = bigram2_order(c, pl, /*want_list=*/n < maxlength);
+                    rc = bigram2_split_fits(c, npos) ? bigram2_order_split(c, pl, /*want_list=*/n < maxlength) : bigram2_order(c, pl, /*want_list=*/n < maxlength);
                 else if (n == 3 && bi2)
                     rc = binned_order(c, pl, KeyTrigramClsListed{c->cls.p}, id_cur, n, true, n < maxlength, false, /*prefill_ids=*/true, sbits_next);  // over the list bigram2 left: every listed window is admissible
                 else if (n == 2 && bi_cls)

@@ -306,6 +306,58 @@ __global__ __launch_bounds__(kBlock) void ks_owner_init_kernel(BinState* __restr
     }
 }
 
+// One device, a corpus beyond one pass (an order with more than ~110 M records: 10^9 tokens): the same split cuts the order's records ONCE into 2^s key slices — the
+// "owners" are the slices, counted one after the other on the same device, and the sub-regions of the one source play the part of the source ranks. The slice's
+// slots come straight from the split's own tables: slot (sub, A') of slice v is run (sub, A = v : A' >> s, c = A' & (2^s - 1)).
+__global__ __launch_bounds__(kKsThreads) void ks_local_init2_kernel(Bi2State* __restrict__ obs, uint32_t* __restrict__ slotbase, const KsSplitState* __restrict__ ss, uint32_t v,
+                                                                     uint32_t s, uint32_t kbits, uint32_t posbits, const uint32_t* __restrict__ nextchunk_keep) {
+    for (uint32_t slot = threadIdx.x; slot < (uint32_t)kKsSlots; slot += kKsThreads) {
+        const uint32_t sub = slot >> 8, ap = slot & 255u, A = (v << (8 - s)) | (ap >> s), c = ap & ((1u << s) - 1u);
+        const uint32_t idx = (sub * kBins + A) * kKsWorld + c;
+        obs->curA[slot]    = ss->hcnt[idx];
+        slotbase[slot]     = ss->soff[idx];
+    }
+    if (threadIdx.x == 0) {
+        obs->kbits     = kbits;
+        obs->posbits   = posbits;
+        obs->nextchunk = *nextchunk_keep;  // the position-list pool goes on where the slice before stopped
+    }
+}
+// a slot of the scan outgrew its region: the run repeats on the fallback path (sticky flag of the run's state)
+__global__ void ks_split_flag_kernel(const KsSplitState* __restrict__ ss, DevState* __restrict__ st) {
+    if (ss->overflow) st->radix_overflow = 4;
+}
+__global__ void ks_keep_chunk_kernel(const Bi2State* __restrict__ obs, uint32_t* __restrict__ nextchunk_keep) { *nextchunk_keep = obs->nextchunk; }
+__global__ __launch_bounds__(kBlock) void ks_local_init_kernel(BinState* __restrict__ bs, const KsSplitState* __restrict__ ss, uint32_t v, uint32_t s) {
+    uint32_t hsum = 0, tbase = 0;
+    for (int g = 0; g < kSub; ++g) {
+        const uint32_t slot = g * kBins + threadIdx.x, ap = threadIdx.x, A = (v << (8 - s)) | (ap >> s), c = ap & ((1u << s) - 1u);
+        const uint32_t idx = ((uint32_t)g * kBins + A) * kKsWorld + c;
+        const uint32_t h = ss->hcnt[idx];
+        const uint32_t t = (h + kScatTile - 1) / kScatTile;
+        uint32_t       tt;
+        const uint32_t tp = block_exclusive_scan(t, &tt);
+        bs->histA[slot]   = h;
+        bs->offA[slot]    = ss->soff[idx];
+        bs->tprefA[slot]  = tbase + tp;
+        tbase += tt;
+        hsum += h;
+    }
+    uint32_t tot;
+    block_exclusive_scan(hsum, &tot);
+    bs->histAt[threadIdx.x] = hsum;
+    if (threadIdx.x == 0) {
+        bs->nrec            = tot;
+        bs->offA[kASlots]   = 0;
+        bs->tprefA[kASlots] = tbase;
+        uint32_t nb = 1;
+        while (nb < (uint32_t)kBins && (uint64_t)nb * kBins * 1024u < tot) nb <<= 1;
+        uint32_t sh = 0;
+        while ((uint32_t)kBins >> sh > nb) ++sh;
+        bs->bshift = sh;
+    }
+}
+
 // order 2, the dense head (both classes < 64: never records): every rank's local histogram -> [0, 4096) counts (all-reduce SUM by the caller),
 // [4096, 8192) this rank where it saw the bigram, else 0x7FFFFFFF (all-reduce MIN: the rank that will export it)
 __global__ __launch_bounds__(kBlock) void ks_head_pack_kernel(const Bi2State* __restrict__ sbs, uint32_t rank, uint32_t* __restrict__ headg) {

@@ -15,9 +15,13 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("slice_positions", ["30000", "7000"])
-def test_sliced_passes_match_the_oracle(slice_positions):
+# (up to 8 slices order 2 scans the corpus once and cuts its records into the slices — bigram2_order_split —, beyond that, or with COLIBRI_RESCAN_SLICES, every
+# slice re-scans: 30000 / 100000 positions per slice give 8 / 4 / 2 slices on these corpora, 7000 gives 64)
+@pytest.mark.parametrize("slice_positions,rescan", [("30000", ""), ("100000", ""), ("7000", ""), ("30000", "1")])
+def test_sliced_passes_match_the_oracle(slice_positions, rescan):
     env = dict(os.environ, COLIBRI_SLICE_POSITIONS=slice_positions)
+    if rescan:
+        env["COLIBRI_RESCAN_SLICES"] = rescan
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sliced_worker.py")], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0 and "SLICED_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
 

@@ -323,9 +323,10 @@ __global__ __launch_bounds__(kKsThreads) void ks_local_init2_kernel(Bi2State* __
         obs->nextchunk = *nextchunk_keep;  // the position-list pool goes on where the slice before stopped
     }
 }
-// a slot of the scan outgrew its region: the run repeats on the fallback path (sticky flag of the run's state)
-__global__ void ks_split_flag_kernel(const KsSplitState* __restrict__ ss, DevState* __restrict__ st) {
-    if (ss->overflow) st->radix_overflow = 4;
+// a slot of the emit kernel outgrew its region: the run repeats on the fallback path (sticky flags of the run's state; orders >= 3: the emit kernel's own check —
+// bin_offsets_kernel in the one-pass form — on the cursors it left)
+__global__ void ks_split_flag_kernel(const KsSplitState* __restrict__ ss, const BinState* __restrict__ bs, DevState* __restrict__ st) {
+    if (ss->overflow) st->radix_overflow = bs != nullptr ? 1 : 4;
 }
 __global__ void ks_keep_chunk_kernel(const Bi2State* __restrict__ obs, uint32_t* __restrict__ nextchunk_keep) { *nextchunk_keep = obs->nextchunk; }
 __global__ __launch_bounds__(kBlock) void ks_local_init_kernel(BinState* __restrict__ bs, const KsSplitState* __restrict__ ss, uint32_t v, uint32_t s) {

@@ -243,6 +243,26 @@ def main():
     sharded = args.gpus > 1 or args.force_shard
     nlocal = 1 if per_process else args.gpus
 
+    # ---- N ranks in this process over RCCL: checked first, in a child process with a deadline (a small corpus, one step) — a multi-GPU RCCL run cannot be rehearsed
+    # on the one-GPU boxes this is developed on, and a hang inside a collective cannot be recovered from in-process. If the child fails or does not return, the
+    # ranks of this run exchange by peer copies between the devices instead (COLIBRI_NO_RCCL: the trainer's other backend) and the line says so.
+    preflight = None
+    if sharded and not per_process and args.gpus > 1 and not args.share_gpu and not os.environ.get("COLIBRI_NO_RCCL") and not os.environ.get("COLIBRI_BENCH_NO_PREFLIGHT"):
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", "1", "--warmup", "1", "--tokens", "2000000", "--vocab", "100000", "--cpu-sample", "0"]
+        t0 = time.time()
+        try:
+            child = subprocess.run(cmd, env=dict(os.environ, COLIBRI_BENCH_NO_PREFLIGHT="1"), capture_output=True, text=True, timeout=240)
+            ok = child.returncode == 0 and '"metric"' in child.stdout
+            why = "" if ok else (child.stderr.strip().splitlines() or ["rc %d" % child.returncode])[-1][:300]
+        except subprocess.TimeoutExpired:
+            ok, why = False, "no answer within 240 s"
+        preflight = {"rccl_ok": ok, "seconds": round(time.time() - t0, 1)}
+        if not ok:
+            preflight["failure"] = why
+            os.environ["COLIBRI_NO_RCCL"] = "1"
+            print(f"bench.py: the RCCL rehearsal with {args.gpus} ranks failed ({why}); this run exchanges by peer copies between the devices", file=sys.stderr)
+
     # ---- synthetic input: generated by worker processes (numpy) before this process touches the GPU ----------------
     my_ranks = [rank] if per_process else list(range(args.gpus))
     specs = [(args.tokens, args.vocab, 44 + r, False) for r in my_ranks]
@@ -473,6 +493,9 @@ def main():
             sh["predicted_ms_per_rank_at_8"] = round(scale * ms1 + xg, 2)
             sh["prediction"] = (f"{scale:.2f} x this step ({ms1:.2f} ms at {args.tokens} tokens -> 125 M tokens per rank) + 7/8 of {scale:.2f} x {info.alltoall_bytes / 1e9:.2f} GB over xGMI at an "
                                 f"assumed {XGMI_A2A_GBS:.0f} GB/s per GPU and direction ({xg:.2f} ms, not overlapped)")
+        sh["exchange"] = "RCCL" if info.rccl else "device copies between the ranks' contexts"
+        if preflight is not None:
+            sh["rccl_rehearsal"] = preflight
         out["sharded"] = sh
     if ctx is not None and not args.no_other_configs:
         out["other_configs"] = other_configs(ctx, capi, payloads[0].size)

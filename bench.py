@@ -301,6 +301,18 @@ def main():
         prev_low = np.concatenate([[True], p[:-1] < 128])
         return int(((p == 0) & prev_low).sum())
 
+    # a multi-rank run that has not finished its warm-up steps after ten minutes is stuck in a collective (a rank died, a link is down): say so and leave,
+    # instead of holding the GPUs until somebody's timeout
+    import threading
+    started = threading.Event()
+    if sharded and args.gpus > 1:
+        def watchdog():
+            if not started.wait(600):
+                sys.stderr.write(f"bench.py: rank {rank}: uploads and warm-up not finished after 600 s: giving up\n")
+                sys.stderr.flush()
+                os._exit(3)
+        threading.Thread(target=watchdog, daemon=True).start()
+
     opt = capi.Options.defaults(mintokens=MINTOKENS, maxlength=MAXLENGTH, profile=2)
     opt_all = capi.Options.defaults(mintokens=MINTOKENS, maxlength=MAXLENGTH, profile=1)
     ctx = tr = None
@@ -343,6 +355,7 @@ def main():
     for _ in range(args.warmup):
         st = step()
     barrier()
+    started.set()
     t0 = time.perf_counter()
     kclasses = (capi.K_CLEAR, capi.K_COUNT, capi.K_PRUNE, capi.K_RESOLVE, capi.K_EMIT, capi.K_SCATTER, capi.K_BINCOUNT, capi.K_EMIT2, capi.K_LEVELB2, capi.K_COUNT2, capi.K_LISTS2)
     kms = {k: 0.0 for k in kclasses}

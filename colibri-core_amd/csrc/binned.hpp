@@ -272,6 +272,7 @@ __global__ __launch_bounds__(kBlock) void bin_offsets_kernel(BinState* __restric
 __device__ __forceinline__ bool locate_tile(const BinState* bs, uint32_t t, uint32_t& a, uint32_t& begin, uint32_t& end) {
     static_assert(kASlots == kBlock * 8, "one lane per 8 slots");
     static_assert(offsetof(BinState, tprefA) % 16 == 0, "vector loads");
+    if (t >= bs->tprefA[kASlots]) return false;  // (block-uniform) the grid is sized for the corpus, a small order has few tiles: leave before the search
     __shared__ uint32_t slotL;
     if (threadIdx.x == 0) slotL = kInvalid;
     __syncthreads();
@@ -638,22 +639,23 @@ __device__ __forceinline__ void bin_count_body(const Rec* __restrict__ recs, Dev
     // A fixed share per block (walk index g = block, block + grid, ...) is balanced to one bin and costs nothing; handing the bins out from queues costs ~40 us per
     // launch at 100 M tokens (8192 tickets on 8 counters: measured 5.38 -> 5.50 ms per step) and pays only when one bin outweighs a block's whole share:
     // the queues are used when the largest bin holds more than twice the records of an average share.
-    const uint32_t mode = bs->walk_mode;
+    const uint32_t mode  = bs->walk_mode;
+    const uint32_t nwalk = (uint32_t)kBins * ((uint32_t)kBins >> bs->bshift);  // bins (a, b) with b >= 256 >> bshift are empty by construction: the transposed walk ends before them
     if (mode == 1 || (mode == 0 && (unsigned long long)bs->maxbin * gridDim.x <= 2ull * bs->total2)) {
-        for (uint32_t g = blockIdx.x; g < (uint32_t)kFinalBins; g += gridDim.x) one(((g & (uint32_t)(kBins - 1)) << 8) | (g >> 8), false, skip_big);
+        for (uint32_t g = blockIdx.x; g < nwalk; g += gridDim.x) one(((g & (uint32_t)(kBins - 1)) << 8) | (g >> 8), false, skip_big);
         return;
     }
     const uint32_t q = blockIdx.x & (uint32_t)(kBinQueues - 1);
     if (threadIdx.x == 0) nextL = atomicAdd(&bs->nextbin[q * 16], 8u);
     __syncthreads();
     uint32_t t = nextL;
-    while (t * kBinQueues + q < (uint32_t)kFinalBins) {
+    while (t * kBinQueues + q < nwalk) {
         __syncthreads();  // everybody has read nextL
         if (threadIdx.x == 0) nextL = atomicAdd(&bs->nextbin[q * 16], 8u);  // the ticket after this one: on its way while these eight bins are counted
 #pragma unroll 1
         for (uint32_t k = 0; k < 8; ++k) {
             const uint32_t g = (t + k) * kBinQueues + q;
-            if (g < (uint32_t)kFinalBins) one(((g & (uint32_t)(kBins - 1)) << 8) | (g >> 8), false, skip_big);
+            if (g < nwalk) one(((g & (uint32_t)(kBins - 1)) << 8) | (g >> 8), false, skip_big);
         }
         __syncthreads();
         t = nextL;
@@ -816,7 +818,8 @@ __global__ __launch_bounds__(kBlock) void compact_bins_kernel(const uint32_t* __
     if (st->done) return;
     const uint32_t res_base = bs->res_base, lane = threadIdx.x & (kWave - 1);
     const uint32_t nwaves = gridDim.x * (kBlock / kWave);
-    for (uint32_t g = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; g < (uint32_t)kFinalBins; g += nwaves) {
+    const uint32_t nwalk = (uint32_t)kBins * ((uint32_t)kBins >> bs->bshift);  // (the bins beyond hold nothing)
+    for (uint32_t g = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; g < nwalk; g += nwaves) {
         const uint32_t f   = ((g & (uint32_t)(kBins - 1)) << 8) | (g >> 8);  // transposed walk, as in bin_count_kernel
         const uint32_t off = bs->cur2[f];
         const uint32_t n   = ((f + 1 < (uint32_t)kFinalBins) ? bs->cur2[f + 1] : bs->kept_total) - off;

@@ -985,7 +985,8 @@ template <int NSUB, bool BASED = false>
 __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const uint32_t* __restrict__ boff, Bi2State* __restrict__ bs,
                                                                        DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
                                                                        uint32_t* __restrict__ wlist, uint32_t* __restrict__ wcnt, uint32_t wcap, bool want_positions,
-                                                                       uint32_t* __restrict__ wcode, const uint32_t* __restrict__ slotbase) {
+                                                                       uint32_t* __restrict__ wcode, const uint32_t* __restrict__ slotbase, uint32_t pool_first = 0,
+                                                                       uint32_t pool_n = 0) {
     if (st->done) return;
     const uint32_t nbig = bs->nhuge;
     if (nbig == 0 || nbig > (uint32_t)kBi2HugeCap) return;  // (more than the list holds: bi2_count_kernel walks every bin itself)
@@ -994,14 +995,15 @@ __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const uns
     __shared__ __attribute__((aligned(16))) uint32_t cntT[kBi2Slots];
     __shared__ uint32_t                              repS[kBi2WReps];
     __shared__ uint32_t                              rsL[NSUB], rnL[NSUB], sbL[NSUB], wsumL[kW], failL;
-    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), g = blockIdx.x * kW + tid / kWave;
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
     const uint32_t pb = bs->posbits;
     const unsigned long long pmask = (1ull << pb) - 1;
-    uint32_t* const mylist = wlist + (size_t)g * wcap;
-    uint32_t* const mycode = wcode != nullptr ? wcode + (size_t)g * wcap : nullptr;
-    uint32_t        cursor = (want_positions && !BASED) ? wcnt[g] : 0u;
-    uint32_t        chunk  = kInvalid;
-    bool            lost   = false;
+    // position lists: a wave of this kernel may list tens of thousands of windows of one bin, far beyond a fixed per-wave capacity — in both forms a wave takes lists
+    // from a POOL (one atomic whenever its current list cannot hold a row). BASED: the chunks of bi2_count_kernel<.., BASED> (wlist = [wcap chunks][kBi2Chunk]).
+    // Otherwise: lists of the wave kernel's own size (wcap entries) behind its kBi2Waves private ones: lists pool_first .. pool_first + pool_n - 1
+    const uint32_t csize = BASED ? kBi2Chunk : wcap, pfirst = BASED ? 0u : pool_first, pn = BASED ? wcap : pool_n;
+    uint32_t       cursor = 0, chunk = kInvalid;
+    bool           lost   = false;
     constexpr int      lgb   = 8;  // kBi2Slots / 4 buckets: a big bin always takes the whole table
     constexpr uint32_t bmask = (1u << lgb) - 1u;
     static_assert(kBi2Slots == 1024 && kBi2BigBin + (kBi2BigBin >> 1) >= kBi2Slots, "big bins use all 256 buckets, as they do in bi2_count_kernel");
@@ -1146,30 +1148,21 @@ __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const uns
                 if (want_positions) {
                     const uint64_t m = __ballot(kept);
                     const uint32_t n = (uint32_t)__popcll(m);
-                    if (BASED) {
-                        if (n && (chunk == kInvalid || cursor + n > kBi2Chunk)) {
-                            if (chunk != kInvalid && lane == 0) wcnt[chunk] = cursor;
-                            uint32_t cc = 0;
-                            if (lane == 0) cc = atomicAdd(&bs->nextchunk, 1u);
-                            cc     = (uint32_t)__builtin_amdgcn_readfirstlane((int)cc);
-                            chunk  = cc < wcap ? cc : kInvalid;
-                            cursor = 0;
-                            if (chunk == kInvalid) lost = true;
-                        }
-                        if (kept && chunk != kInvalid) wlist[(size_t)chunk * kBi2Chunk + cursor + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pos;
-                        if (chunk != kInvalid) cursor += n;
-                    } else {
-                        if (kept) {
-                            const uint32_t at = cursor + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                            if (at < wcap) {
-                                mylist[at] = pos;
-                                if (mycode != nullptr) mycode[at] = fcode | r;
-                            } else {
-                                lost = true;
-                            }
-                        }
-                        cursor += n;
+                    if (n && (chunk == kInvalid || cursor + n > csize)) {  // (wave-uniform) this row does not fit: close the list, take the next one of the pool
+                        if (chunk != kInvalid && lane == 0) wcnt[chunk] = cursor;
+                        uint32_t cc = 0;
+                        if (lane == 0) cc = atomicAdd(&bs->nextchunk, 1u);
+                        cc     = (uint32_t)__builtin_amdgcn_readfirstlane((int)cc);
+                        chunk  = cc < pn ? pfirst + cc : kInvalid;
+                        cursor = 0;
+                        if (chunk == kInvalid) lost = true;
                     }
+                    if (kept && chunk != kInvalid) {
+                        const size_t at = (size_t)chunk * csize + cursor + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        wlist[at]       = pos;
+                        if (wcode != nullptr) wcode[at] = fcode | r;
+                    }
+                    if (chunk != kInvalid) cursor += n;
                 }
             }
         }
@@ -1177,14 +1170,17 @@ __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const uns
         if (reps_lds)
             for (uint32_t r = tid; r < ktotal; r += kBi2BigThreads) sp_rep[spo + r] = repS[r];
     }
-    if (BASED) {
-        if (want_positions && chunk != kInvalid && lane == 0) wcnt[chunk] = cursor;
-    } else if (want_positions && lane == 0) {
-        wcnt[g] = min(cursor, wcap);
-    }
+    if (want_positions && chunk != kInvalid && lane == 0) wcnt[chunk] = cursor;
     if (__any(lost) && lane == 0) bs->overflow = 3;
 }
 
+// the list pool's cursor across the passes of a sliced order (Bi2State is zeroed per pass)
+__global__ void bi2_chunk_cursor_kernel(Bi2State* __restrict__ bs, uint32_t* __restrict__ keep, bool restore) {
+    if (restore)
+        bs->nextchunk = *keep;
+    else
+        *keep = bs->nextchunk;
+}
 // per-bin survivor counts -> dense result offsets, bin by bin; block a scans A bin a
 __global__ __launch_bounds__(kBi2BBins) void bi2_kept_scan_kernel(Bi2State* __restrict__ bs, const DevState* __restrict__ st) {
     if (st->done) return;

@@ -851,7 +851,7 @@ inline uint32_t slice_bits(uint64_t records) {  // passes needed for that many r
     return s;
 }
 struct Bigram2Plan {
-    uint32_t nslots, region, pshift, nbuckets, wcap, clsbits, posbits, sbits;
+    uint32_t nslots, region, pshift, nbuckets, wcap, wextra, clsbits, posbits, sbits;
     Bi2Lists pl;
 };
 Bigram2Plan bigram2_plan(const colibri_ctx* c, uint32_t npos) {
@@ -867,6 +867,7 @@ Bigram2Plan bigram2_plan(const colibri_ctx* c, uint32_t npos) {
     b.pl.pshift = b.pshift;
     b.pl.pcap   = ((1u << b.pshift) / 4 + 4096 + 3) & ~3u;  // a bucket's entries spread evenly over the 8 shards: twice the expected worst case
     b.wcap      = (uint32_t)(((uint64_t)npos * 6 / 10 / kBi2Waves) * 2 + 4096);
+    b.wextra    = npos / b.wcap + kBi2Waves * kWave / kBi2BigThreads + 64;  // the list pool of bi2_count_big_kernel: every position once, one partly filled list per wave of its grid
     b.clsbits   = 1;
     while ((1ull << b.clsbits) <= (uint64_t)c->maxclass) ++b.clsbits;
     b.posbits = 1;
@@ -884,8 +885,8 @@ int bigram2_alloc(colibri_ctx* c, uint32_t npos) {
     const Bigram2Plan b = bigram2_plan(c, npos);
     int               rc;
     if ((rc = dev_alloc(c, c->b2.state, 1)) || (rc = dev_alloc(c, c->b2.boff, (size_t)b.nslots * (kBi2BBins + 1))) ||
-        (rc = dev_alloc(c, c->b2.head_rows, (size_t)kBi2EmitGrid * 2 * kBi2HeadN)) || (rc = dev_alloc(c, c->b2.wlist, (size_t)kBi2Waves * b.wcap)) ||
-        (rc = dev_alloc(c, c->b2.wcnt, kBi2Waves)) || (rc = dev_alloc(c, c->b2.plist, (size_t)kBi2Shards * kBi2Buckets * b.pl.pcap + 64)) ||
+        (rc = dev_alloc(c, c->b2.head_rows, (size_t)kBi2EmitGrid * 2 * kBi2HeadN)) || (rc = dev_alloc(c, c->b2.wlist, (size_t)(kBi2Waves + b.wextra) * b.wcap)) ||
+        (rc = dev_alloc(c, c->b2.wcnt, (size_t)kBi2Waves + b.wextra + 1)) || (rc = dev_alloc(c, c->b2.plist, (size_t)kBi2Shards * kBi2Buckets * b.pl.pcap + 64)) ||
         (rc = dev_alloc(c, c->b2.bitmap, (size_t)npos / 32 + 16)) || (rc = dev_alloc(c, c->b2.headsurv, kBi2HeadN / 32)))
         return rc;
     if (b.sbits) {
@@ -905,7 +906,7 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
     if (ids_out != nullptr) {
         int rc;
         if (b.sbits != 0 || !want_list) return fail(c, COLIBRI_ERR_STATE, "bigram2_order: ids need the single-pass form with lists");
-        if ((rc = dev_alloc(c, c->b2.wcode, (size_t)kBi2Waves * b.wcap)) || (rc = dev_alloc(c, c->b2.pcode, (size_t)kBi2Shards * kBi2Buckets * b.pl.pcap + 64)) ||
+        if ((rc = dev_alloc(c, c->b2.wcode, (size_t)(kBi2Waves + b.wextra) * b.wcap)) || (rc = dev_alloc(c, c->b2.pcode, (size_t)kBi2Shards * kBi2Buckets * b.pl.pcap + 64)) ||
             (rc = dev_alloc(c, c->b2.headid, kBi2HeadN)))
             return rc;
         HIP_TRY(c, hipMemsetAsync(ids_out, 0xFF, sizeof(uint32_t) * (size_t)npos, c->stream));
@@ -915,7 +916,8 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
     auto* const       recsB = reinterpret_cast<unsigned long long*>(c->recs[1].p);
     uint32_t* const   nlist = c->alist_n.p + 1;  // order 3 reads alist[3 & 1]
     HIP_TRY(c, hipMemsetAsync(nlist, 0, sizeof(uint32_t), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->b2.wcnt.p, 0, sizeof(uint32_t) * kBi2Waves, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->b2.wcnt.p, 0, sizeof(uint32_t) * ((size_t)kBi2Waves + b.wextra + 1), c->stream));  // (the last word: the pool's cursor between the passes of a sliced order)
+    uint32_t* const   keep = c->b2.wcnt.p + kBi2Waves + b.wextra;
     const BinnedIO io = binned_planes(c, pl, false);  // the sparse survivor arrays live in recs[0], free again after level B
     for (uint32_t slice = 0; slice < (1u << b.sbits); ++slice) {  // one pass per slice of the keys (one pass unless the corpus exceeds ~110 M positions)
         HIP_TRY(c, hipMemsetAsync(bs, 0, sizeof(Bi2State), c->stream));
@@ -938,8 +940,11 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
         }
         {
             Prof p(c, COLIBRI_K_COUNT2);
+            if (b.sbits) hipLaunchKernelGGL(bi2_chunk_cursor_kernel, dim3(1), dim3(1), 0, c->stream, bs, keep, true);
             hipLaunchKernelGGL((bi2_count_big_kernel<(int)kBi2Sub>), dim3(kBi2Waves * kWave / kBi2BigThreads), dim3(kBi2BigThreads), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p,
-                               pl.thr, io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list, ids_out != nullptr ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr);
+                               pl.thr, io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list, ids_out != nullptr ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                               kBi2Waves, b.wextra);
+            if (b.sbits) hipLaunchKernelGGL(bi2_chunk_cursor_kernel, dim3(1), dim3(1), 0, c->stream, bs, keep, false);
             hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr, io.sp_rep, io.sp_cnt,
                                c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list, ids_out != nullptr ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr, true);
         }
@@ -954,7 +959,7 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
     HIP_TRY(c, hipMemsetAsync(c->b2.bitmap.p + npos / 32, 0, sizeof(uint32_t) * 16, c->stream));  // words beyond the corpus read as zero
     {
         Prof p(c, COLIBRI_K_LISTS2);
-        hipLaunchKernelGGL(bi2_pospart_kernel, dim3(512), dim3(kBi2Threads), 0, c->stream, c->b2.wlist.p, c->b2.wcnt.p, kBi2Waves, b.wcap, bs, c->state.p, c->b2.plist.p, b.pl,
+        hipLaunchKernelGGL(bi2_pospart_kernel, dim3(512), dim3(kBi2Threads), 0, c->stream, c->b2.wlist.p, c->b2.wcnt.p, kBi2Waves + b.wextra, b.wcap, bs, c->state.p, c->b2.plist.p, b.pl,
                            ids_out != nullptr ? (const uint32_t*)c->b2.wcode.p : (const uint32_t*)nullptr, ids_out != nullptr ? c->b2.pcode.p : (uint32_t*)nullptr);
         if (ids_out != nullptr) {
             static const uint32_t ids_grid = [] {
@@ -1870,6 +1875,11 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
         }
         if ((rc = read_state(c))) return rc;
         if (binned && c->hstate.radix_overflow == 4) {  // the second-generation order 2 could not hold this corpus (a hot bigram outside the dense head): first-generation kernels
+            if (getenv("COLIBRI_DEBUG_OVERFLOW")) {  // (which part of it gave up: 1 a record region, 2 a final bin's table, 3 a position list; 0: the position buckets or a split)
+                uint32_t why = 0;
+                (void)hipMemcpy(&why, &c->b2.state.p->overflow, sizeof why, hipMemcpyDeviceToHost);
+                fprintf(stderr, "colibri: second-generation order 2 gave up (Bi2State.overflow = %u); repeating on the first-generation kernels\n", why);
+            }
             c->b2.disabled = true;
             const int rc2  = colibri_train_once(c, &o, stats_out);
             c->b2.disabled = false;

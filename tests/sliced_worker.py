@@ -20,10 +20,14 @@ def main():
     corpora = {"zipf_phrases_300k": synth.zipf_corpus(300_000, 20_000, 7, phrases=True, header=False),
                "zipf_120k_small_vocab": synth.zipf_corpus(120_000, 40, 8, header=False),  # every bigram in the dense head
                "random_long_sentences": synth.random_corpus(rng, nsent=4000, maxlen=40, vocab=300, big_classes=False)}
+    runs = ((2, 5), (3, 8), (2, 2))
+    if os.environ.get("COLIBRI_SLICED_WORKER_HOT"):  # tests/test_gpu_hot_bins.py: a corpus whose hot keys fill single bins with tens of thousands of records
+        from test_gpu_hot_bins import hot_corpus
+        corpora, runs = {"hot_keys_2m5": hot_corpus()}, ((2, 5),)
     with capi.Context(0) as ctx:
         for name, payload in corpora.items():
             ctx.upload(payload)
-            for thr, maxlength in ((2, 5), (3, 8), (2, 2)):
+            for thr, maxlength in runs:
                 want = oracle.train(payload, thr, maxlength)
                 st = ctx.train(mintokens=thr, maxlength=maxlength)
                 got, _ = ctx.export_dict()

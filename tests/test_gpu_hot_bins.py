@@ -104,3 +104,12 @@ def test_sliced_runs(slice_positions):
     env = dict(os.environ, COLIBRI_SLICE_POSITIONS=slice_positions, COLIBRI_SLICED_WORKER_HOT="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sliced_worker.py")], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0 and "SLICED_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+@pytest.mark.parametrize("walk", ["1", "2"], ids=["fixed-shares", "queues"])
+def test_both_bin_walks_of_the_count_kernel(walk):
+    """orders >= 3: the count kernel walks its bins in fixed shares or takes them from queues — chosen per launch by the largest bin; here each is forced
+    (COLIBRI_BIN_WALK, read once per process) on the small corpora of tests/sliced_worker.py, unsliced, against the oracle"""
+    env = dict(os.environ, COLIBRI_SLICE_POSITIONS="1000000000", COLIBRI_BIN_WALK=walk)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sliced_worker.py")], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0 and "SLICED_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]

@@ -1168,11 +1168,14 @@ inline bool binned_split_fits(uint32_t sbits) { return sbits >= 1 && sbits <= kS
 // the positions whose `gate` entry is valid -> c->sklist / c->sklist_n: the skipgram passes of an order walk this list (at orders 4 and 5 a
 // few percent of the positions) instead of the whole corpus
 int build_skip_list(colibri_ctx* c, const TrainPlan& pl, const uint32_t* gate) {
-    int rc;
-    if ((rc = dev_alloc(c, c->sklist, (size_t)pl.npos + 1)) || (rc = dev_alloc(c, c->sklist_n, 1))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->sklist_n.p, 0, sizeof(uint32_t), c->stream));
+    const uint32_t ntiles = std::max<uint32_t>(1, blocks_for(pl.npos, kPairTile));
+    int            rc;
+    if ((rc = dev_alloc(c, c->sklist, (size_t)pl.npos + 1)) || (rc = dev_alloc(c, c->sklist_n, 1)) || (rc = dev_alloc(c, c->idx_cnt, (size_t)ntiles + 2))) return rc;
     Prof p(c, COLIBRI_K_SKIPGRAM);
-    hipLaunchKernelGGL(list_from_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, gate, pl.npos, c->sklist.p, c->sklist_n.p);
+    // in position order (count per tile, short scan, write): the references of an indexed model's skipgram passes are emitted entry by entry of this list
+    hipLaunchKernelGGL(emit_count_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, gate, pl.npos, c->idx_cnt.p, (const DevState*)nullptr);
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->idx_cnt.p, ntiles, c->idx_cnt.p + ntiles);
+    hipLaunchKernelGGL(list_write_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, gate, pl.npos, (const uint32_t*)c->idx_cnt.p, c->sklist.p, c->sklist_n.p);
     c->skl   = c->sklist.p;
     c->skl_n = c->sklist_n.p;
     return COLIBRI_OK;
@@ -1219,6 +1222,7 @@ int skipgram_pass(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, con
 }
 
 int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool ensure);
+int emit_pairs_list(colibri_ctx* c, uint32_t bound, const uint32_t* ids);
 // MINSKIPTYPES of an indexed model: a skipgram needs that many distinct fillers = distinct surviving n-grams (results [src_first, src_first + src_count)) whose
 // representative window it masks. `ids`: the RESULT index of every window's skipgram (the k1 survivors of the count threshold sit at res_total..); the ones
 // with too few fillers leave the results again and the per-position indices follow (over `list`, or over every position when there is none).
@@ -1284,7 +1288,9 @@ int skipgram_pass_radix(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mas
                                    (const uint32_t*)c->skl);
             hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
         }
-        if (need_ids && (rc = binned_resolve_stage(c, pl, out, n, true, false, nullptr, 0u, /*prefill_ids=*/true, /*decode=*/true, last ? res_total : 0u, c->skl, c->skl_n))) return rc;
+        // (no fill of `out`: every listed position is written, valid or not, and every reader — the next level's keys, the filler filter, the emission of the
+        // references — walks the same list)
+        if (need_ids && (rc = binned_resolve_stage(c, pl, out, n, true, false, nullptr, 0u, /*prefill_ids=*/false, /*decode=*/true, last ? res_total : 0u, c->skl, c->skl_n))) return rc;
         if (last && ids_out) *ids_out = out;
         left = out;
         offl = 0;
@@ -1469,6 +1475,24 @@ int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool en
         HIP_TRY(c, hipMemsetAsync(c->pair_chain.p + 2, 0, sizeof(unsigned long long), c->stream));
         c->pair_pass ^= 1;
     }
+}
+
+// the same over the entries of the order's skip list (c->skl, at most `bound` of them): the occurrences of the skipgrams a pass kept (kernels.hpp: emit_*_list_kernel)
+int emit_pairs_list(colibri_ctx* c, uint32_t bound, const uint32_t* ids) {
+    const uint32_t ntiles = std::max<uint32_t>(1, blocks_for(bound, kPairTile));
+    int            rc;
+    if ((rc = dev_alloc(c, c->idx_cnt, (size_t)ntiles + 2))) return rc;
+    uint32_t* const cnt = c->idx_cnt.p;
+    Prof            p(c, COLIBRI_K_INDEX);
+    const uint64_t  cap = c->pairs[0].n;
+    hipLaunchKernelGGL(emit_count_list_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, (const uint32_t*)c->skl, (const uint32_t*)c->skl_n, cnt, c->state.p);
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, cnt, ntiles, cnt + ntiles);
+    hipLaunchKernelGGL(pairs_advance_kernel, dim3(1), dim3(1), 0, c->stream, c->pair_chain.p, c->pair_pass, cnt + ntiles, cap);
+    const bool packed = c->pair_sb != 0;
+    hipLaunchKernelGGL(emit_write_list_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, (const uint32_t*)c->skl, (const uint32_t*)c->skl_n, (const uint32_t*)cnt, c->pair_chain.p,
+                       c->pair_pass, cap, c->pairs[0].p, packed ? (const PosBlock*)c->pos_blocks.p : (const PosBlock*)nullptr, c->pair_sb, c->pair_tb);
+    c->pair_pass ^= 1;
+    return COLIBRI_OK;
 }
 
 // two-level exclusive scan of n u32 values into u64 offsets (out[0..n-1]); *total (optional) = their sum, read back after a sync
@@ -2349,7 +2373,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                             return colibri_train_once(c, &again, stats_out);
                         }
                         if (rc) return rc;
-                        if (k && (rc = emit_pairs(c, pl, ids, false))) return rc;  // occurrences of the kept skipgrams of this pass -> forward index
+                        if (k && (rc = emit_pairs_list(c, valid_n[n], ids))) return rc;  // occurrences of the kept skipgrams of this pass -> forward index, over the order's list
                     } else {
                         if ((rc = skipgram_pass(c, pl, n, mask, c->ids[n].p, nullptr, valid_n[n], pl.thr, true, o.minskiptypes > 1 ? (uint32_t)o.minskiptypes : 0u, &f, &k, &fs))) return rc;
                         if (k) {  // occurrences of the kept skipgrams of this pass -> forward index

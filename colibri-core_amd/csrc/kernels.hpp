@@ -1368,6 +1368,75 @@ __global__ __launch_bounds__(kPairThreads) void emit_write_kernel(const uint32_t
     }
 }
 
+// The positions whose entry of `ids` is valid, in ascending order (emit_count_kernel's tile counts, scanned: blockoff[ntiles] = their number): the list the
+// skipgram passes of an order walk. In position order, so that references emitted list entry by list entry (below) arrive in corpus order, as the stable sort of
+// the forward index needs them.
+__global__ __launch_bounds__(kPairThreads) void list_write_kernel(const uint32_t* __restrict__ ids, uint32_t npos, const uint32_t* __restrict__ blockoff, uint32_t* __restrict__ list,
+                                                                   uint32_t* __restrict__ nlist) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *nlist = blockoff[gridDim.x];
+    if (blockoff[blockIdx.x + 1] == blockoff[blockIdx.x]) return;
+    const uint32_t base = blockIdx.x * kPairTile + threadIdx.x * kPairPer;
+    uint32_t       v[kPairPer], c = 0;
+    pair_load(ids, npos, base, v);
+#pragma unroll
+    for (int k = 0; k < kPairPer; ++k) c += v[k] != kInvalid;
+    uint32_t total;
+    uint32_t o = blockoff[blockIdx.x] + pair_block_scan(c, &total);
+#pragma unroll
+    for (int k = 0; k < kPairPer; ++k)
+        if (v[k] != kInvalid) list[o++] = base + k;
+}
+// emit_count / emit_write over the ENTRIES of such a list instead of over every position: the skipgram passes of an indexed model leave ids at the few
+// positions of the order's list (everything else in `ids` is stale), and a pass over the 10^8 positions of the corpus per gap mask (two sweeps, 0.24 ms) cost more
+// than the pass's counting. `bound`: what the host knows the list cannot exceed (the grid); entries beyond *nlist count as invalid.
+__global__ __launch_bounds__(kPairThreads) void emit_count_list_kernel(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ list, const uint32_t* __restrict__ nlist,
+                                                                        uint32_t* __restrict__ blockcnt, DevState* __restrict__ st) {
+    const uint32_t n = st->done ? 0u : *nlist;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (unsigned long long)n > (unsigned long long)gridDim.x * kPairTile) st->overflow = 1;  // (the list outgrew the host's bound: never silently)
+    uint32_t       c = 0;
+    const uint32_t base = blockIdx.x * kPairTile + threadIdx.x * kPairPer;
+#pragma unroll
+    for (int k = 0; k < kPairPer; ++k)
+        if (base + k < n) c += ids[list[base + k]] != kInvalid;
+    uint32_t total;
+    pair_block_scan(c, &total);
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kPairThreads) void emit_write_list_kernel(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ list, const uint32_t* __restrict__ nlist,
+                                                                        const uint32_t* __restrict__ blockoff, const unsigned long long* __restrict__ chain, int which, uint64_t cap,
+                                                                        unsigned long long* __restrict__ pairs, const PosBlock* __restrict__ blocks, uint32_t sb, uint32_t tb) {
+    if (blockoff[blockIdx.x + 1] == blockoff[blockIdx.x]) return;
+    const uint32_t n = *nlist, base = blockIdx.x * kPairTile + threadIdx.x * kPairPer;
+    uint32_t       v[kPairPer], p[kPairPer], c = 0;
+#pragma unroll
+    for (int k = 0; k < kPairPer; ++k) {
+        p[k] = base + k < n ? list[base + k] : 0u;
+        v[k] = base + k < n ? ids[p[k]] : kInvalid;
+        c += v[k] != kInvalid;
+    }
+    uint32_t       total;
+    uint64_t       o     = chain[which] + blockoff[blockIdx.x] + pair_block_scan(c, &total);
+    const uint32_t tmask = tb >= 32 ? 0xFFFFFFFFu : (1u << tb) - 1u;
+#pragma unroll
+    for (int k = 0; k < kPairPer; ++k) {
+        if (v[k] != kInvalid) {
+            if (o < cap) {
+                if (blocks != nullptr) {
+                    const uint4    r     = *reinterpret_cast<const uint4*>(blocks + (p[k] >> 6));
+                    const uint64_t delim = ((uint64_t)r.w << 32) | r.z;
+                    const uint32_t bit   = p[k] & 63u;
+                    const uint64_t below = delim & ((1ull << bit) - 1ull);
+                    const uint32_t sent = r.x + (uint32_t)__popcll(below), tok = below ? bit - (64u - (uint32_t)__clzll(below)) : p[k] - r.y;
+                    pairs[o] = ((unsigned long long)v[k] << (sb + tb)) | ((unsigned long long)sent << tb) | (tok & tmask);
+                } else {
+                    pairs[o] = ((unsigned long long)v[k] << 32) | p[k];
+                }
+            }
+            ++o;
+        }
+    }
+}
+
 // ---- stable LSD radix sort of (key, value) u32 pairs, 8 bits per pass ----
 constexpr int kSortTile = 4096;  // elements per block per pass
 __global__ __launch_bounds__(kBlock) void sort_hist_kernel(const uint32_t* __restrict__ keys, uint64_t n, int shift, uint32_t nblocks, uint32_t* __restrict__ ghist) {

@@ -51,6 +51,7 @@ struct colibri_ctx {
 
     // corpus
     bool              have_corpus = false;
+    bool              split_exact = false;  // sliced orders of this corpus take the exact split (a run of the direct one outgrew its room)
     uint64_t          nbytes      = 0;
     uint32_t          first_sentence = 1;
     uint32_t          npos = 0, ndelim = 0, nsent = 0, maxclass = 0, flags = 0;
@@ -410,6 +411,7 @@ int ingest(colibri_ctx* c, const void* src, uint64_t nbytes, uint32_t first_sent
     if (nbytes) HIP_TRY(c, hipMemcpyAsync(c->bytes.p, src, nbytes, kind, c->stream));
     if ((rc = tokenise(c))) return rc;
     c->have_corpus = true;
+    c->split_exact = false;
     return COLIBRI_OK;
 }
 
@@ -1006,8 +1008,15 @@ int bigram2_order_split(colibri_ctx* c, const TrainPlan& pl, bool want_list) {
     Bi2State* const sbs   = c->b2.state.p;
     Bi2State* const obs   = ks.obs.p;
     auto* const     recsA = reinterpret_cast<unsigned long long*>(c->recs[0].p);
-    auto* const     seg   = reinterpret_cast<unsigned long long*>(c->recs[1].p);        // the slices' segments (8 bytes x records) ...
-    auto* const     segB  = seg + c->recs[1].n;                                          // ... and their level-B output: the two halves of recs[1] (16 bytes x positions)
+    // the slices' segments and the level-B output of one slice. Exact split (histogram, scan, move): dense segments in the first half of recs[1], level B into the second.
+    // Direct split (the default): every (slot, slice) run has room for `cap` records anywhere in recs[1], level B writes into recs[0] behind the two sparse planes
+    const bool      direct = !c->split_exact && !getenv("COLIBRI_SPLIT_EXACT");
+    auto* const     seg    = reinterpret_cast<unsigned long long*>(c->recs[1].p);
+    // (level B keeps the slot layout of its input: its output needs the extent of the segments, not the size of a slice)
+    const uint64_t  extent = std::min<uint64_t>(2ull * c->recs[1].n, 2ull * c->recs[0].n - npos - 2);
+    const uint32_t  cap    = (uint32_t)std::min<uint64_t>(extent / ((uint64_t)kKsSlots * kKsWorld), 0xFFFFFFFFull / ((uint64_t)kKsSlots * kKsWorld));
+    auto* const     segB   = direct ? reinterpret_cast<unsigned long long*>(c->recs[0].p) + ((size_t)npos + 2) : seg + c->recs[1].n;
+    const uint32_t  roomB  = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, direct ? extent : (uint64_t)c->recs[1].n);
     uint32_t* const nlist = c->alist_n.p + 1;
     uint32_t* const keep  = ks.lcnt.p;  // the position-list pool's cursor between slices
     HIP_TRY(c, hipMemsetAsync(nlist, 0, sizeof(uint32_t), c->stream));
@@ -1024,12 +1033,17 @@ int bigram2_order_split(colibri_ctx* c, const TrainPlan& pl, bool want_list) {
     {
         Prof           p(c, COLIBRI_K_SCATTER);
         const KsSplit8 sp{s, b.posbits + K - 8 - s, b.posbits, 0u};
-        hipLaunchKernelGGL((ks_split_hist_kernel<unsigned long long, KsSplit8>), dim3(kKsSlots), dim3(kKsThreads), 0, c->stream, (const unsigned long long*)recsA, region,
-                           (const uint32_t*)sbs->curA, sp, ks.split.p);
-        hipLaunchKernelGGL(ks_split_scan_kernel, dim3(1), dim3(kKsThreads), 0, c->stream, ks.split.p, s, V, (const DevState*)c->state.p);
-        hipLaunchKernelGGL((ks_split_move_kernel<unsigned long long, KsSplit8, 4>), dim3(kKsSlots), dim3(kKsThreads), 0, c->stream, (const unsigned long long*)recsA, region,
-                           (const uint32_t*)sbs->curA, sp, (const KsSplitState*)ks.split.p, seg);
-        hipLaunchKernelGGL(ks_split_flag_kernel, dim3(1), dim3(1), 0, c->stream, (const KsSplitState*)ks.split.p, (const BinState*)nullptr, c->state.p);
+        if (direct) {
+            hipLaunchKernelGGL((ks_split_direct_kernel<unsigned long long, KsSplit8, 4>), dim3(kKsSlots), dim3(kKsThreads), 0, c->stream, (const unsigned long long*)recsA, region,
+                               (const uint32_t*)sbs->curA, sp, cap, ks.split.p, seg);
+        } else {
+            hipLaunchKernelGGL((ks_split_hist_kernel<unsigned long long, KsSplit8>), dim3(kKsSlots), dim3(kKsThreads), 0, c->stream, (const unsigned long long*)recsA, region,
+                               (const uint32_t*)sbs->curA, sp, ks.split.p);
+            hipLaunchKernelGGL(ks_split_scan_kernel, dim3(1), dim3(kKsThreads), 0, c->stream, ks.split.p, s, V, (const DevState*)c->state.p);
+            hipLaunchKernelGGL((ks_split_move_kernel<unsigned long long, KsSplit8, 4>), dim3(kKsSlots), dim3(kKsThreads), 0, c->stream, (const unsigned long long*)recsA, region,
+                               (const uint32_t*)sbs->curA, sp, (const KsSplitState*)ks.split.p, seg);
+            hipLaunchKernelGGL(ks_split_flag_kernel, dim3(1), dim3(1), 0, c->stream, (const KsSplitState*)ks.split.p, (const BinState*)nullptr, c->state.p);
+        }
     }
     const BinnedIO io = binned_planes(c, pl, false);  // the sparse survivor arrays live in recs[0]: the emit kernel's regions are free once the split has moved them
     for (uint32_t v = 0; v < V; ++v) {
@@ -1038,7 +1052,8 @@ int bigram2_order_split(colibri_ctx* c, const TrainPlan& pl, bool want_list) {
             HIP_TRY(c, hipMemcpyAsync(obs->headcnt, sbs->headcnt, 2 * sizeof(uint32_t) * kBi2HeadN, hipMemcpyDeviceToDevice, c->stream));
         {
             Prof p(c, COLIBRI_K_LEVELB2);
-            hipLaunchKernelGGL(ks_local_init2_kernel, dim3(1), dim3(kKsThreads), 0, c->stream, obs, ks.slotbase.p, (const KsSplitState*)ks.split.p, v, s, K - s, b.posbits + s, (const uint32_t*)keep);
+            hipLaunchKernelGGL(ks_local_init2_kernel, dim3(1), dim3(kKsThreads), 0, c->stream, obs, ks.slotbase.p, (const KsSplitState*)ks.split.p, v, s, K - s, b.posbits + s, (const uint32_t*)keep,
+                               roomB, c->state.p);
             hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, obs, 0xFFFFFFFFu, kBi2Sub, (const DevState*)c->state.p);
             hipLaunchKernelGGL(bi2_levelB_kernel, dim3(kKsSlots), dim3(kBi2Threads), 0, c->stream, (const unsigned long long*)seg, segB, 0xFFFFFFFFu, (const Bi2State*)obs, ks.oboff.p,
                                (const DevState*)c->state.p, (const uint32_t*)ks.slotbase.p);
@@ -1118,8 +1133,11 @@ int binned_order_split(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uin
     const uint32_t* nlist_in = c->alist_n.p + (n & 1);
     uint32_t* const ids_at   = need_ids ? c->ids_at.p : nullptr;
     const BinnedIO  io       = binned_planes(c, pl, false);
-    Rec* const      seg      = c->recs[1].p;                      // the slices' segments
+    Rec* const      seg      = c->recs[1].p;                      // the slices' segments (direct split, the default: room for `cap` records per (slot, slice) run; exact: dense)
     Rec* const      R2       = c->recs[0].p + (pl.npos / 2 + 1);  // level-B output of one slice: recs[0] behind the two sparse planes (free once the split has moved the records)
+    const bool      direct   = !c->split_exact && !getenv("COLIBRI_SPLIT_EXACT");
+    const uint32_t  cap      = (uint32_t)std::min<uint64_t>(c->recs[1].n / ((uint64_t)kKsSlots * kKsWorld), 0xFFFFFFFFull / ((uint64_t)kKsSlots * kKsWorld));
+    const uint32_t  room2    = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, c->recs[0].n - (pl.npos / 2 + 1));
     HIP_TRY(c, hipMemsetAsync(c->binstate.p, 0, sizeof(BinState), c->stream));
     HIP_TRY(c, hipMemsetAsync(ks.split.p, 0, sizeof(KsSplitState), c->stream));
     {
@@ -1131,17 +1149,22 @@ int binned_order_split(colibri_ctx* c, const TrainPlan& pl, const KeyFn& fn, uin
         Prof            p(c, COLIBRI_K_SCATTER);
         const KsSplit16 sp{s, 0u};
         const uint4*    recs4 = reinterpret_cast<const uint4*>(c->recs[0].p);
-        hipLaunchKernelGGL((ks_split_hist_kernel<uint4, KsSplit16>), dim3(kKsSlots), dim3(kKsThreads), 0, c->stream, recs4, region, (const uint32_t*)c->binstate.p->curA, sp, ks.split.p);
-        hipLaunchKernelGGL(ks_split_scan_kernel, dim3(1), dim3(kKsThreads), 0, c->stream, ks.split.p, s, V, (const DevState*)c->state.p);
-        hipLaunchKernelGGL((ks_split_move_kernel<uint4, KsSplit16, 2>), dim3(kKsSlots), dim3(kKsThreads), 0, c->stream, recs4, region, (const uint32_t*)c->binstate.p->curA, sp,
-                           (const KsSplitState*)ks.split.p, reinterpret_cast<uint4*>(seg));
-        hipLaunchKernelGGL(ks_split_flag_kernel, dim3(1), dim3(1), 0, c->stream, (const KsSplitState*)ks.split.p, (const BinState*)c->binstate.p, c->state.p);
+        if (direct) {
+            hipLaunchKernelGGL((ks_split_direct_kernel<uint4, KsSplit16, 2>), dim3(kKsSlots), dim3(kKsThreads), 0, c->stream, recs4, region, (const uint32_t*)c->binstate.p->curA, sp, cap, ks.split.p,
+                               reinterpret_cast<uint4*>(seg));
+        } else {
+            hipLaunchKernelGGL((ks_split_hist_kernel<uint4, KsSplit16>), dim3(kKsSlots), dim3(kKsThreads), 0, c->stream, recs4, region, (const uint32_t*)c->binstate.p->curA, sp, ks.split.p);
+            hipLaunchKernelGGL(ks_split_scan_kernel, dim3(1), dim3(kKsThreads), 0, c->stream, ks.split.p, s, V, (const DevState*)c->state.p);
+            hipLaunchKernelGGL((ks_split_move_kernel<uint4, KsSplit16, 2>), dim3(kKsSlots), dim3(kKsThreads), 0, c->stream, recs4, region, (const uint32_t*)c->binstate.p->curA, sp,
+                               (const KsSplitState*)ks.split.p, reinterpret_cast<uint4*>(seg));
+            hipLaunchKernelGGL(ks_split_flag_kernel, dim3(1), dim3(1), 0, c->stream, (const KsSplitState*)ks.split.p, (const BinState*)c->binstate.p, c->state.p);
+        }
     }
     for (uint32_t v = 0; v < V; ++v) {
         HIP_TRY(c, hipMemsetAsync(c->binstate.p, 0, sizeof(BinState), c->stream));
         {
             Prof p(c, COLIBRI_K_SCATTER);
-            hipLaunchKernelGGL(ks_local_init_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->binstate.p, (const KsSplitState*)ks.split.p, v, s);
+            hipLaunchKernelGGL(ks_local_init_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->binstate.p, (const KsSplitState*)ks.split.p, v, s, room2, c->state.p);
             hipLaunchKernelGGL(bin_hist2_kernel, dim3(tiles + kBins), dim3(kBlock), 0, c->stream, (const Rec*)seg, (const DevState*)c->state.p, c->binstate.p);
             hipLaunchKernelGGL(bin_scan2_kernel, dim3(kBins), dim3(kBlock), 0, c->stream, c->binstate.p);
             hipLaunchKernelGGL(bin_scatter_kernel, dim3(tiles + kBins), dim3(kBlock), 0, c->stream, (const Rec*)seg, R2, (const DevState*)c->state.p, c->binstate.p);
@@ -1898,6 +1921,10 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             }
         }
         if ((rc = read_state(c))) return rc;
+        if (binned && c->hstate.radix_overflow == 8 && !c->split_exact) {  // a run of the direct split of a sliced order outgrew its room (keys far from uniform): the exact split
+            c->split_exact = true;  // (for this corpus: reset by the next upload)
+            return colibri_train_once(c, &o, stats_out);
+        }
         if (binned && c->hstate.radix_overflow == 4) {  // the second-generation order 2 could not hold this corpus (a hot bigram outside the dense head): first-generation kernels
             if (getenv("COLIBRI_DEBUG_OVERFLOW")) {  // (which part of it gave up: 1 a record region, 2 a final bin's table, 3 a position list; 0: the position buckets or a split)
                 uint32_t why = 0;

@@ -49,6 +49,7 @@ struct KsTileLds {
     T        stg[kKsThreads * PER];
     uint8_t  bin[kKsThreads * PER];
     uint32_t cnt[512], off[512], wsum[8], cur[kKsWorld], gb[kKsWorld], start[kKsWorld + 1];
+    uint32_t lim[kKsWorld];  // end of each bin's room in `out` (entries beyond are dropped: the caller notices from its cursors)
 };
 // every thread of the (1024-thread) block calls it; L.cur[b] = where bin b's next run goes in `out` (advanced here)
 template <class T, int PER>
@@ -86,8 +87,9 @@ __device__ __forceinline__ void ks_partition_tile(KsTileLds<T, PER>& L, const bo
     }
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < total; j += kKsThreads) {
-        const uint32_t b                      = L.bin[j];
-        out[(size_t)L.gb[b] + (j - L.start[b])] = L.stg[j];
+        const uint32_t b  = L.bin[j];
+        const uint32_t at = L.gb[b] + (j - L.start[b]);
+        if (at < L.lim[b]) out[(size_t)at] = L.stg[j];
     }
     __syncthreads();
 }
@@ -225,7 +227,10 @@ __global__ __launch_bounds__(kKsThreads) void ks_split_move_kernel(const RecT* _
     __shared__ KsTileLds<RecT, PER> L;
     constexpr uint32_t              kTile = kKsThreads * PER;
     const uint32_t                  slot = blockIdx.x, n = min(slotcnt[slot], region), nb = 1u << sp.w;
-    if (threadIdx.x < kKsWorld) L.cur[threadIdx.x] = ss->soff[slot * kKsWorld + threadIdx.x];
+    if (threadIdx.x < kKsWorld) {
+        L.cur[threadIdx.x] = ss->soff[slot * kKsWorld + threadIdx.x];
+        L.lim[threadIdx.x] = 0xFFFFFFFFu;
+    }
     const size_t base = (size_t)slot * region;
     RecT         r[PER];
     auto         load_tile = [&](uint32_t j0) {
@@ -252,6 +257,57 @@ __global__ __launch_bounds__(kKsThreads) void ks_split_move_kernel(const RecT* _
         }
         load_tile(j0 + kTile);  // the next tile is in flight while this one is partitioned in LDS
         ks_partition_tile<RecT, PER>(L, valid, c, v, nb, out);
+    }
+}
+
+// The split without its histogram, for the key slices of one device (colibri_hip.hip: bigram2_order_split / binned_order_split): nothing has to leave dense, so
+// run (slot, c) simply gets room for `cap` records at (slot * 8 + c) * cap and the block that owns the slot — the only writer of its eight runs — moves the records
+// in one sweep and leaves the counts it reached in the split's tables (hcnt / soff, as the histogram and the scan would have). A run that outgrows its room
+// (keys far from uniform) drops the excess and raises the flag: the run repeats with the exact split.
+template <class RecT, class Split, int PER>
+__global__ __launch_bounds__(kKsThreads) void ks_split_direct_kernel(const RecT* __restrict__ recs, uint32_t region, const uint32_t* __restrict__ slotcnt, Split sp, uint32_t cap,
+                                                                      KsSplitState* __restrict__ ss, RecT* __restrict__ out) {
+    __shared__ KsTileLds<RecT, PER> L;
+    constexpr uint32_t              kTile = kKsThreads * PER;
+    const uint32_t                  slot = blockIdx.x, have = slotcnt[slot], n = min(have, region), nb = 1u << sp.w;
+    if (threadIdx.x < kKsWorld) {
+        L.cur[threadIdx.x] = (slot * kKsWorld + threadIdx.x) * cap;
+        L.lim[threadIdx.x] = (slot * kKsWorld + threadIdx.x + 1) * cap;
+    }
+    const size_t base = (size_t)slot * region;
+    RecT         r[PER];
+    auto         load_tile = [&](uint32_t j0) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const uint32_t j = j0 + k * kKsThreads + threadIdx.x;
+            if (j < n) r[k] = recs[base + j];
+        }
+    };
+    load_tile(0);
+    __syncthreads();
+    for (uint32_t j0 = 0; j0 < n; j0 += kTile) {
+        bool     valid[PER];
+        uint32_t c[PER];
+        RecT     v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            valid[k] = j0 + k * kKsThreads + threadIdx.x < n;
+            c[k]     = 0;
+            if (valid[k]) {
+                c[k] = sp.cbin(r[k]);
+                v[k] = sp.out(r[k]);
+            }
+        }
+        load_tile(j0 + kTile);
+        ks_partition_tile<RecT, PER>(L, valid, c, v, nb, out);
+    }
+    __syncthreads();
+    if (threadIdx.x < kKsWorld) {
+        const uint32_t first = (slot * kKsWorld + threadIdx.x) * cap, got = L.cur[threadIdx.x] - first;
+        ss->hcnt[slot * kKsWorld + threadIdx.x] = min(got, cap);
+        ss->soff[slot * kKsWorld + threadIdx.x] = first;
+        if (got > cap) atomicMax(&ss->overflow, 2u);  // 2: a run outgrew its room (the exact split will do); 1: a slot of the emit kernel overflowed (nothing here will)
+        if (threadIdx.x == 0 && have > region) atomicMax(&ss->overflow, 1u);
     }
 }
 
@@ -310,11 +366,25 @@ __global__ __launch_bounds__(kBlock) void ks_owner_init_kernel(BinState* __restr
 // "owners" are the slices, counted one after the other on the same device, and the sub-regions of the one source play the part of the source ranks. The slice's
 // slots come straight from the split's own tables: slot (sub, A') of slice v is run (sub, A = v : A' >> s, c = A' & (2^s - 1)).
 __global__ __launch_bounds__(kKsThreads) void ks_local_init2_kernel(Bi2State* __restrict__ obs, uint32_t* __restrict__ slotbase, const KsSplitState* __restrict__ ss, uint32_t v,
-                                                                     uint32_t s, uint32_t kbits, uint32_t posbits, const uint32_t* __restrict__ nextchunk_keep) {
+                                                                     uint32_t s, uint32_t kbits, uint32_t posbits, const uint32_t* __restrict__ nextchunk_keep, uint32_t room,
+                                                                     DevState* __restrict__ st) {
+    // `room`: records the slice's level-B output has space for. A slice that holds more (keys far from uniform) is not counted: the run repeats on the fallback path
+    __shared__ uint32_t sumL;
+    if (threadIdx.x == 0) sumL = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t slot = threadIdx.x; slot < (uint32_t)kKsSlots; slot += kKsThreads) {
+        const uint32_t sub = slot >> 8, ap = slot & 255u, A = (v << (8 - s)) | (ap >> s), c = ap & ((1u << s) - 1u);
+        mine += ss->hcnt[(sub * kBins + A) * kKsWorld + c];
+    }
+    atomicAdd(&sumL, mine);
+    __syncthreads();
+    const bool fits = sumL <= room && !ss->overflow;
+    if (!fits && threadIdx.x == 0) st->radix_overflow = ss->overflow == 2 ? 8 : 4;  // 8: again with the exact split; 4: on the first-generation kernels
     for (uint32_t slot = threadIdx.x; slot < (uint32_t)kKsSlots; slot += kKsThreads) {
         const uint32_t sub = slot >> 8, ap = slot & 255u, A = (v << (8 - s)) | (ap >> s), c = ap & ((1u << s) - 1u);
         const uint32_t idx = (sub * kBins + A) * kKsWorld + c;
-        obs->curA[slot]    = ss->hcnt[idx];
+        obs->curA[slot]    = fits ? ss->hcnt[idx] : 0u;
         slotbase[slot]     = ss->soff[idx];
     }
     if (threadIdx.x == 0) {
@@ -329,12 +399,21 @@ __global__ void ks_split_flag_kernel(const KsSplitState* __restrict__ ss, const 
     if (ss->overflow) st->radix_overflow = bs != nullptr ? 1 : 4;
 }
 __global__ void ks_keep_chunk_kernel(const Bi2State* __restrict__ obs, uint32_t* __restrict__ nextchunk_keep) { *nextchunk_keep = obs->nextchunk; }
-__global__ __launch_bounds__(kBlock) void ks_local_init_kernel(BinState* __restrict__ bs, const KsSplitState* __restrict__ ss, uint32_t v, uint32_t s) {
-    uint32_t hsum = 0, tbase = 0;
+__global__ __launch_bounds__(kBlock) void ks_local_init_kernel(BinState* __restrict__ bs, const KsSplitState* __restrict__ ss, uint32_t v, uint32_t s, uint32_t room,
+                                                                DevState* __restrict__ st) {
+    uint32_t hsum = 0, tbase = 0, mine = 0;
+    for (int g = 0; g < kSub; ++g) {
+        const uint32_t ap = threadIdx.x, A = (v << (8 - s)) | (ap >> s), c = ap & ((1u << s) - 1u);
+        mine += ss->hcnt[((uint32_t)g * kBins + A) * kKsWorld + c];
+    }
+    uint32_t all;
+    block_exclusive_scan(mine, &all);
+    const bool fits = all <= room && !ss->overflow;  // (`room`: what the slice's level-B output has space for; a split that dropped records is not counted either)
+    if (!fits && threadIdx.x == 0) st->radix_overflow = ss->overflow == 2 ? 8 : 1;  // 8: again with the exact split; 1: on the global table
     for (int g = 0; g < kSub; ++g) {
         const uint32_t slot = g * kBins + threadIdx.x, ap = threadIdx.x, A = (v << (8 - s)) | (ap >> s), c = ap & ((1u << s) - 1u);
         const uint32_t idx = ((uint32_t)g * kBins + A) * kKsWorld + c;
-        const uint32_t h = ss->hcnt[idx];
+        const uint32_t h = fits ? ss->hcnt[idx] : 0u;
         const uint32_t t = (h + kScatTile - 1) / kScatTile;
         uint32_t       tt;
         const uint32_t tp = block_exclusive_scan(t, &tt);
@@ -557,7 +636,10 @@ __global__ __launch_bounds__(kKsThreads) void ks_route_move_kernel(Spec sp, uint
     constexpr uint32_t              kTile = kKsThreads * PER;
     for (uint32_t l = blockIdx.x; l < nlists; l += gridDim.x) {
         const uint32_t n = sp.count(l);
-        if (threadIdx.x < kKsWorld) L.cur[threadIdx.x] = loff[l * kKsWorld + threadIdx.x];
+        if (threadIdx.x < kKsWorld) {
+            L.cur[threadIdx.x] = loff[l * kKsWorld + threadIdx.x];
+            L.lim[threadIdx.x] = 0xFFFFFFFFu;
+        }
         __syncthreads();
         for (uint32_t j0 = 0; j0 < n; j0 += kTile) {
             bool     valid[PER];

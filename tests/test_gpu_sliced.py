@@ -17,10 +17,14 @@ pytestmark = pytest.mark.gpu
 
 # (up to 8 slices order 2 scans the corpus once and cuts its records into the slices — bigram2_order_split —, beyond that, or with COLIBRI_RESCAN_SLICES, every
 # slice re-scans: 30000 / 100000 positions per slice give 8 / 4 / 2 slices on these corpora, 7000 gives 64)
-@pytest.mark.parametrize("slice_positions,rescan", [("30000", ""), ("100000", ""), ("7000", ""), ("30000", "1")])
+# The split itself has two forms: direct (a sweep into runs of fixed room; the default) and exact (histogram, scan, move: what a run falls back to when a run
+# outgrows its room — which the small-vocabulary corpus here does on its own); COLIBRI_SPLIT_EXACT forces the second.
+@pytest.mark.parametrize("slice_positions,rescan", [("30000", ""), ("100000", ""), ("7000", ""), ("30000", "1"), ("30000", "exact")])
 def test_sliced_passes_match_the_oracle(slice_positions, rescan):
     env = dict(os.environ, COLIBRI_SLICE_POSITIONS=slice_positions)
-    if rescan:
+    if rescan == "exact":
+        env["COLIBRI_SPLIT_EXACT"] = "1"
+    elif rescan:
         env["COLIBRI_RESCAN_SLICES"] = rescan
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sliced_worker.py")], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0 and "SLICED_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]

@@ -436,16 +436,22 @@ __device__ __forceinline__ uint32_t bi2_scan512(const uint32_t* inL, uint32_t* o
     return tot;
 }
 
+#ifndef COLIBRI_LB_PER
+#define COLIBRI_LB_PER 8
+#endif
+// level B's own tile: 8192 records — a tile's run for one of the 512 B bins is then 128 bytes on average instead of 64 (the PMC passes showed 1.46 x the bytes written for
+// the records moved: partial lines). One block of 88 KB of LDS per CU instead of two of 44 KB; 4 / 6 / 8 / 12 records per lane: 5.12 / 5.09 / 4.97 / 5.03 ms per 10^8-token step.
+constexpr int kBi2LbPer = COLIBRI_LB_PER, kBi2LbTile = kBi2Threads * kBi2LbPer;
 // ---- level B: one block partitions one slot by B bin ------------------------------------------------------------------------------
 // boff: [nslots][513] exclusive offsets of the slot's B bins inside the slot (same slot layout in recsB as in recsA).
 // B bin of a record: the nine mix bits below the A bin, shifted down by bshift when an order has few records.
 // slotbase (optional; key-sharded runs, kshard.hpp): the slots are the chunks of a receive buffer — slot s starts at record slotbase[s] instead of s * region
-__global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_levelB_kernel(const unsigned long long* recsA, unsigned long long* __restrict__ recsB, uint32_t region,
+__global__ __launch_bounds__(kBi2Threads, kBi2LbPer == 4 ? kBi2Threads / 128 : 1) void bi2_levelB_kernel(const unsigned long long* recsA, unsigned long long* __restrict__ recsB, uint32_t region,
                                                                                      const Bi2State* __restrict__ bs, uint32_t* __restrict__ boff, const DevState* __restrict__ st,
                                                                                      const uint32_t* __restrict__ slotbase = nullptr) {
     if (st->done) return;
-    __shared__ unsigned long long stgL[kBi2Tile];
-    __shared__ uint16_t           binL[kBi2Tile];
+    __shared__ unsigned long long stgL[kBi2LbTile];
+    __shared__ uint16_t           binL[kBi2LbTile];
     __shared__ uint32_t           histL[kBi2BBins], offL[kBi2BBins], curL[kBi2BBins], gbL[kBi2BBins], wsumL[8];
     const uint32_t  slot = blockIdx.x;
     const uint32_t  n    = min(bs->curA[slot], region);
@@ -456,15 +462,15 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_levelB_ker
     if (threadIdx.x < kBi2BBins) histL[threadIdx.x] = 0;
     __syncthreads();
     // sweep 1: histogram of the slot, two tiles of loads ahead of their LDS atomics
-    for (uint32_t j0 = 0; j0 < n; j0 += 2 * kBi2Tile) {
-        unsigned long long r[2 * kBi2Per];
+    for (uint32_t j0 = 0; j0 < n; j0 += 2 * kBi2LbTile) {
+        unsigned long long r[2 * kBi2LbPer];
 #pragma unroll
-        for (int k = 0; k < 2 * kBi2Per; ++k) {
+        for (int k = 0; k < 2 * kBi2LbPer; ++k) {
             const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
             r[k]             = (j < n) ? recsA[base + j] : 0ull;
         }
 #pragma unroll
-        for (int k = 0; k < 2 * kBi2Per; ++k) {
+        for (int k = 0; k < 2 * kBi2LbPer; ++k) {
             const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
             if (j < n) atomicAdd(&histL[((uint32_t)(r[k] >> bbit) & 511u) >> bsh], 1u);
         }
@@ -477,25 +483,25 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_levelB_ker
     }
     if (threadIdx.x == 0) bo[kBi2BBins] = n;
     // sweep 2: tile-local counting sort, runs appended at the block's own cursors (nobody else writes this slot); the next tile is prefetched
-    unsigned long long r[kBi2Per];
+    unsigned long long r[kBi2LbPer];
     auto               load_tile = [&](uint32_t j0) {
 #pragma unroll
-        for (int k = 0; k < kBi2Per; ++k) {
+        for (int k = 0; k < kBi2LbPer; ++k) {
             const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
             r[k]             = (j < n) ? recsA[base + j] : 0ull;
         }
     };
     load_tile(0);
-    for (uint32_t j0 = 0; j0 < n; j0 += kBi2Tile) {
-        unsigned long long x[kBi2Per];
-        uint32_t           rank[kBi2Per];
+    for (uint32_t j0 = 0; j0 < n; j0 += kBi2LbTile) {
+        unsigned long long x[kBi2LbPer];
+        uint32_t           rank[kBi2LbPer];
         if (threadIdx.x < kBi2BBins) histL[threadIdx.x] = 0;
 #pragma unroll
-        for (int k = 0; k < kBi2Per; ++k) x[k] = r[k];
-        load_tile(j0 + kBi2Tile);
+        for (int k = 0; k < kBi2LbPer; ++k) x[k] = r[k];
+        load_tile(j0 + kBi2LbTile);
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < kBi2Per; ++k) {
+        for (int k = 0; k < kBi2LbPer; ++k) {
             const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
             rank[k]          = kInvalid;
             if (j < n) {
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_levelB_ker
             curL[threadIdx.x] += histL[threadIdx.x];
         }
 #pragma unroll
-        for (int k = 0; k < kBi2Per; ++k) {
+        for (int k = 0; k < kBi2LbPer; ++k) {
             if (rank[k] != kInvalid) {
                 const uint32_t b = rank[k] >> 16, p = offL[b] + (rank[k] & 0xFFFFu);
                 stgL[p]          = x[k];
@@ -518,7 +524,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_levelB_ker
             }
         }
         __syncthreads();
-        const uint32_t m = min(n - j0, (uint32_t)kBi2Tile);
+        const uint32_t m = min(n - j0, (uint32_t)kBi2LbTile);
         for (uint32_t j = threadIdx.x; j < m; j += kBi2Threads) {
             const uint32_t b                     = binL[j];
             recsB[base + gbL[b] + (j - offL[b])] = stgL[j];

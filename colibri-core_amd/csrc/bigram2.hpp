@@ -1205,7 +1205,8 @@ __global__ __launch_bounds__(kBi2BBins) void bi2_kept_scan_kernel(Bi2State* __re
 }
 // head bigrams -> survivors; found / kept of the order
 __global__ __launch_bounds__(kBlock) void bi2_finish_kernel(DevState* __restrict__ st, Bi2State* __restrict__ bs, uint32_t threshold, uint32_t res_cap,
-                                                             uint32_t* __restrict__ headsurv_keep /* first pass: the head survivor bits, kept for the list kernel; else NULL */) {
+                                                             uint32_t* __restrict__ headsurv_keep /* first pass: the head survivor bits, kept for the list kernel; else NULL */,
+                                                             uint32_t ovf_code = 4 /* what st->radix_overflow becomes when this order could not be held (chain.hpp's orders: 5) */) {
     if (st->done) return;
     uint32_t htot, ftot, hftot;
     block_exclusive_scan(bs->found_part[threadIdx.x], &ftot);
@@ -1232,7 +1233,7 @@ __global__ __launch_bounds__(kBlock) void bi2_finish_kernel(DevState* __restrict
         st->found += ftot + hftot;
         st->kept += tot + htot;
         if ((uint64_t)bs->res_base + tot + htot > res_cap) st->overflow = 1;
-        if (bs->overflow) st->radix_overflow = 4;  // the host re-runs on the first-generation kernels
+        if (bs->overflow && st->radix_overflow != 4) st->radix_overflow = ovf_code;  // the host re-runs on the first-generation kernels
         const uint64_t next = (uint64_t)st->id_base + bs->nrec;  // keeps the id space of the later orders disjoint, as bin_advance_prepare_kernel does
         if (next >= 0xFFFFFFF0ull) st->radix_overflow = 3;
         st->id_base = (uint32_t)next;

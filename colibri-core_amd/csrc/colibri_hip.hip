@@ -20,6 +20,7 @@
 #include "colibri_hip.h"
 #include "binned.hpp"
 #include "bigram2.hpp"
+#include "chain.hpp"
 #include "kshard.hpp"
 #include "textenc.hpp"
 #include "constrained.hpp"
@@ -143,6 +144,8 @@ struct colibri_ctx {
         DevBuf<uint8_t>  sid;                    // sliced orders: the key slice of the window at every position (first pass), read by the later passes
         DevBuf<uint32_t> wcode, pcode, headid;  // the modes that keep ids: (bin, rank) codes beside the positions, result index of every head bigram
         bool             disabled = false;  // set for the rerun after this path could not hold an order (region / bin / list overflow)
+        DevBuf<Bi2State> state2, state3;    // chain.hpp: orders >= 3 on this engine ping-pong between these two (odd orders: state2); order 2's stays in `state`
+        bool             chain_disabled = false;  // set for the rerun after an order >= 3 did not fit the engine (key bits, a region, a bin)
         bool             attr_set = false;
     } b2;
     DevBuf<uint32_t>  alist[2], alist_n; // binned path: active-position lists (ping-pong) and their lengths [2]
@@ -526,6 +529,7 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->tx.table); dev_free(c->tx.state); dev_free(c->tx.info); dev_free(c->tx.events); dev_free(c->tx.evcnt);
     dev_free(c->flag2);
     dev_free(c->b2.wcode); dev_free(c->b2.pcode); dev_free(c->b2.headid); dev_free(c->b2.sid);
+    dev_free(c->b2.state2); dev_free(c->b2.state3);
     dev_free(c->b2.state); dev_free(c->b2.boff); dev_free(c->b2.head_rows); dev_free(c->b2.wlist); dev_free(c->b2.wcnt); dev_free(c->b2.plist); dev_free(c->b2.bitmap); dev_free(c->b2.headsurv);
     dev_free(c->ids_at);
     dev_free(c->alist[0]);
@@ -883,7 +887,7 @@ bool bigram2_fits(const colibri_ctx* c, uint32_t npos) {
     const Bigram2Plan b = bigram2_plan(c, npos);
     return npos < (1u << kBi2MaxPosBits) && 2 * b.clsbits - b.sbits - 8 + b.posbits <= 64;
 }
-int bigram2_alloc(colibri_ctx* c, uint32_t npos) {
+int bigram2_alloc(colibri_ctx* c, uint32_t npos, bool chain = false) {
     const Bigram2Plan b = bigram2_plan(c, npos);
     int               rc;
     if ((rc = dev_alloc(c, c->b2.state, 1)) || (rc = dev_alloc(c, c->b2.boff, (size_t)b.nslots * (kBi2BBins + 1))) ||
@@ -891,18 +895,24 @@ int bigram2_alloc(colibri_ctx* c, uint32_t npos) {
         (rc = dev_alloc(c, c->b2.wcnt, (size_t)kBi2Waves + b.wextra + 1)) || (rc = dev_alloc(c, c->b2.plist, (size_t)kBi2Shards * kBi2Buckets * b.pl.pcap + 64)) ||
         (rc = dev_alloc(c, c->b2.bitmap, (size_t)npos / 32 + 16)) || (rc = dev_alloc(c, c->b2.headsurv, kBi2HeadN / 32)))
         return rc;
+    if (chain && ((rc = dev_alloc(c, c->b2.state2, 1)) || (rc = dev_alloc(c, c->b2.state3, 1)) || (rc = dev_alloc(c, c->b2.wcode, (size_t)(kBi2Waves + b.wextra) * b.wcap)) ||
+                  (rc = dev_alloc(c, c->b2.pcode, (size_t)kBi2Shards * kBi2Buckets * b.pl.pcap + 64)) || (rc = dev_alloc(c, c->b2.headid, kBi2HeadN))))
+        return rc;
     if (b.sbits) {
         if ((rc = dev_alloc(c, c->b2.sid, (size_t)npos + 64))) return rc;
         HIP_TRY(c, hipMemsetAsync(c->b2.sid.p + (npos & ~15u), 0xFF, 64, c->stream));  // the 16-byte loads of the last positions read "no window" beyond the corpus
     }
     if (!c->b2.attr_set) {
         HIP_TRY(c, hipFuncSetAttribute((const void*)bi2_bitmap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)1 << kBi2MaxPosBits) / kBi2Buckets / 8)));
+        HIP_TRY(c, hipFuncSetAttribute((const void*)chain_bitmap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)1 << kBi2MaxPosBits) / kBi2Buckets / 8)));
         c->b2.attr_set = true;
     }
     return COLIBRI_OK;
 }
 // ids_out (the modes that keep every order's ids; one pass only): also the RESULT index of the bigram at every position, kInvalid where it did not survive
-int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t* ids_out = nullptr) {
+// chain (chain.hpp: order 3 runs on this engine too): instead of the bitmap -> list of order 3, the (position, code) pairs of the surviving windows sorted into position
+// buckets and the bitmap with the head survivors in it — what chain_emit_kernel walks
+int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t* ids_out = nullptr, bool chain = false) {
     const uint32_t    npos = pl.npos, nsurv = c->maxclass / 32 + 1;
     const Bigram2Plan b    = bigram2_plan(c, npos);
     if (ids_out != nullptr) {
@@ -913,6 +923,8 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
             return rc;
         HIP_TRY(c, hipMemsetAsync(ids_out, 0xFF, sizeof(uint32_t) * (size_t)npos, c->stream));
     }
+    if (chain && (b.sbits != 0 || ids_out != nullptr)) return fail(c, COLIBRI_ERR_STATE, "bigram2_order: the chained orders need the single-pass plain form");
+    const bool        with_codes = ids_out != nullptr || (chain && want_list);
     Bi2State* const   bs   = c->b2.state.p;
     auto* const       recsA = reinterpret_cast<unsigned long long*>(c->recs[0].p);
     auto* const       recsB = reinterpret_cast<unsigned long long*>(c->recs[1].p);
@@ -944,16 +956,16 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
             Prof p(c, COLIBRI_K_COUNT2);
             if (b.sbits) hipLaunchKernelGGL(bi2_chunk_cursor_kernel, dim3(1), dim3(1), 0, c->stream, bs, keep, true);
             hipLaunchKernelGGL((bi2_count_big_kernel<(int)kBi2Sub>), dim3(kBi2Waves * kWave / kBi2BigThreads), dim3(kBi2BigThreads), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p,
-                               pl.thr, io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list, ids_out != nullptr ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                               pl.thr, io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list, with_codes ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr,
                                kBi2Waves, b.wextra);
             if (b.sbits) hipLaunchKernelGGL(bi2_chunk_cursor_kernel, dim3(1), dim3(1), 0, c->stream, bs, keep, false);
             hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr, io.sp_rep, io.sp_cnt,
-                               c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list, ids_out != nullptr ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr, true);
+                               c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list, with_codes ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr, true);
         }
         {
             Prof p(c, COLIBRI_K_PRUNE);
             hipLaunchKernelGGL(bi2_kept_scan_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->state.p);
-            hipLaunchKernelGGL(bi2_finish_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->state.p, bs, pl.thr, pl.res_cap, slice == 0 ? c->b2.headsurv.p : (uint32_t*)nullptr);
+            hipLaunchKernelGGL(bi2_finish_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->state.p, bs, pl.thr, pl.res_cap, slice == 0 ? c->b2.headsurv.p : (uint32_t*)nullptr, 4u);
             hipLaunchKernelGGL(bi2_compact_kernel, dim3(1025), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, bs, c->res_rep.p, c->res_cnt.p, pl.res_cap);
         }
     }
@@ -962,7 +974,12 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
     {
         Prof p(c, COLIBRI_K_LISTS2);
         hipLaunchKernelGGL(bi2_pospart_kernel, dim3(512), dim3(kBi2Threads), 0, c->stream, c->b2.wlist.p, c->b2.wcnt.p, kBi2Waves + b.wextra, b.wcap, bs, c->state.p, c->b2.plist.p, b.pl,
-                           ids_out != nullptr ? (const uint32_t*)c->b2.wcode.p : (const uint32_t*)nullptr, ids_out != nullptr ? c->b2.pcode.p : (uint32_t*)nullptr);
+                           with_codes ? (const uint32_t*)c->b2.wcode.p : (const uint32_t*)nullptr, with_codes ? c->b2.pcode.p : (uint32_t*)nullptr);
+        if (chain) {  // the bitmap with the head survivors in it (and st->valid); the pairs stay where the partition left them: chain_order(3) walks them
+            hipLaunchKernelGGL(chain_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, (const Bi2State*)bs, (const uint32_t*)c->b2.plist.p, b.pl,
+                               c->state.p, c->b2.bitmap.p, (const uint32_t*)c->cls.p, (const uint32_t*)c->uni_surv.p, (const uint32_t*)c->b2.headsurv.p);
+            return COLIBRI_OK;
+        }
         if (ids_out != nullptr) {
             static const uint32_t ids_grid = [] {
                 const char* e = getenv("COLIBRI_IDS_GRID");
@@ -977,6 +994,63 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
         hipLaunchKernelGGL(bi2_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, bs, c->b2.plist.p, b.pl, c->state.p, c->b2.bitmap.p);
         hipLaunchKernelGGL(bi2_list3_kernel, dim3(2048), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_surv.p, npos, c->b2.headsurv.p, c->b2.bitmap.p, c->state.p, c->alist[1].p, nlist, ids_out,
                            ids_out != nullptr ? (const uint32_t*)c->b2.headid.p : (const uint32_t*)nullptr);
+    }
+    return COLIBRI_OK;
+}
+
+// Order n >= 3 on the same engine (chain.hpp): the pairs order n - 1 left -> records -> level B -> one wave per final bin -> survivors; the pairs for order n + 1.
+// Everything is enqueued; nothing is read back. Bi2State ping-pongs: order n's in state (n even) / state2 (n odd), order n - 1's is read for the list lengths,
+// the per-bin dense offsets and the result base (order 2's own state is kept: colibri_order2_records reads it after the run).
+int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next) {
+    const uint32_t        npos = pl.npos;
+    const Bigram2Plan     b    = bigram2_plan(c, npos);
+    Bi2State* const       bs   = (n & 1) ? c->b2.state2.p : c->b2.state3.p;
+    const Bi2State* const prev = n == 3 ? c->b2.state.p : (n & 1) ? c->b2.state3.p : c->b2.state2.p;
+    auto* const           recsA = reinterpret_cast<unsigned long long*>(c->recs[0].p);
+    auto* const           recsB = reinterpret_cast<unsigned long long*>(c->recs[1].p);
+    const BinnedIO        io    = binned_planes(c, pl, false);
+    HIP_TRY(c, hipMemsetAsync(bs, 0, sizeof(Bi2State), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->b2.wcnt.p, 0, sizeof(uint32_t) * ((size_t)kBi2Waves + b.wextra + 1), c->stream));
+    {
+        Prof p(c, COLIBRI_K_EMIT);
+        if (n == 3) {
+            hipLaunchKernelGGL(bi2_headids_kernel, dim3(1), dim3(kBlock), 0, c->stream, prev, (const DevState*)c->state.p, c->b2.headid.p);
+            hipLaunchKernelGGL((chain_emit_kernel<true>), dim3(kBi2EmitGrid), dim3(kBi2Threads), 0, c->stream, (const uint32_t*)c->cls.p, npos, (uint32_t)n, b.clsbits, b.posbits, prev,
+                               (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p, b.pl, b.nbuckets, (const uint32_t*)c->b2.bitmap.p, (const uint32_t*)c->uni_surv.p,
+                               (const uint32_t*)c->b2.headsurv.p, (const uint32_t*)c->b2.headid.p, recsA, b.region, kBi2Sub, bs, c->state.p);
+        } else {
+            hipLaunchKernelGGL((chain_emit_kernel<false>), dim3(kBi2EmitGrid), dim3(kBi2Threads), 0, c->stream, (const uint32_t*)c->cls.p, npos, (uint32_t)n, b.clsbits, b.posbits, prev,
+                               (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p, b.pl, b.nbuckets, (const uint32_t*)c->b2.bitmap.p, (const uint32_t*)nullptr,
+                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, recsA, b.region, kBi2Sub, bs, c->state.p);
+        }
+        hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, b.region, kBi2Sub, c->state.p);
+    }
+    {
+        Prof p(c, COLIBRI_K_LEVELB2);
+        hipLaunchKernelGGL(bi2_levelB_kernel, dim3(b.nslots), dim3(kBi2Threads), 0, c->stream, recsA, recsB, b.region, bs, c->b2.boff.p, c->state.p);
+        hipLaunchKernelGGL(bi2_binoff_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->b2.boff.p, kBi2Sub, c->state.p);
+    }
+    {
+        Prof p(c, COLIBRI_K_BINCOUNT);
+        hipLaunchKernelGGL((bi2_count_big_kernel<(int)kBi2Sub>), dim3(kBi2Waves * kWave / kBi2BigThreads), dim3(kBi2BigThreads), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr,
+                           io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_next, want_next ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr, kBi2Waves, b.wextra);
+        hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr, io.sp_rep, io.sp_cnt,
+                           c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_next, want_next ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr, true);
+    }
+    {
+        Prof p(c, COLIBRI_K_PRUNE);
+        hipLaunchKernelGGL(bi2_kept_scan_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->state.p);
+        hipLaunchKernelGGL(bi2_finish_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->state.p, bs, pl.thr, pl.res_cap, (uint32_t*)nullptr, 16u);
+        hipLaunchKernelGGL(bi2_compact_kernel, dim3(1025), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, bs, c->res_rep.p, c->res_cnt.p, pl.res_cap);
+    }
+    if (!want_next) return COLIBRI_OK;
+    HIP_TRY(c, hipMemsetAsync(c->b2.bitmap.p + npos / 32, 0, sizeof(uint32_t) * 16, c->stream));
+    {
+        Prof p(c, COLIBRI_K_LISTS2);
+        hipLaunchKernelGGL(bi2_pospart_kernel, dim3(512), dim3(kBi2Threads), 0, c->stream, c->b2.wlist.p, c->b2.wcnt.p, kBi2Waves + b.wextra, b.wcap, bs, c->state.p, c->b2.plist.p, b.pl,
+                           (const uint32_t*)c->b2.wcode.p, c->b2.pcode.p);
+        hipLaunchKernelGGL(chain_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, (const Bi2State*)bs, (const uint32_t*)c->b2.plist.p, b.pl,
+                           c->state.p, c->b2.bitmap.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     }
     return COLIBRI_OK;
 }
@@ -1767,6 +1841,8 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     const bool tri_cls = binned && uni_direct && !synced && c->maxclass < (1u << 21) && o.maxlength >= 3;
     const bool bi_cls = tri_cls && uni_shift != 0;  // ... and order 2 is keyed by classes + the order-1 survivor bitmap: no per-position order-1 ids at all
     const bool bi2 = binned && bi2_ok;
+    // orders >= 3 on the same engine (chain.hpp): one pass per order (corpora a single pass holds), the plain run
+    const bool chain = bi2 && !big && bigram2_plan(c, npos).sbits == 0 && o.maxlength >= 3 && !c->b2.chain_disabled && !getenv("COLIBRI_NO_CHAIN");
     if (tri_cls && !bi2 && ((rc = dev_alloc(c, c->flags_at, (size_t)npos + 1)) || (rc = dev_alloc(c, c->flag2, (size_t)npos + 4)))) return rc;
     // ---- HBM layout (sized once; nothing is allocated inside the unsynced order loop) ----------------
     // table: an order admits at most `npos` windows -> 1.5x slots; results: every survivor has >= 2 occurrences
@@ -1809,7 +1885,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             return rc;
         if ((rc = dev_alloc(c, c->rep_of, (size_t)npos + 1)) || (rc = dev_alloc(c, c->ids_at, (size_t)npos + 1)) || (rc = dev_alloc(c, c->binstate, 1))) return rc;
         if ((rc = dev_alloc(c, c->alist[0], (size_t)npos + 1)) || (rc = dev_alloc(c, c->alist[1], (size_t)npos + 1)) || (rc = dev_alloc(c, c->alist_n, 2))) return rc;
-        if (bi2 && (rc = bigram2_alloc(c, npos))) return rc;
+        if (bi2 && (rc = bigram2_alloc(c, npos, chain))) return rc;
     }
     // the modes that keep every order's ids run order 2 on the second-generation kernels as well, which then also leave the result index of the bigram at
     // every position (bi2_ids_kernel); one pass only, class-keyed, no word threshold (its cut of the order-1 ids comes after their references are emitted)
@@ -1876,6 +1952,10 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                 // carry a survivor id are visited (the active list the previous order's resolve left behind)
                 if (n == 1)
                     rc = binned_order(c, pl, KeyUnigram{c->bytes.p, c->tokstart.p}, id_cur, n, false, n < maxlength);
+                else if (n == 2 && chain)
+                    rc = bigram2_order(c, pl, /*want_list=*/n < maxlength, nullptr, /*chain=*/true);
+                else if (n >= 3 && chain)
+                    rc = chain_order(c, pl, n, /*want_next=*/n < maxlength);
                 else if (n == 2 && bi2)
                     rc = bigram2_split_fits(c, npos) ? bigram2_order_split(c, pl, /*want_list=*/n < maxlength) : bigram2_order(c, pl, /*want_list=*/n < maxlength);
                 else if (n == 3 && bi2)  // over the list bigram2 left: every listed window is admissible
@@ -1924,6 +2004,13 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
         if (binned && c->hstate.radix_overflow == 8 && !c->split_exact) {  // a run of the direct split of a sliced order outgrew its room (keys far from uniform): the exact split
             c->split_exact = true;  // (for this corpus: reset by the next upload)
             return colibri_train_once(c, &o, stats_out);
+        }
+        if (binned && c->hstate.radix_overflow == 16) {  // an order >= 3 did not fit the second-generation engine (key bits, a region, a bin): those orders on the first-generation kernels
+            if (getenv("COLIBRI_DEBUG_OVERFLOW")) fprintf(stderr, "colibri: a chained order gave up; repeating with orders >= 3 on the first-generation kernels\n");
+            c->b2.chain_disabled = true;
+            const int rc2        = colibri_train_once(c, &o, stats_out);
+            c->b2.chain_disabled = false;
+            return rc2;
         }
         if (binned && c->hstate.radix_overflow == 4) {  // the second-generation order 2 could not hold this corpus (a hot bigram outside the dense head): first-generation kernels
             if (getenv("COLIBRI_DEBUG_OVERFLOW")) {  // (which part of it gave up: 1 a record region, 2 a final bin's table, 3 a position list; 0: the position buckets or a split)

@@ -36,6 +36,12 @@ CASES = {
     "z20m_seed7_phrases_indexed": (dict(ntok=20_000_000, vocab=300_000, seed=7, phrases=True), "i", []),
     "z20m_seed7_phrases_exhaustive_skipgrams": (dict(ntok=20_000_000, vocab=300_000, seed=7, phrases=True), "us", []),
     "z20m_seed7_phrases_indexed_skipgrams_T1": (dict(ntok=20_000_000, vocab=300_000, seed=7, phrases=True), "is", ["-T", "1"]),
+    # BASELINE.json configs[2]: the 1 B-token corpus bench.py's other_configs.z1b_* build — the eight 125 M-token shards (seeds 44..51) an 8-GPU run holds,
+    # concatenated in rank order (one header). The reference needs ~35-50 GB and 1-2 h for it; the address space is capped so that it fails instead of
+    # taking the container down. Its model FILE is not kept (1 GB): only the digest.
+    "z1b_seeds44_51_plain": (dict(ntok=125_000_000, vocab=1_000_000, seeds=list(range(44, 52))), "U", []),
+    # the fallback the round-3 review names if the container cannot hold the above: four shards
+    "z500m_seeds44_47_plain": (dict(ntok=125_000_000, vocab=1_000_000, seeds=list(range(44, 48))), "U", []),
 }
 
 LINE = re.compile(r"Found (\d+) (ngrams|skipgrams)\.\.\.pruned (\d+)(?: plus (\d+) extra skipgrams)?\.*total kept: (\d+)")
@@ -46,17 +52,27 @@ def run_case(name):
     kw, mode, extra = CASES[name]
     kw = dict(kw)
     t0 = time.time()
-    data = synth.zipf_corpus(kw.pop("ntok"), kw.pop("vocab"), kw.pop("seed"), **kw)
+    seeds = kw.pop("seeds", None)
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as td:
         corpus = os.path.join(td, "c.colibri.dat")
         model = os.path.join(td, "m.colibri.patternmodel")
         with open(corpus, "wb") as f:
-            f.write(data)
-        del data
+            if seeds is None:
+                f.write(synth.zipf_corpus(kw.pop("ntok"), kw.pop("vocab"), kw.pop("seed"), **kw))
+            else:  # shards of an N-GPU run, concatenated in rank order under one header
+                ntok, vocab = kw.pop("ntok"), kw.pop("vocab")
+                f.write(synth.HEADER)
+                for seed in seeds:
+                    f.write(synth.zipf_corpus(ntok, vocab, seed, header=False, **kw))
         gen_s = time.time() - t0
         cmd = [REF_DRIVER, "train", corpus, mode, "5", "2", "-o", model] + extra
+        if seeds is not None:
+            cmd = ["prlimit", "--as=%d" % (int(os.environ.get("REF_AS_GB", "57")) << 30)] + cmd
         t0 = time.time()
-        p = subprocess.run(cmd, check=True, capture_output=True, text=True)
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        if p.returncode != 0:
+            sys.stderr.write(p.stderr[-4000:])
+            raise SystemExit("%s: the reference exited with %d after %.0f s" % (name, p.returncode, time.time() - t0))
         wall_s = time.time() - t0
         info = json.loads(p.stdout.strip().splitlines()[-1])
         orders, order, kind = [], None, None

@@ -64,6 +64,7 @@ constexpr int      kBi2BmThreads = 1024;                  // bitmap kernels: one
 constexpr uint32_t kBi2BigBin    = 1536;                  // records from which a final bin counts as big
 constexpr uint32_t kBi2HugeBin   = COLIBRI_BI2_HUGE;      // ... and as huge: counted by a workgroup (bi2_count_big_kernel), not by a wave
 constexpr int      kBi2HugeCap   = 4096;
+constexpr uint32_t kBi2HeadCode  = 0x80000000u;           // a list entry's code with this bit: a head window, the low 12 bits name the class pair (chain.hpp)
 constexpr int      kBi2BigCap    = 32768;                 // (a 10^9-token corpus counted in 8 key slices: ~7000 per slice)
 
 struct Bi2State {
@@ -76,17 +77,34 @@ struct Bi2State {
     uint32_t headcnt[kBi2HeadN], headposinv[kBi2HeadN];  // the reduced head histogram: count and ~(lowest position) per (c0, c1)
     uint32_t headsurv[kBi2HeadN / 32];                   // bit k = head bigram k survived
     uint32_t headbase[kBlock];                           // first result rank of the head survivors of lane t (16 head keys per lane)
-    uint32_t pcur[kBi2Shards * kBi2Buckets];             // position-list cursors
+    uint32_t pcur[(kBi2Shards + 1) * kBi2Buckets];       // position-list cursors (shard 8: chain.hpp's lists of the head windows, one per bucket)
     uint32_t nrec, bshift, overflow, kept_bins, kept_head, nbig, nhuge;
     uint32_t kbits;     // key bits below the slice bits (K - s): A bin = bits [kbits-1 : kbits-8], B bin = the nine below
     uint32_t posbits;   // position bits of a record
     uint32_t res_base;  // first result index of this pass's survivors (an order counted in slices appends pass after pass)
+    uint32_t hugebin;   // records from which a final bin goes to bi2_count_big_kernel; 0: kBi2HugeBin (written with kbits by the emit kernel of the order)
     uint32_t nextchunk;                 // owner passes of key-sharded runs: next free chunk of the position-list pool (bi2_count_kernel<.., BASED>)
     uint32_t nextbin[kBi2Shards * 16];  // work queues of the count kernel (one per shard, 64 bytes apart): next group of bins to hand out
     uint32_t big[kBi2BigCap];           // final bins with more than kBi2BigBin records: counted first (one wave each), so that none of them starts late
     uint32_t huge[kBi2HugeCap];         // ... with more than kBi2HugeBin records: one workgroup each
 };
 
+// ---- position lists: one per (shard, position bucket), filled by bi2_pospart_kernel (and, shard 8, by bi2_emit_kernel for chain.hpp) ----------
+struct Bi2Lists {
+    uint32_t pcap;    // entries per (shard, bucket) list, a multiple of 4
+    uint32_t pshift;  // bucket = position >> pshift
+    uint32_t hbase;   // chain.hpp: the head windows' lists (shard 8) start at this entry, list b at hbase + (b << pshift) with room for every position of the bucket
+};
+// first entry and capacity of list (shard x, bucket b)
+__device__ __forceinline__ void bi2_list_of(const Bi2Lists& pl, uint32_t x, uint32_t b, uint32_t& first, uint32_t& cap) {
+    if (x < (uint32_t)kBi2Shards) {
+        first = (x * kBi2Buckets + b) * pl.pcap;  // (fits 32 bits: shards * buckets * pcap <= 8 * positions)
+        cap   = pl.pcap;
+    } else {
+        first = pl.hbase + (b << pl.pshift);
+        cap   = 1u << pl.pshift;
+    }
+}
 // exclusive scan of 256 LDS values by the first 256 threads of a block of any size; every thread of the block must call it
 __device__ __forceinline__ uint32_t bi2_scan256(const uint32_t* inL, uint32_t* outL, uint32_t* wsumL) {
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -138,7 +156,10 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kerne
                                                                                    DevState* __restrict__ st, uint32_t* __restrict__ head_rows,
                                                                                    uint8_t* __restrict__ sid = nullptr /* optional (first pass of a sliced order): the key slice of the
                                                                                        window at every position, 0xFF where no record will ever start (not admissible, or a head bigram) */,
-                                                                                   uint32_t kmin = 0 /* key-sharded runs (kshard.hpp): at least this many key bits (17 + owner bits) */) {
+                                                                                   uint32_t kmin = 0 /* key-sharded runs (kshard.hpp): at least this many key bits (17 + owner bits) */,
+                                                                                   uint32_t* __restrict__ hplist = nullptr, uint32_t* __restrict__ hpcode = nullptr /* optional (chain.hpp):
+                                                                                       every head window also joins list (shard 8, bucket) as (position, kBi2HeadCode | head pair) */,
+                                                                                   Bi2Lists hpl = Bi2Lists{0u, 0u, 0u}) {
     if (st->done) return;
     const uint32_t K  = max(max(2u * clsbits, 17u + sbits), kmin);  // key = (class at i) << clsbits | class at i + 1
     const uint32_t Kp = K - sbits;                      // ... of which the slice fixes the top sbits
@@ -150,7 +171,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kerne
     __shared__ uint8_t            binL[kBi2Tile];
     __shared__ uint32_t           histL[kBins], offL[kBins], gbaseL[kBins], wsumL[4];
     __shared__ uint32_t           headL[kBi2HeadN], hposL[kBi2HeadN], survL[kBi2SurvLds];
-    __shared__ uint32_t           redL[kBi2Threads / kWave];
+    __shared__ uint32_t           redL[kBi2Threads / kWave], hcntL, hbaseL;
     for (int k = threadIdx.x; k < kBi2HeadN; k += kBi2Threads) {
         headL[k] = 0;
         hposL[k] = 0xFFFFFFFFu;
@@ -179,6 +200,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kerne
         const uint32_t base = tile * kBi2Tile;
         uint32_t       d0[kBi2Per], d1[kBi2Per], ok[kBi2Per];
         if (threadIdx.x < kBins) histL[threadIdx.x] = 0;
+        if (threadIdx.x == kBins) hcntL = 0;
 #pragma unroll
         for (int k = 0; k < kBi2Per; ++k) {
             d0[k]             = c0[k];
@@ -196,10 +218,12 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kerne
         __syncthreads();
         unsigned long long rec[kBi2Per];
         uint32_t           rank[kBi2Per];  // [11:0] rank inside the tile's A bin, [23:16] the A bin; kInvalid: no record
+        uint32_t           hrk[kBi2Per];   // head windows (lists wanted): rank among the tile's head windows << 12 | head pair
 #pragma unroll
         for (int k = 0; k < kBi2Per; ++k) {
             const uint32_t i = base + k * kBi2Threads + threadIdx.x;
             rank[k]          = kInvalid;
+            hrk[k]           = kInvalid;
             rec[k]           = 0;
             uint32_t mine    = 0xFFu;
             if (ok[k]) {
@@ -209,6 +233,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kerne
                         const uint32_t h = d0[k] * kBi2Head + d1[k];
                         atomicAdd(&headL[h], 1u);
                         atomicMin(&hposL[h], i);
+                        if (hplist != nullptr) hrk[k] = (atomicAdd(&hcntL, 1u) << 12) | h;
                     }
                 } else {
                     const uint64_t m = bi2_mix(((uint64_t)d0[k] << clsbits) | d1[k], K);
@@ -234,6 +259,9 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kerne
                 g = slot * region + min(at, region - min(region, h));
             }
             gbaseL[threadIdx.x] = g;
+        } else if (threadIdx.x == kBins && hplist != nullptr) {  // the tile's head windows: one reservation in the bucket's list (a tile lies inside one bucket, and the list holds
+            const uint32_t h = hcntL, b = base >> hpl.pshift;     // every position of it)
+            hbaseL           = hpl.hbase + (b << hpl.pshift) + (h ? atomicAdd(&bs->pcur[kBi2Shards * kBi2Buckets + b], h) : 0u);
         }
 #pragma unroll
         for (int k = 0; k < kBi2Per; ++k) {
@@ -244,6 +272,15 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kerne
             }
         }
         __syncthreads();
+        if (hplist != nullptr) {
+            const uint32_t hb = hbaseL;
+#pragma unroll
+            for (int k = 0; k < kBi2Per; ++k)
+                if (hrk[k] != kInvalid) {
+                    hplist[hb + (hrk[k] >> 12)] = base + k * kBi2Threads + threadIdx.x;
+                    hpcode[hb + (hrk[k] >> 12)] = kBi2HeadCode | (hrk[k] & 0xFFFu);
+                }
+        }
         const uint32_t n = offL[kBins - 1] + histL[kBins - 1];
         for (uint32_t j = threadIdx.x; j < n; j += kBi2Threads) {
             const uint32_t a                         = binL[j];
@@ -545,7 +582,7 @@ __global__ __launch_bounds__(kBi2BBins) void bi2_binoff_kernel(Bi2State* __restr
             t += bo[b + 1] - bo[b];
         }
     inL[b] = t;
-    if (t > kBi2HugeBin) {
+    if (t > (bs->hugebin ? bs->hugebin : kBi2HugeBin)) {
         const uint32_t k = atomicAdd(&bs->nhuge, 1u);
         if (k < (uint32_t)kBi2HugeCap) bs->huge[k] = a * kBi2BBins + b;
     }
@@ -678,6 +715,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
     uint32_t        chunk  = kInvalid;                                      // BASED: the chunk being filled (cursor = entries in it)
     bool            lost   = false;  // the list ran out of room
     const bool      skip_huge = big_elsewhere && bs->nhuge <= (uint32_t)kBi2HugeCap;  // bi2_count_big_kernel has counted those
+    const uint32_t  hugebin   = bs->hugebin ? bs->hugebin : kBi2HugeBin;
 #ifdef BI2_PROF
     unsigned long long tacc[12] = {0}, tlast = wall_clock64();
 #define BI2_W(k) do { const unsigned long long t_ = wall_clock64(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
@@ -705,7 +743,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
         }
         const uint32_t spo = (uint32_t)__builtin_amdgcn_readlane((int)v, 2 * NSUB);
         BI2_W(1);
-        if (total == 0 || (!big_pass && skip_big && total > kBi2BigBin) || (skip_huge && total > kBi2HugeBin)) return;
+        if (total == 0 || (!big_pass && skip_big && total > kBi2BigBin) || (skip_huge && total > hugebin)) return;
         auto locate = [&](uint32_t j) -> size_t {  // record j (< total) of the bin -> its index in recsB
             uint32_t off = 0, slot = 0, sbase = 0;
             bool     ok  = false;
@@ -1275,17 +1313,15 @@ __global__ __launch_bounds__(kBlock) void bi2_compact_kernel(const uint32_t* __r
     }
 }
 
-// ---- positions: the waves' unsorted lists -> one list per (shard, position bucket) ------------------------------------------------------------
-struct Bi2Lists {
-    uint32_t pcap;    // entries per (shard, bucket) list, a multiple of 4
-    uint32_t pshift;  // bucket = position >> pshift
-};
+// ---- positions: the waves' unsorted lists -> one list per (shard, position bucket) (Bi2Lists: above) ------------------------------------------
 // tile-local counting sort by bucket in LDS, one reserved run per (tile, bucket); block x takes the lists x, x + gridDim.x, ...
 __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_pospart_kernel(const uint32_t* __restrict__ wlist, const uint32_t* __restrict__ wcnt, uint32_t nlists, uint32_t wcap,
                                                                                       Bi2State* __restrict__ bs, DevState* __restrict__ st, uint32_t* __restrict__ plist, Bi2Lists pl,
                                                                                       const uint32_t* __restrict__ wcode = nullptr, uint32_t* __restrict__ pcode = nullptr,
-                                                                                      uint32_t flat_n = 0) {
+                                                                                      uint32_t flat_n = 0, bool dense = false) {
     // wcode / pcode (optional): the (bin, rank) codes travel with their positions
+    // dense (chain.hpp; after bi2_kept_scan_kernel): the codes leave as dense survivor numbers (per-bin offset + rank). A wave's list holds long runs of one bin's
+    // windows, so the offset look-up is nearly a broadcast here — after the partition it would be a random gather per entry
     // flat_n (key-sharded runs: the positions the owners sent back, one array): wlist holds flat_n entries, cut into nlists pieces of wcap; wcnt is not read
     if (st->done) return;
     static_assert(kBi2Buckets == kBi2Threads, "one lane per position bucket");
@@ -1305,6 +1341,11 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_pospart_ke
                 const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
                 p[k]             = j < n ? src[j] : 0xFFFFFFFFu;
                 code[k]          = (csrc != nullptr && j < n) ? csrc[j] : 0u;
+            }
+            if (dense) {
+#pragma unroll
+                for (int k = 0; k < kBi2Per; ++k)
+                    if (p[k] != 0xFFFFFFFFu) code[k] = bs->binkept[code[k] >> 10] + (code[k] & 1023u);
             }
             __syncthreads();
 #pragma unroll

@@ -10,37 +10,66 @@
 //     into position buckets, chain_bitmap_kernel turns the positions into one bit each, and chain_emit_kernel walks the PAIRS: pair (i, code) becomes a record of order n
 //     iff bit i + 1 is set. The code names the (n-1)-gram (final bin, rank among the bin's survivors -> dense number through the per-bin offsets the order's scan left);
 //     the class id at i + n - 1 is one gather inside the bucket's window. Nothing is scattered by position and nothing but list entries is read;
-//   * order 2's dense head (class pairs below 64 x 64, counted in LDS, never records) joins through a streaming pass over the class ids: head windows carry the dense
-//     number bi2_headids_kernel gives their pair.
+//   * order 2's dense head (class pairs below 64 x 64, counted in LDS, never records) joins through one streaming pass over the class ids that appends the windows of
+//     surviving head pairs to the lists as ordinary pairs (chain_head_pairs_kernel): nothing downstream knows about the head.
 // add / prune semantics (reference :2059-2073, :2107-2128) are the count kernel's: exact keys, threshold on the exact count, lowest position as representative.
 #pragma once
 #include "bigram2.hpp"
 
 namespace colibri {
 
-constexpr int kChPer   = 4;                       // candidates per lane and step
-constexpr int kChStep  = kBi2Threads * kChPer;    // 4096 candidates per step
-constexpr int kChQueue = 2 * kChStep;             // records waiting for a partition step (a step starts with fewer than kChStep of them)
-constexpr int kChQPer  = kChQueue / kBi2Threads;  // 8
+#ifndef COLIBRI_CH_THREADS
+#define COLIBRI_CH_THREADS 512
+#endif
+constexpr int kChThreads = COLIBRI_CH_THREADS;    // emit blocks: several per CU — a step is a chain of dependent round trips (pairs, gathers, a reservation), other blocks fill them
+constexpr int kChPer     = 4;                     // candidates per lane and step
+constexpr int kChStep    = kChThreads * kChPer;   // candidates per step
+constexpr int kChQueue   = 2 * kChStep;           // records waiting for a partition step (a step starts with fewer than kChStep of them)
+constexpr int kChQPer    = kChQueue / kChThreads;
 
-// ---- bitmap: per position bucket, the listed positions -> one bit each; order 2 also ORs the surviving head windows in; st->valid += set bits -------------------------
-// (bi2_bitmap_kernel + the head evaluation bi2_list3_kernel did while streaming.) bitmap words beyond the corpus must read zero (the caller clears 16 of them).
+#ifndef COLIBRI_CH_HUGE
+#define COLIBRI_CH_HUGE 4096
+#endif
+// Orders >= 3 have no dense head: the hottest n-grams (tens of thousands of windows of one key at 10^8 tokens) are ordinary records, one final bin each. A bin beyond this
+// many records goes to the workgroup kernel (order 2: 16 384): a single wave streams 4 rows per round trip, and the hottest bin below the limit is the count kernel's tail.
+constexpr uint32_t kChHugeBin = COLIBRI_CH_HUGE;
+constexpr uint32_t kChLists = kBi2Shards + 1;  // lists per bucket: the eight shards bi2_pospart_kernel fills, and (order 2) the head windows' list
+
+// ---- order 2's head windows are pairs like all others ---------------------------------------------------------------------------------------------------------------
+// The 64 x 64 most frequent class pairs are counted in LDS and never become records, so the count kernel lists none of their windows. bi2_emit_kernel, which sees every
+// window anyway, appends (position, kBi2HeadCode | pair) for every head window to list (shard 8, bucket) — room for every position of the bucket —; whether the pair
+// survived is known after the count: bi2_headids_kernel's table gives a surviving pair its result index, kInvalid otherwise, and the two readers of the lists look it up
+// (16 KB, cache-resident). Rounds 2-3 evaluated the head again, from the class ids, in every kernel that needed "did the bigram at i survive".
+__device__ __forceinline__ bool chain_head_alive(uint32_t code, const uint32_t* __restrict__ headid) { return headid[code & 0xFFFu] != kInvalid; }
+
+// ---- bitmap: per position bucket, the listed positions -> one bit each; st->valid += set bits ---------------------------------------------------------------------------
+// bitmap words beyond the corpus must read zero (the caller clears 16 of them).
 __global__ __launch_bounds__(kBi2BmThreads) void chain_bitmap_kernel(uint32_t npos, const Bi2State* __restrict__ bs, const uint32_t* __restrict__ plist, Bi2Lists pl, DevState* __restrict__ st,
-                                                                      uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ cls /* order 2: the head windows; else nullptr */,
-                                                                      const uint32_t* __restrict__ surv, const uint32_t* __restrict__ headsurv) {
+                                                                      uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ pcode = nullptr /* order 2: the head windows' codes ... */,
+                                                                      const uint32_t* __restrict__ headid = nullptr /* ... and who of them survived */) {
     if (st->done) return;
     extern __shared__ uint32_t bmL[];  // (1 << pshift) / 32 words
-    __shared__ uint32_t        hsL[kBi2HeadN / 32], redL[kBi2BmThreads / kWave];
+    __shared__ uint32_t        redL[kBi2BmThreads / kWave];
     const uint32_t b = blockIdx.x, start = b << pl.pshift;
     if (start >= npos) return;
     const uint32_t size   = min(1u << pl.pshift, npos - start);
     const uint32_t nwords = (size + 31) / 32;
     for (uint32_t w = threadIdx.x; w < nwords; w += kBi2BmThreads) bmL[w] = 0;
-    if (cls != nullptr && threadIdx.x < kBi2HeadN / 32) hsL[threadIdx.x] = headsurv[threadIdx.x];
     __syncthreads();
+    if (headid != nullptr) {  // the head windows' list: only the windows of surviving pairs count
+        uint32_t first, cap;
+        bi2_list_of(pl, kBi2Shards, b, first, cap);
+        const uint32_t n = min(bs->pcur[kBi2Shards * kBi2Buckets + b], cap);
+        for (uint32_t j = threadIdx.x; j < n; j += kBi2BmThreads) {
+            const uint32_t o = plist[first + j] - start;
+            if (chain_head_alive(pcode[first + j], headid)) atomicOr(&bmL[o >> 5], 1u << (o & 31u));
+        }
+    }
     for (uint32_t x = 0; x < (uint32_t)kBi2Shards; ++x) {
-        const uint32_t     l = x * kBi2Buckets + b, n = min(bs->pcur[l], pl.pcap);
-        const uint32_t*    p = plist + (size_t)l * pl.pcap;  // 16-byte aligned: pcap is a multiple of 4
+        uint32_t first, cap;
+        bi2_list_of(pl, x, b, first, cap);
+        const uint32_t     n = min(bs->pcur[x * kBi2Buckets + b], cap);
+        const uint32_t*    p = plist + first;  // 16-byte aligned: pcap and hbase are multiples of 4
         const uint4* const v = reinterpret_cast<const uint4*>(p);
         const uint32_t     nv = n >> 2;
         for (uint32_t j = threadIdx.x; j < nv; j += kBi2BmThreads) {
@@ -54,27 +83,6 @@ __global__ __launch_bounds__(kBi2BmThreads) void chain_bitmap_kernel(uint32_t np
         if (threadIdx.x < (n & 3u)) {
             const uint32_t o = p[(nv << 2) + threadIdx.x] - start;
             atomicOr(&bmL[o >> 5], 1u << (o & 31u));
-        }
-    }
-    if (cls != nullptr) {  // head bigrams never became records: their windows are evaluated here, against the head survivor bits (cls is readable, zeros, beyond npos)
-        const uint32_t sw0 = surv[0], sw1 = surv[1];
-        for (uint32_t i0 = 0; i0 < size; i0 += 4 * kBi2BmThreads) {
-            uint32_t c0[4], c1[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t i = i0 + k * kBi2BmThreads + threadIdx.x;
-                c0[k]            = i < size ? cls[start + i] : 0u;
-                c1[k]            = i < size ? cls[start + i + 1] : 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t i = i0 + k * kBi2BmThreads + threadIdx.x;
-                if (c0[k] - 1u < (uint32_t)(kBi2Head - 1) && c1[k] - 1u < (uint32_t)(kBi2Head - 1)) {
-                    const uint32_t s0 = (c0[k] < 32 ? sw0 >> c0[k] : sw1 >> (c0[k] - 32)) & 1u, s1 = (c1[k] < 32 ? sw0 >> c1[k] : sw1 >> (c1[k] - 32)) & 1u;
-                    const uint32_t h  = c0[k] * kBi2Head + c1[k];
-                    if (s0 & s1 & (hsL[h >> 5] >> (h & 31u))) atomicOr(&bmL[i >> 5], 1u << (i & 31u));
-                }
-            }
         }
     }
     __syncthreads();
@@ -96,44 +104,17 @@ __global__ __launch_bounds__(kBi2BmThreads) void chain_bitmap_kernel(uint32_t np
 
 // ---- emit: (position, code) pairs of order n - 1 -> 8-byte records of order n, partitioned by A bin ---------------------------------------------------------------------
 // grid: a multiple of nsub persistent blocks. Candidates are appended to an LDS queue step by step (a block-wide scan of the lanes' counts: no atomics, a deterministic
-// order); whenever the queue holds a tile's worth it is counting-sorted by A bin in place and leaves as one run per (queue, A bin) into the block's sub-region, exactly as
+// order); whenever the queue holds a step's worth it is counting-sorted by A bin in place and leaves as one run per (queue, A bin) into the block's sub-region, exactly as
 // bi2_emit_kernel's tiles do. Key bits: idbits (for the survivors order n - 1 kept) + clsbits; what does not fit the record or the count kernel's 31-bit in-bin key raises
 // Bi2State::overflow (the host repeats the run on the first-generation kernels for these orders).
-template <bool HEAD>
-__global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void chain_emit_kernel(const uint32_t* __restrict__ cls, uint32_t npos, uint32_t n, uint32_t clsbits, uint32_t pb,
-                                                                                     const Bi2State* __restrict__ prev, const uint32_t* __restrict__ plist, const uint32_t* __restrict__ pcode,
-                                                                                     Bi2Lists pl, uint32_t nbuckets, const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ surv,
-                                                                                     const uint32_t* __restrict__ headsurv, const uint32_t* __restrict__ headid,
-                                                                                     unsigned long long* __restrict__ recsA, uint32_t region, uint32_t nsub, Bi2State* __restrict__ bs,
-                                                                                     DevState* __restrict__ st) {
-    if (st->done) return;
-    const uint32_t kept_prev = prev->kept_bins + prev->kept_head;
-    uint32_t       idbits    = 1;
-    while (idbits < 32 && (1ull << idbits) < (uint64_t)kept_prev + 1) ++idbits;
-    const uint32_t K = max(idbits + clsbits, 17u);
-    if (threadIdx.x == 0) {
-        bs->kbits   = K;
-        bs->posbits = pb;
-    }
-    if (K > 48u || K - 8u + pb > 64u) {  // (the count kernel's in-bin key holds K - 17 + bshift <= 31 bits; the record K - 8 bits beside the position)
-        if (threadIdx.x == 0) bs->overflow = 1;
-        return;
-    }
-    __shared__ unsigned long long qL[kChQueue];
-    __shared__ uint8_t            qaL[kChQueue];
-    __shared__ uint32_t           histL[kBins], offL[kBins], gbaseL[kBins], wsumL[kBi2Threads / kWave];
-    __shared__ uint32_t           hsL[HEAD ? kBi2HeadN / 32 : 1];
-    if (HEAD) {
-        if (threadIdx.x < kBi2HeadN / 32) hsL[threadIdx.x] = headsurv[threadIdx.x];
-        __syncthreads();
-    }
-    const uint32_t           sub   = blockIdx.x % nsub;
-    const uint32_t           rbase = prev->res_base;
-    const unsigned long long kmask = (1ull << (K - 8)) - 1ull;
-    uint32_t                 qn    = 0;  // records in the queue (block-uniform)
-    uint32_t                 nadm  = 0;  // thread 0: records appended by this block
+struct ChainQueue {
+    unsigned long long* qL;   // [kChQueue]
+    uint8_t*            qaL;  // [kChQueue]
+    uint32_t *          histL, *offL, *gbaseL, *wsumL;  // [kBins] x 3, [kChThreads / kWave]
+    uint32_t            qn;   // records in the queue (block-uniform)
+    uint32_t            nadm; // records appended by this block (block-uniform)
     // the queue's records leave: counting sort by A bin in place (every lane holds its entries in registers across the barrier), one reservation per (queue, A bin)
-    auto flush = [&]() {
+    __device__ __forceinline__ void flush(unsigned long long* __restrict__ recsA, uint32_t region, uint32_t sub, Bi2State* __restrict__ bs) {
         __syncthreads();  // the appends are visible
         if (threadIdx.x < kBins) histL[threadIdx.x] = 0;
         __syncthreads();
@@ -141,7 +122,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void chain_emit_ker
         uint32_t           rk[kChQPer];
 #pragma unroll
         for (int q = 0; q < kChQPer; ++q) {
-            const uint32_t j = q * kBi2Threads + threadIdx.x;
+            const uint32_t j = q * kChThreads + threadIdx.x;
             r[q]             = 0;
             rk[q]            = kInvalid;
             if (j < qn) {
@@ -172,99 +153,161 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void chain_emit_ker
             }
         }
         __syncthreads();
-        for (uint32_t j = threadIdx.x; j < qn; j += kBi2Threads) {
+        for (uint32_t j = threadIdx.x; j < qn; j += kChThreads) {
             const uint32_t a                         = qaL[j];
             recsA[(size_t)gbaseL[a] + (j - offL[a])] = qL[j];
         }
         __syncthreads();
         qn = 0;
+    }
+};
+static_assert(kChStep / kChThreads == kChPer && kChThreads >= kBins && kChThreads % kWave == 0 && kChThreads / kWave <= 16, "bi2_scan256 / bi2_block_scan");
+
+struct ChainKey {
+    uint32_t           K, clsbits, pb;
+    unsigned long long kmask;
+    __device__ __forceinline__ void put(ChainQueue& q, uint32_t at, uint32_t dn, uint32_t cn, uint32_t pos) const {
+        const uint64_t m = bi2_mix(((uint64_t)dn << clsbits) | cn, K);
+        q.qL[at]         = ((m & kmask) << pb) | pos;
+        q.qaL[at]        = (uint8_t)(m >> (K - 8));
+    }
+};
+// key bits of order n from what order n - 1 kept; false (and Bi2State::overflow) when the engine cannot hold them
+__device__ __forceinline__ bool chain_key_bits(const Bi2State* __restrict__ prev, uint32_t clsbits, uint32_t pb, Bi2State* __restrict__ bs, ChainKey& ck, uint32_t hugebin = 0) {
+    const uint32_t kept_prev = prev->kept_bins + prev->kept_head;
+    uint32_t       idbits    = 1;
+    while (idbits < 32 && (1ull << idbits) < (uint64_t)kept_prev + 1) ++idbits;
+    const uint32_t K = max(idbits + clsbits, 17u);
+    if (threadIdx.x == 0) {
+        bs->kbits   = K;
+        bs->posbits = pb;
+        bs->hugebin = hugebin ? hugebin : kChHugeBin;
+    }
+    if (K > 48u || K - 8u + pb > 64u) {  // (the count kernel's in-bin key holds K - 17 + bshift <= 31 bits; the record K - 8 bits beside the position)
+        if (threadIdx.x == 0) bs->overflow = 1;
+        return false;
+    }
+    ck.K       = K;
+    ck.clsbits = clsbits;
+    ck.pb      = pb;
+    ck.kmask   = (1ull << (K - 8)) - 1ull;
+    return true;
+}
+
+#define CHAIN_QUEUE_LDS(q)                                                                       \
+    __shared__ unsigned long long q##_qL[kChQueue];                                              \
+    __shared__ uint8_t            q##_qaL[kChQueue];                                             \
+    __shared__ uint32_t           q##_histL[kBins], q##_offL[kBins], q##_gbaseL[kBins], q##_wsumL[kChThreads / kWave]; \
+    ChainQueue q{q##_qL, q##_qaL, q##_histL, q##_offL, q##_gbaseL, q##_wsumL, 0u, 0u}
+
+// (a) the listed windows.
+// Where a step's gathers land decides this kernel: a pair's class id at i + n - 1 is a 4-byte read inside its bucket's 512 KB window of the class-id array, and block b
+// runs on XCD b % 8 with its own 4 MB L2. The first version gave every block whole (shard, bucket) lists, eight consecutive blocks the eight shards of one bucket: every
+// XCD fetched every window, ~100 windows were open per XCD at a time, and each gather went to HBM for a whole line (45 M pairs: 0.75 ms, ~6 GB of fetches for 0.18 GB of
+// class ids). Now the buckets are dealt to the XCDs (bucket mod 8), an XCD's steps — pieces of kChStep pairs of its lists, bucket by bucket — are numbered by
+// chain_steps_kernel, and the XCD's blocks take them round-robin: at any time an XCD works on ~3 adjacent buckets, whose windows stay in its L2.
+constexpr uint32_t kChXcds = 8;
+// table: [kChXcds][cap] entries {index of the step's first pair in plist / pcode, pairs of the step}; nsteps: [kChXcds]
+__global__ __launch_bounds__(kBi2Threads) void chain_steps_kernel(const Bi2State* __restrict__ prev, Bi2Lists pl, uint32_t nbuckets, uint2* __restrict__ table, uint32_t cap,
+                                                                   uint32_t* __restrict__ nsteps, const DevState* __restrict__ st) {
+    if (st->done) return;
+    __shared__ uint32_t wsumL[kBi2Threads / kWave];
+    constexpr uint32_t  kPer = (kBi2Buckets / kChXcds * kChLists + kBi2Threads - 1) / kBi2Threads;  // lists of an XCD per lane (2), in (bucket, shard) order
+    const uint32_t      x = blockIdx.x;
+    uint32_t            first[kPer], n[kPer], ns[kPer], sum = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) {
+        const uint32_t idx = threadIdx.x * kPer + q, bucket = x + kChXcds * (idx / kChLists), shard = idx % kChLists;
+        uint32_t       lcap = 0;
+        first[q] = n[q] = 0;
+        if (bucket < nbuckets) {
+            bi2_list_of(pl, shard, bucket, first[q], lcap);
+            n[q] = min(prev->pcur[shard * kBi2Buckets + bucket], lcap);
+        }
+        ns[q] = (n[q] + kChStep - 1) / kChStep;
+        sum += ns[q];
+    }
+    uint32_t total;
+    uint32_t base = bi2_block_scan<kBi2Threads>(sum, &total, wsumL);
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q)
+        for (uint32_t k = 0; k < ns[q]; ++k, ++base)
+            if (base < cap) table[(size_t)x * cap + base] = make_uint2(first[q] + k * (uint32_t)kChStep, min((uint32_t)kChStep, n[q] - k * (uint32_t)kChStep));
+    if (threadIdx.x == 0) nsteps[x] = min(total, cap);
+}
+// (steps of an XCD at most: every list of its buckets filled + one partial step each)
+inline uint32_t chain_steps_cap(const Bi2Lists& pl) { return (kBi2Buckets / kChXcds) * (kBi2Shards * (pl.pcap / kChStep + 1) + ((1u << pl.pshift) / kChStep + 1)); }
+
+__global__ __launch_bounds__(kChThreads, 6) void chain_emit_kernel(const uint32_t* __restrict__ cls, uint32_t npos, uint32_t n, uint32_t clsbits, uint32_t pb, const Bi2State* __restrict__ prev,
+                                                                    const uint32_t* __restrict__ plist, const uint32_t* __restrict__ pcode, Bi2Lists pl,
+                                                                    const uint2* __restrict__ table, uint32_t cap, const uint32_t* __restrict__ nsteps,
+                                                                    const uint32_t* __restrict__ bitmap, unsigned long long* __restrict__ recsA, uint32_t region, uint32_t nsub,
+                                                                    Bi2State* __restrict__ bs, DevState* __restrict__ st, const uint32_t* __restrict__ headid /* order 3 */, uint32_t dbg = 0) {
+    if (st->done) return;
+    ChainKey ck;
+    if (!chain_key_bits(prev, clsbits, pb, bs, ck, dbg >> 8)) return;
+    CHAIN_QUEUE_LDS(Q);
+    const uint32_t        sub = blockIdx.x % nsub;
+    const uint32_t        x = blockIdx.x % kChXcds, nper = gridDim.x / kChXcds, ns = nsteps[x];  // (grid: a multiple of 8)
+    const uint2* const    tab = table + (size_t)x * cap;
+    const uint32_t        rbase = prev->res_base;
+    uint32_t              k = blockIdx.x / kChXcds;
+    // software pipeline, two steps deep: the table entry of step k + 2 nper and the pairs of step k + nper are in flight while step k's gathers and partition run
+    // (every one of these is a memory round trip; issued one after the other they were the step's time)
+    uint32_t ps[kChPer], code[kChPer];
+    bool     ok[kChPer];
+    uint2    e1 = k < ns ? tab[k] : make_uint2(0u, 0u);  // the step whose pairs are loaded next
+    auto     load_pairs = [&]() {
+#pragma unroll
+        for (int q = 0; q < kChPer; ++q) {
+            const uint32_t j = q * kChThreads + threadIdx.x;
+            ok[q]            = j < e1.y;
+            ps[q]            = ok[q] ? plist[(size_t)e1.x + j] : 0u;
+            code[q]          = ok[q] ? pcode[(size_t)e1.x + j] : 0u;
+        }
     };
-    // appends this lane's candidates (ok[k]: key material in dn[k] / cn[k], position in ps[k]) to the queue
-    auto append = [&](const bool* ok, const uint32_t* dn, const uint32_t* cn, const uint32_t* ps) {
+    load_pairs();
+    e1 = k + nper < ns ? tab[k + nper] : make_uint2(0u, 0u);
+    while (k < ns) {
+        uint32_t p2[kChPer], c2[kChPer], w[kChPer], cn[kChPer];
+        bool     k2[kChPer];
+#pragma unroll
+        for (int q = 0; q < kChPer; ++q) {
+            p2[q] = ps[q];
+            c2[q] = code[q];
+            k2[q] = ok[q];
+        }
+#pragma unroll
+        for (int q = 0; q < kChPer; ++q)  // first gather: did the (n-1)-gram at i + 1 survive (the bucket's 16 KB of the bitmap: mostly the CU's own cache)
+            w[q] = (k2[q] && !(dbg & 1u)) ? bitmap[(p2[q] + 1u) >> 5] : 0x55555555u;
+        load_pairs();  // of step k + nper (its entry arrived a step ago)
+        k += nper;
+        e1 = k + nper < ns ? tab[k + nper] : make_uint2(0u, 0u);
         uint32_t cnt = 0;
 #pragma unroll
-        for (int k = 0; k < kChPer; ++k) cnt += ok[k] ? 1u : 0u;
+        for (int q = 0; q < kChPer; ++q) {
+            k2[q] = k2[q] && ((w[q] >> ((p2[q] + 1u) & 31u)) & 1u);
+            if (k2[q] && (c2[q] & kBi2HeadCode)) {  // a head window of order 2: the dense number of its pair, if the pair survived
+                const uint32_t r = headid[c2[q] & 0xFFFu];
+                k2[q]            = r != kInvalid;
+                c2[q]            = r - rbase;
+            }
+            cnt += k2[q] ? 1u : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < kChPer; ++q)  // second gather, for the admitted windows only: the class id at i + n - 1, anywhere in the bucket's 512 KB of class ids — a line from
+            cn[q] = (k2[q] && !(dbg & 2u)) ? cls[p2[q] + n - 1u] : (p2[q] & 1023u);  // L2 per window (~120 G/s on MI355X): the kernel's time
         uint32_t total;
-        uint32_t at = qn + bi2_block_scan<kBi2Threads>(cnt, &total, wsumL);
+        uint32_t at = Q.qn + bi2_block_scan<kChThreads>(cnt, &total, Q.wsumL);
 #pragma unroll
-        for (int k = 0; k < kChPer; ++k) {
-            if (ok[k]) {
-                const uint64_t m = bi2_mix(((uint64_t)dn[k] << clsbits) | cn[k], K);
-                qL[at]           = ((m & kmask) << pb) | ps[k];
-                qaL[at]          = (uint8_t)(m >> (K - 8));
-                ++at;
-            }
-        }
-        qn += total;
-        if (threadIdx.x == 0) nadm += total;
-        if (qn >= (uint32_t)kChStep) flush();
-    };
-    // (a) the listed windows: one unit = one (shard, bucket) list of order n - 1
-    const uint32_t nunits = nbuckets * (uint32_t)kBi2Shards;
-    for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
-        const uint32_t l  = (u & (uint32_t)(kBi2Shards - 1)) * kBi2Buckets + (u >> 3);
-        const uint32_t nl = min(prev->pcur[l], pl.pcap);
-        const size_t   o  = (size_t)l * pl.pcap;
-        static_assert(kBi2Shards == 8, "unit -> (shard, bucket)");
-        for (uint32_t j0 = 0; j0 < nl; j0 += kChStep) {
-            uint32_t ps[kChPer], code[kChPer], w[kChPer], cn[kChPer], dn[kChPer];
-            bool     ok[kChPer];
-#pragma unroll
-            for (int k = 0; k < kChPer; ++k) {
-                const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
-                ok[k]            = j < nl;
-                ps[k]            = ok[k] ? plist[o + j] : 0u;
-                code[k]          = ok[k] ? pcode[o + j] : 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < kChPer; ++k) {  // the gathers: all inside the bucket's window (bitmap 16 KB, class ids 512 KB) or a cache-resident table
-                w[k]  = ok[k] ? bitmap[(ps[k] + 1u) >> 5] : 0u;
-                cn[k] = ok[k] ? cls[ps[k] + n - 1u] : 0u;
-                dn[k] = ok[k] ? prev->binkept[code[k] >> 10] : 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < kChPer; ++k) {
-                ok[k] = ok[k] && ((w[k] >> ((ps[k] + 1u) & 31u)) & 1u);
-                dn[k] += code[k] & 1023u;
-            }
-            append(ok, dn, cn, ps);
-        }
+        for (int q = 0; q < kChPer; ++q)
+            if (k2[q]) ck.put(Q, at++, c2[q] /* bi2_pospart_kernel left dense survivor numbers */, cn[q], p2[q]);
+        Q.qn += total;
+        Q.nadm += total;
+        if (Q.qn >= (uint32_t)kChStep) Q.flush(recsA, region, sub, bs);
     }
-    // (b) order 3: the windows whose bigram is a surviving head pair (they are on no list)
-    if (HEAD) {
-        const uint32_t sw0 = surv[0], sw1 = surv[1];
-        const uint32_t ntiles = (npos + kChStep - 1) / kChStep;
-        for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-            uint32_t ps[kChPer], c0[kChPer], c1[kChPer], w[kChPer], cn[kChPer], dn[kChPer];
-            bool     ok[kChPer];
-#pragma unroll
-            for (int k = 0; k < kChPer; ++k) {
-                ps[k] = tile * kChStep + k * kBi2Threads + threadIdx.x;
-                c0[k] = ps[k] < npos ? cls[ps[k]] : 0u;
-                c1[k] = ps[k] < npos ? cls[ps[k] + 1u] : 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < kChPer; ++k) {
-                ok[k] = false;
-                w[k] = cn[k] = dn[k] = 0;
-                if (c0[k] - 1u < (uint32_t)(kBi2Head - 1) && c1[k] - 1u < (uint32_t)(kBi2Head - 1)) {
-                    const uint32_t s0 = (c0[k] < 32 ? sw0 >> c0[k] : sw1 >> (c0[k] - 32)) & 1u, s1 = (c1[k] < 32 ? sw0 >> c1[k] : sw1 >> (c1[k] - 32)) & 1u;
-                    const uint32_t h  = c0[k] * kBi2Head + c1[k];
-                    if (s0 & s1 & (hsL[h >> 5] >> (h & 31u))) {
-                        ok[k] = true;
-                        w[k]  = bitmap[(ps[k] + 1u) >> 5];
-                        cn[k] = cls[ps[k] + 2u];
-                        dn[k] = headid[h] - rbase;
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < kChPer; ++k) ok[k] = ok[k] && ((w[k] >> ((ps[k] + 1u) & 31u)) & 1u);
-            append(ok, dn, cn, ps);
-        }
-    }
-    if (qn) flush();
-    if (threadIdx.x == 0 && nadm) atomicAdd(&st->admitted, nadm);
+    if (Q.qn) Q.flush(recsA, region, sub, bs);
+    if (threadIdx.x == 0 && Q.nadm) atomicAdd(&st->admitted, Q.nadm);
 }
 
 }  // namespace colibri

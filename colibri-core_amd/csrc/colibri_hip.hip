@@ -144,6 +144,7 @@ struct colibri_ctx {
         DevBuf<uint8_t>  sid;                    // sliced orders: the key slice of the window at every position (first pass), read by the later passes
         DevBuf<uint32_t> wcode, pcode, headid;  // the modes that keep ids: (bin, rank) codes beside the positions, result index of every head bigram
         bool             disabled = false;  // set for the rerun after this path could not hold an order (region / bin / list overflow)
+        DevBuf<uint32_t> steps;             // ... chain_steps_kernel: the step tables of the eight XCDs, then their lengths
         DevBuf<Bi2State> state2, state3;    // chain.hpp: orders >= 3 on this engine ping-pong between these two (odd orders: state2); order 2's stays in `state`
         bool             chain_disabled = false;  // set for the rerun after an order >= 3 did not fit the engine (key bits, a region, a bin)
         bool             attr_set = false;
@@ -529,7 +530,7 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->tx.table); dev_free(c->tx.state); dev_free(c->tx.info); dev_free(c->tx.events); dev_free(c->tx.evcnt);
     dev_free(c->flag2);
     dev_free(c->b2.wcode); dev_free(c->b2.pcode); dev_free(c->b2.headid); dev_free(c->b2.sid);
-    dev_free(c->b2.state2); dev_free(c->b2.state3);
+    dev_free(c->b2.state2); dev_free(c->b2.state3); dev_free(c->b2.steps);
     dev_free(c->b2.state); dev_free(c->b2.boff); dev_free(c->b2.head_rows); dev_free(c->b2.wlist); dev_free(c->b2.wcnt); dev_free(c->b2.plist); dev_free(c->b2.bitmap); dev_free(c->b2.headsurv);
     dev_free(c->ids_at);
     dev_free(c->alist[0]);
@@ -858,6 +859,7 @@ inline uint32_t slice_bits(uint64_t records) {  // passes needed for that many r
 }
 struct Bigram2Plan {
     uint32_t nslots, region, pshift, nbuckets, wcap, wextra, clsbits, posbits, sbits;
+    size_t   listn;  // entries of plist / pcode when the head windows' lists are behind the shards' (chain.hpp)
     Bi2Lists pl;
 };
 Bigram2Plan bigram2_plan(const colibri_ctx* c, uint32_t npos) {
@@ -872,6 +874,8 @@ Bigram2Plan bigram2_plan(const colibri_ctx* c, uint32_t npos) {
     b.nbuckets  = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)npos + (1u << b.pshift) - 1) >> b.pshift));
     b.pl.pshift = b.pshift;
     b.pl.pcap   = ((1u << b.pshift) / 4 + 4096 + 3) & ~3u;  // a bucket's entries spread evenly over the 8 shards: twice the expected worst case
+    b.pl.hbase  = kBi2Shards * kBi2Buckets * b.pl.pcap;     // (chain.hpp) the head windows' lists lie behind the shards'
+    b.listn     = (size_t)b.pl.hbase + ((size_t)b.nbuckets << b.pshift) + 64;
     b.wcap      = (uint32_t)(((uint64_t)npos * 6 / 10 / kBi2Waves) * 2 + 4096);
     b.wextra    = npos / b.wcap + kBi2Waves * kWave / kBi2BigThreads + 64;  // the list pool of bi2_count_big_kernel: every position once, one partly filled list per wave of its grid
     b.clsbits   = 1;
@@ -892,11 +896,11 @@ int bigram2_alloc(colibri_ctx* c, uint32_t npos, bool chain = false) {
     int               rc;
     if ((rc = dev_alloc(c, c->b2.state, 1)) || (rc = dev_alloc(c, c->b2.boff, (size_t)b.nslots * (kBi2BBins + 1))) ||
         (rc = dev_alloc(c, c->b2.head_rows, (size_t)kBi2EmitGrid * 2 * kBi2HeadN)) || (rc = dev_alloc(c, c->b2.wlist, (size_t)(kBi2Waves + b.wextra) * b.wcap)) ||
-        (rc = dev_alloc(c, c->b2.wcnt, (size_t)kBi2Waves + b.wextra + 1)) || (rc = dev_alloc(c, c->b2.plist, (size_t)kBi2Shards * kBi2Buckets * b.pl.pcap + 64)) ||
+        (rc = dev_alloc(c, c->b2.wcnt, (size_t)kBi2Waves + b.wextra + 1)) || (rc = dev_alloc(c, c->b2.plist, chain ? b.listn : (size_t)kBi2Shards * kBi2Buckets * b.pl.pcap + 64)) ||
         (rc = dev_alloc(c, c->b2.bitmap, (size_t)npos / 32 + 16)) || (rc = dev_alloc(c, c->b2.headsurv, kBi2HeadN / 32)))
         return rc;
-    if (chain && ((rc = dev_alloc(c, c->b2.state2, 1)) || (rc = dev_alloc(c, c->b2.state3, 1)) || (rc = dev_alloc(c, c->b2.wcode, (size_t)(kBi2Waves + b.wextra) * b.wcap)) ||
-                  (rc = dev_alloc(c, c->b2.pcode, (size_t)kBi2Shards * kBi2Buckets * b.pl.pcap + 64)) || (rc = dev_alloc(c, c->b2.headid, kBi2HeadN))))
+    if (chain && ((rc = dev_alloc(c, c->b2.steps, 2 * (size_t)kChXcds * chain_steps_cap(b.pl) + kChXcds)) || (rc = dev_alloc(c, c->b2.state2, 1)) || (rc = dev_alloc(c, c->b2.state3, 1)) || (rc = dev_alloc(c, c->b2.wcode, (size_t)(kBi2Waves + b.wextra) * b.wcap)) ||
+                  (rc = dev_alloc(c, c->b2.pcode, b.listn)) || (rc = dev_alloc(c, c->b2.headid, kBi2HeadN))))
         return rc;
     if (b.sbits) {
         if ((rc = dev_alloc(c, c->b2.sid, (size_t)npos + 64))) return rc;
@@ -939,7 +943,8 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
             Prof p(c, COLIBRI_K_EMIT2);
             if (slice == 0 || b.sbits < 2 || getenv("COLIBRI_SLICED_EMIT_OFF"))  // (two slices: a step of 16 384 positions would fill the queue)
                 hipLaunchKernelGGL(bi2_emit_kernel, dim3(kBi2EmitGrid), dim3(kBi2Threads), 0, c->stream, c->cls.p, c->uni_surv.p, nsurv, npos, b.clsbits, b.sbits, slice, b.posbits, recsA,
-                                   b.region, kBi2Sub, bs, c->state.p, c->b2.head_rows.p, b.sbits ? c->b2.sid.p : (uint8_t*)nullptr);
+                                   b.region, kBi2Sub, bs, c->state.p, c->b2.head_rows.p, b.sbits ? c->b2.sid.p : (uint8_t*)nullptr, 0u, (chain && want_list) ? c->b2.plist.p : (uint32_t*)nullptr,
+                                   (chain && want_list) ? c->b2.pcode.p : (uint32_t*)nullptr, b.pl);
             else  // the first pass left every window's slice in sid: the later ones only touch their own windows
                 hipLaunchKernelGGL(bi2_emit_sliced_kernel, dim3(kBi2EmitGrid), dim3(kBi2Threads), 0, c->stream, c->cls.p, (const uint8_t*)c->b2.sid.p, npos, b.clsbits, b.sbits, slice, b.posbits,
                                    std::max(1u, std::min(8u, 1u << b.sbits) / 4u), recsA, b.region, kBi2Sub, bs, c->state.p);
@@ -974,10 +979,11 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
     {
         Prof p(c, COLIBRI_K_LISTS2);
         hipLaunchKernelGGL(bi2_pospart_kernel, dim3(512), dim3(kBi2Threads), 0, c->stream, c->b2.wlist.p, c->b2.wcnt.p, kBi2Waves + b.wextra, b.wcap, bs, c->state.p, c->b2.plist.p, b.pl,
-                           with_codes ? (const uint32_t*)c->b2.wcode.p : (const uint32_t*)nullptr, with_codes ? c->b2.pcode.p : (uint32_t*)nullptr);
-        if (chain) {  // the bitmap with the head survivors in it (and st->valid); the pairs stay where the partition left them: chain_order(3) walks them
+                           with_codes ? (const uint32_t*)c->b2.wcode.p : (const uint32_t*)nullptr, with_codes ? c->b2.pcode.p : (uint32_t*)nullptr, 0u, /*dense=*/chain);
+        if (chain) {  // who of the head pairs survived; the bitmap of all listed positions (and st->valid). The pairs stay where they are: chain_order(3) walks them
+            hipLaunchKernelGGL(bi2_headids_kernel, dim3(1), dim3(kBlock), 0, c->stream, (const Bi2State*)bs, (const DevState*)c->state.p, c->b2.headid.p);
             hipLaunchKernelGGL(chain_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, (const Bi2State*)bs, (const uint32_t*)c->b2.plist.p, b.pl,
-                               c->state.p, c->b2.bitmap.p, (const uint32_t*)c->cls.p, (const uint32_t*)c->uni_surv.p, (const uint32_t*)c->b2.headsurv.p);
+                               c->state.p, c->b2.bitmap.p, (const uint32_t*)c->b2.pcode.p, (const uint32_t*)c->b2.headid.p);
             return COLIBRI_OK;
         }
         if (ids_out != nullptr) {
@@ -1013,16 +1019,14 @@ int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next) {
     HIP_TRY(c, hipMemsetAsync(c->b2.wcnt.p, 0, sizeof(uint32_t) * ((size_t)kBi2Waves + b.wextra + 1), c->stream));
     {
         Prof p(c, COLIBRI_K_EMIT);
-        if (n == 3) {
-            hipLaunchKernelGGL(bi2_headids_kernel, dim3(1), dim3(kBlock), 0, c->stream, prev, (const DevState*)c->state.p, c->b2.headid.p);
-            hipLaunchKernelGGL((chain_emit_kernel<true>), dim3(kBi2EmitGrid), dim3(kBi2Threads), 0, c->stream, (const uint32_t*)c->cls.p, npos, (uint32_t)n, b.clsbits, b.posbits, prev,
-                               (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p, b.pl, b.nbuckets, (const uint32_t*)c->b2.bitmap.p, (const uint32_t*)c->uni_surv.p,
-                               (const uint32_t*)c->b2.headsurv.p, (const uint32_t*)c->b2.headid.p, recsA, b.region, kBi2Sub, bs, c->state.p);
-        } else {
-            hipLaunchKernelGGL((chain_emit_kernel<false>), dim3(kBi2EmitGrid), dim3(kBi2Threads), 0, c->stream, (const uint32_t*)c->cls.p, npos, (uint32_t)n, b.clsbits, b.posbits, prev,
-                               (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p, b.pl, b.nbuckets, (const uint32_t*)c->b2.bitmap.p, (const uint32_t*)nullptr,
-                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, recsA, b.region, kBi2Sub, bs, c->state.p);
-        }
+        static const uint32_t grid = getenv("COLIBRI_CH_GRID") ? (uint32_t)atoi(getenv("COLIBRI_CH_GRID")) : 768u;  // (a multiple of kBi2Sub; three resident blocks per CU)
+        const uint32_t cap = chain_steps_cap(b.pl);
+        hipLaunchKernelGGL(chain_steps_kernel, dim3(kChXcds), dim3(kBi2Threads), 0, c->stream, prev, b.pl, b.nbuckets, reinterpret_cast<uint2*>(c->b2.steps.p), cap,
+                           c->b2.steps.p + 2 * (size_t)kChXcds * cap, (const DevState*)c->state.p);
+        hipLaunchKernelGGL(chain_emit_kernel, dim3(grid), dim3(kChThreads), 0, c->stream, (const uint32_t*)c->cls.p, npos, (uint32_t)n, b.clsbits, b.posbits, prev,
+                           (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p, b.pl, reinterpret_cast<const uint2*>(c->b2.steps.p), cap,
+                           (const uint32_t*)(c->b2.steps.p + 2 * (size_t)kChXcds * cap),
+                           (const uint32_t*)c->b2.bitmap.p, recsA, b.region, kBi2Sub, bs, c->state.p, (const uint32_t*)c->b2.headid.p, getenv("COLIBRI_CH_DBG") ? (uint32_t)atoi(getenv("COLIBRI_CH_DBG")) : 0u);
         hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, b.region, kBi2Sub, c->state.p);
     }
     {
@@ -1048,9 +1052,9 @@ int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next) {
     {
         Prof p(c, COLIBRI_K_LISTS2);
         hipLaunchKernelGGL(bi2_pospart_kernel, dim3(512), dim3(kBi2Threads), 0, c->stream, c->b2.wlist.p, c->b2.wcnt.p, kBi2Waves + b.wextra, b.wcap, bs, c->state.p, c->b2.plist.p, b.pl,
-                           (const uint32_t*)c->b2.wcode.p, c->b2.pcode.p);
+                           (const uint32_t*)c->b2.wcode.p, c->b2.pcode.p, 0u, /*dense=*/true);
         hipLaunchKernelGGL(chain_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, (const Bi2State*)bs, (const uint32_t*)c->b2.plist.p, b.pl,
-                           c->state.p, c->b2.bitmap.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                           c->state.p, c->b2.bitmap.p);
     }
     return COLIBRI_OK;
 }

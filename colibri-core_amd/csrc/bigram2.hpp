@@ -67,7 +67,7 @@ constexpr int      kBi2HugeCap   = 4096;
 constexpr uint32_t kBi2HeadCode  = 0x80000000u;           // a list entry's code with this bit: a head window, the low 12 bits name the class pair (chain.hpp)
 constexpr int      kBi2BigCap    = 32768;                 // (a 10^9-token corpus counted in 8 key slices: ~7000 per slice)
 
-struct Bi2State {
+struct __attribute__((aligned(16))) Bi2State {
     uint32_t curA[kBi2MaxSlots];  // emit cursors = records per slot (beyond `region`: overflow)
     uint32_t cntA[kBins];         // records per A bin
     uint32_t offAt[kBins + 1];    // exclusive scan of cntA

@@ -42,8 +42,17 @@ constexpr uint32_t kChLists = kBi2Shards + 1;  // lists per bucket: the eight sh
 // (16 KB, cache-resident). Rounds 2-3 evaluated the head again, from the class ids, in every kernel that needed "did the bigram at i survive".
 __device__ __forceinline__ bool chain_head_alive(uint32_t code, const uint32_t* __restrict__ headid) { return headid[code & 0xFFFu] != kInvalid; }
 
+// ---- one launch clears what an order starts from: its Bi2State and the position lists' counts (two fills of ~5 us each before) ----------------------------------------
+__global__ __launch_bounds__(kBlock) void chain_reset_kernel(Bi2State* __restrict__ bs, uint32_t* __restrict__ wcnt, uint32_t nwcnt) {
+    static_assert(sizeof(Bi2State) % 16 == 0, "cleared with 16-byte stores");
+    uint4* const   p = reinterpret_cast<uint4*>(bs);
+    const uint32_t n = (uint32_t)(sizeof(Bi2State) / 16), t = blockIdx.x * kBlock + threadIdx.x, step = gridDim.x * kBlock;
+    for (uint32_t i = t; i < n; i += step) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (uint32_t i = t; i < nwcnt; i += step) wcnt[i] = 0u;
+}
+
 // ---- bitmap: per position bucket, the listed positions -> one bit each; st->valid += set bits ---------------------------------------------------------------------------
-// bitmap words beyond the corpus must read zero (the caller clears 16 of them).
+// The 16 words beyond the corpus read zero (the last bucket's block clears them: chain_emit_kernel looks at bit i + 1).
 __global__ __launch_bounds__(kBi2BmThreads) void chain_bitmap_kernel(uint32_t npos, const Bi2State* __restrict__ bs, const uint32_t* __restrict__ plist, Bi2Lists pl, DevState* __restrict__ st,
                                                                       uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ pcode = nullptr /* order 2: the head windows' codes ... */,
                                                                       const uint32_t* __restrict__ headid = nullptr /* ... and who of them survived */) {
@@ -92,6 +101,7 @@ __global__ __launch_bounds__(kBi2BmThreads) void chain_bitmap_kernel(uint32_t np
         bitmap[(start >> 5) + w] = x;
         nset += (uint32_t)__popc(x);
     }
+    if (start + size == npos && threadIdx.x < 16) bitmap[(start >> 5) + nwords + threadIdx.x] = 0u;
     for (int off = 32; off > 0; off >>= 1) nset += __shfl_down(nset, off, kWave);
     if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nset;
     __syncthreads();

@@ -146,6 +146,8 @@ struct colibri_ctx {
         bool             disabled = false;  // set for the rerun after this path could not hold an order (region / bin / list overflow)
         DevBuf<uint32_t> steps;             // ... chain_steps_kernel: the step tables of the eight XCDs, then their lengths
         DevBuf<Bi2State> state2, state3;    // chain.hpp: orders >= 3 on this engine ping-pong between these two (odd orders: state2); order 2's stays in `state`
+        hipStream_t      aux = nullptr;     // ... the hot bins' workgroup kernel runs beside the wave kernel
+        hipEvent_t       ev_fork = nullptr, ev_join = nullptr;
         bool             chain_disabled = false;  // set for the rerun after an order >= 3 did not fit the engine (key bits, a region, a bin)
         bool             attr_set = false;
     } b2;
@@ -584,6 +586,11 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->keylen);
     dev_free(c->keyoff);
     dev_free(c->bsum);
+    if (c->b2.aux) {
+        (void)hipStreamDestroy(c->b2.aux);
+        (void)hipEventDestroy(c->b2.ev_fork);
+        (void)hipEventDestroy(c->b2.ev_join);
+    }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -897,8 +904,13 @@ int bigram2_alloc(colibri_ctx* c, uint32_t npos, bool chain = false) {
     if ((rc = dev_alloc(c, c->b2.state, 1)) || (rc = dev_alloc(c, c->b2.boff, (size_t)b.nslots * (kBi2BBins + 1))) ||
         (rc = dev_alloc(c, c->b2.head_rows, (size_t)kBi2EmitGrid * 2 * kBi2HeadN)) || (rc = dev_alloc(c, c->b2.wlist, (size_t)(kBi2Waves + b.wextra) * b.wcap)) ||
         (rc = dev_alloc(c, c->b2.wcnt, (size_t)kBi2Waves + b.wextra + 1)) || (rc = dev_alloc(c, c->b2.plist, chain ? b.listn : (size_t)kBi2Shards * kBi2Buckets * b.pl.pcap + 64)) ||
-        (rc = dev_alloc(c, c->b2.bitmap, (size_t)npos / 32 + 16)) || (rc = dev_alloc(c, c->b2.headsurv, kBi2HeadN / 32)))
+        (rc = dev_alloc(c, c->b2.bitmap, (size_t)npos / 32 + 24)) || (rc = dev_alloc(c, c->b2.headsurv, kBi2HeadN / 32)))
         return rc;
+    if (chain && c->b2.aux == nullptr) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->b2.aux, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->b2.ev_fork, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->b2.ev_join, hipEventDisableTiming));
+    }
     if (chain && ((rc = dev_alloc(c, c->b2.steps, 2 * (size_t)kChXcds * chain_steps_cap(b.pl) + kChXcds)) || (rc = dev_alloc(c, c->b2.state2, 1)) || (rc = dev_alloc(c, c->b2.state3, 1)) || (rc = dev_alloc(c, c->b2.wcode, (size_t)(kBi2Waves + b.wextra) * b.wcap)) ||
                   (rc = dev_alloc(c, c->b2.pcode, b.listn)) || (rc = dev_alloc(c, c->b2.headid, kBi2HeadN))))
         return rc;
@@ -1015,8 +1027,7 @@ int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next) {
     auto* const           recsA = reinterpret_cast<unsigned long long*>(c->recs[0].p);
     auto* const           recsB = reinterpret_cast<unsigned long long*>(c->recs[1].p);
     const BinnedIO        io    = binned_planes(c, pl, false);
-    HIP_TRY(c, hipMemsetAsync(bs, 0, sizeof(Bi2State), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->b2.wcnt.p, 0, sizeof(uint32_t) * ((size_t)kBi2Waves + b.wextra + 1), c->stream));
+    hipLaunchKernelGGL(chain_reset_kernel, dim3(256), dim3(kBlock), 0, c->stream, bs, c->b2.wcnt.p, kBi2Waves + b.wextra + 1);
     {
         Prof p(c, COLIBRI_K_EMIT);
         static const uint32_t grid = getenv("COLIBRI_CH_GRID") ? (uint32_t)atoi(getenv("COLIBRI_CH_GRID")) : 768u;  // (a multiple of kBi2Sub; three resident blocks per CU)
@@ -1035,11 +1046,17 @@ int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next) {
         hipLaunchKernelGGL(bi2_binoff_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->b2.boff.p, kBi2Sub, c->state.p);
     }
     {
+        // the hot bins (a workgroup each: tens of thousands of windows of one frequent n-gram) run beside the wave kernel, on a second stream: they touch other bins, other
+        // position lists (the pool behind the waves' own) and share only atomically updated counters. One after the other the few hot bins cost ~0.1 ms at order 3
         Prof p(c, COLIBRI_K_BINCOUNT);
-        hipLaunchKernelGGL((bi2_count_big_kernel<(int)kBi2Sub>), dim3(kBi2Waves * kWave / kBi2BigThreads), dim3(kBi2BigThreads), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr,
+        HIP_TRY(c, hipEventRecord(c->b2.ev_fork, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->b2.aux, c->b2.ev_fork, 0));
+        hipLaunchKernelGGL((bi2_count_big_kernel<(int)kBi2Sub>), dim3(kBi2Waves * kWave / kBi2BigThreads), dim3(kBi2BigThreads), 0, c->b2.aux, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr,
                            io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_next, want_next ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr, kBi2Waves, b.wextra);
+        HIP_TRY(c, hipEventRecord(c->b2.ev_join, c->b2.aux));
         hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr, io.sp_rep, io.sp_cnt,
                            c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_next, want_next ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr, true);
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->b2.ev_join, 0));
     }
     {
         Prof p(c, COLIBRI_K_PRUNE);
@@ -1048,7 +1065,6 @@ int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next) {
         hipLaunchKernelGGL(bi2_compact_kernel, dim3(1025), dim3(kBlock), 0, c->stream, io.sp_rep, io.sp_cnt, c->state.p, bs, c->res_rep.p, c->res_cnt.p, pl.res_cap);
     }
     if (!want_next) return COLIBRI_OK;
-    HIP_TRY(c, hipMemsetAsync(c->b2.bitmap.p + npos / 32, 0, sizeof(uint32_t) * 16, c->stream));
     {
         Prof p(c, COLIBRI_K_LISTS2);
         hipLaunchKernelGGL(bi2_pospart_kernel, dim3(512), dim3(kBi2Threads), 0, c->stream, c->b2.wlist.p, c->b2.wcnt.p, kBi2Waves + b.wextra, b.wcap, bs, c->state.p, c->b2.plist.p, b.pl,

@@ -82,6 +82,8 @@ struct __attribute__((aligned(16))) Bi2State {
     uint32_t kbits;     // key bits below the slice bits (K - s): A bin = bits [kbits-1 : kbits-8], B bin = the nine below
     uint32_t posbits;   // position bits of a record
     uint32_t res_base;  // first result index of this pass's survivors (an order counted in slices appends pass after pass)
+    uint32_t cskip;      // key-sharded runs (kshard2.hpp): the w mix bits between the A bin and the B bin (they pick the owner-local A' bin at the source, and are part of it at the owner)
+    uint32_t bshift_fix; // key-sharded runs: bshift + 1 as every rank agreed on it (0: bi2_offsets_kernel derives it from this pass's record count)
     uint32_t hugebin;   // records from which a final bin goes to bi2_count_big_kernel; 0: kBi2HugeBin (written with kbits by the emit kernel of the order)
     uint32_t nextchunk;                 // owner passes of key-sharded runs: next free chunk of the position-list pool (bi2_count_kernel<.., BASED>)
     uint32_t nextbin[kBi2Shards * 16];  // work queues of the count kernel (one per shard, 64 bytes apart): next group of bins to hand out
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void bi2_offsets_kernel(Bi2State* __restric
         // the 31-bit in-bin key must hold every mix bit the bin does not fix: kbits - 17 + bshift <= 31
         const uint32_t K = bs->kbits;
         if (sh + K > 48u) sh = K >= 48u ? 0u : 48u - K;
-        bs->bshift = sh;
+        bs->bshift = bs->bshift_fix ? bs->bshift_fix - 1u : sh;
     }
 }
 
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2LbPer == 4 ? kBi2Threads / 128 : 1
     const uint32_t  slot = blockIdx.x;
     const uint32_t  n    = min(bs->curA[slot], region);
     const uint32_t  bsh  = bs->bshift;
-    const uint32_t  bbit = bs->posbits + bs->kbits - 17;  // the B bin = the nine mix bits below the A bin = record bits [bbit + 8 : bbit]
+    const uint32_t  bbit = bs->posbits + bs->kbits - 17 - bs->cskip;  // the B bin = the nine mix bits below the A bin (and the cskip bits) = record bits [bbit + 8 : bbit]
     const size_t    base = slotbase != nullptr ? (size_t)slotbase[slot] : (size_t)slot * region;
     uint32_t* const bo   = boff + (size_t)slot * (kBi2BBins + 1);
     if (threadIdx.x < kBi2BBins) histL[threadIdx.x] = 0;
@@ -691,7 +693,11 @@ __device__ unsigned long long bi2_prof[16];
 // late waves —, so a fixed capacity per wave is no bound there; the pool needs room for the survivors plus one partly filled chunk per wave.
 constexpr uint32_t kBi2Chunk = 4096;
 // ROWS: records per lane held in registers (bins of up to 64 x ROWS records are read once; an owner of a 125 M-token-per-rank run holds ~810 per bin: 16 rows)
-template <int NSUB, bool BASED = false, int ROWS = kBi2WRows>
+// KEY4 (key-sharded runs, kshard2.hpp; with BASED): the owner's form. recsB is an array of 4-BYTE in-bin keys, the sources' streams one after the other, in final-bin
+// order (the sources partitioned completely); a record's "position" is its place: source << 28 | index in the source's stream (bs->posbits = 31). Nothing is listed:
+// every record's entry of code_at (= wlist) becomes (final bin << 10 | rank of its key among the bin's survivors), or kInvalid — in stream order, so the source finds its
+// windows again by counting. A record's "position" is its place in the receive buffer (31 bits; lower place = lower source rank first).
+template <int NSUB, bool BASED = false, int ROWS = kBi2WRows, bool KEY4 = false>
 __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const uint32_t* __restrict__ boff, Bi2State* __restrict__ bs,
                                                               DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
                                                               uint32_t* __restrict__ wlist, uint32_t* __restrict__ wcnt, uint32_t wcap, bool want_positions,
@@ -701,6 +707,9 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
                                                               bool big_elsewhere = false /* bi2_count_big_kernel has counted the huge bins */) {
     if (st->done) return;
     static_assert(3 * NSUB + 1 <= kWave, "bound loaders are lanes of the wave");
+    static_assert(!KEY4 || (BASED && NSUB == 8), "the owner's form");
+    const uint32_t* const keys4   = reinterpret_cast<const uint32_t*>(recsB);
+    uint32_t* const       code_at = wlist;
     __shared__ __attribute__((aligned(16))) uint32_t keyT[kBi2Slots];
     __shared__ __attribute__((aligned(16))) uint32_t cntT[kBi2Slots];
     __shared__ uint32_t                              repS[kBi2WReps];
@@ -759,11 +768,16 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
             }
             return BASED ? (size_t)sbase + off : (size_t)slot * region + off;
         };
+        auto load = [&](uint32_t j) -> unsigned long long {  // record j of the bin as (key << pb | position)
+            if (!KEY4) return recsB[locate(j)];
+            const uint32_t idx = (uint32_t)locate(j);
+            return ((unsigned long long)(keys4[idx] & 0x7FFFFFFFu) << 31) | idx;
+        };
         unsigned long long x[ROWS];
 #pragma unroll
         for (int q = 0; q < ROWS; ++q) {
             const uint32_t j = q * kWave + lane;
-            x[q]             = j < total ? recsB[locate(j)] : 0ull;
+            x[q]             = j < total ? load(j) : 0ull;
         }
         BI2_W(2);
         uint32_t nslots = 256;
@@ -809,7 +823,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t j = j0 + k * kWave + lane;
-                    y[k]             = j < total ? recsB[locate(j)] : ~0ull;
+                    y[k]             = j < total ? load(j) : ~0ull;
                 }
             };
             load4(ROWS * kWave);
@@ -867,7 +881,15 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
             if (ktotal) atomicAdd(&bs->kept_part[a], ktotal);
         }
         BI2_W(6);
-        if (ktotal == 0) return;
+        if (ktotal == 0) {
+            if (KEY4) {  // nothing of this bin survived: its records say so
+#pragma unroll
+                for (int q = 0; q < ROWS; ++q)
+                    if ((uint32_t)(q * kWave) + lane < total) code_at[(uint32_t)(x[q] & pmask)] = kInvalid;
+                for (uint32_t j = ROWS * kWave + lane; j < total; j += kWave) code_at[locate(j)] = kInvalid;
+            }
+            return;
+        }
         const bool reps_lds = ktotal <= (uint32_t)kBi2WReps;
         {
             uint32_t r = excl;
@@ -898,6 +920,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
             if (valid) c = cntT[s];
             const bool     kept = (c & kBi2Kept) != 0;
             const uint32_t r    = c & ~kBi2Kept;
+            if (KEY4 && valid) code_at[pos] = kept ? (fcode | r) : kInvalid;  // (a run's records lie one after the other: the stores of a row are coalesced)
             if (kept) {  // (read first: a hot key's windows all aim at one word, and after the first rows hardly any of them lowers it)
                 if (reps_lds) {
                     if (pos < repS[r]) atomicMin(&repS[r], pos);
@@ -905,7 +928,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
                     atomicMin(&sp_rep[spo + r], pos);
                 }
             }
-            if (want_positions) {
+            if (want_positions && !KEY4) {
                 const uint64_t m = __ballot(kept);
                 const uint32_t n = (uint32_t)__popcll(m);
                 if (BASED) {
@@ -944,7 +967,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t j = j0 + k * kWave + lane;
-                    y[k]             = j < total ? recsB[locate(j)] : ~0ull;
+                    y[k]             = j < total ? load(j) : ~0ull;
                 }
             };
             load4(ROWS * kWave);
@@ -1025,7 +1048,7 @@ __device__ __forceinline__ void bi2_merge_leader(bool& act, uint32_t key, uint32
             act = false;
     }
 }
-template <int NSUB, bool BASED = false>
+template <int NSUB, bool BASED = false, bool KEY4 = false>
 __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const uint32_t* __restrict__ boff, Bi2State* __restrict__ bs,
                                                                        DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
                                                                        uint32_t* __restrict__ wlist, uint32_t* __restrict__ wcnt, uint32_t wcap, bool want_positions,
@@ -1034,6 +1057,8 @@ __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const uns
     if (st->done) return;
     const uint32_t nbig = bs->nhuge;
     if (nbig == 0 || nbig > (uint32_t)kBi2HugeCap) return;  // (more than the list holds: bi2_count_kernel walks every bin itself)
+    const uint32_t* const keys4   = reinterpret_cast<const uint32_t*>(recsB);
+    uint32_t* const       code_at = wlist;
     constexpr int                                    kW = kBi2BigThreads / kWave;
     __shared__ __attribute__((aligned(16))) uint32_t keyT[kBi2Slots];
     __shared__ __attribute__((aligned(16))) uint32_t cntT[kBi2Slots];
@@ -1095,7 +1120,12 @@ __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const uns
 #pragma unroll
             for (int q = 0; q < kBi2BigRows; ++q) {
                 const uint32_t j = j0 + q * kBi2BigThreads + tid;
-                y[q]             = j < total ? recsB[locate(j)] : ~0ull;
+                if (KEY4) {
+                    const uint32_t idx = j < total ? (uint32_t)locate(j) : 0u;
+                    y[q]               = j < total ? (((unsigned long long)(keys4[idx] & 0x7FFFFFFFu) << 31) | idx) : ~0ull;
+                } else {
+                    y[q] = j < total ? recsB[locate(j)] : ~0ull;
+                }
             }
         };
         // pass 1: find or insert, count
@@ -1149,7 +1179,11 @@ __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const uns
             bs->binkept[a * kBi2BBins + b] = ktotal;
             if (ktotal) atomicAdd(&bs->kept_part[a], ktotal);
         }
-        if (ktotal == 0) continue;
+        if (ktotal == 0) {
+            if (KEY4)
+                for (uint32_t j = tid; j < total; j += kBi2BigThreads) code_at[locate(j)] = kInvalid;
+            continue;
+        }
         const bool reps_lds = ktotal <= (uint32_t)kBi2WReps;
         {
             uint32_t       r     = excl;
@@ -1182,6 +1216,7 @@ __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const uns
                 if (valid) c = cntT[bi2_find(keyT, key, bi2_bucket_of(key, lgb, bmask), bmask)];
                 const bool     kept = (c & kBi2Kept) != 0;
                 const uint32_t r    = c & ~kBi2Kept;
+                if (KEY4 && valid) code_at[pos] = kept ? (fcode | r) : kInvalid;
                 if (kept) {
                     if (reps_lds) {
                         if (pos < repS[r]) atomicMin(&repS[r], pos);
@@ -1189,7 +1224,7 @@ __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const uns
                         atomicMin(&sp_rep[spo + r], pos);
                     }
                 }
-                if (want_positions) {
+                if (want_positions && !KEY4) {
                     const uint64_t m = __ballot(kept);
                     const uint32_t n = (uint32_t)__popcll(m);
                     if (n && (chunk == kInvalid || cursor + n > csize)) {  // (wave-uniform) this row does not fit: close the list, take the next one of the pool

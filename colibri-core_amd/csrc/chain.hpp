@@ -175,25 +175,31 @@ static_assert(kChStep / kChThreads == kChPer && kChThreads >= kBins && kChThread
 
 struct ChainKey {
     uint32_t           K, clsbits, pb;
+    uint32_t           pshift, pdrop;  // key-sharded runs whose key and position exceed 64 bits (kshard2.hpp): the record's position lacks the three bits above pshift
     unsigned long long kmask;
     __device__ __forceinline__ void put(ChainQueue& q, uint32_t at, uint32_t dn, uint32_t cn, uint32_t pos) const {
         const uint64_t m = bi2_mix(((uint64_t)dn << clsbits) | cn, K);
-        q.qL[at]         = ((m & kmask) << pb) | pos;
-        q.qaL[at]        = (uint8_t)(m >> (K - 8));
+        if (pdrop) pos = ((pos >> (pshift + 3)) << pshift) | (pos & ((1u << pshift) - 1u));
+        q.qL[at]  = ((m & kmask) << pb) | pos;
+        q.qaL[at] = (uint8_t)(m >> (K - 8));
     }
 };
 // key bits of order n from what order n - 1 kept; false (and Bi2State::overflow) when the engine cannot hold them
-__device__ __forceinline__ bool chain_key_bits(const Bi2State* __restrict__ prev, uint32_t clsbits, uint32_t pb, Bi2State* __restrict__ bs, ChainKey& ck, uint32_t hugebin = 0) {
+// kfix (key-sharded runs): the key bits every rank agreed on (the numbers are global there); pb is then the width of the record's position field
+__device__ __forceinline__ bool chain_key_bits(const Bi2State* __restrict__ prev, uint32_t clsbits, uint32_t pb, Bi2State* __restrict__ bs, ChainKey& ck, uint32_t hugebin = 0,
+                                               uint32_t kfix = 0, uint32_t pshift = 0, uint32_t pdrop = 0) {
     const uint32_t kept_prev = prev->kept_bins + prev->kept_head;
     uint32_t       idbits    = 1;
     while (idbits < 32 && (1ull << idbits) < (uint64_t)kept_prev + 1) ++idbits;
-    const uint32_t K = max(idbits + clsbits, 17u);
+    const uint32_t K = kfix ? kfix : max(idbits + clsbits, 17u);
     if (threadIdx.x == 0) {
         bs->kbits   = K;
         bs->posbits = pb;
         bs->hugebin = hugebin ? hugebin : kChHugeBin;
     }
-    if (K > 48u || K - 8u + pb > 64u) {  // (the count kernel's in-bin key holds K - 17 + bshift <= 31 bits; the record K - 8 bits beside the position)
+    ck.pshift = pshift;
+    ck.pdrop  = pdrop;
+    if ((!kfix && K > 48u) || K - 8u + pb > 64u) {  // (the count kernel's in-bin key holds K - 17 + bshift <= 31 bits; the record K - 8 bits beside the position)
         if (threadIdx.x == 0) bs->overflow = 1;
         return false;
     }
@@ -252,15 +258,16 @@ __global__ __launch_bounds__(kChThreads, 6) void chain_emit_kernel(const uint32_
                                                                     const uint32_t* __restrict__ plist, const uint32_t* __restrict__ pcode, Bi2Lists pl,
                                                                     const uint2* __restrict__ table, uint32_t cap, const uint32_t* __restrict__ nsteps,
                                                                     const uint32_t* __restrict__ bitmap, unsigned long long* __restrict__ recsA, uint32_t region, uint32_t nsub,
-                                                                    Bi2State* __restrict__ bs, DevState* __restrict__ st, const uint32_t* __restrict__ headid /* order 3 */, uint32_t dbg = 0) {
+                                                                    Bi2State* __restrict__ bs, DevState* __restrict__ st, const uint32_t* __restrict__ headid /* order 3 */, uint32_t dbg = 0,
+                                                                    uint32_t kfix = 0, uint32_t pdrop = 0 /* key-sharded runs: agreed key bits; pb then excludes the dropped bits */) {
     if (st->done) return;
     ChainKey ck;
-    if (!chain_key_bits(prev, clsbits, pb, bs, ck, dbg >> 8)) return;
+    if (!chain_key_bits(prev, clsbits, pb, bs, ck, dbg >> 8, kfix, pl.pshift, pdrop)) return;
     CHAIN_QUEUE_LDS(Q);
     const uint32_t        sub = blockIdx.x % nsub;
     const uint32_t        x = blockIdx.x % kChXcds, nper = gridDim.x / kChXcds, ns = nsteps[x];  // (grid: a multiple of 8)
     const uint2* const    tab = table + (size_t)x * cap;
-    const uint32_t        rbase = prev->res_base;
+    const uint32_t        rbase = kfix ? 0u : prev->res_base;  // (key-sharded runs: the head table holds global numbers)
     uint32_t              k = blockIdx.x / kChXcds;
     // software pipeline, two steps deep: the table entry of step k + 2 nper and the pairs of step k + nper are in flight while step k's gathers and partition run
     // (every one of these is a memory round trip; issued one after the other they were the step's time)

@@ -22,6 +22,7 @@
 #include "bigram2.hpp"
 #include "chain.hpp"
 #include "kshard.hpp"
+#include "kshard2.hpp"
 #include "textenc.hpp"
 #include "constrained.hpp"
 #include "flexgrams.hpp"
@@ -221,6 +222,13 @@ struct colibri_ctx {
         DevBuf<uint32_t>     osp_rep, osp_cnt, ores_rep, ores_cnt;  // owner: sparse per-bin survivors, dense survivors of the order
         DevBuf<uint32_t>     fin_rep, fin_cnt;                      // this rank's share of the model
         DevBuf<unsigned char> sbuf, rbuf[2], fbs, exs, fbr, exr;    // records out / in (+ level-B output); feedback and exports out / in
+        // second form (kshard2.hpp): the source's complete partition, the owner's per-record codes, the feedback's tiles
+        DevBuf<Ks2State>  ks2;
+        DevBuf<Ks2FbInfo> fbinfo;
+        DevBuf<uint32_t>  tab, key4, posbuf, rowtot, code_at, tcnt, fpos, fcode, zero8k, small;
+        uint32_t          sbase[kKsWorld + 1] = {0};  // this rank's send order: first key of each owner's share
+        uint32_t          bshift = 0;                 // the order's B-bin shift, agreed by all ranks
+        Bi2State*         src_state = nullptr;        // the source side's Bi2State of the running order
         hipStream_t side = nullptr;   // the host's early looks at exchange sizes (kshard_api.inc: ks_peek_*)
         hipEvent_t  ev = nullptr;
         uint32_t*   pinned = nullptr;
@@ -575,6 +583,8 @@ void colibri_destroy(colibri_ctx* c) {
         dev_free(k.oboff); dev_free(k.owcnt); dev_free(k.owlist); dev_free(k.lcnt); dev_free(k.loff); dev_free(k.reply_at); dev_free(k.osp_rep); dev_free(k.osp_cnt); dev_free(k.ores_rep);
         dev_free(k.ores_cnt); dev_free(k.fin_rep); dev_free(k.fin_cnt); dev_free(k.sbuf); dev_free(k.rbuf[0]); dev_free(k.rbuf[1]); dev_free(k.fbs); dev_free(k.exs); dev_free(k.fbr);
         dev_free(k.exr);
+        dev_free(k.ks2); dev_free(k.fbinfo); dev_free(k.tab); dev_free(k.key4); dev_free(k.posbuf); dev_free(k.rowtot); dev_free(k.code_at); dev_free(k.tcnt); dev_free(k.fpos);
+        dev_free(k.fcode); dev_free(k.zero8k); dev_free(k.small);
         if (k.side) (void)hipStreamDestroy(k.side);
         if (k.ev) (void)hipEventDestroy(k.ev);
         if (k.pinned) (void)hipHostFree(k.pinned);

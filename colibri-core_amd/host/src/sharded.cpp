@@ -316,13 +316,15 @@ class RankDriver {
             exchange({}, {{cnt, nclasses, false}}, s, false);
             chk(colibri_kshard_uni_apply(c), "colibri_kshard_uni_apply");
         }
-        int maxn = tokens_g ? 1 : 0;
+        int      maxn = tokens_g ? 1 : 0;
+        uint64_t est = tokens_g, ids = 0;  // an upper bound of the next order's records over all ranks; the numbers the last order handed out
         for (int n = 2; n <= maxlength && tokens_g; ++n) {
             void *                send = nullptr, *tab = nullptr, *head = nullptr;
-            std::vector<uint64_t> per_owner((size_t)world, 0), per_src((size_t)world, 0), one((size_t)world, 1);
-            uint32_t              recbytes = 0;
+            std::vector<uint64_t> per_owner((size_t)world, 0), per_src((size_t)world, 0);
+            uint32_t              recbytes = 0, tab_words = 0;
             uint64_t              admitted = 0;
-            step(colibri_kshard_emit(c, n, &send, &tab, per_owner.data(), &recbytes, &head, &admitted), "colibri_kshard_emit");
+            const int             more = n < maxlength;
+            step(colibri_kshard_emit(c, n, est, ids, more, &send, &tab, &tab_words, per_owner.data(), &recbytes, &head, &admitted), "colibri_kshard_emit");
             std::vector<uint64_t> mine = per_owner;
             mine.push_back(admitted);
             const auto everyone = agree(mine, err, "key-sharded run: window scan", s);
@@ -337,33 +339,41 @@ class RankDriver {
             void *recv = nullptr, *tab_recv = nullptr;
             step(colibri_kshard_recv_buffers(c, nrecv, &recv, &tab_recv), "colibri_kshard_recv_buffers");
             agree_cheap(err, "key-sharded run: receive buffers", s);
-            std::vector<uint64_t> tabn((size_t)world, 256);
+            std::vector<uint64_t> tabn((size_t)world, tab_words);
             std::vector<Reduce>   reds;
             if (head) {
                 reds.push_back({head, 4096, false});
                 reds.push_back({(uint32_t*)head + 4096, 4096, true});
             }
             exchange({{send, &per_owner, recv, &per_src, recbytes}, {tab, &tabn, tab_recv, &tabn, sizeof(uint32_t)}}, reds, s, false);
-            const int             more = n < maxlength;
             void *                fb = nullptr, *ex = nullptr;
-            std::vector<uint64_t> fb_dst((size_t)world, 0), ex_dst((size_t)world, 0), fb_src((size_t)world, 0), ex_src((size_t)world, 0);
+            std::vector<uint64_t> fb_dst((size_t)world, 0), ex_dst((size_t)world, 0), fb_src((size_t)world, 0), ex_src((size_t)world, 0), kept_by((size_t)world, 0);
             uint32_t              fb_bytes = 0;
-            step(colibri_kshard_count(c, n, per_src.data(), more, &fb, fb_dst.data(), &fb_bytes, &ex, ex_dst.data()), "colibri_kshard_count");
+            uint64_t              kept_bins = 0;
+            step(colibri_kshard_count(c, n, per_src.data(), more, &fb, fb_dst.data(), &fb_bytes, &ex, ex_dst.data(), &kept_bins), "colibri_kshard_count");
             mine = fb_dst;
             mine.insert(mine.end(), ex_dst.begin(), ex_dst.end());
+            mine.push_back(kept_bins);
             const auto back = agree(mine, err, "key-sharded run: count", s);
-            uint64_t   nfb = 0, nex = 0;
+            uint64_t   nfb = 0, nex = 0, fb_all = 0, keys_all = 0;
             for (int r = 0; r < world; ++r) {
                 fb_src[(size_t)r] = back[(size_t)r][(size_t)rank];
                 ex_src[(size_t)r] = back[(size_t)r][(size_t)(world + rank)];
+                kept_by[(size_t)r] = back[(size_t)r][(size_t)(2 * world)];
                 nfb += fb_src[(size_t)r];
                 nex += ex_src[(size_t)r];
+                for (int q = 0; q < world; ++q) fb_all += back[(size_t)r][(size_t)q];
+                for (int q = 0; q < world; ++q) keys_all += everyone[(size_t)r][(size_t)q];
             }
             void *fb_recv = nullptr, *ex_recv = nullptr;
             step(colibri_kshard_feedback_buffers(c, nfb, nex, &fb_recv, &ex_recv), "colibri_kshard_feedback_buffers");
             agree_cheap(err, "key-sharded run: feedback buffers", s);
             exchange({{fb, &fb_dst, fb_recv, &fb_src, fb_bytes}, {ex, &ex_dst, ex_recv, &ex_src, 8}}, {}, s, false);
-            chk(colibri_kshard_apply(c, n, nfb, nex, more), "colibri_kshard_apply");
+            // the feedback is a bit per key and a number per surviving key's window: at most that many windows reach the next order (every rank computes the same bound)
+            est = more ? std::min<uint64_t>(keys_all, fb_all) + 4096 * (uint64_t)world : 0;
+            if (n == 2) est += tokens_g / 4;  // (order 2's head windows are on no owner's list; a quarter of the corpus bounds them for any corpus the dense head is made for)
+            step(colibri_kshard_apply(c, n, fb_src.data(), ex_src.data(), kept_by.data(), more, &ids), "colibri_kshard_apply");
+            agree_cheap(err, "key-sharded run: feedback applied", s);
         }
         std::vector<uint64_t> mine(3 * COLIBRI_MAX_ORDER, 0), found_g(COLIBRI_MAX_ORDER, 0), kept_g(COLIBRI_MAX_ORDER, 0), adm_g(COLIBRI_MAX_ORDER, 0);
         uint32_t              syncs = 0;

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define COLIBRI_ABI_VERSION 2 /* 2: colibri_train leaves stats.keybytes at 0 (colibri_result_sizes computes it), kernel classes 11..14, colibri_kshard_*, colibri_stream */
+#define COLIBRI_ABI_VERSION 3 /* 3: colibri_kshard_emit / _count / _apply carry 4-byte keys, bit + number feedback (round 4). 2: colibri_train leaves stats.keybytes at 0 (colibri_result_sizes computes it), kernel classes 11..14, colibri_kshard_*, colibri_stream */
 #define COLIBRI_MAX_ORDER 128 /* per-order statistics are kept for n < 128; MAXLENGTH defaults to 100 in the reference */
 
 enum {
@@ -204,15 +204,22 @@ int colibri_kshard_info(colibri_ctx* ctx, const colibri_options* opt, int* eligi
 int colibri_kshard_begin(colibri_ctx* ctx, const colibri_options* opt, int world, int rank, uint64_t maxclass_global, uint64_t maxpositions_global);
 int colibri_kshard_uni_count(colibri_ctx* ctx, void** cnt_dev, uint32_t* nclasses);
 int colibri_kshard_uni_apply(colibri_ctx* ctx);
-/* per_owner[world]: records for each rank, laid out in rank order in *send_dev (*recbytes each: 8 at order 2, 16 above); *tab_dev: u32[world][256], row d goes to rank d;
+/* est_records: an upper bound of the order's records over ALL ranks (order 2: the corpus' tokens; above: the windows that survived the order below), ids_global: the
+ * numbers the order below handed out over all ranks (colibri_kshard_apply's *ids_global) — the same values on every rank; more: order n + 1 follows.
+ * per_owner[world]: keys for each rank, in rank order in *send_dev (*recbytes = 4 each: the source has partitioned its records completely, a key is what the final bin
+ * does not fix); *tab_dev: u32[world][*tab_words] (the runs' lengths per (owner, bin)), row d goes to rank d;
  * *head_dev: order 2: u32[2][4096] (row 0: all-reduce SUM, row 1: all-reduce MIN, in place), else NULL; *admitted: windows this rank counted at order n */
-int colibri_kshard_emit(colibri_ctx* ctx, int n, void** send_dev, void** tab_dev, uint64_t* per_owner, uint32_t* recbytes, void** head_dev, uint64_t* admitted);
-int colibri_kshard_recv_buffers(colibri_ctx* ctx, uint64_t nrecords, void** recv_dev /* records, concatenated in source order */, void** tab_recv_dev /* u32[world][256], row s from rank s */);
-/* per_src[world]: records received from each rank. more: order n + 1 follows (feedback is produced). fb_per_dst / ex_per_dst [world]: entries for each rank, in rank
- * order in *fb_dev (*fb_bytes each) / *ex_dev (8 bytes each) */
-int colibri_kshard_count(colibri_ctx* ctx, int n, const uint64_t* per_src, int more, void** fb_dev, uint64_t* fb_per_dst, uint32_t* fb_bytes, void** ex_dev, uint64_t* ex_per_dst);
+int colibri_kshard_emit(colibri_ctx* ctx, int n, uint64_t est_records, uint64_t ids_global, int more, void** send_dev, void** tab_dev, uint32_t* tab_words, uint64_t* per_owner,
+                        uint32_t* recbytes, void** head_dev, uint64_t* admitted);
+int colibri_kshard_recv_buffers(colibri_ctx* ctx, uint64_t nrecords, void** recv_dev /* keys, concatenated in source order */, void** tab_recv_dev /* u32[world][tab_words], row s from rank s */);
+/* per_src[world]: keys received from each rank. more: order n + 1 follows (feedback is produced). fb_per_dst [world]: feedback for each rank, in rank order in *fb_dev, in
+ * units of *fb_bytes (= 4): per source, in the order it sent, one bit per key, then the dense number of every surviving key's window; ex_per_dst: exports (8 bytes each) in
+ * *ex_dev; *kept_bins: the keys this owner kept (the caller gathers them over the ranks: colibri_kshard_apply's kept_per_owner) */
+int colibri_kshard_count(colibri_ctx* ctx, int n, const uint64_t* per_src, int more, void** fb_dev, uint64_t* fb_per_dst, uint32_t* fb_bytes, void** ex_dev, uint64_t* ex_per_dst,
+                         uint64_t* kept_bins);
 int colibri_kshard_feedback_buffers(colibri_ctx* ctx, uint64_t nfeedback, uint64_t nexports, void** fb_recv_dev, void** ex_recv_dev); /* each concatenated in owner order */
-int colibri_kshard_apply(colibri_ctx* ctx, int n, uint64_t nfeedback, uint64_t nexports, int more);
+/* fb_src / ex_src [world]: feedback units / exports received from each owner; kept_per_owner[world]; *ids_global: the numbers order n handed out over all ranks */
+int colibri_kshard_apply(colibri_ctx* ctx, int n, const uint64_t* fb_src, const uint64_t* ex_src, const uint64_t* kept_per_owner, int more, uint64_t* ids_global);
 /* arrays of COLIBRI_MAX_ORDER: distinct keys / survivors among the keys this rank OWNS (order 1: global, on rank 0 only), windows it counted; *syncs: host look-ups so far */
 int colibri_kshard_local_stats(colibri_ctx* ctx, uint64_t* found, uint64_t* kept, uint64_t* admitted, uint32_t* syncs);
 int colibri_kshard_finish(colibri_ctx* ctx, const uint64_t* found_global, const uint64_t* kept_global, const uint64_t* admitted_global, uint64_t totaltokens_global, int maxn,

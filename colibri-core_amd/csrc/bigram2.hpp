@@ -82,7 +82,7 @@ struct __attribute__((aligned(16))) Bi2State {
     uint32_t kbits;     // key bits below the slice bits (K - s): A bin = bits [kbits-1 : kbits-8], B bin = the nine below
     uint32_t posbits;   // position bits of a record
     uint32_t res_base;  // first result index of this pass's survivors (an order counted in slices appends pass after pass)
-    uint32_t cskip;      // key-sharded runs (kshard2.hpp): the w mix bits between the A bin and the B bin (they pick the owner-local A' bin at the source, and are part of it at the owner)
+    uint32_t cskip;      // key-sharded runs (kshard2.hpp): the w mix bits below the B bin's that complete the owner's final bin (the source cuts every (A, B) bin by them)
     uint32_t bshift_fix; // key-sharded runs: bshift + 1 as every rank agreed on it (0: bi2_offsets_kernel derives it from this pass's record count)
     uint32_t hugebin;   // records from which a final bin goes to bi2_count_big_kernel; 0: kBi2HugeBin (written with kbits by the emit kernel of the order)
     uint32_t nextchunk;                 // owner passes of key-sharded runs: next free chunk of the position-list pool (bi2_count_kernel<.., BASED>)
@@ -487,18 +487,24 @@ constexpr int kBi2LbPer = COLIBRI_LB_PER, kBi2LbTile = kBi2Threads * kBi2LbPer;
 // slotbase (optional; key-sharded runs, kshard.hpp): the slots are the chunks of a receive buffer — slot s starts at record slotbase[s] instead of s * region
 __global__ __launch_bounds__(kBi2Threads, kBi2LbPer == 4 ? kBi2Threads / 128 : 1) void bi2_levelB_kernel(const unsigned long long* recsA, unsigned long long* __restrict__ recsB, uint32_t region,
                                                                                      const Bi2State* __restrict__ bs, uint32_t* __restrict__ boff, const DevState* __restrict__ st,
-                                                                                     const uint32_t* __restrict__ slotbase = nullptr) {
+                                                                                     const uint32_t* __restrict__ slotbase = nullptr,
+                                                                                     uint32_t* __restrict__ cbhist = nullptr /* key-sharded runs (kshard2.hpp), [nslots][512 x 8]: also the
+                                                                                         slot's records per (B, C), C = the cskip mix bits below the B bin's — the sweep reads them anyway */) {
     if (st->done) return;
+    __shared__ uint32_t           cbL[8 * kBi2BBins];
     __shared__ unsigned long long stgL[kBi2LbTile];
     __shared__ uint16_t           binL[kBi2LbTile];
     __shared__ uint32_t           histL[kBi2BBins], offL[kBi2BBins], curL[kBi2BBins], gbL[kBi2BBins], wsumL[8];
     const uint32_t  slot = blockIdx.x;
     const uint32_t  n    = min(bs->curA[slot], region);
     const uint32_t  bsh  = bs->bshift;
-    const uint32_t  bbit = bs->posbits + bs->kbits - 17 - bs->cskip;  // the B bin = the nine mix bits below the A bin (and the cskip bits) = record bits [bbit + 8 : bbit]
+    const uint32_t  bbit = bs->posbits + bs->kbits - 17;  // the B bin = the nine mix bits below the A bin = record bits [bbit + 8 : bbit]
     const size_t    base = slotbase != nullptr ? (size_t)slotbase[slot] : (size_t)slot * region;
     uint32_t* const bo   = boff + (size_t)slot * (kBi2BBins + 1);
     if (threadIdx.x < kBi2BBins) histL[threadIdx.x] = 0;
+    const uint32_t cmask = (1u << bs->cskip) - 1u;
+    if (cbhist != nullptr)
+        for (uint32_t e = threadIdx.x; e < (cmask + 1u) * kBi2BBins; e += kBi2Threads) cbL[e] = 0;
     __syncthreads();
     // sweep 1: histogram of the slot, two tiles of loads ahead of their LDS atomics
     for (uint32_t j0 = 0; j0 < n; j0 += 2 * kBi2LbTile) {
@@ -511,10 +517,16 @@ __global__ __launch_bounds__(kBi2Threads, kBi2LbPer == 4 ? kBi2Threads / 128 : 1
 #pragma unroll
         for (int k = 0; k < 2 * kBi2LbPer; ++k) {
             const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
-            if (j < n) atomicAdd(&histL[((uint32_t)(r[k] >> bbit) & 511u) >> bsh], 1u);
+            if (j < n) {
+                const uint32_t b = ((uint32_t)(r[k] >> bbit) & 511u) >> bsh;
+                atomicAdd(&histL[b], 1u);
+                if (cbhist != nullptr) atomicAdd(&cbL[(b << bs->cskip) | ((uint32_t)(r[k] >> (bbit + bsh - bs->cskip)) & cmask)], 1u);
+            }
         }
     }
     __syncthreads();
+    if (cbhist != nullptr)
+        for (uint32_t e = threadIdx.x; e < (cmask + 1u) * kBi2BBins; e += kBi2Threads) cbhist[(size_t)slot * (8 * kBi2BBins) + e] = cbL[e];
     bi2_scan512(histL, offL, wsumL);
     if (threadIdx.x < kBi2BBins) {
         bo[threadIdx.x]   = offL[threadIdx.x];

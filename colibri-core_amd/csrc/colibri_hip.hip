@@ -225,7 +225,7 @@ struct colibri_ctx {
         // second form (kshard2.hpp): the source's complete partition, the owner's per-record codes, the feedback's tiles
         DevBuf<Ks2State>  ks2;
         DevBuf<Ks2FbInfo> fbinfo;
-        DevBuf<uint32_t>  tab, key4, posbuf, rowtot, code_at, tcnt, fpos, fcode, zero8k, small;
+        DevBuf<uint32_t>  tab, key4, posbuf, rowtot, code_at, tcnt, fpos, fcode, zero8k, small, cbhist;
         uint32_t          sbase[kKsWorld + 1] = {0};  // this rank's send order: first key of each owner's share
         uint32_t          bshift = 0;                 // the order's B-bin shift, agreed by all ranks
         Bi2State*         src_state = nullptr;        // the source side's Bi2State of the running order
@@ -584,7 +584,7 @@ void colibri_destroy(colibri_ctx* c) {
         dev_free(k.ores_cnt); dev_free(k.fin_rep); dev_free(k.fin_cnt); dev_free(k.sbuf); dev_free(k.rbuf[0]); dev_free(k.rbuf[1]); dev_free(k.fbs); dev_free(k.exs); dev_free(k.fbr);
         dev_free(k.exr);
         dev_free(k.ks2); dev_free(k.fbinfo); dev_free(k.tab); dev_free(k.key4); dev_free(k.posbuf); dev_free(k.rowtot); dev_free(k.code_at); dev_free(k.tcnt); dev_free(k.fpos);
-        dev_free(k.fcode); dev_free(k.zero8k); dev_free(k.small);
+        dev_free(k.fcode); dev_free(k.zero8k); dev_free(k.small); dev_free(k.cbhist);
         if (k.side) (void)hipStreamDestroy(k.side);
         if (k.ev) (void)hipEventDestroy(k.ev);
         if (k.pinned) (void)hipHostFree(k.pinned);

@@ -12,7 +12,8 @@
 //   * FEEDBACK per source, in the order the source sent: one bit per record, then the survivors' numbers (dense per owner) — the source walks its own send order, counts
 //     bits, and has (position, number) pairs: exactly what the count kernel's position lists are on one device, so the next order's emit (chain_emit_kernel) is unchanged;
 //   * EXPORTS: a kept pattern goes to the lowest rank that holds an occurrence, as (index in that rank's stream, global count); the rank looks the position up.
-// Mix bit layout, from the top: [A: 8, the top w of them the owner][C: w][B: 9 (>> bshift)][in-bin key]. The owner's A' bin = (A's low 8 - w bits, C).
+// Mix bit layout, from the top: [A: 8, the top w of them the owner][B: 9 - bshift][C: w][in-bin key]. The owner's final bin = (A's low 8 - w bits, B, C), read as
+// (A': its top 8 bits, B': the rest) — the eight pieces of a source's (A, B) bin are neighbours in its send order.
 // Global numbering of the survivors of an order: owner d's dense numbers shifted by the kept counts of the owners before it (the caller gathers them), order 2's dense
 // head behind all owners — identical on every rank, so (number, class) is the same key everywhere.
 #pragma once
@@ -48,37 +49,30 @@ __global__ void ks2_set_kernel(Bi2State* __restrict__ bs, uint32_t cskip, uint32
 }
 
 // ---- source: (A, B) bins -> (owner, A', B) runs ------------------------------------------------------------------------------------------------------------------------
-// block a = A bin a (all its sub-regions' slots, after level B). tab: [world][kKs2Bins] records per (owner, A', B).
-__global__ __launch_bounds__(kKsThreads) void ks2_hist_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const Bi2State* __restrict__ bs, uint32_t w, uint32_t nsub,
+// block a = A bin a: the (B, C) histograms level B left per slot (bi2_levelB_kernel's cbhist), summed over the A bin's sub-regions. tab: [world][kKs2Bins] records per
+// (owner, A', B'). (The first version swept the records a second time for this: 0.28 ms per 85 M records.)
+__global__ __launch_bounds__(kKsThreads) void ks2_hist_kernel(const uint32_t* __restrict__ cbhist, uint32_t region, const Bi2State* __restrict__ bs, uint32_t w, uint32_t nsub,
                                                                uint32_t* __restrict__ tab, Ks2State* __restrict__ ks) {
-    __shared__ uint32_t histL[kKsWorld * kBi2BBins];  // [C][B]
-    const uint32_t      a = blockIdx.x, W = 1u << w, bsh = bs->bshift;
-    const uint32_t      bbit = bs->posbits + bs->kbits - 17 - w, cbit = bbit + 9;
-    for (uint32_t e = threadIdx.x; e < W * kBi2BBins; e += kKsThreads) histL[e] = 0;
-    __syncthreads();
-    for (uint32_t s = 0; s < nsub; ++s) {
-        const uint32_t slot = s * kBins + a, have = bs->curA[slot], n = min(have, region);
-        if (have > region && threadIdx.x == 0) ks->overflow = 1;
-        const size_t base = (size_t)slot * region;
-        for (uint32_t j0 = 0; j0 < n; j0 += 4 * kKsThreads) {
-            unsigned long long r[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t j = j0 + k * kKsThreads + threadIdx.x;
-                r[k]             = j < n ? recsB[base + j] : 0ull;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (j0 + k * kKsThreads + threadIdx.x < n) atomicAdd(&histL[(((uint32_t)(r[k] >> cbit) & (W - 1u)) << 9) | (((uint32_t)(r[k] >> bbit) & 511u) >> bsh)], 1u);
-        }
-    }
-    __syncthreads();
-    const uint32_t d = a >> (8 - w), alow = a & ((1u << (8 - w)) - 1u);
-    for (uint32_t e = threadIdx.x; e < W * kBi2BBins; e += kKsThreads) tab[((size_t)d * kBins + ((alow << w) | (e >> 9))) * kBi2BBins + (e & 511u)] = histL[e];
-    const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
-    if (wave < W) {  // wave c: the records of A' = (alow, c)
+    __shared__ uint32_t histL[kKsWorld * kBi2BBins];  // [B][C] = the A bin's share of the owner's bins, in their order
+    const uint32_t      a = blockIdx.x, W = 1u << w, bsh = bs->bshift, lb = 9 - bsh;  // lb: bits of B'
+    const uint32_t      nE = ((uint32_t)kBi2BBins >> bsh) << w;                       // final bins of this A bin
+    for (uint32_t e = threadIdx.x; e < nE; e += kKsThreads) {
         uint32_t v = 0;
-        for (uint32_t b = lane; b < (uint32_t)kBi2BBins; b += kWave) v += histL[(wave << 9) | b];
+        for (uint32_t s = 0; s < nsub; ++s) v += cbhist[(size_t)(s * kBins + a) * (8 * kBi2BBins) + e];
+        histL[e] = v;
+    }
+    if (threadIdx.x < nsub && bs->curA[threadIdx.x * kBins + a] > region) ks->overflow = 1;
+    __syncthreads();
+    // the owner's bin (17 - bsh bits) = (alow, e): A' = its top 8 bits, B' = its low 9 - bsh; this block's bins are W whole rows
+    const uint32_t d = a >> (8 - w), alow = a & ((1u << (8 - w)) - 1u);
+    for (uint32_t e = threadIdx.x; e < W * kBi2BBins; e += kKsThreads) {
+        const uint32_t row = e >> 9, bp = e & 511u;  // row: which of the W rows of this A bin
+        tab[((size_t)d * kBins + ((alow << w) | row)) * kBi2BBins + bp] = bp < (1u << lb) ? histL[(row << lb) | bp] : 0u;
+    }
+    const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    if (wave < W) {  // wave r: the records of A' = (alow, r)
+        uint32_t v = 0;
+        for (uint32_t b = lane; b < (1u << lb); b += kWave) v += histL[(wave << lb) | b];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
         if (lane == 0) ks->rowsum[d * kBins + ((alow << w) | wave)] = v;
     }
@@ -101,22 +95,25 @@ __global__ __launch_bounds__(kKsThreads) void ks2_rows_kernel(Ks2State* __restri
 // pdrop (chain_emit_kernel's records when key and position do not fit 64 bits): the position lacks the three bits above `pshift` — its bucket mod 8, which is the
 // sub-region the record lies in (an XCD's blocks emit the records of the buckets dealt to it into the sub-region of its number)
 __global__ __launch_bounds__(kKsThreads) void ks2_move_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const Bi2State* __restrict__ bs, uint32_t w, uint32_t nsub,
-                                                               const uint32_t* __restrict__ tab, const Ks2State* __restrict__ ks, uint32_t pshift, uint32_t pdrop,
-                                                               uint32_t* __restrict__ key4, uint32_t* __restrict__ posbuf) {
+                                                               const uint32_t* __restrict__ tab, const Ks2State* __restrict__ ks, const uint32_t* __restrict__ boff, uint32_t pshift,
+                                                               uint32_t pdrop, uint32_t* __restrict__ key4, uint32_t* __restrict__ posbuf) {
     __shared__ uint32_t curL[kKsWorld * kBi2BBins], inL[kBi2BBins], outL[kBi2BBins], wsumL[8];
-    const uint32_t      a = blockIdx.x, W = 1u << w, bsh = bs->bshift, pb = bs->posbits;
-    const uint32_t      bbit = pb + bs->kbits - 17 - w, cbit = bbit + 9;
-    const uint32_t      kmask = (1u << (bbit + bsh - pb)) - 1u;  // the in-bin key: every mix bit below the B bin's used bits (<= 31 of them)
+    const uint32_t      a = blockIdx.x, W = 1u << w, bsh = bs->bshift, pb = bs->posbits, lb = 9 - bsh;
+    const uint32_t      bbit = pb + bs->kbits - 17;  // B = record bits [bbit + 8 : bbit + bsh], C = the w bits below, the in-bin key what is left above the position
+    const uint32_t      cbit = bbit + bsh - w;
+    const uint32_t      kmask = (1u << (cbit - pb)) - 1u;  // (<= 31 bits: the caller checked)
     const uint32_t      d = a >> (8 - w), alow = a & ((1u << (8 - w)) - 1u);
     const unsigned long long pmask = (1ull << pb) - 1ull;
-    for (uint32_t c = 0; c < W; ++c) {
-        const uint32_t row = d * kBins + ((alow << w) | c);
+    for (uint32_t r = 0; r < W; ++r) {  // row r of this A bin's share = A' (alow, r): its B' bins' places
+        const uint32_t row = d * kBins + ((alow << w) | r);
         if (threadIdx.x < (uint32_t)kBi2BBins) inL[threadIdx.x] = tab[(size_t)row * kBi2BBins + threadIdx.x];
         __syncthreads();
         bi2_scan512(inL, outL, wsumL);
-        if (threadIdx.x < (uint32_t)kBi2BBins) curL[(c << 9) | threadIdx.x] = ks->rowbase[row] + outL[threadIdx.x];
+        if (threadIdx.x < (1u << lb)) curL[(r << lb) | threadIdx.x] = ks->rowbase[row] + outL[threadIdx.x];
         __syncthreads();
     }
+    // (tried: one wave per (A, B) bin with ballot ranks instead of the LDS atomics — the runs level B leaves per slot are ~50 records: 0.64 ms against 0.47 at order 2)
+    (void)boff;
     for (uint32_t s = 0; s < nsub; ++s) {
         const uint32_t slot = s * kBins + a, n = min(bs->curA[slot], region);
         const size_t   base = (size_t)slot * region;
@@ -130,7 +127,8 @@ __global__ __launch_bounds__(kKsThreads) void ks2_move_kernel(const unsigned lon
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (j0 + k * kKsThreads + threadIdx.x < n) {
-                    const uint32_t at = atomicAdd(&curL[(((uint32_t)(r[k] >> cbit) & (W - 1u)) << 9) | (((uint32_t)(r[k] >> bbit) & 511u) >> bsh)], 1u);
+                    const uint32_t e  = (uint32_t)(r[k] >> cbit) & ((1u << (lb + w)) - 1u);  // (B, C): the slot is sorted by B, so a wave's records fall into a few neighbouring bins
+                    const uint32_t at = atomicAdd(&curL[e], 1u);
                     uint32_t       p  = (uint32_t)(r[k] & pmask);
                     if (pdrop) p = ((p >> pshift) << (pshift + 3)) | (s << pshift) | (p & ((1u << pshift) - 1u));
                     key4[at]   = (uint32_t)(r[k] >> pb) & kmask;
@@ -312,13 +310,14 @@ struct Ks2Secs {
     uint32_t off[kKsWorld + 1];
     uint32_t gbase[kKsWorld];  // what owner d's dense numbers are shifted by
 };
-constexpr uint32_t kKs2DecTile = kKsThreads * 32;
+// tile = kKs2Tile records of one owner's share (a lane: four consecutive records = one nibble of a bitmap word): every load of a tile is independent of the others (the
+// first version walked a word's bits lane by lane — a chain of ~27 dependent look-ups per lane: 1.4 ms for 85 M records)
 __global__ __launch_bounds__(kKsThreads) void ks2_dec_count_kernel(const uint32_t* __restrict__ fbr, Ks2Segs sg, Ks2Secs sc, uint32_t ntiles, uint32_t* __restrict__ tcnt) {
     __shared__ uint32_t wsumL[kKsThreads / kWave];
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t d = ks2_seg_of_tile(sg, tile), wi = (tile - sg.tbase[d]) * kKsThreads + threadIdx.x, nwords = (sg.base[d + 1] - sg.base[d] + 31) / 32;
+        const uint32_t d = ks2_seg_of_tile(sg, tile), wi = (tile - sg.tbase[d]) * (kKs2Tile / 32) + threadIdx.x, nwords = (sg.base[d + 1] - sg.base[d] + 31) / 32;
         uint32_t       total;
-        bi2_block_scan<kKsThreads>(wi < nwords ? (uint32_t)__popc(fbr[sc.off[d] + wi]) : 0u, &total, wsumL);
+        bi2_block_scan<kKsThreads>((threadIdx.x < kKs2Tile / 32 && wi < nwords) ? (uint32_t)__popc(fbr[sc.off[d] + wi]) : 0u, &total, wsumL);
         if (threadIdx.x == 0) tcnt[tile] = total;
     }
 }
@@ -326,20 +325,28 @@ __global__ __launch_bounds__(kKsThreads) void ks2_dec_write_kernel(const uint32_
                                                                     const uint32_t* __restrict__ posbuf, uint32_t* __restrict__ fpos, uint32_t* __restrict__ fcode) {
     __shared__ uint32_t wsumL[kKsThreads / kWave];
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t d = ks2_seg_of_tile(sg, tile), wi = (tile - sg.tbase[d]) * kKsThreads + threadIdx.x, n = sg.base[d + 1] - sg.base[d], nwords = (n + 31) / 32;
-        uint32_t       m = wi < nwords ? fbr[sc.off[d] + wi] : 0u;
-        uint32_t       total;
-        const uint32_t ex = bi2_block_scan<kKsThreads>((uint32_t)__popc(m), &total, wsumL);
-        uint32_t       o  = tscan[tile] + ex;                        // place in the flat output
-        uint32_t       ci = sc.off[d] + nwords + (o - tscan[sg.tbase[d]]);  // ... and of the window's number in the owner's section
-        while (m) {
-            const uint32_t k = (uint32_t)__builtin_ctz(m);
-            m &= m - 1;
-            fpos[o]  = posbuf[sg.base[d] + wi * 32 + k];
-            fcode[o] = sc.gbase[d] + fbr[ci];
-            ++o;
-            ++ci;
+        const uint32_t d = ks2_seg_of_tile(sg, tile), lt = tile - sg.tbase[d], n = sg.base[d + 1] - sg.base[d], nwords = (n + 31) / 32;
+        const uint32_t wi = lt * (kKs2Tile / 32) + threadIdx.x / 8, j0 = lt * kKs2Tile + threadIdx.x * 4;
+        const uint32_t nib = wi < nwords ? (fbr[sc.off[d] + wi] >> (4 * (threadIdx.x & 7u))) & 15u : 0u;
+        uint32_t       p[4] = {0u, 0u, 0u, 0u};
+        if (nib) {  // (bits beyond the share's last record are clear)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p[k] = j0 + k < n ? posbuf[sg.base[d] + j0 + k] : 0u;
         }
+        uint32_t       total;
+        const uint32_t ex = bi2_block_scan<kKsThreads>((uint32_t)__popc(nib), &total, wsumL);
+        uint32_t       o  = tscan[tile] + ex;                              // place in the flat output
+        const uint32_t cb = sc.off[d] + nwords + (o - tscan[sg.tbase[d]]);  // ... and of the lane's first number in the owner's section
+        uint32_t       g[4], q = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = (nib >> k) & 1u ? fbr[cb + q++] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((nib >> k) & 1u) {
+                fpos[o]  = p[k];
+                fcode[o] = sc.gbase[d] + g[k];
+                ++o;
+            }
     }
 }
 // the exports this rank receives (owner by owner): (index in the stream it sent to that owner | count << 32), or a flagged position -> the result arrays

@@ -1361,7 +1361,60 @@ __global__ __launch_bounds__(kBlock) void bi2_compact_kernel(const uint32_t* __r
 }
 
 // ---- positions: the waves' unsorted lists -> one list per (shard, position bucket) (Bi2Lists: above) ------------------------------------------
-// tile-local counting sort by bucket in LDS, one reserved run per (tile, bucket); block x takes the lists x, x + gridDim.x, ...
+// tile-local counting sort by bucket in LDS, one reserved run per (tile, bucket). The LDS of one tile:
+struct Bi2PospartLds {
+    uint32_t stgL[kBi2Tile], stgC[kBi2Tile];
+    uint16_t binL[kBi2Tile];
+    uint32_t histL[kBi2Buckets], offL[kBi2Buckets], gbaseL[kBi2Buckets], wsumL[kBi2Threads / kWave];
+};
+// one tile: every lane brings up to kBi2Per (position, code) entries (position 0xFFFFFFFF: none); every thread of the block calls it
+__device__ __forceinline__ void bi2_pospart_tile(Bi2PospartLds& L, const uint32_t (&p)[kBi2Per], const uint32_t (&code)[kBi2Per], uint32_t shard, Bi2State* __restrict__ bs,
+                                                 DevState* __restrict__ st, uint32_t* __restrict__ plist, Bi2Lists pl, uint32_t* __restrict__ pcode) {
+    static_assert(kBi2Buckets == kBi2Threads, "one lane per position bucket");
+    uint32_t rank[kBi2Per];
+    L.histL[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kBi2Per; ++k) {
+        rank[k] = kInvalid;
+        if (p[k] != 0xFFFFFFFFu) {
+            const uint32_t b = p[k] >> pl.pshift;
+            rank[k]          = atomicAdd(&L.histL[b], 1u) | (b << 16);
+        }
+    }
+    __syncthreads();
+    uint32_t tot;
+    L.offL[threadIdx.x] = bi2_block_scan<kBi2Threads>(L.histL[threadIdx.x], &tot, L.wsumL);
+    __syncthreads();  // every bucket's offset is written
+    {
+        const uint32_t h = L.histL[threadIdx.x];
+        uint32_t       g = 0;
+        if (h) {
+            const uint32_t l  = shard * kBi2Buckets + threadIdx.x;
+            const uint32_t at = atomicAdd(&bs->pcur[l], h);
+            if (at + h > pl.pcap) st->radix_overflow = 4;  // (the order's finish kernel has run: the flag goes straight to the run's state)
+            g = l * pl.pcap + min(at, pl.pcap - min(pl.pcap, h));  // (fits 32 bits: shards * buckets * pcap <= 8 * positions)
+        }
+        L.gbaseL[threadIdx.x] = g;
+    }
+#pragma unroll
+    for (int k = 0; k < kBi2Per; ++k) {
+        if (rank[k] != kInvalid) {
+            const uint32_t b = rank[k] >> 16, q = L.offL[b] + (rank[k] & 0xFFFFu);
+            L.stgL[q]        = p[k];
+            L.stgC[q]        = code[k];
+            L.binL[q]        = (uint16_t)b;
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < tot; j += kBi2Threads) {
+        const uint32_t b                           = L.binL[j];
+        plist[(size_t)L.gbaseL[b] + (j - L.offL[b])] = L.stgL[j];
+        if (pcode != nullptr) pcode[(size_t)L.gbaseL[b] + (j - L.offL[b])] = L.stgC[j];
+    }
+    __syncthreads();
+}
+// the waves' lists: block x takes the lists x, x + gridDim.x, ...
 __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_pospart_kernel(const uint32_t* __restrict__ wlist, const uint32_t* __restrict__ wcnt, uint32_t nlists, uint32_t wcap,
                                                                                       Bi2State* __restrict__ bs, DevState* __restrict__ st, uint32_t* __restrict__ plist, Bi2Lists pl,
                                                                                       const uint32_t* __restrict__ wcode = nullptr, uint32_t* __restrict__ pcode = nullptr,
@@ -1371,18 +1424,14 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_pospart_ke
     // windows, so the offset look-up is nearly a broadcast here — after the partition it would be a random gather per entry
     // flat_n (key-sharded runs: the positions the owners sent back, one array): wlist holds flat_n entries, cut into nlists pieces of wcap; wcnt is not read
     if (st->done) return;
-    static_assert(kBi2Buckets == kBi2Threads, "one lane per position bucket");
-    __shared__ uint32_t stgL[kBi2Tile], stgC[kBi2Tile];
-    __shared__ uint16_t binL[kBi2Tile];
-    __shared__ uint32_t histL[kBi2Buckets], offL[kBi2Buckets], gbaseL[kBi2Buckets], wsumL[kBi2Threads / kWave];
-    const uint32_t      shard = blockIdx.x & (uint32_t)(kBi2Shards - 1);
+    __shared__ Bi2PospartLds L;
+    const uint32_t           shard = blockIdx.x & (uint32_t)(kBi2Shards - 1);
     for (uint32_t w = blockIdx.x; w < nlists; w += gridDim.x) {
         const uint32_t        n   = flat_n ? min(wcap, flat_n - min(flat_n, w * wcap)) : min(wcnt[w], wcap);
         const uint32_t* const src  = wlist + (size_t)w * wcap;
         const uint32_t* const csrc = wcode != nullptr ? wcode + (size_t)w * wcap : nullptr;
         for (uint32_t j0 = 0; j0 < n; j0 += kBi2Tile) {
-            uint32_t p[kBi2Per], rank[kBi2Per], code[kBi2Per];
-            histL[threadIdx.x] = 0;
+            uint32_t p[kBi2Per], code[kBi2Per];
 #pragma unroll
             for (int k = 0; k < kBi2Per; ++k) {
                 const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
@@ -1394,49 +1443,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_pospart_ke
                 for (int k = 0; k < kBi2Per; ++k)
                     if (p[k] != 0xFFFFFFFFu) code[k] = bs->binkept[code[k] >> 10] + (code[k] & 1023u);
             }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < kBi2Per; ++k) {
-                rank[k] = kInvalid;
-                if (p[k] != 0xFFFFFFFFu) {
-                    const uint32_t b = p[k] >> pl.pshift;
-                    rank[k]          = atomicAdd(&histL[b], 1u) | (b << 16);
-                }
-            }
-            __syncthreads();
-            {
-                uint32_t tot;
-                offL[threadIdx.x] = bi2_block_scan<kBi2Threads>(histL[threadIdx.x], &tot, wsumL);
-            }
-            __syncthreads();  // every bucket's offset is written
-            {
-                const uint32_t h = histL[threadIdx.x];
-                uint32_t       g = 0;
-                if (h) {
-                    const uint32_t l  = shard * kBi2Buckets + threadIdx.x;
-                    const uint32_t at = atomicAdd(&bs->pcur[l], h);
-                    if (at + h > pl.pcap) st->radix_overflow = 4;  // (the order's finish kernel has run: the flag goes straight to the run's state)
-                    g = l * pl.pcap + min(at, pl.pcap - min(pl.pcap, h));  // (fits 32 bits: shards * buckets * pcap <= 8 * positions)
-                }
-                gbaseL[threadIdx.x] = g;
-            }
-#pragma unroll
-            for (int k = 0; k < kBi2Per; ++k) {
-                if (rank[k] != kInvalid) {
-                    const uint32_t b = rank[k] >> 16, q = offL[b] + (rank[k] & 0xFFFFu);
-                    stgL[q]          = p[k];
-                    stgC[q]          = code[k];
-                    binL[q]          = (uint16_t)b;
-                }
-            }
-            __syncthreads();
-            const uint32_t m = min(n - j0, (uint32_t)kBi2Tile);
-            for (uint32_t j = threadIdx.x; j < m; j += kBi2Threads) {
-                const uint32_t b                      = binL[j];
-                plist[(size_t)gbaseL[b] + (j - offL[b])] = stgL[j];
-                if (pcode != nullptr) pcode[(size_t)gbaseL[b] + (j - offL[b])] = stgC[j];
-            }
-            __syncthreads();
+            bi2_pospart_tile(L, p, code, shard, bs, st, plist, pl, pcode);
         }
     }
 }

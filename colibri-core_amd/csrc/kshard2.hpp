@@ -321,32 +321,30 @@ __global__ __launch_bounds__(kKsThreads) void ks2_dec_count_kernel(const uint32_
         if (threadIdx.x == 0) tcnt[tile] = total;
     }
 }
-__global__ __launch_bounds__(kKsThreads) void ks2_dec_write_kernel(const uint32_t* __restrict__ fbr, Ks2Segs sg, Ks2Secs sc, uint32_t ntiles, const uint32_t* __restrict__ tscan,
-                                                                    const uint32_t* __restrict__ posbuf, uint32_t* __restrict__ fpos, uint32_t* __restrict__ fcode) {
-    __shared__ uint32_t wsumL[kKsThreads / kWave];
+// ... and straight into the position buckets: a tile's surviving windows are one tile of bi2_pospart_kernel's partition (the flat (position, number) arrays between
+// the two cost a write and a read of 8 bytes per surviving window)
+static_assert(kKs2Tile == kBi2Tile && kKsThreads == kBi2Threads && kBi2Per == 4, "a feedback tile is a partition tile: four consecutive records per lane");
+__global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void ks2_dec_pospart_kernel(const uint32_t* __restrict__ fbr, Ks2Segs sg, Ks2Secs sc, uint32_t ntiles,
+                                                                                          const uint32_t* __restrict__ tscan, const uint32_t* __restrict__ posbuf, Bi2State* __restrict__ bs,
+                                                                                          DevState* __restrict__ st, uint32_t* __restrict__ plist, Bi2Lists pl, uint32_t* __restrict__ pcode) {
+    __shared__ Bi2PospartLds L;
+    const uint32_t           shard = blockIdx.x & (uint32_t)(kBi2Shards - 1);
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t d = ks2_seg_of_tile(sg, tile), lt = tile - sg.tbase[d], n = sg.base[d + 1] - sg.base[d], nwords = (n + 31) / 32;
         const uint32_t wi = lt * (kKs2Tile / 32) + threadIdx.x / 8, j0 = lt * kKs2Tile + threadIdx.x * 4;
-        const uint32_t nib = wi < nwords ? (fbr[sc.off[d] + wi] >> (4 * (threadIdx.x & 7u))) & 15u : 0u;
-        uint32_t       p[4] = {0u, 0u, 0u, 0u};
-        if (nib) {  // (bits beyond the share's last record are clear)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) p[k] = j0 + k < n ? posbuf[sg.base[d] + j0 + k] : 0u;
-        }
-        uint32_t       total;
-        const uint32_t ex = bi2_block_scan<kKsThreads>((uint32_t)__popc(nib), &total, wsumL);
-        uint32_t       o  = tscan[tile] + ex;                              // place in the flat output
-        const uint32_t cb = sc.off[d] + nwords + (o - tscan[sg.tbase[d]]);  // ... and of the lane's first number in the owner's section
-        uint32_t       g[4], q = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) g[k] = (nib >> k) & 1u ? fbr[cb + q++] : 0u;
+        const uint32_t nib = wi < nwords ? (fbr[sc.off[d] + wi] >> (4 * (threadIdx.x & 7u))) & 15u : 0u;  // (bits beyond the share's last record are clear)
+        uint32_t       p[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, g[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if ((nib >> k) & 1u) {
-                fpos[o]  = p[k];
-                fcode[o] = sc.gbase[d] + g[k];
-                ++o;
-            }
+            if ((nib >> k) & 1u) p[k] = posbuf[sg.base[d] + j0 + k];
+        uint32_t       total;
+        const uint32_t ex = bi2_block_scan<kBi2Threads>((uint32_t)__popc(nib), &total, L.wsumL);
+        const uint32_t cb = sc.off[d] + nwords + (tscan[tile] - tscan[sg.tbase[d]]) + ex;  // the lane's first number in the owner's section
+        uint32_t       q  = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((nib >> k) & 1u) g[k] = sc.gbase[d] + fbr[cb + q++];
+        bi2_pospart_tile(L, p, g, shard, bs, st, plist, pl, pcode);
     }
 }
 // the exports this rank receives (owner by owner): (index in the stream it sent to that owner | count << 32), or a flagged position -> the result arrays

@@ -144,17 +144,22 @@ struct Shared {
     std::vector<std::vector<std::vector<uint32_t>>> hostred;   // [rank][reduction]: host copies (copies back end)
     std::mutex                                      errm;
     std::string                                     error;
+    bool                                            poisoned = false;  // the communicators were aborted (a rank failed inside or beside a collective): no further run on this trainer
     Shared(int w, int nl, int first) : world(w), nlocal(nl), first_rank(first), rv(nl), comms((size_t)nl, nullptr), device((size_t)nl, 0), ints((size_t)w), ops((size_t)w), hostred((size_t)w) {}
     bool threads() const { return nlocal == world; }
     void fail(const std::string& what) {
-        {
+        std::vector<ncclComm_t> mine;  // every communicator is aborted exactly once: the first failing rank takes them all (its peers' collectives then return errors and
+        {                              // those ranks come here too, to find nothing left)
             std::lock_guard<std::mutex> l(errm);
             if (error.empty()) error = what;
+            if (use_rccl) {
+                for (auto& cm : comms)
+                    if (cm) mine.push_back(cm), cm = nullptr;
+                poisoned = true;
+            }
         }
         rv.abort();
-        if (use_rccl)  // peers inside (or about to enter) a collective return with an error instead of waiting for this rank
-            for (auto& cm : comms)
-                if (cm) (void)ncclCommAbort(cm), cm = nullptr;
+        for (ncclComm_t cm : mine) (void)ncclCommAbort(cm);  // peers inside (or about to enter) a collective return with an error instead of waiting for this rank
     }
 };
 
@@ -171,7 +176,12 @@ class RankDriver {
     void chk(int rc, const char* what) {
         if (rc != COLIBRI_OK) throw std::runtime_error(std::string(what) + ": " + (c ? colibri_last_error(c) : "no context") + " (status " + std::to_string(rc) + ")");
     }
-    ncclComm_t comm() const { return sh.comms[(size_t)li]; }
+    ncclComm_t comm() const {
+        std::lock_guard<std::mutex> l(sh.errm);
+        const ncclComm_t            cm = sh.comms[(size_t)li];
+        if (!cm) throw Aborted();  // (another rank failed and took the communicators down)
+        return cm;
+    }
 
     // ---- collectives ----------------------------------------------------------------------------------------------------
     // host values of every rank, [rank][k]. Threads: through shared memory; one process per rank: an RCCL all-gather on `s`
@@ -271,15 +281,9 @@ class RankDriver {
         if (!bad.empty()) throw AgreedFailure(std::string(what) + " failed on rank(s) " + bad + (err.empty() ? "" : ": " + err));
         return all;
     }
-    // the same for steps that fail only when memory runs out: threads agree (a barrier); one process per rank: no extra collective — a rank that fails
-    // aborts its communicator, and its peers' next collective returns with an error
-    void agree_cheap(const std::string& err, const char* what, hipStream_t s) {
-        if (sh.threads()) {
-            agree({}, err, what, s);
-        } else if (!err.empty()) {
-            throw std::runtime_error(std::string(what) + ": " + err);
-        }
-    }
+    // the same for steps that fail only when memory runs out and are FOLLOWED BY AN EXCHANGE into what they reserved. (Round 3 skipped the collective with one process
+    // per rank and let the failing rank abort its communicator — which does not wake a peer already inside an intra-node RCCL kernel: the peers hung.)
+    void agree_cheap(const std::string& err, const char* what, hipStream_t s) { agree({}, err, what, s); }
 
     // ---- key-sharded counting (colibri_kshard_*) ---------------------------------------------------------------------------------
     // false: not applicable to this run (some rank's corpus or the options are outside it): the caller takes the candidate exchange
@@ -300,9 +304,12 @@ class RankDriver {
         }
         if (!all_ok || maxclass_g >= (1u << 21) || npos_g >= (1u << 28)) return false;
         std::string err;
+        // COLIBRI_FAULT="<rank>:<step name>" (tests): that rank pretends the step failed — every rank must then leave the run together, with that message
+        static const char* const fault = std::getenv("COLIBRI_FAULT");
         auto        step = [&](int rc, const char* what) {
             if (rc != COLIBRI_OK && err.empty()) err = std::string(what) + ": " + colibri_last_error(c) + " (status " + std::to_string(rc) + ")";
-            return rc == COLIBRI_OK;
+            if (fault && err.empty() && std::atoi(fault) == rank && std::strchr(fault, ':') && std::string(std::strchr(fault, ':') + 1) == what) err = std::string(what) + ": injected fault";
+            return err.empty();
         };
         step(colibri_kshard_begin(c, &o, world, rank, maxclass_g, npos_g), "colibri_kshard_begin");
         agree({}, err, "key-sharded run: begin", s);
@@ -314,7 +321,7 @@ class RankDriver {
             step(colibri_kshard_uni_count(c, &cnt, &nclasses), "colibri_kshard_uni_count");
             agree_cheap(err, "key-sharded run: order 1", s);
             exchange({}, {{cnt, nclasses, false}}, s, false);
-            chk(colibri_kshard_uni_apply(c), "colibri_kshard_uni_apply");
+            step(colibri_kshard_uni_apply(c), "colibri_kshard_uni_apply");  // (can fail on an allocation: its status travels with the next agreement, order 2's window scan)
         }
         int      maxn = tokens_g ? 1 : 0;
         uint64_t est = tokens_g, ids = 0;  // an upper bound of the next order's records over all ranks; the numbers the last order handed out
@@ -324,7 +331,8 @@ class RankDriver {
             uint32_t              recbytes = 0, tab_words = 0;
             uint64_t              admitted = 0;
             const int             more = n < maxlength;
-            step(colibri_kshard_emit(c, n, est, ids, more, &send, &tab, &tab_words, per_owner.data(), &recbytes, &head, &admitted), "colibri_kshard_emit");
+            if (err.empty())  // (a failure of the order below's last step — nothing was exchanged since — travels with this agreement)
+                step(colibri_kshard_emit(c, n, est, ids, more, &send, &tab, &tab_words, per_owner.data(), &recbytes, &head, &admitted), "colibri_kshard_emit");
             std::vector<uint64_t> mine = per_owner;
             mine.push_back(admitted);
             const auto everyone = agree(mine, err, "key-sharded run: window scan", s);
@@ -372,12 +380,11 @@ class RankDriver {
             // the feedback is a bit per key and a number per surviving key's window: at most that many windows reach the next order (every rank computes the same bound)
             est = more ? std::min<uint64_t>(keys_all, fb_all) + 4096 * (uint64_t)world : 0;
             if (n == 2) est += tokens_g / 4;  // (order 2's head windows are on no owner's list; a quarter of the corpus bounds them for any corpus the dense head is made for)
-            step(colibri_kshard_apply(c, n, fb_src.data(), ex_src.data(), kept_by.data(), more, &ids), "colibri_kshard_apply");
-            agree_cheap(err, "key-sharded run: feedback applied", s);
+            step(colibri_kshard_apply(c, n, fb_src.data(), ex_src.data(), kept_by.data(), more, &ids), "colibri_kshard_apply");  // (its status: the next agreement's)
         }
         std::vector<uint64_t> mine(3 * COLIBRI_MAX_ORDER, 0), found_g(COLIBRI_MAX_ORDER, 0), kept_g(COLIBRI_MAX_ORDER, 0), adm_g(COLIBRI_MAX_ORDER, 0);
         uint32_t              syncs = 0;
-        step(colibri_kshard_local_stats(c, mine.data(), mine.data() + COLIBRI_MAX_ORDER, mine.data() + 2 * COLIBRI_MAX_ORDER, &syncs), "colibri_kshard_local_stats");
+        if (err.empty()) step(colibri_kshard_local_stats(c, mine.data(), mine.data() + COLIBRI_MAX_ORDER, mine.data() + 2 * COLIBRI_MAX_ORDER, &syncs), "colibri_kshard_local_stats");
         // (only the orders that ran travel: the process back end's gather buffer is small)
         std::vector<uint64_t> brief;
         for (int n = 1; n <= std::max(maxn, 1) && n < COLIBRI_MAX_ORDER; ++n) {
@@ -712,6 +719,10 @@ class ShardedTrainer {
     // one host thread per local rank runs `f(rank driver)`; the first failure is the trainer's error
     template <class F>
     bool run(F f) {
+        if (sh.poisoned) {  // (colibri_sharded.h: the trainer survives between runs — unless a run tore its communicators down)
+            error = "this trainer's communicators were aborted by an earlier failure (" + sh.error + "): create a new trainer";
+            return false;
+        }
         sh.rv.reset();
         sh.error.clear();
         std::vector<std::thread> threads;

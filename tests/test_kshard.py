@@ -131,3 +131,32 @@ def test_2m_tokens_two_ranks_against_the_single_device_model():
     got = digest.model_digest(key_off, np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts]))
     assert got == want
     assert [st.found[n] for n in range(1, 6)] == [one.found[n] for n in range(1, 6)] and [st.kept[n] for n in range(1, 6)] == [one.kept[n] for n in range(1, 6)]
+
+
+FAULT_SCRIPT = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import conftest, oracle
+from colibri_amd import capi
+payload = conftest.small_corpora()["zipf200k_phrases"]
+want = oracle.train(payload, 2, 5)
+with capi.ShardedTrainer(4, devices=[0, 0, 0, 0]) as tr:
+    tr.upload_split(payload)
+    st = tr.train(mintokens=2, maxlength=5)
+    assert tr.export_dict() == want.counts, "model differs"
+    print("PROTOCOL", tr.info.protocol)
+"""
+
+
+@pytest.mark.parametrize("fault", ["2:colibri_kshard_emit", "1:colibri_kshard_count", "3:colibri_kshard_apply", "0:colibri_kshard_uni_apply", "2:colibri_kshard_recv_buffers",
+                                   "1:colibri_kshard_feedback_buffers"])
+def test_a_step_that_fails_on_one_rank_takes_every_rank_out_together(fault, tmp_path):
+    """RankDriver::agree (host/src/sharded.cpp): COLIBRI_FAULT makes ONE rank of four report a failure at one step of the key-sharded run. No rank may be left waiting in
+    a barrier or a collective: all leave the run at the same agreement, the trainer repeats it with the candidate exchange, and the model is still the oracle's."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, COLIBRI_FAULT=fault)
+    p = subprocess.run([sys.executable, "-c", FAULT_SCRIPT, os.path.join(root, "tests"), os.path.join(root, "oracle")], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "PROTOCOL 1" in p.stdout, p.stdout[-500:]
+    assert "failed on rank(s) " + fault.split(":")[0] in p.stderr, p.stderr[-1000:]  # (rank 0 reports who failed; the reason is the failing rank's)

@@ -237,21 +237,26 @@ struct Ks2RouteExports {
 };
 
 // ---- owner: feedback = per source, in stream order, one bit per record, then the survivors' dense numbers -------------------------------------------------------------
-// tile = kKs2Tile records of one source's stream (a lane: four consecutive records). tcnt[tile] = records of the tile whose key survived
+// tile = kKs2Tile records of one source's stream. tcnt[tile] = records of the tile whose key survived. One WAVE per tile, no barrier (a block-wide scan per tile for
+// one number cost 1 ms per 120 M records)
 __global__ __launch_bounds__(kKsThreads) void ks2_fb_count_kernel(const uint32_t* __restrict__ code_at, Ks2Segs sg, uint32_t ntiles, uint32_t* __restrict__ tcnt) {
-    __shared__ uint32_t wsumL[kKsThreads / kWave];
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t s = ks2_seg_of_tile(sg, tile), j0 = (tile - sg.tbase[s]) * kKs2Tile + threadIdx.x * 4, n = sg.base[s + 1] - sg.base[s];
+    const uint32_t lane = threadIdx.x & (kWave - 1), nwaves = gridDim.x * (kKsThreads / kWave);
+    for (uint32_t tile = blockIdx.x * (kKsThreads / kWave) + threadIdx.x / kWave; tile < ntiles; tile += nwaves) {
+        const uint32_t s = ks2_seg_of_tile(sg, tile), t0 = (tile - sg.tbase[s]) * kKs2Tile, n = sg.base[s + 1] - sg.base[s];
+        const uint32_t* const src = code_at + sg.base[s];
         uint32_t       c = 0;
-        if (j0 + 3 < n) {
-            const uint4 v = *reinterpret_cast<const uint4*>(code_at + sg.base[s] + j0);  // (16-byte aligned when the segment starts at a multiple of 4: the caller pads)
-            c             = (v.x != kInvalid) + (v.y != kInvalid) + (v.z != kInvalid) + (v.w != kInvalid);
-        } else {
-            for (uint32_t k = 0; k < 4; ++k) c += (j0 + k < n && code_at[sg.base[s] + j0 + k] != kInvalid) ? 1u : 0u;
+#pragma unroll 4
+        for (uint32_t k = 0; k < kKs2Tile / (4 * kWave); ++k) {
+            const uint32_t j0 = t0 + (k * kWave + lane) * 4;
+            if (j0 + 3 < n) {
+                const uint4 v = *reinterpret_cast<const uint4*>(src + j0);
+                c += (v.x != kInvalid) + (v.y != kInvalid) + (v.z != kInvalid) + (v.w != kInvalid);
+            } else {
+                for (uint32_t q = 0; q < 4; ++q) c += (j0 + q < n && src[j0 + q] != kInvalid) ? 1u : 0u;
+            }
         }
-        uint32_t total;
-        bi2_block_scan<kKsThreads>(c, &total, wsumL);
-        if (threadIdx.x == 0) tcnt[tile] = total;
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, kWave);
+        if (lane == 0) tcnt[tile] = c;
     }
 }
 struct Ks2FbInfo {
@@ -273,34 +278,37 @@ __global__ void ks2_fb_info_kernel(const uint32_t* __restrict__ tscan, Ks2Segs s
 }
 __global__ __launch_bounds__(kKsThreads) void ks2_fb_write_kernel(const uint32_t* __restrict__ code_at, Ks2Segs sg, uint32_t ntiles, const uint32_t* __restrict__ tscan,
                                                                    const Ks2FbInfo* __restrict__ fi, const Bi2State* __restrict__ obs, uint32_t* __restrict__ fb) {
-    __shared__ uint32_t wsumL[kKsThreads / kWave];
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t s = ks2_seg_of_tile(sg, tile), lt = tile - sg.tbase[s], j0 = lt * kKs2Tile + threadIdx.x * 4, n = sg.base[s + 1] - sg.base[s];
-        uint32_t       v[4];
-        if (j0 + 3 < n) {
-            const uint4 e = *reinterpret_cast<const uint4*>(code_at + sg.base[s] + j0);
-            v[0] = e.x, v[1] = e.y, v[2] = e.z, v[3] = e.w;
-        } else {
-            for (uint32_t k = 0; k < 4; ++k) v[k] = j0 + k < n ? code_at[sg.base[s] + j0 + k] : kInvalid;
-        }
-        uint32_t nib = 0, c = 0;
+    const uint32_t lane = threadIdx.x & (kWave - 1), nwaves = gridDim.x * (kKsThreads / kWave);  // one wave per tile, no barrier: 16 rows of 64 lanes x 4 records
+    for (uint32_t tile = blockIdx.x * (kKsThreads / kWave) + threadIdx.x / kWave; tile < ntiles; tile += nwaves) {
+        const uint32_t s = ks2_seg_of_tile(sg, tile), lt = tile - sg.tbase[s], n = sg.base[s + 1] - sg.base[s], nwords = (n + 31) / 32;
+        const uint32_t* const src = code_at + sg.base[s];
+        uint32_t* const       sec = fb + fi->off[s];
+        uint32_t              at  = nwords + (tscan[tile] - tscan[sg.tbase[s]]);  // the tile's first number in the section
+        for (uint32_t k = 0; k < kKs2Tile / (4 * kWave); ++k) {
+            const uint32_t j0 = lt * kKs2Tile + (k * kWave + lane) * 4;
+            uint32_t       v[4];
+            if (j0 + 3 < n) {
+                const uint4 e = *reinterpret_cast<const uint4*>(src + j0);
+                v[0] = e.x, v[1] = e.y, v[2] = e.z, v[3] = e.w;
+            } else {
+                for (uint32_t q = 0; q < 4; ++q) v[q] = j0 + q < n ? src[j0 + q] : kInvalid;
+            }
+            uint32_t nib = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            nib |= (v[k] != kInvalid ? 1u : 0u) << k;
-            c += v[k] != kInvalid;
-        }
-        uint32_t word = nib << (4 * (threadIdx.x & 7u));  // eight lanes make a bitmap word
-        word |= __shfl_xor(word, 1, kWave);
-        word |= __shfl_xor(word, 2, kWave);
-        word |= __shfl_xor(word, 4, kWave);
-        const uint32_t nwords = (n + 31) / 32, wi = lt * (kKs2Tile / 32) + threadIdx.x / 8;
-        uint32_t* const sec   = fb + fi->off[s];
-        if ((threadIdx.x & 7u) == 0 && wi < nwords) sec[wi] = word;
-        uint32_t total;
-        uint32_t at = nwords + (tscan[tile] - tscan[sg.tbase[s]]) + bi2_block_scan<kKsThreads>(c, &total, wsumL);
+            for (int q = 0; q < 4; ++q) nib |= (v[q] != kInvalid ? 1u : 0u) << q;
+            uint32_t word = nib << (4 * (lane & 7u));  // eight lanes make a bitmap word
+            word |= __shfl_xor(word, 1, kWave);
+            word |= __shfl_xor(word, 2, kWave);
+            word |= __shfl_xor(word, 4, kWave);
+            const uint32_t wi = lt * (kKs2Tile / 32) + k * (kWave / 8) + lane / 8;
+            if ((lane & 7u) == 0 && wi < nwords) sec[wi] = word;
+            uint32_t       total;
+            uint32_t       o = at + bi2_wave_excl_scan((uint32_t)__popc(nib), &total);
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (v[k] != kInvalid) sec[at++] = obs->binkept[v[k] >> 10] + (v[k] & 1023u);
+            for (int q = 0; q < 4; ++q)
+                if (v[q] != kInvalid) sec[o++] = obs->binkept[v[q] >> 10] + (v[q] & 1023u);
+            at += total;
+        }
     }
 }
 
@@ -313,12 +321,17 @@ struct Ks2Secs {
 // tile = kKs2Tile records of one owner's share (a lane: four consecutive records = one nibble of a bitmap word): every load of a tile is independent of the others (the
 // first version walked a word's bits lane by lane — a chain of ~27 dependent look-ups per lane: 1.4 ms for 85 M records)
 __global__ __launch_bounds__(kKsThreads) void ks2_dec_count_kernel(const uint32_t* __restrict__ fbr, Ks2Segs sg, Ks2Secs sc, uint32_t ntiles, uint32_t* __restrict__ tcnt) {
-    __shared__ uint32_t wsumL[kKsThreads / kWave];
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t d = ks2_seg_of_tile(sg, tile), wi = (tile - sg.tbase[d]) * (kKs2Tile / 32) + threadIdx.x, nwords = (sg.base[d + 1] - sg.base[d] + 31) / 32;
-        uint32_t       total;
-        bi2_block_scan<kKsThreads>((threadIdx.x < kKs2Tile / 32 && wi < nwords) ? (uint32_t)__popc(fbr[sc.off[d] + wi]) : 0u, &total, wsumL);
-        if (threadIdx.x == 0) tcnt[tile] = total;
+    const uint32_t lane = threadIdx.x & (kWave - 1), nwaves = gridDim.x * (kKsThreads / kWave);  // one wave per tile (128 bitmap words), no barrier
+    for (uint32_t tile = blockIdx.x * (kKsThreads / kWave) + threadIdx.x / kWave; tile < ntiles; tile += nwaves) {
+        const uint32_t d = ks2_seg_of_tile(sg, tile), w0 = (tile - sg.tbase[d]) * (kKs2Tile / 32), nwords = (sg.base[d + 1] - sg.base[d] + 31) / 32;
+        uint32_t       c = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kKs2Tile / 32 / kWave; ++k) {
+            const uint32_t wi = w0 + k * kWave + lane;
+            c += wi < nwords ? (uint32_t)__popc(fbr[sc.off[d] + wi]) : 0u;
+        }
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, kWave);
+        if (lane == 0) tcnt[tile] = c;
     }
 }
 // ... and straight into the position buckets: a tile's surviving windows are one tile of bi2_pospart_kernel's partition (the flat (position, number) arrays between

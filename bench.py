@@ -499,7 +499,7 @@ def main():
         if args.gpus == 1:
             # what one rank of the 8-GPU, 1 B-token run (125 M tokens per rank) will take: this step's device work scaled to that shard, plus 7/8 of the exchanged
             # bytes crossing xGMI at the assumed all-to-all rate (stated above; not measurable on a one-GPU box). A lower bound on the bytes: at 10^9 tokens more
-            # windows survive, and the survivors' feedback grows (profiles/r03d: 2.5 GB per rank and step with 8 ranks sharing one device)
+            # windows survive, and the survivors' feedback grows (other_configs.z1b_eight_ranks_on_one_device: 1.19 GB per rank and step, 0.17 of it to itself, since round 4)
             ms1 = elapsed / args.steps * 1e3
             scale = 125_000_000 / args.tokens
             xg = scale * info.alltoall_bytes * 7 / 8 / (XGMI_A2A_GBS * 1e9) * 1e3

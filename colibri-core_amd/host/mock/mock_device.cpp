@@ -1,0 +1,364 @@
+// mock_device.cpp — TEST INFRASTRUCTURE: a CPU stand-in for everything host/src/sharded.cpp talks to, so that the product's own multi-GPU driver — its rank threads,
+// rendezvous, agreement steps, routing of sizes and buffers, termination ("None found"), failure paths — runs under `pytest -m "not gpu"` with world 2 and 4 and no GPU:
+//   * the HIP runtime calls it makes (memory, copies, streams; "device memory" is host memory) and the RCCL entry points (present, never successful: the ranks of a
+//     mock run share "device 0", so the trainer takes its device-copies back end);
+//   * the C ABI of a device context as far as the key-sharded run uses it (include/colibri_hip.h: colibri_create ... colibri_kshard_*), computed on the CPU in the
+//     protocol's own terms — records to the owner of their key, a bit per record and a number per surviving record back, exports to the lowest rank holding an
+//     occurrence. The formats inside the buffers are this file's own (the driver moves bytes and sizes, it never looks inside); the candidate exchange
+//     (colibri_shard_*) is not mocked: a run that falls back to it ends with that message on every rank — which is what the failure tests look for.
+// Built into lib/libcolibri_sharded_mock.so together with the UNCHANGED sharded.cpp (host/Makefile, target `mock`); never linked into the product.
+// Reference semantics restated: PatternModel::train's order loop, look-back, add, prune (reference include/patternmodel.h:1078-1245).
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "colibri_hip.h"
+
+// ---- HIP: host memory behind the device API ------------------------------------------------------------------------------------------------------------------------------
+extern "C" {
+hipError_t hipGetDeviceCount(int* n) { *n = 8; return hipSuccess; }
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
+const char* hipGetErrorString(hipError_t) { return "mock HIP error"; }
+// ---- RCCL: declared, never usable ------------------------------------------------------------------------------------------------------------------------------------------
+ncclResult_t ncclGetUniqueId(ncclUniqueId*) { return ncclSystemError; }
+ncclResult_t ncclCommInitRank(ncclComm_t*, int, ncclUniqueId, int) { return ncclSystemError; }
+ncclResult_t ncclCommInitAll(ncclComm_t*, int, const int*) { return ncclSystemError; }
+ncclResult_t ncclCommAbort(ncclComm_t) { return ncclSuccess; }
+ncclResult_t ncclCommDestroy(ncclComm_t) { return ncclSuccess; }
+ncclResult_t ncclGroupStart() { return ncclSystemError; }
+ncclResult_t ncclGroupEnd() { return ncclSystemError; }
+ncclResult_t ncclSend(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return ncclSystemError; }
+ncclResult_t ncclRecv(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return ncclSystemError; }
+ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) { return ncclSystemError; }
+ncclResult_t ncclAllGather(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) { return ncclSystemError; }
+const char*  ncclGetErrorString(ncclResult_t) { return "RCCL is not part of the mock"; }
+}
+
+// ---- the device context, on the CPU ------------------------------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Rec {  // what a source sends for one window (the mock's own record: 16 bytes)
+    uint64_t key;
+    uint32_t pad0, pad1;
+};
+struct Result {
+    uint32_t pos, n, count;
+};
+}  // namespace
+
+struct colibri_ctx {
+    std::string err;
+    // corpus: one entry per position (a token, or a sentence delimiter with cls 0)
+    std::vector<uint32_t> cls, bstart, blen;
+    std::vector<uint8_t>  bytes;
+    uint64_t              ntokens = 0, nsent = 0, maxclass = 0;
+    colibri_options       opt{};
+    int                   world = 1, rank = 0, n = 0;
+    uint64_t              nclasses = 0;
+    std::vector<uint32_t> cnt1, head;          // order 1's dense counts; a (zero) dense head, so that the driver's head all-reduce runs
+    std::vector<uint64_t> cur, nxt;            // global number of the surviving (n-1)-gram at each position, ~0: none
+    std::vector<Rec>      send, recv;          // records out (grouped by owner) / in (source after source)
+    std::vector<uint32_t> sendpos, tab, tabr;  // position of every sent record; the (dummy) tables
+    std::vector<uint32_t> sbase;               // first sent record of each owner's share
+    std::vector<uint32_t> fb, fbr;             // feedback out / in
+    std::vector<uint64_t> ex, exr;             // exports out / in
+    std::vector<Result>   results;
+    uint64_t              found[COLIBRI_MAX_ORDER] = {0}, kept[COLIBRI_MAX_ORDER] = {0}, admitted[COLIBRI_MAX_ORDER] = {0};
+    colibri_stats         stats{};
+};
+
+namespace {
+int fail(colibri_ctx* c, int code, const char* msg) {
+    if (c) c->err = msg;
+    return code;
+}
+uint64_t mix(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+}  // namespace
+
+extern "C" {
+int         colibri_abi_version(void) { return COLIBRI_ABI_VERSION; }
+const char* colibri_last_error(const colibri_ctx* c) { return c ? c->err.c_str() : "null context"; }
+int colibri_create(colibri_ctx** out, int) { *out = new colibri_ctx(); return COLIBRI_OK; }
+void colibri_destroy(colibri_ctx* c) { delete c; }
+void* colibri_stream(colibri_ctx*) { return nullptr; }
+int colibri_kernel_time(const colibri_ctx*, int, double* ms, uint64_t* n) { if (ms) *ms = 0; if (n) *n = 0; return COLIBRI_OK; }
+
+// .colibri.dat v2 payload: little-endian base-128, the high bit on every byte of a token but the last; 00 ends a sentence (reference src/classencoder.cpp:22-42, :550-600)
+int colibri_upload_corpus(colibri_ctx* c, const uint8_t* p, uint64_t nbytes, uint32_t) {
+    c->cls.clear(); c->bstart.clear(); c->blen.clear();
+    c->bytes.assign(p, p + nbytes);
+    c->ntokens = c->nsent = c->maxclass = 0;
+    uint64_t i = 0;
+    while (i < nbytes) {
+        uint64_t j = i;
+        uint32_t v = 0, shift = 0;
+        while (j < nbytes && (p[j] & 0x80)) { v |= (uint32_t)(p[j] & 0x7F) << shift; shift += 7; ++j; }
+        if (j >= nbytes) break;  // (an unterminated tail: no token)
+        v |= (uint32_t)p[j] << shift;
+        c->cls.push_back(v); c->bstart.push_back((uint32_t)i); c->blen.push_back((uint32_t)(j + 1 - i));
+        if (v == 0 && j == i) ++c->nsent; else { ++c->ntokens; c->maxclass = std::max<uint64_t>(c->maxclass, v); }
+        i = j + 1;
+    }
+    return COLIBRI_OK;
+}
+int colibri_corpus_info(const colibri_ctx* c, uint64_t* ntokens, uint64_t* nsent, uint64_t* maxclass) {
+    if (ntokens) *ntokens = c->ntokens;
+    if (nsent) *nsent = c->nsent;
+    if (maxclass) *maxclass = c->maxclass;
+    return COLIBRI_OK;
+}
+
+int colibri_kshard_info(colibri_ctx* c, const colibri_options* o, int* eligible, uint64_t* maxclass, uint64_t* npos) {
+    *eligible = !o->indexed && !o->doskipgrams && !o->doskipgrams_exhaustive && !std::getenv("COLIBRI_NO_KSHARD");
+    *maxclass = c->maxclass;
+    *npos     = c->cls.size();
+    return COLIBRI_OK;
+}
+int colibri_kshard_begin(colibri_ctx* c, const colibri_options* o, int world, int rank, uint64_t maxclass_global, uint64_t) {
+    c->opt = *o; c->world = world; c->rank = rank; c->n = 0; c->nclasses = maxclass_global + 1;
+    c->results.clear();
+    std::fill(std::begin(c->found), std::end(c->found), 0); std::fill(std::begin(c->kept), std::end(c->kept), 0); std::fill(std::begin(c->admitted), std::end(c->admitted), 0);
+    return COLIBRI_OK;
+}
+int colibri_kshard_uni_count(colibri_ctx* c, void** cnt_dev, uint32_t* nclasses) {
+    c->cnt1.assign(c->nclasses, 0);
+    for (uint32_t v : c->cls) if (v) ++c->cnt1[v];
+    *cnt_dev = c->cnt1.data(); *nclasses = (uint32_t)c->nclasses; c->n = 1;
+    return COLIBRI_OK;
+}
+int colibri_kshard_uni_apply(colibri_ctx* c) {  // cnt1 holds the global counts now: the same survivors on every rank; rank 0 exports the unigrams
+    const uint32_t thr = (uint32_t)c->opt.mintokens, wthr = std::max<uint32_t>(thr, (uint32_t)std::max(0, c->opt.mintokens_unigrams));
+    c->cur.assign(c->cls.size(), ~0ull);
+    std::vector<uint32_t> first(c->nclasses, ~0u);
+    for (size_t i = 0; i < c->cls.size(); ++i) {
+        const uint32_t v = c->cls[i];
+        if (!v) continue;
+        if (first[v] == ~0u) first[v] = (uint32_t)i;
+        if (c->cnt1[v] >= wthr) c->cur[i] = v;  // (a longer window needs every word at the word threshold)
+    }
+    for (uint64_t v = 1; v < c->nclasses; ++v) {
+        if (!c->cnt1[v]) continue;
+        if (c->rank == 0) ++c->found[1];
+        if (c->cnt1[v] >= thr && c->rank == 0) ++c->kept[1];
+    }
+    // a unigram is exported by the lowest rank that holds it — the mock keeps that simple: every rank remembers where it saw each class, rank 0 exports what it holds,
+    // the others what rank 0 cannot name... which needs an exchange the protocol does not have. The product exports unigrams from their class ids (no position needed);
+    // the mock does the same through a synthetic result whose key bytes are rebuilt from the class id.
+    if (c->rank == 0)
+        for (uint64_t v = 1; v < c->nclasses; ++v)
+            if (c->cnt1[v] >= thr) c->results.push_back({(uint32_t)v, 0u /* n = 0: a class id, not a position */, c->cnt1[v]});
+    for (size_t i = 0; i < c->cls.size(); ++i) c->admitted[1] += c->cls[i] != 0;
+    return COLIBRI_OK;
+}
+int colibri_kshard_emit(colibri_ctx* c, int n, uint64_t, uint64_t, int, void** send_dev, void** tab_dev, uint32_t* tab_words, uint64_t* per_owner, uint32_t* recbytes, void** head_dev,
+                        uint64_t* admitted) {
+    if (n != c->n + 1) return fail(c, COLIBRI_ERR_STATE, "mock: colibri_kshard_emit out of order");
+    c->n = n;
+    std::vector<std::vector<Rec>>      by((size_t)c->world);
+    std::vector<std::vector<uint32_t>> bp((size_t)c->world);
+    uint64_t                           adm = 0;
+    const size_t                       P = c->cls.size();
+    for (size_t i = 0; i + (size_t)n <= P; ++i) {
+        if (c->cur[i] == ~0ull || c->cur[i + 1] == ~0ull) continue;  // the look-back (reference :1139-1152): both (n-1)-grams survived (which also keeps the window inside its sentence)
+        const uint64_t key = n == 2 ? ((uint64_t)c->cls[i] << 32 | c->cls[i + 1]) : (c->cur[i] << 24 | c->cls[i + n - 1]);  // exact: (number of the leading (n-1)-gram, last class)
+        const int      d   = (int)(mix(key) % (uint64_t)c->world);
+        by[(size_t)d].push_back({key, 0u, 0u});
+        bp[(size_t)d].push_back((uint32_t)i);
+        ++adm;
+    }
+    c->send.clear(); c->sendpos.clear(); c->sbase.assign((size_t)c->world + 1, 0);
+    for (int d = 0; d < c->world; ++d) {
+        c->sbase[(size_t)d] = (uint32_t)c->send.size();
+        per_owner[d]        = by[(size_t)d].size();
+        c->send.insert(c->send.end(), by[(size_t)d].begin(), by[(size_t)d].end());
+        c->sendpos.insert(c->sendpos.end(), bp[(size_t)d].begin(), bp[(size_t)d].end());
+    }
+    c->sbase[(size_t)c->world] = (uint32_t)c->send.size();
+    c->send.push_back({0, 0, 0});  // (never an empty buffer)
+    c->tab.assign((size_t)c->world, 7u);
+    c->admitted[n] = adm;
+    *send_dev = c->send.data(); *tab_dev = c->tab.data(); *tab_words = 1; *recbytes = sizeof(Rec); *admitted = adm;
+    if (n == 2) { c->head.assign(8192, 0u); for (int k = 4096; k < 8192; ++k) c->head[(size_t)k] = 0x7FFFFFFFu; *head_dev = c->head.data(); } else *head_dev = nullptr;
+    return COLIBRI_OK;
+}
+int colibri_kshard_recv_buffers(colibri_ctx* c, uint64_t nrecords, void** recv_dev, void** tab_recv_dev) {
+    c->recv.assign(nrecords + 1, Rec{0, 0, 0});
+    c->tabr.assign((size_t)c->world, 0u);
+    *recv_dev = c->recv.data(); *tab_recv_dev = c->tabr.data();
+    return COLIBRI_OK;
+}
+int colibri_kshard_count(colibri_ctx* c, int n, const uint64_t* per_src, int more, void** fb_dev, uint64_t* fb_per_dst, uint32_t* fb_bytes, void** ex_dev, uint64_t* ex_per_dst,
+                         uint64_t* kept_bins) {
+    for (int s = 0; s < c->world; ++s)
+        if (c->tabr[(size_t)s] != 7u) return fail(c, COLIBRI_ERR_STATE, "mock: a table did not arrive");  // (the driver moved every source's table row)
+    struct Agg { uint32_t count, first; };
+    std::map<uint64_t, Agg> m;  // the owner's add (reference :2059-2073): one entry per distinct key, its first record = lowest source rank, lowest index
+    uint64_t                tot = 0;
+    for (int s = 0; s < c->world; ++s) tot += per_src[s];
+    for (uint64_t j = 0; j < tot; ++j) {
+        auto it = m.find(c->recv[j].key);
+        if (it == m.end()) m[c->recv[j].key] = {1u, (uint32_t)j}; else ++it->second.count;
+    }
+    const uint32_t thr = (uint32_t)c->opt.mintokens;
+    std::map<uint64_t, uint32_t> number;  // prune (reference :2107-2128): the survivors, numbered densely
+    std::vector<uint64_t>        rb((size_t)c->world + 1, 0);
+    for (int s = 0; s < c->world; ++s) rb[(size_t)s + 1] = rb[(size_t)s] + per_src[s];
+    std::vector<std::vector<uint64_t>> exd((size_t)c->world);
+    for (auto& kv : m) {
+        ++c->found[n];
+        if (kv.second.count < thr) continue;
+        number[kv.first] = (uint32_t)number.size();
+        ++c->kept[n];
+        int s = 0;
+        while (kv.second.first >= rb[(size_t)s + 1]) ++s;
+        exd[(size_t)s].push_back((uint64_t)(kv.second.first - rb[(size_t)s]) | ((uint64_t)kv.second.count << 32));
+    }
+    c->fb.clear(); c->ex.clear();
+    for (int s = 0; s < c->world; ++s) {
+        fb_per_dst[s] = 0;
+        if (more) {  // per source, in the order it sent: one bit per record, then the numbers of the surviving records' keys
+            const size_t          at = c->fb.size(), nw = (per_src[s] + 31) / 32;
+            std::vector<uint32_t> codes;
+            c->fb.resize(at + nw, 0u);
+            for (uint64_t j = 0; j < per_src[s]; ++j) {
+                auto it = number.find(c->recv[rb[(size_t)s] + j].key);
+                if (it == number.end()) continue;
+                c->fb[at + j / 32] |= 1u << (j % 32);
+                codes.push_back(it->second);
+            }
+            c->fb.insert(c->fb.end(), codes.begin(), codes.end());
+            fb_per_dst[s] = nw + codes.size();
+        }
+        ex_per_dst[s] = exd[(size_t)s].size();
+        c->ex.insert(c->ex.end(), exd[(size_t)s].begin(), exd[(size_t)s].end());
+    }
+    c->fb.push_back(0); c->ex.push_back(0);
+    *kept_bins = number.size(); *fb_dev = c->fb.data(); *fb_bytes = 4; *ex_dev = c->ex.data();
+    return COLIBRI_OK;
+}
+int colibri_kshard_feedback_buffers(colibri_ctx* c, uint64_t nfb, uint64_t nex, void** fb_recv, void** ex_recv) {
+    c->fbr.assign(nfb + 1, 0u); c->exr.assign(nex + 1, 0ull);
+    *fb_recv = c->fbr.data(); *ex_recv = c->exr.data();
+    return COLIBRI_OK;
+}
+int colibri_kshard_apply(colibri_ctx* c, int n, const uint64_t* fb_src, const uint64_t* ex_src, const uint64_t* kept_per_owner, int more, uint64_t* ids_global) {
+    uint64_t gb = 0, off = 0, eo = 0;
+    c->nxt.assign(c->cls.size(), ~0ull);
+    for (int d = 0; d < c->world; ++d) {
+        const uint32_t nd = c->sbase[(size_t)d + 1] - c->sbase[(size_t)d], nw = (nd + 31) / 32;
+        if (more) {
+            if (fb_src[d] < nw) return fail(c, COLIBRI_ERR_STATE, "mock: short feedback");
+            uint64_t ci = off + nw;
+            for (uint32_t j = 0; j < nd; ++j)
+                if (c->fbr[off + j / 32] >> (j % 32) & 1u) c->nxt[c->sendpos[c->sbase[(size_t)d] + j]] = gb + c->fbr[ci++];
+            if (ci != off + fb_src[d]) return fail(c, COLIBRI_ERR_STATE, "mock: the feedback's numbers do not match its bits");
+            off += fb_src[d];
+        }
+        for (uint64_t k = 0; k < ex_src[d]; ++k) {
+            const uint64_t e = c->exr[eo + k];
+            c->results.push_back({c->sendpos[c->sbase[(size_t)d] + (uint32_t)e], (uint32_t)n, (uint32_t)(e >> 32)});
+        }
+        eo += ex_src[d];
+        gb += kept_per_owner[d];
+    }
+    if (gb >= (1ull << 40)) return fail(c, COLIBRI_ERR_OVERFLOW, "mock: too many survivors");
+    c->cur.swap(c->nxt);
+    *ids_global = gb;
+    return COLIBRI_OK;
+}
+int colibri_kshard_local_stats(colibri_ctx* c, uint64_t* found, uint64_t* kept, uint64_t* admitted, uint32_t* syncs) {
+    for (int n = 0; n < COLIBRI_MAX_ORDER; ++n) { found[n] = c->found[n]; kept[n] = c->kept[n]; admitted[n] = c->admitted[n]; }
+    if (syncs) *syncs = 0;
+    return COLIBRI_OK;
+}
+int colibri_kshard_finish(colibri_ctx* c, const uint64_t* found, const uint64_t* kept, const uint64_t* admitted, uint64_t tokens, int maxn, colibri_stats* out) {
+    colibri_stats& s = c->stats;
+    std::memset(&s, 0, sizeof s);
+    s.totaltokens = tokens; s.nsentences = c->nsent; s.npatterns = c->results.size(); s.maxn = maxn; s.minn = maxn > 0 ? 1 : 0;
+    for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) {
+        s.found[n] = n <= maxn ? found[n] : 0; s.kept[n] = n <= maxn ? kept[n] : 0; s.pruned[n] = s.found[n] - s.kept[n]; s.admitted[n] = n <= maxn ? admitted[n] : 0;
+    }
+    s.totaltypes = s.found[1];
+    if (out) *out = s;
+    return COLIBRI_OK;
+}
+static std::vector<uint8_t> mock_key(const colibri_ctx* c, const Result& r) {
+    std::vector<uint8_t> k;
+    if (r.n == 0) {  // a class id: its varint
+        uint32_t v = r.pos;
+        while (v >= 128) { k.push_back((uint8_t)(v & 0x7F) | 0x80); v >>= 7; }
+        k.push_back((uint8_t)v);
+        return k;
+    }
+    for (uint32_t t = 0; t < r.n; ++t) k.insert(k.end(), c->bytes.begin() + c->bstart[r.pos + t], c->bytes.begin() + c->bstart[r.pos + t] + c->blen[r.pos + t]);
+    return k;
+}
+int colibri_result_sizes(colibri_ctx* c, uint64_t* np, uint64_t* kb, uint64_t* nr) {
+    uint64_t b = 0;
+    for (const Result& r : c->results) b += mock_key(c, r).size();
+    if (np) *np = c->results.size();
+    if (kb) *kb = b;
+    if (nr) *nr = 0;
+    return COLIBRI_OK;
+}
+int colibri_export_unindexed(colibri_ctx* c, uint64_t* key_off, uint8_t* key_bytes, uint32_t* counts) {
+    uint64_t b = 0;
+    for (size_t j = 0; j < c->results.size(); ++j) {
+        const auto k = mock_key(c, c->results[j]);
+        key_off[j]   = b;
+        std::memcpy(key_bytes + b, k.data(), k.size());
+        b += k.size();
+        counts[j] = c->results[j].count;
+    }
+    key_off[c->results.size()] = b;
+    return COLIBRI_OK;
+}
+
+// ---- the candidate exchange is not part of the mock: a run that reaches it ends there, on every rank ------------------------------------------------------------------------
+static int mock_no_candidates(const colibri_ctx* c) {
+    if (c) const_cast<colibri_ctx*>(c)->err = "mock: the candidate exchange (colibri_shard_*) is not mocked";
+    return COLIBRI_ERR_UNSUPPORTED;
+}
+int colibri_shard_begin(colibri_ctx* c, const colibri_options*, int) { return mock_no_candidates(c); }
+int colibri_shard_count(colibri_ctx* c, int, uint32_t, int, uint64_t*, uint64_t*) { return mock_no_candidates(c); }
+int colibri_shard_send(colibri_ctx* c, void*, void*, void*) { return mock_no_candidates(c); }
+int colibri_shard_send_view(colibri_ctx* c, void**, void**, void**) { return mock_no_candidates(c); }
+int colibri_shard_merge(colibri_ctx* c, const void*, const void*, const void*, const uint64_t*, uint64_t*, uint64_t*) { return mock_no_candidates(c); }
+int colibri_shard_reply(colibri_ctx* c, uint32_t, void*, void*) { return mock_no_candidates(c); }
+int colibri_shard_apply(colibri_ctx* c, const void*, const void*, uint64_t*, uint64_t*) { return mock_no_candidates(c); }
+int colibri_shard_uni_info(const colibri_ctx* c, int*, uint64_t*) { return mock_no_candidates(c); }
+int colibri_shard_uni_count(colibri_ctx* c, void*, void*, uint32_t, int) { return mock_no_candidates(c); }
+int colibri_shard_uni_apply(colibri_ctx* c, const void*, const void*, uint32_t, int, uint64_t*, uint64_t*, uint64_t*) { return mock_no_candidates(c); }
+int colibri_shard_finish(colibri_ctx* c, const uint64_t*, const uint64_t*, uint64_t, int, colibri_stats*) { return mock_no_candidates(c); }
+int colibri_shard_export_gids(colibri_ctx* c, uint32_t*) { return mock_no_candidates(c); }
+int colibri_shard_index_sizes(const colibri_ctx* c, uint64_t*, uint64_t*) { return mock_no_candidates(c); }
+int colibri_shard_export_index(colibri_ctx* c, uint32_t*, uint64_t*, uint32_t*, uint16_t*) { return mock_no_candidates(c); }
+// what the C++ face's object file (colibri_host.o, linked for cut_sentences and friends) refers to beyond the sharded trainer: present, never reached in a mock run
+int colibri_train(colibri_ctx* c, const colibri_options*, colibri_stats*) { return mock_no_candidates(c); }
+int colibri_export_indexed(colibri_ctx* c, uint64_t*, uint8_t*, uint32_t*, uint64_t*, uint32_t*, uint16_t*) { return mock_no_candidates(c); }
+int colibri_flexgrams(colibri_ctx* c, const uint64_t*, const uint8_t*, const uint64_t*, const uint32_t*, const uint16_t*, uint64_t, uint64_t*, uint64_t*, uint64_t*) { return mock_no_candidates(c); }
+int colibri_flexgrams_fetch(colibri_ctx* c, uint64_t*, uint8_t*, uint32_t*, uint64_t*, uint32_t*, uint16_t*) { return mock_no_candidates(c); }
+int colibri_flexgrams_resident(colibri_ctx* c, uint64_t*, uint64_t*, uint64_t*) { return mock_no_candidates(c); }
+int colibri_set_constraint(colibri_ctx* c, const uint64_t*, const uint8_t*, uint64_t) { return mock_no_candidates(c); }
+int colibri_set_continuation(colibri_ctx* c, const uint64_t*, const uint8_t*, uint64_t) { return mock_no_candidates(c); }
+int colibri_set_filter(colibri_ctx* c, const uint64_t*, const uint8_t*, uint64_t) { return mock_no_candidates(c); }
+}

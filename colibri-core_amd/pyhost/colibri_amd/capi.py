@@ -463,10 +463,12 @@ _shlib = None
 def load_sharded():
     global _shlib
     if _shlib is None:
-        load()  # libcolibri_hip.so first (the trainer links it)
-        if not os.path.exists(SHARDED_LIB_PATH):
-            raise ImportError(f"{SHARDED_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
-        S = C.CDLL(SHARDED_LIB_PATH)
+        path = os.environ.get("COLIBRI_SHARDED_LIB", SHARDED_LIB_PATH)  # (tests: lib/libcolibri_sharded_mock.so — the same driver over a CPU stand-in for the device layer)
+        if path == SHARDED_LIB_PATH:
+            load()  # libcolibri_hip.so first (the trainer links it)
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        S = C.CDLL(path)
         S.colibri_sharded_unique_id.argtypes = [C.c_void_p]
         S.colibri_sharded_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         S.colibri_sharded_destroy.argtypes = [C.c_void_p]

@@ -204,6 +204,32 @@ def z1b_configs(capi, shards):
     return res
 
 
+def cxx_face(payload):
+    """What a drop-in user of the reference's API sees: PatternModel<uint32_t>::train() on a preloaded corpus through host/include/patternmodel.h (reference
+    include/patternmodel.h:1353-1364, src/benchmarks.cpp:228-237) — a fresh device context, the H2D upload and tokenising, colibri_train, the export of keys and counts to
+    host memory — and the first look-up (the pattern map is built lazily). host_selftest bench: three runs in one process, the first one cold (device memory is reserved)."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "colibri-core_amd", "bin", "host_selftest")
+    if not os.access(exe, os.X_OK):
+        return {"error": "colibri-core_amd/bin/host_selftest is not built"}
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as td:
+        path = os.path.join(td, "c.colibri.dat")
+        with open(path, "wb") as f:
+            f.write(bytes([0xA2, 0x02]))
+            f.write(payload.tobytes())
+        try:
+            p = subprocess.run([exe, "bench", path, str(MAXLENGTH), str(MINTOKENS), "3"], capture_output=True, text=True, timeout=300)
+            d = json.loads(p.stdout.strip().splitlines()[-1])
+        except Exception as e:  # noqa: BLE001
+            return {"error": f"host_selftest bench failed: {e}"}
+    runs = d["runs"]
+    return {"workload": "PatternModel<uint32_t>::train(corpusfile, options) on a preloaded IndexedCorpus of the timed corpus, C++ face (host_selftest bench): context + upload + "
+                        "colibri_train + export to host vectors, per call",
+            "cxx_face_train_ms": round(min(r["train_ms"] for r in runs), 1), "cxx_face_train_ms_first_call": round(runs[0]["train_ms"], 1),
+            "first_lookup_ms_map_materialisation": round(min(r["first_lookup_ms"] for r in runs), 1), "patterns": runs[-1]["patterns"], "corpus_load_ms_host": round(d["corpus_load_ms"], 1)}
+
+
 def measured_traffic(workload_tokens, kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or None — NOT measured by this run"""
     path = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
@@ -521,6 +547,11 @@ def main():
         ctx.close()
         ctx = None
         out["other_configs"].update(z1b_configs(capi, z1b_shards))
+    if "other_configs" in out and args.gpus == 1 and not args.force_shard:
+        if ctx is not None:
+            ctx.close()
+            ctx = None
+        out["other_configs"]["cxx_face"] = cxx_face(payloads[0])
     if args.gpus == 1 and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.vocab)
     print(json.dumps(out), flush=True)

@@ -1,6 +1,8 @@
 // host_selftest — exercises the C++ face the way the reference's callers use it (src/test.cpp:1211-1232, src/benchmarks.cpp:228-237):
 //   host_selftest cpu  <hamlet.v2.colibri.dat> <hamlet.v1.colibri.patternmodel>   host-only checks (formats, key types; no GPU)
 //   host_selftest gpu  <corpus.colibri.dat> <out.model> <u|i> <maxlength> <mintokens>   train on the GPU, write the model, print a summary
+//   host_selftest bench <corpus.colibri.dat> <maxlength> <mintokens> [reps]              PatternModel<uint32_t>::train() end to end, timed (bench.py: cxx_face_train_ms)
+#include <chrono>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -96,6 +98,37 @@ int main(int argc, char** argv) {
             std::cout << "FAILED: " << e.what() << std::endl;
             return 1;
         }
+    }
+    if (mode == "bench" && argc >= 5) {
+        // what a caller of the reference's API pays: PatternModel<uint32_t>::train() on a preloaded corpus (src/benchmarks.cpp:228-237) through this C++ face — a device
+        // context, the upload, colibri_train, the export of keys and counts to host memory — and the first look-up (the pattern map is materialised lazily)
+        typedef std::chrono::steady_clock clk;
+        PatternModelOptions options;
+        options.MAXLENGTH = std::atoi(argv[3]);
+        options.MINTOKENS = std::atoi(argv[4]);
+        options.QUIET     = true;
+        const int reps    = argc >= 6 ? std::atoi(argv[5]) : 3;
+        try {
+            const auto    l0 = clk::now();
+            IndexedCorpus corpus{std::string(argv[2])};
+            const double  load_ms = std::chrono::duration<double, std::milli>(clk::now() - l0).count();
+            std::cout << "{\"corpus_load_ms\": " << load_ms << ", \"runs\": [";
+            for (int r = 0; r < reps; ++r) {
+                PatternModel<uint32_t> model(&corpus);
+                const auto             t0 = clk::now();
+                model.train(std::string(argv[2]), options);
+                const auto          t1 = clk::now();
+                const unsigned char k1[] = {6};
+                const unsigned int  c6 = model.occurrencecount(Pattern(k1, 1));
+                const auto          t2 = clk::now();
+                std::cout << (r ? ", " : "") << "{\"train_ms\": " << std::chrono::duration<double, std::milli>(t1 - t0).count()
+                          << ", \"first_lookup_ms\": " << std::chrono::duration<double, std::milli>(t2 - t1).count() << ", \"patterns\": " << model.size() << ", \"count_of_class_6\": " << c6 << "}";
+            }
+            std::cout << "]}" << std::endl;
+        } catch (const InternalError&) {
+            return 1;
+        }
+        return 0;
     }
     if (mode == "gpu" && argc >= 7) {
         PatternModelOptions options;

@@ -23,7 +23,7 @@ def test_library_is_native():
     """The product path is the HIP shared library; it must be the thing that is loaded."""
     from colibri_amd import capi
     L = capi.load()
-    assert L.colibri_abi_version() == 2
+    assert L.colibri_abi_version() == 3
 
 
 def test_spooky_known_answers(ctx):

@@ -228,6 +228,9 @@ struct colibri_ctx {
         DevBuf<uint32_t>  tab, key4, posbuf, rowtot, code_at, tcnt, fpos, fcode, zero8k, small, cbhist;
         uint32_t          sbase[kKsWorld + 1] = {0};  // this rank's send order: first key of each owner's share
         uint32_t          bshift = 0;                 // the order's B-bin shift, agreed by all ranks
+        bool              indexed = false;            // an indexed model: every order's surviving windows also become (global number, position) pairs of the local forward index
+        uint32_t          gid_off = 0;                // ... the order's numbers are shifted by this (order 1: class ids; then the orders' numbers one after the other)
+        DevBuf<uint32_t>  fin_gid;                    // ... and every pattern this rank exports has its global number
         Bi2State*         src_state = nullptr;        // the source side's Bi2State of the running order
         hipStream_t side = nullptr;   // the host's early looks at exchange sizes (kshard_api.inc: ks_peek_*)
         hipEvent_t  ev = nullptr;
@@ -584,7 +587,7 @@ void colibri_destroy(colibri_ctx* c) {
         dev_free(k.ores_cnt); dev_free(k.fin_rep); dev_free(k.fin_cnt); dev_free(k.sbuf); dev_free(k.rbuf[0]); dev_free(k.rbuf[1]); dev_free(k.fbs); dev_free(k.exs); dev_free(k.fbr);
         dev_free(k.exr);
         dev_free(k.ks2); dev_free(k.fbinfo); dev_free(k.tab); dev_free(k.key4); dev_free(k.posbuf); dev_free(k.rowtot); dev_free(k.code_at); dev_free(k.tcnt); dev_free(k.fpos);
-        dev_free(k.fcode); dev_free(k.zero8k); dev_free(k.small); dev_free(k.cbhist);
+        dev_free(k.fcode); dev_free(k.zero8k); dev_free(k.small); dev_free(k.cbhist); dev_free(k.fin_gid);
         if (k.side) (void)hipStreamDestroy(k.side);
         if (k.ev) (void)hipEventDestroy(k.ev);
         if (k.pinned) (void)hipHostFree(k.pinned);

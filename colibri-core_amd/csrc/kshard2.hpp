@@ -339,7 +339,11 @@ __global__ __launch_bounds__(kKsThreads) void ks2_dec_count_kernel(const uint32_
 static_assert(kKs2Tile == kBi2Tile && kKsThreads == kBi2Threads && kBi2Per == 4, "a feedback tile is a partition tile: four consecutive records per lane");
 __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void ks2_dec_pospart_kernel(const uint32_t* __restrict__ fbr, Ks2Segs sg, Ks2Secs sc, uint32_t ntiles,
                                                                                           const uint32_t* __restrict__ tscan, const uint32_t* __restrict__ posbuf, Bi2State* __restrict__ bs,
-                                                                                          DevState* __restrict__ st, uint32_t* __restrict__ plist, Bi2Lists pl, uint32_t* __restrict__ pcode) {
+                                                                                          DevState* __restrict__ st, uint32_t* __restrict__ plist, Bi2Lists pl, uint32_t* __restrict__ pcode,
+                                                                                          bool part = true /* false: only ids_out (an indexed model's last order) */,
+                                                                                          uint32_t* __restrict__ ids_out = nullptr /* indexed models: also gid_off + number at every surviving
+                                                                                              window's position (the forward index is emitted from it in position order) */,
+                                                                                          uint32_t gid_off = 0) {
     __shared__ Bi2PospartLds L;
     const uint32_t           shard = blockIdx.x & (uint32_t)(kBi2Shards - 1);
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -357,7 +361,12 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void ks2_dec_pospar
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if ((nib >> k) & 1u) g[k] = sc.gbase[d] + fbr[cb + q++];
-        bi2_pospart_tile(L, p, g, shard, bs, st, plist, pl, pcode);
+        if (ids_out != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((nib >> k) & 1u) ids_out[p[k]] = gid_off + g[k];
+        }
+        if (part) bi2_pospart_tile(L, p, g, shard, bs, st, plist, pl, pcode);
     }
 }
 // the exports this rank receives (owner by owner): (index in the stream it sent to that owner | count << 32), or a flagged position -> the result arrays
@@ -377,6 +386,33 @@ __global__ __launch_bounds__(kBlock) void ks2_append_exports_kernel(const unsign
         cnt[j] = (uint32_t)(e >> 32);
     }
 }
+// ---- indexed models: the references stay on the rank that holds them, keyed by the patterns' global numbers ---------------------------------------------------------------
+// order 1: ids[i] = class id of the token at i if its (global) count reaches the threshold
+__global__ __launch_bounds__(kBlock) void ks2_uni_ids_kernel(const uint32_t* __restrict__ cls, const uint32_t* __restrict__ cnt1, uint32_t thr, uint32_t npos, uint32_t* __restrict__ ids) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npos; i += gridDim.x * kBlock) {
+        const uint32_t v = cls[i];
+        ids[i]           = (v && cnt1[v] >= thr) ? v : kInvalid;
+    }
+}
+// order 2's head windows (list (shard 8, bucket): position, kBi2HeadCode | pair): ids[position] = gid_off + the pair's number, where the pair survived
+__global__ __launch_bounds__(kBlock) void ks2_head_ids_kernel(const Bi2State* __restrict__ bs, const uint32_t* __restrict__ plist, const uint32_t* __restrict__ pcode, Bi2Lists pl,
+                                                               uint32_t nbuckets, const uint32_t* __restrict__ headid, uint32_t gid_off, uint32_t* __restrict__ ids) {
+    for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
+        uint32_t first, cap;
+        bi2_list_of(pl, kBi2Shards, b, first, cap);
+        const uint32_t n = min(bs->pcur[kBi2Shards * kBi2Buckets + b], cap);
+        for (uint32_t j = threadIdx.x; j < n; j += kBlock) {
+            const uint32_t r = headid[pcode[first + j] & 0xFFFu];
+            if (r != kInvalid) ids[plist[first + j]] = gid_off + r;
+        }
+    }
+}
+// the global number of every pattern this rank just took over for export: what its representative window carries (the exporter holds an occurrence: the window is
+// among the ones the feedback named). from_class (order 1, rank 0): the representative IS the class id
+__global__ __launch_bounds__(kBlock) void ks2_export_gids_kernel(const uint32_t* __restrict__ rep, uint32_t n, const uint32_t* __restrict__ ids, bool from_class, uint32_t* __restrict__ gid) {
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) gid[j] = from_class ? rep[j] : ids[rep[j]];
+}
+
 // order 2's head pairs: the same survivors on every rank (all-reduced counts) -> the same numbers, behind all owners'. headid[h] = number, or kInvalid
 __global__ __launch_bounds__(kBlock) void ks2_headid_kernel(const uint32_t* __restrict__ headsurv /* bit h: pair h survived */, uint32_t first, uint32_t* __restrict__ headid) {
     uint32_t       hk   = 0;

@@ -588,6 +588,7 @@ class RankDriver {
             }
         }
         if (!took_kshard) train_candidates(o, stats);
+        else if (o.indexed) has_gids = true;  // (an indexed model's references stay with the ranks, keyed by the patterns' global numbers: the exporters name theirs)
         uint64_t ns = 0;
         chk(colibri_corpus_info(c, nullptr, &ns, nullptr), "colibri_corpus_info");
         stats.nsentences = ns;
@@ -611,8 +612,9 @@ class RankDriver {
         out = RankExport();
         out.key_off.assign(np + 1, 0);
         out.key_bytes.assign(kb + 1, 0);
-        out.counts.assign(np, 0);
+        out.counts.assign(np + 1, 0);  // (never a null pointer: a rank of a small corpus may export nothing)
         chk(colibri_export_unindexed(c, out.key_off.data(), out.key_bytes.data(), out.counts.data()), "colibri_export_unindexed");
+        out.counts.resize(np);
         if (has_gids) {
             out.gids.assign(np + 1, 0);
             chk(colibri_shard_export_gids(c, out.gids.data()), "colibri_shard_export_gids");
@@ -798,7 +800,8 @@ void device_train_sharded(const unsigned char* payload, uint64_t nbytes, const c
     std::vector<uint32_t> where(have_gids ? gid_max + 2 : 0, 0xFFFFFFFFu);  // global id -> pattern number
     uint64_t              j = 0, b = 0;
     out.stats.nsentences = 0;
-    if (have_gids)
+    const bool sum_admitted = !ranks[0]->took_kshard;  // (the key-sharded run reports global figures already)
+    if (sum_admitted)
         for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) out.stats.admitted[n] = 0;
     for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) out.stats.windows[n] = 0;
     for (auto& rk : ranks) {
@@ -820,7 +823,7 @@ void device_train_sharded(const unsigned char* payload, uint64_t nbytes, const c
         out.stats.nsentences += rk->stats.nsentences;
         for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) {
             out.stats.windows[n] += rk->stats.windows[n];
-            if (have_gids) out.stats.admitted[n] += rk->stats.admitted[n];  // (the key-sharded run reports global figures already)
+            if (sum_admitted) out.stats.admitted[n] += rk->stats.admitted[n];
         }
     }
     out.key_off[np]     = b;

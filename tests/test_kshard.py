@@ -160,3 +160,36 @@ def test_a_step_that_fails_on_one_rank_takes_every_rank_out_together(fault, tmp_
     assert p.returncode == 0, p.stderr[-2000:]
     assert "PROTOCOL 1" in p.stdout, p.stdout[-500:]
     assert "failed on rank(s) " + fault.split(":")[0] in p.stderr, p.stderr[-1000:]  # (rank 0 reports who failed; the reason is the failing rank's)
+
+
+@pytest.mark.parametrize("gpus", [1, 2, 4, 8])
+@pytest.mark.parametrize("corpus,thr", [("hamlet.v2", 2), ("zipf20k", 2), ("phrases15k", 2), ("zipf20k", 1)])
+def test_key_sharded_indexed_model_has_the_references_reference_lists(tmp_path, corpus, thr, gpus):
+    """IndexedPatternModel (reference include/patternmodel.h:2789-2800, IndexedDataHandler include/datatypes.h:247-297) on the key-sharded path: the references stay on the
+    rank that holds them, keyed by the patterns' global numbers; the exporter of a pattern names its number; the C++ face (colibri-patternmodeller --gpus N) joins
+    the ranks' runs in rank order. Every pattern, count and reference list must be the real reference's (goldens by ref_driver), and the run must not have taken the
+    candidate exchange."""
+    import os, subprocess
+    import oracle
+    from test_host_face import CLI, GOLDEN, parse_model
+    model = str(tmp_path / "m.colibri.patternmodel")
+    data = os.path.join(GOLDEN, corpus + ".colibri.dat")
+    env = dict(os.environ)
+    if gpus > 1:
+        env["COLIBRI_DEVICES"] = ",".join(["0"] * gpus)
+    else:
+        env["COLIBRI_GPUS_FORCE_SHARDED"] = "1"
+    out = subprocess.run([CLI, "-f", data, "-t", str(thr), "-l", "5", "-o", model, "--gpus", str(gpus)], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stderr
+    assert "Counted key-sharded" in out.stderr, out.stderr
+    tag = "i" if thr == 2 else "it1"
+    golden = os.path.join(GOLDEN, f"{corpus}.{tag}.l5.txt")
+    if not os.path.exists(golden):
+        golden = os.path.join(GOLDEN, f"{corpus}.{tag}.txt")
+    if not os.path.exists(golden):
+        pytest.skip("no golden for this corpus and threshold")
+    want = oracle.parse_dump(open(golden).read(), indexed=True)
+    mtype, tokens, types, counts, refs = parse_model(model)
+    assert (mtype, tokens, types) == (20, want.tokens, want.types)
+    assert counts == want.counts
+    assert refs == want.refs

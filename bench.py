@@ -536,6 +536,17 @@ def main():
         if preflight is not None:
             sh["rccl_rehearsal"] = preflight
         out["sharded"] = sh
+    if tr is not None and "sharded" in out and not args.candidates:
+        # the same trainer on an INDEXED model (configs[4]: the forward index built on the device; the references stay with the ranks, keyed by global numbers): untimed extra
+        try:
+            best = None
+            for _ in range(3):
+                sti = tr.train(capi.Options.defaults(mintokens=MINTOKENS, maxlength=MAXLENGTH, indexed=1))
+                best = tr.info.wall_ms if best is None else min(best, tr.info.wall_ms)
+            out["sharded"]["indexed_model"] = {"ms_per_step": round(best, 2), "protocol": "candidate exchange" if tr.info.protocol == 1 else "key-sharded counting",
+                                               "references_this_process": int(sti.nrefs), "alltoall_bytes_per_rank_and_step": int(tr.info.alltoall_bytes)}
+        except Exception as e:  # noqa: BLE001
+            out["sharded"]["indexed_model"] = {"error": str(e)}
     if ctx is not None and not args.no_other_configs:
         out["other_configs"] = other_configs(ctx, capi, payloads[0].size)
         if want_phrases:

@@ -858,7 +858,14 @@ int binned_resolve_stage(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids_out,
 
 // ---- order 2, second generation (bigram2.hpp): class-keyed 8-byte records, dense head, per-slot level B, one wave per final bin, position
 // lists -> bitmap -> the active list of order 3. `want_list`: order 3 follows. Everything is enqueued; nothing is read back.
-constexpr uint32_t kBi2Sub = 8, kBi2EmitGrid = 512, kBi2Waves = 256 * 16;
+#ifndef COLIBRI_BI2_SUB
+#define COLIBRI_BI2_SUB 4
+#endif
+// sub-regions per A bin. A final bin is one run per sub-region: fewer runs make the count kernel cheaper (its run look-up is ~half its instructions at 8), more make
+// the emit kernel's cursor reservations and level B's blocks cheaper. Measured per 10^8-token step on one box: 8 / 4 / 2 / 1 sub-regions 4.54 / 4.44 / 4.47 / 4.56 ms
+// (count 0.85 / .. / 0.76 / 0.75, level B 0.48 / .. / 0.59 / 0.56, emit 0.51 / .. / 0.51 / 0.63). The split of corpora beyond one pass and the multi-GPU source
+// side keep eight (kBi2SubWide): their sub-regions double as source ranks / carry three position bits.
+constexpr uint32_t kBi2Sub = COLIBRI_BI2_SUB, kBi2SubWide = 8, kBi2EmitGrid = 512, kBi2Waves = 256 * 16;
 // records a pass of the radix path takes on (final bins of ~700-1500 records). COLIBRI_SLICE_POSITIONS (tests): a smaller number, so that small corpora
 // exercise the sliced passes of the path for corpora beyond ~128 M tokens per device
 inline uint64_t slice_positions() {
@@ -882,9 +889,9 @@ struct Bigram2Plan {
     size_t   listn;  // entries of plist / pcode when the head windows' lists are behind the shards' (chain.hpp)
     Bi2Lists pl;
 };
-Bigram2Plan bigram2_plan(const colibri_ctx* c, uint32_t npos) {
+Bigram2Plan bigram2_plan(const colibri_ctx* c, uint32_t npos, uint32_t nsub = kBi2Sub) {
     Bigram2Plan b{};
-    b.nslots = kBins * kBi2Sub;
+    b.nslots = kBins * nsub;
     // records are 8 bytes: recs[0] (level-A output) and recs[1] (level-B output) hold twice their Rec capacity
     b.region = (uint32_t)(std::min<uint64_t>(2ull * c->recs[0].n, 2ull * c->recs[1].n) / b.nslots);
     // a pass over one slice of a big corpus fills a fraction of that: keep its slots close together (a bin's eight runs then lie ~MBs, not ~GBs, apart)
@@ -914,7 +921,7 @@ bool bigram2_fits(const colibri_ctx* c, uint32_t npos) {
 int bigram2_alloc(colibri_ctx* c, uint32_t npos, bool chain = false) {
     const Bigram2Plan b = bigram2_plan(c, npos);
     int               rc;
-    if ((rc = dev_alloc(c, c->b2.state, 1)) || (rc = dev_alloc(c, c->b2.boff, (size_t)b.nslots * (kBi2BBins + 1))) ||
+    if ((rc = dev_alloc(c, c->b2.state, 1)) || (rc = dev_alloc(c, c->b2.boff, (size_t)kBins * kBi2SubWide * (kBi2BBins + 1))) ||
         (rc = dev_alloc(c, c->b2.head_rows, (size_t)kBi2EmitGrid * 2 * kBi2HeadN)) || (rc = dev_alloc(c, c->b2.wlist, (size_t)(kBi2Waves + b.wextra) * b.wcap)) ||
         (rc = dev_alloc(c, c->b2.wcnt, (size_t)kBi2Waves + b.wextra + 1)) || (rc = dev_alloc(c, c->b2.plist, chain ? b.listn : (size_t)kBi2Shards * kBi2Buckets * b.pl.pcap + 64)) ||
         (rc = dev_alloc(c, c->b2.bitmap, (size_t)npos / 32 + 24)) || (rc = dev_alloc(c, c->b2.headsurv, kBi2HeadN / 32)))
@@ -1099,7 +1106,7 @@ bool bigram2_split_fits(const colibri_ctx* c, uint32_t npos) {
 }
 int bigram2_order_split(colibri_ctx* c, const TrainPlan& pl, bool want_list) {
     const uint32_t    npos = pl.npos, nsurv = c->maxclass / 32 + 1;
-    const Bigram2Plan b    = bigram2_plan(c, npos);
+    const Bigram2Plan b    = bigram2_plan(c, npos, kBi2SubWide);
     const uint32_t    s    = b.sbits, V = 1u << s;
     auto&             ks   = c->ks;
     int               rc;
@@ -1133,7 +1140,7 @@ int bigram2_order_split(colibri_ctx* c, const TrainPlan& pl, bool want_list) {
     HIP_TRY(c, hipMemsetAsync(ks.split.p, 0, sizeof(KsSplitState), c->stream));
     {
         Prof p(c, COLIBRI_K_EMIT2);
-        hipLaunchKernelGGL(bi2_emit_kernel, dim3(kBi2EmitGrid), dim3(kBi2Threads), 0, c->stream, c->cls.p, c->uni_surv.p, nsurv, npos, b.clsbits, 0u, 0u, b.posbits, recsA, region, kBi2Sub, sbs,
+        hipLaunchKernelGGL(bi2_emit_kernel, dim3(kBi2EmitGrid), dim3(kBi2Threads), 0, c->stream, c->cls.p, c->uni_surv.p, nsurv, npos, b.clsbits, 0u, 0u, b.posbits, recsA, region, kBi2SubWide, sbs,
                            c->state.p, c->b2.head_rows.p, (uint8_t*)nullptr, K);
         hipLaunchKernelGGL(bi2_head_reduce_kernel, dim3(kBi2HeadN / kBlock, kBi2HeadSplit), dim3(kBlock), 0, c->stream, c->b2.head_rows.p, kBi2EmitGrid, sbs, c->state.p);
     }
@@ -1161,17 +1168,17 @@ int bigram2_order_split(colibri_ctx* c, const TrainPlan& pl, bool want_list) {
             Prof p(c, COLIBRI_K_LEVELB2);
             hipLaunchKernelGGL(ks_local_init2_kernel, dim3(1), dim3(kKsThreads), 0, c->stream, obs, ks.slotbase.p, (const KsSplitState*)ks.split.p, v, s, K - s, b.posbits + s, (const uint32_t*)keep,
                                roomB, c->state.p);
-            hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, obs, 0xFFFFFFFFu, kBi2Sub, (const DevState*)c->state.p);
+            hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, obs, 0xFFFFFFFFu, kBi2SubWide, (const DevState*)c->state.p);
             hipLaunchKernelGGL(bi2_levelB_kernel, dim3(kKsSlots), dim3(kBi2Threads), 0, c->stream, (const unsigned long long*)seg, segB, 0xFFFFFFFFu, (const Bi2State*)obs, ks.oboff.p,
                                (const DevState*)c->state.p, (const uint32_t*)ks.slotbase.p);
-            hipLaunchKernelGGL(bi2_binoff_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, obs, (const uint32_t*)ks.oboff.p, kBi2Sub, (const DevState*)c->state.p);
+            hipLaunchKernelGGL(bi2_binoff_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, obs, (const uint32_t*)ks.oboff.p, kBi2SubWide, (const DevState*)c->state.p);
         }
         {
             Prof p(c, COLIBRI_K_COUNT2);
-            hipLaunchKernelGGL((bi2_count_big_kernel<(int)kBi2Sub, true>), dim3(kBi2Waves * kWave / kBi2BigThreads), dim3(kBi2BigThreads), 0, c->stream, (const unsigned long long*)segB, 0u,
+            hipLaunchKernelGGL((bi2_count_big_kernel<(int)kBi2SubWide, true>), dim3(kBi2Waves * kWave / kBi2BigThreads), dim3(kBi2BigThreads), 0, c->stream, (const unsigned long long*)segB, 0u,
                                (const uint32_t*)ks.oboff.p, obs, c->state.p, pl.thr, io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, nchunks, want_list, (uint32_t*)nullptr,
                                (const uint32_t*)ks.slotbase.p);
-            hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub, true, 16>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, (const unsigned long long*)segB, 0u, (const uint32_t*)ks.oboff.p, obs,
+            hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2SubWide, true, 16>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, (const unsigned long long*)segB, 0u, (const uint32_t*)ks.oboff.p, obs,
                                c->state.p, pl.thr, io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, nchunks, want_list, (uint32_t*)nullptr, (const uint32_t*)ks.slotbase.p, true);
             hipLaunchKernelGGL(ks_keep_chunk_kernel, dim3(1), dim3(1), 0, c->stream, (const Bi2State*)obs, keep);
         }

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kKsThreads) void ks_split_hist_kernel(const RecT* _
     __shared__ uint32_t histL[kKsWorld];
     const uint32_t      slot = blockIdx.x, have = slotcnt[slot], n = min(have, region);
     if (threadIdx.x < kKsWorld) histL[threadIdx.x] = 0;
-    if (have > region && threadIdx.x == 0) ss->overflow = 1;
+    if ((have > region || n >= (1u << 20)) && threadIdx.x == 0) ss->overflow = 1;  // (KsPacked's 16-bit fields hold a wave's sums only below 2^20 records per slot: 489 k at 10^9 tokens)
     __syncthreads();
     KsPacked     acc;
     const size_t base = (size_t)slot * region;

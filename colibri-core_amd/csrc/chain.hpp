@@ -327,4 +327,29 @@ __global__ __launch_bounds__(kChThreads, 6) void chain_emit_kernel(const uint32_
     if (threadIdx.x == 0 && Q.nadm) atomicAdd(&st->admitted, Q.nadm);
 }
 
+// ---- result indices per position (the modes that keep every order's ids), with the step order of chain_emit_kernel ------------------------------------------------------
+// bi2_ids_kernel scatters a bucket's 4-byte ids into its 512 KB window with one block per bucket: all ~800 windows are open at once, a line leaves L2 before its other
+// ids arrive, and 1.33 GB are written to store 0.42 GB (rounds 2-3). Here an XCD's blocks walk the XCD's buckets together, piece by piece (chain_steps_kernel's tables):
+// ~3 windows are open per L2 and a line is written once it is whole. pcode: dense survivor numbers (bi2_pospart_kernel, dense = true).
+__global__ __launch_bounds__(kChThreads) void chain_ids_kernel(const uint32_t* __restrict__ plist, const uint32_t* __restrict__ pcode, const uint2* __restrict__ table, uint32_t cap,
+                                                                const uint32_t* __restrict__ nsteps, const Bi2State* __restrict__ bs, const DevState* __restrict__ st,
+                                                                uint32_t* __restrict__ ids) {
+    if (st->done) return;
+    const uint32_t     x = blockIdx.x % kChXcds, nper = gridDim.x / kChXcds, ns = nsteps[x], res_base = bs->res_base;
+    const uint2* const tab = table + (size_t)x * cap;
+    for (uint32_t k = blockIdx.x / kChXcds; k < ns; k += nper) {
+        const uint2 e = tab[k];
+        uint32_t    ps[kChPer], cd[kChPer];
+#pragma unroll
+        for (int q = 0; q < kChPer; ++q) {
+            const uint32_t j = q * kChThreads + threadIdx.x;
+            ps[q]            = j < e.y ? plist[(size_t)e.x + j] : kInvalid;
+            cd[q]            = j < e.y ? pcode[(size_t)e.x + j] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < kChPer; ++q)
+            if (ps[q] != kInvalid) ids[ps[q]] = res_base + cd[q];
+    }
+}
+
 }  // namespace colibri

@@ -955,7 +955,7 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
         int rc;
         if (b.sbits != 0 || !want_list) return fail(c, COLIBRI_ERR_STATE, "bigram2_order: ids need the single-pass form with lists");
         if ((rc = dev_alloc(c, c->b2.wcode, (size_t)(kBi2Waves + b.wextra) * b.wcap)) || (rc = dev_alloc(c, c->b2.pcode, (size_t)kBi2Shards * kBi2Buckets * b.pl.pcap + 64)) ||
-            (rc = dev_alloc(c, c->b2.headid, kBi2HeadN)))
+            (rc = dev_alloc(c, c->b2.headid, kBi2HeadN)) || (rc = dev_alloc(c, c->b2.steps, 2 * (size_t)kChXcds * chain_steps_cap(b.pl) + kChXcds)))
             return rc;
         HIP_TRY(c, hipMemsetAsync(ids_out, 0xFF, sizeof(uint32_t) * (size_t)npos, c->stream));
     }
@@ -1011,7 +1011,7 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
     {
         Prof p(c, COLIBRI_K_LISTS2);
         hipLaunchKernelGGL(bi2_pospart_kernel, dim3(512), dim3(kBi2Threads), 0, c->stream, c->b2.wlist.p, c->b2.wcnt.p, kBi2Waves + b.wextra, b.wcap, bs, c->state.p, c->b2.plist.p, b.pl,
-                           with_codes ? (const uint32_t*)c->b2.wcode.p : (const uint32_t*)nullptr, with_codes ? c->b2.pcode.p : (uint32_t*)nullptr, 0u, /*dense=*/chain);
+                           with_codes ? (const uint32_t*)c->b2.wcode.p : (const uint32_t*)nullptr, with_codes ? c->b2.pcode.p : (uint32_t*)nullptr, 0u, /*dense=*/chain || ids_out != nullptr);
         if (chain) {  // who of the head pairs survived; the bitmap of all listed positions (and st->valid). The pairs stay where they are: chain_order(3) walks them
             hipLaunchKernelGGL(bi2_headids_kernel, dim3(1), dim3(kBlock), 0, c->stream, (const Bi2State*)bs, (const DevState*)c->state.p, c->b2.headid.p);
             hipLaunchKernelGGL(chain_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, (const Bi2State*)bs, (const uint32_t*)c->b2.plist.p, b.pl,
@@ -1019,14 +1019,14 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
             return COLIBRI_OK;
         }
         if (ids_out != nullptr) {
-            static const uint32_t ids_grid = [] {
-                const char* e = getenv("COLIBRI_IDS_GRID");
-                const long  v = e ? strtol(e, nullptr, 10) : 0;
-                return v > 0 ? (uint32_t)v : 0xFFFFFFFFu;  // one block per bucket: fewer, persistent blocks (fewer windows open, hoping for whole lines out of L2) measured slower —
-                                                              // 32 / 64 / 128 / 256 / 1024 blocks: indexed run 15.1 / 13.5 / 12.8 / 12.5 / 12.4 ms: the kernel wants parallelism, not locality
-            }();
-            hipLaunchKernelGGL(bi2_ids_kernel, dim3(std::min(b.nbuckets, ids_grid)), dim3(kBi2BmThreads), 0, c->stream, npos, bs, c->b2.plist.p, c->b2.pcode.p, b.pl, c->state.p, ids_out,
-                               b.nbuckets);
+            // the ids' scatter in the step order of chain_emit_kernel (an XCD's blocks fill ~3 bucket windows at a time: whole lines leave L2), not one block per bucket
+            const uint32_t cap = chain_steps_cap(b.pl);
+            hipLaunchKernelGGL(chain_steps_kernel, dim3(kChXcds), dim3(kBi2Threads), 0, c->stream, (const Bi2State*)bs, b.pl, b.nbuckets, reinterpret_cast<uint2*>(c->b2.steps.p), cap,
+                               c->b2.steps.p + 2 * (size_t)kChXcds * cap, (const DevState*)c->state.p);
+            static const uint32_t ids_grid = getenv("COLIBRI_IDS_GRID") ? (uint32_t)atoi(getenv("COLIBRI_IDS_GRID")) : 1024u;  // (a multiple of 8)
+            hipLaunchKernelGGL(chain_ids_kernel, dim3(ids_grid), dim3(kChThreads), 0, c->stream, (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p,
+                               reinterpret_cast<const uint2*>(c->b2.steps.p), cap, (const uint32_t*)(c->b2.steps.p + 2 * (size_t)kChXcds * cap), (const Bi2State*)bs,
+                               (const DevState*)c->state.p, ids_out);
             hipLaunchKernelGGL(bi2_headids_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, c->state.p, c->b2.headid.p);
         }
         hipLaunchKernelGGL(bi2_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, bs, c->b2.plist.p, b.pl, c->state.p, c->b2.bitmap.p);

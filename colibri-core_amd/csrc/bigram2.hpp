@@ -84,6 +84,7 @@ struct __attribute__((aligned(16))) Bi2State {
     uint32_t res_base;  // first result index of this pass's survivors (an order counted in slices appends pass after pass)
     uint32_t cskip;      // key-sharded runs (kshard2.hpp): the w mix bits below the B bin's that complete the owner's final bin (the source cuts every (A, B) bin by them)
     uint32_t bshift_fix; // key-sharded runs: bshift + 1 as every rank agreed on it (0: bi2_offsets_kernel derives it from this pass's record count)
+    uint32_t ran;        // set by bi2_finish_kernel: this order was counted (the run had not ended before it) — what bi2_compact_kernel asks when it runs beside the path
     uint32_t hugebin;   // records from which a final bin goes to bi2_count_big_kernel; 0: kBi2HugeBin (written with kbits by the emit kernel of the order)
     uint32_t nextchunk;                 // owner passes of key-sharded runs: next free chunk of the position-list pool (bi2_count_kernel<.., BASED>)
     uint32_t nextbin[kBi2Shards * 16];  // work queues of the count kernel (one per shard, 64 bytes apart): next group of bins to hand out
@@ -1314,6 +1315,7 @@ __global__ __launch_bounds__(kBlock) void bi2_finish_kernel(DevState* __restrict
     if (threadIdx.x == 0) {
         const uint32_t tot = bs->kept_bins;
         bs->kept_head      = htot;
+        bs->ran            = 1;
         bs->res_base       = st->res_total + st->kept;  // (st->found / st->kept are zero at the start of an order: the passes of a sliced order add up)
         st->found += ftot + hftot;
         st->kept += tot + htot;
@@ -1326,8 +1328,10 @@ __global__ __launch_bounds__(kBlock) void bi2_finish_kernel(DevState* __restrict
 }
 // sparse per-bin survivors -> dense result list: one wave copies one bin's run; the last block appends the head survivors
 __global__ __launch_bounds__(kBlock) void bi2_compact_kernel(const uint32_t* __restrict__ sp_rep, const uint32_t* __restrict__ sp_cnt, const DevState* __restrict__ st,
-                                                              const Bi2State* __restrict__ bs, uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap) {
-    if (st->done) return;
+                                                              const Bi2State* __restrict__ bs, uint32_t* __restrict__ res_rep, uint32_t* __restrict__ res_cnt, uint32_t res_cap,
+                                                              bool beside = false /* on a second stream, behind the order's finish kernel: the run's state may already say "done"
+                                                                                     because THIS order ended it — the order's own flag decides */) {
+    if (beside ? !bs->ran : st->done != 0) return;
     const uint32_t res_base = bs->res_base, lane = threadIdx.x & (kWave - 1);
     if (blockIdx.x + 1 < gridDim.x) {
         const uint32_t nwaves = (gridDim.x - 1) * (kBlock / kWave);

@@ -172,6 +172,8 @@ def z1b_configs(capi, shards):
         prev_low = np.concatenate([[True], p[:-1] < 128])
         return int(((p == 0) & prev_low).sum())
     res = {}
+    fx = load_fixture("z1b_seeds44_51_plain")  # what the reference's own train() left for this corpus (8030 s on one core of the build container)
+    want = (fx["npatterns"], [o["kept"] for o in fx["orders"]]) if fx else None
     whole = np.concatenate(shards)
     with capi.Context(0) as c:
         c.upload(whole)
@@ -185,7 +187,8 @@ def z1b_configs(capi, shards):
     one = (int(st.npatterns), [int(st.kept[n]) for n in range(1, MAXLENGTH + 1)])
     res["z1b_single_device"] = {"workload": "configs[2]'s 1 B-token corpus (8 x 125 M tokens, seeds 44..51) in one context", "ms_per_step": round(best, 2),
                                 "M_patterns_counted_per_s": round(windows / best / 1e3, 1), "patterns_in_model": one[0], "kept_per_order": one[1],
-                                "passes_over_key_slices_at_order_2": passes}
+                                "passes_over_key_slices_at_order_2": passes,
+                                "self_check": ("ok" if one == want else "FAILED") if want else "no fixture"}
     nsent = [sentences_of(p) for p in shards]
     with capi.ShardedTrainer(8, devices=[0] * 8) as tr:
         for r, p in enumerate(shards):
@@ -196,11 +199,23 @@ def z1b_configs(capi, shards):
             best = tr.info.wall_ms if best is None else min(best, tr.info.wall_ms)
         info = tr.info
         eight = (int(st.npatterns), [int(st.kept[n]) for n in range(1, MAXLENGTH + 1)])
+        check8 = None
+        if fx:  # every rank exports its share of the model: the multiset digest of all (key, count) rows against the reference's
+            from concurrent.futures import ThreadPoolExecutor
+            from colibri_amd import digest
+            shares = [tr.export_arrays(r) for r in range(8)]
+            with ThreadPoolExecutor(8) as ex:
+                got = digest.combine(list(ex.map(lambda a: digest.model_digest(*a), shares)))
+            del shares
+            check8 = eight == want and all(got[k] == fx[k] for k in ("sum1", "xor1", "sum2", "xor2", "npatterns", "occurrences", "keybytes"))
     res["z1b_eight_ranks_on_one_device"] = {"workload": "the same shards, one rank each, all eight ranks on this device (what `--gpus 8` runs on eight devices, minus xGMI)",
                                             "ms_per_step": round(best, 2), "M_patterns_counted_per_s": round(windows / best / 1e3, 1), "patterns_in_model": eight[0],
                                             "kept_per_order": eight[1], "protocol": "candidate exchange" if info.protocol == 1 else "key-sharded counting",
                                             "alltoall_bytes_per_rank_and_step": int(info.alltoall_bytes), "of_which_to_self": int(info.alltoall_bytes_to_self),
-                                            "same_model_as_z1b_single_device": eight == one}
+                                            "same_model_as_z1b_single_device": eight == one,
+                                            "self_check": ("ok" if check8 else "FAILED") if check8 is not None else "no fixture",
+                                            "self_check_against": "the reference's model of the 1 B-token corpus: per-order kept, totals, multiset digest of the "
+                                                                  "(key, count) rows (tests/golden/fullsize/z1b_seeds44_51_plain.json)"}
     return res
 
 

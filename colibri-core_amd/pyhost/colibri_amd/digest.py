@@ -76,6 +76,23 @@ def model_digest(key_off, key_bytes, counts, refs=None):
     return out
 
 
+def combine(parts):
+    """the digest of a model given as disjoint shares (one per rank of a sharded trainer): sums add mod 2^64, xors xor, totals add"""
+    out = {"sum1": 0, "xor1": 0, "sum2": 0, "xor2": 0, "npatterns": 0, "occurrences": 0, "keybytes": 0, "patterns_by_length": {}}
+    for d in parts:
+        for k in ("sum1", "sum2"):
+            out[k] = (out[k] + int(d[k], 16)) & 0xFFFFFFFFFFFFFFFF
+        for k in ("xor1", "xor2"):
+            out[k] ^= int(d[k], 16)
+        for k in ("npatterns", "occurrences", "keybytes"):
+            out[k] += d[k]
+        for n, c in d["patterns_by_length"].items():
+            out["patterns_by_length"][n] = out["patterns_by_length"].get(n, 0) + c
+    for k in ("sum1", "xor1", "sum2", "xor2"):
+        out[k] = "%016x" % out[k]
+    return out
+
+
 def parse_model_file(path):
     """.colibri.patternmodel (reference include/patternmodel.h:670-760 writer; types 10 = unindexed, 20 = indexed) -> flat arrays
     (mtype, tokens, types, key_off u64[n+1], key_bytes u8[], counts u32[n], refs or None) in file order. Keys without the

@@ -230,3 +230,41 @@ def test_id_keeping_modes_are_the_references_models(name, kw):
         st = ctx.train(mintokens=2, maxlength=5, **kw)
         key_off, key_bytes, counts, refs = ctx.export_arrays()
     assert_is_the_references_model(fixture(name), st, key_off, key_bytes, counts, refs)
+
+
+@pytest.mark.skipif((os.cpu_count() or 1) < 8, reason="generating the 1 B-token corpus takes eight host cores a minute")
+def test_one_billion_tokens_is_the_references_model():
+    """BASELINE.json configs[2]: the eight 125 M-token shards (seeds 44..51) of an 8-GPU run. The reference's own PatternModel::train took 8030 s and 32 GB for
+    their concatenation (tests/golden/make_fullsize_golden.py z1b_seeds44_51_plain); the fixture holds what it printed per order and the multiset digest of the
+    model it wrote. Two product paths must give exactly that model: one context over the whole corpus (key slices), and the multi-GPU trainer with its eight ranks
+    on this one device (key-sharded counting; every pattern exported by exactly one rank — the digests of the shares combine)."""
+    import multiprocessing
+    from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
+    from colibri_amd import capi, digest, synth
+    fx = fixture("z1b_seeds44_51_plain")
+    with ProcessPoolExecutor(8, mp_context=multiprocessing.get_context("spawn")) as pool:  # (not fork: this process may hold a HIP context already)
+        jobs = [pool.submit(synth.zipf_corpus, fx["corpus"]["ntok"], fx["corpus"]["vocab"], seed, header=False) for seed in fx["corpus"]["seeds"]]
+        shards = [np.frombuffer(j.result(), dtype=np.uint8) for j in jobs]
+    with capi.Context(0) as ctx:
+        ctx.upload(np.concatenate(shards))
+        st = ctx.train(mintokens=2, maxlength=5)
+        key_off, key_bytes, counts, _ = ctx.export_arrays()
+    assert_is_the_references_model(fx, st, key_off, key_bytes, counts)
+    del key_off, key_bytes, counts
+
+    def sentences_of(p):
+        return int(((p == 0) & np.concatenate([[True], p[:-1] < 128])).sum())
+    nsent = [sentences_of(p) for p in shards]
+    with capi.ShardedTrainer(8, devices=[0] * 8) as tr:
+        for r, p in enumerate(shards):
+            tr.upload(r, p, 1 + sum(nsent[:r]))
+        st = tr.train(maxlength=5, mintokens=2)
+        assert tr.info.protocol == 0  # key-sharded counting (colibri_kshard_*)
+        shares = [tr.export_arrays(r) for r in range(8)]
+    with ThreadPoolExecutor(8) as ex:
+        got = digest.combine(list(ex.map(lambda a: digest.model_digest(*a), shares)))
+    for k in ("sum1", "xor1", "sum2", "xor2", "npatterns", "occurrences", "keybytes", "patterns_by_length"):
+        assert got[k] == fx[k], k
+    assert (st.totaltokens, st.totaltypes, st.npatterns) == (fx["tokens"], fx["types"], fx["npatterns"])
+    assert [st.kept[o["n"]] for o in fx["orders"]] == [o["kept"] for o in fx["orders"]]
+    assert [st.found[o["n"]] for o in fx["orders"]] == [o["found"] for o in fx["orders"]]

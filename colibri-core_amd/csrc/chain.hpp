@@ -333,7 +333,8 @@ __global__ __launch_bounds__(kChThreads, 6) void chain_emit_kernel(const uint32_
 // ~3 windows are open per L2 and a line is written once it is whole. pcode: dense survivor numbers (bi2_pospart_kernel, dense = true).
 __global__ __launch_bounds__(kChThreads) void chain_ids_kernel(const uint32_t* __restrict__ plist, const uint32_t* __restrict__ pcode, const uint2* __restrict__ table, uint32_t cap,
                                                                 const uint32_t* __restrict__ nsteps, const Bi2State* __restrict__ bs, const DevState* __restrict__ st,
-                                                                uint32_t* __restrict__ ids) {
+                                                                uint32_t* __restrict__ ids, const uint32_t* __restrict__ headid = nullptr /* order 2 of a chained run: the head
+                                                                windows are listed too (kBi2HeadCode | pair); their result indices, kInvalid where the pair did not survive */) {
     if (st->done) return;
     const uint32_t     x = blockIdx.x % kChXcds, nper = gridDim.x / kChXcds, ns = nsteps[x], res_base = bs->res_base;
     const uint2* const tab = table + (size_t)x * cap;
@@ -348,7 +349,37 @@ __global__ __launch_bounds__(kChThreads) void chain_ids_kernel(const uint32_t* _
         }
 #pragma unroll
         for (int q = 0; q < kChPer; ++q)
-            if (ps[q] != kInvalid) ids[ps[q]] = res_base + cd[q];
+            if (ps[q] != kInvalid) ids[ps[q]] = (headid != nullptr && (cd[q] & kBi2HeadCode)) ? headid[cd[q] & 0xFFFu] : res_base + cd[q];
+    }
+}
+
+// ---- the windows order n admits, as a list (the exhaustive skipgram passes of order n walk it: reference patternmodel.h:1163-1171, every admitted window) -------------------
+// bitmap: the surviving (n-1)-grams (chain_bitmap_kernel); window i is admitted when bits i and i + 1 are set. Tiles take their room with one atomic each: the list is
+// ascending inside a tile only, which is all its readers ask for (bi2_list3_kernel's list of order 3 is the same).
+__global__ __launch_bounds__(kBlock) void chain_alist_kernel(const uint32_t* __restrict__ bitmap, uint32_t npos, const DevState* __restrict__ st, uint32_t* __restrict__ list_out,
+                                                              uint32_t* __restrict__ nlist_out) {
+    if (st->done) return;
+    __shared__ uint32_t stageL[kBlock * 32], baseL, wsumL[kBlock / kWave];
+    const uint32_t      nwords = (npos + 31) / 32, ntiles = (nwords + kBlock - 1) / kBlock;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t w = tile * kBlock + threadIdx.x;
+        uint32_t       y = 0;
+        if (w < nwords) {
+            const uint32_t x = bitmap[w], nx = bitmap[w + 1];  // (the words beyond the corpus read zero)
+            y = x & ((x >> 1) | (nx << 31));
+        }
+        uint32_t       total;
+        const uint32_t excl = bi2_block_scan<kBlock>(__popc(y), &total, wsumL);
+        if (threadIdx.x == 0) baseL = total ? atomicAdd(nlist_out, total) : 0u;
+        uint32_t o = excl;
+        while (y) {
+            stageL[o++] = w * 32 + (uint32_t)__builtin_ctz(y);
+            y &= y - 1;
+        }
+        __syncthreads();
+        const uint32_t gb = baseL;
+        for (uint32_t j = threadIdx.x; j < total; j += kBlock) list_out[gb + j] = stageL[j];
+        __syncthreads();
     }
 }
 

@@ -969,6 +969,15 @@ int chain_compact_join(colibri_ctx* c) {
     c->b2.compact_pending = false;
     return COLIBRI_OK;
 }
+// result index per position from the (position, dense number) pairs an order left in the position lists (chain_ids_kernel), `ids` pre-filled with kInvalid
+void chain_ids(colibri_ctx* c, const Bigram2Plan& b, const Bi2State* bs, uint32_t* ids, const uint32_t* headid) {
+    const uint32_t cap = chain_steps_cap(b.pl);
+    hipLaunchKernelGGL(chain_steps_kernel, dim3(kChXcds), dim3(kBi2Threads), 0, c->stream, bs, b.pl, b.nbuckets, reinterpret_cast<uint2*>(c->b2.steps.p), cap,
+                       c->b2.steps.p + 2 * (size_t)kChXcds * cap, (const DevState*)c->state.p);
+    static const uint32_t ids_grid = getenv("COLIBRI_IDS_GRID") ? (uint32_t)atoi(getenv("COLIBRI_IDS_GRID")) : 1024u;  // (a multiple of 8)
+    hipLaunchKernelGGL(chain_ids_kernel, dim3(ids_grid), dim3(kChThreads), 0, c->stream, (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p,
+                       reinterpret_cast<const uint2*>(c->b2.steps.p), cap, (const uint32_t*)(c->b2.steps.p + 2 * (size_t)kChXcds * cap), bs, (const DevState*)c->state.p, ids, headid);
+}
 // chain (chain.hpp: order 3 runs on this engine too): instead of the bitmap -> list of order 3, the (position, code) pairs of the surviving windows sorted into position
 // buckets and the bitmap with the head survivors in it — what chain_emit_kernel walks
 int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t* ids_out = nullptr, bool chain = false) {
@@ -982,7 +991,7 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
             return rc;
         HIP_TRY(c, hipMemsetAsync(ids_out, 0xFF, sizeof(uint32_t) * (size_t)npos, c->stream));
     }
-    if (chain && (b.sbits != 0 || ids_out != nullptr)) return fail(c, COLIBRI_ERR_STATE, "bigram2_order: the chained orders need the single-pass plain form");
+    if (chain && b.sbits != 0) return fail(c, COLIBRI_ERR_STATE, "bigram2_order: the chained orders need the single-pass form");
     const bool        with_codes = ids_out != nullptr || (chain && want_list);
     Bi2State* const   bs   = c->b2.state.p;
     auto* const       recsA = reinterpret_cast<unsigned long long*>(c->recs[0].p);
@@ -1044,17 +1053,12 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
             hipLaunchKernelGGL(bi2_headids_kernel, dim3(1), dim3(kBlock), 0, c->stream, (const Bi2State*)bs, (const DevState*)c->state.p, c->b2.headid.p);
             hipLaunchKernelGGL(chain_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, (const Bi2State*)bs, (const uint32_t*)c->b2.plist.p, b.pl,
                                c->state.p, c->b2.bitmap.p, (const uint32_t*)c->b2.pcode.p, (const uint32_t*)c->b2.headid.p);
+            if (ids_out != nullptr) chain_ids(c, b, bs, ids_out, (const uint32_t*)c->b2.headid.p);  // (the id-keeping modes on the chained engine: the head windows are in the lists)
             return COLIBRI_OK;
         }
         if (ids_out != nullptr) {
             // the ids' scatter in the step order of chain_emit_kernel (an XCD's blocks fill ~3 bucket windows at a time: whole lines leave L2), not one block per bucket
-            const uint32_t cap = chain_steps_cap(b.pl);
-            hipLaunchKernelGGL(chain_steps_kernel, dim3(kChXcds), dim3(kBi2Threads), 0, c->stream, (const Bi2State*)bs, b.pl, b.nbuckets, reinterpret_cast<uint2*>(c->b2.steps.p), cap,
-                               c->b2.steps.p + 2 * (size_t)kChXcds * cap, (const DevState*)c->state.p);
-            static const uint32_t ids_grid = getenv("COLIBRI_IDS_GRID") ? (uint32_t)atoi(getenv("COLIBRI_IDS_GRID")) : 1024u;  // (a multiple of 8)
-            hipLaunchKernelGGL(chain_ids_kernel, dim3(ids_grid), dim3(kChThreads), 0, c->stream, (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p,
-                               reinterpret_cast<const uint2*>(c->b2.steps.p), cap, (const uint32_t*)(c->b2.steps.p + 2 * (size_t)kChXcds * cap), (const Bi2State*)bs,
-                               (const DevState*)c->state.p, ids_out);
+            chain_ids(c, b, bs, ids_out, nullptr);
             hipLaunchKernelGGL(bi2_headids_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, c->state.p, c->b2.headid.p);
         }
         hipLaunchKernelGGL(bi2_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, bs, c->b2.plist.p, b.pl, c->state.p, c->b2.bitmap.p);
@@ -1067,7 +1071,7 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
 // Order n >= 3 on the same engine (chain.hpp): the pairs order n - 1 left -> records -> level B -> one wave per final bin -> survivors; the pairs for order n + 1.
 // Everything is enqueued; nothing is read back. Bi2State ping-pongs: order n's in state (n even) / state2 (n odd), order n - 1's is read for the list lengths,
 // the per-bin dense offsets and the result base (order 2's own state is kept: colibri_order2_records reads it after the run).
-int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next) {
+int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next, uint32_t* ids_out = nullptr /* the id-keeping modes: the result index of the n-gram at every position */) {
     const uint32_t        npos = pl.npos;
     const Bigram2Plan     b    = bigram2_plan(c, npos);
     Bi2State* const       bs   = (n & 1) ? c->b2.state2.p : c->b2.state3.p;
@@ -1122,6 +1126,11 @@ int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next) {
                            (const uint32_t*)c->b2.wcode.p, c->b2.pcode.p, 0u, /*dense=*/true);
         hipLaunchKernelGGL(chain_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, (const Bi2State*)bs, (const uint32_t*)c->b2.plist.p, b.pl,
                            c->state.p, c->b2.bitmap.p);
+    }
+    if (ids_out != nullptr) {
+        Prof p(c, COLIBRI_K_RESOLVE);
+        HIP_TRY(c, hipMemsetAsync(ids_out, 0xFF, sizeof(uint32_t) * (size_t)npos, c->stream));
+        chain_ids(c, b, bs, ids_out, nullptr);
     }
     return COLIBRI_OK;
 }
@@ -1966,7 +1975,9 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     // every position (bi2_ids_kernel); one pass only, class-keyed, no word threshold (its cut of the order-1 ids comes after their references are emitted)
     const bool bi2_synced = radix_synced && !continued && !filtered && !backoff && wthr == 0 && o.table_mode == 0 && !(c->flags & kFlagNonCanonical) && uni_range_shift(c) != 0 &&
                             c->maxclass < (1u << 21) && o.maxlength >= 2 && bigram2_fits(c, npos) && bigram2_plan(c, npos).sbits == 0 && !c->b2.disabled;
-    if (bi2_synced && (rc = bigram2_alloc(c, npos))) return rc;
+    // ... and, since round 4, their orders >= 3 on the chained engine (chain.hpp) like the plain run's: an order's (position, dense number) pairs become its ids per position
+    const bool chain_synced = bi2_synced && o.maxlength >= 3 && !c->b2.chain_disabled && !getenv("COLIBRI_NO_CHAIN") && !getenv("COLIBRI_NO_CHAIN_IDS");
+    if (bi2_synced && (rc = bigram2_alloc(c, npos, chain_synced))) return rc;
     if (!binned && (rc = dev_alloc(c, c->table, pl.table_slots))) return rc;  // the plain radix run needs no table (a bin overflow re-runs with table_mode = 1)
     if ((rc = dev_alloc(c, c->res_rep, pl.res_cap))) return rc;
     if ((rc = dev_alloc(c, c->res_cnt, pl.res_cap))) return rc;
@@ -2191,7 +2202,15 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                         hipLaunchKernelGGL(uni_resid_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_resid.p, c->ids[1].p, c->state.p, npos);
                     }
                 } else if (n == 2) {
-                    if ((rc = bigram2_order(c, pl, /*want_list=*/true, c->ids[2].p))) return rc;
+                    if ((rc = bigram2_order(c, pl, /*want_list=*/true, c->ids[2].p, /*chain=*/chain_synced))) return rc;
+                } else if (chain_synced) {
+                    if (o.doskipgrams_exhaustive) {  // the windows this order admits, for its skipgram passes: from the bitmap of order n - 1, which this order's own replaces
+                        HIP_TRY(c, hipMemsetAsync(c->alist_n.p + (n & 1), 0, sizeof(uint32_t), c->stream));
+                        hipLaunchKernelGGL(chain_alist_kernel, dim3(1024), dim3(kBlock), 0, c->stream, (const uint32_t*)c->b2.bitmap.p, npos, (const DevState*)c->state.p, c->alist[n & 1].p,
+                                           c->alist_n.p + (n & 1));
+                    }
+                    if ((rc = chain_order(c, pl, n, /*want_next=*/true, c->ids[n].p))) return rc;
+                    if (o.doskipgrams_exhaustive && (rc = chain_compact_join(c))) return rc;  // (the skipgram passes count in the buffers the order's survivors are being copied from)
                 } else {
                     if ((rc = binned_count_stage(c, pl, KeyNgram{c->ids[n - 1].p, n}, n, true, pl.thr, false, true, false, /*dense_code=*/true))) return rc;
                     const BinnedIO io = binned_planes(c, pl, false);
@@ -2227,7 +2246,13 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             }
             std::vector<uint32_t> log(4 + 5 * nlogged, 0);
             if (nlogged) HIP_TRY(c, hipMemcpyAsync(log.data(), c->seglog.p, sizeof(uint32_t) * log.size(), hipMemcpyDeviceToHost, c->stream));
-            if ((rc = read_state(c))) return rc;
+            if ((rc = chain_compact_join(c)) || (rc = read_state(c))) return rc;
+            if (c->hstate.radix_overflow == 16) {  // an order >= 3 did not fit the chained engine (key bits, a region, a bin): the run again with round 3's orders >= 3
+                c->b2.chain_disabled = true;
+                const int rc2        = colibri_train_once(c, &o, stats_out);
+                c->b2.chain_disabled = false;
+                return rc2;
+            }
             if (c->hstate.radix_overflow == 4) {  // the second-generation order 2 could not hold this corpus: again, on the first-generation kernels
                 c->b2.disabled = true;
                 const int rc2  = colibri_train_once(c, &o, stats_out);

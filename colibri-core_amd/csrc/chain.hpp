@@ -55,7 +55,9 @@ __global__ __launch_bounds__(kBlock) void chain_reset_kernel(Bi2State* __restric
 // The 16 words beyond the corpus read zero (the last bucket's block clears them: chain_emit_kernel looks at bit i + 1).
 __global__ __launch_bounds__(kBi2BmThreads) void chain_bitmap_kernel(uint32_t npos, const Bi2State* __restrict__ bs, const uint32_t* __restrict__ plist, Bi2Lists pl, DevState* __restrict__ st,
                                                                       uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ pcode = nullptr /* order 2: the head windows' codes ... */,
-                                                                      const uint32_t* __restrict__ headid = nullptr /* ... and who of them survived */) {
+                                                                      const uint32_t* __restrict__ headid = nullptr /* ... and who of them survived */,
+                                                                      uint32_t* __restrict__ wpre = nullptr /* optional, per bitmap word: set bits of the bucket before the word ... */,
+                                                                      uint32_t* __restrict__ btot = nullptr /* ... and per bucket: its set bits (chain_pairs_kernel ranks with them) */) {
     if (st->done) return;
     extern __shared__ uint32_t bmL[];  // (1 << pshift) / 32 words
     __shared__ uint32_t        redL[kBi2BmThreads / kWave];
@@ -102,6 +104,18 @@ __global__ __launch_bounds__(kBi2BmThreads) void chain_bitmap_kernel(uint32_t np
         nset += (uint32_t)__popc(x);
     }
     if (start + size == npos && threadIdx.x < 16) bitmap[(start >> 5) + nwords + threadIdx.x] = 0u;
+    if (wpre != nullptr) {  // a lane takes a run of consecutive words: exclusive prefix of their popcounts inside the bucket
+        const uint32_t per = (nwords + kBi2BmThreads - 1) / kBi2BmThreads, w0 = threadIdx.x * per, w1 = min(nwords, w0 + per);
+        uint32_t       mine = 0;
+        for (uint32_t w = w0; w < w1; ++w) mine += (uint32_t)__popc(bmL[w]);
+        uint32_t total;
+        uint32_t run = bi2_block_scan<kBi2BmThreads>(mine, &total, redL);
+        for (uint32_t w = w0; w < w1; ++w) {
+            wpre[(start >> 5) + w] = run;
+            run += (uint32_t)__popc(bmL[w]);
+        }
+        if (threadIdx.x == 0) btot[b] = total;
+    }
     for (int off = 32; off > 0; off >>= 1) nset += __shfl_down(nset, off, kWave);
     if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nset;
     __syncthreads();
@@ -350,6 +364,69 @@ __global__ __launch_bounds__(kChThreads) void chain_ids_kernel(const uint32_t* _
 #pragma unroll
         for (int q = 0; q < kChPer; ++q)
             if (ps[q] != kInvalid) ids[ps[q]] = (headid != nullptr && (cd[q] & kBi2HeadCode)) ? headid[cd[q] & 0xFFFu] : res_base + cd[q];
+    }
+}
+
+// ---- the forward index's (pattern, reference) pairs of an order, straight from the order's position lists (indexed models without skipgram passes) ---------------------
+// emit_count / emit_write compact an order's ids per position into pairs in position order: two sweeps over an array of npos ids that chain_ids_kernel first has to
+// scatter (and a fill before it). The bitmap of the listed positions IS that compaction's index: the pair of position p lands at
+// (set bits before p) = btot's prefix up to p's bucket + wpre[word of p] + popcount of the word's bits below p — a perfect rank, no sweep, no ids. Same step order as
+// chain_ids_kernel (the bucket's words of bitmap / wpre / the position-block table stay in the XCD's L2). Output order and content equal emit_write_kernel's.
+__global__ __launch_bounds__(kChThreads) void chain_pairs_kernel(const uint32_t* __restrict__ plist, const uint32_t* __restrict__ pcode, const uint2* __restrict__ table, uint32_t cap,
+                                                                  const uint32_t* __restrict__ nsteps, const Bi2State* __restrict__ bs, const DevState* __restrict__ st,
+                                                                  const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ wpre, const uint32_t* __restrict__ btot,
+                                                                  uint32_t nbuckets, uint32_t pshift, const uint4* __restrict__ blocks, const unsigned long long* __restrict__ chain,
+                                                                  int which, uint64_t pcap, unsigned long long* __restrict__ pairs, uint32_t* __restrict__ pay, uint32_t sb, uint32_t tb,
+                                                                  const uint32_t* __restrict__ headid) {
+    if (st->done) return;
+    __shared__ uint32_t bbaseL[kBi2Buckets], wsumL[kChThreads / kWave];
+    static_assert(kBi2Buckets == 2 * kChThreads, "two buckets per lane");
+    {
+        const uint32_t b0 = 2 * threadIdx.x, t0 = b0 < nbuckets ? btot[b0] : 0u, t1 = b0 + 1 < nbuckets ? btot[b0 + 1] : 0u;
+        uint32_t       total;
+        const uint32_t excl = bi2_block_scan<kChThreads>(t0 + t1, &total, wsumL);
+        bbaseL[b0]     = excl;
+        bbaseL[b0 + 1] = excl + t0;
+    }
+    __syncthreads();
+    const uint32_t     x = blockIdx.x % kChXcds, nper = gridDim.x / kChXcds, ns = nsteps[x], res_base = bs->res_base;
+    const uint2* const tab   = table + (size_t)x * cap;
+    const uint64_t     obase = chain[which];
+    const uint32_t     tmask = tb >= 32 ? 0xFFFFFFFFu : (1u << tb) - 1u;
+    for (uint32_t k = blockIdx.x / kChXcds; k < ns; k += nper) {
+        const uint2 e = tab[k];
+        uint32_t    ps[kChPer], cd[kChPer], bw[kChPer], wp[kChPer];
+        uint4       r[kChPer];
+#pragma unroll
+        for (int q = 0; q < kChPer; ++q) {
+            const uint32_t j = q * kChThreads + threadIdx.x;
+            ps[q]            = j < e.y ? plist[(size_t)e.x + j] : kInvalid;
+            cd[q]            = j < e.y ? pcode[(size_t)e.x + j] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < kChPer; ++q) {  // all gathers of the lane in flight together
+            const uint32_t p = ps[q] != kInvalid ? ps[q] : 0u;
+            bw[q]            = bitmap[p >> 5];
+            wp[q]            = wpre[p >> 5];
+            r[q]             = blocks[p >> 6];
+        }
+#pragma unroll
+        for (int q = 0; q < kChPer; ++q) {
+            if (ps[q] == kInvalid) continue;
+            const uint32_t p = ps[q];
+            if (!((bw[q] >> (p & 31u)) & 1u)) continue;  // (a head window whose pair did not survive)
+            const uint32_t id  = (headid != nullptr && (cd[q] & kBi2HeadCode)) ? headid[cd[q] & 0xFFFu] : res_base + cd[q];
+            const uint64_t o   = obase + bbaseL[p >> pshift] + wp[q] + (uint32_t)__popc(bw[q] & ((1u << (p & 31u)) - 1u));
+            if (o >= pcap) continue;  // (pairs_advance_kernel flags the overflow)
+            const uint32_t bit = p & 63u;
+            const uint64_t below = ((((uint64_t)r[q].w << 32) | r[q].z)) & ((1ull << bit) - 1ull);
+            const uint32_t sent = r[q].x + (uint32_t)__popcll(below), tok = below ? bit - (64u - (uint32_t)__clzll(below)) : p - r[q].y;
+            if (pay != nullptr) {
+                reinterpret_cast<uint32_t*>(pairs)[o] = id;
+                pay[o]                                = (sent << tb) | (tok & tmask);
+            } else
+                pairs[o] = ((unsigned long long)id << (sb + tb)) | ((unsigned long long)sent << tb) | (tok & tmask);
+        }
     }
 }
 

@@ -90,6 +90,7 @@ struct colibri_ctx {
     uint64_t          npairs = 0;
     DevBuf<unsigned long long> pair_chain;  // the pair counters (kernels.hpp: emit_write_kernel)
     int               pair_pass = 0;
+    bool              pair_split = false;  // the pairs travel as two u32 arrays (id, sentence << tb | token) and the sort drops the id byte a pass has used (kernels.hpp: isort_*)
     uint32_t          pair_sb = 0, pair_tb = 0;  // packed pairs (id << (sb + tb) | sentence << tb | token): bits of the sentence / token fields; 0 / 0: id << 32 | position
     DevBuf<uint32_t>  ref_sentence;
     DevBuf<uint16_t>  ref_token;
@@ -145,6 +146,8 @@ struct colibri_ctx {
         DevBuf<uint8_t>  sid;                    // sliced orders: the key slice of the window at every position (first pass), read by the later passes
         DevBuf<uint32_t> wcode, pcode, headid;  // the modes that keep ids: (bin, rank) codes beside the positions, result index of every head bigram
         bool             disabled = false;  // set for the rerun after this path could not hold an order (region / bin / list overflow)
+        DevBuf<uint32_t> wpre, btot;        // ... chain_bitmap_kernel's rank tables (per bitmap word / per bucket) when the forward index's pairs come straight from the lists
+        bool             pairs_direct = false;  // an indexed model on the chained engine: the pairs of the orders >= 3 come from chain_pairs_kernel, not from sweeps over ids per position
         DevBuf<uint32_t> steps;             // ... chain_steps_kernel: the step tables of the eight XCDs, then their lengths
         DevBuf<Bi2State> state2, state3;    // chain.hpp: orders >= 3 on this engine ping-pong between these two (odd orders: state2); order 2's stays in `state`
         hipStream_t      aux = nullptr;     // ... the hot bins' workgroup kernel runs beside the wave kernel
@@ -978,6 +981,22 @@ void chain_ids(colibri_ctx* c, const Bigram2Plan& b, const Bi2State* bs, uint32_
     hipLaunchKernelGGL(chain_ids_kernel, dim3(ids_grid), dim3(kChThreads), 0, c->stream, (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p,
                        reinterpret_cast<const uint2*>(c->b2.steps.p), cap, (const uint32_t*)(c->b2.steps.p + 2 * (size_t)kChXcds * cap), bs, (const DevState*)c->state.p, ids, headid);
 }
+// the forward index's pairs of the order whose lists, bitmap and rank tables are in place (chain_pairs_kernel); the pair counters advance by the order's valid positions
+void chain_pairs(colibri_ctx* c, const Bigram2Plan& b, const Bi2State* bs, const uint32_t* headid) {
+    Prof           p(c, COLIBRI_K_INDEX);
+    const uint32_t cap  = chain_steps_cap(b.pl);
+    const uint64_t pcap = c->pairs[0].n;
+    hipLaunchKernelGGL(chain_steps_kernel, dim3(kChXcds), dim3(kBi2Threads), 0, c->stream, bs, b.pl, b.nbuckets, reinterpret_cast<uint2*>(c->b2.steps.p), cap,
+                       c->b2.steps.p + 2 * (size_t)kChXcds * cap, (const DevState*)c->state.p);
+    static const uint32_t grid = getenv("COLIBRI_IDS_GRID") ? (uint32_t)atoi(getenv("COLIBRI_IDS_GRID")) : 1024u;  // (a multiple of 8)
+    hipLaunchKernelGGL(chain_pairs_kernel, dim3(grid), dim3(kChThreads), 0, c->stream, (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p,
+                       reinterpret_cast<const uint2*>(c->b2.steps.p), cap, (const uint32_t*)(c->b2.steps.p + 2 * (size_t)kChXcds * cap), bs, (const DevState*)c->state.p,
+                       (const uint32_t*)c->b2.bitmap.p, (const uint32_t*)c->b2.wpre.p, (const uint32_t*)c->b2.btot.p, b.nbuckets, b.pshift,
+                       reinterpret_cast<const uint4*>(c->pos_blocks.p), (const unsigned long long*)c->pair_chain.p, c->pair_pass, pcap, c->pairs[0].p,
+                       c->pair_split ? reinterpret_cast<uint32_t*>(c->pairs[0].p) + pcap : (uint32_t*)nullptr, c->pair_sb, c->pair_tb, headid);
+    hipLaunchKernelGGL(pairs_advance_kernel, dim3(1), dim3(1), 0, c->stream, c->pair_chain.p, c->pair_pass, (const uint32_t*)&c->state.p->valid, pcap);
+    c->pair_pass ^= 1;
+}
 // chain (chain.hpp: order 3 runs on this engine too): instead of the bitmap -> list of order 3, the (position, code) pairs of the surviving windows sorted into position
 // buckets and the bitmap with the head survivors in it — what chain_emit_kernel walks
 int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t* ids_out = nullptr, bool chain = false) {
@@ -1125,8 +1144,10 @@ int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next, uint
         hipLaunchKernelGGL(bi2_pospart_kernel, dim3(512), dim3(kBi2Threads), 0, c->stream, c->b2.wlist.p, c->b2.wcnt.p, kBi2Waves + b.wextra, b.wcap, bs, c->state.p, c->b2.plist.p, b.pl,
                            (const uint32_t*)c->b2.wcode.p, c->b2.pcode.p, 0u, /*dense=*/true);
         hipLaunchKernelGGL(chain_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, (const Bi2State*)bs, (const uint32_t*)c->b2.plist.p, b.pl,
-                           c->state.p, c->b2.bitmap.p);
+                           c->state.p, c->b2.bitmap.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, c->b2.pairs_direct ? c->b2.wpre.p : (uint32_t*)nullptr,
+                           c->b2.pairs_direct ? c->b2.btot.p : (uint32_t*)nullptr);
     }
+    if (c->b2.pairs_direct) chain_pairs(c, b, bs, nullptr);
     if (ids_out != nullptr) {
         Prof p(c, COLIBRI_K_RESOLVE);
         HIP_TRY(c, hipMemsetAsync(ids_out, 0xFF, sizeof(uint32_t) * (size_t)npos, c->stream));
@@ -1584,6 +1605,7 @@ int pairs_begin(colibri_ctx* c, uint32_t npos) {
     HIP_TRY(c, hipMemsetAsync(c->pair_chain.p, 0, sizeof(unsigned long long) * kChainHead, c->stream));
     c->pair_pass = 0;
     c->npairs    = 0;
+    c->pair_split = false;  // (the caller's to set: colibri_train_once does when the pairs are packed; the sharded runs keep whole pairs — they cut the sorted references by id)
     if (c->pairs[0].n < 2ull * npos && (rc = dev_alloc(c, c->pairs[0], (size_t)(2ull * npos) + 1))) return rc;  // the usual model: ~1.6 pairs per position at n <= 5
     // position -> (sentence, token) table of the corpus (once per upload)
     if (!c->pos_blocks_valid) {
@@ -1636,10 +1658,12 @@ int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool en
             hipLaunchKernelGGL(pairs_advance_kernel, dim3(1), dim3(1), 0, c->stream, c->pair_chain.p, c->pair_pass, cnt + ntiles, cap);
             const bool packed = c->pair_sb != 0;
             hipLaunchKernelGGL(emit_write_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, pl.npos, cnt, c->pair_chain.p, c->pair_pass, cap, c->pairs[0].p,
-                               packed ? (const PosBlock*)c->pos_blocks.p : (const PosBlock*)nullptr, c->pair_sb, c->pair_tb);
+                               packed ? (const PosBlock*)c->pos_blocks.p : (const PosBlock*)nullptr, c->pair_sb, c->pair_tb,
+                               c->pair_split ? reinterpret_cast<uint32_t*>(c->pairs[0].p) + cap : (uint32_t*)nullptr);
         }
         c->pair_pass ^= 1;
         if (!ensure) return COLIBRI_OK;
+        if (c->pair_split) return fail(c, COLIBRI_ERR_STATE, "emit_pairs: split pairs do not grow in place");
         uint64_t n = 0;
         bool     over = false;
         int      rc;
@@ -1667,7 +1691,8 @@ int emit_pairs_list(colibri_ctx* c, uint32_t bound, const uint32_t* ids) {
     hipLaunchKernelGGL(pairs_advance_kernel, dim3(1), dim3(1), 0, c->stream, c->pair_chain.p, c->pair_pass, cnt + ntiles, cap);
     const bool packed = c->pair_sb != 0;
     hipLaunchKernelGGL(emit_write_list_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, (const uint32_t*)c->skl, (const uint32_t*)c->skl_n, (const uint32_t*)cnt, c->pair_chain.p,
-                       c->pair_pass, cap, c->pairs[0].p, packed ? (const PosBlock*)c->pos_blocks.p : (const PosBlock*)nullptr, c->pair_sb, c->pair_tb);
+                       c->pair_pass, cap, c->pairs[0].p, packed ? (const PosBlock*)c->pos_blocks.p : (const PosBlock*)nullptr, c->pair_sb, c->pair_tb,
+                       c->pair_split ? reinterpret_cast<uint32_t*>(c->pairs[0].p) + cap : (uint32_t*)nullptr);
     c->pair_pass ^= 1;
     return COLIBRI_OK;
 }
@@ -1742,6 +1767,50 @@ int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = fal
         const int  nbits  = bits_for(nresults);
         const bool packed = c->pair_sb != 0;
         const int  idshift = packed ? (int)(c->pair_sb + c->pair_tb) : 32;
+        if (c->pair_split) {
+            if (keep_sorted_ids) return fail(c, COLIBRI_ERR_STATE, "finalize_index: split pairs keep no ids");
+            const uint32_t nblocks = (uint32_t)((n + (uint64_t)kITile * kISuper - 1) / ((uint64_t)kITile * kISuper));  // (one table column per block of kISuper tiles)
+            const uint32_t nh = 256u * nblocks, nb = blocks_for(nh, kBlock * 4);
+            // buffers: pairs[0] = { id u32[cap], reference u32[cap] } as emitted; a pass writes { reference u32[n], id rest TOUT[n] } into the other buffer
+            const uint64_t  cap0 = c->pairs[0].n;
+            const void*     dig  = c->pairs[0].p;
+            const uint32_t* pay  = reinterpret_cast<const uint32_t*>(c->pairs[0].p) + cap0;
+            int             in_bytes = 4;
+            for (int shift = 0; shift < nbits; shift += 8) {
+                const bool last = shift + 8 >= nbits;
+                const int  rem  = nbits - shift - 8, out_bytes = rem <= 8 ? 1 : rem <= 16 ? 2 : 4;
+                uint32_t* const opay = reinterpret_cast<uint32_t*>(c->pairs[cur ^ 1].p);
+                void* const     odig = opay + n;
+                if (in_bytes == 4)
+                    hipLaunchKernelGGL(isort_hist_kernel<uint32_t>, dim3(nblocks), dim3(kS64Threads), 0, c->stream, (const uint32_t*)dig, n, nblocks, c->sort_hist.p);
+                else if (in_bytes == 2)
+                    hipLaunchKernelGGL(isort_hist_kernel<uint16_t>, dim3(nblocks), dim3(kS64Threads), 0, c->stream, (const uint16_t*)dig, n, nblocks, c->sort_hist.p);
+                else
+                    hipLaunchKernelGGL(isort_hist_kernel<uint8_t>, dim3(nblocks), dim3(kS64Threads), 0, c->stream, (const uint8_t*)dig, n, nblocks, c->sort_hist.p);
+                hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->sort_hist.p, nh, c->sort_bsum.p);
+                hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->sort_bsum.p, nb, c->sort_bsum.p + nb);
+                hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->sort_hist.p, nh, c->sort_bsum.p, c->sort_off.p);
+#define ISORT(TIN, TOUT, FIN)                                                                                                                                                   \
+    hipLaunchKernelGGL((isort_scatter_kernel<TIN, TOUT, FIN>), dim3(nblocks), dim3(kS64Threads), 0, c->stream, (const TIN*)dig, pay, n, nblocks, c->sort_off.p, opay, (TOUT*)odig, \
+                       c->first_sentence, c->ref_sentence.p, c->ref_token.p, c->pair_tb)
+                if (last) {
+                    if (in_bytes == 4) ISORT(uint32_t, uint8_t, true);
+                    else if (in_bytes == 2) ISORT(uint16_t, uint8_t, true);
+                    else ISORT(uint8_t, uint8_t, true);
+                } else if (in_bytes == 4) {
+                    if (out_bytes == 4) ISORT(uint32_t, uint32_t, false);
+                    else if (out_bytes == 2) ISORT(uint32_t, uint16_t, false);
+                    else ISORT(uint32_t, uint8_t, false);
+                } else {
+                    ISORT(uint16_t, uint8_t, false);  // (u16 in: 9..16 bits left, 1..8 after this pass)
+                }
+#undef ISORT
+                cur ^= 1;
+                dig      = odig;
+                pay      = opay;
+                in_bytes = out_bytes;
+            }
+        } else
         for (int shift = 0; shift < nbits; shift += 8) {
             const bool last = shift + 8 >= nbits;  // the last pass writes (sentence, token) [and the ids] instead of pairs
             hipLaunchKernelGGL(sort64_hist_kernel, dim3(nblocks), dim3(kS64Threads), 0, c->stream, c->pairs[cur].p, n, idshift + shift, nblocks, c->sort_hist.p);
@@ -1895,6 +1964,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     std::fill(std::begin(c->k_launches), std::end(c->k_launches), 0);
     c->segments.clear();
     c->npairs = 0;
+    c->b2.pairs_direct = false;
     if (c->b2.compact_pending) {  // (a run that ended early left a copy on the second stream)
         (void)hipStreamSynchronize(c->b2.aux);
         c->b2.compact_pending = false;
@@ -1953,6 +2023,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     pl.pos_grid = stream_grid(npos);
     const int maxlength = std::min<int>(o.maxlength, COLIBRI_MAX_ORDER - 1);
     if (o.indexed && (rc = pairs_begin(c, npos))) return rc;
+    c->pair_split = o.indexed && c->pair_sb != 0 && c->pair_sb + c->pair_tb <= 32 && !getenv("COLIBRI_WHOLE_PAIRS");
 
     if (c->ids.size() < 2) c->ids.resize(2);
     if ((rc = dev_alloc(c, c->ids[0], (size_t)npos + 1))) return rc;
@@ -2176,6 +2247,13 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
         }
         if (enq) {
             c->ids1_is_cls = !o.indexed;
+            // an indexed model on the chained engine: the pairs of the orders >= 3 come straight from the orders' position lists (chain_pairs_kernel: a rank per listed
+            // position instead of a fill and two sweeps over npos ids, which cost those sparse orders more than their counting). Order 2 keeps the sweeps: with 5 x 10^7 pairs
+            // the ranks' gathers cost what the sweeps do (measured: 2.2 ms with three gathers per pair, ~1 ms at best). Without skipgram passes nobody reads the ids of the
+            // orders >= 3 then, and they are not built
+            c->b2.pairs_direct = chain_synced && o.indexed && c->pair_sb != 0 && !getenv("COLIBRI_NO_DIRECT_PAIRS");
+            const bool ids_high = !c->b2.pairs_direct || o.doskipgrams || o.doskipgrams_exhaustive;
+            if (c->b2.pairs_direct && ((rc = dev_alloc(c, c->b2.wpre, (size_t)npos / 32 + 64)) || (rc = dev_alloc(c, c->b2.btot, kBi2Buckets)))) return rc;
             const uint32_t nclasses = c->maxclass + 1;
             if ((rc = dev_alloc(c, c->cnt1, (size_t)nclasses + 1)) || (rc = dev_alloc(c, c->rep1, (size_t)nclasses + 1)) || (rc = dev_alloc(c, c->uni_resid, (size_t)nclasses + 1)) ||
                 (rc = uni_alloc(c)))
@@ -2209,7 +2287,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                         hipLaunchKernelGGL(chain_alist_kernel, dim3(1024), dim3(kBlock), 0, c->stream, (const uint32_t*)c->b2.bitmap.p, npos, (const DevState*)c->state.p, c->alist[n & 1].p,
                                            c->alist_n.p + (n & 1));
                     }
-                    if ((rc = chain_order(c, pl, n, /*want_next=*/true, c->ids[n].p))) return rc;
+                    if ((rc = chain_order(c, pl, n, /*want_next=*/true, ids_high ? c->ids[n].p : (uint32_t*)nullptr))) return rc;
                     if (o.doskipgrams_exhaustive && (rc = chain_compact_join(c))) return rc;  // (the skipgram passes count in the buffers the order's survivors are being copied from)
                 } else {
                     if ((rc = binned_count_stage(c, pl, KeyNgram{c->ids[n - 1].p, n}, n, true, pl.thr, false, true, false, /*dense_code=*/true))) return rc;
@@ -2224,7 +2302,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                     if ((rc = binned_resolve_stage(c, pl, c->ids[n].p, n, true, true, nullptr, 0u, /*prefill_ids=*/true, /*decode=*/true, kDecodeBaseOnDevice))) return rc;
                 }
                 hipLaunchKernelGGL(idm_ngram_end_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, n);
-                if (o.indexed && (rc = emit_pairs(c, pl, c->ids[n].p, false))) return rc;
+                if (o.indexed && !(c->b2.pairs_direct && n >= 3) && (rc = emit_pairs(c, pl, c->ids[n].p, false))) return rc;
                 if (o.doskipgrams_exhaustive && n >= 3) {  // patternmodel.h:1163-1171 -> computeskipgrams :1370-1527, for every admissible window: the order's own active list
                     if (n > kMaxSkipgramTokens) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 31 tokens do not exist (a gap mask has 32 bits; set MAXLENGTH)");
                     c->skl   = c->alist[n & 1].p;

@@ -1336,7 +1336,8 @@ struct __attribute__((aligned(16))) PosBlock {
 __global__ __launch_bounds__(kPairThreads) void emit_write_kernel(const uint32_t* __restrict__ ids, uint32_t npos, const uint32_t* __restrict__ blockoff,
                                                                    const unsigned long long* __restrict__ chain, int which, uint64_t cap,
                                                                    unsigned long long* __restrict__ pairs, const PosBlock* __restrict__ blocks = nullptr, uint32_t sb = 0,
-                                                                   uint32_t tb = 0) {
+                                                                   uint32_t tb = 0, uint32_t* __restrict__ pay = nullptr /* split pairs (isort_*): the id goes to pairs as u32[],
+                                                                   sentence << tb | token here */) {
     if (blockoff[blockIdx.x + 1] == blockoff[blockIdx.x]) return;  // nothing in this tile (the passes of the high orders are sparse); [ntiles] holds the total
     const uint32_t base = blockIdx.x * kPairTile + threadIdx.x * kPairPer;
     uint32_t       v[kPairPer], c = 0;
@@ -1358,7 +1359,11 @@ __global__ __launch_bounds__(kPairThreads) void emit_write_kernel(const uint32_t
                     const uint32_t p = base + k, bit = p & 63u;
                     const uint64_t below = delim & ((1ull << bit) - 1ull);
                     const uint32_t sent = r.x + (uint32_t)__popcll(below), tok = below ? bit - (64u - (uint32_t)__clzll(below)) : p - r.y;
-                    pairs[o] = ((unsigned long long)v[k] << (sb + tb)) | ((unsigned long long)sent << tb) | (tok & tmask);
+                    if (pay != nullptr) {
+                        reinterpret_cast<uint32_t*>(pairs)[o] = v[k];
+                        pay[o]                                = (sent << tb) | (tok & tmask);
+                    } else
+                        pairs[o] = ((unsigned long long)v[k] << (sb + tb)) | ((unsigned long long)sent << tb) | (tok & tmask);
                 } else {
                     pairs[o] = ((unsigned long long)v[k] << 32) | (base + k);
                 }
@@ -1404,7 +1409,8 @@ __global__ __launch_bounds__(kPairThreads) void emit_count_list_kernel(const uin
 }
 __global__ __launch_bounds__(kPairThreads) void emit_write_list_kernel(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ list, const uint32_t* __restrict__ nlist,
                                                                         const uint32_t* __restrict__ blockoff, const unsigned long long* __restrict__ chain, int which, uint64_t cap,
-                                                                        unsigned long long* __restrict__ pairs, const PosBlock* __restrict__ blocks, uint32_t sb, uint32_t tb) {
+                                                                        unsigned long long* __restrict__ pairs, const PosBlock* __restrict__ blocks, uint32_t sb, uint32_t tb,
+                                                                        uint32_t* __restrict__ pay = nullptr) {
     if (blockoff[blockIdx.x + 1] == blockoff[blockIdx.x]) return;
     const uint32_t n = *nlist, base = blockIdx.x * kPairTile + threadIdx.x * kPairPer;
     uint32_t       v[kPairPer], p[kPairPer], c = 0;
@@ -1427,7 +1433,11 @@ __global__ __launch_bounds__(kPairThreads) void emit_write_list_kernel(const uin
                     const uint32_t bit   = p[k] & 63u;
                     const uint64_t below = delim & ((1ull << bit) - 1ull);
                     const uint32_t sent = r.x + (uint32_t)__popcll(below), tok = below ? bit - (64u - (uint32_t)__clzll(below)) : p[k] - r.y;
-                    pairs[o] = ((unsigned long long)v[k] << (sb + tb)) | ((unsigned long long)sent << tb) | (tok & tmask);
+                    if (pay != nullptr) {
+                        reinterpret_cast<uint32_t*>(pairs)[o] = v[k];
+                        pay[o]                                = (sent << tb) | (tok & tmask);
+                    } else
+                        pairs[o] = ((unsigned long long)v[k] << (sb + tb)) | ((unsigned long long)sent << tb) | (tok & tmask);
                 } else {
                     pairs[o] = ((unsigned long long)v[k] << 32) | p[k];
                 }
@@ -1626,6 +1636,137 @@ __global__ __launch_bounds__(kS64Threads, kS64Threads / 128) void sort64_scatter
                 if (sorted_id != nullptr) sorted_id[dst] = (uint32_t)(y[q] >> 32);
             }
         }
+    }
+}
+
+// ---- the same sort over SPLIT pairs: the id (what is left of it) and the reference travel in two arrays, and the id loses the byte a pass has sorted by ----
+// The index needs the references grouped by id, not the ids: after the pass over id bits 0-7 nobody reads those bits again. Pass k reads TIN per element (u32, then
+// u16 / u8 as the remaining id bits allow), sorts by its low byte and writes the rest (>> 8) as TOUT beside the 4-byte reference (sentence << tb | token); the histogram
+// of a pass reads only the id array. Per element and three passes: 4 + 8 + 6, 2 + 6 + 5, 1 + 5 + 6 = 43 bytes against 3 x 24 of the packed form (161 M references: the
+// sort's 3.6 ms of the indexed model's step).
+// Tiles: a block takes kISuper consecutive tiles of kITile elements (one table column per block instead of one per 4096 elements: the tables of the packed sort are
+// 10 M entries per pass, written and read as scattered words); inside a tile every WAVE owns 512 consecutive elements (kIRows rows of 64), so an element's rank among
+// its digit is (count in the waves before) + (count in this wave's earlier rows: a running per-wave counter in LDS) + (rank among the row's lanes: ballots) — 16 counters
+// per digit to scan instead of 64, and runs of 32 elements per digit and tile leaving for the output.
+constexpr int kIRows = 8, kITile = kS64Threads * kIRows, kISuper = 4, kIWaves = kS64Threads / kWave;
+__device__ __forceinline__ uint64_t isort_peers(uint32_t d, bool valid) {
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const uint64_t m = __ballot((d >> b) & 1u);
+        peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    return peers;
+}
+template <typename TIN>
+__global__ __launch_bounds__(kS64Threads) void isort_hist_kernel(const TIN* __restrict__ dig, uint64_t n, uint32_t nblocks, uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t h[256];
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t t0 = (uint64_t)blockIdx.x * kITile * kISuper, t1 = min(n, t0 + (uint64_t)kITile * kISuper);
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    for (uint64_t i0 = t0; i0 < t1; i0 += (uint64_t)kS64Threads * 4) {  // four rows of the block in flight
+        uint32_t x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint64_t i = i0 + (uint64_t)r * kS64Threads + threadIdx.x;
+            x[r]             = i < t1 ? (uint32_t)dig[i] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // one LDS atomic per distinct digit of a wave's row (the high byte of a dense id takes few values: 64-way conflicts otherwise)
+            const bool     valid = i0 + (uint64_t)r * kS64Threads + threadIdx.x < t1;
+            const uint64_t peers = isort_peers(x[r] & 255u, valid);
+            if (valid && (peers & ((1ull << lane) - 1ull)) == 0) atomicAdd(&h[x[r] & 255u], (uint32_t)__popcll(peers));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) ghist[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+template <typename TIN, typename TOUT, bool FINAL>
+__global__ __launch_bounds__(kS64Threads, kS64Threads / 128) void isort_scatter_kernel(const TIN* __restrict__ dig, const uint32_t* __restrict__ pay, uint64_t n, uint32_t nblocks,
+                                                                                        const unsigned long long* __restrict__ goff, uint32_t* __restrict__ out_pay,
+                                                                                        TOUT* __restrict__ out_dig, uint32_t first_sentence, uint32_t* __restrict__ ref_sentence,
+                                                                                        uint16_t* __restrict__ ref_token, uint32_t tb) {
+    __shared__ uint32_t           stgP[kITile], stgD[kITile];
+    __shared__ uint16_t           wcntL[kIWaves][256];  // elements of digit d wave w has seen in the tile so far; then: those of the waves before it
+    __shared__ uint32_t           histL[256], offL[256], wsumL[4];
+    __shared__ unsigned long long gbaseL[256];
+    if (threadIdx.x < 256) gbaseL[threadIdx.x] = goff[(uint64_t)threadIdx.x * nblocks + blockIdx.x];
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint32_t tmask = tb >= 32 ? 0xFFFFFFFFu : (1u << tb) - 1u;
+    const uint64_t s0 = (uint64_t)blockIdx.x * kITile * kISuper, s1 = min(n, s0 + (uint64_t)kITile * kISuper);
+    for (uint64_t t0 = s0; t0 < s1; t0 += kITile) {
+        for (uint32_t k = threadIdx.x; k < (uint32_t)(kIWaves * 256 / 2); k += kS64Threads) reinterpret_cast<uint32_t*>(&wcntL[0][0])[k] = 0;
+        uint32_t x[kIRows], y[kIRows], rank[kIRows];
+#pragma unroll
+        for (int r = 0; r < kIRows; ++r) {  // the wave's 512 consecutive elements, row by row
+            const uint64_t i = t0 + (uint64_t)wave * (kWave * kIRows) + (uint64_t)r * kWave + lane;
+            x[r]             = i < s1 ? (uint32_t)dig[i] : 0u;
+            y[r]             = i < s1 ? pay[i] : 0u;
+        }
+        __syncthreads();  // (the counters are clear; the staging area of the tile before has left)
+#pragma unroll
+        for (int r = 0; r < kIRows; ++r) {
+            const bool     valid = t0 + (uint64_t)wave * (kWave * kIRows) + (uint64_t)r * kWave + lane < s1;
+            const uint32_t d     = x[r] & 255u;
+            const uint64_t peers = isort_peers(d, valid);
+            const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+            const uint32_t seen  = wcntL[wave][d];
+            rank[r]              = seen + below;
+            __builtin_amdgcn_wave_barrier();  // (every lane of the row has read its counter before the row's leaders advance them)
+            if (valid && below == 0) wcntL[wave][d] = (uint16_t)(seen + (uint32_t)__popcll(peers));
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {  // digit t: the waves' counts -> exclusive prefixes over the waves
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < kIWaves; ++w) {
+                const uint32_t c        = wcntL[w][threadIdx.x];
+                wcntL[w][threadIdx.x] = (uint16_t)run;
+                run += c;
+            }
+            histL[threadIdx.x] = run;
+        }
+        __syncthreads();
+        {  // exclusive scan of the 256 digit totals (first four waves)
+            uint32_t v = 0, incl = 0;
+            if (threadIdx.x < 256) {
+                v    = histL[threadIdx.x];
+                incl = v;
+                for (int off = 1; off < kWave; off <<= 1) {
+                    const uint32_t t = __shfl_up(incl, off, kWave);
+                    if ((int)lane >= off) incl += t;
+                }
+                if (lane == kWave - 1) wsumL[wave] = incl;
+            }
+            __syncthreads();
+            if (threadIdx.x < 256) offL[threadIdx.x] = (wave > 0 ? wsumL[0] : 0u) + (wave > 1 ? wsumL[1] : 0u) + (wave > 2 ? wsumL[2] : 0u) + incl - v;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < kIRows; ++r) {
+            if (t0 + (uint64_t)wave * (kWave * kIRows) + (uint64_t)r * kWave + lane < s1) {
+                const uint32_t d = x[r] & 255u, o = offL[d] + wcntL[wave][d] + rank[r];
+                stgP[o] = y[r];
+                stgD[o] = x[r];
+            }
+        }
+        __syncthreads();
+        const uint32_t cnt = (uint32_t)min((uint64_t)kITile, s1 - t0);
+        for (uint32_t j = threadIdx.x; j < cnt; j += kS64Threads) {
+            const uint32_t xx = stgD[j], yy = stgP[j], d = xx & 255u;
+            const uint64_t dst = gbaseL[d] + (j - offL[d]);
+            if (FINAL) {
+                ref_sentence[dst] = first_sentence + (tb >= 32 ? 0u : yy >> tb);
+                ref_token[dst]    = (uint16_t)(yy & tmask);
+            } else {
+                out_pay[dst] = yy;
+                out_dig[dst] = (TOUT)(xx >> 8);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) gbaseL[threadIdx.x] += histL[threadIdx.x];  // the next tile of the block continues every digit's run
     }
 }
 

@@ -1419,7 +1419,7 @@ int skipgram_pass(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, con
     return COLIBRI_OK;
 }
 
-int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool ensure);
+int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool ensure, const uint32_t* surv = nullptr, const uint32_t* resid = nullptr);
 int emit_pairs_list(colibri_ctx* c, uint32_t bound, const uint32_t* ids);
 // MINSKIPTYPES of an indexed model: a skipgram needs that many distinct fillers = distinct surviving n-grams (results [src_first, src_first + src_count)) whose
 // representative window it masks. `ids`: the RESULT index of every window's skipgram (the k1 survivors of the count threshold sit at res_total..); the ones
@@ -1644,7 +1644,8 @@ int pairs_count(colibri_ctx* c, uint64_t* n, bool* overflowed) {
     *overflowed = h[2] != 0;
     return COLIBRI_OK;
 }
-int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool ensure) {
+// surv / resid (order 1 of an indexed model whose ids[1] nobody else reads): `ids` is the class per position; a class's survivor bit and result index stand in for the id
+int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool ensure, const uint32_t* surv, const uint32_t* resid) {
     const uint32_t ntiles = std::max<uint32_t>(1, blocks_for(pl.npos, kPairTile));
     int            rc0;
     if ((rc0 = dev_alloc(c, c->idx_cnt, (size_t)ntiles + 2))) return rc0;
@@ -1653,13 +1654,14 @@ int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool en
         {
             Prof p(c, COLIBRI_K_INDEX);
             const uint64_t cap = c->pairs[0].n;
-            hipLaunchKernelGGL(emit_count_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, pl.npos, cnt, (const DevState*)c->state.p);
+            hipLaunchKernelGGL(emit_count_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, pl.npos, cnt, (const DevState*)c->state.p, surv,
+                               surv != nullptr ? &c->state.p->valid : (uint32_t*)nullptr);
             hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, cnt, ntiles, cnt + ntiles);
             hipLaunchKernelGGL(pairs_advance_kernel, dim3(1), dim3(1), 0, c->stream, c->pair_chain.p, c->pair_pass, cnt + ntiles, cap);
             const bool packed = c->pair_sb != 0;
             hipLaunchKernelGGL(emit_write_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, pl.npos, cnt, c->pair_chain.p, c->pair_pass, cap, c->pairs[0].p,
                                packed ? (const PosBlock*)c->pos_blocks.p : (const PosBlock*)nullptr, c->pair_sb, c->pair_tb,
-                               c->pair_split ? reinterpret_cast<uint32_t*>(c->pairs[0].p) + cap : (uint32_t*)nullptr);
+                               c->pair_split ? reinterpret_cast<uint32_t*>(c->pairs[0].p) + cap : (uint32_t*)nullptr, resid);
         }
         c->pair_pass ^= 1;
         if (!ensure) return COLIBRI_OK;
@@ -2253,6 +2255,8 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             // orders >= 3 then, and they are not built
             c->b2.pairs_direct = chain_synced && o.indexed && c->pair_sb != 0 && !getenv("COLIBRI_NO_DIRECT_PAIRS");
             const bool ids_high = !c->b2.pairs_direct || o.doskipgrams || o.doskipgrams_exhaustive;
+            // ... and order 1's come from the class ids (survivor bit, result index per class): nobody reads ids[1] then (order 2 is keyed by classes)
+            const bool uni_pairs_direct = o.indexed && !o.doskipgrams && !o.doskipgrams_exhaustive && maxlength >= 2 && !getenv("COLIBRI_NO_DIRECT_PAIRS");
             if (c->b2.pairs_direct && ((rc = dev_alloc(c, c->b2.wpre, (size_t)npos / 32 + 64)) || (rc = dev_alloc(c, c->b2.btot, kBi2Buckets)))) return rc;
             const uint32_t nclasses = c->maxclass + 1;
             if ((rc = dev_alloc(c, c->cnt1, (size_t)nclasses + 1)) || (rc = dev_alloc(c, c->rep1, (size_t)nclasses + 1)) || (rc = dev_alloc(c, c->uni_resid, (size_t)nclasses + 1)) ||
@@ -2275,7 +2279,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                         hipLaunchKernelGGL(uni_finish_kernel, dim3(stream_grid(nclasses)), dim3(kBlock), 0, c->stream, c->cnt1.p, (const uint32_t*)nullptr, nclasses, pl.thr, c->state.p,
                                            c->res_rep.p, c->res_cnt.p, pl.res_cap, reinterpret_cast<uint16_t*>(c->uni_surv.p), /*count_valid=*/!o.indexed, c->uni_resid.p);
                     }
-                    if (!c->ids1_is_cls) {
+                    if (!c->ids1_is_cls && !uni_pairs_direct) {
                         Prof p(c, COLIBRI_K_RESOLVE);
                         hipLaunchKernelGGL(uni_resid_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_resid.p, c->ids[1].p, c->state.p, npos);
                     }
@@ -2301,8 +2305,11 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                     }
                     if ((rc = binned_resolve_stage(c, pl, c->ids[n].p, n, true, true, nullptr, 0u, /*prefill_ids=*/true, /*decode=*/true, kDecodeBaseOnDevice))) return rc;
                 }
+                if (n == 1 && uni_pairs_direct) {  // (before the order's figures are closed: the emission counts the positions with a surviving unigram, as uni_resid_ids_kernel does)
+                    if ((rc = emit_pairs(c, pl, c->cls.p, false, c->uni_surv.p, c->uni_resid.p))) return rc;
+                }
                 hipLaunchKernelGGL(idm_ngram_end_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, n);
-                if (o.indexed && !(c->b2.pairs_direct && n >= 3) && (rc = emit_pairs(c, pl, c->ids[n].p, false))) return rc;
+                if (o.indexed && !(c->b2.pairs_direct && n >= 3) && !(n == 1 && uni_pairs_direct) && (rc = emit_pairs(c, pl, c->ids[n].p, false))) return rc;
                 if (o.doskipgrams_exhaustive && n >= 3) {  // patternmodel.h:1163-1171 -> computeskipgrams :1370-1527, for every admissible window: the order's own active list
                     if (n > kMaxSkipgramTokens) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 31 tokens do not exist (a gap mask has 32 bits; set MAXLENGTH)");
                     c->skl   = c->alist[n & 1].p;

@@ -1305,18 +1305,28 @@ __device__ __forceinline__ uint32_t pair_block_scan(uint32_t c, uint32_t* total)
 // the model needs). (A one-sweep version with a decoupled look-back over the 12.8 K tiles was 2 x slower: too few tiles in flight to hide the chain.)
 constexpr int kChainHead = 3;
 __global__ __launch_bounds__(kPairThreads) void emit_count_kernel(const uint32_t* __restrict__ ids, uint32_t npos, uint32_t* __restrict__ blockcnt,
-                                                                   const DevState* __restrict__ st = nullptr /* optional: an enqueued run that is over (st->done) emits nothing */) {
+                                                                   const DevState* __restrict__ st = nullptr /* optional: an enqueued run that is over (st->done) emits nothing */,
+                                                                   const uint32_t* __restrict__ surv = nullptr /* order 1 of an indexed model without skipgram passes: `ids` is the
+                                                                   CLASS per position, a position counts when its class survived (one bit per class); no ids[1] is built ... */,
+                                                                   uint32_t* __restrict__ valid_out = nullptr /* ... and the positions with a surviving unigram are counted here */) {
     if (st != nullptr && st->done) {
         if (threadIdx.x == 0) blockcnt[blockIdx.x] = 0;
         return;
     }
     uint32_t v[kPairPer], c = 0;
     pair_load(ids, npos, blockIdx.x * kPairTile + threadIdx.x * kPairPer, v);
+    if (surv != nullptr) {
+#pragma unroll
+        for (int k = 0; k < kPairPer; ++k) v[k] = (v[k] != kInvalid && v[k] != 0u && ((surv[v[k] >> 5] >> (v[k] & 31u)) & 1u)) ? 0u : kInvalid;
+    }
 #pragma unroll
     for (int k = 0; k < kPairPer; ++k) c += v[k] != kInvalid;
     uint32_t total;
     pair_block_scan(c, &total);
-    if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
+    if (threadIdx.x == 0) {
+        blockcnt[blockIdx.x] = total;
+        if (valid_out != nullptr && total) atomicAdd(valid_out, total);
+    }
 }
 __global__ void pairs_advance_kernel(unsigned long long* __restrict__ chain, int which, const uint32_t* __restrict__ total, uint64_t cap) {
     const unsigned long long after = chain[which] + *total;
@@ -1337,11 +1347,16 @@ __global__ __launch_bounds__(kPairThreads) void emit_write_kernel(const uint32_t
                                                                    const unsigned long long* __restrict__ chain, int which, uint64_t cap,
                                                                    unsigned long long* __restrict__ pairs, const PosBlock* __restrict__ blocks = nullptr, uint32_t sb = 0,
                                                                    uint32_t tb = 0, uint32_t* __restrict__ pay = nullptr /* split pairs (isort_*): the id goes to pairs as u32[],
-                                                                   sentence << tb | token here */) {
+                                                                   sentence << tb | token here */,
+                                                                   const uint32_t* __restrict__ resid = nullptr /* `ids` is the class per position: the id is resid[class] */) {
     if (blockoff[blockIdx.x + 1] == blockoff[blockIdx.x]) return;  // nothing in this tile (the passes of the high orders are sparse); [ntiles] holds the total
     const uint32_t base = blockIdx.x * kPairTile + threadIdx.x * kPairPer;
     uint32_t       v[kPairPer], c = 0;
     pair_load(ids, npos, base, v);
+    if (resid != nullptr) {
+#pragma unroll
+        for (int k = 0; k < kPairPer; ++k) v[k] = (v[k] != kInvalid && v[k] != 0u) ? resid[v[k]] : kInvalid;
+    }
 #pragma unroll
     for (int k = 0; k < kPairPer; ++k) c += v[k] != kInvalid;
     uint4 r = make_uint4(0u, 0u, 0u, 0u);
@@ -1664,19 +1679,32 @@ __global__ __launch_bounds__(kS64Threads) void isort_hist_kernel(const TIN* __re
     if (threadIdx.x < 256) h[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t t0 = (uint64_t)blockIdx.x * kITile * kISuper, t1 = min(n, t0 + (uint64_t)kITile * kISuper);
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    for (uint64_t i0 = t0; i0 < t1; i0 += (uint64_t)kS64Threads * 4) {  // four rows of the block in flight
-        uint32_t x[4];
+    // (plain LDS atomics: matching the lanes of a row by digit with ballots first — one atomic per distinct digit — cost 240 cycles per row of 64 and made this pass
+    // instruction-bound at 0.29 ms whatever the element size; the conflicts of the skewed high byte cost less)
+    for (uint64_t i0 = t0; i0 < t1; i0 += (uint64_t)kS64Threads * 8) {  // eight rows of the block in flight
+        uint32_t x[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 8; ++r) {
             const uint64_t i = i0 + (uint64_t)r * kS64Threads + threadIdx.x;
-            x[r]             = i < t1 ? (uint32_t)dig[i] : 0u;
+            x[r]             = i < t1 ? (uint32_t)dig[i] : 0xFFFFFFFFu;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {  // one LDS atomic per distinct digit of a wave's row (the high byte of a dense id takes few values: 64-way conflicts otherwise)
-            const bool     valid = i0 + (uint64_t)r * kS64Threads + threadIdx.x < t1;
-            const uint64_t peers = isort_peers(x[r] & 255u, valid);
-            if (valid && (peers & ((1ull << lane) - 1ull)) == 0) atomicAdd(&h[x[r] & 255u], (uint32_t)__popcll(peers));
+        for (int r = 0; r < 8; ++r) {
+            // dense ids follow the classes' frequency ranks: the high byte is 0 for half of all references, and 34 lanes of a row adding to one counter serialise. Two
+            // rounds peel the digit of the first lane still waiting (one atomic for the whole group); what is left adds for itself
+            bool           todo = i0 + (uint64_t)r * kS64Threads + threadIdx.x < t1;
+            const uint32_t d    = x[r] & 255u;
+#pragma unroll
+            for (int round = 0; round < 2; ++round) {
+                const uint64_t waiting = __ballot(todo);
+                if (!waiting) break;
+                const uint32_t lead = (uint32_t)__builtin_ctzll(waiting);
+                const uint32_t dl   = (uint32_t)__shfl((int)d, (int)lead, kWave);
+                const uint64_t grp  = __ballot(todo && d == dl);
+                if ((threadIdx.x & (kWave - 1)) == lead) atomicAdd(&h[dl], (uint32_t)__popcll(grp));
+                todo = todo && d != dl;
+            }
+            if (todo) atomicAdd(&h[d], 1u);
         }
     }
     __syncthreads();

@@ -1449,6 +1449,32 @@ int filter_by_fillers(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids, uint32
     return COLIBRI_OK;
 }
 
+// ... enqueued (no look at the pass from the host): k1 and the pass's first result are read on the device, `bound` >= k1
+int filter_by_fillers_dev(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids, uint32_t bound, uint32_t minsrc, uint32_t src_first, uint32_t src_count, const uint32_t* list,
+                          const uint32_t* nlist) {
+    int rc;
+    (void)pl;
+    if ((rc = dev_alloc(c, c->nsrc, (size_t)bound + 1)) || (rc = dev_alloc(c, c->skip_off, (size_t)bound + 1)) || (rc = dev_alloc(c, c->skip_tmp, 2 * (size_t)bound + 2))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->nsrc.p, 0, sizeof(uint32_t) * bound, c->stream));
+    {
+        Prof p(c, COLIBRI_K_SKIPGRAM);
+        if (src_count)
+            hipLaunchKernelGGL(skip_sources_results_dev_kernel, dim3(stream_grid(src_count)), dim3(kBlock), 0, c->stream, c->res_rep.p, src_first, src_count, ids, (const DevState*)c->state.p,
+                               c->nsrc.p, bound);
+        hipLaunchKernelGGL(skip_keep_flags_dev_kernel, dim3(stream_grid(bound)), dim3(kBlock), 0, c->stream, c->nsrc.p, (const DevState*)c->state.p, minsrc, bound);
+    }
+    if ((rc = scan_u32(c, c->nsrc.p, bound, c->skip_off.p, nullptr))) return rc;
+    const unsigned long long* total = c->bsum.p + std::max<uint32_t>(1, blocks_for(bound, kBlock * 4));
+    {
+        Prof p(c, COLIBRI_K_SKIPGRAM);
+        hipLaunchKernelGGL(skip_filter_gather_dev_kernel, dim3(stream_grid(bound)), dim3(kBlock), 0, c->stream, c->nsrc.p, c->skip_off.p, c->state.p, c->res_rep.p, c->res_cnt.p, c->skip_tmp.p, bound);
+        hipLaunchKernelGGL(skip_filter_store_dev_kernel, dim3(stream_grid(bound)), dim3(kBlock), 0, c->stream, c->skip_tmp.p, bound, total, c->res_rep.p, c->res_cnt.p, (const DevState*)c->state.p);
+        hipLaunchKernelGGL(skip_remap_ids_dev_kernel, dim3(stream_grid(pl.npos / 4 + 1)), dim3(kBlock), 0, c->stream, list, nlist, ids, c->nsrc.p, c->skip_off.p, (const DevState*)c->state.p, bound);
+        hipLaunchKernelGGL(skip_set_kept_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, total);
+    }
+    return COLIBRI_OK;
+}
+
 // The same pass on the radix path (emit -> level B -> per-bin LDS count -> resolve, over c->sklist): no global atomics. A level that is not the last
 // interns every pair (threshold 1) and hands dense ids to the next one; the last level appends its survivors to the results and, when `ids_out` is
 // given (indexed models), leaves every window's RESULT index there. kRerunOnTable: a bin outgrew its LDS table (the caller re-runs on the global table).
@@ -1458,9 +1484,10 @@ constexpr int kRerunOnTable = 1000;
 // seglog (unindexed passes only: nothing of the pass is needed on the host before the order's other passes have run): no read-back — the pass is reset, logged and
 // added to the run's state on the device (skip_pass_begin / skip_pass_end); *found_out / *kept_out stay untouched, the caller reads the log after the order.
 int skipgram_pass_radix(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, const uint32_t* gate, const uint32_t* gate2, uint32_t thr, uint32_t res_total, uint32_t* found_out,
-                        uint32_t* kept_out, uint32_t** ids_out, uint32_t minsrc = 0, uint32_t src_first = 0, uint32_t src_count = 0, uint32_t* seglog = nullptr) {
+                        uint32_t* kept_out, uint32_t** ids_out, uint32_t minsrc = 0, uint32_t src_first = 0, uint32_t src_count = 0, uint32_t* seglog = nullptr,
+                        uint32_t kept_bound = 0 /* logged passes with a filler filter: what the host knows the pass cannot keep more than */) {
     const std::vector<std::pair<int, int>> parts = mask_parts(mask, n);
-    if (seglog != nullptr && (ids_out != nullptr || minsrc > 1)) return fail(c, COLIBRI_ERR_STATE, "skipgram_pass_radix: a logged pass keeps no ids");
+    if (seglog != nullptr && minsrc > 1 && (ids_out == nullptr || kept_bound == 0)) return fail(c, COLIBRI_ERR_STATE, "skipgram_pass_radix: a logged pass with a filler filter needs ids and a bound");
     const uint32_t* left = part_ids(c, parts[0].second);
     uint32_t        offl = (uint32_t)parts[0].first;
     int             rc;
@@ -1488,12 +1515,15 @@ int skipgram_pass_radix(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mas
         }
         // (no fill of `out`: every listed position is written, valid or not, and every reader — the next level's keys, the filler filter, the emission of the
         // references — walks the same list)
-        if (need_ids && (rc = binned_resolve_stage(c, pl, out, n, true, false, nullptr, 0u, /*prefill_ids=*/false, /*decode=*/true, last ? res_total : 0u, c->skl, c->skl_n))) return rc;
+        if (need_ids && (rc = binned_resolve_stage(c, pl, out, n, true, false, nullptr, 0u, /*prefill_ids=*/false, /*decode=*/true,
+                                                   last ? (seglog != nullptr ? kDecodeBaseOnDevice : res_total) : 0u, c->skl, c->skl_n)))
+            return rc;
         if (last && ids_out) *ids_out = out;
         left = out;
         offl = 0;
     }
     if (seglog != nullptr) {
+        if (minsrc > 1 && (rc = filter_by_fillers_dev(c, pl, *ids_out, kept_bound, minsrc, src_first, src_count, c->skl, c->skl_n))) return rc;
         hipLaunchKernelGGL(skip_pass_end_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, seglog, (uint32_t)n, mask);
         return COLIBRI_OK;
     }
@@ -2654,7 +2684,53 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             if ((rc = write_state(c))) return rc;
             if (valid_n[n] == 0 && !constrained && !continued && !filtered && !(backoff && n >= backoff + 1)) break;  // nothing can be admitted at n + 1 (a back-off order asks the order-b survivors instead)
         }
-        if (o.doskipgrams && !constrained) {  // IndexedPatternModel::trainskipgrams (patternmodel.h:2969-3010): from the SURVIVING n-grams, n = 3..
+        // ... enqueued, when the n-gram orders were (round 4): no look at a pass from the host — its counters, the filler filter's sizes and "None found" live on the device,
+        // one log per run (skip_pass_end_kernel) —; each pass used to cost two read-backs (0.9 ms of the indexed + skipgrams step in stream drains)
+        bool skips_logged = false;
+        if (o.doskipgrams && !constrained && radix_synced && enq && o.indexed && !getenv("COLIBRI_SYNCED_SKIPS")) {
+            size_t total = 0;
+            for (int n = 3; n <= std::min<int>(maxlength, s.maxn) && total <= kSegLogCap; ++n) total += n > 16 ? (size_t)kSegLogCap + 1 : gap_masks(n, o.maxskips).size();
+            skips_logged = total <= kSegLogCap && std::min<int>(maxlength, s.maxn) <= kMaxSkipgramTokens;
+        }
+        if (skips_logged && std::min<int>(maxlength, s.maxn) >= 3) {
+            if ((rc = dev_alloc(c, c->seglog, 4 + 5 * (size_t)kSegLogCap))) return rc;
+            HIP_TRY(c, hipMemsetAsync(c->seglog.p, 0, sizeof(uint32_t) * 4, c->stream));
+            c->hstate.found = c->hstate.kept = c->hstate.admitted = c->hstate.valid = 0;
+            c->hstate.radix_overflow = 0;
+            c->hstate.res_total      = res_total;
+            if ((rc = write_state(c))) return rc;
+            size_t nlogged = 0;
+            for (int n = 3; n <= std::min<int>(maxlength, s.maxn); ++n) {
+                if ((rc = build_skip_list(c, pl, c->ids[n].p))) return rc;
+                const std::vector<uint32_t> masks = gap_masks(n, o.maxskips);
+                const uint32_t minsrc = o.minskiptypes > 1 ? (uint32_t)o.minskiptypes : 0u;
+                const uint32_t bound  = valid_n[n] / std::max(1u, pl.thr) + 1;  // a kept skipgram has >= MINTOKENS of the list's windows
+                for (uint32_t mask : masks) {
+                    uint32_t  f = 0, k = 0;
+                    uint32_t* ids = nullptr;
+                    if ((rc = skipgram_pass_radix(c, pl, n, mask, c->ids[n].p, nullptr, pl.thr, 0u, &f, &k, &ids, minsrc, ngram_first[n], ngram_kept[n], c->seglog.p, bound))) return rc;
+                    if ((rc = emit_pairs_list(c, valid_n[n], ids))) return rc;  // (a pass that kept nothing left no valid id)
+                }
+                hipLaunchKernelGGL(skip_order_end_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, (const uint32_t*)c->seglog.p, (uint32_t)nlogged, (uint32_t)masks.size());
+                nlogged += masks.size();
+            }
+            std::vector<uint32_t> log(4 + 5 * nlogged, 0);
+            if (nlogged) HIP_TRY(c, hipMemcpyAsync(log.data(), c->seglog.p, sizeof(uint32_t) * log.size(), hipMemcpyDeviceToHost, c->stream));
+            if ((rc = read_state(c))) return rc;
+            if (c->hstate.radix_overflow) {
+                colibri_options again = o;
+                again.table_mode      = 1;
+                return colibri_train_once(c, &again, stats_out);
+            }
+            for (size_t e = 0; e < nlogged && e < log[0]; ++e) {
+                const uint32_t* x = log.data() + 4 + 5 * e;
+                s.found[x[2]] += x[4];
+                s.kept[x[2]] += x[1];
+                if (x[1]) c->segments.push_back({x[0], x[1], (int)x[2], x[3]});
+            }
+            res_total = c->hstate.res_total;
+        }
+        if (o.doskipgrams && !constrained && !skips_logged) {  // IndexedPatternModel::trainskipgrams (patternmodel.h:2969-3010): from the SURVIVING n-grams, n = 3..
             for (int n = 3; n <= std::min<int>(maxlength, s.maxn); ++n) {
                 if (n > kMaxSkipgramTokens) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 31 tokens do not exist (a gap mask has 32 bits; set MAXLENGTH)");
                 uint32_t found_n = 0;

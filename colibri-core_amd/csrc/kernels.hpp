@@ -556,9 +556,68 @@ __global__ __launch_bounds__(kBlock) void skip_remap_ids_kernel(const uint32_t* 
     }
 }
 
+constexpr uint32_t kSegLogCap = 4096, kSegLogCapConst = kSegLogCap;
+// The same filter with nothing of the pass known to the host (enqueued passes of an indexed model): the pass's kept skipgrams k1 = st->kept and its first result
+// st->res_total are read on the device; `bound` >= k1 sizes the arrays (flags beyond k1 are zero, so a scan over `bound` entries gives the same offsets and total).
+__global__ __launch_bounds__(kBlock) void skip_sources_results_dev_kernel(const uint32_t* __restrict__ res_rep, uint32_t first, uint32_t count, const uint32_t* __restrict__ skip_id,
+                                                                           const DevState* __restrict__ st, uint32_t* __restrict__ nsrc, uint32_t bound) {
+    if (st->done) return;
+    const uint32_t base = st->res_total;
+    for (uint32_t r = blockIdx.x * kBlock + threadIdx.x; r < count; r += gridDim.x * kBlock) {
+        const uint32_t s = skip_id[res_rep[first + r]];
+        if (s != kInvalid && s - base < bound) atomicAdd(&nsrc[s - base], 1u);
+    }
+}
+__global__ __launch_bounds__(kBlock) void skip_keep_flags_dev_kernel(uint32_t* __restrict__ nsrc, const DevState* __restrict__ st, uint32_t minsrc, uint32_t bound) {
+    if (st->done) return;
+    const uint32_t n = min(st->kept, bound);
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < bound; j += gridDim.x * kBlock) nsrc[j] = (j < n && nsrc[j] >= minsrc) ? 1u : 0u;
+}
+__global__ __launch_bounds__(kBlock) void skip_filter_gather_dev_kernel(const uint32_t* __restrict__ flag, const unsigned long long* __restrict__ off, DevState* __restrict__ st,
+                                                                         const uint32_t* __restrict__ res_rep, const uint32_t* __restrict__ res_cnt, uint32_t* __restrict__ tmp, uint32_t bound) {
+    if (st->done) return;
+    const uint32_t n = st->kept, base = st->res_total;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n > bound) st->overflow = 1;  // (the host's bound did not hold: never silently)
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < min(n, bound); j += gridDim.x * kBlock)
+        if (flag[j]) {
+            tmp[off[j]]         = res_rep[base + j];
+            tmp[bound + off[j]] = res_cnt[base + j];
+        }
+}
+// ... and the pass's kept count becomes the filtered one (the last block to finish would do; a launch of its own keeps the order obvious)
+__global__ __launch_bounds__(kBlock) void skip_filter_store_dev_kernel(const uint32_t* __restrict__ tmp, uint32_t bound, const unsigned long long* __restrict__ total, uint32_t* __restrict__ res_rep,
+                                                                        uint32_t* __restrict__ res_cnt, const DevState* __restrict__ st) {
+    if (st->done) return;
+    const uint32_t kept = (uint32_t)*total, base = st->res_total;
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < kept; j += gridDim.x * kBlock) {
+        res_rep[base + j] = tmp[j];
+        res_cnt[base + j] = tmp[bound + j];
+    }
+}
+__global__ __launch_bounds__(kBlock) void skip_remap_ids_dev_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ nlist, uint32_t* __restrict__ ids,
+                                                                     const uint32_t* __restrict__ flag, const unsigned long long* __restrict__ off, const DevState* __restrict__ st,
+                                                                     uint32_t bound) {
+    if (st->done) return;
+    const uint32_t n = *nlist, base = st->res_total;
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+        const uint32_t p = list[j], s = ids[p];
+        if (s != kInvalid) ids[p] = (s - base < bound && flag[s - base]) ? base + (uint32_t)off[s - base] : kInvalid;
+    }
+}
+__global__ void skip_set_kept_kernel(DevState* __restrict__ st, const unsigned long long* __restrict__ total) {
+    if (st->done) return;
+    st->kept = (uint32_t)*total;
+}
+// after the passes of one order of IndexedPatternModel::trainskipgrams: no skipgram found at this length ends the run (" None found", reference patternmodel.h:2992-2994)
+__global__ void skip_order_end_kernel(DevState* __restrict__ st, const uint32_t* __restrict__ log, uint32_t first_entry, uint32_t nentries) {
+    if (st->done) return;
+    uint32_t found = 0;
+    for (uint32_t e = first_entry; e < first_entry + nentries && e < kSegLogCapConst; ++e) found += log[4 + 5 * (size_t)e + 4];
+    if (!found) st->done = 1;
+}
+
 // Skipgram passes without a host round trip each (unindexed models): the pass's counters are reset and, at its end, logged and folded into the run's state on
 // the device; the host reads the log once per order. log[0] = entries so far; entry e = log[4 + 5 e ..]: first result, results, order, gap mask, distinct found.
-constexpr uint32_t kSegLogCap = 4096;
 __global__ void skip_pass_begin_kernel(DevState* __restrict__ st) {
     if (st->done) return;
     st->found = st->kept = st->admitted = st->valid = 0;

@@ -324,6 +324,12 @@ struct Prof {
     }
     ~Prof() {
         if (idx != (size_t)-1) (void)hipEventRecord(c->events[idx].b, c->stream);
+        static const bool dbg = getenv("COLIBRI_DEBUG_SYNC") != nullptr;  // (hunting a faulting kernel: every stage is waited for and named)
+        if (dbg) {
+            const hipError_t e = hipStreamSynchronize(c->stream);
+            fprintf(stderr, "colibri: stage %d done (%s)\n", cls, hipGetErrorString(e));
+            fflush(stderr);
+        }
     }
 };
 
@@ -874,15 +880,20 @@ int binned_resolve_stage(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids_out,
 constexpr uint32_t kBi2Sub = COLIBRI_BI2_SUB, kBi2SubWide = 8, kBi2EmitGrid = 512, kBi2Waves = 256 * 16;
 // records a pass of the radix path takes on (final bins of ~700-1500 records). COLIBRI_SLICE_POSITIONS (tests): a smaller number, so that small corpora
 // exercise the sliced passes of the path for corpora beyond ~128 M tokens per device
+// Round 4: ONE pass of the second-generation engine holds ~2 x 10^8 positions of the bench distribution (a final bin's LDS table takes ~2500 distinct keys; at 2.5 x 10^8
+// tokens bins overflow: Bi2State.overflow 2), and one full pass beats two half-full ones (200 M tokens: 9.3 against 11.4 ms; the id-keeping kinds, which have no sliced
+// form, 23.6 / 19.8 against 52 / 58 ms on the global table). A run whose bins do overflow in that range repeats with the old pass size (tl_small_passes), not on the
+// first-generation kernels.
+thread_local bool tl_small_passes = false;
 inline uint64_t slice_positions() {
-    static const uint64_t v = [] {
+    static const uint64_t env = [] {
         const char* e = getenv("COLIBRI_SLICE_POSITIONS");
-        const unsigned long long x = e ? strtoull(e, nullptr, 10) : 0ull;
-        return x ? (uint64_t)x : 110ull * 1000 * 1000;
+        return (uint64_t)(e ? strtoull(e, nullptr, 10) : 0ull);
     }();
-    return v;
+    return env ? env : tl_small_passes ? 110ull * 1000 * 1000 : 215ull * 1000 * 1000;
 }
-inline uint64_t big_corpus_tokens() { return getenv("COLIBRI_SLICE_POSITIONS") ? slice_positions() : 128ull * 1000 * 1000; }
+inline bool retry_with_small_passes(uint64_t npos) { return !tl_small_passes && !getenv("COLIBRI_SLICE_POSITIONS") && npos > 110ull * 1000 * 1000; }
+inline uint64_t big_corpus_tokens() { return getenv("COLIBRI_SLICE_POSITIONS") ? slice_positions() : tl_small_passes ? 128ull * 1000 * 1000 : 200ull * 1000 * 1000; }
 inline uint32_t slice_bits(uint64_t records) {  // passes needed for that many records, as a power of two (at most 64)
     if (records <= slice_positions()) return 0;
     // once an order is sliced, fuller passes are cheaper (the per-bin cost of the count kernels is mostly fixed): up to 14/11 of the single-pass size each
@@ -2061,7 +2072,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     if ((rc = dev_alloc(c, c->ids[0], (size_t)npos + 1))) return rc;
     if ((rc = dev_alloc(c, c->ids[1], (size_t)npos + 1))) return rc;
     // the per-pass modes count their n-gram passes of order >= 2 on the radix path too (result indices as ids, see bin_count's dense codes)
-    const bool radix_synced = synced && !constrained && o.table_mode == 0 && c->ntokens <= 128ull * 1000 * 1000;
+    const bool radix_synced = synced && !constrained && o.table_mode == 0 && c->ntokens <= big_corpus_tokens();
     c->profile_class = bi2 ? COLIBRI_K_COUNT2 : (binned || radix_synced) ? COLIBRI_K_BINCOUNT : COLIBRI_K_COUNT;
     // ... and so do the passes of a constrained run: a member window's key is its pattern number in the constraint set, counted in LDS like any other key
     const bool radix_constrained = constrained && o.table_mode == 0 && c->ntokens <= 128ull * 1000 * 1000;
@@ -2206,6 +2217,12 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                 uint32_t why = 0;
                 (void)hipMemcpy(&why, &c->b2.state.p->overflow, sizeof why, hipMemcpyDeviceToHost);
                 fprintf(stderr, "colibri: second-generation order 2 gave up (Bi2State.overflow = %u); repeating on the first-generation kernels\n", why);
+            }
+            if (retry_with_small_passes(npos)) {  // (a corpus beyond the old pass size: its bins get the old load back before anything slower is tried)
+                tl_small_passes = true;
+                const int rc2   = colibri_train_once(c, &o, stats_out);
+                tl_small_passes = false;
+                return rc2;
             }
             c->b2.disabled = true;
             const int rc2  = colibri_train_once(c, &o, stats_out);
@@ -2369,6 +2386,12 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                 return rc2;
             }
             if (c->hstate.radix_overflow == 4) {  // the second-generation order 2 could not hold this corpus: again, on the first-generation kernels
+                if (retry_with_small_passes(npos)) {  // (a corpus beyond the old pass size: its bins get the old load back before anything slower is tried)
+                    tl_small_passes = true;
+                    const int rc2   = colibri_train_once(c, &o, stats_out);
+                    tl_small_passes = false;
+                    return rc2;
+                }
                 c->b2.disabled = true;
                 const int rc2  = colibri_train_once(c, &o, stats_out);
                 c->b2.disabled = false;
@@ -2580,6 +2603,12 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             }
             if ((rc = read_state(c))) return rc;
             if (bi2_synced && c->hstate.radix_overflow == 4) {  // the second-generation order 2 could not hold this corpus: again, on the first-generation kernels
+                if (retry_with_small_passes(npos)) {  // (a corpus beyond the old pass size: its bins get the old load back before anything slower is tried)
+                    tl_small_passes = true;
+                    const int rc2   = colibri_train_once(c, &o, stats_out);
+                    tl_small_passes = false;
+                    return rc2;
+                }
                 c->b2.disabled = true;
                 const int rc2  = colibri_train_once(c, &o, stats_out);
                 c->b2.disabled = false;

@@ -885,17 +885,19 @@ constexpr uint32_t kBi2Sub = COLIBRI_BI2_SUB, kBi2SubWide = 8, kBi2EmitGrid = 51
 // form, 23.6 / 19.8 against 52 / 58 ms on the global table). A run whose bins do overflow in that range repeats with the old pass size (tl_small_passes), not on the
 // first-generation kernels.
 thread_local bool tl_small_passes = false;
-inline uint64_t slice_positions() {
+inline uint64_t slice_env() {
     static const uint64_t env = [] {
         const char* e = getenv("COLIBRI_SLICE_POSITIONS");
         return (uint64_t)(e ? strtoull(e, nullptr, 10) : 0ull);
     }();
-    return env ? env : tl_small_passes ? 110ull * 1000 * 1000 : 215ull * 1000 * 1000;
+    return env;
 }
-inline bool retry_with_small_passes(uint64_t npos) { return !tl_small_passes && !getenv("COLIBRI_SLICE_POSITIONS") && npos > 110ull * 1000 * 1000; }
-inline uint64_t big_corpus_tokens() { return getenv("COLIBRI_SLICE_POSITIONS") ? slice_positions() : tl_small_passes ? 128ull * 1000 * 1000 : 200ull * 1000 * 1000; }
+inline uint64_t slice_positions() { return slice_env() ? slice_env() : 110ull * 1000 * 1000; }  // records per pass ONCE an order is sliced (fuller passes overflow their bins)
+inline uint64_t single_pass_positions() { return slice_env() ? slice_env() : tl_small_passes ? 110ull * 1000 * 1000 : 215ull * 1000 * 1000; }  // ... and what one pass takes alone
+inline bool retry_with_small_passes(uint64_t npos) { return !tl_small_passes && !slice_env() && npos > 110ull * 1000 * 1000; }
+inline uint64_t big_corpus_tokens() { return slice_env() ? slice_env() : tl_small_passes ? 128ull * 1000 * 1000 : 200ull * 1000 * 1000; }
 inline uint32_t slice_bits(uint64_t records) {  // passes needed for that many records, as a power of two (at most 64)
-    if (records <= slice_positions()) return 0;
+    if (records <= single_pass_positions()) return 0;
     // once an order is sliced, fuller passes are cheaper (the per-bin cost of the count kernels is mostly fixed): up to 14/11 of the single-pass size each
     uint32_t s = 1;
     while (s < 6 && ((slice_positions() * 14 / 11) << s) < records) ++s;

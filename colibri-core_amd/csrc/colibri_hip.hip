@@ -892,7 +892,9 @@ inline uint64_t slice_env() {
     }();
     return env;
 }
-inline uint64_t slice_positions() { return slice_env() ? slice_env() : 110ull * 1000 * 1000; }  // records per pass ONCE an order is sliced (fuller passes overflow their bins)
+// records per pass ONCE an order is sliced: never more than round 3's size, whatever the environment says (fuller passes overflow their bins; a probe with four passes of
+// 2.6 x 10^8 records ended in a memory fault, not in an overflow flag)
+inline uint64_t slice_positions() { return slice_env() ? std::min<uint64_t>(slice_env(), 110ull * 1000 * 1000) : 110ull * 1000 * 1000; }
 inline uint64_t single_pass_positions() { return slice_env() ? slice_env() : tl_small_passes ? 110ull * 1000 * 1000 : 215ull * 1000 * 1000; }  // ... and what one pass takes alone
 inline bool retry_with_small_passes(uint64_t npos) { return !tl_small_passes && !slice_env() && npos > 110ull * 1000 * 1000; }
 inline uint64_t big_corpus_tokens() { return slice_env() ? slice_env() : tl_small_passes ? 128ull * 1000 * 1000 : 200ull * 1000 * 1000; }

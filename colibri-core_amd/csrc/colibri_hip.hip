@@ -2305,7 +2305,14 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             // the ranks' gathers cost what the sweeps do (measured: 2.2 ms with three gathers per pair, ~1 ms at best). Without skipgram passes nobody reads the ids of the
             // orders >= 3 then, and they are not built
             c->b2.pairs_direct = chain_synced && o.indexed && c->pair_sb != 0 && !getenv("COLIBRI_NO_DIRECT_PAIRS");
-            const bool ids_high = !c->b2.pairs_direct || o.doskipgrams || o.doskipgrams_exhaustive;
+            // Who reads ids[n] (n >= 2) of a chained run: trainskipgrams' lists and keys (every order), emit_pairs (order 2; the higher orders unless their pairs come
+            // from the lists), the exhaustive passes' part ids (parts have at most maxlength - 2 tokens; their gate is the list itself: chain_alist_kernel's windows ARE
+            // the admitted ones). Nobody else: an order's fill + scatter (0.06 + 0.03..0.6 ms) is skipped where nobody does
+            auto want_ids = [&](int n) {
+                if (!chain_synced || o.doskipgrams || getenv("COLIBRI_ALL_IDS")) return true;
+                if (o.indexed && (n == 2 || !c->b2.pairs_direct)) return true;
+                return o.doskipgrams_exhaustive && n <= maxlength - 2;
+            };
             // ... and order 1's come from the class ids (survivor bit, result index per class): nobody reads ids[1] then (order 2 is keyed by classes)
             const bool uni_pairs_direct = o.indexed && !o.doskipgrams && !o.doskipgrams_exhaustive && maxlength >= 2 && !getenv("COLIBRI_NO_DIRECT_PAIRS");
             if (c->b2.pairs_direct && ((rc = dev_alloc(c, c->b2.wpre, (size_t)npos / 32 + 64)) || (rc = dev_alloc(c, c->b2.btot, kBi2Buckets)))) return rc;
@@ -2335,14 +2342,14 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                         hipLaunchKernelGGL(uni_resid_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_resid.p, c->ids[1].p, c->state.p, npos);
                     }
                 } else if (n == 2) {
-                    if ((rc = bigram2_order(c, pl, /*want_list=*/true, c->ids[2].p, /*chain=*/chain_synced))) return rc;
+                    if ((rc = bigram2_order(c, pl, /*want_list=*/true, want_ids(2) ? c->ids[2].p : (uint32_t*)nullptr, /*chain=*/chain_synced))) return rc;
                 } else if (chain_synced) {
                     if (o.doskipgrams_exhaustive) {  // the windows this order admits, for its skipgram passes: from the bitmap of order n - 1, which this order's own replaces
                         HIP_TRY(c, hipMemsetAsync(c->alist_n.p + (n & 1), 0, sizeof(uint32_t), c->stream));
                         hipLaunchKernelGGL(chain_alist_kernel, dim3(1024), dim3(kBlock), 0, c->stream, (const uint32_t*)c->b2.bitmap.p, npos, (const DevState*)c->state.p, c->alist[n & 1].p,
                                            c->alist_n.p + (n & 1));
                     }
-                    if ((rc = chain_order(c, pl, n, /*want_next=*/true, ids_high ? c->ids[n].p : (uint32_t*)nullptr))) return rc;
+                    if ((rc = chain_order(c, pl, n, /*want_next=*/true, want_ids(n) ? c->ids[n].p : (uint32_t*)nullptr))) return rc;
                     if (o.doskipgrams_exhaustive && (rc = chain_compact_join(c))) return rc;  // (the skipgram passes count in the buffers the order's survivors are being copied from)
                 } else {
                     if ((rc = binned_count_stage(c, pl, KeyNgram{c->ids[n - 1].p, n}, n, true, pl.thr, false, true, false, /*dense_code=*/true))) return rc;
@@ -2368,7 +2375,8 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                     const std::vector<uint32_t> masks = gap_masks(n, o.maxskips);
                     for (uint32_t mask : masks) {
                         uint32_t f = 0, k = 0;
-                        if ((rc = skipgram_pass_radix(c, pl, n, mask, c->ids[n - 1].p, c->ids[n - 1].p, thr_skip, 0u, &f, &k, nullptr, 0, 0, 0, c->seglog.p))) return rc;
+                        const uint32_t* const gate = chain_synced && !getenv("COLIBRI_ALL_IDS") ? (const uint32_t*)nullptr : (const uint32_t*)c->ids[n - 1].p;
+                        if ((rc = skipgram_pass_radix(c, pl, n, mask, gate, gate, thr_skip, 0u, &f, &k, nullptr, 0, 0, 0, c->seglog.p))) return rc;
                     }
                     nlogged += masks.size();
                 }

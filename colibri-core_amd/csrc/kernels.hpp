@@ -344,14 +344,14 @@ struct KeyTrigramCls {
 // part (exhaustive: both (n-1)-grams survived = gate[i], gate2[i+1]; indexed: the n-gram itself survived = gate[i]).
 // Level >= 2 of a multi-part skipgram pairs the previous level's slot index (left, offset 0) with the next part's id.
 struct KeyPair {
-    const uint32_t* gate;
+    const uint32_t* gate;   // may be NULL
     const uint32_t* gate2;  // may be NULL
     const uint32_t* left;
     uint32_t        offl;
     const uint32_t* right;
     uint32_t        offr;
     __device__ __forceinline__ bool operator()(uint32_t i, uint32_t npos, uint64_t& key, uint64_t& hash) const {
-        if (gate[i] == kInvalid) return false;
+        if (gate != nullptr && gate[i] == kInvalid) return false;  // (NULL: the caller's list holds admitted windows only — chain_alist_kernel's)
         if (gate2 != nullptr && (i + 1 >= npos || gate2[i + 1] == kInvalid)) return false;
         const uint32_t l = left[i + offl], r = right[i + offr];
         if (l == kInvalid || r == kInvalid) return false;  // cannot happen for an admissible window; kept as a guard

@@ -710,7 +710,9 @@ constexpr uint32_t kBi2Chunk = 4096;
 // order (the sources partitioned completely); a record's "position" is its place: source << 28 | index in the source's stream (bs->posbits = 31). Nothing is listed:
 // every record's entry of code_at (= wlist) becomes (final bin << 10 | rank of its key among the bin's survivors), or kInvalid — in stream order, so the source finds its
 // windows again by counting. A record's "position" is its place in the receive buffer (31 bits; lower place = lower source rank first).
-template <int NSUB, bool BASED = false, int ROWS = kBi2WRows, bool KEY4 = false>
+// SLOTS: the LDS table of a final bin (1024: 900 distinct keys, what a pass of ~2 x 10^8 positions of the bench distribution fills; 2048 for the passes beyond — half
+// the waves per CU, which is why it is not the default). A bin's survivors are numbered in 10 bits either way (more than 1023 of them: overflow 2, like a full table).
+template <int NSUB, bool BASED = false, int ROWS = kBi2WRows, bool KEY4 = false, int SLOTS = kBi2Slots>
 __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const uint32_t* __restrict__ boff, Bi2State* __restrict__ bs,
                                                               DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
                                                               uint32_t* __restrict__ wlist, uint32_t* __restrict__ wcnt, uint32_t wcap, bool want_positions,
@@ -723,9 +725,10 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
     static_assert(!KEY4 || (BASED && NSUB == 8), "the owner's form");
     const uint32_t* const keys4   = reinterpret_cast<const uint32_t*>(recsB);
     uint32_t* const       code_at = wlist;
-    __shared__ __attribute__((aligned(16))) uint32_t keyT[kBi2Slots];
-    __shared__ __attribute__((aligned(16))) uint32_t cntT[kBi2Slots];
+    __shared__ __attribute__((aligned(16))) uint32_t keyT[SLOTS];
+    __shared__ __attribute__((aligned(16))) uint32_t cntT[SLOTS];
     __shared__ uint32_t                              repS[kBi2WReps];
+    constexpr uint32_t kMaxLoad = kBi2MaxLoad * (uint32_t)(SLOTS / kBi2Slots);
     const uint32_t bsh = bs->bshift, nB = (uint32_t)kBi2BBins >> bsh, nfinal = (uint32_t)kBins * nB;
     const uint32_t lane = threadIdx.x, wid = blockIdx.x, nwaves = gridDim.x;
     const uint32_t pb = bs->posbits;
@@ -794,7 +797,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
         }
         BI2_W(2);
         uint32_t nslots = 256;
-        while (nslots < (uint32_t)kBi2Slots && nslots < total + (total >> 1)) nslots <<= 1;
+        while (nslots < (uint32_t)SLOTS && nslots < total + (total >> 1)) nslots <<= 1;
         int lgb = 6;  // log2 of the number of buckets
         while ((4u << lgb) < nslots) ++lgb;
         const uint32_t bmask = (1u << lgb) - 1u;
@@ -884,7 +887,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
         uint32_t       distinct, ktotal;
         const uint32_t excl = bi2_wave_excl_scan(keep, &ktotal);
         bi2_wave_excl_scan(used, &distinct);
-        if (distinct > kBi2MaxLoad) {
+        if (distinct > kMaxLoad || ktotal > 1023u) {
             if (lane == 0) bs->overflow = 2;
             return;
         }
@@ -1061,7 +1064,7 @@ __device__ __forceinline__ void bi2_merge_leader(bool& act, uint32_t key, uint32
             act = false;
     }
 }
-template <int NSUB, bool BASED = false, bool KEY4 = false>
+template <int NSUB, bool BASED = false, bool KEY4 = false, int SLOTS = kBi2Slots>
 __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const uint32_t* __restrict__ boff, Bi2State* __restrict__ bs,
                                                                        DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
                                                                        uint32_t* __restrict__ wlist, uint32_t* __restrict__ wcnt, uint32_t wcap, bool want_positions,
@@ -1073,10 +1076,11 @@ __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const uns
     const uint32_t* const keys4   = reinterpret_cast<const uint32_t*>(recsB);
     uint32_t* const       code_at = wlist;
     constexpr int                                    kW = kBi2BigThreads / kWave;
-    __shared__ __attribute__((aligned(16))) uint32_t keyT[kBi2Slots];
-    __shared__ __attribute__((aligned(16))) uint32_t cntT[kBi2Slots];
+    __shared__ __attribute__((aligned(16))) uint32_t keyT[SLOTS];
+    __shared__ __attribute__((aligned(16))) uint32_t cntT[SLOTS];
     __shared__ uint32_t                              repS[kBi2WReps];
     __shared__ uint32_t                              rsL[NSUB], rnL[NSUB], sbL[NSUB], wsumL[kW], failL;
+    constexpr uint32_t kMaxLoad = kBi2MaxLoad * (uint32_t)(SLOTS / kBi2Slots);
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
     const uint32_t pb = bs->posbits;
     const unsigned long long pmask = (1ull << pb) - 1;
@@ -1086,9 +1090,9 @@ __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const uns
     const uint32_t csize = BASED ? kBi2Chunk : wcap, pfirst = BASED ? 0u : pool_first, pn = BASED ? wcap : pool_n;
     uint32_t       cursor = 0, chunk = kInvalid;
     bool           lost   = false;
-    constexpr int      lgb   = 8;  // kBi2Slots / 4 buckets: a big bin always takes the whole table
+    constexpr int      lgb   = SLOTS == 2048 ? 9 : 8;  // SLOTS / 4 buckets: a big bin always takes the whole table
     constexpr uint32_t bmask = (1u << lgb) - 1u;
-    static_assert(kBi2Slots == 1024 && kBi2BigBin + (kBi2BigBin >> 1) >= kBi2Slots, "big bins use all 256 buckets, as they do in bi2_count_kernel");
+    static_assert((SLOTS == 1024 || SLOTS == 2048) && kBi2Slots == 1024 && kBi2BigBin + (kBi2BigBin >> 1) >= kBi2Slots, "big bins use all buckets, as they do in bi2_count_kernel");
     for (uint32_t k = blockIdx.x; k < nbig; k += gridDim.x) {
         const uint32_t f = bs->huge[k], a = f / kBi2BBins, b = f % kBi2BBins;
         __syncthreads();  // the bin before is done with the tables
@@ -1099,7 +1103,7 @@ __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const uns
             sbL[tid]           = BASED ? slotbase[tid * kBins + a] : 0u;
         }
         if (tid == 0) failL = 0;
-        for (uint32_t s = tid; s < (uint32_t)kBi2Slots; s += kBi2BigThreads) {
+        for (uint32_t s = tid; s < (uint32_t)SLOTS; s += kBi2BigThreads) {
             keyT[s] = kBi2Empty;
             cntT[s] = 0u;
         }
@@ -1176,14 +1180,19 @@ __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const uns
             continue;
         }
         // survivors: thread t looks at the two slots from 2 t — ranks in slot order, as in bi2_count_kernel
-        constexpr uint32_t per = kBi2Slots / kBi2BigThreads;
-        static_assert(per == 2, "two slots per thread");
+        constexpr uint32_t per = SLOTS / kBi2BigThreads;  // (two or four slots per thread)
         const uint32_t s0 = tid * per;
-        const uint32_t k0 = keyT[s0], k1 = keyT[s0 + 1], c0 = cntT[s0], c1 = cntT[s0 + 1];
+        uint32_t       cS[per], nk = 0, nu = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < per; ++i) {
+            cS[i] = cntT[s0 + i];
+            nk += cS[i] >= threshold;
+            nu += keyT[s0 + i] != kBi2Empty;
+        }
         uint32_t       distinct, ktotal;
-        const uint32_t excl = bi2_block_scan<kBi2BigThreads>((c0 >= threshold) + (c1 >= threshold), &ktotal, wsumL);
-        bi2_block_scan<kBi2BigThreads>((k0 != kBi2Empty) + (k1 != kBi2Empty), &distinct, wsumL);
-        if (distinct > kBi2MaxLoad) {
+        const uint32_t excl = bi2_block_scan<kBi2BigThreads>(nk, &ktotal, wsumL);
+        bi2_block_scan<kBi2BigThreads>(nu, &distinct, wsumL);
+        if (distinct > kMaxLoad || ktotal > 1023u) {
             if (tid == 0) bs->overflow = 2;
             continue;
         }
@@ -1199,12 +1208,11 @@ __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const uns
         }
         const bool reps_lds = ktotal <= (uint32_t)kBi2WReps;
         {
-            uint32_t       r     = excl;
-            const uint32_t c2[2] = {c0, c1};
+            uint32_t r = excl;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (c2[i] >= threshold) {
-                    sp_cnt[spo + r] = c2[i];
+            for (uint32_t i = 0; i < per; ++i) {
+                if (cS[i] >= threshold) {
+                    sp_cnt[spo + r] = cS[i];
                     cntT[s0 + i]    = kBi2Kept | r;
                     if (reps_lds)
                         repS[r] = 0xFFFFFFFFu;

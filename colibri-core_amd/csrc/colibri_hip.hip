@@ -895,9 +895,13 @@ inline uint64_t slice_env() {
 // records per pass ONCE an order is sliced: never more than round 3's size, whatever the environment says (fuller passes overflow their bins; a probe with four passes of
 // 2.6 x 10^8 records ended in a memory fault, not in an overflow flag)
 inline uint64_t slice_positions() { return slice_env() ? std::min<uint64_t>(slice_env(), 110ull * 1000 * 1000) : 110ull * 1000 * 1000; }
-inline uint64_t single_pass_positions() { return slice_env() ? slice_env() : tl_small_passes ? 110ull * 1000 * 1000 : 215ull * 1000 * 1000; }  // ... and what one pass takes alone
+// ... and what one pass takes alone: 2.15 x 10^8 with the count kernels' 1024-slot bin tables (and the chained orders), twice that with their 2048-slot form (order 2
+// of corpora in between: bigram2_order's `wide`; their orders >= 3 run round 3's kernels — a chained record has no room for 29 position bits beside its key)
+constexpr uint64_t kNarrowPassPositions = 215ull * 1000 * 1000, kWidePassPositions = 430ull * 1000 * 1000;
+inline uint64_t single_pass_positions() { return slice_env() ? slice_env() : tl_small_passes ? 110ull * 1000 * 1000 : kWidePassPositions; }
 inline bool retry_with_small_passes(uint64_t npos) { return !tl_small_passes && !slice_env() && npos > 110ull * 1000 * 1000; }
-inline uint64_t big_corpus_tokens() { return slice_env() ? slice_env() : tl_small_passes ? 128ull * 1000 * 1000 : 200ull * 1000 * 1000; }
+inline uint64_t big_corpus_tokens() { return slice_env() ? slice_env() : tl_small_passes ? 128ull * 1000 * 1000 : 400ull * 1000 * 1000; }
+inline bool chain_fits(uint64_t npos) { return slice_env() ? true : npos <= kNarrowPassPositions; }  // (one pass on the 1024-slot tables, <= 28 position bits)
 inline uint32_t slice_bits(uint64_t records) {  // passes needed for that many records, as a power of two (at most 64)
     if (records <= single_pass_positions()) return 0;
     // once an order is sliced, fuller passes are cheaper (the per-bin cost of the count kernels is mostly fixed): up to 14/11 of the single-pass size each
@@ -1058,10 +1062,20 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
         {
             Prof p(c, COLIBRI_K_COUNT2);
             if (b.sbits) hipLaunchKernelGGL(bi2_chunk_cursor_kernel, dim3(1), dim3(1), 0, c->stream, bs, keep, true);
+            const bool wide = b.sbits == 0 && !slice_env() && npos > kNarrowPassPositions;  // one pass over more records than the 1024-slot tables hold: the 2048-slot form
+            if (wide)
+                hipLaunchKernelGGL((bi2_count_big_kernel<(int)kBi2Sub, false, false, 2048>), dim3(kBi2Waves * kWave / kBi2BigThreads), dim3(kBi2BigThreads), 0, c->stream, recsB, b.region,
+                                   c->b2.boff.p, bs, c->state.p, pl.thr, io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list, with_codes ? c->b2.wcode.p : (uint32_t*)nullptr,
+                                   (const uint32_t*)nullptr, kBi2Waves, b.wextra);
+            else
             hipLaunchKernelGGL((bi2_count_big_kernel<(int)kBi2Sub>), dim3(kBi2Waves * kWave / kBi2BigThreads), dim3(kBi2BigThreads), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p,
                                pl.thr, io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list, with_codes ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr,
                                kBi2Waves, b.wextra);
             if (b.sbits) hipLaunchKernelGGL(bi2_chunk_cursor_kernel, dim3(1), dim3(1), 0, c->stream, bs, keep, false);
+            if (wide)
+                hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub, false, kBi2WRows, false, 2048>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p,
+                                   pl.thr, io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list, with_codes ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr, true);
+            else
             hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr, io.sp_rep, io.sp_cnt,
                                c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_list, with_codes ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr, true);
         }
@@ -2043,7 +2057,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     const bool bi_cls = tri_cls && uni_shift != 0;  // ... and order 2 is keyed by classes + the order-1 survivor bitmap: no per-position order-1 ids at all
     const bool bi2 = binned && bi2_ok;
     // orders >= 3 on the same engine (chain.hpp): one pass per order (corpora a single pass holds), the plain run
-    const bool chain = bi2 && !big && bigram2_plan(c, npos).sbits == 0 && o.maxlength >= 3 && !c->b2.chain_disabled && !getenv("COLIBRI_NO_CHAIN");
+    const bool chain = bi2 && !big && bigram2_plan(c, npos).sbits == 0 && chain_fits(npos) && o.maxlength >= 3 && !c->b2.chain_disabled && !getenv("COLIBRI_NO_CHAIN");
     if (tri_cls && !bi2 && ((rc = dev_alloc(c, c->flags_at, (size_t)npos + 1)) || (rc = dev_alloc(c, c->flag2, (size_t)npos + 4)))) return rc;
     // ---- HBM layout (sized once; nothing is allocated inside the unsynced order loop) ----------------
     // table: an order admits at most `npos` windows -> 1.5x slots; results: every survivor has >= 2 occurrences
@@ -2094,7 +2108,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     const bool bi2_synced = radix_synced && !continued && !filtered && !backoff && wthr == 0 && o.table_mode == 0 && !(c->flags & kFlagNonCanonical) && uni_range_shift(c) != 0 &&
                             c->maxclass < (1u << 21) && o.maxlength >= 2 && bigram2_fits(c, npos) && bigram2_plan(c, npos).sbits == 0 && !c->b2.disabled;
     // ... and, since round 4, their orders >= 3 on the chained engine (chain.hpp) like the plain run's: an order's (position, dense number) pairs become its ids per position
-    const bool chain_synced = bi2_synced && o.maxlength >= 3 && !c->b2.chain_disabled && !getenv("COLIBRI_NO_CHAIN") && !getenv("COLIBRI_NO_CHAIN_IDS");
+    const bool chain_synced = bi2_synced && chain_fits(npos) && o.maxlength >= 3 && !c->b2.chain_disabled && !getenv("COLIBRI_NO_CHAIN") && !getenv("COLIBRI_NO_CHAIN_IDS");
     if (bi2_synced && (rc = bigram2_alloc(c, npos, chain_synced))) return rc;
     if (!binned && (rc = dev_alloc(c, c->table, pl.table_slots))) return rc;  // the plain radix run needs no table (a bin overflow re-runs with table_mode = 1)
     if ((rc = dev_alloc(c, c->res_rep, pl.res_cap))) return rc;

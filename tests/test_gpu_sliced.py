@@ -50,20 +50,41 @@ def test_sliced_radix_path_agrees_with_the_table_at_300m_tokens():
 
 @pytest.mark.parametrize("kw", [dict(indexed=1), dict(doskipgrams_exhaustive=1), dict(indexed=1, doskipgrams=1, minskiptypes=2)], ids=["indexed", "exhaustive_skipgrams", "indexed_skipgrams_T2"])
 def test_id_keeping_kinds_beyond_128m_tokens_stay_on_the_radix_path(kw):
-    """Rounds 1-3: an indexed or skipgram model of more than 128 M tokens per device fell to the global table (2.6 x the per-token cost). One pass of the second-generation
-    engine holds ~2 x 10^8 positions: at 200 M tokens the id-keeping kinds run it (last_mode 2) and must give the table path's model, reference lists included.
+    """Rounds 1-3: an indexed or skipgram model of more than 128 M tokens per device fell to the global table (2.6 x the per-token cost). Since round 4 one pass of the
+    second-generation engine holds 2 x 10^8 positions, and 4 x 10^8 with the count kernels' 2048-slot bin tables: at 300 M tokens the id-keeping kinds run it
+    (last_mode 2, one pass) and must give the table path's model, reference lists included.
     The reference has one code path at any size (include/patternmodel.h:880-1345, :2789-2800, :2969-3010)."""
     from colibri_amd import capi, digest, synth
+    payload = np.concatenate([np.frombuffer(synth.zipf_corpus(100_000_000, 1_000_000, 300 + k, header=False), dtype=np.uint8) for k in range(3)])
+    got = {}
+    with capi.Context(0) as ctx:
+        ctx.upload(payload)
+        del payload
+        for mode in (0, 1):
+            st = ctx.train(mintokens=2, maxlength=5, table_mode=mode, **kw)
+            assert ctx.last_mode(with_passes=True) == ((2, 1) if mode == 0 else (1, 1))
+            key_off, key_bytes, counts, refs = ctx.export_arrays()
+            got[mode] = ((st.totaltokens, st.npatterns, st.nrefs, [st.found[n] for n in range(1, 6)], [st.kept[n] for n in range(1, 6)]),
+                         digest.model_digest(key_off, key_bytes, counts, refs))
+            del key_off, key_bytes, counts, refs
+    assert got[0][0][0] == 300_000_000
+    assert got[0] == got[1]
+
+
+def test_plain_run_of_200m_tokens_is_one_chained_pass():
+    """... and the plain run: up to 2 x 10^8 positions one pass of every order on the chained engine (round 3: two key slices from 110 M positions on), the same model as
+    the table path's."""
+    from colibri_amd import capi, synth
+    from test_gpu_fullsize import row_hashes, summary
     payload = np.concatenate([np.frombuffer(synth.zipf_corpus(100_000_000, 1_000_000, 300 + k, header=False), dtype=np.uint8) for k in range(2)])
     got = {}
     with capi.Context(0) as ctx:
         ctx.upload(payload)
         for mode in (0, 1):
-            st = ctx.train(mintokens=2, maxlength=5, table_mode=mode, **kw)
-            assert ctx.last_mode() == (2 if mode == 0 else 1)
-            key_off, key_bytes, counts, refs = ctx.export_arrays()
-            got[mode] = ((st.totaltokens, st.npatterns, st.nrefs, [st.found[n] for n in range(1, 6)], [st.kept[n] for n in range(1, 6)]),
-                         digest.model_digest(key_off, key_bytes, counts, refs))
-            del key_off, key_bytes, counts, refs
-    assert got[0][0][0] == 200_000_000
-    assert got[0] == got[1]
+            st = ctx.train(mintokens=2, maxlength=5, table_mode=mode)
+            assert ctx.last_mode(with_passes=True) == ((2, 1) if mode == 0 else (1, 1))
+            key_off, key_bytes, counts, _ = ctx.export_arrays()
+            got[mode] = (summary(st), row_hashes(key_off, key_bytes, counts))
+    assert got[0][0] == got[1][0] and got[0][0][0] == 200_000_000
+    for x, y in zip(got[0][1], got[1][1]):
+        assert np.array_equal(np.sort(x), np.sort(y))

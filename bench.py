@@ -172,6 +172,20 @@ def z1b_configs(capi, shards):
         prev_low = np.concatenate([[True], p[:-1] < 128])
         return int(((p == 0) & prev_low).sum())
     res = {}
+    # three of the shards in one context: 375 M tokens, beyond what rounds 1-3 counted in one pass (110 M positions) and kept on the radix path for the id-keeping
+    # kinds (128 M tokens); since round 4 one pass of the second-generation engine with 2048-slot bin tables (untimed extras, best of two)
+    with capi.Context(0) as c:
+        c.upload(np.concatenate(shards[:3]))
+        entry = {"workload": "three of configs[2]'s shards (375 M tokens) in one context", "kinds": {}}
+        for name, kw in (("plain", {}), ("indexed", dict(indexed=1)), ("exhaustive_skipgrams", dict(doskipgrams_exhaustive=1))):
+            best, st = None, None
+            for _ in range(2):
+                st = c.train(maxlength=MAXLENGTH, mintokens=MINTOKENS, **kw)
+                best = st.train_ms if best is None else min(best, st.train_ms)
+            mode, passes = c.last_mode(with_passes=True)
+            entry["kinds"][name] = {"ms_per_step": round(best, 2), "patterns_in_model": int(st.npatterns), "references": int(st.nrefs),
+                                    "path": "radix" if mode == 2 else "global table", "passes_at_order_2": passes}
+        res["z375m_single_device"] = entry
     fx = load_fixture("z1b_seeds44_51_plain")  # what the reference's own train() left for this corpus (8030 s on one core of the build container)
     want = (fx["npatterns"], [o["kept"] for o in fx["orders"]]) if fx else None
     whole = np.concatenate(shards)

@@ -2234,7 +2234,8 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             if (getenv("COLIBRI_DEBUG_OVERFLOW")) {  // (which part of it gave up: 1 a record region, 2 a final bin's table, 3 a position list; 0: the position buckets or a split)
                 uint32_t why = 0;
                 (void)hipMemcpy(&why, &c->b2.state.p->overflow, sizeof why, hipMemcpyDeviceToHost);
-                fprintf(stderr, "colibri: second-generation order 2 gave up (Bi2State.overflow = %u); repeating on the first-generation kernels\n", why);
+                fprintf(stderr, "colibri: second-generation order 2 gave up (Bi2State.overflow = %u); repeating %s\n", why,
+                        retry_with_small_passes(npos) ? "with round 3's pass size" : "on the first-generation kernels");
             }
             if (retry_with_small_passes(npos)) {  // (a corpus beyond the old pass size: its bins get the old load back before anything slower is tried)
                 tl_small_passes = true;

@@ -90,10 +90,11 @@ def test_plain_run_of_200m_tokens_is_one_chained_pass():
         assert np.array_equal(np.sort(x), np.sort(y))
 
 
-def test_a_pass_whose_bins_overflow_repeats_with_smaller_passes():
+@pytest.mark.parametrize("kw,path", [({}, (2, 2)), (dict(indexed=1), (1, 1))], ids=["plain", "indexed"])
+def test_a_pass_whose_bins_overflow_repeats_with_smaller_passes(kw, path):
     """The single-pass limit (2.15 x 10^8 positions) is what the bench distribution fills the count kernels' bin tables with; a corpus with more distinct keys per window
     overflows them earlier: 140 M uniformly drawn tokens over 10^6 types put ~1000 distinct bigrams into every final bin (the tables hold 900). The run must notice
-    (Bi2State.overflow 2), repeat with round 3's pass size — two key slices — and give the table path's model."""
+    (Bi2State.overflow 2), repeat with round 3's pass size — two key slices; an indexed model, which has no sliced form, on the global table — and give the table path's model."""
     from colibri_amd import capi, synth
     from test_gpu_fullsize import row_hashes, summary
     T = 140_000_000
@@ -104,10 +105,10 @@ def test_a_pass_whose_bins_overflow_repeats_with_smaller_passes():
     with capi.Context(0) as ctx:
         ctx.upload(payload)
         for mode in (0, 1):
-            st = ctx.train(mintokens=2, maxlength=5, table_mode=mode)
-            assert ctx.last_mode(with_passes=True) == ((2, 2) if mode == 0 else (1, 1))
+            st = ctx.train(mintokens=2, maxlength=5, table_mode=mode, **kw)
+            assert ctx.last_mode(with_passes=True) == (path if mode == 0 else (1, 1))
             key_off, key_bytes, counts, _ = ctx.export_arrays()
-            got[mode] = (summary(st), row_hashes(key_off, key_bytes, counts))
+            got[mode] = (summary(st) + (st.nrefs,), row_hashes(key_off, key_bytes, counts))
     assert got[0][0] == got[1][0] and got[0][0][0] == T
     for x, y in zip(got[0][1], got[1][1]):
         assert np.array_equal(np.sort(x), np.sort(y))

@@ -341,6 +341,93 @@ __global__ __launch_bounds__(kChThreads, 6) void chain_emit_kernel(const uint32_
     if (threadIdx.x == 0 && Q.nadm) atomicAdd(&st->admitted, Q.nadm);
 }
 
+// ---- a skipgram pass of TWO parts on the same engine (exhaustive skipgrams of a chained run: reference patternmodel.h:1163-1171 -> computeskipgrams :1370-1527) -----------
+// The masked form of an admitted window is named by its two parts' ids (a class id for a one-token part, the result index of the part's n-gram otherwise): a key of
+// lbits + rbits bits, mixed and cut into 8-byte records exactly like an order's (number, class) keys — so the pass runs level B, the wave-per-bin count and the
+// compaction of the n-gram orders instead of round 1's 12-byte records (bin_emit / bin_hist2 / bin_scatter / bin_count). list: the admitted windows of the order
+// (chain_alist_kernel); a key that does not fit (two result indices of 24 bits beside 27 position bits) raises Bi2State::overflow like an order's: the run repeats on
+// round 3's passes.
+// HEAD (both parts one token): the frames of two frequent words ("the _ of") are as hot as the bigrams of order 2 — without its dense head the pass spends 0.84 ms in
+// the workgroup kernel for hot bins — and are counted like them: pairs of classes below kBi2Head in an LDS histogram per block (count, lowest position), rows reduced
+// by bi2_head_reduce_kernel, survivors appended by bi2_finish / bi2_compact. head_rows: [gridDim.x][2][kBi2HeadN] (gridDim.x <= kBi2EmitGrid).
+template <bool HEAD>
+__global__ __launch_bounds__(kChThreads, 6) void skip_emit_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ left, uint32_t offl,
+                                                                   const uint32_t* __restrict__ right, uint32_t offr, uint32_t l_is_cls, uint32_t r_is_cls, uint32_t clsbits, uint32_t pb,
+                                                                   unsigned long long* __restrict__ recsA, uint32_t region, uint32_t nsub, Bi2State* __restrict__ bs, DevState* __restrict__ st,
+                                                                   uint32_t* __restrict__ head_rows = nullptr) {
+    if (st->done) return;
+    __shared__ uint32_t headL[HEAD ? kBi2HeadN : 1], hposL[HEAD ? kBi2HeadN : 1];
+    if (HEAD) {
+        for (int k = threadIdx.x; k < kBi2HeadN; k += kChThreads) {
+            headL[k] = 0;
+            hposL[k] = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+    }
+    auto flush_head = [&]() {
+        if (HEAD) {
+            __syncthreads();
+            uint32_t* const row = head_rows + (size_t)blockIdx.x * (2 * kBi2HeadN);
+            for (int k = threadIdx.x; k < kBi2HeadN; k += kChThreads) {
+                row[k]             = headL[k];
+                row[kBi2HeadN + k] = hposL[k];
+            }
+        }
+    };
+    uint32_t idb = 1;
+    while (idb < 32 && (1ull << idb) < (uint64_t)st->res_total + 1) ++idb;
+    const uint32_t lbits = l_is_cls ? clsbits : idb, rbits = r_is_cls ? clsbits : idb;
+    ChainKey       ck;
+    if (lbits + rbits > 48u) {
+        if (threadIdx.x == 0) bs->overflow = 1;
+        flush_head();
+        return;
+    }
+    if (!chain_key_bits(bs, rbits, pb, bs, ck, 0, max(lbits + rbits, 17u))) {
+        flush_head();
+        return;
+    }
+    CHAIN_QUEUE_LDS(Q);
+    const uint32_t sub = blockIdx.x % nsub, n = *nlist;
+    for (uint32_t t0 = blockIdx.x * (uint32_t)kChStep; t0 < n; t0 += gridDim.x * (uint32_t)kChStep) {
+        uint32_t p[kChPer], l[kChPer], r[kChPer], cnt = 0;
+        bool     ok[kChPer];
+#pragma unroll
+        for (int q = 0; q < kChPer; ++q) {
+            const uint32_t j = t0 + q * kChThreads + threadIdx.x;
+            ok[q]            = j < n;
+            p[q]             = ok[q] ? list[j] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < kChPer; ++q) {
+            l[q] = ok[q] ? left[p[q] + offl] : 0u;
+            r[q] = ok[q] ? right[p[q] + offr] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < kChPer; ++q) {
+            ok[q] = ok[q] && l[q] != kInvalid && r[q] != kInvalid;  // (cannot fail for an admitted window; kept as a guard)
+            if (HEAD && ok[q] && l[q] < (uint32_t)kBi2Head && r[q] < (uint32_t)kBi2Head) {
+                const uint32_t h = l[q] * kBi2Head + r[q];
+                atomicAdd(&headL[h], 1u);
+                atomicMin(&hposL[h], p[q]);
+                ok[q] = false;
+            }
+            cnt += ok[q] ? 1u : 0u;
+        }
+        uint32_t total;
+        uint32_t at = Q.qn + bi2_block_scan<kChThreads>(cnt, &total, Q.wsumL);
+#pragma unroll
+        for (int q = 0; q < kChPer; ++q)
+            if (ok[q]) ck.put(Q, at++, l[q], r[q], p[q]);
+        Q.qn += total;
+        Q.nadm += total;
+        if (Q.qn >= (uint32_t)kChStep) Q.flush(recsA, region, sub, bs);
+    }
+    if (Q.qn) Q.flush(recsA, region, sub, bs);
+    flush_head();
+    if (threadIdx.x == 0 && Q.nadm) atomicAdd(&st->admitted, Q.nadm);
+}
+
 // ---- result indices per position (the modes that keep every order's ids), with the step order of chain_emit_kernel ------------------------------------------------------
 // bi2_ids_kernel scatters a bucket's 4-byte ids into its 512 KB window with one block per bucket: all ~800 windows are open at once, a line leaves L2 before its other
 // ids arrive, and 1.33 GB are written to store 0.42 GB (rounds 2-3). Here an XCD's blocks walk the XCD's buckets together, piece by piece (chain_steps_kernel's tables):

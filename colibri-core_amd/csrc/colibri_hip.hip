@@ -1185,6 +1185,43 @@ int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next, uint
     return COLIBRI_OK;
 }
 
+// One two-part skipgram pass of order n on the same engine (skip_emit_kernel), enqueued: reset -> records -> level B -> count -> survivors -> the run's log
+// (skip_pass_begin / _end_kernel). Bi2State: the one chain_order(n + 1) will reset anyway (order n - 1's; order 2's own state stays). No lists, no ids: the passes of
+// an unindexed model leave patterns and counts only.
+int skip_pass_chain(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, const uint32_t* left, uint32_t offl, bool l_is_cls, const uint32_t* right, uint32_t offr, bool r_is_cls,
+                    uint32_t thr, uint32_t* seglog) {
+    const Bigram2Plan b    = bigram2_plan(c, pl.npos);
+    Bi2State* const   bs   = (n & 1) ? c->b2.state3.p : c->b2.state2.p;
+    auto* const       recsA = reinterpret_cast<unsigned long long*>(c->recs[0].p);
+    auto* const       recsB = reinterpret_cast<unsigned long long*>(c->recs[1].p);
+    const BinnedIO    io    = binned_planes(c, pl, false);
+    Prof              p(c, COLIBRI_K_SKIPGRAM);
+    hipLaunchKernelGGL(skip_pass_begin_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p);
+    hipLaunchKernelGGL(chain_reset_kernel, dim3(256), dim3(kBlock), 0, c->stream, bs, c->b2.wcnt.p, 0u);
+    if (l_is_cls && r_is_cls) {  // both parts one token: the dense head of order 2 (frames of two frequent words)
+        hipLaunchKernelGGL(skip_emit_kernel<true>, dim3(kBi2EmitGrid), dim3(kChThreads), 0, c->stream, (const uint32_t*)c->skl, (const uint32_t*)c->skl_n, left, offl, right, offr, 1u, 1u,
+                           b.clsbits, b.posbits, recsA, b.region, kBi2Sub, bs, c->state.p, c->b2.head_rows.p);
+        hipLaunchKernelGGL(bi2_head_reduce_kernel, dim3(kBi2HeadN / kBlock, kBi2HeadSplit), dim3(kBlock), 0, c->stream, c->b2.head_rows.p, kBi2EmitGrid, bs, c->state.p);
+    } else {
+        static const uint32_t grid = getenv("COLIBRI_CH_GRID") ? (uint32_t)atoi(getenv("COLIBRI_CH_GRID")) : 768u;
+        hipLaunchKernelGGL(skip_emit_kernel<false>, dim3(grid), dim3(kChThreads), 0, c->stream, (const uint32_t*)c->skl, (const uint32_t*)c->skl_n, left, offl, right, offr,
+                           l_is_cls ? 1u : 0u, r_is_cls ? 1u : 0u, b.clsbits, b.posbits, recsA, b.region, kBi2Sub, bs, c->state.p, (uint32_t*)nullptr);
+    }
+    hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, b.region, kBi2Sub, c->state.p);
+    hipLaunchKernelGGL(bi2_levelB_kernel, dim3(b.nslots), dim3(kBi2Threads), 0, c->stream, recsA, recsB, b.region, bs, c->b2.boff.p, c->state.p);
+    hipLaunchKernelGGL(bi2_binoff_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->b2.boff.p, kBi2Sub, c->state.p);
+    hipLaunchKernelGGL((bi2_count_big_kernel<(int)kBi2Sub>), dim3(kBi2Waves * kWave / kBi2BigThreads), dim3(kBi2BigThreads), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, thr,
+                       io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, b.wcap, false, (uint32_t*)nullptr, (const uint32_t*)nullptr, kBi2Waves, b.wextra);
+    hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, thr, io.sp_rep, io.sp_cnt, c->b2.wlist.p,
+                       c->b2.wcnt.p, b.wcap, false, (uint32_t*)nullptr, (const uint32_t*)nullptr, true);
+    hipLaunchKernelGGL(bi2_kept_scan_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->state.p);
+    hipLaunchKernelGGL(bi2_finish_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->state.p, bs, thr, pl.res_cap, (uint32_t*)nullptr, 16u);
+    hipLaunchKernelGGL(bi2_compact_kernel, dim3(1025), dim3(kBlock), 0, c->stream, (const uint32_t*)io.sp_rep, (const uint32_t*)io.sp_cnt, (const DevState*)c->state.p, (const Bi2State*)bs,
+                       c->res_rep.p, c->res_cnt.p, pl.res_cap, false);
+    hipLaunchKernelGGL(skip_pass_end_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, seglog, (uint32_t)n, mask);
+    return COLIBRI_OK;
+}
+
 // Order 2 of a corpus beyond one pass (more than ~110 M records: 10^9 tokens on one device), round 3: the windows are scanned ONCE and their records cut ONCE into 2^s key
 // slices (ks_split_*: the split of the multi-GPU protocol with the slices as "owners" and the sub-regions of the one source as "source ranks"); every slice then
 // runs level B and the count on its own dense segment. Rounds 1-2 re-scanned the corpus per slice (bi2_emit_sliced_kernel: 1.4 ms per pass on 10^9 positions,
@@ -2391,6 +2428,15 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                     for (uint32_t mask : masks) {
                         uint32_t f = 0, k = 0;
                         const uint32_t* const gate = chain_synced && !getenv("COLIBRI_ALL_IDS") ? (const uint32_t*)nullptr : (const uint32_t*)c->ids[n - 1].p;
+                        const std::vector<std::pair<int, int>> parts = mask_parts(mask, n);
+                        // two parts, at least one of them a single token (class id, ~20 bits; two result indices of ~24 bits do not fit a record beside the position)
+                        const bool one_token_part = parts.size() == 2 && c->ids1_is_cls && (parts[0].second == 1 || parts[1].second == 1);
+                        if (chain_synced && one_token_part && !o.indexed && !getenv("COLIBRI_ALL_IDS") && !getenv("COLIBRI_NO_SKIP_CHAIN")) {  // ... on the chained engine
+                            if ((rc = skip_pass_chain(c, pl, n, mask, part_ids(c, parts[0].second), (uint32_t)parts[0].first, parts[0].second == 1 && c->ids1_is_cls,
+                                                      part_ids(c, parts[1].second), (uint32_t)parts[1].first, parts[1].second == 1 && c->ids1_is_cls, thr_skip, c->seglog.p)))
+                                return rc;
+                            continue;
+                        }
                         if ((rc = skipgram_pass_radix(c, pl, n, mask, gate, gate, thr_skip, 0u, &f, &k, nullptr, 0, 0, 0, c->seglog.p))) return rc;
                     }
                     nlogged += masks.size();

@@ -523,26 +523,33 @@ __global__ __launch_bounds__(kChThreads) void chain_pairs_kernel(const uint32_t*
 __global__ __launch_bounds__(kBlock) void chain_alist_kernel(const uint32_t* __restrict__ bitmap, uint32_t npos, const DevState* __restrict__ st, uint32_t* __restrict__ list_out,
                                                               uint32_t* __restrict__ nlist_out) {
     if (st->done) return;
-    __shared__ uint32_t stageL[kBlock * 32], baseL, wsumL[kBlock / kWave];
-    const uint32_t      nwords = (npos + 31) / 32, ntiles = (nwords + kBlock - 1) / kBlock;
+    __shared__ uint32_t baseL, wsumL[kBlock / kWave];
+    constexpr uint32_t  kPerLane = 8;  // consecutive bitmap words per lane: a lane's windows leave as one run (no staging; one scan and one reservation per 65 536 positions)
+    const uint32_t      nwords = (npos + 31) / 32, ntiles = (nwords + kBlock * kPerLane - 1) / (kBlock * kPerLane);
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t w = tile * kBlock + threadIdx.x;
-        uint32_t       y = 0;
-        if (w < nwords) {
-            const uint32_t x = bitmap[w], nx = bitmap[w + 1];  // (the words beyond the corpus read zero)
-            y = x & ((x >> 1) | (nx << 31));
+        const uint32_t w0 = (tile * kBlock + threadIdx.x) * kPerLane;
+        uint32_t       y[kPerLane], cnt = 0;
+        uint32_t       x = w0 < nwords ? bitmap[w0] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < kPerLane; ++k) {
+            const uint32_t nx = w0 + k + 1 <= nwords ? bitmap[w0 + k + 1] : 0u;  // (the words beyond the corpus read zero)
+            y[k]              = w0 + k < nwords ? x & ((x >> 1) | (nx << 31)) : 0u;
+            cnt += (uint32_t)__popc(y[k]);
+            x = nx;
         }
         uint32_t       total;
-        const uint32_t excl = bi2_block_scan<kBlock>(__popc(y), &total, wsumL);
+        const uint32_t excl = bi2_block_scan<kBlock>(cnt, &total, wsumL);
         if (threadIdx.x == 0) baseL = total ? atomicAdd(nlist_out, total) : 0u;
-        uint32_t o = excl;
-        while (y) {
-            stageL[o++] = w * 32 + (uint32_t)__builtin_ctz(y);
-            y &= y - 1;
-        }
         __syncthreads();
-        const uint32_t gb = baseL;
-        for (uint32_t j = threadIdx.x; j < total; j += kBlock) list_out[gb + j] = stageL[j];
+        uint32_t o = baseL + excl;
+#pragma unroll
+        for (uint32_t k = 0; k < kPerLane; ++k) {
+            uint32_t yy = y[k];
+            while (yy) {
+                list_out[o++] = (w0 + k) * 32 + (uint32_t)__builtin_ctz(yy);
+                yy &= yy - 1;
+            }
+        }
         __syncthreads();
     }
 }

@@ -717,7 +717,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
                                                               DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
                                                               uint32_t* __restrict__ wlist, uint32_t* __restrict__ wcnt, uint32_t wcap, bool want_positions,
                                                               uint32_t* __restrict__ wcode = nullptr /* optional, beside wlist: (final bin << 10) | rank of the window's key among the
-                                                                                                        bin's survivors — what bi2_ids_kernel turns into the window's RESULT index */,
+                                                                                                        bin's survivors — what bi2_pospart_kernel (dense) and chain_ids_kernel turn into the window's RESULT index */,
                                                               const uint32_t* __restrict__ slotbase = nullptr,
                                                               bool big_elsewhere = false /* bi2_count_big_kernel has counted the huge bins */) {
     if (st->done) return;
@@ -1493,37 +1493,8 @@ __global__ __launch_bounds__(kBi2BmThreads) void bi2_bitmap_kernel(uint32_t npos
     for (uint32_t w = threadIdx.x; w < nwords; w += kBi2BmThreads) bitmap[(start >> 5) + w] = bmL[w];
 }
 
-// ---- result indices per position (the modes that keep every order's ids: forward index, skipgram passes) ------------------------------------
-// per position bucket: the listed (position, code) pairs -> ids[position] = RESULT index of the window's bigram (the array is pre-filled with kInvalid;
-// the scatter stays inside the bucket's window of 2^pshift positions). Head bigrams: bi2_list3_kernel writes theirs from the table bi2_headids_kernel leaves.
-// The 4-byte stores of a bucket land in one window of 2^pshift positions (512 KB at 10^8 positions). (Round 3 tried fewer, persistent blocks so that few windows
-// are open at a time and the stores meet in L2: slower at every grid size below one block per bucket — the kernel is bound by loads in flight.)
-__global__ __launch_bounds__(kBi2BmThreads) void bi2_ids_kernel(uint32_t npos, const Bi2State* __restrict__ bs, const uint32_t* __restrict__ plist, const uint32_t* __restrict__ pcode,
-                                                                 Bi2Lists pl, const DevState* __restrict__ st, uint32_t* __restrict__ ids, uint32_t nbuckets) {
-    if (st->done) return;
-    const uint32_t res_base = bs->res_base;
-    for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
-        if ((b << pl.pshift) >= npos) break;
-        for (uint32_t x = 0; x < (uint32_t)kBi2Shards; ++x) {
-            const uint32_t l = x * kBi2Buckets + b, n = min(bs->pcur[l], pl.pcap);
-            const size_t   o = (size_t)l * pl.pcap;
-            for (uint32_t j0 = 0; j0 < n; j0 += 4 * kBi2BmThreads) {
-                uint32_t code[4], pos[4], off[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {  // loads, then the gathers from the 512 KB offset table, then the stores
-                    const uint32_t j = j0 + k * kBi2BmThreads + threadIdx.x;
-                    code[k]          = j < n ? pcode[o + j] : 0u;
-                    pos[k]           = j < n ? plist[o + j] : 0u;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) off[k] = bs->binkept[code[k] >> 10];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (j0 + k * kBi2BmThreads + threadIdx.x < n) ids[pos[k]] = res_base + off[k] + (code[k] & 1023u);
-            }
-        }
-    }
-}
+// ---- result indices per position (the modes that keep every order's ids: forward index, skipgram passes): chain.hpp's chain_ids_kernel (rounds 2-3 scattered a bucket's ids
+// with one block per bucket — bi2_ids_kernel, 1.33 GB written for 0.42 GB of ids). The head bigrams' result indices: -----------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void bi2_headids_kernel(const Bi2State* __restrict__ bs, const DevState* __restrict__ st, uint32_t* __restrict__ headid /* [kBi2HeadN] */) {
     if (st->done) return;
     uint32_t       r    = bs->res_base + bs->kept_bins + bs->headbase[threadIdx.x];  // as bi2_compact_kernel numbers them

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kChThreads, 6) void skip_emit_kernel(const uint32_t
 }
 
 // ---- result indices per position (the modes that keep every order's ids), with the step order of chain_emit_kernel ------------------------------------------------------
-// bi2_ids_kernel scatters a bucket's 4-byte ids into its 512 KB window with one block per bucket: all ~800 windows are open at once, a line leaves L2 before its other
+// Rounds 2-3 (bi2_ids_kernel) scattered a bucket's 4-byte ids into its 512 KB window with one block per bucket: all ~800 windows are open at once, a line leaves L2 before its other
 // ids arrive, and 1.33 GB are written to store 0.42 GB (rounds 2-3). Here an XCD's blocks walk the XCD's buckets together, piece by piece (chain_steps_kernel's tables):
 // ~3 windows are open per L2 and a line is written once it is whole. pcode: dense survivor numbers (bi2_pospart_kernel, dense = true).
 __global__ __launch_bounds__(kChThreads) void chain_ids_kernel(const uint32_t* __restrict__ plist, const uint32_t* __restrict__ pcode, const uint2* __restrict__ table, uint32_t cap,

@@ -2146,7 +2146,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
         if (bi2 && (rc = bigram2_alloc(c, npos, chain))) return rc;
     }
     // the modes that keep every order's ids run order 2 on the second-generation kernels as well, which then also leave the result index of the bigram at
-    // every position (bi2_ids_kernel); one pass only, class-keyed, no word threshold (its cut of the order-1 ids comes after their references are emitted)
+    // every position (chain_ids_kernel); one pass only, class-keyed, no word threshold (its cut of the order-1 ids comes after their references are emitted)
     const bool bi2_synced = radix_synced && !continued && !filtered && !backoff && wthr == 0 && o.table_mode == 0 && !(c->flags & kFlagNonCanonical) && uni_range_shift(c) != 0 &&
                             c->maxclass < (1u << 21) && o.maxlength >= 2 && bigram2_fits(c, npos) && bigram2_plan(c, npos).sbits == 0 && !c->b2.disabled;
     // ... and, since round 4, their orders >= 3 on the chained engine (chain.hpp) like the plain run's: an order's (position, dense number) pairs become its ids per position

@@ -44,6 +44,21 @@ __host__ __device__ __forceinline__ uint64_t bi2_mix(uint64_t x, uint32_t K) {
     return x;
 }
 
+#ifndef COLIBRI_BI2_WEU
+#define COLIBRI_BI2_WEU 4
+#endif
+#ifndef COLIBRI_BI2_WROWS
+#define COLIBRI_BI2_WROWS 12
+#endif
+#ifndef COLIBRI_BI2_WSLOTS
+#define COLIBRI_BI2_WSLOTS 1024
+#endif
+#ifndef COLIBRI_BI2_BINTARGET
+#define COLIBRI_BI2_BINTARGET 700
+#endif
+constexpr int      kBi2WRows = COLIBRI_BI2_WROWS;   // records per lane in registers (bins of up to 64 x this many records are read once)
+constexpr int      kBi2WSlots = COLIBRI_BI2_WSLOTS; // the wave kernel's LDS table
+constexpr uint32_t kBi2BinTarget = COLIBRI_BI2_BINTARGET;  // records per final bin aimed at
 constexpr int      kBi2Threads  = 1024;                   // emit / level-B block (wide blocks, few items per lane: short LDS chains, 32 waves per CU)
 constexpr int      kBi2Per      = 4;                      // items per lane
 constexpr int      kBi2Tile     = kBi2Threads * kBi2Per;  // 4096 windows (records) per tile
@@ -440,7 +455,7 @@ __global__ __launch_bounds__(kBlock) void bi2_offsets_kernel(Bi2State* __restric
         bs->nrec         = tot;
         // aim at <= ~700 records per final bin; at least 8 B bins (the 31-bit in-bin key needs three mix bits fixed by the B bin)
         uint32_t nb = 8;
-        while (nb < (uint32_t)kBi2BBins && (uint64_t)nb * kBins * 700u < tot) nb <<= 1;
+        while (nb < (uint32_t)kBi2BBins && (uint64_t)nb * kBins * kBi2BinTarget < tot) nb <<= 1;
         uint32_t sh = 0;
         while ((uint32_t)kBi2BBins >> sh > nb) ++sh;
         // the 31-bit in-bin key must hold every mix bit the bin does not fix: kbits - 17 + bshift <= 31
@@ -622,7 +637,6 @@ __global__ __launch_bounds__(kBi2BBins) void bi2_binoff_kernel(Bi2State* __restr
 // the windows of surviving keys are appended, unsorted, to the wave's private list (ballot-compacted, coalesced): bi2_pospart_kernel sorts them
 // into position buckets afterwards. Bins are handed out dynamically, the big ones (a hot key outside the dense head) first; their records
 // beyond the register window are streamed four rows at a time with the next four in flight.
-constexpr int      kBi2WRows = 12;   // records per lane in registers (bins of up to 768 records are read once)
 constexpr int      kBi2WReps = 256;  // survivors of a bin whose lowest position is tracked in LDS (beyond: device atomics on the result array)
 constexpr uint32_t kBi2Kept  = 0x80000000u;
 __device__ __forceinline__ uint32_t bi2_wave_excl_scan(uint32_t v, uint32_t* total) {
@@ -712,8 +726,8 @@ constexpr uint32_t kBi2Chunk = 4096;
 // windows again by counting. A record's "position" is its place in the receive buffer (31 bits; lower place = lower source rank first).
 // SLOTS: the LDS table of a final bin (1024: 900 distinct keys, what a pass of ~2 x 10^8 positions of the bench distribution fills; 2048 for the passes beyond — half
 // the waves per CU, which is why it is not the default). A bin's survivors are numbered in 10 bits either way (more than 1023 of them: overflow 2, like a full table).
-template <int NSUB, bool BASED = false, int ROWS = kBi2WRows, bool KEY4 = false, int SLOTS = kBi2Slots>
-__global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const uint32_t* __restrict__ boff, Bi2State* __restrict__ bs,
+template <int NSUB, bool BASED = false, int ROWS = kBi2WRows, bool KEY4 = false, int SLOTS = kBi2WSlots>
+__global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const uint32_t* __restrict__ boff, Bi2State* __restrict__ bs,
                                                               DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
                                                               uint32_t* __restrict__ wlist, uint32_t* __restrict__ wcnt, uint32_t wcap, bool want_positions,
                                                               uint32_t* __restrict__ wcode = nullptr /* optional, beside wlist: (final bin << 10) | rank of the window's key among the
@@ -727,8 +741,8 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
     uint32_t* const       code_at = wlist;
     __shared__ __attribute__((aligned(16))) uint32_t keyT[SLOTS];
     __shared__ __attribute__((aligned(16))) uint32_t cntT[SLOTS];
-    __shared__ uint32_t                              repS[kBi2WReps];
-    constexpr uint32_t kMaxLoad = kBi2MaxLoad * (uint32_t)(SLOTS / kBi2Slots);
+    __shared__ uint32_t                              repS[SLOTS / 4];
+    constexpr uint32_t kMaxLoad = kBi2MaxLoad * (uint32_t)SLOTS / (uint32_t)kBi2Slots;
     const uint32_t bsh = bs->bshift, nB = (uint32_t)kBi2BBins >> bsh, nfinal = (uint32_t)kBins * nB;
     const uint32_t lane = threadIdx.x, wid = blockIdx.x, nwaves = gridDim.x;
     const uint32_t pb = bs->posbits;
@@ -906,7 +920,7 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
             }
             return;
         }
-        const bool reps_lds = ktotal <= (uint32_t)kBi2WReps;
+        const bool reps_lds = ktotal <= (uint32_t)(SLOTS / 4);
         {
             uint32_t r = excl;
             for (uint32_t k = 0; k < per; k += 4) {
@@ -1007,27 +1021,41 @@ __global__ __launch_bounds__(kWave, 4) void bi2_count_kernel(const unsigned long
             for (uint32_t r = lane; r < ktotal; r += kWave) sp_rep[spo + r] = repS[r];
         BI2_W(10);
     };
-    // the big bins first, one per wave, so that none of them starts when the others are about to finish; then the regular walk
+    // the big bins first, one per wave, so that none of them starts when the others are about to finish; then the regular walk: bins are handed out four at a time
+    // from 8 queues (queue q = the bins g with g mod 8 == q; a single counter would serialise ~12 ns per request): a wave that drew a big bin simply takes fewer of the
+    // others. ONE call site of process_bin (round 5): inlined twice it made 60 KB of code against 64 KB of instruction cache per two CUs; now 29 KB.
     const uint32_t nbig = bs->nbig;
     const bool     skip_big = nbig <= (uint32_t)kBi2BigCap;  // (more big bins than the list holds: the regular walk takes them all)
-    if (skip_big)
-        for (uint32_t k = wid; k < nbig; k += nwaves) {
-            const uint32_t f = bs->big[k];
-            process_bin(f / kBi2BBins, f % kBi2BBins, true, true);
-        }
-    // bins are handed out four at a time from 8 queues (queue q = the bins g with g mod 8 == q; a single counter would serialise ~12 ns per request):
-    // a wave that drew a big bin simply takes fewer of the others
     const uint32_t q = wid & (uint32_t)(kBi2Shards - 1);
-    for (;;) {
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(&bs->nextbin[q * 16], 4u);
-        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        if (t * kBi2Shards + q >= nfinal) break;
+    uint32_t       kb = skip_big ? wid : kInvalid, tk = 0, tleft = 0;
 #pragma unroll 1
-        for (uint32_t k = 0; k < 4; ++k) {
-            const uint32_t g = (t + k) * kBi2Shards + q;
-            if (g < nfinal) process_bin(g & (uint32_t)(kBins - 1), g >> 8, false, skip_big);
+    for (;;) {
+        uint32_t a, b;
+        bool     bigp;
+        if (kb < nbig) {
+            const uint32_t f = bs->big[kb];
+            kb += nwaves;
+            a    = f / kBi2BBins;
+            b    = f % kBi2BBins;
+            bigp = true;
+        } else {
+            if (tleft == 0) {
+                uint32_t t = 0;
+                if (lane == 0) t = atomicAdd(&bs->nextbin[q * 16], 4u);
+                t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+                if (t * kBi2Shards + q >= nfinal) break;
+                tk    = t;
+                tleft = 4;
+            }
+            const uint32_t g = tk * kBi2Shards + q;
+            ++tk;
+            --tleft;
+            if (g >= nfinal) continue;
+            a    = g & (uint32_t)(kBins - 1);
+            b    = g >> 8;
+            bigp = false;
         }
+        process_bin(a, b, bigp, skip_big);
     }
 #ifdef BI2_PROF
     if (lane == 0)

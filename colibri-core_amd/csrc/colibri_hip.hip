@@ -870,6 +870,9 @@ int binned_resolve_stage(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids_out,
 
 // ---- order 2, second generation (bigram2.hpp): class-keyed 8-byte records, dense head, per-slot level B, one wave per final bin, position
 // lists -> bitmap -> the active list of order 3. `want_list`: order 3 follows. Everything is enqueued; nothing is read back.
+#ifndef COLIBRI_BI2_WPC
+#define COLIBRI_BI2_WPC 16
+#endif
 #ifndef COLIBRI_BI2_SUB
 #define COLIBRI_BI2_SUB 4
 #endif
@@ -877,7 +880,7 @@ int binned_resolve_stage(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids_out,
 // the emit kernel's cursor reservations and level B's blocks cheaper. Measured per 10^8-token step on one box: 8 / 4 / 2 / 1 sub-regions 4.54 / 4.44 / 4.47 / 4.56 ms
 // (count 0.85 / .. / 0.76 / 0.75, level B 0.48 / .. / 0.59 / 0.56, emit 0.51 / .. / 0.51 / 0.63). The split of corpora beyond one pass and the multi-GPU source
 // side keep eight (kBi2SubWide): their sub-regions double as source ranks / carry three position bits.
-constexpr uint32_t kBi2Sub = COLIBRI_BI2_SUB, kBi2SubWide = 8, kBi2EmitGrid = 512, kBi2Waves = 256 * 16;
+constexpr uint32_t kBi2Sub = COLIBRI_BI2_SUB, kBi2SubWide = 8, kBi2EmitGrid = 512, kBi2Waves = 256 * COLIBRI_BI2_WPC;
 // records a pass of the radix path takes on (final bins of ~700-1500 records). COLIBRI_SLICE_POSITIONS (tests): a smaller number, so that small corpora
 // exercise the sliced passes of the path for corpora beyond ~128 M tokens per device
 // Round 4: ONE pass of the second-generation engine holds ~2 x 10^8 positions of the bench distribution (a final bin's LDS table takes ~2500 distinct keys; at 2.5 x 10^8
@@ -2040,6 +2043,19 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
     if (!c || !opt_in) return COLIBRI_ERR_ARG;
     for (;;) {
         const int rc = colibri_train_once(c, opt_in, stats_out);
+#ifdef BI2_PROF  // (experimental builds only) where bi2_count_kernel's waves spent their cycles: sections of process_bin, summed over waves and launches of this call
+        {
+            unsigned long long h[16] = {0}, z[16] = {0};
+            if (hipMemcpyFromSymbol(h, HIP_SYMBOL(colibri::bi2_prof), sizeof h) == hipSuccess) {
+                unsigned long long t = 0;
+                for (int k = 0; k < 12; ++k) t += h[k];
+                fprintf(stderr, "BI2_PROF");
+                for (int k = 0; k < 12; ++k) fprintf(stderr, " s%d=%.1f%%", k, t ? 100.0 * (double)h[k] / (double)t : 0.0);
+                fprintf(stderr, " total=%llu\n", t);
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(colibri::bi2_prof), z, sizeof z);
+            }
+        }
+#endif
         // a result buffer ran out (a corpus that keeps unusually many patterns per position: duplicated text): more room, again
         // (one result per position and order — with skipgrams one per gap mask as well: up to ~6 x 10^5 masks for a window of 31 tokens)
         const uint64_t per_window = (opt_in->doskipgrams || opt_in->doskipgrams_exhaustive) ? 700000ull : 1ull;

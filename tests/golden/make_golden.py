@@ -123,7 +123,7 @@ def main():
             unstable.append(os.path.basename(out))
             os.remove(out)
     # MINTOKENS = 1 (the reference's single pass over all lengths)
-    for name, l in [("hamlet.v2", 5), ("edge", 5), ("zipf20k", 3)]:
+    for name, l in [("hamlet.v2", 5), ("edge", 5), ("zipf20k", 3), ("zipf20k", 5)]:  # (zipf20k at l = 5: tests/test_kshard.py's key-sharded indexed threshold-1 cases)
         for mode in ("u", "i"):
             out = os.path.join(HERE, f"{name}.{mode}t1.l{l}.txt")
             subprocess.check_call([DRIVER, "train", os.path.join(HERE, f"{name}.colibri.dat"), mode, str(l), "1", "-q", "-d", out], stdout=subprocess.DEVNULL)

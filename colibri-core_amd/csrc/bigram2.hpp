@@ -664,41 +664,52 @@ __device__ __forceinline__ uint32_t bi2_scan4(const uint4& v, uint32_t key, bool
 }
 __device__ __forceinline__ uint32_t bi2_bucket_of(uint32_t key, int lgb, uint32_t bmask) { return ((key * 0x9E3779B1u) >> (32 - lgb)) & bmask; }
 // finds or inserts two keys per lane (A and B, each optional); slots are returned through sa / sb (kInvalid: table full)
+// Round 5: ONE look at the bucket (vA / vB, read by the caller), then a walk of compare-and-swaps. The look settles the hits (about half of a bin's records) and names the
+// first free slot; a lane that loses that slot to another key (lanes of one row racing for the same bucket: the usual case, 128 inserts into 256 buckets) tries the NEXT
+// slot right away — its compare-and-swap returns what the slot holds, which is all a new look would tell — and walks on into the next bucket when the bucket is full.
+// Slots fill left to right and are never freed, so a key is in the first slot of its walk that holds it or is empty. Round 4 went back to the look after every lost race:
+// ~4 rounds of (16-byte read, 16 compares and selects, compare-and-swap) per pair of rows, 42 % of the kernel.
+// ownA / ownB: this lane's compare-and-swap put the key into the table — exactly one record per distinct key of the bin is its key's "owner"
 __device__ __forceinline__ void bi2_insert2(uint32_t* keyT, uint32_t bmask, bool actA, uint32_t keyA, uint32_t bkA, uint4 vA, uint32_t& sa, bool actB, uint32_t keyB, uint32_t bkB, uint4 vB,
-                                            uint32_t& sb) {
-    uint32_t walkedA = 0, walkedB = 0;
+                                            uint32_t& sb, bool& ownA, bool& ownB) {
+    const uint32_t smask = bmask * 4u + 3u;
+    ownA = ownB = false;
+    bool           hitA = false, hitB = false;
+    const uint32_t iA = bi2_scan4(vA, keyA, hitA), iB = bi2_scan4(vB, keyB, hitB);
+    uint32_t       pA = (bkA * 4u + iA) & smask, pB = (bkB * 4u + iB) & smask;  // (no slot of the bucket is free or holds the key: the next bucket's first)
     sa = sb = kInvalid;
-    while (actA || actB) {
-        bool           hitA = false, hitB = false;
-        const uint32_t iA = actA ? bi2_scan4(vA, keyA, hitA) : 4u, iB = actB ? bi2_scan4(vB, keyB, hitB) : 4u;
-        const bool     casA = actA && iA < 4 && !hitA, casB = actB && iB < 4 && !hitB;
-        uint32_t       oldA = 0, oldB = 0;
-        if (casA) oldA = atomicCAS(&keyT[bkA * 4 + iA], kBi2Empty, keyA);
-        if (casB) oldB = atomicCAS(&keyT[bkB * 4 + iB], kBi2Empty, keyB);
+    if (actA && hitA) {
+        sa   = pA;
+        actA = false;
+    }
+    if (actB && hitB) {
+        sb   = pB;
+        actB = false;
+    }
+    uint32_t steps = 0;
+    while (__any(actA || actB)) {
+        uint32_t oldA = kBi2Empty, oldB = kBi2Empty;
+        if (actA) oldA = atomicCAS(&keyT[pA], kBi2Empty, keyA);
+        if (actB) oldB = atomicCAS(&keyT[pB], kBi2Empty, keyB);
         if (actA) {
-            if (iA < 4) {
-                if (hitA || oldA == kBi2Empty || oldA == keyA) {
-                    sa   = bkA * 4 + iA;
-                    actA = false;
-                }
+            if (oldA == kBi2Empty || oldA == keyA) {
+                sa   = pA;
+                ownA = oldA == kBi2Empty;
+                actA = false;
             } else {
-                bkA = (bkA + 1) & bmask;
-                if (++walkedA > bmask) actA = false;
+                pA = (pA + 1u) & smask;
             }
         }
         if (actB) {
-            if (iB < 4) {
-                if (hitB || oldB == kBi2Empty || oldB == keyB) {
-                    sb   = bkB * 4 + iB;
-                    actB = false;
-                }
+            if (oldB == kBi2Empty || oldB == keyB) {
+                sb   = pB;
+                ownB = oldB == kBi2Empty;
+                actB = false;
             } else {
-                bkB = (bkB + 1) & bmask;
-                if (++walkedB > bmask) actB = false;
+                pB = (pB + 1u) & smask;
             }
         }
-        if (actA) vA = *reinterpret_cast<const uint4*>(keyT + bkA * 4);
-        if (actB) vB = *reinterpret_cast<const uint4*>(keyT + bkB * 4);
+        if (++steps > smask) break;  // (every slot holds another key: the caller reports the overflow)
     }
 }
 // slot of a key that is known to be in the table
@@ -821,7 +832,7 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
         }
         BI2_W(3);
         // pass 1: two rows per round
-        uint32_t sl[ROWS];
+        uint32_t sl[ROWS], own = 0;  // own: bit q = this lane's record of row q put its key into the table (one "owner" per distinct key)
         bool     fail = false;
 #pragma unroll
         for (int q = 0; q < ROWS; q += 2) {
@@ -831,7 +842,9 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
                 const uint32_t keyA = (uint32_t)(x[q] >> pb) & 0x7FFFFFFFu, keyB = (uint32_t)(x[q + 1] >> pb) & 0x7FFFFFFFu;
                 const uint32_t bkA = bi2_bucket_of(keyA, lgb, bmask), bkB = bi2_bucket_of(keyB, lgb, bmask);
                 const uint4    vA = *reinterpret_cast<const uint4*>(keyT + bkA * 4), vB = *reinterpret_cast<const uint4*>(keyT + bkB * 4);
-                bi2_insert2(keyT, bmask, actA, keyA, bkA, vA, sl[q], actB, keyB, bkB, vB, sl[q + 1]);
+                bool           oA, oB;
+                bi2_insert2(keyT, bmask, actA, keyA, bkA, vA, sl[q], actB, keyB, bkB, vB, sl[q + 1], oA, oB);
+                own |= (oA ? 1u << q : 0u) | (oB ? 2u << q : 0u);
                 if (actA) {
                     if (sl[q] == kInvalid)
                         fail = true;
@@ -868,7 +881,8 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
                     const uint32_t keyA = (uint32_t)(z[k] >> pb) & 0x7FFFFFFFu, keyB = (uint32_t)(z[k + 1] >> pb) & 0x7FFFFFFFu;
                     const uint32_t bkA = bi2_bucket_of(keyA, lgb, bmask), bkB = bi2_bucket_of(keyB, lgb, bmask);
                     uint32_t       tA, tB;
-                    bi2_insert2(keyT, bmask, actA, keyA, bkA, *reinterpret_cast<const uint4*>(keyT + bkA * 4), tA, actB, keyB, bkB, *reinterpret_cast<const uint4*>(keyT + bkB * 4), tB);
+                    bool           oA, oB;
+                    bi2_insert2(keyT, bmask, actA, keyA, bkA, *reinterpret_cast<const uint4*>(keyT + bkA * 4), tA, actB, keyB, bkB, *reinterpret_cast<const uint4*>(keyT + bkB * 4), tB, oA, oB);
                     if (actA) {
                         if (tA == kInvalid)
                             fail = true;
@@ -889,21 +903,69 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
             if (lane == 0) bs->overflow = 2;
             return;
         }
-        // survivors: lane l looks at the nslots / 64 consecutive slots from l * (nslots / 64), four at a time
-        const uint32_t per  = nslots / kWave;
-        uint32_t       used = 0, keep = 0;
-        for (uint32_t k = 0; k < per; k += 4) {
-            const uint32_t s  = lane * per + k;
-            const uint4    kk = *reinterpret_cast<const uint4*>(keyT + s), cc = *reinterpret_cast<const uint4*>(cntT + s);
-            used += (kk.x != kBi2Empty) + (kk.y != kBi2Empty) + (kk.z != kBi2Empty) + (kk.w != kBi2Empty);
-            keep += (cc.x >= threshold) + (cc.y >= threshold) + (cc.z >= threshold) + (cc.w >= threshold);  // an empty slot counts 0 (threshold >= 1)
-        }
-        uint32_t       distinct, ktotal;
-        const uint32_t excl = bi2_wave_excl_scan(keep, &ktotal);
-        bi2_wave_excl_scan(used, &distinct);
-        if (distinct > kMaxLoad || ktotal > 1023u) {
-            if (lane == 0) bs->overflow = 2;
-            return;
+        // survivors. Every distinct key has exactly one owner among the records, so a bin whose records are all in registers is ranked from the records' side: per row one
+        // look at the owners' counters, two ballots — instead of two sweeps over the 1024 slots (16 per lane, a branch per slot: 15 % of the kernel in round 4).
+        // Survivor r of the bin keeps its lowest position in LDS while r < SLOTS / 4, in the result array (device atomics) beyond.
+        constexpr uint32_t kReps = (uint32_t)(SLOTS / 4);
+        uint32_t           distinct = 0, ktotal = 0;
+        if (total <= (uint32_t)(ROWS * kWave)) {
+#pragma unroll
+            for (int q = 0; q < ROWS; ++q) {
+                if ((uint32_t)(q * kWave) < total) {
+                    const bool     owner = (own >> q) & 1u;
+                    const uint32_t c     = owner ? cntT[sl[q]] : 0u;
+                    const bool     kept  = owner && c >= threshold;
+                    const uint64_t mk    = __ballot(kept);
+                    distinct += (uint32_t)__popcll(__ballot(owner));
+                    if (kept) {
+                        const uint32_t r = ktotal + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+                        sp_cnt[spo + r]  = c;
+                        cntT[sl[q]]      = kBi2Kept | r;  // from here on: the key survived, and which survivor of the bin it is
+                        if (r < kReps)
+                            repS[r] = 0xFFFFFFFFu;
+                        else
+                            sp_rep[spo + r] = 0xFFFFFFFFu;
+                    }
+                    ktotal += (uint32_t)__popcll(mk);
+                }
+            }
+            if (distinct > kMaxLoad || ktotal > 1023u) {
+                if (lane == 0) bs->overflow = 2;
+                return;
+            }
+        } else {  // a bin beyond the register window: lane l sweeps the nslots / 64 consecutive slots from l * (nslots / 64), four at a time
+            const uint32_t per  = nslots / kWave;
+            uint32_t       used = 0, keep = 0;
+            for (uint32_t k = 0; k < per; k += 4) {
+                const uint32_t s  = lane * per + k;
+                const uint4    kk = *reinterpret_cast<const uint4*>(keyT + s), cc = *reinterpret_cast<const uint4*>(cntT + s);
+                used += (kk.x != kBi2Empty) + (kk.y != kBi2Empty) + (kk.z != kBi2Empty) + (kk.w != kBi2Empty);
+                keep += (cc.x >= threshold) + (cc.y >= threshold) + (cc.z >= threshold) + (cc.w >= threshold);  // an empty slot counts 0 (threshold >= 1)
+            }
+            const uint32_t excl = bi2_wave_excl_scan(keep, &ktotal);
+            bi2_wave_excl_scan(used, &distinct);
+            if (distinct > kMaxLoad || ktotal > 1023u) {
+                if (lane == 0) bs->overflow = 2;
+                return;
+            }
+            uint32_t r = excl;
+            for (uint32_t k = 0; k < per; k += 4) {
+                const uint32_t s0 = lane * per + k;
+                const uint4    cc = *reinterpret_cast<const uint4*>(cntT + s0);
+                const uint32_t c4[4] = {cc.x, cc.y, cc.z, cc.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (c4[i] >= threshold) {
+                        sp_cnt[spo + r] = c4[i];
+                        cntT[s0 + i]    = kBi2Kept | r;
+                        if (r < kReps)
+                            repS[r] = 0xFFFFFFFFu;
+                        else
+                            sp_rep[spo + r] = 0xFFFFFFFFu;
+                        ++r;
+                    }
+                }
+            }
         }
         if (lane == 0) {
             atomicAdd(&bs->found_part[a], distinct);
@@ -920,29 +982,8 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
             }
             return;
         }
-        const bool reps_lds = ktotal <= (uint32_t)(SLOTS / 4);
-        {
-            uint32_t r = excl;
-            for (uint32_t k = 0; k < per; k += 4) {
-                const uint32_t s0 = lane * per + k;
-                const uint4    cc = *reinterpret_cast<const uint4*>(cntT + s0);
-                const uint32_t c4[4] = {cc.x, cc.y, cc.z, cc.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (c4[i] >= threshold) {
-                        sp_cnt[spo + r] = c4[i];
-                        cntT[s0 + i]    = kBi2Kept | r;  // from here on: the key survived, and which survivor of the bin it is
-                        if (reps_lds)
-                            repS[r] = 0xFFFFFFFFu;
-                        else
-                            sp_rep[spo + r] = 0xFFFFFFFFu;
-                        ++r;
-                    }
-                }
-            }
-        }
         BI2_W(7);
-        if (!reps_lds) __threadfence();  // the initial values of the result entries precede the atomics below
+        if (ktotal > kReps) __threadfence();  // the initial values of the result entries precede the atomics below
         // pass 2: every window of a surviving key: lowest position of the key; the position joins the wave's list
         const uint32_t fcode = (a * (uint32_t)kBi2BBins + b) << 10;
         auto settle = [&](bool valid, uint32_t pos, uint32_t s) {
@@ -952,7 +993,7 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
             const uint32_t r    = c & ~kBi2Kept;
             if (KEY4 && valid) code_at[pos] = kept ? (fcode | r) : kInvalid;  // (a run's records lie one after the other: the stores of a row are coalesced)
             if (kept) {  // (read first: a hot key's windows all aim at one word, and after the first rows hardly any of them lowers it)
-                if (reps_lds) {
+                if (r < kReps) {
                     if (pos < repS[r]) atomicMin(&repS[r], pos);
                 } else if (pos < __hip_atomic_load(&sp_rep[spo + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     atomicMin(&sp_rep[spo + r], pos);
@@ -1017,8 +1058,7 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
             }
         }
         BI2_W(9);
-        if (reps_lds)
-            for (uint32_t r = lane; r < ktotal; r += kWave) sp_rep[spo + r] = repS[r];
+        for (uint32_t r = lane; r < min(ktotal, kReps); r += kWave) sp_rep[spo + r] = repS[r];
         BI2_W(10);
     };
     // the big bins first, one per wave, so that none of them starts when the others are about to finish; then the regular walk: bins are handed out four at a time
@@ -1186,7 +1226,8 @@ __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const uns
                 bi2_merge_leader(actB, keyB, wB, lane);
                 const uint32_t bkA = bi2_bucket_of(keyA, lgb, bmask), bkB = bi2_bucket_of(keyB, lgb, bmask);
                 uint32_t       tA, tB;
-                bi2_insert2(keyT, bmask, actA, keyA, bkA, *reinterpret_cast<const uint4*>(keyT + bkA * 4), tA, actB, keyB, bkB, *reinterpret_cast<const uint4*>(keyT + bkB * 4), tB);
+                bool           oA, oB;
+                bi2_insert2(keyT, bmask, actA, keyA, bkA, *reinterpret_cast<const uint4*>(keyT + bkA * 4), tA, actB, keyB, bkB, *reinterpret_cast<const uint4*>(keyT + bkB * 4), tB, oA, oB);
                 if (actA) {
                     if (tA == kInvalid)
                         fail = true;

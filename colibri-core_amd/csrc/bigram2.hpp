@@ -671,44 +671,31 @@ __device__ __forceinline__ uint32_t bi2_bucket_of(uint32_t key, int lgb, uint32_
 // ~4 rounds of (16-byte read, 16 compares and selects, compare-and-swap) per pair of rows, 42 % of the kernel.
 // ownA / ownB: this lane's compare-and-swap put the key into the table — exactly one record per distinct key of the bin is its key's "owner"
 __device__ __forceinline__ void bi2_insert2(uint32_t* keyT, uint32_t bmask, bool actA, uint32_t keyA, uint32_t bkA, uint4 vA, uint32_t& sa, bool actB, uint32_t keyB, uint32_t bkB, uint4 vB,
-                                            uint32_t& sb, bool& ownA, bool& ownB) {
+                                            uint32_t& sb, uint32_t& ownA, uint32_t& ownB) {
+    // The walk's state is INTEGER per lane (the slot to try, bit 31 = still walking) and every update a select: as booleans (act / hit / own per row) the state lived in
+    // 64-bit scalar masks that each branch merged with three scalar instructions — the kernel executed more scalar than vector instructions.
+    constexpr uint32_t kWalk = 0x80000000u;
     const uint32_t smask = bmask * 4u + 3u;
-    ownA = ownB = false;
     bool           hitA = false, hitB = false;
     const uint32_t iA = bi2_scan4(vA, keyA, hitA), iB = bi2_scan4(vB, keyB, hitB);
-    uint32_t       pA = (bkA * 4u + iA) & smask, pB = (bkB * 4u + iB) & smask;  // (no slot of the bucket is free or holds the key: the next bucket's first)
-    sa = sb = kInvalid;
-    if (actA && hitA) {
-        sa   = pA;
-        actA = false;
-    }
-    if (actB && hitB) {
-        sb   = pB;
-        actB = false;
-    }
+    const uint32_t pA = (bkA * 4u + iA) & smask, pB = (bkB * 4u + iB) & smask;  // (no slot of the bucket is free or holds the key: the next bucket's first)
+    sa            = (actA && hitA) ? pA : kInvalid;
+    sb            = (actB && hitB) ? pB : kInvalid;
+    uint32_t qa   = (actA && !hitA) ? (pA | kWalk) : 0u, qb = (actB && !hitB) ? (pB | kWalk) : 0u;
+    ownA = ownB   = 0u;
     uint32_t steps = 0;
-    while (__any(actA || actB)) {
-        uint32_t oldA = kBi2Empty, oldB = kBi2Empty;
-        if (actA) oldA = atomicCAS(&keyT[pA], kBi2Empty, keyA);
-        if (actB) oldB = atomicCAS(&keyT[pB], kBi2Empty, keyB);
-        if (actA) {
-            if (oldA == kBi2Empty || oldA == keyA) {
-                sa   = pA;
-                ownA = oldA == kBi2Empty;
-                actA = false;
-            } else {
-                pA = (pA + 1u) & smask;
-            }
-        }
-        if (actB) {
-            if (oldB == kBi2Empty || oldB == keyB) {
-                sb   = pB;
-                ownB = oldB == kBi2Empty;
-                actB = false;
-            } else {
-                pB = (pB + 1u) & smask;
-            }
-        }
+    while (__any(((qa | qb) & kWalk) != 0u)) {
+        uint32_t oldA = 0u, oldB = 0u;
+        if (qa & kWalk) oldA = atomicCAS(&keyT[qa & smask], kBi2Empty, keyA);
+        if (qb & kWalk) oldB = atomicCAS(&keyT[qb & smask], kBi2Empty, keyB);
+        const bool wA = (qa & kWalk) != 0u, wB = (qb & kWalk) != 0u;
+        const bool dA = wA && (oldA == kBi2Empty || oldA == keyA), dB = wB && (oldB == kBi2Empty || oldB == keyB);
+        sa   = dA ? (qa & smask) : sa;
+        sb   = dB ? (qb & smask) : sb;
+        ownA = (dA && oldA == kBi2Empty) ? 1u : ownA;
+        ownB = (dB && oldB == kBi2Empty) ? 1u : ownB;
+        qa   = dA ? 0u : (wA ? (((qa + 1u) & smask) | kWalk) : qa);
+        qb   = dB ? 0u : (wB ? (((qb + 1u) & smask) | kWalk) : qb);
         if (++steps > smask) break;  // (every slot holds another key: the caller reports the overflow)
     }
 }
@@ -842,21 +829,12 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
                 const uint32_t keyA = (uint32_t)(x[q] >> pb) & 0x7FFFFFFFu, keyB = (uint32_t)(x[q + 1] >> pb) & 0x7FFFFFFFu;
                 const uint32_t bkA = bi2_bucket_of(keyA, lgb, bmask), bkB = bi2_bucket_of(keyB, lgb, bmask);
                 const uint4    vA = *reinterpret_cast<const uint4*>(keyT + bkA * 4), vB = *reinterpret_cast<const uint4*>(keyT + bkB * 4);
-                bool           oA, oB;
+                uint32_t       oA, oB;
                 bi2_insert2(keyT, bmask, actA, keyA, bkA, vA, sl[q], actB, keyB, bkB, vB, sl[q + 1], oA, oB);
-                own |= (oA ? 1u << q : 0u) | (oB ? 2u << q : 0u);
-                if (actA) {
-                    if (sl[q] == kInvalid)
-                        fail = true;
-                    else
-                        atomicAdd(&cntT[sl[q]], 1u);
-                }
-                if (actB) {
-                    if (sl[q + 1] == kInvalid)
-                        fail = true;
-                    else
-                        atomicAdd(&cntT[sl[q + 1]], 1u);
-                }
+                own |= (oA << q) | (oB << (q + 1));
+                fail |= (actA && sl[q] == kInvalid) || (actB && sl[q + 1] == kInvalid);  // (an idle lane's slot is kInvalid too)
+                if (sl[q] != kInvalid) atomicAdd(&cntT[sl[q]], 1u);
+                if (sl[q + 1] != kInvalid) atomicAdd(&cntT[sl[q + 1]], 1u);
             }
         }
         BI2_W(4);
@@ -881,20 +859,11 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
                     const uint32_t keyA = (uint32_t)(z[k] >> pb) & 0x7FFFFFFFu, keyB = (uint32_t)(z[k + 1] >> pb) & 0x7FFFFFFFu;
                     const uint32_t bkA = bi2_bucket_of(keyA, lgb, bmask), bkB = bi2_bucket_of(keyB, lgb, bmask);
                     uint32_t       tA, tB;
-                    bool           oA, oB;
+                    uint32_t       oA, oB;
                     bi2_insert2(keyT, bmask, actA, keyA, bkA, *reinterpret_cast<const uint4*>(keyT + bkA * 4), tA, actB, keyB, bkB, *reinterpret_cast<const uint4*>(keyT + bkB * 4), tB, oA, oB);
-                    if (actA) {
-                        if (tA == kInvalid)
-                            fail = true;
-                        else
-                            atomicAdd(&cntT[tA], 1u);
-                    }
-                    if (actB) {
-                        if (tB == kInvalid)
-                            fail = true;
-                        else
-                            atomicAdd(&cntT[tB], 1u);
-                    }
+                    fail |= (actA && tA == kInvalid) || (actB && tB == kInvalid);
+                    if (tA != kInvalid) atomicAdd(&cntT[tA], 1u);
+                    if (tB != kInvalid) atomicAdd(&cntT[tB], 1u);
                 }
             }
         }
@@ -1226,7 +1195,7 @@ __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const uns
                 bi2_merge_leader(actB, keyB, wB, lane);
                 const uint32_t bkA = bi2_bucket_of(keyA, lgb, bmask), bkB = bi2_bucket_of(keyB, lgb, bmask);
                 uint32_t       tA, tB;
-                bool           oA, oB;
+                uint32_t       oA, oB;
                 bi2_insert2(keyT, bmask, actA, keyA, bkA, *reinterpret_cast<const uint4*>(keyT + bkA * 4), tA, actB, keyB, bkB, *reinterpret_cast<const uint4*>(keyT + bkB * 4), tB, oA, oB);
                 if (actA) {
                     if (tA == kInvalid)

@@ -770,31 +770,30 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
             v = bs->binoff[a * kBi2BBins + b];
         else if (BASED && lane < (uint32_t)(3 * NSUB + 1))
             v = slotbase[(lane - (uint32_t)(2 * NSUB + 1)) * kBins + a];
-        uint32_t rs[NSUB], rn[NSUB], sb[NSUB], total = 0;
+        // record j (< total) of the bin lies at index j + adj[s] of recsB, s = the first run with j < end[s] (scalar registers; mod 2^32 — an index into the record
+        // arrays is below 2^32: they are sized for < 2^30 positions)
+        uint32_t adj[NSUB], end[NSUB], total = 0;
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
-            rs[s] = (uint32_t)__builtin_amdgcn_readlane((int)v, s);
-            rn[s] = (uint32_t)__builtin_amdgcn_readlane((int)v, NSUB + s) - rs[s];
-            sb[s] = BASED ? (uint32_t)__builtin_amdgcn_readlane((int)v, 2 * NSUB + 1 + s) : 0u;
-            total += rn[s];
+            const uint32_t rs = (uint32_t)__builtin_amdgcn_readlane((int)v, s), rn = (uint32_t)__builtin_amdgcn_readlane((int)v, NSUB + s) - rs;
+            const uint32_t sb = BASED ? (uint32_t)__builtin_amdgcn_readlane((int)v, 2 * NSUB + 1 + s) : ((uint32_t)s * kBins + a) * region;
+            adj[s]            = sb + rs - total;
+            total += rn;
+            end[s] = total;
         }
         const uint32_t spo = (uint32_t)__builtin_amdgcn_readlane((int)v, 2 * NSUB);
         BI2_W(1);
         if (total == 0 || (!big_pass && skip_big && total > kBi2BigBin) || (skip_huge && total > hugebin)) return;
-        auto locate = [&](uint32_t j) -> size_t {  // record j (< total) of the bin -> its index in recsB
-            uint32_t off = 0, slot = 0, sbase = 0;
-            bool     ok  = false;
+        auto locate = [&](uint32_t j) -> uint32_t {
+            // (the values pass through readfirstlane: a select between two reads of a local array is folded into one read at a selected address, which pins the array
+            // to scratch memory — every locate() then waits for a scratch load)
+            uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)adj[NSUB - 1]);
 #pragma unroll
-            for (int s = 0; s < NSUB; ++s) {
-                if (!ok && j < rn[s]) {
-                    ok    = true;
-                    off   = rs[s] + j;
-                    slot  = (uint32_t)s * kBins + a;
-                    sbase = sb[s];
-                }
-                if (!ok) j -= rn[s];
+            for (int s = NSUB - 2; s >= 0; --s) {
+                const uint32_t as = (uint32_t)__builtin_amdgcn_readfirstlane((int)adj[s]), es = (uint32_t)__builtin_amdgcn_readfirstlane((int)end[s]);
+                o                 = j < es ? as : o;
             }
-            return BASED ? (size_t)sbase + off : (size_t)slot * region + off;
+            return j + o;
         };
         auto load = [&](uint32_t j) -> unsigned long long {  // record j of the bin as (key << pb | position)
             if (!KEY4) return recsB[locate(j)];
@@ -955,15 +954,15 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
         if (ktotal > kReps) __threadfence();  // the initial values of the result entries precede the atomics below
         // pass 2: every window of a surviving key: lowest position of the key; the position joins the wave's list
         const uint32_t fcode = (a * (uint32_t)kBi2BBins + b) << 10;
-        auto settle = [&](bool valid, uint32_t pos, uint32_t s) {
-            uint32_t c = 0;
-            if (valid) c = cntT[s];
+        // c: the record's table entry after the ranking (kBi2Kept | rank of a surviving key); direct: the bin's records are all in registers (no hot key: the lowest
+        // position goes straight into an LDS minimum — a hot key's windows, which all aim at one word, look first)
+        auto settle = [&](bool valid, uint32_t pos, uint32_t c, bool direct) {
             const bool     kept = (c & kBi2Kept) != 0;
             const uint32_t r    = c & ~kBi2Kept;
             if (KEY4 && valid) code_at[pos] = kept ? (fcode | r) : kInvalid;  // (a run's records lie one after the other: the stores of a row are coalesced)
             if (kept) {  // (read first: a hot key's windows all aim at one word, and after the first rows hardly any of them lowers it)
                 if (r < kReps) {
-                    if (pos < repS[r]) atomicMin(&repS[r], pos);
+                    if (direct || pos < repS[r]) atomicMin(&repS[r], pos);
                 } else if (pos < __hip_atomic_load(&sp_rep[spo + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     atomicMin(&sp_rep[spo + r], pos);
                 }
@@ -997,9 +996,15 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
                 }
             }
         };
+        {
+            uint32_t cq[ROWS];  // all rows' entries are requested before the first is looked at (one LDS round trip per bin instead of one per row)
 #pragma unroll
-        for (int q = 0; q < ROWS; ++q)
-            if ((uint32_t)(q * kWave) < total) settle(sl[q] != kInvalid, (uint32_t)(x[q] & pmask), sl[q]);
+            for (int q = 0; q < ROWS; ++q) cq[q] = ((uint32_t)(q * kWave) < total && sl[q] != kInvalid) ? cntT[sl[q]] : 0u;
+            const bool direct = total <= (uint32_t)(ROWS * kWave);
+#pragma unroll
+            for (int q = 0; q < ROWS; ++q)
+                if ((uint32_t)(q * kWave) < total) settle(sl[q] != kInvalid, (uint32_t)(x[q] & pmask), cq[q], direct);
+        }
         BI2_W(8);
         if (total > (uint32_t)(ROWS * kWave)) {
             unsigned long long y[4];
@@ -1021,7 +1026,7 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
                     if ((uint32_t)(j0 + k * kWave) < total) {
                         const bool     valid = z[k] != ~0ull;
                         const uint32_t key   = (uint32_t)(z[k] >> pb) & 0x7FFFFFFFu;
-                        settle(valid, (uint32_t)(z[k] & pmask), valid ? bi2_find(keyT, key, bi2_bucket_of(key, lgb, bmask), bmask) : 0u);
+                        settle(valid, (uint32_t)(z[k] & pmask), valid ? cntT[bi2_find(keyT, key, bi2_bucket_of(key, lgb, bmask), bmask)] : 0u, false);
                     }
                 }
             }

@@ -21,6 +21,8 @@
 #include <string>
 #include <unordered_set>
 #include <vector>
+#include <cstring>
+#include <thread>
 
 #include "colibri_hip.h"
 #include "patternstore.h"
@@ -89,6 +91,12 @@ struct TrainResult {
     std::vector<uint16_t>      ref_token;
     std::shared_ptr<void>      device;  ///< (optional) the device context that still holds this model in HBM, for follow-up passes that need no host round trip
     size_t                     size() const { return counts.size(); }
+    TrainResult()                              = default;
+    TrainResult(const TrainResult&)            = default;
+    TrainResult(TrainResult&&)                 = default;
+    TrainResult& operator=(const TrainResult&) = default;
+    TrainResult& operator=(TrainResult&&)      = default;
+    ~TrainResult();  ///< the arrays go back to the process' result pool (colibri_host.cpp): the next export writes into pages that are already mapped
 };
 
 /** MINLENGTH > 1 in an unconstrained run: the reference counts the shorter orders (the look-back needs them) and prunes them away afterwards
@@ -150,6 +158,84 @@ inline void write_value_from_result(std::ostream& out, const TrainResult& r, siz
         k += n;
     }
 }
+/** Look-ups on a device result that is still flat arrays: an open-addressed table (slot -> pattern number + 1) over the keys, built by several host threads the first
+ *  time a caller asks for a pattern. The reference's callers look patterns up right after train() (src/test.cpp:1214-1232, src/benchmarks.cpp:232-236); turning the
+ *  9.4 M patterns of a 10^8-token model into unordered_map nodes first cost 2.6-3.1 s (one heap Pattern per node), this costs tens of milliseconds. The node map is
+ *  still built when a caller iterates, inserts or asks for an iterator / a non-trivial value object. */
+class FlatIndex {
+  public:
+    explicit FlatIndex(const TrainResult& r) : r_(r) { build(); }
+    /** pattern number of the key, or (size_t)-1 */
+    size_t find(const unsigned char* key, size_t n) const {
+        if (r_.size() == 0) return (size_t)-1;
+        for (uint64_t s = hash(key, n) & mask_;; s = (s + 1) & mask_) {
+            const uint32_t e = table_.get()[s];
+            if (e == 0) return (size_t)-1;
+            const size_t j = e - 1;
+            if ((size_t)(r_.key_off[j + 1] - r_.key_off[j]) == n && std::memcmp(r_.key_bytes.data() + r_.key_off[j], key, n) == 0) return j;
+        }
+    }
+
+  private:
+    static uint64_t hash(const unsigned char* p, size_t n) {  // (any well-mixed hash: the table is private to this process)
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+        while (n >= 8) {
+            uint64_t w;
+            std::memcpy(&w, p, 8);
+            h = (h ^ w) * 0xff51afd7ed558ccdULL;
+            h ^= h >> 32;
+            p += 8;
+            n -= 8;
+        }
+        uint64_t w = 0;
+        std::memcpy(&w, p, n);
+        h = (h ^ w) * 0xc4ceb9fe1a85ec53ULL;
+        h ^= h >> 29;
+        h *= 0xff51afd7ed558ccdULL;
+        return h ^ (h >> 32);
+    }
+    void build() {
+        const size_t n = r_.size();
+        if (n == 0 || n >= 0xFFFFFFFFull) {
+            if (n) throw InternalError();
+            return;
+        }
+        uint64_t slots = 64;
+        while (slots < n + n / 2) slots <<= 1;
+        mask_ = slots - 1;
+        table_.reset(static_cast<uint32_t*>(std::calloc(slots, sizeof(uint32_t))));  // (zero pages on first touch: the threads below fault them in)
+        if (!table_) throw std::bad_alloc();
+        unsigned nt = std::thread::hardware_concurrency();
+        nt          = std::max(1u, std::min(nt ? nt : 4u, 32u));
+        if (n < 200000) nt = 1;
+        uint32_t* const tab = table_.get();
+        auto            job = [this, tab, n, nt](unsigned t) {
+            const size_t a = n * t / nt, b = n * (t + 1) / nt;
+            for (size_t j = a; j < b; ++j) {
+                const unsigned char* k = r_.key_bytes.data() + r_.key_off[j];
+                const size_t         m = (size_t)(r_.key_off[j + 1] - r_.key_off[j]);
+                for (uint64_t s = hash(k, m) & mask_;; s = (s + 1) & mask_) {
+                    uint32_t expect = 0;
+                    if (__atomic_compare_exchange_n(&tab[s], &expect, (uint32_t)(j + 1), false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+                }
+            }
+        };
+        if (nt == 1) {
+            job(0);
+        } else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t) th.emplace_back(job, t);
+            for (auto& x : th) x.join();  // (join = the table's writes are visible to the caller)
+        }
+    }
+    struct Free {
+        void operator()(uint32_t* p) const { std::free(p); }
+    };
+    const TrainResult&              r_;
+    std::unique_ptr<uint32_t, Free> table_;
+    uint64_t                        mask_ = 0;
+};
+
 template <class V>
 struct is_indexed_value {
     static const bool value = false;
@@ -175,9 +261,19 @@ class PatternModel : public MapType, public PatternModelInterface {
                                            // empty, so types() does not compute them again — a pattern list without one-token lines keeps 0 types
     ValueHandler  valuehandler;
     std::shared_ptr<colibri_host::TrainResult> result;  // device results not yet turned into map nodes
+    mutable std::shared_ptr<colibri_host::FlatIndex> flatindex;  // ... and the look-up table over them (built by the first has() / occurrencecount())
+    /** pattern number in the pending device result, (size_t)-1 if absent; only meaningful while `result` is set */
+    size_t flat_find(const Pattern& p) const {
+        if (!flatindex) flatindex = std::make_shared<colibri_host::FlatIndex>(*result);
+        return flatindex->find(p.data, p.bytesize());
+    }
+    static unsigned int flat_count(const colibri_host::TrainResult& r, size_t j) {
+        return colibri_host::is_indexed_value<ValueType>::value ? (r.ref_off.empty() ? 0u : (unsigned int)(r.ref_off[j + 1] - r.ref_off[j])) : (unsigned int)r.counts[j];
+    }
 
     void install_result(std::shared_ptr<colibri_host::TrainResult> r) {
         result = r;
+        flatindex.reset();
         this->data.clear();
         PatternModel* self = this;
         this->pending_size = [r]() { return r->size(); };
@@ -188,6 +284,7 @@ class PatternModel : public MapType, public PatternModelInterface {
                 colibri_host::value_from_result(*r, j, v);
                 self->data.emplace(Pattern(r->key_bytes.data() + r->key_off[j], (size_t)(r->key_off[j + 1] - r->key_off[j])), std::move(v));
             }
+            self->flatindex.reset();
             self->result.reset();
         };
     }
@@ -226,8 +323,8 @@ class PatternModel : public MapType, public PatternModelInterface {
     PatternModelInterface* getinterface() { return (PatternModelInterface*)this; }
 
     size_t       size() const override { return MapType::size(); }
-    bool         has(const Pattern& p) const override { return MapType::has(p); }
-    bool         has(const PatternPointer& p) const override { return MapType::has(p); }
+    bool         has(const Pattern& p) const override { return result ? flat_find(p) != (size_t)-1 : MapType::has(p); }
+    bool         has(const PatternPointer& p) const override { return this->has(Pattern(p)); }
     int          maxlength() const override { return maxn; }
     int          minlength() const override { return minn; }
     unsigned int types() override {  // a loaded model without a type count falls back to the word types its patterns hold (reference :1700-1704)
@@ -268,6 +365,10 @@ class PatternModel : public MapType, public PatternModelInterface {
         return NULL;
     }
     unsigned int occurrencecount(const Pattern& pattern) override {
+        if (result) {  // a model fresh from the device: answered from its flat arrays
+            const size_t j = flat_find(pattern);
+            return j == (size_t)-1 ? 0u : flat_count(*result, j);
+        }
         ValueType* v = getdata(pattern, false);
         return v ? valuehandler.count(*v) : 0;
     }
@@ -335,6 +436,7 @@ class PatternModel : public MapType, public PatternModelInterface {
                 loaded_patterns = this->size();
                 this->data.clear();
                 result.reset();
+                flatindex.reset();
                 this->pending_fill = nullptr;
                 this->pending_size = nullptr;
                 maxn = 0;
@@ -596,6 +698,7 @@ class PatternModel : public MapType, public PatternModelInterface {
         int mintokens = options.MINTOKENS == -1 ? 0 : options.MINTOKENS;
         this->data.clear();
         result.reset();
+        flatindex.reset();
         this->pending_fill = nullptr;
         this->pending_size = nullptr;
         const bool file_indexed = model_type == INDEXEDPATTERNMODEL;
@@ -1162,6 +1265,7 @@ class IndexedPatternModel : public PatternModel<IndexedData, IndexedDataHandler,
             // the model has not been turned into map nodes yet: the flexgrams are appended to its flat arrays (no pattern of a freshly trained model
             // is a flexgram — a corpus with a literal {**} token is refused at upload — so every one of them is new)
             colibri_host::TrainResult& r   = *this->result;
+            this->flatindex.reset();  // (built over the arrays as they were)
             const size_t               np  = r.size(), nf = flex.size();
             const uint64_t             kb  = r.key_off[np], nr = r.ref_off[np], fkb = flex.key_off[nf], fnr = flex.ref_off[nf];
             r.key_bytes.resize((size_t)(kb + fkb) + 1);

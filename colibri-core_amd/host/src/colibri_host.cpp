@@ -1,12 +1,15 @@
 // colibri_host.cpp — non-template parts of the C++ face: key-type helpers, corpus / model file formats, and the glue
 // that drives libcolibri_hip.so through its C ABI (include/colibri_hip.h). No counting happens here.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
 #include <iterator>
 #include <map>
+#include <mutex>
 #include <sstream>
 
 #include "algorithms.h"
@@ -427,6 +430,80 @@ struct CtxGuard {
     colibri_ctx* c = nullptr;
     ~CtxGuard() { colibri_destroy(c); }
 };
+// One idle device context per GPU is kept between plain train() calls of a process: creating a context, reserving its working buffers in HBM and releasing them again
+// cost ~15 ms of a ~34 ms call on a 10^8-token corpus (COLIBRI_HOST_TIMING=1), and a caller that trains model after model pays them every time. A context that ran
+// with a constraint / filter / continuation set, or that failed, is never returned here. The cached context is not destroyed at exit (the HIP runtime may already be
+// gone when static destructors run; the driver reclaims the memory). COLIBRI_CTX_CACHE=0 turns this off.
+struct CtxCache {
+    std::mutex                  m;
+    std::map<int, colibri_ctx*> idle;
+    static CtxCache& get() {
+        static CtxCache* c = new CtxCache;  // (leaked on purpose, see above)
+        return *c;
+    }
+    static bool on() {
+        static const bool v = [] {
+            const char* e = std::getenv("COLIBRI_CTX_CACHE");
+            return !(e && e[0] == '0');
+        }();
+        return v;
+    }
+    colibri_ctx* take(int device) {
+        if (!on()) return nullptr;
+        std::lock_guard<std::mutex> l(m);
+        auto                        it = idle.find(device);
+        if (it == idle.end()) return nullptr;
+        colibri_ctx* c = it->second;
+        idle.erase(it);
+        return c;
+    }
+    void give(int device, colibri_ctx* c) {  // takes ownership
+        if (c == nullptr) return;
+        if (on()) {
+            std::lock_guard<std::mutex> l(m);
+            if (idle.find(device) == idle.end()) {
+                idle[device] = c;
+                return;
+            }
+        }
+        colibri_destroy(c);
+    }
+};
+// The arrays of the last released result (one set per process) wait for the next export: 150 MB of keys / offsets / counts for a 10^8-token model are ~37 000 fresh
+// pages otherwise — 27-31 ms of page faults per train() once nothing else keeps the heap warm, twice the device work. They are handed over with their old size (no
+// zero fill: the export overwrites every element). COLIBRI_RESULT_POOL=0 turns this off.
+struct ResultPool {
+    std::mutex                 m;
+    bool                       full = false;
+    std::vector<uint64_t>      key_off, ref_off;
+    std::vector<unsigned char> key_bytes;
+    std::vector<uint32_t>      counts, ref_sentence;
+    std::vector<uint16_t>      ref_token;
+    static ResultPool& get() {
+        static ResultPool* p = new ResultPool;  // (leaked on purpose: released models may outlive static destructors)
+        return *p;
+    }
+    static bool on() {
+        static const bool v = [] {
+            const char* e = std::getenv("COLIBRI_RESULT_POOL");
+            return !(e && e[0] == '0');
+        }();
+        return v;
+    }
+};
+void take_result_buffers(TrainResult& out) {
+    if (!ResultPool::on()) return;
+    ResultPool&                 p = ResultPool::get();
+    std::lock_guard<std::mutex> l(p.m);
+    if (!p.full) return;
+    out.key_off.swap(p.key_off);
+    out.key_bytes.swap(p.key_bytes);
+    out.counts.swap(p.counts);
+    out.ref_off.swap(p.ref_off);
+    out.ref_sentence.swap(p.ref_sentence);
+    out.ref_token.swap(p.ref_token);
+    p.full = false;
+}
 [[noreturn]] void raise(colibri_ctx* c, int rc, const char* what) {
     std::cerr << "ERROR: " << what << " failed (status " << rc << "): " << (c ? colibri_last_error(c) : "no MI355X / HIP device available; there is no CPU fallback") << std::endl;
     throw InternalError();
@@ -455,13 +532,38 @@ void device_flexgrams_resident(const std::shared_ptr<void>& device, TrainResult&
     fetch_flexgrams(c, nf, kb, nr, out);
 }
 
+TrainResult::~TrainResult() {
+    if (!ResultPool::on() || key_off.capacity() + key_bytes.capacity() + ref_sentence.capacity() < (1u << 18)) return;  // (small results are not worth keeping)
+    ResultPool&                 p = ResultPool::get();
+    std::lock_guard<std::mutex> l(p.m);
+    if (p.full) return;
+    p.key_off.swap(key_off);
+    p.key_bytes.swap(key_bytes);
+    p.counts.swap(counts);
+    p.ref_off.swap(ref_off);
+    p.ref_sentence.swap(ref_sentence);
+    p.ref_token.swap(ref_token);
+    p.full = true;
+}
+
 void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out, const ConstraintKeys* constraint,
                   bool keep_device, bool continuation, bool as_filter) {
     CtxGuard    g;
     const char* dev = std::getenv("COLIBRI_DEVICE");
-    int         rc  = colibri_create(&g.c, dev ? std::atoi(dev) : 0);
+    // COLIBRI_HOST_TIMING=1: where a call's wall time goes (context, upload, train, export), one line on stderr
+    static const bool timing = std::getenv("COLIBRI_HOST_TIMING") != nullptr;
+    typedef std::chrono::steady_clock clk;
+    const auto  t0 = clk::now();
+    auto        ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const int   device = dev ? std::atoi(dev) : 0;
+    const bool  plain  = constraint == NULL && !keep_device;  // (the modes a set of keys switches on stay with a context: such a context is not shared)
+    int         rc     = COLIBRI_OK;
+    if (plain) g.c = CtxCache::get().take(device);
+    if (g.c == nullptr) rc = colibri_create(&g.c, device);
     if (rc != COLIBRI_OK) raise(nullptr, rc, "colibri_create");
+    const auto t1 = clk::now();
     if ((rc = colibri_upload_corpus(g.c, payload, nbytes, firstsentence)) != COLIBRI_OK) raise(g.c, rc, "colibri_upload_corpus");
+    const auto t2 = clk::now();
     if (constraint != NULL && as_filter) {
         const uint64_t             np   = constraint->off.empty() ? 0 : constraint->off.size() - 1;
         static const unsigned char none = 0;
@@ -493,15 +595,37 @@ void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_o
         if ((rc = colibri_set_constraint(g.c, constraint->off.data(), constraint->bytes.empty() ? &none : constraint->bytes.data(), np)) != COLIBRI_OK) raise(g.c, rc, "colibri_set_constraint");
     }
     if ((rc = colibri_train(g.c, &opt, &out.stats)) != COLIBRI_OK) raise(g.c, rc, "colibri_train");
+    const auto t3 = clk::now();
     uint64_t np = 0, kb = 0, nr = 0;
     if ((rc = colibri_result_sizes(g.c, &np, &kb, &nr)) != COLIBRI_OK) raise(g.c, rc, "colibri_result_sizes");
-    out.key_off.assign(np + 1, 0);
-    out.key_bytes.assign(kb + 1, 0);
-    out.counts.assign(np, 0);
+    const auto t4 = clk::now();
+    take_result_buffers(out);  // (arrays of a released model, pages mapped; every element below is written by the export)
+    out.key_off.resize(np + 1);
+    out.key_bytes.resize(kb + 1);
+    out.key_bytes[kb] = 0;
+    out.counts.resize(np);
+    if (!opt.indexed) {  // (an unindexed result has no reference arrays at all: value_from_result() asks ref_off.empty())
+        out.ref_off.clear();
+        out.ref_sentence.clear();
+        out.ref_token.clear();
+    }
+    const auto t5 = clk::now();
+    struct Report {
+        bool on; clk::time_point t0, t1, t2, t3, t4, t5;
+        ~Report() {
+            if (!on) return;
+            auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            fprintf(stderr, "COLIBRI_HOST_TIMING create %.2f upload %.2f train %.2f sizes %.2f alloc %.2f export %.2f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5),
+                    ms(t5, clk::now()));
+        }
+    } report{timing, t0, t1, t2, t3, t4, t5};
+    (void)ms;
     if (opt.indexed) {
-        out.ref_off.assign(np + 1, 0);
-        out.ref_sentence.assign(nr + 1, 0);
-        out.ref_token.assign(nr + 1, 0);
+        out.ref_off.resize(np + 1);
+        out.ref_sentence.resize(nr + 1);
+        out.ref_token.resize(nr + 1);
+        out.ref_sentence[nr] = 0;
+        out.ref_token[nr]    = 0;
         rc = colibri_export_indexed(g.c, out.key_off.data(), out.key_bytes.data(), out.counts.data(), out.ref_off.data(), out.ref_sentence.data(), out.ref_token.data());
         if (rc != COLIBRI_OK) raise(g.c, rc, "colibri_export_indexed");
         if (keep_device) {  // the caller may follow up on the resident model (computeflexgrams_fromskipgrams); released with the pending result
@@ -512,6 +636,10 @@ void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_o
         uint32_t dummy = 0;
         rc = colibri_export_unindexed(g.c, out.key_off.data(), out.key_bytes.data(), np ? out.counts.data() : &dummy);
         if (rc != COLIBRI_OK) raise(g.c, rc, "colibri_export_unindexed");
+    }
+    if (plain && g.c != nullptr) {  // everything went well: the context waits for the next call
+        CtxCache::get().give(device, g.c);
+        g.c = nullptr;
     }
 }
 

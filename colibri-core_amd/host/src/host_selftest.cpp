@@ -99,6 +99,51 @@ int main(int argc, char** argv) {
             return 1;
         }
     }
+    if (mode == "lookup" && argc >= 6) {
+        // lookup <corpus> <u|i> <maxlength> <mintokens>: has() / occurrencecount() on a model FRESH from the device (answered from its flat arrays through the look-up table,
+        // host/include/patternmodel.h FlatIndex) against the same model turned into map nodes by iteration — every pattern, and for every pattern two keys that are not in it
+        try {
+            PatternModelOptions options;
+            options.MAXLENGTH = std::atoi(argv[4]);
+            options.MINTOKENS = std::atoi(argv[5]);
+            options.QUIET     = true;
+            IndexedCorpus corpus{std::string(argv[2])};
+            size_t        checked = 0, absent = 0;
+            auto          run     = [&](auto& fresh, auto& walked) {
+                fresh.train(std::string(argv[2]), options);
+                walked.train(std::string(argv[2]), options);
+                for (auto it = walked.begin(); it != walked.end(); ++it) {  // (begin() builds the node map of `walked`; `fresh` stays flat)
+                    const Pattern& p = it->first;
+                    CHECK(fresh.has(p));
+                    CHECK(fresh.occurrencecount(p) == walked.occurrencecount(p));
+                    ++checked;
+                    std::string longer((const char*)p.data, p.bytesize());
+                    longer.push_back((char)0x7e);  // one more token, class 126
+                    const Pattern q((const unsigned char*)longer.data(), longer.size());
+                    CHECK(fresh.has(q) == walked.has(q));
+                    CHECK(fresh.occurrencecount(q) == walked.occurrencecount(q));
+                    std::string other = longer;
+                    other[0]          = (char)(other[0] == 0x7d ? 0x7c : 0x7d);
+                    const Pattern o((const unsigned char*)other.data(), other.size());
+                    CHECK(fresh.has(o) == walked.has(o));
+                    absent += !walked.has(q);
+                }
+                CHECK(fresh.size() == walked.size());
+            };
+            if (std::string(argv[3]) == "i") {
+                IndexedPatternModel<> fresh(&corpus), walked(&corpus);
+                run(fresh, walked);
+            } else {
+                PatternModel<uint32_t> fresh(&corpus), walked(&corpus);
+                run(fresh, walked);
+            }
+            std::cout << (fails ? "FAILED" : "OK") << " " << checked << " " << absent << std::endl;
+            return fails ? 1 : 0;
+        } catch (const std::exception& e) {
+            std::cout << "EXCEPTION " << e.what() << std::endl;
+            return 1;
+        }
+    }
     if (mode == "bench" && argc >= 5) {
         // what a caller of the reference's API pays: PatternModel<uint32_t>::train() on a preloaded corpus (src/benchmarks.cpp:228-237) through this C++ face — a device
         // context, the upload, colibri_train, the export of keys and counts to host memory — and the first look-up (the pattern map is materialised lazily)

@@ -106,6 +106,17 @@ def test_cxx_api_preloaded_corpus(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("corpus,kind,l,t", [("hamlet.v2", "u", 5, 2), ("zipf20k", "u", 5, 1), ("phrases15k", "i", 4, 2), ("zipf20k", "i", 3, 1)])
+def test_cxx_api_lookups_on_a_fresh_model_match_the_node_map(corpus, kind, l, t):
+    """has() / occurrencecount() right after train() (reference include/patternmodel.h:1994-2050; its callers: src/test.cpp:1214-1232) are answered from the flat result
+    arrays (host/include/patternmodel.h FlatIndex) — every pattern and two absent keys per pattern against the same model as unordered_map nodes."""
+    out = subprocess.run([SELFTEST, "lookup", os.path.join(GOLDEN, corpus + ".colibri.dat"), kind, str(l), str(t)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    verdict, checked, absent = out.stdout.split()
+    assert verdict == "OK" and int(checked) > 100 and int(absent) > 0
+
+
+@pytest.mark.gpu
 def test_cxx_api_errors_are_internalerror(tmp_path):
     out = subprocess.run([SELFTEST, "gpu", os.path.join(GOLDEN, "hamlet.v2.colibri.dat"), str(tmp_path / "m"), "is", "5", "2", "b2"], capture_output=True, text=True)
     assert out.returncode == 1 and "EXCEPTION" in out.stdout  # MAXBACKOFFLENGTH < MAXLENGTH with skipgrams is outside the accelerated subset: loud failure, no fallback

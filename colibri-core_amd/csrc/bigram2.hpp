@@ -501,13 +501,17 @@ constexpr int kBi2LbPer = COLIBRI_LB_PER, kBi2LbTile = kBi2Threads * kBi2LbPer;
 // boff: [nslots][513] exclusive offsets of the slot's B bins inside the slot (same slot layout in recsB as in recsA).
 // B bin of a record: the nine mix bits below the A bin, shifted down by bshift when an order has few records.
 // slotbase (optional; key-sharded runs, kshard.hpp): the slots are the chunks of a receive buffer — slot s starts at record slotbase[s] instead of s * region
+// CB (key-sharded runs only): the (B, C) histogram and its 16 KB of LDS. One block per CU either way (90 / 106 KB). Round 5 measured TWO blocks per CU (74 KB each
+// without the staged bins' array, B bins recomputed from the records): 0.86 against 0.74 ms per step over all orders — 512 slots of ~660 KB in flight no longer fit the
+// 256 MB Infinity Cache the second sweep reads from.
+template <bool CB = false>
 __global__ __launch_bounds__(kBi2Threads, kBi2LbPer == 4 ? kBi2Threads / 128 : 1) void bi2_levelB_kernel(const unsigned long long* recsA, unsigned long long* __restrict__ recsB, uint32_t region,
                                                                                      const Bi2State* __restrict__ bs, uint32_t* __restrict__ boff, const DevState* __restrict__ st,
                                                                                      const uint32_t* __restrict__ slotbase = nullptr,
                                                                                      uint32_t* __restrict__ cbhist = nullptr /* key-sharded runs (kshard2.hpp), [nslots][512 x 8]: also the
                                                                                          slot's records per (B, C), C = the cskip mix bits below the B bin's — the sweep reads them anyway */) {
     if (st->done) return;
-    __shared__ uint32_t           cbL[8 * kBi2BBins];
+    __shared__ uint32_t           cbL[CB ? 8 * kBi2BBins : 1];
     __shared__ unsigned long long stgL[kBi2LbTile];
     __shared__ uint16_t           binL[kBi2LbTile];
     __shared__ uint32_t           histL[kBi2BBins], offL[kBi2BBins], curL[kBi2BBins], gbL[kBi2BBins], wsumL[8];
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2LbPer == 4 ? kBi2Threads / 128 : 1
     uint32_t* const bo   = boff + (size_t)slot * (kBi2BBins + 1);
     if (threadIdx.x < kBi2BBins) histL[threadIdx.x] = 0;
     const uint32_t cmask = (1u << bs->cskip) - 1u;
-    if (cbhist != nullptr)
+    if (CB && cbhist != nullptr)
         for (uint32_t e = threadIdx.x; e < (cmask + 1u) * kBi2BBins; e += kBi2Threads) cbL[e] = 0;
     __syncthreads();
     // sweep 1: histogram of the slot, two tiles of loads ahead of their LDS atomics
@@ -536,12 +540,12 @@ __global__ __launch_bounds__(kBi2Threads, kBi2LbPer == 4 ? kBi2Threads / 128 : 1
             if (j < n) {
                 const uint32_t b = ((uint32_t)(r[k] >> bbit) & 511u) >> bsh;
                 atomicAdd(&histL[b], 1u);
-                if (cbhist != nullptr) atomicAdd(&cbL[(b << bs->cskip) | ((uint32_t)(r[k] >> (bbit + bsh - bs->cskip)) & cmask)], 1u);
+                if (CB && cbhist != nullptr) atomicAdd(&cbL[(b << bs->cskip) | ((uint32_t)(r[k] >> (bbit + bsh - bs->cskip)) & cmask)], 1u);
             }
         }
     }
     __syncthreads();
-    if (cbhist != nullptr)
+    if (CB && cbhist != nullptr)
         for (uint32_t e = threadIdx.x; e < (cmask + 1u) * kBi2BBins; e += kBi2Threads) cbhist[(size_t)slot * (8 * kBi2BBins) + e] = cbL[e];
     bi2_scan512(histL, offL, wsumL);
     if (threadIdx.x < kBi2BBins) {

@@ -1059,7 +1059,7 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
         }
         {
             Prof p(c, COLIBRI_K_LEVELB2);
-            hipLaunchKernelGGL(bi2_levelB_kernel, dim3(b.nslots), dim3(kBi2Threads), 0, c->stream, recsA, recsB, b.region, bs, c->b2.boff.p, c->state.p);
+            hipLaunchKernelGGL(bi2_levelB_kernel<false>, dim3(b.nslots), dim3(kBi2Threads), 0, c->stream, recsA, recsB, b.region, bs, c->b2.boff.p, c->state.p);
             hipLaunchKernelGGL(bi2_binoff_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->b2.boff.p, kBi2Sub, c->state.p);
         }
         {
@@ -1147,7 +1147,7 @@ int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next, uint
     }
     {
         Prof p(c, COLIBRI_K_LEVELB2);
-        hipLaunchKernelGGL(bi2_levelB_kernel, dim3(b.nslots), dim3(kBi2Threads), 0, c->stream, recsA, recsB, b.region, bs, c->b2.boff.p, c->state.p);
+        hipLaunchKernelGGL(bi2_levelB_kernel<false>, dim3(b.nslots), dim3(kBi2Threads), 0, c->stream, recsA, recsB, b.region, bs, c->b2.boff.p, c->state.p);
         hipLaunchKernelGGL(bi2_binoff_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->b2.boff.p, kBi2Sub, c->state.p);
     }
     {
@@ -1211,7 +1211,7 @@ int skip_pass_chain(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, c
                            l_is_cls ? 1u : 0u, r_is_cls ? 1u : 0u, b.clsbits, b.posbits, recsA, b.region, kBi2Sub, bs, c->state.p, (uint32_t*)nullptr);
     }
     hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, b.region, kBi2Sub, c->state.p);
-    hipLaunchKernelGGL(bi2_levelB_kernel, dim3(b.nslots), dim3(kBi2Threads), 0, c->stream, recsA, recsB, b.region, bs, c->b2.boff.p, c->state.p);
+    hipLaunchKernelGGL(bi2_levelB_kernel<false>, dim3(b.nslots), dim3(kBi2Threads), 0, c->stream, recsA, recsB, b.region, bs, c->b2.boff.p, c->state.p);
     hipLaunchKernelGGL(bi2_binoff_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->b2.boff.p, kBi2Sub, c->state.p);
     // (the hot bins' workgroups beside the wave kernel on the second stream, as in chain_order: 0.05 ms per pass of n = 4)
     HIP_TRY(c, hipEventRecord(c->b2.ev_fork, c->stream));
@@ -1304,7 +1304,7 @@ int bigram2_order_split(colibri_ctx* c, const TrainPlan& pl, bool want_list) {
             hipLaunchKernelGGL(ks_local_init2_kernel, dim3(1), dim3(kKsThreads), 0, c->stream, obs, ks.slotbase.p, (const KsSplitState*)ks.split.p, v, s, K - s, b.posbits + s, (const uint32_t*)keep,
                                roomB, c->state.p);
             hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, obs, 0xFFFFFFFFu, kBi2SubWide, (const DevState*)c->state.p);
-            hipLaunchKernelGGL(bi2_levelB_kernel, dim3(kKsSlots), dim3(kBi2Threads), 0, c->stream, (const unsigned long long*)seg, segB, 0xFFFFFFFFu, (const Bi2State*)obs, ks.oboff.p,
+            hipLaunchKernelGGL(bi2_levelB_kernel<false>, dim3(kKsSlots), dim3(kBi2Threads), 0, c->stream, (const unsigned long long*)seg, segB, 0xFFFFFFFFu, (const Bi2State*)obs, ks.oboff.p,
                                (const DevState*)c->state.p, (const uint32_t*)ks.slotbase.p);
             hipLaunchKernelGGL(bi2_binoff_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, obs, (const uint32_t*)ks.oboff.p, kBi2SubWide, (const DevState*)c->state.p);
         }

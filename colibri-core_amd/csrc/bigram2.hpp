@@ -101,6 +101,7 @@ struct __attribute__((aligned(16))) Bi2State {
     uint32_t bshift_fix; // key-sharded runs: bshift + 1 as every rank agreed on it (0: bi2_offsets_kernel derives it from this pass's record count)
     uint32_t ran;        // set by bi2_finish_kernel: this order was counted (the run had not ended before it) — what bi2_compact_kernel asks when it runs beside the path
     uint32_t hugebin;   // records from which a final bin goes to bi2_count_big_kernel; 0: kBi2HugeBin (written with kbits by the emit kernel of the order)
+    uint32_t head_windows;              // key-sharded runs, order 2 (ks_finish2_kernel): the windows of the surviving head pairs over ALL ranks — what order 3 adds to the owners' lists
     uint32_t nextchunk;                 // owner passes of key-sharded runs: next free chunk of the position-list pool (bi2_count_kernel<.., BASED>)
     uint32_t nextbin[kBi2Shards * 16];  // work queues of the count kernel (one per shard, 64 bytes apart): next group of bins to hand out
     uint32_t big[kBi2BigCap];           // final bins with more than kBi2BigBin records: counted first (one wave each), so that none of them starts late

@@ -215,7 +215,7 @@ struct colibri_ctx {
     struct KShard {
         bool     active = false, first_gen = false, pending_uni = false, ran = false;  // ran: the context's trained model comes from a key-sharded run
         int      world = 1, rank = 0, n = 0, cur = 0;
-        uint32_t w = 0, nclasses = 0, uni_shift = 0, clsbits = 0, posbits = 0, kbits = 0, owcap = 0, fin_total = 0, syncs = 0;
+        uint32_t w = 0, nclasses = 0, uni_shift = 0, clsbits = 0, posbits = 0, kbits = 0, owcap = 0, fin_total = 0, syncs = 0, head_windows = 0;
         DevBuf<KsSplitState> split;
         DevBuf<KsRouteState> rstate;  // [0] feedback, [1] exports
         DevBuf<KsStats>      stats;
@@ -994,12 +994,32 @@ int chain_compact_join(colibri_ctx* c) {
     c->b2.compact_pending = false;
     return COLIBRI_OK;
 }
+// Grids of the kernels that walk chain_steps_kernel's tables: block b works for XCD b % 8 and emits into sub-region b % nsub, so a grid must be a multiple of both —
+// a tuning override that is not would make blocks repeat other blocks' steps (duplicated records). The environment value is rounded up to the next multiple of 8 (which
+// kBi2Sub and kBi2SubWide divide); 0 or garbage falls back to the default.
+inline uint32_t chain_grid(const char* env_name, uint32_t dflt) {
+    const char* e = getenv(env_name);
+    const long  v = e ? atol(e) : 0;
+    if (v <= 0 || v > 65536) return dflt;
+    return (uint32_t)((v + 7) / 8 * 8);
+}
+static_assert(8 % COLIBRI_BI2_SUB == 0, "chain_grid rounds to multiples of 8");
+// chain_emit_kernel's measurement switches (bit 0 / 1: skip the bitmap / class gather — WRONG models, right clocks; bits 8+: the hot-bin limit) exist in experimental
+// builds only (-DCOLIBRI_DEBUG_KNOBS): a stray environment variable must not be able to change a product run's result.
+inline uint32_t chain_dbg() {
+#ifdef COLIBRI_DEBUG_KNOBS
+    static const uint32_t v = getenv("COLIBRI_CH_DBG") ? (uint32_t)atoi(getenv("COLIBRI_CH_DBG")) : 0u;
+    return v;
+#else
+    return 0u;
+#endif
+}
 // result index per position from the (position, dense number) pairs an order left in the position lists (chain_ids_kernel), `ids` pre-filled with kInvalid
 void chain_ids(colibri_ctx* c, const Bigram2Plan& b, const Bi2State* bs, uint32_t* ids, const uint32_t* headid) {
     const uint32_t cap = chain_steps_cap(b.pl);
     hipLaunchKernelGGL(chain_steps_kernel, dim3(kChXcds), dim3(kBi2Threads), 0, c->stream, bs, b.pl, b.nbuckets, reinterpret_cast<uint2*>(c->b2.steps.p), cap,
                        c->b2.steps.p + 2 * (size_t)kChXcds * cap, (const DevState*)c->state.p);
-    static const uint32_t ids_grid = getenv("COLIBRI_IDS_GRID") ? (uint32_t)atoi(getenv("COLIBRI_IDS_GRID")) : 1024u;  // (a multiple of 8)
+    static const uint32_t ids_grid = chain_grid("COLIBRI_IDS_GRID", 1024u);
     hipLaunchKernelGGL(chain_ids_kernel, dim3(ids_grid), dim3(kChThreads), 0, c->stream, (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p,
                        reinterpret_cast<const uint2*>(c->b2.steps.p), cap, (const uint32_t*)(c->b2.steps.p + 2 * (size_t)kChXcds * cap), bs, (const DevState*)c->state.p, ids, headid);
 }
@@ -1010,7 +1030,7 @@ void chain_pairs(colibri_ctx* c, const Bigram2Plan& b, const Bi2State* bs, const
     const uint64_t pcap = c->pairs[0].n;
     hipLaunchKernelGGL(chain_steps_kernel, dim3(kChXcds), dim3(kBi2Threads), 0, c->stream, bs, b.pl, b.nbuckets, reinterpret_cast<uint2*>(c->b2.steps.p), cap,
                        c->b2.steps.p + 2 * (size_t)kChXcds * cap, (const DevState*)c->state.p);
-    static const uint32_t grid = getenv("COLIBRI_IDS_GRID") ? (uint32_t)atoi(getenv("COLIBRI_IDS_GRID")) : 1024u;  // (a multiple of 8)
+    static const uint32_t grid = chain_grid("COLIBRI_IDS_GRID", 1024u);
     hipLaunchKernelGGL(chain_pairs_kernel, dim3(grid), dim3(kChThreads), 0, c->stream, (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p,
                        reinterpret_cast<const uint2*>(c->b2.steps.p), cap, (const uint32_t*)(c->b2.steps.p + 2 * (size_t)kChXcds * cap), bs, (const DevState*)c->state.p,
                        (const uint32_t*)c->b2.bitmap.p, (const uint32_t*)c->b2.wpre.p, (const uint32_t*)c->b2.btot.p, b.nbuckets, b.pshift,
@@ -1135,14 +1155,14 @@ int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next, uint
     hipLaunchKernelGGL(chain_reset_kernel, dim3(256), dim3(kBlock), 0, c->stream, bs, c->b2.wcnt.p, kBi2Waves + b.wextra + 1);
     {
         Prof p(c, COLIBRI_K_EMIT);
-        static const uint32_t grid = getenv("COLIBRI_CH_GRID") ? (uint32_t)atoi(getenv("COLIBRI_CH_GRID")) : 768u;  // (a multiple of kBi2Sub; three resident blocks per CU)
+        static const uint32_t grid = chain_grid("COLIBRI_CH_GRID", 768u);  // (three resident blocks per CU)
         const uint32_t cap = chain_steps_cap(b.pl);
         hipLaunchKernelGGL(chain_steps_kernel, dim3(kChXcds), dim3(kBi2Threads), 0, c->stream, prev, b.pl, b.nbuckets, reinterpret_cast<uint2*>(c->b2.steps.p), cap,
                            c->b2.steps.p + 2 * (size_t)kChXcds * cap, (const DevState*)c->state.p);
         hipLaunchKernelGGL(chain_emit_kernel, dim3(grid), dim3(kChThreads), 0, c->stream, (const uint32_t*)c->cls.p, npos, (uint32_t)n, b.clsbits, b.posbits, prev,
                            (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p, b.pl, reinterpret_cast<const uint2*>(c->b2.steps.p), cap,
                            (const uint32_t*)(c->b2.steps.p + 2 * (size_t)kChXcds * cap),
-                           (const uint32_t*)c->b2.bitmap.p, recsA, b.region, kBi2Sub, bs, c->state.p, (const uint32_t*)c->b2.headid.p, getenv("COLIBRI_CH_DBG") ? (uint32_t)atoi(getenv("COLIBRI_CH_DBG")) : 0u);
+                           (const uint32_t*)c->b2.bitmap.p, recsA, b.region, kBi2Sub, bs, c->state.p, (const uint32_t*)c->b2.headid.p, chain_dbg());
         hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, b.region, kBi2Sub, c->state.p);
     }
     {
@@ -1206,7 +1226,7 @@ int skip_pass_chain(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, c
                            b.clsbits, b.posbits, recsA, b.region, kBi2Sub, bs, c->state.p, c->b2.head_rows.p);
         hipLaunchKernelGGL(bi2_head_reduce_kernel, dim3(kBi2HeadN / kBlock, kBi2HeadSplit), dim3(kBlock), 0, c->stream, c->b2.head_rows.p, kBi2EmitGrid, bs, c->state.p);
     } else {
-        static const uint32_t grid = getenv("COLIBRI_CH_GRID") ? (uint32_t)atoi(getenv("COLIBRI_CH_GRID")) : 768u;
+        static const uint32_t grid = chain_grid("COLIBRI_CH_GRID", 768u);
         hipLaunchKernelGGL(skip_emit_kernel<false>, dim3(grid), dim3(kChThreads), 0, c->stream, (const uint32_t*)c->skl, (const uint32_t*)c->skl_n, left, offl, right, offr,
                            l_is_cls ? 1u : 0u, r_is_cls ? 1u : 0u, b.clsbits, b.posbits, recsA, b.region, kBi2Sub, bs, c->state.p, (uint32_t*)nullptr);
     }

@@ -454,13 +454,14 @@ __global__ __launch_bounds__(kBlock) void ks_finish2_kernel(DevState* __restrict
                                                              uint32_t res_cap, uint32_t* __restrict__ headsurv_keep) {
     uint32_t htot, ftot, hftot;
     block_exclusive_scan(obs->found_part[threadIdx.x], &ftot);
-    uint32_t hk = 0, hf = 0, bits = 0, mine = 0;
+    uint32_t hk = 0, hf = 0, bits = 0, mine = 0, hw = 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const uint32_t c = headg[threadIdx.x * 16 + q];
         hf += c != 0;
         if (c >= threshold) {
             bits |= 1u << q;
+            hw += c;  // (headg holds the all-reduced counts: every rank computes the same sum)
             if (headg[kBi2HeadN + threadIdx.x * 16 + q] == rank) {
                 mine |= 1u << q;
                 ++hk;
@@ -472,9 +473,12 @@ __global__ __launch_bounds__(kBlock) void ks_finish2_kernel(DevState* __restrict
     const uint32_t ho          = block_exclusive_scan(hk, &htot);
     obs->headbase[threadIdx.x] = ho;
     block_exclusive_scan(hf, &hftot);
+    uint32_t hwtot;
+    block_exclusive_scan(hw, &hwtot);
     if (threadIdx.x == 0) {
         const uint32_t tot = obs->kept_bins;
         obs->kept_head     = htot;
+        obs->head_windows  = hwtot;
         obs->res_base      = ost->res_total + ost->kept;
         ost->found += ftot + (rank == 0 ? hftot : 0u);
         ost->kept += tot + htot;

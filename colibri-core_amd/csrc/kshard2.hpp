@@ -263,6 +263,7 @@ struct Ks2FbInfo {
     uint32_t ncodes[kKsWorld];  // survivors per source
     uint32_t off[kKsWorld + 1];  // first word of each source's section of the feedback buffer: [bits: ceil(n / 32) words][numbers]
     uint32_t kept_bins;          // this owner's survivors of the order (without the head): the caller shifts the owners' numbers by them
+    uint32_t head_windows;       // order 2: the windows of the surviving head pairs, over all ranks (colibri_kshard_head_windows)
 };
 // after the scan of tcnt (scan[ntiles] = total): the sections' places
 __global__ void ks2_fb_info_kernel(const uint32_t* __restrict__ tscan, Ks2Segs sg, uint32_t world, uint32_t ntiles, const Bi2State* __restrict__ obs, Ks2FbInfo* __restrict__ fi) {
@@ -275,6 +276,7 @@ __global__ void ks2_fb_info_kernel(const uint32_t* __restrict__ tscan, Ks2Segs s
     }
     fi->off[kKsWorld] = off;
     fi->kept_bins     = obs->kept_bins;
+    fi->head_windows  = obs->head_windows;
 }
 __global__ __launch_bounds__(kKsThreads) void ks2_fb_write_kernel(const uint32_t* __restrict__ code_at, Ks2Segs sg, uint32_t ntiles, const uint32_t* __restrict__ tscan,
                                                                    const Ks2FbInfo* __restrict__ fi, const Bi2State* __restrict__ obs, uint32_t* __restrict__ fb) {

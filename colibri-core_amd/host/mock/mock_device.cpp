@@ -255,6 +255,7 @@ int colibri_kshard_count(colibri_ctx* c, int n, const uint64_t* per_src, int mor
     *kept_bins = number.size(); *fb_dev = c->fb.data(); *fb_bytes = 4; *ex_dev = c->ex.data();
     return COLIBRI_OK;
 }
+int colibri_kshard_head_windows(const colibri_ctx*, uint64_t* windows) { *windows = 0; return COLIBRI_OK; }  // (the stand-in has no dense head: every window is a record)
 int colibri_kshard_feedback_buffers(colibri_ctx* c, uint64_t nfb, uint64_t nex, void** fb_recv, void** ex_recv) {
     c->fbr.assign(nfb + 1, 0u); c->exr.assign(nex + 1, 0ull);
     *fb_recv = c->fbr.data(); *ex_recv = c->exr.data();

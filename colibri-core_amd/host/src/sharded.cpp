@@ -379,7 +379,11 @@ class RankDriver {
             exchange({{fb, &fb_dst, fb_recv, &fb_src, fb_bytes}, {ex, &ex_dst, ex_recv, &ex_src, 8}}, {}, s, false);
             // the feedback is a bit per key and a number per surviving key's window: at most that many windows reach the next order (every rank computes the same bound)
             est = more ? std::min<uint64_t>(keys_all, fb_all) + 4096 * (uint64_t)world : 0;
-            if (n == 2) est += tokens_g / 4;  // (order 2's head windows are on no owner's list; a quarter of the corpus bounds them for any corpus the dense head is made for)
+            if (n == 2 && more) {  // order 2's head windows are on no owner's list: their exact number over all ranks (round 4 added a quarter of the corpus, a guess that a
+                uint64_t hw = 0;   // small vocabulary breaks: fuller bins than the tables hold, and the whole run repeated on the candidate exchange)
+                step(colibri_kshard_head_windows(c, &hw), "colibri_kshard_head_windows");
+                est += hw;
+            }
             step(colibri_kshard_apply(c, n, fb_src.data(), ex_src.data(), kept_by.data(), more, &ids), "colibri_kshard_apply");  // (its status: the next agreement's)
         }
         std::vector<uint64_t> mine(3 * COLIBRI_MAX_ORDER, 0), found_g(COLIBRI_MAX_ORDER, 0), kept_g(COLIBRI_MAX_ORDER, 0), adm_g(COLIBRI_MAX_ORDER, 0);

@@ -24,7 +24,7 @@ EXPORTED = [
     "colibri_shard_finish", "colibri_shard_export_gids", "colibri_shard_index_sizes", "colibri_shard_export_index",
     "colibri_shard_uni_info", "colibri_shard_uni_count", "colibri_shard_uni_apply",
     "colibri_order2_records", "colibri_stream", "colibri_kshard_info", "colibri_kshard_begin", "colibri_kshard_uni_count", "colibri_kshard_uni_apply", "colibri_kshard_emit", "colibri_kshard_recv_buffers",
-    "colibri_kshard_count", "colibri_kshard_feedback_buffers", "colibri_kshard_apply", "colibri_kshard_local_stats", "colibri_kshard_finish",
+    "colibri_kshard_count", "colibri_kshard_head_windows", "colibri_kshard_feedback_buffers", "colibri_kshard_apply", "colibri_kshard_local_stats", "colibri_kshard_finish",
     "colibri_set_constraint", "colibri_set_continuation", "colibri_set_filter", "colibri_text_upload", "colibri_text_count", "colibri_text_words", "colibri_text_encode", "colibri_text_fetch", "colibri_text_as_corpus",
     "colibri_flexgrams", "colibri_flexgrams_resident", "colibri_flexgrams_fetch",
 ]

@@ -217,6 +217,9 @@ int colibri_kshard_recv_buffers(colibri_ctx* ctx, uint64_t nrecords, void** recv
  * *ex_dev; *kept_bins: the keys this owner kept (the caller gathers them over the ranks: colibri_kshard_apply's kept_per_owner) */
 int colibri_kshard_count(colibri_ctx* ctx, int n, const uint64_t* per_src, int more, void** fb_dev, uint64_t* fb_per_dst, uint32_t* fb_bytes, void** ex_dev, uint64_t* ex_per_dst,
                          uint64_t* kept_bins);
+/* after colibri_kshard_count of order 2: the windows of the surviving head pairs (both classes < 64: counted densely, on no owner's list) over ALL ranks — the same value
+ * on every rank (the head counts are all-reduced); with the feedback sizes it bounds order 3's records exactly. No device look-up: read with the count step's sizes. */
+int colibri_kshard_head_windows(const colibri_ctx* ctx, uint64_t* windows);
 int colibri_kshard_feedback_buffers(colibri_ctx* ctx, uint64_t nfeedback, uint64_t nexports, void** fb_recv_dev, void** ex_recv_dev); /* each concatenated in owner order */
 /* fb_src / ex_src [world]: feedback units / exports received from each owner; kept_per_owner[world]; *ids_global: the numbers order n handed out over all ranks */
 int colibri_kshard_apply(colibri_ctx* ctx, int n, const uint64_t* fb_src, const uint64_t* ex_src, const uint64_t* kept_per_owner, int more, uint64_t* ids_global);

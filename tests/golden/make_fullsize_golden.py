@@ -40,6 +40,11 @@ CASES = {
     # concatenated in rank order (one header). The reference needs ~35-50 GB and 1-2 h for it; the address space is capped so that it fails instead of
     # taking the container down. Its model FILE is not kept (1 GB): only the digest.
     "z1b_seeds44_51_plain": (dict(ntok=125_000_000, vocab=1_000_000, seeds=list(range(44, 52))), "U", []),
+    # round 5: the id-keeping kinds on the TIMED corpus (bench.py other_configs.indexed / .exhaustive_skipgrams carry a self_check against these), and the three shards
+    # of other_configs.z375m_single_device
+    "z100m_seed44_indexed": (dict(ntok=100_000_000, vocab=1_000_000, seed=44), "i", []),
+    "z100m_seed44_exhaustive_skipgrams": (dict(ntok=100_000_000, vocab=1_000_000, seed=44), "us", []),
+    "z375m_seeds44_46_plain": (dict(ntok=125_000_000, vocab=1_000_000, seeds=list(range(44, 47))), "U", []),
     # the fallback the round-3 review names if the container cannot hold the above: four shards
     "z500m_seeds44_47_plain": (dict(ntok=125_000_000, vocab=1_000_000, seeds=list(range(44, 48))), "U", []),
 }

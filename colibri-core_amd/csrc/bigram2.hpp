@@ -101,6 +101,7 @@ struct __attribute__((aligned(16))) Bi2State {
     uint32_t bshift_fix; // key-sharded runs: bshift + 1 as every rank agreed on it (0: bi2_offsets_kernel derives it from this pass's record count)
     uint32_t ran;        // set by bi2_finish_kernel: this order was counted (the run had not ended before it) — what bi2_compact_kernel asks when it runs beside the path
     uint32_t hugebin;   // records from which a final bin goes to bi2_count_big_kernel; 0: kBi2HugeBin (written with kbits by the emit kernel of the order)
+    uint32_t emit_done;                 // blocks of the order's emit kernel that have finished: the last one runs bi2_offsets_tail
     uint32_t head_windows;              // key-sharded runs, order 2 (ks_finish2_kernel): the windows of the surviving head pairs over ALL ranks — what order 3 adds to the owners' lists
     uint32_t nextchunk;                 // owner passes of key-sharded runs: next free chunk of the position-list pool (bi2_count_kernel<.., BASED>)
     uint32_t nextbin[kBi2Shards * 16];  // work queues of the count kernel (one per shard, 64 bytes apart): next group of bins to hand out
@@ -163,6 +164,49 @@ __device__ __forceinline__ uint32_t bi2_block_scan(uint32_t v, uint32_t* total, 
     *total              = __shfl(wincl, T / kWave - 1, kWave);
     __syncthreads();
     return base + incl - v;
+}
+
+// ---- records per A bin, their scan, the B-bin shift for this record count: the last block of an emit kernel to finish does it ---------------------------------------
+// (round 5; bi2_offsets_kernel — one block after the emit kernel — cost a launch per order and per skipgram pass.) Every block of the emit kernel calls this as its
+// last statement with three LDS arrays it no longer needs (histL, offL: kBins words; wsumL: 4) and a flag word. The cursors were advanced by device-scope atomics of
+// other blocks: they are read with agent-scope atomic loads (this CU's L1 may hold nothing of them, but must not be trusted to).
+// NO __threadfence(): a device-scope release on this multi-XCD part writes the XCD's whole L2 back — 512 blocks doing so at the end of a kernel that has just written
+// 0.7 GB of records cost 0.13-0.3 ms per launch (measured). None is needed: the cursors are only ever touched by returning device-scope atomics, which have been
+// performed when their value is back, i.e. before the block's barrier and its own ticket; the last block reads them with atomic loads, and what it writes is read by
+// the next kernel.
+__device__ __forceinline__ void bi2_offsets_tail(Bi2State* __restrict__ bs, uint32_t region, uint32_t nsub, uint32_t* inL, uint32_t* outL, uint32_t* wsumL, uint32_t* flagL) {
+    __syncthreads();
+    if (threadIdx.x == 0) *flagL = (atomicAdd(&bs->emit_done, 1u) + 1u == gridDim.x) ? 1u : 0u;
+    __syncthreads();
+    if (*flagL == 0u) return;
+    uint32_t s = 0;
+    if (threadIdx.x < (uint32_t)kBins) {
+        for (uint32_t g = 0; g < nsub; ++g) {
+            const uint32_t h = __hip_atomic_load(&bs->curA[g * kBins + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (h > region) bs->overflow = 1;
+            s += min(h, region);
+        }
+        inL[threadIdx.x] = s;
+    }
+    __syncthreads();
+    const uint32_t tot = bi2_scan256(inL, outL, wsumL);
+    if (threadIdx.x < (uint32_t)kBins) {
+        bs->cntA[threadIdx.x]  = s;
+        bs->offAt[threadIdx.x] = outL[threadIdx.x];
+    }
+    if (threadIdx.x == 0) {
+        bs->offAt[kBins] = tot;
+        bs->nrec         = tot;
+        // aim at <= ~700 records per final bin; at least 8 B bins (the 31-bit in-bin key needs three mix bits fixed by the B bin)
+        uint32_t nb = 8;
+        while (nb < (uint32_t)kBi2BBins && (uint64_t)nb * kBins * kBi2BinTarget < tot) nb <<= 1;
+        uint32_t sh = 0;
+        while ((uint32_t)kBi2BBins >> sh > nb) ++sh;
+        // the 31-bit in-bin key must hold every mix bit the bin does not fix: kbits - 17 + bshift <= 31
+        const uint32_t K = bs->kbits;
+        if (sh + K > 48u) sh = K >= 48u ? 0u : 48u - K;
+        bs->bshift = bs->bshift_fix ? bs->bshift_fix - 1u : sh;
+    }
 }
 
 // ---- emit: windows -> head histogram | 8-byte records partitioned by A bin -------------------------------------------------------------
@@ -320,6 +364,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kerne
         for (int w = 0; w < kBi2Threads / kWave; ++w) a += redL[w];
         if (a) atomicAdd(&st->admitted, a);
     }
+    bi2_offsets_tail(bs, region, nsub, histL, offL, wsumL, &hcntL);
 }
 
 // The later passes of a sliced order (corpora beyond ~128 M tokens per device): the first pass left every window's key slice in `sid`, so a pass only looks at the
@@ -420,6 +465,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_slice
         }
         __syncthreads();
     }
+    bi2_offsets_tail(bs, region, nsub, histL, offL, wsumL, &qnL);
 }
 
 // column sums / minima of the head rows: grid (kBi2HeadN / 256, kBi2HeadSplit), block (x, y) reduces rows y, y + kBi2HeadSplit, ... of 256 head keys
@@ -1373,6 +1419,62 @@ __global__ __launch_bounds__(kBlock) void bi2_finish_kernel(DevState* __restrict
         bs->kept_head      = htot;
         bs->ran            = 1;
         bs->res_base       = st->res_total + st->kept;  // (st->found / st->kept are zero at the start of an order: the passes of a sliced order add up)
+        st->found += ftot + hftot;
+        st->kept += tot + htot;
+        if ((uint64_t)bs->res_base + tot + htot > res_cap) st->overflow = 1;
+        if (bs->overflow && st->radix_overflow != 4) st->radix_overflow = ovf_code;  // the host re-runs on the first-generation kernels
+        const uint64_t next = (uint64_t)st->id_base + bs->nrec;  // keeps the id space of the later orders disjoint, as bin_advance_prepare_kernel does
+        if (next >= 0xFFFFFFF0ull) st->radix_overflow = 3;
+        st->id_base = (uint32_t)next;
+    }
+}
+// bi2_kept_scan_kernel and bi2_finish_kernel in ONE launch (round 5: a launch of a few microseconds of work still costs ~5 us of the step, and every order and every
+// skipgram pass had both): blocks 0 .. kBins - 1 scan their A bin, block kBins does the order's bookkeeping — it needs the per-A-bin totals only (found_part,
+// kept_part: complete when the count kernels are), not the scans. grid kBins + 1, kBi2BBins threads.
+__global__ __launch_bounds__(kBi2BBins) void bi2_kept_finish_kernel(DevState* __restrict__ st, Bi2State* __restrict__ bs, uint32_t threshold, uint32_t res_cap,
+                                                                     uint32_t* __restrict__ headsurv_keep, uint32_t ovf_code) {
+    if (st->done) return;
+    __shared__ uint32_t inL[kBi2BBins], outL[kBi2BBins], wsumL[8], beforeL;
+    if (blockIdx.x < (uint32_t)kBins) {
+        const uint32_t a = blockIdx.x;
+        inL[threadIdx.x] = threadIdx.x < a ? bs->kept_part[threadIdx.x] : 0u;  // (kBins <= kBi2BBins: entries beyond 255 are zero)
+        __syncthreads();
+        const uint32_t before = bi2_scan512(inL, outL, wsumL);
+        if (threadIdx.x == 0) beforeL = before;
+        __syncthreads();
+        inL[threadIdx.x] = bs->binkept[a * kBi2BBins + threadIdx.x];
+        __syncthreads();
+        const uint32_t tot                        = bi2_scan512(inL, outL, wsumL);
+        bs->binkept[a * kBi2BBins + threadIdx.x] = beforeL + outL[threadIdx.x];
+        if (a == kBins - 1 && threadIdx.x == 0) bs->kept_bins = beforeL + tot;
+        return;
+    }
+    static_assert(kBi2HeadN == kBlock * 16 && kBins == kBlock && kBi2BBins >= kBlock, "16 head keys per lane of the first 256");
+    const bool low = threadIdx.x < (uint32_t)kBlock;
+    uint32_t   htot, ftot, hftot, tot;
+    bi2_block_scan<kBi2BBins>(low ? bs->found_part[threadIdx.x] : 0u, &ftot, wsumL);
+    bi2_block_scan<kBi2BBins>(low ? bs->kept_part[threadIdx.x] : 0u, &tot, wsumL);
+    uint32_t hk = 0, hf = 0, bits = 0;
+    if (low) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t c = bs->headcnt[threadIdx.x * 16 + q];
+            hf += c != 0;
+            if (c >= threshold) {
+                ++hk;
+                bits |= 1u << q;
+            }
+        }
+        reinterpret_cast<uint16_t*>(bs->headsurv)[threadIdx.x] = (uint16_t)bits;
+        if (headsurv_keep != nullptr) reinterpret_cast<uint16_t*>(headsurv_keep)[threadIdx.x] = (uint16_t)bits;
+    }
+    const uint32_t ho = bi2_block_scan<kBi2BBins>(hk, &htot, wsumL);
+    if (low) bs->headbase[threadIdx.x] = ho;
+    bi2_block_scan<kBi2BBins>(hf, &hftot, wsumL);
+    if (threadIdx.x == 0) {
+        bs->kept_head = htot;
+        bs->ran       = 1;
+        bs->res_base  = st->res_total + st->kept;  // (st->found / st->kept are zero at the start of an order: the passes of a sliced order add up)
         st->found += ftot + hftot;
         st->kept += tot + htot;
         if ((uint64_t)bs->res_base + tot + htot > res_cap) st->overflow = 1;

@@ -265,6 +265,44 @@ __global__ __launch_bounds__(kBi2Threads) void chain_steps_kernel(const Bi2State
             if (base < cap) table[(size_t)x * cap + base] = make_uint2(first[q] + k * (uint32_t)kChStep, min((uint32_t)kChStep, n[q] - k * (uint32_t)kChStep));
     if (threadIdx.x == 0) nsteps[x] = min(total, cap);
 }
+// chain_reset_kernel and chain_steps_kernel in ONE launch (what an order starts with; they touch different states — the new order's, and the lists of the one before):
+// blocks 0 .. 7 number the XCDs' steps, the others clear. grid kChXcds + kChResetBlocks, kBi2Threads threads.
+constexpr uint32_t kChResetBlocks = 64;
+__global__ __launch_bounds__(kBi2Threads) void chain_begin_kernel(const Bi2State* __restrict__ prev, Bi2Lists pl, uint32_t nbuckets, uint2* __restrict__ table, uint32_t cap,
+                                                                   uint32_t* __restrict__ nsteps, const DevState* __restrict__ st, Bi2State* __restrict__ bs, uint32_t* __restrict__ wcnt,
+                                                                   uint32_t nwcnt) {
+    if (blockIdx.x >= kChXcds) {  // (cleared whether or not the run has ended, as chain_reset_kernel does)
+        uint4* const   p = reinterpret_cast<uint4*>(bs);
+        const uint32_t n = (uint32_t)(sizeof(Bi2State) / 16), t = (blockIdx.x - kChXcds) * kBi2Threads + threadIdx.x, step = (gridDim.x - kChXcds) * kBi2Threads;
+        for (uint32_t i = t; i < n; i += step) p[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t i = t; i < nwcnt; i += step) wcnt[i] = 0u;
+        return;
+    }
+    if (st->done) return;
+    __shared__ uint32_t wsumL[kBi2Threads / kWave];
+    constexpr uint32_t  kPer = (kBi2Buckets / kChXcds * kChLists + kBi2Threads - 1) / kBi2Threads;
+    const uint32_t      x = blockIdx.x;
+    uint32_t            first[kPer], n[kPer], ns[kPer], sum = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) {
+        const uint32_t idx = threadIdx.x * kPer + q, bucket = x + kChXcds * (idx / kChLists), shard = idx % kChLists;
+        uint32_t       lcap = 0;
+        first[q] = n[q] = 0;
+        if (bucket < nbuckets) {
+            bi2_list_of(pl, shard, bucket, first[q], lcap);
+            n[q] = min(prev->pcur[shard * kBi2Buckets + bucket], lcap);
+        }
+        ns[q] = (n[q] + kChStep - 1) / kChStep;
+        sum += ns[q];
+    }
+    uint32_t total;
+    uint32_t base = bi2_block_scan<kBi2Threads>(sum, &total, wsumL);
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q)
+        for (uint32_t k = 0; k < ns[q]; ++k, ++base)
+            if (base < cap) table[(size_t)x * cap + base] = make_uint2(first[q] + k * (uint32_t)kChStep, min((uint32_t)kChStep, n[q] - k * (uint32_t)kChStep));
+    if (threadIdx.x == 0) nsteps[x] = min(total, cap);
+}
 // (steps of an XCD at most: every list of its buckets filled + one partial step each)
 inline uint32_t chain_steps_cap(const Bi2Lists& pl) { return (kBi2Buckets / kChXcds) * (kBi2Shards * (pl.pcap / kChStep + 1) + ((1u << pl.pshift) / kChStep + 1)); }
 
@@ -339,6 +377,7 @@ __global__ __launch_bounds__(kChThreads, 6) void chain_emit_kernel(const uint32_
     }
     if (Q.qn) Q.flush(recsA, region, sub, bs);
     if (threadIdx.x == 0 && Q.nadm) atomicAdd(&st->admitted, Q.nadm);
+    bi2_offsets_tail(bs, region, nsub, Q.histL, Q.offL, Q.wsumL, Q.gbaseL);
 }
 
 // ---- a skipgram pass of TWO parts on the same engine (exhaustive skipgrams of a chained run: reference patternmodel.h:1163-1171 -> computeskipgrams :1370-1527) -----------
@@ -426,6 +465,7 @@ __global__ __launch_bounds__(kChThreads, 6) void skip_emit_kernel(const uint32_t
     if (Q.qn) Q.flush(recsA, region, sub, bs);
     flush_head();
     if (threadIdx.x == 0 && Q.nadm) atomicAdd(&st->admitted, Q.nadm);
+    bi2_offsets_tail(bs, region, nsub, Q.histL, Q.offL, Q.wsumL, Q.gbaseL);
 }
 
 // ---- result indices per position (the modes that keep every order's ids), with the step order of chain_emit_kernel ------------------------------------------------------

@@ -1075,7 +1075,7 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
                                    std::max(1u, std::min(8u, 1u << b.sbits) / 4u), recsA, b.region, kBi2Sub, bs, c->state.p);
             if (slice == 0)
                 hipLaunchKernelGGL(bi2_head_reduce_kernel, dim3(kBi2HeadN / kBlock, kBi2HeadSplit), dim3(kBlock), 0, c->stream, c->b2.head_rows.p, kBi2EmitGrid, bs, c->state.p);
-            hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, b.region, kBi2Sub, c->state.p);
+            // (records per A bin, scan, B-bin shift: the emit kernel's last block, bi2_offsets_tail)
         }
         {
             Prof p(c, COLIBRI_K_LEVELB2);
@@ -1104,8 +1104,7 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
         }
         {
             Prof p(c, COLIBRI_K_PRUNE);
-            hipLaunchKernelGGL(bi2_kept_scan_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->state.p);
-            hipLaunchKernelGGL(bi2_finish_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->state.p, bs, pl.thr, pl.res_cap, slice == 0 ? c->b2.headsurv.p : (uint32_t*)nullptr, 4u);
+            hipLaunchKernelGGL(bi2_kept_finish_kernel, dim3(kBins + 1), dim3(kBi2BBins), 0, c->stream, c->state.p, bs, pl.thr, pl.res_cap, slice == 0 ? c->b2.headsurv.p : (uint32_t*)nullptr, 4u);
             if (chain) {
                 int rcf;
                 if ((rcf = chain_compact_fork(c, io, bs, pl))) return rcf;
@@ -1152,18 +1151,17 @@ int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next, uint
     const BinnedIO        io    = binned_planes(c, pl, false);
     int rcj;
     if ((rcj = chain_compact_join(c))) return rcj;  // (the emit kernel below overwrites the sparse arrays the order before is still being copied from)
-    hipLaunchKernelGGL(chain_reset_kernel, dim3(256), dim3(kBlock), 0, c->stream, bs, c->b2.wcnt.p, kBi2Waves + b.wextra + 1);
     {
         Prof p(c, COLIBRI_K_EMIT);
         static const uint32_t grid = chain_grid("COLIBRI_CH_GRID", 768u);  // (three resident blocks per CU)
         const uint32_t cap = chain_steps_cap(b.pl);
-        hipLaunchKernelGGL(chain_steps_kernel, dim3(kChXcds), dim3(kBi2Threads), 0, c->stream, prev, b.pl, b.nbuckets, reinterpret_cast<uint2*>(c->b2.steps.p), cap,
-                           c->b2.steps.p + 2 * (size_t)kChXcds * cap, (const DevState*)c->state.p);
+        hipLaunchKernelGGL(chain_begin_kernel, dim3(kChXcds + kChResetBlocks), dim3(kBi2Threads), 0, c->stream, prev, b.pl, b.nbuckets, reinterpret_cast<uint2*>(c->b2.steps.p), cap,
+                           c->b2.steps.p + 2 * (size_t)kChXcds * cap, (const DevState*)c->state.p, bs, c->b2.wcnt.p, kBi2Waves + b.wextra + 1);
         hipLaunchKernelGGL(chain_emit_kernel, dim3(grid), dim3(kChThreads), 0, c->stream, (const uint32_t*)c->cls.p, npos, (uint32_t)n, b.clsbits, b.posbits, prev,
                            (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p, b.pl, reinterpret_cast<const uint2*>(c->b2.steps.p), cap,
                            (const uint32_t*)(c->b2.steps.p + 2 * (size_t)kChXcds * cap),
                            (const uint32_t*)c->b2.bitmap.p, recsA, b.region, kBi2Sub, bs, c->state.p, (const uint32_t*)c->b2.headid.p, chain_dbg());
-        hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, b.region, kBi2Sub, c->state.p);
+        // (records per A bin, scan, B-bin shift: the emit kernel's last block, bi2_offsets_tail)
     }
     {
         Prof p(c, COLIBRI_K_LEVELB2);
@@ -1185,8 +1183,7 @@ int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next, uint
     }
     {
         Prof p(c, COLIBRI_K_PRUNE);
-        hipLaunchKernelGGL(bi2_kept_scan_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->state.p);
-        hipLaunchKernelGGL(bi2_finish_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->state.p, bs, pl.thr, pl.res_cap, (uint32_t*)nullptr, 16u);
+        hipLaunchKernelGGL(bi2_kept_finish_kernel, dim3(kBins + 1), dim3(kBi2BBins), 0, c->stream, c->state.p, bs, pl.thr, pl.res_cap, (uint32_t*)nullptr, 16u);
         int rcf;
         if ((rcf = chain_compact_fork(c, io, bs, pl))) return rcf;
     }
@@ -1230,7 +1227,7 @@ int skip_pass_chain(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, c
         hipLaunchKernelGGL(skip_emit_kernel<false>, dim3(grid), dim3(kChThreads), 0, c->stream, (const uint32_t*)c->skl, (const uint32_t*)c->skl_n, left, offl, right, offr,
                            l_is_cls ? 1u : 0u, r_is_cls ? 1u : 0u, b.clsbits, b.posbits, recsA, b.region, kBi2Sub, bs, c->state.p, (uint32_t*)nullptr);
     }
-    hipLaunchKernelGGL(bi2_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, b.region, kBi2Sub, c->state.p);
+    // (records per A bin, scan, B-bin shift: the emit kernel's last block, bi2_offsets_tail)
     hipLaunchKernelGGL(bi2_levelB_kernel<false>, dim3(b.nslots), dim3(kBi2Threads), 0, c->stream, recsA, recsB, b.region, bs, c->b2.boff.p, c->state.p);
     hipLaunchKernelGGL(bi2_binoff_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->b2.boff.p, kBi2Sub, c->state.p);
     // (the hot bins' workgroups beside the wave kernel on the second stream, as in chain_order: 0.05 ms per pass of n = 4)
@@ -1242,8 +1239,7 @@ int skip_pass_chain(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, c
     hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, thr, io.sp_rep, io.sp_cnt, c->b2.wlist.p,
                        c->b2.wcnt.p, b.wcap, false, (uint32_t*)nullptr, (const uint32_t*)nullptr, true);
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->b2.ev_join, 0));
-    hipLaunchKernelGGL(bi2_kept_scan_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->state.p);
-    hipLaunchKernelGGL(bi2_finish_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->state.p, bs, thr, pl.res_cap, (uint32_t*)nullptr, 16u);
+    hipLaunchKernelGGL(bi2_kept_finish_kernel, dim3(kBins + 1), dim3(kBi2BBins), 0, c->stream, c->state.p, bs, thr, pl.res_cap, (uint32_t*)nullptr, 16u);
     hipLaunchKernelGGL(bi2_compact_kernel, dim3(1025), dim3(kBlock), 0, c->stream, (const uint32_t*)io.sp_rep, (const uint32_t*)io.sp_cnt, (const DevState*)c->state.p, (const Bi2State*)bs,
                        c->res_rep.p, c->res_cnt.p, pl.res_cap, false);
     hipLaunchKernelGGL(skip_pass_end_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, seglog, (uint32_t)n, mask);

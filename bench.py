@@ -117,12 +117,13 @@ def cpu_baseline(sample_tokens, vocab):
             "seconds": round(dt, 3), "host_cores": os.cpu_count(), "full_size_reference": full}
 
 
-def other_configs(ctx, capi, nbytes):
+def other_configs(ctx, capi, nbytes, default_corpus=False):
     """The other model kinds of BASELINE.json on the corpus that is resident: configs[3] (skipgrams: the exhaustive unindexed variant and the
     indexed one with MINSKIPTYPES = 2) and configs[4] (indexed model = forward index on the device). Untimed steps after the timed region: best of
     three train() calls each, with the kernel classes bracketed by HIP events in a fourth. Algorithmic bytes: the counting stage of the n-gram
     passes as in `roofline` plus, for indexed models, 8 bytes per reference written once and read once per 8-bit sort pass."""
     res = {}
+    all_ok = True
     kinds = (("exhaustive_skipgrams", dict(doskipgrams_exhaustive=1)), ("indexed", dict(indexed=1)), ("indexed_skipgrams_T2", dict(indexed=1, doskipgrams=1, minskiptypes=2)))
     for name, kw in kinds:
         best, st = None, None
@@ -137,7 +138,22 @@ def other_configs(ctx, capi, nbytes):
         res[name] = {"ms_per_step": round(best, 3), "patterns_in_model": int(st.npatterns), "references": int(st.nrefs), "dominant_kernel_class": dom,
                      "kernel_ms_per_step": kms, "algorithmic_bytes_per_step": round(algo), "achieved_GBps": round(algo / (best * 1e-3) / 1e9, 1),
                      "frac_of_hbm_peak": round(algo / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-    return res
+        # round 5: the real reference's own model of THIS corpus in this kind (tests/golden/fullsize/z100m_seed44_{indexed,exhaustive_skipgrams}.json: 750 s / 887 s of
+        # its train() in the build container): totals and the multiset digest of every (key, count[, reference list]) row. The indexed skipgram kind at the default
+        # MINSKIPTYPES has no stable reference output (tests/golden/unstable_reference_outputs.json).
+        fx = load_fixture({"exhaustive_skipgrams": "z100m_seed44_exhaustive_skipgrams", "indexed": "z100m_seed44_indexed"}.get(name, "-")) if default_corpus else None
+        if fx is not None:
+            from colibri_amd import digest
+            key_off, key_bytes, counts, refs = ctx.export_arrays()
+            d = digest.model_digest(key_off, key_bytes, counts, refs)
+            ok = all(d[k] == fx[k] for k in ("sum1", "xor1", "sum2", "xor2", "npatterns", "occurrences", "keybytes")) and (refs is None or d["nrefs"] == fx["nrefs"])
+            res[name]["self_check"] = ("ok" if ok else "FAILED") + ": the multiset digest of every (key, count%s) row equals the real reference's model of this corpus" % (
+                ", reference list" if refs is not None else "")
+            all_ok = all_ok and ok
+            del key_off, key_bytes, counts, refs
+        else:
+            res[name]["self_check"] = "no reference model for this configuration"
+    return res, all_ok
 
 
 def phrases_config(ctx, capi, payload):
@@ -579,7 +595,9 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["sharded"]["indexed_model"] = {"error": str(e)}
     if ctx is not None and not args.no_other_configs:
-        out["other_configs"] = other_configs(ctx, capi, payloads[0].size)
+        out["other_configs"], kinds_ok = other_configs(ctx, capi, payloads[0].size, default_corpus=(args.tokens, args.vocab, args.gpus) == (100_000_000, 1_000_000, 1))
+        if not kinds_ok:
+            check_ok = False
         if want_phrases:
             ph, ph_ok = phrases_config(ctx, capi, phrase_payload)
             out["other_configs"]["phrases"] = ph

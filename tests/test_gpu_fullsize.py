@@ -232,6 +232,22 @@ def test_id_keeping_modes_are_the_references_models(name, kw):
     assert_is_the_references_model(fixture(name), st, key_off, key_bytes, counts, refs)
 
 
+@pytest.mark.parametrize("name,kw", [("z100m_seed44_indexed", dict(indexed=1)), ("z100m_seed44_exhaustive_skipgrams", dict(doskipgrams_exhaustive=1))])
+def test_id_keeping_modes_on_the_bench_corpus_are_the_references_models(name, kw):
+    """configs 4 / 5 on the TIMED corpus (10^8 tokens, 161 M references / 12.2 M patterns): the reference's own IndexedPatternModel::train / exhaustive computeskipgrams
+    run took 750 s / 887 s in the build container (tests/golden/make_fullsize_golden.py); every (key, count[, reference list]) row enters the digest. bench.py's
+    other_configs.indexed / .exhaustive_skipgrams carry the same check."""
+    from colibri_amd import capi, synth
+    fx = fixture(name)
+    payload = synth.zipf_corpus(fx["corpus"]["ntok"], fx["corpus"]["vocab"], fx["corpus"]["seed"], header=False)
+    with capi.Context(0) as ctx:
+        ctx.upload(payload)
+        del payload
+        st = ctx.train(mintokens=2, maxlength=5, **kw)
+        key_off, key_bytes, counts, refs = ctx.export_arrays()
+    assert_is_the_references_model(fx, st, key_off, key_bytes, counts, refs)
+
+
 @pytest.mark.skipif((os.cpu_count() or 1) < 8, reason="generating the 1 B-token corpus takes eight host cores a minute")
 def test_one_billion_tokens_is_the_references_model():
     """BASELINE.json configs[2]: the eight 125 M-token shards (seeds 44..51) of an 8-GPU run. The reference's own PatternModel::train took 8030 s and 32 GB for

@@ -1,8 +1,9 @@
 """Worker of the CPU test of the key-sharded protocol (launched by torch.distributed.run from tests/test_sharded.py, backend gloo): the steps
 host/src/sharded.cpp drives through colibri_kshard_* — order 1 as an all-reduce of dense class counts; at every higher order each rank turns the windows of ITS
 sentences that pass the look-back into records (key, position), every record travels to the owner of its key, the owner counts and applies the threshold to the
-global count, the positions of surviving windows go back to their sources (the next order's look-back) and every surviving pattern is exported by the lowest rank
-that holds an occurrence; the loop ends at the first order no rank admits a window for — stated position by position in Python on a numpy stand-in, so that the
+global count; round 4's wire format (csrc/kshard2.hpp): KEYS travel (the positions stay at home, in send order), the owner answers one bit per key and the dense number
+of every surviving key's window in the order the source sent, numbers become global by the kept counts of the owners before; every surviving pattern is exported, as
+(index in the exporter's stream, count), by the lowest rank that holds an occurrence; the loop ends at the first order no rank admits a window for — stated position by position in Python on a numpy stand-in, so that the
 PROTOCOL (routing, termination, export election, the sums that make the statistics) is checked against the oracle without a GPU. The HIP kernels behind the same
 steps are checked on the GPU (tests/test_kshard.py)."""
 import os
@@ -72,50 +73,67 @@ def train(payload_shard, thr, maxlength):
             if cnt[c] >= thr:
                 exports[bytes(synth.encode_v2(__import__("numpy").array([c], dtype="uint32")))] = int(cnt[c])
     stats[1] = [int((cnt[1:] > 0).sum()) if rank == 0 else 0, int((cnt[1:] >= thr).sum()) if rank == 0 else 0, admitted]
-    surv_prev = [alive[c] for c in cls]  # per position: the (n-1)-gram starting here survived
+    # per position: the GLOBAL number of the surviving (n-1)-gram that starts here, None if there is none (order 1: the class id names the unigram)
+    num_prev = [c if alive[c] else None for c in cls]
     maxn = 1 if int(cnt.sum()) else 0
     for n in range(2, maxlength + 1):
-        # source side: the windows that pass the look-back become records (key = the window's class ids; the real records carry a bijective mix of them)
-        recs = [[] for _ in range(world)]
+        # source side (csrc/kshard2.hpp: emit -> level B -> ks2_move): the windows that pass the look-back become KEYS, sent in one stream per owner; the window's
+        # position stays at home, in the same order. The key is exact: order 2 the class pair, order n >= 3 (global number of the leading (n-1)-gram, last class)
+        # (the real stream carries the bits of its bijective mix that the (owner, bin) does not fix).
+        send = [[] for _ in range(world)]
+        home = [[] for _ in range(world)]
         nadm = 0
         for i in range(npos - n + 1):
-            if surv_prev[i] and surv_prev[i + 1] and all(cls[i + k] for k in range(n)):
-                key = tuple(cls[i:i + n])
-                recs[mix64(hash(key) & ((1 << 63) - 1)) % world].append((key, i))
+            if num_prev[i] is not None and num_prev[i + 1] is not None:
+                key = (cls[i], cls[i + 1]) if n == 2 else (num_prev[i], cls[i + n - 1])
+                d = mix64(hash(key) & ((1 << 63) - 1)) % world
+                send[d].append(key)
+                home[d].append(i)
                 nadm += 1
         sizes = [None] * world
         dist.all_gather_object(sizes, nadm)
         if sum(sizes) == 0:  # "None found" (patternmodel.h:1189-1194): no rank has a window of this order left
             break
         maxn = n
-        got = all_to_all(recs, world)
-        # owner side: exact global counts of the keys this rank owns
+        got = all_to_all(send, world)
+        # owner side (bi2_count_kernel<.., KEY4>): exact global counts of the keys this rank owns; a record's "position" is its place (source, index in the stream)
         table = {}
         for src in range(world):
-            for key, pos in got[src]:
+            for j, key in enumerate(got[src]):
                 e = table.setdefault(key, [0, (world, 0)])
                 e[0] += 1
-                e[1] = min(e[1], (src, pos))
-        feedback = [[] for _ in range(world)]
-        exp_out = [[] for _ in range(world)]
-        for src in range(world):
-            for key, pos in got[src]:
-                if table[key][0] >= thr:
-                    feedback[src].append(pos)
-        for key, (c, (src, pos)) in table.items():
+                e[1] = min(e[1], (src, j))
+        dense = {}  # the survivors' dense numbers on this owner (any fixed order: here by first occurrence)
+        for key, (c, first) in sorted(table.items(), key=lambda kv: kv[1][1]):
             if c >= thr:
-                exp_out[src].append((pos, c))
-        stats[n] = [len(table), sum(1 for e in table.values() if e[0] >= thr), nadm]
+                dense[key] = len(dense)
+        # feedback (ks2_fb_*): per source, IN THE ORDER THE SOURCE SENT, one bit per key and then the dense number of every surviving key's window;
+        # exports: (index in the exporter's stream, count) to the lowest rank holding an occurrence
+        feedback = [([1 if key in dense else 0 for key in got[src]], [dense[key] for key in got[src] if key in dense]) for src in range(world)]
+        exp_out = [[] for _ in range(world)]
+        for key, (c, (src, j)) in table.items():
+            if c >= thr:
+                exp_out[src].append((j, c))
+        stats[n] = [len(table), len(dense), nadm]
+        kept_all = [None] * world
+        dist.all_gather_object(kept_all, len(dense))  # owner d's numbers are shifted by the kept counts of the owners before it: identical on every rank
+        base = [sum(kept_all[:d]) for d in range(world)]
         fb = all_to_all(feedback, world)
         ex = all_to_all(exp_out, world)
-        surv = [False] * npos
-        for part in fb:
-            for pos in part:
-                surv[pos] = True
-        for part in ex:
-            for pos, c in part:
-                exports[b"".join(toks[pos + k][1] for k in range(n))] = c
-        surv_prev = surv
+        # apply (ks2_dec_*): the source walks its own send order, counts bits and has (position, global number) of every surviving window
+        num = [None] * npos
+        for d in range(world):
+            bits, numbers = fb[d]
+            assert len(bits) == len(home[d]) and sum(bits) == len(numbers)
+            k = 0
+            for j, pos in enumerate(home[d]):
+                if bits[j]:
+                    num[pos] = base[d] + numbers[k]
+                    k += 1
+            for j, c in ex[d]:
+                pos = home[d][j]
+                exports[b"".join(toks[pos + k2][1] for k2 in range(n))] = c
+        num_prev = num
     allstats = [None] * world
     dist.all_gather_object(allstats, stats)
     total = {n: [sum(s.get(n, [0, 0, 0])[k] for s in allstats) for k in range(3)] for n in range(1, maxn + 1)}

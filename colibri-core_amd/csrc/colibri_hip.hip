@@ -783,9 +783,11 @@ uint32_t uni_range_shift(const colibri_ctx* c) {
     while (shift <= 14 && ((uint64_t)c->maxclass >> shift) >= (uint64_t)kUniBins) ++shift;
     return shift > 14 ? 0u : shift;
 }
+// room of a tail bin of the one-pass order 1 (kernels.hpp uni_onepass_kernel): 1.5 x the even share of ALL positions + slack, a multiple of 8 (16-byte loads)
+inline uint32_t uni_bin_cap(uint32_t npos) { return (uint32_t)((((uint64_t)npos / kUniBins) * 3 / 2 + 4096 + 7) & ~7ull); }
 int uni_alloc(colibri_ctx* c) {
     int rc;
-    if ((rc = dev_alloc(c, c->unistate, 1)) || (rc = dev_alloc(c, c->uni_tail, (size_t)c->npos + 8)) || (rc = dev_alloc(c, c->uni_rows, (size_t)kUniHeadGrid * kUniHead)) ||
+    if ((rc = dev_alloc(c, c->unistate, 1)) || (rc = dev_alloc(c, c->uni_tail, (size_t)kUniBins * uni_bin_cap(c->npos) + 8)) || (rc = dev_alloc(c, c->uni_rows, (size_t)kUniHeadGrid * kUniHead)) ||
         (rc = dev_alloc(c, c->uni_surv, (size_t)c->maxclass / 32 + 4)))
         return rc;
     return COLIBRI_OK;
@@ -795,7 +797,21 @@ int uni_count_partitioned(colibri_ctx* c, uint32_t shift, uint32_t* cnt, uint32_
     HIP_TRY(c, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * nclasses, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->unistate.p, 0, sizeof(UniState), c->stream));
     Prof p(c, COLIBRI_K_COUNT);
-    hipLaunchKernelGGL(uni_head_kernel, dim3(kUniHeadGrid), dim3(kBlock), 0, c->stream, c->cls.p, c->npos, shift, c->uni_rows.p, c->unistate.p, c->state.p);
+    static const bool two_pass = getenv("COLIBRI_UNI_TWO_PASS") != nullptr;  // (round 4's form, for comparison)
+    if (!two_pass) {
+        // COLIBRI_UNI_BIN_CAP (tests): a smaller room per tail bin, so that ordinary corpora take the overflow route (uni_tail_atomics_kernel) — the result is the same
+        static const uint32_t cap_env = getenv("COLIBRI_UNI_BIN_CAP") ? (uint32_t)std::max(8l, atol(getenv("COLIBRI_UNI_BIN_CAP")) & ~7l) : 0u;
+        const uint32_t cap = cap_env ? std::min(cap_env, uni_bin_cap(c->npos)) : uni_bin_cap(c->npos), nrows = (c->maxclass >> 12) + 1;
+        // (measured, 10^8 tokens: this fused pass 0.43 ms for order 1; round 4's two passes 0.45; the head histogram on a second stream BESIDE a tail-only partition 0.48 —
+        // the two kernels contend for the same LDS pipes)
+        hipLaunchKernelGGL(uni_onepass_kernel<true>, dim3(kUniHeadGrid), dim3(kUni1Threads), 0, c->stream, c->cls.p, c->npos, cap, c->uni_rows.p, c->unistate.p, c->uni_tail.p, c->state.p);
+        hipLaunchKernelGGL(uni_head_reduce_kernel, dim3(kUniHead / kBlock, 16), dim3(kBlock), 0, c->stream, c->uni_rows.p, kUniHeadGrid, cnt, nclasses, c->state.p);
+        hipLaunchKernelGGL(uni_tail_count1_kernel, dim3(kUniBins * kUniSlices), dim3(kBlock), sizeof(uint32_t) * 16 * nrows, c->stream, c->uni_tail.p, c->unistate.p, cap, nrows, cnt,
+                           nclasses, c->state.p);
+        hipLaunchKernelGGL(uni_tail_atomics_kernel, dim3(2048), dim3(kBlock), 0, c->stream, c->cls.p, c->npos, c->unistate.p, cnt, c->state.p);
+        return COLIBRI_OK;
+    }
+    hipLaunchKernelGGL(uni_head_kernel<true>, dim3(kUniHeadGrid), dim3(kBlock), 0, c->stream, c->cls.p, c->npos, shift, c->uni_rows.p, c->unistate.p, c->state.p);
     hipLaunchKernelGGL(uni_head_reduce_kernel, dim3(kUniHead / kBlock, 16), dim3(kBlock), 0, c->stream, c->uni_rows.p, kUniHeadGrid, cnt, nclasses, c->state.p);
     hipLaunchKernelGGL(uni_offsets_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->unistate.p);
     hipLaunchKernelGGL(uni_partition_kernel, dim3(256 * 4), dim3(kBlock), 0, c->stream, c->cls.p, c->npos, shift, c->unistate.p, c->uni_tail.p, c->state.p);

@@ -730,8 +730,29 @@ constexpr uint32_t kUniSliceMin = 65536;  // ... but a slice is never smaller th
 struct UniState {
     uint32_t hist[kUniBins];     // tail tokens per bin
     uint32_t off[kUniBins + 1];  // exclusive scan
-    uint32_t cur[kUniBins];      // partition cursors
+    uint32_t cur[kUniBins];      // partition cursors (the one-pass form: the bins' sizes)
+    uint32_t overflow;           // the one-pass form: a bin outgrew its room
 };
+// exclusive scan of 256 LDS values by the first 256 threads of a block of any size (>= 256); every thread of the block must call it
+__device__ __forceinline__ uint32_t bi2_uni_scan256(const uint32_t* inL, uint32_t* outL, uint32_t* wsumL) {
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t       v = 0, incl = 0;
+    if (threadIdx.x < 256) {
+        v    = inL[threadIdx.x];
+        incl = v;
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, kWave);
+            if ((int)lane >= off) incl += t;
+        }
+        if (lane == kWave - 1) wsumL[wave] = incl;
+    }
+    __syncthreads();
+    const uint32_t s0 = wsumL[0], s1 = wsumL[1], s2 = wsumL[2], s3 = wsumL[3];
+    if (threadIdx.x < 256) outL[threadIdx.x] = (wave > 0 ? s0 : 0u) + (wave > 1 ? s1 : 0u) + (wave > 2 ? s2 : 0u) + incl - v;
+    __syncthreads();
+    return s0 + s1 + s2 + s3;
+}
+template <bool BINS = true>  // BINS = false: the head histogram and the token count only (the one-pass tail of round 5 needs no bin sizes)
 __global__ __launch_bounds__(kBlock) void uni_head_kernel(const uint32_t* __restrict__ cls, uint32_t npos, uint32_t shift, uint32_t* __restrict__ head_rows /*[gridDim.x][kUniHead]*/,
                                                            UniState* __restrict__ us, DevState* __restrict__ st) {
     if (st->done) return;
@@ -756,7 +777,7 @@ __global__ __launch_bounds__(kBlock) void uni_head_kernel(const uint32_t* __rest
                 ++nadm;
                 if (c[q] < (uint32_t)kUniHead)
                     atomicAdd(&histL[c[q]], 1u);
-                else
+                else if (BINS)
                     atomicAdd(&binL[c[q] >> shift], 1u);
             }
         }
@@ -764,7 +785,7 @@ __global__ __launch_bounds__(kBlock) void uni_head_kernel(const uint32_t* __rest
     __syncthreads();
     // the block's head histogram leaves as one plain row (512 blocks x 8192 flush atomics would cost 0.16 ms at the memory-side atomic rate)
     for (int k = threadIdx.x; k < kUniHead; k += kBlock) head_rows[(size_t)blockIdx.x * kUniHead + k] = histL[k];
-    if (binL[threadIdx.x]) atomicAdd(&us->hist[threadIdx.x], binL[threadIdx.x]);
+    if (BINS && binL[threadIdx.x]) atomicAdd(&us->hist[threadIdx.x], binL[threadIdx.x]);
     for (int off = 32; off > 0; off >>= 1) nadm += __shfl_down(nadm, off, kWave);
     if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nadm;
     __syncthreads();
@@ -874,6 +895,152 @@ __global__ __launch_bounds__(kBlock) void uni_tail_count_kernel(const uint16_t* 
     for (uint32_t k = threadIdx.x; k < width; k += kBlock) {
         const uint32_t h = uniHistL[k];
         if (h && cbase + k < nclasses) atomicAdd(&cnt1[cbase + k], h);
+    }
+}
+// ---- order 1 in ONE pass over the class ids (round 5) ---------------------------------------------------------------------------------------------------------------
+// The two-pass form above reads the corpus twice: once for the head histogram and the sizes of the 256 tail bins (a bin's place in the tail array needs every bin's size),
+// once to partition. Here a tail bin is not a class RANGE but every 256th GROUP of 16 consecutive classes — bin = (c >> 4) & 255, 2-byte offset inside it
+// ((c >> 12) << 4) | (c & 15) —: under any class distribution that is not built against it the bins fill evenly (the frequent classes, which a range puts into one
+// bin, are dealt round-robin), so every bin gets the same fixed room (`cap`, 1.5 x its even share + slack) and nothing has to be known before the one pass that counts the
+// head in LDS, sorts a tile's tail tokens by bin and appends the runs. A bin's counters (16 x (classes >> 12) <= 16 384) fit LDS for class ids below 2^22, and a group of 16
+// classes is one 64-byte line of the count array. A bin that does outgrow its room raises UniState::overflow: uni_tail_count1_kernel then adds nothing and
+// uni_tail_atomics_kernel (one more launch, ~5 us when idle) counts the tail with global atomics — slow, exact, and only for corpora built to fill one bin.
+constexpr int kUni1Threads = 1024, kUni1Per = 8, kUni1Tile = kUni1Threads * kUni1Per;  // 8192 positions per tile: 60 KB of LDS, two blocks per CU
+// HEAD = false: the tail only (no head histogram). Measured and not used: uni_head_kernel<false> on a second stream beside it — 0.48 ms per 10^8 tokens against 0.43
+// fused and 0.45 for round 4's two passes.
+template <bool HEAD>
+__global__ __launch_bounds__(kUni1Threads, kUni1Threads / 128) void uni_onepass_kernel(const uint32_t* __restrict__ cls, uint32_t npos, uint32_t cap,
+                                                                                        uint32_t* __restrict__ head_rows /*[gridDim.x][kUniHead]*/, UniState* __restrict__ us,
+                                                                                        uint16_t* __restrict__ tail /*[kUniBins][cap]*/, DevState* __restrict__ st) {
+    if (st->done) return;
+    __shared__ uint32_t histL[HEAD ? kUniHead : 1];
+    __shared__ uint16_t stageL[kUni1Tile];
+    __shared__ uint8_t  sbinL[kUni1Tile];
+    __shared__ uint32_t cntL[kUniBins], offL[kUniBins], curL[kUniBins], gbaseL[kUniBins], wsumL[4], redL[kUni1Threads / kWave], totL;
+    if (HEAD)
+        for (int k = threadIdx.x; k < kUniHead; k += kUni1Threads) histL[k] = 0;
+    const uint32_t ntiles = (npos + kUni1Tile - 1) / kUni1Tile;
+    uint32_t       nadm   = 0;
+    uint32_t       c[kUni1Per];
+    auto           load_tile = [&](uint32_t tile) {
+#pragma unroll
+        for (int q = 0; q < kUni1Per; ++q) {
+            const uint32_t i = tile * kUni1Tile + q * kUni1Threads + threadIdx.x;
+            c[q]             = (tile < ntiles && i < npos) ? cls[i] : 0u;
+        }
+    };
+    load_tile(blockIdx.x);
+    __syncthreads();
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t d[kUni1Per];
+#pragma unroll
+        for (int q = 0; q < kUni1Per; ++q) d[q] = c[q];
+        if (threadIdx.x < (uint32_t)kUniBins) {
+            cntL[threadIdx.x] = 0;
+            curL[threadIdx.x] = 0;
+        }
+        load_tile(tile + gridDim.x);  // the next tile's class ids travel while this one is counted
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kUni1Per; ++q) {
+            if (d[q] != 0) {
+                ++nadm;
+                if (d[q] < (uint32_t)kUniHead) {
+                    if (HEAD) atomicAdd(&histL[d[q]], 1u);
+                } else {
+                    atomicAdd(&cntL[(d[q] >> 4) & 255u], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t tot = bi2_uni_scan256(cntL, offL, wsumL);
+            if (threadIdx.x == 0) totL = tot;
+            if (threadIdx.x < (uint32_t)kUniBins) {
+                const uint32_t h = cntL[threadIdx.x];
+                uint32_t       g = 0;
+                if (h) {
+                    const uint32_t at = atomicAdd(&us->cur[threadIdx.x], h);  // one reservation per (tile, bin)
+                    if (at + h > cap) us->overflow = 1;
+                    g = threadIdx.x * cap + min(at, cap - min(cap, h));
+                }
+                gbaseL[threadIdx.x] = g;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kUni1Per; ++q) {
+            if (d[q] >= (uint32_t)kUniHead) {
+                const uint32_t b = (d[q] >> 4) & 255u, slot = offL[b] + atomicAdd(&curL[b], 1u);
+                stageL[slot]     = (uint16_t)(((d[q] >> 12) << 4) | (d[q] & 15u));
+                sbinL[slot]      = (uint8_t)b;
+            }
+        }
+        __syncthreads();
+        const uint32_t total = totL;
+        for (uint32_t j = threadIdx.x; j < total; j += kUni1Threads) {
+            const uint32_t b                          = sbinL[j];
+            tail[(size_t)gbaseL[b] + (j - offL[b])] = stageL[j];
+        }
+        __syncthreads();
+    }
+    if (!HEAD) return;
+    // the block's head histogram leaves as one plain row (flush atomics would run at the memory-side atomic rate)
+    for (int k = threadIdx.x; k < kUniHead; k += kUni1Threads) head_rows[(size_t)blockIdx.x * kUniHead + k] = histL[k];
+    for (int off = 32; off > 0; off >>= 1) nadm += __shfl_down(nadm, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) redL[threadIdx.x / kWave] = nadm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0;
+        for (int w = 0; w < kUni1Threads / kWave; ++w) a += redL[w];
+        if (a) atomicAdd(&st->admitted, a);
+    }
+}
+// block (bin, slice): LDS histogram of the bin's 16 x nrows classes (dynamic LDS: 64 x nrows bytes); class of offset k: ((k >> 4) << 12) | (bin << 4) | (k & 15)
+__global__ __launch_bounds__(kBlock) void uni_tail_count1_kernel(const uint16_t* __restrict__ tail, const UniState* __restrict__ us, uint32_t cap, uint32_t nrows,
+                                                                  uint32_t* __restrict__ cnt1, uint32_t nclasses, const DevState* __restrict__ st) {
+    if (st->done || us->overflow) return;
+    extern __shared__ uint32_t uniHistL[];
+    const uint32_t bin = blockIdx.x / kUniSlices, slice = blockIdx.x % kUniSlices;
+    const uint32_t n   = min(us->cur[bin], cap);
+    if (n == 0) return;
+    uint32_t nsl = (n + kUniSliceMin - 1) / kUniSliceMin;
+    if (nsl > (uint32_t)kUniSlices) nsl = kUniSlices;
+    if (slice >= nsl) return;
+    const uint32_t b0 = bin * cap, per = (n + nsl - 1) / nsl, begin = b0 + slice * per, end = min(b0 + n, begin + per);
+    const uint32_t width = nrows << 4;
+    for (uint32_t k = threadIdx.x; k < width; k += kBlock) uniHistL[k] = 0;
+    __syncthreads();
+    // 8 tokens (16 bytes) per load: the body of the slice is read as uint4, the unaligned ends token by token (cap is a multiple of 8)
+    const uint32_t vbegin = min(end, (begin + 7u) & ~7u), vend = max(vbegin, end & ~7u);
+    if (threadIdx.x < vbegin - begin) atomicAdd(&uniHistL[tail[begin + threadIdx.x]], 1u);
+    if (threadIdx.x < end - vend) atomicAdd(&uniHistL[tail[vend + threadIdx.x]], 1u);
+    const uint4* const v  = reinterpret_cast<const uint4*>(tail + vbegin);
+    const uint32_t     nv = (vend - vbegin) >> 3;
+    for (uint32_t j = threadIdx.x; j < nv; j += kBlock) {
+        const uint4 x = v[j];
+        atomicAdd(&uniHistL[x.x & 0xFFFFu], 1u);
+        atomicAdd(&uniHistL[x.x >> 16], 1u);
+        atomicAdd(&uniHistL[x.y & 0xFFFFu], 1u);
+        atomicAdd(&uniHistL[x.y >> 16], 1u);
+        atomicAdd(&uniHistL[x.z & 0xFFFFu], 1u);
+        atomicAdd(&uniHistL[x.z >> 16], 1u);
+        atomicAdd(&uniHistL[x.w & 0xFFFFu], 1u);
+        atomicAdd(&uniHistL[x.w >> 16], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < width; k += kBlock) {
+        const uint32_t h = uniHistL[k], cl = ((k >> 4) << 12) | (bin << 4) | (k & 15u);
+        if (h && cl < nclasses) atomicAdd(&cnt1[cl], h);
+    }
+}
+// a tail bin outgrew its room (a corpus built for it): the tail classes once more, with one global atomic per token
+__global__ __launch_bounds__(kBlock) void uni_tail_atomics_kernel(const uint32_t* __restrict__ cls, uint32_t npos, const UniState* __restrict__ us, uint32_t* __restrict__ cnt1,
+                                                                   const DevState* __restrict__ st) {
+    if (st->done || !us->overflow) return;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npos; i += gridDim.x * kBlock) {
+        const uint32_t c = cls[i];
+        if (c >= (uint32_t)kUniHead) atomicAdd(&cnt1[c], 1u);
     }
 }
 // classes -> result list (threshold), found / kept

@@ -528,3 +528,14 @@ def test_sentences_longer_than_the_u16_token_offset(ctx):
     assert got == want.counts
     for n in range(1, 5):
         assert st.windows[n] == (70_000 - n + 1) + (50 - n + 1) + (66_000 - n + 1)
+
+
+@pytest.mark.parametrize("env", [{"COLIBRI_UNI_BIN_CAP": "64"}, {"COLIBRI_UNI_TWO_PASS": "1"}], ids=["tail_bin_overflow", "two_pass"])
+def test_order_one_routes_match_the_oracle(env):
+    """Order 1 (reference include/patternmodel.h:1078-1178 at n = 1, prune :2107-2128) has three routes on the device: the one-pass partition (default), its overflow
+    route — a tail bin outgrew its fixed room: the tail classes are counted with global atomics (forced here by a room of 64 tokens; the corpora hold classes up to
+    20 000, i.e. beyond the 8 192 of the LDS head) — and round 4's two passes. All three must give the oracle's model."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "sliced_worker.py")], capture_output=True, text=True, env=dict(os.environ, **env), timeout=900)
+    assert p.returncode == 0 and "SLICED_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]

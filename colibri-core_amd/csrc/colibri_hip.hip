@@ -1074,12 +1074,18 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
     auto* const       recsA = reinterpret_cast<unsigned long long*>(c->recs[0].p);
     auto* const       recsB = reinterpret_cast<unsigned long long*>(c->recs[1].p);
     uint32_t* const   nlist = c->alist_n.p + 1;  // order 3 reads alist[3 & 1]
-    HIP_TRY(c, hipMemsetAsync(nlist, 0, sizeof(uint32_t), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->b2.wcnt.p, 0, sizeof(uint32_t) * ((size_t)kBi2Waves + b.wextra + 1), c->stream));  // (the last word: the pool's cursor between the passes of a sliced order)
+    // a chained run's order 2 starts from ONE launch that clears its state and the lists' counts (as every later order does); the other forms keep their fills
+    const bool one_reset = chain && b.sbits == 0;
+    if (one_reset) {
+        hipLaunchKernelGGL(chain_reset_kernel, dim3(256), dim3(kBlock), 0, c->stream, bs, c->b2.wcnt.p, kBi2Waves + b.wextra + 1);
+    } else {
+        HIP_TRY(c, hipMemsetAsync(nlist, 0, sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->b2.wcnt.p, 0, sizeof(uint32_t) * ((size_t)kBi2Waves + b.wextra + 1), c->stream));  // (the last word: the pool's cursor between the passes of a sliced order)
+    }
     uint32_t* const   keep = c->b2.wcnt.p + kBi2Waves + b.wextra;
     const BinnedIO io = binned_planes(c, pl, false);  // the sparse survivor arrays live in recs[0], free again after level B
     for (uint32_t slice = 0; slice < (1u << b.sbits); ++slice) {  // one pass per slice of the keys (one pass unless the corpus exceeds ~110 M positions)
-        HIP_TRY(c, hipMemsetAsync(bs, 0, sizeof(Bi2State), c->stream));
+        if (!one_reset) HIP_TRY(c, hipMemsetAsync(bs, 0, sizeof(Bi2State), c->stream));
         {
             Prof p(c, COLIBRI_K_EMIT2);
             if (slice == 0 || b.sbits < 2 || getenv("COLIBRI_SLICED_EMIT_OFF"))  // (two slices: a step of 16 384 positions would fill the queue)
@@ -1130,7 +1136,7 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
         }
     }
     if (!want_list) return COLIBRI_OK;
-    HIP_TRY(c, hipMemsetAsync(c->b2.bitmap.p + npos / 32, 0, sizeof(uint32_t) * 16, c->stream));  // words beyond the corpus read as zero
+    if (!chain) HIP_TRY(c, hipMemsetAsync(c->b2.bitmap.p + npos / 32, 0, sizeof(uint32_t) * 16, c->stream));  // words beyond the corpus read as zero (chain_bitmap_kernel's last block clears them itself)
     {
         Prof p(c, COLIBRI_K_LISTS2);
         hipLaunchKernelGGL(bi2_pospart_kernel, dim3(512), dim3(kBi2Threads), 0, c->stream, c->b2.wlist.p, c->b2.wcnt.p, kBi2Waves + b.wextra, b.wcap, bs, c->state.p, c->b2.plist.p, b.pl,

@@ -154,7 +154,7 @@ struct colibri_ctx {
         hipEvent_t       ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
         bool             compact_pending = false;  // an order's survivors are being copied to the result list on the second stream (nothing on the path reads them before the export)
         bool             chain_disabled = false;  // set for the rerun after an order >= 3 did not fit the engine (key bits, a region, a bin)
-        bool             attr_set = false;
+        bool             attr_set = false, ids_attr_set = false;
     } b2;
     DevBuf<uint32_t>  alist[2], alist_n; // binned path: active-position lists (ping-pong) and their lengths [2]
     DevBuf<BinState>  binstate;
@@ -1031,13 +1031,28 @@ inline uint32_t chain_dbg() {
 #endif
 }
 // result index per position from the (position, dense number) pairs an order left in the position lists (chain_ids_kernel), `ids` pre-filled with kInvalid
-void chain_ids(colibri_ctx* c, const Bigram2Plan& b, const Bi2State* bs, uint32_t* ids, const uint32_t* headid) {
+int chain_ids(colibri_ctx* c, const Bigram2Plan& b, const Bi2State* bs, uint32_t* ids, const uint32_t* headid) {
+    // bucket windows of up to 2^18 positions: built part by part in LDS and written as whole lines (chain_ids_full_kernel); larger ones (corpora beyond 2.7 x 10^8
+    // positions) and COLIBRI_IDS_SCATTER: round 4's scatter into the pre-filled array
+    static const bool scatter = getenv("COLIBRI_IDS_SCATTER") != nullptr;
+    if (!scatter && b.pshift <= 18) {
+        const uint32_t plog = std::max(2u, b.pshift > 15 ? b.pshift - 15 : 0u);
+        if (!c->b2.ids_attr_set) {
+            HIP_TRY(c, hipFuncSetAttribute((const void*)chain_ids_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            c->b2.ids_attr_set = true;
+        }
+        hipLaunchKernelGGL(chain_ids_full_kernel, dim3(((b.nbuckets + kChXcds - 1) / kChXcds) * (kChXcds << plog)), dim3(kBi2Threads), sizeof(uint32_t) << (b.pshift - plog), c->stream,
+                           (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p, b.pl, b.nbuckets, plog, c->npos, bs, (const DevState*)c->state.p, ids, headid);
+        return COLIBRI_OK;
+    }
+    HIP_TRY(c, hipMemsetAsync(ids, 0xFF, sizeof(uint32_t) * (size_t)c->npos, c->stream));
     const uint32_t cap = chain_steps_cap(b.pl);
     hipLaunchKernelGGL(chain_steps_kernel, dim3(kChXcds), dim3(kBi2Threads), 0, c->stream, bs, b.pl, b.nbuckets, reinterpret_cast<uint2*>(c->b2.steps.p), cap,
                        c->b2.steps.p + 2 * (size_t)kChXcds * cap, (const DevState*)c->state.p);
     static const uint32_t ids_grid = chain_grid("COLIBRI_IDS_GRID", 1024u);
     hipLaunchKernelGGL(chain_ids_kernel, dim3(ids_grid), dim3(kChThreads), 0, c->stream, (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p,
                        reinterpret_cast<const uint2*>(c->b2.steps.p), cap, (const uint32_t*)(c->b2.steps.p + 2 * (size_t)kChXcds * cap), bs, (const DevState*)c->state.p, ids, headid);
+    return COLIBRI_OK;
 }
 // the forward index's pairs of the order whose lists, bitmap and rank tables are in place (chain_pairs_kernel); the pair counters advance by the order's valid positions
 void chain_pairs(colibri_ctx* c, const Bigram2Plan& b, const Bi2State* bs, const uint32_t* headid) {
@@ -1066,7 +1081,6 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
         if ((rc = dev_alloc(c, c->b2.wcode, (size_t)(kBi2Waves + b.wextra) * b.wcap)) || (rc = dev_alloc(c, c->b2.pcode, (size_t)kBi2Shards * kBi2Buckets * b.pl.pcap + 64)) ||
             (rc = dev_alloc(c, c->b2.headid, kBi2HeadN)) || (rc = dev_alloc(c, c->b2.steps, 2 * (size_t)kChXcds * chain_steps_cap(b.pl) + kChXcds)))
             return rc;
-        HIP_TRY(c, hipMemsetAsync(ids_out, 0xFF, sizeof(uint32_t) * (size_t)npos, c->stream));
     }
     if (chain && b.sbits != 0) return fail(c, COLIBRI_ERR_STATE, "bigram2_order: the chained orders need the single-pass form");
     const bool        with_codes = ids_out != nullptr || (chain && want_list);
@@ -1145,12 +1159,16 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
             hipLaunchKernelGGL(bi2_headids_kernel, dim3(1), dim3(kBlock), 0, c->stream, (const Bi2State*)bs, (const DevState*)c->state.p, c->b2.headid.p);
             hipLaunchKernelGGL(chain_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, (const Bi2State*)bs, (const uint32_t*)c->b2.plist.p, b.pl,
                                c->state.p, c->b2.bitmap.p, (const uint32_t*)c->b2.pcode.p, (const uint32_t*)c->b2.headid.p);
-            if (ids_out != nullptr) chain_ids(c, b, bs, ids_out, (const uint32_t*)c->b2.headid.p);  // (the id-keeping modes on the chained engine: the head windows are in the lists)
+            if (ids_out != nullptr) {  // (the id-keeping modes on the chained engine: the head windows are in the lists)
+                int rci;
+                if ((rci = chain_ids(c, b, bs, ids_out, (const uint32_t*)c->b2.headid.p))) return rci;
+            }
             return COLIBRI_OK;
         }
         if (ids_out != nullptr) {
             // the ids' scatter in the step order of chain_emit_kernel (an XCD's blocks fill ~3 bucket windows at a time: whole lines leave L2), not one block per bucket
-            chain_ids(c, b, bs, ids_out, nullptr);
+            int rci;
+            if ((rci = chain_ids(c, b, bs, ids_out, nullptr))) return rci;
             hipLaunchKernelGGL(bi2_headids_kernel, dim3(1), dim3(kBlock), 0, c->stream, bs, c->state.p, c->b2.headid.p);
         }
         hipLaunchKernelGGL(bi2_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, bs, c->b2.plist.p, b.pl, c->state.p, c->b2.bitmap.p);
@@ -1221,8 +1239,8 @@ int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next, uint
     if (c->b2.pairs_direct) chain_pairs(c, b, bs, nullptr);
     if (ids_out != nullptr) {
         Prof p(c, COLIBRI_K_RESOLVE);
-        HIP_TRY(c, hipMemsetAsync(ids_out, 0xFF, sizeof(uint32_t) * (size_t)npos, c->stream));
-        chain_ids(c, b, bs, ids_out, nullptr);
+        int rci;
+        if ((rci = chain_ids(c, b, bs, ids_out, nullptr))) return rci;
     }
     return COLIBRI_OK;
 }

@@ -511,27 +511,39 @@ __global__ __launch_bounds__(kBi2Threads) void chain_ids_full_kernel(const uint3
     for (uint32_t k = threadIdx.x; k < wlen; k += kBi2Threads) idsL[k] = kInvalid;
     __syncthreads();
     const uint32_t res_base = bs->res_base, nl = headid != nullptr ? kChLists : (uint32_t)kBi2Shards;
-    for (uint32_t x = 0; x < nl; ++x) {
-        uint32_t first, cap;
-        bi2_list_of(pl, x, bucket, first, cap);
-        const uint32_t     n  = min(bs->pcur[x * kBi2Buckets + bucket], cap);
-        const uint4* const v  = reinterpret_cast<const uint4*>(plist + first);  // 16-byte aligned: pcap and hbase are multiples of 4
-        const uint32_t     nv = n >> 2;
-        auto               put = [&](uint32_t pos, uint32_t at) {
-            const uint32_t o = pos - start;
-            if (o < wlen) {
-                const uint32_t cd = pcode[at];
-                idsL[o]           = (headid != nullptr && (cd & kBi2HeadCode)) ? headid[cd & 0xFFFu] : res_base + cd;
-            }
-        };
-        for (uint32_t j = threadIdx.x; j < nv; j += kBi2Threads) {
-            const uint4 e = v[j];
-            put(e.x, first + 4 * j);
-            put(e.y, first + 4 * j + 1);
-            put(e.z, first + 4 * j + 2);
-            put(e.w, first + 4 * j + 3);
+    // all lists of the bucket at once: their lengths, then one 16-byte load per list and round in flight together (list after list, each round trip waited for the one
+    // before: 0.51 ms per order, a block per CU has nothing else to run)
+    uint32_t first[kChLists], nn[kChLists], nmax = 0;
+#pragma unroll
+    for (uint32_t x = 0; x < kChLists; ++x) {
+        uint32_t cap = 0;
+        first[x] = nn[x] = 0;
+        if (x < nl) {
+            bi2_list_of(pl, x, bucket, first[x], cap);
+            nn[x] = min(bs->pcur[x * kBi2Buckets + bucket], cap);
         }
-        if (threadIdx.x < (n & 3u)) put(plist[first + (nv << 2) + threadIdx.x], first + (nv << 2) + threadIdx.x);
+        nmax = max(nmax, nn[x]);
+    }
+    auto put = [&](uint32_t pos, uint32_t at) {
+        const uint32_t o = pos - start;
+        if (o < wlen) {
+            const uint32_t cd = pcode[at];
+            idsL[o]           = (headid != nullptr && (cd & kBi2HeadCode)) ? headid[cd & 0xFFFu] : res_base + cd;
+        }
+    };
+    for (uint32_t j = threadIdx.x; j * 4u < nmax; j += kBi2Threads) {
+        uint4 e[kChLists];
+#pragma unroll
+        for (uint32_t x = 0; x < kChLists; ++x)  // (16-byte aligned: pcap and hbase are multiples of 4; a list's last, partial vector is read whole — the lists have room —
+            e[x] = j * 4u < nn[x] ? reinterpret_cast<const uint4*>(plist + first[x])[j] : make_uint4(0u, 0u, 0u, 0u);  // and cut by the length below)
+#pragma unroll
+        for (uint32_t x = 0; x < kChLists; ++x) {
+            const uint32_t at = first[x] + 4u * j, left = nn[x] > 4u * j ? nn[x] - 4u * j : 0u;
+            if (left > 0u) put(e[x].x, at);
+            if (left > 1u) put(e[x].y, at + 1u);
+            if (left > 2u) put(e[x].z, at + 2u);
+            if (left > 3u) put(e[x].w, at + 3u);
+        }
     }
     __syncthreads();
     const uint32_t m = min(wlen, npos - start);

@@ -1036,7 +1036,8 @@ int chain_ids(colibri_ctx* c, const Bigram2Plan& b, const Bi2State* bs, uint32_t
     // positions) and COLIBRI_IDS_SCATTER: round 4's scatter into the pre-filled array
     static const bool scatter = getenv("COLIBRI_IDS_SCATTER") != nullptr;
     if (!scatter && b.pshift <= 18) {
-        const uint32_t plog = std::max(2u, b.pshift > 15 ? b.pshift - 15 : 0u);
+        static const uint32_t plog_min = getenv("COLIBRI_IDS_PLOG") ? (uint32_t)atoi(getenv("COLIBRI_IDS_PLOG")) : 2u;  // (parts per bucket, log2; measured at 10^8 tokens, indexed model: 2 / 3 / 4 -> 9.30 / 9.62 / 10.13 ms — the parts' re-reads of the lists reach HBM)
+        const uint32_t plog = std::min(b.pshift, std::max(std::min(plog_min, 6u), b.pshift > 15 ? b.pshift - 15 : 0u));
         if (!c->b2.ids_attr_set) {
             HIP_TRY(c, hipFuncSetAttribute((const void*)chain_ids_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
             c->b2.ids_attr_set = true;

@@ -139,6 +139,57 @@ __global__ __launch_bounds__(kKsThreads) void ks2_move_kernel(const unsigned lon
     }
 }
 
+// Round 5: one block per SLOT (sub-region, A bin) instead of one per A bin: 2048 blocks instead of 256 — a block per CU streaming 332 000 records through LDS cursors
+// had nothing to hide its round trips behind (0.46 ms at order 2 for 0.68 GB in, 0.68 GB out). A slot's records start, per (B, C), where the slots before it in the
+// same A bin end: the A bin's places as before (tab rows scanned, rowbase) plus the (B, C) counts level B left for the sub-regions before this one (cbhist).
+__global__ __launch_bounds__(kKsThreads) void ks2_move_slot_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const Bi2State* __restrict__ bs, uint32_t w, uint32_t nsub,
+                                                                    const uint32_t* __restrict__ tab, const Ks2State* __restrict__ ks, const uint32_t* __restrict__ cbhist, uint32_t pshift,
+                                                                    uint32_t pdrop, uint32_t* __restrict__ key4, uint32_t* __restrict__ posbuf) {
+    __shared__ uint32_t curL[kKsWorld * kBi2BBins], inL[kBi2BBins], outL[kBi2BBins], wsumL[8];
+    const uint32_t      slot = blockIdx.x, s = slot / kBins, a = slot % kBins;
+    if (s >= nsub) return;
+    const uint32_t n = min(bs->curA[slot], region);
+    if (n == 0) return;
+    const uint32_t W = 1u << w, bsh = bs->bshift, pb = bs->posbits, lb = 9 - bsh;
+    const uint32_t bbit = pb + bs->kbits - 17, cbit = bbit + bsh - w, kmask = (1u << (cbit - pb)) - 1u;
+    const uint32_t d = a >> (8 - w), alow = a & ((1u << (8 - w)) - 1u);
+    const unsigned long long pmask = (1ull << pb) - 1ull;
+    for (uint32_t r = 0; r < W; ++r) {
+        const uint32_t row = d * kBins + ((alow << w) | r);
+        if (threadIdx.x < (uint32_t)kBi2BBins) inL[threadIdx.x] = tab[(size_t)row * kBi2BBins + threadIdx.x];
+        __syncthreads();
+        bi2_scan512(inL, outL, wsumL);
+        if (threadIdx.x < (1u << lb)) curL[(r << lb) | threadIdx.x] = ks->rowbase[row] + outL[threadIdx.x];
+        __syncthreads();
+    }
+    for (uint32_t e = threadIdx.x; e < (1u << (lb + w)); e += kKsThreads) {
+        uint32_t before = 0;
+        for (uint32_t t = 0; t < s; ++t) before += cbhist[(size_t)(t * kBins + a) * (8 * kBi2BBins) + e];
+        curL[e] += before;
+    }
+    __syncthreads();
+    const size_t base = (size_t)slot * region;
+    for (uint32_t j0 = 0; j0 < n; j0 += 4 * kKsThreads) {
+        unsigned long long r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t j = j0 + k * kKsThreads + threadIdx.x;
+            r[k]             = j < n ? recsB[base + j] : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (j0 + k * kKsThreads + threadIdx.x < n) {
+                const uint32_t e  = (uint32_t)(r[k] >> cbit) & ((1u << (lb + w)) - 1u);
+                const uint32_t at = atomicAdd(&curL[e], 1u);
+                uint32_t       p  = (uint32_t)(r[k] & pmask);
+                if (pdrop) p = ((p >> pshift) << (pshift + 3)) | (s << pshift) | (p & ((1u << pshift) - 1u));
+                key4[at]   = (uint32_t)(r[k] >> pb) & kmask;
+                posbuf[at] = p;
+            }
+        }
+    }
+}
+
 // ---- owner: the received tables -> the run bounds the count kernel reads --------------------------------------------------------------------------------------------------
 // block a' (512 threads): per source the exclusive scan of row (source, a') -> oboff[(source * 256 + a') * 513 + b]; rowtot[source * 256 + a']
 __global__ __launch_bounds__(kBi2BBins) void ks2_owner_rows_kernel(const uint32_t* __restrict__ tab_recv, uint32_t world, uint32_t* __restrict__ oboff, uint32_t* __restrict__ rowtot) {

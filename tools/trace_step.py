@@ -2,7 +2,7 @@
 usage: python tools/trace_step.py <kernel_trace.csv> [first-kernel-substring]"""
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r['Start_Timestamp']))
-first = sys.argv[2] if len(sys.argv) > 2 else 'uni_head_kernel'
+first = sys.argv[2] if len(sys.argv) > 2 else "uni_onepass_kernel"
 starts = [i for i, r in enumerate(rows) if first in r['Kernel_Name']]
 i0 = starts[-1]
 step = rows[i0:]

@@ -201,6 +201,18 @@ def z1b_configs(capi, shards):
             mode, passes = c.last_mode(with_passes=True)
             entry["kinds"][name] = {"ms_per_step": round(best, 2), "patterns_in_model": int(st.npatterns), "references": int(st.nrefs),
                                     "path": "radix" if mode == 2 else "global table", "passes_at_order_2": passes}
+            # round 5: the reference's own model of these three shards (tests/golden/fullsize/z375m_seeds44_46_plain.json, 2490 s of its train()): the plain model row for
+            # row; the indexed model holds the same patterns with the same counts (its reference lists are pinned at 10^8 tokens: other_configs.indexed)
+            fx375 = load_fixture("z375m_seeds44_46_plain") if name in ("plain", "indexed") else None
+            if fx375 is not None:
+                from colibri_amd import digest
+                key_off, key_bytes, counts, _ = c.export_arrays()
+                d = digest.model_digest(key_off, key_bytes, counts)
+                ok = all(d[k] == fx375[k] for k in ("sum1", "xor1", "sum2", "xor2", "npatterns", "occurrences", "keybytes"))
+                entry["kinds"][name]["self_check"] = ("ok" if ok else "FAILED") + ": (key, count) rows = the reference's model of these shards"
+                del key_off, key_bytes, counts
+            else:
+                entry["kinds"][name]["self_check"] = "no reference model (the same kind is pinned at 10^8 tokens: other_configs.exhaustive_skipgrams)"
         res["z375m_single_device"] = entry
     fx = load_fixture("z1b_seeds44_51_plain")  # what the reference's own train() left for this corpus (8030 s on one core of the build container)
     want = (fx["npatterns"], [o["kept"] for o in fx["orders"]]) if fx else None

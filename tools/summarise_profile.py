@@ -35,6 +35,18 @@ with open(os.path.join(out, f"{tag}_pmc_by_kernel.csv"), "w", newline="") as f:
         n = max(len(fs), len(ws), 1)
         w.writerow([k, n, round(sum(fs), 1), round(sum(fs) / n, 1), round(sum(ws), 1), round(sum(ws) / n, 1)])
 
+# Σ over the step's kernels, per step: a step = one launch of bi2_emit_kernel (order 2's scan); kernels launched less often than that are per-run (tokeniser, export)
+steps = max((len(d.get("FETCH_SIZE", [])) for k, d in agg.items() if "bi2_emit_kernel" in k), default=0)
+if steps:
+    f_sum = sum(sum(d.get("FETCH_SIZE", [])) for k, d in agg.items() if len(d.get("FETCH_SIZE", [])) >= steps) * 1024 / steps
+    w_sum = sum(sum(d.get("WRITE_SIZE", [])) for k, d in agg.items() if len(d.get("WRITE_SIZE", [])) >= steps) * 1024 / steps
+    step_sum = {"steps_profiled": steps, "fetch_bytes_per_step_raw": round(f_sum), "write_bytes_per_step_raw": round(w_sum),
+                "hbm_bytes_per_step_2F_plus_W": round(2 * f_sum + w_sum), "note": "per-step kernels only (launched at least once per step); FETCH_SIZE doubled as for the dominant kernel"}
+    with open(os.path.join(out, f"{tag}_pmc_step_sum.json"), "w") as f:
+        json.dump(step_sum, f, indent=1)
+    print("sum over the step's kernels:", json.dumps(step_sum))
+
+
 def tot(pattern, counter):
     return sum(sum(d.get(counter, [])) for k, d in agg.items() if pattern in k)
 

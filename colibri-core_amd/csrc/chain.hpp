@@ -499,11 +499,26 @@ __global__ __launch_bounds__(kChThreads) void chain_ids_kernel(const uint32_t* _
 // after the other in dispatch order, so the lists come from HBM once — and writes the window out as whole lines, kInvalid where no window survived: no fill of the array
 // beforehand, no partial-line writes (chain_ids_kernel: 1.59 GB written for 0.42 GB of ids, 0.4-0.66 ms per order; the fill: 0.1 ms).
 // grid: ceil(nbuckets / 8) * parts * 8 blocks of kBi2Threads; dynamic LDS: 4 << (pshift - plog) bytes.
+// PairsOut (indexed models, order 2): the part's ids ARE the forward index's pairs of these positions, in position order — pair k of the part lands at
+// (pairs before the bucket) + (the bitmap's prefix at the part's first word: chain_bitmap_kernel's wpre / btot) + k: no array of ids in memory, no counting and no
+// writing sweep over it (emit_count / emit_write_kernel: 0.13 + 0.49 ms per 10^8 tokens). Same content and order as emit_write_kernel's pairs.
+struct ChainPairsOut {
+    const uint32_t*           wpre;    // per bitmap word: set bits of the bucket before the word; nullptr: no pairs
+    const uint32_t*           btot;    // per bucket: its set bits
+    const uint4*              blocks;  // PosBlock per 64 positions
+    const unsigned long long* chain;   // pair counters: chain[which] = pairs written so far
+    unsigned long long*       pairs;
+    uint32_t*                 pay;     // split pairs: ids as u32 in `pairs`, references here; nullptr: packed 64-bit pairs
+    unsigned long long        pcap;
+    int                       which;
+    uint32_t                  sb, tb;
+};
 __global__ __launch_bounds__(kBi2Threads) void chain_ids_full_kernel(const uint32_t* __restrict__ plist, const uint32_t* __restrict__ pcode, Bi2Lists pl, uint32_t nbuckets, uint32_t plog,
-                                                                      uint32_t npos, const Bi2State* __restrict__ bs, const DevState* __restrict__ st, uint32_t* __restrict__ ids,
-                                                                      const uint32_t* __restrict__ headid) {
+                                                                      uint32_t npos, const Bi2State* __restrict__ bs, const DevState* __restrict__ st, uint32_t* __restrict__ ids /* or nullptr */,
+                                                                      const uint32_t* __restrict__ headid, ChainPairsOut po) {
     if (st->done) return;
     extern __shared__ uint32_t idsL[];
+    __shared__ uint32_t        wsumL[kBi2Threads / kWave];
     const uint32_t xcd = blockIdx.x % kChXcds, part = (blockIdx.x / kChXcds) & ((1u << plog) - 1u), bucket = (blockIdx.x / (kChXcds << plog)) * kChXcds + xcd;
     if (bucket >= nbuckets) return;
     const uint32_t wlen = (1u << pl.pshift) >> plog, start = (bucket << pl.pshift) + part * wlen;
@@ -547,7 +562,50 @@ __global__ __launch_bounds__(kBi2Threads) void chain_ids_full_kernel(const uint3
     }
     __syncthreads();
     const uint32_t m = min(wlen, npos - start);
-    for (uint32_t k = threadIdx.x; k < m; k += kBi2Threads) ids[start + k] = idsL[k];
+    if (ids != nullptr)
+        for (uint32_t k = threadIdx.x; k < m; k += kBi2Threads) ids[start + k] = idsL[k];
+    if (po.wpre == nullptr) return;
+    // pairs: a wave takes rows of 64 consecutive positions (one entry of the position table per row), ballots give every pair its place: coalesced stores.
+    // (A lane per 32 consecutive positions, each writing its own run of ~14 pairs, made every store a partial line: 0.9 ms slower than the sweeps it replaces.)
+    uint32_t before = 0;  // set bits of the buckets before this one
+    for (uint32_t k = threadIdx.x; k < bucket; k += kBi2Threads) before += po.btot[k];
+    uint32_t btotal;
+    bi2_block_scan<kBi2Threads>(before, &btotal, wsumL);
+    constexpr uint32_t kW   = kBi2Threads / kWave;
+    const uint32_t     lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint32_t     rows = (m + kWave - 1) / kWave, rper = (rows + kW - 1) / kW, r0 = wave * rper, r1 = min(rows, r0 + rper);  // this wave's rows
+    uint32_t           mine = 0;
+    for (uint32_t r = r0; r < r1; ++r) {
+        const uint32_t k = r * kWave + lane;
+        mine += (uint32_t)__popcll(__ballot(k < m && idsL[k] != kInvalid));
+    }
+    uint32_t       ptotal;
+    const uint32_t wexcl = bi2_block_scan<kBi2Threads>(lane == 0 ? mine : 0u, &ptotal, wsumL);  // pairs of the waves before (the value of the wave's lane 0 counts)
+    const uint32_t wbase = (uint32_t)__shfl((int)wexcl, 0, kWave);
+    const uint32_t tmask = po.tb >= 32 ? 0xFFFFFFFFu : (1u << po.tb) - 1u;
+    uint64_t       o     = po.chain[po.which] + btotal + po.wpre[start >> 5] + wbase;
+    for (uint32_t r = r0; r < r1; ++r) {
+        const uint32_t k = r * kWave + lane, p = start + k;
+        const uint32_t id = k < m ? idsL[k] : kInvalid;
+        const uint64_t mk = __ballot(id != kInvalid);
+        if (mk == 0) continue;
+        const uint4 rb = po.blocks[p >> 6];  // (start is a multiple of 64: the row is one block of the table, the same address for the 64 lanes)
+        if (id != kInvalid) {
+            const uint64_t at = o + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+            if (at < po.pcap) {  // (pairs_advance_kernel flags the overflow)
+                const uint32_t bit   = p & 63u;
+                const uint64_t below = ((((uint64_t)rb.w << 32) | rb.z)) & ((1ull << bit) - 1ull);
+                const uint32_t sent = rb.x + (uint32_t)__popcll(below), tok = below ? bit - (64u - (uint32_t)__clzll(below)) : p - rb.y;
+                if (po.pay != nullptr) {
+                    reinterpret_cast<uint32_t*>(po.pairs)[at] = id;
+                    po.pay[at]                                = (sent << po.tb) | (tok & tmask);
+                } else {
+                    po.pairs[at] = ((unsigned long long)id << (po.sb + po.tb)) | ((unsigned long long)sent << po.tb) | (tok & tmask);
+                }
+            }
+        }
+        o += (uint32_t)__popcll(mk);
+    }
 }
 
 // ---- the forward index's (pattern, reference) pairs of an order, straight from the order's position lists (indexed models without skipgram passes) ---------------------

@@ -147,6 +147,7 @@ struct colibri_ctx {
         DevBuf<uint32_t> wcode, pcode, headid;  // the modes that keep ids: (bin, rank) codes beside the positions, result index of every head bigram
         bool             disabled = false;  // set for the rerun after this path could not hold an order (region / bin / list overflow)
         DevBuf<uint32_t> wpre, btot;        // ... chain_bitmap_kernel's rank tables (per bitmap word / per bucket) when the forward index's pairs come straight from the lists
+        bool             pairs2_direct = false;  // ... and order 2's from chain_ids_full_kernel's LDS parts (round 5)
         bool             pairs_direct = false;  // an indexed model on the chained engine: the pairs of the orders >= 3 come from chain_pairs_kernel, not from sweeps over ids per position
         DevBuf<uint32_t> steps;             // ... chain_steps_kernel: the step tables of the eight XCDs, then their lengths
         DevBuf<Bi2State> state2, state3;    // chain.hpp: orders >= 3 on this engine ping-pong between these two (odd orders: state2); order 2's stays in `state`
@@ -1031,11 +1032,28 @@ inline uint32_t chain_dbg() {
 #endif
 }
 // result index per position from the (position, dense number) pairs an order left in the position lists (chain_ids_kernel), `ids` pre-filled with kInvalid
-int chain_ids(colibri_ctx* c, const Bigram2Plan& b, const Bi2State* bs, uint32_t* ids, const uint32_t* headid) {
-    // bucket windows of up to 2^18 positions: built part by part in LDS and written as whole lines (chain_ids_full_kernel); larger ones (corpora beyond 2.7 x 10^8
-    // positions) and COLIBRI_IDS_SCATTER: round 4's scatter into the pre-filled array
+// bucket windows of up to 2^18 positions are built part by part in LDS and written as whole lines (chain_ids_full_kernel); larger ones (corpora beyond 2.7 x 10^8
+// positions) and COLIBRI_IDS_SCATTER: round 4's scatter into the pre-filled array
+inline bool chain_ids_full_applies(const Bigram2Plan& b) {
     static const bool scatter = getenv("COLIBRI_IDS_SCATTER") != nullptr;
-    if (!scatter && b.pshift <= 18) {
+    return !scatter && b.pshift <= 18;
+}
+// pairs: also the forward index's pairs of the order, from the same LDS parts (indexed chained runs, order 2; the bitmap kernel has left wpre / btot); ids may then be null
+int chain_ids(colibri_ctx* c, const Bigram2Plan& b, const Bi2State* bs, uint32_t* ids, const uint32_t* headid, bool pairs = false) {
+    if (chain_ids_full_applies(b)) {
+        ChainPairsOut po{};
+        if (pairs) {
+            po.wpre   = c->b2.wpre.p;
+            po.btot   = c->b2.btot.p;
+            po.blocks = reinterpret_cast<const uint4*>(c->pos_blocks.p);
+            po.chain  = c->pair_chain.p;
+            po.pairs  = c->pairs[0].p;
+            po.pcap   = c->pairs[0].n;
+            po.pay    = c->pair_split ? reinterpret_cast<uint32_t*>(c->pairs[0].p) + po.pcap : (uint32_t*)nullptr;
+            po.which  = c->pair_pass;
+            po.sb     = c->pair_sb;
+            po.tb     = c->pair_tb;
+        }
         static const uint32_t plog_min = getenv("COLIBRI_IDS_PLOG") ? (uint32_t)atoi(getenv("COLIBRI_IDS_PLOG")) : 2u;  // (parts per bucket, log2; measured at 10^8 tokens, indexed model: 2 / 3 / 4 -> 9.30 / 9.62 / 10.13 ms — the parts' re-reads of the lists reach HBM)
         const uint32_t plog = std::min(b.pshift, std::max(std::min(plog_min, 6u), b.pshift > 15 ? b.pshift - 15 : 0u));
         if (!c->b2.ids_attr_set) {
@@ -1043,9 +1061,14 @@ int chain_ids(colibri_ctx* c, const Bigram2Plan& b, const Bi2State* bs, uint32_t
             c->b2.ids_attr_set = true;
         }
         hipLaunchKernelGGL(chain_ids_full_kernel, dim3(((b.nbuckets + kChXcds - 1) / kChXcds) * (kChXcds << plog)), dim3(kBi2Threads), sizeof(uint32_t) << (b.pshift - plog), c->stream,
-                           (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p, b.pl, b.nbuckets, plog, c->npos, bs, (const DevState*)c->state.p, ids, headid);
+                           (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p, b.pl, b.nbuckets, plog, c->npos, bs, (const DevState*)c->state.p, ids, headid, po);
+        if (pairs) {
+            hipLaunchKernelGGL(pairs_advance_kernel, dim3(1), dim3(1), 0, c->stream, c->pair_chain.p, c->pair_pass, (const uint32_t*)&c->state.p->valid, po.pcap);
+            c->pair_pass ^= 1;
+        }
         return COLIBRI_OK;
     }
+    if (pairs || ids == nullptr) return fail(c, COLIBRI_ERR_STATE, "chain_ids: pairs need the LDS form");
     HIP_TRY(c, hipMemsetAsync(ids, 0xFF, sizeof(uint32_t) * (size_t)c->npos, c->stream));
     const uint32_t cap = chain_steps_cap(b.pl);
     hipLaunchKernelGGL(chain_steps_kernel, dim3(kChXcds), dim3(kBi2Threads), 0, c->stream, bs, b.pl, b.nbuckets, reinterpret_cast<uint2*>(c->b2.steps.p), cap,
@@ -1158,11 +1181,13 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
                            with_codes ? (const uint32_t*)c->b2.wcode.p : (const uint32_t*)nullptr, with_codes ? c->b2.pcode.p : (uint32_t*)nullptr, 0u, /*dense=*/chain || ids_out != nullptr);
         if (chain) {  // who of the head pairs survived; the bitmap of all listed positions (and st->valid). The pairs stay where they are: chain_order(3) walks them
             hipLaunchKernelGGL(bi2_headids_kernel, dim3(1), dim3(kBlock), 0, c->stream, (const Bi2State*)bs, (const DevState*)c->state.p, c->b2.headid.p);
+            const bool pairs2 = c->b2.pairs2_direct;  // (an indexed chained run: order 2's forward-index pairs leave with the ids' LDS parts)
             hipLaunchKernelGGL(chain_bitmap_kernel, dim3(b.nbuckets), dim3(kBi2BmThreads), ((size_t)1 << b.pshift) / 8, c->stream, npos, (const Bi2State*)bs, (const uint32_t*)c->b2.plist.p, b.pl,
-                               c->state.p, c->b2.bitmap.p, (const uint32_t*)c->b2.pcode.p, (const uint32_t*)c->b2.headid.p);
-            if (ids_out != nullptr) {  // (the id-keeping modes on the chained engine: the head windows are in the lists)
+                               c->state.p, c->b2.bitmap.p, (const uint32_t*)c->b2.pcode.p, (const uint32_t*)c->b2.headid.p, pairs2 ? c->b2.wpre.p : (uint32_t*)nullptr,
+                               pairs2 ? c->b2.btot.p : (uint32_t*)nullptr);
+            if (ids_out != nullptr || pairs2) {  // (the id-keeping modes on the chained engine: the head windows are in the lists)
                 int rci;
-                if ((rci = chain_ids(c, b, bs, ids_out, (const uint32_t*)c->b2.headid.p))) return rci;
+                if ((rci = chain_ids(c, b, bs, ids_out, (const uint32_t*)c->b2.headid.p, pairs2))) return rci;
             }
             return COLIBRI_OK;
         }
@@ -2141,6 +2166,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     c->segments.clear();
     c->npairs = 0;
     c->b2.pairs_direct = false;
+    c->b2.pairs2_direct = false;
     if (c->b2.compact_pending) {  // (a run that ended early left a copy on the second stream)
         (void)hipStreamSynchronize(c->b2.aux);
         c->b2.compact_pending = false;
@@ -2435,12 +2461,13 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             // the ranks' gathers cost what the sweeps do (measured: 2.2 ms with three gathers per pair, ~1 ms at best). Without skipgram passes nobody reads the ids of the
             // orders >= 3 then, and they are not built
             c->b2.pairs_direct = chain_synced && o.indexed && c->pair_sb != 0 && !getenv("COLIBRI_NO_DIRECT_PAIRS");
+            c->b2.pairs2_direct = c->b2.pairs_direct && chain_ids_full_applies(bigram2_plan(c, npos)) && !getenv("COLIBRI_NO_DIRECT_PAIRS2");  // order 2's too (round 5)
             // Who reads ids[n] (n >= 2) of a chained run: trainskipgrams' lists and keys (every order), emit_pairs (order 2; the higher orders unless their pairs come
             // from the lists), the exhaustive passes' part ids (parts have at most maxlength - 2 tokens; their gate is the list itself: chain_alist_kernel's windows ARE
             // the admitted ones). Nobody else: an order's fill + scatter (0.06 + 0.03..0.6 ms) is skipped where nobody does
             auto want_ids = [&](int n) {
                 if (!chain_synced || o.doskipgrams || getenv("COLIBRI_ALL_IDS")) return true;
-                if (o.indexed && (n == 2 || !c->b2.pairs_direct)) return true;
+                if (o.indexed && ((n == 2 && !c->b2.pairs2_direct) || !c->b2.pairs_direct)) return true;
                 return o.doskipgrams_exhaustive && n <= maxlength - 2;
             };
             // ... and order 1's come from the class ids (survivor bit, result index per class): nobody reads ids[1] then (order 2 is keyed by classes)
@@ -2497,7 +2524,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                     if ((rc = emit_pairs(c, pl, c->cls.p, false, c->uni_surv.p, c->uni_resid.p))) return rc;
                 }
                 hipLaunchKernelGGL(idm_ngram_end_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, n);
-                if (o.indexed && !(c->b2.pairs_direct && n >= 3) && !(n == 1 && uni_pairs_direct) && (rc = emit_pairs(c, pl, c->ids[n].p, false))) return rc;
+                if (o.indexed && !(c->b2.pairs_direct && (n >= 3 || (n == 2 && c->b2.pairs2_direct))) && !(n == 1 && uni_pairs_direct) && (rc = emit_pairs(c, pl, c->ids[n].p, false))) return rc;
                 if (o.doskipgrams_exhaustive && n >= 3) {  // patternmodel.h:1163-1171 -> computeskipgrams :1370-1527, for every admissible window: the order's own active list
                     if (n > kMaxSkipgramTokens) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 31 tokens do not exist (a gap mask has 32 bits; set MAXLENGTH)");
                     c->skl   = c->alist[n & 1].p;

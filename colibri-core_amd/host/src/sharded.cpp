@@ -304,11 +304,16 @@ class RankDriver {
         }
         if (!all_ok || maxclass_g >= (1u << 21) || npos_g >= (1u << 28)) return false;
         std::string err;
-        // COLIBRI_FAULT="<rank>:<step name>" (tests): that rank pretends the step failed — every rank must then leave the run together, with that message
+        // COLIBRI_FAULT="<rank>:<step name>" (test builds only: -DCOLIBRI_TEST_HOOKS — lib/libcolibri_sharded_hooks.so and the mock; the shipped trainer does not read it):
+        // that rank pretends the step failed — every rank must then leave the run together, with that message
+#ifdef COLIBRI_TEST_HOOKS
         static const char* const fault = std::getenv("COLIBRI_FAULT");
+#endif
         auto        step = [&](int rc, const char* what) {
             if (rc != COLIBRI_OK && err.empty()) err = std::string(what) + ": " + colibri_last_error(c) + " (status " + std::to_string(rc) + ")";
+#ifdef COLIBRI_TEST_HOOKS
             if (fault && err.empty() && std::atoi(fault) == rank && std::strchr(fault, ':') && std::string(std::strchr(fault, ':') + 1) == what) err = std::string(what) + ": injected fault";
+#endif
             return err.empty();
         };
         step(colibri_kshard_begin(c, &o, world, rank, maxclass_g, npos_g), "colibri_kshard_begin");

@@ -464,8 +464,8 @@ def load_sharded():
     global _shlib
     if _shlib is None:
         path = os.environ.get("COLIBRI_SHARDED_LIB", SHARDED_LIB_PATH)  # (tests: lib/libcolibri_sharded_mock.so — the same driver over a CPU stand-in for the device layer)
-        if path == SHARDED_LIB_PATH:
-            load()  # libcolibri_hip.so first (the trainer links it)
+        if "mock" not in os.path.basename(path):
+            load()  # libcolibri_hip.so first (the trainer — and its test build with the fault hook, libcolibri_sharded_hooks.so — links it)
         if not os.path.exists(path):
             raise ImportError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
         S = C.CDLL(path)

@@ -155,7 +155,7 @@ def test_a_step_that_fails_on_one_rank_takes_every_rank_out_together(fault, tmp_
     a barrier or a collective: all leave the run at the same agreement, the trainer repeats it with the candidate exchange, and the model is still the oracle's."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, COLIBRI_FAULT=fault)
+    env = dict(os.environ, COLIBRI_FAULT=fault, COLIBRI_SHARDED_LIB=os.path.join(root, "colibri-core_amd", "lib", "libcolibri_sharded_hooks.so"))  # (the shipped trainer has no hook)
     p = subprocess.run([sys.executable, "-c", FAULT_SCRIPT, os.path.join(root, "tests"), os.path.join(root, "oracle")], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     assert "PROTOCOL 1" in p.stdout, p.stdout[-500:]

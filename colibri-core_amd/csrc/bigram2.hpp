@@ -101,6 +101,8 @@ struct __attribute__((aligned(16))) Bi2State {
     uint32_t bshift_fix; // key-sharded runs: bshift + 1 as every rank agreed on it (0: bi2_offsets_kernel derives it from this pass's record count)
     uint32_t ran;        // set by bi2_finish_kernel: this order was counted (the run had not ended before it) — what bi2_compact_kernel asks when it runs beside the path
     uint32_t hugebin;   // records from which a final bin goes to bi2_count_big_kernel; 0: kBi2HugeBin (written with kbits by the emit kernel of the order)
+    uint32_t pdshift;                   // chain.hpp, corpora beyond 2.15 x 10^8 positions: pshift + 1 when a record's position lacks the three bits above pshift (they equal
+                                        // the sub-region the record lies in); the count kernels (PDROP) put them back. 0: positions are whole
     uint32_t emit_done;                 // blocks of the order's emit kernel that have finished: the last one runs bi2_offsets_tail
     uint32_t head_windows;              // key-sharded runs, order 2 (ks_finish2_kernel): the windows of the surviving head pairs over ALL ranks — what order 3 adds to the owners' lists
     uint32_t nextchunk;                 // owner passes of key-sharded runs: next free chunk of the position-list pool (bi2_count_kernel<.., BASED>)
@@ -775,7 +777,9 @@ constexpr uint32_t kBi2Chunk = 4096;
 // windows again by counting. A record's "position" is its place in the receive buffer (31 bits; lower place = lower source rank first).
 // SLOTS: the LDS table of a final bin (1024: 900 distinct keys, what a pass of ~2 x 10^8 positions of the bench distribution fills; 2048 for the passes beyond — half
 // the waves per CU, which is why it is not the default). A bin's survivors are numbered in 10 bits either way (more than 1023 of them: overflow 2, like a full table).
-template <int NSUB, bool BASED = false, int ROWS = kBi2WRows, bool KEY4 = false, int SLOTS = kBi2WSlots>
+// PDROP (chained orders of corpora beyond 2.15 x 10^8 positions, eight sub-regions): the records' positions lack three bits (Bi2State::pdshift); run s of a bin lies in
+// sub-region s, which names them.
+template <int NSUB, bool BASED = false, int ROWS = kBi2WRows, bool KEY4 = false, int SLOTS = kBi2WSlots, bool PDROP = false>
 __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const uint32_t* __restrict__ boff, Bi2State* __restrict__ bs,
                                                               DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
                                                               uint32_t* __restrict__ wlist, uint32_t* __restrict__ wcnt, uint32_t wcap, bool want_positions,
@@ -796,6 +800,8 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
     const uint32_t lane = threadIdx.x, wid = blockIdx.x, nwaves = gridDim.x;
     const uint32_t pb = bs->posbits;
     const unsigned long long pmask = (1ull << pb) - 1;
+    const uint32_t pdsh = PDROP ? bs->pdshift : 0u;
+    static_assert(!PDROP || (!BASED && !KEY4 && NSUB == 8), "three dropped bits = one of eight sub-regions");
     uint32_t* const mylist = wlist + (size_t)wid * wcap;
     uint32_t* const mycode = wcode != nullptr ? wcode + (size_t)wid * wcap : nullptr;
     static_assert(kBi2MaxLoad < 1024 && kBi2Final <= (1 << 22), "a (bin, rank) code fits 32 bits");
@@ -845,6 +851,14 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
                 o                 = j < es ? as : o;
             }
             return j + o;
+        };
+        auto fixpos = [&](uint32_t p, uint32_t j) -> uint32_t {  // the position of record j of the bin as the corpus knows it
+            if (!PDROP || pdsh == 0u) return p;
+            uint32_t sub = 0;
+#pragma unroll
+            for (int s = 0; s < NSUB - 1; ++s) sub += j >= (uint32_t)__builtin_amdgcn_readfirstlane((int)end[s]) ? 1u : 0u;
+            const uint32_t sh = pdsh - 1u;
+            return ((p >> sh) << (sh + 3u)) | (sub << sh) | (p & ((1u << sh) - 1u));
         };
         auto load = [&](uint32_t j) -> unsigned long long {  // record j of the bin as (key << pb | position)
             if (!KEY4) return recsB[locate(j)];
@@ -1054,7 +1068,7 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
             const bool direct = total <= (uint32_t)(ROWS * kWave);
 #pragma unroll
             for (int q = 0; q < ROWS; ++q)
-                if ((uint32_t)(q * kWave) < total) settle(sl[q] != kInvalid, (uint32_t)(x[q] & pmask), cq[q], direct);
+                if ((uint32_t)(q * kWave) < total) settle(sl[q] != kInvalid, fixpos((uint32_t)(x[q] & pmask), (uint32_t)(q * kWave) + lane), cq[q], direct);
         }
         BI2_W(8);
         if (total > (uint32_t)(ROWS * kWave)) {
@@ -1077,7 +1091,7 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
                     if ((uint32_t)(j0 + k * kWave) < total) {
                         const bool     valid = z[k] != ~0ull;
                         const uint32_t key   = (uint32_t)(z[k] >> pb) & 0x7FFFFFFFu;
-                        settle(valid, (uint32_t)(z[k] & pmask), valid ? cntT[bi2_find(keyT, key, bi2_bucket_of(key, lgb, bmask), bmask)] : 0u, false);
+                        settle(valid, fixpos((uint32_t)(z[k] & pmask), j0 + (uint32_t)(k * kWave) + lane), valid ? cntT[bi2_find(keyT, key, bi2_bucket_of(key, lgb, bmask), bmask)] : 0u, false);
                     }
                 }
             }
@@ -1157,7 +1171,7 @@ __device__ __forceinline__ void bi2_merge_leader(bool& act, uint32_t key, uint32
             act = false;
     }
 }
-template <int NSUB, bool BASED = false, bool KEY4 = false, int SLOTS = kBi2Slots>
+template <int NSUB, bool BASED = false, bool KEY4 = false, int SLOTS = kBi2Slots, bool PDROP = false>
 __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const uint32_t* __restrict__ boff, Bi2State* __restrict__ bs,
                                                                        DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
                                                                        uint32_t* __restrict__ wlist, uint32_t* __restrict__ wcnt, uint32_t wcap, bool want_positions,
@@ -1177,6 +1191,7 @@ __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const uns
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
     const uint32_t pb = bs->posbits;
     const unsigned long long pmask = (1ull << pb) - 1;
+    const uint32_t pdsh = PDROP ? bs->pdshift : 0u;
     // position lists: a wave of this kernel may list tens of thousands of windows of one bin, far beyond a fixed per-wave capacity — in both forms a wave takes lists
     // from a POOL (one atomic whenever its current list cannot hold a row). BASED: the chunks of bi2_count_kernel<.., BASED> (wlist = [wcap chunks][kBi2Chunk]).
     // Otherwise: lists of the wave kernel's own size (wcap entries) behind its kBi2Waves private ones: lists pool_first .. pool_first + pool_n - 1
@@ -1326,7 +1341,19 @@ __global__ __launch_bounds__(kBi2BigThreads) void bi2_count_big_kernel(const uns
             for (int q = 0; q < kBi2BigRows; ++q) {
                 if (j0 + q * kBi2BigThreads + (tid & ~(uint32_t)(kWave - 1)) >= total) continue;  // (wave-uniform)
                 const bool     valid = y[q] != ~0ull;
-                const uint32_t key = (uint32_t)(y[q] >> pb) & 0x7FFFFFFFu, pos = (uint32_t)(y[q] & pmask);
+                const uint32_t key = (uint32_t)(y[q] >> pb) & 0x7FFFFFFFu;
+                uint32_t       pos = (uint32_t)(y[q] & pmask);
+                if (PDROP && pdsh != 0u) {  // (see bi2_count_kernel: the run the record lies in names the three bits its position lacks)
+                    uint32_t jj = j0 + q * kBi2BigThreads + tid, sub = 0;
+#pragma unroll
+                    for (int s2 = 0; s2 < NSUB - 1; ++s2) {
+                        const bool beyond = jj >= rn[s2] && sub == (uint32_t)s2;
+                        jj -= beyond ? rn[s2] : 0u;
+                        sub += beyond ? 1u : 0u;
+                    }
+                    const uint32_t sh = pdsh - 1u;
+                    pos               = ((pos >> sh) << (sh + 3u)) | (sub << sh) | (pos & ((1u << sh) - 1u));
+                }
                 uint32_t       c = 0;
                 if (valid) c = cntT[bi2_find(keyT, key, bi2_bucket_of(key, lgb, bmask), bmask)];
                 const bool     kept = (c & kBi2Kept) != 0;

@@ -210,6 +210,7 @@ __device__ __forceinline__ bool chain_key_bits(const Bi2State* __restrict__ prev
         bs->kbits   = K;
         bs->posbits = pb;
         bs->hugebin = hugebin ? hugebin : kChHugeBin;
+        bs->pdshift = pdrop ? pshift + 1u : 0u;
     }
     ck.pshift = pshift;
     ck.pdrop  = pdrop;

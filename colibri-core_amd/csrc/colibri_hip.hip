@@ -922,6 +922,13 @@ inline uint64_t single_pass_positions() { return slice_env() ? slice_env() : tl_
 inline bool retry_with_small_passes(uint64_t npos) { return !tl_small_passes && !slice_env() && npos > 110ull * 1000 * 1000; }
 inline uint64_t big_corpus_tokens() { return slice_env() ? slice_env() : tl_small_passes ? 128ull * 1000 * 1000 : 400ull * 1000 * 1000; }
 inline bool chain_fits(uint64_t npos) { return slice_env() ? true : npos <= kNarrowPassPositions; }  // (one pass on the 1024-slot tables, <= 28 position bits)
+// Round 5, plain runs: the chained orders also between 2.15 and 4.3 x 10^8 positions — eight sub-regions, the 2048-slot count kernels, and records whose position lacks
+// the three bits that equal their sub-region (kshard2.hpp's pdrop: 29 position bits beside a 37-bit key do not fit 64) — COLIBRI_NO_WIDE_CHAIN: round 3's orders >= 3 there
+inline bool chain_wide(uint64_t npos) {
+    static const bool force = getenv("COLIBRI_FORCE_WIDE_CHAIN") != nullptr;  // (tests: small corpora through the wide form of the chained orders; same model)
+    return force || (!slice_env() && npos > kNarrowPassPositions);
+}
+inline bool chain_fits_plain(uint64_t npos) { return chain_fits(npos) || (npos <= kWidePassPositions && !getenv("COLIBRI_NO_WIDE_CHAIN")); }
 inline uint32_t slice_bits(uint64_t records) {  // passes needed for that many records, as a power of two (at most 64)
     if (records <= single_pass_positions()) return 0;
     // once an order is sliced, fuller passes are cheaper (the per-bin cost of the count kernels is mostly fixed): up to 14/11 of the single-pass size each
@@ -1209,7 +1216,9 @@ int bigram2_order(colibri_ctx* c, const TrainPlan& pl, bool want_list, uint32_t*
 // the per-bin dense offsets and the result base (order 2's own state is kept: colibri_order2_records reads it after the run).
 int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next, uint32_t* ids_out = nullptr /* the id-keeping modes: the result index of the n-gram at every position */) {
     const uint32_t        npos = pl.npos;
-    const Bigram2Plan     b    = bigram2_plan(c, npos);
+    const bool            wide = chain_wide(npos);  // (eight sub-regions, 2048-slot tables, three position bits dropped: see chain_wide)
+    const uint32_t        nsub = wide ? kBi2SubWide : kBi2Sub, pdrop = wide ? 3u : 0u;
+    const Bigram2Plan     b    = bigram2_plan(c, npos, nsub);
     Bi2State* const       bs   = (n & 1) ? c->b2.state2.p : c->b2.state3.p;
     const Bi2State* const prev = n == 3 ? c->b2.state.p : (n & 1) ? c->b2.state3.p : c->b2.state2.p;
     auto* const           recsA = reinterpret_cast<unsigned long long*>(c->recs[0].p);
@@ -1223,16 +1232,16 @@ int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next, uint
         const uint32_t cap = chain_steps_cap(b.pl);
         hipLaunchKernelGGL(chain_begin_kernel, dim3(kChXcds + kChResetBlocks), dim3(kBi2Threads), 0, c->stream, prev, b.pl, b.nbuckets, reinterpret_cast<uint2*>(c->b2.steps.p), cap,
                            c->b2.steps.p + 2 * (size_t)kChXcds * cap, (const DevState*)c->state.p, bs, c->b2.wcnt.p, kBi2Waves + b.wextra + 1);
-        hipLaunchKernelGGL(chain_emit_kernel, dim3(grid), dim3(kChThreads), 0, c->stream, (const uint32_t*)c->cls.p, npos, (uint32_t)n, b.clsbits, b.posbits, prev,
+        hipLaunchKernelGGL(chain_emit_kernel, dim3(grid), dim3(kChThreads), 0, c->stream, (const uint32_t*)c->cls.p, npos, (uint32_t)n, b.clsbits, b.posbits - pdrop, prev,
                            (const uint32_t*)c->b2.plist.p, (const uint32_t*)c->b2.pcode.p, b.pl, reinterpret_cast<const uint2*>(c->b2.steps.p), cap,
                            (const uint32_t*)(c->b2.steps.p + 2 * (size_t)kChXcds * cap),
-                           (const uint32_t*)c->b2.bitmap.p, recsA, b.region, kBi2Sub, bs, c->state.p, (const uint32_t*)c->b2.headid.p, chain_dbg());
+                           (const uint32_t*)c->b2.bitmap.p, recsA, b.region, nsub, bs, c->state.p, (const uint32_t*)c->b2.headid.p, chain_dbg(), 0u, pdrop);
         // (records per A bin, scan, B-bin shift: the emit kernel's last block, bi2_offsets_tail)
     }
     {
         Prof p(c, COLIBRI_K_LEVELB2);
         hipLaunchKernelGGL(bi2_levelB_kernel<false>, dim3(b.nslots), dim3(kBi2Threads), 0, c->stream, recsA, recsB, b.region, bs, c->b2.boff.p, c->state.p);
-        hipLaunchKernelGGL(bi2_binoff_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->b2.boff.p, kBi2Sub, c->state.p);
+        hipLaunchKernelGGL(bi2_binoff_kernel, dim3(kBins), dim3(kBi2BBins), 0, c->stream, bs, c->b2.boff.p, nsub, c->state.p);
     }
     {
         // the hot bins (a workgroup each: tens of thousands of windows of one frequent n-gram) run beside the wave kernel, on a second stream: they touch other bins, other
@@ -1240,11 +1249,20 @@ int chain_order(colibri_ctx* c, const TrainPlan& pl, int n, bool want_next, uint
         Prof p(c, COLIBRI_K_BINCOUNT);
         HIP_TRY(c, hipEventRecord(c->b2.ev_fork, c->stream));
         HIP_TRY(c, hipStreamWaitEvent(c->b2.aux, c->b2.ev_fork, 0));
-        hipLaunchKernelGGL((bi2_count_big_kernel<(int)kBi2Sub>), dim3(kBi2Waves * kWave / kBi2BigThreads), dim3(kBi2BigThreads), 0, c->b2.aux, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr,
-                           io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_next, want_next ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr, kBi2Waves, b.wextra);
+        if (wide)
+            hipLaunchKernelGGL((bi2_count_big_kernel<(int)kBi2SubWide, false, false, 2048, true>), dim3(kBi2Waves * kWave / kBi2BigThreads), dim3(kBi2BigThreads), 0, c->b2.aux, recsB, b.region,
+                               c->b2.boff.p, bs, c->state.p, pl.thr, io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_next, want_next ? c->b2.wcode.p : (uint32_t*)nullptr,
+                               (const uint32_t*)nullptr, kBi2Waves, b.wextra);
+        else
+            hipLaunchKernelGGL((bi2_count_big_kernel<(int)kBi2Sub>), dim3(kBi2Waves * kWave / kBi2BigThreads), dim3(kBi2BigThreads), 0, c->b2.aux, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr,
+                               io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_next, want_next ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr, kBi2Waves, b.wextra);
         HIP_TRY(c, hipEventRecord(c->b2.ev_join, c->b2.aux));
-        hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr, io.sp_rep, io.sp_cnt,
-                           c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_next, want_next ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr, true);
+        if (wide)
+            hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2SubWide, false, kBi2WRows, false, 2048, true>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p,
+                               pl.thr, io.sp_rep, io.sp_cnt, c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_next, want_next ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr, true);
+        else
+            hipLaunchKernelGGL((bi2_count_kernel<(int)kBi2Sub>), dim3(kBi2Waves), dim3(kWave), 0, c->stream, recsB, b.region, c->b2.boff.p, bs, c->state.p, pl.thr, io.sp_rep, io.sp_cnt,
+                               c->b2.wlist.p, c->b2.wcnt.p, b.wcap, want_next, want_next ? c->b2.wcode.p : (uint32_t*)nullptr, (const uint32_t*)nullptr, true);
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->b2.ev_join, 0));
     }
     {
@@ -2198,7 +2216,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     const bool bi_cls = tri_cls && uni_shift != 0;  // ... and order 2 is keyed by classes + the order-1 survivor bitmap: no per-position order-1 ids at all
     const bool bi2 = binned && bi2_ok;
     // orders >= 3 on the same engine (chain.hpp): one pass per order (corpora a single pass holds), the plain run
-    const bool chain = bi2 && !big && bigram2_plan(c, npos).sbits == 0 && chain_fits(npos) && o.maxlength >= 3 && !c->b2.chain_disabled && !getenv("COLIBRI_NO_CHAIN");
+    const bool chain = bi2 && !big && bigram2_plan(c, npos).sbits == 0 && chain_fits_plain(npos) && o.maxlength >= 3 && !c->b2.chain_disabled && !getenv("COLIBRI_NO_CHAIN");
     if (tri_cls && !bi2 && ((rc = dev_alloc(c, c->flags_at, (size_t)npos + 1)) || (rc = dev_alloc(c, c->flag2, (size_t)npos + 4)))) return rc;
     // ---- HBM layout (sized once; nothing is allocated inside the unsynced order loop) ----------------
     // table: an order admits at most `npos` windows -> 1.5x slots; results: every survivor has >= 2 occurrences

@@ -15,7 +15,7 @@ from colibri_amd import capi, synth  # noqa: E402
 
 
 def main():
-    assert os.environ.get("COLIBRI_SLICE_POSITIONS") or os.environ.get("COLIBRI_UNI_BIN_CAP") or os.environ.get("COLIBRI_UNI_TWO_PASS")  # (tests/test_gpu_parity.py: order 1's routes)
+    assert os.environ.get("COLIBRI_SLICE_POSITIONS") or os.environ.get("COLIBRI_UNI_BIN_CAP") or os.environ.get("COLIBRI_UNI_TWO_PASS") or os.environ.get("COLIBRI_FORCE_WIDE_CHAIN")  # (tests/test_gpu_parity.py: order 1's routes, the wide chained orders)
     rng = np.random.default_rng(5)
     corpora = {"zipf_phrases_300k": synth.zipf_corpus(300_000, 20_000, 7, phrases=True, header=False),
                "zipf_120k_small_vocab": synth.zipf_corpus(120_000, 40, 8, header=False),  # every bigram in the dense head

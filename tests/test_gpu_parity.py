@@ -539,3 +539,13 @@ def test_order_one_routes_match_the_oracle(env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "tests", "sliced_worker.py")], capture_output=True, text=True, env=dict(os.environ, **env), timeout=900)
     assert p.returncode == 0 and "SLICED_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+def test_wide_chained_orders_match_the_oracle():
+    """Plain runs between 2.15 and 4.3 x 10^8 positions count their orders >= 3 on the chained engine with eight sub-regions, 2048-slot bin tables and records whose
+    position lacks the three bits equal to their sub-region (csrc/chain.hpp ChainKey::put, bi2_count_kernel<.., PDROP>). COLIBRI_FORCE_WIDE_CHAIN sends small corpora
+    through exactly that form; the model must be the oracle's (reference include/patternmodel.h:1078-1178, look-back :1139-1152)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "sliced_worker.py")], capture_output=True, text=True, env=dict(os.environ, COLIBRI_FORCE_WIDE_CHAIN="1"), timeout=900)
+    assert p.returncode == 0 and "SLICED_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]

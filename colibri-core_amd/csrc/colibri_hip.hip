@@ -2267,7 +2267,8 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     const bool bi2_synced = radix_synced && !continued && !filtered && !backoff && wthr == 0 && o.table_mode == 0 && !(c->flags & kFlagNonCanonical) && uni_range_shift(c) != 0 &&
                             c->maxclass < (1u << 21) && o.maxlength >= 2 && bigram2_fits(c, npos) && bigram2_plan(c, npos).sbits == 0 && !c->b2.disabled;
     // ... and, since round 4, their orders >= 3 on the chained engine (chain.hpp) like the plain run's: an order's (position, dense number) pairs become its ids per position
-    const bool chain_synced = bi2_synced && chain_fits(npos) && o.maxlength >= 3 && !c->b2.chain_disabled && !getenv("COLIBRI_NO_CHAIN") && !getenv("COLIBRI_NO_CHAIN_IDS");
+    // (the wide form of the chained orders serves indexed models too; the skipgram passes on the chained engine — skip_pass_chain — have no wide form)
+    const bool chain_synced = bi2_synced && (chain_fits(npos) || (chain_fits_plain(npos) && !o.doskipgrams && !o.doskipgrams_exhaustive)) && o.maxlength >= 3 && !c->b2.chain_disabled && !getenv("COLIBRI_NO_CHAIN") && !getenv("COLIBRI_NO_CHAIN_IDS");
     if (bi2_synced && (rc = bigram2_alloc(c, npos, chain_synced))) return rc;
     if (!binned && (rc = dev_alloc(c, c->table, pl.table_slots))) return rc;  // the plain radix run needs no table (a bin overflow re-runs with table_mode = 1)
     if ((rc = dev_alloc(c, c->res_rep, pl.res_cap))) return rc;

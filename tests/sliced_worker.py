@@ -36,6 +36,11 @@ def main():
                 for n in range(1, maxlength + 1):
                     assert (st.found[n], st.kept[n]) == (want.stats[n][0], want.stats[n][2]), (name, thr, maxlength, n)
                 assert ctx.last_mode() == 2, ("the radix path must have run (not the global-table fallback)", name, thr, maxlength, ctx.last_mode(True))
+            if os.environ.get("COLIBRI_FORCE_WIDE_CHAIN"):  # the wide chained orders serve indexed models too: every reference list
+                want = oracle.train(payload, 2, 5, indexed=True)
+                ctx.train(mintokens=2, maxlength=5, indexed=1)
+                got, refs = ctx.export_dict()
+                assert got == want.counts and refs == want.refs, (name, "indexed")
     print("SLICED_OK")
 
 

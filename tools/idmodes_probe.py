@@ -1,3 +1,4 @@
+"""ms per train() of the three id-keeping model kinds on the bench corpus (best of four; environment variables select variants): python tools/idmodes_probe.py"""
 import sys, os
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "colibri-core_amd", "pyhost"))
 from colibri_amd import capi, synth

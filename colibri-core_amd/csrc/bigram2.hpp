@@ -793,7 +793,29 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
     const uint32_t* const keys4   = reinterpret_cast<const uint32_t*>(recsB);
     uint32_t* const       code_at = wlist;
     __shared__ __attribute__((aligned(16))) uint32_t keyT[SLOTS];
-    __shared__ __attribute__((aligned(16))) uint32_t cntT[SLOTS];
+    // C16 (experimental, -DCOLIBRI_BI2_CNT16): 16-bit counters — 7 KB of LDS per wave instead of 9 (20 resident waves per CU instead of 17). A bin of 32 768 records or
+    // more cannot be counted then (bit 15 marks a survivor): such bins belong to the workgroup kernel; if its list overflowed, the order falls back.
+#ifdef COLIBRI_BI2_CNT16
+    constexpr bool C16 = SLOTS == 1024 && !KEY4 && !BASED;
+#else
+    constexpr bool C16 = false;
+#endif
+    __shared__ __attribute__((aligned(16))) uint32_t cntT[C16 ? SLOTS / 2 : SLOTS];
+    uint16_t* const cnt16 = reinterpret_cast<uint16_t*>(cntT);
+    constexpr uint32_t kKeptBit = C16 ? 0x8000u : kBi2Kept;
+    auto cnt_add = [&](uint32_t sl_) {
+        if (C16)
+            atomicAdd(&cntT[sl_ >> 1], 1u << ((sl_ & 1u) * 16u));
+        else
+            atomicAdd(&cntT[sl_], 1u);
+    };
+    auto cnt_get = [&](uint32_t sl_) -> uint32_t { return C16 ? (uint32_t)cnt16[sl_] : cntT[sl_]; };
+    auto cnt_keep = [&](uint32_t sl_, uint32_t r_) {
+        if (C16)
+            cnt16[sl_] = (uint16_t)(kKeptBit | r_);
+        else
+            cntT[sl_] = kKeptBit | r_;
+    };
     __shared__ uint32_t                              repS[SLOTS / 4];
     constexpr uint32_t kMaxLoad = kBi2MaxLoad * (uint32_t)SLOTS / (uint32_t)kBi2Slots;
     const uint32_t bsh = bs->bshift, nB = (uint32_t)kBi2BBins >> bsh, nfinal = (uint32_t)kBins * nB;
@@ -841,6 +863,10 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
         const uint32_t spo = (uint32_t)__builtin_amdgcn_readlane((int)v, 2 * NSUB);
         BI2_W(1);
         if (total == 0 || (!big_pass && skip_big && total > kBi2BigBin) || (skip_huge && total > hugebin)) return;
+        if (C16 && total >= 32768u) {  // (only when the workgroup kernel's list overflowed)
+            if (lane == 0) bs->overflow = 2;
+            return;
+        }
         auto locate = [&](uint32_t j) -> uint32_t {
             // (the values pass through readfirstlane: a select between two reads of a local array is folded into one read at a selected address, which pins the array
             // to scratch memory — every locate() then waits for a scratch load)
@@ -879,7 +905,10 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
         const uint32_t bmask = (1u << lgb) - 1u;
         for (uint32_t s = lane * 4; s < nslots; s += kWave * 4) {
             *reinterpret_cast<uint4*>(keyT + s) = make_uint4(kBi2Empty, kBi2Empty, kBi2Empty, kBi2Empty);
-            *reinterpret_cast<uint4*>(cntT + s) = make_uint4(0u, 0u, 0u, 0u);
+            if (C16)
+                *reinterpret_cast<uint2*>(cnt16 + s) = make_uint2(0u, 0u);
+            else
+                *reinterpret_cast<uint4*>(cntT + s) = make_uint4(0u, 0u, 0u, 0u);
         }
         BI2_W(3);
         // pass 1: two rows per round
@@ -897,8 +926,8 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
                 bi2_insert2(keyT, bmask, actA, keyA, bkA, vA, sl[q], actB, keyB, bkB, vB, sl[q + 1], oA, oB);
                 own |= (oA << q) | (oB << (q + 1));
                 fail |= (actA && sl[q] == kInvalid) || (actB && sl[q + 1] == kInvalid);  // (an idle lane's slot is kInvalid too)
-                if (sl[q] != kInvalid) atomicAdd(&cntT[sl[q]], 1u);
-                if (sl[q + 1] != kInvalid) atomicAdd(&cntT[sl[q + 1]], 1u);
+                if (sl[q] != kInvalid) cnt_add(sl[q]);
+                if (sl[q + 1] != kInvalid) cnt_add(sl[q + 1]);
             }
         }
         BI2_W(4);
@@ -926,8 +955,8 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
                     uint32_t       oA, oB;
                     bi2_insert2(keyT, bmask, actA, keyA, bkA, *reinterpret_cast<const uint4*>(keyT + bkA * 4), tA, actB, keyB, bkB, *reinterpret_cast<const uint4*>(keyT + bkB * 4), tB, oA, oB);
                     fail |= (actA && tA == kInvalid) || (actB && tB == kInvalid);
-                    if (tA != kInvalid) atomicAdd(&cntT[tA], 1u);
-                    if (tB != kInvalid) atomicAdd(&cntT[tB], 1u);
+                    if (tA != kInvalid) cnt_add(tA);
+                    if (tB != kInvalid) cnt_add(tB);
                 }
             }
         }
@@ -946,14 +975,14 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
             for (int q = 0; q < ROWS; ++q) {
                 if ((uint32_t)(q * kWave) < total) {
                     const bool     owner = (own >> q) & 1u;
-                    const uint32_t c     = owner ? cntT[sl[q]] : 0u;
+                    const uint32_t c     = owner ? cnt_get(sl[q]) : 0u;
                     const bool     kept  = owner && c >= threshold;
                     const uint64_t mk    = __ballot(kept);
                     distinct += (uint32_t)__popcll(__ballot(owner));
                     if (kept) {
                         const uint32_t r = ktotal + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
                         sp_cnt[spo + r]  = c;
-                        cntT[sl[q]]      = kBi2Kept | r;  // from here on: the key survived, and which survivor of the bin it is
+                        cnt_keep(sl[q], r);  // from here on: the key survived, and which survivor of the bin it is
                         if (r < kReps)
                             repS[r] = 0xFFFFFFFFu;
                         else
@@ -971,7 +1000,7 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
             uint32_t       used = 0, keep = 0;
             for (uint32_t k = 0; k < per; k += 4) {
                 const uint32_t s  = lane * per + k;
-                const uint4    kk = *reinterpret_cast<const uint4*>(keyT + s), cc = *reinterpret_cast<const uint4*>(cntT + s);
+                const uint4    kk = *reinterpret_cast<const uint4*>(keyT + s), cc = make_uint4(cnt_get(s), cnt_get(s + 1), cnt_get(s + 2), cnt_get(s + 3));
                 used += (kk.x != kBi2Empty) + (kk.y != kBi2Empty) + (kk.z != kBi2Empty) + (kk.w != kBi2Empty);
                 keep += (cc.x >= threshold) + (cc.y >= threshold) + (cc.z >= threshold) + (cc.w >= threshold);  // an empty slot counts 0 (threshold >= 1)
             }
@@ -984,13 +1013,13 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
             uint32_t r = excl;
             for (uint32_t k = 0; k < per; k += 4) {
                 const uint32_t s0 = lane * per + k;
-                const uint4    cc = *reinterpret_cast<const uint4*>(cntT + s0);
+                const uint4    cc = make_uint4(cnt_get(s0), cnt_get(s0 + 1), cnt_get(s0 + 2), cnt_get(s0 + 3));
                 const uint32_t c4[4] = {cc.x, cc.y, cc.z, cc.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (c4[i] >= threshold) {
                         sp_cnt[spo + r] = c4[i];
-                        cntT[s0 + i]    = kBi2Kept | r;
+                        cnt_keep(s0 + i, r);
                         if (r < kReps)
                             repS[r] = 0xFFFFFFFFu;
                         else
@@ -1022,8 +1051,8 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
         // c: the record's table entry after the ranking (kBi2Kept | rank of a surviving key); direct: the bin's records are all in registers (no hot key: the lowest
         // position goes straight into an LDS minimum — a hot key's windows, which all aim at one word, look first)
         auto settle = [&](bool valid, uint32_t pos, uint32_t c, bool direct) {
-            const bool     kept = (c & kBi2Kept) != 0;
-            const uint32_t r    = c & ~kBi2Kept;
+            const bool     kept = (c & kKeptBit) != 0;
+            const uint32_t r    = c & ~kKeptBit;
             if (KEY4 && valid) code_at[pos] = kept ? (fcode | r) : kInvalid;  // (a run's records lie one after the other: the stores of a row are coalesced)
             if (kept) {  // (read first: a hot key's windows all aim at one word, and after the first rows hardly any of them lowers it)
                 if (r < kReps) {
@@ -1064,7 +1093,7 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
         {
             uint32_t cq[ROWS];  // all rows' entries are requested before the first is looked at (one LDS round trip per bin instead of one per row)
 #pragma unroll
-            for (int q = 0; q < ROWS; ++q) cq[q] = ((uint32_t)(q * kWave) < total && sl[q] != kInvalid) ? cntT[sl[q]] : 0u;
+            for (int q = 0; q < ROWS; ++q) cq[q] = ((uint32_t)(q * kWave) < total && sl[q] != kInvalid) ? cnt_get(sl[q]) : 0u;
             const bool direct = total <= (uint32_t)(ROWS * kWave);
 #pragma unroll
             for (int q = 0; q < ROWS; ++q)
@@ -1091,7 +1120,7 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
                     if ((uint32_t)(j0 + k * kWave) < total) {
                         const bool     valid = z[k] != ~0ull;
                         const uint32_t key   = (uint32_t)(z[k] >> pb) & 0x7FFFFFFFu;
-                        settle(valid, fixpos((uint32_t)(z[k] & pmask), j0 + (uint32_t)(k * kWave) + lane), valid ? cntT[bi2_find(keyT, key, bi2_bucket_of(key, lgb, bmask), bmask)] : 0u, false);
+                        settle(valid, fixpos((uint32_t)(z[k] & pmask), j0 + (uint32_t)(k * kWave) + lane), valid ? cnt_get(bi2_find(keyT, key, bi2_bucket_of(key, lgb, bmask), bmask)) : 0u, false);
                     }
                 }
             }

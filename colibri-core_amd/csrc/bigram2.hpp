@@ -44,9 +44,14 @@ __host__ __device__ __forceinline__ uint64_t bi2_mix(uint64_t x, uint32_t K) {
     return x;
 }
 
+#ifndef COLIBRI_BI2_CNT16
+#define COLIBRI_BI2_CNT16 1
+#endif
 #ifndef COLIBRI_BI2_WEU
 #define COLIBRI_BI2_WEU 4
 #endif
+// waves per SIMD the wave-per-bin count kernel is compiled for: five where its 16-bit counters leave the LDS for them (96 registers), else COLIBRI_BI2_WEU
+constexpr int bi2_count_weu(int slots, bool key4, bool based) { return (COLIBRI_BI2_CNT16 && slots == 1024 && !key4 && !based) ? 5 : COLIBRI_BI2_WEU; }
 #ifndef COLIBRI_BI2_WROWS
 #define COLIBRI_BI2_WROWS 12
 #endif
@@ -780,7 +785,7 @@ constexpr uint32_t kBi2Chunk = 4096;
 // PDROP (chained orders of corpora beyond 2.15 x 10^8 positions, eight sub-regions): the records' positions lack three bits (Bi2State::pdshift); run s of a bin lies in
 // sub-region s, which names them.
 template <int NSUB, bool BASED = false, int ROWS = kBi2WRows, bool KEY4 = false, int SLOTS = kBi2WSlots, bool PDROP = false>
-__global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const uint32_t* __restrict__ boff, Bi2State* __restrict__ bs,
+__global__ __launch_bounds__(kWave, bi2_count_weu(SLOTS, KEY4, BASED)) void bi2_count_kernel(const unsigned long long* __restrict__ recsB, uint32_t region, const uint32_t* __restrict__ boff, Bi2State* __restrict__ bs,
                                                               DevState* __restrict__ st, uint32_t threshold, uint32_t* __restrict__ sp_rep, uint32_t* __restrict__ sp_cnt,
                                                               uint32_t* __restrict__ wlist, uint32_t* __restrict__ wcnt, uint32_t wcap, bool want_positions,
                                                               uint32_t* __restrict__ wcode = nullptr /* optional, beside wlist: (final bin << 10) | rank of the window's key among the
@@ -793,13 +798,10 @@ __global__ __launch_bounds__(kWave, COLIBRI_BI2_WEU) void bi2_count_kernel(const
     const uint32_t* const keys4   = reinterpret_cast<const uint32_t*>(recsB);
     uint32_t* const       code_at = wlist;
     __shared__ __attribute__((aligned(16))) uint32_t keyT[SLOTS];
-    // C16 (experimental, -DCOLIBRI_BI2_CNT16): 16-bit counters — 7 KB of LDS per wave instead of 9 (20 resident waves per CU instead of 17). A bin of 32 768 records or
-    // more cannot be counted then (bit 15 marks a survivor): such bins belong to the workgroup kernel; if its list overflowed, the order falls back.
-#ifdef COLIBRI_BI2_CNT16
-    constexpr bool C16 = SLOTS == 1024 && !KEY4 && !BASED;
-#else
-    constexpr bool C16 = false;
-#endif
+    // C16 (the single-device form with 1024-slot tables): 16-bit counters — 7 KB of LDS per wave instead of 9, so that 20 waves are resident per CU instead of 17
+    // (with <= 96 registers: bi2_count_weu). Order-2 count 0.548 -> 0.503 ms per 10^8 tokens. A bin of 32 768 records or more cannot be counted then (bit 15 marks a
+    // survivor): such bins belong to the workgroup kernel; if its list overflowed, the order falls back. -DCOLIBRI_BI2_CNT16=0: 32-bit counters everywhere.
+    constexpr bool C16 = COLIBRI_BI2_CNT16 && SLOTS == 1024 && !KEY4 && !BASED;
     __shared__ __attribute__((aligned(16))) uint32_t cntT[C16 ? SLOTS / 2 : SLOTS];
     uint16_t* const cnt16 = reinterpret_cast<uint16_t*>(cntT);
     constexpr uint32_t kKeptBit = C16 ? 0x8000u : kBi2Kept;
@@ -1534,6 +1536,7 @@ __global__ __launch_bounds__(kBi2BBins) void bi2_kept_finish_kernel(DevState* __
         st->found += ftot + hftot;
         st->kept += tot + htot;
         if ((uint64_t)bs->res_base + tot + htot > res_cap) st->overflow = 1;
+        if (bs->overflow && st->pad[0] == 0) st->pad[0] = bs->overflow | (bs->kbits << 8) | (bs->posbits << 16) | (bs->bshift << 24);  // (COLIBRI_DEBUG_OVERFLOW: what gave up first)
         if (bs->overflow && st->radix_overflow != 4) st->radix_overflow = ovf_code;  // the host re-runs on the first-generation kernels
         const uint64_t next = (uint64_t)st->id_base + bs->nrec;  // keeps the id space of the later orders disjoint, as bin_advance_prepare_kernel does
         if (next >= 0xFFFFFFF0ull) st->radix_overflow = 3;

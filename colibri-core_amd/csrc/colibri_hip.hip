@@ -888,7 +888,7 @@ int binned_resolve_stage(colibri_ctx* c, const TrainPlan& pl, uint32_t* ids_out,
 // ---- order 2, second generation (bigram2.hpp): class-keyed 8-byte records, dense head, per-slot level B, one wave per final bin, position
 // lists -> bitmap -> the active list of order 3. `want_list`: order 3 follows. Everything is enqueued; nothing is read back.
 #ifndef COLIBRI_BI2_WPC
-#define COLIBRI_BI2_WPC 16
+#define COLIBRI_BI2_WPC 20  // (waves of the count kernel per CU: what its 16-bit-counter form keeps resident; the other forms — 9+ KB of LDS — run 17 of them at a time)
 #endif
 #ifndef COLIBRI_BI2_SUB
 #define COLIBRI_BI2_SUB 4
@@ -955,8 +955,12 @@ Bigram2Plan bigram2_plan(const colibri_ctx* c, uint32_t npos, uint32_t nsub = kB
     b.pl.pcap   = ((1u << b.pshift) / 4 + 4096 + 3) & ~3u;  // a bucket's entries spread evenly over the 8 shards: twice the expected worst case
     b.pl.hbase  = kBi2Shards * kBi2Buckets * b.pl.pcap;     // (chain.hpp) the head windows' lists lie behind the shards'
     b.listn     = (size_t)b.pl.hbase + ((size_t)b.nbuckets << b.pshift) + 64;
-    b.wcap      = (uint32_t)(((uint64_t)npos * 6 / 10 / kBi2Waves) * 2 + 4096);
-    b.wextra    = npos / b.wcap + kBi2Waves * kWave / kBi2BigThreads + 64;  // the list pool of bi2_count_big_kernel: every position once, one partly filled list per wave of its grid
+    // a wave's list: twice its even share of the ~0.6 npos surviving windows — of the waves that are RESIDENT at a time: the 2048-slot count kernels of corpora beyond
+    // 2.15 x 10^8 positions hold 17 KB of LDS each, nine per CU, and the first 2304 of the launched waves draw every bin (a run that lost windows this way falls back)
+    const uint32_t resident = (!slice_env() && npos > kNarrowPassPositions) ? std::min(kBi2Waves, 256u * 9u) : kBi2Waves;
+    b.wcap      = (uint32_t)(((uint64_t)npos * 6 / 10 / resident) * 2 + 4096);
+    b.wextra    = npos / b.wcap + kBi2Waves + 64;  // the list pool of bi2_count_big_kernel: every position once, one partly filled list per WAVE of its grid (round 4 counted its
+                                                   // blocks: 375 M tokens with ~10^3 hot trigram bins ran the pool dry — Bi2State.overflow 3 — once the lists grew)
     b.clsbits   = 1;
     while ((1ull << b.clsbits) <= (uint64_t)c->maxclass) ++b.clsbits;
     b.posbits = 1;
@@ -2384,7 +2388,14 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             return colibri_train_once(c, &o, stats_out);
         }
         if (binned && c->hstate.radix_overflow == 16) {  // an order >= 3 did not fit the second-generation engine (key bits, a region, a bin): those orders on the first-generation kernels
-            if (getenv("COLIBRI_DEBUG_OVERFLOW")) fprintf(stderr, "colibri: a chained order gave up; repeating with orders >= 3 on the first-generation kernels\n");
+            if (getenv("COLIBRI_DEBUG_OVERFLOW")) {  // (which part: Bi2State.overflow 1 a record region / the key bits, 2 a final bin's table, 3 a position list)
+                uint32_t w2 = 0, w3 = 0;
+                if (c->b2.state2.p) (void)hipMemcpy(&w2, &c->b2.state2.p->overflow, sizeof w2, hipMemcpyDeviceToHost);
+                if (c->b2.state3.p) (void)hipMemcpy(&w3, &c->b2.state3.p->overflow, sizeof w3, hipMemcpyDeviceToHost);
+                fprintf(stderr, "colibri: a chained order gave up (Bi2State.overflow of the odd / even orders now: %u / %u; first: overflow %u, key bits %u, position bits %u, bshift %u); "
+                                "repeating with orders >= 3 on the first-generation kernels\n", w2, w3, c->hstate.pad[0] & 255u, (c->hstate.pad[0] >> 8) & 255u, (c->hstate.pad[0] >> 16) & 255u,
+                        c->hstate.pad[0] >> 24);
+            }
             c->b2.chain_disabled = true;
             const int rc2        = colibri_train_once(c, &o, stats_out);
             c->b2.chain_disabled = false;

@@ -25,6 +25,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -145,21 +146,31 @@ struct Shared {
     std::mutex                                      errm;
     std::string                                     error;
     bool                                            poisoned = false;  // the communicators were aborted (a rank failed inside or beside a collective): no further run on this trainer
-    Shared(int w, int nl, int first) : world(w), nlocal(nl), first_rank(first), rv(nl), comms((size_t)nl, nullptr), device((size_t)nl, 0), ints((size_t)w), ops((size_t)w), hostred((size_t)w) {}
+    // held shared by a rank while it hands its communicator to RCCL (between comm() and the return of the enqueueing calls); fail() asks for it exclusively, for a
+    // bounded time, before it aborts that communicator: a peer that has just fetched its handle gets to finish its (microseconds of) enqueueing, a peer that is
+    // stuck inside RCCL waiting for the failed rank is aborted all the same once the wait runs out (that is what the abort is for)
+    std::unique_ptr<std::shared_timed_mutex[]>      enqueueing;
+    Shared(int w, int nl, int first)
+        : world(w), nlocal(nl), first_rank(first), rv(nl), comms((size_t)nl, nullptr), device((size_t)nl, 0), ints((size_t)w), ops((size_t)w), hostred((size_t)w),
+          enqueueing(new std::shared_timed_mutex[(size_t)nl]) {}
     bool threads() const { return nlocal == world; }
     void fail(const std::string& what) {
-        std::vector<ncclComm_t> mine;  // every communicator is aborted exactly once: the first failing rank takes them all (its peers' collectives then return errors and
-        {                              // those ranks come here too, to find nothing left)
+        std::vector<std::pair<ncclComm_t, int>> mine;  // every communicator is aborted exactly once: the first failing rank takes them all (its peers' collectives then
+        {                                              // return errors and those ranks come here too, to find nothing left)
             std::lock_guard<std::mutex> l(errm);
             if (error.empty()) error = what;
             if (use_rccl) {
-                for (auto& cm : comms)
-                    if (cm) mine.push_back(cm), cm = nullptr;
+                for (int k = 0; k < nlocal; ++k)
+                    if (comms[(size_t)k]) mine.emplace_back(comms[(size_t)k], k), comms[(size_t)k] = nullptr;
                 poisoned = true;
             }
         }
         rv.abort();
-        for (ncclComm_t cm : mine) (void)ncclCommAbort(cm);  // peers inside (or about to enter) a collective return with an error instead of waiting for this rank
+        for (const auto& [cm, k] : mine) {  // peers inside (or about to enter) a collective return with an error instead of waiting for this rank
+            const bool quiet = enqueueing[(size_t)k].try_lock_for(std::chrono::milliseconds(200));  // (comm() hands out nothing any more: whoever holds this fetched its handle before)
+            (void)ncclCommAbort(cm);
+            if (quiet) enqueueing[(size_t)k].unlock();
+        }
     }
 };
 
@@ -199,7 +210,10 @@ class RankDriver {
         uint64_t* const d = (uint64_t*)gather_dev.reserve(sizeof(uint64_t) * 4096);
         std::memcpy(gather_host, mine.data(), k * sizeof(uint64_t));
         HIPCHK(hipMemcpyAsync(d, gather_host, k * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-        NCCLCHK(ncclAllGather(d, d + k, k, ncclUint64, comm(), s));
+        {
+            std::shared_lock<std::shared_timed_mutex> enq(sh.enqueueing[(size_t)li]);
+            NCCLCHK(ncclAllGather(d, d + k, k, ncclUint64, comm(), s));
+        }
         HIPCHK(hipMemcpyAsync(gather_host + k, d + k, k * (size_t)world * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         std::vector<std::vector<uint64_t>> all((size_t)world);
@@ -216,6 +230,7 @@ class RankDriver {
             }
         for (const Reduce& r : reds) bytes_reduce += r.n * sizeof(uint32_t);
         if (sh.use_rccl) {
+            std::shared_lock<std::shared_timed_mutex> enq(sh.enqueueing[(size_t)li]);  // (Shared::fail)
             if (!a2a.empty()) {
                 NCCLCHK(ncclGroupStart());
                 for (const A2A& op : a2a) {
@@ -231,6 +246,7 @@ class RankDriver {
                 NCCLCHK(ncclGroupEnd());
             }
             for (const Reduce& r : reds) NCCLCHK(ncclAllReduce(r.buf, r.buf, r.n, ncclUint32, r.minimum ? ncclMin : ncclSum, comm(), s));
+            enq.unlock();
             if (sync) HIPCHK(hipStreamSynchronize(s));
             return;
         }

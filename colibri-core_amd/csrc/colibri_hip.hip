@@ -160,6 +160,7 @@ struct colibri_ctx {
     DevBuf<uint32_t>  alist[2], alist_n; // binned path: active-position lists (ping-pong) and their lengths [2]
     DevBuf<BinState>  binstate;
     bool              export_ready = false;  // keylen / keyoff / keybytes of the trained model are computed
+    std::vector<uint8_t> ids_built;          // ids[n] holds THIS run's survivor ids (the id-keeping loop skips the orders nobody reads: a reader of a skipped order is refused, built_ids)
     bool              ids1_is_cls = false;   // this run keeps no per-position order-1 ids: one-token skipgram parts are named by their class ids (part_ids)
     int               last_mode = 0;    // 1 = global table, 2 = binned (what the last train() actually ran)
     int               profile_class = COLIBRI_K_COUNT;  // profile = 2: the one kernel class that is bracketed with events
@@ -1559,6 +1560,13 @@ int build_skip_list(colibri_ctx* c, const TrainPlan& pl, const uint32_t* gate) {
 
 // identity of a skipgram part of `len` tokens at a position: the survivor id of that n-gram — or, for one-token parts of a run that keeps no order-1 ids
 // (c->ids1_is_cls: unindexed, class-keyed order 2), the token's class id, which names a surviving word just as well
+// ids[n] of the running train, or nullptr (and the context's message) when this run did not build them: the id-keeping loop leaves out what its readers, listed at
+// want_ids, do not ask for, and the buffers keep an earlier run's ids — a reader that list does not know fails here instead of counting garbage
+inline const uint32_t* built_ids(colibri_ctx* c, int n) {
+    if (n >= 0 && (size_t)n < c->ids_built.size() && c->ids_built[(size_t)n]) return c->ids[(size_t)n].p;
+    (void)fail(c, COLIBRI_ERR_STATE, "internal: the survivor ids of order %d were not built in this run (colibri_train: want_ids)", n);
+    return nullptr;
+}
 inline const uint32_t* part_ids(const colibri_ctx* c, int len) { return (len == 1 && c->ids1_is_cls) ? (const uint32_t*)c->cls.p : (const uint32_t*)c->ids[(size_t)len].p; }
 
 int skipgram_pass(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, const uint32_t* gate, const uint32_t* gate2, uint32_t participants, uint32_t thr, bool count_sources,
@@ -2441,6 +2449,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
     } else {
         // ---------- skipgram / indexed modes: one host round trip per pass (sizes, lazily grown per-order id arrays) ----------
         if ((int)c->ids.size() < maxlength + 2) c->ids.resize(maxlength + 2);
+        c->ids_built.assign(c->ids.size(), 0);
         c->ids1_is_cls        = false;
         bool       list_valid = false;  // the active list of the previous radix pass exists
         const bool uni_synced = !constrained && o.table_mode == 0 && !(c->flags & kFlagNonCanonical) && c->maxclass < (1u << 28);
@@ -2527,9 +2536,11 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                     if (!c->ids1_is_cls && !uni_pairs_direct) {
                         Prof p(c, COLIBRI_K_RESOLVE);
                         hipLaunchKernelGGL(uni_resid_ids_kernel, dim3(pl.pos_grid), dim3(kBlock), 0, c->stream, c->cls.p, c->uni_resid.p, c->ids[1].p, c->state.p, npos);
+                        c->ids_built[1] = 1;
                     }
                 } else if (n == 2) {
                     if ((rc = bigram2_order(c, pl, /*want_list=*/true, want_ids(2) ? c->ids[2].p : (uint32_t*)nullptr, /*chain=*/chain_synced))) return rc;
+                    c->ids_built[2] = want_ids(2);
                 } else if (chain_synced) {
                     if (o.doskipgrams_exhaustive) {  // the windows this order admits, for its skipgram passes: from the bitmap of order n - 1, which this order's own replaces
                         HIP_TRY(c, hipMemsetAsync(c->alist_n.p + (n & 1), 0, sizeof(uint32_t), c->stream));
@@ -2537,6 +2548,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                                            c->alist_n.p + (n & 1));
                     }
                     if ((rc = chain_order(c, pl, n, /*want_next=*/true, want_ids(n) ? c->ids[n].p : (uint32_t*)nullptr))) return rc;
+                    c->ids_built[(size_t)n] = want_ids(n);
                     if (o.doskipgrams_exhaustive && (rc = chain_compact_join(c))) return rc;  // (the skipgram passes count in the buffers the order's survivors are being copied from)
                 } else {
                     if ((rc = binned_count_stage(c, pl, KeyNgram{c->ids[n - 1].p, n}, n, true, pl.thr, false, true, false, /*dense_code=*/true))) return rc;
@@ -2549,12 +2561,17 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                         hipLaunchKernelGGL(bin_advance_prepare_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, c->binstate.p);
                     }
                     if ((rc = binned_resolve_stage(c, pl, c->ids[n].p, n, true, true, nullptr, 0u, /*prefill_ids=*/true, /*decode=*/true, kDecodeBaseOnDevice))) return rc;
+                    c->ids_built[(size_t)n] = 1;
                 }
                 if (n == 1 && uni_pairs_direct) {  // (before the order's figures are closed: the emission counts the positions with a surviving unigram, as uni_resid_ids_kernel does)
                     if ((rc = emit_pairs(c, pl, c->cls.p, false, c->uni_surv.p, c->uni_resid.p))) return rc;
                 }
                 hipLaunchKernelGGL(idm_ngram_end_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, n);
-                if (o.indexed && !(c->b2.pairs_direct && (n >= 3 || (n == 2 && c->b2.pairs2_direct))) && !(n == 1 && uni_pairs_direct) && (rc = emit_pairs(c, pl, c->ids[n].p, false))) return rc;
+                if (o.indexed && !(c->b2.pairs_direct && (n >= 3 || (n == 2 && c->b2.pairs2_direct))) && !(n == 1 && uni_pairs_direct)) {
+                    const uint32_t* const idn = built_ids(c, n);
+                    if (!idn) return COLIBRI_ERR_STATE;
+                    if ((rc = emit_pairs(c, pl, idn, false))) return rc;
+                }
                 if (o.doskipgrams_exhaustive && n >= 3) {  // patternmodel.h:1163-1171 -> computeskipgrams :1370-1527, for every admissible window: the order's own active list
                     if (n > kMaxSkipgramTokens) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 31 tokens do not exist (a gap mask has 32 bits; set MAXLENGTH)");
                     c->skl   = c->alist[n & 1].p;
@@ -2562,11 +2579,14 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                     const std::vector<uint32_t> masks = gap_masks(n, o.maxskips);
                     for (uint32_t mask : masks) {
                         uint32_t f = 0, k = 0;
-                        const uint32_t* const gate = chain_synced && !getenv("COLIBRI_ALL_IDS") ? (const uint32_t*)nullptr : (const uint32_t*)c->ids[n - 1].p;
+                        const uint32_t* const gate = chain_synced && !getenv("COLIBRI_ALL_IDS") ? (const uint32_t*)nullptr : built_ids(c, n - 1);
+                        if (!gate && !(chain_synced && !getenv("COLIBRI_ALL_IDS"))) return COLIBRI_ERR_STATE;
                         const std::vector<std::pair<int, int>> parts = mask_parts(mask, n);
                         // two parts, at least one of them a single token (class id, ~20 bits; two result indices of ~24 bits do not fit a record beside the position)
                         const bool one_token_part = parts.size() == 2 && c->ids1_is_cls && (parts[0].second == 1 || parts[1].second == 1);
                         if (chain_synced && one_token_part && !o.indexed && !getenv("COLIBRI_ALL_IDS") && !getenv("COLIBRI_NO_SKIP_CHAIN")) {  // ... on the chained engine
+                            for (const auto& part : parts)
+                                if (!(part.second == 1 && c->ids1_is_cls) && !built_ids(c, part.second)) return COLIBRI_ERR_STATE;
                             if ((rc = skip_pass_chain(c, pl, n, mask, part_ids(c, parts[0].second), (uint32_t)parts[0].first, parts[0].second == 1 && c->ids1_is_cls,
                                                       part_ids(c, parts[1].second), (uint32_t)parts[1].first, parts[1].second == 1 && c->ids1_is_cls, thr_skip, c->seglog.p)))
                                 return rc;
@@ -2635,6 +2655,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
         }
         for (int n = constrained ? std::max(1, o.minlength) : 1; n <= maxlength && !c->hstate.done && !enq; ++n) {
             if ((rc = dev_alloc(c, c->ids[n], (size_t)npos + 1))) return rc;
+            c->ids_built[(size_t)n] = 1;  // (the per-order loop builds every order's ids)
             if (continued && c->cs.has_order(n)) {
                 // "Skipping n-grams, already in model" (patternmodel.h:983-995): nothing is counted; the windows that ARE patterns of the loaded model get
                 // the pattern's number as their survivor id, which is all the look-back of the next order asks for (:1139-1152: this->has(subngram))
@@ -2867,7 +2888,9 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                 if (radix_synced && listed_order) {  // the order's own active list IS the list of positions whose (n-1)-gram survived
                     c->skl   = c->alist[n & 1].p;
                     c->skl_n = c->alist_n.p + (n & 1);
-                } else if ((rc = build_skip_list(c, pl, c->ids[n - 1].p)))
+                } else if (!built_ids(c, n - 1))
+                    return COLIBRI_ERR_STATE;
+                else if ((rc = build_skip_list(c, pl, c->ids[n - 1].p)))
                     return rc;
                 const std::vector<uint32_t> masks = gap_masks(n, o.maxskips);
                 const bool logged = radix_synced && masks.size() <= kSegLogCap;  // the order's passes are enqueued without a read-back each; one look at the log afterwards
@@ -2938,6 +2961,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             if ((rc = write_state(c))) return rc;
             size_t nlogged = 0;
             for (int n = 3; n <= std::min<int>(maxlength, s.maxn); ++n) {
+                if (!built_ids(c, n)) return COLIBRI_ERR_STATE;
                 if ((rc = build_skip_list(c, pl, c->ids[n].p))) return rc;
                 const std::vector<uint32_t> masks = gap_masks(n, o.maxskips);
                 const uint32_t minsrc = o.minskiptypes > 1 ? (uint32_t)o.minskiptypes : 0u;
@@ -2971,6 +2995,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             for (int n = 3; n <= std::min<int>(maxlength, s.maxn); ++n) {
                 if (n > kMaxSkipgramTokens) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 31 tokens do not exist (a gap mask has 32 bits; set MAXLENGTH)");
                 uint32_t found_n = 0;
+                if (!built_ids(c, n)) return COLIBRI_ERR_STATE;
                 if ((rc = build_skip_list(c, pl, c->ids[n].p))) return rc;
                 for (uint32_t mask : gap_masks(n, o.maxskips)) {
                     uint32_t f = 0, k = 0;

@@ -1551,15 +1551,13 @@ int build_skip_list(colibri_ctx* c, const TrainPlan& pl, const uint32_t* gate) {
     Prof p(c, COLIBRI_K_SKIPGRAM);
     // in position order (count per tile, short scan, write): the references of an indexed model's skipgram passes are emitted entry by entry of this list
     hipLaunchKernelGGL(emit_count_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, gate, pl.npos, c->idx_cnt.p, (const DevState*)nullptr);
-    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->idx_cnt.p, ntiles, c->idx_cnt.p + ntiles);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(kPairThreads), 0, c->stream, c->idx_cnt.p, ntiles, c->idx_cnt.p + ntiles);
     hipLaunchKernelGGL(list_write_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, gate, pl.npos, (const uint32_t*)c->idx_cnt.p, c->sklist.p, c->sklist_n.p);
     c->skl   = c->sklist.p;
     c->skl_n = c->sklist_n.p;
     return COLIBRI_OK;
 }
 
-// identity of a skipgram part of `len` tokens at a position: the survivor id of that n-gram — or, for one-token parts of a run that keeps no order-1 ids
-// (c->ids1_is_cls: unindexed, class-keyed order 2), the token's class id, which names a surviving word just as well
 // ids[n] of the running train, or nullptr (and the context's message) when this run did not build them: the id-keeping loop leaves out what its readers, listed at
 // want_ids, do not ask for, and the buffers keep an earlier run's ids — a reader that list does not know fails here instead of counting garbage
 inline const uint32_t* built_ids(colibri_ctx* c, int n) {
@@ -1567,6 +1565,8 @@ inline const uint32_t* built_ids(colibri_ctx* c, int n) {
     (void)fail(c, COLIBRI_ERR_STATE, "internal: the survivor ids of order %d were not built in this run (colibri_train: want_ids)", n);
     return nullptr;
 }
+// identity of a skipgram part of `len` tokens at a position: the survivor id of that n-gram — or, for one-token parts of a run that keeps no order-1 ids
+// (c->ids1_is_cls: unindexed, class-keyed order 2), the token's class id, which names a surviving word just as well
 inline const uint32_t* part_ids(const colibri_ctx* c, int len) { return (len == 1 && c->ids1_is_cls) ? (const uint32_t*)c->cls.p : (const uint32_t*)c->ids[(size_t)len].p; }
 
 int skipgram_pass(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, const uint32_t* gate, const uint32_t* gate2, uint32_t participants, uint32_t thr, bool count_sources,
@@ -1872,7 +1872,7 @@ int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool en
             const uint64_t cap = c->pairs[0].n;
             hipLaunchKernelGGL(emit_count_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, pl.npos, cnt, (const DevState*)c->state.p, surv,
                                surv != nullptr ? &c->state.p->valid : (uint32_t*)nullptr);
-            hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, cnt, ntiles, cnt + ntiles);
+            hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(kPairThreads), 0, c->stream, cnt, ntiles, cnt + ntiles);
             hipLaunchKernelGGL(pairs_advance_kernel, dim3(1), dim3(1), 0, c->stream, c->pair_chain.p, c->pair_pass, cnt + ntiles, cap);
             const bool packed = c->pair_sb != 0;
             hipLaunchKernelGGL(emit_write_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, pl.npos, cnt, c->pair_chain.p, c->pair_pass, cap, c->pairs[0].p,
@@ -1905,7 +1905,7 @@ int emit_pairs_list(colibri_ctx* c, uint32_t bound, const uint32_t* ids) {
     Prof            p(c, COLIBRI_K_INDEX);
     const uint64_t  cap = c->pairs[0].n;
     hipLaunchKernelGGL(emit_count_list_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, (const uint32_t*)c->skl, (const uint32_t*)c->skl_n, cnt, c->state.p);
-    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBlock), 0, c->stream, cnt, ntiles, cnt + ntiles);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(kPairThreads), 0, c->stream, cnt, ntiles, cnt + ntiles);
     hipLaunchKernelGGL(pairs_advance_kernel, dim3(1), dim3(1), 0, c->stream, c->pair_chain.p, c->pair_pass, cnt + ntiles, cap);
     const bool packed = c->pair_sb != 0;
     hipLaunchKernelGGL(emit_write_list_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, (const uint32_t*)c->skl, (const uint32_t*)c->skl_n, (const uint32_t*)cnt, c->pair_chain.p,

@@ -4,10 +4,15 @@
 //     mock run share "device 0", so the trainer takes its device-copies back end);
 //   * the C ABI of a device context as far as the key-sharded run uses it (include/colibri_hip.h: colibri_create ... colibri_kshard_*), computed on the CPU in the
 //     protocol's own terms — records to the owner of their key, a bit per record and a number per surviving record back, exports to the lowest rank holding an
-//     occurrence. The formats inside the buffers are this file's own (the driver moves bytes and sizes, it never looks inside); the candidate exchange
-//     (colibri_shard_*) is not mocked: a run that falls back to it ends with that message on every rank — which is what the failure tests look for.
+//     occurrence. The formats inside the buffers are this file's own (the driver moves bytes and sizes, it never looks inside);
+//   * the candidate exchange (colibri_shard_*: every other model kind — exhaustive skipgrams, indexed models, indexed skipgrams — and every run the key-sharded
+//     protocol hands back) in the terms include/colibri_hip.h states for it: a pass (n, mask, level) counts its keys locally, the distinct candidates travel to the
+//     owner of their key with their local counts (and, at an indexed skipgram's last level, the number of its distinct source n-grams this rank exports), the owner
+//     sums, prunes, numbers the survivors globally and names the lowest contributing rank exporter, the replies come back in the order the records left.
 // Built into lib/libcolibri_sharded_mock.so together with the UNCHANGED sharded.cpp (host/Makefile, target `mock`); never linked into the product.
-// Reference semantics restated: PatternModel::train's order loop, look-back, add, prune (reference include/patternmodel.h:1078-1245).
+// Reference semantics restated: PatternModel::train's order loop, look-back, add, prune (reference include/patternmodel.h:1078-1245); the masked forms of every
+// admitted window (:1163-1171, computeskipgrams :1370-1527 as executed: the validity test reduces to the window's look-back); IndexedPatternModel::trainskipgrams
+// (:2969-3010) with the derived pruneskipgrams (:3362-3383: distinct skip contents = distinct source n-grams).
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
@@ -58,7 +63,34 @@ struct Rec {  // what a source sends for one window (the mock's own record: 16 b
     uint32_t pad0, pad1;
 };
 struct Result {
-    uint32_t pos, n, count;
+    uint32_t pos, n, count, mask;  // mask: bit k set = token k of the window is a gap (a skipgram); 0: an n-gram
+};
+constexpr uint32_t INV = 0xFFFFFFFFu;
+struct Own {  // one key on its owner: the sum over the ranks, the distinct source n-grams, the lowest rank that sent it, its global number
+    uint32_t total, nsrc, minrank, gid;
+};
+struct ShardRun {  // the candidate exchange's state between its calls
+    bool                               active = false;
+    int                                world = 1, n = 0, level = 1;
+    uint32_t                           thr = 2, thr_skip = 2, mask = 0, pthr = 2, minsrc = 0;
+    bool                               final_level = true, use_aux = false;
+    std::vector<std::vector<uint32_t>> ids;         // ids[n][position]: global number of the surviving n-gram that starts there, INV: none
+    std::vector<uint32_t>              scratch[2];  // numbers of a skipgram's left part so far, per position
+    std::vector<uint32_t>              mark;        // bit n: this rank exports the n-gram whose representative occurrence starts here
+    std::vector<uint32_t>*             out = nullptr;
+    std::vector<uint64_t>              keyof;                        // this pass's key per position, ~0: no candidate
+    std::vector<uint64_t>              pkeys;                        // distinct candidates grouped by owner ...
+    std::vector<uint32_t>              pcounts, paux, prep;          // ... their local counts, distinct-source counts, first positions
+    std::vector<uint64_t>              rkeys;                        // owner side: the records as they arrived
+    std::vector<uint32_t>              rsrc;
+    std::map<uint64_t, Own>            owner;
+    uint64_t                           admitted_n[COLIBRI_MAX_ORDER] = {0};
+    std::vector<uint32_t>              res_gid;  // global number of every exported pattern (parallel to ctx->results)
+    std::vector<std::pair<uint32_t, uint32_t>> pairs;  // indexed models: (global number, position) of every local occurrence of a surviving pattern
+    // the local forward index once finished
+    std::vector<uint32_t> ugid, ref_sentence;
+    std::vector<uint64_t> uoff;
+    std::vector<uint16_t> ref_token;
 };
 }  // namespace
 
@@ -81,6 +113,8 @@ struct colibri_ctx {
     std::vector<Result>   results;
     uint64_t              found[COLIBRI_MAX_ORDER] = {0}, kept[COLIBRI_MAX_ORDER] = {0}, admitted[COLIBRI_MAX_ORDER] = {0};
     colibri_stats         stats{};
+    uint32_t              first_sentence = 1;
+    ShardRun              sh;
 };
 
 namespace {
@@ -103,7 +137,8 @@ void* colibri_stream(colibri_ctx*) { return nullptr; }
 int colibri_kernel_time(const colibri_ctx*, int, double* ms, uint64_t* n) { if (ms) *ms = 0; if (n) *n = 0; return COLIBRI_OK; }
 
 // .colibri.dat v2 payload: little-endian base-128, the high bit on every byte of a token but the last; 00 ends a sentence (reference src/classencoder.cpp:22-42, :550-600)
-int colibri_upload_corpus(colibri_ctx* c, const uint8_t* p, uint64_t nbytes, uint32_t) {
+int colibri_upload_corpus(colibri_ctx* c, const uint8_t* p, uint64_t nbytes, uint32_t first_sentence) {
+    c->first_sentence = first_sentence;
     c->cls.clear(); c->bstart.clear(); c->blen.clear();
     c->bytes.assign(p, p + nbytes);
     c->ntokens = c->nsent = c->maxclass = 0;
@@ -165,7 +200,7 @@ int colibri_kshard_uni_apply(colibri_ctx* c) {  // cnt1 holds the global counts 
     // the mock does the same through a synthetic result whose key bytes are rebuilt from the class id.
     if (c->rank == 0)
         for (uint64_t v = 1; v < c->nclasses; ++v)
-            if (c->cnt1[v] >= thr) c->results.push_back({(uint32_t)v, 0u /* n = 0: a class id, not a position */, c->cnt1[v]});
+            if (c->cnt1[v] >= thr) c->results.push_back({(uint32_t)v, 0u /* n = 0: a class id, not a position */, c->cnt1[v], 0u});
     for (size_t i = 0; i < c->cls.size(); ++i) c->admitted[1] += c->cls[i] != 0;
     return COLIBRI_OK;
 }
@@ -276,7 +311,7 @@ int colibri_kshard_apply(colibri_ctx* c, int n, const uint64_t* fb_src, const ui
         }
         for (uint64_t k = 0; k < ex_src[d]; ++k) {
             const uint64_t e = c->exr[eo + k];
-            c->results.push_back({c->sendpos[c->sbase[(size_t)d] + (uint32_t)e], (uint32_t)n, (uint32_t)(e >> 32)});
+            c->results.push_back({c->sendpos[c->sbase[(size_t)d] + (uint32_t)e], (uint32_t)n, (uint32_t)(e >> 32), 0u});
         }
         eo += ex_src[d];
         gb += kept_per_owner[d];
@@ -310,7 +345,10 @@ static std::vector<uint8_t> mock_key(const colibri_ctx* c, const Result& r) {
         k.push_back((uint8_t)v);
         return k;
     }
-    for (uint32_t t = 0; t < r.n; ++t) k.insert(k.end(), c->bytes.begin() + c->bstart[r.pos + t], c->bytes.begin() + c->bstart[r.pos + t] + c->blen[r.pos + t]);
+    for (uint32_t t = 0; t < r.n; ++t) {
+        if (r.mask >> t & 1u) k.push_back(3);  // a gapped token is the one byte 03 (reference src/pattern.cpp:886-908)
+        else k.insert(k.end(), c->bytes.begin() + c->bstart[r.pos + t], c->bytes.begin() + c->bstart[r.pos + t] + c->blen[r.pos + t]);
+    }
     return k;
 }
 int colibri_result_sizes(colibri_ctx* c, uint64_t* np, uint64_t* kb, uint64_t* nr) {
@@ -334,25 +372,288 @@ int colibri_export_unindexed(colibri_ctx* c, uint64_t* key_off, uint8_t* key_byt
     return COLIBRI_OK;
 }
 
-// ---- the candidate exchange is not part of the mock: a run that reaches it ends there, on every rank ------------------------------------------------------------------------
+// ---- the candidate exchange (include/colibri_hip.h "colibri_shard_*"), on the CPU ------------------------------------------------------------------------------------------
+namespace {
+std::vector<std::pair<int, int>> parts_of(uint32_t mask, int n) {  // the contiguous non-gap stretches of a gap mask: (first token, tokens) (reference src/algorithms.cpp:33-54, complemented)
+    std::vector<std::pair<int, int>> parts;
+    for (int k = 0; k < n;) {
+        if (mask >> k & 1u) { ++k; continue; }
+        int e = k;
+        while (e < n && !(mask >> e & 1u)) ++e;
+        parts.push_back({k, e - k});
+        k = e;
+    }
+    return parts;
+}
+uint32_t id_at(const std::vector<uint32_t>& v, size_t i) { return i < v.size() ? v[i] : INV; }
+}  // namespace
+
+int colibri_shard_begin(colibri_ctx* c, const colibri_options* o, int world) {
+    if (!c || !o || world < 1 || world > 64) return COLIBRI_ERR_ARG;
+    if (std::getenv("COLIBRI_MOCK_NO_CANDIDATES")) return fail(c, COLIBRI_ERR_UNSUPPORTED, "mock: the candidate exchange is switched off (COLIBRI_MOCK_NO_CANDIDATES)");
+    c->opt = *o;
+    if (c->opt.mintokens == -1) c->opt.mintokens = 2;  // (reference :883-888)
+    if (c->opt.mintokens < 1) c->opt.mintokens = 1;
+    if (c->opt.mintokens_skipgrams < c->opt.mintokens) c->opt.mintokens_skipgrams = c->opt.mintokens;
+    ShardRun& sh = c->sh;
+    sh           = ShardRun();
+    sh.active    = true;
+    sh.world     = world;
+    sh.thr       = (uint32_t)c->opt.mintokens;
+    sh.thr_skip  = (uint32_t)c->opt.mintokens_skipgrams;
+    sh.mark.assign(c->cls.size() + 1, 0u);
+    c->results.clear();
+    return COLIBRI_OK;
+}
+
+// the local count of pass (n, mask, level); its distinct keys grouped by owner = mix(key) % world
+int colibri_shard_count(colibri_ctx* c, int n, uint32_t mask, int level, uint64_t* ncandidates, uint64_t* per_owner) {
+    if (!c || !ncandidates || !per_owner || n < 1 || n >= COLIBRI_MAX_ORDER) return COLIBRI_ERR_ARG;
+    ShardRun& sh = c->sh;
+    if (!sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
+    const colibri_options& o = c->opt;
+    const size_t           P = c->cls.size();
+    if ((int)sh.ids.size() < n + 2) sh.ids.resize((size_t)n + 2);
+    sh.n = n; sh.mask = mask; sh.level = level; sh.final_level = true; sh.use_aux = false; sh.pthr = sh.thr; sh.minsrc = 0;
+    sh.keyof.assign(P, ~0ull);
+    std::vector<std::pair<int, int>> parts;
+    if (mask == 0) {
+        sh.ids[(size_t)n].assign(P, INV);
+        sh.out = &sh.ids[(size_t)n];
+    } else {
+        if (n < 3 || n > 31 || !(o.doskipgrams || o.doskipgrams_exhaustive)) return fail(c, COLIBRI_ERR_ARG, "skipgram pass needs 3 <= n <= 31 and a skipgram mode");
+        parts = parts_of(mask, n);
+        if (level < 1 || level >= (int)parts.size()) return fail(c, COLIBRI_ERR_ARG, "skipgram pass level out of range");
+        sh.final_level = level + 1 == (int)parts.size();
+        sh.out         = &sh.scratch[level & 1];
+        if (!sh.final_level) sh.pthr = 1;  // an intermediate level only names pairs of numbers: everything survives, nothing is exported
+        else if (o.doskipgrams) { sh.use_aux = true; sh.minsrc = o.minskiptypes > 1 ? (uint32_t)o.minskiptypes : 0u; }  // (reference :3000-3003, :3362-3383)
+        else sh.pthr = o.minskiptypes > 1 ? sh.thr_skip : sh.thr;                                                       // (reference :1233-1243, :2167-2186)
+    }
+    struct Loc { uint32_t count, first, nsrc; };
+    std::map<uint64_t, Loc> table;
+    uint64_t                adm = 0;
+    for (size_t i = 0; i < P; ++i) {
+        uint64_t key;
+        if (mask == 0 && n == 1) {
+            if (!c->cls[i]) continue;
+            key = c->cls[i];
+        } else if (mask == 0) {  // the look-back (reference :1139-1152): both (n-1)-grams survived — which also keeps the window inside its sentence
+            const uint32_t a = id_at(sh.ids[(size_t)n - 1], i), b = id_at(sh.ids[(size_t)n - 1], i + 1);
+            if (a == INV || b == INV) continue;
+            key = (uint64_t)a << 32 | b;
+        } else {
+            // indexed models: a masked form of every surviving n-gram (trainskipgrams); otherwise of every admitted window (:1163-1171)
+            if (o.doskipgrams ? id_at(sh.ids[(size_t)n], i) == INV : (id_at(sh.ids[(size_t)n - 1], i) == INV || id_at(sh.ids[(size_t)n - 1], i + 1) == INV)) continue;
+            const uint32_t l = level == 1 ? id_at(sh.ids[(size_t)parts[0].second], i + (size_t)parts[0].first) : id_at(sh.scratch[(level - 1) & 1], i);
+            const uint32_t r = id_at(sh.ids[(size_t)parts[(size_t)level].second], i + (size_t)parts[(size_t)level].first);
+            if (l == INV || r == INV) continue;
+            key = (uint64_t)l << 32 | r;
+        }
+        ++adm;
+        sh.keyof[i] = key;
+        auto it     = table.find(key);
+        if (it == table.end()) it = table.insert({key, Loc{0u, (uint32_t)i, 0u}}).first;
+        ++it->second.count;
+        if (sh.use_aux && (sh.mark[i] >> n & 1u)) ++it->second.nsrc;  // this occurrence is THE representative of an n-gram this rank exports: one more distinct filler
+    }
+    if (mask == 0) sh.admitted_n[n] = adm;
+    if (mask != 0) sh.out->assign(P, INV);
+    std::vector<std::vector<std::pair<uint64_t, Loc>>> by((size_t)sh.world);
+    for (const auto& kv : table) by[(size_t)(mix(kv.first) % (uint64_t)sh.world)].push_back(kv);
+    sh.pkeys.clear(); sh.pcounts.clear(); sh.paux.clear(); sh.prep.clear();
+    for (int d = 0; d < sh.world; ++d) {
+        per_owner[d] = by[(size_t)d].size();
+        for (const auto& kv : by[(size_t)d]) { sh.pkeys.push_back(kv.first); sh.pcounts.push_back(kv.second.count); sh.paux.push_back(kv.second.nsrc); sh.prep.push_back(kv.second.first); }
+    }
+    *ncandidates = sh.pkeys.size();
+    sh.pkeys.push_back(0); sh.pcounts.push_back(0); sh.paux.push_back(0);  // (never an empty buffer)
+    return COLIBRI_OK;
+}
+int colibri_shard_send_view(colibri_ctx* c, void** keys, void** counts, void** aux) {
+    if (!c || !keys || !counts) return COLIBRI_ERR_ARG;
+    if (!c->sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
+    *keys = c->sh.pkeys.data(); *counts = c->sh.pcounts.data();
+    if (aux) *aux = c->sh.use_aux ? (void*)c->sh.paux.data() : nullptr;
+    return COLIBRI_OK;
+}
+int colibri_shard_send(colibri_ctx* c, void* keys, void* counts, void* aux) {
+    if (!c || !c->sh.active) return COLIBRI_ERR_STATE;
+    const size_t m = c->sh.pkeys.size() - 1;
+    if (m && (!keys || !counts)) return COLIBRI_ERR_ARG;
+    if (m) { std::memcpy(keys, c->sh.pkeys.data(), 8 * m); std::memcpy(counts, c->sh.pcounts.data(), 4 * m); }
+    if (m && aux) { if (c->sh.use_aux) std::memcpy(aux, c->sh.paux.data(), 4 * m); else std::memset(aux, 0, 4 * m); }
+    return COLIBRI_OK;
+}
+// owner side: the records of every rank (source after source), summed per key; pruned by the pass's threshold and, for an indexed skipgram, its distinct fillers
+int colibri_shard_merge(colibri_ctx* c, const void* keys, const void* counts, const void* aux, const uint64_t* per_src, uint64_t* found, uint64_t* kept) {
+    if (!c || !per_src || !found || !kept) return COLIBRI_ERR_ARG;
+    ShardRun& sh = c->sh;
+    if (!sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
+    uint64_t tot = 0;
+    for (int s = 0; s < sh.world; ++s) tot += per_src[s];
+    if (tot && (!keys || !counts)) return COLIBRI_ERR_ARG;
+    if (sh.use_aux && tot && !aux) return fail(c, COLIBRI_ERR_ARG, "this pass needs the distinct-source counts (aux buffer)");
+    sh.rkeys.assign((const uint64_t*)keys, (const uint64_t*)keys + tot);
+    sh.rsrc.clear(); sh.owner.clear();
+    for (int s = 0; s < sh.world; ++s) sh.rsrc.insert(sh.rsrc.end(), (size_t)per_src[s], (uint32_t)s);
+    for (uint64_t j = 0; j < tot; ++j) {
+        auto it = sh.owner.find(sh.rkeys[j]);
+        if (it == sh.owner.end()) it = sh.owner.insert({sh.rkeys[j], Own{0u, 0u, INV, INV}}).first;
+        else if (it->second.minrank == sh.rsrc[j]) return fail(c, COLIBRI_ERR_STATE, "mock: a rank sent one key twice");
+        it->second.total += ((const uint32_t*)counts)[j];
+        if (sh.use_aux) it->second.nsrc += ((const uint32_t*)aux)[j];
+        it->second.minrank = std::min(it->second.minrank, sh.rsrc[j]);  // (sources arrive in rank order: the first one)
+    }
+    *found = sh.owner.size(); *kept = 0;
+    for (const auto& kv : sh.owner) *kept += kv.second.total >= sh.pthr && kv.second.nsrc >= sh.minsrc;
+    return COLIBRI_OK;
+}
+int colibri_shard_reply(colibri_ctx* c, uint32_t gid_base, void* reply_gid, void* reply_cnt) {
+    if (!c) return COLIBRI_ERR_ARG;
+    ShardRun& sh = c->sh;
+    if (!sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
+    if (!sh.rkeys.empty() && (!reply_gid || !reply_cnt)) return COLIBRI_ERR_ARG;
+    uint32_t next = gid_base;
+    for (auto& kv : sh.owner) kv.second.gid = (kv.second.total >= sh.pthr && kv.second.nsrc >= sh.minsrc) ? next++ : INV;
+    for (size_t j = 0; j < sh.rkeys.size(); ++j) {
+        const Own& e = sh.owner[sh.rkeys[j]];
+        ((uint32_t*)reply_gid)[j] = e.gid == INV ? INV : (e.gid | (e.minrank == sh.rsrc[j] ? 0x80000000u : 0u));
+        ((uint32_t*)reply_cnt)[j] = e.total;
+    }
+    return COLIBRI_OK;
+}
+// contributor side: the replies in the order the records left; the survivors' global numbers per position; the patterns this rank was named exporter of
+int colibri_shard_apply(colibri_ctx* c, const void* reply_gid, const void* reply_cnt, uint64_t* exported, uint64_t* admitted) {
+    if (!c) return COLIBRI_ERR_ARG;
+    ShardRun& sh = c->sh;
+    if (!sh.active || sh.n < 1) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_apply out of order");
+    const size_t m = sh.pkeys.size() - 1;
+    if (m && (!reply_gid || !reply_cnt)) return COLIBRI_ERR_ARG;
+    std::map<uint64_t, uint32_t> gmap;
+    uint64_t                     k = 0;
+    for (size_t j = 0; j < m; ++j) {
+        const uint32_t g = ((const uint32_t*)reply_gid)[j];
+        if (g == INV) continue;
+        gmap[sh.pkeys[j]] = g & 0x7FFFFFFFu;
+        if (!(g & 0x80000000u) || !sh.final_level) continue;
+        c->results.push_back({sh.prep[j], (uint32_t)sh.n, ((const uint32_t*)reply_cnt)[j], sh.mask});
+        sh.res_gid.push_back(g & 0x7FFFFFFFu);
+        if (sh.mask == 0 && c->opt.doskipgrams && sh.n < 32) sh.mark[sh.prep[j]] |= 1u << sh.n;
+        ++k;
+    }
+    for (size_t i = 0; i < sh.keyof.size(); ++i) {
+        if (sh.keyof[i] == ~0ull) continue;
+        auto it = gmap.find(sh.keyof[i]);
+        if (it == gmap.end()) continue;
+        (*sh.out)[i] = it->second;
+        if (c->opt.indexed && sh.final_level) sh.pairs.push_back({it->second, (uint32_t)i});  // the forward index, keyed by GLOBAL number (reference :2789-2800)
+    }
+    if (exported) *exported = k;
+    if (admitted) *admitted = sh.admitted_n[sh.n];
+    return COLIBRI_OK;
+}
+// order 1 on class-indexed arrays (canonical encodings): local counts -> [all-reduce SUM / MIN by the caller] -> apply; a unigram's global number is its class id
+int colibri_shard_uni_info(const colibri_ctx* c, int* eligible, uint64_t* maxclass) {
+    if (!c || !eligible || !maxclass) return COLIBRI_ERR_ARG;
+    *eligible = (std::getenv("COLIBRI_MOCK_NO_DENSE_UNIGRAMS") || c->maxclass >= (1u << 23)) ? 0 : 1;  // (wider ids: the keyed unigram pass — the product's bound is 2^28, a CPU test's is smaller)
+    *maxclass = c->maxclass;
+    return COLIBRI_OK;
+}
+int colibri_shard_uni_count(colibri_ctx* c, void* cnt, void* minrank, uint32_t nclasses, int rank) {
+    if (!c || !cnt || !minrank || nclasses <= c->maxclass) return COLIBRI_ERR_ARG;
+    if (!c->sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
+    std::fill((uint32_t*)cnt, (uint32_t*)cnt + nclasses, 0u);
+    std::fill((uint32_t*)minrank, (uint32_t*)minrank + nclasses, 0x7FFFFFFFu);
+    for (uint32_t v : c->cls)
+        if (v) { ++((uint32_t*)cnt)[v]; ((uint32_t*)minrank)[v] = (uint32_t)rank; }
+    return COLIBRI_OK;
+}
+int colibri_shard_uni_apply(colibri_ctx* c, const void* cnt_g, const void* minrank_g, uint32_t nclasses, int rank, uint64_t* found, uint64_t* kept, uint64_t* exported) {
+    if (!c || !cnt_g || !minrank_g || !found || !kept) return COLIBRI_ERR_ARG;
+    ShardRun& sh = c->sh;
+    if (!sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
+    const uint32_t *cnt = (const uint32_t*)cnt_g, *mr = (const uint32_t*)minrank_g;
+    const uint32_t  wthr = std::max<uint32_t>(sh.thr, (uint32_t)std::max(0, c->opt.mintokens_unigrams));  // (a longer window needs every word at the word threshold)
+    if (sh.ids.size() < 3) sh.ids.resize(3);
+    sh.ids[1].assign(c->cls.size(), INV);
+    sh.n = 1; sh.mask = 0;
+    *found = *kept = 0;
+    uint64_t k = 0;
+    for (uint32_t v = 1; v < nclasses; ++v) {
+        if (!cnt[v]) continue;
+        ++*found;
+        if (cnt[v] < sh.thr) continue;
+        ++*kept;
+        if (mr[v] != (uint32_t)rank) continue;
+        c->results.push_back({v, 0u /* a class id, not a position */, cnt[v], 0u});
+        sh.res_gid.push_back(v);
+        ++k;
+    }
+    for (size_t i = 0; i < c->cls.size(); ++i) {
+        const uint32_t v = c->cls[i];
+        if (!v) continue;
+        ++sh.admitted_n[1];
+        if (cnt[v] >= wthr) sh.ids[1][i] = v;
+        if (cnt[v] >= sh.thr && c->opt.indexed) sh.pairs.push_back({v, (uint32_t)i});
+    }
+    if (exported) *exported = k;
+    return COLIBRI_OK;
+}
+int colibri_shard_finish(colibri_ctx* c, const uint64_t* found, const uint64_t* kept, uint64_t tokens, int maxn, colibri_stats* out) {
+    if (!c || !found || !kept) return COLIBRI_ERR_ARG;
+    ShardRun& sh = c->sh;
+    if (!sh.active) return fail(c, COLIBRI_ERR_STATE, "colibri_shard_begin first");
+    colibri_stats& s = c->stats;
+    std::memset(&s, 0, sizeof s);
+    s.totaltokens = tokens; s.nsentences = c->nsent; s.npatterns = c->results.size(); s.maxn = maxn; s.minn = maxn > 0 ? 1 : 0;
+    for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) { s.found[n] = found[n]; s.kept[n] = kept[n]; s.pruned[n] = found[n] - kept[n]; s.admitted[n] = sh.admitted_n[n]; }
+    s.totaltypes = s.found[1];
+    // the local forward index: per global number (ascending) the occurrences in corpus order, as (sentence, token) — sentences numbered from the shard's first_sentence
+    std::sort(sh.pairs.begin(), sh.pairs.end());
+    std::vector<uint32_t> sent(c->cls.size(), 0u), tok(c->cls.size(), 0u);
+    uint32_t              sn = c->first_sentence, tn = 0;
+    for (size_t i = 0; i < c->cls.size(); ++i) {
+        sent[i] = sn; tok[i] = tn;
+        if (c->cls[i] == 0 && c->blen[i] == 1) { ++sn; tn = 0; } else ++tn;
+    }
+    sh.ugid.clear(); sh.uoff.clear(); sh.ref_sentence.clear(); sh.ref_token.clear();
+    for (size_t j = 0; j < sh.pairs.size(); ++j) {
+        if (j == 0 || sh.pairs[j].first != sh.pairs[j - 1].first) { sh.ugid.push_back(sh.pairs[j].first); sh.uoff.push_back(j); }
+        sh.ref_sentence.push_back(sent[sh.pairs[j].second]);
+        sh.ref_token.push_back((uint16_t)tok[sh.pairs[j].second]);
+    }
+    sh.uoff.push_back(sh.pairs.size());
+    s.nrefs   = c->opt.indexed ? sh.pairs.size() : 0;
+    sh.active = false;
+    if (out) *out = s;
+    return COLIBRI_OK;
+}
+int colibri_shard_export_gids(colibri_ctx* c, uint32_t* gids) {
+    if (!c || (!gids && !c->sh.res_gid.empty())) return COLIBRI_ERR_ARG;
+    if (c->sh.res_gid.size() != c->results.size()) return fail(c, COLIBRI_ERR_STATE, "mock: no candidate-exchange run to name the patterns of");
+    std::copy(c->sh.res_gid.begin(), c->sh.res_gid.end(), gids);
+    return COLIBRI_OK;
+}
+int colibri_shard_index_sizes(const colibri_ctx* c, uint64_t* ngids, uint64_t* nrefs) {
+    if (!c || !ngids || !nrefs) return COLIBRI_ERR_ARG;
+    *ngids = c->sh.ugid.size(); *nrefs = c->sh.ref_sentence.size();
+    return COLIBRI_OK;
+}
+int colibri_shard_export_index(colibri_ctx* c, uint32_t* gids, uint64_t* ref_off, uint32_t* ref_sentence, uint16_t* ref_token) {
+    if (!c || !ref_off) return COLIBRI_ERR_ARG;
+    const ShardRun& sh = c->sh;
+    std::copy(sh.ugid.begin(), sh.ugid.end(), gids);
+    if (sh.uoff.empty()) ref_off[0] = 0; else std::copy(sh.uoff.begin(), sh.uoff.end(), ref_off);
+    std::copy(sh.ref_sentence.begin(), sh.ref_sentence.end(), ref_sentence);
+    std::copy(sh.ref_token.begin(), sh.ref_token.end(), ref_token);
+    return COLIBRI_OK;
+}
+// ---- single-device training and the queries on a resident model are not part of the mock --------------------------------------------------------------------------------------
 static int mock_no_candidates(const colibri_ctx* c) {
-    if (c) const_cast<colibri_ctx*>(c)->err = "mock: the candidate exchange (colibri_shard_*) is not mocked";
+    if (c) const_cast<colibri_ctx*>(c)->err = "mock: single-device training and resident-model queries are not mocked";
     return COLIBRI_ERR_UNSUPPORTED;
 }
-int colibri_shard_begin(colibri_ctx* c, const colibri_options*, int) { return mock_no_candidates(c); }
-int colibri_shard_count(colibri_ctx* c, int, uint32_t, int, uint64_t*, uint64_t*) { return mock_no_candidates(c); }
-int colibri_shard_send(colibri_ctx* c, void*, void*, void*) { return mock_no_candidates(c); }
-int colibri_shard_send_view(colibri_ctx* c, void**, void**, void**) { return mock_no_candidates(c); }
-int colibri_shard_merge(colibri_ctx* c, const void*, const void*, const void*, const uint64_t*, uint64_t*, uint64_t*) { return mock_no_candidates(c); }
-int colibri_shard_reply(colibri_ctx* c, uint32_t, void*, void*) { return mock_no_candidates(c); }
-int colibri_shard_apply(colibri_ctx* c, const void*, const void*, uint64_t*, uint64_t*) { return mock_no_candidates(c); }
-int colibri_shard_uni_info(const colibri_ctx* c, int*, uint64_t*) { return mock_no_candidates(c); }
-int colibri_shard_uni_count(colibri_ctx* c, void*, void*, uint32_t, int) { return mock_no_candidates(c); }
-int colibri_shard_uni_apply(colibri_ctx* c, const void*, const void*, uint32_t, int, uint64_t*, uint64_t*, uint64_t*) { return mock_no_candidates(c); }
-int colibri_shard_finish(colibri_ctx* c, const uint64_t*, const uint64_t*, uint64_t, int, colibri_stats*) { return mock_no_candidates(c); }
-int colibri_shard_export_gids(colibri_ctx* c, uint32_t*) { return mock_no_candidates(c); }
-int colibri_shard_index_sizes(const colibri_ctx* c, uint64_t*, uint64_t*) { return mock_no_candidates(c); }
-int colibri_shard_export_index(colibri_ctx* c, uint32_t*, uint64_t*, uint32_t*, uint16_t*) { return mock_no_candidates(c); }
 // what the C++ face's object file (colibri_host.o, linked for cut_sentences and friends) refers to beyond the sharded trainer: present, never reached in a mock run
 int colibri_train(colibri_ctx* c, const colibri_options*, colibri_stats*) { return mock_no_candidates(c); }
 int colibri_export_indexed(colibri_ctx* c, uint64_t*, uint8_t*, uint32_t*, uint64_t*, uint32_t*, uint16_t*) { return mock_no_candidates(c); }

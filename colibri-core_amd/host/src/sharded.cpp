@@ -434,12 +434,22 @@ class RankDriver {
     void all_to_all(const void* send, const std::vector<uint64_t>& send_n, void* recv, const std::vector<uint64_t>& recv_n, size_t elem) {
         exchange({{send, &send_n, recv, &recv_n, elem}}, {}, stream, true);
     }
+    // COLIBRI_FAULT="<rank>:<step name>" in test builds (see train_kshard): that rank pretends the step failed
+    void inject(std::string& err, const char* what) const {
+#ifdef COLIBRI_TEST_HOOKS
+        static const char* const fault = std::getenv("COLIBRI_FAULT");
+        if (fault && err.empty() && std::atoi(fault) == rank && std::strchr(fault, ':') && std::string(std::strchr(fault, ':') + 1) == what) err = std::string(what) + ": injected fault";
+#else
+        (void)err, (void)what;
+#endif
+    }
     void pass(int n, uint32_t mask, int level, bool use_aux, uint64_t& found_all, uint64_t& kept_all) {
         uint64_t              ncand = 0;
         std::vector<uint64_t> per_owner((size_t)world, 0), per_src((size_t)world, 0);
         std::string           err;
         const int             rc0 = colibri_shard_count(c, n, mask, level, &ncand, per_owner.data());
         if (rc0 != COLIBRI_OK) err = std::string("colibri_shard_count: ") + colibri_last_error(c);
+        inject(err, "colibri_shard_count");
         const auto sizes = agree(per_owner, err, "sharded pass: local count", stream);
         uint64_t   nrecv = 0;
         for (int r = 0; r < world; ++r) {
@@ -456,6 +466,7 @@ class RankDriver {
         } catch (const std::exception& e) {
             err = e.what();
         }
+        inject(err, "colibri_shard_send_view");
         agree({}, err, "sharded pass: exchange buffers", stream);
         std::vector<A2A> ops{{skeys, &per_owner, rkeys.p, &per_src, 8}, {scnts, &per_owner, rcnts.p, &per_src, 4}};
         if (use_aux) ops.push_back({saux, &per_owner, raux.p, &per_src, 4});
@@ -463,6 +474,7 @@ class RankDriver {
         uint64_t found = 0, kept = 0;
         const int rc1 = colibri_shard_merge(c, rkeys.p, rcnts.p, use_aux ? raux.p : nullptr, per_src.data(), &found, &kept);
         if (rc1 != COLIBRI_OK) err = std::string("colibri_shard_merge: ") + colibri_last_error(c);
+        inject(err, "colibri_shard_merge");
         try {
             rgid.reserve(nr * 4), rtot.reserve(nr * 4), gid.reserve(ns * 4), tot.reserve(ns * 4);
         } catch (const std::exception& e) {
@@ -479,9 +491,15 @@ class RankDriver {
         if (found_all == 0) return;  // nothing anywhere: every rank sees it at once (reference "None found", patternmodel.h:1189-1194)
         if (gid_total + kept_all >= (1ull << 31)) err = "more than 2^31 surviving patterns";
         if (err.empty() && colibri_shard_reply(c, (uint32_t)base, rgid.p, rtot.p) != COLIBRI_OK) err = std::string("colibri_shard_reply: ") + colibri_last_error(c);
+        inject(err, "colibri_shard_reply");
         agree({}, err, "sharded pass: replies", stream);
         exchange({{rgid.p, &per_src, gid.p, &per_owner, 4}, {rtot.p, &per_src, tot.p, &per_owner, 4}}, {}, stream, true);
         uint64_t exported = 0, admitted = 0;
+        {  // (a step no agreement follows: a rank that fails here aborts the run's rendezvous, which is what takes its peers out of the next one)
+            std::string e;
+            inject(e, "colibri_shard_apply");
+            if (!e.empty()) throw std::runtime_error(e);
+        }
         chk(colibri_shard_apply(c, gid.p, tot.p, &exported, &admitted), "colibri_shard_apply");
         gid_total += kept_all;
     }
@@ -503,6 +521,7 @@ class RankDriver {
         } catch (const std::exception& e) {
             err = e.what();
         }
+        inject(err, "colibri_shard_uni_count");
         agree({}, err, "sharded run: order 1", stream);
         exchange({}, {{ucnt.p, (size_t)nclasses, false}, {umr.p, (size_t)nclasses, true}}, stream, true);
         uint64_t exported = 0;
@@ -534,6 +553,7 @@ class RankDriver {
         gid_total = 0;
         std::string err;
         if (colibri_shard_begin(c, &o, world) != COLIBRI_OK) err = std::string("colibri_shard_begin: ") + colibri_last_error(c);
+        inject(err, "colibri_shard_begin");
         agree({}, err, "sharded run: begin", stream);
         if (o.mintokens == -1) o.mintokens = 2;
         if (o.mintokens == 0) o.mintokens = 1;

@@ -1,6 +1,8 @@
 """CPU (no GPU): the product's own multi-GPU driver — host/src/sharded.cpp, unchanged — over a CPU stand-in for the device layer (host/mock/mock_device.cpp ->
 lib/libcolibri_sharded_mock.so): rank threads, rendezvous, the agreement before every exchange, the routing of sizes and buffers through the all-to-alls and
 all-reduces, "None found" termination, and what happens when one rank fails. Round 3 tested a numpy restatement of the protocol instead of the driver.
+Both protocols: key-sharded counting (plain models) and the candidate exchange — what exhaustive-skipgram models (BASELINE configs[3]), indexed models and
+indexed skipgram models (configs[4]) take at N > 1, pass by pass, level by level — against the oracle's model of the whole corpus.
 Each case runs in its own process (the library reads COLIBRI_SHARDED_LIB / COLIBRI_FAULT once)."""
 import os
 import subprocess
@@ -33,16 +35,44 @@ print("OK")
 """
 
 
+KINDS = {"u": {}, "us": dict(doskipgrams_exhaustive=True), "usT1": dict(doskipgrams_exhaustive=True, minskiptypes=1), "usy3": dict(doskipgrams_exhaustive=True, mintokens_skipgrams=3),
+         "i": dict(indexed=True), "is": dict(indexed=True, doskipgrams=True), "isT1": dict(indexed=True, doskipgrams=True, minskiptypes=1), "isT3": dict(indexed=True, doskipgrams=True, minskiptypes=3)}
+
+SCRIPT_CANDIDATES = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import conftest, oracle
+from colibri_amd import capi
+world, name, maxlength, thr, kind = int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), eval(sys.argv[7])
+payload = conftest.small_corpora()[name]
+want = oracle.train(payload, thr, maxlength, **kind)
+with capi.ShardedTrainer(world, devices=[0] * world) as tr:
+    tr.upload_split(payload)
+    if not kind:
+        tr.set_protocol(1)  # a plain model would be counted key-sharded
+    for rep in range(2):
+        st = tr.train(mintokens=thr, maxlength=maxlength, **{k: int(v) for k, v in kind.items()})
+        got = tr.export_dict()
+        assert tr.info.protocol == 1 and tr.info.rccl == 0
+        assert got == want.counts, ("model differs", len(got), len(want.counts), sorted(set(got.items()) ^ set(want.counts.items()))[:6])
+        assert (st.totaltokens, st.totaltypes, st.maxn, st.npatterns) == (want.tokens, want.types, want.maxn, len(want.counts)), (st.totaltokens, st.totaltypes, st.maxn, st.npatterns)
+        for n in range(1, min(maxlength, 20) + 1):
+            assert (st.found[n], st.kept[n]) == (want.stats[n][0], want.stats[n][2]), (n, st.found[n], st.kept[n], want.stats[n])
+print("OK")
+"""
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "colibri-core_amd", "host"), "mock"])
 
 
-def run(args, fault=None, timeout=120):
+def run(args, fault=None, timeout=120, script=SCRIPT, env_extra=None):
     build()
     env = dict(os.environ, COLIBRI_SHARDED_LIB=MOCK, COLIBRI_NO_RCCL="1")
     if fault:
         env["COLIBRI_FAULT"] = fault
-    return subprocess.run([sys.executable, "-c", SCRIPT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")] + [str(a) for a in args], env=env, capture_output=True, text=True,
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, "-c", script, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")] + [str(a) for a in args], env=env, capture_output=True, text=True,
                           timeout=timeout)
 
 
@@ -54,12 +84,81 @@ def test_the_cxx_driver_builds_the_oracles_model_on_the_mock(world, name, maxlen
     assert p.returncode == 0 and "OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
 
 
-@pytest.mark.parametrize("fault", ["2:colibri_kshard_begin", "1:colibri_kshard_uni_count", "0:colibri_kshard_uni_apply", "3:colibri_kshard_emit", "2:colibri_kshard_recv_buffers",
-                                   "1:colibri_kshard_count", "0:colibri_kshard_feedback_buffers", "3:colibri_kshard_apply", "1:colibri_kshard_local_stats"])
+@pytest.mark.parametrize("world", [1, 2, 4])
+@pytest.mark.parametrize("kind", list(KINDS))
+@pytest.mark.parametrize("name,maxlength,thr", [("zipf20k", 5, 2), ("rand3", 6, 2), ("repeat", 9, 3), ("one_long_sentence", 5, 2)])
+def test_the_cxx_driver_builds_every_model_kind_by_candidate_exchange(world, kind, name, maxlength, thr):
+    """train_candidates (host/src/sharded.cpp): order 1 by all-reduce of the class-indexed arrays, every n-gram pass, every level of every gap mask of the
+    exhaustive-skipgram orders (reference include/patternmodel.h:1163-1171) and of IndexedPatternModel::trainskipgrams (:2969-3010: distinct-filler counts travel
+    with the last level), termination at "None found" — the union of what the ranks export is the oracle's model, with its per-order found / kept figures"""
+    p = run([world, name, maxlength, thr, repr(KINDS[kind])], script=SCRIPT_CANDIDATES)
+    assert p.returncode == 0 and "OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+
+
+@pytest.mark.parametrize("world,name,maxlength,thr,kind", [(3, "zipf20k", 5, 2, "us"), (3, "rand_noempty", 5, 2, "is"), (2, "zipf20k", 4, 1, "us"), (2, "rand2", 4, 1, "isT1"), (4, "empty", 5, 2, "us"),
+                                                           (4, "one_token", 5, 2, "is"), (2, "only_delims", 5, 2, "i"), (8, "short_sentences", 5, 2, "us"), (2, "cls_2p21", 5, 2, "us"),
+                                                           (5, "zipf200k_phrases", 4, 2, "u")])
+def test_candidate_exchange_edges(world, name, maxlength, thr, kind):
+    """a world that is not a power of two (never key-sharded), threshold 1 (every window and every masked form kept), ranks whose shard is empty, wide class ids"""
+    p = run([world, name, maxlength, thr, repr(KINDS[kind])], script=SCRIPT_CANDIDATES, timeout=300)
+    assert p.returncode == 0 and "OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+
+
+def test_order_1_by_key_exchange_when_a_rank_is_not_canonical():
+    """a rank whose class encoding is not canonical takes every rank to the keyed unigram pass (sharded.cpp unigrams_dense -> false)"""
+    p = run([2, "zipf20k", 4, 2, repr(KINDS["us"])], script=SCRIPT_CANDIDATES, env_extra={"COLIBRI_MOCK_NO_DENSE_UNIGRAMS": "1"})
+    assert p.returncode == 0 and "OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+
+
+KSHARD_STEPS = ["2:colibri_kshard_begin", "1:colibri_kshard_uni_count", "0:colibri_kshard_uni_apply", "3:colibri_kshard_emit", "2:colibri_kshard_recv_buffers", "1:colibri_kshard_count",
+                "0:colibri_kshard_feedback_buffers", "3:colibri_kshard_apply", "1:colibri_kshard_local_stats"]
+
+SCRIPT_FALLBACK = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import conftest, oracle
+from colibri_amd import capi
+world, name, maxlength, thr = int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), int(sys.argv[6])
+payload = conftest.small_corpora()[name]
+want = oracle.train(payload, thr, maxlength)
+with capi.ShardedTrainer(world, devices=[0] * world) as tr:
+    tr.upload_split(payload)
+    st = tr.train(mintokens=thr, maxlength=maxlength)
+    assert tr.info.protocol == 1, "the run did not fall back"
+    assert tr.export_dict() == want.counts
+    assert (st.totaltokens, st.totaltypes, st.maxn, st.npatterns) == (want.tokens, want.types, want.maxn, len(want.counts))
+print("OK")
+"""
+
+
+@pytest.mark.parametrize("fault", KSHARD_STEPS)
 def test_a_failing_rank_takes_all_ranks_out_of_the_run_together(fault):
     """one rank of four reports a failure at one step: nobody may stay behind in a barrier (the subprocess would time out); every rank leaves at the same agreement,
-    the trainer turns to the candidate exchange — which the mock does not have — and the run ends with an error that names it, on a trainer that can be destroyed"""
-    p = run([4, "zipf20k", 5, 2], fault=fault, timeout=60)
+    the trainer turns to the candidate exchange; with that switched off in the mock the run ends with an error that names it, on a trainer that can be destroyed"""
+    p = run([4, "zipf20k", 5, 2], fault=fault, timeout=60, env_extra={"COLIBRI_MOCK_NO_CANDIDATES": "1"})
     assert p.returncode != 0
     assert "failed on rank(s) " + fault.split(":")[0] in p.stderr, p.stderr[-1500:]
-    assert "candidate exchange" in p.stderr and "not mocked" in p.stderr, p.stderr[-1500:]
+    assert "candidate exchange" in p.stderr and "switched off" in p.stderr, p.stderr[-1500:]
+
+
+@pytest.mark.parametrize("fault", KSHARD_STEPS)
+def test_a_key_sharded_run_that_gives_up_is_repeated_by_candidate_exchange(fault):
+    """the same failures with the whole driver behind them: all ranks leave the key-sharded run together, repeat it with the candidate exchange (what a record
+    region or final bin that overflows on one rank leads to on the device) and build the oracle's model"""
+    p = run([4, "zipf20k", 5, 2], fault=fault, timeout=60, script=SCRIPT_FALLBACK)
+    assert p.returncode == 0 and "OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+    assert "failed on rank(s) " + fault.split(":")[0] in p.stderr and "repeating the run with the candidate exchange" in p.stderr, p.stderr[-1500:]
+
+
+@pytest.mark.parametrize("kind", ["us", "is"])
+@pytest.mark.parametrize("fault", ["1:colibri_shard_begin", "2:colibri_shard_uni_count", "0:colibri_shard_count", "3:colibri_shard_send_view", "1:colibri_shard_merge", "2:colibri_shard_reply",
+                                   "3:colibri_shard_apply"])
+def test_a_failing_rank_of_a_candidate_exchange_ends_the_run_on_every_rank(fault, kind):
+    """the candidate exchange has nothing to fall back to: a step that fails on one rank ends the run on all four — at the agreement that follows it, or (the apply step,
+    which no agreement follows) through the aborted rendezvous — with an error that names the step; nobody hangs, the trainer can be destroyed"""
+    p = run([4, "zipf20k", 5, 2, repr(KINDS[kind])], fault=fault, timeout=60, script=SCRIPT_CANDIDATES)
+    assert p.returncode != 0
+    if "apply" in fault:
+        assert fault.split(":")[1] + ": injected fault" in p.stderr, p.stderr[-1500:]
+    else:  # (the message of whichever rank reported first: it names the failing rank, not necessarily the reason)
+        assert "failed on rank(s) " + fault.split(":")[0] in p.stderr, p.stderr[-1500:]

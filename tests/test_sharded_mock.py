@@ -162,3 +162,24 @@ def test_a_failing_rank_of_a_candidate_exchange_ends_the_run_on_every_rank(fault
         assert fault.split(":")[1] + ": injected fault" in p.stderr, p.stderr[-1500:]
     else:  # (the message of whichever rank reported first: it names the failing rank, not necessarily the reason)
         assert "failed on rank(s) " + fault.split(":")[0] in p.stderr, p.stderr[-1500:]
+
+
+# ---- the CLI over the stand-in: PatternModel::train -> device_train_sharded -> rank threads -> the merge of the ranks' exports and forward indexes -> the reference's text ----------
+MOCK_CLI = os.path.join(ROOT, "colibri-core_amd", "bin", "colibri-patternmodeller-mock")
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("case", ["hamlet.u", "hamlet.us", "hamlet.i", "hamlet.is", "zipf20k.us", "zipf20k.is"])
+def test_the_cli_trained_over_n_ranks_prints_what_the_reference_prints(case, world):
+    """`colibri-patternmodeller --gpus N` (host/src/patternmodeller.cpp, host/include/patternmodel.h train(), host/src/sharded.cpp device_train_sharded) on the CPU stand-in:
+    print (with every pattern's reference list, merged from the ranks' forward indexes in rank order), report and histogram equal the text the REAL reference printed
+    for its own model of the same corpus (tests/golden/views/, reference include/patternmodel.h:2294-2601, :2907-2959, :3390-3450)"""
+    import test_views
+    build()
+    corpus, flags, cls = test_views.CASES[case]
+    for view, vf in test_views.VIEW_FLAGS.items():
+        p = subprocess.run([MOCK_CLI, "-f", os.path.join(test_views.GOLD, f"{corpus}.colibri.dat"), "-c", os.path.join(test_views.GOLD, cls), vf, "--gpus", str(world)] + flags,
+                           capture_output=True, timeout=300, env=dict(os.environ, COLIBRI_NO_RCCL="1"))
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        assert b"sentence-sharded over " + str(world).encode() in p.stderr
+        test_views.check(case, view, p.stdout)

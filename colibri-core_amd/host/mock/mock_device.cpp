@@ -1,7 +1,8 @@
 // mock_device.cpp — TEST INFRASTRUCTURE: a CPU stand-in for everything host/src/sharded.cpp talks to, so that the product's own multi-GPU driver — its rank threads,
 // rendezvous, agreement steps, routing of sizes and buffers, termination ("None found"), failure paths — runs under `pytest -m "not gpu"` with world 2 and 4 and no GPU:
-//   * the HIP runtime calls it makes (memory, copies, streams; "device memory" is host memory) and the RCCL entry points (present, never successful: the ranks of a
-//     mock run share "device 0", so the trainer takes its device-copies back end);
+//   * the HIP runtime calls it makes (memory, copies, streams; "device memory" is host memory);
+//   * the RCCL entry points it calls, between the ranks of one process (below): ranks on distinct "devices" take the trainer's RCCL back end — groups of sends and
+//     receives, all-reduces, all-gathers, communicators from ncclCommInitAll or from a unique id — ranks that share "device 0" its device-copies back end;
 //   * the C ABI of a device context as far as the key-sharded run uses it (include/colibri_hip.h: colibri_create ... colibri_kshard_*), computed on the CPU in the
 //     protocol's own terms — records to the owner of their key, a bit per record and a number per surviving record back, exports to the lowest rank holding an
 //     occurrence. The formats inside the buffers are this file's own (the driver moves bytes and sizes, it never looks inside);
@@ -17,8 +18,14 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <string>
 #include <vector>
@@ -41,19 +48,220 @@ hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "mock HIP error"; }
-// ---- RCCL: declared, never usable ------------------------------------------------------------------------------------------------------------------------------------------
-ncclResult_t ncclGetUniqueId(ncclUniqueId*) { return ncclSystemError; }
-ncclResult_t ncclCommInitRank(ncclComm_t*, int, ncclUniqueId, int) { return ncclSystemError; }
-ncclResult_t ncclCommInitAll(ncclComm_t*, int, const int*) { return ncclSystemError; }
-ncclResult_t ncclCommAbort(ncclComm_t) { return ncclSuccess; }
-ncclResult_t ncclCommDestroy(ncclComm_t) { return ncclSuccess; }
-ncclResult_t ncclGroupStart() { return ncclSystemError; }
-ncclResult_t ncclGroupEnd() { return ncclSystemError; }
-ncclResult_t ncclSend(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return ncclSystemError; }
-ncclResult_t ncclRecv(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return ncclSystemError; }
-ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) { return ncclSystemError; }
-ncclResult_t ncclAllGather(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) { return ncclSystemError; }
-const char*  ncclGetErrorString(ncclResult_t) { return "RCCL is not part of the mock"; }
+}  // extern "C"
+
+// ---- RCCL between the ranks of ONE process: the calls host/src/sharded.cpp makes, carried out on the CPU when the LAST rank of the communicator arrives -----------------------------
+// (an all-gather, an all-reduce, or a group of sends and receives is complete when the call returns — a stream is a formality here). What it checks that copies between
+// contexts cannot: every send meets a receive of the same size on the peer it names, in the order both sides enqueued them; every rank of a collective passes the same count,
+// type and operator; a communicator that was aborted wakes and fails everyone inside it. ncclCommInitAll serves the one-thread-per-rank trainer, ncclGetUniqueId +
+// ncclCommInitRank the one-trainer-per-rank form (bench.py --gpus N: here one trainer per Python thread). COLIBRI_NO_RCCL=1 (the trainer's own switch) still selects the copies.
+namespace {
+struct P2P { const char* send; char* recv; size_t bytes; int peer; };
+struct Posted;
+struct Coll { int kind = 0; const void* send = nullptr; void* recv = nullptr; size_t count = 0; int dtype = 0, op = 0; };  // kind 1: all-reduce, 2: all-gather
+struct CommGroup {
+    std::mutex               m;
+    std::condition_variable  cv;
+    int                      n = 0, joined = 0, arrived = 0;
+    uint64_t                 generation = 0;
+    bool                     aborted = false, mismatch = false;
+    std::map<std::pair<int, int>, std::deque<Posted*>> queue;  // (source, destination) -> the sends posted and not yet taken, in order
+    std::vector<Coll>        coll;               // [rank]
+    std::vector<std::vector<unsigned char>> tmp; // [rank]: an all-reduce's result before anyone's (in-place) buffer is overwritten
+    // all ranks meet; the last one to arrive runs `work` (under the lock: the others are parked). false: the communicator was aborted or the ranks disagreed
+    template <class F>
+    bool meet(F work) {
+        std::unique_lock<std::mutex> l(m);
+        if (aborted) return false;
+        const uint64_t g = generation;
+        if (++arrived == n) {
+            work();
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+        } else if (!cv.wait_for(l, std::chrono::seconds(60), [&] { return generation != g || aborted; })) {
+            if (std::getenv("COLIBRI_MOCK_RCCL_DEBUG")) std::fprintf(stderr, "mock RCCL: a collective of %d ranks saw only %d arrive\n", n, arrived);
+            aborted = true;  // (a peer never came: a test must fail, not hang)
+            cv.notify_all();
+        }
+        return !aborted && !mismatch;
+    }
+};
+std::mutex                                          g_idm;
+std::map<std::string, std::shared_ptr<CommGroup>>   g_groups;  // unique id -> the communicator its ranks are joining
+uint64_t                                            g_next_id = 1;
+size_t nccl_size(ncclDataType_t t) { return t == ncclUint64 || t == ncclInt64 || t == ncclFloat64 ? 8 : (t == ncclUint8 || t == ncclInt8) ? 1 : (t == ncclFloat16 || t == ncclBfloat16) ? 2 : 4; }
+}  // namespace
+struct ncclComm {
+    std::shared_ptr<CommGroup> g;
+    int                        rank = 0;
+};
+namespace {
+struct Posted { ncclComm* cm; P2P op; bool is_send, done; };
+}  // namespace
+namespace {
+thread_local std::vector<Posted> t_ops;  // what this thread enqueued inside its open group
+thread_local bool                t_open = false;
+}  // namespace
+
+extern "C" {
+ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
+    std::lock_guard<std::mutex> l(g_idm);
+    std::memset(id, 0, sizeof *id);
+    const uint64_t v = g_next_id++;
+    std::memcpy(id->internal, &v, sizeof v);
+    std::memcpy(id->internal + 8, "colibri-mock-rccl", 17);
+    return ncclSuccess;
+}
+ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int rank) {
+    if (!out || nranks < 1 || rank < 0 || rank >= nranks) return ncclInvalidArgument;
+    std::shared_ptr<CommGroup> g;
+    {
+        std::lock_guard<std::mutex> l(g_idm);
+        auto& slot = g_groups[std::string(id.internal, sizeof id.internal)];
+        if (!slot) {
+            slot = std::make_shared<CommGroup>();
+            slot->n = nranks;
+            slot->coll.resize((size_t)nranks); slot->tmp.resize((size_t)nranks);
+        }
+        g = slot;
+    }
+    if (g->n != nranks) return ncclInvalidArgument;
+    std::unique_lock<std::mutex> l(g->m);
+    ++g->joined;
+    g->cv.notify_all();
+    if (!g->cv.wait_for(l, std::chrono::seconds(60), [&] { return g->joined >= g->n; })) return ncclSystemError;  // (the real call blocks until every rank has joined, too)
+    *out = new ncclComm{g, rank};
+    return ncclSuccess;
+}
+ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int*) {
+    auto g = std::make_shared<CommGroup>();
+    g->n = g->joined = ndev;
+    g->coll.resize((size_t)ndev); g->tmp.resize((size_t)ndev);
+    for (int r = 0; r < ndev; ++r) comms[r] = new ncclComm{g, r};
+    return ncclSuccess;
+}
+ncclResult_t ncclCommAbort(ncclComm_t cm) {
+    if (!cm) return ncclInvalidArgument;
+    {
+        std::lock_guard<std::mutex> l(cm->g->m);
+        cm->g->aborted = true;
+        cm->g->cv.notify_all();
+    }
+    delete cm;
+    return ncclSuccess;
+}
+ncclResult_t ncclCommDestroy(ncclComm_t cm) { delete cm; return ncclSuccess; }
+ncclResult_t ncclGroupStart() {
+    if (t_open) return ncclInvalidUsage;
+    t_open = true;
+    t_ops.clear();
+    return ncclSuccess;
+}
+static ncclResult_t enqueue(ncclComm_t cm, const P2P& op, bool is_send) {
+    if (!cm || op.peer < 0 || op.peer >= cm->g->n) return ncclInvalidArgument;
+    if (!t_open) return ncclInvalidUsage;  // (the trainer never sends outside a group: a lone ncclSend would block on its peer)
+    t_ops.push_back({cm, op, is_send, false});
+    return ncclSuccess;
+}
+ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t cm, hipStream_t) { return enqueue(cm, P2P{(const char*)buf, nullptr, count * nccl_size(t), peer}, true); }
+ncclResult_t ncclRecv(void* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t cm, hipStream_t) { return enqueue(cm, P2P{nullptr, (char*)buf, count * nccl_size(t), peer}, false); }
+// point-to-point semantics: the group is complete when each of its sends was taken by the peer's matching receive and each of its receives was filled — only the pairs
+// that talk to each other wait for each other (a rank with an empty shard posts nothing and waits for nobody)
+ncclResult_t ncclGroupEnd() {
+    if (!t_open) return ncclInvalidUsage;
+    t_open = false;
+    if (t_ops.empty()) return ncclSuccess;
+    std::shared_ptr<CommGroup> g = t_ops[0].cm->g;
+    for (const Posted& o : t_ops)
+        if (o.cm->g != g) return ncclInvalidUsage;  // (one communicator per group is all the trainer needs)
+    std::unique_lock<std::mutex> l(g->m);
+    static const bool trace = std::getenv("COLIBRI_MOCK_RCCL_TRACE") != nullptr;
+    for (Posted& o : t_ops) {
+        if (o.is_send) g->queue[{o.cm->rank, o.op.peer}].push_back(&o);
+        if (trace) std::fprintf(stderr, "T rank %d posts %s %zu peer %d (%p)\n", o.cm->rank, o.is_send ? "send" : "recv", o.op.bytes, o.op.peer, (void*)&o);
+    }
+    g->cv.notify_all();
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(60);
+    for (;;) {
+        if (g->aborted || g->mismatch) break;
+        bool all = true;
+        for (Posted& o : t_ops) {
+            if (o.done) continue;
+            if (!o.is_send) {
+                auto& q = g->queue[{o.op.peer, o.cm->rank}];
+                if (!q.empty()) {
+                    Posted* sd = q.front();
+                    q.pop_front();
+                    if (sd->op.bytes != o.op.bytes) {
+                        if (std::getenv("COLIBRI_MOCK_RCCL_DEBUG")) std::fprintf(stderr, "mock RCCL: rank %d receives %zu bytes from rank %d, which sends %zu\n", o.cm->rank, o.op.bytes, o.op.peer, sd->op.bytes);
+                        g->mismatch = true;
+                        break;
+                    }  // the k-th receive posted for a peer takes the k-th send that peer posted for this rank
+                    std::memcpy(o.op.recv, sd->op.send, o.op.bytes);
+                    sd->done = o.done = true;
+                    if (trace) std::fprintf(stderr, "T rank %d takes %zu from %d (%p)\n", o.cm->rank, o.op.bytes, o.op.peer, (void*)sd);
+                    g->cv.notify_all();
+                    continue;
+                }
+            }
+            all = false;
+        }
+        if (g->mismatch) { g->cv.notify_all(); break; }
+        all = std::all_of(t_ops.begin(), t_ops.end(), [](const Posted& o) { return o.done; });  // (a send to itself is taken by a receive later in the same scan)
+        if (all) break;
+        if (g->cv.wait_until(l, deadline) == std::cv_status::timeout) {  // (a peer never came: a test must fail, not hang)
+            if (std::getenv("COLIBRI_MOCK_RCCL_DEBUG"))
+                for (const Posted& o : t_ops)
+                    if (!o.done) std::fprintf(stderr, "mock RCCL: rank %d still waits to %s %zu bytes %s rank %d\n", o.cm->rank, o.is_send ? "send" : "receive", o.op.bytes, o.is_send ? "to" : "from", o.op.peer);
+            g->aborted = true;
+            g->cv.notify_all();
+            break;
+        }
+    }
+    if (trace) std::fprintf(stderr, "T rank %d leaves its group\n", t_ops[0].cm->rank);
+    const bool ok = !g->aborted && !g->mismatch;
+    if (!ok)  // nobody may keep a pointer into this thread's list
+        for (auto& kv : g->queue)
+            for (auto it = kv.second.begin(); it != kv.second.end();) it = (std::find_if(t_ops.begin(), t_ops.end(), [&](const Posted& o) { return &o == *it; }) != t_ops.end()) ? kv.second.erase(it) : it + 1;
+    l.unlock();
+    t_ops.clear();
+    return ok ? ncclSuccess : ncclInternalError;
+}
+ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataType_t t, ncclRedOp_t op, ncclComm_t cm, hipStream_t) {
+    if (!cm) return ncclInvalidArgument;
+    if (t != ncclUint32 || (op != ncclSum && op != ncclMin)) return ncclInvalidArgument;  // (what the trainer reduces: u32 counts by SUM, ranks by MIN)
+    const std::shared_ptr<CommGroup> keep = cm->g;  // (the communicator may be aborted — deleted — by a failing peer while this rank is parked)
+    CommGroup&                       g    = *keep;
+    { std::lock_guard<std::mutex> l(g.m); g.coll[(size_t)cm->rank] = Coll{1, send, recv, count, (int)t, (int)op}; }
+    const bool ok = g.meet([&] {
+        for (int r = 0; r < g.n; ++r)
+            if (g.coll[(size_t)r].kind != 1 || g.coll[(size_t)r].count != count || g.coll[(size_t)r].op != (int)op) { g.mismatch = true; return; }
+        std::vector<uint32_t> red((const uint32_t*)g.coll[0].send, (const uint32_t*)g.coll[0].send + count);
+        for (int r = 1; r < g.n; ++r) {
+            const uint32_t* o = (const uint32_t*)g.coll[(size_t)r].send;
+            for (size_t j = 0; j < count; ++j) red[j] = op == ncclMin ? std::min(red[j], o[j]) : red[j] + o[j];
+        }
+        for (int r = 0; r < g.n; ++r) { std::memcpy(g.coll[(size_t)r].recv, red.data(), count * 4); g.coll[(size_t)r] = Coll(); }
+    });
+    return ok ? ncclSuccess : ncclInternalError;
+}
+ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataType_t t, ncclComm_t cm, hipStream_t) {
+    if (!cm) return ncclInvalidArgument;
+    const std::shared_ptr<CommGroup> keep = cm->g;
+    CommGroup&                       g    = *keep;
+    const size_t                     nb   = count * nccl_size(t);
+    { std::lock_guard<std::mutex> l(g.m); g.coll[(size_t)cm->rank] = Coll{2, send, recv, nb, (int)t, 0}; }
+    const bool ok = g.meet([&] {
+        for (int r = 0; r < g.n; ++r)
+            if (g.coll[(size_t)r].kind != 2 || g.coll[(size_t)r].count != nb) { g.mismatch = true; return; }
+        std::vector<unsigned char> all(nb * (size_t)g.n);
+        for (int r = 0; r < g.n; ++r) std::memcpy(all.data() + nb * (size_t)r, g.coll[(size_t)r].send, nb);
+        for (int r = 0; r < g.n; ++r) { std::memcpy(g.coll[(size_t)r].recv, all.data(), all.size()); g.coll[(size_t)r] = Coll(); }
+    });
+    return ok ? ncclSuccess : ncclInternalError;
+}
+const char* ncclGetErrorString(ncclResult_t e) { return e == ncclInternalError ? "mock RCCL: the communicator was aborted, a peer never arrived, or the ranks' calls do not match" : "mock RCCL error"; }
 }
 
 // ---- the device context, on the CPU ------------------------------------------------------------------------------------------------------------------------------------------

@@ -164,6 +164,94 @@ def test_a_failing_rank_of_a_candidate_exchange_ends_the_run_on_every_rank(fault
         assert "failed on rank(s) " + fault.split(":")[0] in p.stderr, p.stderr[-1500:]
 
 
+# ---- the trainer's RCCL back end over the stand-in's in-process RCCL: what `bench.py --gpus N` and `colibri-patternmodeller --gpus N` run on N devices --------------------------
+SCRIPT_RCCL = r"""
+import sys, threading
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import conftest, oracle
+from colibri_amd import capi
+from colibri_amd.dist import shard_payload
+world, name, maxlength, thr, kind, mode = int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), eval(sys.argv[7]), sys.argv[8]
+payload = conftest.small_corpora()[name]
+want = oracle.train(payload, thr, maxlength, **kind)
+kw = dict(mintokens=thr, maxlength=maxlength, **{k: int(v) for k, v in kind.items()})
+if mode == "threads":
+    with capi.ShardedTrainer(world) as tr:
+        tr.upload_split(payload)
+        for rep in range(2):
+            st = tr.train(**kw)
+            assert tr.info.rccl == 1, "not on the RCCL back end"
+            assert tr.export_dict() == want.counts
+            assert (st.totaltokens, st.totaltypes, st.maxn, st.npatterns) == (want.tokens, want.types, want.maxn, len(want.counts))
+        print("protocol", tr.info.protocol, "a2a bytes", tr.info.alltoall_bytes)
+else:
+    uid = capi.sharded_unique_id()
+    shards = shard_payload(payload, world)
+    got, errs, stats = [None] * world, [], [None] * world
+    def rank_main(r):
+        try:
+            with capi.ShardedTrainer(world, nlocal=1, first_rank=r, devices=[r], unique_id=uid) as tr:
+                tr.upload(0, shards[r][0], shards[r][1])
+                for rep in range(2):
+                    stats[r] = tr.train(**kw)
+                    assert tr.info.rccl == 1
+                    got[r] = tr.export_dict()
+        except Exception as e:
+            errs.append((r, repr(e)))
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs
+    union = {}
+    for g in got:
+        assert not (set(g) & set(union)), "a pattern exported by two ranks"
+        union.update(g)
+    assert union == want.counts, (len(union), len(want.counts))
+    for st in stats:
+        assert (st.totaltokens, st.totaltypes, st.maxn) == (want.tokens, want.types, want.maxn)
+        for n in range(1, min(maxlength, 20) + 1):
+            assert (st.found[n], st.kept[n]) == (want.stats[n][0], want.stats[n][2]), n
+    assert sum(st.npatterns for st in stats) == len(want.counts)
+print("OK")
+"""
+
+
+def run_rccl(args, fault=None, timeout=180):
+    build()
+    env = dict(os.environ, COLIBRI_SHARDED_LIB=MOCK)
+    env.pop("COLIBRI_NO_RCCL", None)
+    if fault:
+        env["COLIBRI_FAULT"] = fault
+    return subprocess.run([sys.executable, "-c", SCRIPT_RCCL, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")] + [str(a) for a in args], env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+@pytest.mark.parametrize("mode", ["threads", "procs"])
+@pytest.mark.parametrize("world,name,maxlength,thr,kind", [(2, "zipf20k", 5, 2, "u"), (4, "zipf20k", 5, 2, "u"), (8, "zipf20k", 5, 2, "u"), (4, "rand_noempty", 8, 3, "u"), (8, "short_sentences", 5, 2, "u"),
+                                                           (4, "empty", 5, 2, "u"), (3, "zipf20k", 5, 2, "u"), (2, "zipf20k", 5, 2, "us"), (4, "zipf20k", 5, 2, "us"), (8, "rand3", 5, 2, "us"),
+                                                           (4, "zipf20k", 5, 2, "i"), (4, "zipf20k", 5, 2, "is"), (3, "rand2", 6, 2, "isT1"), (8, "one_token", 5, 2, "is")])
+def test_the_rccl_back_end_of_the_cxx_driver(mode, world, name, maxlength, thr, kind):
+    """ranks on distinct devices: every exchange of host/src/sharded.cpp goes through ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd, ncclAllReduce (SUM, MIN) and — one
+    trainer per rank, communicators from a unique id, as bench.py --gpus N builds them — ncclAllGather for the ranks' host values. The stand-in's RCCL refuses a send without
+    a receive of the same size on the peer it names, and collectives whose ranks disagree: sizes, offsets and orders of the driver's calls are checked, not only their results.
+    `threads`: one trainer holding all ranks (ncclCommInitAll); `procs`: one trainer per rank, each on its own Python thread. Both protocols (plain models: key-sharded)."""
+    p = run_rccl([world, name, maxlength, thr, repr(KINDS[kind]), mode])
+    assert p.returncode == 0 and "OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+
+
+@pytest.mark.parametrize("mode", ["threads", "procs"])
+@pytest.mark.parametrize("fault,kind", [("1:colibri_kshard_count", "u"), ("2:colibri_shard_merge", "us"), ("3:colibri_shard_apply", "is"), ("0:colibri_shard_count", "i")])
+def test_a_failing_rank_on_the_rccl_back_end(mode, fault, kind):
+    """agreed failures leave the communicators intact (the plain model's run is repeated by candidate exchange and succeeds); a failure no agreement follows aborts them
+    (ncclCommAbort wakes the peers parked inside a collective): every rank ends, nobody hangs"""
+    p = run_rccl([4, "zipf20k", 5, 2, repr(KINDS[kind]), mode], fault=fault, timeout=150)
+    if kind == "u":
+        assert p.returncode == 0 and "OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+        assert "repeating the run with the candidate exchange" in p.stderr
+    else:
+        assert p.returncode != 0
+        assert ("injected fault" in p.stderr + p.stdout) or ("failed on rank(s) " + fault.split(":")[0] in p.stderr + p.stdout), (p.stdout[-800:], p.stderr[-1500:])
+
+
 # ---- the CLI over the stand-in: PatternModel::train -> device_train_sharded -> rank threads -> the merge of the ranks' exports and forward indexes -> the reference's text ----------
 MOCK_CLI = os.path.join(ROOT, "colibri-core_amd", "bin", "colibri-patternmodeller-mock")
 

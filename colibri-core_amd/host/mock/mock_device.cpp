@@ -322,6 +322,7 @@ struct colibri_ctx {
     uint64_t              found[COLIBRI_MAX_ORDER] = {0}, kept[COLIBRI_MAX_ORDER] = {0}, admitted[COLIBRI_MAX_ORDER] = {0};
     colibri_stats         stats{};
     uint32_t              first_sentence = 1;
+    uint64_t              kbase = 0;  // key-sharded run: the global number of the current order's survivor 0
     ShardRun              sh;
 };
 
@@ -371,7 +372,7 @@ int colibri_corpus_info(const colibri_ctx* c, uint64_t* ntokens, uint64_t* nsent
 }
 
 int colibri_kshard_info(colibri_ctx* c, const colibri_options* o, int* eligible, uint64_t* maxclass, uint64_t* npos) {
-    *eligible = !o->indexed && !o->doskipgrams && !o->doskipgrams_exhaustive && !std::getenv("COLIBRI_NO_KSHARD");
+    *eligible = !o->doskipgrams && !o->doskipgrams_exhaustive && !std::getenv("COLIBRI_NO_KSHARD");  // (plain and indexed models, as on the device)
     *maxclass = c->maxclass;
     *npos     = c->cls.size();
     return COLIBRI_OK;
@@ -379,6 +380,8 @@ int colibri_kshard_info(colibri_ctx* c, const colibri_options* o, int* eligible,
 int colibri_kshard_begin(colibri_ctx* c, const colibri_options* o, int world, int rank, uint64_t maxclass_global, uint64_t) {
     c->opt = *o; c->world = world; c->rank = rank; c->n = 0; c->nclasses = maxclass_global + 1;
     c->results.clear();
+    c->sh    = ShardRun();  // (an indexed run names its patterns and keeps its forward index the way a candidate-exchange run does: global numbers)
+    c->kbase = c->nclasses;  // a unigram's global number is its class id; order 2's survivors follow
     std::fill(std::begin(c->found), std::end(c->found), 0); std::fill(std::begin(c->kept), std::end(c->kept), 0); std::fill(std::begin(c->admitted), std::end(c->admitted), 0);
     return COLIBRI_OK;
 }
@@ -408,8 +411,11 @@ int colibri_kshard_uni_apply(colibri_ctx* c) {  // cnt1 holds the global counts 
     // the mock does the same through a synthetic result whose key bytes are rebuilt from the class id.
     if (c->rank == 0)
         for (uint64_t v = 1; v < c->nclasses; ++v)
-            if (c->cnt1[v] >= thr) c->results.push_back({(uint32_t)v, 0u /* n = 0: a class id, not a position */, c->cnt1[v], 0u});
-    for (size_t i = 0; i < c->cls.size(); ++i) c->admitted[1] += c->cls[i] != 0;
+            if (c->cnt1[v] >= thr) { c->results.push_back({(uint32_t)v, 0u /* n = 0: a class id, not a position */, c->cnt1[v], 0u}); c->sh.res_gid.push_back((uint32_t)v); }
+    for (size_t i = 0; i < c->cls.size(); ++i) {
+        c->admitted[1] += c->cls[i] != 0;
+        if (c->opt.indexed && c->cls[i] && c->cnt1[c->cls[i]] >= thr) c->sh.pairs.push_back({c->cls[i], (uint32_t)i});
+    }
     return COLIBRI_OK;
 }
 int colibri_kshard_emit(colibri_ctx* c, int n, uint64_t, uint64_t, int, void** send_dev, void** tab_dev, uint32_t* tab_words, uint64_t* per_owner, uint32_t* recbytes, void** head_dev,
@@ -478,7 +484,7 @@ int colibri_kshard_count(colibri_ctx* c, int n, const uint64_t* per_src, int mor
     c->fb.clear(); c->ex.clear();
     for (int s = 0; s < c->world; ++s) {
         fb_per_dst[s] = 0;
-        if (more) {  // per source, in the order it sent: one bit per record, then the numbers of the surviving records' keys
+        if (more || c->opt.indexed) {  // (an indexed model needs every survivor's number at its last order too: its references are keyed by it) per source, in the order it sent: one bit per record, then the numbers of the surviving records' keys
             const size_t          at = c->fb.size(), nw = (per_src[s] + 31) / 32;
             std::vector<uint32_t> codes;
             c->fb.resize(at + nw, 0u);
@@ -509,7 +515,7 @@ int colibri_kshard_apply(colibri_ctx* c, int n, const uint64_t* fb_src, const ui
     c->nxt.assign(c->cls.size(), ~0ull);
     for (int d = 0; d < c->world; ++d) {
         const uint32_t nd = c->sbase[(size_t)d + 1] - c->sbase[(size_t)d], nw = (nd + 31) / 32;
-        if (more) {
+        if (more || c->opt.indexed) {
             if (fb_src[d] < nw) return fail(c, COLIBRI_ERR_STATE, "mock: short feedback");
             uint64_t ci = off + nw;
             for (uint32_t j = 0; j < nd; ++j)
@@ -520,15 +526,42 @@ int colibri_kshard_apply(colibri_ctx* c, int n, const uint64_t* fb_src, const ui
         for (uint64_t k = 0; k < ex_src[d]; ++k) {
             const uint64_t e = c->exr[eo + k];
             c->results.push_back({c->sendpos[c->sbase[(size_t)d] + (uint32_t)e], (uint32_t)n, (uint32_t)(e >> 32), 0u});
+            if (c->opt.indexed) c->sh.res_gid.push_back((uint32_t)(c->kbase + c->nxt[c->results.back().pos]));  // (the owner's feedback numbered this window a moment ago)
         }
         eo += ex_src[d];
         gb += kept_per_owner[d];
     }
     if (gb >= (1ull << 40)) return fail(c, COLIBRI_ERR_OVERFLOW, "mock: too many survivors");
+    if (c->opt.indexed)
+        for (size_t i = 0; i < c->nxt.size(); ++i)
+            if (c->nxt[i] != ~0ull) c->sh.pairs.push_back({(uint32_t)(c->kbase + c->nxt[i]), (uint32_t)i});
+    c->kbase += gb;
     c->cur.swap(c->nxt);
     *ids_global = gb;
     return COLIBRI_OK;
 }
+}  // extern "C"
+namespace {
+// the local forward index: per global number (ascending) the occurrences in corpus order, as (sentence, token) — sentences numbered from the shard's first_sentence
+void build_local_index(colibri_ctx* c) {
+    ShardRun& sh = c->sh;
+    std::sort(sh.pairs.begin(), sh.pairs.end());
+    std::vector<uint32_t> sent(c->cls.size(), 0u), tok(c->cls.size(), 0u);
+    uint32_t              sn = c->first_sentence, tn = 0;
+    for (size_t i = 0; i < c->cls.size(); ++i) {
+        sent[i] = sn; tok[i] = tn;
+        if (c->cls[i] == 0 && c->blen[i] == 1) { ++sn; tn = 0; } else ++tn;
+    }
+    sh.ugid.clear(); sh.uoff.clear(); sh.ref_sentence.clear(); sh.ref_token.clear();
+    for (size_t j = 0; j < sh.pairs.size(); ++j) {
+        if (j == 0 || sh.pairs[j].first != sh.pairs[j - 1].first) { sh.ugid.push_back(sh.pairs[j].first); sh.uoff.push_back(j); }
+        sh.ref_sentence.push_back(sent[sh.pairs[j].second]);
+        sh.ref_token.push_back((uint16_t)tok[sh.pairs[j].second]);
+    }
+    sh.uoff.push_back(sh.pairs.size());
+}
+}  // namespace
+extern "C" {
 int colibri_kshard_local_stats(colibri_ctx* c, uint64_t* found, uint64_t* kept, uint64_t* admitted, uint32_t* syncs) {
     for (int n = 0; n < COLIBRI_MAX_ORDER; ++n) { found[n] = c->found[n]; kept[n] = c->kept[n]; admitted[n] = c->admitted[n]; }
     if (syncs) *syncs = 0;
@@ -542,6 +575,7 @@ int colibri_kshard_finish(colibri_ctx* c, const uint64_t* found, const uint64_t*
         s.found[n] = n <= maxn ? found[n] : 0; s.kept[n] = n <= maxn ? kept[n] : 0; s.pruned[n] = s.found[n] - s.kept[n]; s.admitted[n] = n <= maxn ? admitted[n] : 0;
     }
     s.totaltypes = s.found[1];
+    if (c->opt.indexed) { build_local_index(c); s.nrefs = c->sh.pairs.size(); }
     if (out) *out = s;
     return COLIBRI_OK;
 }
@@ -817,21 +851,7 @@ int colibri_shard_finish(colibri_ctx* c, const uint64_t* found, const uint64_t* 
     s.totaltokens = tokens; s.nsentences = c->nsent; s.npatterns = c->results.size(); s.maxn = maxn; s.minn = maxn > 0 ? 1 : 0;
     for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) { s.found[n] = found[n]; s.kept[n] = kept[n]; s.pruned[n] = found[n] - kept[n]; s.admitted[n] = sh.admitted_n[n]; }
     s.totaltypes = s.found[1];
-    // the local forward index: per global number (ascending) the occurrences in corpus order, as (sentence, token) — sentences numbered from the shard's first_sentence
-    std::sort(sh.pairs.begin(), sh.pairs.end());
-    std::vector<uint32_t> sent(c->cls.size(), 0u), tok(c->cls.size(), 0u);
-    uint32_t              sn = c->first_sentence, tn = 0;
-    for (size_t i = 0; i < c->cls.size(); ++i) {
-        sent[i] = sn; tok[i] = tn;
-        if (c->cls[i] == 0 && c->blen[i] == 1) { ++sn; tn = 0; } else ++tn;
-    }
-    sh.ugid.clear(); sh.uoff.clear(); sh.ref_sentence.clear(); sh.ref_token.clear();
-    for (size_t j = 0; j < sh.pairs.size(); ++j) {
-        if (j == 0 || sh.pairs[j].first != sh.pairs[j - 1].first) { sh.ugid.push_back(sh.pairs[j].first); sh.uoff.push_back(j); }
-        sh.ref_sentence.push_back(sent[sh.pairs[j].second]);
-        sh.ref_token.push_back((uint16_t)tok[sh.pairs[j].second]);
-    }
-    sh.uoff.push_back(sh.pairs.size());
+    build_local_index(c);
     s.nrefs   = c->opt.indexed ? sh.pairs.size() : 0;
     sh.active = false;
     if (out) *out = s;

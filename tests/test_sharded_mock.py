@@ -19,12 +19,13 @@ sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
 import conftest, oracle
 from colibri_amd import capi
 world, name, maxlength, thr = int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), int(sys.argv[6])
+indexed = len(sys.argv) > 7 and sys.argv[7] == "indexed"
 payload = conftest.small_corpora()[name]
-want = oracle.train(payload, thr, maxlength)
+want = oracle.train(payload, thr, maxlength, indexed=indexed)
 with capi.ShardedTrainer(world, devices=[0] * world) as tr:
     tr.upload_split(payload)
     for rep in range(2):  # the trainer keeps its shards between runs
-        st = tr.train(mintokens=thr, maxlength=maxlength)
+        st = tr.train(mintokens=thr, maxlength=maxlength, indexed=int(indexed))
         got = tr.export_dict()
         assert got == want.counts, ("model differs", len(got), len(want.counts))
         assert (st.totaltokens, st.totaltypes, st.maxn, st.npatterns) == (want.tokens, want.types, want.maxn, len(want.counts)), (st.totaltokens, st.totaltypes, st.maxn, st.npatterns)
@@ -48,8 +49,8 @@ payload = conftest.small_corpora()[name]
 want = oracle.train(payload, thr, maxlength, **kind)
 with capi.ShardedTrainer(world, devices=[0] * world) as tr:
     tr.upload_split(payload)
-    if not kind:
-        tr.set_protocol(1)  # a plain model would be counted key-sharded
+    if not any("skipgram" in k for k in kind):
+        tr.set_protocol(1)  # a plain or indexed model without skipgrams would be counted key-sharded
     for rep in range(2):
         st = tr.train(mintokens=thr, maxlength=maxlength, **{k: int(v) for k, v in kind.items()})
         got = tr.export_dict()
@@ -81,6 +82,15 @@ def run(args, fault=None, timeout=120, script=SCRIPT, env_extra=None):
                                                 ("only_delims", 5, 2), ("one_long_sentence", 5, 2)])
 def test_the_cxx_driver_builds_the_oracles_model_on_the_mock(world, name, maxlength, thr):
     p = run([world, name, maxlength, thr])
+    assert p.returncode == 0 and "OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+@pytest.mark.parametrize("name,maxlength,thr", [("zipf20k", 5, 2), ("rand_noempty", 8, 3), ("repeat", 4, 1), ("short_sentences", 5, 2), ("one_token", 3, 2)])
+def test_indexed_models_are_counted_key_sharded(world, name, maxlength, thr):
+    """an indexed model takes the key-sharded protocol too (its feedback numbers the survivors of the last order as well: the references are keyed by those numbers);
+    counts and figures vs the oracle here, the reference lists through the CLI below (hamlet.i at 2 and 4 ranks)"""
+    p = run([world, name, maxlength, thr, "indexed"])
     assert p.returncode == 0 and "OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
 
 
@@ -239,7 +249,7 @@ def test_the_rccl_back_end_of_the_cxx_driver(mode, world, name, maxlength, thr, 
 
 
 @pytest.mark.parametrize("mode", ["threads", "procs"])
-@pytest.mark.parametrize("fault,kind", [("1:colibri_kshard_count", "u"), ("2:colibri_shard_merge", "us"), ("3:colibri_shard_apply", "is"), ("0:colibri_shard_count", "i")])
+@pytest.mark.parametrize("fault,kind", [("1:colibri_kshard_count", "u"), ("2:colibri_shard_merge", "us"), ("3:colibri_shard_apply", "is"), ("0:colibri_shard_count", "usT1")])
 def test_a_failing_rank_on_the_rccl_back_end(mode, fault, kind):
     """agreed failures leave the communicators intact (the plain model's run is repeated by candidate exchange and succeeds); a failure no agreement follows aborts them
     (ncclCommAbort wakes the peers parked inside a collective): every rank ends, nobody hangs"""
@@ -270,4 +280,5 @@ def test_the_cli_trained_over_n_ranks_prints_what_the_reference_prints(case, wor
                            capture_output=True, timeout=300, env=dict(os.environ, COLIBRI_NO_RCCL="1"))
         assert p.returncode == 0, p.stderr.decode()[-2000:]
         assert b"sentence-sharded over " + str(world).encode() in p.stderr
+        assert (b"Counted key-sharded" in p.stderr) == (case in ("hamlet.u", "hamlet.i") and world in (2, 4)), p.stderr.decode()[-800:]
         test_views.check(case, view, p.stdout)

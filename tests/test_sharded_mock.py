@@ -282,3 +282,50 @@ def test_the_cli_trained_over_n_ranks_prints_what_the_reference_prints(case, wor
         assert b"sentence-sharded over " + str(world).encode() in p.stderr
         assert (b"Counted key-sharded" in p.stderr) == (case in ("hamlet.u", "hamlet.i") and world in (2, 4)), p.stderr.decode()[-800:]
         test_views.check(case, view, p.stdout)
+
+
+SCRIPT_CONTRACT = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import conftest, oracle
+from colibri_amd import capi
+payload = conftest.small_corpora()["zipf20k"]
+with capi.ShardedTrainer(2, devices=[0, 0]) as tr:  # nothing uploaded yet
+    try:
+        tr.train(mintokens=2, maxlength=3)
+        raise SystemExit("a run without a corpus succeeded")
+    except capi.ColibriError as e:
+        assert "no corpus uploaded" in str(e), str(e)
+    tr.upload_split(payload)  # ... and the same trainer is usable afterwards
+    tr.train(mintokens=2, maxlength=3)
+    assert tr.export_dict() == oracle.train(payload, 2, 3).counts
+with capi.ShardedTrainer(4) as tr:  # RCCL back end; rank 3 fails where no agreement follows: the communicators are aborted
+    tr.upload_split(payload)
+    try:
+        tr.train(mintokens=2, maxlength=4, doskipgrams_exhaustive=1)
+        raise SystemExit("the injected fault did not fail the run")
+    except capi.ColibriError as e:
+        assert "injected fault" in str(e), str(e)
+    try:
+        tr.train(mintokens=2, maxlength=4)
+        raise SystemExit("a trainer whose communicators were aborted ran again")
+    except capi.ColibriError as e:
+        assert "create a new trainer" in str(e), str(e)
+for bad in (0, 65):
+    try:
+        capi.ShardedTrainer(bad)
+        raise SystemExit(f"a trainer of {bad} ranks was created")
+    except capi.ColibriError:
+        pass
+print("OK")
+"""
+
+
+def test_the_trainers_contract_between_runs():
+    """include/colibri_sharded.h: a run without a corpus is an error the trainer survives; a trainer whose communicators a failure aborted refuses further runs and says
+    what to do; rank counts outside 1..64 are refused"""
+    build()
+    env = dict(os.environ, COLIBRI_SHARDED_LIB=MOCK, COLIBRI_FAULT="3:colibri_shard_apply")
+    env.pop("COLIBRI_NO_RCCL", None)
+    p = subprocess.run([sys.executable, "-c", SCRIPT_CONTRACT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])

@@ -45,6 +45,14 @@ def test_exchange_protocol_gloo_cpu(tmp_path, world, corpus, maxlength):
     run_workers(tmp_path, world, "numpy", corpus, maxlength)
 
 
+@pytest.mark.parametrize("world,mode,corpus,maxlength", [(w, m, "1", 5) for w in (2, 3) for m in ("us", "usy3", "i", "is", "isT1")] + [(2, "us", "zipf", 4), (2, "is", "zipf", 4)])
+def test_exchange_protocol_of_every_model_kind_gloo_cpu(tmp_path, world, mode, corpus, maxlength):
+    """colibri_amd.dist.ShardedTrainer over gloo with the numpy stand-in engine, one process per rank: the skipgram passes level by level (exhaustive: BASELINE configs[3];
+    indexed trainskipgrams with the distinct-filler counts in the last level's exchange: configs[4]) and the forward index merged by global id in rank order — the union of
+    the ranks' exports, every reference list and the per-order figures equal the oracle's on the whole corpus"""
+    run_workers(tmp_path, world, "numpy", corpus, maxlength, mode=mode)
+
+
 @pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("corpus,maxlength,thr", [("rand_noempty", 5, 2), ("zipf20k", 5, 2), ("short_sentences", 4, 2), ("repeat", 9, 3), ("one_token", 3, 2), ("empty", 3, 2), ("zipf20k", 3, 1)])
 def test_key_sharded_protocol_gloo_cpu(tmp_path, world, corpus, maxlength, thr):

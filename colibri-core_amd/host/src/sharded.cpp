@@ -649,6 +649,21 @@ class RankDriver {
         HIPCHK(hipSetDevice(dev));
         chk(colibri_export_unindexed(c, key_off, key_bytes, counts), "colibri_export_unindexed");
     }
+    void export_gids(uint32_t* gids) {
+        HIPCHK(hipSetDevice(dev));
+        if (!trained || !has_gids) throw std::runtime_error("the last run left no global pattern numbers (an indexed model, or the candidate exchange, has them)");
+        chk(colibri_shard_export_gids(c, gids), "colibri_shard_export_gids");
+    }
+    void index_sizes(uint64_t* ngids, uint64_t* nrefs) {
+        HIPCHK(hipSetDevice(dev));
+        if (!trained) throw std::runtime_error("no trained model");
+        chk(colibri_shard_index_sizes(c, ngids, nrefs), "colibri_shard_index_sizes");
+    }
+    void export_index(uint32_t* gids, uint64_t* ref_off, uint32_t* ref_sentence, uint16_t* ref_token) {
+        HIPCHK(hipSetDevice(dev));
+        if (!trained) throw std::runtime_error("no trained model");
+        chk(colibri_shard_export_index(c, gids, ref_off, ref_sentence, ref_token), "colibri_shard_export_index");
+    }
     // this rank's share of the model into `out`
     void fetch(bool indexed) {
         HIPCHK(hipSetDevice(dev));
@@ -1033,6 +1048,36 @@ int colibri_sharded_export_unindexed(colibri_sharded* t, int local_rank, uint64_
     } catch (const std::exception& e) {
         t->err = e.what();
         return COLIBRI_ERR_HIP;
+    }
+    return COLIBRI_OK;
+}
+int colibri_sharded_export_gids(colibri_sharded* t, int local_rank, uint32_t* gids) {
+    if (!t || !gids || local_rank < 0 || local_rank >= (int)t->tr.ranks.size()) return COLIBRI_ERR_ARG;
+    try {
+        t->tr.ranks[(size_t)local_rank]->export_gids(gids);
+    } catch (const std::exception& e) {
+        t->err = e.what();
+        return COLIBRI_ERR_STATE;
+    }
+    return COLIBRI_OK;
+}
+int colibri_sharded_index_sizes(colibri_sharded* t, int local_rank, uint64_t* ngids, uint64_t* nrefs) {
+    if (!t || !ngids || !nrefs || local_rank < 0 || local_rank >= (int)t->tr.ranks.size()) return COLIBRI_ERR_ARG;
+    try {
+        t->tr.ranks[(size_t)local_rank]->index_sizes(ngids, nrefs);
+    } catch (const std::exception& e) {
+        t->err = e.what();
+        return COLIBRI_ERR_STATE;
+    }
+    return COLIBRI_OK;
+}
+int colibri_sharded_export_index(colibri_sharded* t, int local_rank, uint32_t* gids, uint64_t* ref_off, uint32_t* ref_sentence, uint16_t* ref_token) {
+    if (!t || !gids || !ref_off || !ref_sentence || !ref_token || local_rank < 0 || local_rank >= (int)t->tr.ranks.size()) return COLIBRI_ERR_ARG;
+    try {
+        t->tr.ranks[(size_t)local_rank]->export_index(gids, ref_off, ref_sentence, ref_token);
+    } catch (const std::exception& e) {
+        t->err = e.what();
+        return COLIBRI_ERR_STATE;
     }
     return COLIBRI_OK;
 }

@@ -61,6 +61,7 @@ SHARDED_LIB_PATH = os.path.join(PKG_ROOT, "lib", "libcolibri_sharded.so")
 SHARDED_EXPORTED = [
     "colibri_sharded_unique_id", "colibri_sharded_create", "colibri_sharded_destroy", "colibri_sharded_last_error", "colibri_sharded_upload", "colibri_sharded_upload_split",
     "colibri_sharded_set_protocol", "colibri_sharded_train", "colibri_sharded_kernel_time", "colibri_sharded_result_sizes", "colibri_sharded_export_unindexed",
+    "colibri_sharded_export_gids", "colibri_sharded_index_sizes", "colibri_sharded_export_index",
 ]
 
 
@@ -482,6 +483,9 @@ def load_sharded():
         S.colibri_sharded_kernel_time.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         S.colibri_sharded_result_sizes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         S.colibri_sharded_export_unindexed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        S.colibri_sharded_export_gids.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        S.colibri_sharded_index_sizes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        S.colibri_sharded_export_index.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _shlib = S
     return _shlib
 
@@ -559,6 +563,22 @@ class ShardedTrainer:
         counts = np.zeros(max(1, npat.value), dtype=np.uint32)
         self._check(self.S.colibri_sharded_export_unindexed(self.h, local_rank, key_off.ctypes.data, key_bytes.ctypes.data, counts.ctypes.data))
         return key_off, key_bytes[: kb.value], counts[: npat.value]
+
+    def export_local(self, local_rank):
+        """one local rank's share of an indexed model, as HipShardEngine.export_local gives it: {"patterns": {global number: (key bytes, count)},
+        "index": {global number: [(sentence, token)]}} — colibri_amd.dist.merge_exports over the ranks' shares (in rank order) is the model with its reference lists"""
+        key_off, key_bytes, counts = self.export_arrays(local_rank)
+        gids = np.zeros(max(1, counts.size), dtype=np.uint32)
+        self._check(self.S.colibri_sharded_export_gids(self.h, local_rank, gids.ctypes.data))
+        raw, off = key_bytes.tobytes(), key_off.tolist()
+        patterns = {int(g): (raw[off[j]: off[j + 1]], int(c)) for j, (g, c) in enumerate(zip(gids[: counts.size].tolist(), counts.tolist()))}
+        ng, nr = C.c_uint64(), C.c_uint64()
+        self._check(self.S.colibri_sharded_index_sizes(self.h, local_rank, C.byref(ng), C.byref(nr)))
+        ug, ro = np.zeros(max(1, ng.value), dtype=np.uint32), np.zeros(ng.value + 1, dtype=np.uint64)
+        rs, rt = np.zeros(max(1, nr.value), dtype=np.uint32), np.zeros(max(1, nr.value), dtype=np.uint16)
+        self._check(self.S.colibri_sharded_export_index(self.h, local_rank, ug.ctypes.data, ro.ctypes.data, rs.ctypes.data, rt.ctypes.data))
+        ro, rs, rt = ro.tolist(), rs.tolist(), rt.tolist()
+        return {"patterns": patterns, "index": {int(g): list(zip(rs[ro[j]: ro[j + 1]], rt[ro[j]: ro[j + 1]])) for j, g in enumerate(ug[: ng.value].tolist())}}
 
     def export_dict(self):
         """the union of the local ranks' shares: {key bytes: count} (every pattern is exported by exactly one rank: a duplicate raises)"""

@@ -52,6 +52,15 @@ int colibri_sharded_train(colibri_sharded* t, const colibri_options* opt, colibr
 int colibri_sharded_kernel_time(colibri_sharded* t, int local_rank, int kernel_class, double* total_ms, uint64_t* launches);
 int colibri_sharded_result_sizes(colibri_sharded* t, int local_rank, uint64_t* npatterns, uint64_t* keybytes);
 int colibri_sharded_export_unindexed(colibri_sharded* t, int local_rank, uint64_t* key_off, uint8_t* key_bytes, uint32_t* counts);
+/* indexed models (options.indexed; replaces what IndexedPatternModel keeps per pattern, reference include/patternmodel.h:2789-2800, include/datatypes.h:247-297): the
+ * references stay with the rank that holds their sentences, keyed by the patterns' GLOBAL numbers.
+ *   colibri_sharded_export_gids:  the global number of every pattern this rank exports, in the order of colibri_sharded_export_unindexed (gids[npatterns]);
+ *   colibri_sharded_index_sizes / _export_index: this rank's forward index — gids[ngids] ascending, ref_off[ngids + 1], ref_sentence / ref_token[nrefs], every run in
+ *   corpus order, sentences numbered globally (colibri_sharded_upload's first_sentence).
+ * A pattern's reference list = the runs of its global number on rank 0, 1, ... concatenated: the ranks hold disjoint, ascending sentence ranges, so that is sorted. */
+int colibri_sharded_export_gids(colibri_sharded* t, int local_rank, uint32_t* gids);
+int colibri_sharded_index_sizes(colibri_sharded* t, int local_rank, uint64_t* ngids, uint64_t* nrefs);
+int colibri_sharded_export_index(colibri_sharded* t, int local_rank, uint32_t* gids, uint64_t* ref_off, uint32_t* ref_sentence, uint16_t* ref_token);
 
 #ifdef __cplusplus
 }

@@ -193,3 +193,23 @@ def test_key_sharded_indexed_model_has_the_references_reference_lists(tmp_path, 
     assert (mtype, tokens, types) == (20, want.tokens, want.types)
     assert counts == want.counts
     assert refs == want.refs
+
+
+@pytest.mark.parametrize("protocol", [0, 1])
+@pytest.mark.parametrize("world,name,maxlength,kw", [(2, "zipf20k", 5, dict(indexed=1)), (4, "zipf200k_phrases", 4, dict(indexed=1)), (1, "rand_noempty", 6, dict(indexed=1)),
+                                                     (4, "zipf20k", 4, dict(indexed=1, doskipgrams=1)), (2, "rand3", 5, dict(indexed=1, doskipgrams=1, minskiptypes=1))])
+def test_the_c_face_exports_an_indexed_models_reference_lists(protocol, world, name, maxlength, kw):
+    """include/colibri_sharded.h colibri_sharded_export_gids / _index_sizes / _export_index on the device: every rank's patterns and forward index by global number; the runs
+    of a number concatenated in rank order = the oracle's reference list of that pattern (reference include/patternmodel.h:2789-2800), key-sharded and by candidate exchange"""
+    import oracle
+    from colibri_amd import capi
+    from colibri_amd.dist import merge_exports
+    payload = CORPORA[name]
+    want = oracle.train(payload, 2, maxlength, **{k: (bool(v) if k != "minskiptypes" else v) for k, v in kw.items()})
+    with capi.ShardedTrainer(world, devices=[0] * world) as tr:
+        tr.upload_split(payload)
+        tr.set_protocol(protocol)
+        tr.train(mintokens=2, maxlength=maxlength, **kw)
+        counts, refs = merge_exports([tr.export_local(r) for r in range(world)])
+    assert counts == want.counts
+    assert refs == want.refs

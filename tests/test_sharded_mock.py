@@ -348,7 +348,6 @@ with capi.ShardedTrainer(world, devices=[0] * world) as tr:
     counts, refs = merge_exports([tr.export_local(r) for r in range(world)])
     assert counts == want.counts
     assert refs == want.refs, "reference lists differ"
-    assert st.nrefs == 0 or True
     any_skip = any("skipgram" in k for k in kind)
     assert tr.info.protocol == (1 if (protocol == 1 or any_skip or world not in (1, 2, 4, 8)) else 0), tr.info.protocol
 print("OK")

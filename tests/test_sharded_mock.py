@@ -198,7 +198,7 @@ if mode == "threads":
 else:
     uid = capi.sharded_unique_id()
     shards = shard_payload(payload, world)
-    got, errs, stats = [None] * world, [], [None] * world
+    got, errs, stats, shares = [None] * world, [], [None] * world, [None] * world
     def rank_main(r):
         try:
             with capi.ShardedTrainer(world, nlocal=1, first_rank=r, devices=[r], unique_id=uid) as tr:
@@ -207,6 +207,8 @@ else:
                     stats[r] = tr.train(**kw)
                     assert tr.info.rccl == 1
                     got[r] = tr.export_dict()
+                    if kind.get("indexed"):
+                        shares[r] = tr.export_local(0)
         except Exception as e:
             errs.append((r, repr(e)))
     ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
@@ -222,6 +224,10 @@ else:
         for n in range(1, min(maxlength, 20) + 1):
             assert (st.found[n], st.kept[n]) == (want.stats[n][0], want.stats[n][2]), n
     assert sum(st.npatterns for st in stats) == len(want.counts)
+    if kind.get("indexed"):  # every rank's forward index by global number (sentences numbered from the first_sentence its caller gave): merged in rank order = the oracle's lists
+        from colibri_amd.dist import merge_exports
+        counts, refs = merge_exports(shares)
+        assert counts == want.counts and refs == want.refs
 print("OK")
 """
 

@@ -87,8 +87,16 @@ constexpr int      kBi2HugeCap   = 4096;
 constexpr uint32_t kBi2HeadCode  = 0x80000000u;           // a list entry's code with this bit: a head window, the low 12 bits name the class pair (chain.hpp)
 constexpr int      kBi2BigCap    = 32768;                 // (a 10^9-token corpus counted in 8 key slices: ~7000 per slice)
 
+#ifndef COLIBRI_BI2_CURPAD
+#define COLIBRI_BI2_CURPAD 1
+#endif
+// The emit kernels reserve a run with one returning atomic per (tile or queue, A bin), on the cursor of slot s at curA[s * kBi2CurPad]. Round 6 measured the cursors
+// 64 and 128 bytes apart (order 1's 256 cursors on lines of their own halved uni_onepass_kernel): here it costs — 3.71 -> 3.75 / 3.81 ms per step, the emit kernels
+// 5-13 % slower (four sub-regions already spread a bin's reservations; the clears and the last block's scan of the cursors grow). Kept adjacent.
+constexpr uint32_t kBi2CurPad = COLIBRI_BI2_CURPAD;
+__host__ __device__ __forceinline__ constexpr uint32_t bi2_cur(uint32_t slot) { return slot * kBi2CurPad; }
 struct __attribute__((aligned(16))) Bi2State {
-    uint32_t curA[kBi2MaxSlots];  // emit cursors = records per slot (beyond `region`: overflow)
+    uint32_t curA[kBi2MaxSlots * kBi2CurPad];  // emit cursors = records per slot (beyond `region`: overflow), kBi2CurPad words apart
     uint32_t cntA[kBins];         // records per A bin
     uint32_t offAt[kBins + 1];    // exclusive scan of cntA
     uint32_t found_part[kBins], kept_part[kBins];
@@ -189,7 +197,7 @@ __device__ __forceinline__ void bi2_offsets_tail(Bi2State* __restrict__ bs, uint
     uint32_t s = 0;
     if (threadIdx.x < (uint32_t)kBins) {
         for (uint32_t g = 0; g < nsub; ++g) {
-            const uint32_t h = __hip_atomic_load(&bs->curA[g * kBins + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t h = __hip_atomic_load(&bs->curA[bi2_cur(g * kBins + threadIdx.x)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (h > region) bs->overflow = 1;
             s += min(h, region);
         }
@@ -220,6 +228,8 @@ __device__ __forceinline__ void bi2_offsets_tail(Bi2State* __restrict__ bs, uint
 // grid: a multiple of nsub persistent blocks; head_rows: [gridDim.x][2][kBi2HeadN] (counts, lowest positions).
 // Wide blocks with few items per lane: every phase of a tile is a short chain of LDS operations, and 32 waves per CU hide each other's latencies.
 constexpr int kBi2SurvLds = 2048;  // words of the order-1 survivor bitmap kept in LDS: the first 65 536 classes (> 80 % of a Zipf corpus' tokens)
+// (Round 6 measured a two-part LDS form — 32 768 classes bit by bit + one "whole group survived" bit per 32 of the others, so that hardly any lane reads the bitmap in
+// memory —: 0.55 -> 0.58 ms; the gathers of the rarer classes are not what the kernel waits for.)
 __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kernel(const uint32_t* cls, const uint32_t* __restrict__ surv, uint32_t nsurvwords, uint32_t npos,
                                                                                    uint32_t clsbits, uint32_t sbits, uint32_t slice, uint32_t pb,
                                                                                    unsigned long long* __restrict__ recsA, uint32_t region, uint32_t nsub, Bi2State* __restrict__ bs,
@@ -266,6 +276,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kerne
     };
     load_tile(blockIdx.x);
     __syncthreads();
+    KP_INIT(0);
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t base = tile * kBi2Tile;
         uint32_t       d0[kBi2Per], d1[kBi2Per], ok[kBi2Per];
@@ -286,6 +297,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kerne
         }
         load_tile(tile + gridDim.x);  // the next tile's class ids are in flight while this one is partitioned in LDS
         __syncthreads();
+        KP(0);
         unsigned long long rec[kBi2Per];
         uint32_t           rank[kBi2Per];  // [11:0] rank inside the tile's A bin, [23:16] the A bin; kInvalid: no record
         uint32_t           hrk[kBi2Per];   // head windows (lists wanted): rank among the tile's head windows << 12 | head pair
@@ -318,20 +330,17 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kerne
             if (sid != nullptr && i < npos) sid[i] = (uint8_t)mine;
         }
         __syncthreads();
+        KP(1);
         bi2_scan256(histL, offL, wsumL);
+        // one reservation per (tile, A bin), on the cursor of this block's sub-region — a memory-side atomic (~2 us): its answer is first needed by the copy-out, so it
+        // travels while the records are staged (round 6)
+        uint32_t rs_at = 0, rs_h = 0;
         if (threadIdx.x < kBins) {
-            const uint32_t h = histL[threadIdx.x];
-            uint32_t       g = 0;
-            if (h) {
-                const uint32_t slot = sub * kBins + threadIdx.x;
-                const uint32_t at   = atomicAdd(&bs->curA[slot], h);  // one reservation per (tile, A bin), on the cursor of this block's sub-region
-                if (at + h > region) bs->overflow = 1;
-                g = slot * region + min(at, region - min(region, h));
-            }
-            gbaseL[threadIdx.x] = g;
+            rs_h = histL[threadIdx.x];
+            if (rs_h) rs_at = atomicAdd(&bs->curA[bi2_cur(sub * kBins + threadIdx.x)], rs_h);
         } else if (threadIdx.x == kBins && hplist != nullptr) {  // the tile's head windows: one reservation in the bucket's list (a tile lies inside one bucket, and the list holds
-            const uint32_t h = hcntL, b = base >> hpl.pshift;     // every position of it)
-            hbaseL           = hpl.hbase + (b << hpl.pshift) + (h ? atomicAdd(&bs->pcur[kBi2Shards * kBi2Buckets + b], h) : 0u);
+            rs_h = hcntL;                                         // every position of it)
+            if (rs_h) rs_at = atomicAdd(&bs->pcur[kBi2Shards * kBi2Buckets + (base >> hpl.pshift)], rs_h);
         }
 #pragma unroll
         for (int k = 0; k < kBi2Per; ++k) {
@@ -341,7 +350,20 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kerne
                 binL[p]          = (uint8_t)a;
             }
         }
+        if (threadIdx.x < kBins) {
+            uint32_t g = 0;
+            if (rs_h) {
+                const uint32_t slot = sub * kBins + threadIdx.x;
+                if (rs_at + rs_h > region) bs->overflow = 1;
+                g = slot * region + min(rs_at, region - min(region, rs_h));
+            }
+            gbaseL[threadIdx.x] = g;
+        } else if (threadIdx.x == kBins && hplist != nullptr) {
+            const uint32_t b = base >> hpl.pshift;
+            hbaseL           = hpl.hbase + (b << hpl.pshift) + rs_at;
+        }
         __syncthreads();
+        KP(2);
         if (hplist != nullptr) {
             const uint32_t hb = hbaseL;
 #pragma unroll
@@ -357,6 +379,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kerne
             recsA[(size_t)gbaseL[a] + (j - offL[a])] = stgL[j];
         }
         __syncthreads();
+        KP(3);
     }
     uint32_t* const row = head_rows + (size_t)blockIdx.x * (2 * kBi2HeadN);
     for (int k = threadIdx.x; k < kBi2HeadN; k += kBi2Threads) {
@@ -372,6 +395,8 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kerne
         if (a) atomicAdd(&st->admitted, a);
     }
     bi2_offsets_tail(bs, region, nsub, histL, offL, wsumL, &hcntL);
+    KP(4);
+    KP_DONE();
 }
 
 // The later passes of a sliced order (corpora beyond ~128 M tokens per device): the first pass left every window's key slice in `sid`, so a pass only looks at the
@@ -458,7 +483,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_slice
             uint32_t       gb = 0;
             if (h) {
                 const uint32_t slot = sub * kBins + threadIdx.x;
-                const uint32_t at   = atomicAdd(&bs->curA[slot], h);
+                const uint32_t at   = atomicAdd(&bs->curA[bi2_cur(slot)], h);
                 if (at + h > region) bs->overflow = 1;
                 gb = slot * region + min(at, region - min(region, h));
             }
@@ -496,7 +521,7 @@ __global__ __launch_bounds__(kBlock) void bi2_offsets_kernel(Bi2State* __restric
     if (st->done) return;
     uint32_t s = 0;
     for (uint32_t g = 0; g < nsub; ++g) {
-        const uint32_t h = bs->curA[g * kBins + threadIdx.x];
+        const uint32_t h = bs->curA[bi2_cur(g * kBins + threadIdx.x)];
         if (h > region) bs->overflow = 1;
         s += min(h, region);
     }
@@ -570,7 +595,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2LbPer == 4 ? kBi2Threads / 128 : 1
     __shared__ uint16_t           binL[kBi2LbTile];
     __shared__ uint32_t           histL[kBi2BBins], offL[kBi2BBins], curL[kBi2BBins], gbL[kBi2BBins], wsumL[8];
     const uint32_t  slot = blockIdx.x;
-    const uint32_t  n    = min(bs->curA[slot], region);
+    const uint32_t  n    = min(bs->curA[bi2_cur(slot)], region);
     const uint32_t  bsh  = bs->bshift;
     const uint32_t  bbit = bs->posbits + bs->kbits - 17;  // the B bin = the nine mix bits below the A bin = record bits [bbit + 8 : bbit]
     const size_t    base = slotbase != nullptr ? (size_t)slotbase[slot] : (size_t)slot * region;
@@ -580,7 +605,11 @@ __global__ __launch_bounds__(kBi2Threads, kBi2LbPer == 4 ? kBi2Threads / 128 : 1
     if (CB && cbhist != nullptr)
         for (uint32_t e = threadIdx.x; e < (cmask + 1u) * kBi2BBins; e += kBi2Threads) cbL[e] = 0;
     __syncthreads();
+    KP_INIT(1);
     // sweep 1: histogram of the slot, two tiles of loads ahead of their LDS atomics
+    // (Round 6 measured the sweep on 2-byte copies of the B bins written by the emit kernels beside the records: the sweep fell from 36 % to 12 % of this kernel, but the
+    // move sweep then waits for HBM — the histogram sweep is also what brings the slot into the Infinity Cache — and the emit kernels' extra 32-byte runs cost more than was
+    // left: 3.71 -> 3.75 ms per step. Not kept.)
     for (uint32_t j0 = 0; j0 < n; j0 += 2 * kBi2LbTile) {
         unsigned long long r[2 * kBi2LbPer];
 #pragma unroll
@@ -599,6 +628,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2LbPer == 4 ? kBi2Threads / 128 : 1
         }
     }
     __syncthreads();
+    KP(0);
     if (CB && cbhist != nullptr)
         for (uint32_t e = threadIdx.x; e < (cmask + 1u) * kBi2BBins; e += kBi2Threads) cbhist[(size_t)slot * (8 * kBi2BBins) + e] = cbL[e];
     bi2_scan512(histL, offL, wsumL);
@@ -625,6 +655,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2LbPer == 4 ? kBi2Threads / 128 : 1
         for (int k = 0; k < kBi2LbPer; ++k) x[k] = r[k];
         load_tile(j0 + kBi2LbTile);
         __syncthreads();
+        KP(1);
 #pragma unroll
         for (int k = 0; k < kBi2LbPer; ++k) {
             const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
@@ -635,7 +666,9 @@ __global__ __launch_bounds__(kBi2Threads, kBi2LbPer == 4 ? kBi2Threads / 128 : 1
             }
         }
         __syncthreads();
+        KP(2);
         bi2_scan512(histL, offL, wsumL);
+        KP(3);
         if (threadIdx.x < kBi2BBins) {
             gbL[threadIdx.x] = curL[threadIdx.x];
             curL[threadIdx.x] += histL[threadIdx.x];
@@ -649,13 +682,16 @@ __global__ __launch_bounds__(kBi2Threads, kBi2LbPer == 4 ? kBi2Threads / 128 : 1
             }
         }
         __syncthreads();
+        KP(4);
         const uint32_t m = min(n - j0, (uint32_t)kBi2LbTile);
         for (uint32_t j = threadIdx.x; j < m; j += kBi2Threads) {
             const uint32_t b                     = binL[j];
             recsB[base + gbL[b] + (j - offL[b])] = stgL[j];
         }
         __syncthreads();
+        KP(5);
     }
+    KP_DONE();
 }
 
 // sparse ranges of the final bins: block a, lane b: records of bin (a, b) over all sub-regions, scanned inside the A bin
@@ -1583,20 +1619,29 @@ __global__ __launch_bounds__(kBlock) void bi2_compact_kernel(const uint32_t* __r
 
 // ---- positions: the waves' unsorted lists -> one list per (shard, position bucket) (Bi2Lists: above) ------------------------------------------
 // tile-local counting sort by bucket in LDS, one reserved run per (tile, bucket). The LDS of one tile:
-struct Bi2PospartLds {
-    uint32_t stgL[kBi2Tile], stgC[kBi2Tile];
-    uint16_t binL[kBi2Tile];
+template <int PER>
+struct Bi2PospartLdsT {
+    uint32_t stgL[kBi2Threads * PER], stgC[kBi2Threads * PER];
+    uint16_t binL[kBi2Threads * PER];
     uint32_t histL[kBi2Buckets], offL[kBi2Buckets], gbaseL[kBi2Buckets], wsumL[kBi2Threads / kWave];
 };
+using Bi2PospartLds = Bi2PospartLdsT<kBi2Per>;
+#ifndef COLIBRI_PP_PER
+#define COLIBRI_PP_PER 4
+#endif
+constexpr int kBi2PpPer = COLIBRI_PP_PER;  // entries per lane and tile of bi2_pospart_kernel
 // one tile: every lane brings up to kBi2Per (position, code) entries (position 0xFFFFFFFF: none); every thread of the block calls it
-__device__ __forceinline__ void bi2_pospart_tile(Bi2PospartLds& L, const uint32_t (&p)[kBi2Per], const uint32_t (&code)[kBi2Per], uint32_t shard, Bi2State* __restrict__ bs,
+template <int PER>
+__device__ __forceinline__ void bi2_pospart_tile(Bi2PospartLdsT<PER>& L, const uint32_t (&p)[PER], const uint32_t (&code)[PER], uint32_t shard, Bi2State* __restrict__ bs,
                                                  DevState* __restrict__ st, uint32_t* __restrict__ plist, Bi2Lists pl, uint32_t* __restrict__ pcode) {
     static_assert(kBi2Buckets == kBi2Threads, "one lane per position bucket");
-    uint32_t rank[kBi2Per];
+    uint32_t rank[PER];
+    KP_INIT(3);  // (per call: what lies between two calls — the loads of the next tile — is the kernel's time minus these sections)
     L.histL[threadIdx.x] = 0;
     __syncthreads();
+    KP(0);
 #pragma unroll
-    for (int k = 0; k < kBi2Per; ++k) {
+    for (int k = 0; k < PER; ++k) {
         rank[k] = kInvalid;
         if (p[k] != 0xFFFFFFFFu) {
             const uint32_t b = p[k] >> pl.pshift;
@@ -1604,22 +1649,17 @@ __device__ __forceinline__ void bi2_pospart_tile(Bi2PospartLds& L, const uint32_
         }
     }
     __syncthreads();
+    KP(1);
     uint32_t tot;
     L.offL[threadIdx.x] = bi2_block_scan<kBi2Threads>(L.histL[threadIdx.x], &tot, L.wsumL);
     __syncthreads();  // every bucket's offset is written
-    {
-        const uint32_t h = L.histL[threadIdx.x];
-        uint32_t       g = 0;
-        if (h) {
-            const uint32_t l  = shard * kBi2Buckets + threadIdx.x;
-            const uint32_t at = atomicAdd(&bs->pcur[l], h);
-            if (at + h > pl.pcap) st->radix_overflow = 4;  // (the order's finish kernel has run: the flag goes straight to the run's state)
-            g = l * pl.pcap + min(at, pl.pcap - min(pl.pcap, h));  // (fits 32 bits: shards * buckets * pcap <= 8 * positions)
-        }
-        L.gbaseL[threadIdx.x] = g;
-    }
+    KP(2);
+    // (the reservation's answer is first needed by the copy-out: the memory-side atomic travels while the tile is staged — round 6)
+    const uint32_t rs_h = L.histL[threadIdx.x], rs_l = shard * kBi2Buckets + threadIdx.x;
+    uint32_t       rs_at = 0;
+    if (rs_h) rs_at = atomicAdd(&bs->pcur[rs_l], rs_h);
 #pragma unroll
-    for (int k = 0; k < kBi2Per; ++k) {
+    for (int k = 0; k < PER; ++k) {
         if (rank[k] != kInvalid) {
             const uint32_t b = rank[k] >> 16, q = L.offL[b] + (rank[k] & 0xFFFFu);
             L.stgL[q]        = p[k];
@@ -1627,16 +1667,27 @@ __device__ __forceinline__ void bi2_pospart_tile(Bi2PospartLds& L, const uint32_
             L.binL[q]        = (uint16_t)b;
         }
     }
+    {
+        uint32_t g = 0;
+        if (rs_h) {
+            if (rs_at + rs_h > pl.pcap) st->radix_overflow = 4;  // (the order's finish kernel has run: the flag goes straight to the run's state)
+            g = rs_l * pl.pcap + min(rs_at, pl.pcap - min(pl.pcap, rs_h));  // (fits 32 bits: shards * buckets * pcap <= 8 * positions)
+        }
+        L.gbaseL[threadIdx.x] = g;
+    }
     __syncthreads();
+    KP(3);
     for (uint32_t j = threadIdx.x; j < tot; j += kBi2Threads) {
         const uint32_t b                           = L.binL[j];
         plist[(size_t)L.gbaseL[b] + (j - L.offL[b])] = L.stgL[j];
         if (pcode != nullptr) pcode[(size_t)L.gbaseL[b] + (j - L.offL[b])] = L.stgC[j];
     }
     __syncthreads();
+    KP(4);
+    KP_DONE();
 }
 // the waves' lists: block x takes the lists x, x + gridDim.x, ...
-__global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_pospart_kernel(const uint32_t* __restrict__ wlist, const uint32_t* __restrict__ wcnt, uint32_t nlists, uint32_t wcap,
+__global__ __launch_bounds__(kBi2Threads, kBi2PpPer <= 4 ? kBi2Threads / 128 : 4) void bi2_pospart_kernel(const uint32_t* __restrict__ wlist, const uint32_t* __restrict__ wcnt, uint32_t nlists, uint32_t wcap,
                                                                                       Bi2State* __restrict__ bs, DevState* __restrict__ st, uint32_t* __restrict__ plist, Bi2Lists pl,
                                                                                       const uint32_t* __restrict__ wcode = nullptr, uint32_t* __restrict__ pcode = nullptr,
                                                                                       uint32_t flat_n = 0, bool dense = false) {
@@ -1645,23 +1696,23 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_pospart_ke
     // windows, so the offset look-up is nearly a broadcast here — after the partition it would be a random gather per entry
     // flat_n (key-sharded runs: the positions the owners sent back, one array): wlist holds flat_n entries, cut into nlists pieces of wcap; wcnt is not read
     if (st->done) return;
-    __shared__ Bi2PospartLds L;
+    __shared__ Bi2PospartLdsT<kBi2PpPer> L;
     const uint32_t           shard = blockIdx.x & (uint32_t)(kBi2Shards - 1);
     for (uint32_t w = blockIdx.x; w < nlists; w += gridDim.x) {
         const uint32_t        n   = flat_n ? min(wcap, flat_n - min(flat_n, w * wcap)) : min(wcnt[w], wcap);
         const uint32_t* const src  = wlist + (size_t)w * wcap;
         const uint32_t* const csrc = wcode != nullptr ? wcode + (size_t)w * wcap : nullptr;
-        for (uint32_t j0 = 0; j0 < n; j0 += kBi2Tile) {
-            uint32_t p[kBi2Per], code[kBi2Per];
+        for (uint32_t j0 = 0; j0 < n; j0 += kBi2Threads * kBi2PpPer) {
+            uint32_t p[kBi2PpPer], code[kBi2PpPer];
 #pragma unroll
-            for (int k = 0; k < kBi2Per; ++k) {
+            for (int k = 0; k < kBi2PpPer; ++k) {
                 const uint32_t j = j0 + k * kBi2Threads + threadIdx.x;
                 p[k]             = j < n ? src[j] : 0xFFFFFFFFu;
                 code[k]          = (csrc != nullptr && j < n) ? csrc[j] : 0u;
             }
             if (dense) {
 #pragma unroll
-                for (int k = 0; k < kBi2Per; ++k)
+                for (int k = 0; k < kBi2PpPer; ++k)
                     if (p[k] != 0xFFFFFFFFu) code[k] = bs->binkept[code[k] >> 10] + (code[k] & 1023u);
             }
             bi2_pospart_tile(L, p, code, shard, bs, st, plist, pl, pcode);

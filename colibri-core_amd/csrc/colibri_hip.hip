@@ -786,10 +786,13 @@ uint32_t uni_range_shift(const colibri_ctx* c) {
     return shift > 14 ? 0u : shift;
 }
 // room of a tail bin of the one-pass order 1 (kernels.hpp uni_onepass_kernel): 1.5 x the even share of ALL positions + slack, a multiple of 8 (16-byte loads)
-inline uint32_t uni_bin_cap(uint32_t npos) { return (uint32_t)((((uint64_t)npos / kUniBins) * 3 / 2 + 4096 + 7) & ~7ull); }
+// Round 6: a bin is kUniSub runs (one per block index mod kUniSub) — this is the room of ONE run; the array ends with a tile of slack (a tile that puts more tokens into
+// the last run than the run has room for writes them all, from the run's start: ADVICE r5)
+inline uint32_t uni_bin_cap(uint32_t npos) { return (uint32_t)((((uint64_t)npos / kUniBins / kUniSub) * 3 / 2 + 2048 + 7) & ~7ull); }
+inline size_t   uni_tail_words(uint32_t npos) { return (size_t)kUniBins * kUniSub * uni_bin_cap(npos) + kUni1Tile + 8; }
 int uni_alloc(colibri_ctx* c) {
     int rc;
-    if ((rc = dev_alloc(c, c->unistate, 1)) || (rc = dev_alloc(c, c->uni_tail, (size_t)kUniBins * uni_bin_cap(c->npos) + 8)) || (rc = dev_alloc(c, c->uni_rows, (size_t)kUniHeadGrid * kUniHead)) ||
+    if ((rc = dev_alloc(c, c->unistate, 1)) || (rc = dev_alloc(c, c->uni_tail, uni_tail_words(c->npos))) || (rc = dev_alloc(c, c->uni_rows, (size_t)kUniHeadGrid * kUniHead)) ||
         (rc = dev_alloc(c, c->uni_surv, (size_t)c->maxclass / 32 + 4)))
         return rc;
     return COLIBRI_OK;
@@ -984,7 +987,7 @@ int bigram2_alloc(colibri_ctx* c, uint32_t npos, bool chain = false) {
         (rc = dev_alloc(c, c->b2.bitmap, (size_t)npos / 32 + 24)) || (rc = dev_alloc(c, c->b2.headsurv, kBi2HeadN / 32)))
         return rc;
     if (chain && c->b2.aux == nullptr) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->b2.aux, hipStreamNonBlocking));
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->b2.aux, hipStreamNonBlocking));  // (round 6 measured the highest stream priority here, for the hot bins' kernel: no difference)
         HIP_TRY(c, hipEventCreateWithFlags(&c->b2.ev_fork, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->b2.ev_join, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->b2.ev_fork2, hipEventDisableTiming));
@@ -2165,6 +2168,25 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
                 for (int k = 0; k < 12; ++k) fprintf(stderr, " s%d=%.1f%%", k, t ? 100.0 * (double)h[k] / (double)t : 0.0);
                 fprintf(stderr, " total=%llu\n", t);
                 (void)hipMemcpyToSymbol(HIP_SYMBOL(colibri::bi2_prof), z, sizeof z);
+            }
+        }
+#endif
+#ifdef COLIBRI_KPROF  // (experimental builds only) phase clocks of the block-structured kernels (device_common.hpp): share of each section, summed over blocks and launches of this call
+        {
+            static const char* const names[8] = {"bi2_emit", "levelB", "uni_onepass", "pospart", "chain_emit", "k5", "k6", "k7"};
+            unsigned long long h[8][12], z[8][12];
+            memset(z, 0, sizeof z);
+            if (hipMemcpyFromSymbol(h, HIP_SYMBOL(colibri::kprof), sizeof h) == hipSuccess) {
+                for (int k = 0; k < 8; ++k) {
+                    unsigned long long t = 0;
+                    for (int s = 0; s < 12; ++s) t += h[k][s];
+                    if (!t) continue;
+                    fprintf(stderr, "KPROF %-12s", names[k]);
+                    for (int s = 0; s < 12; ++s)
+                        if (h[k][s]) fprintf(stderr, " s%d=%.1f%%", s, 100.0 * (double)h[k][s] / (double)t);
+                    fprintf(stderr, " total=%.1fM\n", (double)t / 1e6);
+                }
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(colibri::kprof), z, sizeof z);
             }
         }
 #endif

@@ -68,6 +68,43 @@ __device__ __forceinline__ void wave_add64(unsigned long long* counter, unsigned
     if (lane_id() == 0 && v) atomicAdd(counter, v);
 }
 
+// ---- phase clocks (experimental builds only: -DCOLIBRI_KPROF) ---------------------------------------------------------------------------------------------------
+// Where a block-structured kernel spends its time: thread 0 of every block reads the shader clock at the marks (placed behind barriers, so that its view is the block's),
+// sums the differences per section and adds them to kprof[kernel][section] when the block ends; colibri_train prints and clears the table. Product builds: no code.
+#ifdef COLIBRI_KPROF
+__device__ unsigned long long kprof[8][12];
+struct KProf {
+    unsigned long long t, acc[12];
+    int                id;
+    __device__ __forceinline__ explicit KProf(int id_) : id(id_) {
+#pragma unroll
+        for (int s = 0; s < 12; ++s) acc[s] = 0;
+        t = clock64();
+    }
+    __device__ __forceinline__ void mark(int s) {
+        if (threadIdx.x == 0) {
+            const unsigned long long n = clock64();
+            acc[s] += n - t;
+            t = n;
+        }
+    }
+    __device__ __forceinline__ void done() {
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int s = 0; s < 12; ++s)
+                if (acc[s]) atomicAdd(&kprof[id][s], acc[s]);
+        }
+    }
+};
+#define KP_INIT(id) KProf kp_(id)
+#define KP(s) kp_.mark(s)
+#define KP_DONE() kp_.done()
+#else
+#define KP_INIT(id) do {} while (0)
+#define KP(s) do {} while (0)
+#define KP_DONE() do {} while (0)
+#endif
+
 // table index of a 64-bit hash for a capacity that is not a power of two: high 32 bits scaled into [0,cap)
 __device__ __forceinline__ uint32_t slot_of_hash(uint64_t h, uint32_t cap) { return (uint32_t)(((h >> 32) * (uint64_t)cap) >> 32); }
 

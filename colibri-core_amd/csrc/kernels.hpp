@@ -727,11 +727,23 @@ constexpr int kUniTile     = 16384;  // tokens per partition tile
 constexpr int kUniTilePer  = kUniTile / kBlock;
 constexpr int kUniSlices   = 8;      // blocks per tail bin (a bin is streamed by up to 8 blocks)
 constexpr uint32_t kUniSliceMin = 65536;  // ... but a slice is never smaller than this
+#ifndef COLIBRI_UNI_SUB
+#define COLIBRI_UNI_SUB 4
+#endif
+#ifndef COLIBRI_UNI_CURPAD
+#define COLIBRI_UNI_CURPAD 32
+#endif
+// The one-pass form reserves room with one returning atomic per (tile, bin). Atomics are executed memory-side and a LINE of cursors serialises like one cursor
+// (docs/history.md: ~12 ns each): 256 adjacent cursors = 16 lines took 12 207 tiles x 256 reservations — 43 % of the kernel's time by its phase clocks (round 6). Hence
+// kUniSub runs per bin (run = block index mod kUniSub) and every cursor on a line of its own (kUniCurPad words apart).
+constexpr int kUniSub = COLIBRI_UNI_SUB, kUniCurPad = COLIBRI_UNI_CURPAD;
 struct UniState {
     uint32_t hist[kUniBins];     // tail tokens per bin
     uint32_t off[kUniBins + 1];  // exclusive scan
-    uint32_t cur[kUniBins];      // partition cursors (the one-pass form: the bins' sizes)
-    uint32_t overflow;           // the one-pass form: a bin outgrew its room
+    uint32_t cur[kUniBins];      // partition cursors of the two-pass form
+    uint32_t overflow;           // the one-pass form: a run outgrew its room
+    uint32_t pad_[kUniCurPad];
+    uint32_t cur1[kUniBins * kUniSub * kUniCurPad];  // the one-pass form: tokens of run (bin, sub) at [(bin * kUniSub + sub) * kUniCurPad]
 };
 // exclusive scan of 256 LDS values by the first 256 threads of a block of any size (>= 256); every thread of the block must call it
 __device__ __forceinline__ uint32_t bi2_uni_scan256(const uint32_t* inL, uint32_t* outL, uint32_t* wsumL) {
@@ -909,9 +921,9 @@ constexpr int kUni1Threads = 1024, kUni1Per = 8, kUni1Tile = kUni1Threads * kUni
 // HEAD = false: the tail only (no head histogram). Measured and not used: uni_head_kernel<false> on a second stream beside it — 0.48 ms per 10^8 tokens against 0.43
 // fused and 0.45 for round 4's two passes.
 template <bool HEAD>
-__global__ __launch_bounds__(kUni1Threads, kUni1Threads / 128) void uni_onepass_kernel(const uint32_t* __restrict__ cls, uint32_t npos, uint32_t cap,
+__global__ __launch_bounds__(kUni1Threads, kUni1Threads / 128) void uni_onepass_kernel(const uint32_t* __restrict__ cls, uint32_t npos, uint32_t cap /* per run */,
                                                                                         uint32_t* __restrict__ head_rows /*[gridDim.x][kUniHead]*/, UniState* __restrict__ us,
-                                                                                        uint16_t* __restrict__ tail /*[kUniBins][cap]*/, DevState* __restrict__ st) {
+                                                                                        uint16_t* __restrict__ tail /*[kUniBins][kUniSub][cap] (+ one tile of slack) */, DevState* __restrict__ st) {
     if (st->done) return;
     __shared__ uint32_t histL[HEAD ? kUniHead : 1];
     __shared__ uint16_t stageL[kUni1Tile];
@@ -931,6 +943,7 @@ __global__ __launch_bounds__(kUni1Threads, kUni1Threads / 128) void uni_onepass_
     };
     load_tile(blockIdx.x);
     __syncthreads();
+    KP_INIT(2);
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint32_t d[kUni1Per];
 #pragma unroll
@@ -941,6 +954,7 @@ __global__ __launch_bounds__(kUni1Threads, kUni1Threads / 128) void uni_onepass_
         }
         load_tile(tile + gridDim.x);  // the next tile's class ids travel while this one is counted
         __syncthreads();
+        KP(0);
 #pragma unroll
         for (int q = 0; q < kUni1Per; ++q) {
             if (d[q] != 0) {
@@ -953,21 +967,20 @@ __global__ __launch_bounds__(kUni1Threads, kUni1Threads / 128) void uni_onepass_
             }
         }
         __syncthreads();
+        KP(1);
+        // one reservation per (tile, bin), on the cursor of this block's run. The atomic runs memory-side (~2 us): its answer is first needed by the write-out, so it
+        // travels while the tile is staged (round 6: the wait sat before the staging and was a third of the kernel)
+        uint32_t rs_at = 0, rs_h = 0;
+        const uint32_t rs_run = threadIdx.x * (uint32_t)kUniSub + blockIdx.x % (uint32_t)kUniSub;
         {
             const uint32_t tot = bi2_uni_scan256(cntL, offL, wsumL);
             if (threadIdx.x == 0) totL = tot;
             if (threadIdx.x < (uint32_t)kUniBins) {
-                const uint32_t h = cntL[threadIdx.x];
-                uint32_t       g = 0;
-                if (h) {
-                    const uint32_t at = atomicAdd(&us->cur[threadIdx.x], h);  // one reservation per (tile, bin)
-                    if (at + h > cap) us->overflow = 1;
-                    g = threadIdx.x * cap + min(at, cap - min(cap, h));
-                }
-                gbaseL[threadIdx.x] = g;
+                rs_h = cntL[threadIdx.x];
+                if (rs_h) rs_at = atomicAdd(&us->cur1[rs_run * (uint32_t)kUniCurPad], rs_h);
             }
         }
-        __syncthreads();
+        KP(2);
 #pragma unroll
         for (int q = 0; q < kUni1Per; ++q) {
             if (d[q] >= (uint32_t)kUniHead) {
@@ -976,14 +989,25 @@ __global__ __launch_bounds__(kUni1Threads, kUni1Threads / 128) void uni_onepass_
                 sbinL[slot]      = (uint8_t)b;
             }
         }
+        if (threadIdx.x < (uint32_t)kUniBins) {
+            uint32_t g = 0;
+            if (rs_h) {
+                if (rs_at + rs_h > cap) us->overflow = 1;
+                g = rs_run * cap + min(rs_at, cap - min(cap, rs_h));  // (h > cap: the run's h entries reach into the next run's room, or — the last run — into the slack
+            }                                                          // behind the array; the counts are done again with atomics either way)
+            gbaseL[threadIdx.x] = g;
+        }
         __syncthreads();
+        KP(3);
         const uint32_t total = totL;
         for (uint32_t j = threadIdx.x; j < total; j += kUni1Threads) {
             const uint32_t b                          = sbinL[j];
             tail[(size_t)gbaseL[b] + (j - offL[b])] = stageL[j];
         }
         __syncthreads();
+        KP(4);
     }
+    KP_DONE();
     if (!HEAD) return;
     // the block's head histogram leaves as one plain row (flush atomics would run at the memory-side atomic rate)
     for (int k = threadIdx.x; k < kUniHead; k += kUni1Threads) head_rows[(size_t)blockIdx.x * kUniHead + k] = histL[k];
@@ -1001,13 +1025,15 @@ __global__ __launch_bounds__(kBlock) void uni_tail_count1_kernel(const uint16_t*
                                                                   uint32_t* __restrict__ cnt1, uint32_t nclasses, const DevState* __restrict__ st) {
     if (st->done || us->overflow) return;
     extern __shared__ uint32_t uniHistL[];
-    const uint32_t bin = blockIdx.x / kUniSlices, slice = blockIdx.x % kUniSlices;
-    const uint32_t n   = min(us->cur[bin], cap);
+    static_assert(kUniSlices % kUniSub == 0, "a run is read by kUniSlices / kUniSub blocks at most");
+    const uint32_t bin = blockIdx.x / kUniSlices, slice = blockIdx.x % kUniSlices, run = bin * (uint32_t)kUniSub + slice % (uint32_t)kUniSub, piece = slice / (uint32_t)kUniSub;
+    const uint32_t n   = min(us->cur1[run * (uint32_t)kUniCurPad], cap);
     if (n == 0) return;
     uint32_t nsl = (n + kUniSliceMin - 1) / kUniSliceMin;
-    if (nsl > (uint32_t)kUniSlices) nsl = kUniSlices;
-    if (slice >= nsl) return;
-    const uint32_t b0 = bin * cap, per = (n + nsl - 1) / nsl, begin = b0 + slice * per, end = min(b0 + n, begin + per);
+    if (nsl > (uint32_t)(kUniSlices / kUniSub)) nsl = kUniSlices / kUniSub;
+    if (piece >= nsl) return;
+    const uint32_t b0 = run * cap, per = (((n + nsl - 1) / nsl) + 7u) & ~7u, begin = min(b0 + n, b0 + piece * per), end = min(b0 + n, begin + per);
+    if (begin >= end) return;
     const uint32_t width = nrows << 4;
     for (uint32_t k = threadIdx.x; k < width; k += kBlock) uniHistL[k] = 0;
     __syncthreads();

@@ -126,6 +126,7 @@ struct KsPacked {
 // mix bits; what leaves is the record an emit pass over slice `owner` of a 2^w-sliced order would have written, with the position tagged by the source rank:
 //   (mix bits below c) << (pb + w) | source << pb | position      — the owner's kernels see positions of pb + w bits
 struct KsSplit8 {
+    static constexpr uint32_t kCurPad = kBi2CurPad;  // (the slots' record counts are Bi2State::curA: one per line)
     uint32_t w, cbit, pb, src;  // cbit = pb + K - 8 - w: the lowest split bit
     __device__ __forceinline__ uint32_t cbin(unsigned long long r) const { return (uint32_t)(r >> cbit) & ((1u << w) - 1u); }
     __device__ __forceinline__ unsigned long long out(unsigned long long r) const {
@@ -137,6 +138,7 @@ struct KsSplit8 {
 // the split bits are hash bits [55 : 56 - w], and the record leaves with hash bits [63 - w : 48 - w] in its meta word (the owner's A and B digits) and the source
 // rank above the item index
 struct KsSplit16 {
+    static constexpr uint32_t kCurPad = 1;  // (BinState::curA)
     uint32_t w, src;
     __device__ __forceinline__ uint64_t hash(const uint4& r) const { return mix64((uint64_t)r.x | ((uint64_t)r.y << 32)); }
     __device__ __forceinline__ uint32_t cbin(const uint4& r) const { return (uint32_t)(hash(r) >> (56 - w)) & ((1u << w) - 1u); }
@@ -153,7 +155,7 @@ template <class RecT, class Split>
 __global__ __launch_bounds__(kKsThreads) void ks_split_hist_kernel(const RecT* __restrict__ recs, uint32_t region, const uint32_t* __restrict__ slotcnt, Split sp,
                                                                     KsSplitState* __restrict__ ss) {
     __shared__ uint32_t histL[kKsWorld];
-    const uint32_t      slot = blockIdx.x, have = slotcnt[slot], n = min(have, region);
+    const uint32_t      slot = blockIdx.x, have = slotcnt[slot * Split::kCurPad], n = min(have, region);
     if (threadIdx.x < kKsWorld) histL[threadIdx.x] = 0;
     if ((have > region || n >= (1u << 20)) && threadIdx.x == 0) ss->overflow = 1;  // (KsPacked's 16-bit fields hold a wave's sums only below 2^20 records per slot: 489 k at 10^9 tokens)
     __syncthreads();
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(kKsThreads) void ks_split_move_kernel(const RecT* _
                                                                     const KsSplitState* __restrict__ ss, RecT* __restrict__ out) {
     __shared__ KsTileLds<RecT, PER> L;
     constexpr uint32_t              kTile = kKsThreads * PER;
-    const uint32_t                  slot = blockIdx.x, n = min(slotcnt[slot], region), nb = 1u << sp.w;
+    const uint32_t                  slot = blockIdx.x, n = min(slotcnt[slot * Split::kCurPad], region), nb = 1u << sp.w;
     if (threadIdx.x < kKsWorld) {
         L.cur[threadIdx.x] = ss->soff[slot * kKsWorld + threadIdx.x];
         L.lim[threadIdx.x] = 0xFFFFFFFFu;
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(kKsThreads) void ks_split_direct_kernel(const RecT*
                                                                       KsSplitState* __restrict__ ss, RecT* __restrict__ out) {
     __shared__ KsTileLds<RecT, PER> L;
     constexpr uint32_t              kTile = kKsThreads * PER;
-    const uint32_t                  slot = blockIdx.x, have = slotcnt[slot], n = min(have, region), nb = 1u << sp.w;
+    const uint32_t                  slot = blockIdx.x, have = slotcnt[slot * Split::kCurPad], n = min(have, region), nb = 1u << sp.w;
     if (threadIdx.x < kKsWorld) {
         L.cur[threadIdx.x] = (slot * kKsWorld + threadIdx.x) * cap;
         L.lim[threadIdx.x] = (slot * kKsWorld + threadIdx.x + 1) * cap;
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(kKsThreads) void ks_owner_init2_kernel(Bi2State* __
     __syncthreads();
     for (int g = 0; g < kKsWorld; ++g) bi2_scan256(cntL + g * kBins, offL + g * kBins, wsumL);
     for (uint32_t s = threadIdx.x; s < (uint32_t)kKsSlots; s += kKsThreads) {
-        obs->curA[s] = cntL[s];
+        obs->curA[bi2_cur(s)] = cntL[s];
         slotbase[s]  = kb.rbase[s >> 8] + offL[s];
     }
     if (threadIdx.x == 0) {
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(kKsThreads) void ks_local_init2_kernel(Bi2State* __
     for (uint32_t slot = threadIdx.x; slot < (uint32_t)kKsSlots; slot += kKsThreads) {
         const uint32_t sub = slot >> 8, ap = slot & 255u, A = (v << (8 - s)) | (ap >> s), c = ap & ((1u << s) - 1u);
         const uint32_t idx = (sub * kBins + A) * kKsWorld + c;
-        obs->curA[slot]    = fits ? ss->hcnt[idx] : 0u;
+        obs->curA[bi2_cur(slot)]    = fits ? ss->hcnt[idx] : 0u;
         slotbase[slot]     = ss->soff[idx];
     }
     if (threadIdx.x == 0) {

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kKsThreads) void ks2_hist_kernel(const uint32_t* __
         for (uint32_t s = 0; s < nsub; ++s) v += cbhist[(size_t)(s * kBins + a) * (8 * kBi2BBins) + e];
         histL[e] = v;
     }
-    if (threadIdx.x < nsub && bs->curA[threadIdx.x * kBins + a] > region) ks->overflow = 1;
+    if (threadIdx.x < nsub && bs->curA[bi2_cur(threadIdx.x * kBins + a)] > region) ks->overflow = 1;
     __syncthreads();
     // the owner's bin (17 - bsh bits) = (alow, e): A' = its top 8 bits, B' = its low 9 - bsh; this block's bins are W whole rows
     const uint32_t d = a >> (8 - w), alow = a & ((1u << (8 - w)) - 1u);
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kKsThreads) void ks2_move_kernel(const unsigned lon
     // (tried: one wave per (A, B) bin with ballot ranks instead of the LDS atomics — the runs level B leaves per slot are ~50 records: 0.64 ms against 0.47 at order 2)
     (void)boff;
     for (uint32_t s = 0; s < nsub; ++s) {
-        const uint32_t slot = s * kBins + a, n = min(bs->curA[slot], region);
+        const uint32_t slot = s * kBins + a, n = min(bs->curA[bi2_cur(slot)], region);
         const size_t   base = (size_t)slot * region;
         for (uint32_t j0 = 0; j0 < n; j0 += 4 * kKsThreads) {
             unsigned long long r[4];
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kKsThreads) void ks2_move_slot_kernel(const unsigne
     __shared__ uint32_t curL[kKsWorld * kBi2BBins], inL[kBi2BBins], outL[kBi2BBins], wsumL[8];
     const uint32_t      slot = blockIdx.x, s = slot / kBins, a = slot % kBins;
     if (s >= nsub) return;
-    const uint32_t n = min(bs->curA[slot], region);
+    const uint32_t n = min(bs->curA[bi2_cur(slot)], region);
     if (n == 0) return;
     const uint32_t W = 1u << w, bsh = bs->bshift, pb = bs->posbits, lb = 9 - bsh;
     const uint32_t bbit = pb + bs->kbits - 17, cbit = bbit + bsh - w, kmask = (1u << (cbit - pb)) - 1u;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kKsThreads) void ks2_owner_init_kernel(Bi2State* __
     __syncthreads();
     for (int g = 0; g < kKsWorld; ++g) bi2_scan256(cntL + g * kBins, offL + g * kBins, wsumL);
     for (uint32_t s = threadIdx.x; s < (uint32_t)kKsSlots; s += kKsThreads) {
-        obs->curA[s] = cntL[s];
+        obs->curA[bi2_cur(s)] = cntL[s];
         slotbase[s]  = kb.rbase[s >> 8] + offL[s];
     }
     if (threadIdx.x == 0) {

@@ -37,6 +37,38 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+# ---- the big synthetic corpora of the -m gpu suite, generated once per session (and side by side when a test asks for several) ------------------------------------
+# Round 5's suite took 968 s of the driver's 1200: ~25 of its corpora of 2 x 10^7 .. 10^8 tokens were drawn again by every test that used them (10^8 tokens: ~30 s of one
+# host core each). The payloads are kept as read-only uint8 arrays (~2 bytes per token).
+_CORPORA = {}
+
+
+def _draw(spec):
+    from colibri_amd import synth
+    ntok, vocab, seed, phrases = spec
+    return synth.zipf_corpus(ntok, vocab, seed, phrases=phrases, header=False)
+
+
+def zipf_many(specs):
+    """[(ntok, vocab, seed, phrases), ...] -> list of uint8 arrays (v2 payloads without header); the missing ones are drawn in parallel processes"""
+    specs = [tuple(s) + (False,) * (4 - len(s)) for s in specs]
+    missing = [s for s in dict.fromkeys(specs) if s not in _CORPORA]
+    if len(missing) > 1 and sum(s[0] for s in missing) >= 20_000_000:
+        import multiprocessing
+        from concurrent.futures import ProcessPoolExecutor
+        with ProcessPoolExecutor(min(8, len(missing)), mp_context=multiprocessing.get_context("spawn")) as pool:  # (not fork: this process may hold a HIP context)
+            for s, b in zip(missing, pool.map(_draw, missing)):
+                _CORPORA[s] = np.frombuffer(b, dtype=np.uint8)
+    else:
+        for s in missing:
+            _CORPORA[s] = np.frombuffer(_draw(s), dtype=np.uint8)
+    return [_CORPORA[s] for s in specs]
+
+
+def zipf_cached(ntok, vocab, seed, phrases=False):
+    return zipf_many([(ntok, vocab, seed, phrases)])[0]
+
+
 @pytest.fixture(scope="session")
 def hamlet_payload():
     """exp/hamlet.v1.colibri.dat of the reference (a data fixture, copied to tests/golden/) converted v1 -> v2."""

@@ -45,6 +45,9 @@ CASES = {
     "z100m_seed44_indexed": (dict(ntok=100_000_000, vocab=1_000_000, seed=44), "i", []),
     "z100m_seed44_exhaustive_skipgrams": (dict(ntok=100_000_000, vocab=1_000_000, seed=44), "us", []),
     "z375m_seeds44_46_plain": (dict(ntok=125_000_000, vocab=1_000_000, seeds=list(range(44, 47))), "U", []),
+    # round 6: the reference lists at 375 M tokens (IndexedPatternModel::train on the three shards: ~650 M references), so that other_configs.z375m_single_device.indexed
+    # is held to the reference's own forward index, not only to the plain model's (key, count) rows
+    "z375m_seeds44_46_indexed": (dict(ntok=125_000_000, vocab=1_000_000, seeds=list(range(44, 47))), "i", []),
     # the fallback the round-3 review names if the container cannot hold the above: four shards
     "z500m_seeds44_47_plain": (dict(ntok=125_000_000, vocab=1_000_000, seeds=list(range(44, 48))), "U", []),
 }

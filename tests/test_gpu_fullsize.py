@@ -18,7 +18,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, zipf_cached, zipf_many
 
 pytestmark = pytest.mark.gpu
 
@@ -73,7 +73,7 @@ def row_hashes(key_off, key_bytes, extra=None):
 @pytest.fixture(scope="module")
 def models():
     from colibri_amd import capi, synth
-    payload = synth.zipf_corpus(TOKENS, 1_000_000, 44, header=False)
+    payload = zipf_many([(TOKENS, 1_000_000, 44, False), (TOKENS, 1_000_000, 44, True)])[0]  # (the phrase corpus of the test below is drawn beside it)
     out = {}
     with capi.Context(0) as ctx:
         ctx.upload(payload)
@@ -108,7 +108,7 @@ def test_default_mode_is_the_references_model_at_full_size(models):
 def test_phrase_corpus_is_the_references_model_at_full_size():
     """the same size with injected repeated phrases (orders 4 and 5 do real work), against the real reference's model"""
     from colibri_amd import capi, synth
-    payload = synth.zipf_corpus(TOKENS, 1_000_000, 44, phrases=True, header=False)
+    payload = zipf_cached(TOKENS, 1_000_000, 44, phrases=True)
     with capi.Context(0) as ctx:
         ctx.upload(payload)
         st = ctx.train(mintokens=2, maxlength=5)
@@ -167,7 +167,8 @@ def test_default_mode_agrees_on_other_class_spaces(vocab, phrases):
     ranges and no class-keyed order 3; 6 M classes: the atomics order 1; 1 M classes with 15 % of the stream overwritten by a phrase
     inventory: hot n-grams up to order 5 — and must give the global-table model every time (multiset of (key, count) rows)."""
     from colibri_amd import capi, synth
-    payload = synth.zipf_corpus(20_000_000, vocab, 46, phrases=phrases, header=False)
+    payload = zipf_many([(20_000_000, 3_000_000, 46, False), (20_000_000, 6_000_000, 46, False), (20_000_000, 1_000_000, 46, True), (20_000_000, 300_000, 7, True)])[
+        [(3_000_000, False), (6_000_000, False), (1_000_000, True)].index((vocab, phrases))]  # (all four 20 M-token corpora of this file at once)
     got = {}
     with capi.Context(0) as ctx:
         ctx.upload(payload)
@@ -199,7 +200,7 @@ def test_id_keeping_modes_default_kernels_against_the_global_table(kw):
     (bin, rank) -> result index hand-over, radix skipgram passes, packed forward-index sort) against the global-table implementation of the same modes (table_mode = 1:
     device atomics, table skipgram passes): identical models as multisets of (key bytes, count, digest of the whole reference list)."""
     from colibri_amd import capi, synth
-    payload = synth.zipf_corpus(20_000_000, 300_000, 7, phrases=True, header=False)
+    payload = zipf_cached(20_000_000, 300_000, 7, phrases=True)
     out = []
     with capi.Context(0) as ctx:
         ctx.upload(payload)
@@ -224,7 +225,7 @@ def test_id_keeping_modes_are_the_references_models(name, kw):
     model is pinned at MINSKIPTYPES = 1: with the default 2 the reference's loop inserts into the map it iterates (patternmodel.h:2986-2991) and its own output is
     not reproducible (tests/golden/unstable_reference_outputs.json)."""
     from colibri_amd import capi, synth
-    payload = synth.zipf_corpus(20_000_000, 300_000, 7, phrases=True, header=False)
+    payload = zipf_cached(20_000_000, 300_000, 7, phrases=True)
     with capi.Context(0) as ctx:
         ctx.upload(payload)
         st = ctx.train(mintokens=2, maxlength=5, **kw)
@@ -239,7 +240,7 @@ def test_id_keeping_modes_on_the_bench_corpus_are_the_references_models(name, kw
     other_configs.indexed / .exhaustive_skipgrams carry the same check."""
     from colibri_amd import capi, synth
     fx = fixture(name)
-    payload = synth.zipf_corpus(fx["corpus"]["ntok"], fx["corpus"]["vocab"], fx["corpus"]["seed"], header=False)
+    payload = zipf_cached(fx["corpus"]["ntok"], fx["corpus"]["vocab"], fx["corpus"]["seed"])
     with capi.Context(0) as ctx:
         ctx.upload(payload)
         del payload
@@ -254,13 +255,10 @@ def test_one_billion_tokens_is_the_references_model():
     their concatenation (tests/golden/make_fullsize_golden.py z1b_seeds44_51_plain); the fixture holds what it printed per order and the multiset digest of the
     model it wrote. Two product paths must give exactly that model: one context over the whole corpus (key slices), and the multi-GPU trainer with its eight ranks
     on this one device (key-sharded counting; every pattern exported by exactly one rank — the digests of the shares combine)."""
-    import multiprocessing
-    from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
+    from concurrent.futures import ThreadPoolExecutor
     from colibri_amd import capi, digest, synth
     fx = fixture("z1b_seeds44_51_plain")
-    with ProcessPoolExecutor(8, mp_context=multiprocessing.get_context("spawn")) as pool:  # (not fork: this process may hold a HIP context already)
-        jobs = [pool.submit(synth.zipf_corpus, fx["corpus"]["ntok"], fx["corpus"]["vocab"], seed, header=False) for seed in fx["corpus"]["seeds"]]
-        shards = [np.frombuffer(j.result(), dtype=np.uint8) for j in jobs]
+    shards = zipf_many([(fx["corpus"]["ntok"], fx["corpus"]["vocab"], seed) for seed in fx["corpus"]["seeds"]])  # (parallel processes; shared with the 375 M-token cases)
     with capi.Context(0) as ctx:
         ctx.upload(np.concatenate(shards))
         st = ctx.train(mintokens=2, maxlength=5)

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, zipf_many
 
 pytestmark = pytest.mark.gpu
 
@@ -33,7 +33,7 @@ def test_sliced_passes_match_the_oracle(slice_positions, rescan):
 def test_sliced_radix_path_agrees_with_the_table_at_300m_tokens():
     from colibri_amd import capi, synth
     from test_gpu_fullsize import row_hashes, summary
-    payload = np.concatenate([np.frombuffer(synth.zipf_corpus(100_000_000, 1_000_000, 200 + k, header=False), dtype=np.uint8) for k in range(3)])
+    payload = np.concatenate(zipf_many([(100_000_000, 1_000_000, 300 + k) for k in range(3)]))
     got = {}
     with capi.Context(0) as ctx:
         ctx.upload(payload)
@@ -55,7 +55,7 @@ def test_id_keeping_kinds_beyond_128m_tokens_stay_on_the_radix_path(kw):
     (last_mode 2, one pass) and must give the table path's model, reference lists included.
     The reference has one code path at any size (include/patternmodel.h:880-1345, :2789-2800, :2969-3010)."""
     from colibri_amd import capi, digest, synth
-    payload = np.concatenate([np.frombuffer(synth.zipf_corpus(100_000_000, 1_000_000, 300 + k, header=False), dtype=np.uint8) for k in range(3)])
+    payload = np.concatenate(zipf_many([(100_000_000, 1_000_000, 300 + k) for k in range(3)]))
     got = {}
     with capi.Context(0) as ctx:
         ctx.upload(payload)
@@ -76,7 +76,7 @@ def test_plain_run_of_200m_tokens_is_one_chained_pass():
     the table path's."""
     from colibri_amd import capi, synth
     from test_gpu_fullsize import row_hashes, summary
-    payload = np.concatenate([np.frombuffer(synth.zipf_corpus(100_000_000, 1_000_000, 300 + k, header=False), dtype=np.uint8) for k in range(2)])
+    payload = np.concatenate(zipf_many([(100_000_000, 1_000_000, 300 + k) for k in range(3)])[:2])
     got = {}
     with capi.Context(0) as ctx:
         ctx.upload(payload)

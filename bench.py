@@ -295,8 +295,9 @@ def measured_traffic(workload_tokens, kernel):
     try:
         with open(path) as f:
             d = json.load(f)
-        if int(d.get("tokens", 0)) == int(workload_tokens) and d.get("kernel") == kernel:
-            return d.get("hbm_bytes_per_launch"), d.get("source", "profiles/pmc_dominant_kernel.json")
+        from colibri_amd import digest
+        if int(d.get("tokens", 0)) == int(workload_tokens) and d.get("kernel") == kernel and d.get("csrc_sha256") == digest.source_digest(ROOT):
+            return d.get("hbm_bytes_per_launch"), d.get("source", "profiles/pmc_dominant_kernel.json")  # (the passes were taken from THIS source tree's library)
     except Exception:
         pass
     return None, None
@@ -522,6 +523,22 @@ def main():
     if fixture is not None:
         check_ok = check_against_reference(fixture, kept, npatterns, arrays)
     del arrays
+    # what a caller of an idle context pays for one model: upload (device to device here: the payload is resident) + tokenise + train + the result sizes, as ONE timed call
+    # sequence; and the upload + tokenise alone on the warm context (the first upload of a context also allocates ~1 GB of corpus arrays: tokenise_ms_first_upload_untimed)
+    tokenise_warm_ms = cold_step_ms = None
+    if ctx is not None:
+        opt_plain = capi.Options.defaults(mintokens=MINTOKENS, maxlength=MAXLENGTH, profile=0)
+        best_u, best_c = 1e9, 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ctx.upload_device(dev_payload.data_ptr(), payloads[0].size, 1)
+            t2 = time.perf_counter()
+            ctx.train(opt_plain)
+            ctx.result_sizes()
+            t3 = time.perf_counter()
+            best_u, best_c = min(best_u, (t2 - t1) * 1e3), min(best_c, (t3 - t1) * 1e3)
+        tokenise_warm_ms, cold_step_ms = best_u, best_c
     traffic, traffic_src = measured_traffic(args.tokens, "bi2_count_kernel" if second else "bin_count_kernel" if binned else "count_kernel") if not sharded else (None, None)
     out = {
         "metric": "M patterns counted/sec at n<=5 thr=2; identical pattern set vs reference",
@@ -551,7 +568,11 @@ def main():
                 f"sentence-sharded x{args.gpus}, " + ("candidate exchange" if (info is not None and info.protocol == 1) else
                                                       "key-sharded counting: all-reduce of the dense class counts (order 1), records to the owner of their key (orders >= 2)")
                 + (", RCCL" if (info is not None and info.rccl) else ", device copies between contexts") + (", one process per rank" if per_process else ", one host thread per rank")),
-            "tokenise_ms_untimed": round(tokenise_ms, 3),
+            "tokenise_ms_untimed": round(tokenise_warm_ms if tokenise_warm_ms is not None else tokenise_ms, 3),
+            "tokenise_ms_first_upload_untimed": round(tokenise_ms, 3),
+            "cold_step_ms": round(cold_step_ms, 3) if cold_step_ms is not None else None,
+            "cold_step_is": "upload (payload resident in HBM) + tokenise + train + result sizes of one model on an idle context, best of 3; tokenise_ms_untimed: the upload + tokenise "
+                            "of it; tokenise_ms_first_upload_untimed: a fresh context's first upload, which also allocates the corpus arrays",
             "corpus_generation_s_untimed": round(gen_s, 2),
         },
         "roofline": {

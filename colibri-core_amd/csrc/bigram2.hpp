@@ -181,6 +181,18 @@ __device__ __forceinline__ uint32_t bi2_block_scan(uint32_t v, uint32_t* total, 
     return base + incl - v;
 }
 
+// the B-bin shift for `tot` records of an order (one thread; bi2_offsets_tail and bi2_offsets_kernel)
+__device__ __forceinline__ void bi2_set_bshift(Bi2State* __restrict__ bs, uint32_t tot) {
+    // aim at <= ~700 records per final bin; at least 8 B bins (the 31-bit in-bin key needs three mix bits fixed by the B bin)
+    uint32_t nb = 8;
+    while (nb < (uint32_t)kBi2BBins && (uint64_t)nb * kBins * kBi2BinTarget < tot) nb <<= 1;
+    uint32_t sh = 0;
+    while ((uint32_t)kBi2BBins >> sh > nb) ++sh;
+    // the 31-bit in-bin key must hold every mix bit the bin does not fix: kbits - 17 + bshift <= 31
+    const uint32_t K = bs->kbits;
+    if (sh + K > 48u) sh = K >= 48u ? 0u : 48u - K;
+    bs->bshift = bs->bshift_fix ? bs->bshift_fix - 1u : sh;
+}
 // ---- records per A bin, their scan, the B-bin shift for this record count: the last block of an emit kernel to finish does it ---------------------------------------
 // (round 5; bi2_offsets_kernel — one block after the emit kernel — cost a launch per order and per skipgram pass.) Every block of the emit kernel calls this as its
 // last statement with three LDS arrays it no longer needs (histL, offL: kBins words; wsumL: 4) and a flag word. The cursors were advanced by device-scope atomics of
@@ -194,6 +206,10 @@ __device__ __forceinline__ void bi2_offsets_tail(Bi2State* __restrict__ bs, uint
     if (threadIdx.x == 0) *flagL = (atomicAdd(&bs->emit_done, 1u) + 1u == gridDim.x) ? 1u : 0u;
     __syncthreads();
     if (*flagL == 0u) return;
+    //  the last block only: an acquire fence at agent scope before it reads what the other blocks' atomics left — this CU's caches are invalidated once, no
+    // cache is written back. The other side needs no release: the cursors are written by device-scope atomics alone, each performed at the memory side before its value
+    // came back to the block that then drew its ticket. (A release in every block is what cost 0.13-0.3 ms per launch.)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     uint32_t s = 0;
     if (threadIdx.x < (uint32_t)kBins) {
         for (uint32_t g = 0; g < nsub; ++g) {
@@ -212,15 +228,7 @@ __device__ __forceinline__ void bi2_offsets_tail(Bi2State* __restrict__ bs, uint
     if (threadIdx.x == 0) {
         bs->offAt[kBins] = tot;
         bs->nrec         = tot;
-        // aim at <= ~700 records per final bin; at least 8 B bins (the 31-bit in-bin key needs three mix bits fixed by the B bin)
-        uint32_t nb = 8;
-        while (nb < (uint32_t)kBi2BBins && (uint64_t)nb * kBins * kBi2BinTarget < tot) nb <<= 1;
-        uint32_t sh = 0;
-        while ((uint32_t)kBi2BBins >> sh > nb) ++sh;
-        // the 31-bit in-bin key must hold every mix bit the bin does not fix: kbits - 17 + bshift <= 31
-        const uint32_t K = bs->kbits;
-        if (sh + K > 48u) sh = K >= 48u ? 0u : 48u - K;
-        bs->bshift = bs->bshift_fix ? bs->bshift_fix - 1u : sh;
+        bi2_set_bshift(bs, tot);
     }
 }
 
@@ -532,15 +540,7 @@ __global__ __launch_bounds__(kBlock) void bi2_offsets_kernel(Bi2State* __restric
     if (threadIdx.x == 0) {
         bs->offAt[kBins] = tot;
         bs->nrec         = tot;
-        // aim at <= ~700 records per final bin; at least 8 B bins (the 31-bit in-bin key needs three mix bits fixed by the B bin)
-        uint32_t nb = 8;
-        while (nb < (uint32_t)kBi2BBins && (uint64_t)nb * kBins * kBi2BinTarget < tot) nb <<= 1;
-        uint32_t sh = 0;
-        while ((uint32_t)kBi2BBins >> sh > nb) ++sh;
-        // the 31-bit in-bin key must hold every mix bit the bin does not fix: kbits - 17 + bshift <= 31
-        const uint32_t K = bs->kbits;
-        if (sh + K > 48u) sh = K >= 48u ? 0u : 48u - K;
-        bs->bshift = bs->bshift_fix ? bs->bshift_fix - 1u : sh;
+        bi2_set_bshift(bs, tot);
     }
 }
 

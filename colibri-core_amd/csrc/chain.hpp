@@ -43,12 +43,16 @@ constexpr uint32_t kChLists = kBi2Shards + 1;  // lists per bucket: the eight sh
 __device__ __forceinline__ bool chain_head_alive(uint32_t code, const uint32_t* __restrict__ headid) { return headid[code & 0xFFFu] != kInvalid; }
 
 // ---- one launch clears what an order starts from: its Bi2State and the position lists' counts (two fills of ~5 us each before) ----------------------------------------
-__global__ __launch_bounds__(kBlock) void chain_reset_kernel(Bi2State* __restrict__ bs, uint32_t* __restrict__ wcnt, uint32_t nwcnt) {
+// thread t of `step` threads clears its share of an order's state and of the lists' counts (chain_reset_kernel, and chain_begin_kernel's clearing blocks)
+__device__ __forceinline__ void chain_clear_state(Bi2State* __restrict__ bs, uint32_t* __restrict__ wcnt, uint32_t nwcnt, uint32_t t, uint32_t step) {
     static_assert(sizeof(Bi2State) % 16 == 0, "cleared with 16-byte stores");
     uint4* const   p = reinterpret_cast<uint4*>(bs);
-    const uint32_t n = (uint32_t)(sizeof(Bi2State) / 16), t = blockIdx.x * kBlock + threadIdx.x, step = gridDim.x * kBlock;
+    const uint32_t n = (uint32_t)(sizeof(Bi2State) / 16);
     for (uint32_t i = t; i < n; i += step) p[i] = make_uint4(0u, 0u, 0u, 0u);
     for (uint32_t i = t; i < nwcnt; i += step) wcnt[i] = 0u;
+}
+__global__ __launch_bounds__(kBlock) void chain_reset_kernel(Bi2State* __restrict__ bs, uint32_t* __restrict__ wcnt, uint32_t nwcnt) {
+    chain_clear_state(bs, wcnt, nwcnt, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock);
 }
 
 // ---- bitmap: per position bucket, the listed positions -> one bit each; st->valid += set bits ---------------------------------------------------------------------------
@@ -245,14 +249,11 @@ __device__ __forceinline__ bool chain_key_bits(const Bi2State* __restrict__ prev
 // class ids). Now the buckets are dealt to the XCDs (bucket mod 8), an XCD's steps — pieces of kChStep pairs of its lists, bucket by bucket — are numbered by
 // chain_steps_kernel, and the XCD's blocks take them round-robin: at any time an XCD works on ~3 adjacent buckets, whose windows stay in its L2.
 constexpr uint32_t kChXcds = 8;
-// table: [kChXcds][cap] entries {index of the step's first pair in plist / pcode, pairs of the step}; nsteps: [kChXcds]
-__global__ __launch_bounds__(kBi2Threads) void chain_steps_kernel(const Bi2State* __restrict__ prev, Bi2Lists pl, uint32_t nbuckets, uint2* __restrict__ table, uint32_t cap,
-                                                                   uint32_t* __restrict__ nsteps, const DevState* __restrict__ st) {
-    if (st->done) return;
-    __shared__ uint32_t wsumL[kBi2Threads / kWave];
-    constexpr uint32_t  kPer = (kBi2Buckets / kChXcds * kChLists + kBi2Threads - 1) / kBi2Threads;  // lists of an XCD per lane (2), in (bucket, shard) order
-    const uint32_t      x = blockIdx.x;
-    uint32_t            first[kPer], n[kPer], ns[kPer], sum = 0;
+// the step table of XCD x (block-wide: every thread of a kBi2Threads block calls it): the XCD's lists in (bucket, shard) order, cut into pieces of kChStep pairs
+__device__ __forceinline__ void chain_number_steps(const Bi2State* __restrict__ prev, const Bi2Lists& pl, uint32_t nbuckets, uint2* __restrict__ table, uint32_t cap,
+                                                   uint32_t* __restrict__ nsteps, uint32_t x, uint32_t* wsumL) {
+    constexpr uint32_t kPer = (kBi2Buckets / kChXcds * kChLists + kBi2Threads - 1) / kBi2Threads;  // lists of an XCD per lane (2), in (bucket, shard) order
+    uint32_t           first[kPer], n[kPer], ns[kPer], sum = 0;
 #pragma unroll
     for (uint32_t q = 0; q < kPer; ++q) {
         const uint32_t idx = threadIdx.x * kPer + q, bucket = x + kChXcds * (idx / kChLists), shard = idx % kChLists;
@@ -273,6 +274,13 @@ __global__ __launch_bounds__(kBi2Threads) void chain_steps_kernel(const Bi2State
             if (base < cap) table[(size_t)x * cap + base] = make_uint2(first[q] + k * (uint32_t)kChStep, min((uint32_t)kChStep, n[q] - k * (uint32_t)kChStep));
     if (threadIdx.x == 0) nsteps[x] = min(total, cap);
 }
+// table: [kChXcds][cap] entries {index of the step's first pair in plist / pcode, pairs of the step}; nsteps: [kChXcds]
+__global__ __launch_bounds__(kBi2Threads) void chain_steps_kernel(const Bi2State* __restrict__ prev, Bi2Lists pl, uint32_t nbuckets, uint2* __restrict__ table, uint32_t cap,
+                                                                   uint32_t* __restrict__ nsteps, const DevState* __restrict__ st) {
+    if (st->done) return;
+    __shared__ uint32_t wsumL[kBi2Threads / kWave];
+    chain_number_steps(prev, pl, nbuckets, table, cap, nsteps, blockIdx.x, wsumL);
+}
 // chain_reset_kernel and chain_steps_kernel in ONE launch (what an order starts with; they touch different states — the new order's, and the lists of the one before):
 // blocks 0 .. 7 number the XCDs' steps, the others clear. grid kChXcds + kChResetBlocks, kBi2Threads threads.
 constexpr uint32_t kChResetBlocks = 64;
@@ -280,36 +288,12 @@ __global__ __launch_bounds__(kBi2Threads) void chain_begin_kernel(const Bi2State
                                                                    uint32_t* __restrict__ nsteps, const DevState* __restrict__ st, Bi2State* __restrict__ bs, uint32_t* __restrict__ wcnt,
                                                                    uint32_t nwcnt) {
     if (blockIdx.x >= kChXcds) {  // (cleared whether or not the run has ended, as chain_reset_kernel does)
-        uint4* const   p = reinterpret_cast<uint4*>(bs);
-        const uint32_t n = (uint32_t)(sizeof(Bi2State) / 16), t = (blockIdx.x - kChXcds) * kBi2Threads + threadIdx.x, step = (gridDim.x - kChXcds) * kBi2Threads;
-        for (uint32_t i = t; i < n; i += step) p[i] = make_uint4(0u, 0u, 0u, 0u);
-        for (uint32_t i = t; i < nwcnt; i += step) wcnt[i] = 0u;
+        chain_clear_state(bs, wcnt, nwcnt, (blockIdx.x - kChXcds) * kBi2Threads + threadIdx.x, (gridDim.x - kChXcds) * kBi2Threads);
         return;
     }
     if (st->done) return;
     __shared__ uint32_t wsumL[kBi2Threads / kWave];
-    constexpr uint32_t  kPer = (kBi2Buckets / kChXcds * kChLists + kBi2Threads - 1) / kBi2Threads;
-    const uint32_t      x = blockIdx.x;
-    uint32_t            first[kPer], n[kPer], ns[kPer], sum = 0;
-#pragma unroll
-    for (uint32_t q = 0; q < kPer; ++q) {
-        const uint32_t idx = threadIdx.x * kPer + q, bucket = x + kChXcds * (idx / kChLists), shard = idx % kChLists;
-        uint32_t       lcap = 0;
-        first[q] = n[q] = 0;
-        if (bucket < nbuckets) {
-            bi2_list_of(pl, shard, bucket, first[q], lcap);
-            n[q] = min(prev->pcur[shard * kBi2Buckets + bucket], lcap);
-        }
-        ns[q] = (n[q] + kChStep - 1) / kChStep;
-        sum += ns[q];
-    }
-    uint32_t total;
-    uint32_t base = bi2_block_scan<kBi2Threads>(sum, &total, wsumL);
-#pragma unroll
-    for (uint32_t q = 0; q < kPer; ++q)
-        for (uint32_t k = 0; k < ns[q]; ++k, ++base)
-            if (base < cap) table[(size_t)x * cap + base] = make_uint2(first[q] + k * (uint32_t)kChStep, min((uint32_t)kChStep, n[q] - k * (uint32_t)kChStep));
-    if (threadIdx.x == 0) nsteps[x] = min(total, cap);
+    chain_number_steps(prev, pl, nbuckets, table, cap, nsteps, blockIdx.x, wsumL);
 }
 // (steps of an XCD at most: every list of its buckets filled + one partial step each)
 inline uint32_t chain_steps_cap(const Bi2Lists& pl) { return (kBi2Buckets / kChXcds) * (kBi2Shards * (pl.pcap / kChStep + 1) + ((1u << pl.pshift) / kChStep + 1)); }

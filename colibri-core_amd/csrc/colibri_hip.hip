@@ -62,6 +62,11 @@ struct colibri_ctx {
     DevBuf<uint32_t>  tokstart;
     DevBuf<uint32_t>  delimpos;
     DevBuf<uint32_t>  cls;              // class id per position (0 = delimiter)
+    // the tokeniser's scratch, kept between uploads: five hipMalloc / hipFree pairs per upload were most of what a caller waited for beside the ~2 ms of kernels
+    // (bench.py tokenise_ms_untimed, round 5: 11.6 ms)
+    DevBuf<uint32_t>  tk_blockcnt, tk_total, tk_dcnt;
+    DevBuf<CorpusInfo> tk_info;
+    DevBuf<unsigned long long> tk_hist;
     DevBuf<PosBlock>  pos_blocks;       // per 64 positions: sentences before, start of the running sentence, delimiter bits (built at the first indexed run on a corpus)
     bool              pos_blocks_valid = false;
     DevBuf<uint32_t>  cnt1, rep1;       // order-1 fast path: count / representative position per class
@@ -165,6 +170,7 @@ struct colibri_ctx {
     int               last_mode = 0;    // 1 = global table, 2 = binned (what the last train() actually ran)
     int               profile_class = COLIBRI_K_COUNT;  // profile = 2: the one kernel class that is bracketed with events
     int               last_passes = 1;  // passes over key slices of the order-2 stage of that run
+    int32_t           run_path = 0, run_fallback = 0, run_retries = 0;  // colibri_stats.path / fallback_reason / retries of the colibri_train call in progress
     struct Segment {
         uint32_t first, count;
         int      n;
@@ -353,9 +359,9 @@ int tokenise(colibri_ctx* c) {
     const uint64_t B = c->nbytes;
     // upper bound of positions = bytes; sized exactly after the count pass
     const uint32_t   nblk = std::max<uint32_t>(1, blocks_for(B, kTokBytesPerBlock));
-    ScopedBuf<uint32_t> blockcnt, total, dcnt;  // (freed on every way out)
-    ScopedBuf<CorpusInfo> info;
-    ScopedBuf<unsigned long long> hist;
+    DevBuf<uint32_t>&           blockcnt = c->tk_blockcnt, &total = c->tk_total, &dcnt = c->tk_dcnt;  // (the context's: grown, never freed between uploads)
+    DevBuf<CorpusInfo>&         info     = c->tk_info;
+    DevBuf<unsigned long long>& hist     = c->tk_hist;
     int rc;
     if ((rc = dev_alloc(c, blockcnt, nblk + 1))) return rc;
     if ((rc = dev_alloc(c, total, 1))) return rc;
@@ -527,6 +533,11 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->delimpos);
     dev_free(c->pos_blocks);
     dev_free(c->cls);
+    dev_free(c->tk_blockcnt);
+    dev_free(c->tk_total);
+    dev_free(c->tk_dcnt);
+    dev_free(c->tk_info);
+    dev_free(c->tk_hist);
     dev_free(c->cnt1);
     dev_free(c->rep1);
     dev_free(c->unistate);
@@ -2154,8 +2165,22 @@ int train_pattern_list(colibri_ctx* c, const colibri_options& o, colibri_stats* 
 }  // namespace
 
 static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, colibri_stats* stats_out);
+// a run is about to be repeated (exactly) on another engine or with more room: what colibri_stats.fallback_reason / retries report
+static inline void note_retry(colibri_ctx* c, int reason) {
+    if (c->run_retries++ == 0) c->run_fallback = reason;
+}
 extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, colibri_stats* stats_out) {
     if (!c || !opt_in) return COLIBRI_ERR_ARG;
+    c->run_path = c->run_fallback = c->run_retries = 0;
+    auto report = [&](int rc_) {
+        if (stats_out && rc_ == COLIBRI_OK) {
+            stats_out->path            = c->run_path;
+            stats_out->fallback_reason = c->run_fallback;
+            stats_out->retries         = c->run_retries;
+            stats_out->reserved_       = 0;
+        }
+        return rc_;
+    };
     for (;;) {
         const int rc = colibri_train_once(c, opt_in, stats_out);
 #ifdef BI2_PROF  // (experimental builds only) where bi2_count_kernel's waves spent their cycles: sections of process_bin, summed over waves and launches of this call
@@ -2196,8 +2221,9 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
         const uint64_t bound = (uint64_t)std::max(1, std::min<int>(opt_in->maxlength, COLIBRI_MAX_ORDER - 1)) * ((uint64_t)c->npos + 1) * per_window;
         if (rc != COLIBRI_ERR_OVERFLOW || !c->hstate.overflow || c->res_cap_used >= std::min<uint64_t>(0x7FFFFFF0ull, bound)) {
             c->res_scale = 1;
-            return rc;
+            return report(rc);
         }
+        note_retry(c, COLIBRI_FALLBACK_RESULTS);
         c->res_scale *= 4;
     }
 }
@@ -2415,6 +2441,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
         if ((rc = chain_compact_join(c)) || (rc = read_state(c))) return rc;
         if (binned && c->hstate.radix_overflow == 8 && !c->split_exact) {  // a run of the direct split of a sliced order outgrew its room (keys far from uniform): the exact split
             c->split_exact = true;  // (for this corpus: reset by the next upload)
+            note_retry(c, COLIBRI_FALLBACK_SPLIT);
             return colibri_train_once(c, &o, stats_out);
         }
         if (binned && c->hstate.radix_overflow == 16) {  // an order >= 3 did not fit the second-generation engine (key bits, a region, a bin): those orders on the first-generation kernels
@@ -2427,11 +2454,13 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                         c->hstate.pad[0] >> 24);
             }
             c->b2.chain_disabled = true;
+            note_retry(c, COLIBRI_FALLBACK_CHAIN);
             const int rc2        = colibri_train_once(c, &o, stats_out);
             c->b2.chain_disabled = false;
             return rc2;
         }
         if (binned && c->hstate.radix_overflow == 4) {  // the second-generation order 2 could not hold this corpus (a hot bigram outside the dense head): first-generation kernels
+            note_retry(c, COLIBRI_FALLBACK_ORDER2);
             if (getenv("COLIBRI_DEBUG_OVERFLOW")) {  // (which part of it gave up: 1 a record region, 2 a final bin's table, 3 a position list; 0: the position buckets or a split)
                 uint32_t why = 0;
                 (void)hipMemcpy(&why, &c->b2.state.p->overflow, sizeof why, hipMemcpyDeviceToHost);
@@ -2456,10 +2485,14 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                             (unsigned long long)(c->recs[0].n / kASlots), npos);
             colibri_options again = o;
             again.table_mode      = 1;
+            note_retry(c, (int)c->hstate.radix_overflow <= 3 ? (int)c->hstate.radix_overflow : COLIBRI_FALLBACK_BIN);
             return colibri_train_once(c, &again, stats_out);
         }
         c->last_mode   = binned ? 2 : 1;
         c->last_passes = bi2 ? (1 << bigram2_plan(c, npos).sbits) : 1;
+        c->run_path    = !binned ? COLIBRI_PATH_TABLE
+                                 : (COLIBRI_PATH_RADIX | (bi2 ? COLIBRI_PATH_BI2 : 0) | (chain ? COLIBRI_PATH_CHAIN : 0) | ((chain && chain_wide(npos)) ? COLIBRI_PATH_WIDE : 0) |
+                                    ((c->last_passes > 1 || big) ? COLIBRI_PATH_SLICED : 0));
         s.maxn = (int32_t)c->hstate.maxn;
         for (int n = 1; n < COLIBRI_MAX_ORDER; ++n) {
             s.found[n]    = c->hstate.s_found[n];
@@ -2630,12 +2663,14 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             if (nlogged) HIP_TRY(c, hipMemcpyAsync(log.data(), c->seglog.p, sizeof(uint32_t) * log.size(), hipMemcpyDeviceToHost, c->stream));
             if ((rc = chain_compact_join(c)) || (rc = read_state(c))) return rc;
             if (c->hstate.radix_overflow == 16) {  // an order >= 3 did not fit the chained engine (key bits, a region, a bin): the run again with round 3's orders >= 3
+                note_retry(c, COLIBRI_FALLBACK_CHAIN);
                 c->b2.chain_disabled = true;
                 const int rc2        = colibri_train_once(c, &o, stats_out);
                 c->b2.chain_disabled = false;
                 return rc2;
             }
             if (c->hstate.radix_overflow == 4) {  // the second-generation order 2 could not hold this corpus: again, on the first-generation kernels
+                note_retry(c, COLIBRI_FALLBACK_ORDER2);
                 if (retry_with_small_passes(npos)) {  // (a corpus beyond the old pass size: its bins get the old load back before anything slower is tried)
                     tl_small_passes = true;
                     const int rc2   = colibri_train_once(c, &o, stats_out);
@@ -2650,6 +2685,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             if (c->hstate.radix_overflow) {  // a bin outgrew its LDS table: the whole run again on the table path (loud, exact, rare)
                 colibri_options again = o;
                 again.table_mode      = 1;
+                note_retry(c, (c->hstate.radix_overflow >= 1 && c->hstate.radix_overflow <= 3) ? (int)c->hstate.radix_overflow : COLIBRI_FALLBACK_BIN);
                 return colibri_train_once(c, &again, stats_out);
             }
             s.maxn = (int32_t)c->hstate.maxn;
@@ -2854,6 +2890,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             }
             if ((rc = read_state(c))) return rc;
             if (bi2_synced && c->hstate.radix_overflow == 4) {  // the second-generation order 2 could not hold this corpus: again, on the first-generation kernels
+                note_retry(c, COLIBRI_FALLBACK_ORDER2);
                 if (retry_with_small_passes(npos)) {  // (a corpus beyond the old pass size: its bins get the old load back before anything slower is tried)
                     tl_small_passes = true;
                     const int rc2   = colibri_train_once(c, &o, stats_out);
@@ -2868,6 +2905,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             if ((radix_synced || radix_constrained) && c->hstate.radix_overflow) {  // a bin outgrew its LDS table: the whole run again on the table path (loud, exact, rare)
                 colibri_options again = o;
                 again.table_mode      = 1;
+                note_retry(c, (c->hstate.radix_overflow >= 1 && c->hstate.radix_overflow <= 3) ? (int)c->hstate.radix_overflow : COLIBRI_FALLBACK_BIN);
                 return colibri_train_once(c, &again, stats_out);
             }
             const uint32_t found = c->hstate.found, kept = c->hstate.kept;
@@ -2896,6 +2934,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                     if (rc == kRerunOnTable) {
                         colibri_options again = o;
                         again.table_mode      = 1;
+                        note_retry(c, (c->hstate.radix_overflow >= 1 && c->hstate.radix_overflow <= 3) ? (int)c->hstate.radix_overflow : COLIBRI_FALLBACK_BIN);
                         return colibri_train_once(c, &again, stats_out);
                     }
                     if (rc) return rc;
@@ -2931,6 +2970,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                     if (rc == kRerunOnTable) {
                         colibri_options again = o;
                         again.table_mode      = 1;
+                        note_retry(c, (c->hstate.radix_overflow >= 1 && c->hstate.radix_overflow <= 3) ? (int)c->hstate.radix_overflow : COLIBRI_FALLBACK_BIN);
                         return colibri_train_once(c, &again, stats_out);
                     }
                     if (rc) return rc;
@@ -2948,6 +2988,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                     if (c->hstate.radix_overflow) {
                         colibri_options again = o;
                         again.table_mode      = 1;
+                        note_retry(c, (c->hstate.radix_overflow >= 1 && c->hstate.radix_overflow <= 3) ? (int)c->hstate.radix_overflow : COLIBRI_FALLBACK_BIN);
                         return colibri_train_once(c, &again, stats_out);
                     }
                     for (size_t e = 0; e < masks.size() && e < log[0]; ++e) {
@@ -3003,6 +3044,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
             if (c->hstate.radix_overflow) {
                 colibri_options again = o;
                 again.table_mode      = 1;
+                note_retry(c, (c->hstate.radix_overflow >= 1 && c->hstate.radix_overflow <= 3) ? (int)c->hstate.radix_overflow : COLIBRI_FALLBACK_BIN);
                 return colibri_train_once(c, &again, stats_out);
             }
             for (size_t e = 0; e < nlogged && e < log[0]; ++e) {
@@ -3029,6 +3071,7 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                         if (rc == kRerunOnTable) {
                             colibri_options again = o;
                             again.table_mode      = 1;
+                            note_retry(c, (c->hstate.radix_overflow >= 1 && c->hstate.radix_overflow <= 3) ? (int)c->hstate.radix_overflow : COLIBRI_FALLBACK_BIN);
                             return colibri_train_once(c, &again, stats_out);
                         }
                         if (rc) return rc;
@@ -3053,8 +3096,15 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
         c->hstate.res_total = res_total;
         c->last_mode        = (radix_synced || radix_constrained) ? 2 : 1;
         c->last_passes      = 1;
+        c->run_path         = !(radix_synced || radix_constrained) ? COLIBRI_PATH_TABLE
+                                                                    : (COLIBRI_PATH_RADIX | (bi2_synced ? COLIBRI_PATH_BI2 : 0) | (chain_synced ? COLIBRI_PATH_CHAIN : 0) |
+                                                                       ((chain_synced && chain_wide(npos)) ? COLIBRI_PATH_WIDE : 0));
+        if (!enq) c->run_path |= COLIBRI_PATH_PER_PASS;
         if (o.indexed && (rc = finalize_index(c, res_total))) {
-            if (rc == kRerunPairs) return colibri_train_once(c, opt_in, stats_out);  // (a model with more than two references per position)
+            if (rc == kRerunPairs) {  // (a model with more than two references per position)
+                note_retry(c, COLIBRI_FALLBACK_PAIRS);
+                return colibri_train_once(c, opt_in, stats_out);
+            }
             return rc;
         }
     }

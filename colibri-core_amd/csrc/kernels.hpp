@@ -1976,7 +1976,10 @@ __global__ __launch_bounds__(kS64Threads, kS64Threads / 128) void sort64_scatter
 // 10 M entries per pass, written and read as scattered words); inside a tile every WAVE owns 512 consecutive elements (kIRows rows of 64), so an element's rank among
 // its digit is (count in the waves before) + (count in this wave's earlier rows: a running per-wave counter in LDS) + (rank among the row's lanes: ballots) — 16 counters
 // per digit to scan instead of 64, and runs of 32 elements per digit and tile leaving for the output.
-constexpr int kIRows = 8, kITile = kS64Threads * kIRows, kISuper = 4, kIWaves = kS64Threads / kWave;
+#ifndef COLIBRI_ISUPER
+#define COLIBRI_ISUPER 4
+#endif
+constexpr int kIRows = 8, kITile = kS64Threads * kIRows, kISuper = COLIBRI_ISUPER, kIWaves = kS64Threads / kWave;
 __device__ __forceinline__ uint64_t isort_peers(uint32_t d, bool valid) {
     uint64_t peers = __ballot(valid);
 #pragma unroll

@@ -17,6 +17,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <set>
 #include <string>
 #include <unordered_set>
@@ -116,6 +117,9 @@ void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_o
 /** the same across `world` GPUs of this node (src/sharded.cpp): the corpus cut into contiguous sentence ranges, one device context and host thread per rank,
  *  RCCL for the exchange of candidate counts; the result is the union of the ranks' exports. Not for constrained runs and pattern lists. */
 void device_train_sharded(const unsigned char* payload, uint64_t nbytes, const colibri_options& opt, uint32_t firstsentence, TrainResult& out, int world);
+/** what the library keeps between plain train() calls of a process — the idle device context of every GPU (its working buffers stay reserved in HBM) and the arrays of the
+ * last released model — given back now (a long-lived caller that is done training, or one that shares the GPU with other work) */
+void release_cached();
 /** how many GPUs train() uses: set_gpus(n) (the CLI's --gpus), else the environment's COLIBRI_GPUS, else 1 */
 void set_gpus(int n);
 int  gpus();
@@ -263,9 +267,24 @@ class PatternModel : public MapType, public PatternModelInterface {
     std::shared_ptr<colibri_host::TrainResult> result;  // device results not yet turned into map nodes
     mutable std::shared_ptr<colibri_host::FlatIndex> flatindex;  // ... and the look-up table over them (built by the first has() / occurrencecount())
     /** pattern number in the pending device result, (size_t)-1 if absent; only meaningful while `result` is set */
-    size_t flat_find(const Pattern& p) const {
-        if (!flatindex) flatindex = std::make_shared<colibri_host::FlatIndex>(*result);
-        return flatindex->find(p.data, p.bytesize());
+    size_t flat_find(const Pattern& p) const { return flat_find(p.data, p.bytesize()); }
+    /** the same for key bytes that are not a Pattern of their own (a PatternPointer's): no copy into a heap Pattern per look-up. The table is built once, under a lock:
+     * read-only look-ups on a fresh model from several threads are as safe as the reference's */
+    size_t flat_find(const unsigned char* bytes, size_t n) const {
+        std::shared_ptr<colibri_host::FlatIndex> f = std::atomic_load(&flatindex);
+        if (!f) {
+            std::lock_guard<std::mutex> l(flat_mutex());
+            f = std::atomic_load(&flatindex);
+            if (!f) {
+                f = std::make_shared<colibri_host::FlatIndex>(*result);
+                std::atomic_store(&flatindex, f);
+            }
+        }
+        return f->find(bytes, n);
+    }
+    static std::mutex& flat_mutex() {
+        static std::mutex m;
+        return m;
     }
     static unsigned int flat_count(const colibri_host::TrainResult& r, size_t j) {
         return colibri_host::is_indexed_value<ValueType>::value ? (r.ref_off.empty() ? 0u : (unsigned int)(r.ref_off[j + 1] - r.ref_off[j])) : (unsigned int)r.counts[j];
@@ -324,7 +343,10 @@ class PatternModel : public MapType, public PatternModelInterface {
 
     size_t       size() const override { return MapType::size(); }
     bool         has(const Pattern& p) const override { return result ? flat_find(p) != (size_t)-1 : MapType::has(p); }
-    bool         has(const PatternPointer& p) const override { return this->has(Pattern(p)); }
+    bool         has(const PatternPointer& p) const override {
+        if (result && p.mask == 0) return flat_find(p.data, (size_t)p.bytes) != (size_t)-1;  // (an unmasked pointer's bytes ARE the key: no heap Pattern per look-up)
+        return this->has(Pattern(p));
+    }
     int          maxlength() const override { return maxn; }
     int          minlength() const override { return minn; }
     unsigned int types() override {  // a loaded model without a type count falls back to the word types its patterns hold (reference :1700-1704)

@@ -457,6 +457,21 @@ struct CtxCache {
         idle.erase(it);
         return c;
     }
+    void evict(int device) {  // device < 0: every device's
+        std::vector<colibri_ctx*> gone;
+        {
+            std::lock_guard<std::mutex> l(m);
+            for (auto it = idle.begin(); it != idle.end();) {
+                if (device < 0 || it->first == device) {
+                    gone.push_back(it->second);
+                    it = idle.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+        }
+        for (colibri_ctx* c : gone) colibri_destroy(c);
+    }
     void give(int device, colibri_ctx* c) {  // takes ownership
         if (c == nullptr) return;
         if (on()) {
@@ -558,7 +573,10 @@ void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_o
     const int   device = dev ? std::atoi(dev) : 0;
     const bool  plain  = constraint == NULL && !keep_device;  // (the modes a set of keys switches on stay with a context: such a context is not shared)
     int         rc     = COLIBRI_OK;
+    // The idle context of a plain train() keeps its working buffers in HBM (several GB at 10^8 tokens). A run that cannot use it — a constrained / kept-on-device one —
+    // would have to find its own memory beside them: it gives the idle context up first. colibri_host::release_cached() does the same on request.
     if (plain) g.c = CtxCache::get().take(device);
+    else CtxCache::get().evict(device);
     if (g.c == nullptr) rc = colibri_create(&g.c, device);
     if (rc != COLIBRI_OK) raise(nullptr, rc, "colibri_create");
     const auto t1 = clk::now();
@@ -640,6 +658,21 @@ void device_train(const unsigned char* payload, uint64_t nbytes, const colibri_o
     if (plain && g.c != nullptr) {  // everything went well: the context waits for the next call
         CtxCache::get().give(device, g.c);
         g.c = nullptr;
+    }
+}
+
+void release_cached() {
+    CtxCache::get().evict(-1);
+    if (ResultPool::on()) {
+        ResultPool&                 p = ResultPool::get();
+        std::lock_guard<std::mutex> l(p.m);
+        std::vector<uint64_t>().swap(p.key_off);
+        std::vector<unsigned char>().swap(p.key_bytes);
+        std::vector<uint32_t>().swap(p.counts);
+        std::vector<uint64_t>().swap(p.ref_off);
+        std::vector<uint32_t>().swap(p.ref_sentence);
+        std::vector<uint16_t>().swap(p.ref_token);
+        p.full = false;
     }
 }
 

@@ -320,7 +320,7 @@ class RankDriver {
         }
         if (!all_ok || maxclass_g >= (1u << 21) || npos_g >= (1u << 28)) return false;
         std::string err;
-        // COLIBRI_FAULT="<rank>:<step name>" (test builds only: -DCOLIBRI_TEST_HOOKS — lib/libcolibri_sharded_hooks.so and the mock; the shipped trainer does not read it):
+        // COLIBRI_FAULT="<rank>:<step name>" (test builds only: -DCOLIBRI_TEST_HOOKS — tests/standin/lib/libcolibri_sharded_hooks.so and the mock; the shipped trainer does not read it):
         // that rank pretends the step failed — every rank must then leave the run together, with that message
 #ifdef COLIBRI_TEST_HOOKS
         static const char* const fault = std::getenv("COLIBRI_FAULT");
@@ -823,6 +823,7 @@ void device_train_sharded(const unsigned char* payload, uint64_t nbytes, const c
         std::cerr << "ERROR: --gpus must be between 1 and 64" << std::endl;
         throw InternalError();
     }
+    release_cached();  // (the ranks' contexts need their GPUs' memory: an idle plain-train context of this process would keep several GB of it — ADVICE r5)
     const auto     t0 = std::chrono::steady_clock::now();
     ShardedTrainer tr(world, world, 0);
     try {

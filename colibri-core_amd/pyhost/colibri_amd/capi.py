@@ -54,7 +54,13 @@ class Stats(C.Structure):
         ("nrefs", C.c_uint64), ("nsentences", C.c_uint64), ("maxn", C.c_int32), ("minn", C.c_int32),
         ("windows", C.c_uint64 * MAX_ORDER), ("admitted", C.c_uint64 * MAX_ORDER), ("found", C.c_uint64 * MAX_ORDER),
         ("pruned", C.c_uint64 * MAX_ORDER), ("kept", C.c_uint64 * MAX_ORDER), ("train_ms", C.c_double),
+        ("path", C.c_int32), ("fallback_reason", C.c_int32), ("retries", C.c_int32), ("reserved_", C.c_int32),  # ABI 4: which engines counted the run / why it was repeated
     ]
+
+
+# colibri_stats.path bits / fallback_reason values (include/colibri_hip.h)
+PATH_TABLE, PATH_RADIX, PATH_BI2, PATH_CHAIN, PATH_WIDE, PATH_SLICED, PATH_PER_PASS = 1, 2, 4, 8, 16, 32, 64
+FALLBACK_NONE, FALLBACK_REGION, FALLBACK_BIN, FALLBACK_IDS, FALLBACK_ORDER2, FALLBACK_SPLIT, FALLBACK_CHAIN, FALLBACK_RESULTS, FALLBACK_PAIRS = 0, 1, 2, 3, 4, 8, 16, 32, 64
 
 
 SHARDED_LIB_PATH = os.path.join(PKG_ROOT, "lib", "libcolibri_sharded.so")

@@ -138,3 +138,18 @@ def parse_model_file(path):
         tok = raw[base + 4].astype(np.uint16) | (raw[base + 5].astype(np.uint16) << np.uint16(8))
         refs = (ref_off, sent, tok)
     return mtype, tokens, types, key_off, key_bytes, counts, refs
+
+
+def source_digest(root):
+    """sha256 over the device library's sources (colibri-core_amd/csrc/* and include/colibri_hip.h, by name): what ties a committed profile to the library it was taken from
+    (profiles/pmc_dominant_kernel.json carries it; bench.py prints roofline.traffic only when the tree it runs from has the same one)"""
+    import hashlib
+    import os
+    h = hashlib.sha256()
+    csrc = os.path.join(root, "colibri-core_amd", "csrc")
+    files = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc))] + [os.path.join(root, "include", "colibri_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()

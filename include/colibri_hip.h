@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define COLIBRI_ABI_VERSION 3 /* 3: colibri_kshard_emit / _count / _apply carry 4-byte keys, bit + number feedback (round 4). 2: colibri_train leaves stats.keybytes at 0 (colibri_result_sizes computes it), kernel classes 11..14, colibri_kshard_*, colibri_stream */
+#define COLIBRI_ABI_VERSION 4 /* 4: colibri_stats says which engines counted the run and why it was repeated, if it was (path, fallback_reason, retries: round 6). 3: colibri_kshard_emit / _count / _apply carry 4-byte keys, bit + number feedback (round 4). 2: colibri_train leaves stats.keybytes at 0 (colibri_result_sizes computes it), kernel classes 11..14, colibri_kshard_*, colibri_stream */
 #define COLIBRI_MAX_ORDER 128 /* per-order statistics are kept for n < 128; MAXLENGTH defaults to 100 in the reference */
 
 enum {
@@ -83,7 +83,32 @@ typedef struct colibri_stats {
     uint64_t pruned[COLIBRI_MAX_ORDER];    /* erased by prune()/pruneskipgrams() at order n                  */
     uint64_t kept[COLIBRI_MAX_ORDER];      /* found - pruned                                                 */
     double   train_ms;                     /* wall time of the device work of train(), host clock            */
+    /* ABI 4: which engines counted the run (COLIBRI_PATH_* bits, of the LAST attempt — the one whose model this is), and whether the run was repeated: an order that does
+     * not fit the engine it started on (a record region, a final bin's LDS table, the key bits) ends the attempt, and the whole run is done again, exactly, on the
+     * next engine down — a 2-10 x cost a caller could only see with COLIBRI_DEBUG_OVERFLOW before. fallback_reason: COLIBRI_FALLBACK_* of the FIRST repeat (0: none);
+     * retries: repeats in all (the result buffers growing counts as one). */
+    int32_t  path, fallback_reason, retries, reserved_;
 } colibri_stats;
+enum {
+    COLIBRI_PATH_TABLE   = 1,  /* the global open-addressed table (device atomics): table_mode = 1, or the last resort                                   */
+    COLIBRI_PATH_RADIX   = 2,  /* the radix path: records partitioned twice, counted in LDS (first-generation kernels for the orders the bits below do not name) */
+    COLIBRI_PATH_BI2     = 4,  /* ... order 2 on the second-generation engine (8-byte records, dense head, one wave per final bin)                        */
+    COLIBRI_PATH_CHAIN   = 8,  /* ... orders >= 3 on that engine too (keys = (number of the leading (n-1)-gram, class))                                    */
+    COLIBRI_PATH_WIDE    = 16, /* ... in its form for 2.15 - 4.3 x 10^8 positions (eight sub-regions, 2048-slot tables)                                     */
+    COLIBRI_PATH_SLICED  = 32, /* an order counted in several passes over slices of its keys (corpora beyond one pass)                                      */
+    COLIBRI_PATH_PER_PASS = 64 /* the id-keeping kinds' loop: one host look-up per pass (indexed / skipgram models off the enqueued loop, constrained runs)   */
+};
+enum {
+    COLIBRI_FALLBACK_NONE      = 0,
+    COLIBRI_FALLBACK_REGION    = 1,  /* an A-bin region of the first-generation radix path outgrew its room   -> global table                */
+    COLIBRI_FALLBACK_BIN       = 2,  /* a final bin outgrew its LDS table (hash skew)                          -> global table                */
+    COLIBRI_FALLBACK_IDS       = 3,  /* survivor id range exhausted                                            -> global table                */
+    COLIBRI_FALLBACK_ORDER2    = 4,  /* the second-generation order 2 could not hold the corpus               -> smaller passes, or first-generation kernels */
+    COLIBRI_FALLBACK_SPLIT     = 8,  /* a run of a sliced order's direct split outgrew its room                -> the exact split             */
+    COLIBRI_FALLBACK_CHAIN     = 16, /* an order >= 3 did not fit the chained engine (key bits, region, bin)   -> first-generation orders >= 3 */
+    COLIBRI_FALLBACK_RESULTS   = 32, /* the result buffers were too small (duplicated text)                    -> four times the room         */
+    COLIBRI_FALLBACK_PAIRS     = 64  /* an index with more references than the pair buffer started with       -> a larger buffer             */
+};
 
 /* kernel classes for colibri_kernel_time */
 enum {

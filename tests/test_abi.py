@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/colibri_hip.h but not exported"
     assert sorted(capi.EXPORTED) == names
-    assert L.colibri_abi_version() == 3
+    assert L.colibri_abi_version() == 4
 
 
 def test_sharded_library_exports_every_declared_symbol():

@@ -1,4 +1,4 @@
-"""CPU (no GPU): the product's own multi-GPU driver — host/src/sharded.cpp, unchanged — over a CPU stand-in for the device layer (host/mock/mock_device.cpp ->
+"""CPU (no GPU): the product's own multi-GPU driver — host/src/sharded.cpp, unchanged — over a CPU stand-in for the device layer (tests/standin/mock_device.cpp ->
 lib/libcolibri_sharded_mock.so): rank threads, rendezvous, the agreement before every exchange, the routing of sizes and buffers through the all-to-alls and
 all-reduces, "None found" termination, and what happens when one rank fails. Round 3 tested a numpy restatement of the protocol instead of the driver.
 Both protocols: key-sharded counting (plain models) and the candidate exchange — what exhaustive-skipgram models (BASELINE configs[3]), indexed models and
@@ -11,7 +11,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MOCK = os.path.join(ROOT, "colibri-core_amd", "lib", "libcolibri_sharded_mock.so")
+MOCK = os.path.join(ROOT, "tests", "standin", "lib", "libcolibri_sharded_mock.so")
 
 SCRIPT = r"""
 import sys
@@ -65,7 +65,7 @@ print("OK")
 
 
 def build():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "colibri-core_amd", "host"), "mock"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "standin"), "mock"])
 
 
 def run(args, fault=None, timeout=120, script=SCRIPT, env_extra=None):
@@ -270,7 +270,7 @@ def test_a_failing_rank_on_the_rccl_back_end(mode, fault, kind):
 
 
 # ---- the CLI over the stand-in: PatternModel::train -> device_train_sharded -> rank threads -> the merge of the ranks' exports and forward indexes -> the reference's text ----------
-MOCK_CLI = os.path.join(ROOT, "colibri-core_amd", "bin", "colibri-patternmodeller-mock")
+MOCK_CLI = os.path.join(ROOT, "tests", "standin", "bin", "colibri-patternmodeller-mock")
 
 
 @pytest.mark.parametrize("world", [2, 3, 4])

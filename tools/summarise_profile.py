@@ -14,6 +14,8 @@ import sys
 src, tag = sys.argv[1], sys.argv[2]
 tokens, nbytes, npos = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "colibri-core_amd", "pyhost"))
+from colibri_amd.digest import source_digest  # noqa: E402
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join(out, f"{tag}_kernel_stats.csv"))
@@ -102,5 +104,6 @@ json.dump({
     "correction": note + "; FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc passes (no tracing domains combined).",
     "calibration_kernels_same_run": cal,
     "source": f"profiles/{tag}_pmc_by_kernel.csv",
+    "csrc_sha256": source_digest(ROOT),  # (the library these passes ran: bench.py prints the traffic only for this very source tree)
 }, open(os.path.join(out, "pmc_dominant_kernel.json"), "w"), indent=1)
 print(open(os.path.join(out, "pmc_dominant_kernel.json")).read())

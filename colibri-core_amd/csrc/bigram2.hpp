@@ -95,6 +95,13 @@ constexpr int      kBi2BigCap    = 32768;                 // (a 10^9-token corpu
 // 5-13 % slower (four sub-regions already spread a bin's reservations; the clears and the last block's scan of the cursors grow). Kept adjacent.
 constexpr uint32_t kBi2CurPad = COLIBRI_BI2_CURPAD;
 __host__ __device__ __forceinline__ constexpr uint32_t bi2_cur(uint32_t slot) { return slot * kBi2CurPad; }
+#ifndef COLIBRI_BI2_PCPAD
+#define COLIBRI_BI2_PCPAD 1
+#endif
+constexpr uint32_t kBi2PcPad = COLIBRI_BI2_PCPAD;  // the position lists' cursors, this many words apart: cursor of list l at pcur[l * kBi2PcPad]. Round 6 measured 4 / 16
+// words: bi2_pospart_kernel's three launches 0.57 -> 0.60 / 0.93 ms — a tile's 1024 reservations are adjacent lanes on adjacent words, which the memory side takes a
+// line at a time. Kept adjacent (as the emit kernels' slot cursors, above).
+__host__ __device__ __forceinline__ constexpr uint32_t bi2_pc(uint32_t l) { return l * kBi2PcPad; }
 struct __attribute__((aligned(16))) Bi2State {
     uint32_t curA[kBi2MaxSlots * kBi2CurPad];  // emit cursors = records per slot (beyond `region`: overflow), kBi2CurPad words apart
     uint32_t cntA[kBins];         // records per A bin
@@ -105,7 +112,7 @@ struct __attribute__((aligned(16))) Bi2State {
     uint32_t headcnt[kBi2HeadN], headposinv[kBi2HeadN];  // the reduced head histogram: count and ~(lowest position) per (c0, c1)
     uint32_t headsurv[kBi2HeadN / 32];                   // bit k = head bigram k survived
     uint32_t headbase[kBlock];                           // first result rank of the head survivors of lane t (16 head keys per lane)
-    uint32_t pcur[(kBi2Shards + 1) * kBi2Buckets];       // position-list cursors (shard 8: chain.hpp's lists of the head windows, one per bucket)
+    uint32_t pcur[(kBi2Shards + 1) * kBi2Buckets * kBi2PcPad];       // position-list cursors (shard 8: chain.hpp's lists of the head windows, one per bucket)
     uint32_t nrec, bshift, overflow, kept_bins, kept_head, nbig, nhuge;
     uint32_t kbits;     // key bits below the slice bits (K - s): A bin = bits [kbits-1 : kbits-8], B bin = the nine below
     uint32_t posbits;   // position bits of a record
@@ -285,6 +292,9 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kerne
     load_tile(blockIdx.x);
     __syncthreads();
     KP_INIT(0);
+    // (Round 6 measured the hand-over of the prefetched tile — the wait for its loads, the survivor look-ups — moved in front of the previous tile's copy-out, as in
+    // uni_onepass_kernel and level B, where it sits in front of the stores the in-order memory counter would otherwise make it wait for: here the twelve more live
+    // registers of a 64-register kernel cost more, 0.55 -> 0.66 ms.)
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t base = tile * kBi2Tile;
         uint32_t       d0[kBi2Per], d1[kBi2Per], ok[kBi2Per];
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(kBi2Threads, kBi2Threads / 128) void bi2_emit_kerne
             if (rs_h) rs_at = atomicAdd(&bs->curA[bi2_cur(sub * kBins + threadIdx.x)], rs_h);
         } else if (threadIdx.x == kBins && hplist != nullptr) {  // the tile's head windows: one reservation in the bucket's list (a tile lies inside one bucket, and the list holds
             rs_h = hcntL;                                         // every position of it)
-            if (rs_h) rs_at = atomicAdd(&bs->pcur[kBi2Shards * kBi2Buckets + (base >> hpl.pshift)], rs_h);
+            if (rs_h) rs_at = atomicAdd(&bs->pcur[bi2_pc(kBi2Shards * kBi2Buckets + (base >> hpl.pshift))], rs_h);
         }
 #pragma unroll
         for (int k = 0; k < kBi2Per; ++k) {
@@ -646,14 +656,16 @@ __global__ __launch_bounds__(kBi2Threads, kBi2LbPer == 4 ? kBi2Threads / 128 : 1
             r[k]             = (j < n) ? recsA[base + j] : 0ull;
         }
     };
+    // x: the tile being sorted; r: the next one, in flight. The hand-over x = r (a wait for r's loads) sits BEFORE a tile's copy-out: behind it, the in-order memory counter
+    // made it a wait for the tile's stores as well (round 6)
+    unsigned long long x[kBi2LbPer];
     load_tile(0);
+#pragma unroll
+    for (int k = 0; k < kBi2LbPer; ++k) x[k] = r[k];
+    load_tile(kBi2LbTile);
     for (uint32_t j0 = 0; j0 < n; j0 += kBi2LbTile) {
-        unsigned long long x[kBi2LbPer];
         uint32_t           rank[kBi2LbPer];
         if (threadIdx.x < kBi2BBins) histL[threadIdx.x] = 0;
-#pragma unroll
-        for (int k = 0; k < kBi2LbPer; ++k) x[k] = r[k];
-        load_tile(j0 + kBi2LbTile);
         __syncthreads();
         KP(1);
 #pragma unroll
@@ -681,6 +693,9 @@ __global__ __launch_bounds__(kBi2Threads, kBi2LbPer == 4 ? kBi2Threads / 128 : 1
                 binL[p]          = (uint16_t)b;
             }
         }
+#pragma unroll
+        for (int k = 0; k < kBi2LbPer; ++k) x[k] = r[k];
+        load_tile(j0 + 2 * kBi2LbTile);
         __syncthreads();
         KP(4);
         const uint32_t m = min(n - j0, (uint32_t)kBi2LbTile);
@@ -1657,7 +1672,7 @@ __device__ __forceinline__ void bi2_pospart_tile(Bi2PospartLdsT<PER>& L, const u
     // (the reservation's answer is first needed by the copy-out: the memory-side atomic travels while the tile is staged — round 6)
     const uint32_t rs_h = L.histL[threadIdx.x], rs_l = shard * kBi2Buckets + threadIdx.x;
     uint32_t       rs_at = 0;
-    if (rs_h) rs_at = atomicAdd(&bs->pcur[rs_l], rs_h);
+    if (rs_h) rs_at = atomicAdd(&bs->pcur[bi2_pc(rs_l)], rs_h);
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         if (rank[k] != kInvalid) {
@@ -1732,7 +1747,7 @@ __global__ __launch_bounds__(kBi2BmThreads) void bi2_bitmap_kernel(uint32_t npos
     for (uint32_t w = threadIdx.x; w < nwords; w += kBi2BmThreads) bmL[w] = 0;
     __syncthreads();
     for (uint32_t x = 0; x < (uint32_t)kBi2Shards; ++x) {
-        const uint32_t     l = x * kBi2Buckets + b, n = min(bs->pcur[l], pl.pcap);
+        const uint32_t     l = x * kBi2Buckets + b, n = min(bs->pcur[bi2_pc(l)], pl.pcap);
         const uint32_t*    p = plist + (size_t)l * pl.pcap;  // 16-byte aligned: pcap is a multiple of 4
         const uint4* const v = reinterpret_cast<const uint4*>(p);
         const uint32_t     nv = n >> 2;

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kBi2BmThreads) void chain_bitmap_kernel(uint32_t np
     if (headid != nullptr) {  // the head windows' list: only the windows of surviving pairs count
         uint32_t first, cap;
         bi2_list_of(pl, kBi2Shards, b, first, cap);
-        const uint32_t n = min(bs->pcur[kBi2Shards * kBi2Buckets + b], cap);
+        const uint32_t n = min(bs->pcur[bi2_pc(kBi2Shards * kBi2Buckets + b)], cap);
         for (uint32_t j = threadIdx.x; j < n; j += kBi2BmThreads) {
             const uint32_t o = plist[first + j] - start;
             if (chain_head_alive(pcode[first + j], headid)) atomicOr(&bmL[o >> 5], 1u << (o & 31u));
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kBi2BmThreads) void chain_bitmap_kernel(uint32_t np
     for (uint32_t x = 0; x < (uint32_t)kBi2Shards; ++x) {
         uint32_t first, cap;
         bi2_list_of(pl, x, b, first, cap);
-        const uint32_t     n = min(bs->pcur[x * kBi2Buckets + b], cap);
+        const uint32_t     n = min(bs->pcur[bi2_pc(x * kBi2Buckets + b)], cap);
         const uint32_t*    p = plist + first;  // 16-byte aligned: pcap and hbase are multiples of 4
         const uint4* const v = reinterpret_cast<const uint4*>(p);
         const uint32_t     nv = n >> 2;
@@ -261,7 +261,7 @@ __device__ __forceinline__ void chain_number_steps(const Bi2State* __restrict__ 
         first[q] = n[q] = 0;
         if (bucket < nbuckets) {
             bi2_list_of(pl, shard, bucket, first[q], lcap);
-            n[q] = min(prev->pcur[shard * kBi2Buckets + bucket], lcap);
+            n[q] = min(prev->pcur[bi2_pc(shard * kBi2Buckets + bucket)], lcap);
         }
         ns[q] = (n[q] + kChStep - 1) / kChStep;
         sum += ns[q];
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(kBi2Threads) void chain_ids_full_kernel(const uint3
         first[x] = nn[x] = 0;
         if (x < nl) {
             bi2_list_of(pl, x, bucket, first[x], cap);
-            nn[x] = min(bs->pcur[x * kBi2Buckets + bucket], cap);
+            nn[x] = min(bs->pcur[bi2_pc(x * kBi2Buckets + bucket)], cap);
         }
         nmax = max(nmax, nn[x]);
     }

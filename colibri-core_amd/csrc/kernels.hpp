@@ -941,18 +941,20 @@ __global__ __launch_bounds__(kUni1Threads, kUni1Threads / 128) void uni_onepass_
             c[q]             = (tile < ntiles && i < npos) ? cls[i] : 0u;
         }
     };
+    // d: the tile being counted; c: the next one, in flight. The hand-over d = c (a wait for c's loads) sits BEFORE a tile's write-out, not behind it: the memory counter
+    // is in order, so behind the write-out it also waited for the tile's 2-byte stores to drain (a third of the kernel by its phase clocks, round 6)
+    uint32_t d[kUni1Per];
     load_tile(blockIdx.x);
+#pragma unroll
+    for (int q = 0; q < kUni1Per; ++q) d[q] = c[q];
+    load_tile(blockIdx.x + gridDim.x);
     __syncthreads();
     KP_INIT(2);
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        uint32_t d[kUni1Per];
-#pragma unroll
-        for (int q = 0; q < kUni1Per; ++q) d[q] = c[q];
         if (threadIdx.x < (uint32_t)kUniBins) {
             cntL[threadIdx.x] = 0;
             curL[threadIdx.x] = 0;
         }
-        load_tile(tile + gridDim.x);  // the next tile's class ids travel while this one is counted
         __syncthreads();
         KP(0);
 #pragma unroll
@@ -989,6 +991,9 @@ __global__ __launch_bounds__(kUni1Threads, kUni1Threads / 128) void uni_onepass_
                 sbinL[slot]      = (uint8_t)b;
             }
         }
+#pragma unroll
+        for (int q = 0; q < kUni1Per; ++q) d[q] = c[q];  // the next tile's class ids (asked for a tile ago) ...
+        load_tile(tile + 2 * gridDim.x);                  // ... and the one after it travels while that one is counted
         if (threadIdx.x < (uint32_t)kUniBins) {
             uint32_t g = 0;
             if (rs_h) {

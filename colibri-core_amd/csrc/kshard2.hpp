@@ -453,7 +453,7 @@ __global__ __launch_bounds__(kBlock) void ks2_head_ids_kernel(const Bi2State* __
     for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
         uint32_t first, cap;
         bi2_list_of(pl, kBi2Shards, b, first, cap);
-        const uint32_t n = min(bs->pcur[kBi2Shards * kBi2Buckets + b], cap);
+        const uint32_t n = min(bs->pcur[bi2_pc(kBi2Shards * kBi2Buckets + b)], cap);
         for (uint32_t j = threadIdx.x; j < n; j += kBlock) {
             const uint32_t r = headid[pcode[first + j] & 0xFFFu];
             if (r != kInvalid) ids[plist[first + j]] = gid_off + r;

@@ -23,7 +23,7 @@ def test_library_is_native():
     """The product path is the HIP shared library; it must be the thing that is loaded."""
     from colibri_amd import capi
     L = capi.load()
-    assert L.colibri_abi_version() == 3
+    assert L.colibri_abi_version() == 4
 
 
 def test_spooky_known_answers(ctx):
@@ -89,6 +89,32 @@ def _compare(ctx, payload, maxlength, mintokens=2, firstsentence=1, **mode):
 def test_train_matches_oracle(ctx, name, maxlength, table_mode):
     """both implementations of the order-n pass: the open-addressed global table (device atomics) and radix partition + LDS count"""
     _compare(ctx, small_corpora()[name], maxlength, table_mode=table_mode)
+
+
+def test_stats_say_which_engines_ran_and_whether_the_run_was_repeated(ctx):
+    """ABI 4 (colibri_stats.path / fallback_reason / retries): a run that gives up on an engine is repeated, exactly, on the next one down — a 2-10 x cost that only an
+    environment variable made visible before. The engines of the attempt whose model this is, and the reason and number of repeats."""
+    import oracle
+    from colibri_amd import capi, synth
+    payload = small_corpora()["zipf200k_phrases"]
+    ctx.upload(payload)
+    st = ctx.train(mintokens=2, maxlength=5)
+    assert st.path == capi.PATH_RADIX | capi.PATH_BI2 | capi.PATH_CHAIN and (st.fallback_reason, st.retries) == (0, 0)
+    st = ctx.train(mintokens=2, maxlength=5, table_mode=1)
+    assert st.path == capi.PATH_TABLE and (st.fallback_reason, st.retries) == (0, 0)
+    st = ctx.train(mintokens=2, maxlength=5, indexed=1)
+    assert st.path & capi.PATH_RADIX and st.path & capi.PATH_BI2 and not st.path & capi.PATH_TABLE and st.retries == 0
+    st = ctx.train(mintokens=2, maxlength=2)
+    assert st.path == capi.PATH_RADIX | capi.PATH_BI2  # (no order >= 3: nothing chained)
+    # duplicated text keeps more patterns than the result buffers start with: the run repeats with more room, and says so
+    L, nsent = 12, 1500
+    sent = np.random.default_rng(11).permutation(np.arange(6, 6 + L * nsent, dtype=np.uint32)).reshape(nsent, L)
+    sym = np.concatenate([np.concatenate([sent, sent], axis=0), np.zeros((2 * nsent, 1), dtype=np.uint32)], axis=1).reshape(-1)
+    dup = synth.encode_v2(sym).tobytes()
+    ctx.upload(dup)
+    st = ctx.train(mintokens=2, maxlength=L)
+    assert st.npatterns == len(oracle.train(dup, 2, L).counts)
+    assert st.fallback_reason == capi.FALLBACK_RESULTS and st.retries >= 1
 
 
 @pytest.mark.parametrize("mintokens", [1, 0, 2, 3, 5, -1, 10])

@@ -107,6 +107,10 @@ def test_a_pass_whose_bins_overflow_repeats_with_smaller_passes(kw, path):
         for mode in (0, 1):
             st = ctx.train(mintokens=2, maxlength=5, table_mode=mode, **kw)
             assert ctx.last_mode(with_passes=True) == (path if mode == 0 else (1, 1))
+            if mode == 0:  # (ABI 4: the repeat is reported, with what made the first attempt give up — the second-generation order 2, whose final bins overflowed)
+                from colibri_amd import capi as _capi
+                assert st.retries >= 1 and st.fallback_reason == _capi.FALLBACK_ORDER2
+                assert st.path & (_capi.PATH_SLICED if not kw else _capi.PATH_TABLE)
             key_off, key_bytes, counts, _ = ctx.export_arrays()
             got[mode] = (summary(st) + (st.nrefs,), row_hashes(key_off, key_bytes, counts))
     assert got[0][0] == got[1][0] and got[0][0][0] == T

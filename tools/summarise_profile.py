@@ -37,13 +37,21 @@ with open(os.path.join(out, f"{tag}_pmc_by_kernel.csv"), "w", newline="") as f:
         n = max(len(fs), len(ws), 1)
         w.writerow([k, n, round(sum(fs), 1), round(sum(fs) / n, 1), round(sum(ws), 1), round(sum(ws) / n, 1)])
 
-# Σ over the step's kernels, per step: a step = one launch of bi2_emit_kernel (order 2's scan); kernels launched less often than that are per-run (tokeniser, export)
+# Σ over the step's kernels, per step: a step = one launch of bi2_emit_kernel (order 2's scan). A kernel belongs to the step when it is launched a whole number of times per
+# step and is not one of the upload / export kernels (bench.py also uploads and tokenises several times for cold_step_ms, and exports once per model kind: those launch
+# counts can reach the step count without being part of a step)
+NOT_STEP = ("tokenise_", "position_info", "delimiter_write", "sentence_length", "export_", "scan_apply", "scan_reduce", "scan_sums", "__amd_rocclr")
 steps = max((len(d.get("FETCH_SIZE", [])) for k, d in agg.items() if "bi2_emit_kernel" in k), default=0)
 if steps:
-    f_sum = sum(sum(d.get("FETCH_SIZE", [])) for k, d in agg.items() if len(d.get("FETCH_SIZE", [])) >= steps) * 1024 / steps
-    w_sum = sum(sum(d.get("WRITE_SIZE", [])) for k, d in agg.items() if len(d.get("WRITE_SIZE", [])) >= steps) * 1024 / steps
+    def in_step(k, d):
+        n = max(len(d.get("FETCH_SIZE", [])), len(d.get("WRITE_SIZE", [])))
+        return n >= steps and n % steps == 0 and not any(x in k for x in NOT_STEP)
+    f_sum = sum(sum(d.get("FETCH_SIZE", [])) for k, d in agg.items() if in_step(k, d)) * 1024 / steps
+    w_sum = sum(sum(d.get("WRITE_SIZE", [])) for k, d in agg.items() if in_step(k, d)) * 1024 / steps
     step_sum = {"steps_profiled": steps, "fetch_bytes_per_step_raw": round(f_sum), "write_bytes_per_step_raw": round(w_sum),
-                "hbm_bytes_per_step_2F_plus_W": round(2 * f_sum + w_sum), "note": "per-step kernels only (launched at least once per step); FETCH_SIZE doubled as for the dominant kernel"}
+                "hbm_bytes_per_step_2F_plus_W": round(2 * f_sum + w_sum),
+                "kernels": sorted(k.split("(")[0].replace("void ", "").replace("colibri::", "") for k, d in agg.items() if in_step(k, d)),
+                "note": "the step's kernels only (a whole number of launches per step; upload, tokeniser, export and runtime copy kernels excluded); FETCH_SIZE doubled as for the dominant kernel"}
     with open(os.path.join(out, f"{tag}_pmc_step_sum.json"), "w") as f:
         json.dump(step_sum, f, indent=1)
     print("sum over the step's kernels:", json.dumps(step_sum))

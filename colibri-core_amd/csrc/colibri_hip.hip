@@ -99,6 +99,11 @@ struct colibri_ctx {
     uint32_t          pair_sb = 0, pair_tb = 0;  // packed pairs (id << (sb + tb) | sentence << tb | token): bits of the sentence / token fields; 0 / 0: id << 32 | position
     DevBuf<uint32_t>  ref_sentence;
     DevBuf<uint16_t>  ref_token;
+    DevBuf<uint32_t>  hot_cnt;             // order 1 of an indexed model: occurrences of the hot unigrams per tile (kernels.hpp: emit_hot_*), [kHotIds][tiles]
+    DevBuf<HotInfo>   hot_info;
+    bool              hot_used = false;    // ... their references lie in ref_sentence / ref_token already: [hot_below, hot_below + hot_n)
+    bool              hot_disorder = false, hot_off = false;  // a hot list came out of order (emit_hot_write_kernel's check): this context sorts every reference from now on
+    uint64_t          hot_below = 0, hot_n = 0;
     DevBuf<Slot>      table;
     DevBuf<Rec>       recs[2];          // binned path: record ping-pong
     DevBuf<uint32_t>  sklist, sklist_n; // skipgram passes: the positions that can take part in the current order
@@ -578,6 +583,8 @@ void colibri_destroy(colibri_ctx* c) {
     dev_free(c->idx_cnt); dev_free(c->sort_hist); dev_free(c->sort_off); dev_free(c->sort_bsum);
     dev_free(c->ref_sentence);
     dev_free(c->ref_token);
+    dev_free(c->hot_cnt);
+    dev_free(c->hot_info);
     dev_free(c->sh.tkeys);
     dev_free(c->sh.pkeys);
     dev_free(c->sh.tcounts);
@@ -1619,7 +1626,7 @@ int skipgram_pass(colibri_ctx* c, const TrainPlan& pl, int n, uint32_t mask, con
     return COLIBRI_OK;
 }
 
-int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool ensure, const uint32_t* surv = nullptr, const uint32_t* resid = nullptr);
+int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool ensure, const uint32_t* surv = nullptr, const uint32_t* resid = nullptr, bool hot1 = false);
 int emit_pairs_list(colibri_ctx* c, uint32_t bound, const uint32_t* ids);
 // MINSKIPTYPES of an indexed model: a skipgram needs that many distinct fillers = distinct surviving n-grams (results [src_first, src_first + src_count)) whose
 // representative window it masks. `ids`: the RESULT index of every window's skipgram (the k1 survivors of the count threshold sit at res_total..); the ones
@@ -1831,10 +1838,12 @@ int grow_keep(colibri_ctx* c, DevBuf<T>& b, uint64_t need, uint64_t keep) {
 // sharded levels, which cannot be run again as a whole): wait, and when the room was short grow the buffer and repeat the pass.
 int pairs_begin(colibri_ctx* c, uint32_t npos) {
     int rc;
-    if ((rc = dev_alloc(c, c->pair_chain, (size_t)kChainHead + 1))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->pair_chain.p, 0, sizeof(unsigned long long) * kChainHead, c->stream));
+    if ((rc = dev_alloc(c, c->pair_chain, (size_t)kChainWords + 1))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->pair_chain.p, 0, sizeof(unsigned long long) * kChainWords, c->stream));
     c->pair_pass = 0;
     c->npairs    = 0;
+    c->hot_used  = false;
+    c->hot_below = c->hot_n = 0;
     c->pair_split = false;  // (the caller's to set: colibri_train_once does when the pairs are packed; the sharded runs keep whole pairs — they cut the sorted references by id)
     if (c->pairs[0].n < 2ull * npos && (rc = dev_alloc(c, c->pairs[0], (size_t)(2ull * npos) + 1))) return rc;  // the usual model: ~1.6 pairs per position at n <= 5
     // position -> (sentence, token) table of the corpus (once per upload)
@@ -1866,20 +1875,48 @@ int pairs_begin(colibri_ctx* c, uint32_t npos) {
 }
 // pairs so far; *overflowed: the buffer was too small for them
 int pairs_count(colibri_ctx* c, uint64_t* n, bool* overflowed) {
-    unsigned long long h[3] = {0, 0, 0};
+    unsigned long long h[kChainWords] = {0, 0, 0, 0, 0, 0};
     HIP_TRY(c, hipMemcpyAsync(h, c->pair_chain.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     *n          = h[c->pair_pass];
     *overflowed = h[2] != 0;
+    c->hot_n     = c->hot_used ? h[kChainHot] : 0;  // (references that never were pairs: emit_hot_write_kernel)
+    c->hot_below = c->hot_used ? h[kChainBelow] : 0;
+    c->hot_disorder = c->hot_used && h[kChainDisorder] != 0;
     return COLIBRI_OK;
 }
 // surv / resid (order 1 of an indexed model whose ids[1] nobody else reads): `ids` is the class per position; a class's survivor bit and result index stand in for the id
-int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool ensure, const uint32_t* surv, const uint32_t* resid) {
+// hot1 (order 1 of an enqueued indexed run with split pairs; c->uni_resid holds the classes' result indices): the references of the most frequent unigrams go straight to
+// their final places and never become pairs (kernels.hpp: emit_hot_*)
+int emit_pairs(colibri_ctx* c, const TrainPlan& pl, const uint32_t* ids, bool ensure, const uint32_t* surv, const uint32_t* resid, bool hot1) {
     const uint32_t ntiles = std::max<uint32_t>(1, blocks_for(pl.npos, kPairTile));
     int            rc0;
     if ((rc0 = dev_alloc(c, c->idx_cnt, (size_t)ntiles + 2))) return rc0;
     uint32_t* const cnt = c->idx_cnt.p;
+    if (hot1 && c->pair_split && c->pair_sb != 0 && !ensure && !c->hot_used && !c->hot_off && !getenv("COLIBRI_NO_HOT_REFS")) {
+        const uint64_t cap = c->pairs[0].n;
+        // the reference arrays exist from here on (finalize_index only ever asks for less): every pair's room plus the hot references'
+        if ((rc0 = dev_alloc(c, c->ref_sentence, (size_t)cap + pl.npos + 2)) || (rc0 = dev_alloc(c, c->ref_token, (size_t)cap + pl.npos + 2)) ||
+            (rc0 = dev_alloc(c, c->hot_cnt, (size_t)kHotIds * ntiles)) || (rc0 = dev_alloc(c, c->hot_info, 1)))
+            return rc0;
+        Prof p(c, COLIBRI_K_INDEX);
+        hipLaunchKernelGGL(hot_setup_kernel, dim3(1), dim3(kPairThreads), 0, c->stream, (const uint32_t*)c->uni_resid.p, c->maxclass + 1, (const uint32_t*)c->res_cnt.p,
+                           (const DevState*)c->state.p, c->hot_info.p, /*closed=*/surv == nullptr ? 1u : 0u);  // (the class form is emitted before the order's figures are closed)
+        hipLaunchKernelGGL(emit_hot_count_kernel, dim3(ntiles), dim3(kPairThreads), 0, c->stream, ids, pl.npos, cnt, (const DevState*)c->state.p, surv, resid,
+                           surv != nullptr ? &c->state.p->valid : (uint32_t*)nullptr, (const HotInfo*)c->hot_info.p, c->hot_cnt.p, ntiles);
+        hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(kPairThreads), 0, c->stream, cnt, ntiles, cnt + ntiles);
+        hipLaunchKernelGGL(hot_scan_kernel, dim3(kHotIds), dim3(kPairThreads), 0, c->stream, c->hot_cnt.p, ntiles, c->hot_info.p);
+        hipLaunchKernelGGL(hot_base_kernel, dim3(1), dim3(kHotIds), 0, c->stream, c->hot_info.p, c->pair_chain.p);
+        hipLaunchKernelGGL(pairs_advance_kernel, dim3(1), dim3(1), 0, c->stream, c->pair_chain.p, c->pair_pass, cnt + ntiles, cap);
+        hipLaunchKernelGGL(emit_hot_write_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(kPairThreads), 0, c->stream, ids, pl.npos, (const uint32_t*)cnt,
+                           c->pair_chain.p, c->pair_pass, cap, reinterpret_cast<uint32_t*>(c->pairs[0].p), reinterpret_cast<uint32_t*>(c->pairs[0].p) + cap,
+                           (const PosBlock*)c->pos_blocks.p, c->pair_tb, surv, resid, (const HotInfo*)c->hot_info.p, (const uint32_t*)c->hot_cnt.p, ntiles, c->first_sentence,
+                           c->ref_sentence.p, c->ref_token.p, (const DevState*)c->state.p);
+        c->pair_pass ^= 1;
+        c->hot_used = true;
+        return COLIBRI_OK;
+    }
     for (;;) {
         {
             Prof p(c, COLIBRI_K_INDEX);
@@ -1984,8 +2021,13 @@ int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = fal
         if ((rc = dev_alloc(c, c->pairs[0], (size_t)(n + n / 8) + 1))) return rc;
         return kRerunPairs;
     }
-    c->npairs = n;
-    if ((rc = dev_alloc(c, c->ref_sentence, (size_t)n + 1)) || (rc = dev_alloc(c, c->ref_token, (size_t)n + 1))) return rc;
+    if (c->hot_disorder) {  // (never seen: emit_hot_write_kernel's ranks rest on the order in which the LDS serves the lanes of one instruction)
+        c->hot_off = true;
+        return kRerunPairs;
+    }
+    c->npairs = n + c->hot_n;  // (the hot unigrams' references were never pairs: they lie where they belong already)
+    if (c->hot_used && (c->ref_sentence.n < c->npairs + 1 || c->ref_token.n < c->npairs + 1)) return fail(c, COLIBRI_ERR_STATE, "finalize_index: the reference arrays are smaller than the model's references");
+    if ((rc = dev_alloc(c, c->ref_sentence, (size_t)c->npairs + 1)) || (rc = dev_alloc(c, c->ref_token, (size_t)c->npairs + 1))) return rc;
     if (!n) return COLIBRI_OK;
     if ((rc = dev_alloc(c, c->pairs[1], (size_t)n))) return rc;
     int cur = 0;
@@ -2024,7 +2066,7 @@ int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = fal
                 hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->sort_hist.p, nh, c->sort_bsum.p, c->sort_off.p);
 #define ISORT(TIN, TOUT, FIN)                                                                                                                                                   \
     hipLaunchKernelGGL((isort_scatter_kernel<TIN, TOUT, FIN>), dim3(nblocks), dim3(kS64Threads), 0, c->stream, (const TIN*)dig, pay, n, nblocks, c->sort_off.p, opay, (TOUT*)odig, \
-                       c->first_sentence, c->ref_sentence.p, c->ref_token.p, c->pair_tb)
+                       c->first_sentence, c->ref_sentence.p, c->ref_token.p, c->pair_tb, c->hot_below, c->hot_n)
                 if (last) {
                     if (in_bytes == 4) ISORT(uint32_t, uint8_t, true);
                     else if (in_bytes == 2) ISORT(uint16_t, uint8_t, true);
@@ -2198,7 +2240,7 @@ extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, coli
 #endif
 #ifdef COLIBRI_KPROF  // (experimental builds only) phase clocks of the block-structured kernels (device_common.hpp): share of each section, summed over blocks and launches of this call
         {
-            static const char* const names[8] = {"bi2_emit", "levelB", "uni_onepass", "pospart", "chain_emit", "k5", "k6", "k7"};
+            static const char* const names[8] = {"bi2_emit", "levelB", "uni_onepass", "pospart", "chain_emit", "hot_write", "k6", "k7"};
             unsigned long long h[8][12], z[8][12];
             memset(z, 0, sizeof z);
             if (hipMemcpyFromSymbol(h, HIP_SYMBOL(colibri::kprof), sizeof h) == hipSuccess) {
@@ -2619,13 +2661,13 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                     c->ids_built[(size_t)n] = 1;
                 }
                 if (n == 1 && uni_pairs_direct) {  // (before the order's figures are closed: the emission counts the positions with a surviving unigram, as uni_resid_ids_kernel does)
-                    if ((rc = emit_pairs(c, pl, c->cls.p, false, c->uni_surv.p, c->uni_resid.p))) return rc;
+                    if ((rc = emit_pairs(c, pl, c->cls.p, false, c->uni_surv.p, c->uni_resid.p, /*hot1=*/true))) return rc;
                 }
                 hipLaunchKernelGGL(idm_ngram_end_kernel, dim3(1), dim3(1), 0, c->stream, c->state.p, n);
                 if (o.indexed && !(c->b2.pairs_direct && (n >= 3 || (n == 2 && c->b2.pairs2_direct))) && !(n == 1 && uni_pairs_direct)) {
                     const uint32_t* const idn = built_ids(c, n);
                     if (!idn) return COLIBRI_ERR_STATE;
-                    if ((rc = emit_pairs(c, pl, idn, false))) return rc;
+                    if ((rc = emit_pairs(c, pl, idn, false, nullptr, nullptr, /*hot1=*/n == 1 && !c->ids1_is_cls))) return rc;  // (ids[1] holds uni_resid's result indices then)
                 }
                 if (o.doskipgrams_exhaustive && n >= 3) {  // patternmodel.h:1163-1171 -> computeskipgrams :1370-1527, for every admissible window: the order's own active list
                     if (n > kMaxSkipgramTokens) return fail(c, COLIBRI_ERR_UNSUPPORTED, "skipgrams of patterns longer than 31 tokens do not exist (a gap mask has 32 bits; set MAXLENGTH)");

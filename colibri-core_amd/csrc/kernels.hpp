@@ -1706,6 +1706,329 @@ __global__ __launch_bounds__(kPairThreads) void emit_write_kernel(const uint32_t
     }
 }
 
+// ---- order 1 of an indexed model: the references of the HOT unigrams never enter the sort (round 6) ----------------------------------------------------------------------
+// The stable sort by result id exists because a pattern's occurrences are spread over the corpus. For the most frequent words they are not spread thinly: a tile of
+// 8192 positions holds hundreds of "the" and still a handful of the 256th word, and these 256 words own ~40 % of the unigram references of a Zipf corpus (a quarter of ALL
+// references of a model with n <= 5) — each of them sorted three times. Here a tile counts its occurrences of every hot id (LDS histogram), one scan per hot id over
+// the tiles gives every tile its place in the id's list, and the write sweep puts the (sentence, token) of a hot occurrence straight at its final place: base of the id's
+// list + occurrences in the tiles before + rank inside the tile (waves own 512 consecutive positions; rank = the waves before + the wave's rows before + the lanes before,
+// as in isort_scatter_kernel). Stable by construction, nothing to sort.
+// Which ids: uni_finish_kernel numbers the surviving classes of a tile of kPruneTile classes consecutively in class order (the tiles among each other in the order their
+// blocks arrived), so the first kHotIds survivors of class tile 0 — classes are frequency-ranked, reference src/classencoder.cpp:220-224 — have the ids base0 .. base0 + hn - 1.
+// In the sorted order of the OTHER references, those of ids below base0 come first (`below` of them: the sum of their counts), so the hot block lies at [below, below + nhot)
+// and the last sort pass moves everything behind `below` up by nhot. Correct for any class numbering; it pays when the low classes are the frequent ones.
+constexpr int kHotIds = 256;
+struct HotInfo {
+    uint32_t           base0, hn;      // hot ids: [base0, base0 + hn)
+    unsigned long long below, nhot;    // references that sort before the hot block; references of the hot ids
+    uint32_t           total[kHotIds], base[kHotIds];  // occurrences per hot id; their exclusive scan
+    uint8_t            hotmap[kPruneTile];             // class c < kPruneTile -> its hot id - base0, 0xFF: not hot (the sweeps over CLASSES look here, not in the 4 MB of resid)
+};
+// one block: the hot ids of this run and the references sorting before them
+__global__ __launch_bounds__(kPairThreads) void hot_setup_kernel(const uint32_t* __restrict__ resid, uint32_t nclasses, const uint32_t* __restrict__ res_cnt, const DevState* __restrict__ st,
+                                                                  HotInfo* __restrict__ hi, uint32_t closed /* idm_ngram_end_kernel has closed order 1: its ids start at res_off[1] */) {
+    __shared__ uint32_t           redA[kPairThreads / kWave], redB[kPairThreads / kWave];
+    __shared__ unsigned long long redC[kPairThreads / kWave];
+    __shared__ uint32_t           base0L;
+    const uint32_t lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    uint32_t       lo = kInvalid, nv = 0;
+    if (!st->done)
+        for (uint32_t cidx = threadIdx.x; cidx < min(nclasses, (uint32_t)kPruneTile); cidx += kPairThreads) {
+            const uint32_t r = resid[cidx];
+            if (r != kInvalid) {
+                lo = min(lo, r);
+                ++nv;
+            }
+        }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_down((int)lo, off, kWave));
+        nv += __shfl_down(nv, off, kWave);
+    }
+    if (lane == 0) redA[w] = lo, redB[w] = nv;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = kInvalid, b = 0;
+        for (int q = 0; q < kPairThreads / kWave; ++q) a = min(a, redA[q]), b += redB[q];
+        base0L    = a;
+        hi->base0 = a == kInvalid ? 0u : a;
+        hi->hn    = a == kInvalid ? 0u : min(b, (uint32_t)kHotIds - 1u);  // (0xFF is the map's "not hot")
+    }
+    __syncthreads();
+    const uint32_t     base0 = base0L == kInvalid ? 0u : base0L;
+    {
+        const uint32_t hn = hi->hn;  // (thread 0 wrote it before the barrier)
+        for (uint32_t cidx = threadIdx.x; cidx < (uint32_t)kPruneTile; cidx += kPairThreads) {
+            const uint32_t r = (cidx < nclasses && !st->done) ? resid[cidx] : kInvalid;
+            hi->hotmap[cidx] = (r != kInvalid && r - base0 < hn) ? (uint8_t)(r - base0) : (uint8_t)0xFF;
+        }
+    }
+    unsigned long long sum = 0;
+    for (uint32_t r0 = (closed ? st->res_off[1] : st->res_total) + threadIdx.x; r0 < base0; r0 += 8 * kPairThreads) {  // (from order 1's first id; eight loads in flight)
+        uint32_t x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = r0 + q * kPairThreads < base0 ? res_cnt[r0 + q * kPairThreads] : 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sum += x[q];
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, kWave);
+    if (lane == 0) redC[w] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int q = 0; q < kPairThreads / kWave; ++q) t += redC[q];
+        hi->below = t;
+        hi->nhot  = 0;
+    }
+}
+// count sweep: per tile the references that will travel as pairs (blockcnt) and the occurrences of every hot id (hotcnt[h * ntiles + tile])
+__global__ __launch_bounds__(kPairThreads) void emit_hot_count_kernel(const uint32_t* __restrict__ ids, uint32_t npos, uint32_t* __restrict__ blockcnt, const DevState* __restrict__ st,
+                                                                       const uint32_t* __restrict__ surv, const uint32_t* __restrict__ resid, uint32_t* __restrict__ valid_out,
+                                                                       const HotInfo* __restrict__ hi, uint32_t* __restrict__ hotcnt, uint32_t ntiles) {
+    __shared__ uint32_t histL[kHotIds], nhL;
+    __shared__ uint32_t mapL[kPruneTile / 4];
+    if (threadIdx.x < kHotIds) histL[threadIdx.x] = 0;
+    if (threadIdx.x == 0) nhL = 0;
+    if (resid != nullptr) mapL[threadIdx.x] = reinterpret_cast<const uint32_t*>(hi->hotmap)[threadIdx.x];
+    static_assert(kPruneTile / 4 == kPairThreads, "one word of the map per thread");
+    __syncthreads();
+    uint32_t c = 0, nh = 0;
+    if (!st->done) {
+        const uint32_t base0 = hi->base0, hn = hi->hn;
+        uint32_t       v[kPairPer];
+        pair_load(ids, npos, blockIdx.x * kPairTile + threadIdx.x * kPairPer, v);
+#pragma unroll
+        for (int k = 0; k < kPairPer; ++k) {
+            uint32_t h = 0xFFu;
+            if (resid != nullptr) {  // classes: a survivor bit says whether the position counts, the map whether its id is hot
+                if (v[k] == kInvalid || v[k] == 0u || !((surv[v[k] >> 5] >> (v[k] & 31u)) & 1u)) continue;
+                if (v[k] < (uint32_t)kPruneTile) h = reinterpret_cast<const uint8_t*>(mapL)[v[k]];
+            } else {
+                if (v[k] == kInvalid) continue;
+                if (v[k] - base0 < hn) h = v[k] - base0;
+            }
+            if (h != 0xFFu) {
+                atomicAdd(&histL[h], 1u);
+                ++nh;
+            } else {
+                ++c;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) nh += __shfl_down(nh, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0 && nh) atomicAdd(&nhL, nh);
+    uint32_t total;
+    pair_block_scan(c, &total);
+    if (threadIdx.x < kHotIds) hotcnt[(size_t)threadIdx.x * ntiles + blockIdx.x] = histL[threadIdx.x];  // (pair_block_scan's barrier is behind every atomic)
+    if (threadIdx.x == 0) {
+        blockcnt[blockIdx.x] = total;
+        if (valid_out != nullptr && total + nhL) atomicAdd(valid_out, total + nhL);  // (ONE atomic per block on this word: a single address takes ~12 ns each)
+    }
+}
+// block h: the tiles' counts of hot id h -> their exclusive scan in place, the id's total to hi->total[h]
+__global__ __launch_bounds__(kPairThreads) void hot_scan_kernel(uint32_t* __restrict__ hotcnt, uint32_t ntiles, HotInfo* __restrict__ hi) {
+    constexpr int   kPer = 16;
+    uint32_t* const data = hotcnt + (size_t)blockIdx.x * ntiles;
+    uint32_t        carry = 0;
+    for (uint32_t base = 0; base < ntiles; base += kPairThreads * kPer) {
+        const uint32_t i0 = base + threadIdx.x * kPer;
+        uint32_t       v[kPer], s = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            v[k] = i0 + k < ntiles ? data[i0 + k] : 0u;
+            s += v[k];
+        }
+        uint32_t tot;
+        uint32_t ex = carry + pair_block_scan(s, &tot);
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            if (i0 + k < ntiles) data[i0 + k] = ex;
+            ex += v[k];
+        }
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) hi->total[blockIdx.x] = carry;
+}
+// one block of kHotIds threads: the hot ids' lists one after the other; chain[kChainHot] / [kChainBelow]: what finalize_index reads with the pair count
+constexpr int kChainHot = 3, kChainBelow = 4, kChainDisorder = 5, kChainWords = 6;
+__global__ __launch_bounds__(kHotIds) void hot_base_kernel(HotInfo* __restrict__ hi, unsigned long long* __restrict__ chain) {
+    __shared__ uint32_t wsum[kHotIds / kWave];
+    const uint32_t      lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave, v = threadIdx.x < hi->hn ? hi->total[threadIdx.x] : 0u;
+    uint32_t            inc = v;
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d);
+        if ((int)lane >= d) inc += t;
+    }
+    if (lane == kWave - 1) wsum[w] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (int q = 0; q < kHotIds / kWave; ++q) {
+        before += (uint32_t)q < w ? wsum[q] : 0u;
+        all += wsum[q];
+    }
+    hi->base[threadIdx.x] = before + inc - v;
+    if (threadIdx.x == 0) {
+        hi->nhot           = all;
+        chain[kChainHot]   = all;
+        chain[kChainBelow] = hi->below;
+    }
+}
+// write sweep (split, packed pairs only): the other references leave as pairs in position order, exactly as emit_write_kernel's; a hot occurrence goes to its final place.
+// Tiles are dealt to the XCDs in contiguous ranges (block b works on tile (b % 8) * per + b / 8): consecutive tiles append to the same lines of a hot list, and
+// should meet in one L2.
+__global__ __launch_bounds__(kPairThreads) void emit_hot_write_kernel(const uint32_t* __restrict__ ids, uint32_t npos, const uint32_t* __restrict__ blockoff,
+                                                                       unsigned long long* chain /* read: [which]; written: [kChainDisorder] */, int which, uint64_t cap,
+                                                                       uint32_t* __restrict__ pair_id, uint32_t* __restrict__ pay, const PosBlock* __restrict__ blocks, uint32_t tb,
+                                                                       const uint32_t* __restrict__ surv,
+                                                                       const uint32_t* __restrict__ resid, const HotInfo* __restrict__ hi, const uint32_t* __restrict__ hotoff,
+                                                                       uint32_t ntiles, uint32_t first_sentence, uint32_t* __restrict__ ref_sentence, uint16_t* __restrict__ ref_token,
+                                                                       const DevState* __restrict__ st) {
+    if (st->done) return;
+    constexpr int  kWaves = kPairThreads / kWave, kRows = kPairPer;
+    const uint32_t per = (ntiles + 7u) / 8u, t = (blockIdx.x % 8u) * per + blockIdx.x / 8u;
+    if (blockIdx.x / 8u >= per || t >= ntiles) return;
+    __shared__ uint32_t rowcnt[kRows * kWaves];
+    __shared__ uint32_t wcntL[kWaves][kHotIds];  // occurrences of hot id h wave w has seen; then: those of the waves before it
+    __shared__ uint32_t toffL[kHotIds], runL[kHotIds], thL[kHotIds], hsumL[kHotIds / kWave];
+    // the tile's hot references, staged in (hot id, position) order: a run per id leaves as whole lines (straight from the lanes, a row of 64 positions wrote to ~15 lists)
+    // (sentence << tb | token in one word, as a pair's payload: 57 KB of LDS in all, two blocks per CU — with a 16-bit token array beside it, 73 KB, only one was resident)
+    __shared__ uint32_t stgS[kPairTile];
+    __shared__ uint8_t  stgH[kPairTile];
+    const uint32_t      lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave, tile = t * kPairTile;
+    const uint32_t      base0 = hi->base0, hn = hi->hn;
+    for (uint32_t k = threadIdx.x; k < (uint32_t)(kWaves * kHotIds); k += kPairThreads) (&wcntL[0][0])[k] = 0;
+    if (threadIdx.x < kHotIds) toffL[threadIdx.x] = threadIdx.x < hn ? hi->base[threadIdx.x] + hotoff[(size_t)threadIdx.x * ntiles + t] : 0u;
+    __shared__ uint32_t mapL[kPruneTile / 4];
+    if (resid != nullptr) mapL[threadIdx.x] = reinterpret_cast<const uint32_t*>(hi->hotmap)[threadIdx.x];
+    uint32_t v[kRows], rank[kRows];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {  // the wave's 512 consecutive positions, row by row
+        const uint32_t p = tile + w * (kWave * kRows) + (uint32_t)r * kWave + lane;
+        v[r]             = p < npos ? ids[p] : kInvalid;
+    }
+    KP_INIT(5);
+    __syncthreads();
+    KP(0);  // (ids / classes, the tile's offsets and the map have arrived)
+    // what a position is: kHqCold (a reference that travels as a pair), kHqNone, or its hot id - base0. Classes: the map says which; the cold classes' result indices are a
+    // gather each (as emit_write_kernel's) whose answer only the last loop needs — the ranking must not wait for it
+    constexpr uint32_t kHqCold = 0x100u, kHqNone = 0x1FFu;
+    uint32_t           hq[kRows], sw[kRows];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r)  // (all rows' survivor words first: a look-up between two rows' gathers would wait for the gather before it — loads return in order)
+        sw[r] = (resid != nullptr && v[r] != kInvalid && v[r] != 0u) ? surv[v[r] >> 5] : 0u;
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+        const uint32_t cc = v[r];
+        hq[r]             = kHqNone;
+        if (resid != nullptr) {
+            if ((sw[r] >> (cc & 31u)) & 1u) {
+                const uint32_t h = cc < (uint32_t)kPruneTile ? (uint32_t)reinterpret_cast<const uint8_t*>(mapL)[cc] : 0xFFu;
+                hq[r]            = h != 0xFFu ? h : kHqCold;
+                v[r]             = h != 0xFFu ? 0u : resid[cc];
+            }
+        } else if (cc != kInvalid) {
+            hq[r] = cc - base0 < hn ? cc - base0 : kHqCold;
+        }
+    }
+    KP(5);  // (this wave's classes / ids have arrived, survivor bits looked up)
+    unsigned long long bal[kRows];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+        const bool hot = hq[r] < kHqCold;
+        bal[r]         = __ballot(hq[r] == kHqCold);
+        if (lane == 0) rowcnt[(int)w * kRows + r] = (uint32_t)__popcll(bal[r]);
+        // rank among the wave's earlier occurrences of the id: one returning LDS add per hot lane. A wave's DS instructions execute in order, so the rows are; lanes of ONE
+        // instruction that hit the same counter are served in lane order on this hardware, which no manual promises — the copy-out checks every run for ascending
+        // references and raises chain[kChainDisorder] otherwise (the run is then repeated with every reference through the sort). Matching the lanes by id with ballots,
+        // as isort_scatter_kernel does, is exact by construction and cost 0.48 of this kernel's 1.02 ms (eight ballots and 64-bit selects per row of 64 positions).
+        rank[r] = hot ? atomicAdd(&wcntL[w][hq[r]], 1u) : 0u;
+    }
+    __syncthreads();
+    KP(1);  // (ranks)
+    static_assert(kRows * kWaves == 2 * kWave, "one wave scans the tile's (wave, row) counts, two per lane");
+    if (w == 0) {
+        const uint32_t a = rowcnt[2 * lane], b2 = rowcnt[2 * lane + 1];
+        uint32_t       inc = a + b2;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint32_t x = __shfl_up(inc, d);
+            if ((int)lane >= d) inc += x;
+        }
+        rowcnt[2 * lane]     = inc - a - b2;
+        rowcnt[2 * lane + 1] = inc - b2;
+    } else if (threadIdx.x - kWave < (uint32_t)kHotIds) {  // hot id q: the waves' counts -> those of the waves before (waves 1 .. 4)
+        const uint32_t q = threadIdx.x - kWave;
+        uint32_t       run = 0;
+#pragma unroll
+        for (int x = 0; x < kWaves; ++x) {
+            const uint32_t cc = wcntL[x][q];
+            wcntL[x][q]       = run;
+            run += cc;
+        }
+        runL[q] = run;
+    }
+    __syncthreads();
+    {  // exclusive scan of the hot ids' tile totals: where an id's run starts in the staging area
+        uint32_t x = 0, inc = 0;
+        if (threadIdx.x < (uint32_t)kHotIds) {
+            x   = runL[threadIdx.x];
+            inc = x;
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const uint32_t y = __shfl_up(inc, d);
+                if ((int)lane >= d) inc += y;
+            }
+            if (lane == kWave - 1) hsumL[w] = inc;
+        }
+        __syncthreads();
+        if (threadIdx.x < (uint32_t)kHotIds) {
+            uint32_t before = 0;
+            for (uint32_t y = 0; y < w; ++y) before += hsumL[y];
+            thL[threadIdx.x] = before + inc - x;
+        }
+        __syncthreads();
+    }
+    KP(2);  // (scans)
+    unsigned long long* const flags = chain;
+    const uint64_t first = chain[which] + blockoff[t], hot0 = hi->below;
+    const uint32_t tmask = tb >= 32 ? 0xFFFFFFFFu : (1u << tb) - 1u;
+    const uint64_t lower = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+        if (hq[r] == kHqNone) continue;
+        const uint32_t p     = tile + w * (kWave * kRows) + (uint32_t)r * kWave + lane;  // p & 63 == lane
+        const uint4    pb    = *reinterpret_cast<const uint4*>(blocks + (p >> 6));        // (one entry per wave and row)
+        const uint64_t delim = ((uint64_t)pb.w << 32) | pb.z, under = delim & lower;
+        const uint32_t sent = pb.x + (uint32_t)__popcll(under), tok = under ? lane - (64u - (uint32_t)__clzll(under)) : p - pb.y;
+        if (hq[r] < kHqCold) {
+            const uint32_t h = hq[r], at = thL[h] + wcntL[w][h] + rank[r];
+            stgS[at]         = (sent << tb) | (tok & tmask);
+            stgH[at]         = (uint8_t)h;
+        } else {
+            const uint64_t o = first + rowcnt[(int)w * kRows + r] + (uint32_t)__popcll(bal[r] & lower);
+            if (o < cap) {
+                pair_id[o] = v[r];
+                pay[o]     = (sent << tb) | (tok & tmask);
+            }
+        }
+    }
+    __syncthreads();
+    KP(3);  // (position blocks read, cold pairs written, hot references staged)
+    const uint32_t nstaged = thL[kHotIds - 1] + runL[kHotIds - 1];
+    bool disorder = false;
+    for (uint32_t j = threadIdx.x; j < nstaged; j += kPairThreads) {
+        const uint32_t h   = stgH[j];
+        const uint64_t dst = hot0 + toffL[h] + (j - thL[h]);
+        const uint32_t yy  = stgS[j];
+        disorder           = disorder || (j > thL[h] && stgS[j - 1] >= yy);  // (inside a run (sentence, token) ascends with the position)
+        ref_sentence[dst]  = first_sentence + (tb >= 32 ? 0u : yy >> tb);
+        ref_token[dst]     = (uint16_t)(yy & tmask);
+    }
+    if (disorder) flags[kChainDisorder] = 1ull;
+    KP(4);
+    KP_DONE();
+}
+
 // The positions whose entry of `ids` is valid, in ascending order (emit_count_kernel's tile counts, scanned: blockoff[ntiles] = their number): the list the
 // skipgram passes of an order walk. In position order, so that references emitted list entry by list entry (below) arrive in corpus order, as the stable sort of
 // the forward index needs them.
@@ -2035,7 +2358,9 @@ template <typename TIN, typename TOUT, bool FINAL>
 __global__ __launch_bounds__(kS64Threads, kS64Threads / 128) void isort_scatter_kernel(const TIN* __restrict__ dig, const uint32_t* __restrict__ pay, uint64_t n, uint32_t nblocks,
                                                                                         const unsigned long long* __restrict__ goff, uint32_t* __restrict__ out_pay,
                                                                                         TOUT* __restrict__ out_dig, uint32_t first_sentence, uint32_t* __restrict__ ref_sentence,
-                                                                                        uint16_t* __restrict__ ref_token, uint32_t tb) {
+                                                                                        uint16_t* __restrict__ ref_token, uint32_t tb,
+                                                                                        uint64_t hot_below = 0, uint64_t hot_n = 0 /* FINAL: the references of the hot unigrams already
+                                                                                            lie at [hot_below, hot_below + hot_n) (emit_hot_write_kernel): what sorts behind moves up */) {
     __shared__ uint32_t           stgP[kITile], stgD[kITile];
     __shared__ uint16_t           wcntL[kIWaves][256];  // elements of digit d wave w has seen in the tile so far; then: those of the waves before it
     __shared__ uint32_t           histL[256], offL[256], wsumL[4];
@@ -2107,8 +2432,9 @@ __global__ __launch_bounds__(kS64Threads, kS64Threads / 128) void isort_scatter_
             const uint32_t xx = stgD[j], yy = stgP[j], d = xx & 255u;
             const uint64_t dst = gbaseL[d] + (j - offL[d]);
             if (FINAL) {
-                ref_sentence[dst] = first_sentence + (tb >= 32 ? 0u : yy >> tb);
-                ref_token[dst]    = (uint16_t)(yy & tmask);
+                const uint64_t fin = dst + (dst >= hot_below ? hot_n : 0ull);
+                ref_sentence[fin]  = first_sentence + (tb >= 32 ? 0u : yy >> tb);
+                ref_token[fin]     = (uint16_t)(yy & tmask);
             } else {
                 out_pay[dst] = yy;
                 out_dig[dst] = (TOUT)(xx >> 8);

@@ -298,6 +298,50 @@ def test_indexed_model_first_sentence_offset_and_long_orders(ctx, hamlet_payload
     _compare(ctx, small_corpora()["one_long_sentence"], 9, indexed=1)
 
 
+def _hot_refs_corpora():
+    """Corpora for the unigram references that bypass the index sort (kernels.hpp: emit_hot_*): the hot ids are the first 256 survivors of the first 4096 classes,
+    whatever those are — frequent words (the usual case), rare ones, none at all."""
+    from colibri_amd import synth
+    rng = np.random.default_rng(606)
+
+    def sentences(toks, lo=1, hi=14):
+        lens = rng.integers(lo, hi, size=toks.size // lo + 1)
+        ends = np.cumsum(lens)
+        ends = ends[ends < toks.size]
+        return synth.encode_v2(np.insert(toks.astype(np.uint32), ends, np.uint32(0))).tobytes() + b"\x00"
+
+    out = {}
+    out["few_classes"] = sentences(6 + np.minimum(rng.pareto(0.8, size=30000).astype(np.int64), 39))                      # 40 classes: fewer survivors than hot ids
+    z = np.minimum(rng.pareto(0.9, size=60000).astype(np.int64), 5999)
+    out["zipf_6000"] = sentences(6 + z)                                                                                    # more than 256 survivors below class 4096, some above
+    out["frequent_high"] = sentences(np.where(z < 300, 9000 + z, 6 + z))                                                   # the frequent words have class ids >= 9000
+    out["none_below_4096"] = sentences(5000 + z)                                                                           # class tile 0 holds no survivor at all
+    out["holes_below_4096"] = sentences(np.where(z % 3 == 0, 6 + z, 20000 + z))                                            # survivors and singletons interleaved
+    out["long_tile"] = sentences(6 + np.minimum(rng.pareto(0.5, size=70000).astype(np.int64), 3), lo=40, hi=90)            # four words: thousands of one id per tile
+    return out
+
+
+@pytest.mark.parametrize("name", ["few_classes", "zipf_6000", "frequent_high", "none_below_4096", "holes_below_4096", "long_tile"])
+@pytest.mark.parametrize("kw", [dict(indexed=1), dict(indexed=1, mintokens=3), dict(indexed=1, doskipgrams=1, maxlength=4), dict(indexed=1, firstsentence=77, maxlength=1)],
+                         ids=["indexed", "thr3", "skipgrams", "order1_only"])
+def test_hot_unigram_references_bypass_the_sort(ctx, name, kw):
+    """Round 6: the references of the hot unigrams are written to their final places by the pair emission of order 1 and never sorted
+    (IndexedPatternModel::add, reference include/patternmodel.h:2789-2800; posttrain's sort :2699-2705). Every reference list against the oracle's."""
+    kw = dict(kw)
+    _compare(ctx, _hot_refs_corpora()[name], kw.pop("maxlength", 5), **kw)
+
+
+def test_hot_unigram_references_equal_the_sorted_ones(ctx, monkeypatch):
+    """... and the same model with the bypass switched off (COLIBRI_NO_HOT_REFS: every reference through the sort) — list for list."""
+    payload = _hot_refs_corpora()["zipf_6000"]
+    ctx.upload(payload)
+    st = ctx.train(mintokens=2, maxlength=3, indexed=1)
+    got = ctx.export_dict()
+    monkeypatch.setenv("COLIBRI_NO_HOT_REFS", "1")
+    st2 = ctx.train(mintokens=2, maxlength=3, indexed=1)
+    assert st2.nrefs == st.nrefs and ctx.export_dict() == got
+
+
 @pytest.mark.parametrize("name", SKIP_CORPORA)
 @pytest.mark.parametrize("extra", [{}, {"minskiptypes": 1}, {"minskiptypes": 3}, {"mintokens_skipgrams": 3}], ids=["default", "T1", "T3", "y3_ignored"])
 def test_indexed_skipgrams_match_oracle(ctx, name, extra):

@@ -102,7 +102,8 @@ struct colibri_ctx {
     DevBuf<uint32_t>  hot_cnt;             // order 1 of an indexed model: occurrences of the hot unigrams per tile (kernels.hpp: emit_hot_*), [kHotIds][tiles]
     DevBuf<HotInfo>   hot_info;
     bool              hot_used = false;    // ... their references lie in ref_sentence / ref_token already: [hot_below, hot_below + hot_n)
-    bool              hot_disorder = false, hot_off = false;  // a hot list came out of order (emit_hot_write_kernel's check): this context sorts every reference from now on
+    bool              hot_disorder = false, hot_off = false;  // a hot list came out of order, or a spot-checked row of the index sort (the ranks from LDS adds rest on the lanes' service
+                                                             // order): this context matches every rank with ballots and sorts every reference from now on
     uint64_t          hot_below = 0, hot_n = 0;
     DevBuf<Slot>      table;
     DevBuf<Rec>       recs[2];          // binned path: record ping-pong
@@ -2011,6 +2012,7 @@ inline int bits_for(uint64_t nvalues) {
 
 // group the pairs by result id (stable LSD radix sort) and turn positions into (sentence, token)
 constexpr int kRerunPairs = 1001;  // the pair buffer was too small (it has been enlarged): the run again
+constexpr int kRerunRanks = 1002;  // a checked rank disagreed (c->hot_off is set): the run again, every rank matched with ballots
 int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = false) {
     int      rc;
     uint64_t n = 0;
@@ -2021,9 +2023,12 @@ int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = fal
         if ((rc = dev_alloc(c, c->pairs[0], (size_t)(n + n / 8) + 1))) return rc;
         return kRerunPairs;
     }
+#ifdef COLIBRI_TEST_HOOKS  // (tests/standin/lib/libcolibri_hip_hooks.so only: the shipped library does not read it) the first attempt pretends a hot run came out of order
+    if (c->hot_used && !c->hot_off && getenv("COLIBRI_FAULT_LDS_ORDER") && !strcmp(getenv("COLIBRI_FAULT_LDS_ORDER"), "hot")) c->hot_disorder = true;
+#endif
     if (c->hot_disorder) {  // (never seen: emit_hot_write_kernel's ranks rest on the order in which the LDS serves the lanes of one instruction)
         c->hot_off = true;
-        return kRerunPairs;
+        return kRerunRanks;
     }
     c->npairs = n + c->hot_n;  // (the hot unigrams' references were never pairs: they lie where they belong already)
     if (c->hot_used && (c->ref_sentence.n < c->npairs + 1 || c->ref_token.n < c->npairs + 1)) return fail(c, COLIBRI_ERR_STATE, "finalize_index: the reference arrays are smaller than the model's references");
@@ -2047,6 +2052,7 @@ int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = fal
             const uint32_t nh = 256u * nblocks, nb = blocks_for(nh, kBlock * 4);
             // buffers: pairs[0] = { id u32[cap], reference u32[cap] } as emitted; a pass writes { reference u32[n], id rest TOUT[n] } into the other buffer
             const uint64_t  cap0 = c->pairs[0].n;
+            const uint32_t  exact_ranks = (c->hot_off || getenv("COLIBRI_EXACT_RANKS")) ? 1u : 0u;  // (kernels.hpp: isort_scatter_kernel)
             const void*     dig  = c->pairs[0].p;
             const uint32_t* pay  = reinterpret_cast<const uint32_t*>(c->pairs[0].p) + cap0;
             int             in_bytes = 4;
@@ -2066,7 +2072,7 @@ int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = fal
                 hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, c->stream, c->sort_hist.p, nh, c->sort_bsum.p, c->sort_off.p);
 #define ISORT(TIN, TOUT, FIN)                                                                                                                                                   \
     hipLaunchKernelGGL((isort_scatter_kernel<TIN, TOUT, FIN>), dim3(nblocks), dim3(kS64Threads), 0, c->stream, (const TIN*)dig, pay, n, nblocks, c->sort_off.p, opay, (TOUT*)odig, \
-                       c->first_sentence, c->ref_sentence.p, c->ref_token.p, c->pair_tb, c->hot_below, c->hot_n)
+                       c->first_sentence, c->ref_sentence.p, c->ref_token.p, c->pair_tb, c->hot_below, c->hot_n, exact_ranks, c->pair_chain.p)
                 if (last) {
                     if (in_bytes == 4) ISORT(uint32_t, uint8_t, true);
                     else if (in_bytes == 2) ISORT(uint16_t, uint8_t, true);
@@ -2101,8 +2107,17 @@ int finalize_index(colibri_ctx* c, uint32_t nresults, bool keep_sorted_ids = fal
             cur ^= 1;
         }
     }
+    unsigned long long disorder = 0;
+    if (c->pair_split) HIP_TRY(c, hipMemcpyAsync(&disorder, c->pair_chain.p + kChainDisorder, sizeof disorder, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
+#ifdef COLIBRI_TEST_HOOKS
+    if (c->pair_split && !c->hot_off && getenv("COLIBRI_FAULT_LDS_ORDER") && !strcmp(getenv("COLIBRI_FAULT_LDS_ORDER"), "sort")) disorder = 1;
+#endif
+    if (disorder) {  // (never seen) a spot-checked row of the sort disagreed with its ballots: again, with every rank matched
+        c->hot_off = true;
+        return kRerunRanks;
+    }
     return COLIBRI_OK;
 }
 
@@ -2209,6 +2224,7 @@ int train_pattern_list(colibri_ctx* c, const colibri_options& o, colibri_stats* 
 static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, colibri_stats* stats_out);
 // a run is about to be repeated (exactly) on another engine or with more room: what colibri_stats.fallback_reason / retries report
 static inline void note_retry(colibri_ctx* c, int reason) {
+    if (getenv("COLIBRI_DEBUG_OVERFLOW")) fprintf(stderr, "colibri: the run is repeated (COLIBRI_FALLBACK_* %d)\n", reason);
     if (c->run_retries++ == 0) c->run_fallback = reason;
 }
 extern "C" int colibri_train(colibri_ctx* c, const colibri_options* opt_in, colibri_stats* stats_out) {
@@ -3143,8 +3159,8 @@ static int colibri_train_once(colibri_ctx* c, const colibri_options* opt_in, col
                                                                        ((chain_synced && chain_wide(npos)) ? COLIBRI_PATH_WIDE : 0));
         if (!enq) c->run_path |= COLIBRI_PATH_PER_PASS;
         if (o.indexed && (rc = finalize_index(c, res_total))) {
-            if (rc == kRerunPairs) {  // (a model with more than two references per position)
-                note_retry(c, COLIBRI_FALLBACK_PAIRS);
+            if (rc == kRerunPairs || rc == kRerunRanks) {  // (a model with more than two references per position; a rank that failed its check)
+                note_retry(c, rc == kRerunPairs ? COLIBRI_FALLBACK_PAIRS : COLIBRI_FALLBACK_LDS_ORDER);
                 return colibri_train_once(c, opt_in, stats_out);
             }
             return rc;

@@ -2360,7 +2360,11 @@ __global__ __launch_bounds__(kS64Threads, kS64Threads / 128) void isort_scatter_
                                                                                         TOUT* __restrict__ out_dig, uint32_t first_sentence, uint32_t* __restrict__ ref_sentence,
                                                                                         uint16_t* __restrict__ ref_token, uint32_t tb,
                                                                                         uint64_t hot_below = 0, uint64_t hot_n = 0 /* FINAL: the references of the hot unigrams already
-                                                                                            lie at [hot_below, hot_below + hot_n) (emit_hot_write_kernel): what sorts behind moves up */) {
+                                                                                            lie at [hot_below, hot_below + hot_n) (emit_hot_write_kernel): what sorts behind moves up */,
+                                                                                        uint32_t exact = 1 /* 0: ranks from returning LDS adds, spot-checked */,
+                                                                                        unsigned long long* flags = nullptr /* the pair chain: [kChainDisorder] */) {
+    static_assert((kIRows & (kIRows - 1)) == 0, "the checked row is the tile number modulo the rows");
+    bool disorder = false;
     __shared__ uint32_t           stgP[kITile], stgD[kITile];
     __shared__ uint16_t           wcntL[kIWaves][256];  // elements of digit d wave w has seen in the tile so far; then: those of the waves before it
     __shared__ uint32_t           histL[256], offL[256], wsumL[4];
@@ -2371,7 +2375,8 @@ __global__ __launch_bounds__(kS64Threads, kS64Threads / 128) void isort_scatter_
     const uint64_t s0 = (uint64_t)blockIdx.x * kITile * kISuper, s1 = min(n, s0 + (uint64_t)kITile * kISuper);
     for (uint64_t t0 = s0; t0 < s1; t0 += kITile) {
         for (uint32_t k = threadIdx.x; k < (uint32_t)(kIWaves * 256 / 2); k += kS64Threads) reinterpret_cast<uint32_t*>(&wcntL[0][0])[k] = 0;
-        uint32_t x[kIRows], y[kIRows], rank[kIRows];
+        const uint32_t tileno = (uint32_t)(t0 / kITile);
+        uint32_t       x[kIRows], y[kIRows], rank[kIRows];
 #pragma unroll
         for (int r = 0; r < kIRows; ++r) {  // the wave's 512 consecutive elements, row by row
             const uint64_t i = t0 + (uint64_t)wave * (kWave * kIRows) + (uint64_t)r * kWave + lane;
@@ -2383,13 +2388,30 @@ __global__ __launch_bounds__(kS64Threads, kS64Threads / 128) void isort_scatter_
         for (int r = 0; r < kIRows; ++r) {
             const bool     valid = t0 + (uint64_t)wave * (kWave * kIRows) + (uint64_t)r * kWave + lane < s1;
             const uint32_t d     = x[r] & 255u;
-            const uint64_t peers = isort_peers(d, valid);
-            const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
-            const uint32_t seen  = wcntL[wave][d];
-            rank[r]              = seen + below;
-            __builtin_amdgcn_wave_barrier();  // (every lane of the row has read its counter before the row's leaders advance them)
-            if (valid && below == 0) wcntL[wave][d] = (uint16_t)(seen + (uint32_t)__popcll(peers));
-            __builtin_amdgcn_wave_barrier();
+            if (exact) {  // ranks by matching the row's lanes (eight ballots): exact by construction
+                const uint64_t peers = isort_peers(d, valid);
+                const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+                const uint32_t seen  = wcntL[wave][d];
+                rank[r]              = seen + below;
+                __builtin_amdgcn_wave_barrier();  // (every lane of the row has read its counter before the row's leaders advance them)
+                if (valid && below == 0) wcntL[wave][d] = (uint16_t)(seen + (uint32_t)__popcll(peers));
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                // ranks from ONE returning LDS add per lane (two 16-bit counters share a word): the rows are served in program order; lanes of one instruction that
+                // hit the same counter are served in lane order on this hardware (see emit_hot_write_kernel) — the three scatter passes 1.80 -> 1.53 ms. What no manual
+                // promises is checked: one row of every eight (a different one tile by tile) is also matched with ballots and must agree, and the hot unigrams' runs
+                // are checked reference by reference; any disagreement raises chain[kChainDisorder] and the run repeats with exact == 1
+                const uint32_t sh  = 16u * (d & 1u);
+                const uint32_t old = valid ? atomicAdd(reinterpret_cast<uint32_t*>(&wcntL[wave][0]) + (d >> 1), 1u << sh) : 0u;
+                rank[r]            = (old >> sh) & 0xFFFFu;
+                if ((uint32_t)r == (tileno & (uint32_t)(kIRows - 1))) {
+                    const uint64_t peers  = isort_peers(d, valid);
+                    const uint32_t below  = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+                    const uint32_t leader = peers ? (uint32_t)__builtin_ctzll(peers) : lane;
+                    const uint32_t lr     = (uint32_t)__shfl((int)rank[r], (int)leader, kWave);
+                    disorder              = disorder || (valid && rank[r] != lr + below);
+                }
+            }
         }
         __syncthreads();
         if (threadIdx.x < 256) {  // digit t: the waves' counts -> exclusive prefixes over the waves
@@ -2443,6 +2465,7 @@ __global__ __launch_bounds__(kS64Threads, kS64Threads / 128) void isort_scatter_
         __syncthreads();
         if (threadIdx.x < 256) gbaseL[threadIdx.x] += histL[threadIdx.x];  // the next tile of the block continues every digit's run
     }
+    if (disorder && flags != nullptr) flags[kChainDisorder] = 1ull;
 }
 
 // position -> (sentence, token): sentence = first_sentence + #delimiters before the position (empty sentences are numbered,

@@ -60,7 +60,7 @@ class Stats(C.Structure):
 
 # colibri_stats.path bits / fallback_reason values (include/colibri_hip.h)
 PATH_TABLE, PATH_RADIX, PATH_BI2, PATH_CHAIN, PATH_WIDE, PATH_SLICED, PATH_PER_PASS = 1, 2, 4, 8, 16, 32, 64
-FALLBACK_NONE, FALLBACK_REGION, FALLBACK_BIN, FALLBACK_IDS, FALLBACK_ORDER2, FALLBACK_SPLIT, FALLBACK_CHAIN, FALLBACK_RESULTS, FALLBACK_PAIRS = 0, 1, 2, 3, 4, 8, 16, 32, 64
+FALLBACK_NONE, FALLBACK_REGION, FALLBACK_BIN, FALLBACK_IDS, FALLBACK_ORDER2, FALLBACK_SPLIT, FALLBACK_CHAIN, FALLBACK_RESULTS, FALLBACK_PAIRS, FALLBACK_LDS_ORDER = 0, 1, 2, 3, 4, 8, 16, 32, 64, 128
 
 
 SHARDED_LIB_PATH = os.path.join(PKG_ROOT, "lib", "libcolibri_sharded.so")

@@ -107,7 +107,8 @@ enum {
     COLIBRI_FALLBACK_SPLIT     = 8,  /* a run of a sliced order's direct split outgrew its room                -> the exact split             */
     COLIBRI_FALLBACK_CHAIN     = 16, /* an order >= 3 did not fit the chained engine (key bits, region, bin)   -> first-generation orders >= 3 */
     COLIBRI_FALLBACK_RESULTS   = 32, /* the result buffers were too small (duplicated text)                    -> four times the room         */
-    COLIBRI_FALLBACK_PAIRS     = 64  /* an index with more references than the pair buffer started with       -> a larger buffer             */
+    COLIBRI_FALLBACK_PAIRS     = 64, /* an index with more references than the pair buffer started with       -> a larger buffer             */
+    COLIBRI_FALLBACK_LDS_ORDER = 128 /* a checked rank of the forward index's build disagreed (ranks from LDS adds) -> every rank matched with ballots */
 };
 
 /* kernel classes for colibri_kernel_time */

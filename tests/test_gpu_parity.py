@@ -342,6 +342,39 @@ def test_hot_unigram_references_equal_the_sorted_ones(ctx, monkeypatch):
     assert st2.nrefs == st.nrefs and ctx.export_dict() == got
 
 
+@pytest.mark.parametrize("where", ["hot", "sort"])
+def test_a_failed_rank_check_repeats_the_run_with_matched_ranks(where, tmp_path):
+    """The forward index's build takes its ranks from returning LDS adds and checks them (every hot run reference by reference, one row of eight of the sort against its
+    ballots); a check that fails repeats the run with every rank matched by ballots and every reference through the sort. The test build of the device library
+    (tests/standin/lib/libcolibri_hip_hooks.so, -DCOLIBRI_TEST_HOOKS) pretends the failure: same model, one retry, the reason in colibri_stats."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hooks = os.path.join(root, "tests", "standin", "lib", "libcolibri_hip_hooks.so")
+    assert os.path.exists(hooks), "tests/standin/Makefile builds it (__graft_entry__.build)"
+    script = textwrap.dedent("""
+        import sys
+        sys.path[:0] = [%r, %r, %r]
+        import oracle
+        from colibri_amd import capi
+        from test_gpu_parity import _hot_refs_corpora
+        payload = _hot_refs_corpora()["zipf_6000"]
+        want = oracle.train(payload, 2, 4, indexed=1)
+        with capi.Context(0) as c:
+            c.upload(payload)
+            for attempt in range(2):  # the second train() of the context: ranks matched from the start, nothing to repeat
+                st = c.train(mintokens=2, maxlength=4, indexed=1)
+                got, refs = c.export_dict()
+                assert got == want.counts and refs == want.refs
+                print("retries", st.retries, "reason", st.fallback_reason)
+        """ % (os.path.join(root, "colibri-core_amd", "pyhost"), os.path.join(root, "oracle"), os.path.join(root, "tests")))
+    env = dict(os.environ, COLIBRI_HIP_LIB=hooks, COLIBRI_FAULT_LDS_ORDER=where)
+    out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    # (a second repeat may follow the first: without the hot unigrams' bypass the pair buffer this small corpus starts with can be too small — COLIBRI_FALLBACK_PAIRS)
+    lines = out.stdout.split("\n")
+    assert lines[0] in ("retries 1 reason 128", "retries 2 reason 128") and lines[1] == "retries 0 reason 0", out.stdout
+
+
 @pytest.mark.parametrize("name", SKIP_CORPORA)
 @pytest.mark.parametrize("extra", [{}, {"minskiptypes": 1}, {"minskiptypes": 3}, {"mintokens_skipgrams": 3}], ids=["default", "T1", "T3", "y3_ignored"])
 def test_indexed_skipgrams_match_oracle(ctx, name, extra):

@@ -449,7 +449,14 @@ int ingest(colibri_ctx* c, const void* src, uint64_t nbytes, uint32_t first_sent
     int          rc;
     if ((rc = dev_alloc(c, c->bytes, padded))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->bytes.p + nbytes, 0, padded - nbytes, c->stream));
+    const auto u0 = std::chrono::steady_clock::now();
     if (nbytes) HIP_TRY(c, hipMemcpyAsync(c->bytes.p, src, nbytes, kind, c->stream));
+    if (getenv("COLIBRI_HOST_TIMING")) {  // (with the C++ face's line of the same switch: the copy alone. Round 6 measured it at 3.4 ms for the 196 MB of 10^8 tokens when uploads
+        // follow each other, and at 5-33 ms, call by call, after the device has idled for the ~0.1 s a caller spends on the model before — with the caller's buffer in 4 KB
+        // or 2 MB pages, registered with the runtime or not, and through a pinned ring filled by eight host threads alike: the links' and copy engines' clocks, not the path)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        fprintf(stderr, "COLIBRI_HOST_TIMING   upload: copy of %.1f MB %.2f ms\n", (double)nbytes / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - u0).count());
+    }
     if ((rc = tokenise(c))) return rc;
     c->have_corpus = true;
     c->split_exact = false;

@@ -644,6 +644,20 @@ def test_order_one_routes_match_the_oracle(env):
     assert p.returncode == 0 and "SLICED_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
 
 
+def test_a_tile_of_one_tail_class_overruns_no_tail_bin(ctx):
+    """a tile of 8192 positions that holds more tokens of ONE tail bin than the bin has room for — here ~8000 tokens of class 0x2FF0, whose bin is
+    the last of the 256 (the over-run used to land behind the tail array) — in a small corpus, where the room per bin is smallest. The bin's overflow takes the atomics
+    route; nothing may be written past the array, and the model is the oracle's."""
+    from colibri_amd import synth
+    rng = np.random.default_rng(5)
+    for hot in (0x2FF0, 0x2FFF, 0x3FF7):  # (c >> 4) & 255 == 255, c >= 8192
+        toks = np.full(8000, hot, dtype=np.uint32)
+        toks[rng.integers(0, 8000, size=300)] = rng.integers(8192, 20000, size=300)
+        tail = np.concatenate([rng.integers(6, 9000, size=40), [0]]).astype(np.uint32)
+        sym = np.concatenate([toks[:4000], [0], toks[4000:], [0], np.tile(tail, 30)]).astype(np.uint32)
+        _compare(ctx, synth.encode_v2(sym).tobytes(), 3)
+
+
 def test_wide_chained_orders_match_the_oracle():
     """Plain runs between 2.15 and 4.3 x 10^8 positions count their orders >= 3 on the chained engine with eight sub-regions, 2048-slot bin tables and records whose
     position lacks the three bits equal to their sub-region (csrc/chain.hpp ChainKey::put, bi2_count_kernel<.., PDROP>). COLIBRI_FORCE_WIDE_CHAIN sends small corpora

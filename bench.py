@@ -203,14 +203,15 @@ def z1b_configs(capi, shards):
                                     "path": "radix" if mode == 2 else "global table", "passes_at_order_2": passes}
             # round 5: the reference's own model of these three shards (tests/golden/fullsize/z375m_seeds44_46_plain.json, 2490 s of its train()): the plain model row for
             # row; the indexed model holds the same patterns with the same counts (its reference lists are pinned at 10^8 tokens: other_configs.indexed)
-            fx375 = load_fixture("z375m_seeds44_46_plain") if name in ("plain", "indexed") else None
+            # round 6: ... and its own INDEXED model of them (z375m_seeds44_46_indexed.json, 2656 s): every (key, count, reference list) row, 650 M references
+            fx375 = load_fixture({"plain": "z375m_seeds44_46_plain", "indexed": "z375m_seeds44_46_indexed"}.get(name, "-"))
             if fx375 is not None:
                 from colibri_amd import digest
-                key_off, key_bytes, counts, _ = c.export_arrays()
-                d = digest.model_digest(key_off, key_bytes, counts)
-                ok = all(d[k] == fx375[k] for k in ("sum1", "xor1", "sum2", "xor2", "npatterns", "occurrences", "keybytes"))
-                entry["kinds"][name]["self_check"] = ("ok" if ok else "FAILED") + ": (key, count) rows = the reference's model of these shards"
-                del key_off, key_bytes, counts
+                key_off, key_bytes, counts, refs = c.export_arrays()
+                d = digest.model_digest(key_off, key_bytes, counts, refs)
+                ok = all(d[k] == fx375[k] for k in ("sum1", "xor1", "sum2", "xor2", "npatterns", "occurrences", "keybytes")) and (refs is None or d["nrefs"] == fx375["nrefs"])
+                entry["kinds"][name]["self_check"] = ("ok" if ok else "FAILED") + ": (key, count%s) rows = the reference's model of these shards" % (", reference list" if refs is not None else "")
+                del key_off, key_bytes, counts, refs
             else:
                 entry["kinds"][name]["self_check"] = "no reference model (the same kind is pinned at 10^8 tokens: other_configs.exhaustive_skipgrams)"
         res["z375m_single_device"] = entry

@@ -451,9 +451,12 @@ int ingest(colibri_ctx* c, const void* src, uint64_t nbytes, uint32_t first_sent
     HIP_TRY(c, hipMemsetAsync(c->bytes.p + nbytes, 0, padded - nbytes, c->stream));
     const auto u0 = std::chrono::steady_clock::now();
     if (nbytes) HIP_TRY(c, hipMemcpyAsync(c->bytes.p, src, nbytes, kind, c->stream));
-    if (getenv("COLIBRI_HOST_TIMING")) {  // (with the C++ face's line of the same switch: the copy alone. Round 6 measured it at 3.4 ms for the 196 MB of 10^8 tokens when uploads
-        // follow each other, and at 5-33 ms, call by call, after the device has idled for the ~0.1 s a caller spends on the model before — with the caller's buffer in 4 KB
-        // or 2 MB pages, registered with the runtime or not, and through a pinned ring filled by eight host threads alike: the links' and copy engines' clocks, not the path)
+    if (getenv("COLIBRI_HOST_TIMING")) {  // (with the C++ face's line of the same switch: the copy alone. Round 6 measured it for the 196 MB of 10^8 tokens: 3.4-3.9 ms
+        // whenever the runtime pins the caller's pages and lets the copy engines read them (every upload of a Python caller; a C++ caller's first uploads), and 10-35 ms,
+        // call by call, in `host_selftest bench` from the second train() on — there the copy engines are busy for < 1 ms of the call (rocprofv3 --memory-copy-trace): the
+        // runtime copies through its own staging buffers with one host thread. It happens when the process' idle context is reused AND a look-up on the model (32 host
+        // threads building the flat index) ran in between; a fresh context per call (COLIBRI_CTX_CACHE=0) or no look-up gives 3.5 ms again. Neither a pinned ring of the
+        // context filled by eight host threads, nor registering the corpus buffer, nor 2 MB pages for it changed that (tools/notes/README.md))
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         fprintf(stderr, "COLIBRI_HOST_TIMING   upload: copy of %.1f MB %.2f ms\n", (double)nbytes / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - u0).count());
     }

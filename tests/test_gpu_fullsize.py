@@ -249,6 +249,23 @@ def test_id_keeping_modes_on_the_bench_corpus_are_the_references_models(name, kw
     assert_is_the_references_model(fx, st, key_off, key_bytes, counts, refs)
 
 
+@pytest.mark.skipif((os.cpu_count() or 1) < 8, reason="the three 125 M-token shards are generated by parallel host processes")
+def test_indexed_model_of_375m_tokens_is_the_references_model():
+    """VERDICT r5 (reference lists pinned above 10^8 tokens): three of configs[2]'s shards in one context, 375 M tokens, 650 M references — beyond one narrow pass, so the
+    chained orders run in their wide form. The reference's own IndexedPatternModel::train on these shards (2656 s in the build container, round 6:
+    tests/golden/fullsize/z375m_seeds44_46_indexed.json) left the multiset digest of every (key, count, reference list) row; posttrain's sort include/patternmodel.h:2699-2705,
+    IndexedData include/datatypes.h:263-270."""
+    from colibri_amd import capi
+    fx = fixture("z375m_seeds44_46_indexed")
+    shards = zipf_many([(fx["corpus"]["ntok"], fx["corpus"]["vocab"], seed) for seed in fx["corpus"]["seeds"]])  # (shared with the 1 B-token case)
+    with capi.Context(0) as ctx:
+        ctx.upload(np.concatenate(shards))
+        st = ctx.train(mintokens=2, maxlength=5, indexed=1)
+        assert ctx.last_mode(with_passes=True) == (2, 1)
+        key_off, key_bytes, counts, refs = ctx.export_arrays()
+    assert_is_the_references_model(fx, st, key_off, key_bytes, counts, refs)
+
+
 @pytest.mark.skipif((os.cpu_count() or 1) < 8, reason="generating the 1 B-token corpus takes eight host cores a minute")
 def test_one_billion_tokens_is_the_references_model():
     """BASELINE.json configs[2]: the eight 125 M-token shards (seeds 44..51) of an 8-GPU run. The reference's own PatternModel::train took 8030 s and 32 GB for

@@ -32,16 +32,41 @@ namespace colibri {
 // position: (K - s - 8) + posbits <= 64. The slice bits exist for corpora beyond ~128 M tokens per device: the order is then counted in 2^s passes,
 // each over the keys of one slice (every pass scans the corpus and keeps its share of the windows), so that a final bin stays within one wave's LDS
 // table and a 30-bit position fits the record.
-constexpr uint64_t kBi2MixC1 = 0xff51afd7ed558ccdULL, kBi2MixC2 = 0xc4ceb9fe1a85ec53ULL;  // odd
+// Round 6: a four-round Feistel network over the key's two halves instead of two 64-bit multiplications (xor-shift, multiply mod 2^K, twice). SQ counters
+// (profiles/r06c_pmc_sq.txt) show bi2_emit_kernel bound by VALU issue: 214 M vector instructions per launch = 137 per window, ~90 % of the SIMDs' cycles once the
+// quarter-rate 32-bit multiplies are priced — and seven of those per window were this function's (v_mul_lo_u32 / v_mad_u64_u32 of the two 64 x 64 -> 64 products).
+// A round is (L, R) -> (L ^ F(R), R): invertible for ANY F, so the network is a bijection of the K-bit integers by construction; F(R) = the top bits of the low 32
+// bits of R x c with 24-bit operands — one full-rate v_mul_u32_u24 — cut to the other half's width. Halves: lo = the low K / 2 bits, hi = the rest (<= 24 bits each for
+// K <= 48: every key of this path; a wider half would only lose its top bits inside F, the map stays a bijection). On 1.27 x 10^7 distinct bigrams of a Zipf corpus the
+// keys per bin are as Poisson as the old mix's at 8 / 15 / 17 bin bits (std 223.0 / 19.8 / 9.8 against 222.8 / 19.7 / 9.9 expected), likewise (number, class) keys.
+constexpr uint32_t kBi2MixC[4] = {0x9E3779u, 0x85EBCBu, 0xC2B2AFu, 0x27D4EBu};  // odd, 24 bits
+__host__ __device__ __forceinline__ uint32_t bi2_mix_f(uint32_t r, uint32_t c, uint32_t outbits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t p = __umul24(r, c);
+#else
+    const uint32_t p = (uint32_t)((uint64_t)(r & 0xFFFFFFu) * c);
+#endif
+    return p >> (32u - outbits);  // (outbits <= 24)
+}
 __host__ __device__ __forceinline__ uint64_t bi2_mix(uint64_t x, uint32_t K) {
+#ifdef COLIBRI_OLD_MIX  // (A/B measurements only: rounds 2-5's mix)
     const uint64_t M = (1ull << K) - 1;
-    const uint32_t h = K >> 1;
-    x ^= x >> h;
-    x = (x * kBi2MixC1) & M;
-    x ^= x >> (h - 1);
-    x = (x * kBi2MixC2) & M;
-    x ^= x >> h;
+    const uint32_t g = K >> 1;
+    x ^= x >> g;
+    x = (x * 0xff51afd7ed558ccdULL) & M;
+    x ^= x >> (g - 1);
+    x = (x * 0xc4ceb9fe1a85ec53ULL) & M;
+    x ^= x >> g;
     return x;
+#endif
+    const uint32_t h = K >> 1, hb = K - h;  // lo: h bits, hi: hb bits (h <= hb)
+    const uint32_t fl = h > 24u ? 24u : h, fh = hb > 24u ? 24u : hb;
+    uint32_t       lo = (uint32_t)x & ((1u << h) - 1u), hi = (uint32_t)(x >> h);  // (K <= 48 + slack: both halves fit a word — K <= 56)
+    hi ^= bi2_mix_f(lo, kBi2MixC[0], fh);
+    lo ^= bi2_mix_f(hi, kBi2MixC[1], fl);
+    hi ^= bi2_mix_f(lo, kBi2MixC[2], fh);
+    lo ^= bi2_mix_f(hi, kBi2MixC[3], fl);
+    return ((uint64_t)hi << h) | lo;
 }
 
 #ifndef COLIBRI_BI2_CNT16

@@ -66,6 +66,16 @@ def test_options_defaults_mirror_patternmodeloptions():
     assert (o.minskiptypes, o.maxskips, o.doskipgrams, o.doskipgrams_exhaustive) == (2, 3, 0, 0)
 
 
+def test_path_bits_and_fallback_reasons_mirror_the_header():
+    """ABI 4: colibri_stats.path / fallback_reason are read through constants of the Python marshalling; they must be the header's (include/colibri_hip.h)."""
+    import re
+    text = open(os.path.join(ROOT, "include", "colibri_hip.h")).read()
+    header = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(COLIBRI_(?:PATH|FALLBACK)_[A-Z0-9_]+)\s*=\s*(\d+)", text)}
+    assert len(header) >= 17 and header["COLIBRI_FALLBACK_LDS_ORDER"] == 128
+    for name, value in header.items():
+        assert getattr(capi, name[len("COLIBRI_"):]) == value, name
+
+
 @pytest.mark.skipif(has_gpu(), reason="only meaningful on the GPU-less build container")
 def test_no_device_fails_loudly_not_silently():
     with pytest.raises(capi.ColibriError) as e:

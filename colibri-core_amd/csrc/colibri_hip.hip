@@ -102,6 +102,7 @@ struct colibri_ctx {
     DevBuf<uint32_t>  hot_cnt;             // order 1 of an indexed model: occurrences of the hot unigrams per tile (kernels.hpp: emit_hot_*), [kHotIds][tiles]
     DevBuf<HotInfo>   hot_info;
     bool              hot_used = false;    // ... their references lie in ref_sentence / ref_token already: [hot_below, hot_below + hot_n)
+    bool              lds_tested = false;   // lds_order_selftest_kernel has run on this context (pairs_begin)
     bool              hot_disorder = false, hot_off = false;  // a hot list came out of order, or a spot-checked row of the index sort (the ranks from LDS adds rest on the lanes' service
                                                              // order): this context matches every rank with ballots and sorts every reference from now on
     uint64_t          hot_below = 0, hot_n = 0;
@@ -1855,6 +1856,19 @@ int pairs_begin(colibri_ctx* c, uint32_t npos) {
     c->npairs    = 0;
     c->hot_used  = false;
     c->hot_below = c->hot_n = 0;
+    if (!c->lds_tested) {  // once per context: are ranks from returning LDS adds the ranks? (kernels.hpp: lds_order_selftest_kernel); otherwise every rank by ballots
+        uint32_t bad = 0;
+        HIP_TRY(c, hipMemsetAsync(c->pair_chain.p + kChainWords, 0, sizeof(unsigned long long), c->stream));
+        hipLaunchKernelGGL(lds_order_selftest_kernel, dim3(64), dim3(kS64Threads), 0, c->stream, reinterpret_cast<uint32_t*>(c->pair_chain.p + kChainWords));
+        HIP_TRY(c, hipMemcpyAsync(&bad, c->pair_chain.p + kChainWords, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+#ifdef COLIBRI_TEST_HOOKS  // (tests/standin/lib/libcolibri_hip_hooks.so only)
+        if (getenv("COLIBRI_FAULT_LDS_ORDER") && !strcmp(getenv("COLIBRI_FAULT_LDS_ORDER"), "selftest")) bad = 1;
+#endif
+        if (bad) c->hot_off = true;
+        c->lds_tested = true;
+    }
     c->pair_split = false;  // (the caller's to set: colibri_train_once does when the pairs are packed; the sharded runs keep whole pairs — they cut the sorted references by id)
     if (c->pairs[0].n < 2ull * npos && (rc = dev_alloc(c, c->pairs[0], (size_t)(2ull * npos) + 1))) return rc;  // the usual model: ~1.6 pairs per position at n <= 5
     // position -> (sentence, token) table of the corpus (once per upload)

@@ -2317,6 +2317,48 @@ __device__ __forceinline__ uint64_t isort_peers(uint32_t d, bool valid) {
     }
     return peers;
 }
+// ---- does the LDS serve the lanes of one returning add in lane order? (round 6) ------------------------------------------------------------------------------------
+// emit_hot_write_kernel and isort_scatter_kernel take an element's rank among its wave's earlier elements of the same id / digit from ONE returning LDS add per lane.
+// Rows follow each other in program order; inside a row the ranks are right iff lanes that hit the same counter are served in ascending lane order — true on this
+// hardware, promised by no manual. Both kernels check their own results (every hot run; one row of eight of the sort); this kernel asks the question once per context,
+// before the first forward index is built, with the patterns the two kernels produce (plain counters and two 16-bit counters per word; every lane on one counter, two
+// counters, a few, a skewed and a uniform spread over 256): the rank from the add against the rank from matching the row's lanes with ballots. *bad != 0: the context
+// matches every rank with ballots from the start (colibri_ctx::hot_off).
+__device__ __forceinline__ uint64_t isort_peers(uint32_t d, bool valid);
+__global__ __launch_bounds__(kS64Threads) void lds_order_selftest_kernel(uint32_t* __restrict__ bad) {
+    constexpr int       kW = kS64Threads / kWave;
+    __shared__ uint32_t plainL[kW][256], packedL[kW][128], seenL[kW][256];
+    const uint32_t      lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    for (uint32_t k = threadIdx.x; k < (uint32_t)(kW * 256); k += kS64Threads) (&plainL[0][0])[k] = (&seenL[0][0])[k] = 0;
+    for (uint32_t k = threadIdx.x; k < (uint32_t)(kW * 128); k += kS64Threads) (&packedL[0][0])[k] = 0;
+    __syncthreads();
+    bool wrong = false;
+    for (uint32_t row = 0; row < 40; ++row) {
+        uint32_t h = (lane * 0x9E3779B1u) ^ ((row + 17u * w + 131u * blockIdx.x) * 0x85EBCA6Bu);
+        h ^= h >> 15;
+        uint32_t d;
+        switch (row % 5u) {
+            case 0: d = row & 255u; break;                        // every lane on one counter
+            case 1: d = (lane >> (row & 3u)) & 1u; break;         // two counters, in runs of 1 / 2 / 4 / 8 lanes
+            case 2: d = h % 7u; break;                            // a few
+            case 3: d = (h & 3u) ? (h >> 8) & 3u : (h >> 8) & 255u; break;  // skewed
+            default: d = h & 255u;                                // uniform
+        }
+        const bool     valid = ((h >> 20) & 15u) != 0u || (row & 1u) == 0u;  // (some rows with idle lanes)
+        const uint64_t peers = isort_peers(d, valid);
+        const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        const uint32_t seen  = seenL[w][d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && below == 0) seenL[w][d] = seen + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t sh = 16u * (d & 1u);
+        const uint32_t a  = valid ? atomicAdd(&plainL[w][d], 1u) : 0u;
+        const uint32_t b  = valid ? (atomicAdd(&packedL[w][d >> 1], 1u << sh) >> sh) & 0xFFFFu : 0u;
+        wrong             = wrong || (valid && (a != seen + below || b != seen + below));
+    }
+    if (wrong) *bad = 1u;
+}
+
 template <typename TIN>
 __global__ __launch_bounds__(kS64Threads) void isort_hist_kernel(const TIN* __restrict__ dig, uint64_t n, uint32_t nblocks, uint32_t* __restrict__ ghist) {
     __shared__ uint32_t h[256];

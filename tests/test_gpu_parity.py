@@ -342,7 +342,7 @@ def test_hot_unigram_references_equal_the_sorted_ones(ctx, monkeypatch):
     assert st2.nrefs == st.nrefs and ctx.export_dict() == got
 
 
-@pytest.mark.parametrize("where", ["hot", "sort"])
+@pytest.mark.parametrize("where", ["hot", "sort", "selftest"])
 def test_a_failed_rank_check_repeats_the_run_with_matched_ranks(where, tmp_path):
     """The forward index's build takes its ranks from returning LDS adds and checks them (every hot run reference by reference, one row of eight of the sort against its
     ballots); a check that fails repeats the run with every rank matched by ballots and every reference through the sort. The test build of the device library
@@ -372,7 +372,10 @@ def test_a_failed_rank_check_repeats_the_run_with_matched_ranks(where, tmp_path)
     assert out.returncode == 0, out.stdout + out.stderr
     # (a second repeat may follow the first: without the hot unigrams' bypass the pair buffer this small corpus starts with can be too small — COLIBRI_FALLBACK_PAIRS)
     lines = out.stdout.split("\n")
-    assert lines[0] in ("retries 1 reason 128", "retries 2 reason 128") and lines[1] == "retries 0 reason 0", out.stdout
+    if where == "selftest":  # the context's own test of the LDS' service order (lds_order_selftest_kernel) fails: ranks are matched from the first run on, nothing repeats for it
+        assert lines[0] in ("retries 0 reason 0", "retries 1 reason 64") and lines[1] == "retries 0 reason 0", out.stdout
+    else:
+        assert lines[0] in ("retries 1 reason 128", "retries 2 reason 128") and lines[1] == "retries 0 reason 0", out.stdout
 
 
 @pytest.mark.parametrize("name", SKIP_CORPORA)

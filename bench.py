@@ -279,12 +279,29 @@ def cxx_face(payload):
             f.write(bytes([0xA2, 0x02]))
             f.write(payload.tobytes())
         try:
-            p = subprocess.run([exe, "bench", path, str(MAXLENGTH), str(MINTOKENS), "3"], capture_output=True, text=True, timeout=300)
+            p = subprocess.run([exe, "bench", path, str(MAXLENGTH), str(MINTOKENS), "3"], capture_output=True, text=True, timeout=300, env=dict(os.environ, COLIBRI_HOST_TIMING="1"))
             d = json.loads(p.stdout.strip().splitlines()[-1])
         except Exception as e:  # noqa: BLE001
             return {"error": f"host_selftest bench failed: {e}"}
     runs = d["runs"]
-    return {"workload": "PatternModel<uint32_t>::train(corpusfile, options) on a preloaded IndexedCorpus of the timed corpus, C++ face (host_selftest bench): context + upload + "
+    # where a call's time goes (COLIBRI_HOST_TIMING lines of the library and the C++ face on stderr): the best call's phases, and the host -> device copy of the corpus
+    # alone per call — 3.4 ms when the runtime pins the caller's pages, 10-35 ms when it stages them through its own buffers
+    import re
+    phases, copies = [], []
+    for line in p.stderr.splitlines():
+        m = re.search(r"COLIBRI_HOST_TIMING create ([0-9.]+) upload ([0-9.]+) train ([0-9.]+) sizes ([0-9.]+) alloc ([0-9.]+) export ([0-9.]+) ms", line)
+        if m:
+            phases.append(dict(zip(("create", "upload", "train", "sizes", "alloc", "export"), (float(x) for x in m.groups()))))
+        m = re.search(r"upload: copy of [0-9.]+ MB ([0-9.]+) ms", line)
+        if m:
+            copies.append(float(m.group(1)))
+    extra = {}
+    if len(phases) == len(runs) and phases:
+        best = min(range(len(runs)), key=lambda i: runs[i]["train_ms"])
+        extra["phases_ms_of_the_best_call"] = phases[best]
+    if copies:
+        extra["corpus_copy_ms_per_call"] = copies
+    return {**extra, "workload": "PatternModel<uint32_t>::train(corpusfile, options) on a preloaded IndexedCorpus of the timed corpus, C++ face (host_selftest bench): context + upload + "
                         "colibri_train + export to host vectors, per call",
             "cxx_face_train_ms": round(min(r["train_ms"] for r in runs), 1), "cxx_face_train_ms_first_call": round(runs[0]["train_ms"], 1),
             "first_lookup_ms": round(min(r["first_lookup_ms"] for r in runs), 1), "first_lookup_ms_worst": round(max(r["first_lookup_ms"] for r in runs), 1), "patterns": runs[-1]["patterns"], "corpus_load_ms_host": round(d["corpus_load_ms"], 1)}
